@@ -1,0 +1,188 @@
+/*
+ * rbd_hip.h — C ABI of librbd_hip.so, the MI355X (gfx950) batched rigid-body
+ * dynamics engine that replaces the data-parallel hot path of
+ * RigidBodyDynamics.jl (reference paths are relative to the upstream repo):
+ *
+ *   rbd_dynamics          <->  dynamics!(result, state, τ, wext)       src/mechanism_algorithms.jl:845-864
+ *   rbd_inverse_dynamics  <->  inverse_dynamics!(τ, jw, acc, state, v̇, wext)  src/mechanism_algorithms.jl:542-553
+ *   rbd_dynamics_bias     <->  dynamics_bias!(result, state)           src/mechanism_algorithms.jl:484-498
+ *   rbd_mass_matrix       <->  mass_matrix!(M::Symmetric, state)       src/mechanism_algorithms.jl:248-272
+ *   rbd_mass_matrix_solve <->  dynamics_solve!(result, τ) (no-loop branch) src/mechanism_algorithms.jl:747-822
+ *   rbd_model_create      <->  MechanismState(mechanism) index tables  src/mechanism_state.jl:79-172
+ *
+ * The reference is pure Julia and has no FFI layer; this header is what a
+ * Julia `ccall` shim (julia/RigidBodyDynamicsGPU.jl) binds.
+ *
+ * Conventions
+ *  - every entry point returns an int status (RBD_OK == 0); nothing throws or
+ *    longjmps across the boundary; caller buffers are never owned by the library;
+ *  - a *state* is one (q, v) of the mechanism; a *batch* is B independent states
+ *    of the same mechanism (one evaluation per state);
+ *  - batch buffers are DEVICE pointers of the workspace's dtype unless
+ *    opts->memory == RBD_MEM_HOST (then the library stages through its own
+ *    device buffers; PCIe time is then inside the call);
+ *  - layout RBD_LAYOUT_SOA: element k of state b lives at x[k*B + b]
+ *    (coordinate-major, coalesced);  RBD_LAYOUT_AOS: x[b*n + k] — the Julia
+ *    `n × B` column-major matrix with one state per column;
+ *  - motion vectors are (angular; linear), force vectors (torque; force), as in
+ *    src/spatial/spatialmotion.jl:122-153 and src/spatial/spatialforce.jl:73-111;
+ *  - calls are asynchronous on the workspace's HIP stream; rbd_sync() waits.
+ *    A model handle is immutable and shareable; a workspace must not be used
+ *    from two host threads at once (same rule as MechanismState/DynamicsResult,
+ *    which are mutable caches: src/mechanism_state.jl:35-78).
+ */
+#ifndef RBD_HIP_H
+#define RBD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+enum {
+  RBD_OK = 0,
+  RBD_ERR_INVALID_ARGUMENT = 1,   /* Julia side: ArgumentError           */
+  RBD_ERR_DIMENSION_MISMATCH = 2, /* Julia side: DimensionMismatch       */
+  RBD_ERR_UNSUPPORTED = 3,        /* joint type / feature not built      */
+  RBD_ERR_NO_DEVICE = 4,          /* no HIP device: the product has NO CPU fallback */
+  RBD_ERR_HIP = 5,                /* a HIP runtime call failed (see rbd_last_hip_error) */
+  RBD_ERR_OUT_OF_MEMORY = 6,
+  RBD_ERR_HAS_LOOPS = 7,          /* inverse_dynamics! on a mechanism with loop joints
+                                     (src/mechanism_algorithms.jl:549)   */
+  RBD_ERR_NOT_POSITIVE_DEFINITE = 8
+};
+
+/* ---- joint types (src/joint_types/ *.jl) ---------------------------------- */
+enum {
+  RBD_JOINT_FIXED = 0,          /* fixed.jl            nq=0 nv=0 */
+  RBD_JOINT_REVOLUTE = 1,       /* revolute.jl         nq=1 nv=1 */
+  RBD_JOINT_PRISMATIC = 2,      /* prismatic.jl        nq=1 nv=1 */
+  RBD_JOINT_QUAT_FLOATING = 3,  /* quaternion_floating.jl nq=7 (w,x,y,z,px,py,pz) nv=6 (ω; v) body frame */
+  RBD_JOINT_PLANAR = 4,         /* planar.jl           nq=3 nv=3 */
+  RBD_JOINT_QUAT_SPHERICAL = 5, /* quaternion_spherical.jl nq=4 nv=3 */
+  RBD_JOINT_SINCOS_REVOLUTE = 6 /* sin_cos_revolute.jl nq=2 nv=1 */
+};
+
+enum { RBD_F64 = 0, RBD_F32 = 1 };
+enum { RBD_LAYOUT_SOA = 0, RBD_LAYOUT_AOS = 1 };
+enum { RBD_MEM_DEVICE = 0, RBD_MEM_HOST = 1 };
+/* forward-dynamics algorithm behind rbd_dynamics */
+enum {
+  RBD_ALGO_ABA = 0,          /* fused articulated-body algorithm (default; tree mechanisms)   */
+  RBD_ALGO_CRBA_CHOLESKY = 1 /* the reference's own route: bias-RNEA + CRBA + Cholesky; also
+                                fills M and c in the workspace; the only route with loop joints */
+};
+
+/* ---- loop (non-tree) joint: src/mechanism_modification.jl:38-43,
+ *      constraint rows src/mechanism_algorithms.jl:574-673 ------------------ */
+typedef struct rbd_loop_joint {
+  int32_t predecessor;      /* moving-body index, -1 = world                          */
+  int32_t successor;        /* moving-body index, -1 = world                          */
+  int32_t joint_type;       /* RBD_JOINT_*                                            */
+  int32_t _pad;
+  double axis[3];           /* Revolute/Prismatic axis in frame_before                */
+  double pred_rot[9];       /* joint_to_predecessor: frame_before -> predecessor body frame, row-major R */
+  double pred_trans[3];
+  double succ_rot[9];       /* joint_to_successor:  frame_after  -> successor body frame, row-major R   */
+  double succ_trans[3];
+  double rotation_from_z_aligned[9]; /* Revolute.rotation_from_z_aligned, src/joint_types/revolute.jl:12-17 */
+  double gains[4];          /* Baumgarte SE3PDGains: angular k, d; linear k, d (default 100,20,100,20:
+                               src/mechanism_algorithms.jl:610-612); all zero = stabilization off */
+} rbd_loop_joint_t;
+
+/* ---- the flattened mechanism ---------------------------------------------
+ * Exactly the tables MechanismState builds once (src/mechanism_state.jl:85-118):
+ * moving body i (0-based) is the successor of tree joint i; bodies are in the
+ * reference's tree-joint order (topological: parents first). After
+ * canonicalize_frame_definitions! (src/mechanism.jl:250-260) the body frame IS
+ * frame_after(joint i) and joint_to_successor of tree joints is identity.      */
+typedef struct rbd_flat_model {
+  int32_t n_bodies;            /* number of moving bodies == tree joints               */
+  int32_t nq, nv;              /* num_positions, num_velocities                        */
+  int32_t n_loops;             /* non-tree joints                                      */
+  const int32_t* parent;       /* [n_bodies] predecessor body of joint i, -1 = world   */
+  const int32_t* joint_type;   /* [n_bodies] RBD_JOINT_*                               */
+  const int32_t* q_offset;     /* [n_bodies] first q index (qranges)                   */
+  const int32_t* v_offset;     /* [n_bodies] first v index (vranges)                   */
+  const double* joint_axis;    /* [n_bodies*3] axis in frame_before (Revolute/Prismatic); Planar: x_axis */
+  const double* joint_axis2;   /* [n_bodies*3] Planar y_axis (else ignored; may be NULL) */
+  const double* pred_rot;      /* [n_bodies*9] joint_to_predecessor R, row-major (src/joint.jl:49) */
+  const double* pred_trans;    /* [n_bodies*3]                                         */
+  const double* inertia_moment;/* [n_bodies*9] J about the body-frame origin, row-major (src/spatial/motion_force_interaction.jl:28-37) */
+  const double* inertia_cross; /* [n_bodies*3] cross_part = mass * com                 */
+  const double* inertia_mass;  /* [n_bodies]                                           */
+  double gravity[3];           /* gravitational_acceleration in the root frame (default 0,0,-9.81: src/mechanism.jl:1) */
+  const rbd_loop_joint_t* loops; /* [n_loops] or NULL                                  */
+} rbd_flat_model_t;
+
+typedef struct rbd_model rbd_model_t; /* opaque, immutable after create               */
+typedef struct rbd_ws rbd_ws_t;       /* opaque, one per host thread / HIP stream     */
+
+typedef struct rbd_opts {
+  int32_t layout;     /* RBD_LAYOUT_*  (default SOA)                                  */
+  int32_t memory;     /* RBD_MEM_*     (default DEVICE)                               */
+  int32_t algorithm;  /* RBD_ALGO_*    (rbd_dynamics only)                            */
+  int32_t stabilization; /* 1 = Baumgarte stabilization with the loop joints' gains (the
+                            reference's default), 0 = `stabilization_gains=nothing`  */
+} rbd_opts_t;
+
+/* ---- model / workspace lifetime ------------------------------------------ */
+int rbd_model_create(const rbd_flat_model_t* desc, rbd_model_t** out); /* deep-copies desc */
+int rbd_model_destroy(rbd_model_t* model);
+int rbd_model_dims(const rbd_model_t* model, int32_t* n_bodies, int32_t* nq, int32_t* nv, int32_t* nc);
+
+/* stream: a hipStream_t passed as void* (NULL = the device's default stream) */
+int rbd_workspace_create(const rbd_model_t* model, int32_t max_batch, int32_t device,
+                         int32_t dtype, void* stream, rbd_ws_t** out);
+int rbd_workspace_destroy(rbd_ws_t* ws);
+int rbd_workspace_set_stream(rbd_ws_t* ws, void* stream);
+int rbd_sync(rbd_ws_t* ws);
+
+/* ---- the hot path ----------------------------------------------------------
+ * q[nq×B], v[nv×B], tau[nv×B] (NULL => zeros, like the ConstVector default),
+ * fext[6*n_bodies×B] external wrench on each moving body in the ROOT frame,
+ * (torque; force) (NULL => none, like NullDict); outputs vdot[nv×B],
+ * qdot[nq×B] (nullable), lambda[nc×B] (nullable).                              */
+int rbd_dynamics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, const void* tau,
+                 const void* fext, void* vdot, void* qdot, void* lambda, const rbd_opts_t* opts);
+
+/* tau_out = M(q) vdot + c(q, v, fext); tree mechanisms only */
+int rbd_inverse_dynamics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, const void* vdot,
+                         const void* fext, void* tau_out, const rbd_opts_t* opts);
+
+/* c_out = c(q, v, fext) = inverse dynamics with vdot = 0 */
+int rbd_dynamics_bias(rbd_ws_t* ws, int32_t B, const void* q, const void* v, const void* fext,
+                      void* c_out, const rbd_opts_t* opts);
+
+/* M_out: nv×nv column-major per state (element (i,j) of state b at
+ * M[(j*nv+i)*B + b] for SOA, M[b*nv*nv + j*nv + i] for AOS). Like the
+ * reference (Symmetric, uplo 'L') only the LOWER triangle i>=j is written.     */
+int rbd_mass_matrix(rbd_ws_t* ws, int32_t B, const void* q, void* M_out, const rbd_opts_t* opts);
+
+/* x = M(q)^-1 rhs via batched lower Cholesky (potrf/potrs of dynamics_solve!);
+ * rhs, x: nv×B. M_out nullable (same layout as rbd_mass_matrix).               */
+int rbd_mass_matrix_solve(rbd_ws_t* ws, int32_t B, const void* q, const void* rhs, void* x,
+                          void* M_out, const rbd_opts_t* opts);
+
+/* after rbd_dynamics(..., RBD_ALGO_CRBA_CHOLESKY): copy the DynamicsResult side
+ * products out of the workspace (any pointer may be NULL). M: nv×nv (lower),
+ * c: nv, K: nc×nv column-major, k: nc; layout per opts.                        */
+int rbd_dynamics_result(rbd_ws_t* ws, int32_t B, void* M, void* c, void* K, void* k,
+                        const rbd_opts_t* opts);
+
+/* ---- diagnostics ------------------------------------------------------------ */
+const char* rbd_status_string(int status);
+const char* rbd_last_hip_error(void);   /* thread-local text of the last HIP failure     */
+/* average device time (ms) of the dominant kernel of the last hot-path call on this
+ * workspace, measured with hipEvents recorded around the launch on ws's stream.
+ * Timing is off by default; enable=1 brackets every launch with events.            */
+int rbd_workspace_enable_timing(rbd_ws_t* ws, int32_t enable);
+int rbd_workspace_last_kernel_ms(rbd_ws_t* ws, float* ms);
+int rbd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBD_HIP_H */

@@ -1,0 +1,129 @@
+"""ctypes front-end of oracle/librbd_oracle.so — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module. All batch
+arrays are AOS: shape (B, n), one state per row (== one Julia column)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+WHAT_DYNAMICS, WHAT_INVERSE_DYNAMICS, WHAT_DYNAMICS_BIAS, WHAT_MASS_MATRIX, WHAT_ABA = range(5)
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "librbd_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("rbd_oracle.c", "rbd_oracle_impl.h")] + [os.path.join(_HERE, "..", "include", "rbd_hip.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "librbd_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "librbd_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+    return _LIB
+
+
+def _sfx(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "_f64", ctypes.c_double
+    if dtype == np.float32:
+        return "_f32", ctypes.c_float
+    raise TypeError(dtype)
+
+
+def _ptr(a, ct):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def _prep(a, dtype, shape):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    assert a.shape == shape, (a.shape, shape)
+    return a
+
+
+def batch(model, what, q, v=None, x=None, fext=None, dtype=np.float64, nthreads=1, want_qdot=False):
+    """Run the oracle over a batch. q:(B,nq) v:(B,nv) x: tau (dynamics/ABA) or vdot (inverse dynamics) (B,nv),
+    fext:(B, 6*n_bodies). Returns out (B,nv) [or (B,nv,nv) col-major-per-state for the mass matrix, i.e.
+    out[b].T is M in row-major numpy indexing M[i,j]] and, when want_qdot, (out, qdot)."""
+    sfx, ct = _sfx(dtype)
+    B = q.shape[0]
+    nq, nv, nb = model.nq, model.nv, model.n_bodies
+    q = _prep(q, dtype, (B, nq))
+    v = _prep(v, dtype, (B, nv))
+    x = _prep(x, dtype, (B, nv))
+    fext = _prep(fext, dtype, (B, 6 * nb))
+    out = np.zeros((B, nv * nv) if what == WHAT_MASS_MATRIX else (B, nv), dtype=dtype)
+    qdot = np.zeros((B, nq), dtype=dtype) if want_qdot else None
+    f = getattr(lib(), "rbdo_batch" + sfx)
+    f.restype = ctypes.c_int
+    st = f(ctypes.byref(model.c_struct()), ctypes.c_int(what), ctypes.c_int(B), ctypes.c_int(nthreads),
+           _ptr(q, ct), _ptr(v, ct), _ptr(x, ct), _ptr(fext, ct), _ptr(out, ct), _ptr(qdot, ct))
+    if st != 0:
+        raise RuntimeError(f"oracle status {st}")
+    if what == WHAT_MASS_MATRIX:
+        out = out.reshape(B, nv, nv).transpose(0, 2, 1)  # -> out[b, i, j] = M[i, j]
+    return (out, qdot) if want_qdot else out
+
+
+def dynamics(model, q, v, tau=None, fext=None, **kw):
+    return batch(model, WHAT_DYNAMICS, q, v, tau, fext, **kw)
+
+
+def aba(model, q, v, tau=None, fext=None, **kw):
+    return batch(model, WHAT_ABA, q, v, tau, fext, **kw)
+
+
+def inverse_dynamics(model, q, v, vdot, fext=None, **kw):
+    return batch(model, WHAT_INVERSE_DYNAMICS, q, v, vdot, fext, **kw)
+
+
+def dynamics_bias(model, q, v, fext=None, **kw):
+    return batch(model, WHAT_DYNAMICS_BIAS, q, v, None, fext, **kw)
+
+
+def mass_matrix(model, q, **kw):
+    """Lower triangle valid (strict upper zero), like the reference's Symmetric(…, :L) storage."""
+    return batch(model, WHAT_MASS_MATRIX, q, **kw)
+
+
+def energy(model, q, v, dtype=np.float64):
+    sfx, ct = _sfx(dtype)
+    f = getattr(lib(), "rbdo_energy" + sfx)
+    f.restype = ctypes.c_int
+    B = q.shape[0]
+    ke, pe = np.zeros(B, dtype), np.zeros(B, dtype)
+    q = np.ascontiguousarray(q, dtype)
+    v = np.ascontiguousarray(v, dtype)
+    for b in range(B):
+        k, p = ct(), ct()
+        st = f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(v[b], ct), ctypes.byref(k), ctypes.byref(p))
+        assert st == 0
+        ke[b], pe[b] = k.value, p.value
+    return ke, pe
+
+
+def transforms(model, q, dtype=np.float64):
+    """transforms_to_root per body: (B, n_bodies, 12) = R row-major (9) + p (3)."""
+    sfx, ct = _sfx(dtype)
+    f = getattr(lib(), "rbdo_transforms" + sfx)
+    f.restype = ctypes.c_int
+    B = q.shape[0]
+    q = np.ascontiguousarray(q, dtype)
+    out = np.zeros((B, model.n_bodies, 12), dtype)
+    for b in range(B):
+        assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(out[b], ct)) == 0
+    return out

@@ -1,0 +1,14 @@
+"""rigidbodydynamics.jl_amd — MI355X-native batched rigid-body dynamics behind RigidBodyDynamics.jl's
+`dynamics!` / `inverse_dynamics!` / `mass_matrix!` / `dynamics_bias!` (src/mechanism_algorithms.jl).
+
+Host side (this package, Python because Julia is not available in the build image): model description +
+flattening (mechanism.py, urdf.py, builders.py) and the batched mirror of the reference's operator
+interface over the C ABI of csrc/librbd_hip.so (state.py, _capi.py).  All arithmetic per state runs in the
+hand-written HIP kernels; there is no CPU fallback."""
+from .mechanism import (DEFAULT_GRAVITATIONAL_ACCELERATION, CartesianFrame3D, Fixed, FlatModel, Joint, JointType, Mechanism,
+                        Planar, Prismatic, QuaternionFloating, QuaternionSpherical, Revolute, RigidBody, SinCosRevolute,
+                        SpatialInertia, Transform3D, attach_, flatten, rand_configuration, rand_velocity,
+                        remove_fixed_tree_joints_, rot_z_y_x, rotation_between)
+from .urdf import default_urdf_joint_types, parse_pose, parse_urdf
+from .builders import (FOUR_BAR_INITIAL_Q, FOUR_BAR_INITIAL_V, double_pendulum, four_bar_linkage, quickstart_double_pendulum)
+from .flatio import load_flat_model, save_flat_model

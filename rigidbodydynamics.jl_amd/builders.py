@@ -1,0 +1,67 @@
+"""Programmatic mechanisms with the literal constants of the reference's examples/tests — BASELINE.json
+configs[0] (double pendulum) and configs[4] (four-bar linkage)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .mechanism import (CartesianFrame3D, Joint, Mechanism, Revolute, RigidBody, SpatialInertia, Transform3D, attach_)
+
+
+def double_pendulum(lc1=-0.5, l1=-1.0, m1=1.0, I1=0.333, lc2=-1.0, m2=1.0, I2=1.33, g=-9.81) -> Mechanism:
+    """The test-suite double pendulum, test/test_double_pendulum.jl:3-30 (axis y, inertias about the joint).
+    The Quickstart example ("examples/1. Quickstart - double pendulum":21-82) is the same construction with
+    I1 = I2 = 0.333, lc1 = lc2 = -0.5, l1 = -1."""
+    axis = np.array([0.0, 1.0, 0.0])
+    world = RigidBody("world")
+    mech = Mechanism(world, gravity=[0, 0, g])
+    inertia1 = SpatialInertia(CartesianFrame3D("upper_link"), moment=I1 * np.outer(axis, axis), com=[0, 0, lc1], mass=m1)
+    body1 = RigidBody(inertia1)
+    joint1 = Joint("shoulder", Revolute(axis))
+    attach_(mech, world, body1, joint1, joint_pose=Transform3D(joint1.frame_before, world.default_frame))
+    inertia2 = SpatialInertia(CartesianFrame3D("lower_link"), moment=I2 * np.outer(axis, axis), com=[0, 0, lc2], mass=m2)
+    body2 = RigidBody(inertia2)
+    joint2 = Joint("elbow", Revolute(axis))
+    attach_(mech, body1, body2, joint2, joint_pose=Transform3D(joint2.frame_before, body1.default_frame, p=[0, 0, l1]))
+    return mech
+
+
+def quickstart_double_pendulum() -> Mechanism:
+    """examples/1. Quickstart - double pendulum/1. Quickstart - double pendulum.jl:21-82."""
+    return double_pendulum(lc1=-0.5, l1=-1.0, m1=1.0, I1=0.333, lc2=-0.5, m2=1.0, I2=0.333)
+
+
+def four_bar_linkage() -> Mechanism:
+    """test/test_simulate.jl:127-190 (the example file differs in com_3; the test's constants are used)."""
+    g = -9.81
+    l_0, l_1, l_2, l_3 = 1.10, 0.5, 1.20, 0.75
+    m_1, m_2, m_3 = 0.5, 1.0, 0.75
+    c_1, c_2, c_3 = 0.25, 0.60, 0.375
+    I_1, I_2, I_3 = 0.333, 0.537, 0.4
+    axis = np.array([0.0, -1.0, 0.0])
+    world = RigidBody("world")
+    mech = Mechanism(world, gravity=[0.0, 0.0, g])
+
+    def link(name, I, m):
+        return RigidBody(SpatialInertia(CartesianFrame3D(name), moment=I * np.outer(axis, axis), com=np.zeros(3), mass=m))
+
+    joint1 = Joint("joint1", Revolute(axis))
+    link1 = link("inertia1_centroidal", I_1, m_1)
+    attach_(mech, world, link1, joint1, joint_pose=Transform3D(joint1.frame_before, world.default_frame),
+            successor_pose=Transform3D(link1.default_frame, joint1.frame_after, p=[c_1, 0, 0]))
+    joint2 = Joint("joint2", Revolute(axis))
+    link2 = link("inertia2_centroidal", I_2, m_2)
+    attach_(mech, link1, link2, joint2, joint_pose=Transform3D(joint2.frame_before, joint1.frame_after, p=[l_1, 0, 0]),
+            successor_pose=Transform3D(link2.default_frame, joint2.frame_after, p=[c_2, 0, 0]))
+    joint3 = Joint("joint3", Revolute(axis))
+    link3 = link("inertia3_centroidal", I_3, m_3)
+    attach_(mech, world, link3, joint3, joint_pose=Transform3D(joint3.frame_before, world.default_frame, p=[l_0, 0, 0]),
+            successor_pose=Transform3D(link3.default_frame, joint3.frame_after, p=[c_3, 0, 0]))
+    # loop joint between link2 and link3
+    joint4 = Joint("joint4", Revolute(axis))
+    attach_(mech, link2, link3, joint4, joint_pose=Transform3D(joint4.frame_before, joint2.frame_after, p=[l_2, 0, 0]),
+            successor_pose=Transform3D(joint3.frame_after, joint4.frame_after, p=[-l_3, 0, 0]))
+    return mech
+
+
+FOUR_BAR_INITIAL_Q = np.array([1.6707963267948966, -1.4591054166649482, 1.5397303602625536])  # test_simulate.jl:195-197
+FOUR_BAR_INITIAL_V = np.array([0.5, -0.47295, 0.341])                                          # :198-200

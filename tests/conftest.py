@@ -1,0 +1,51 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+MODELS = os.path.join(ROOT, "tests", "golden", "models")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def rbd():
+    import rbd_amd
+    return rbd_amd
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as o
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def models(rbd):
+    """name -> FlatModel: URDF mechanisms from the committed flat-model fixtures, the rest built in code."""
+    m = {name: rbd.load_flat_model(os.path.join(MODELS, name + ".json"))
+         for name in ("atlas_floating", "atlas_fixed", "acrobot_urdf", "valkyrie_floating")}
+    m["double_pendulum"] = rbd.flatten(rbd.double_pendulum())
+    m["quickstart_pendulum"] = rbd.flatten(rbd.quickstart_double_pendulum())
+    m["four_bar"] = rbd.flatten(rbd.four_bar_linkage())
+    return m
+
+
+def rand_inputs(rbd, model, B, seed, fext=False):
+    rng = np.random.default_rng(seed)
+    q = rbd.rand_configuration(model, B, rng)
+    v = rbd.rand_velocity(model, B, rng)
+    tau = rng.random((B, model.nv))
+    out = [q, v, tau]
+    if fext:
+        out.append(rng.random((B, 6 * model.n_bodies)))
+    return out
