@@ -12,3 +12,6 @@ from .mechanism import (DEFAULT_GRAVITATIONAL_ACCELERATION, CartesianFrame3D, Fi
 from .urdf import default_urdf_joint_types, parse_pose, parse_urdf
 from .builders import (FOUR_BAR_INITIAL_Q, FOUR_BAR_INITIAL_V, double_pendulum, four_bar_linkage, quickstart_double_pendulum)
 from .flatio import load_flat_model, save_flat_model
+from . import _capi
+from .state import (DimensionMismatch, DynamicsResult, MechanismState, dynamics_, dynamics_bias_, inverse_dynamics_, mass_matrix_,
+                    mass_matrix_solve_, rand_, set_configuration_, set_velocity_, zero_configuration_)

@@ -1,0 +1,76 @@
+"""ctypes binding of csrc/librbd_hip.so (include/rbd_hip.h).  The product path: if the shared library is
+missing or no HIP device is visible, everything here raises — there is NO CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librbd_hip.so")
+
+RBD_OK = 0
+F64, F32 = 0, 1
+LAYOUT_SOA, LAYOUT_AOS = 0, 1
+MEM_DEVICE, MEM_HOST = 0, 1
+ALGO_ABA, ALGO_CRBA_CHOLESKY = 0, 1
+
+# every symbol include/rbd_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = (
+    "rbd_model_create", "rbd_model_destroy", "rbd_model_dims", "rbd_workspace_create", "rbd_workspace_destroy",
+    "rbd_workspace_set_stream", "rbd_sync", "rbd_dynamics", "rbd_inverse_dynamics", "rbd_dynamics_bias", "rbd_mass_matrix",
+    "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
+    "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version",
+)
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [("layout", ctypes.c_int32), ("memory", ctypes.c_int32), ("algorithm", ctypes.c_int32), ("stabilization", ctypes.c_int32)]
+
+
+class RBDError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__(f"{where}: status {status} ({detail})")
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(rigidbodydynamics.jl_amd has no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i32 = ctypes.c_void_p, ctypes.c_int32
+        L.rbd_status_string.restype = ctypes.c_char_p
+        L.rbd_status_string.argtypes = [ctypes.c_int]
+        L.rbd_last_hip_error.restype = ctypes.c_char_p
+        L.rbd_model_create.argtypes = [vp, ctypes.POINTER(vp)]
+        L.rbd_model_destroy.argtypes = [vp]
+        L.rbd_model_dims.argtypes = [vp] + [ctypes.POINTER(i32)] * 4
+        L.rbd_workspace_create.argtypes = [vp, i32, i32, i32, vp, ctypes.POINTER(vp)]
+        L.rbd_workspace_destroy.argtypes = [vp]
+        L.rbd_workspace_set_stream.argtypes = [vp, vp]
+        L.rbd_sync.argtypes = [vp]
+        L.rbd_dynamics.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_inverse_dynamics.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_dynamics_bias.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_mass_matrix.argtypes = [vp, i32, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_mass_matrix_solve.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_dynamics_result.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_workspace_enable_timing.argtypes = [vp, i32]
+        L.rbd_workspace_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        _lib = L
+    return _lib
+
+
+def check(status: int, where: str):
+    if status != RBD_OK:
+        L = lib()
+        detail = L.rbd_status_string(status).decode()
+        hip = L.rbd_last_hip_error().decode()
+        if status in (4, 5, 6) and hip:
+            detail += "; " + hip
+        raise RBDError(status, where, detail)

@@ -1,0 +1,460 @@
+// rbd_capi.hip — the C ABI of librbd_hip.so (include/rbd_hip.h): model flattening for the device,
+// workspace/stream management, argument checking, kernel dispatch.  No torch types, no CPU fallback:
+// every hot-path entry point launches HIP kernels or fails with a status code.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rbd_hip.h"
+#include "rbd_internal.hpp"
+
+using namespace rbd;
+
+static thread_local std::string g_last_hip_error;
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      g_last_hip_error = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+      return (e_ == hipErrorOutOfMemory) ? RBD_ERR_OUT_OF_MEMORY : RBD_ERR_HIP;                    \
+    }                                                                                              \
+  } while (0)
+
+static int joint_nq_host(int t) {
+  switch (t) {
+    case RBD_JOINT_FIXED: return 0;
+    case RBD_JOINT_REVOLUTE: case RBD_JOINT_PRISMATIC: return 1;
+    case RBD_JOINT_QUAT_FLOATING: return 7;
+    case RBD_JOINT_PLANAR: return 3;
+    case RBD_JOINT_QUAT_SPHERICAL: return 4;
+    case RBD_JOINT_SINCOS_REVOLUTE: return 2;
+    default: return -1;
+  }
+}
+static int joint_nv_host(int t) {
+  switch (t) {
+    case RBD_JOINT_FIXED: return 0;
+    case RBD_JOINT_REVOLUTE: case RBD_JOINT_PRISMATIC: case RBD_JOINT_SINCOS_REVOLUTE: return 1;
+    case RBD_JOINT_QUAT_FLOATING: return 6;
+    case RBD_JOINT_PLANAR: case RBD_JOINT_QUAT_SPHERICAL: return 3;
+    default: return -1;
+  }
+}
+
+struct rbd_model {
+  int32_t nb = 0, nq = 0, nv = 0, nc = 0, nloops = 0;
+  int32_t lps = 1, nlevels = 0, maxchild = 0, maxnvj = 0;
+  double gravity[3] = {0, 0, 0};
+  std::vector<int32_t> ib;      // nb * IB_STRIDE
+  std::vector<double> rb;       // nb * RB_STRIDE
+  std::vector<int32_t> nslots;  // nlevels
+  std::vector<int32_t> dof_body;
+  std::vector<int32_t> anc;     // nb * nlevels
+  std::vector<rbd_loop_joint_t> loops;
+};
+
+struct rbd_ws {
+  const rbd_model* model = nullptr;
+  int32_t device = 0, dtype = RBD_F64, max_batch = 0;
+  hipStream_t stream = nullptr;
+  DevModel dm{};
+  void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr;
+  // staging for RBD_MEM_HOST (lazy)
+  void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // internal device scratch (mass matrix / bias for the CRBA route), lazy
+  void* d_M = nullptr; void* d_c = nullptr;
+  size_t d_M_bytes = 0, d_c_bytes = 0;
+  // timing
+  int32_t timing = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_pending = false;
+};
+
+extern "C" {
+
+int rbd_version(void) { return 100; }
+
+const char* rbd_status_string(int s) {
+  switch (s) {
+    case RBD_OK: return "ok";
+    case RBD_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case RBD_ERR_DIMENSION_MISMATCH: return "dimension mismatch";
+    case RBD_ERR_UNSUPPORTED: return "unsupported joint type or feature";
+    case RBD_ERR_NO_DEVICE: return "no HIP device available (librbd_hip has no CPU fallback)";
+    case RBD_ERR_HIP: return "HIP runtime error";
+    case RBD_ERR_OUT_OF_MEMORY: return "out of memory";
+    case RBD_ERR_HAS_LOOPS: return "This method can currently only handle tree Mechanisms.";
+    case RBD_ERR_NOT_POSITIVE_DEFINITE: return "mass matrix not positive definite";
+    default: return "unknown status";
+  }
+}
+const char* rbd_last_hip_error(void) { return g_last_hip_error.c_str(); }
+
+int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
+  if (!d || !out) return RBD_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (d->n_bodies < 1 || !d->parent || !d->joint_type || !d->q_offset || !d->v_offset || !d->joint_axis || !d->pred_rot ||
+      !d->pred_trans || !d->inertia_moment || !d->inertia_cross || !d->inertia_mass)
+    return RBD_ERR_INVALID_ARGUMENT;
+  if (d->n_bodies > 64) return RBD_ERR_UNSUPPORTED;  // one wavefront per state is the current limit
+  if (d->n_loops < 0 || (d->n_loops > 0 && !d->loops)) return RBD_ERR_INVALID_ARGUMENT;
+  rbd_model* m = new (std::nothrow) rbd_model();
+  if (!m) return RBD_ERR_OUT_OF_MEMORY;
+  const int nb = d->n_bodies;
+  m->nb = nb; m->nq = d->nq; m->nv = d->nv; m->nloops = d->n_loops;
+  memcpy(m->gravity, d->gravity, sizeof m->gravity);
+  int lps = 1;
+  while (lps < nb) lps <<= 1;
+  m->lps = lps;
+  // consistency of the q / v ranges with the joint types (qranges/vranges: src/mechanism_state.jl:47-48)
+  int qsum = 0, vsum = 0;
+  std::vector<int> level(nb, 0), nchild(nb, 0);
+  m->ib.assign((size_t)nb * IB_STRIDE, -1);
+  for (int i = 0; i < nb; ++i) {
+    const int t = d->joint_type[i];
+    const int nqi = joint_nq_host(t), nvi = joint_nv_host(t);
+    if (nqi < 0) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
+    if (t == RBD_JOINT_PLANAR || t == RBD_JOINT_QUAT_SPHERICAL) { delete m; return RBD_ERR_UNSUPPORTED; }
+    if (d->q_offset[i] != qsum || d->v_offset[i] != vsum) { delete m; return RBD_ERR_DIMENSION_MISMATCH; }
+    qsum += nqi; vsum += nvi;
+    if (nvi > m->maxnvj) m->maxnvj = nvi;
+    const int p = d->parent[i];
+    if (p >= i || p < -1) { delete m; return RBD_ERR_INVALID_ARGUMENT; }  // parents first
+    level[i] = p < 0 ? 0 : level[p] + 1;
+    int32_t* ib = &m->ib[(size_t)i * IB_STRIDE];
+    ib[IB_PARENT] = p; ib[IB_JTYPE] = t; ib[IB_QOFF] = d->q_offset[i]; ib[IB_VOFF] = d->v_offset[i]; ib[IB_LEVEL] = level[i];
+    if (p >= 0) {
+      if (nchild[p] >= IB_MAXCHILD) { delete m; return RBD_ERR_UNSUPPORTED; }
+      m->ib[(size_t)p * IB_STRIDE + IB_CHILD0 + nchild[p]] = i;
+      nchild[p]++;
+    }
+    if (level[i] + 1 > m->nlevels) m->nlevels = level[i] + 1;
+  }
+  if (qsum != d->nq || vsum != d->nv) { delete m; return RBD_ERR_DIMENSION_MISMATCH; }
+  if (m->nlevels > MAX_LEVELS) { delete m; return RBD_ERR_UNSUPPORTED; }
+  m->nslots.assign(m->nlevels, 0);
+  for (int i = 0; i < nb; ++i) {
+    m->ib[(size_t)i * IB_STRIDE + IB_NCHILD] = nchild[i];
+    if (nchild[i] > m->maxchild) m->maxchild = nchild[i];
+    if (nchild[i] > 0 && nchild[i] > m->nslots[level[i] + 1]) m->nslots[level[i] + 1] = nchild[i];
+  }
+  m->rb.assign((size_t)nb * RB_STRIDE, 0.0);
+  for (int i = 0; i < nb; ++i) {
+    double* rb = &m->rb[(size_t)i * RB_STRIDE];
+    for (int k = 0; k < 3; ++k) rb[RB_AXIS + k] = d->joint_axis[3 * i + k];
+    if (d->joint_axis2) for (int k = 0; k < 3; ++k) rb[RB_AXIS2 + k] = d->joint_axis2[3 * i + k];
+    for (int k = 0; k < 9; ++k) rb[RB_XPR + k] = d->pred_rot[9 * i + k];
+    for (int k = 0; k < 3; ++k) rb[RB_XPP + k] = d->pred_trans[3 * i + k];
+    const double* J = d->inertia_moment + 9 * i;
+    rb[RB_J + 0] = J[0]; rb[RB_J + 1] = J[1]; rb[RB_J + 2] = J[2]; rb[RB_J + 3] = J[4]; rb[RB_J + 4] = J[5]; rb[RB_J + 5] = J[8];
+    for (int k = 0; k < 3; ++k) rb[RB_MC + k] = d->inertia_cross[3 * i + k];
+    rb[RB_M] = d->inertia_mass[i];
+  }
+  m->dof_body.assign(m->nv > 0 ? m->nv : 1, 0);
+  for (int i = 0; i < nb; ++i)
+    for (int k = 0; k < joint_nv_host(d->joint_type[i]); ++k) m->dof_body[d->v_offset[i] + k] = i;
+  m->anc.assign((size_t)nb * m->nlevels, -1);
+  for (int i = 0; i < nb; ++i) {
+    int a = i;
+    for (int k = 0; k < m->nlevels && a >= 0; ++k) { m->anc[(size_t)i * m->nlevels + k] = a; a = d->parent[a]; }
+  }
+  m->nc = 0;
+  for (int l = 0; l < d->n_loops; ++l) {
+    const int nvl = joint_nv_host(d->loops[l].joint_type);
+    if (nvl < 0) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
+    if (d->loops[l].predecessor >= nb || d->loops[l].successor >= nb) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
+    m->nc += 6 - nvl;  // num_constraints: src/joint.jl:12
+    m->loops.push_back(d->loops[l]);
+  }
+  *out = m;
+  return RBD_OK;
+}
+
+int rbd_model_destroy(rbd_model_t* m) {
+  delete m;
+  return RBD_OK;
+}
+
+int rbd_model_dims(const rbd_model_t* m, int32_t* nb, int32_t* nq, int32_t* nv, int32_t* nc) {
+  if (!m) return RBD_ERR_INVALID_ARGUMENT;
+  if (nb) *nb = m->nb;
+  if (nq) *nq = m->nq;
+  if (nv) *nv = m->nv;
+  if (nc) *nc = m->nc;
+  return RBD_OK;
+}
+
+static int upload(void** dst, const void* src, size_t bytes) {
+  HIP_TRY(hipMalloc(dst, bytes ? bytes : 16));
+  if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return RBD_OK;
+}
+
+int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device, int32_t dtype, void* stream, rbd_ws_t** out) {
+  if (!m || !out || max_batch < 1 || (dtype != RBD_F64 && dtype != RBD_F32)) return RBD_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    g_last_hip_error = "hipGetDeviceCount: no device";
+    return RBD_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) return RBD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(device));
+  rbd_ws* w = new (std::nothrow) rbd_ws();
+  if (!w) return RBD_ERR_OUT_OF_MEMORY;
+  w->model = m; w->device = device; w->dtype = dtype; w->max_batch = max_batch; w->stream = (hipStream_t)stream;
+  int st = upload(&w->d_ib, m->ib.data(), m->ib.size() * sizeof(int32_t));
+  if (st == RBD_OK) {
+    if (dtype == RBD_F64) {
+      st = upload(&w->d_rb, m->rb.data(), m->rb.size() * sizeof(double));
+    } else {
+      std::vector<float> rbf(m->rb.begin(), m->rb.end());
+      st = upload(&w->d_rb, rbf.data(), rbf.size() * sizeof(float));
+    }
+  }
+  if (st == RBD_OK) st = upload(&w->d_nslots, m->nslots.data(), m->nslots.size() * sizeof(int32_t));
+  if (st == RBD_OK) st = upload(&w->d_dof_body, m->dof_body.data(), m->dof_body.size() * sizeof(int32_t));
+  if (st == RBD_OK) st = upload(&w->d_anc, m->anc.data(), m->anc.size() * sizeof(int32_t));
+  if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+  DevModel& dm = w->dm;
+  dm.nb = m->nb; dm.nq = m->nq; dm.nv = m->nv; dm.lps = m->lps; dm.nlevels = m->nlevels; dm.maxchild = m->maxchild; dm.maxnvj = m->maxnvj;
+  dm.ib = (const int32_t*)w->d_ib; dm.rb = w->d_rb; dm.nslots = (const int32_t*)w->d_nslots;
+  dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc;
+  memcpy(dm.gravity, m->gravity, sizeof dm.gravity);
+  *out = w;
+  return RBD_OK;
+}
+
+int rbd_workspace_destroy(rbd_ws_t* w) {
+  if (!w) return RBD_OK;
+  (void)hipSetDevice(w->device);
+  void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_M, w->d_c};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (void* p : w->stage) if (p) (void)hipFree(p);
+  if (w->ev0) (void)hipEventDestroy(w->ev0);
+  if (w->ev1) (void)hipEventDestroy(w->ev1);
+  delete w;
+  return RBD_OK;
+}
+
+int rbd_workspace_set_stream(rbd_ws_t* w, void* stream) {
+  if (!w) return RBD_ERR_INVALID_ARGUMENT;
+  w->stream = (hipStream_t)stream;
+  return RBD_OK;
+}
+
+int rbd_sync(rbd_ws_t* w) {
+  if (!w) return RBD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  return RBD_OK;
+}
+
+int rbd_workspace_enable_timing(rbd_ws_t* w, int32_t enable) {
+  if (!w) return RBD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(w->device));
+  if (enable && !w->ev0) {
+    HIP_TRY(hipEventCreate(&w->ev0));
+    HIP_TRY(hipEventCreate(&w->ev1));
+  }
+  w->timing = enable ? 1 : 0;
+  return RBD_OK;
+}
+
+int rbd_workspace_last_kernel_ms(rbd_ws_t* w, float* ms) {
+  if (!w || !ms || !w->ev_pending) return RBD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipEventSynchronize(w->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, w->ev0, w->ev1));
+  return RBD_OK;
+}
+
+}  // extern "C"
+
+// ---- dispatch helpers -------------------------------------------------------------------------
+namespace {
+
+size_t esize(const rbd_ws* w) { return w->dtype == RBD_F64 ? 8 : 4; }
+
+Layout layout_of(int layout, long n, long B) {
+  Layout L;
+  if (layout == RBD_LAYOUT_AOS) { L.sk = 1; L.sb = n; } else { L.sk = B; L.sb = 1; }
+  return L;
+}
+
+struct Opts { int layout, memory, algorithm, stabilization; };
+Opts read_opts(const rbd_opts_t* o) {
+  Opts r{RBD_LAYOUT_SOA, RBD_MEM_DEVICE, RBD_ALGO_ABA, 1};
+  if (o) { r.layout = o->layout; r.memory = o->memory; r.algorithm = o->algorithm; r.stabilization = o->stabilization; }
+  return r;
+}
+
+int check_common(rbd_ws* w, int32_t B, const Opts& o) {
+  if (!w) return RBD_ERR_INVALID_ARGUMENT;
+  if (B < 0 || B > w->max_batch) return RBD_ERR_DIMENSION_MISMATCH;
+  if (o.layout != RBD_LAYOUT_SOA && o.layout != RBD_LAYOUT_AOS) return RBD_ERR_INVALID_ARGUMENT;
+  if (o.memory != RBD_MEM_DEVICE && o.memory != RBD_MEM_HOST) return RBD_ERR_INVALID_ARGUMENT;
+  return RBD_OK;
+}
+
+// host-memory mode: copy `src` (host) into staging slot `slot`; returns device pointer via *dev
+int stage_in(rbd_ws* w, int slot, const void* src, size_t bytes, const void** dev) {
+  if (!src) { *dev = nullptr; return RBD_OK; }
+  if (w->stage_bytes[slot] < bytes) {
+    if (w->stage[slot]) HIP_TRY(hipFree(w->stage[slot]));
+    w->stage[slot] = nullptr; w->stage_bytes[slot] = 0;
+    HIP_TRY(hipMalloc(&w->stage[slot], bytes));
+    w->stage_bytes[slot] = bytes;
+  }
+  HIP_TRY(hipMemcpyAsync(w->stage[slot], src, bytes, hipMemcpyHostToDevice, w->stream));
+  *dev = w->stage[slot];
+  return RBD_OK;
+}
+int stage_out_alloc(rbd_ws* w, int slot, void* dst, size_t bytes, void** dev) {
+  if (!dst) { *dev = nullptr; return RBD_OK; }
+  if (w->stage_bytes[slot] < bytes) {
+    if (w->stage[slot]) HIP_TRY(hipFree(w->stage[slot]));
+    w->stage[slot] = nullptr; w->stage_bytes[slot] = 0;
+    HIP_TRY(hipMalloc(&w->stage[slot], bytes));
+    w->stage_bytes[slot] = bytes;
+  }
+  *dev = w->stage[slot];
+  return RBD_OK;
+}
+int stage_out_copy(rbd_ws* w, void* dst, const void* dev, size_t bytes) {
+  if (!dst) return RBD_OK;
+  HIP_TRY(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, w->stream));
+  return RBD_OK;
+}
+
+struct Timed {
+  rbd_ws* w;
+  explicit Timed(rbd_ws* w_) : w(w_) { if (w->timing) (void)hipEventRecord(w->ev0, w->stream); }
+  ~Timed() { if (w->timing) { (void)hipEventRecord(w->ev1, w->stream); w->ev_pending = true; } }
+};
+
+int ensure(void** p, size_t* have, size_t need) {
+  if (*have >= need) return RBD_OK;
+  if (*p) HIP_TRY(hipFree(*p));
+  *p = nullptr; *have = 0;
+  HIP_TRY(hipMalloc(p, need));
+  *have = need;
+  return RBD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
+                 void* lambda, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!q || !v || !vdot) return RBD_ERR_INVALID_ARGUMENT;
+  const rbd_model* m = w->model;
+  if (m->nloops > 0 || o.algorithm == RBD_ALGO_CRBA_CHOLESKY) return RBD_ERR_UNSUPPORTED;  // loop/Cholesky route: next
+  (void)lambda;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t es = esize(w);
+  const void *dq = q, *dv = v, *dtau = tau, *df = fext;
+  void *dvd = vdot, *dqd = qdot;
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_in(w, 1, v, es * m->nv * B, &dv)) ||
+        (st = stage_in(w, 2, tau, es * m->nv * B, &dtau)) || (st = stage_in(w, 3, fext, es * 6 * m->nb * B, &df)) ||
+        (st = stage_out_alloc(w, 4, vdot, es * m->nv * B, &dvd)) || (st = stage_out_alloc(w, 5, qdot, es * m->nq * B, &dqd)))
+      return st;
+  }
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
+  {
+    Timed t(w);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_aba<double>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_aba<float>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+  }
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_out_copy(w, vdot, dvd, es * m->nv * B)) || (st = stage_out_copy(w, qdot, dqd, es * m->nq * B))) return st;
+  }
+  return RBD_OK;
+}
+
+static int rnea_common(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* vdot, const void* fext, void* tau_out,
+                       const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!q || !v || !tau_out) return RBD_ERR_INVALID_ARGUMENT;
+  const rbd_model* m = w->model;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t es = esize(w);
+  const void *dq = q, *dv = v, *dvd = vdot, *df = fext;
+  void* dt = tau_out;
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_in(w, 1, v, es * m->nv * B, &dv)) ||
+        (st = stage_in(w, 2, vdot, es * m->nv * B, &dvd)) || (st = stage_in(w, 3, fext, es * 6 * m->nb * B, &df)) ||
+        (st = stage_out_alloc(w, 4, tau_out, es * m->nv * B, &dt)))
+      return st;
+  }
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
+  {
+    Timed t(w);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dt, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dt, Lq, Lv, Lf, w->stream));
+  }
+  if (o.memory == RBD_MEM_HOST) return stage_out_copy(w, tau_out, dt, es * m->nv * B);
+  return RBD_OK;
+}
+
+int rbd_inverse_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* vdot, const void* fext, void* tau_out,
+                         const rbd_opts_t* opts) {
+  if (w && w->model->nloops > 0) return RBD_ERR_HAS_LOOPS;  // src/mechanism_algorithms.jl:549
+  if (!vdot) return RBD_ERR_INVALID_ARGUMENT;
+  return rnea_common(w, B, q, v, vdot, fext, tau_out, opts);
+}
+
+int rbd_dynamics_bias(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* fext, void* c_out, const rbd_opts_t* opts) {
+  return rnea_common(w, B, q, v, nullptr, fext, c_out, opts);
+}
+
+int rbd_mass_matrix(rbd_ws_t* w, int32_t B, const void* q, void* M_out, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!q || !M_out) return RBD_ERR_INVALID_ARGUMENT;
+  const rbd_model* m = w->model;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t es = esize(w);
+  const void* dq = q;
+  void* dM = M_out;
+  const size_t mbytes = es * (size_t)m->nv * m->nv * B;
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_out_alloc(w, 6, M_out, mbytes, &dM))) return st;
+  }
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
+  {
+    Timed t(w);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
+    else HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
+  }
+  if (o.memory == RBD_MEM_HOST) return stage_out_copy(w, M_out, dM, mbytes);
+  return RBD_OK;
+}
+
+int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs, void* x, void* M_out, const rbd_opts_t* opts) {
+  (void)w; (void)B; (void)q; (void)rhs; (void)x; (void)M_out; (void)opts;
+  return RBD_ERR_UNSUPPORTED;
+}
+
+int rbd_dynamics_result(rbd_ws_t* w, int32_t B, void* M, void* c, void* K, void* k, const rbd_opts_t* opts) {
+  (void)w; (void)B; (void)M; (void)c; (void)K; (void)k; (void)opts;
+  return RBD_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

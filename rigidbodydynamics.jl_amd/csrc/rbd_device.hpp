@@ -1,0 +1,260 @@
+// rbd_device.hpp — device-side model view and spatial-algebra primitives for the gfx950 kernels.
+//
+// Execution model (all kernels in rbd_kernels.hip): ONE LANE PER (state, body).  A state of a
+// mechanism with n_bodies moving bodies occupies LPS = next_pow2(n_bodies) adjacent lanes of a
+// 64-wide wavefront (Atlas: 31 bodies -> 32 lanes -> 2 states per wave).  Every per-body quantity
+// of the Featherstone passes lives in that lane's VGPRs for the whole kernel; the tree sweeps are
+// level-synchronous and parent<->child traffic is wave shuffles (ds_bpermute), so the only HBM
+// traffic is the algorithmic q/v/tau in, vdot out.  All quantities are expressed in the ROOT
+// frame, as in the reference (src/mechanism_state.jl:744-748, :776, :842), so the backward sweeps
+// are plain sums.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rbd {
+
+// per-body integer record
+enum { IB_PARENT = 0, IB_JTYPE = 1, IB_QOFF = 2, IB_VOFF = 3, IB_LEVEL = 4, IB_NCHILD = 5, IB_CHILD0 = 6, IB_MAXCHILD = 6, IB_STRIDE = IB_CHILD0 + IB_MAXCHILD };
+// per-body real record: axis(3) axis2(3) XpR(9) Xpp(3) J(6: xx xy xz yy yz zz) mc(3) m(1)
+enum { RB_AXIS = 0, RB_AXIS2 = 3, RB_XPR = 6, RB_XPP = 15, RB_J = 18, RB_MC = 24, RB_M = 27, RB_STRIDE = 28 };
+enum { MAX_LEVELS = 64 };
+
+struct DevModel {
+  int32_t nb, nq, nv;
+  int32_t lps;        // lanes per state (power of two, <= 64)
+  int32_t nlevels;    // tree depth
+  int32_t maxchild;   // max children of any body (<= IB_MAXCHILD)
+  int32_t maxnvj;     // max velocity dimension of any tree joint
+  const int32_t* ib;  // [nb * IB_STRIDE]
+  const void* rb;     // [nb * RB_STRIDE] of the kernel's scalar type
+  const int32_t* nslots;  // [nlevels] child slots that must be gathered when processing level l
+                          // (= max #children, over parents at level l-1, located at level l)
+  const int32_t* dof_body;  // [nv] body of velocity index
+  const int32_t* anc;       // [nb * nlevels] anc[b*nlevels + k] = k-th ancestor body of b (k=0: b itself), -1 past the root
+  double gravity[3];
+};
+
+// element (k, b) of an n x B batch buffer
+struct Layout {
+  long sk, sb;  // SOA: sk = B, sb = 1;  AOS: sk = 1, sb = n
+};
+
+#define RBD_DEV __device__ __forceinline__
+
+template <typename T> RBD_DEV T shfl(T x, int src) { return __shfl(x, src, 64); }
+
+template <typename T> RBD_DEV void cross3(const T* a, const T* b, T* o) {
+  T x = a[1] * b[2] - a[2] * b[1];
+  T y = a[2] * b[0] - a[0] * b[2];
+  T z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+template <typename T> RBD_DEV void matvec3(const T* R, const T* x, T* o) {
+  T a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+  T b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+  T c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+template <typename T> RBD_DEV void matTvec3(const T* R, const T* x, T* o) {
+  T a = R[0] * x[0] + R[3] * x[1] + R[6] * x[2];
+  T b = R[1] * x[0] + R[4] * x[1] + R[7] * x[2];
+  T c = R[2] * x[0] + R[5] * x[1] + R[8] * x[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+template <typename T> RBD_DEV void matmul3(const T* A, const T* B, T* C) {
+  T t[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) C[k] = t[k];
+}
+// transform_spatial_motion (src/spatial/util.jl:104-108): (Rw, Rv + p x Rw)
+template <typename T> RBD_DEV void xmotion(const T* R, const T* p, const T* m, T* o) {
+  T a[3], l[3], c[3];
+  matvec3(R, m, a);
+  matvec3(R, m + 3, l);
+  cross3(p, a, c);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = a[k]; o[3 + k] = l[k] + c[k]; }
+}
+// inverse of xmotion: (R'w, R'(v - p x w))
+template <typename T> RBD_DEV void xmotion_inv(const T* R, const T* p, const T* m, T* o) {
+  T c[3], d[3];
+  cross3(p, m, c);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = m[3 + k] - c[k];
+  matTvec3(R, m, o);
+  matTvec3(R, d, o + 3);
+}
+// wrench transform (src/spatial/spatialforce.jl:152-158): (Rt + p x Rf, Rf)
+template <typename T> RBD_DEV void xforce(const T* R, const T* p, const T* w, T* o) {
+  T a[3], l[3], c[3];
+  matvec3(R, w, a);
+  matvec3(R, w + 3, l);
+  cross3(p, l, c);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = a[k] + c[k]; o[3 + k] = l[k]; }
+}
+// inverse wrench transform = S' w for a floating joint: (R'(t - p x f), R'f)
+template <typename T> RBD_DEV void xforce_inv(const T* R, const T* p, const T* w, T* o) {
+  T c[3], d[3];
+  cross3(p, w + 3, c);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = w[k] - c[k];
+  matTvec3(R, d, o);
+  matTvec3(R, w + 3, o + 3);
+}
+// se3_commutator (src/spatial/util.jl:117-121)
+template <typename T> RBD_DEV void se3_comm(const T* x, const T* y, T* o) {
+  T a[3], b[3], c[3];
+  cross3(x, y, a);
+  cross3(x, y + 3, b);
+  cross3(x + 3, y, c);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = a[k]; o[3 + k] = b[k] + c[k]; }
+}
+template <typename T> RBD_DEV T dot6(const T* a, const T* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+
+// rigid-body inertia in the root frame: J (6 unique: xx xy xz yy yz zz), c = m*com, m
+template <typename T> struct RInertia { T J[6]; T c[3]; T m; };
+
+// mul_inertia (src/spatial/util.jl:110-114): (J w + c x v, m v - c x w)
+template <typename T> RBD_DEV void mul_inertia(const RInertia<T>& I, const T* t, T* o) {
+  const T* J = I.J;
+  T b[3], d[3];
+  cross3(I.c, t + 3, b);
+  cross3(I.c, t, d);
+  o[0] = J[0] * t[0] + J[1] * t[1] + J[2] * t[2] + b[0];
+  o[1] = J[1] * t[0] + J[3] * t[1] + J[4] * t[2] + b[1];
+  o[2] = J[2] * t[0] + J[4] * t[1] + J[5] * t[2] + b[2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o[3 + k] = I.m * t[3 + k] - d[k];
+}
+// transform(inertia, H) (src/spatial/motion_force_interaction.jl:160-176)
+template <typename T> RBD_DEV void inertia_to_root(const T* Jb /*6*/, const T* mcb, T m, const T* R, const T* p, RInertia<T>& O) {
+  T Rmc[3], mp[3];
+  matvec3(R, mcb, Rmc);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) mp[k] = m * p[k];
+  // Y = X + X' + mp p',  X = Rmc p'  (symmetric)
+  T Y[6];
+  Y[0] = 2 * Rmc[0] * p[0] + mp[0] * p[0];
+  Y[1] = Rmc[0] * p[1] + Rmc[1] * p[0] + mp[0] * p[1];
+  Y[2] = Rmc[0] * p[2] + Rmc[2] * p[0] + mp[0] * p[2];
+  Y[3] = 2 * Rmc[1] * p[1] + mp[1] * p[1];
+  Y[4] = Rmc[1] * p[2] + Rmc[2] * p[1] + mp[1] * p[2];
+  Y[5] = 2 * Rmc[2] * p[2] + mp[2] * p[2];
+  T trY = Y[0] + Y[3] + Y[5];
+  // R J R'
+  T Jf[9] = {Jb[0], Jb[1], Jb[2], Jb[1], Jb[3], Jb[4], Jb[2], Jb[4], Jb[5]};
+  T RJ[9];
+  matmul3(R, Jf, RJ);
+  // (RJ) R' upper triangle: sum_k RJ[i][k] R[j][k]
+  T A[6];
+  A[0] = RJ[0] * R[0] + RJ[1] * R[1] + RJ[2] * R[2];
+  A[1] = RJ[0] * R[3] + RJ[1] * R[4] + RJ[2] * R[5];
+  A[2] = RJ[0] * R[6] + RJ[1] * R[7] + RJ[2] * R[8];
+  A[3] = RJ[3] * R[3] + RJ[4] * R[4] + RJ[5] * R[5];
+  A[4] = RJ[3] * R[6] + RJ[4] * R[7] + RJ[5] * R[8];
+  A[5] = RJ[6] * R[6] + RJ[7] * R[7] + RJ[8] * R[8];
+  O.J[0] = A[0] - Y[0] + trY; O.J[1] = A[1] - Y[1]; O.J[2] = A[2] - Y[2];
+  O.J[3] = A[3] - Y[3] + trY; O.J[4] = A[4] - Y[4]; O.J[5] = A[5] - Y[5] + trY;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) O.c[k] = Rmc[k] + mp[k];
+  O.m = m;
+}
+// newton_euler cross term: T x* (I T) = (w x k + v x l ; w x l), (k, l) = I T
+template <typename T> RBD_DEV void momentum_cross(const RInertia<T>& I, const T* t, T* o) {
+  T h[6], a[3], b[3], c[3];
+  mul_inertia(I, t, h);
+  cross3(t, h, a);
+  cross3(t + 3, h + 3, b);
+  cross3(t, h + 3, c);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = a[k] + b[k]; o[3 + k] = c[k]; }
+}
+
+// ---- packed symmetric 6x6 (upper, row-major): index of (i, j), i <= j ----
+__host__ __device__ constexpr int SI(int i, int j) { return i <= j ? (i * 6 - i * (i - 1) / 2 + (j - i)) : (j * 6 - j * (j - 1) / 2 + (i - j)); }
+
+template <typename T> RBD_DEV void sym6_from_inertia(const RInertia<T>& I, T* A /*21*/) {
+  const T z = T(0);
+  const T* c = I.c;
+  A[SI(0, 0)] = I.J[0]; A[SI(0, 1)] = I.J[1]; A[SI(0, 2)] = I.J[2]; A[SI(0, 3)] = z;     A[SI(0, 4)] = -c[2]; A[SI(0, 5)] = c[1];
+  A[SI(1, 1)] = I.J[3]; A[SI(1, 2)] = I.J[4]; A[SI(1, 3)] = c[2];   A[SI(1, 4)] = z;     A[SI(1, 5)] = -c[0];
+  A[SI(2, 2)] = I.J[5]; A[SI(2, 3)] = -c[1];  A[SI(2, 4)] = c[0];   A[SI(2, 5)] = z;
+  A[SI(3, 3)] = I.m;    A[SI(3, 4)] = z;      A[SI(3, 5)] = z;
+  A[SI(4, 4)] = I.m;    A[SI(4, 5)] = z;
+  A[SI(5, 5)] = I.m;
+}
+template <typename T> RBD_DEV void sym6_mul(const T* A, const T* x, T* o) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    T s = T(0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s += A[SI(i, j)] * x[j];
+    o[i] = s;
+  }
+}
+// in-place LDL' of a packed SPD 6x6 (A = L D L', unit lower L stored in the strict part as A[SI(j,i)], D on the diagonal)
+// and solve A x = b.  No square roots; the pivots are 1/d.
+template <typename T> RBD_DEV void sym6_solve(T* A, const T* b, T* x) {
+  T dinv[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    T d = A[SI(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= A[SI(k, j)] * A[SI(k, j)] * A[SI(k, k)];
+    A[SI(j, j)] = d;
+    dinv[j] = T(1) / d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      T s = A[SI(j, i)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= A[SI(k, i)] * A[SI(k, j)] * A[SI(k, k)];
+      A[SI(j, i)] = s * dinv[j];  // L[i][j]
+    }
+  }
+  T y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    T s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= A[SI(k, i)] * y[k];
+    y[i] = s;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    T s = y[i] * dinv[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= A[SI(i, k)] * x[k];
+    x[i] = s;
+  }
+}
+
+// AngleAxis -> R given sin, cos (formula of src/joint_types/sin_cos_revolute.jl:69-96)
+template <typename T> RBD_DEV void rot_axis_sc(const T* ax, T s, T c, T* R) {
+  T c1 = T(1) - c;
+  T c1x2 = c1 * ax[0] * ax[0], c1y2 = c1 * ax[1] * ax[1], c1z2 = c1 * ax[2] * ax[2];
+  T c1xy = c1 * ax[0] * ax[1], c1xz = c1 * ax[0] * ax[2], c1yz = c1 * ax[1] * ax[2];
+  T sx = s * ax[0], sy = s * ax[1], sz = s * ax[2];
+  R[0] = T(1) - c1y2 - c1z2; R[3] = c1xy + sz;          R[6] = c1xz - sy;
+  R[1] = c1xy - sz;          R[4] = T(1) - c1x2 - c1z2; R[7] = c1yz + sx;
+  R[2] = c1xz + sy;          R[5] = c1yz - sx;          R[8] = T(1) - c1x2 - c1y2;
+}
+// unit quaternion (w,x,y,z) -> R (Rotations.jl QuatRotation, normalize=false)
+template <typename T> RBD_DEV void rot_quat(T w, T x, T y, T z, T* R) {
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+RBD_DEV void sincos_t(double x, double* s, double* c) { sincos(x, s, c); }
+RBD_DEV void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
+
+}  // namespace rbd

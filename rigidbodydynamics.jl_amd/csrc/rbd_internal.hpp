@@ -1,0 +1,15 @@
+// rbd_internal.hpp — host-side declarations shared by rbd_kernels.hip and rbd_capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rbd_device.hpp"
+
+namespace rbd {
+template <typename T>
+hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
+                      void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+template <typename T>
+hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
+                       Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+template <typename T>
+hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill, hipStream_t s);
+}  // namespace rbd

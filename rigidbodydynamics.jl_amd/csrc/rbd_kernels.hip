@@ -1,0 +1,575 @@
+// rbd_kernels.hip — hand-written gfx950 kernels for the batched hot path of RigidBodyDynamics.jl:
+//   aba_kernel   : dynamics!        (src/mechanism_algorithms.jl:845-864) as a fused world-frame
+//                  articulated-body algorithm (same v̇ = M⁻¹(τ − c))
+//   rnea_kernel  : inverse_dynamics! (:542-553) and dynamics_bias! (:484-498)
+//   crba_kernel  : mass_matrix!      (:248-272)
+// Mapping: one lane per (state, body); level-synchronous sweeps; parent/child exchange by wave
+// shuffles; per-body quantities stay in VGPRs (see rbd_device.hpp).
+#include "rbd_device.hpp"
+#include "rbd_internal.hpp"
+#include "rbd_hip.h"
+
+namespace rbd {
+
+template <typename T> struct Body {
+  // topology
+  int parent, jtype, qoff, voff, level, nchild;
+  int child[IB_MAXCHILD];
+  int plane;  // lane of the parent body (own lane if parent is the world)
+  // lane bookkeeping
+  int lane, sub, base;
+  long state;
+  bool valid;
+};
+
+template <typename T> RBD_DEV int joint_nq(int t) {
+  return t == RBD_JOINT_QUAT_FLOATING ? 7 : t == RBD_JOINT_SINCOS_REVOLUTE ? 2 : (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC) ? 1 : 0;
+}
+RBD_DEV int joint_nv(int t) {
+  return t == RBD_JOINT_QUAT_FLOATING ? 6 : (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC || t == RBD_JOINT_SINCOS_REVOLUTE) ? 1 : 0;
+}
+
+template <typename T> RBD_DEV void load_body(const DevModel& M, long B, Body<T>& b) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  b.lane = threadIdx.x & 63;
+  const long wave = tid >> 6;
+  const int lps = M.lps;
+  b.sub = b.lane & (lps - 1);
+  b.base = b.lane - b.sub;
+  b.state = wave * (64 / lps) + (b.lane / lps);
+  b.valid = (b.sub < M.nb) && (b.state < B);
+  const int body = b.sub < M.nb ? b.sub : 0;
+  const int32_t* ib = M.ib + body * IB_STRIDE;
+  b.parent = ib[IB_PARENT];
+  b.jtype = ib[IB_JTYPE];
+  b.qoff = ib[IB_QOFF];
+  b.voff = ib[IB_VOFF];
+  b.level = b.valid ? ib[IB_LEVEL] : -1;  // idle lanes never commit
+  b.nchild = ib[IB_NCHILD];
+#pragma unroll
+  for (int k = 0; k < IB_MAXCHILD; ++k) b.child[k] = ib[IB_CHILD0 + k];
+  b.plane = b.parent >= 0 ? b.base + b.parent : b.lane;
+}
+
+// joint_transform(q) composed with joint_to_predecessor: XL = Xpred * Tj(q)
+// (src/mechanism_state.jl:699; revolute.jl:59-62, prismatic.jl:69-73, quaternion_floating.jl:81-83,
+//  sin_cos_revolute.jl:69-96, fixed.jl)
+template <typename T> RBD_DEV void local_transform(const Body<T>& b, const T* rb, const T* qj, T* XR, T* Xp) {
+  T Rj[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+  T pj[3] = {T(0), T(0), T(0)};
+  const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]};
+  if (b.jtype == RBD_JOINT_REVOLUTE) {
+    T s, c;
+    sincos_t(qj[0], &s, &c);
+    rot_axis_sc(ax, s, c, Rj);
+  } else if (b.jtype == RBD_JOINT_SINCOS_REVOLUTE) {
+    rot_axis_sc(ax, qj[0], qj[1], Rj);
+  } else if (b.jtype == RBD_JOINT_PRISMATIC) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pj[k] = qj[0] * ax[k];
+  } else if (b.jtype == RBD_JOINT_QUAT_FLOATING) {
+    rot_quat(qj[0], qj[1], qj[2], qj[3], Rj);
+    pj[0] = qj[4]; pj[1] = qj[5]; pj[2] = qj[6];
+  }
+  T XpR[9], Xpp[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) XpR[k] = rb[RB_XPR + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) Xpp[k] = rb[RB_XPP + k];
+  matmul3(XpR, Rj, XR);
+  matvec3(XpR, pj, Xp);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) Xp[k] += Xpp[k];
+}
+
+// local joint twist S_local * v in frame_after (revolute.jl:64-68, prismatic.jl:75-79, quaternion_floating.jl:182-188)
+template <typename T> RBD_DEV void local_joint_motion(const Body<T>& b, const T* rb, const T* vj, T* o) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o[k] = T(0);
+  if (b.jtype == RBD_JOINT_REVOLUTE || b.jtype == RBD_JOINT_SINCOS_REVOLUTE) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = rb[RB_AXIS + k] * vj[0];
+  } else if (b.jtype == RBD_JOINT_PRISMATIC) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[3 + k] = rb[RB_AXIS + k] * vj[0];
+  } else if (b.jtype == RBD_JOINT_QUAT_FLOATING) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = vj[k];
+  }
+}
+
+template <typename T> RBD_DEV void load_joint_q(const Body<T>& b, const T* __restrict__ q, Layout L, T* qj) {
+  const int n = joint_nq<T>(b.jtype);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) qj[k] = (b.valid && k < n) ? q[(long)(b.qoff + k) * L.sk + b.state * L.sb] : T(0);
+}
+template <typename T> RBD_DEV void load_joint_v(const Body<T>& b, const T* __restrict__ v, Layout L, T* vj) {
+  const int n = joint_nv(b.jtype);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vj[k] = (v != nullptr && b.valid && k < n) ? v[(long)(b.voff + k) * L.sk + b.state * L.sb] : T(0);
+}
+template <typename T> RBD_DEV void load_body_wrench(const Body<T>& b, const T* __restrict__ f, Layout L, T* w) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) w[k] = (f != nullptr && b.valid) ? f[(long)(6 * b.sub + k) * L.sk + b.state * L.sb] : T(0);
+}
+template <typename T> RBD_DEV void store_joint_v(const Body<T>& b, T* __restrict__ out, Layout L, const T* x) {
+  const int n = joint_nv(b.jtype);
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (b.valid && k < n) out[(long)(b.voff + k) * L.sk + b.state * L.sb] = x[k];
+}
+
+// velocity_to_configuration_derivative! (quaternion_floating.jl:126-136, spatial/util.jl:127-134, sin_cos_revolute.jl; default q̇ = v)
+template <typename T> RBD_DEV void store_qdot(const Body<T>& b, T* __restrict__ qdot, Layout L, const T* qj, const T* vj) {
+  if (qdot == nullptr || !b.valid) return;
+  T o[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) o[k] = T(0);
+  if (b.jtype == RBD_JOINT_REVOLUTE || b.jtype == RBD_JOINT_PRISMATIC) {
+    o[0] = vj[0];
+  } else if (b.jtype == RBD_JOINT_SINCOS_REVOLUTE) {
+    o[0] = qj[1] * vj[0];
+    o[1] = -qj[0] * vj[0];
+  } else if (b.jtype == RBD_JOINT_QUAT_FLOATING) {
+    const T w = qj[0], x = qj[1], y = qj[2], z = qj[3];
+    o[0] = (-x * vj[0] - y * vj[1] - z * vj[2]) / 2;
+    o[1] = (w * vj[0] - z * vj[1] + y * vj[2]) / 2;
+    o[2] = (z * vj[0] + w * vj[1] - x * vj[2]) / 2;
+    o[3] = (-y * vj[0] + x * vj[1] + w * vj[2]) / 2;
+    T R[9];
+    rot_quat(w, x, y, z, R);
+    matvec3(R, vj + 3, o + 4);
+  }
+  const int n = joint_nq<T>(b.jtype);
+#pragma unroll
+  for (int k = 0; k < 7; ++k)
+    if (k < n) qdot[(long)(b.qoff + k) * L.sk + b.state * L.sb] = o[k];
+}
+
+// Top-down sweep 1: transforms to root and twists (update_transforms! src/mechanism_state.jl:687-700,
+// update_twists_wrt_world! :769-780).  XR/Xp: local transform in, transform-to-root out.  vJ: joint twist in the
+// root frame (T_b - T_parent).  Optionally also carries spatial accelerations (spatial_accelerations!
+// src/mechanism_algorithms.jl:387-417): acc_local = S_local*v̇ in, acc = a_b out, with a_root = -gravity.
+template <typename T, bool WITH_ACC>
+RBD_DEV void sweep_kinematics(const DevModel& M, const Body<T>& b, T* R, T* p, const T* tj_local, T* Tw, T* vJ,
+                              const T* aj_local, T* acc) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { Tw[k] = T(0); vJ[k] = T(0); }
+  if (WITH_ACC) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = T(0);
+  }
+  for (int l = 0; l < M.nlevels; ++l) {
+    T pR[9], pp[3], pT[6], pa[6];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pR[k] = shfl(R[k], b.plane);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pp[k] = shfl(p[k], b.plane);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pT[k] = shfl(Tw[k], b.plane);
+    if (WITH_ACC) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pa[k] = shfl(acc[k], b.plane);
+    }
+    if (b.level == l) {
+      if (b.parent >= 0) {
+        T nR[9], np[3];
+        matmul3(pR, R, nR);
+        matvec3(pR, p, np);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = nR[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = np[k] + pp[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pT[k] = T(0);
+        if (WITH_ACC) {
+          pa[0] = pa[1] = pa[2] = T(0);
+          pa[3] = T(-M.gravity[0]); pa[4] = T(-M.gravity[1]); pa[5] = T(-M.gravity[2]);
+        }
+      }
+      xmotion(R, p, tj_local, vJ);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Tw[k] = pT[k] + vJ[k];
+      if (WITH_ACC) {
+        // a_b = a_p + (-T_b) x T_p + X a_joint    (mechanism_algorithms.jl:414)
+        T nT[6], cr[6], aj[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) nT[k] = -Tw[k];
+        se3_comm(nT, pT, cr);
+        xmotion(R, p, aj_local, aj);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = pa[k] + cr[k] + aj[k];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused forward dynamics (ABA).  One launch: FK + twists, articulated inertias bottom-up, accelerations top-down.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
+                                                  const T* __restrict__ tau, const T* __restrict__ fext,
+                                                  T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
+  Body<T> b;
+  load_body(M, B, b);
+  const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
+
+  T qj[7], vj[6], tj[6];
+  load_joint_q(b, q, Lq, qj);
+  load_joint_v(b, v, Lv, vj);
+  load_joint_v(b, tau, Lv, tj);
+  store_qdot(b, qdot, Lq, qj, vj);
+
+  T R[9], p[3], tl[6], Tw[6], vJ[6];
+  local_transform(b, rb, qj, R, p);
+  local_joint_motion(b, rb, vj, tl);
+  sweep_kinematics<T, false>(M, b, R, p, tl, Tw, vJ, nullptr, nullptr);
+
+  // per-body, all lanes in parallel: motion subspace, bias term, inertia, bias force
+  const bool one_dof = (b.jtype == RBD_JOINT_REVOLUTE || b.jtype == RBD_JOINT_PRISMATIC || b.jtype == RBD_JOINT_SINCOS_REVOLUTE);
+  const bool floating = (b.jtype == RBD_JOINT_QUAT_FLOATING);
+  T S[6];
+  {
+    T one[6] = {T(1), T(0), T(0), T(0), T(0), T(0)};
+    T sl[6];
+    local_joint_motion(b, rb, one, sl);  // S_local for 1-dof joints
+    xmotion(R, p, sl, S);
+  }
+  T cb[6];
+  se3_comm(Tw, vJ, cb);  // [T_b, vJ]: bias acceleration increment (mechanism_state.jl:814-830)
+  T IA[21], pA[6];
+  {
+    RInertia<T> I;
+    T Jb[6], mc[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jb[k] = rb[RB_J + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mc[k] = rb[RB_MC + k];
+    inertia_to_root(Jb, mc, rb[RB_M], R, p, I);
+    sym6_from_inertia(I, IA);
+    momentum_cross(I, Tw, pA);
+    T fe[6];
+    load_body_wrench(b, fext, Lf, fe);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pA[k] -= fe[k];
+  }
+  if (!b.valid) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) IA[k] = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pA[k] = T(0);
+  }
+
+  // bottom-up: articulated-body inertias and bias forces
+  T U[6], Dinv = T(0), u = T(0);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) U[k] = T(0);
+  T Ia[21], pa[6];  // what this body hands to its parent
+#pragma unroll
+  for (int k = 0; k < 21; ++k) Ia[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pa[k] = T(0);
+  for (int l = M.nlevels - 1; l >= 0; --l) {
+    if (b.level == l) {
+      if (one_dof) {
+        sym6_mul(IA, S, U);
+        const T D = dot6(S, U);
+        Dinv = T(1) / D;
+        u = tj[0] - dot6(S, pA);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j) Ia[SI(i, j)] = IA[SI(i, j)] - U[i] * (U[j] * Dinv);
+        T Iac[6];
+        sym6_mul(Ia, cb, Iac);
+        const T ud = u * Dinv;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pa[k] = pA[k] + Iac[k] + U[k] * ud;
+      } else if (floating) {
+        // 6-dof joint: Ia = 0, pa = S^-T tau = wrench transform of tau to the root frame
+        xforce(R, p, tj, pa);
+      } else {  // fixed joint in the tree: pass through (vJ = 0 => cb = 0)
+#pragma unroll
+        for (int k = 0; k < 21; ++k) Ia[k] = IA[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pa[k] = pA[k];
+      }
+    }
+    // parents (level l-1) gather from their children (all at level l)
+    if (l > 0) {
+      const int ns = M.nslots[l];
+      for (int s = 0; s < ns; ++s) {
+        const int c = (s == 0) ? b.child[0] : (s == 1) ? b.child[1] : (s == 2) ? b.child[2] : (s == 3) ? b.child[3] : (s == 4) ? b.child[4] : b.child[5];
+        const bool take = (b.level == l - 1) && (s < b.nchild);
+        const int src = take ? b.base + c : b.lane;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) {
+          const T x = shfl(Ia[k], src);
+          if (take) IA[k] += x;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const T x = shfl(pa[k], src);
+          if (take) pA[k] += x;
+        }
+      }
+    }
+  }
+
+  // top-down: accelerations and v̇
+  T acc[6], vd[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { acc[k] = T(0); vd[k] = T(0); }
+  for (int l = 0; l < M.nlevels; ++l) {
+    T ap[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ap[k] = shfl(acc[k], b.plane);
+    if (b.level == l) {
+      if (b.parent < 0) {
+        ap[0] = ap[1] = ap[2] = T(0);
+        ap[3] = T(-M.gravity[0]); ap[4] = T(-M.gravity[1]); ap[5] = T(-M.gravity[2]);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ap[k] += cb[k];
+      if (one_dof) {
+        vd[0] = (u - dot6(U, ap)) * Dinv;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = ap[k] + S[k] * vd[0];
+      } else if (floating) {
+        // IA a_b = S^-T tau - pA ;  v̇ = S^-1 (a_b - a')
+        T rhs[6], d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rhs[k] = pa[k] - pA[k];
+        sym6_solve(IA, rhs, acc);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = acc[k] - ap[k];
+        xmotion_inv(R, p, d, vd);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = ap[k];
+      }
+    }
+  }
+  store_joint_v(b, vdot, Lv, vd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RNEA: inverse_dynamics! (vdot != nullptr) and dynamics_bias! (vdot == nullptr).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
+                                                   const T* __restrict__ vdot, const T* __restrict__ fext,
+                                                   T* __restrict__ tau, Layout Lq, Layout Lv, Layout Lf) {
+  Body<T> b;
+  load_body(M, B, b);
+  const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
+  T qj[7], vj[6], aj[6];
+  load_joint_q(b, q, Lq, qj);
+  load_joint_v(b, v, Lv, vj);
+  load_joint_v(b, vdot, Lv, aj);
+  T R[9], p[3], tl[6], al[6], Tw[6], vJ[6], acc[6];
+  local_transform(b, rb, qj, R, p);
+  local_joint_motion(b, rb, vj, tl);
+  local_joint_motion(b, rb, aj, al);  // joint_spatial_acceleration: S_local * v̇ (revolute.jl:76-81)
+  sweep_kinematics<T, true>(M, b, R, p, tl, Tw, vJ, al, acc);
+
+  // newton_euler! (mechanism_algorithms.jl:428-439): w = I a + T x* I T - wext
+  T w[6];
+  {
+    RInertia<T> I;
+    T Jb[6], mc[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jb[k] = rb[RB_J + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mc[k] = rb[RB_MC + k];
+    inertia_to_root(Jb, mc, rb[RB_M], R, p, I);
+    T Ia[6], x[6], fe[6];
+    mul_inertia(I, acc, Ia);
+    momentum_cross(I, Tw, x);
+    load_body_wrench(b, fext, Lf, fe);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w[k] = b.valid ? (Ia[k] + x[k] - fe[k]) : T(0);
+  }
+  // joint_wrenches_and_torques! (:442-459): w_parent += w_child, bottom-up
+  for (int l = M.nlevels - 1; l >= 1; --l) {
+    const int ns = M.nslots[l];
+    for (int s = 0; s < ns; ++s) {
+      const int c = (s == 0) ? b.child[0] : (s == 1) ? b.child[1] : (s == 2) ? b.child[2] : (s == 3) ? b.child[3] : (s == 4) ? b.child[4] : b.child[5];
+      const bool take = (b.level == l - 1) && (s < b.nchild);
+      const int src = take ? b.base + c : b.lane;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const T x = shfl(w[k], src);
+        if (take) w[k] += x;
+      }
+    }
+  }
+  // tau = S' w
+  T out[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out[k] = T(0);
+  if (b.jtype == RBD_JOINT_QUAT_FLOATING) {
+    xforce_inv(R, p, w, out);
+  } else {
+    T one[6] = {T(1), T(0), T(0), T(0), T(0), T(0)};
+    T sl[6], S[6];
+    local_joint_motion(b, rb, one, sl);
+    xmotion(R, p, sl, S);
+    out[0] = dot6(S, w);
+  }
+  store_joint_v(b, tau, Lv, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CRBA: mass_matrix! (src/mechanism_algorithms.jl:248-272) with update_crb_inertias!
+// (src/mechanism_state.jl:852-868).  Row block of body i: M[i, j] = F_i · S_j for every dof j of an
+// ancestor-or-self joint (support set), zero elsewhere; only the lower triangle is written.
+// M_out: element (i, j) of state b at M[(j*nv + i)*Lm.sk + b*Lm.sb].
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* __restrict__ q, T* __restrict__ Mout,
+                                                   Layout Lq, Layout Lm, int zero_fill) {
+  Body<T> b;
+  load_body(M, B, b);
+  const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
+  T qj[7];
+  load_joint_q(b, q, Lq, qj);
+  T R[9], p[3], zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, Tw[6], vJ[6];
+  local_transform(b, rb, qj, R, p);
+  sweep_kinematics<T, false>(M, b, R, p, zero6, Tw, vJ, nullptr, nullptr);
+  RInertia<T> Ic;
+  {
+    T Jb[6], mc[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jb[k] = rb[RB_J + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mc[k] = rb[RB_MC + k];
+    inertia_to_root(Jb, mc, rb[RB_M], R, p, Ic);
+    if (!b.valid) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Ic.J[k] = T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ic.c[k] = T(0);
+      Ic.m = T(0);
+    }
+  }
+  // composite-rigid-body inertias, bottom-up (10 scalars per child)
+  for (int l = M.nlevels - 1; l >= 1; --l) {
+    const int ns = M.nslots[l];
+    for (int s = 0; s < ns; ++s) {
+      const int c = (s == 0) ? b.child[0] : (s == 1) ? b.child[1] : (s == 2) ? b.child[2] : (s == 3) ? b.child[3] : (s == 4) ? b.child[4] : b.child[5];
+      const bool take = (b.level == l - 1) && (s < b.nchild);
+      const int src = take ? b.base + c : b.lane;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const T x = shfl(Ic.J[k], src); if (take) Ic.J[k] += x; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const T x = shfl(Ic.c[k], src); if (take) Ic.c[k] += x; }
+      { const T x = shfl(Ic.m, src); if (take) Ic.m += x; }
+    }
+  }
+  const int nvi = joint_nv(b.jtype);
+  const long nv = M.nv;
+  // own motion subspace columns S (6 x nvi) and force columns F = Ic S
+  // 1-dof: one column; floating: 6 columns = Xm(H) e_k.
+  for (int ci = 0; ci < 6; ++ci) {
+    if (ci >= M.maxnvj) break;  // uniform
+    T e[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    T sl[6], Si[6], Fi[6];
+    if (b.jtype == RBD_JOINT_QUAT_FLOATING) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sl[k] = (k == ci) ? T(1) : T(0);
+    } else {
+      e[0] = T(1);
+      local_joint_motion(b, rb, e, sl);
+    }
+    xmotion(R, p, sl, Si);
+    mul_inertia(Ic, Si, Fi);
+    const bool have_col = b.valid && ci < nvi;
+    const long row = b.voff + ci;
+    // walk up the support chain: ancestors a_0 = self, a_1 = parent, ...
+    for (int k = 0; k < M.nlevels; ++k) {
+      const int a = M.anc[(b.sub < M.nb ? b.sub : 0) * M.nlevels + k];  // body index or -1
+      const int src = (a >= 0) ? b.base + a : b.lane;
+      // ancestor's transform and joint data via shuffles
+      T aR[9], ap[3];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) aR[j] = shfl(R[j], src);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ap[j] = shfl(p[j], src);
+      const int ajt = __shfl(b.jtype, src, 64);
+      const int avoff = __shfl(b.voff, src, 64);
+      T aax[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) aax[j] = shfl(rb[RB_AXIS + j], src);
+      if (have_col && a >= 0) {
+        const int anv = joint_nv(ajt);
+        for (int cj = 0; cj < anv; ++cj) {
+          const long col = avoff + cj;
+          if (col > row) continue;  // lower triangle only (self block)
+          T slj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, Sj[6];
+          if (ajt == RBD_JOINT_QUAT_FLOATING) {
+            slj[cj] = T(1);
+          } else if (ajt == RBD_JOINT_PRISMATIC) {
+            slj[3] = aax[0]; slj[4] = aax[1]; slj[5] = aax[2];
+          } else {
+            slj[0] = aax[0]; slj[1] = aax[1]; slj[2] = aax[2];
+          }
+          xmotion(aR, ap, slj, Sj);
+          Mout[(col * nv + row) * Lm.sk + b.state * Lm.sb] = dot6(Fi, Sj);
+        }
+      }
+    }
+  }
+  // structural zeros of the lower triangle (the reference writes them too: mechanism_algorithms.jl:266-267)
+  if (zero_fill && b.valid) {
+    for (int ci = 0; ci < nvi; ++ci) {
+      const long row = b.voff + ci;
+      for (long col = 0; col <= row; ++col) {
+        // supported iff dof_body[col] is an ancestor-or-self of this body
+        const int cb_ = M.dof_body[col];
+        bool sup = false;
+        for (int k = 0; k < M.nlevels; ++k) sup |= (M.anc[b.sub * M.nlevels + k] == cb_);
+        if (!sup) Mout[(col * nv + row) * Lm.sk + b.state * Lm.sb] = T(0);
+      }
+    }
+  }
+}
+
+// ---- launchers -----------------------------------------------------------------------------
+static inline dim3 grid_for(const DevModel& M, long B, int block) {
+  const long spw = 64 / M.lps;
+  const long waves = (B + spw - 1) / spw;
+  const long wpb = block / 64;
+  return dim3((unsigned)((waves + wpb - 1) / wpb));
+}
+
+template <typename T>
+hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
+                      void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+  hipLaunchKernelGGL(aba_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
+                     (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
+                       Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+  hipLaunchKernelGGL(rnea_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)vdot,
+                     (const T*)fext, (T*)tau, Lq, Lv, Lf);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill, hipStream_t s) {
+  hipLaunchKernelGGL(crba_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (T*)Mout, Lq, Lm, zero_fill);
+  return hipGetLastError();
+}
+
+template hipError_t launch_aba<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_aba<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_crba<double>(const DevModel&, long, const void*, void*, Layout, Layout, int, hipStream_t);
+template hipError_t launch_crba<float>(const DevModel&, long, const void*, void*, Layout, Layout, int, hipStream_t);
+
+}  // namespace rbd

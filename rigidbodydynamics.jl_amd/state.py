@@ -1,0 +1,290 @@
+"""Batched mirror of the reference's operator interface for the hot path.
+
+    reference (one state, CPU)                                this package (B states, one MI355X)
+    MechanismState(mechanism)            mechanism_state.jl:79    MechanismState(mechanism, batch, dtype, device)
+    DynamicsResult(mechanism)            dynamics_result.jl:37    DynamicsResult(mechanism, batch, dtype, device)
+    dynamics!(result, state, τ, wext)    mechanism_algorithms.jl:845   dynamics_(result, state, torques, externalwrenches)
+    inverse_dynamics!(τ, jw, acc, state, v̇, wext)      :542           inverse_dynamics_(torquesout, state, vd, externalwrenches)
+    dynamics_bias!(result, state)                        :496           dynamics_bias_(result, state, externalwrenches)
+    mass_matrix!(M, state) / (result, state)             :248/:274      mass_matrix_(M_or_result, state)
+
+`q`, `v`, … are torch tensors on the GPU with ONE STATE PER COLUMN of the Julia matrix, i.e. shape (B, n) row-major
+(== Julia `n × B` column-major, RBD_LAYOUT_AOS) by default, or (n, B) with layout="soa".  Julia's `!` becomes a
+trailing underscore.  All arithmetic happens in csrc/librbd_hip.so; errors map to the reference's exception types.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _capi
+from .mechanism import FlatModel, Mechanism, flatten
+
+
+class DimensionMismatch(ValueError):
+    """Julia's DimensionMismatch (e.g. src/mechanism_algorithms.jl:250)."""
+
+
+def _raise(status, where):
+    try:
+        _capi.check(status, where)
+    except _capi.RBDError as e:
+        if e.status == 2:
+            raise DimensionMismatch(str(e)) from None
+        if e.status == 1:
+            raise ValueError(str(e)) from None  # ArgumentError
+        if e.status == 7:
+            raise RuntimeError("This method can currently only handle tree Mechanisms.") from None
+        raise
+
+
+class _Model:
+    """Owns the rbd_model_t handle for a FlatModel (re-flatten when `modcount` changes, like @modcountcheck)."""
+
+    def __init__(self, flat: FlatModel):
+        self.flat = flat
+        h = ctypes.c_void_p()
+        _raise(_capi.lib().rbd_model_create(ctypes.cast(ctypes.byref(flat.c_struct()), ctypes.c_void_p), ctypes.byref(h)), "rbd_model_create")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _capi.lib().rbd_model_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _as_model(mechanism_or_flat) -> _Model:
+    if isinstance(mechanism_or_flat, _Model):
+        return mechanism_or_flat
+    if isinstance(mechanism_or_flat, Mechanism):
+        cached = getattr(mechanism_or_flat, "_rbd_model", None)
+        if cached is None or cached[0] != mechanism_or_flat.modcount:
+            cached = (mechanism_or_flat.modcount, _Model(flatten(mechanism_or_flat)))
+            mechanism_or_flat._rbd_model = cached
+        return cached[1]
+    if isinstance(mechanism_or_flat, FlatModel):
+        cached = getattr(mechanism_or_flat, "_rbd_model", None)
+        if cached is None:
+            cached = _Model(mechanism_or_flat)
+            mechanism_or_flat._rbd_model = cached
+        return cached
+    raise TypeError(type(mechanism_or_flat))
+
+
+_TORCH_DTYPE = {torch.float64: _capi.F64, torch.float32: _capi.F32}
+
+
+class _Workspace:
+    def __init__(self, model: _Model, batch: int, dtype: torch.dtype, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("rigidbodydynamics.jl_amd runs on an MI355X only (no CPU path); got device " + str(device))
+        self.model, self.batch, self.dtype, self.device = model, batch, dtype, device
+        h = ctypes.c_void_p()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _raise(_capi.lib().rbd_workspace_create(model.handle, batch, idx, _TORCH_DTYPE[dtype], ctypes.c_void_p(stream), ctypes.byref(h)),
+               "rbd_workspace_create")
+        self.handle = h
+
+    def use_current_stream(self):
+        _capi.lib().rbd_workspace_set_stream(self.handle, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _capi.lib().rbd_workspace_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class MechanismState:
+    """Batch of B states (q, v) of one mechanism on one GPU.  `layout="aos"`: q is (B, nq) — one state per Julia
+    column; `layout="soa"`: q is (nq, B)."""
+
+    def __init__(self, mechanism, batch: int = 1, dtype: torch.dtype = torch.float64, device="cuda", layout: str = "aos"):
+        self.model = _as_model(mechanism)
+        self.flat = self.model.flat
+        self.batch, self.dtype, self.device, self.layout = int(batch), dtype, torch.device(device), layout
+        if layout not in ("aos", "soa"):
+            raise ValueError("layout must be 'aos' or 'soa'")
+        self.ws = _Workspace(self.model, self.batch, dtype, self.device)
+        self.q = self._zeros(self.flat.nq)
+        self.v = self._zeros(self.flat.nv)
+        zero_configuration_(self)
+
+    def _zeros(self, n):
+        shape = (self.batch, n) if self.layout == "aos" else (n, self.batch)
+        return torch.zeros(shape, dtype=self.dtype, device=self.device)
+
+    def _opts(self, algorithm=_capi.ALGO_ABA, stabilization=1):
+        return _capi.Opts(_capi.LAYOUT_AOS if self.layout == "aos" else _capi.LAYOUT_SOA, _capi.MEM_DEVICE, algorithm, stabilization)
+
+    def _check(self, t: Optional[torch.Tensor], n: int, what: str):
+        if t is None:
+            return
+        shape = (self.batch, n) if self.layout == "aos" else (n, self.batch)
+        if tuple(t.shape) != shape:
+            raise DimensionMismatch(f"{what}: expected shape {shape}, got {tuple(t.shape)}")
+        if t.dtype != self.dtype or t.device.type != "cuda" or not t.is_contiguous():
+            raise ValueError(f"{what}: must be a contiguous {self.dtype} CUDA tensor")
+
+    def num_positions(self):
+        return self.flat.nq
+
+    def num_velocities(self):
+        return self.flat.nv
+
+
+def _from_host(state: MechanismState, a: np.ndarray) -> torch.Tensor:
+    t = torch.as_tensor(np.ascontiguousarray(a), dtype=state.dtype)
+    if state.layout == "soa":
+        t = t.t().contiguous()
+    return t.to(state.device)
+
+
+def set_configuration_(state: MechanismState, q):
+    """`set_configuration!(state, q)`: q is (B, nq) host/torch data, one state per row."""
+    q = q if isinstance(q, torch.Tensor) else _from_host(state, np.asarray(q))
+    state._check(q, state.flat.nq, "q")
+    state.q.copy_(q)
+
+
+def set_velocity_(state: MechanismState, v):
+    v = v if isinstance(v, torch.Tensor) else _from_host(state, np.asarray(v))
+    state._check(v, state.flat.nv, "v")
+    state.v.copy_(v)
+
+
+def zero_configuration_(state: MechanismState):
+    """`zero_configuration!`: identity quaternions (quaternion_floating.jl:169-173), sin/cos = (0, 1), zeros elsewhere."""
+    from .mechanism import JOINT_QUAT_FLOATING, JOINT_QUAT_SPHERICAL, JOINT_SINCOS_REVOLUTE
+    q = np.zeros((state.batch, state.flat.nq))
+    for i in range(state.flat.n_bodies):
+        t, o = int(state.flat.joint_type[i]), int(state.flat.q_offset[i])
+        if t in (JOINT_QUAT_FLOATING, JOINT_QUAT_SPHERICAL):
+            q[:, o] = 1.0
+        elif t == JOINT_SINCOS_REVOLUTE:
+            q[:, o + 1] = 1.0
+    state.q.copy_(_from_host(state, q))
+    state.v.zero_()
+
+
+def rand_(state: MechanismState, seed: int = 0):
+    """`rand!(state)` with the reference's per-joint distributions (SURVEY.md §8 d)."""
+    from .mechanism import rand_configuration, rand_velocity
+    rng = np.random.default_rng(seed)
+    set_configuration_(state, rand_configuration(state.flat, state.batch, rng))
+    set_velocity_(state, rand_velocity(state.flat, state.batch, rng))
+
+
+class DynamicsResult:
+    """Output container with the reference's field names (src/dynamics_result.jl:11-36), batched."""
+
+    def __init__(self, mechanism, batch: int = 1, dtype: torch.dtype = torch.float64, device="cuda", layout: str = "aos"):
+        self.model = _as_model(mechanism)
+        f = self.model.flat
+        self.batch, self.dtype, self.device, self.layout = int(batch), dtype, torch.device(device), layout
+        z = lambda n: torch.zeros((batch, n) if layout == "aos" else (n, batch), dtype=dtype, device=self.device)
+        self.massmatrix = z(f.nv * f.nv)       # nv×nv column-major per state, lower triangle valid (Symmetric 'L')
+        self.dynamicsbias = z(f.nv)
+        self.qd = z(f.nq)                        # q̇
+        self.vd = z(f.nv)                        # v̇
+        self.lambda_ = z(max(f.nc, 1))[:, :f.nc] if layout == "aos" else z(max(f.nc, 1))[:f.nc]  # λ
+        self.constraintjacobian = z(f.nc * f.nv)
+        self.constraintbias = z(f.nc)
+
+    def massmatrix_dense(self) -> torch.Tensor:
+        """(B, nv, nv) symmetric matrices M[b, i, j] from the lower-triangular column-major storage."""
+        nv = self.model.flat.nv
+        m = self.massmatrix if self.layout == "aos" else self.massmatrix.t()
+        L = torch.tril(m.reshape(self.batch, nv, nv).transpose(1, 2))
+        return L + torch.tril(L, -1).transpose(1, 2)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[torch.Tensor] = None,
+              externalwrenches: Optional[torch.Tensor] = None, stabilization_gains="default", algorithm: str = "aba"):
+    """`dynamics!(result, state, torques, externalwrenches; stabilization_gains)` (src/mechanism_algorithms.jl:845-864):
+    fills `result.vd` (v̇) and `result.qd` (q̇).  `torques` (B, nv) defaults to zeros; `externalwrenches` is a dense
+    (B, 6*n_bodies) tensor of root-frame wrenches (torque; force) per moving body (None == NullDict).
+    algorithm="aba": fused articulated-body kernel; "crba": the reference's own CRBA + Cholesky route, which also
+    fills result.massmatrix and result.dynamicsbias."""
+    f = state.flat
+    state._check(torques, f.nv, "torques")
+    state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
+    state.ws.use_current_stream()
+    algo = _capi.ALGO_ABA if algorithm == "aba" else _capi.ALGO_CRBA_CHOLESKY
+    opts = state._opts(algo, 0 if stabilization_gains is None else 1)
+    lam = result.lambda_ if f.nc > 0 else None
+    st = _capi.lib().rbd_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
+                                  _ptr(result.vd), _ptr(result.qd), _ptr(lam), ctypes.byref(opts))
+    _raise(st, "rbd_dynamics")
+    if algo == _capi.ALGO_CRBA_CHOLESKY:
+        st = _capi.lib().rbd_dynamics_result(state.ws.handle, state.batch, _ptr(result.massmatrix), _ptr(result.dynamicsbias),
+                                             _ptr(result.constraintjacobian if f.nc else None),
+                                             _ptr(result.constraintbias if f.nc else None), ctypes.byref(opts))
+        _raise(st, "rbd_dynamics_result")
+    return None
+
+
+def inverse_dynamics_(torquesout: torch.Tensor, state: MechanismState, vd: torch.Tensor,
+                      externalwrenches: Optional[torch.Tensor] = None):
+    """`inverse_dynamics!(torquesout, jointwrenchesout, accelerations, state, v̇, externalwrenches)` (:542-553)."""
+    f = state.flat
+    state._check(torquesout, f.nv, "torquesout")
+    state._check(vd, f.nv, "v̇")
+    state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
+    state.ws.use_current_stream()
+    opts = state._opts()
+    st = _capi.lib().rbd_inverse_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(vd), _ptr(externalwrenches),
+                                          _ptr(torquesout), ctypes.byref(opts))
+    _raise(st, "rbd_inverse_dynamics")
+    return torquesout
+
+
+def dynamics_bias_(result_or_out, state: MechanismState, externalwrenches: Optional[torch.Tensor] = None):
+    """`dynamics_bias!(result, state)` / `dynamics_bias!(torques, …, state, externalwrenches)` (:484-498)."""
+    out = result_or_out.dynamicsbias if isinstance(result_or_out, DynamicsResult) else result_or_out
+    f = state.flat
+    state._check(out, f.nv, "dynamicsbias")
+    state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
+    state.ws.use_current_stream()
+    opts = state._opts()
+    st = _capi.lib().rbd_dynamics_bias(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(externalwrenches), _ptr(out),
+                                       ctypes.byref(opts))
+    _raise(st, "rbd_dynamics_bias")
+    return out
+
+
+def mass_matrix_(M_or_result, state: MechanismState):
+    """`mass_matrix!(M::Symmetric, state)` / `mass_matrix!(result, state)` (:248-274): M is (B, nv*nv), each row an
+    nv×nv column-major matrix whose LOWER triangle is written (uplo == 'L')."""
+    out = M_or_result.massmatrix if isinstance(M_or_result, DynamicsResult) else M_or_result
+    f = state.flat
+    state._check(out, f.nv * f.nv, "mass matrix has wrong size")
+    state.ws.use_current_stream()
+    opts = state._opts()
+    st = _capi.lib().rbd_mass_matrix(state.ws.handle, state.batch, _ptr(state.q), _ptr(out), ctypes.byref(opts))
+    _raise(st, "rbd_mass_matrix")
+    return out
+
+
+def mass_matrix_solve_(x: torch.Tensor, state: MechanismState, rhs: torch.Tensor, M_out: Optional[torch.Tensor] = None):
+    """x = M(q)⁻¹ rhs by batched lower Cholesky — `dynamics_solve!`'s potrf!/potrs! branch (:764, :819)."""
+    f = state.flat
+    state._check(x, f.nv, "x")
+    state._check(rhs, f.nv, "rhs")
+    state._check(M_out, f.nv * f.nv, "M_out")
+    state.ws.use_current_stream()
+    opts = state._opts()
+    st = _capi.lib().rbd_mass_matrix_solve(state.ws.handle, state.batch, _ptr(state.q), _ptr(rhs), _ptr(x), _ptr(M_out), ctypes.byref(opts))
+    _raise(st, "rbd_mass_matrix_solve")
+    return x

@@ -1,0 +1,195 @@
+"""GPU parity: the HIP path (through the C ABI of librbd_hip.so) against the CPU oracle on identical seeded inputs.
+
+Tolerances (stated per BASELINE.md §4):
+  fp64: max |x_gpu - x_oracle| <= 1e-10 * max(1, max|x_oracle|)   (the reference's own atol is 1e-10,
+        test/test_mechanism_algorithms.jl:739; GPU ABA vs the oracle's CRBA+Cholesky route differ by ~1e-13 rel.)
+  fp32: v̇ is cond(M)-limited (cond ≈ 5e5 on Atlas) so parity is stated as backward error
+        ||M v̇ - (τ - c)|| / ||τ - c|| <= 2e-5 with M, c from the fp64 oracle, plus a loose forward bound 3e-2·max|v̇|
+        (precedent atol 1e-3, test/test_mechanism_modification.jl:339);
+        τ (RNEA) and M (CRBA) have no solve: relative 2e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rand_inputs
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf"]
+TD = {"f64": torch.float64, "f32": torch.float32}
+ND = {"f64": np.float64, "f32": np.float32}
+
+
+def dev(x, state):
+    t = torch.as_tensor(np.ascontiguousarray(x), dtype=state.dtype)
+    if state.layout == "soa":
+        t = t.t().contiguous()
+    return t.cuda()
+
+
+def host(t, state):
+    t = t.detach().cpu()
+    if state.layout == "soa":
+        t = t.t()
+    return t.double().numpy()
+
+
+def make(rbd, model, B, dtype, layout, seed, fext=True):
+    q, v, tau, fe = rand_inputs(rbd, model, B, seed, fext=True)
+    state = rbd.MechanismState(model, B, dtype=TD[dtype], layout=layout)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    # inputs as seen by the device (fp32 rounding of inputs is not the kernel's error)
+    q, v, tau, fe = [a.astype(ND[dtype]).astype(np.float64) for a in (q, v, tau, fe)]
+    return state, q, v, tau, (fe if fext else None)
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", MODELS)
+def test_dynamics_f64(rbd, oracle, models, name, layout):
+    model = models[name]
+    B = 67  # ragged: not a multiple of the states-per-wave of any model
+    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 11)
+    result = rbd.DynamicsResult(model, B, layout=layout)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state))
+    torch.cuda.synchronize()
+    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    got = host(result.vd, state)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(host(result.qd, state) - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_dynamics_defaults_no_tau_no_wrenches(rbd, oracle, models, name):
+    model = models[name]
+    B = 5
+    state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 12)
+    result = rbd.DynamicsResult(model, B)
+    rbd.dynamics_(result, state)  # torques = ConstVector(0), externalwrenches = NullDict
+    ref = oracle.dynamics(model, q, v)
+    assert np.abs(host(result.vd, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", MODELS)
+def test_inverse_dynamics_and_bias_f64(rbd, oracle, models, name, layout):
+    model = models[name]
+    B = 33
+    state, q, v, vd, fe = make(rbd, model, B, "f64", layout, 13)
+    out = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state))
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+    assert np.abs(host(out, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    result = rbd.DynamicsResult(model, B, layout=layout)
+    rbd.dynamics_bias_(result, state, dev(fe, state))
+    ref = oracle.dynamics_bias(model, q, v, fe)
+    assert np.abs(host(result.dynamicsbias, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    rbd.dynamics_bias_(result, state)
+    ref = oracle.dynamics_bias(model, q, v)
+    assert np.abs(host(result.dynamicsbias, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", MODELS)
+def test_mass_matrix_f64(rbd, oracle, models, name, layout):
+    model = models[name]
+    B = 19
+    state, q, v, _, _ = make(rbd, model, B, "f64", layout, 14)
+    result = rbd.DynamicsResult(model, B, layout=layout)
+    result.massmatrix.fill_(float("nan"))  # the lower triangle must be fully written, zeros included
+    rbd.mass_matrix_(result, state)
+    nv = model.nv
+    got = host(result.massmatrix, state).reshape(B, nv, nv).transpose(0, 2, 1)  # [b, i, j]
+    ref = oracle.mass_matrix(model, q)
+    il = np.tril_indices(nv)
+    g, r = got[:, il[0], il[1]], ref[:, il[0], il[1]]
+    assert np.isfinite(g).all()
+    assert np.abs(g - r).max() <= 1e-10 * max(1.0, np.abs(r).max())
+    # structural zeros are exact zeros, like the reference (mechanism_algorithms.jl:266-267)
+    assert ((r == 0) <= (g == 0)).all()
+
+
+@pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "double_pendulum"])
+def test_dynamics_f32(rbd, oracle, models, name):
+    model = models[name]
+    B = 257
+    state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 15)
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state))
+    got = host(result.vd, state)
+    ref = oracle.dynamics(model, q, v, tau, fe)
+    back = oracle.inverse_dynamics(model, q, v, got, fe)
+    c = oracle.dynamics_bias(model, q, v, fe)
+    rel = np.linalg.norm(back - tau, axis=1) / np.linalg.norm(tau - c, axis=1)
+    assert rel.max() <= 2e-5, rel.max()
+    assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name", ["atlas_floating", "double_pendulum"])
+def test_rnea_crba_f32(rbd, oracle, models, name):
+    model = models[name]
+    B = 64
+    state, q, v, vd, fe = make(rbd, model, B, "f32", "aos", 16)
+    out = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state))
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+    assert np.abs(host(out, state) - ref).max() <= 2e-5 * np.abs(ref).max()
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32)
+    rbd.mass_matrix_(result, state)
+    nv = model.nv
+    got = host(result.massmatrix, state).reshape(B, nv, nv).transpose(0, 2, 1)
+    ref = oracle.mass_matrix(model, q)
+    il = np.tril_indices(nv)
+    assert np.abs(got[:, il[0], il[1]] - ref[:, il[0], il[1]]).max() <= 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4096])
+def test_batch_sizes_and_round_trip(rbd, oracle, models, B):
+    """Edge batch sizes; at the BASELINE size (4096) also the size-independent property of
+    test/test_mechanism_algorithms.jl:729-740: dynamics! then inverse_dynamics! returns τ (GPU-only round trip)."""
+    model = models["atlas_floating"]
+    state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 17)
+    result = rbd.DynamicsResult(model, B)
+    t, f = dev(tau, state), dev(fe, state)
+    rbd.dynamics_(result, state, t, f)
+    back = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(back, state, result.vd, f)
+    c = torch.zeros_like(state.v)
+    rbd.dynamics_bias_(c, state, f)
+    scale = float((t - c).abs().max())
+    assert float((back - t).abs().max()) <= 1e-10 * max(1.0, scale)
+    n = min(B, 64)
+    ref = oracle.dynamics(model, q[:n], v[:n], tau[:n], fe[:n])
+    assert np.abs(host(result.vd, state)[:n] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+def test_kinetic_energy_identity_full_size(rbd, models):
+    """½ v'Mv computed from the GPU mass matrix equals v·(ID(v̇=v) - ID(0))/2 … i.e. M v = ID(q, 0-velocity, v̇=v) - ID(q,0,0):
+    a CPU-free consistency check of CRBA against RNEA at B = 4096."""
+    model = models["atlas_floating"]
+    B = 4096
+    state, q, v, _, _ = make(rbd, model, B, "f64", "aos", 18)
+    result = rbd.DynamicsResult(model, B)
+    rbd.mass_matrix_(result, state)
+    M = result.massmatrix_dense()
+    vv = state.v.clone()
+    rbd.set_velocity_(state, torch.zeros_like(vv))
+    a, g = torch.zeros_like(vv), torch.zeros_like(vv)
+    rbd.inverse_dynamics_(a, state, vv)
+    rbd.dynamics_bias_(g, state)
+    Mv = torch.einsum("bij,bj->bi", M, vv)
+    assert float((Mv - (a - g)).abs().max()) <= 1e-9 * float(Mv.abs().max())
+
+
+def test_errors(rbd, models):
+    model = models["atlas_floating"]
+    state = rbd.MechanismState(model, 4)
+    result = rbd.DynamicsResult(model, 4)
+    with pytest.raises(rbd.DimensionMismatch):
+        rbd.dynamics_(result, state, torch.zeros(4, model.nv + 1, dtype=torch.float64, device="cuda"))
+    with pytest.raises(rbd.DimensionMismatch):
+        rbd.mass_matrix_(torch.zeros(4, 5, dtype=torch.float64, device="cuda"), state)
+    with pytest.raises(ValueError):
+        rbd.dynamics_(result, state, torch.zeros(4, model.nv, dtype=torch.float32, device="cuda"))
