@@ -222,17 +222,28 @@ typedef struct {
 } FN(cache_t);
 #define CACHE FN(cache_t)
 
+/* per-thread scratch, grown on demand and reused across evaluations (keeps malloc out of the timed baseline) */
+static __thread CACHE FN(tls_cache);
+static __thread int FN(tls_nb) = 0, FN(tls_nv) = 0;
 static int FN(cache_alloc)(const rbd_flat_model_t* m, CACHE* c) {
+  CACHE* t = &FN(tls_cache);
+  if (FN(tls_nb) < m->n_bodies || FN(tls_nv) < m->nv) {
+    if (FN(tls_nb) > 0) { free(t->H); free(t->S); free(t->T); free(t->A); free(t->W); free(t->I); }
+    int nb = m->n_bodies, nv = m->nv > 0 ? m->nv : 1;
+    t->H = (XF*)malloc(sizeof(XF) * (size_t)nb);
+    t->S = (REAL*)malloc(sizeof(REAL) * 6 * (size_t)nv);
+    t->T = (REAL*)malloc(sizeof(REAL) * 6 * (size_t)nb);
+    t->A = (REAL*)malloc(sizeof(REAL) * 6 * (size_t)nb);
+    t->W = (REAL*)malloc(sizeof(REAL) * 6 * (size_t)nb);
+    t->I = (INERTIA*)malloc(sizeof(INERTIA) * (size_t)nb);
+    if (!(t->H && t->S && t->T && t->A && t->W && t->I)) { FN(tls_nb) = 0; return -1; }
+    FN(tls_nb) = nb; FN(tls_nv) = nv;
+  }
+  *c = *t;
   c->nb = m->n_bodies; c->nq = m->nq; c->nv = m->nv;
-  c->H = (XF*)malloc(sizeof(XF) * (size_t)c->nb);
-  c->S = (REAL*)malloc(sizeof(REAL) * 6 * (size_t)(c->nv > 0 ? c->nv : 1));
-  c->T = (REAL*)malloc(sizeof(REAL) * 6 * (size_t)c->nb);
-  c->A = (REAL*)malloc(sizeof(REAL) * 6 * (size_t)c->nb);
-  c->W = (REAL*)malloc(sizeof(REAL) * 6 * (size_t)c->nb);
-  c->I = (INERTIA*)malloc(sizeof(INERTIA) * (size_t)c->nb);
-  return (c->H && c->S && c->T && c->A && c->W && c->I) ? 0 : -1;
+  return 0;
 }
-static void FN(cache_free)(CACHE* c) { free(c->H); free(c->S); free(c->T); free(c->A); free(c->W); free(c->I); }
+static void FN(cache_free)(CACHE* c) { (void)c; }
 
 static void FN(load_xpred)(const rbd_flat_model_t* m, int i, XF* X) {
   for (int k = 0; k < 9; ++k) X->R[k] = (REAL)m->pred_rot[9 * i + k];

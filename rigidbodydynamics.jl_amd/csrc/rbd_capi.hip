@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -53,6 +54,9 @@ struct rbd_model {
   std::vector<int32_t> ib;      // nb * IB_STRIDE
   std::vector<double> rb;       // nb * RB_STRIDE
   std::vector<int32_t> nslots;  // nlevels
+  uint64_t perm_down = 0;
+  int32_t inner_floating = 0;
+  std::vector<int32_t> slot_of, order;  // reference body index <-> DFS pre-order slot
   std::vector<int32_t> dof_body;
   std::vector<int32_t> anc;     // nb * nlevels
   std::vector<rbd_loop_joint_t> loops;
@@ -114,8 +118,8 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   m->lps = lps;
   // consistency of the q / v ranges with the joint types (qranges/vranges: src/mechanism_state.jl:47-48)
   int qsum = 0, vsum = 0;
-  std::vector<int> level(nb, 0), nchild(nb, 0);
-  m->ib.assign((size_t)nb * IB_STRIDE, -1);
+  std::vector<std::vector<int>> kids(nb);
+  std::vector<int> roots;
   for (int i = 0; i < nb; ++i) {
     const int t = d->joint_type[i];
     const int nqi = joint_nq_host(t), nvi = joint_nv_host(t);
@@ -125,28 +129,58 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     qsum += nqi; vsum += nvi;
     if (nvi > m->maxnvj) m->maxnvj = nvi;
     const int p = d->parent[i];
-    if (p >= i || p < -1) { delete m; return RBD_ERR_INVALID_ARGUMENT; }  // parents first
-    level[i] = p < 0 ? 0 : level[p] + 1;
-    int32_t* ib = &m->ib[(size_t)i * IB_STRIDE];
-    ib[IB_PARENT] = p; ib[IB_JTYPE] = t; ib[IB_QOFF] = d->q_offset[i]; ib[IB_VOFF] = d->v_offset[i]; ib[IB_LEVEL] = level[i];
-    if (p >= 0) {
-      if (nchild[p] >= IB_MAXCHILD) { delete m; return RBD_ERR_UNSUPPORTED; }
-      m->ib[(size_t)p * IB_STRIDE + IB_CHILD0 + nchild[p]] = i;
-      nchild[p]++;
-    }
-    if (level[i] + 1 > m->nlevels) m->nlevels = level[i] + 1;
+    if (p >= i || p < -1) { delete m; return RBD_ERR_INVALID_ARGUMENT; }  // parents first (src/mechanism_state.jl:44)
+    if (p >= 0) kids[p].push_back(i); else roots.push_back(i);
   }
   if (qsum != d->nq || vsum != d->nv) { delete m; return RBD_ERR_DIMENSION_MISMATCH; }
+  // DFS pre-order slots: first child of slot s is slot s+1
+  m->order.clear(); m->slot_of.assign(nb, -1);
+  {
+    std::vector<int> stack(roots.rbegin(), roots.rend());
+    while (!stack.empty()) {
+      const int i = stack.back(); stack.pop_back();
+      m->slot_of[i] = (int)m->order.size();
+      m->order.push_back(i);
+      for (auto it = kids[i].rbegin(); it != kids[i].rend(); ++it) stack.push_back(*it);
+    }
+  }
+  std::vector<int> level(nb, 0);  // by slot
+  m->ib.assign((size_t)nb * IB_STRIDE, -1);
+  for (int s = 0; s < nb; ++s) {
+    const int i = m->order[s];
+    const int p = d->parent[i];
+    const int ps = p < 0 ? -1 : m->slot_of[p];
+    level[s] = ps < 0 ? 0 : level[ps] + 1;
+    if (level[s] + 1 > m->nlevels) m->nlevels = level[s] + 1;
+    int32_t* ib = &m->ib[(size_t)s * IB_STRIDE];
+    ib[IB_PARENT] = ps; ib[IB_JTYPE] = d->joint_type[i]; ib[IB_QOFF] = d->q_offset[i]; ib[IB_VOFF] = d->v_offset[i];
+    ib[IB_LEVEL] = level[s]; ib[IB_ORIG] = i;
+    if (d->joint_type[i] == RBD_JOINT_QUAT_FLOATING && ps >= 0) m->inner_floating = 1;
+    const int nc = (int)kids[i].size();
+    if (nc > IB_MAXCHILD) { delete m; return RBD_ERR_UNSUPPORTED; }
+    ib[IB_NCHILD] = nc;
+    for (int k = 0; k < nc; ++k) ib[IB_CHILD0 + k] = m->slot_of[kids[i][k]];  // slot_of children assigned below for later slots
+    if (nc > m->maxchild) m->maxchild = nc;
+  }
+  // children slots (now that every slot is known)
+  for (int s = 0; s < nb; ++s) {
+    const int i = m->order[s];
+    for (int k = 0; k < (int)kids[i].size(); ++k) m->ib[(size_t)s * IB_STRIDE + IB_CHILD0 + k] = m->slot_of[kids[i][k]];
+  }
   if (m->nlevels > MAX_LEVELS) { delete m; return RBD_ERR_UNSUPPORTED; }
-  m->nslots.assign(m->nlevels, 0);
-  for (int i = 0; i < nb; ++i) {
-    m->ib[(size_t)i * IB_STRIDE + IB_NCHILD] = nchild[i];
-    if (nchild[i] > m->maxchild) m->maxchild = nchild[i];
-    if (nchild[i] > 0 && nchild[i] > m->nslots[level[i] + 1]) m->nslots[level[i] + 1] = nchild[i];
+  m->nslots.assign(MAX_LEVELS, 0);
+  m->perm_down = 0;
+  for (int s = 0; s < nb; ++s) {
+    const int nc = m->ib[(size_t)s * IB_STRIDE + IB_NCHILD];
+    if (nc > 0 && nc > m->nslots[level[s] + 1]) m->nslots[level[s] + 1] = nc;
+    const int ps = m->ib[(size_t)s * IB_STRIDE + IB_PARENT];
+    if (ps >= 0 && ps != s - 1) m->perm_down |= (uint64_t)1 << level[s];
+    if (ps >= 0 && m->ib[(size_t)ps * IB_STRIDE + IB_CHILD0] != ps + 1) { delete m; return RBD_ERR_INVALID_ARGUMENT; }  // pre-order invariant
   }
   m->rb.assign((size_t)nb * RB_STRIDE, 0.0);
-  for (int i = 0; i < nb; ++i) {
-    double* rb = &m->rb[(size_t)i * RB_STRIDE];
+  for (int s = 0; s < nb; ++s) {
+    const int i = m->order[s];
+    double* rb = &m->rb[(size_t)s * RB_STRIDE];
     for (int k = 0; k < 3; ++k) rb[RB_AXIS + k] = d->joint_axis[3 * i + k];
     if (d->joint_axis2) for (int k = 0; k < 3; ++k) rb[RB_AXIS2 + k] = d->joint_axis2[3 * i + k];
     for (int k = 0; k < 9; ++k) rb[RB_XPR + k] = d->pred_rot[9 * i + k];
@@ -158,11 +192,11 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   }
   m->dof_body.assign(m->nv > 0 ? m->nv : 1, 0);
   for (int i = 0; i < nb; ++i)
-    for (int k = 0; k < joint_nv_host(d->joint_type[i]); ++k) m->dof_body[d->v_offset[i] + k] = i;
+    for (int k = 0; k < joint_nv_host(d->joint_type[i]); ++k) m->dof_body[d->v_offset[i] + k] = m->slot_of[i];
   m->anc.assign((size_t)nb * m->nlevels, -1);
-  for (int i = 0; i < nb; ++i) {
-    int a = i;
-    for (int k = 0; k < m->nlevels && a >= 0; ++k) { m->anc[(size_t)i * m->nlevels + k] = a; a = d->parent[a]; }
+  for (int s = 0; s < nb; ++s) {
+    int a = s;
+    for (int k = 0; k < m->nlevels && a >= 0; ++k) { m->anc[(size_t)s * m->nlevels + k] = a; a = m->ib[(size_t)a * IB_STRIDE + IB_PARENT]; }
   }
   m->nc = 0;
   for (int l = 0; l < d->n_loops; ++l) {
@@ -218,15 +252,21 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       st = upload(&w->d_rb, rbf.data(), rbf.size() * sizeof(float));
     }
   }
-  if (st == RBD_OK) st = upload(&w->d_nslots, m->nslots.data(), m->nslots.size() * sizeof(int32_t));
   if (st == RBD_OK) st = upload(&w->d_dof_body, m->dof_body.data(), m->dof_body.size() * sizeof(int32_t));
   if (st == RBD_OK) st = upload(&w->d_anc, m->anc.data(), m->anc.size() * sizeof(int32_t));
   if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
   DevModel& dm = w->dm;
   dm.nb = m->nb; dm.nq = m->nq; dm.nv = m->nv; dm.lps = m->lps; dm.nlevels = m->nlevels; dm.maxchild = m->maxchild; dm.maxnvj = m->maxnvj;
-  dm.ib = (const int32_t*)w->d_ib; dm.rb = w->d_rb; dm.nslots = (const int32_t*)w->d_nslots;
+  dm.ib = (const int32_t*)w->d_ib; dm.rb = w->d_rb;
+  dm.perm_down = m->perm_down;
+  dm.inner_floating = m->inner_floating;
+  for (int l = 0; l < MAX_LEVELS; ++l) dm.nslots[l] = (uint8_t)m->nslots[l];
   dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc;
   memcpy(dm.gravity, m->gravity, sizeof dm.gravity);
+  {
+    const char* e = getenv("RBD_ABA_STOP_AFTER");  // profiling aid only
+    dm.debug_stop = e ? atoi(e) : 0;
+  }
   *out = w;
   return RBD_OK;
 }

@@ -15,23 +15,28 @@
 namespace rbd {
 
 // per-body integer record
-enum { IB_PARENT = 0, IB_JTYPE = 1, IB_QOFF = 2, IB_VOFF = 3, IB_LEVEL = 4, IB_NCHILD = 5, IB_CHILD0 = 6, IB_MAXCHILD = 6, IB_STRIDE = IB_CHILD0 + IB_MAXCHILD };
+enum { IB_PARENT = 0, IB_JTYPE = 1, IB_QOFF = 2, IB_VOFF = 3, IB_LEVEL = 4, IB_NCHILD = 5, IB_ORIG = 6, IB_CHILD0 = 7, IB_MAXCHILD = 6, IB_STRIDE = IB_CHILD0 + IB_MAXCHILD };
 // per-body real record: axis(3) axis2(3) XpR(9) Xpp(3) J(6: xx xy xz yy yz zz) mc(3) m(1)
 enum { RB_AXIS = 0, RB_AXIS2 = 3, RB_XPR = 6, RB_XPP = 15, RB_J = 18, RB_MC = 24, RB_M = 27, RB_STRIDE = 28 };
 enum { MAX_LEVELS = 64 };
 
+// Bodies are renumbered on the host into DFS PRE-ORDER "slots": the first child of slot s is slot s+1, so the
+// parent->first-child hop of every sweep is a DPP wave shift (v_mov_b32_dpp wave_shr:1 / wave_shl:1, VALU rate)
+// instead of an LDS-crossbar ds_bpermute; only branch points (2nd, 3rd ... child) use ds_bpermute.
 struct DevModel {
   int32_t nb, nq, nv;
   int32_t lps;        // lanes per state (power of two, <= 64)
   int32_t nlevels;    // tree depth
   int32_t maxchild;   // max children of any body (<= IB_MAXCHILD)
   int32_t maxnvj;     // max velocity dimension of any tree joint
-  const int32_t* ib;  // [nb * IB_STRIDE]
-  const void* rb;     // [nb * RB_STRIDE] of the kernel's scalar type
-  const int32_t* nslots;  // [nlevels] child slots that must be gathered when processing level l
-                          // (= max #children, over parents at level l-1, located at level l)
-  const int32_t* dof_body;  // [nv] body of velocity index
-  const int32_t* anc;       // [nb * nlevels] anc[b*nlevels + k] = k-th ancestor body of b (k=0: b itself), -1 past the root
+  int32_t inner_floating;  // some 6-dof joint is not attached to the world (selects the general aba_kernel instantiation)
+  int32_t debug_stop; // profiling aid (env RBD_ABA_STOP_AFTER): aba_kernel exits after phase 1..5 with a checksum store; 0 = full
+  const int32_t* ib;  // [nb * IB_STRIDE], indexed by slot; parent/children are slots, IB_ORIG the reference body index
+  const void* rb;     // [nb * RB_STRIDE] of the kernel's scalar type, indexed by slot
+  const int32_t* dof_body;  // [nv] slot of velocity index
+  const int32_t* anc;       // [nb * nlevels] anc[s*nlevels + k] = k-th ancestor slot of s (k=0: s itself), -1 past the root
+  uint64_t perm_down;       // bit l set: some body at level l has parent slot != s-1 (top-down hop needs ds_bpermute at level l)
+  uint8_t nslots[MAX_LEVELS];  // child slots to gather when the bottom-up sweep processes level l (max #children of level l-1 parents)
   double gravity[3];
 };
 
@@ -43,6 +48,18 @@ struct Layout {
 #define RBD_DEV __device__ __forceinline__
 
 template <typename T> RBD_DEV T shfl(T x, int src) { return __shfl(x, src, 64); }
+
+// DPP wave shifts (gfx9 DPP_WF_SR1 = 0x138: lane i <- lane i-1; DPP_WF_SL1 = 0x130: lane i <- lane i+1; lanes shifted in read 0)
+template <int CTRL> RBD_DEV float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> RBD_DEV double dpp_mov(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <typename T> RBD_DEV T from_prev_lane(T x) { return dpp_mov<0x138>(x); }
+template <typename T> RBD_DEV T from_next_lane(T x) { return dpp_mov<0x130>(x); }
 
 template <typename T> RBD_DEV void cross3(const T* a, const T* b, T* o) {
   T x = a[1] * b[2] - a[2] * b[1];

@@ -13,7 +13,7 @@ namespace rbd {
 
 template <typename T> struct Body {
   // topology
-  int parent, jtype, qoff, voff, level, nchild;
+  int parent, jtype, qoff, voff, level, nchild, orig;
   int child[IB_MAXCHILD];
   int plane;  // lane of the parent body (own lane if parent is the world)
   // lane bookkeeping
@@ -27,6 +27,46 @@ template <typename T> RBD_DEV int joint_nq(int t) {
 }
 RBD_DEV int joint_nv(int t) {
   return t == RBD_JOINT_QUAT_FLOATING ? 6 : (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC || t == RBD_JOINT_SINCOS_REVOLUTE) ? 1 : 0;
+}
+
+
+template <typename T> RBD_DEV int child_sel(const Body<T>& b, int s) {
+  return (s == 0) ? b.child[0] : (s == 1) ? b.child[1] : (s == 2) ? b.child[2] : (s == 3) ? b.child[3] : (s == 4) ? b.child[4] : b.child[5];
+}
+// Parents at level l-1 pull N values from their s-th child (all children of a parent sit at level l) and add them.
+// Slot 0 (first child == next lane in DFS pre-order) is a DPP wave shift; further children use ds_bpermute.
+// All moves are issued before any is consumed; non-takers add x*0 (x is always finite).
+template <typename T, int N> RBD_DEV void gather_add(const Body<T>& b, int l, int s, const T* give, T* acc) {
+  const bool take = (b.level == l - 1) && (s < b.nchild);
+  const T mask = take ? T(1) : T(0);
+  constexpr int CH = 9;  // moves in flight per batch (bounds the temporaries)
+  if (s == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] += from_next_lane(give[k]) * mask;
+  } else {
+    const int c = child_sel(b, s);
+    const int src = take ? b.base + c : b.lane;
+#pragma unroll
+    for (int k0 = 0; k0 < N; k0 += CH) {
+      T tmp[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+        if (k0 + k < N) tmp[k] = shfl(give[k0 + k], src);
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+        if (k0 + k < N) acc[k0 + k] += tmp[k] * mask;
+    }
+  }
+}
+// Top-down hop: every lane reads N values of its parent's lane (DPP shift when all level-l parents are the previous lane).
+template <typename T, int N> RBD_DEV void pull_parent(const DevModel& M, const Body<T>& b, int l, const T* x, T* out) {
+  if ((M.perm_down >> l) & 1) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = shfl(x[k], b.plane);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = from_prev_lane(x[k]);
+  }
 }
 
 template <typename T> RBD_DEV void load_body(const DevModel& M, long B, Body<T>& b) {
@@ -46,6 +86,7 @@ template <typename T> RBD_DEV void load_body(const DevModel& M, long B, Body<T>&
   b.voff = ib[IB_VOFF];
   b.level = b.valid ? ib[IB_LEVEL] : -1;  // idle lanes never commit
   b.nchild = ib[IB_NCHILD];
+  b.orig = ib[IB_ORIG];
 #pragma unroll
   for (int k = 0; k < IB_MAXCHILD; ++k) b.child[k] = ib[IB_CHILD0 + k];
   b.plane = b.parent >= 0 ? b.base + b.parent : b.lane;
@@ -110,7 +151,7 @@ template <typename T> RBD_DEV void load_joint_v(const Body<T>& b, const T* __res
 }
 template <typename T> RBD_DEV void load_body_wrench(const Body<T>& b, const T* __restrict__ f, Layout L, T* w) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k) w[k] = (f != nullptr && b.valid) ? f[(long)(6 * b.sub + k) * L.sk + b.state * L.sb] : T(0);
+  for (int k = 0; k < 6; ++k) w[k] = (f != nullptr && b.valid) ? f[(long)(6 * b.orig + k) * L.sk + b.state * L.sb] : T(0);
 }
 template <typename T> RBD_DEV void store_joint_v(const Body<T>& b, T* __restrict__ out, Layout L, const T* x) {
   const int n = joint_nv(b.jtype);
@@ -151,43 +192,33 @@ template <typename T> RBD_DEV void store_qdot(const Body<T>& b, T* __restrict__ 
 // root frame (T_b - T_parent).  Optionally also carries spatial accelerations (spatial_accelerations!
 // src/mechanism_algorithms.jl:387-417): acc_local = S_local*v̇ in, acc = a_b out, with a_root = -gravity.
 template <typename T, bool WITH_ACC>
-RBD_DEV void sweep_kinematics(const DevModel& M, const Body<T>& b, T* R, T* p, const T* tj_local, T* Tw, T* vJ,
-                              const T* aj_local, T* acc) {
+RBD_DEV void sweep_kinematics(const DevModel& M, const Body<T>& b, const T* XR, const T* Xp, T* R, T* p, const T* tj_local, T* Tw,
+                              T* vJ, const T* aj_local, T* acc) {
+  // level 0 (the root transform is the identity): H = XL, T = vJ, a = -g + X a_joint.  Written for every lane; deeper
+  // lanes overwrite at their level.  Inside the level loop the new values never read the registers they replace, so
+  // the exec-masked block writes them in place (no copies).
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { Tw[k] = T(0); vJ[k] = T(0); }
+  for (int k = 0; k < 9; ++k) R[k] = XR[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) p[k] = Xp[k];
+  xmotion(R, p, tj_local, vJ);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Tw[k] = vJ[k];
   if (WITH_ACC) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc[k] = T(0);
+    xmotion(R, p, aj_local, acc);
+    acc[3] -= T(M.gravity[0]); acc[4] -= T(M.gravity[1]); acc[5] -= T(M.gravity[2]);
   }
-  for (int l = 0; l < M.nlevels; ++l) {
+  for (int l = 1; l < M.nlevels; ++l) {
     T pR[9], pp[3], pT[6], pa[6];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) pR[k] = shfl(R[k], b.plane);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) pp[k] = shfl(p[k], b.plane);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) pT[k] = shfl(Tw[k], b.plane);
-    if (WITH_ACC) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pa[k] = shfl(acc[k], b.plane);
-    }
+    pull_parent<T, 9>(M, b, l, R, pR);
+    pull_parent<T, 3>(M, b, l, p, pp);
+    pull_parent<T, 6>(M, b, l, Tw, pT);
+    if (WITH_ACC) pull_parent<T, 6>(M, b, l, acc, pa);
     if (b.level == l) {
-      if (b.parent >= 0) {
-        T nR[9], np[3];
-        matmul3(pR, R, nR);
-        matvec3(pR, p, np);
+      matmul3(pR, XR, R);
+      matvec3(pR, Xp, p);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = nR[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = np[k] + pp[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) pT[k] = T(0);
-        if (WITH_ACC) {
-          pa[0] = pa[1] = pa[2] = T(0);
-          pa[3] = T(-M.gravity[0]); pa[4] = T(-M.gravity[1]); pa[5] = T(-M.gravity[2]);
-        }
-      }
+      for (int k = 0; k < 3; ++k) p[k] += pp[k];
       xmotion(R, p, tj_local, vJ);
 #pragma unroll
       for (int k = 0; k < 6; ++k) Tw[k] = pT[k] + vJ[k];
@@ -206,10 +237,18 @@ RBD_DEV void sweep_kinematics(const DevModel& M, const Body<T>& b, T* R, T* p, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// (RBD_DEBUG_STOP: phase-ablation aid for profiling; never taken in production, debug_stop == 0)
 // Fused forward dynamics (ABA).  One launch: FK + twists, articulated inertias bottom-up, accelerations top-down.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
+#define RBD_DEBUG_STOP(phase, expr)                                  \
+  if (M.debug_stop == (phase)) {                                     \
+    T chk_[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};                \
+    chk_[0] = (expr);                                                \
+    store_joint_v(b, vdot, Lv, chk_);                                \
+    return;                                                          \
+  }
+template <typename T, bool INNER_FLOAT>
+__global__ __launch_bounds__(256, 2) void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
                                                   const T* __restrict__ tau, const T* __restrict__ fext,
                                                   T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
   Body<T> b;
@@ -221,11 +260,14 @@ __global__ __launch_bounds__(256) void aba_kernel(DevModel M, long B, const T* _
   load_joint_v(b, v, Lv, vj);
   load_joint_v(b, tau, Lv, tj);
   store_qdot(b, qdot, Lq, qj, vj);
+  RBD_DEBUG_STOP(1, qj[0] + vj[0] + tj[0]);
 
-  T R[9], p[3], tl[6], Tw[6], vJ[6];
-  local_transform(b, rb, qj, R, p);
+  T XR[9], Xp[3], R[9], p[3], tl[6], Tw[6], vJ[6];
+  local_transform(b, rb, qj, XR, Xp);
   local_joint_motion(b, rb, vj, tl);
-  sweep_kinematics<T, false>(M, b, R, p, tl, Tw, vJ, nullptr, nullptr);
+  RBD_DEBUG_STOP(2, XR[0] + XR[4] + XR[8] + Xp[0] + tl[0]);
+  sweep_kinematics<T, false>(M, b, XR, Xp, R, p, tl, Tw, vJ, nullptr, nullptr);
+  RBD_DEBUG_STOP(3, R[0] + R[4] + R[8] + p[0] + Tw[0] + Tw[5] + vJ[2]);
 
   // per-body, all lanes in parallel: motion subspace, bias term, inertia, bias force
   const bool one_dof = (b.jtype == RBD_JOINT_REVOLUTE || b.jtype == RBD_JOINT_PRISMATIC || b.jtype == RBD_JOINT_SINCOS_REVOLUTE);
@@ -262,61 +304,93 @@ __global__ __launch_bounds__(256) void aba_kernel(DevModel M, long B, const T* _
     for (int k = 0; k < 6; ++k) pA[k] = T(0);
   }
 
-  // bottom-up: articulated-body inertias and bias forces
+  RBD_DEBUG_STOP(4, IA[0] + IA[20] + IA[7] + pA[0] + pA[5] + cb[1] + S[2]);
+
+  // bottom-up: articulated-body inertias and bias forces.  Lanes at level l finish (U, D, u); every lane then forms
+  // its hand-off (Ia, pa) = (IA - U D^-1 U', pA + Ia cb + U D^-1 u) — only the hand-offs of level-l lanes are pulled.
+  // (6-dof joints keep pa = S^-T tau — the wrench transform of tau to the root frame — in U, which they do not
+  //  otherwise need, and park their transform in LDS until the top-down sweep: cold data out of the VGPR budget.)
   T U[6], Dinv = T(0), u = T(0);
 #pragma unroll
   for (int k = 0; k < 6; ++k) U[k] = T(0);
-  T Ia[21], pa[6];  // what this body hands to its parent
+  __shared__ T stash[12][256];
+  if (floating) {
+    xforce(R, p, tj, U);
 #pragma unroll
-  for (int k = 0; k < 21; ++k) Ia[k] = T(0);
+    for (int k = 0; k < 9; ++k) stash[k][threadIdx.x] = R[k];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) pa[k] = T(0);
-  for (int l = M.nlevels - 1; l >= 0; --l) {
-    if (b.level == l) {
-      if (one_dof) {
-        sym6_mul(IA, S, U);
-        const T D = dot6(S, U);
-        Dinv = T(1) / D;
-        u = tj[0] - dot6(S, pA);
+    for (int k = 0; k < 3; ++k) stash[9 + k][threadIdx.x] = p[k];
+  }
+  const T tau0 = tj[0];
+  const bool inner_floating = floating && (b.parent >= 0);
+#pragma unroll 1
+  for (int l = M.nlevels - 1; l >= 1; --l) {
+    if (b.level == l && one_dof) {
+      sym6_mul(IA, S, U);
+      Dinv = T(1) / dot6(S, U);
+      u = tau0 - dot6(S, pA);
+    }
+    // Hand-off entries are formed one at a time and consumed at once (no 27-wide temporary): the first child is the
+    // next lane (DPP shift); further children (branch points only) re-form the entries and pull them with ds_bpermute.
+    // Givers sit at level l (mask 0: their own IA/pA are untouched), takers at level l-1.
+    const T kI = (INNER_FLOAT && inner_floating) ? T(0) : T(1);
+    const T m0 = ((b.level == l - 1) && (b.nchild >= 1)) ? T(1) : T(0);
+    T Iac[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 6; ++i) {
+      const T ud = U[i] * Dinv;
 #pragma unroll
-          for (int j = i; j < 6; ++j) Ia[SI(i, j)] = IA[SI(i, j)] - U[i] * (U[j] * Dinv);
-        T Iac[6];
-        sym6_mul(Ia, cb, Iac);
-        const T ud = u * Dinv;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) pa[k] = pA[k] + Iac[k] + U[k] * ud;
-      } else if (floating) {
-        // 6-dof joint: Ia = 0, pa = S^-T tau = wrench transform of tau to the root frame
-        xforce(R, p, tj, pa);
-      } else {  // fixed joint in the tree: pass through (vJ = 0 => cb = 0)
-#pragma unroll
-        for (int k = 0; k < 21; ++k) Ia[k] = IA[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) pa[k] = pA[k];
+      for (int j = i; j < 6; ++j) {
+        T g = IA[SI(i, j)] - ud * U[j];
+        if (INNER_FLOAT) g *= kI;
+        Iac[i] += g * cb[j];
+        if (j > i) Iac[j] += g * cb[i];
+        IA[SI(i, j)] += from_next_lane(g) * m0;
       }
     }
-    // parents (level l-1) gather from their children (all at level l)
-    if (l > 0) {
-      const int ns = M.nslots[l];
-      for (int s = 0; s < ns; ++s) {
-        const int c = (s == 0) ? b.child[0] : (s == 1) ? b.child[1] : (s == 2) ? b.child[2] : (s == 3) ? b.child[3] : (s == 4) ? b.child[4] : b.child[5];
-        const bool take = (b.level == l - 1) && (s < b.nchild);
-        const int src = take ? b.base + c : b.lane;
+    T gp[6];
+    {
+      const T udp = u * Dinv;
 #pragma unroll
-        for (int k = 0; k < 21; ++k) {
-          const T x = shfl(Ia[k], src);
-          if (take) IA[k] += x;
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const T x = shfl(pa[k], src);
-          if (take) pA[k] += x;
-        }
+      for (int k = 0; k < 6; ++k) {
+        gp[k] = pA[k] + Iac[k] + U[k] * udp;
+        if (INNER_FLOAT) gp[k] = inner_floating ? U[k] : gp[k];
+        pA[k] += from_next_lane(gp[k]) * m0;
       }
+    }
+    const int ns = (int)M.nslots[l];
+#pragma unroll 1
+    for (int s = 1; s < ns; ++s) {
+      const bool take = (b.level == l - 1) && (s < b.nchild);
+      const int src = take ? b.base + child_sel(b, s) : b.lane;
+      const T mask = take ? T(1) : T(0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const T ud = U[i] * Dinv;
+        T tmp[6];
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+          T g = IA[SI(i, j)] - ud * U[j];
+          if (INNER_FLOAT) g *= kI;
+          tmp[j] = shfl(g, src);
+        }
+#pragma unroll
+        for (int j = i; j < 6; ++j) IA[SI(i, j)] += tmp[j] * mask;
+      }
+      T tp[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tp[k] = shfl(gp[k], src);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pA[k] += tp[k] * mask;
     }
   }
+  if (b.level == 0 && one_dof) {
+    sym6_mul(IA, S, U);
+    Dinv = T(1) / dot6(S, U);
+    u = tau0 - dot6(S, pA);
+  }
+
+  RBD_DEBUG_STOP(5, IA[0] + IA[20] + pA[0] + U[0] + u + Dinv);
 
   // top-down: accelerations and v̇
   T acc[6], vd[6];
@@ -324,8 +398,7 @@ __global__ __launch_bounds__(256) void aba_kernel(DevModel M, long B, const T* _
   for (int k = 0; k < 6; ++k) { acc[k] = T(0); vd[k] = T(0); }
   for (int l = 0; l < M.nlevels; ++l) {
     T ap[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) ap[k] = shfl(acc[k], b.plane);
+    pull_parent<T, 6>(M, b, l, acc, ap);
     if (b.level == l) {
       if (b.parent < 0) {
         ap[0] = ap[1] = ap[2] = T(0);
@@ -339,13 +412,17 @@ __global__ __launch_bounds__(256) void aba_kernel(DevModel M, long B, const T* _
         for (int k = 0; k < 6; ++k) acc[k] = ap[k] + S[k] * vd[0];
       } else if (floating) {
         // IA a_b = S^-T tau - pA ;  v̇ = S^-1 (a_b - a')
-        T rhs[6], d[6];
+        T rhs[6], d[6], Rs[9], ps[3];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) rhs[k] = pa[k] - pA[k];
+        for (int k = 0; k < 6; ++k) rhs[k] = U[k] - pA[k];
         sym6_solve(IA, rhs, acc);
 #pragma unroll
         for (int k = 0; k < 6; ++k) d[k] = acc[k] - ap[k];
-        xmotion_inv(R, p, d, vd);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rs[k] = stash[k][threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ps[k] = stash[9 + k][threadIdx.x];
+        xmotion_inv(Rs, ps, d, vd);
       } else {
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc[k] = ap[k];
@@ -369,11 +446,11 @@ __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* 
   load_joint_q(b, q, Lq, qj);
   load_joint_v(b, v, Lv, vj);
   load_joint_v(b, vdot, Lv, aj);
-  T R[9], p[3], tl[6], al[6], Tw[6], vJ[6], acc[6];
-  local_transform(b, rb, qj, R, p);
+  T XR[9], Xp[3], R[9], p[3], tl[6], al[6], Tw[6], vJ[6], acc[6];
+  local_transform(b, rb, qj, XR, Xp);
   local_joint_motion(b, rb, vj, tl);
   local_joint_motion(b, rb, aj, al);  // joint_spatial_acceleration: S_local * v̇ (revolute.jl:76-81)
-  sweep_kinematics<T, true>(M, b, R, p, tl, Tw, vJ, al, acc);
+  sweep_kinematics<T, true>(M, b, XR, Xp, R, p, tl, Tw, vJ, al, acc);
 
   // newton_euler! (mechanism_algorithms.jl:428-439): w = I a + T x* I T - wext
   T w[6];
@@ -394,16 +471,13 @@ __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* 
   }
   // joint_wrenches_and_torques! (:442-459): w_parent += w_child, bottom-up
   for (int l = M.nlevels - 1; l >= 1; --l) {
-    const int ns = M.nslots[l];
+    const int ns = (int)M.nslots[l];
+#pragma unroll 1
     for (int s = 0; s < ns; ++s) {
-      const int c = (s == 0) ? b.child[0] : (s == 1) ? b.child[1] : (s == 2) ? b.child[2] : (s == 3) ? b.child[3] : (s == 4) ? b.child[4] : b.child[5];
-      const bool take = (b.level == l - 1) && (s < b.nchild);
-      const int src = take ? b.base + c : b.lane;
+      T give[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const T x = shfl(w[k], src);
-        if (take) w[k] += x;
-      }
+      for (int k = 0; k < 6; ++k) give[k] = w[k];
+      gather_add<T, 6>(b, l, s, give, w);
     }
   }
   // tau = S' w
@@ -436,9 +510,9 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
   const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
   T qj[7];
   load_joint_q(b, q, Lq, qj);
-  T R[9], p[3], zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, Tw[6], vJ[6];
-  local_transform(b, rb, qj, R, p);
-  sweep_kinematics<T, false>(M, b, R, p, zero6, Tw, vJ, nullptr, nullptr);
+  T XR[9], Xp[3], R[9], p[3], zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, Tw[6], vJ[6];
+  local_transform(b, rb, qj, XR, Xp);
+  sweep_kinematics<T, false>(M, b, XR, Xp, R, p, zero6, Tw, vJ, nullptr, nullptr);
   RInertia<T> Ic;
   {
     T Jb[6], mc[3];
@@ -457,16 +531,21 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
   }
   // composite-rigid-body inertias, bottom-up (10 scalars per child)
   for (int l = M.nlevels - 1; l >= 1; --l) {
-    const int ns = M.nslots[l];
+    const int ns = (int)M.nslots[l];
+#pragma unroll 1
     for (int s = 0; s < ns; ++s) {
-      const int c = (s == 0) ? b.child[0] : (s == 1) ? b.child[1] : (s == 2) ? b.child[2] : (s == 3) ? b.child[3] : (s == 4) ? b.child[4] : b.child[5];
-      const bool take = (b.level == l - 1) && (s < b.nchild);
-      const int src = take ? b.base + c : b.lane;
+      T give[10], acc[10];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { const T x = shfl(Ic.J[k], src); if (take) Ic.J[k] += x; }
+      for (int k = 0; k < 6; ++k) give[k] = acc[k] = Ic.J[k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { const T x = shfl(Ic.c[k], src); if (take) Ic.c[k] += x; }
-      { const T x = shfl(Ic.m, src); if (take) Ic.m += x; }
+      for (int k = 0; k < 3; ++k) give[6 + k] = acc[6 + k] = Ic.c[k];
+      give[9] = acc[9] = Ic.m;
+      gather_add<T, 10>(b, l, s, give, acc);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Ic.J[k] = acc[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ic.c[k] = acc[6 + k];
+      Ic.m = acc[9];
     }
   }
   const int nvi = joint_nv(b.jtype);
@@ -548,8 +627,12 @@ static inline dim3 grid_for(const DevModel& M, long B, int block) {
 template <typename T>
 hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
                       void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
-  hipLaunchKernelGGL(aba_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
-                     (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
+  if (M.inner_floating)
+    hipLaunchKernelGGL((aba_kernel<T, true>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
+                       (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
+  else
+    hipLaunchKernelGGL((aba_kernel<T, false>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
+                       (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
   return hipGetLastError();
 }
 template <typename T>
