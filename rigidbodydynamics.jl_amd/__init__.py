@@ -14,4 +14,4 @@ from .builders import (FOUR_BAR_INITIAL_Q, FOUR_BAR_INITIAL_V, double_pendulum, 
 from .flatio import load_flat_model, save_flat_model
 from . import _capi
 from .state import (DimensionMismatch, DynamicsResult, MechanismState, dynamics_, dynamics_bias_, inverse_dynamics_, mass_matrix_,
-                    mass_matrix_solve_, rand_, set_configuration_, set_velocity_, zero_configuration_)
+                    mass_matrix_solve_, rand_, set_configuration_, set_velocity_, sync, zero_configuration_)

@@ -72,8 +72,10 @@ struct rbd_ws {
   void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // internal device scratch (mass matrix / bias for the CRBA route), lazy
-  void* d_M = nullptr; void* d_c = nullptr;
-  size_t d_M_bytes = 0, d_c_bytes = 0;
+  void* d_M = nullptr; void* d_c = nullptr; void* d_K = nullptr; void* d_k = nullptr;
+  size_t d_M_bytes = 0, d_c_bytes = 0, d_K_bytes = 0, d_k_bytes = 0;
+  int* d_notpd = nullptr;  // device flag: some state's mass matrix was not positive definite (checked by rbd_sync)
+  int32_t result_layout = RBD_LAYOUT_SOA; int32_t result_B = 0;
   // timing
   int32_t timing = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -254,6 +256,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   }
   if (st == RBD_OK) st = upload(&w->d_dof_body, m->dof_body.data(), m->dof_body.size() * sizeof(int32_t));
   if (st == RBD_OK) st = upload(&w->d_anc, m->anc.data(), m->anc.size() * sizeof(int32_t));
+  if (st == RBD_OK) { int zero = 0; st = upload((void**)&w->d_notpd, &zero, sizeof(int)); }
   if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
   DevModel& dm = w->dm;
   dm.nb = m->nb; dm.nq = m->nq; dm.nv = m->nv; dm.lps = m->lps; dm.nlevels = m->nlevels; dm.maxchild = m->maxchild; dm.maxnvj = m->maxnvj;
@@ -274,7 +277,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_M, w->d_c};
+  void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
@@ -293,6 +296,12 @@ int rbd_sync(rbd_ws_t* w) {
   if (!w) return RBD_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(w->device));
   HIP_TRY(hipStreamSynchronize(w->stream));
+  int flag = 0;
+  HIP_TRY(hipMemcpy(&flag, w->d_notpd, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) {
+    HIP_TRY(hipMemset(w->d_notpd, 0, sizeof(int)));
+    return RBD_ERR_NOT_POSITIVE_DEFINITE;  // LAPACK.potrf! would have thrown PosDefException
+  }
   return RBD_OK;
 }
 
@@ -398,7 +407,7 @@ int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const voi
   if (st != RBD_OK) return st;
   if (!q || !v || !vdot) return RBD_ERR_INVALID_ARGUMENT;
   const rbd_model* m = w->model;
-  if (m->nloops > 0 || o.algorithm == RBD_ALGO_CRBA_CHOLESKY) return RBD_ERR_UNSUPPORTED;  // loop/Cholesky route: next
+  if (m->nloops > 0) return RBD_ERR_UNSUPPORTED;  // loop-joint branch of dynamics_solve!: next
   (void)lambda;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
@@ -412,7 +421,24 @@ int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const voi
       return st;
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
-  {
+  if (o.algorithm == RBD_ALGO_CRBA_CHOLESKY) {
+    // the reference's own route (src/mechanism_algorithms.jl:856-862): c = dynamics_bias!, M = mass_matrix!, then
+    // potrf!/potrs!.  M and c stay in the workspace (layout of this call) for rbd_dynamics_result.
+    const Layout Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
+    if ((st = ensure(&w->d_M, &w->d_M_bytes, es * (size_t)m->nv * m->nv * B)) || (st = ensure(&w->d_c, &w->d_c_bytes, es * (size_t)m->nv * B)))
+      return st;
+    w->result_layout = o.layout; w->result_B = B;
+    Timed t(w);
+    if (w->dtype == RBD_F64) {
+      HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, Lq, Lv, Lf, w->stream));
+      HIP_TRY(launch_crba<double>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
+      HIP_TRY(launch_chol_solve<double>(m->nv, B, w->d_M, dtau, w->d_c, dvd, nullptr, Lm, Lv, w->d_notpd, w->stream));
+    } else {
+      HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, Lq, Lv, Lf, w->stream));
+      HIP_TRY(launch_crba<float>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
+      HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_M, dtau, w->d_c, dvd, nullptr, Lm, Lv, w->d_notpd, w->stream));
+    }
+  } else {
     Timed t(w);
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba<double>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba<float>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
@@ -444,8 +470,8 @@ static int rnea_common(rbd_ws_t* w, int32_t B, const void* q, const void* v, con
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
   {
     Timed t(w);
-    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dt, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dt, Lq, Lv, Lf, w->stream));
+    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf, w->stream));
   }
   if (o.memory == RBD_MEM_HOST) return stage_out_copy(w, tau_out, dt, es * m->nv * B);
   return RBD_OK;
@@ -488,13 +514,57 @@ int rbd_mass_matrix(rbd_ws_t* w, int32_t B, const void* q, void* M_out, const rb
 }
 
 int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs, void* x, void* M_out, const rbd_opts_t* opts) {
-  (void)w; (void)B; (void)q; (void)rhs; (void)x; (void)M_out; (void)opts;
-  return RBD_ERR_UNSUPPORTED;
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!q || !rhs || !x) return RBD_ERR_INVALID_ARGUMENT;
+  const rbd_model* m = w->model;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t es = esize(w);
+  const size_t mbytes = es * (size_t)m->nv * m->nv * B;
+  const void *dq = q, *dr = rhs;
+  void *dx = x, *dM = M_out;
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_in(w, 2, rhs, es * m->nv * B, &dr)) ||
+        (st = stage_out_alloc(w, 4, x, es * m->nv * B, &dx)) || (st = stage_out_alloc(w, 6, M_out, mbytes, &dM)))
+      return st;
+  }
+  if (!dM) {
+    if ((st = ensure(&w->d_M, &w->d_M_bytes, mbytes))) return st;
+    dM = w->d_M;
+  }
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
+  {
+    Timed t(w);
+    if (w->dtype == RBD_F64) {
+      HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
+      HIP_TRY(launch_chol_solve<double>(m->nv, B, dM, dr, nullptr, dx, nullptr, Lm, Lv, w->d_notpd, w->stream));
+    } else {
+      HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
+      HIP_TRY(launch_chol_solve<float>(m->nv, B, dM, dr, nullptr, dx, nullptr, Lm, Lv, w->d_notpd, w->stream));
+    }
+  }
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_out_copy(w, x, dx, es * m->nv * B)) || (st = stage_out_copy(w, M_out, dM, mbytes))) return st;
+  }
+  return RBD_OK;
 }
 
 int rbd_dynamics_result(rbd_ws_t* w, int32_t B, void* M, void* c, void* K, void* k, const rbd_opts_t* opts) {
-  (void)w; (void)B; (void)M; (void)c; (void)K; (void)k; (void)opts;
-  return RBD_ERR_UNSUPPORTED;
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  const rbd_model* m = w->model;
+  if (B != w->result_B || o.layout != w->result_layout) return RBD_ERR_DIMENSION_MISMATCH;  // must match the producing rbd_dynamics call
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t es = esize(w);
+  const hipMemcpyKind kind = (o.memory == RBD_MEM_HOST) ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (M) { if (!w->d_M) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(M, w->d_M, es * (size_t)m->nv * m->nv * B, kind, w->stream)); }
+  if (c) { if (!w->d_c) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(c, w->d_c, es * (size_t)m->nv * B, kind, w->stream)); }
+  if (K && m->nc > 0) { if (!w->d_K) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(K, w->d_K, es * (size_t)m->nc * m->nv * B, kind, w->stream)); }
+  if (k && m->nc > 0) { if (!w->d_k) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(k, w->d_k, es * (size_t)m->nc * B, kind, w->stream)); }
+  return RBD_OK;
 }
 
 }  // extern "C"

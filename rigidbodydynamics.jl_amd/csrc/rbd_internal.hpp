@@ -9,7 +9,12 @@ hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, c
                       void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 template <typename T>
 hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
-                       Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+                       void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 template <typename T>
 hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill, hipStream_t s);
 }  // namespace rbd
+namespace rbd {
+template <typename T>
+hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv,
+                             int* notpd, hipStream_t s);
+}

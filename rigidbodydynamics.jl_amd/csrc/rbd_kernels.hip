@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void aba_kernel(DevModel M, long B, const T
 template <typename T>
 __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
                                                    const T* __restrict__ vdot, const T* __restrict__ fext,
-                                                   T* __restrict__ tau, Layout Lq, Layout Lv, Layout Lf) {
+                                                   T* __restrict__ tau, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
   Body<T> b;
   load_body(M, B, b);
   const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* 
   load_joint_q(b, q, Lq, qj);
   load_joint_v(b, v, Lv, vj);
   load_joint_v(b, vdot, Lv, aj);
+  store_qdot(b, qdot, Lq, qj, vj);
   T XR[9], Xp[3], R[9], p[3], tl[6], al[6], Tw[6], vJ[6], acc[6];
   local_transform(b, rb, qj, XR, Xp);
   local_joint_motion(b, rb, vj, tl);
@@ -637,9 +638,9 @@ hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, c
 }
 template <typename T>
 hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
-                       Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+                       void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
   hipLaunchKernelGGL(rnea_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)vdot,
-                     (const T*)fext, (T*)tau, Lq, Lv, Lf);
+                     (const T*)fext, (T*)tau, (T*)qdot, Lq, Lv, Lf);
   return hipGetLastError();
 }
 template <typename T>
@@ -650,9 +651,101 @@ hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Lay
 
 template hipError_t launch_aba<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_aba<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
-template hipError_t launch_rnea<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, Layout, Layout, Layout, hipStream_t);
-template hipError_t launch_rnea<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_crba<double>(const DevModel&, long, const void*, void*, Layout, Layout, int, hipStream_t);
 template hipError_t launch_crba<float>(const DevModel&, long, const void*, void*, Layout, Layout, int, hipStream_t);
+
+}  // namespace rbd
+
+// ---------------------------------------------------------------------------------------------
+// Batched dense Cholesky + solve: dynamics_solve!'s potrf!('L') / potrs! branch
+// (src/mechanism_algorithms.jl:762-766, :819).  One wavefront per state, one lane per matrix row, the
+// factor lives in LDS (row stride 4*odd words: conflict-free ds_read_b128 of own rows, broadcast reads of the
+// pivot row).  rhs_i = (tau_i or 0) - (c_i or 0).  Reads only the LOWER triangle of M (uplo == 'L').
+// Left-looking: column j of L is finished from rows j.. using the already finished columns 0..j-1.
+// ---------------------------------------------------------------------------------------------
+namespace rbd {
+
+template <typename T> struct SqrtT;
+template <> struct SqrtT<double> { static __device__ __forceinline__ double f(double x) { return sqrt(x); } };
+template <> struct SqrtT<float> { static __device__ __forceinline__ float f(float x) { return sqrtf(x); } };
+
+template <typename T>
+__global__ __launch_bounds__(256) void chol_solve_kernel(int nv, int stride, long B, const T* __restrict__ Mg, const T* __restrict__ tau,
+                                                         const T* __restrict__ c, T* __restrict__ x, T* __restrict__ Lout,
+                                                         Layout Lm, Layout Lv, int* __restrict__ notpd) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long state = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (state >= B) return;  // whole wave exits together (one state per wave)
+  T* A = smem + (size_t)wave * ((size_t)nv * stride + 64);  // [nv][stride] factor, then 64 words of broadcast scratch
+  T* bc = A + (size_t)nv * stride;
+  const int i = lane;
+  const bool row = i < nv;
+  // load the lower triangle: for fixed column j the lanes read consecutive rows (coalesced for AOS)
+  for (int j = 0; j < nv; ++j)
+    if (row && i >= j) A[i * stride + j] = Mg[((long)j * nv + i) * Lm.sk + state * Lm.sb];
+  T b = T(0);
+  if (row) {
+    if (tau) b = tau[(long)i * Lv.sk + state * Lv.sb];
+    if (c) b -= c[(long)i * Lv.sk + state * Lv.sb];
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  bool bad = false;
+  for (int j = 0; j < nv; ++j) {
+    // s = A[i][j] - sum_{k<j} L[i][k] L[j][k]
+    T s = T(0);
+    if (row && i >= j) {
+      s = A[i * stride + j];
+      const T* ri = A + i * stride;
+      const T* rj = A + j * stride;
+      for (int k = 0; k < j; ++k) s -= ri[k] * rj[k];
+    }
+    // pivot: lane j holds s = d
+    const T d = shfl(s, j);
+    if (!(d > T(0))) bad = true;
+    const T dr = SqrtT<T>::f(d);
+    if (row && i >= j) A[i * stride + j] = (i == j) ? dr : s / dr;
+  }
+  if (bad && lane == 0) atomicOr(notpd, 1);
+  // forward substitution L y = b (column oriented): y_k final at step k
+  for (int k = 0; k < nv; ++k) {
+    const T lkk = A[k * stride + k];
+    const T yk = shfl(b, k) / lkk;
+    if (i == k) b = yk;
+    if (row && i > k) b -= A[i * stride + k] * yk;
+  }
+  // backward substitution L' x = y: x_k final at step k (descending); lanes i < k subtract L[k][i] x_k
+  for (int k = nv - 1; k >= 0; --k) {
+    const T lkk = A[k * stride + k];
+    const T xk = shfl(b, k) / lkk;
+    if (i == k) b = xk;
+    if (row && i < k) b -= A[k * stride + i] * xk;
+  }
+  if (row) x[(long)i * Lv.sk + state * Lv.sb] = b;
+  if (Lout) {  // optional: the factor (lower), same layout as M
+    for (int j = 0; j < nv; ++j)
+      if (row && i >= j) Lout[((long)j * nv + i) * Lm.sk + state * Lm.sb] = A[i * stride + j];
+  }
+  (void)bc;
+}
+
+template <typename T>
+hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv,
+                             int* notpd, hipStream_t s) {
+  int stride = nv | 1;            // odd multiple ...
+  stride = ((nv + 3) / 4) * 4;    // ... of 4 words: 4*odd keeps 16-byte row alignment and spreads rows over the banks
+  if (((stride / 4) & 1) == 0) stride += 4;
+  const int wpb = 4;
+  const size_t shmem = (size_t)wpb * ((size_t)nv * stride + 64) * sizeof(T);
+  const dim3 grid((unsigned)((B + wpb - 1) / wpb));
+  hipLaunchKernelGGL(chol_solve_kernel<T>, grid, dim3(64 * wpb), shmem, s, nv, stride, B, (const T*)M, (const T*)tau, (const T*)c, (T*)x,
+                     (T*)Lout, Lm, Lv, notpd);
+  return hipGetLastError();
+}
+template hipError_t launch_chol_solve<double>(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t);
+template hipError_t launch_chol_solve<float>(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t);
 
 }  // namespace rbd

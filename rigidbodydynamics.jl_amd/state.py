@@ -288,3 +288,10 @@ def mass_matrix_solve_(x: torch.Tensor, state: MechanismState, rhs: torch.Tensor
     st = _capi.lib().rbd_mass_matrix_solve(state.ws.handle, state.batch, _ptr(state.q), _ptr(rhs), _ptr(x), _ptr(M_out), ctypes.byref(opts))
     _raise(st, "rbd_mass_matrix_solve")
     return x
+
+
+def sync(state: MechanismState) -> int:
+    """`rbd_sync`: wait for the workspace's stream; returns the status (8 == some mass matrix was not positive definite,
+    the batched analogue of LAPACK.potrf!'s PosDefException)."""
+    state.ws.use_current_stream()
+    return int(_capi.lib().rbd_sync(state.ws.handle))

@@ -206,3 +206,84 @@ def test_errors(rbd, models):
         rbd.mass_matrix_(torch.zeros(4, 5, dtype=torch.float64, device="cuda"), state)
     with pytest.raises(ValueError):
         rbd.dynamics_(result, state, torch.zeros(4, model.nv, dtype=torch.float32, device="cuda"))
+
+
+# ---- the reference's own route: dynamics_bias! + mass_matrix! + potrf!/potrs! (RBD_ALGO_CRBA_CHOLESKY) ---------------
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "double_pendulum", "acrobot_urdf"])
+def test_dynamics_crba_cholesky_route_f64(rbd, oracle, models, name, layout):
+    model = models[name]
+    B = 37
+    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 21)
+    result = rbd.DynamicsResult(model, B, layout=layout)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="crba")
+    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    got = host(result.vd, state)
+    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(host(result.qd, state) - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
+    # the DynamicsResult side products of the reference: massmatrix (lower) and dynamicsbias
+    nv = model.nv
+    Mg = host(result.massmatrix, state).reshape(B, nv, nv).transpose(0, 2, 1)
+    Mr = oracle.mass_matrix(model, q)
+    il = np.tril_indices(nv)
+    assert np.abs(Mg[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= 1e-10 * max(1.0, np.abs(Mr).max())
+    cr = oracle.dynamics_bias(model, q, v, fe)
+    assert np.abs(host(result.dynamicsbias, state) - cr).max() <= 1e-10 * max(1.0, np.abs(cr).max())
+    # and it agrees with the fused ABA kernel
+    r2 = rbd.DynamicsResult(model, B, layout=layout)
+    rbd.dynamics_(r2, state, dev(tau, state), dev(fe, state), algorithm="aba")
+    assert float((r2.vd - result.vd).abs().max()) <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+def test_mass_matrix_solve_f32_config3(rbd, oracle, models):
+    """BASELINE configs[2] shape at a size the oracle finishes quickly: Atlas floating fp32 mass_matrix! + Cholesky solve.
+    Backward error ||M x - rhs|| / ||rhs|| with the fp64 oracle's M (cond(M) ~ 5e5 limits the forward error)."""
+    model = models["atlas_floating"]
+    B = 1024
+    state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 22)
+    x = torch.zeros_like(state.v)
+    Mout = torch.zeros(B, model.nv * model.nv, dtype=torch.float32, device="cuda")
+    rbd.mass_matrix_solve_(x, state, dev(tau, state), Mout)
+    assert rbd.sync(state) == 0
+    M = oracle.mass_matrix(model, q)
+    Ms = np.tril(M) + np.transpose(np.tril(M, -1), (0, 2, 1))
+    xg = host(x, state)
+    # normwise backward error (Rigal–Gaches): ||M x - r|| / (||M|| ||x|| + ||r||)  — fp32 Cholesky: O(n eps) ~ 2e-6
+    res = np.einsum("bij,bj->bi", Ms, xg) - tau
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau, axis=1))
+    assert eta.max() <= 1e-5, eta.max()
+    xr = np.linalg.solve(Ms, tau[..., None])[..., 0]
+    assert np.abs(xg - xr).max() <= 3e-2 * np.abs(xr).max()
+
+
+def test_mass_matrix_solve_full_size_property(rbd, models):
+    """configs[2] at full size (B = 65536 fp32): size-independent property M (M^-1 r) = r, checked on the GPU with the
+    GPU's own mass matrix (torch fp64 matmul as the checker)."""
+    model = models["atlas_floating"]
+    B = 65536
+    state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 23)
+    rhs = dev(tau, state)
+    x = torch.zeros_like(state.v)
+    Mout = torch.zeros(B, model.nv * model.nv, dtype=torch.float32, device="cuda")
+    rbd.mass_matrix_solve_(x, state, rhs, Mout)
+    nv = model.nv
+    L = torch.tril(Mout.reshape(B, nv, nv).transpose(1, 2).double())
+    Ms = L + torch.tril(L, -1).transpose(1, 2)
+    res = torch.einsum("bij,bj->bi", Ms, x.double()) - rhs.double()
+    eta = res.norm(dim=1) / (torch.linalg.matrix_norm(Ms) * x.double().norm(dim=1) + rhs.double().norm(dim=1))
+    assert float(eta.max()) <= 1e-5
+
+
+def test_not_positive_definite_is_reported(rbd, models):
+    """potrf! throws PosDefException in the reference (src/mechanism_algorithms.jl:764); here rbd_sync reports status 8."""
+    model = rbd.flatten(rbd.double_pendulum())
+    model.inertia_moment = -model.inertia_moment  # unphysical: M is not SPD
+    model.inertia_mass = -model.inertia_mass
+    model.inertia_cross = -model.inertia_cross
+    model._c = None
+    state = rbd.MechanismState(model, 4)
+    result = rbd.DynamicsResult(model, 4)
+    rbd.rand_(state, 3)
+    rbd.dynamics_(result, state, algorithm="crba")
+    assert rbd.sync(state) == 8
+    assert rbd.sync(state) == 0  # the flag is cleared once reported
