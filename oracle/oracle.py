@@ -127,3 +127,24 @@ def transforms(model, q, dtype=np.float64):
     for b in range(B):
         assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(out[b], ct)) == 0
     return out
+
+
+def dynamics_loops(model, q, v, tau=None, fext=None, stabilize=True, dtype=np.float64):
+    """dynamics! for mechanisms with loop joints. Returns dict(vdot, qdot, lam, K [B,nc,nv], k, M [B,nv,nv] lower, c)."""
+    sfx, ct = _sfx(dtype)
+    f = getattr(lib(), "rbdo_dynamics_loops" + sfx)
+    f.restype = ctypes.c_int
+    B, nq, nv, nb, nc = q.shape[0], model.nq, model.nv, model.n_bodies, model.nc
+    q = _prep(q, dtype, (B, nq)); v = _prep(v, dtype, (B, nv)); tau = _prep(tau, dtype, (B, nv)); fext = _prep(fext, dtype, (B, 6 * nb))
+    out = dict(vdot=np.zeros((B, nv), dtype), qdot=np.zeros((B, nq), dtype), lam=np.zeros((B, max(nc, 1)), dtype),
+               K=np.zeros((B, nv, max(nc, 1)), dtype), k=np.zeros((B, max(nc, 1)), dtype), M=np.zeros((B, nv, nv), dtype), c=np.zeros((B, nv), dtype))
+    for b in range(B):
+        st = f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(v[b], ct), _ptr(None if tau is None else tau[b], ct),
+               _ptr(None if fext is None else fext[b], ct), ctypes.c_int(1 if stabilize else 0), _ptr(out["vdot"][b], ct), _ptr(out["qdot"][b], ct),
+               _ptr(out["lam"][b], ct), _ptr(out["K"][b], ct), _ptr(out["k"][b], ct), _ptr(out["M"][b], ct), _ptr(out["c"][b], ct))
+        if st != 0:
+            raise RuntimeError(f"oracle status {st}")
+    out["K"] = out["K"].transpose(0, 2, 1)[:, :nc]   # column-major (nv, nc) per state -> [b, c, v]
+    out["M"] = out["M"].transpose(0, 2, 1)
+    out["lam"], out["k"] = out["lam"][:, :nc], out["k"][:, :nc]
+    return out

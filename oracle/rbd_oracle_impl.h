@@ -537,6 +537,188 @@ int FN(rbdo_mass_matrix_solve)(const rbd_flat_model_t* m, const REAL* q, const R
   return st;
 }
 
+/* ---- loop (non-tree) joints ------------------------------------------------------------------------------
+ * constraint_jacobian! src/mechanism_algorithms.jl:574-598, constraint_bias! :630-673 (Baumgarte stabilization through
+ * pd(..., SE3PDMethod{:Linearized}) src/pdcontrol.jl:109-122), dynamics_solve! loop branch :768-816.            */
+static int FN(loop_nc)(int t) { return 6 - FN(joint_nv)(t); }
+
+/* constraint_wrench_subspace in frame_after(loop joint): revolute.jl:91-98, prismatic.jl:101-108, fixed.jl (identity) */
+static int FN(constraint_basis)(const rbd_loop_joint_t* lj, REAL* Tl /* 6 x nc, column c at Tl + 6 c */) {
+  int nc = FN(loop_nc)(lj->joint_type);
+  const double* R = lj->rotation_from_z_aligned; /* row-major */
+  for (int k = 0; k < 6 * nc; ++k) Tl[k] = 0;
+  switch (lj->joint_type) {
+    case RBD_JOINT_REVOLUTE: case RBD_JOINT_SINCOS_REVOLUTE:
+      for (int r = 0; r < 3; ++r) { Tl[6 * 0 + r] = (REAL)R[3 * r + 0]; Tl[6 * 1 + r] = (REAL)R[3 * r + 1];
+        Tl[6 * 2 + 3 + r] = (REAL)R[3 * r + 0]; Tl[6 * 3 + 3 + r] = (REAL)R[3 * r + 1]; Tl[6 * 4 + 3 + r] = (REAL)R[3 * r + 2]; }
+      return nc;
+    case RBD_JOINT_PRISMATIC:
+      for (int r = 0; r < 3; ++r) { Tl[6 * 0 + r] = (REAL)R[3 * r + 0]; Tl[6 * 1 + r] = (REAL)R[3 * r + 1]; Tl[6 * 2 + r] = (REAL)R[3 * r + 2];
+        Tl[6 * 3 + 3 + r] = (REAL)R[3 * r + 0]; Tl[6 * 4 + 3 + r] = (REAL)R[3 * r + 1]; }
+      return nc;
+    case RBD_JOINT_FIXED:
+      for (int c = 0; c < 6; ++c) Tl[6 * c + c] = 1;
+      return nc;
+    case RBD_JOINT_QUAT_FLOATING: return 0;
+    default: return -1;
+  }
+}
+
+/* symmetric eigen-decomposition by cyclic Jacobi: A (n x n, row-major, destroyed: diagonal = eigenvalues), V = eigenvectors (columns) */
+static void FN(jacobi_eig)(REAL* A, REAL* V, int n) {
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j);
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    REAL off = 0, diag = 0;
+    for (int i = 0; i < n; ++i) { diag += A[i * n + i] * A[i * n + i]; for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j]; }
+    if (off <= (REAL)1e-60 + diag * (REAL)1e-34) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        REAL apq = A[p * n + q];
+        if (apq == 0) continue;
+        REAL theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+        REAL t = (theta >= 0 ? (REAL)1 : (REAL)-1) / ((theta >= 0 ? theta : -theta) + SQRT(theta * theta + 1));
+        REAL c = 1 / SQRT(t * t + 1), sn = t * c;
+        for (int k = 0; k < n; ++k) { REAL akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - sn * akq; A[k * n + q] = sn * akp + c * akq; }
+        for (int k = 0; k < n; ++k) { REAL apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - sn * aqk; A[q * n + k] = sn * apk + c * aqk; }
+        for (int k = 0; k < n; ++k) { REAL vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - sn * vkq; V[k * n + q] = sn * vkp + c * vkq; }
+      }
+  }
+}
+
+/* dynamics! for mechanisms with loop joints (the full :845-864 path).  Outputs: vdot[nv], lambda[nc] (min-norm, like
+ * LAPACK gelsy! with rcond 1e-10 — third-party, restated as the truncated pseudo-inverse of the PSD Schur matrix),
+ * Kout [nc x nv] column-major, kout [nc] (nullable).  stabilize != 0: Baumgarte with the loop joints' gains.          */
+int FN(rbdo_dynamics_loops)(const rbd_flat_model_t* m, const REAL* q, const REAL* v, const REAL* tau, const REAL* fext, int stabilize,
+                            REAL* vdot, REAL* qdot, REAL* lambda, REAL* Kout, REAL* kout, REAL* Mout, REAL* cout) {
+  int nv = m->nv, nb = m->n_bodies, nc = 0;
+  for (int l = 0; l < m->n_loops; ++l) nc += FN(loop_nc)(m->loops[l].joint_type);
+  CACHE c;
+  if (FN(cache_alloc)(m, &c)) return RBD_ERR_OUT_OF_MEMORY;
+  REAL* M = (REAL*)malloc(sizeof(REAL) * (size_t)(nv * nv + 1));
+  REAL* cb = (REAL*)malloc(sizeof(REAL) * (size_t)(nv + 1));
+  REAL* K = (REAL*)calloc((size_t)(nc * nv + 1), sizeof(REAL)); /* row-major here: K[ci*nv + vi] */
+  REAL* kk = (REAL*)calloc((size_t)(nc + 1), sizeof(REAL));
+  REAL* Y = (REAL*)malloc(sizeof(REAL) * (size_t)(nc * nv + 1));
+  REAL* A = (REAL*)malloc(sizeof(REAL) * (size_t)(nc * nc + 1));
+  REAL* V = (REAL*)malloc(sizeof(REAL) * (size_t)(nc * nc + 1));
+  REAL* z = (REAL*)malloc(sizeof(REAL) * (size_t)(nv + 1));
+  REAL* bvec = (REAL*)malloc(sizeof(REAL) * (size_t)(nc + 1));
+  REAL* Abias = (REAL*)malloc(sizeof(REAL) * 6 * (size_t)nb);
+  if (qdot) FN(rbdo_configuration_derivative)(m, q, v, qdot);
+  FN(update_transforms)(m, q, &c);
+  FN(update_motion_subspaces)(m, q, &c);
+  FN(update_twists)(m, v, &c);
+  FN(update_inertias)(m, &c);
+  FN(accelerations)(m, NULL, &c);
+  /* bias accelerations wrt world WITHOUT gravity (state.bias_accelerations_wrt_world): c.A carries -g at the root */
+  for (int i = 0; i < nb; ++i) for (int j = 0; j < 6; ++j) Abias[6 * i + j] = c.A[6 * i + j] - (j >= 3 ? -(REAL)m->gravity[j - 3] : (REAL)0);
+  FN(wrenches_and_torques)(m, fext, &c, cb);
+  FN(mass_matrix_cached)(m, &c, M);
+  if (Mout) memcpy(Mout, M, sizeof(REAL) * (size_t)(nv * nv));
+  if (cout) memcpy(cout, cb, sizeof(REAL) * (size_t)nv);
+  int row0 = 0, st = RBD_OK;
+  const REAL I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int l = 0; l < m->n_loops && st == RBD_OK; ++l) {
+    const rbd_loop_joint_t* lj = &m->loops[l];
+    REAL Tl[36];
+    int ncl = FN(constraint_basis)(lj, Tl);
+    if (ncl < 0) { st = RBD_ERR_UNSUPPORTED; break; }
+    XF Hp, Hs, Xp, Xs, Fb, Fa;
+    memcpy(Hp.R, I3, sizeof I3); Hp.p[0] = Hp.p[1] = Hp.p[2] = 0; Hs = Hp;
+    if (lj->predecessor >= 0) Hp = c.H[lj->predecessor];
+    if (lj->successor >= 0) Hs = c.H[lj->successor];
+    for (int k = 0; k < 9; ++k) { Xp.R[k] = (REAL)lj->pred_rot[k]; Xs.R[k] = (REAL)lj->succ_rot[k]; }
+    for (int k = 0; k < 3; ++k) { Xp.p[k] = (REAL)lj->pred_trans[k]; Xs.p[k] = (REAL)lj->succ_trans[k]; }
+    FN(xf_mul)(&Hp, &Xp, &Fb); /* before_to_root: mechanism_state.jl:707 */
+    FN(xf_mul)(&Hs, &Xs, &Fa); /* after_to_root:  :708, also the frame of the constraint wrench basis :791 */
+    REAL Tw[36];
+    for (int ci = 0; ci < ncl; ++ci) FN(xforce)(&Fa, Tl + 6 * ci, Tl + 6 * ci + 3, Tw + 6 * ci, Tw + 6 * ci + 3);
+    /* path predecessor -> successor (src/graphs/tree_path.jl:41-63): 'up' edges from the predecessor side (sign -1),
+     * 'down' edges on the successor side (sign +1) */
+    int a = lj->predecessor, b = lj->successor;
+    while (a != b) {
+      int body, sign;
+      if (a > b) { body = a; sign = -1; a = m->parent[a]; } else { body = b; sign = 1; b = m->parent[b]; }
+      int nvj = FN(joint_nv)(m->joint_type[body]);
+      for (int col = 0; col < nvj; ++col) {
+        int vi = m->v_offset[body] + col;
+        const REAL* S = c.S + 6 * vi;
+        for (int ci = 0; ci < ncl; ++ci) {
+          REAL d = 0;
+          for (int j = 0; j < 6; ++j) d += Tw[6 * ci + j] * S[j];
+          K[(row0 + ci) * nv + vi] = sign < 0 ? -d : d;
+        }
+      }
+    }
+    /* constraint_bias! */
+    REAL Tp[6], Ts[6], Ap[6], As[6], cr[6], ba[6];
+    for (int j = 0; j < 6; ++j) {
+      Tp[j] = lj->predecessor >= 0 ? c.T[6 * lj->predecessor + j] : (REAL)0; Ts[j] = lj->successor >= 0 ? c.T[6 * lj->successor + j] : (REAL)0;
+      Ap[j] = lj->predecessor >= 0 ? Abias[6 * lj->predecessor + j] : (REAL)0; As[j] = lj->successor >= 0 ? Abias[6 * lj->successor + j] : (REAL)0;
+    }
+    FN(se3_comm)(Ts, Tp, cr);
+    for (int j = 0; j < 6; ++j) ba[j] = cr[j] + (As[j] - Ap[j]);
+    if (stabilize) {
+      XF Fbi, Tn, Fai;
+      FN(xf_inv)(&Fb, &Fbi);
+      FN(xf_mul)(&Fbi, &Fa, &Tn); /* joint transform of the loop joint: frame_after -> frame_before */
+      FN(xf_inv)(&Fa, &Fai);
+      REAL jt[6], jl[6], stab[6], sw[6], Rtp[3];
+      for (int j = 0; j < 6; ++j) jt[j] = Ts[j] - Tp[j];
+      FN(xm)(&Fai, jt, jt + 3, jl, jl + 3); /* joint twist in frame_after */
+      REAL psi[3] = {(Tn.R[7] - Tn.R[5]) / 2, (Tn.R[2] - Tn.R[6]) / 2, (Tn.R[3] - Tn.R[1]) / 2}; /* spatial/util.jl:178-183 */
+      for (int i = 0; i < 3; ++i) Rtp[i] = Tn.R[i] * Tn.p[0] + Tn.R[3 + i] * Tn.p[1] + Tn.R[6 + i] * Tn.p[2];
+      for (int i = 0; i < 3; ++i) {
+        stab[i] = -(REAL)lj->gains[0] * psi[i] - (REAL)lj->gains[1] * jl[i];
+        stab[3 + i] = -(REAL)lj->gains[2] * Rtp[i] - (REAL)lj->gains[3] * jl[3 + i];
+      }
+      FN(xm)(&Fa, stab, stab + 3, sw, sw + 3);
+      for (int j = 0; j < 6; ++j) ba[j] -= sw[j];
+    }
+    for (int ci = 0; ci < ncl; ++ci) { REAL d = 0; for (int j = 0; j < 6; ++j) d += Tw[6 * ci + j] * ba[j]; kk[row0 + ci] = d; }
+    row0 += ncl;
+  }
+  if (st == RBD_OK) st = FN(chol_lower)(M, nv); /* L */
+  if (st == RBD_OK) {
+    for (int i = 0; i < nv; ++i) z[i] = (tau ? tau[i] : (REAL)0) - cb[i];
+    REAL* rhs = (REAL*)malloc(sizeof(REAL) * (size_t)(nv + 1));
+    memcpy(rhs, z, sizeof(REAL) * (size_t)nv);
+    if (nc > 0) {
+      FN(fwd_subst)(M, nv, z);                                   /* z = L^-1 (tau - c) */
+      for (int ci = 0; ci < nc; ++ci) {                          /* Y = K L^-T  <=>  L Y' = K' */
+        memcpy(Y + ci * nv, K + ci * nv, sizeof(REAL) * (size_t)nv);
+        FN(fwd_subst)(M, nv, Y + ci * nv);
+      }
+      for (int i = 0; i < nc; ++i) {
+        for (int j = 0; j < nc; ++j) { REAL s2 = 0; for (int k = 0; k < nv; ++k) s2 += Y[i * nv + k] * Y[j * nv + k]; A[i * nc + j] = s2; }
+        REAL s2 = kk[i]; for (int k = 0; k < nv; ++k) s2 += Y[i * nv + k] * z[k]; bvec[i] = s2;
+      }
+      /* lambda = min-norm least-squares solution of A lambda = b (A PSD, possibly singular): gelsy!(A, b, 1e-10) */
+      FN(jacobi_eig)(A, V, nc);
+      REAL emax = 0;
+      for (int i = 0; i < nc; ++i) if (A[i * nc + i] > emax) emax = A[i * nc + i];
+      for (int i = 0; i < nc; ++i) lambda[i] = 0;
+      for (int e = 0; e < nc; ++e) {
+        REAL ev = A[e * nc + e];
+        if (ev > (REAL)1e-10 * emax) {
+          REAL d = 0; for (int i = 0; i < nc; ++i) d += V[i * nc + e] * bvec[i];
+          d /= ev;
+          for (int i = 0; i < nc; ++i) lambda[i] += V[i * nc + e] * d;
+        }
+      }
+      for (int vi = 0; vi < nv; ++vi) { REAL s2 = 0; for (int ci = 0; ci < nc; ++ci) s2 += K[ci * nv + vi] * lambda[ci]; rhs[vi] -= s2; }
+    }
+    FN(fwd_subst)(M, nv, rhs); FN(bwd_subst)(M, nv, rhs);
+    memcpy(vdot, rhs, sizeof(REAL) * (size_t)nv);
+    free(rhs);
+    if (Kout) for (int ci = 0; ci < nc; ++ci) for (int vi = 0; vi < nv; ++vi) Kout[vi * nc + ci] = K[ci * nv + vi];
+    if (kout) memcpy(kout, kk, sizeof(REAL) * (size_t)nc);
+  }
+  free(M); free(cb); free(K); free(kk); free(Y); free(A); free(V); free(z); free(bvec); free(Abias);
+  FN(cache_free)(&c);
+  return st;
+}
+
 /* ---- independent cross-check: world-frame articulated-body algorithm (NOT in the reference;
  * SURVEY.md App. A item 12).  Must reproduce rbdo_dynamics' v̇. ----------------------------- */
 static void FN(sym6_from_inertia)(const INERTIA* I, REAL* A /*6x6 row-major*/) {

@@ -60,6 +60,8 @@ struct rbd_model {
   std::vector<int32_t> dof_body;
   std::vector<int32_t> anc;     // nb * nlevels
   std::vector<rbd_loop_joint_t> loops;
+  std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref;  // loop tables (reference body indices)
+  std::vector<double> loop_r, axis_ref;
 };
 
 struct rbd_ws {
@@ -74,6 +76,8 @@ struct rbd_ws {
   // internal device scratch (mass matrix / bias for the CRBA route), lazy
   void* d_M = nullptr; void* d_c = nullptr; void* d_K = nullptr; void* d_k = nullptr;
   size_t d_M_bytes = 0, d_c_bytes = 0, d_K_bytes = 0, d_k_bytes = 0;
+  void* d_body = nullptr; void* d_scratch = nullptr; size_t d_body_bytes = 0, d_scratch_bytes = 0;
+  void* d_loop_i = nullptr; void* d_loop_r = nullptr; void* d_loop_path = nullptr; void* d_jt_ref = nullptr; void* d_voff_ref = nullptr; void* d_axis_ref = nullptr;
   int* d_notpd = nullptr;  // device flag: some state's mass matrix was not positive definite (checked by rbd_sync)
   int32_t result_layout = RBD_LAYOUT_SOA; int32_t result_B = 0;
   // timing
@@ -201,12 +205,44 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     for (int k = 0; k < m->nlevels && a >= 0; ++k) { m->anc[(size_t)s * m->nlevels + k] = a; a = m->ib[(size_t)a * IB_STRIDE + IB_PARENT]; }
   }
   m->nc = 0;
+  m->jt_ref.assign(d->joint_type, d->joint_type + nb);
+  m->voff_ref.assign(d->v_offset, d->v_offset + nb);
+  m->axis_ref.assign(d->joint_axis, d->joint_axis + 3 * nb);
   for (int l = 0; l < d->n_loops; ++l) {
-    const int nvl = joint_nv_host(d->loops[l].joint_type);
+    const rbd_loop_joint_t& lj = d->loops[l];
+    const int nvl = joint_nv_host(lj.joint_type);
     if (nvl < 0) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
-    if (d->loops[l].predecessor >= nb || d->loops[l].successor >= nb) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
-    m->nc += 6 - nvl;  // num_constraints: src/joint.jl:12
-    m->loops.push_back(d->loops[l]);
+    if (lj.predecessor >= nb || lj.successor >= nb || lj.predecessor < -1 || lj.successor < -1) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
+    const int ncl = 6 - nvl;  // num_constraints: src/joint.jl:12
+    // local constraint wrench basis in frame_after(joint): revolute.jl:91-98, prismatic.jl:101-108, fixed.jl
+    double Tl[36] = {0};
+    const double* R = lj.rotation_from_z_aligned;
+    if (lj.joint_type == RBD_JOINT_REVOLUTE || lj.joint_type == RBD_JOINT_SINCOS_REVOLUTE) {
+      for (int r = 0; r < 3; ++r) { Tl[0 + r] = R[3 * r]; Tl[6 + r] = R[3 * r + 1]; Tl[12 + 3 + r] = R[3 * r]; Tl[18 + 3 + r] = R[3 * r + 1]; Tl[24 + 3 + r] = R[3 * r + 2]; }
+    } else if (lj.joint_type == RBD_JOINT_PRISMATIC) {
+      for (int r = 0; r < 3; ++r) { Tl[0 + r] = R[3 * r]; Tl[6 + r] = R[3 * r + 1]; Tl[12 + r] = R[3 * r + 2]; Tl[18 + 3 + r] = R[3 * r]; Tl[24 + 3 + r] = R[3 * r + 1]; }
+    } else if (lj.joint_type == RBD_JOINT_FIXED) {
+      for (int c = 0; c < 6; ++c) Tl[6 * c + c] = 1;
+    } else if (lj.joint_type != RBD_JOINT_QUAT_FLOATING) {
+      delete m; return RBD_ERR_UNSUPPORTED;
+    }
+    const int path_begin = (int)m->loop_path.size() / 2;
+    int a = lj.predecessor, b = lj.successor;  // TreePath(pred, succ): src/graphs/tree_path.jl:41-63
+    while (a != b) {
+      if (a > b) { m->loop_path.push_back(a); m->loop_path.push_back(-1); a = d->parent[a]; }
+      else { m->loop_path.push_back(b); m->loop_path.push_back(1); b = d->parent[b]; }
+    }
+    const int path_end = (int)m->loop_path.size() / 2;
+    const int32_t rec[8] = {lj.predecessor, lj.successor, lj.joint_type, m->nc, ncl, path_begin, path_end, 0};
+    m->loop_i.insert(m->loop_i.end(), rec, rec + 8);
+    double r64[64] = {0};
+    for (int k = 0; k < 9; ++k) { r64[k] = lj.pred_rot[k]; r64[12 + k] = lj.succ_rot[k]; }
+    for (int k = 0; k < 3; ++k) { r64[9 + k] = lj.pred_trans[k]; r64[21 + k] = lj.succ_trans[k]; }
+    for (int k = 0; k < 4; ++k) r64[24 + k] = lj.gains[k];
+    for (int k = 0; k < 36; ++k) r64[28 + k] = Tl[k];
+    m->loop_r.insert(m->loop_r.end(), r64, r64 + 64);
+    m->nc += ncl;
+    m->loops.push_back(lj);
   }
   *out = m;
   return RBD_OK;
@@ -257,6 +293,22 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   if (st == RBD_OK) st = upload(&w->d_dof_body, m->dof_body.data(), m->dof_body.size() * sizeof(int32_t));
   if (st == RBD_OK) st = upload(&w->d_anc, m->anc.data(), m->anc.size() * sizeof(int32_t));
   if (st == RBD_OK) { int zero = 0; st = upload((void**)&w->d_notpd, &zero, sizeof(int)); }
+  if (st == RBD_OK && m->nloops > 0) {
+    st = upload(&w->d_loop_i, m->loop_i.data(), m->loop_i.size() * sizeof(int32_t));
+    if (st == RBD_OK) st = upload(&w->d_loop_path, m->loop_path.data(), m->loop_path.size() * sizeof(int32_t));
+    if (st == RBD_OK) st = upload(&w->d_jt_ref, m->jt_ref.data(), m->jt_ref.size() * sizeof(int32_t));
+    if (st == RBD_OK) st = upload(&w->d_voff_ref, m->voff_ref.data(), m->voff_ref.size() * sizeof(int32_t));
+    if (st == RBD_OK) {
+      if (dtype == RBD_F64) {
+        st = upload(&w->d_loop_r, m->loop_r.data(), m->loop_r.size() * sizeof(double));
+        if (st == RBD_OK) st = upload(&w->d_axis_ref, m->axis_ref.data(), m->axis_ref.size() * sizeof(double));
+      } else {
+        std::vector<float> a(m->loop_r.begin(), m->loop_r.end()), b2(m->axis_ref.begin(), m->axis_ref.end());
+        st = upload(&w->d_loop_r, a.data(), a.size() * sizeof(float));
+        if (st == RBD_OK) st = upload(&w->d_axis_ref, b2.data(), b2.size() * sizeof(float));
+      }
+    }
+  }
   if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
   DevModel& dm = w->dm;
   dm.nb = m->nb; dm.nq = m->nq; dm.nv = m->nv; dm.lps = m->lps; dm.nlevels = m->nlevels; dm.maxchild = m->maxchild; dm.maxnvj = m->maxnvj;
@@ -277,7 +329,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd};
+  void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
@@ -398,6 +450,39 @@ int ensure(void** p, size_t* have, size_t need) {
 
 }  // namespace
 
+namespace {
+template <typename T>
+int dynamics_loops_t(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd,
+                     void* dlam) {
+  const rbd_model* m = w->model;
+  const size_t es = sizeof(T);
+  const int nv = m->nv, nc = m->nc;
+  const long stride = (long)nv * nv + 2L * nc * nv + 2L * nc * nc + 2L * nv + 2L * nc;
+  int st;
+  if ((st = ensure(&w->d_M, &w->d_M_bytes, es * (size_t)nv * nv * B)) || (st = ensure(&w->d_c, &w->d_c_bytes, es * (size_t)nv * B)) ||
+      (st = ensure(&w->d_K, &w->d_K_bytes, es * (size_t)(nc * nv > 0 ? nc * nv : 1) * B)) || (st = ensure(&w->d_k, &w->d_k_bytes, es * (size_t)(nc > 0 ? nc : 1) * B)) ||
+      (st = ensure(&w->d_body, &w->d_body_bytes, es * (size_t)m->nb * 24 * B)) || (st = ensure(&w->d_scratch, &w->d_scratch_bytes, es * (size_t)stride * B)))
+    return st;
+  w->result_layout = o.layout; w->result_B = B;
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
+  const Layout Lm = layout_of(o.layout, (long)nv * nv, B), Lc = layout_of(o.layout, nc, B), Lk = layout_of(o.layout, (long)nc * nv, B);
+  LoopView<T> V;
+  V.nloops = m->nloops; V.nc = nc; V.nv = nv; V.nb = m->nb;
+  V.li = (const int32_t*)w->d_loop_i; V.lr = (const T*)w->d_loop_r; V.path = (const int32_t*)w->d_loop_path;
+  V.jt = (const int32_t*)w->d_jt_ref; V.voff = (const int32_t*)w->d_voff_ref; V.axis = (const T*)w->d_axis_ref;
+  Timed t(w);
+  HIP_TRY(launch_rnea<T>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, w->d_body, Lq, Lv, Lf, w->stream));
+  HIP_TRY(launch_crba<T>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
+  HIP_TRY(launch_loop_solve<T>(V, B, o.stabilization, w->d_body, w->d_M, w->d_c, dtau, dvd, dlam, w->d_K, w->d_k, w->d_scratch, stride, Lm, Lv, Lc, Lk,
+                               m->gravity, w->d_notpd, w->stream));
+  return RBD_OK;
+}
+int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd, void* dlam) {
+  return w->dtype == RBD_F64 ? dynamics_loops_t<double>(w, B, o, dq, dv, dtau, df, dvd, dqd, dlam)
+                             : dynamics_loops_t<float>(w, B, o, dq, dv, dtau, df, dvd, dqd, dlam);
+}
+}  // namespace
+
 extern "C" {
 
 int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
@@ -407,21 +492,23 @@ int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const voi
   if (st != RBD_OK) return st;
   if (!q || !v || !vdot) return RBD_ERR_INVALID_ARGUMENT;
   const rbd_model* m = w->model;
-  if (m->nloops > 0) return RBD_ERR_UNSUPPORTED;  // loop-joint branch of dynamics_solve!: next
-  (void)lambda;
+  const bool loops = m->nloops > 0;  // has_loops(mechanism): only the CRBA route exists (src/mechanism_algorithms.jl:858-861)
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   const size_t es = esize(w);
   const void *dq = q, *dv = v, *dtau = tau, *df = fext;
-  void *dvd = vdot, *dqd = qdot;
+  void *dvd = vdot, *dqd = qdot, *dlam = lambda;
   if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_out_alloc(w, 7, lambda, es * (m->nc > 0 ? m->nc : 1) * B, &dlam))) return st;
     if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_in(w, 1, v, es * m->nv * B, &dv)) ||
         (st = stage_in(w, 2, tau, es * m->nv * B, &dtau)) || (st = stage_in(w, 3, fext, es * 6 * m->nb * B, &df)) ||
         (st = stage_out_alloc(w, 4, vdot, es * m->nv * B, &dvd)) || (st = stage_out_alloc(w, 5, qdot, es * m->nq * B, &dqd)))
       return st;
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
-  if (o.algorithm == RBD_ALGO_CRBA_CHOLESKY) {
+  if (loops) {
+    if ((st = dynamics_loops(w, B, o, dq, dv, dtau, df, dvd, dqd, dlam))) return st;
+  } else if (o.algorithm == RBD_ALGO_CRBA_CHOLESKY) {
     // the reference's own route (src/mechanism_algorithms.jl:856-862): c = dynamics_bias!, M = mass_matrix!, then
     // potrf!/potrs!.  M and c stay in the workspace (layout of this call) for rbd_dynamics_result.
     const Layout Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
@@ -430,11 +517,11 @@ int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const voi
     w->result_layout = o.layout; w->result_B = B;
     Timed t(w);
     if (w->dtype == RBD_F64) {
-      HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, Lq, Lv, Lf, w->stream));
+      HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, nullptr, Lq, Lv, Lf, w->stream));
       HIP_TRY(launch_crba<double>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
       HIP_TRY(launch_chol_solve<double>(m->nv, B, w->d_M, dtau, w->d_c, dvd, nullptr, Lm, Lv, w->d_notpd, w->stream));
     } else {
-      HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, Lq, Lv, Lf, w->stream));
+      HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, nullptr, Lq, Lv, Lf, w->stream));
       HIP_TRY(launch_crba<float>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
       HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_M, dtau, w->d_c, dvd, nullptr, Lm, Lv, w->d_notpd, w->stream));
     }
@@ -444,7 +531,9 @@ int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const voi
     else HIP_TRY(launch_aba<float>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
   }
   if (o.memory == RBD_MEM_HOST) {
-    if ((st = stage_out_copy(w, vdot, dvd, es * m->nv * B)) || (st = stage_out_copy(w, qdot, dqd, es * m->nq * B))) return st;
+    if ((st = stage_out_copy(w, vdot, dvd, es * m->nv * B)) || (st = stage_out_copy(w, qdot, dqd, es * m->nq * B)) ||
+        (st = stage_out_copy(w, lambda, dlam, es * m->nc * B)))
+      return st;
   }
   return RBD_OK;
 }
@@ -470,8 +559,8 @@ static int rnea_common(rbd_ws_t* w, int32_t B, const void* q, const void* v, con
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
   {
     Timed t(w);
-    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf, w->stream));
+    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dt, nullptr, nullptr, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dt, nullptr, nullptr, Lq, Lv, Lf, w->stream));
   }
   if (o.memory == RBD_MEM_HOST) return stage_out_copy(w, tau_out, dt, es * m->nv * B);
   return RBD_OK;

@@ -45,6 +45,17 @@ struct Layout {
   long sk, sb;  // SOA: sk = B, sb = 1;  AOS: sk = 1, sb = n
 };
 
+// loop (non-tree) joint tables for loop_solve_kernel; indices are REFERENCE body indices (not slots)
+template <typename T> struct LoopView {
+  int nloops, nc, nv, nb;
+  const int32_t* li;   // [nloops*8]: pred, succ, type, row0, ncl, path_begin, path_end, pad   (reference body indices)
+  const T* lr;         // [nloops*64]: Xpred R(9) p(3), Xsucc R(9) p(3), gains(4), local wrench basis Tl (6 x up to 6 = 36)
+  const int32_t* path; // [*][2]: reference body index, sign
+  const int32_t* jt;   // [nb] joint type by reference body index
+  const int32_t* voff; // [nb]
+  const T* axis;       // [nb*3]
+};
+
 #define RBD_DEV __device__ __forceinline__
 
 template <typename T> RBD_DEV T shfl(T x, int src) { return __shfl(x, src, 64); }

@@ -9,7 +9,7 @@ hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, c
                       void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 template <typename T>
 hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
-                       void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+                       void* qdot, void* body_out, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 template <typename T>
 hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill, hipStream_t s);
 }  // namespace rbd
@@ -17,4 +17,10 @@ namespace rbd {
 template <typename T>
 hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv,
                              int* notpd, hipStream_t s);
+}
+namespace rbd {
+template <typename T>
+hipError_t launch_loop_solve(const LoopView<T>& V, long B, int stabilize, const void* body, const void* M, const void* c, const void* tau, void* vdot,
+                             void* lambda, void* K, void* k, void* scratch, long scratch_stride, Layout Lm, Layout Lv, Layout Lc, Layout Lk,
+                             const double* gravity, int* notpd, hipStream_t s);
 }

@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256, 2) void aba_kernel(DevModel M, long B, const T
 template <typename T>
 __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
                                                    const T* __restrict__ vdot, const T* __restrict__ fext,
-                                                   T* __restrict__ tau, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
+                                                   T* __restrict__ tau, T* __restrict__ qdot, T* __restrict__ body_out,
+                                                   Layout Lq, Layout Lv, Layout Lf) {
   Body<T> b;
   load_body(M, B, b);
   const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
@@ -452,6 +453,17 @@ __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* 
   local_joint_motion(b, rb, vj, tl);
   local_joint_motion(b, rb, aj, al);  // joint_spatial_acceleration: S_local * v̇ (revolute.jl:76-81)
   sweep_kinematics<T, true>(M, b, XR, Xp, R, p, tl, Tw, vJ, al, acc);
+  if (body_out != nullptr && b.valid) {
+    // per-body kinematics for the loop-joint branch (constraint_jacobian!/constraint_bias!): [state][reference body][24] =
+    // transform_to_root R (9), p (3); twist_wrt_world (6); acceleration incl. the -gravity root term (6)
+    T* o = body_out + (b.state * M.nb + b.orig) * 24;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[9 + k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { o[12 + k] = Tw[k]; o[18 + k] = acc[k]; }
+  }
 
   // newton_euler! (mechanism_algorithms.jl:428-439): w = I a + T x* I T - wext
   T w[6];
@@ -638,9 +650,9 @@ hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, c
 }
 template <typename T>
 hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
-                       void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+                       void* qdot, void* body_out, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
   hipLaunchKernelGGL(rnea_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)vdot,
-                     (const T*)fext, (T*)tau, (T*)qdot, Lq, Lv, Lf);
+                     (const T*)fext, (T*)tau, (T*)qdot, (T*)body_out, Lq, Lv, Lf);
   return hipGetLastError();
 }
 template <typename T>
@@ -651,8 +663,8 @@ hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Lay
 
 template hipError_t launch_aba<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_aba<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
-template hipError_t launch_rnea<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
-template hipError_t launch_rnea<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_crba<double>(const DevModel&, long, const void*, void*, Layout, Layout, int, hipStream_t);
 template hipError_t launch_crba<float>(const DevModel&, long, const void*, void*, Layout, Layout, int, hipStream_t);
 
@@ -747,5 +759,185 @@ hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, con
 }
 template hipError_t launch_chol_solve<double>(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t);
 template hipError_t launch_chol_solve<float>(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t);
+
+}  // namespace rbd
+
+// ---------------------------------------------------------------------------------------------
+// Loop-joint branch of dynamics! (src/mechanism_algorithms.jl:858-861 and dynamics_solve! :768-816): one thread per
+// state.  K = constraint_jacobian! (:574-598), k = constraint_bias! (:630-673, Baumgarte term through the Linearized SE(3)
+// PD law, src/pdcontrol.jl:109-122), then  L = chol(M), Y = K L^-T, z = L^-1(tau - c), A = Y Y', b = Y z + k,
+// lambda = min-norm LS solution of A lambda = b (gelsy!, rcond 1e-10; restated as the truncated pseudo-inverse of the PSD
+// matrix A via cyclic Jacobi), v̇ = M^-1 (tau - c - K' lambda).  Mechanisms with loops are small (four-bar: nv 3, nc 5), so
+// this branch favours generality over speed: all matrices live in a per-state global scratch block.
+// ---------------------------------------------------------------------------------------------
+namespace rbd {
+
+template <typename T> RBD_DEV void xf_compose(const T* AR, const T* Ap, const T* BR, const T* Bp, T* CR, T* Cp) {
+  matmul3(AR, BR, CR);
+  matvec3(AR, Bp, Cp);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) Cp[k] += Ap[k];
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void loop_solve_kernel(LoopView<T> V, long B, int stabilize, const T* __restrict__ body, const T* __restrict__ Mg,
+                                                        const T* __restrict__ cg, const T* __restrict__ tau, T* __restrict__ vdot,
+                                                        T* __restrict__ lambda, T* __restrict__ Kg, T* __restrict__ kg, T* __restrict__ scratch,
+                                                        long scratch_stride, Layout Lm, Layout Lv, Layout Lc, Layout Lk, double g0, double g1,
+                                                        double g2, int* __restrict__ notpd) {
+  const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (st >= B) return;
+  const int nv = V.nv, nc = V.nc, nb = V.nb;
+  T* L = scratch + st * scratch_stride;  // nv*nv (column-major, lower)
+  T* K = L + nv * nv;                    // nc*nv row-major
+  T* Y = K + nc * nv;                    // nc*nv row-major
+  T* A = Y + nc * nv;                    // nc*nc
+  T* E = A + nc * nc;                    // nc*nc eigenvectors
+  T* z = E + nc * nc;                    // nv
+  T* rhs = z + nv;                       // nv
+  T* bv = rhs + nv;                      // nc
+  T* kk = bv + nc;                       // nc
+  const T* bd = body + st * nb * 24;
+  const T I3[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+  const T Z3[3] = {T(0), T(0), T(0)};
+  for (int i = 0; i < nc * nv; ++i) K[i] = T(0);
+  for (int l = 0; l < V.nloops; ++l) {
+    const int32_t* li = V.li + 8 * l;
+    const T* lr = V.lr + 64 * l;
+    const int pred = li[0], succ = li[1], row0 = li[3], ncl = li[4];
+    const T* HpR = pred >= 0 ? bd + pred * 24 : I3; const T* Hpp = pred >= 0 ? bd + pred * 24 + 9 : Z3;
+    const T* HsR = succ >= 0 ? bd + succ * 24 : I3; const T* Hsp = succ >= 0 ? bd + succ * 24 + 9 : Z3;
+    T FbR[9], Fbp[3], FaR[9], Fap[3];
+    xf_compose(HpR, Hpp, lr, lr + 9, FbR, Fbp);        // before_to_root (src/mechanism_state.jl:707)
+    xf_compose(HsR, Hsp, lr + 12, lr + 21, FaR, Fap);  // after_to_root  (:708, :791)
+    T Tw[36];
+    for (int ci = 0; ci < ncl; ++ci) xforce(FaR, Fap, lr + 28 + 6 * ci, Tw + 6 * ci);
+    for (int e = li[5]; e < li[6]; ++e) {
+      const int bj = V.path[2 * e], sign = V.path[2 * e + 1];
+      const int t = V.jt[bj];
+      const int nvj = joint_nv(t);
+      const T* R = bd + bj * 24; const T* p = R + 9;
+      for (int col = 0; col < nvj; ++col) {
+        T sl[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, S[6];
+        if (t == RBD_JOINT_QUAT_FLOATING) sl[col] = T(1);
+        else if (t == RBD_JOINT_PRISMATIC) { sl[3] = V.axis[3 * bj]; sl[4] = V.axis[3 * bj + 1]; sl[5] = V.axis[3 * bj + 2]; }
+        else { sl[0] = V.axis[3 * bj]; sl[1] = V.axis[3 * bj + 1]; sl[2] = V.axis[3 * bj + 2]; }
+        xmotion(R, p, sl, S);
+        const int vi = V.voff[bj] + col;
+        for (int ci = 0; ci < ncl; ++ci) { const T d = dot6(Tw + 6 * ci, S); K[(row0 + ci) * nv + vi] = sign < 0 ? -d : d; }
+      }
+    }
+    // constraint_bias!
+    T Tp[6], Ts[6], Ap[6], As[6], cr[6], ba[6];
+    const T grav[6] = {T(0), T(0), T(0), T(-g0), T(-g1), T(-g2)};  // the exported accelerations carry -gravity from the root
+    for (int j = 0; j < 6; ++j) {
+      Tp[j] = pred >= 0 ? bd[pred * 24 + 12 + j] : T(0); Ts[j] = succ >= 0 ? bd[succ * 24 + 12 + j] : T(0);
+      Ap[j] = pred >= 0 ? bd[pred * 24 + 18 + j] - grav[j] : T(0); As[j] = succ >= 0 ? bd[succ * 24 + 18 + j] - grav[j] : T(0);
+    }
+    se3_comm(Ts, Tp, cr);
+    for (int j = 0; j < 6; ++j) ba[j] = cr[j] + (As[j] - Ap[j]);
+    if (stabilize) {
+      // Tn = inv(Fb) * Fa ; joint twist in frame_after ; Linearized SE(3) PD ; back to the root frame
+      T TnR[9], d3[3], Tnp[3], jt[6], jl[6], stab[6], sw[6], Rtp[3];
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) TnR[3 * i + j] = FbR[i] * FaR[j] + FbR[3 + i] * FaR[3 + j] + FbR[6 + i] * FaR[6 + j];
+      for (int k = 0; k < 3; ++k) d3[k] = Fap[k] - Fbp[k];
+      matTvec3(FbR, d3, Tnp);
+      for (int j = 0; j < 6; ++j) jt[j] = Ts[j] - Tp[j];
+      xmotion_inv(FaR, Fap, jt, jl);
+      const T psi[3] = {(TnR[7] - TnR[5]) / 2, (TnR[2] - TnR[6]) / 2, (TnR[3] - TnR[1]) / 2};  // spatial/util.jl:178-183
+      matTvec3(TnR, Tnp, Rtp);
+      for (int i = 0; i < 3; ++i) { stab[i] = -lr[24] * psi[i] - lr[25] * jl[i]; stab[3 + i] = -lr[26] * Rtp[i] - lr[27] * jl[3 + i]; }
+      xmotion(FaR, Fap, stab, sw);
+      for (int j = 0; j < 6; ++j) ba[j] -= sw[j];
+    }
+    for (int ci = 0; ci < ncl; ++ci) kk[row0 + ci] = dot6(Tw + 6 * ci, ba);
+  }
+  // L = chol(M)
+  for (int j = 0; j < nv; ++j)
+    for (int i = j; i < nv; ++i) L[j * nv + i] = Mg[((long)j * nv + i) * Lm.sk + st * Lm.sb];
+  bool bad = false;
+  for (int j = 0; j < nv; ++j) {
+    T d = L[j * nv + j];
+    for (int k = 0; k < j; ++k) d -= L[k * nv + j] * L[k * nv + j];
+    if (!(d > T(0))) bad = true;
+    d = SqrtT<T>::f(d);
+    L[j * nv + j] = d;
+    for (int i = j + 1; i < nv; ++i) {
+      T s = L[j * nv + i];
+      for (int k = 0; k < j; ++k) s -= L[k * nv + i] * L[k * nv + j];
+      L[j * nv + i] = s / d;
+    }
+  }
+  if (bad) atomicOr(notpd, 1);
+  auto fwd = [&](T* x) { for (int i = 0; i < nv; ++i) { T s = x[i]; for (int k = 0; k < i; ++k) s -= L[k * nv + i] * x[k]; x[i] = s / L[i * nv + i]; } };
+  auto bwd = [&](T* x) { for (int i = nv - 1; i >= 0; --i) { T s = x[i]; for (int k = i + 1; k < nv; ++k) s -= L[i * nv + k] * x[k]; x[i] = s / L[i * nv + i]; } };
+  for (int i = 0; i < nv; ++i) {
+    const T t = tau ? tau[(long)i * Lv.sk + st * Lv.sb] : T(0);
+    z[i] = t - cg[(long)i * Lv.sk + st * Lv.sb];
+    rhs[i] = z[i];
+  }
+  if (nc > 0) {
+    fwd(z);
+    for (int ci = 0; ci < nc; ++ci) { for (int k = 0; k < nv; ++k) Y[ci * nv + k] = K[ci * nv + k]; fwd(Y + ci * nv); }
+    for (int i = 0; i < nc; ++i) {
+      for (int j = 0; j < nc; ++j) { T s = T(0); for (int k = 0; k < nv; ++k) s += Y[i * nv + k] * Y[j * nv + k]; A[i * nc + j] = s; }
+      T s = kk[i]; for (int k = 0; k < nv; ++k) s += Y[i * nv + k] * z[k]; bv[i] = s;
+    }
+    // cyclic Jacobi eigen-decomposition of the PSD Schur matrix
+    for (int i = 0; i < nc; ++i) for (int j = 0; j < nc; ++j) E[i * nc + j] = (i == j) ? T(1) : T(0);
+    const T tiny = sizeof(T) == 8 ? T(1e-34) : T(1e-16);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+      T off = T(0), dg = T(0);
+      for (int i = 0; i < nc; ++i) { dg += A[i * nc + i] * A[i * nc + i]; for (int j = i + 1; j < nc; ++j) off += A[i * nc + j] * A[i * nc + j]; }
+      if (off <= dg * tiny) break;
+      for (int p = 0; p < nc - 1; ++p)
+        for (int q = p + 1; q < nc; ++q) {
+          const T apq = A[p * nc + q];
+          if (apq == T(0)) continue;
+          const T theta = (A[q * nc + q] - A[p * nc + p]) / (2 * apq);
+          const T at = theta >= T(0) ? theta : -theta;
+          const T t = (theta >= T(0) ? T(1) : T(-1)) / (at + SqrtT<T>::f(theta * theta + 1));
+          const T c = 1 / SqrtT<T>::f(t * t + 1), sn = t * c;
+          for (int k = 0; k < nc; ++k) { const T a = A[k * nc + p], b2 = A[k * nc + q]; A[k * nc + p] = c * a - sn * b2; A[k * nc + q] = sn * a + c * b2; }
+          for (int k = 0; k < nc; ++k) { const T a = A[p * nc + k], b2 = A[q * nc + k]; A[p * nc + k] = c * a - sn * b2; A[q * nc + k] = sn * a + c * b2; }
+          for (int k = 0; k < nc; ++k) { const T a = E[k * nc + p], b2 = E[k * nc + q]; E[k * nc + p] = c * a - sn * b2; E[k * nc + q] = sn * a + c * b2; }
+        }
+    }
+    T emax = T(0);
+    for (int i = 0; i < nc; ++i) if (A[i * nc + i] > emax) emax = A[i * nc + i];
+    for (int i = 0; i < nc; ++i) kk[i] = kk[i];  // (k kept for output below)
+    for (int i = 0; i < nc; ++i) Y[i] = T(0);    // reuse Y[0..nc) as lambda accumulator (Y no longer needed)
+    const T rcond = sizeof(T) == 8 ? T(1e-10) : T(1e-6);
+    for (int e = 0; e < nc; ++e) {
+      const T ev = A[e * nc + e];
+      if (ev > rcond * emax) {
+        T d = T(0);
+        for (int i = 0; i < nc; ++i) d += E[i * nc + e] * bv[i];
+        d /= ev;
+        for (int i = 0; i < nc; ++i) Y[i] += E[i * nc + e] * d;
+      }
+    }
+    for (int vi = 0; vi < nv; ++vi) { T s = T(0); for (int ci = 0; ci < nc; ++ci) s += K[ci * nv + vi] * Y[ci]; rhs[vi] -= s; }
+    for (int ci = 0; ci < nc; ++ci) {
+      if (lambda) lambda[(long)ci * Lc.sk + st * Lc.sb] = Y[ci];
+      kg[(long)ci * Lc.sk + st * Lc.sb] = kk[ci];
+      for (int vi = 0; vi < nv; ++vi) Kg[((long)vi * nc + ci) * Lk.sk + st * Lk.sb] = K[ci * nv + vi];
+    }
+  }
+  fwd(rhs); bwd(rhs);
+  for (int i = 0; i < nv; ++i) vdot[(long)i * Lv.sk + st * Lv.sb] = rhs[i];
+}
+
+template <typename T>
+hipError_t launch_loop_solve(const LoopView<T>& V, long B, int stabilize, const void* body, const void* M, const void* c, const void* tau, void* vdot,
+                             void* lambda, void* K, void* k, void* scratch, long scratch_stride, Layout Lm, Layout Lv, Layout Lc, Layout Lk,
+                             const double* gravity, int* notpd, hipStream_t s) {
+  hipLaunchKernelGGL(loop_solve_kernel<T>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, V, B, stabilize, (const T*)body, (const T*)M, (const T*)c,
+                     (const T*)tau, (T*)vdot, (T*)lambda, (T*)K, (T*)k, (T*)scratch, scratch_stride, Lm, Lv, Lc, Lk, gravity[0], gravity[1],
+                     gravity[2], notpd);
+  return hipGetLastError();
+}
+template hipError_t launch_loop_solve<double>(const LoopView<double>&, long, int, const void*, const void*, const void*, const void*, void*, void*, void*, void*, void*, long, Layout, Layout, Layout, Layout, const double*, int*, hipStream_t);
+template hipError_t launch_loop_solve<float>(const LoopView<float>&, long, int, const void*, const void*, const void*, const void*, void*, void*, void*, void*, void*, long, Layout, Layout, Layout, Layout, const double*, int*, hipStream_t);
 
 }  // namespace rbd

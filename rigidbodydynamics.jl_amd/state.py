@@ -227,7 +227,7 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
     st = _capi.lib().rbd_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
                                   _ptr(result.vd), _ptr(result.qd), _ptr(lam), ctypes.byref(opts))
     _raise(st, "rbd_dynamics")
-    if algo == _capi.ALGO_CRBA_CHOLESKY:
+    if algo == _capi.ALGO_CRBA_CHOLESKY or f.nc > 0:  # mechanisms with loop joints always take the reference's CRBA route
         st = _capi.lib().rbd_dynamics_result(state.ws.handle, state.batch, _ptr(result.massmatrix), _ptr(result.dynamicsbias),
                                              _ptr(result.constraintjacobian if f.nc else None),
                                              _ptr(result.constraintbias if f.nc else None), ctypes.byref(opts))

@@ -287,3 +287,55 @@ def test_not_positive_definite_is_reported(rbd, models):
     rbd.dynamics_(result, state, algorithm="crba")
     assert rbd.sync(state) == 8
     assert rbd.sync(state) == 0  # the flag is cleared once reported
+
+
+# ---- loop joints: BASELINE configs[4] — four-bar linkage (test/test_simulate.jl:127-190), B = 4096 fp64 -------------------
+def four_bar_inputs(rbd, B, seed):
+    rng = np.random.default_rng(seed)
+    q = np.tile(rbd.FOUR_BAR_INITIAL_Q, (B, 1))
+    q[:, 0] += rng.uniform(-0.05, 0.05, B)  # constraint violation exercises the Baumgarte term (SURVEY.md §8 d, config 5)
+    v = np.tile(rbd.FOUR_BAR_INITIAL_V, (B, 1))
+    tau = rng.random((B, 3))
+    return q, v, tau
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("stabilize", [True, False])
+def test_four_bar_dynamics_f64(rbd, oracle, models, stabilize, layout):
+    model = models["four_bar"]
+    B = 4096
+    q, v, tau = four_bar_inputs(rbd, B, 31)
+    state = rbd.MechanismState(model, B, layout=layout)
+    result = rbd.DynamicsResult(model, B, layout=layout)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    rbd.dynamics_(result, state, dev(tau, state), stabilization_gains="default" if stabilize else None)
+    assert rbd.sync(state) == 0
+    n = 256
+    ref = oracle.dynamics_loops(model, q[:n], v[:n], tau[:n], stabilize=stabilize)
+    got = host(result.vd, state)
+    assert np.abs(got[:n] - ref["vdot"]).max() <= 1e-10 * max(1.0, np.abs(ref["vdot"]).max())
+    nv, nc = model.nv, model.nc
+    K = host(result.constraintjacobian, state).reshape(B, nv, nc).transpose(0, 2, 1)  # nc×nv column-major per state -> [b, c, v]
+    k = host(result.constraintbias, state)
+    lam = host(result.lambda_, state)
+    assert np.abs(K[:n] - ref["K"]).max() <= 1e-12
+    assert np.abs(k[:n] - ref["k"]).max() <= 1e-10 * max(1.0, np.abs(ref["k"]).max())
+    # λ: both sides take the minimum-norm solution (gelsy! semantics); v̇ does not depend on the choice
+    assert np.abs(lam[:n] - ref["lam"]).max() <= 1e-8 * max(1.0, np.abs(ref["lam"]).max())
+    # size-independent properties at the full batch: the KKT conditions of dynamics! (mechanism_algorithms.jl:828-836)
+    Mg = host(result.massmatrix, state).reshape(B, nv, nv).transpose(0, 2, 1)
+    Ms = np.tril(Mg) + np.transpose(np.tril(Mg, -1), (0, 2, 1))
+    c = host(result.dynamicsbias, state)
+    r1 = np.einsum("bij,bj->bi", Ms, got) + c + np.einsum("bcv,bc->bv", K, lam) - tau
+    assert np.abs(r1).max() <= 1e-10
+    r2 = np.einsum("bcv,bv->bc", K, got) + k
+    assert np.abs(r2).max() <= 1e-8
+
+
+def test_inverse_dynamics_rejects_loops(rbd, models):
+    """inverse_dynamics! 'can currently only handle tree Mechanisms' (src/mechanism_algorithms.jl:549)."""
+    model = models["four_bar"]
+    state = rbd.MechanismState(model, 4)
+    with pytest.raises(RuntimeError, match="tree Mechanisms"):
+        rbd.inverse_dynamics_(torch.zeros_like(state.v), state, torch.zeros_like(state.v))
