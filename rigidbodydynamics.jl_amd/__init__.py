@@ -15,3 +15,4 @@ from .flatio import load_flat_model, save_flat_model
 from . import _capi
 from .state import (DimensionMismatch, DynamicsResult, MechanismState, dynamics_, dynamics_bias_, inverse_dynamics_, mass_matrix_,
                     mass_matrix_solve_, rand_, set_configuration_, set_velocity_, sync, zero_configuration_)
+from .distributed import gather_results, shard_range, shard_sizes
