@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librbd_hip.so")
+LIB_PATH = os.environ.get("RBD_LIB") or os.path.join(_HERE, "csrc", "librbd_hip.so")  # RBD_LIB: A/B kernel variants (experiments only)
 
 RBD_OK = 0
 F64, F32 = 0, 1

@@ -282,6 +282,18 @@ template <typename T> RBD_DEV void rot_quat(T w, T x, T y, T z, T* R) {
   R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
 }
 
+// reciprocal of a well-scaled positive number (joint-space inertia D): hardware estimate + 2 Newton steps (the IEEE
+// division expansion costs ~3x as many instructions; D is never denormal/huge for a physical mechanism)
+RBD_DEV double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  return r;
+}
+RBD_DEV float rcp_nr(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r);
+}
 RBD_DEV void sincos_t(double x, double* s, double* c) { sincos(x, s, c); }
 RBD_DEV void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
 

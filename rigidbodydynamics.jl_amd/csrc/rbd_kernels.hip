@@ -237,9 +237,10 @@ RBD_DEV void sweep_kinematics(const DevModel& M, const Body<T>& b, const T* XR, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// (RBD_DEBUG_STOP: phase-ablation aid for profiling; never taken in production, debug_stop == 0)
+// (RBD_DEBUG_STOP: phase-ablation aid, compiled only with -DRBD_PROFILE_PHASES (scripts/gpu_ablate.sh); absent from the product build)
 // Fused forward dynamics (ABA).  One launch: FK + twists, articulated inertias bottom-up, accelerations top-down.
 // ---------------------------------------------------------------------------------------------
+#ifdef RBD_PROFILE_PHASES
 #define RBD_DEBUG_STOP(phase, expr)                                  \
   if (M.debug_stop == (phase)) {                                     \
     T chk_[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};                \
@@ -247,8 +248,14 @@ RBD_DEV void sweep_kinematics(const DevModel& M, const Body<T>& b, const T* XR, 
     store_joint_v(b, vdot, Lv, chk_);                                \
     return;                                                          \
   }
+#else
+#define RBD_DEBUG_STOP(phase, expr)
+#endif
+#ifndef RBD_ABA_F32_WAVES
+#define RBD_ABA_F32_WAVES 3
+#endif
 template <typename T, bool INNER_FLOAT>
-__global__ __launch_bounds__(256, 2) void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
+__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 2 : RBD_ABA_F32_WAVES)) void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
                                                   const T* __restrict__ tau, const T* __restrict__ fext,
                                                   T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
   Body<T> b;
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void aba_kernel(DevModel M, long B, const T
   for (int l = M.nlevels - 1; l >= 1; --l) {
     if (b.level == l && one_dof) {
       sym6_mul(IA, S, U);
-      Dinv = T(1) / dot6(S, U);
+      Dinv = rcp_nr(dot6(S, U));
       u = tau0 - dot6(S, pA);
     }
     // Hand-off entries are formed one at a time and consumed at once (no 27-wide temporary): the first child is the
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void aba_kernel(DevModel M, long B, const T
   }
   if (b.level == 0 && one_dof) {
     sym6_mul(IA, S, U);
-    Dinv = T(1) / dot6(S, U);
+    Dinv = rcp_nr(dot6(S, U));
     u = tau0 - dot6(S, pA);
   }
 
@@ -396,36 +403,51 @@ __global__ __launch_bounds__(256, 2) void aba_kernel(DevModel M, long B, const T
   T acc[6], vd[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) { acc[k] = T(0); vd[k] = T(0); }
-  for (int l = 0; l < M.nlevels; ++l) {
+  auto finish_body = [&](const T* a_parent) {
+    T ap[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ap[k] = a_parent[k] + cb[k];
+    if (one_dof) {
+      vd[0] = (u - dot6(U, ap)) * Dinv;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] = ap[k] + S[k] * vd[0];
+    } else if (floating) {
+      // IA a_b = S^-T tau - pA ;  v̇ = S^-1 (a_b - a')
+      T rhs[6], d[6], Rs[9], ps[3];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rhs[k] = U[k] - pA[k];
+      sym6_solve(IA, rhs, acc);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d[k] = acc[k] - ap[k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rs[k] = stash[k][threadIdx.x];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ps[k] = stash[9 + k][threadIdx.x];
+      xmotion_inv(Rs, ps, d, vd);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] = ap[k];
+    }
+  };
+  {
+    // level 0: the parent is the world, a_world = -gravity (mechanism_algorithms.jl:405)
+    const T a0[6] = {T(0), T(0), T(0), T(-M.gravity[0]), T(-M.gravity[1]), T(-M.gravity[2])};
+    if (b.level == 0) finish_body(a0);
+  }
+#pragma unroll 1
+  for (int l = 1; l < M.nlevels; ++l) {
     T ap[6];
     pull_parent<T, 6>(M, b, l, acc, ap);
     if (b.level == l) {
-      if (b.parent < 0) {
-        ap[0] = ap[1] = ap[2] = T(0);
-        ap[3] = T(-M.gravity[0]); ap[4] = T(-M.gravity[1]); ap[5] = T(-M.gravity[2]);
-      }
+      if (INNER_FLOAT) {
+        finish_body(ap);
+      } else {  // every 6-dof joint is at level 0: only the cheap 1-dof / fixed update remains in the loop
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ap[k] += cb[k];
-      if (one_dof) {
-        vd[0] = (u - dot6(U, ap)) * Dinv;
+        for (int k = 0; k < 6; ++k) ap[k] += cb[k];
+        const T x = one_dof ? (u - dot6(U, ap)) * Dinv : T(0);
+        vd[0] = x;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] = ap[k] + S[k] * vd[0];
-      } else if (floating) {
-        // IA a_b = S^-T tau - pA ;  v̇ = S^-1 (a_b - a')
-        T rhs[6], d[6], Rs[9], ps[3];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) rhs[k] = U[k] - pA[k];
-        sym6_solve(IA, rhs, acc);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] = acc[k] - ap[k];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rs[k] = stash[k][threadIdx.x];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ps[k] = stash[9 + k][threadIdx.x];
-        xmotion_inv(Rs, ps, d, vd);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] = ap[k];
+        for (int k = 0; k < 6; ++k) acc[k] = ap[k] + S[k] * x;
       }
     }
   }
