@@ -339,3 +339,45 @@ def test_inverse_dynamics_rejects_loops(rbd, models):
     state = rbd.MechanismState(model, 4)
     with pytest.raises(RuntimeError, match="tree Mechanisms"):
         rbd.inverse_dynamics_(torch.zeros_like(state.v), state, torch.zeros_like(state.v))
+
+
+# ---- the C ABI driven directly (what the Julia shim does): host buffers (RBD_MEM_HOST), timing hooks, B = 0 ----------------
+def test_c_abi_host_memory_mode(rbd, oracle, models):
+    import ctypes
+    from rigidbodydynamics_jl_amd import _capi
+    from rigidbodydynamics_jl_amd.state import _Model
+    model = models["atlas_floating"]
+    B = 33
+    q, v, tau, fe = rand_inputs(rbd, model, B, 41, fext=True)
+    L = _capi.lib()
+    m = _Model(model)
+    ws = ctypes.c_void_p()
+    assert L.rbd_workspace_create(m.handle, B, 0, _capi.F64, None, ctypes.byref(ws)) == 0
+    opts = _capi.Opts(_capi.LAYOUT_AOS, _capi.MEM_HOST, _capi.ALGO_ABA, 1)
+    vd, qd = np.zeros((B, model.nv)), np.zeros((B, model.nq))
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert L.rbd_workspace_enable_timing(ws, 1) == 0
+    assert L.rbd_dynamics(ws, B, P(q), P(v), P(tau), P(fe), P(vd), P(qd), None, ctypes.byref(opts)) == 0
+    assert L.rbd_sync(ws) == 0
+    ms = ctypes.c_float()
+    assert L.rbd_workspace_last_kernel_ms(ws, ctypes.byref(ms)) == 0 and 0 < ms.value < 50
+    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    assert np.abs(vd - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(qd - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
+    # inverse dynamics, bias and mass matrix through host buffers
+    t = np.zeros((B, model.nv))
+    assert L.rbd_inverse_dynamics(ws, B, P(q), P(v), P(vd), P(fe), P(t), ctypes.byref(opts)) == 0
+    assert L.rbd_sync(ws) == 0
+    assert np.abs(t - tau).max() <= 1e-9 * max(1.0, np.abs(tau).max())   # round trip dynamics! -> inverse_dynamics!
+    Mh = np.full((B, model.nv * model.nv), np.nan)
+    assert L.rbd_mass_matrix(ws, B, P(q), P(Mh), ctypes.byref(opts)) == 0
+    assert L.rbd_sync(ws) == 0
+    Mr = oracle.mass_matrix(model, q)
+    il = np.tril_indices(model.nv)
+    got = Mh.reshape(B, model.nv, model.nv).transpose(0, 2, 1)
+    assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= 1e-10 * np.abs(Mr).max()
+    # B = 0 is a no-op; B > max_batch is a DimensionMismatch; null q is an ArgumentError
+    assert L.rbd_dynamics(ws, 0, P(q), P(v), None, None, P(vd), None, None, ctypes.byref(opts)) == 0
+    assert L.rbd_dynamics(ws, B + 1, P(q), P(v), None, None, P(vd), None, None, ctypes.byref(opts)) == 2
+    assert L.rbd_dynamics(ws, B, None, P(v), None, None, P(vd), None, None, ctypes.byref(opts)) == 1
+    assert L.rbd_workspace_destroy(ws) == 0
