@@ -559,6 +559,9 @@ static int FN(constraint_basis)(const rbd_loop_joint_t* lj, REAL* Tl /* 6 x nc, 
     case RBD_JOINT_FIXED:
       for (int c = 0; c < 6; ++c) Tl[6 * c + c] = 1;
       return nc;
+    case RBD_JOINT_QUAT_SPHERICAL: /* quaternion_spherical.jl:50-55 */
+      for (int c = 0; c < 3; ++c) Tl[6 * c + 3 + c] = 1;
+      return nc;
     case RBD_JOINT_QUAT_FLOATING: return 0;
     default: return -1;
   }

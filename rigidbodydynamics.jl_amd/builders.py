@@ -65,3 +65,54 @@ def four_bar_linkage() -> Mechanism:
 
 FOUR_BAR_INITIAL_Q = np.array([1.6707963267948966, -1.4591054166649482, 1.5397303602625536])  # test_simulate.jl:195-197
 FOUR_BAR_INITIAL_V = np.array([0.5, -0.47295, 0.341])                                          # :198-200
+
+
+# ---- random mechanisms in the style of the reference's test fixtures ------------------------------------------------
+def _rand_rotation(rng) -> np.ndarray:
+    q = rng.standard_normal(4)
+    w, x, y, z = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def rand_spatial_inertia(rng, frame) -> SpatialInertia:
+    """`rand(SpatialInertia{T}, frame)` src/spatial/motion_force_interaction.jl:178-196."""
+    ixx, iyy = rng.random() / 10.0, rng.random() / 10.0
+    lb, ub = abs(ixx - iyy), ixx + iyy
+    izz = rng.random() * (ub - lb) + lb
+    R = _rand_rotation(rng)
+    return SpatialInertia(frame, moment_about_com=R @ np.diag([ixx, iyy, izz]) @ R.T, com=rng.random(3) - 0.5, mass=rng.random())
+
+
+def rand_joint_type(rng, name: str):
+    """`rand(JointType)`: random unit axes (revolute.jl:30-33, prismatic.jl, planar.jl:37-42)."""
+    from .mechanism import Fixed, Planar, Prismatic, QuaternionFloating, QuaternionSpherical, Revolute, SinCosRevolute
+    ax = lambda: rng.standard_normal(3)
+    if name == "Planar":
+        x = ax(); x /= np.linalg.norm(x)
+        y = ax(); y -= (x @ y) * x
+        return Planar(x, y)
+    return {"Revolute": lambda: Revolute(ax()), "Prismatic": lambda: Prismatic(ax()), "SinCosRevolute": lambda: SinCosRevolute(ax()),
+            "Fixed": Fixed, "QuaternionFloating": QuaternionFloating, "QuaternionSpherical": QuaternionSpherical}[name]()
+
+
+def rand_tree_mechanism(rng, joint_types, parentselector=None) -> Mechanism:
+    """`rand_tree_mechanism(parentselector, jointtypes...)` src/mechanism_modification.jl:382-396: each new body hangs off a
+    parent chosen among ALL bodies (the world included) through a random joint pose."""
+    world = RigidBody("world")
+    mech = Mechanism(world)
+    parent = world
+    for i, name in enumerate(joint_types):
+        joint = Joint(f"joint{i + 1}", rand_joint_type(rng, name))
+        pose = Transform3D(joint.frame_before, parent.default_frame, _rand_rotation(rng), rng.random(3))
+        body = RigidBody(rand_spatial_inertia(rng, CartesianFrame3D(f"body{i + 1}")))
+        attach_(mech, parent, body, joint, joint_pose=pose, successor_pose=Transform3D(body.default_frame, joint.frame_after))
+        parent = parentselector(mech, rng) if parentselector else mech.bodies[rng.integers(len(mech.bodies))]
+    return mech
+
+
+def randmech(rng) -> Mechanism:
+    """test/test_mechanism_algorithms.jl:1-11 with SPQuatFloating (out of scope) replaced by QuaternionSpherical."""
+    return rand_tree_mechanism(rng, ["QuaternionFloating"] + ["Revolute"] * 5 + ["Fixed"] * 5 + ["Prismatic"] * 5 + ["Planar"] * 5 +
+                               ["QuaternionSpherical"] * 2 + ["SinCosRevolute"] * 2)

@@ -55,13 +55,13 @@ struct rbd_model {
   std::vector<double> rb;       // nb * RB_STRIDE
   std::vector<int32_t> nslots;  // nlevels
   uint64_t perm_down = 0;
-  int32_t inner_floating = 0;
+  int32_t inner_floating = 0, has3dof = 0;
   std::vector<int32_t> slot_of, order;  // reference body index <-> DFS pre-order slot
   std::vector<int32_t> dof_body;
   std::vector<int32_t> anc;     // nb * nlevels
   std::vector<rbd_loop_joint_t> loops;
   std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref;  // loop tables (reference body indices)
-  std::vector<double> loop_r, axis_ref;
+  std::vector<double> loop_r, axis_ref, axis2_ref;
 };
 
 struct rbd_ws {
@@ -77,7 +77,7 @@ struct rbd_ws {
   void* d_M = nullptr; void* d_c = nullptr; void* d_K = nullptr; void* d_k = nullptr;
   size_t d_M_bytes = 0, d_c_bytes = 0, d_K_bytes = 0, d_k_bytes = 0;
   void* d_body = nullptr; void* d_scratch = nullptr; size_t d_body_bytes = 0, d_scratch_bytes = 0;
-  void* d_loop_i = nullptr; void* d_loop_r = nullptr; void* d_loop_path = nullptr; void* d_jt_ref = nullptr; void* d_voff_ref = nullptr; void* d_axis_ref = nullptr;
+  void* d_loop_i = nullptr; void* d_loop_r = nullptr; void* d_loop_path = nullptr; void* d_jt_ref = nullptr; void* d_voff_ref = nullptr; void* d_axis_ref = nullptr; void* d_axis2_ref = nullptr;
   int* d_notpd = nullptr;  // device flag: some state's mass matrix was not positive definite (checked by rbd_sync)
   int32_t result_layout = RBD_LAYOUT_SOA; int32_t result_B = 0;
   // timing
@@ -130,7 +130,8 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     const int t = d->joint_type[i];
     const int nqi = joint_nq_host(t), nvi = joint_nv_host(t);
     if (nqi < 0) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
-    if (t == RBD_JOINT_PLANAR || t == RBD_JOINT_QUAT_SPHERICAL) { delete m; return RBD_ERR_UNSUPPORTED; }
+    if (t == RBD_JOINT_PLANAR || t == RBD_JOINT_QUAT_SPHERICAL) m->has3dof = 1;
+    if (t == RBD_JOINT_PLANAR && !d->joint_axis2) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
     if (d->q_offset[i] != qsum || d->v_offset[i] != vsum) { delete m; return RBD_ERR_DIMENSION_MISMATCH; }
     qsum += nqi; vsum += nvi;
     if (nvi > m->maxnvj) m->maxnvj = nvi;
@@ -208,6 +209,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   m->jt_ref.assign(d->joint_type, d->joint_type + nb);
   m->voff_ref.assign(d->v_offset, d->v_offset + nb);
   m->axis_ref.assign(d->joint_axis, d->joint_axis + 3 * nb);
+  if (d->joint_axis2) m->axis2_ref.assign(d->joint_axis2, d->joint_axis2 + 3 * nb); else m->axis2_ref.assign(3 * nb, 0.0);
   for (int l = 0; l < d->n_loops; ++l) {
     const rbd_loop_joint_t& lj = d->loops[l];
     const int nvl = joint_nv_host(lj.joint_type);
@@ -223,8 +225,10 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
       for (int r = 0; r < 3; ++r) { Tl[0 + r] = R[3 * r]; Tl[6 + r] = R[3 * r + 1]; Tl[12 + r] = R[3 * r + 2]; Tl[18 + 3 + r] = R[3 * r]; Tl[24 + 3 + r] = R[3 * r + 1]; }
     } else if (lj.joint_type == RBD_JOINT_FIXED) {
       for (int c = 0; c < 6; ++c) Tl[6 * c + c] = 1;
+    } else if (lj.joint_type == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl:50-55: angular 0, linear identity
+      for (int c = 0; c < 3; ++c) Tl[6 * c + 3 + c] = 1;
     } else if (lj.joint_type != RBD_JOINT_QUAT_FLOATING) {
-      delete m; return RBD_ERR_UNSUPPORTED;
+      delete m; return RBD_ERR_UNSUPPORTED;  // Planar loop joints carry no axes in rbd_loop_joint_t yet
     }
     const int path_begin = (int)m->loop_path.size() / 2;
     int a = lj.predecessor, b = lj.successor;  // TreePath(pred, succ): src/graphs/tree_path.jl:41-63
@@ -302,10 +306,12 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       if (dtype == RBD_F64) {
         st = upload(&w->d_loop_r, m->loop_r.data(), m->loop_r.size() * sizeof(double));
         if (st == RBD_OK) st = upload(&w->d_axis_ref, m->axis_ref.data(), m->axis_ref.size() * sizeof(double));
+        if (st == RBD_OK) st = upload(&w->d_axis2_ref, m->axis2_ref.data(), m->axis2_ref.size() * sizeof(double));
       } else {
-        std::vector<float> a(m->loop_r.begin(), m->loop_r.end()), b2(m->axis_ref.begin(), m->axis_ref.end());
+        std::vector<float> a(m->loop_r.begin(), m->loop_r.end()), b2(m->axis_ref.begin(), m->axis_ref.end()), b3(m->axis2_ref.begin(), m->axis2_ref.end());
         st = upload(&w->d_loop_r, a.data(), a.size() * sizeof(float));
         if (st == RBD_OK) st = upload(&w->d_axis_ref, b2.data(), b2.size() * sizeof(float));
+        if (st == RBD_OK) st = upload(&w->d_axis2_ref, b3.data(), b3.size() * sizeof(float));
       }
     }
   }
@@ -315,6 +321,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   dm.ib = (const int32_t*)w->d_ib; dm.rb = w->d_rb;
   dm.perm_down = m->perm_down;
   dm.inner_floating = m->inner_floating;
+  dm.has3dof = m->has3dof;
   for (int l = 0; l < MAX_LEVELS; ++l) dm.nslots[l] = (uint8_t)m->nslots[l];
   dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc;
   memcpy(dm.gravity, m->gravity, sizeof dm.gravity);
@@ -329,7 +336,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref};
+  void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
@@ -469,7 +476,7 @@ int dynamics_loops_t(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const 
   LoopView<T> V;
   V.nloops = m->nloops; V.nc = nc; V.nv = nv; V.nb = m->nb;
   V.li = (const int32_t*)w->d_loop_i; V.lr = (const T*)w->d_loop_r; V.path = (const int32_t*)w->d_loop_path;
-  V.jt = (const int32_t*)w->d_jt_ref; V.voff = (const int32_t*)w->d_voff_ref; V.axis = (const T*)w->d_axis_ref;
+  V.jt = (const int32_t*)w->d_jt_ref; V.voff = (const int32_t*)w->d_voff_ref; V.axis = (const T*)w->d_axis_ref; V.axis2 = (const T*)w->d_axis2_ref;
   Timed t(w);
   HIP_TRY(launch_rnea<T>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, w->d_body, Lq, Lv, Lf, w->stream));
   HIP_TRY(launch_crba<T>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));

@@ -29,6 +29,7 @@ struct DevModel {
   int32_t nlevels;    // tree depth
   int32_t maxchild;   // max children of any body (<= IB_MAXCHILD)
   int32_t maxnvj;     // max velocity dimension of any tree joint
+  int32_t has3dof;     // some tree joint is QuaternionSpherical / Planar (selects the NDOF = 3 aba_kernel instantiation)
   int32_t inner_floating;  // some 6-dof joint is not attached to the world (selects the general aba_kernel instantiation)
   int32_t debug_stop; // profiling aid (env RBD_ABA_STOP_AFTER): aba_kernel exits after phase 1..5 with a checksum store; 0 = full
   const int32_t* ib;  // [nb * IB_STRIDE], indexed by slot; parent/children are slots, IB_ORIG the reference body index
@@ -54,6 +55,7 @@ template <typename T> struct LoopView {
   const int32_t* jt;   // [nb] joint type by reference body index
   const int32_t* voff; // [nb]
   const T* axis;       // [nb*3]
+  const T* axis2;      // [nb*3] (Planar y axis)
 };
 
 #define RBD_DEV __device__ __forceinline__

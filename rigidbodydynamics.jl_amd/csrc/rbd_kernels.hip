@@ -23,10 +23,12 @@ template <typename T> struct Body {
 };
 
 template <typename T> RBD_DEV int joint_nq(int t) {
-  return t == RBD_JOINT_QUAT_FLOATING ? 7 : t == RBD_JOINT_SINCOS_REVOLUTE ? 2 : (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC) ? 1 : 0;
+  return t == RBD_JOINT_QUAT_FLOATING ? 7 : t == RBD_JOINT_QUAT_SPHERICAL ? 4 : t == RBD_JOINT_PLANAR ? 3 : t == RBD_JOINT_SINCOS_REVOLUTE ? 2
+         : (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC) ? 1 : 0;
 }
 RBD_DEV int joint_nv(int t) {
-  return t == RBD_JOINT_QUAT_FLOATING ? 6 : (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC || t == RBD_JOINT_SINCOS_REVOLUTE) ? 1 : 0;
+  return t == RBD_JOINT_QUAT_FLOATING ? 6 : (t == RBD_JOINT_QUAT_SPHERICAL || t == RBD_JOINT_PLANAR) ? 3
+         : (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC || t == RBD_JOINT_SINCOS_REVOLUTE) ? 1 : 0;
 }
 
 
@@ -111,6 +113,16 @@ template <typename T> RBD_DEV void local_transform(const Body<T>& b, const T* rb
   } else if (b.jtype == RBD_JOINT_QUAT_FLOATING) {
     rot_quat(qj[0], qj[1], qj[2], qj[3], Rj);
     pj[0] = qj[4]; pj[1] = qj[5]; pj[2] = qj[6];
+  } else if (b.jtype == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl:39-42
+    rot_quat(qj[0], qj[1], qj[2], qj[3], Rj);
+  } else if (b.jtype == RBD_JOINT_PLANAR) {  // planar.jl:65-70: rotate about x × y after translating in the x-y plane
+    const T ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
+    T az[3], s, c;
+    cross3(ax, ay, az);
+    sincos_t(qj[2], &s, &c);
+    rot_axis_sc(az, s, c, Rj);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pj[k] = ax[k] * qj[0] + ay[k] * qj[1];
   }
   T XpR[9], Xpp[3];
 #pragma unroll
@@ -136,6 +148,36 @@ template <typename T> RBD_DEV void local_joint_motion(const Body<T>& b, const T*
   } else if (b.jtype == RBD_JOINT_QUAT_FLOATING) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = vj[k];
+  } else if (b.jtype == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl:98-104
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = vj[k];
+  } else if (b.jtype == RBD_JOINT_PLANAR) {  // planar.jl:72-77: linear = x v1 + y v2, angular = (x × y) v3
+    const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
+    T az[3];
+    cross3(ax, ay, az);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k] = az[k] * vj[2]; o[3 + k] = ax[k] * vj[0] + ay[k] * vj[1]; }
+  }
+}
+
+// column k of the local motion subspace of a joint of type t (axis, axis2 in frame_before == frame_after axes):
+// revolute.jl:83-89, prismatic.jl:93-99, quaternion_floating.jl:85-91, quaternion_spherical.jl:43-49, planar.jl:79-86
+template <typename T> RBD_DEV void subspace_col(int t, const T* ax, const T* ay, int k, T* o) {
+#pragma unroll
+  for (int j = 0; j < 6; ++j) o[j] = T(0);
+  if (t == RBD_JOINT_QUAT_FLOATING) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) o[j] = (j == k) ? T(1) : T(0);
+  } else if (t == RBD_JOINT_QUAT_SPHERICAL) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[j] = (j == k) ? T(1) : T(0);
+  } else if (t == RBD_JOINT_PRISMATIC) {
+    o[3] = ax[0]; o[4] = ax[1]; o[5] = ax[2];
+  } else if (t == RBD_JOINT_PLANAR) {
+    if (k == 2) { T az[3]; cross3(ax, ay, az); o[0] = az[0]; o[1] = az[1]; o[2] = az[2]; }
+    else { const T* a = (k == 0) ? ax : ay; o[3] = a[0]; o[4] = a[1]; o[5] = a[2]; }
+  } else if (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_SINCOS_REVOLUTE) {
+    o[0] = ax[0]; o[1] = ax[1]; o[2] = ax[2];
   }
 }
 
@@ -180,6 +222,18 @@ template <typename T> RBD_DEV void store_qdot(const Body<T>& b, T* __restrict__ 
     T R[9];
     rot_quat(w, x, y, z, R);
     matvec3(R, vj + 3, o + 4);
+  } else if (b.jtype == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl:74-78
+    const T w = qj[0], x = qj[1], y = qj[2], z = qj[3];
+    o[0] = (-x * vj[0] - y * vj[1] - z * vj[2]) / 2;
+    o[1] = (w * vj[0] - z * vj[1] + y * vj[2]) / 2;
+    o[2] = (z * vj[0] + w * vj[1] - x * vj[2]) / 2;
+    o[3] = (-y * vj[0] + x * vj[1] + w * vj[2]) / 2;
+  } else if (b.jtype == RBD_JOINT_PLANAR) {  // planar.jl velocity_to_configuration_derivative!: q̇_lin = Rot2(θ) v_lin
+    T sn, cs;
+    sincos_t(qj[2], &sn, &cs);
+    o[0] = cs * vj[0] - sn * vj[1];
+    o[1] = sn * vj[0] + cs * vj[1];
+    o[2] = vj[2];
   }
   const int n = joint_nq<T>(b.jtype);
 #pragma unroll
@@ -254,10 +308,16 @@ RBD_DEV void sweep_kinematics(const DevModel& M, const Body<T>& b, const T* XR, 
 #ifndef RBD_ABA_F32_WAVES
 #define RBD_ABA_F32_WAVES 3
 #endif
-template <typename T, bool INNER_FLOAT>
-__global__ __launch_bounds__(256, (sizeof(T) == 8 ? 2 : RBD_ABA_F32_WAVES)) void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
-                                                  const T* __restrict__ tau, const T* __restrict__ fext,
-                                                  T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
+// packed symmetric NDOF x NDOF index
+__host__ __device__ constexpr int DI(int k, int m, int n) { return k <= m ? (k * n - k * (k - 1) / 2 + (m - k)) : (m * n - m * (m - 1) / 2 + (k - m)); }
+
+// NDOF = 1: every non-floating tree joint has one degree of freedom (the common case, e.g. Atlas);
+// NDOF = 3: the mechanism also has QuaternionSpherical / Planar tree joints (S is 6x3, D a 3x3 SPD block).
+template <typename T, bool INNER_FLOAT, int NDOF>
+__global__ __launch_bounds__(256, (sizeof(T) == 8 ? (NDOF == 1 ? 2 : 1) : (NDOF == 1 ? RBD_ABA_F32_WAVES : 2)))
+void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau,
+                const T* __restrict__ fext, T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
+  constexpr int ND2 = NDOF * (NDOF + 1) / 2;
   Body<T> b;
   load_body(M, B, b);
   const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
@@ -277,14 +337,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 2 : RBD_ABA_F32_WAVES)) void
   RBD_DEBUG_STOP(3, R[0] + R[4] + R[8] + p[0] + Tw[0] + Tw[5] + vJ[2]);
 
   // per-body, all lanes in parallel: motion subspace, bias term, inertia, bias force
-  const bool one_dof = (b.jtype == RBD_JOINT_REVOLUTE || b.jtype == RBD_JOINT_PRISMATIC || b.jtype == RBD_JOINT_SINCOS_REVOLUTE);
   const bool floating = (b.jtype == RBD_JOINT_QUAT_FLOATING);
-  T S[6];
-  {
-    T one[6] = {T(1), T(0), T(0), T(0), T(0), T(0)};
-    T sl[6];
-    local_joint_motion(b, rb, one, sl);  // S_local for 1-dof joints
-    xmotion(R, p, sl, S);
+  const int nvj = joint_nv(b.jtype);
+  const int ndof = floating ? 0 : nvj;  // columns handled through (S, U, D); the 6-dof joint has its own closed form
+  T S[NDOF][6];
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) {
+    T e[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, sl[6];
+    e[k] = T(1);
+    local_joint_motion(b, rb, e, sl);  // column k of the local motion subspace
+    xmotion(R, p, sl, S[k]);
+    if (k >= ndof) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) S[k][j] = T(0);
+    }
   }
   T cb[6];
   se3_comm(Tw, vJ, cb);  // [T_b, vJ]: bias acceleration increment (mechanism_state.jl:814-830)
@@ -311,44 +377,85 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 2 : RBD_ABA_F32_WAVES)) void
     for (int k = 0; k < 6; ++k) pA[k] = T(0);
   }
 
-  RBD_DEBUG_STOP(4, IA[0] + IA[20] + IA[7] + pA[0] + pA[5] + cb[1] + S[2]);
+  RBD_DEBUG_STOP(4, IA[0] + IA[20] + IA[7] + pA[0] + pA[5] + cb[1] + S[0][2]);
 
   // bottom-up: articulated-body inertias and bias forces.  Lanes at level l finish (U, D, u); every lane then forms
   // its hand-off (Ia, pa) = (IA - U D^-1 U', pA + Ia cb + U D^-1 u) — only the hand-offs of level-l lanes are pulled.
-  // (6-dof joints keep pa = S^-T tau — the wrench transform of tau to the root frame — in U, which they do not
+  // (6-dof joints keep pa = S^-T tau — the wrench transform of tau to the root frame — in U[0], which they do not
   //  otherwise need, and park their transform in LDS until the top-down sweep: cold data out of the VGPR budget.)
-  T U[6], Dinv = T(0), u = T(0);
+  T U[NDOF][6], Dinv[ND2], u[NDOF];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) U[k] = T(0);
+  for (int k = 0; k < NDOF; ++k) {
+    u[k] = T(0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) U[k][j] = T(0);
+  }
+#pragma unroll
+  for (int k = 0; k < ND2; ++k) Dinv[k] = T(0);
   __shared__ T stash[12][256];
   if (floating) {
-    xforce(R, p, tj, U);
+    xforce(R, p, tj, U[0]);
 #pragma unroll
     for (int k = 0; k < 9; ++k) stash[k][threadIdx.x] = R[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) stash[9 + k][threadIdx.x] = p[k];
   }
-  const T tau0 = tj[0];
+  T tauj[NDOF];
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) tauj[k] = tj[k];
   const bool inner_floating = floating && (b.parent >= 0);
+  auto finish_joint = [&]() {  // U = IA S, D = S'U, u = tau - S'pA, Dinv = D^-1 on the active ndof x ndof block
+    T D[ND2];
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) sym6_mul(IA, S[k], U[k]);
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) {
+      u[k] = tauj[k] - dot6(S[k], pA);
+#pragma unroll
+      for (int m = k; m < NDOF; ++m) D[DI(k, m, NDOF)] = dot6(S[k], U[m]);
+    }
+    if (NDOF == 1) {
+      Dinv[0] = rcp_nr(D[0]);
+    } else {
+      if (ndof == 1) {
+        Dinv[DI(0, 0, NDOF)] = rcp_nr(D[DI(0, 0, NDOF)]);
+      } else {  // 3x3 SPD inverse by cofactors
+        const T d00 = D[DI(0, 0, NDOF)], d01 = D[DI(0, 1, NDOF)], d02 = D[DI(0, 2, NDOF)], d11 = D[DI(1, 1, NDOF)], d12 = D[DI(1, 2, NDOF)],
+                d22 = D[DI(2, 2, NDOF)];
+        const T c00 = d11 * d22 - d12 * d12, c01 = d02 * d12 - d01 * d22, c02 = d01 * d12 - d02 * d11;
+        const T c11 = d00 * d22 - d02 * d02, c12 = d01 * d02 - d00 * d12, c22 = d00 * d11 - d01 * d01;
+        const T idet = rcp_nr(d00 * c00 + d01 * c01 + d02 * c02);
+        Dinv[DI(0, 0, NDOF)] = c00 * idet; Dinv[DI(0, 1, NDOF)] = c01 * idet; Dinv[DI(0, 2, NDOF)] = c02 * idet;
+        Dinv[DI(1, 1, NDOF)] = c11 * idet; Dinv[DI(1, 2, NDOF)] = c12 * idet; Dinv[DI(2, 2, NDOF)] = c22 * idet;
+      }
+    }
+  };
 #pragma unroll 1
   for (int l = M.nlevels - 1; l >= 1; --l) {
-    if (b.level == l && one_dof) {
-      sym6_mul(IA, S, U);
-      Dinv = rcp_nr(dot6(S, U));
-      u = tau0 - dot6(S, pA);
-    }
+    if (b.level == l && ndof > 0) finish_joint();
     // Hand-off entries are formed one at a time and consumed at once (no 27-wide temporary): the first child is the
     // next lane (DPP shift); further children (branch points only) re-form the entries and pull them with ds_bpermute.
     // Givers sit at level l (mask 0: their own IA/pA are untouched), takers at level l-1.
     const T kI = (INNER_FLOAT && inner_floating) ? T(0) : T(1);
     const T m0 = ((b.level == l - 1) && (b.nchild >= 1)) ? T(1) : T(0);
+    T W[NDOF][6];  // W = U D^-1
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        T w = T(0);
+#pragma unroll
+        for (int m = 0; m < NDOF; ++m) w += U[m][i] * Dinv[DI(k, m, NDOF)];
+        W[k][i] = w;
+      }
     T Iac[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const T ud = U[i] * Dinv;
 #pragma unroll
       for (int j = i; j < 6; ++j) {
-        T g = IA[SI(i, j)] - ud * U[j];
+        T g = IA[SI(i, j)];
+#pragma unroll
+        for (int k = 0; k < NDOF; ++k) g -= W[k][i] * U[k][j];
         if (INNER_FLOAT) g *= kI;
         Iac[i] += g * cb[j];
         if (j > i) Iac[j] += g * cb[i];
@@ -356,14 +463,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 2 : RBD_ABA_F32_WAVES)) void
       }
     }
     T gp[6];
-    {
-      const T udp = u * Dinv;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        gp[k] = pA[k] + Iac[k] + U[k] * udp;
-        if (INNER_FLOAT) gp[k] = inner_floating ? U[k] : gp[k];
-        pA[k] += from_next_lane(gp[k]) * m0;
-      }
+    for (int k = 0; k < 6; ++k) {
+      T x = pA[k] + Iac[k];
+#pragma unroll
+      for (int m = 0; m < NDOF; ++m) x += W[m][k] * u[m];
+      gp[k] = x;
+      if (INNER_FLOAT) gp[k] = inner_floating ? U[0][k] : gp[k];
+      pA[k] += from_next_lane(gp[k]) * m0;
     }
     const int ns = (int)M.nslots[l];
 #pragma unroll 1
@@ -373,11 +480,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 2 : RBD_ABA_F32_WAVES)) void
       const T mask = take ? T(1) : T(0);
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const T ud = U[i] * Dinv;
         T tmp[6];
 #pragma unroll
         for (int j = i; j < 6; ++j) {
-          T g = IA[SI(i, j)] - ud * U[j];
+          T g = IA[SI(i, j)];
+#pragma unroll
+          for (int k = 0; k < NDOF; ++k) g -= W[k][i] * U[k][j];
           if (INNER_FLOAT) g *= kI;
           tmp[j] = shfl(g, src);
         }
@@ -391,31 +499,39 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 2 : RBD_ABA_F32_WAVES)) void
       for (int k = 0; k < 6; ++k) pA[k] += tp[k] * mask;
     }
   }
-  if (b.level == 0 && one_dof) {
-    sym6_mul(IA, S, U);
-    Dinv = rcp_nr(dot6(S, U));
-    u = tau0 - dot6(S, pA);
-  }
+  if (b.level == 0 && ndof > 0) finish_joint();
 
-  RBD_DEBUG_STOP(5, IA[0] + IA[20] + pA[0] + U[0] + u + Dinv);
+  RBD_DEBUG_STOP(5, IA[0] + IA[20] + pA[0] + U[0][0] + u[0] + Dinv[0]);
 
   // top-down: accelerations and v̇
   T acc[6], vd[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) { acc[k] = T(0); vd[k] = T(0); }
+  auto joint_accel = [&](const T* ap) {  // v̇ = D^-1 (u - U'a'), a = a' + S v̇   (ap = a' = a_parent + cb)
+    T r[NDOF];
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) r[k] = u[k] - dot6(U[k], ap);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = ap[k];
+#pragma unroll
+    for (int k = 0; k < NDOF; ++k) {
+      T x = T(0);
+#pragma unroll
+      for (int m = 0; m < NDOF; ++m) x += Dinv[DI(k, m, NDOF)] * r[m];
+      vd[k] = x;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[j] += S[k][j] * x;
+    }
+  };
   auto finish_body = [&](const T* a_parent) {
     T ap[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) ap[k] = a_parent[k] + cb[k];
-    if (one_dof) {
-      vd[0] = (u - dot6(U, ap)) * Dinv;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) acc[k] = ap[k] + S[k] * vd[0];
-    } else if (floating) {
+    if (floating) {
       // IA a_b = S^-T tau - pA ;  v̇ = S^-1 (a_b - a')
       T rhs[6], d[6], Rs[9], ps[3];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) rhs[k] = U[k] - pA[k];
+      for (int k = 0; k < 6; ++k) rhs[k] = U[0][k] - pA[k];
       sym6_solve(IA, rhs, acc);
 #pragma unroll
       for (int k = 0; k < 6; ++k) d[k] = acc[k] - ap[k];
@@ -425,8 +541,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 2 : RBD_ABA_F32_WAVES)) void
       for (int k = 0; k < 3; ++k) ps[k] = stash[9 + k][threadIdx.x];
       xmotion_inv(Rs, ps, d, vd);
     } else {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) acc[k] = ap[k];
+      joint_accel(ap);  // fixed joints: S = U = 0 => a = a'
     }
   };
   {
@@ -441,13 +556,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 8 ? 2 : RBD_ABA_F32_WAVES)) void
     if (b.level == l) {
       if (INNER_FLOAT) {
         finish_body(ap);
-      } else {  // every 6-dof joint is at level 0: only the cheap 1-dof / fixed update remains in the loop
+      } else {  // every 6-dof joint is at level 0: only the cheap update remains in the loop
 #pragma unroll
         for (int k = 0; k < 6; ++k) ap[k] += cb[k];
-        const T x = one_dof ? (u - dot6(U, ap)) * Dinv : T(0);
-        vd[0] = x;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] = ap[k] + S[k] * x;
+        joint_accel(ap);
       }
     }
   }
@@ -522,11 +634,15 @@ __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* 
   if (b.jtype == RBD_JOINT_QUAT_FLOATING) {
     xforce_inv(R, p, w, out);
   } else {
-    T one[6] = {T(1), T(0), T(0), T(0), T(0), T(0)};
-    T sl[6], S[6];
-    local_joint_motion(b, rb, one, sl);
-    xmotion(R, p, sl, S);
-    out[0] = dot6(S, w);
+    const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
+    const int ncol = M.has3dof ? 3 : 1;  // uniform
+    for (int k = 0; k < ncol; ++k) {
+      T sl[6], S[6];
+      subspace_col(b.jtype, ax, ay, k, sl);
+      xmotion(R, p, sl, S);
+      const T d = dot6(S, w);
+      if (k == 0) out[0] = d; else if (k == 1) out[1] = d; else out[2] = d;
+    }
   }
   store_joint_v(b, tau, Lv, out);
 }
@@ -589,14 +705,10 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
   // 1-dof: one column; floating: 6 columns = Xm(H) e_k.
   for (int ci = 0; ci < 6; ++ci) {
     if (ci >= M.maxnvj) break;  // uniform
-    T e[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     T sl[6], Si[6], Fi[6];
-    if (b.jtype == RBD_JOINT_QUAT_FLOATING) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) sl[k] = (k == ci) ? T(1) : T(0);
-    } else {
-      e[0] = T(1);
-      local_joint_motion(b, rb, e, sl);
+    {
+      const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
+      subspace_col(b.jtype, ax, ay, ci, sl);
     }
     xmotion(R, p, sl, Si);
     mul_inertia(Ic, Si, Fi);
@@ -614,22 +726,18 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
       for (int j = 0; j < 3; ++j) ap[j] = shfl(p[j], src);
       const int ajt = __shfl(b.jtype, src, 64);
       const int avoff = __shfl(b.voff, src, 64);
-      T aax[3];
+      T aax[3], aay[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) aax[j] = shfl(rb[RB_AXIS + j], src);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) aay[j] = M.has3dof ? shfl(rb[RB_AXIS2 + j], src) : T(0);
       if (have_col && a >= 0) {
         const int anv = joint_nv(ajt);
         for (int cj = 0; cj < anv; ++cj) {
           const long col = avoff + cj;
           if (col > row) continue;  // lower triangle only (self block)
-          T slj[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, Sj[6];
-          if (ajt == RBD_JOINT_QUAT_FLOATING) {
-            slj[cj] = T(1);
-          } else if (ajt == RBD_JOINT_PRISMATIC) {
-            slj[3] = aax[0]; slj[4] = aax[1]; slj[5] = aax[2];
-          } else {
-            slj[0] = aax[0]; slj[1] = aax[1]; slj[2] = aax[2];
-          }
+          T slj[6], Sj[6];
+          subspace_col(ajt, aax, aay, cj, slj);
           xmotion(aR, ap, slj, Sj);
           Mout[(col * nv + row) * Lm.sk + b.state * Lm.sb] = dot6(Fi, Sj);
         }
@@ -662,12 +770,12 @@ static inline dim3 grid_for(const DevModel& M, long B, int block) {
 template <typename T>
 hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
                       void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
-  if (M.inner_floating)
-    hipLaunchKernelGGL((aba_kernel<T, true>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
-                       (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
-  else
-    hipLaunchKernelGGL((aba_kernel<T, false>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
-                       (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
+#define RBD_LAUNCH_ABA(IF, ND)                                                                                                  \
+  hipLaunchKernelGGL((aba_kernel<T, IF, ND>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)tau, \
+                     (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf)
+  if (M.has3dof) { if (M.inner_floating) RBD_LAUNCH_ABA(true, 3); else RBD_LAUNCH_ABA(false, 3); }
+  else { if (M.inner_floating) RBD_LAUNCH_ABA(true, 1); else RBD_LAUNCH_ABA(false, 1); }
+#undef RBD_LAUNCH_ABA
   return hipGetLastError();
 }
 template <typename T>
@@ -840,10 +948,8 @@ __global__ __launch_bounds__(64) void loop_solve_kernel(LoopView<T> V, long B, i
       const int nvj = joint_nv(t);
       const T* R = bd + bj * 24; const T* p = R + 9;
       for (int col = 0; col < nvj; ++col) {
-        T sl[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, S[6];
-        if (t == RBD_JOINT_QUAT_FLOATING) sl[col] = T(1);
-        else if (t == RBD_JOINT_PRISMATIC) { sl[3] = V.axis[3 * bj]; sl[4] = V.axis[3 * bj + 1]; sl[5] = V.axis[3 * bj + 2]; }
-        else { sl[0] = V.axis[3 * bj]; sl[1] = V.axis[3 * bj + 1]; sl[2] = V.axis[3 * bj + 2]; }
+        T sl[6], S[6];
+        subspace_col(t, V.axis + 3 * bj, V.axis2 + 3 * bj, col, sl);
         xmotion(R, p, sl, S);
         const int vi = V.voff[bj] + col;
         for (int ci = 0; ci < ncl; ++ci) { const T d = dot6(Tw + 6 * ci, S); K[(row0 + ci) * nv + vi] = sign < 0 ? -d : d; }

@@ -37,6 +37,11 @@ def models(rbd):
     m["double_pendulum"] = rbd.flatten(rbd.double_pendulum())
     m["quickstart_pendulum"] = rbd.flatten(rbd.quickstart_double_pendulum())
     m["four_bar"] = rbd.flatten(rbd.four_bar_linkage())
+    # test/test_mechanism_algorithms.jl:1-11 style random trees: mixed joint types, several roots, inner floating joints
+    for seed in (1, 2, 3):
+        m[f"randmech{seed}"] = rbd.flatten(rbd.randmech(np.random.default_rng(seed)))
+    # a 6-dof joint in the middle of a chain (maximal-coordinates style) and a spherical/planar mix below it
+    m["inner_floating"] = rbd.flatten(rbd.rand_tree_mechanism(np.random.default_rng(7), ["Revolute", "Prismatic", "QuaternionFloating", "Revolute", "QuaternionSpherical", "Planar", "QuaternionFloating", "Revolute"]))
     return m
 
 

@@ -16,7 +16,7 @@ from conftest import rand_inputs
 
 pytestmark = pytest.mark.gpu
 
-MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf"]
+MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf", "randmech1", "randmech2", "randmech3", "inner_floating"]
 TD = {"f64": torch.float64, "f32": torch.float32}
 ND = {"f64": np.float64, "f32": np.float32}
 

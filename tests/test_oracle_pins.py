@@ -84,7 +84,7 @@ def test_atlas_flattening_checksums(models):
     assert (ax.n_bodies, ax.nq, ax.nv) == (30, 30, 30)
 
 
-MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum"]
+MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "randmech1", "randmech2", "randmech3", "inner_floating"]
 
 
 @pytest.mark.parametrize("name", MODELS)
