@@ -147,10 +147,15 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
         torch.cuda.synchronize(device)
-        g0 = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, result.vd)  # the RCCL gather of DynamicsResult.v̇ over xGMI
-        torch.cuda.synchronize(device)
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        try:
+            dist.all_gather_into_tensor(gathered, result.vd)  # warm-up (RCCL channel setup)
+            torch.cuda.synchronize(device)
+            g0 = time.perf_counter()
+            dist.all_gather_into_tensor(gathered, result.vd)  # the RCCL gather of DynamicsResult.v̇ over xGMI
+            torch.cuda.synchronize(device)
+            gather_ms = (time.perf_counter() - g0) * 1e3
+        except Exception as e:  # the gather is outside the timed region: never lose the measurement to it
+            gather_ms = f"failed: {type(e).__name__}: {e}"
 
     # sanity: the timed work produced the right answer (checked outside the timed region, small sample)
     import oracle

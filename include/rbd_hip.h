@@ -9,6 +9,7 @@
  *   rbd_mass_matrix       <->  mass_matrix!(M::Symmetric, state)       src/mechanism_algorithms.jl:248-272
  *   rbd_mass_matrix_solve <->  dynamics_solve!(result, τ) (no-loop branch) src/mechanism_algorithms.jl:747-822
  *   rbd_model_create      <->  MechanismState(mechanism) index tables  src/mechanism_state.jl:79-172
+ *   rbd_simulate          <->  simulate(state0, T; Δt) / MuntheKaasIntegrator.step  src/simulate.jl:36-55, src/ode_integrators.jl:233-299
  *
  * The reference is pure Julia and has no FFI layer; this header is what a
  * Julia `ccall` shim (julia/RigidBodyDynamicsGPU.jl) binds.
@@ -171,6 +172,18 @@ int rbd_mass_matrix_solve(rbd_ws_t* ws, int32_t B, const void* q, const void* rh
  * c: nv, K: nc×nv column-major, k: nc; layout per opts.                        */
 int rbd_dynamics_result(rbd_ws_t* ws, int32_t B, void* M, void* c, void* K, void* k,
                         const rbd_opts_t* opts);
+
+/* ---- the caller of the hot path: batched `simulate` --------------------------------------------
+ * simulate(state0, final_time; Δt) src/simulate.jl:36-55 == MuntheKaasIntegrator.step (src/ode_integrators.jl:233-299) with
+ * the runge_kutta_4 tableau (:48-55), for every state of the batch in lockstep, entirely on the device (no host round trip
+ * per stage).  rbd_simulate: nsteps steps with constant tau / fext (the reference's default control is zero_torque!); q, v
+ * are advanced in place.  rbd_mk_stage: one stage at a time for callers that evaluate a controller per stage —
+ * stage 0 snapshots (q, v) as the base point and leaves the stage-1 state in (q, v); stage s = 1..3 takes the v̇ of the
+ * previous stage state and leaves the next stage state in (q, v); stage 4 takes the last v̇ and leaves the end-of-step
+ * state.  Loop mechanisms use the loop branch with opts->stabilization.                                              */
+int rbd_simulate(rbd_ws_t* ws, int32_t B, void* q, void* v, const void* tau, const void* fext, double dt, int32_t nsteps,
+                 const rbd_opts_t* opts);
+int rbd_mk_stage(rbd_ws_t* ws, int32_t B, int32_t stage, double dt, void* q, void* v, const void* vdot_prev, const rbd_opts_t* opts);
 
 /* ---- diagnostics ------------------------------------------------------------ */
 const char* rbd_status_string(int status);

@@ -1,0 +1,178 @@
+"""TEST INFRASTRUCTURE, NOT PRODUCT CODE — numpy restatement of the reference's `simulate` path:
+
+  simulate(state0, final_time; Δt)             src/simulate.jl:36-55  (zero_torque! control, RK4 tableau, every step stored)
+  MuntheKaasIntegrator.step                    src/ode_integrators.jl:233-299
+  runge_kutta_4                                src/ode_integrators.jl:48-55
+  local_coordinates! / global_coordinates!     src/joint_types/joint_types.jl:9-18 (default), sin_cos_revolute.jl:173-196,
+                                               quaternion_spherical.jl:139-154, quaternion_floating.jl:205-249
+  log_with_time_derivative / exp on SE(3)      src/spatial/spatialmotion.jl:226-332
+  rotation_vector_rate                         src/spatial/util.jl:88-102
+
+The dynamics inside each stage comes from the C oracle (oracle/rbd_oracle.c).  Rotations.jl conversions
+(QuatRotation <-> RotationVec / AngleAxis / RotMatrix) are third-party and restated with quaternion algebra: within a
+step the relative rotation is small, so every conversion is on its principal branch and the result is unique up to the
+sign of the quaternion (tests compare rotation matrices).  One state at a time (small batches only)."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle
+
+FIXED, REVOLUTE, PRISMATIC, FLOATING, PLANAR, SPHERICAL, SINCOS = range(7)
+NQ = {FIXED: 0, REVOLUTE: 1, PRISMATIC: 1, FLOATING: 7, PLANAR: 3, SPHERICAL: 4, SINCOS: 2}
+NV = {FIXED: 0, REVOLUTE: 1, PRISMATIC: 1, FLOATING: 6, PLANAR: 3, SPHERICAL: 3, SINCOS: 1}
+EPS = np.finfo(np.float64).eps
+
+
+def qmul(a, b):
+    w1, x1, y1, z1 = a
+    w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def qconj(a):
+    return np.array([a[0], -a[1], -a[2], -a[3]])
+
+
+def qrot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def quat_from_rotvec(r):
+    th = np.linalg.norm(r)
+    s = 0.5 if th < EPS else np.sin(th / 2) / th
+    return np.array([np.cos(th / 2), s * r[0], s * r[1], s * r[2]])
+
+
+def rotvec_from_quat(q):
+    s = np.linalg.norm(q[1:])
+    th = 2 * np.arctan2(s, q[0])
+    sc = 2.0 if s < EPS else th / s
+    return sc * q[1:]
+
+
+def se3_comm(xw, xv, yw, yv):
+    return np.cross(xw, yw), np.cross(xw, yv) + np.cross(xv, yw)
+
+
+def se3_log_with_rate(dq, dp, w, v):
+    """_log + log_with_time_derivative (spatialmotion.jl:226-304) of the relative transform (dq, dp) with body twist (w, v)."""
+    psi = rotvec_from_quat(dq)
+    th = np.linalg.norm(psi)
+    if th < EPS:
+        return psi, dp.copy(), w.copy(), v.copy()
+    th2 = th / 2
+    alpha = th2 * np.cos(th2) / np.sin(th2)
+    qv = dp - np.cross(psi, dp) / 2 + (1 - alpha) / th ** 2 * np.cross(psi, np.cross(psi, dp))
+    beta = th2 ** 2 / np.sin(th2) ** 2
+    A = (2 * (1 - alpha) + (alpha - beta) / 2) / th ** 2
+    Bc = ((1 - alpha) + (alpha - beta) / 2) / th ** 4
+    a1 = se3_comm(psi, qv, w, v)
+    a2 = se3_comm(psi, qv, *a1)
+    a3 = se3_comm(psi, qv, *a2)
+    a4 = se3_comm(psi, qv, *a3)
+    return psi, qv, w + a1[0] / 2 + A * a2[0] + Bc * a4[0], v + a1[1] / 2 + A * a2[1] + Bc * a4[1]
+
+
+def se3_exp(prot, ptrans):
+    """exp(::Twist) spatialmotion.jl:311-332 -> (relative quaternion, relative translation)."""
+    th = np.linalg.norm(prot)
+    if th < EPS:
+        return np.array([1.0, 0, 0, 0]), ptrans.copy()
+    om = prot / th
+    dq = quat_from_rotvec(prot)
+    vv = ptrans / th
+    t = np.cross(om, vv)
+    t = t - qrot(dq) @ t + om * (om @ vv) * th
+    return dq, t
+
+
+def rotation_vector_rate(phi, w):
+    """spatial/util.jl:88-102 (Bortz equation)."""
+    out = w + np.cross(phi, w) / 2
+    th = np.linalg.norm(phi)
+    if th > EPS:
+        out = out + 1 / th ** 2 * (1 - (th * np.sin(th)) / (2 * (1 - np.cos(th)))) * np.cross(phi, np.cross(phi, w))
+    return out
+
+
+def local_rate(model, q0, q, v):
+    """ϕ̇ of `local_coordinates!(ϕ, ϕ̇, state, q0)` for every tree joint (ϕ itself is not needed by the integrator)."""
+    out = np.zeros(model.nv)
+    for i in range(model.n_bodies):
+        t, qo, vo = int(model.joint_type[i]), int(model.q_offset[i]), int(model.v_offset[i])
+        qi0, qi, vi = q0[qo:qo + NQ[t]], q[qo:qo + NQ[t]], v[vo:vo + NV[t]]
+        if t in (REVOLUTE, PRISMATIC, SINCOS):
+            out[vo] = vi[0]
+        elif t == PLANAR:  # default: ϕ̇ = velocity_to_configuration_derivative(q, v)
+            s, c = np.sin(qi[2]), np.cos(qi[2])
+            out[vo:vo + 3] = [c * vi[0] - s * vi[1], s * vi[0] + c * vi[1], vi[2]]
+        elif t == SPHERICAL:
+            phi = rotvec_from_quat(qmul(qconj(qi0), qi))
+            out[vo:vo + 3] = rotation_vector_rate(phi, vi)
+        elif t == FLOATING:
+            dq = qmul(qconj(qi0[:4]), qi[:4])
+            dp = qrot(qi0[:4]).T @ (qi[4:] - qi0[4:])
+            _, _, wd, vd = se3_log_with_rate(dq, dp, vi[:3], vi[3:])
+            out[vo:vo + 6] = np.r_[wd, vd]
+    return out
+
+
+def global_coordinates(model, q0, phi):
+    q = np.zeros(model.nq)
+    for i in range(model.n_bodies):
+        t, qo, vo = int(model.joint_type[i]), int(model.q_offset[i]), int(model.v_offset[i])
+        qi0, ph = q0[qo:qo + NQ[t]], phi[vo:vo + NV[t]]
+        if t in (REVOLUTE, PRISMATIC, PLANAR):
+            q[qo:qo + NQ[t]] = qi0 + ph
+        elif t == SINCOS:
+            s0, c0 = qi0
+            sd, cd = np.sin(ph[0]), np.cos(ph[0])
+            q[qo:qo + 2] = [s0 * cd + c0 * sd, c0 * cd - s0 * sd]
+        elif t == SPHERICAL:
+            q[qo:qo + 4] = qmul(qi0, quat_from_rotvec(ph))
+        elif t == FLOATING:
+            dq, dt = se3_exp(ph[:3], ph[3:])
+            q[qo:qo + 4] = qmul(qi0[:4], dq)
+            q[qo + 4:qo + 7] = qi0[4:] + qrot(qi0[:4]) @ dt
+    return q
+
+
+RK4_A = np.array([[0, 0, 0, 0], [0.5, 0, 0, 0], [0, 0.5, 0, 0], [0, 0, 1.0, 0]])
+RK4_B = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6])
+
+
+def vdot(model, q, v, tau, stabilize):
+    if model.n_loops:
+        return oracle.dynamics_loops(model, q[None], v[None], None if tau is None else tau[None], stabilize=stabilize)["vdot"][0]
+    return oracle.dynamics(model, q[None], v[None], None if tau is None else tau[None])[0]
+
+
+def step(model, q0, v0, dt, tau=None, stabilize=True):
+    """One MuntheKaasIntegrator step with the RK4 tableau (ode_integrators.jl:233-299)."""
+    phids, vds = [], []
+    for i in range(4):
+        phi = sum((dt * RK4_A[i, j] * phids[j] for j in range(i) if RK4_A[i, j] != 0), np.zeros(model.nv))
+        v = v0 + sum((dt * RK4_A[i, j] * vds[j] for j in range(i) if RK4_A[i, j] != 0), np.zeros(model.nv))
+        q = global_coordinates(model, q0, phi)
+        vds.append(vdot(model, q, v, tau, stabilize))
+        phids.append(local_rate(model, q0, q, v))
+    phi = sum(dt * RK4_B[i] * phids[i] for i in range(4))
+    v = v0 + sum(dt * RK4_B[i] * vds[i] for i in range(4))
+    return global_coordinates(model, q0, phi), v
+
+
+def simulate(model, q, v, final_time, dt, tau=None, stabilize=True):
+    """`simulate`: steps while t < final_time (ode_integrators.jl:307-316). q, v: (B, n). Returns ts, q_end, v_end."""
+    q, v = np.array(q, float), np.array(v, float)
+    t, ts = 0.0, [0.0]
+    while t < final_time:
+        for b in range(q.shape[0]):
+            q[b], v[b] = step(model, q[b], v[b], dt, None if tau is None else tau[b], stabilize)
+        t += dt
+        ts.append(t)
+    return np.array(ts), q, v

@@ -78,6 +78,7 @@ struct rbd_ws {
   size_t d_M_bytes = 0, d_c_bytes = 0, d_K_bytes = 0, d_k_bytes = 0;
   void* d_body = nullptr; void* d_scratch = nullptr; size_t d_body_bytes = 0, d_scratch_bytes = 0;
   void* d_loop_i = nullptr; void* d_loop_r = nullptr; void* d_loop_path = nullptr; void* d_jt_ref = nullptr; void* d_voff_ref = nullptr; void* d_axis_ref = nullptr; void* d_axis2_ref = nullptr;
+  MkBuffers mk{}; void* d_vdwork = nullptr; size_t mk_elems = 0;  // Munthe-Kaas integrator scratch (lazy)
   int* d_notpd = nullptr;  // device flag: some state's mass matrix was not positive definite (checked by rbd_sync)
   int32_t result_layout = RBD_LAYOUT_SOA; int32_t result_B = 0;
   // timing
@@ -339,6 +340,10 @@ int rbd_workspace_destroy(rbd_ws_t* w) {
   void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
+  {
+    void* mkp[] = {w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.phid[1], w->mk.phid[2], w->mk.phid[3], w->mk.vd[0], w->mk.vd[1], w->mk.vd[2], w->mk.vd[3], w->d_vdwork};
+    for (void* p : mkp) if (p) (void)hipFree(p);
+  }
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   delete w;
@@ -490,28 +495,13 @@ int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const vo
 }
 }  // namespace
 
-extern "C" {
-
-int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
-                 void* lambda, const rbd_opts_t* opts) {
-  const Opts o = read_opts(opts);
-  int st = check_common(w, B, o);
-  if (st != RBD_OK) return st;
-  if (!q || !v || !vdot) return RBD_ERR_INVALID_ARGUMENT;
+// dynamics! on device pointers: ABA, the reference's CRBA + Cholesky route, or the loop-joint branch
+static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd,
+                        void* dqd, void* dlam) {
   const rbd_model* m = w->model;
-  const bool loops = m->nloops > 0;  // has_loops(mechanism): only the CRBA route exists (src/mechanism_algorithms.jl:858-861)
-  if (B == 0) return RBD_OK;
-  HIP_TRY(hipSetDevice(w->device));
   const size_t es = esize(w);
-  const void *dq = q, *dv = v, *dtau = tau, *df = fext;
-  void *dvd = vdot, *dqd = qdot, *dlam = lambda;
-  if (o.memory == RBD_MEM_HOST) {
-    if ((st = stage_out_alloc(w, 7, lambda, es * (m->nc > 0 ? m->nc : 1) * B, &dlam))) return st;
-    if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_in(w, 1, v, es * m->nv * B, &dv)) ||
-        (st = stage_in(w, 2, tau, es * m->nv * B, &dtau)) || (st = stage_in(w, 3, fext, es * 6 * m->nb * B, &df)) ||
-        (st = stage_out_alloc(w, 4, vdot, es * m->nv * B, &dvd)) || (st = stage_out_alloc(w, 5, qdot, es * m->nq * B, &dqd)))
-      return st;
-  }
+  const bool loops = m->nloops > 0;  // has_loops(mechanism): only the CRBA route exists (src/mechanism_algorithms.jl:858-861)
+  int st;
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
   if (loops) {
     if ((st = dynamics_loops(w, B, o, dq, dv, dtau, df, dvd, dqd, dlam))) return st;
@@ -537,6 +527,31 @@ int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const voi
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba<double>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba<float>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
   }
+  return RBD_OK;
+}
+
+extern "C" {
+
+int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
+                 void* lambda, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!q || !v || !vdot) return RBD_ERR_INVALID_ARGUMENT;
+  const rbd_model* m = w->model;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t es = esize(w);
+  const void *dq = q, *dv = v, *dtau = tau, *df = fext;
+  void *dvd = vdot, *dqd = qdot, *dlam = lambda;
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_out_alloc(w, 7, lambda, es * (m->nc > 0 ? m->nc : 1) * B, &dlam))) return st;
+    if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_in(w, 1, v, es * m->nv * B, &dv)) ||
+        (st = stage_in(w, 2, tau, es * m->nv * B, &dtau)) || (st = stage_in(w, 3, fext, es * 6 * m->nb * B, &df)) ||
+        (st = stage_out_alloc(w, 4, vdot, es * m->nv * B, &dvd)) || (st = stage_out_alloc(w, 5, qdot, es * m->nq * B, &dqd)))
+      return st;
+  }
+  if ((st = run_dynamics(w, B, o, dq, dv, dtau, df, dvd, dqd, dlam))) return st;
   if (o.memory == RBD_MEM_HOST) {
     if ((st = stage_out_copy(w, vdot, dvd, es * m->nv * B)) || (st = stage_out_copy(w, qdot, dqd, es * m->nq * B)) ||
         (st = stage_out_copy(w, lambda, dlam, es * m->nc * B)))
@@ -660,6 +675,73 @@ int rbd_dynamics_result(rbd_ws_t* w, int32_t B, void* M, void* c, void* K, void*
   if (c) { if (!w->d_c) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(c, w->d_c, es * (size_t)m->nv * B, kind, w->stream)); }
   if (K && m->nc > 0) { if (!w->d_K) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(K, w->d_K, es * (size_t)m->nc * m->nv * B, kind, w->stream)); }
   if (k && m->nc > 0) { if (!w->d_k) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(k, w->d_k, es * (size_t)m->nc * B, kind, w->stream)); }
+  return RBD_OK;
+}
+
+
+static int mk_ensure(rbd_ws* w, int32_t B) {
+  const rbd_model* m = w->model;
+  const size_t es = esize(w);
+  if (w->mk_elems >= (size_t)B) return RBD_OK;
+  void** ptrs[] = {&w->mk.q0, &w->mk.v0, &w->mk.phid[0], &w->mk.phid[1], &w->mk.phid[2], &w->mk.phid[3], &w->mk.vd[0], &w->mk.vd[1], &w->mk.vd[2],
+                   &w->mk.vd[3], &w->d_vdwork};
+  for (void** p : ptrs) { if (*p) HIP_TRY(hipFree(*p)); *p = nullptr; }
+  w->mk_elems = 0;
+  const size_t nq = (size_t)(m->nq > 0 ? m->nq : 1), nv = (size_t)(m->nv > 0 ? m->nv : 1);
+  HIP_TRY(hipMalloc(&w->mk.q0, es * nq * B));
+  HIP_TRY(hipMalloc(&w->mk.v0, es * nv * B));
+  for (int k = 0; k < 4; ++k) { HIP_TRY(hipMalloc(&w->mk.phid[k], es * nv * B)); HIP_TRY(hipMalloc(&w->mk.vd[k], es * nv * B)); }
+  HIP_TRY(hipMalloc(&w->d_vdwork, es * nv * B));
+  w->mk_elems = (size_t)B;
+  return RBD_OK;
+}
+
+int rbd_mk_stage(rbd_ws_t* w, int32_t B, int32_t stage, double dt, void* q, void* v, const void* vdot_prev, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!q || !v || stage < 0 || stage > 4 || (stage > 0 && !vdot_prev) || o.memory != RBD_MEM_DEVICE) return RBD_ERR_INVALID_ARGUMENT;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  if ((st = mk_ensure(w, B))) return st;
+  const rbd_model* m = w->model;
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B);
+  if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, stage, dt, q, v, vdot_prev, w->mk, Lq, Lv, w->stream));
+  else HIP_TRY(launch_mk_stage<float>(w->dm, B, stage, dt, q, v, vdot_prev, w->mk, Lq, Lv, w->stream));
+  return RBD_OK;
+}
+
+int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, const void* fext, double dt, int32_t nsteps, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!q || !v || nsteps < 0 || !(dt > 0)) return RBD_ERR_INVALID_ARGUMENT;
+  if (B == 0 || nsteps == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const rbd_model* m = w->model;
+  const size_t es = esize(w);
+  void *dq = q, *dv = v;
+  const void *dtau = tau, *df = fext;
+  if (o.memory == RBD_MEM_HOST) {
+    const void *cq, *cv;
+    if ((st = stage_in(w, 0, q, es * m->nq * B, &cq)) || (st = stage_in(w, 1, v, es * m->nv * B, &cv)) ||
+        (st = stage_in(w, 2, tau, es * m->nv * B, &dtau)) || (st = stage_in(w, 3, fext, es * 6 * m->nb * B, &df)))
+      return st;
+    dq = const_cast<void*>(cq); dv = const_cast<void*>(cv);
+  }
+  if ((st = mk_ensure(w, B))) return st;
+  Opts od = o; od.memory = RBD_MEM_DEVICE;
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B);
+  for (int step = 0; step < nsteps; ++step) {
+    for (int stage = 0; stage <= 4; ++stage) {
+      if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));
+      else HIP_TRY(launch_mk_stage<float>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));
+      if (stage < 4 && (st = run_dynamics(w, B, od, dq, dv, dtau, df, w->d_vdwork, nullptr, nullptr))) return st;
+    }
+  }
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_out_copy(w, q, dq, es * m->nq * B)) || (st = stage_out_copy(w, v, dv, es * m->nv * B))) return st;
+  }
   return RBD_OK;
 }
 

@@ -58,6 +58,12 @@ template <typename T> struct LoopView {
   const T* axis2;      // [nb*3] (Planar y axis)
 };
 
+// integrator scratch of mk_stage_kernel (same layout as the caller's q / v)
+struct MkBuffers {
+  void* q0; void* v0;   // base point of the step, AOS-agnostic: same layout as q / v
+  void* phid[4]; void* vd[4];
+};
+
 #define RBD_DEV __device__ __forceinline__
 
 template <typename T> RBD_DEV T shfl(T x, int src) { return __shfl(x, src, 64); }

@@ -24,3 +24,8 @@ hipError_t launch_loop_solve(const LoopView<T>& V, long B, int stabilize, const 
                              void* lambda, void* K, void* k, void* scratch, long scratch_stride, Layout Lm, Layout Lv, Layout Lc, Layout Lk,
                              const double* gravity, int* notpd, hipStream_t s);
 }
+namespace rbd {
+template <typename T>
+hipError_t launch_mk_stage(const DevModel& M, long B, int stage, double dt, void* q, void* v, const void* vdot_prev, const MkBuffers& W,
+                           Layout Lq, Layout Lv, hipStream_t s);
+}

@@ -295,3 +295,75 @@ def sync(state: MechanismState) -> int:
     the batched analogue of LAPACK.potrf!'s PosDefException)."""
     state.ws.use_current_stream()
     return int(_capi.lib().rbd_sync(state.ws.handle))
+
+
+RK4_C = (0.0, 0.5, 0.5, 1.0)  # c = row sums of the runge_kutta_4 tableau (src/ode_integrators.jl:48-55)
+
+
+def simulate_(state: MechanismState, final_time: float, control_=None, dt: float = 1e-4, torques: Optional[torch.Tensor] = None,
+              externalwrenches: Optional[torch.Tensor] = None, stabilization_gains="default", store: bool = False):
+    """`simulate(state0, final_time, control!; Δt, stabilization_gains)` (src/simulate.jl:36-55) for a whole batch in lockstep:
+    Munthe-Kaas RK4 on the device, `state.q` / `state.v` advanced in place.
+
+    * `control_ is None`: constant `torques` (default zero, the reference's `zero_torque!`) — every stage of every step runs on
+      the GPU without returning to the host (`rbd_simulate`).
+    * `control_(torques, t, state)`: called before each stage's `dynamics!` exactly like the reference's closure
+      (src/simulate.jl:42-48); it must fill the (B, nv) `torques` tensor in place.
+    Returns `ts` (and the lists `qs`, `vs` of per-step snapshots when `store`), with the reference's loop `while t < final_time`."""
+    f = state.flat
+    state._check(torques, f.nv, "torques")
+    state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
+    state.ws.use_current_stream()
+    opts = state._opts(_capi.ALGO_ABA, 0 if stabilization_gains is None else 1)
+    L = _capi.lib()
+    ts, t = [0.0], 0.0
+    qs, vs = ([state.q.clone()], [state.v.clone()]) if store else (None, None)
+    nsteps = 0
+    while t < final_time:  # ode_integrators.jl:311-314
+        t += dt
+        ts.append(t)
+        nsteps += 1
+    if control_ is None and not store:
+        _raise(L.rbd_simulate(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
+                              ctypes.c_double(dt), nsteps, ctypes.byref(opts)), "rbd_simulate")
+    elif control_ is None:
+        for _ in range(nsteps):
+            _raise(L.rbd_simulate(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
+                                  ctypes.c_double(dt), 1, ctypes.byref(opts)), "rbd_simulate")
+            qs.append(state.q.clone())
+            vs.append(state.v.clone())
+    else:
+        tau = torch.zeros_like(state.v) if torques is None else torques
+        vd = torch.zeros_like(state.v)
+        lam = torch.zeros((state.batch, max(f.nc, 1)), dtype=state.dtype, device=state.device)
+        for k in range(nsteps):
+            for stage in range(5):
+                _raise(L.rbd_mk_stage(state.ws.handle, state.batch, stage, ctypes.c_double(dt), _ptr(state.q), _ptr(state.v),
+                                      _ptr(vd if stage > 0 else None), ctypes.byref(opts)), "rbd_mk_stage")
+                if stage < 4:
+                    control_(tau, ts[k] + RK4_C[stage] * dt, state)
+                    _raise(L.rbd_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(tau), _ptr(externalwrenches),
+                                          _ptr(vd), None, _ptr(lam if f.nc else None), ctypes.byref(opts)), "rbd_dynamics")
+            if store:
+                qs.append(state.q.clone())
+                vs.append(state.v.clone())
+    ts = np.array(ts)
+    return (ts, qs, vs) if store else ts
+
+
+def dynamics_ode_(xd: torch.Tensor, result: DynamicsResult, state: MechanismState, x: torch.Tensor, torques: Optional[torch.Tensor] = None,
+                  externalwrenches: Optional[torch.Tensor] = None, stabilization_gains="default"):
+    """`dynamics!(ẋ, result, state, x, torques, externalwrenches)` (src/mechanism_algorithms.jl:880-889), the form used with
+    off-the-shelf ODE solvers: x = [q; v] per state, (B, nq + nv); `copyto!(state, x)`, `dynamics!`, `copyto!(ẋ, result)` with
+    ẋ = [q̇; v̇] (src/dynamics_result.jl:89-95; no additional contact state in scope)."""
+    f = state.flat
+    if state.layout != "aos":
+        raise ValueError("dynamics_ode_ expects the AOS layout (one state vector per row)")
+    if tuple(x.shape) != (state.batch, f.nq + f.nv) or tuple(xd.shape) != (state.batch, f.nq + f.nv):
+        raise DimensionMismatch(f"x / ẋ must be ({state.batch}, {f.nq + f.nv})")
+    state.q.copy_(x[:, :f.nq])
+    state.v.copy_(x[:, f.nq:])
+    dynamics_(result, state, torques, externalwrenches, stabilization_gains=stabilization_gains)
+    xd[:, :f.nq].copy_(result.qd)
+    xd[:, f.nq:].copy_(result.vd)
+    return xd

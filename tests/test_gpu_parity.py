@@ -381,3 +381,108 @@ def test_c_abi_host_memory_mode(rbd, oracle, models):
     assert L.rbd_dynamics(ws, B + 1, P(q), P(v), None, None, P(vd), None, None, ctypes.byref(opts)) == 2
     assert L.rbd_dynamics(ws, B, None, P(v), None, None, P(vd), None, None, ctypes.byref(opts)) == 1
     assert L.rbd_workspace_destroy(ws) == 0
+
+
+# ---- batched `simulate` (Munthe-Kaas RK4 on the device) vs the numpy restatement of src/ode_integrators.jl:233-299 -----------
+def quat_blocks(model):
+    from rigidbodydynamics_jl_amd.mechanism import JOINT_QUAT_FLOATING, JOINT_QUAT_SPHERICAL
+    return [int(model.q_offset[i]) for i in range(model.n_bodies) if int(model.joint_type[i]) in (JOINT_QUAT_FLOATING, JOINT_QUAT_SPHERICAL)]
+
+
+def canon_q(model, q):
+    """quaternions are compared up to sign (q and -q are the same rotation)."""
+    q = q.copy()
+    for o in quat_blocks(model):
+        s = np.sign(q[:, o:o + 1])
+        s[s == 0] = 1
+        q[:, o:o + 4] *= s
+    return q
+
+
+@pytest.mark.parametrize("name", ["atlas_floating", "double_pendulum", "acrobot_urdf", "randmech1", "inner_floating"])
+def test_simulate_matches_oracle_f64(rbd, oracle, models, name):
+    import simulate_np
+    model = models[name]
+    B, dt, T = 6, 1e-3, 0.0095
+    q, v, tau, _ = rand_inputs(rbd, model, B, 51, fext=True)
+    state = rbd.MechanismState(model, B)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    ts = rbd.simulate_(state, T, dt=dt, torques=dev(tau, state))
+    ts_ref, q_ref, v_ref = simulate_np.simulate(model, q, v, T, dt, tau)
+    assert len(ts) == len(ts_ref) == 11
+    qg, vg = host(state.q, state), host(state.v, state)
+    assert np.abs(canon_q(model, qg) - canon_q(model, q_ref)).max() <= 1e-11 * max(1.0, np.abs(q_ref).max())
+    assert np.abs(vg - v_ref).max() <= 1e-9 * max(1.0, np.abs(v_ref).max())
+
+
+def test_simulate_with_controller_and_store(rbd, oracle, models):
+    """control!(torques, t, state) is evaluated before every stage's dynamics! (src/simulate.jl:42-48)."""
+    import simulate_np
+    model = models["double_pendulum"]
+    B, dt = 4, 1e-2
+    q, v, tau = rand_inputs(rbd, model, B, 52)
+    state = rbd.MechanismState(model, B)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    d_tau = dev(tau, state)
+    calls = []
+
+    def control_(torques, t, st):
+        calls.append(t)
+        torques.copy_(d_tau)   # constant controller, so the constant-torque oracle applies
+
+    ts, qs, vs = rbd.simulate_(state, 0.05, control_=control_, dt=dt, store=True)
+    _, q_ref, v_ref = simulate_np.simulate(model, q, v, 0.05, dt, tau)
+    assert len(qs) == len(ts) and len(calls) == 4 * (len(ts) - 1)
+    assert np.allclose(calls[:4], [0.0, 0.005, 0.005, 0.01])
+    assert np.abs(host(state.q, state) - q_ref).max() <= 1e-11 and np.abs(host(state.v, state) - v_ref).max() <= 1e-10
+    assert torch.equal(qs[-1], state.q)
+
+
+def test_simulate_four_bar_loops(rbd, oracle, models):
+    """The loop-joint branch inside the integrator: closure is kept (no stabilization) like test/test_simulate.jl:203-213, here
+    for 0.1 s on the GPU, against the oracle's integration of the same states."""
+    import simulate_np
+    model = models["four_bar"]
+    B, dt = 8, 1e-3
+    q = np.tile(rbd.FOUR_BAR_INITIAL_Q, (B, 1))
+    v = np.zeros((B, 3))
+    state = rbd.MechanismState(model, B)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    rbd.simulate_(state, 0.0995, dt=dt, stabilization_gains=None)
+    _, q_ref, v_ref = simulate_np.simulate(model, q[:1], v[:1], 0.0995, dt, stabilize=False)
+    assert np.abs(host(state.q, state) - q_ref).max() <= 1e-10 and np.abs(host(state.v, state) - v_ref).max() <= 1e-9
+
+
+def test_simulate_energy_full_batch(rbd, oracle, models):
+    """Size-independent property at B = 4096: free motion conserves KE + PE (checked with the oracle's energy on a sample)."""
+    model = models["atlas_floating"]
+    B = 4096
+    q, v, _ = rand_inputs(rbd, model, B, 53)
+    state = rbd.MechanismState(model, B)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    rbd.simulate_(state, 0.0195, dt=1e-3)
+    n = 64
+    ke0, pe0 = oracle.energy(model, q[:n], v[:n])
+    ke1, pe1 = oracle.energy(model, host(state.q, state)[:n], host(state.v, state)[:n])
+    assert (np.abs(ke1 + pe1 - ke0 - pe0) / (np.abs(ke0) + np.abs(pe0))).max() < 1e-7
+    qn = state.q[:, :4].norm(dim=1)
+    assert float((qn - 1).abs().max()) < 1e-12
+
+
+def test_dynamics_ode_form(rbd, oracle, models):
+    """dynamics!(ẋ, result, state, x, …) — src/mechanism_algorithms.jl:880-889 / test/test_mechanism_algorithms.jl:755-771."""
+    model = models["atlas_floating"]
+    B = 9
+    q, v, tau = rand_inputs(rbd, model, B, 61)
+    state = rbd.MechanismState(model, B)
+    result = rbd.DynamicsResult(model, B)
+    x = torch.as_tensor(np.hstack([q, v])).cuda()
+    xd = torch.zeros_like(x)
+    rbd.dynamics_ode_(xd, result, state, x, dev(tau, state))
+    vd, qd = oracle.dynamics(model, q, v, tau, want_qdot=True)
+    ref = np.hstack([qd, vd])
+    assert np.abs(xd.cpu().numpy() - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
