@@ -162,8 +162,9 @@ int rbd_dynamics_bias(rbd_ws_t* ws, int32_t B, const void* q, const void* v, con
  * reference (Symmetric, uplo 'L') only the LOWER triangle i>=j is written.     */
 int rbd_mass_matrix(rbd_ws_t* ws, int32_t B, const void* q, void* M_out, const rbd_opts_t* opts);
 
-/* x = M(q)^-1 rhs via batched lower Cholesky (potrf/potrs of dynamics_solve!);
- * rhs, x: nv×B. M_out nullable (same layout as rbd_mass_matrix).               */
+/* x = M(q)^-1 rhs; rhs, x: nv×B.  opts->algorithm == RBD_ALGO_CRBA_CHOLESKY: CRBA + batched lower Cholesky, the potrf/potrs
+ * of dynamics_solve!;  RBD_ALGO_ABA (default): the O(n) articulated-body solve (forward dynamics with v = 0, g = 0,
+ * tau = rhs), which never forms M.  M_out nullable (same layout as rbd_mass_matrix); tree mechanisms.              */
 int rbd_mass_matrix_solve(rbd_ws_t* ws, int32_t B, const void* q, const void* rhs, void* x,
                           void* M_out, const rbd_opts_t* opts);
 

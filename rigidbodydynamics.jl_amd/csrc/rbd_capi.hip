@@ -59,6 +59,7 @@ struct rbd_model {
   std::vector<int32_t> slot_of, order;  // reference body index <-> DFS pre-order slot
   std::vector<int32_t> dof_body;
   std::vector<int32_t> anc;     // nb * nlevels
+  std::vector<uint64_t> row_mask;  // nv
   std::vector<rbd_loop_joint_t> loops;
   std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref;  // loop tables (reference body indices)
   std::vector<double> loop_r, axis_ref, axis2_ref;
@@ -69,7 +70,7 @@ struct rbd_ws {
   int32_t device = 0, dtype = RBD_F64, max_batch = 0;
   hipStream_t stream = nullptr;
   DevModel dm{};
-  void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr;
+  void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
   // staging for RBD_MEM_HOST (lazy)
   void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -206,6 +207,20 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     int a = s;
     for (int k = 0; k < m->nlevels && a >= 0; ++k) { m->anc[(size_t)s * m->nlevels + k] = a; a = m->ib[(size_t)a * IB_STRIDE + IB_PARENT]; }
   }
+  // support structure per dof row (support_set_masks, src/mechanism_state.jl:95-98); nv <= 64 here is guaranteed by nb <= 64 only
+  // for 1-dof joints, so wider mechanisms fall back to an empty mask (then every lower entry is written as computed or zero-filled)
+  m->row_mask.assign(m->nv > 0 ? m->nv : 1, 0);
+  if (m->nv <= 64) {
+    for (int r = 0; r < m->nv; ++r) {
+      const int sr = m->dof_body[r];
+      for (int c = 0; c <= r; ++c) {
+        const int sc = m->dof_body[c];
+        bool sup = false;
+        for (int k = 0; k < m->nlevels; ++k) sup |= (m->anc[(size_t)sr * m->nlevels + k] == sc);
+        if (sup) m->row_mask[r] |= (uint64_t)1 << c;
+      }
+    }
+  } else { delete m; return RBD_ERR_UNSUPPORTED; }
   m->nc = 0;
   m->jt_ref.assign(d->joint_type, d->joint_type + nb);
   m->voff_ref.assign(d->v_offset, d->v_offset + nb);
@@ -297,6 +312,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   }
   if (st == RBD_OK) st = upload(&w->d_dof_body, m->dof_body.data(), m->dof_body.size() * sizeof(int32_t));
   if (st == RBD_OK) st = upload(&w->d_anc, m->anc.data(), m->anc.size() * sizeof(int32_t));
+  if (st == RBD_OK) st = upload(&w->d_row_mask, m->row_mask.data(), m->row_mask.size() * sizeof(uint64_t));
   if (st == RBD_OK) { int zero = 0; st = upload((void**)&w->d_notpd, &zero, sizeof(int)); }
   if (st == RBD_OK && m->nloops > 0) {
     st = upload(&w->d_loop_i, m->loop_i.data(), m->loop_i.size() * sizeof(int32_t));
@@ -324,7 +340,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   dm.inner_floating = m->inner_floating;
   dm.has3dof = m->has3dof;
   for (int l = 0; l < MAX_LEVELS; ++l) dm.nslots[l] = (uint8_t)m->nslots[l];
-  dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc;
+  dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc; dm.row_mask = (const uint64_t*)w->d_row_mask;
   memcpy(dm.gravity, m->gravity, sizeof dm.gravity);
   {
     const char* e = getenv("RBD_ABA_STOP_AFTER");  // profiling aid only
@@ -337,7 +353,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -641,12 +657,12 @@ int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs
         (st = stage_out_alloc(w, 4, x, es * m->nv * B, &dx)) || (st = stage_out_alloc(w, 6, M_out, mbytes, &dM)))
       return st;
   }
-  if (!dM) {
+  if (!dM && o.algorithm == RBD_ALGO_CRBA_CHOLESKY) {
     if ((st = ensure(&w->d_M, &w->d_M_bytes, mbytes))) return st;
     dM = w->d_M;
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
-  {
+  if (o.algorithm == RBD_ALGO_CRBA_CHOLESKY) {
     Timed t(w);
     if (w->dtype == RBD_F64) {
       HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
@@ -654,6 +670,20 @@ int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs
     } else {
       HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
       HIP_TRY(launch_chol_solve<float>(m->nv, B, dM, dr, nullptr, dx, nullptr, Lm, Lv, w->d_notpd, w->stream));
+    }
+  } else {
+    // O(n) solve: x = M(q)^-1 rhs is forward dynamics with v = 0, no gravity and tau = rhs (then c = 0), i.e. one pass of
+    // the articulated-body kernel — no matrix is formed unless the caller asked for it.
+    DevModel dm0 = w->dm;
+    dm0.gravity[0] = dm0.gravity[1] = dm0.gravity[2] = 0.0;
+    const Layout Lf = layout_of(o.layout, 6L * m->nb, B);
+    Timed t(w);
+    if (w->dtype == RBD_F64) {
+      HIP_TRY(launch_aba<double>(dm0, B, dq, nullptr, dr, nullptr, dx, nullptr, Lq, Lv, Lf, w->stream));
+      if (dM) HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
+    } else {
+      HIP_TRY(launch_aba<float>(dm0, B, dq, nullptr, dr, nullptr, dx, nullptr, Lq, Lv, Lf, w->stream));
+      if (dM) HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
     }
   }
   if (o.memory == RBD_MEM_HOST) {

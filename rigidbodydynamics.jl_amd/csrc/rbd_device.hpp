@@ -35,6 +35,7 @@ struct DevModel {
   const int32_t* ib;  // [nb * IB_STRIDE], indexed by slot; parent/children are slots, IB_ORIG the reference body index
   const void* rb;     // [nb * RB_STRIDE] of the kernel's scalar type, indexed by slot
   const int32_t* dof_body;  // [nv] slot of velocity index
+  const uint64_t* row_mask; // [nv] bit c of row_mask[r]: M[r, c] is structurally non-zero (joint of dof c supports the body of dof r), c <= r
   const int32_t* anc;       // [nb * nlevels] anc[s*nlevels + k] = k-th ancestor slot of s (k=0: s itself), -1 past the root
   uint64_t perm_down;       // bit l set: some body at level l has parent slot != s-1 (top-down hop needs ds_bpermute at level l)
   uint8_t nslots[MAX_LEVELS];  // child slots to gather when the bottom-up sweep processes level l (max #children of level l-1 parents)

@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* 
 // ancestor-or-self joint (support set), zero elsewhere; only the lower triangle is written.
 // M_out: element (i, j) of state b at M[(j*nv + i)*Lm.sk + b*Lm.sb].
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NDOF>
 __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* __restrict__ q, T* __restrict__ Mout,
                                                    Layout Lq, Layout Lm, int zero_fill) {
   Body<T> b;
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
       Ic.m = T(0);
     }
   }
-  // composite-rigid-body inertias, bottom-up (10 scalars per child)
+  // composite-rigid-body inertias, bottom-up (10 scalars per child; first child by DPP): update_crb_inertias!
   for (int l = M.nlevels - 1; l >= 1; --l) {
     const int ns = (int)M.nslots[l];
 #pragma unroll 1
@@ -699,48 +699,80 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
       Ic.m = acc[9];
     }
   }
-  const int nvi = joint_nv(b.jtype);
+  const int jt = b.jtype;
+  const int nvi = joint_nv(jt);
   const long nv = M.nv;
-  // own motion subspace columns S (6 x nvi) and force columns F = Ic S
-  // 1-dof: one column; floating: 6 columns = Xm(H) e_k.
-  for (int ci = 0; ci < 6; ++ci) {
-    if (ci >= M.maxnvj) break;  // uniform
-    T sl[6], Si[6], Fi[6];
-    {
-      const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
-      subspace_col(b.jtype, ax, ay, ci, sl);
+  const bool own_floating = (jt == RBD_JOINT_QUAT_FLOATING);
+  const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
+  // What a lane publishes about its own joint: a 6-dof joint publishes its transform (R, p); a joint with <= NDOF degrees of
+  // freedom publishes its root-frame motion subspace columns.  Walking up the support chain (support_set_masks,
+  // src/mechanism_state.jl:95-98) is then "pull the record my parent currently holds", tree-depth times.
+  constexpr int RS = NDOF * 6 > 12 ? NDOF * 6 : 12;
+  T rec[RS];
+#pragma unroll
+  for (int k = 0; k < RS; ++k) rec[k] = T(0);
+  if (own_floating) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rec[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rec[9 + k] = p[k];
+  } else {
+#pragma unroll
+    for (int c = 0; c < NDOF; ++c) {
+      T sl[6];
+      subspace_col(jt, ax, ay, c, sl);
+      if (c < nvi) xmotion(R, p, sl, rec + 6 * c);
     }
-    xmotion(R, p, sl, Si);
-    mul_inertia(Ic, Si, Fi);
-    const bool have_col = b.valid && ci < nvi;
-    const long row = b.voff + ci;
-    // walk up the support chain: ancestors a_0 = self, a_1 = parent, ...
-    for (int k = 0; k < M.nlevels; ++k) {
-      const int a = M.anc[(b.sub < M.nb ? b.sub : 0) * M.nlevels + k];  // body index or -1
-      const int src = (a >= 0) ? b.base + a : b.lane;
-      // ancestor's transform and joint data via shuffles
-      T aR[9], ap[3];
+  }
+  int rjt = jt, rvoff = b.voff;
+  // own force columns F_c = Ic S_c (mass_matrix!: Fi = Ici * Si, src/mechanism_algorithms.jl:258-260)
+  T F[NDOF][6];
 #pragma unroll
-      for (int j = 0; j < 9; ++j) aR[j] = shfl(R[j], src);
+  for (int c = 0; c < NDOF; ++c) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) ap[j] = shfl(p[j], src);
-      const int ajt = __shfl(b.jtype, src, 64);
-      const int avoff = __shfl(b.voff, src, 64);
-      T aax[3], aay[3];
+    for (int k = 0; k < 6; ++k) F[c][k] = T(0);
+    if (!own_floating && c < nvi) mul_inertia(Ic, rec + 6 * c, F[c]);
+  }
+  auto emit = [&](const T* Fc, long row) {  // M[row, cols of the recorded joint] = Fc · S_col, lower triangle only
+    if (rjt == RBD_JOINT_QUAT_FLOATING) {
+      T o6[6];
+      xforce_inv(rec, rec + 9, Fc, o6);  // S' F for S = Xm(H): the inverse wrench transform
 #pragma unroll
-      for (int j = 0; j < 3; ++j) aax[j] = shfl(rb[RB_AXIS + j], src);
+      for (int cj = 0; cj < 6; ++cj) {
+        const long col = rvoff + cj;
+        if (col <= row) Mout[(col * nv + row) * Lm.sk + b.state * Lm.sb] = o6[cj];
+      }
+    } else {
+      const int anv = joint_nv(rjt);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) aay[j] = M.has3dof ? shfl(rb[RB_AXIS2 + j], src) : T(0);
-      if (have_col && a >= 0) {
-        const int anv = joint_nv(ajt);
-        for (int cj = 0; cj < anv; ++cj) {
-          const long col = avoff + cj;
-          if (col > row) continue;  // lower triangle only (self block)
-          T slj[6], Sj[6];
-          subspace_col(ajt, aax, aay, cj, slj);
-          xmotion(aR, ap, slj, Sj);
-          Mout[(col * nv + row) * Lm.sk + b.state * Lm.sb] = dot6(Fi, Sj);
+      for (int cj = 0; cj < NDOF; ++cj) {
+        const long col = rvoff + cj;
+        if (cj < anv && col <= row) Mout[(col * nv + row) * Lm.sk + b.state * Lm.sb] = dot6(Fc, rec + 6 * cj);
+      }
+    }
+  };
+#pragma unroll 1
+  for (int k = 0; k < M.nlevels; ++k) {
+    if (k > 0) {
+#pragma unroll
+      for (int j = 0; j < RS; ++j) rec[j] = shfl(rec[j], b.plane);
+      rjt = __shfl(rjt, b.plane, 64);
+      rvoff = __shfl(rvoff, b.plane, 64);
+    }
+    if (b.valid && k <= b.level) {
+      if (own_floating) {
+#pragma unroll 1
+        for (int ci = 0; ci < 6; ++ci) {
+          T sl[6], Si[6], Fc[6];
+          subspace_col(jt, ax, ay, ci, sl);
+          xmotion(R, p, sl, Si);
+          mul_inertia(Ic, Si, Fc);
+          emit(Fc, (long)b.voff + ci);
         }
+      } else {
+#pragma unroll
+        for (int ci = 0; ci < NDOF; ++ci)
+          if (ci < nvi) emit(F[ci], (long)b.voff + ci);
       }
     }
   }
@@ -748,12 +780,11 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
   if (zero_fill && b.valid) {
     for (int ci = 0; ci < nvi; ++ci) {
       const long row = b.voff + ci;
-      for (long col = 0; col <= row; ++col) {
-        // supported iff dof_body[col] is an ancestor-or-self of this body
-        const int cb_ = M.dof_body[col];
-        bool sup = false;
-        for (int k = 0; k < M.nlevels; ++k) sup |= (M.anc[b.sub * M.nlevels + k] == cb_);
-        if (!sup) Mout[(col * nv + row) * Lm.sk + b.state * Lm.sb] = T(0);
+      unsigned long long m = ~M.row_mask[row] & ((row >= 63) ? ~0ull : ((2ull << row) - 1));
+      while (m) {
+        const long col = __builtin_ctzll(m);
+        m &= m - 1;
+        Mout[(col * nv + row) * Lm.sk + b.state * Lm.sb] = T(0);
       }
     }
   }
@@ -787,7 +818,8 @@ hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, 
 }
 template <typename T>
 hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill, hipStream_t s) {
-  hipLaunchKernelGGL(crba_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (T*)Mout, Lq, Lm, zero_fill);
+  if (M.has3dof) hipLaunchKernelGGL((crba_kernel<T, 3>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (T*)Mout, Lq, Lm, zero_fill);
+  else hipLaunchKernelGGL((crba_kernel<T, 1>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (T*)Mout, Lq, Lm, zero_fill);
   return hipGetLastError();
 }
 

@@ -277,14 +277,16 @@ def mass_matrix_(M_or_result, state: MechanismState):
     return out
 
 
-def mass_matrix_solve_(x: torch.Tensor, state: MechanismState, rhs: torch.Tensor, M_out: Optional[torch.Tensor] = None):
-    """x = M(q)⁻¹ rhs by batched lower Cholesky — `dynamics_solve!`'s potrf!/potrs! branch (:764, :819)."""
+def mass_matrix_solve_(x: torch.Tensor, state: MechanismState, rhs: torch.Tensor, M_out: Optional[torch.Tensor] = None,
+                       algorithm: str = "cholesky"):
+    """x = M(q)⁻¹ rhs.  algorithm="cholesky": CRBA + batched lower Cholesky — `dynamics_solve!`'s potrf!/potrs! branch (:764, :819);
+    algorithm="aba": the O(n) articulated-body solve (same x, M never formed unless `M_out` is given)."""
     f = state.flat
     state._check(x, f.nv, "x")
     state._check(rhs, f.nv, "rhs")
     state._check(M_out, f.nv * f.nv, "M_out")
     state.ws.use_current_stream()
-    opts = state._opts()
+    opts = state._opts(_capi.ALGO_CRBA_CHOLESKY if algorithm == "cholesky" else _capi.ALGO_ABA)
     st = _capi.lib().rbd_mass_matrix_solve(state.ws.handle, state.batch, _ptr(state.q), _ptr(rhs), _ptr(x), _ptr(M_out), ctypes.byref(opts))
     _raise(st, "rbd_mass_matrix_solve")
     return x

@@ -1,0 +1,52 @@
+"""Throughput of every hot-path entry point (not the headline line — bench.py is): evals/s and µs per launch, graph-replayed so
+the GPU is the bottleneck.  usage: python scripts/bench_ops.py [--batch 4096] [--dtype f64] [--model atlas_floating]"""
+import argparse, ctypes, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+import rbd_amd as rbd
+from rigidbodydynamics_jl_amd import _capi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--dtype", default="f64"); ap.add_argument("--model", default="atlas_floating")
+ap.add_argument("--reps", type=int, default=200)
+args = ap.parse_args()
+tdt = torch.float64 if args.dtype == "f64" else torch.float32
+model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
+B = args.batch
+rng = np.random.default_rng(1)
+state = rbd.MechanismState(model, B, dtype=tdt); result = rbd.DynamicsResult(model, B, dtype=tdt)
+rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng)); rbd.set_velocity_(state, rbd.rand_velocity(model, B, rng))
+tau = torch.rand(B, model.nv, dtype=tdt, device="cuda"); out = torch.zeros_like(tau)
+ops = {
+    "dynamics! (ABA)": lambda: rbd.dynamics_(result, state, tau),
+    "dynamics! (CRBA+Cholesky route)": lambda: rbd.dynamics_(result, state, tau, algorithm="crba"),
+    "inverse_dynamics!": lambda: rbd.inverse_dynamics_(out, state, tau),
+    "dynamics_bias!": lambda: rbd.dynamics_bias_(result, state),
+    "mass_matrix!": lambda: rbd.mass_matrix_(result, state),
+    "mass_matrix! + Cholesky solve": lambda: rbd.mass_matrix_solve_(out, state, tau, result.massmatrix),
+    "M^-1 rhs via the articulated-body solve": lambda: rbd.mass_matrix_solve_(out, state, tau, algorithm="aba"),
+}
+res = {}
+for name, f in ops.items():
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(); cap = torch.cuda.Stream()
+    with torch.cuda.stream(cap):
+        f()
+        with torch.cuda.graph(g, stream=cap):
+            for _ in range(args.reps): f()
+    torch.cuda.synchronize(); g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / args.reps * 1e3
+    res[name] = {"us_per_launch": round(us, 2), "Mevals_per_s": round(B / us, 1)}
+# simulate: steps/s (each step = 4 dynamics! + 5 stage kernels)
+q0, v0 = state.q.clone(), state.v.clone()
+rbd.simulate_(state, 0.0095, dt=1e-3); torch.cuda.synchronize()
+state.q.copy_(q0); state.v.copy_(v0)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); rbd.simulate_(state, 0.0995, dt=1e-3); e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 100 * 1e3
+res["simulate (RK4 step = 4 dynamics!)"] = {"us_per_step": round(us, 2), "Msteps_per_s": round(B / us, 2)}
+print(json.dumps({"model": args.model, "batch": B, "dtype": args.dtype, "ops": res}))

@@ -486,3 +486,19 @@ def test_dynamics_ode_form(rbd, oracle, models):
     vd, qd = oracle.dynamics(model, q, v, tau, want_qdot=True)
     ref = np.hstack([qd, vd])
     assert np.abs(xd.cpu().numpy() - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", ["atlas_floating", "randmech2", "inner_floating"])
+def test_mass_matrix_solve_aba_equals_cholesky(rbd, oracle, models, name):
+    """x = M⁻¹ rhs through the O(n) articulated-body solve and through CRBA + Cholesky agree (fp64, 1e-10)."""
+    model = models[name]
+    B = 41
+    state, q, v, rhs, _ = make(rbd, model, B, "f64", "aos", 71)
+    xa, xc = torch.zeros_like(state.v), torch.zeros_like(state.v)
+    rbd.mass_matrix_solve_(xa, state, dev(rhs, state), algorithm="aba")
+    rbd.mass_matrix_solve_(xc, state, dev(rhs, state), algorithm="cholesky")
+    M = oracle.mass_matrix(model, q)
+    Ms = np.tril(M) + np.transpose(np.tril(M, -1), (0, 2, 1))
+    xr = np.linalg.solve(Ms, rhs[..., None])[..., 0]
+    for x in (xa, xc):
+        assert np.abs(host(x, state) - xr).max() <= 1e-9 * max(1.0, np.abs(xr).max())
