@@ -906,11 +906,91 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(int nv, int stride, lon
   (void)bc;
 }
 
+// Register-resident variant used for nv <= 64: lane i keeps row i of the matrix in VGPRs (statically indexed, loops fully
+// unrolled over the padded size NVP = nv rounded up to a multiple of 8; the padding is an identity block so no guards are
+// needed).  Right-looking: column j is scaled by 1/sqrt(pivot), then every lane updates its own row with the column entries
+// L[k][j] broadcast by v_readlane (uniform lane index) — no LDS traffic and no waits inside the factorization.  The factor
+// is then transposed through LDS once for the backward substitution.
+RBD_DEV float bcast_lane(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+RBD_DEV double bcast_lane(double x, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+
+template <typename T, int NVP>
+__global__ __launch_bounds__(256) void chol_reg_kernel(int nv, long B, const T* __restrict__ Mg, const T* __restrict__ tau, const T* __restrict__ c,
+                                                       T* __restrict__ x, T* __restrict__ Lout, Layout Lm, Layout Lv, int* __restrict__ notpd) {
+  __shared__ T Lt[4][NVP][NVP + 1];  // per wave: the factor, for transposed reads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long state = (long)blockIdx.x * 4 + wave;
+  const bool live = state < B;
+  const int i = lane;
+  T row[NVP];
+#pragma unroll
+  for (int j = 0; j < NVP; ++j) {
+    T a = (i == j) ? T(1) : T(0);  // identity padding
+    if (live && i < nv && j <= i && j < nv) a = Mg[((long)j * nv + i) * Lm.sk + state * Lm.sb];
+    row[j] = a;
+  }
+  T b = T(0);
+  if (live && i < nv) {
+    if (tau) b = tau[(long)i * Lv.sk + state * Lv.sb];
+    if (c) b -= c[(long)i * Lv.sk + state * Lv.sb];
+  }
+  bool bad = false;
+  T dinv_own = T(1);
+#pragma unroll
+  for (int j = 0; j < NVP; ++j) {
+    const T d = bcast_lane(row[j], j);
+    bad |= !(d > T(0));
+    const T dr = SqrtT<T>::f(d);
+    const T di = T(1) / dr;
+    const T l = (i == j) ? dr : row[j] * di;  // L[i][j], meaningful for i >= j
+    row[j] = l;
+    dinv_own = (i == j) ? di : dinv_own;
+#pragma unroll
+    for (int k = j + 1; k < NVP; ++k) row[k] -= l * bcast_lane(l, k);  // A[i][k] -= L[i][j] L[k][j], meaningful for i >= k
+  }
+  if (live && bad && lane == 0) atomicOr(notpd, 1);
+  // forward substitution L y = b (column oriented)
+#pragma unroll
+  for (int k = 0; k < NVP; ++k) {
+    const T yk = bcast_lane(b, k) * bcast_lane(dinv_own, k);
+    b = (i == k) ? yk : ((i > k) ? b - row[k] * yk : b);
+  }
+  // transpose the factor through LDS, then backward substitution L' x = y
+  if (i < NVP) {
+#pragma unroll
+    for (int j = 0; j < NVP; ++j) Lt[wave][i][j] = row[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = NVP - 1; k >= 0; --k) {
+    const T xk = bcast_lane(b, k) * bcast_lane(dinv_own, k);
+    const T lki = (i < NVP) ? Lt[wave][k][i < NVP ? i : 0] : T(0);  // L[k][i]
+    b = (i == k) ? xk : ((i < k) ? b - lki * xk : b);
+  }
+  if (live && i < nv) x[(long)i * Lv.sk + state * Lv.sb] = b;
+  if (Lout && live && i < nv) {
+#pragma unroll
+    for (int j = 0; j < NVP; ++j)
+      if (j <= i && j < nv) Lout[((long)j * nv + i) * Lm.sk + state * Lm.sb] = row[j];
+  }
+}
+
 template <typename T>
 hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv,
                              int* notpd, hipStream_t s) {
-  int stride = nv | 1;            // odd multiple ...
-  stride = ((nv + 3) / 4) * 4;    // ... of 4 words: 4*odd keeps 16-byte row alignment and spreads rows over the banks
+  const dim3 grid4((unsigned)((B + 3) / 4));
+#define RBD_CHOL_REG(NVP)                                                                                                      \
+  if (nv <= NVP) {                                                                                                            \
+    hipLaunchKernelGGL((chol_reg_kernel<T, NVP>), grid4, dim3(256), 0, s, nv, B, (const T*)M, (const T*)tau, (const T*)c, (T*)x, \
+                       (T*)Lout, Lm, Lv, notpd);                                                                              \
+    return hipGetLastError();                                                                                                 \
+  }
+  RBD_CHOL_REG(8) RBD_CHOL_REG(16) RBD_CHOL_REG(24) RBD_CHOL_REG(32) RBD_CHOL_REG(40) RBD_CHOL_REG(48)
+#undef RBD_CHOL_REG
+  // larger systems: the LDS-resident kernel
+  int stride = ((nv + 3) / 4) * 4;  // 4*odd words: 16-byte row alignment, rows spread over the banks
   if (((stride / 4) & 1) == 0) stride += 4;
   const int wpb = 4;
   const size_t shmem = (size_t)wpb * ((size_t)nv * stride + 64) * sizeof(T);
