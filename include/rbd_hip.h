@@ -168,6 +168,11 @@ int rbd_mass_matrix(rbd_ws_t* ws, int32_t B, const void* q, void* M_out, const r
 int rbd_mass_matrix_solve(rbd_ws_t* ws, int32_t B, const void* q, const void* rhs, void* x,
                           void* M_out, const rbd_opts_t* opts);
 
+/* The dense step of dynamics_solve! on its own: L = potrf!('L', M) and x = potrs!(L, rhs) for B caller-provided nv×nv SPD
+ * matrices (lower triangles read; device pointers).  L_out (nullable) receives the factor — DynamicsResult.L
+ * (src/dynamics_result.jl:32).  fp32 with nv <= 40 runs on the matrix cores (chol_mfma_kernel).                        */
+int rbd_cholesky_solve(rbd_ws_t* ws, int32_t B, const void* M, const void* rhs, void* x, void* L_out, const rbd_opts_t* opts);
+
 /* after rbd_dynamics(..., RBD_ALGO_CRBA_CHOLESKY): copy the DynamicsResult side
  * products out of the workspace (any pointer may be NULL). M: nv×nv (lower),
  * c: nv, K: nc×nv column-major, k: nc; layout per opts.                        */

@@ -775,4 +775,20 @@ int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, cons
   return RBD_OK;
 }
 
+
+int rbd_cholesky_solve(rbd_ws_t* w, int32_t B, const void* M, const void* rhs, void* x, void* L_out, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!M || !rhs || !x || o.memory != RBD_MEM_DEVICE) return RBD_ERR_INVALID_ARGUMENT;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const rbd_model* m = w->model;
+  const Layout Lv = layout_of(o.layout, m->nv, B), Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
+  Timed t(w);
+  if (w->dtype == RBD_F64) HIP_TRY(launch_chol_solve<double>(m->nv, B, M, rhs, nullptr, x, L_out, Lm, Lv, w->d_notpd, w->stream));
+  else HIP_TRY(launch_chol_solve<float>(m->nv, B, M, rhs, nullptr, x, L_out, Lm, Lv, w->d_notpd, w->stream));
+  return RBD_OK;
+}
+
 }  // extern "C"

@@ -977,9 +977,187 @@ __global__ __launch_bounds__(256) void chol_reg_kernel(int nv, long B, const T* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA tile Cholesky (fp32): 16 states per wavefront.  A state is a quad of lanes; the matrix is cut into 4x4 tiles and
+// lane r of the quad keeps row r of every lower tile in VGPRs (tile (I,J), register c  <->  A[4I + r][4J + c]).  Per block
+// column J: (1) the diagonal tile is factored inside the quad (DPP quad broadcasts), (2) the panel tiles below are solved
+// against it row by row (X = T L_d^-T), (3) the trailing sub-matrix gets the rank-4 update  T(I,J') -= X_I X_J'^T  as four
+// v_mfma_f32_4x4x1_16B_f32 per tile: one instruction updates the tile of all 16 states.  Operand/result layout of that
+// instruction (probed on gfx950, scripts/ubench/mfma4x4.hip): D[i][j] lives in lane 4*block + j, register i and equals
+// A[lane 4*block + i] * B[lane 4*block + j]; feeding A = -X_J'[:,k], B = X_I[:,k] therefore leaves tile (I,J') in exactly the
+// "lane = row, register = column" form it is stored in — no transposes anywhere.  This is the one true dense contraction of
+// the path (the O(n^3) part of dynamics_solve!, src/mechanism_algorithms.jl:764), which is why it is the one place MFMA is used.
+// Padding to NT*4 is an identity block.  Forward/backward substitution reuse the tiles (quad broadcasts / quad sums).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int K> RBD_DEV float quad_bcast(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true));
+}
+RBD_DEV float quad_sum(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+  return x;
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void chol_mfma_kernel(int nv, long B, const float* __restrict__ Mg, const float* __restrict__ tau,
+                                                       const float* __restrict__ c, float* __restrict__ x, float* __restrict__ Lout,
+                                                       Layout Lm, Layout Lv, int* __restrict__ notpd) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 3;
+  const long state = (long)blockIdx.x * 16 + (lane >> 2);
+  const bool live = state < B;
+  f32x4_t t[NT][NT];  // lower tiles only (I >= J)
+#pragma unroll
+  for (int I = 0; I < NT; ++I)
+#pragma unroll
+    for (int J = 0; J <= I; ++J)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int row = 4 * I + r, col = 4 * J + cc;
+        float a = (row == col) ? 1.0f : 0.0f;
+        if (live && row < nv && col <= row) a = Mg[((long)col * nv + row) * Lm.sk + state * Lm.sb];
+        t[I][J][cc] = a;
+      }
+  float y[NT];
+#pragma unroll
+  for (int I = 0; I < NT; ++I) {
+    const int row = 4 * I + r;
+    float b = 0.0f;
+    if (live && row < nv) {
+      if (tau) b = tau[(long)row * Lv.sk + state * Lv.sb];
+      if (c) b -= c[(long)row * Lv.sk + state * Lv.sb];
+    }
+    y[I] = b;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int J = 0; J < NT; ++J) {
+    // (1) diagonal tile: unblocked Cholesky inside the quad
+    float dinv[4];
+#define RBD_DIAG_STEP(K)                                                              \
+    {                                                                                 \
+      const float d = quad_bcast<K>(t[J][J][K]);                                      \
+      bad |= !(d > 0.0f);                                                             \
+      const float rs = 1.0f / SqrtT<float>::f(d);                                     \
+      dinv[K] = rs;                                                                   \
+      const float lk = (r == K) ? d * rs : t[J][J][K] * rs;                           \
+      t[J][J][K] = lk;                                                                \
+      if (K < 1) t[J][J][1] -= lk * quad_bcast<1>(lk);                                \
+      if (K < 2) t[J][J][2] -= lk * quad_bcast<2>(lk);                                \
+      if (K < 3) t[J][J][3] -= lk * quad_bcast<3>(lk);                                \
+    }
+    RBD_DIAG_STEP(0) RBD_DIAG_STEP(1) RBD_DIAG_STEP(2) RBD_DIAG_STEP(3)
+#undef RBD_DIAG_STEP
+    // entries of the factored diagonal tile, uniform inside the quad: Ld[k][m] = L[4J+k][4J+m], m < k
+    const float l10 = quad_bcast<1>(t[J][J][0]), l20 = quad_bcast<2>(t[J][J][0]), l30 = quad_bcast<3>(t[J][J][0]);
+    const float l21 = quad_bcast<2>(t[J][J][1]), l31 = quad_bcast<3>(t[J][J][1]), l32 = quad_bcast<3>(t[J][J][2]);
+    // (2) panel: X = T L_d^-T, one row per lane
+#pragma unroll
+    for (int I = J + 1; I < NT; ++I) {
+      const float x0 = t[I][J][0] * dinv[0];
+      const float x1 = (t[I][J][1] - x0 * l10) * dinv[1];
+      const float x2 = (t[I][J][2] - x0 * l20 - x1 * l21) * dinv[2];
+      const float x3 = (t[I][J][3] - x0 * l30 - x1 * l31 - x2 * l32) * dinv[3];
+      t[I][J][0] = x0; t[I][J][1] = x1; t[I][J][2] = x2; t[I][J][3] = x3;
+    }
+    // (3) trailing update on the matrix cores: T(I,J') -= X_I X_J'^T for J < J' <= I
+#pragma unroll
+    for (int Jp = J + 1; Jp < NT; ++Jp) {
+      const float n0 = -t[Jp][J][0], n1 = -t[Jp][J][1], n2 = -t[Jp][J][2], n3 = -t[Jp][J][3];
+#pragma unroll
+      for (int I = Jp; I < NT; ++I) {
+        f32x4_t acc = t[I][Jp];
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(n0, t[I][J][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(n1, t[I][J][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(n2, t[I][J][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(n3, t[I][J][3], acc, 0, 0, 0);
+        t[I][Jp] = acc;
+      }
+    }
+    // forward substitution for this block column: y_J <- L_d^-1 y_J, then y_I -= X(I,J) y_J
+    {
+      float v0 = quad_bcast<0>(y[J]) * dinv[0];
+      y[J] = (r == 0) ? v0 : y[J] - t[J][J][0] * v0;
+      float v1 = quad_bcast<1>(y[J]) * dinv[1];
+      y[J] = (r == 1) ? v1 : ((r > 1) ? y[J] - t[J][J][1] * v1 : y[J]);
+      float v2 = quad_bcast<2>(y[J]) * dinv[2];
+      y[J] = (r == 2) ? v2 : ((r > 2) ? y[J] - t[J][J][2] * v2 : y[J]);
+      float v3 = quad_bcast<3>(y[J]) * dinv[3];
+      y[J] = (r == 3) ? v3 : y[J];
+#pragma unroll
+      for (int I = J + 1; I < NT; ++I) y[I] -= t[I][J][0] * v0 + t[I][J][1] * v1 + t[I][J][2] * v2 + t[I][J][3] * v3;
+    }
+  }
+  if (live && bad && r == 0) atomicOr(notpd, 1);
+  // backward substitution L' x = y, block columns in reverse
+#pragma unroll
+  for (int J = NT - 1; J >= 0; --J) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;  // (X(I,J)' x_I)[c], partial per lane (row)
+#pragma unroll
+    for (int I = J + 1; I < NT; ++I) { a0 += t[I][J][0] * y[I]; a1 += t[I][J][1] * y[I]; a2 += t[I][J][2] * y[I]; a3 += t[I][J][3] * y[I]; }
+    a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2); a3 = quad_sum(a3);
+    float yj = y[J] - ((r == 0) ? a0 : (r == 1) ? a1 : (r == 2) ? a2 : a3);
+    // x_k = (y_k - sum_{m>k} L[m][k] x_m) / L[k][k] inside the diagonal tile: L[m][k] is register k of lane m
+    const float d0 = quad_bcast<0>(t[J][J][0]), d1 = quad_bcast<1>(t[J][J][1]), d2 = quad_bcast<2>(t[J][J][2]), d3 = quad_bcast<3>(t[J][J][3]);
+    // (cross-lane reads are issued unconditionally — a DPP source lane that a divergent branch has masked off reads as 0)
+    const float b30 = quad_bcast<3>(t[J][J][0]), b31 = quad_bcast<3>(t[J][J][1]), b32 = quad_bcast<3>(t[J][J][2]);
+    const float b20 = quad_bcast<2>(t[J][J][0]), b21 = quad_bcast<2>(t[J][J][1]);
+    const float x3 = quad_bcast<3>(yj) / d3;
+    const float l3r = (r == 0) ? b30 : (r == 1) ? b31 : b32;
+    yj = (r == 3) ? x3 : yj - l3r * x3;
+    const float x2 = quad_bcast<2>(yj) / d2;
+    const float l2r = (r == 0) ? b20 : b21;
+    yj = (r == 2) ? x2 : ((r < 2) ? yj - l2r * x2 : yj);
+    const float x1 = quad_bcast<1>(yj) / d1;
+    const float l1r = quad_bcast<1>(t[J][J][0]);
+    yj = (r == 1) ? x1 : ((r < 1) ? yj - l1r * x1 : yj);
+    const float x0 = quad_bcast<0>(yj) / d0;
+    yj = (r == 0) ? x0 : yj;
+    y[J] = yj;
+  }
+#pragma unroll
+  for (int I = 0; I < NT; ++I) {
+    const int row = 4 * I + r;
+    if (live && row < nv) x[(long)row * Lv.sk + state * Lv.sb] = y[I];
+  }
+  if (Lout && live) {
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int row = 4 * I + r, col = 4 * J + cc;
+          if (row < nv && col <= row) Lout[((long)col * nv + row) * Lm.sk + state * Lm.sb] = t[I][J][cc];
+        }
+  }
+}
+
+template <typename T> struct MfmaChol {
+  static bool launch(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t) { return false; }
+};
+template <> struct MfmaChol<float> {
+  static bool launch(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv, int* notpd,
+                     hipStream_t s) {
+    const dim3 grid((unsigned)((B + 15) / 16));
+#define RBD_CHOL_MFMA(NT)                                                                                                           \
+    if (nv <= 4 * NT) {                                                                                                             \
+      hipLaunchKernelGGL((chol_mfma_kernel<NT>), grid, dim3(64), 0, s, nv, B, (const float*)M, (const float*)tau, (const float*)c,  \
+                         (float*)x, (float*)Lout, Lm, Lv, notpd);                                                                   \
+      return true;                                                                                                                  \
+    }
+    RBD_CHOL_MFMA(1) RBD_CHOL_MFMA(2) RBD_CHOL_MFMA(4) RBD_CHOL_MFMA(6) RBD_CHOL_MFMA(8) RBD_CHOL_MFMA(9) RBD_CHOL_MFMA(10)
+#undef RBD_CHOL_MFMA
+    return false;
+  }
+};
+
 template <typename T>
 hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv,
                              int* notpd, hipStream_t s) {
+  if (MfmaChol<T>::launch(nv, B, M, tau, c, x, Lout, Lm, Lv, notpd, s)) return hipGetLastError();  // fp32, nv <= 40: matrix cores
   const dim3 grid4((unsigned)((B + 3) / 4));
 #define RBD_CHOL_REG(NVP)                                                                                                      \
   if (nv <= NVP) {                                                                                                            \

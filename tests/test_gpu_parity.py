@@ -502,3 +502,51 @@ def test_mass_matrix_solve_aba_equals_cholesky(rbd, oracle, models, name):
     xr = np.linalg.solve(Ms, rhs[..., None])[..., 0]
     for x in (xa, xc):
         assert np.abs(host(x, state) - xr).max() <= 1e-9 * max(1.0, np.abs(xr).max())
+
+
+@pytest.mark.parametrize("name", ["double_pendulum", "acrobot_urdf", "atlas_fixed", "atlas_floating", "randmech3"])
+def test_cholesky_route_f32_mfma(rbd, oracle, models, name):
+    """fp32 CRBA + Cholesky route: for nv <= 40 the factorization runs on the matrix cores (chol_mfma_kernel, tile sizes
+    NT = 1, 1, 8, 9, 10 here).  Checked by the backward error of M x = tau - c with the fp64 oracle's M and c."""
+    model = models[name]
+    B = 50  # not a multiple of the 16 states a wavefront factors at once
+    state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 81)
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="crba")
+    assert rbd.sync(state) == 0
+    xg = host(result.vd, state)
+    M = oracle.mass_matrix(model, q)
+    Ms = np.tril(M) + np.transpose(np.tril(M, -1), (0, 2, 1))
+    rhs = tau - oracle.dynamics_bias(model, q, v, fe)
+    res = np.einsum("bij,bj->bi", Ms, xg) - rhs
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(rhs, axis=1))
+    assert np.isfinite(xg).all() and eta.max() <= 2e-5, eta.max()
+
+
+@pytest.mark.parametrize("dtype,name", [("f32", "atlas_floating"), ("f32", "atlas_fixed"), ("f32", "randmech1"), ("f64", "atlas_floating"),
+                                        ("f64", "double_pendulum")])
+def test_cholesky_solve_factor_and_solution(rbd, models, dtype, name):
+    """rbd_cholesky_solve on caller-provided SPD matrices: L equals LAPACK's potrf factor, x = A⁻¹ b (fp32, nv <= 40: the MFMA
+    tile kernel; fp64: the register-resident kernel)."""
+    import ctypes
+    from rigidbodydynamics_jl_amd import _capi
+    model = models[name]
+    nv, B = model.nv, 37
+    rng = np.random.default_rng(91)
+    A = rng.standard_normal((B, nv, nv))
+    A = A @ A.transpose(0, 2, 1) + nv * np.eye(nv)
+    b = rng.standard_normal((B, nv))
+    st = rbd.MechanismState(model, B, dtype=TD[dtype])
+    lower_colmajor = np.tril(A).transpose(0, 2, 1).reshape(B, nv * nv)   # only the lower triangle is provided
+    M = torch.as_tensor(lower_colmajor.copy(), dtype=TD[dtype]).cuda()
+    rhs = torch.as_tensor(b, dtype=TD[dtype]).cuda()
+    x, L = torch.zeros_like(rhs), torch.zeros_like(M)
+    opts = st._opts()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert _capi.lib().rbd_cholesky_solve(st.ws.handle, B, P(M), P(rhs), P(x), P(L), ctypes.byref(opts)) == 0
+    assert rbd.sync(st) == 0
+    Lg = np.tril(L.double().cpu().numpy().reshape(B, nv, nv).transpose(0, 2, 1))
+    tol = 1e-12 if dtype == "f64" else 2e-5
+    assert np.abs(Lg - np.linalg.cholesky(A)).max() <= tol * np.abs(A).max() ** 0.5
+    xr = np.linalg.solve(A, b[..., None])[..., 0]
+    assert np.abs(x.double().cpu().numpy() - xr).max() <= tol * max(1.0, np.abs(xr).max())
