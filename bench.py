@@ -212,7 +212,15 @@ def main():
         out["rccl_all_gather_vdot_ms"] = gather_ms
 
     if not args.no_cpu_baseline:
-        ncores = os.cpu_count() or 1
+        # host threads actually available to this process: affinity mask, capped by the cgroup CPU quota when there is one
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                ncores = max(1, min(ncores, int(round(int(quota) / int(period)))))
+        except Exception:
+            pass
+        os.environ.setdefault("OMP_PROC_BIND", "close")
         S1 = 2048
         qs, vs, ts = q[:S1], v[:S1], tau[:S1]
         fs = fext[:S1] if fext is not None else None
@@ -223,8 +231,8 @@ def main():
             oracle.dynamics(model, qs, vs, ts, fs, nthreads=1)
             reps1 += 1
         t1t = (time.perf_counter() - c0) / (reps1 * S1)
-        # all cores: a sample large enough that the OpenMP fork/join is amortised (512 states per thread per call)
-        tile = max(1, (ncores * 512 + B - 1) // B)
+        # all cores: a sample large enough that the OpenMP fork/join is amortised (2048 states per thread per call)
+        tile = max(1, (ncores * 2048 + B - 1) // B)
         qN, vN, tN = np.tile(q, (tile, 1)), np.tile(v, (tile, 1)), np.tile(tau, (tile, 1))
         fN = np.tile(fext, (tile, 1)) if fext is not None else None
         SN = qN.shape[0]
