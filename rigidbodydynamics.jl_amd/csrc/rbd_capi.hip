@@ -762,7 +762,20 @@ int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, cons
   if ((st = mk_ensure(w, B))) return st;
   Opts od = o; od.memory = RBD_MEM_DEVICE;
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B);
-  for (int step = 0; step < nsteps; ++step) {
+  const bool fused = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA);
+  const Layout Lf = layout_of(o.layout, 6L * m->nb, B);
+  for (int step = 0; fused && step < nsteps; ++step) {
+    // tree mechanism, articulated-body route: each of the four stages is ONE launch (stage bookkeeping fused into aba_kernel)
+    for (int stage = 0; stage < 4; ++stage) {
+      MkFuse F{};
+      F.stage = stage; F.dt = dt; F.W = w->mk; F.q_state = dq; F.v_state = dv;
+      if (w->dtype == RBD_F64) HIP_TRY(launch_aba<double>(w->dm, B, dq, dv, dtau, df, nullptr, nullptr, Lq, Lv, Lf, w->stream, &F));
+      else HIP_TRY(launch_aba<float>(w->dm, B, dq, dv, dtau, df, nullptr, nullptr, Lq, Lv, Lf, w->stream, &F));
+    }
+    if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, 4, dt, dq, dv, nullptr, w->mk, Lq, Lv, w->stream));
+    else HIP_TRY(launch_mk_stage<float>(w->dm, B, 4, dt, dq, dv, nullptr, w->mk, Lq, Lv, w->stream));
+  }
+  for (int step = 0; !fused && step < nsteps; ++step) {
     for (int stage = 0; stage <= 4; ++stage) {
       if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));
       else HIP_TRY(launch_mk_stage<float>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));

@@ -60,9 +60,18 @@ template <typename T> struct LoopView {
 };
 
 // integrator scratch of mk_stage_kernel (same layout as the caller's q / v)
+// fused-integrator descriptor handed to aba_kernel (stage < 0: plain dynamics!)
+struct MkBuffers;
 struct MkBuffers {
   void* q0; void* v0;   // base point of the step, AOS-agnostic: same layout as q / v
   void* phid[4]; void* vd[4];
+};
+
+struct MkFuse {
+  int32_t stage;  // 0..3, or -1
+  double dt;
+  MkBuffers W;
+  void* q_state; void* v_state;
 };
 
 #define RBD_DEV __device__ __forceinline__
@@ -303,6 +312,10 @@ RBD_DEV float rcp_nr(float x) {
   float r = __builtin_amdgcn_rcpf(x);
   return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r);
 }
+template <typename T> struct SqrtT;
+template <> struct SqrtT<double> { static __device__ __forceinline__ double f(double x) { return sqrt(x); } };
+template <> struct SqrtT<float> { static __device__ __forceinline__ float f(float x) { return sqrtf(x); } };
+
 RBD_DEV void sincos_t(double x, double* s, double* c) { sincos(x, s, c); }
 RBD_DEV void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
 

@@ -6,7 +6,7 @@
 namespace rbd {
 template <typename T>
 hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
-                      void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+                      void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s, const MkFuse* fuse = nullptr);
 template <typename T>
 hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
                        void* qdot, void* body_out, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
