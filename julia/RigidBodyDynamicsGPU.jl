@@ -212,4 +212,19 @@ function mass_matrix!(M::Array{T, 3}, state::BatchedMechanismState{T}) where {T}
 end
 mass_matrix!(result::BatchedDynamicsResult, state::BatchedMechanismState) = mass_matrix!(result.massmatrix, state)
 
+"""`simulate(state0, final_time; Δt, stabilization_gains)` — src/simulate.jl:36-55 for the whole batch: Munthe-Kaas RK4 on the
+device (`rbd_simulate`), constant `torques` (the default control is `zero_torque!`); `state.q`, `state.v` are advanced in place."""
+function RigidBodyDynamics.simulate(state::BatchedMechanismState{T}, final_time; Δt = 1e-4, torques = nothing, stabilization_gains = :default) where {T}
+    checkmodcount(state)
+    nsteps, t = 0, zero(T)
+    while t < final_time            # same loop as integrate(), src/ode_integrators.jl:311-314
+        t += Δt; nsteps += 1
+    end
+    check(ccall((:rbd_simulate, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
+        state.ws, batchsize(state), state.q, state.v, nullable(torques), C_NULL, Float64(Δt), nsteps,
+        opts(stabilization = stabilization_gains === nothing ? 0 : 1)), "rbd_simulate")
+    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+    range(zero(T), step = T(Δt), length = nsteps + 1)
+end
+
 end # module

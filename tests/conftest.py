@@ -19,6 +19,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def rbd():
     import rbd_amd
+    if not os.path.exists(rbd_amd._capi.LIB_PATH):  # fresh checkout: build in-tree (hipcc cross-compiles without a GPU)
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(ROOT, "rigidbodydynamics.jl_amd", "csrc", "build.sh")])
     return rbd_amd
 
 

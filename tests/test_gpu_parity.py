@@ -550,3 +550,25 @@ def test_cholesky_solve_factor_and_solution(rbd, models, dtype, name):
     assert np.abs(Lg - np.linalg.cholesky(A)).max() <= tol * np.abs(A).max() ** 0.5
     xr = np.linalg.solve(A, b[..., None])[..., 0]
     assert np.abs(x.double().cpu().numpy() - xr).max() <= tol * max(1.0, np.abs(xr).max())
+
+
+def test_config4_shard_f32_full_size_round_trip(rbd, oracle, models):
+    """BASELINE configs[3]: one GPU's shard of the 524 288-state fp32 batch (65 536 states).  Size-independent property on the
+    GPU (dynamics! then inverse_dynamics! returns τ, in fp32 backward-error terms) plus an oracle check on a sample."""
+    model = models["atlas_floating"]
+    B = 65536
+    state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 3)
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32)
+    t = dev(tau, state)
+    rbd.dynamics_(result, state, t)
+    back = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(back, state, result.vd)
+    c = torch.zeros_like(state.v)
+    rbd.dynamics_bias_(c, state)
+    rel = (back - t).norm(dim=1) / (t - c).norm(dim=1)
+    assert float(rel.max()) <= 5e-4          # fp32 RNEA(ABA(τ)) − τ, cond(M) ≈ 5e5
+    n = 128
+    vd = host(result.vd, state)[:n]
+    resid = oracle.inverse_dynamics(model, q[:n], v[:n], vd) - tau[:n]
+    cc = oracle.dynamics_bias(model, q[:n], v[:n])
+    assert (np.linalg.norm(resid, axis=1) / np.linalg.norm(tau[:n] - cc, axis=1)).max() <= 2e-5
