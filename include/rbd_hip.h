@@ -191,6 +191,13 @@ int rbd_simulate(rbd_ws_t* ws, int32_t B, void* q, void* v, const void* tau, con
                  const rbd_opts_t* opts);
 int rbd_mk_stage(rbd_ws_t* ws, int32_t B, int32_t stage, double dt, void* q, void* v, const void* vdot_prev, const rbd_opts_t* opts);
 
+/* ---- kinematics by-products of the same forward-kinematics pass (device pointers; every output nullable) ---------------
+ * momentum_matrix: 6×nv column-major per state, root frame, (angular; linear) — momentum_matrix!(out, state)
+ *   src/mechanism_algorithms.jl:313-327;  com: 3×B — center_of_mass(state) :28-50;  energy: 2×B = (kinetic_energy,
+ *   gravitational_potential_energy) src/mechanism_state.jl:886-903 (needs v).                                          */
+int rbd_kinematics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* momentum_matrix, void* com, void* energy,
+                   const rbd_opts_t* opts);
+
 /* ---- diagnostics ------------------------------------------------------------ */
 const char* rbd_status_string(int status);
 const char* rbd_last_hip_error(void);   /* thread-local text of the last HIP failure     */

@@ -148,3 +148,17 @@ def dynamics_loops(model, q, v, tau=None, fext=None, stabilize=True, dtype=np.fl
     out["M"] = out["M"].transpose(0, 2, 1)
     out["lam"], out["k"] = out["lam"][:, :nc], out["k"][:, :nc]
     return out
+
+
+def momentum_matrix(model, q, v=None, dtype=np.float64):
+    """(A [B, 6, nv], hsum [B, 6] = Σ_b I_b T_b (when v is given), com [B, 3])."""
+    sfx, ct = _sfx(dtype)
+    f = getattr(lib(), "rbdo_momentum_matrix" + sfx)
+    f.restype = ctypes.c_int
+    B = q.shape[0]
+    q = np.ascontiguousarray(q, dtype)
+    v = None if v is None else np.ascontiguousarray(v, dtype)
+    A = np.zeros((B, model.nv, 6), dtype); h = np.zeros((B, 6), dtype); com = np.zeros((B, 3), dtype)
+    for b in range(B):
+        assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(None if v is None else v[b], ct), _ptr(A[b], ct), _ptr(h[b], ct), _ptr(com[b], ct)) == 0
+    return A.transpose(0, 2, 1), h, com

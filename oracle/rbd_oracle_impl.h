@@ -847,6 +847,45 @@ int FN(rbdo_energy)(const rbd_flat_model_t* m, const REAL* q, const REAL* v, REA
   return RBD_OK;
 }
 
+/* momentum_matrix! in the root frame: src/mechanism_algorithms.jl:313-327 — column i = crb_inertia(body(i)) * S_i.
+ * A: 6 x nv column-major (angular; linear).  Also momentum = sum_b I_b T_b (src/mechanism_state.jl:878-880) for the check
+ * of test/test_mechanism_algorithms.jl:527-545, and center_of_mass: src/mechanism_algorithms.jl:28-50.               */
+int FN(rbdo_momentum_matrix)(const rbd_flat_model_t* m, const REAL* q, const REAL* v, REAL* A, REAL* hsum, REAL* com) {
+  CACHE c;
+  if (FN(cache_alloc)(m, &c)) return RBD_ERR_OUT_OF_MEMORY;
+  FN(update_transforms)(m, q, &c);
+  FN(update_motion_subspaces)(m, q, &c);
+  FN(update_inertias)(m, &c);
+  INERTIA* Ic = (INERTIA*)malloc(sizeof(INERTIA) * (size_t)c.nb);
+  for (int i = 0; i < c.nb; ++i) Ic[i] = c.I[i];
+  for (int i = c.nb - 1; i >= 0; --i) {
+    int p = m->parent[i];
+    if (p >= 0) {
+      for (int k = 0; k < 9; ++k) Ic[p].J[k] += Ic[i].J[k];
+      for (int k = 0; k < 3; ++k) Ic[p].c[k] += Ic[i].c[k];
+      Ic[p].m += Ic[i].m;
+    }
+  }
+  for (int i = 0; i < c.nb; ++i) {
+    int nvi = FN(joint_nv)(m->joint_type[i]);
+    for (int k = 0; k < nvi; ++k) FN(mul_inertia)(&Ic[i], c.S + 6 * (m->v_offset[i] + k), A + 6 * (m->v_offset[i] + k));
+  }
+  if (hsum && v) {
+    FN(update_twists)(m, v, &c);
+    for (int j = 0; j < 6; ++j) hsum[j] = 0;
+    for (int i = 0; i < c.nb; ++i) { REAL h[6]; FN(mul_inertia)(&c.I[i], c.T + 6 * i, h); for (int j = 0; j < 6; ++j) hsum[j] += h[j]; }
+  }
+  if (com) {
+    REAL mass = 0, s3[3] = {0, 0, 0};
+    for (int i = 0; i < c.nb; ++i)
+      if (c.I[i].m > 0) { mass += c.I[i].m; for (int k = 0; k < 3; ++k) s3[k] += c.I[i].c[k]; } /* m * com_world = world cross_part */
+    for (int k = 0; k < 3; ++k) com[k] = s3[k] / mass;
+  }
+  free(Ic);
+  FN(cache_free)(&c);
+  return RBD_OK;
+}
+
 /* transforms_to_root of every moving body, for FK checks: out[b*12 ..] = R (9, row-major), p (3) */
 int FN(rbdo_transforms)(const rbd_flat_model_t* m, const REAL* q, REAL* out) {
   CACHE c;

@@ -804,4 +804,21 @@ int rbd_cholesky_solve(rbd_ws_t* w, int32_t B, const void* M, const void* rhs, v
   return RBD_OK;
 }
 
+
+int rbd_kinematics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* momentum_matrix, void* com, void* energy, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!q || o.memory != RBD_MEM_DEVICE || (energy && !v)) return RBD_ERR_INVALID_ARGUMENT;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const rbd_model* m = w->model;
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), La = layout_of(o.layout, 6L * m->nv, B);
+  const Layout L3 = layout_of(o.layout, 3, B), L2 = layout_of(o.layout, 2, B);
+  Timed t(w);
+  if (w->dtype == RBD_F64) HIP_TRY(launch_kin<double>(w->dm, B, q, v, momentum_matrix, com, energy, Lq, Lv, La, L3, L2, w->stream));
+  else HIP_TRY(launch_kin<float>(w->dm, B, q, v, momentum_matrix, com, energy, Lq, Lv, La, L3, L2, w->stream));
+  return RBD_OK;
+}
+
 }  // extern "C"

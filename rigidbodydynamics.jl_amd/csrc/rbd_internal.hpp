@@ -29,3 +29,8 @@ template <typename T>
 hipError_t launch_mk_stage(const DevModel& M, long B, int stage, double dt, void* q, void* v, const void* vdot_prev, const MkBuffers& W,
                            Layout Lq, Layout Lv, hipStream_t s);
 }
+namespace rbd {
+template <typename T>
+hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, void* A, void* com, void* energy, Layout Lq, Layout Lv, Layout La,
+                      Layout L3, Layout L2, hipStream_t s);
+}

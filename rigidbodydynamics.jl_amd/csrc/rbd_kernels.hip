@@ -801,6 +801,96 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kinematics by-products from the same FK pass: momentum_matrix! in the root frame
+// (src/mechanism_algorithms.jl:313-327: column i = crb_inertia(body(i)) * S_i), center_of_mass (:28-50),
+// kinetic_energy / gravitational_potential_energy (src/mechanism_state.jl:886-903).  Outputs are nullable:
+//   A_out [6*nv x B] (6 x nv column-major per state), com_out [3 x B], energy_out [2 x B] = (kinetic, potential).
+// ---------------------------------------------------------------------------------------------
+template <typename T> RBD_DEV T group_sum(T x, int lps) {  // sum over the lanes of one state (lps = power of two)
+  for (int o = 1; o < lps; o <<= 1) x += shfl(x, (int)((threadIdx.x & 63) ^ o));
+  return x;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void kin_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v, T* __restrict__ A_out,
+                                                  T* __restrict__ com_out, T* __restrict__ energy_out, Layout Lq, Layout Lv, Layout La,
+                                                  Layout L3, Layout L2) {
+  Body<T> b;
+  load_body(M, B, b);
+  const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
+  T qj[7], vj[6];
+  load_joint_q(b, q, Lq, qj);
+  load_joint_v(b, v, Lv, vj);
+  T XR[9], Xp[3], R[9], p[3], tl[6], Tw[6], vJ[6];
+  local_transform(b, rb, qj, XR, Xp);
+  local_joint_motion(b, rb, vj, tl);
+  sweep_kinematics<T, false>(M, b, XR, Xp, R, p, tl, Tw, vJ, nullptr, nullptr);
+  RInertia<T> Ic;
+  {
+    T Jb[6], mc[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jb[k] = rb[RB_J + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mc[k] = rb[RB_MC + k];
+    inertia_to_root(Jb, mc, rb[RB_M], R, p, Ic);
+    if (!b.valid) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Ic.J[k] = T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ic.c[k] = T(0);
+      Ic.m = T(0);
+    }
+  }
+  // energies and centre of mass: per-body terms summed over the state's lanes
+  {
+    T h[6];
+    mul_inertia(Ic, Tw, h);
+    const T ke = b.valid ? dot6(h, Tw) / 2 : T(0);
+    const T pe = -(T(M.gravity[0]) * Ic.c[0] + T(M.gravity[1]) * Ic.c[1] + T(M.gravity[2]) * Ic.c[2]);  // -m g·com, m com = root-frame cross part
+    const T has = (Ic.m > T(0)) ? T(1) : T(0);
+    const T kes = group_sum(ke, M.lps), pes = group_sum(pe * has, M.lps);
+    const T ms = group_sum(Ic.m * has, M.lps);
+    const T cx = group_sum(Ic.c[0] * has, M.lps), cy = group_sum(Ic.c[1] * has, M.lps), cz = group_sum(Ic.c[2] * has, M.lps);
+    if (b.valid && b.sub == 0) {
+      if (energy_out) { energy_out[0 * L2.sk + b.state * L2.sb] = kes; energy_out[1 * L2.sk + b.state * L2.sb] = pes; }
+      if (com_out) { com_out[0 * L3.sk + b.state * L3.sb] = cx / ms; com_out[1 * L3.sk + b.state * L3.sb] = cy / ms; com_out[2 * L3.sk + b.state * L3.sb] = cz / ms; }
+    }
+  }
+  if (A_out == nullptr) return;  // uniform
+  for (int l = M.nlevels - 1; l >= 1; --l) {
+    const int ns = (int)M.nslots[l];
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) {
+      T give[10], acc[10];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) give[k] = acc[k] = Ic.J[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) give[6 + k] = acc[6 + k] = Ic.c[k];
+      give[9] = acc[9] = Ic.m;
+      gather_add<T, 10>(b, l, s, give, acc);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Ic.J[k] = acc[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ic.c[k] = acc[6 + k];
+      Ic.m = acc[9];
+    }
+  }
+  const int nvi = joint_nv(b.jtype);
+  const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
+#pragma unroll 1
+  for (int ci = 0; ci < nvi; ++ci) {
+    T sl[6], Si[6], F[6];
+    subspace_col(b.jtype, ax, ay, ci, sl);
+    xmotion(R, p, sl, Si);
+    mul_inertia(Ic, Si, F);
+    if (b.valid) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) A_out[((long)(b.voff + ci) * 6 + k) * La.sk + b.state * La.sb] = F[k];
+    }
+  }
+}
+
 // ---- launchers -----------------------------------------------------------------------------
 static inline dim3 grid_for(const DevModel& M, long B, int block) {
   const long spw = 64 / M.lps;
@@ -808,6 +898,16 @@ static inline dim3 grid_for(const DevModel& M, long B, int block) {
   const long wpb = block / 64;
   return dim3((unsigned)((waves + wpb - 1) / wpb));
 }
+
+template <typename T>
+hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, void* A, void* com, void* energy, Layout Lq, Layout Lv, Layout La,
+                      Layout L3, Layout L2, hipStream_t s) {
+  hipLaunchKernelGGL(kin_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (T*)A, (T*)com, (T*)energy, Lq, Lv, La,
+                     L3, L2);
+  return hipGetLastError();
+}
+template hipError_t launch_kin<double>(const DevModel&, long, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_kin<float>(const DevModel&, long, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, Layout, Layout, hipStream_t);
 
 template <typename T>
 hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,

@@ -369,3 +369,39 @@ def dynamics_ode_(xd: torch.Tensor, result: DynamicsResult, state: MechanismStat
     xd[:, :f.nq].copy_(result.qd)
     xd[:, f.nq:].copy_(result.vd)
     return xd
+
+
+def _kin(state: MechanismState, A=None, com=None, energy=None):
+    state.ws.use_current_stream()
+    opts = state._opts()
+    _raise(_capi.lib().rbd_kinematics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(A), _ptr(com), _ptr(energy),
+                                      ctypes.byref(opts)), "rbd_kinematics")
+
+
+def momentum_matrix_(out: torch.Tensor, state: MechanismState):
+    """`momentum_matrix!(out, state)` in the root frame (src/mechanism_algorithms.jl:313-327): out is (B, 6*nv), each row a 6×nv
+    column-major matrix whose column i is crb_inertia(body(i))·S_i, (angular; linear)."""
+    state._check(out, 6 * state.flat.nv, "momentum matrix")
+    _kin(state, A=out)
+    return out
+
+
+def center_of_mass(state: MechanismState) -> torch.Tensor:
+    """`center_of_mass(state)` in the root frame (src/mechanism_algorithms.jl:28-50): (B, 3)."""
+    out = state._zeros(3)
+    _kin(state, com=out)
+    return out
+
+
+def kinetic_energy(state: MechanismState) -> torch.Tensor:
+    """`kinetic_energy(state)` (src/mechanism_state.jl:886-888, :989-994): (B,)."""
+    e = state._zeros(2)
+    _kin(state, energy=e)
+    return e[:, 0] if state.layout == "aos" else e[0]
+
+
+def gravitational_potential_energy(state: MechanismState) -> torch.Tensor:
+    """`gravitational_potential_energy(state)` (src/mechanism_state.jl:897-903, :996-1000): (B,)."""
+    e = state._zeros(2)
+    _kin(state, energy=e)
+    return e[:, 1] if state.layout == "aos" else e[1]

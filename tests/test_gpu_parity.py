@@ -572,3 +572,52 @@ def test_config4_shard_f32_full_size_round_trip(rbd, oracle, models):
     resid = oracle.inverse_dynamics(model, q[:n], v[:n], vd) - tau[:n]
     cc = oracle.dynamics_bias(model, q[:n], v[:n])
     assert (np.linalg.norm(resid, axis=1) / np.linalg.norm(tau[:n] - cc, axis=1)).max() <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", MODELS)
+def test_kinematics_byproducts_f64(rbd, oracle, models, name, layout):
+    """momentum_matrix!, center_of_mass, kinetic_energy, gravitational_potential_energy
+    (test/test_mechanism_algorithms.jl:527-545, :564-572; tolerance 1e-12 relative as in the reference test)."""
+    model = models[name]
+    B = 45
+    state, q, v, _, _ = make(rbd, model, B, "f64", layout, 31)
+    A = torch.zeros((B, 6 * model.nv) if layout == "aos" else (6 * model.nv, B), dtype=torch.float64, device="cuda")
+    rbd.momentum_matrix_(A, state)
+    com = rbd.center_of_mass(state)
+    ke, pe = rbd.kinetic_energy(state), rbd.gravitational_potential_energy(state)
+    torch.cuda.synchronize()
+    A_ref, _, com_ref = oracle.momentum_matrix(model, q, v)
+    ke_ref, pe_ref = oracle.energy(model, q, v)
+    got = host(A, state).reshape(B, model.nv, 6).transpose(0, 2, 1)
+    assert np.abs(got - A_ref).max() <= 1e-12 * max(1.0, np.abs(A_ref).max())
+    assert np.abs(host(com, state) - com_ref).max() <= 1e-12 * max(1.0, np.abs(com_ref).max())
+    assert np.abs(ke.cpu().numpy() - ke_ref).max() <= 1e-12 * max(1.0, np.abs(ke_ref).max())
+    assert np.abs(pe.cpu().numpy() - pe_ref).max() <= 1e-12 * max(1.0, np.abs(pe_ref).max())
+
+
+@pytest.mark.gpu
+def test_kinematics_byproducts_f32_and_full_size(rbd, oracle, models):
+    model = models["atlas_floating"]
+    state, q, v, _, _ = make(rbd, model, 64, "f32", "aos", 32)
+    A = torch.zeros((64, 6 * model.nv), dtype=torch.float32, device="cuda")
+    rbd.momentum_matrix_(A, state)
+    A_ref, _, com_ref = oracle.momentum_matrix(model, q, v)
+    got = host(A, state).reshape(64, model.nv, 6).transpose(0, 2, 1)
+    assert np.abs(got - A_ref).max() <= 2e-5 * np.abs(A_ref).max()
+    assert np.abs(host(rbd.center_of_mass(state), state) - com_ref).max() <= 1e-5
+    # full size, CPU-free: A v (momentum) against the floating-base rows of M v — for a floating root joint the first six
+    # rows of M v are the total momentum expressed in the base frame, so |h| must agree; and KE = v'(Mv)/2.
+    B = 4096
+    state, q, v, _, _ = make(rbd, model, B, "f64", "aos", 33)
+    A = torch.zeros((B, 6 * model.nv), dtype=torch.float64, device="cuda")
+    rbd.momentum_matrix_(A, state)
+    result = rbd.DynamicsResult(model, B)
+    rbd.mass_matrix_(result, state)
+    Mv = torch.einsum("bij,bj->bi", result.massmatrix_dense(), state.v)
+    ke = rbd.kinetic_energy(state)
+    assert float((0.5 * (Mv * state.v).sum(1) - ke).abs().max()) <= 1e-10 * float(ke.abs().max())
+    h = torch.einsum("bki,bi->bk", A.view(B, model.nv, 6).transpose(1, 2), state.v)
+    # rotate the angular/linear parts back into the base frame: only norms of the force part are frame independent
+    assert float((h[:, 3:].norm(dim=1) - Mv[:, 3:6].norm(dim=1)).abs().max()) <= 1e-9 * float(h[:, 3:].norm(dim=1).max())

@@ -9,6 +9,7 @@ vectors and Julia is unavailable, so the pins are its closed-form
   test/test_mechanism_algorithms.jl:654-675  gravity term = d PE / d q
   test/test_mechanism_algorithms.jl:729-740  dynamics! -> inverse_dynamics round trip, atol 1e-10
   test/test_mechanism_algorithms.jl:742-753  dynamics_bias = inverse_dynamics(vdot = 0)
+  test/test_mechanism_algorithms.jl:527-545  momentum matrix: A v = sum_b I_b T_b, atol 1e-12
   test/test_mechanism_algorithms.jl:707-727  momentum-rate balance with external wrenches (through the
                                               floating-base rows of tau)
 """
@@ -187,3 +188,17 @@ def test_f32_oracle_tracks_f64(rbd, oracle, models):
     c = oracle.dynamics_bias(model, q, v)
     rel = np.linalg.norm(back - tau, axis=1) / np.linalg.norm(tau - c, axis=1)
     assert rel.max() < 1e-4
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_momentum_matrix_times_v_is_total_momentum(rbd, oracle, models, name):
+    """test/test_mechanism_algorithms.jl:527-545 (A·v against Σ_b I_b T_b) plus center_of_mass against PE = -m g·com."""
+    model = models[name]
+    q, v, _ = rand_inputs(rbd, model, 8, 5)
+    A, h, com = oracle.momentum_matrix(model, q, v)
+    _, pe = oracle.energy(model, q, v)
+    g = np.asarray(model.gravity, float)
+    mass = float(np.sum(model.inertia_mass))
+    for b in range(8):
+        assert np.abs(A[b] @ v[b] - h[b]).max() <= 1e-12 * max(1.0, np.abs(h[b]).max())
+        assert abs(-mass * g @ com[b] - pe[b]) <= 1e-12 * max(1.0, abs(pe[b]))
