@@ -72,8 +72,12 @@ enum { RBD_MEM_DEVICE = 0, RBD_MEM_HOST = 1 };
 /* forward-dynamics algorithm behind rbd_dynamics */
 enum {
   RBD_ALGO_ABA = 0,          /* fused articulated-body algorithm (default; tree mechanisms)   */
-  RBD_ALGO_CRBA_CHOLESKY = 1 /* the reference's own route: bias-RNEA + CRBA + Cholesky; also
+  RBD_ALGO_CRBA_CHOLESKY = 1,/* the reference's own route: bias-RNEA + CRBA + Cholesky; also
                                 fills M and c in the workspace; the only route with loop joints */
+  /* RBD_ALGO_ABA picks between two mappings of the same algorithm by batch size; these force one (tests, benchmarks): */
+  RBD_ALGO_ABA_LANES = 2,    /* one lane per (state, body), level-synchronous sweeps: small batches             */
+  RBD_ALGO_ABA_CHAINS = 3    /* a few lanes per state walk chains of the tree: large batches.  RBD_ERR_UNSUPPORTED
+                                for mechanisms with 3-dof tree joints or a 6-dof joint not on the world           */
 };
 
 /* ---- loop (non-tree) joint: src/mechanism_modification.jl:38-43,
@@ -132,6 +136,10 @@ typedef struct rbd_opts {
 /* ---- model / workspace lifetime ------------------------------------------ */
 int rbd_model_create(const rbd_flat_model_t* desc, rbd_model_t** out); /* deep-copies desc */
 int rbd_model_destroy(rbd_model_t* model);
+/* Introspection of the chain-scheduled ABA plan (RBD_ALGO_ABA_CHAINS): tracks (lanes) per state, steps per pass, LDS fields
+ * per state, and the steps×tracks table of reference body indices (-1 = idle).  RBD_ERR_UNSUPPORTED when the mechanism is
+ * outside that mapping's scope.  Host-only, no device needed. */
+int rbd_model_chain_plan(const rbd_model_t* model, int32_t* tracks, int32_t* steps, int32_t* lds_fields, int32_t* table, int32_t capacity);
 int rbd_model_dims(const rbd_model_t* model, int32_t* n_bodies, int32_t* nq, int32_t* nv, int32_t* nc);
 
 /* stream: a hipStream_t passed as void* (NULL = the device's default stream) */

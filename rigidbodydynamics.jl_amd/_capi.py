@@ -12,14 +12,14 @@ RBD_OK = 0
 F64, F32 = 0, 1
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 MEM_DEVICE, MEM_HOST = 0, 1
-ALGO_ABA, ALGO_CRBA_CHOLESKY = 0, 1
+ALGO_ABA, ALGO_CRBA_CHOLESKY, ALGO_ABA_LANES, ALGO_ABA_CHAINS = 0, 1, 2, 3
 
 # every symbol include/rbd_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = (
     "rbd_model_create", "rbd_model_destroy", "rbd_model_dims", "rbd_workspace_create", "rbd_workspace_destroy",
     "rbd_workspace_set_stream", "rbd_sync", "rbd_dynamics", "rbd_inverse_dynamics", "rbd_dynamics_bias", "rbd_mass_matrix",
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
-    "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics",
+    "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan",
 )
 
 
@@ -61,6 +61,7 @@ def lib():
         L.rbd_mass_matrix_solve.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_dynamics_result.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_cholesky_solve.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_model_chain_plan.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), i32]
         L.rbd_kinematics.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_simulate.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.c_double, i32, ctypes.POINTER(Opts)]
         L.rbd_mk_stage.argtypes = [vp, i32, i32, ctypes.c_double, vp, vp, vp, ctypes.POINTER(Opts)]

@@ -12,6 +12,7 @@
 
 #include "rbd_hip.h"
 #include "rbd_internal.hpp"
+#include "rbd_chain_plan.hpp"
 
 using namespace rbd;
 
@@ -63,6 +64,7 @@ struct rbd_model {
   std::vector<rbd_loop_joint_t> loops;
   std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref;  // loop tables (reference body indices)
   std::vector<double> loop_r, axis_ref, axis2_ref;
+  ChainPlan chain;  // plan of aba_chain_kernel (chain.ok == false: mechanism outside its scope)
 };
 
 struct rbd_ws {
@@ -70,6 +72,7 @@ struct rbd_ws {
   int32_t device = 0, dtype = RBD_F64, max_batch = 0;
   hipStream_t stream = nullptr;
   DevModel dm{};
+  ChainModel cm{}; void* d_chain_tab = nullptr; void* d_chain_cb = nullptr; size_t chain_lds_bytes = 0; long chain_min_batch = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
   // staging for RBD_MEM_HOST (lazy)
   void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -264,12 +267,38 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     m->nc += ncl;
     m->loops.push_back(lj);
   }
+  {
+    // tracks per state of the chain-scheduled ABA: enough for the chains that overlap in time, at most 4 (one wavefront per
+    // SIMD of a CU at the LDS-bound residency); RBD_CHAIN_G overrides for experiments
+    int nheads = 0;
+    for (int s = 0; s < nb; ++s) {
+      const int ps = m->ib[(size_t)s * IB_STRIDE + IB_PARENT];
+      if (ps < 0 || m->ib[(size_t)ps * IB_STRIDE + IB_CHILD0] != s) ++nheads;
+    }
+    int G = 1;
+    while (G < nheads && G < 4) G <<= 1;
+    if (const char* e = getenv("RBD_CHAIN_G")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) G = g; }
+    if (m->nloops == 0) m->chain = build_chain_plan(nb, m->ib, G);
+  }
   *out = m;
   return RBD_OK;
 }
 
 int rbd_model_destroy(rbd_model_t* m) {
   delete m;
+  return RBD_OK;
+}
+
+int rbd_model_chain_plan(const rbd_model_t* m, int32_t* tracks, int32_t* steps, int32_t* lds_fields, int32_t* table, int32_t capacity) {
+  if (!m) return RBD_ERR_INVALID_ARGUMENT;
+  if (!m->chain.ok) return RBD_ERR_UNSUPPORTED;
+  if (tracks) *tracks = m->chain.G;
+  if (steps) *steps = m->chain.ns;
+  if (lds_fields) *lds_fields = (int32_t)m->chain.lds_fields(m->nb);
+  if (table) {
+    if (capacity < (int32_t)m->chain.tab.size()) return RBD_ERR_DIMENSION_MISMATCH;
+    for (size_t i = 0; i < m->chain.tab.size(); ++i) table[i] = m->chain.tab[i] < 0 ? -1 : m->order[m->chain.tab[i]];  // reference body indices
+  }
   return RBD_OK;
 }
 
@@ -342,6 +371,24 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   for (int l = 0; l < MAX_LEVELS; ++l) dm.nslots[l] = (uint8_t)m->nslots[l];
   dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc; dm.row_mask = (const uint64_t*)w->d_row_mask;
   memcpy(dm.gravity, m->gravity, sizeof dm.gravity);
+  if (m->chain.ok) {
+    const ChainPlan& P = m->chain;
+    st = upload(&w->d_chain_tab, P.tab.data(), P.tab.size() * sizeof(int32_t));
+    if (st == RBD_OK) st = upload(&w->d_chain_cb, P.cb.data(), P.cb.size() * sizeof(int32_t));
+    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+    ChainModel& cm = w->cm;
+    cm.nb = m->nb; cm.ns = P.ns; cm.G = P.G; cm.spw = 64 / P.G; cm.nfl = P.nfl; cm.nfs = P.nfs;
+    cm.tab = (const int32_t*)w->d_chain_tab; cm.cb = (const int32_t*)w->d_chain_cb; cm.rb = w->d_rb;
+    for (int l = 0; l < MAX_LEVELS; ++l) cm.nrounds[l] = P.nrounds[l];
+    memcpy(cm.gravity, m->gravity, sizeof cm.gravity);
+    w->chain_lds_bytes = P.lds_fields(m->nb) * (size_t)(64 / P.G) * (dtype == RBD_F64 ? 8 : 4);
+    if (w->chain_lds_bytes > 160 * 1024) w->chain_lds_bytes = 0;  // does not fit: lanes mapping only
+    // RBD_ALGO_ABA picks the chain mapping where it measured faster than lane-per-body on MI355X (profiles/r01_chain_sweep.txt):
+    // fp32 from 16384 states up (6 wavefronts per CU fit the LDS budget); in fp64 the 48 KB per wavefront leave one wavefront
+    // per SIMD and the lanes mapping stays ahead at every batch size, so it is opt-in there (RBD_ALGO_ABA_CHAINS).
+    w->chain_min_batch = dtype == RBD_F32 ? 16384 : (1L << 40);
+    if (const char* e = getenv("RBD_CHAIN_MIN_BATCH")) w->chain_min_batch = atol(e);
+  }
   {
     const char* e = getenv("RBD_ABA_STOP_AFTER");  // profiling aid only
     dm.debug_stop = e ? atoi(e) : 0;
@@ -353,7 +400,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -539,9 +586,17 @@ static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, con
       HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_M, dtau, w->d_c, dvd, nullptr, Lm, Lv, w->d_notpd, w->stream));
     }
   } else {
+    const bool can_chain = m->chain.ok && w->chain_lds_bytes > 0;
+    if (o.algorithm == RBD_ALGO_ABA_CHAINS && !can_chain) return RBD_ERR_UNSUPPORTED;
+    const bool chains = o.algorithm == RBD_ALGO_ABA_CHAINS || (o.algorithm == RBD_ALGO_ABA && can_chain && B >= w->chain_min_batch);
     Timed t(w);
-    if (w->dtype == RBD_F64) HIP_TRY(launch_aba<double>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_aba<float>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    if (chains) {
+      if (w->dtype == RBD_F64) HIP_TRY(launch_aba_chain<double>(w->cm, B, w->chain_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+      else HIP_TRY(launch_aba_chain<float>(w->cm, B, w->chain_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    } else {
+      if (w->dtype == RBD_F64) HIP_TRY(launch_aba<double>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+      else HIP_TRY(launch_aba<float>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    }
   }
   return RBD_OK;
 }

@@ -34,3 +34,8 @@ template <typename T>
 hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, void* A, void* com, void* energy, Layout Lq, Layout Lv, Layout La,
                       Layout L3, Layout L2, hipStream_t s);
 }
+namespace rbd {
+template <typename T>
+hipError_t launch_aba_chain(const ChainModel& C, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
+                            void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+}

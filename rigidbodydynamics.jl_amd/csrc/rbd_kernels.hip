@@ -891,6 +891,10 @@ __global__ __launch_bounds__(256) void kin_kernel(DevModel M, long B, const T* _
   }
 }
 
+}  // namespace rbd
+#include "rbd_chain.hpp"
+namespace rbd {
+
 // ---- launchers -----------------------------------------------------------------------------
 static inline dim3 grid_for(const DevModel& M, long B, int block) {
   const long spw = 64 / M.lps;
@@ -908,6 +912,37 @@ hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, v
 }
 template hipError_t launch_kin<double>(const DevModel&, long, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_kin<float>(const DevModel&, long, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, Layout, Layout, hipStream_t);
+
+template <typename T, int G>
+static hipError_t launch_aba_chain_g(const ChainModel& C, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
+                                     void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+  if (lds_bytes > 64 * 1024) {
+    static thread_local size_t raised = 0;
+    if (raised < lds_bytes) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_chain_kernel<T, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+      raised = lds_bytes;
+    }
+  }
+  const long spw = 64 / G;
+  hipLaunchKernelGGL((aba_chain_kernel<T, G>), dim3((unsigned)((B + spw - 1) / spw)), dim3(64), lds_bytes, s, C, B, (const T*)q, (const T*)v,
+                     (const T*)tau, (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_aba_chain(const ChainModel& C, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
+                            void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+  switch (C.G) {
+    case 1: return launch_aba_chain_g<T, 1>(C, B, lds_bytes, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+    case 2: return launch_aba_chain_g<T, 2>(C, B, lds_bytes, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+    case 4: return launch_aba_chain_g<T, 4>(C, B, lds_bytes, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+    case 8: return launch_aba_chain_g<T, 8>(C, B, lds_bytes, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+    case 16: return launch_aba_chain_g<T, 16>(C, B, lds_bytes, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+template hipError_t launch_aba_chain<double>(const ChainModel&, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_aba_chain<float>(const ChainModel&, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
 
 template <typename T>
 hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,

@@ -215,13 +215,14 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
     """`dynamics!(result, state, torques, externalwrenches; stabilization_gains)` (src/mechanism_algorithms.jl:845-864):
     fills `result.vd` (v̇) and `result.qd` (q̇).  `torques` (B, nv) defaults to zeros; `externalwrenches` is a dense
     (B, 6*n_bodies) tensor of root-frame wrenches (torque; force) per moving body (None == NullDict).
-    algorithm="aba": fused articulated-body kernel; "crba": the reference's own CRBA + Cholesky route, which also
-    fills result.massmatrix and result.dynamicsbias."""
+    algorithm="aba": fused articulated-body kernel (mapping chosen by batch size; "aba_lanes" / "aba_chains" force one);
+    "crba": the reference's own CRBA + Cholesky route, which also fills result.massmatrix and result.dynamicsbias."""
     f = state.flat
     state._check(torques, f.nv, "torques")
     state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
     state.ws.use_current_stream()
-    algo = _capi.ALGO_ABA if algorithm == "aba" else _capi.ALGO_CRBA_CHOLESKY
+    algo = {"aba": _capi.ALGO_ABA, "crba": _capi.ALGO_CRBA_CHOLESKY, "aba_lanes": _capi.ALGO_ABA_LANES,
+            "aba_chains": _capi.ALGO_ABA_CHAINS}[algorithm]
     opts = state._opts(algo, 0 if stabilization_gains is None else 1)
     lam = result.lambda_ if f.nc > 0 else None
     st = _capi.lib().rbd_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
@@ -405,3 +406,24 @@ def gravitational_potential_energy(state: MechanismState) -> torch.Tensor:
     e = state._zeros(2)
     _kin(state, energy=e)
     return e[:, 1] if state.layout == "aos" else e[1]
+
+
+def chain_plan(flat):
+    """The chain-scheduled ABA plan of a mechanism (host-side introspection of `rbd_model_chain_plan`): dict with `tracks`,
+    `steps`, `lds_fields` and `table` (steps × tracks array of body indices, -1 = idle); None when the mechanism is outside
+    that mapping's scope."""
+    import numpy as np
+    L = _capi.lib()
+    h = ctypes.c_void_p()
+    _raise(L.rbd_model_create(ctypes.cast(ctypes.byref(flat.c_struct()), ctypes.c_void_p), ctypes.byref(h)), "rbd_model_create")
+    try:
+        g, ns, nf = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        st = L.rbd_model_chain_plan(h, ctypes.byref(g), ctypes.byref(ns), ctypes.byref(nf), None, 0)
+        if st == 3:  # RBD_ERR_UNSUPPORTED
+            return None
+        _raise(st, "rbd_model_chain_plan")
+        tab = np.zeros(ns.value * g.value, np.int32)
+        _raise(L.rbd_model_chain_plan(h, None, None, None, tab.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), tab.size), "rbd_model_chain_plan")
+        return {"tracks": g.value, "steps": ns.value, "lds_fields": nf.value, "table": tab.reshape(ns.value, g.value)}
+    finally:
+        L.rbd_model_destroy(h)

@@ -1,0 +1,76 @@
+"""Host-side invariants of the chain-scheduled ABA plan (rbd_model_chain_plan; csrc/rbd_chain_plan.hpp).  No GPU needed: the
+plan is index bookkeeping built by rbd_model_create."""
+import numpy as np
+import pytest
+
+PLANNED = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf"]
+
+
+def check_plan(flat, plan):
+    tab = plan["table"]
+    nb = flat.n_bodies
+    # every body exactly once
+    placed = tab[tab >= 0]
+    assert sorted(placed.tolist()) == list(range(nb))
+    step = {int(b): s for s in range(tab.shape[0]) for b in tab[s] if b >= 0}
+    # a body runs after its parent (pass A / C order; pass B is the reverse)
+    for b in range(nb):
+        p = int(flat.parent[b])
+        if p >= 0:
+            assert step[b] > step[p]
+    # the schedule is no longer than one body per step, and at least the depth of the tree
+    depth = np.zeros(nb, int)
+    for b in range(nb):
+        depth[b] = 0 if flat.parent[b] < 0 else depth[flat.parent[b]] + 1
+    assert depth.max() + 1 <= plan["steps"] <= nb
+    assert plan["tracks"] in (1, 2, 4, 8, 16)
+
+
+@pytest.mark.parametrize("name", PLANNED)
+def test_chain_plan_invariants(rbd, models, name):
+    flat = models[name]
+    plan = rbd.chain_plan(flat)
+    assert plan is not None
+    check_plan(flat, plan)
+
+
+def test_chain_plan_atlas_reaches_the_critical_path(rbd, models):
+    """Atlas: 5 chains on 4 tracks; the schedule is as long as the deepest chain (pelvis ... hand: 11 bodies), and the LDS
+    footprint (fields x 16 states x 8 B) lets three fp64 wavefronts share a CU."""
+    plan = rbd.chain_plan(models["atlas_floating"])
+    assert plan["tracks"] == 4 and plan["steps"] == 11
+    assert plan["lds_fields"] * 16 * 8 * 3 <= 160 * 1024
+
+
+@pytest.mark.parametrize("name", ["randmech1", "randmech2", "randmech3", "inner_floating"])
+def test_chain_plan_scope(rbd, models, name):
+    """3-dof tree joints and 6-dof joints below another body stay with the lane-per-body mapping; anything else plans."""
+    flat = models[name]
+    jt = np.asarray(flat.joint_type)
+    out_of_scope = np.any((jt == 4) | (jt == 5)) or np.any((jt == 3) & (np.asarray(flat.parent) >= 0))
+    plan = rbd.chain_plan(flat)
+    assert (plan is None) == bool(out_of_scope)
+    if plan is not None:
+        check_plan(flat, plan)
+
+
+def random_tree(rbd, rng, n, floating_root, chain_bias):
+    """rand_tree_mechanism (src/mechanism_modification.jl:382-396) with a parent selector that mixes chains and bushes."""
+    types = (["QuaternionFloating"] if floating_root else []) + [str(rng.choice(["Revolute", "Prismatic", "Fixed", "SinCosRevolute"])) for _ in range(n)]
+
+    def selector(mech, r):
+        bodies = [b for b in mech.bodies if not (floating_root and b is mech.bodies[0])]  # keep the 6-dof joint the only child of the world
+        return bodies[-1] if r.random() < chain_bias else bodies[r.integers(len(bodies))]
+
+    return rbd.rand_tree_mechanism(rng, types, selector)
+
+
+def test_chain_plan_random_trees(rbd):
+    """Random topologies (revolute / prismatic / fixed / sin-cos joints, up to 40 bodies, from chain-like to bushy)."""
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        mech = random_tree(rbd, rng, int(rng.integers(1, 40)), bool(trial % 2), float(rng.uniform(0, 1)))
+        flat = rbd.flatten(mech)
+        plan = rbd.chain_plan(flat)
+        assert plan is not None
+        check_plan(flat, plan)

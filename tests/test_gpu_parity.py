@@ -621,3 +621,94 @@ def test_kinematics_byproducts_f32_and_full_size(rbd, oracle, models):
     h = torch.einsum("bki,bi->bk", A.view(B, model.nv, 6).transpose(1, 2), state.v)
     # rotate the angular/linear parts back into the base frame: only norms of the force part are frame independent
     assert float((h[:, 3:].norm(dim=1) - Mv[:, 3:6].norm(dim=1)).abs().max()) <= 1e-9 * float(h[:, 3:].norm(dim=1).max())
+
+
+# ---- chain-scheduled ABA (RBD_ALGO_ABA_CHAINS): the same dynamics! through the other lane mapping -------------------------
+CHAIN_MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", CHAIN_MODELS)
+def test_dynamics_chains_f64(rbd, oracle, models, name, layout):
+    model = models[name]
+    B = 67  # ragged against every states-per-wave (64, 32, 16)
+    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 41)
+    result = rbd.DynamicsResult(model, B, layout=layout)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_chains")
+    torch.cuda.synchronize()
+    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    got = host(result.vd, state)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(host(result.qd, state) - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
+    # and against the lane-per-body mapping, no torques / wrenches (defaults)
+    r1, r2 = rbd.DynamicsResult(model, B, layout=layout), rbd.DynamicsResult(model, B, layout=layout)
+    rbd.dynamics_(r1, state, algorithm="aba_chains")
+    rbd.dynamics_(r2, state, algorithm="aba_lanes")
+    assert float((r1.vd - r2.vd).abs().max()) <= 1e-10 * max(1.0, float(r2.vd.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 1000])
+def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B):
+    model = models["atlas_floating"]
+    state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 42 + B)
+    result = rbd.DynamicsResult(model, B)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_chains")
+    ref = oracle.dynamics(model, q, v, tau, fe)
+    assert np.abs(host(result.vd, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 43 + B)
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_chains")
+    ref = oracle.dynamics(model, q, v, tau, fe)
+    got = host(result.vd, state)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())  # same bound as test_dynamics_f32
+
+
+@pytest.mark.gpu
+def test_dynamics_chains_random_trees(rbd, oracle):
+    """Random revolute / prismatic / fixed / sin-cos trees (with and without a floating root), as the reference's randomized tests do."""
+    from test_chain_plan import random_tree
+    rng = np.random.default_rng(9)
+    for trial in range(12):
+        mech = random_tree(rbd, rng, int(rng.integers(1, 30)), bool(trial % 2), float(rng.uniform(0, 1)))
+        model = rbd.flatten(mech)
+        B = 33
+        state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 50 + trial)
+        result = rbd.DynamicsResult(model, B)
+        rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_chains")
+        ref = oracle.dynamics(model, q, v, tau, fe)
+        got = host(result.vd, state)
+        assert np.isfinite(got).all(), trial
+        assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), trial
+
+
+@pytest.mark.gpu
+def test_dynamics_chains_scope_and_auto_selection(rbd, oracle, models):
+    model = models["randmech1"]  # has 3-dof joints: outside the chain mapping
+    state, *_ = make(rbd, model, 8, "f64", "aos", 60)
+    result = rbd.DynamicsResult(model, 8)
+    with pytest.raises(Exception):
+        rbd.dynamics_(result, state, algorithm="aba_chains")
+    rbd.dynamics_(result, state)  # default still works (lanes)
+    # full size: both mappings agree with each other and the dynamics! -> inverse_dynamics round trip closes
+    # (test/test_mechanism_algorithms.jl:729-740); in fp32 the default picks the chain mapping from 16384 states up
+    model = models["atlas_floating"]
+    B = 32768
+    state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 61)
+    r0, r1 = rbd.DynamicsResult(model, B), rbd.DynamicsResult(model, B)
+    t = dev(tau, state)
+    rbd.dynamics_(r0, state, t, algorithm="aba_chains")
+    rbd.dynamics_(r1, state, t, algorithm="aba_lanes")
+    assert float((r0.vd - r1.vd).abs().max()) <= 1e-9 * float(r1.vd.abs().max())
+    back = torch.zeros_like(t)
+    rbd.inverse_dynamics_(back, state, r0.vd)
+    assert float((back - t).abs().max()) <= 1e-8 * max(1.0, float(t.abs().max()))
+    state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 62)
+    r0, r1 = rbd.DynamicsResult(model, B, dtype=torch.float32), rbd.DynamicsResult(model, B, dtype=torch.float32)
+    t = dev(tau, state)
+    rbd.dynamics_(r0, state, t)
+    rbd.dynamics_(r1, state, t, algorithm="aba_lanes")
+    assert float((r0.vd - r1.vd).abs().max()) <= 2e-3 * float(r1.vd.abs().max())
