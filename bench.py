@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture the K steps in one hipGraph")
     ap.add_argument("--gather-every-step", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--algorithm", default="aba", choices=["aba", "aba_lanes", "aba_chains"],
+    ap.add_argument("--algorithm", default="aba", choices=["aba", "aba_lanes", "aba_chains", "aba_banks"],
                     help="lane mapping of the fused ABA: aba = the library's choice by batch size")
     ap.add_argument("--wrenches", action="store_true", help="random external wrench on every body (as perf/runbenchmarks.jl:59-67)")
     args = ap.parse_args()
@@ -93,7 +93,7 @@ def main():
 
     # low-overhead launch: pre-marshalled ctypes call straight into the C ABI
     L = _capi.lib()
-    opts = state._opts({"aba": 0, "aba_lanes": 2, "aba_chains": 3}[args.algorithm])
+    opts = state._opts({"aba": 0, "aba_lanes": 2, "aba_chains": 3, "aba_banks": 4}[args.algorithm])
     stream = torch.cuda.current_stream(device)
     L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(stream.cuda_stream))
     c_args = (state.ws.handle, B, ctypes.c_void_p(state.q.data_ptr()), ctypes.c_void_p(state.v.data_ptr()),

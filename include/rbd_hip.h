@@ -76,8 +76,10 @@ enum {
                                 fills M and c in the workspace; the only route with loop joints */
   /* RBD_ALGO_ABA picks between two mappings of the same algorithm by batch size; these force one (tests, benchmarks): */
   RBD_ALGO_ABA_LANES = 2,    /* one lane per (state, body), level-synchronous sweeps: small batches             */
-  RBD_ALGO_ABA_CHAINS = 3    /* a few lanes per state walk chains of the tree: large batches.  RBD_ERR_UNSUPPORTED
+  RBD_ALGO_ABA_CHAINS = 3,   /* a few lanes per state walk chains of the tree: large batches.  RBD_ERR_UNSUPPORTED
                                 for mechanisms with 3-dof tree joints or a 6-dof joint not on the world           */
+  RBD_ALGO_ABA_BANKS = 4     /* lane-per-body with two bodies per lane (levels split into two banks): twice the
+                                states per wavefront.  Same scope as the chain mapping                            */
 };
 
 /* ---- loop (non-tree) joint: src/mechanism_modification.jl:38-43,

@@ -1,0 +1,327 @@
+// rbd_bank.hpp — "banked" lane-per-body ABA: every lane carries TWO bodies (included by rbd_kernels.hip after aba_kernel).
+//
+// aba_kernel keeps one body per lane, so a state of n bodies needs next_pow2(n) lanes and each level-synchronous sweep
+// step is issued for all of them although only the bodies of one level do useful work.  The sweeps are issue-bound
+// (DESIGN.md §3.3), so the cost of a sweep step is per WAVEFRONT, not per body: packing twice as many states into a
+// wavefront halves the instruction issue of the sweeps.  Here the bodies are split by level into two banks — bank 0 =
+// levels [0, L0), bank 1 = levels [L0, nlevels) — and lane j of a state carries body j of bank 0 AND body j of bank 1, each
+// with its own register set (Atlas: 15 + 16 bodies on 16 lanes, 4 states per wavefront instead of 2).  A sweep step at
+// level l touches only the register set of the bank that owns l, so the level loops are the same code as aba_kernel's,
+// run once per bank range; the single hop that crosses banks (level L0-1 <-> L0) is a ds_bpermute between the two register
+// sets.  Within a bank the bodies are in DFS pre-order, so the first-child hop stays a DPP wave shift.
+// The per-body set-up (joint transform, inertia, bias terms) runs once per bank with all lanes busy.
+// Scope: 1-dof and fixed tree joints, 6-dof joints on the world (everything else stays with aba_kernel).
+#pragma once
+
+namespace rbd {
+
+template <typename T> struct BankRegs {
+  Body<T> b;
+  const T* rb;
+  T R[9], p[3], Tw[6], vJ[6];
+  T S[6], cb[6], IA[21], pA[6], U[6], Dinv, u;
+  T tj[6];  // joint torques (6 for the floating joint)
+  T acc[6], vd[6];
+};
+
+template <typename T> RBD_DEV void load_bank_body(const BankModel& M, int k, long B, Body<T>& b) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  b.lane = threadIdx.x & 63;
+  const long wave = tid >> 6;
+  const int lps = M.lps;
+  b.sub = b.lane & (lps - 1);
+  b.base = b.lane - b.sub;
+  b.state = wave * (64 / lps) + (b.lane / lps);
+  b.valid = (b.sub < M.nbk[k]) && (b.state < B);
+  const int32_t* ib = M.ib[k] + (b.sub < M.nbk[k] ? b.sub : 0) * IB_STRIDE;
+  b.parent = ib[IB_PARENT];
+  b.jtype = ib[IB_JTYPE];
+  b.qoff = ib[IB_QOFF];
+  b.voff = ib[IB_VOFF];
+  b.level = b.valid ? ib[IB_LEVEL] : -1;
+  b.nchild = ib[IB_NCHILD];
+  b.orig = ib[IB_ORIG];
+#pragma unroll
+  for (int c = 0; c < IB_MAXCHILD; ++c) b.child[c] = ib[IB_CHILD0 + c];
+  b.plane = b.parent >= 0 ? b.base + b.parent : b.lane;  // parent slot (of the parent's bank) in this state's lane group
+}
+
+// top-down hop of N values: lanes of `cb` read their parent's copy of x (the parent's bank register set)
+template <typename T, int N, bool CROSS> RBD_DEV void bank_pull(const BankModel& M, const Body<T>& cb, int l, const T* x, T* out) {
+  if (CROSS || ((M.perm_down >> l) & 1)) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = shfl(x[k], cb.plane);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = from_prev_lane(x[k]);
+  }
+}
+
+// forward-kinematics step at level l: `c` (bodies at level l) from `par` (their parents' bank)
+template <typename T, bool CROSS> RBD_DEV void bank_fk_step(const BankModel& M, int l, const BankRegs<T>& par, BankRegs<T>& c, const T* XR, const T* Xp, const T* tl) {
+  T pR[9], pp[3], pT[6];
+  bank_pull<T, 9, CROSS>(M, c.b, l, par.R, pR);
+  bank_pull<T, 3, CROSS>(M, c.b, l, par.p, pp);
+  bank_pull<T, 6, CROSS>(M, c.b, l, par.Tw, pT);
+  if (c.b.level == l) {
+    matmul3(pR, XR, c.R);
+    matvec3(pR, Xp, c.p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c.p[k] += pp[k];
+    xmotion(c.R, c.p, tl, c.vJ);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c.Tw[k] = pT[k] + c.vJ[k];
+  }
+}
+
+// U = IA S, D = S'U, u = tau - S'pA for the lanes of `r` at level l (1-dof joints; fixed joints keep U = 0, 1/D = 0)
+template <typename T> RBD_DEV void bank_finish_joint(int l, BankRegs<T>& r) {
+  if (r.b.level == l && joint_nv(r.b.jtype) == 1) {
+    sym6_mul(r.IA, r.S, r.U);
+    r.u = r.tj[0] - dot6(r.S, r.pA);
+    r.Dinv = rcp_nr(dot6(r.S, r.U));
+  }
+}
+
+// bottom-up hand-off: lanes of `gv` at level l give (Ia, pa) = (IA - U D^-1 U', pA + Ia cb + U D^-1 u); lanes of `tk` at level
+// l-1 add what their children give.  In-bank (gv and tk are the same register set): first child by DPP, the others by
+// ds_bpermute; across banks every child by ds_bpermute.  Entries are formed and consumed one at a time (see aba_kernel).
+template <typename T, bool CROSS> RBD_DEV void bank_handoff(int l, int ns, const BankRegs<T>& gv, BankRegs<T>& tk) {
+  const bool takes = (tk.b.level == l - 1);
+  T W[6];  // U D^-1 (6-dof joints sit at level 0 and never give: their 1/D stays 0)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) W[k] = gv.U[k] * gv.Dinv;
+  const T m0 = (!CROSS && takes && tk.b.nchild >= 1) ? T(1) : T(0);
+  T Iac[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, gp[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = i; j < 6; ++j) {
+      const T g = gv.IA[SI(i, j)] - W[i] * gv.U[j];
+      Iac[i] += g * gv.cb[j];
+      if (j > i) Iac[j] += g * gv.cb[i];
+      if (!CROSS) tk.IA[SI(i, j)] += from_next_lane(g) * m0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    gp[k] = gv.pA[k] + Iac[k] + W[k] * gv.u;
+    if (!CROSS) tk.pA[k] += from_next_lane(gp[k]) * m0;
+  }
+#pragma unroll 1
+  for (int s = CROSS ? 0 : 1; s < ns; ++s) {
+    const bool take = takes && (s < tk.b.nchild);
+    const int src = take ? tk.b.base + child_sel(tk.b, s) : tk.b.lane;
+    const T mask = take ? T(1) : T(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      T tmp[6];
+#pragma unroll
+      for (int j = i; j < 6; ++j) tmp[j] = shfl(gv.IA[SI(i, j)] - W[i] * gv.U[j], src);
+#pragma unroll
+      for (int j = i; j < 6; ++j) tk.IA[SI(i, j)] += tmp[j] * mask;
+    }
+    T tp[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tp[k] = shfl(gp[k], src);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tk.pA[k] += tp[k] * mask;
+  }
+}
+
+// v̇ = D^-1 (u - U'a'), a = a' + S v̇ with a' = a_parent + cb
+template <typename T> RBD_DEV void bank_joint_accel(BankRegs<T>& r, const T* a_parent) {
+  T ap[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ap[k] = a_parent[k] + r.cb[k];
+  const T x = r.Dinv * (r.u - dot6(r.U, ap));
+  r.vd[0] = x;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) r.acc[k] = ap[k] + r.S[k] * x;
+}
+
+// Register budget: both banks' recursion state would need ~300 VGPRs in fp64, i.e. one wavefront per SIMD, and a lone
+// wavefront issues at only ~5 cycles per instruction.  The bank that is not being swept therefore parks its live values in a
+// lane-private LDS column (PARK_SLOTS values per lane, no synchronisation needed): the kernel fits 256 VGPRs and two
+// wavefronts per SIMD interleave.
+enum { PARK_KIN = 0 /* R 9, p 3, Tw 6, vJ 6 of bank 0 */, PARK_FWD = 12 /* U 6, 1/D, u, S 6, cb 6 of bank 1 */, PARK_SLOTS = 32 };
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
+                                                         const T* __restrict__ tau, const T* __restrict__ fext, T* __restrict__ vdot,
+                                                         T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
+  extern __shared__ double park_raw[];
+  T* const park = reinterpret_cast<T*>(park_raw) + threadIdx.x;  // slot i of this lane: park[i * 256]
+  BankRegs<T> r0, r1;
+  // ---- per-body set-up (once per bank, every lane busy): joint transform and joint twist in the joint frame ----
+  auto setup = [&](int k, BankRegs<T>& c, T* XR, T* Xp, T* tl) {
+    load_bank_body(M, k, B, c.b);
+    c.rb = reinterpret_cast<const T*>(M.rb[k]) + (c.b.sub < M.nbk[k] ? c.b.sub : 0) * RB_STRIDE;
+    T qj[7], vj[6];
+    load_joint_q(c.b, q, Lq, qj);
+    load_joint_v(c.b, v, Lv, vj);
+    load_joint_v(c.b, tau, Lv, c.tj);
+    store_qdot(c.b, qdot, Lq, qj, vj);
+    local_transform(c.b, c.rb, qj, XR, Xp);
+    local_joint_motion(c.b, c.rb, vj, tl);
+    // as if at level 0 (transform to root = local transform); deeper lanes overwrite at their level
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = XR[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.p[i] = Xp[i];
+    xmotion(c.R, c.p, tl, c.vJ);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c.Tw[i] = c.vJ[i];
+  };
+  // ---- per-body terms in the root frame: motion subspace, bias acceleration, inertia, bias force ----
+  auto terms = [&](BankRegs<T>& c, bool accumulate) {  // accumulate: IA, pA already hold what the children handed up
+    T e1[6] = {T(1), T(0), T(0), T(0), T(0), T(0)}, sl[6];
+    local_joint_motion(c.b, c.rb, e1, sl);
+    xmotion(c.R, c.p, sl, c.S);
+    const bool floating = c.b.jtype == RBD_JOINT_QUAT_FLOATING;
+    if (floating || joint_nv(c.b.jtype) == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) c.S[i] = T(0);
+    }
+    se3_comm(c.Tw, c.vJ, c.cb);
+    RInertia<T> I;
+    T Jb[6], mc[3], fe[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Jb[i] = c.rb[RB_J + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mc[i] = c.rb[RB_MC + i];
+    inertia_to_root(Jb, mc, c.rb[RB_M], c.R, c.p, I);
+    T Io[21], po[6];
+    sym6_from_inertia(I, Io);
+    momentum_cross(I, c.Tw, po);
+    load_body_wrench(c.b, fext, Lf, fe);
+    const T keep = c.b.valid ? T(1) : T(0);  // idle lanes carry zeros (their values may be shifted into masked-off neighbours)
+#pragma unroll
+    for (int i = 0; i < 21; ++i) c.IA[i] = (accumulate ? c.IA[i] : T(0)) + (c.b.valid ? Io[i] : T(0));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c.pA[i] = (accumulate ? c.pA[i] : T(0)) + (c.b.valid ? po[i] - fe[i] : T(0));
+    (void)keep;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c.U[i] = T(0);
+    c.Dinv = T(0);
+    c.u = T(0);
+    if (floating) xforce(c.R, c.p, c.tj, c.U);  // 6-dof joints (level 0): U carries S^-T tau; R, p stay parked for the top-down sweep
+  };
+
+  // ---- top-down: transforms to root and twists (update_transforms!, update_twists_wrt_world!) ----
+  {
+    T XR[9], Xp[3], tl[6];
+    setup(0, r0, XR, Xp, tl);
+#pragma unroll 1
+    for (int l = 1; l < M.L0; ++l) bank_fk_step<T, false>(M, l, r0, r0, XR, Xp, tl);
+  }
+  {
+    T XR[9], Xp[3], tl[6];
+    setup(1, r1, XR, Xp, tl);
+    bank_fk_step<T, true>(M, M.L0, r0, r1, XR, Xp, tl);
+    // bank 0 rests until bank 1 has been swept bottom-up
+#pragma unroll
+    for (int i = 0; i < 9; ++i) park[(PARK_KIN + i) * 256] = r0.R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) park[(PARK_KIN + 9 + i) * 256] = r0.p[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { park[(PARK_KIN + 12 + i) * 256] = r0.Tw[i]; park[(PARK_KIN + 18 + i) * 256] = r0.vJ[i]; }
+#pragma unroll 1
+    for (int l = M.L0 + 1; l < M.nlevels; ++l) bank_fk_step<T, false>(M, l, r1, r1, XR, Xp, tl);
+  }
+  terms(r1, false);
+
+  // ---- bottom-up: articulated-body inertias and bias forces ----
+#pragma unroll 1
+  for (int l = M.nlevels - 1; l > M.L0; --l) {
+    bank_finish_joint(l, r1);
+    bank_handoff<T, false>(l, (int)M.nslots[l], r1, r1);
+  }
+  bank_finish_joint(M.L0, r1);
+  // across the banks: the children's hand-off lands in bank 0's (still empty) accumulators; bank 1 then keeps only what the
+  // top-down sweep needs, parked while bank 0 is swept; only then does bank 0 wake up and add its own inertia and bias force
+#pragma unroll
+  for (int i = 0; i < 21; ++i) r0.IA[i] = T(0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r0.pA[i] = T(0);
+  bank_handoff<T, true>(M.L0, (int)M.nslots[M.L0], r1, r0);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r0.R[i] = park[(PARK_KIN + i) * 256];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r0.p[i] = park[(PARK_KIN + 9 + i) * 256];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { r0.Tw[i] = park[(PARK_KIN + 12 + i) * 256]; r0.vJ[i] = park[(PARK_KIN + 18 + i) * 256]; }
+  // (bank 0's Tw, vJ slots are free again: bank 1's set takes them; R, p stay for the 6-dof joints)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    park[(PARK_FWD + i) * 256] = r1.U[i];
+    park[(PARK_FWD + 8 + i) * 256] = r1.S[i];
+    park[(PARK_FWD + 14 + i) * 256] = r1.cb[i];
+  }
+  park[(PARK_FWD + 6) * 256] = r1.Dinv;
+  park[(PARK_FWD + 7) * 256] = r1.u;
+  terms(r0, true);
+#pragma unroll 1
+  for (int l = M.L0 - 1; l >= 1; --l) {
+    bank_finish_joint(l, r0);
+    bank_handoff<T, false>(l, (int)M.nslots[l], r0, r0);
+  }
+  bank_finish_joint(0, r0);
+
+  // ---- top-down: accelerations and v̇ ----
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { r0.acc[i] = T(0); r0.vd[i] = T(0); }
+  {
+    const T a0[6] = {T(0), T(0), T(0), T(-M.gravity[0]), T(-M.gravity[1]), T(-M.gravity[2])};  // a_world = -gravity
+    BankRegs<T>& c = r0;
+    if (c.b.level == 0) {
+      if (c.b.jtype == RBD_JOINT_QUAT_FLOATING) {
+        // IA a = S^-T tau - pA;  v̇ = S^-1 (a - a_world)   ([T, vJ] = 0 on the world)
+        T rhs[6], d[6], Rs[9], ps[3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rhs[i] = c.U[i] - c.pA[i];
+        sym6_solve(c.IA, rhs, c.acc);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = c.acc[i] - a0[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rs[i] = park[(PARK_KIN + i) * 256];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ps[i] = park[(PARK_KIN + 9 + i) * 256];
+        xmotion_inv(Rs, ps, d, c.vd);
+      } else {
+        bank_joint_accel(c, a0);
+      }
+    }
+  }
+#pragma unroll 1
+  for (int l = 1; l < M.L0; ++l) {
+    T ap[6];
+    bank_pull<T, 6, false>(M, r0.b, l, r0.acc, ap);
+    if (r0.b.level == l) bank_joint_accel(r0, ap);
+  }
+  store_joint_v(r0.b, vdot, Lv, r0.vd);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    r1.U[i] = park[(PARK_FWD + i) * 256];
+    r1.S[i] = park[(PARK_FWD + 8 + i) * 256];
+    r1.cb[i] = park[(PARK_FWD + 14 + i) * 256];
+    r1.acc[i] = T(0);
+    r1.vd[i] = T(0);
+  }
+  r1.Dinv = park[(PARK_FWD + 6) * 256];
+  r1.u = park[(PARK_FWD + 7) * 256];
+  {
+    T ap[6];
+    bank_pull<T, 6, true>(M, r1.b, M.L0, r0.acc, ap);
+    if (r1.b.level == M.L0) bank_joint_accel(r1, ap);
+  }
+#pragma unroll 1
+  for (int l = M.L0 + 1; l < M.nlevels; ++l) {
+    T ap[6];
+    bank_pull<T, 6, false>(M, r1.b, l, r1.acc, ap);
+    if (r1.b.level == l) bank_joint_accel(r1, ap);
+  }
+  store_joint_v(r1.b, vdot, Lv, r1.vd);
+}
+
+}  // namespace rbd

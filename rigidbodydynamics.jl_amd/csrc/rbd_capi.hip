@@ -3,6 +3,7 @@
 // every hot-path entry point launches HIP kernels or fails with a status code.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,6 +65,11 @@ struct rbd_model {
   std::vector<rbd_loop_joint_t> loops;
   std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref;  // loop tables (reference body indices)
   std::vector<double> loop_r, axis_ref, axis2_ref;
+  // banked lane-per-body mapping (aba_bank_kernel): two bodies per lane, split at level bank_L0; bank_lps == 0: not applicable
+  int32_t bank_lps = 0, bank_L0 = 0, bank_nb[2] = {0, 0};
+  std::vector<int32_t> bank_ib[2];
+  std::vector<double> bank_rb[2];
+  uint64_t bank_perm_down = 0;
   ChainPlan chain;  // plan of aba_chain_kernel (chain.ok == false: mechanism outside its scope)
 };
 
@@ -72,7 +78,8 @@ struct rbd_ws {
   int32_t device = 0, dtype = RBD_F64, max_batch = 0;
   hipStream_t stream = nullptr;
   DevModel dm{};
-  ChainModel cm{}; void* d_chain_tab = nullptr; void* d_chain_cb = nullptr; size_t chain_lds_bytes = 0; long chain_min_batch = 0;
+  BankModel bm{}; void* d_bank_ib[2] = {nullptr, nullptr}; void* d_bank_rb[2] = {nullptr, nullptr};
+  ChainModel cm{}; void* d_chain_tab = nullptr; void* d_chain_cb = nullptr; size_t chain_lds_bytes = 0; long chain_min_batch = 0; int bank_auto = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
   // staging for RBD_MEM_HOST (lazy)
   void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -267,6 +274,40 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     m->nc += ncl;
     m->loops.push_back(lj);
   }
+  if (m->nloops == 0 && !m->has3dof && !m->inner_floating && m->nlevels >= 2) {
+    // banked mapping: split the levels so that both banks fit the fewest lanes
+    std::vector<int> per_level(m->nlevels, 0);
+    for (int s = 0; s < nb; ++s) per_level[level[s]]++;
+    int best_L0 = 0, best_lanes = 1 << 30, best_diff = 1 << 30;
+    for (int L0 = 1; L0 < m->nlevels; ++L0) {
+      int cA = 0, cB = 0;
+      for (int l = 0; l < m->nlevels; ++l) (l < L0 ? cA : cB) += per_level[l];
+      int lanes = 1;
+      while (lanes < std::max(cA, cB)) lanes <<= 1;
+      const int diff = std::abs(cA - cB);
+      if (lanes < best_lanes || (lanes == best_lanes && diff < best_diff)) { best_lanes = lanes; best_L0 = L0; best_diff = diff; }
+    }
+    if (best_lanes < m->lps) {  // only when it packs more states into a wavefront than one body per lane does
+      m->bank_lps = best_lanes; m->bank_L0 = best_L0;
+      std::vector<int> bslot(nb, -1);  // slot within the body's bank; the global DFS pre-order filtered by level keeps first child = next slot
+      int cnt[2] = {0, 0};
+      for (int s = 0; s < nb; ++s) bslot[s] = cnt[level[s] >= best_L0]++;
+      m->bank_nb[0] = cnt[0]; m->bank_nb[1] = cnt[1];
+      for (int k = 0; k < 2; ++k) { m->bank_ib[k].assign((size_t)std::max(cnt[k], 1) * IB_STRIDE, -1); m->bank_rb[k].assign((size_t)std::max(cnt[k], 1) * RB_STRIDE, 0.0); }
+      m->bank_perm_down = 0;
+      for (int s = 0; s < nb; ++s) {
+        const int k = level[s] >= best_L0, j = bslot[s];
+        const int32_t* src = &m->ib[(size_t)s * IB_STRIDE];
+        int32_t* dst = &m->bank_ib[k][(size_t)j * IB_STRIDE];
+        memcpy(dst, src, sizeof(int32_t) * IB_STRIDE);
+        const int ps = src[IB_PARENT];
+        dst[IB_PARENT] = ps < 0 ? -1 : bslot[ps];
+        for (int c2 = 0; c2 < src[IB_NCHILD]; ++c2) dst[IB_CHILD0 + c2] = bslot[src[IB_CHILD0 + c2]];
+        if (ps >= 0 && level[s] != best_L0 && bslot[ps] != j - 1) m->bank_perm_down |= (uint64_t)1 << level[s];
+        memcpy(&m->bank_rb[k][(size_t)j * RB_STRIDE], &m->rb[(size_t)s * RB_STRIDE], sizeof(double) * RB_STRIDE);
+      }
+    }
+  }
   {
     // tracks per state of the chain-scheduled ABA: enough for the chains that overlap in time, at most 4 (one wavefront per
     // SIMD of a CU at the LDS-bound residency); RBD_CHAIN_G overrides for experiments
@@ -371,6 +412,20 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   for (int l = 0; l < MAX_LEVELS; ++l) dm.nslots[l] = (uint8_t)m->nslots[l];
   dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc; dm.row_mask = (const uint64_t*)w->d_row_mask;
   memcpy(dm.gravity, m->gravity, sizeof dm.gravity);
+  if (m->bank_lps > 0) {
+    BankModel& bm = w->bm;
+    for (int k = 0; k < 2 && st == RBD_OK; ++k) {
+      st = upload(&w->d_bank_ib[k], m->bank_ib[k].data(), m->bank_ib[k].size() * sizeof(int32_t));
+      if (st != RBD_OK) break;
+      if (dtype == RBD_F64) st = upload(&w->d_bank_rb[k], m->bank_rb[k].data(), m->bank_rb[k].size() * sizeof(double));
+      else { std::vector<float> f(m->bank_rb[k].begin(), m->bank_rb[k].end()); st = upload(&w->d_bank_rb[k], f.data(), f.size() * sizeof(float)); }
+      bm.ib[k] = (const int32_t*)w->d_bank_ib[k]; bm.rb[k] = w->d_bank_rb[k]; bm.nbk[k] = m->bank_nb[k];
+    }
+    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+    bm.lps = m->bank_lps; bm.nlevels = m->nlevels; bm.L0 = m->bank_L0; bm.perm_down = m->bank_perm_down;
+    for (int l = 0; l < MAX_LEVELS; ++l) bm.nslots[l] = (uint8_t)m->nslots[l];
+    memcpy(bm.gravity, m->gravity, sizeof bm.gravity);
+  }
   if (m->chain.ok) {
     const ChainPlan& P = m->chain;
     st = upload(&w->d_chain_tab, P.tab.data(), P.tab.size() * sizeof(int32_t));
@@ -400,7 +455,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -589,8 +644,14 @@ static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, con
     const bool can_chain = m->chain.ok && w->chain_lds_bytes > 0;
     if (o.algorithm == RBD_ALGO_ABA_CHAINS && !can_chain) return RBD_ERR_UNSUPPORTED;
     const bool chains = o.algorithm == RBD_ALGO_ABA_CHAINS || (o.algorithm == RBD_ALGO_ABA && can_chain && B >= w->chain_min_batch);
+    const bool can_bank = m->bank_lps > 0;
+    if (o.algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
+    const bool banks = !chains && (o.algorithm == RBD_ALGO_ABA_BANKS || (o.algorithm == RBD_ALGO_ABA && can_bank && w->bank_auto));
     Timed t(w);
-    if (chains) {
+    if (banks) {
+      if (w->dtype == RBD_F64) HIP_TRY(launch_aba_bank<double>(w->bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+      else HIP_TRY(launch_aba_bank<float>(w->bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    } else if (chains) {
       if (w->dtype == RBD_F64) HIP_TRY(launch_aba_chain<double>(w->cm, B, w->chain_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
       else HIP_TRY(launch_aba_chain<float>(w->cm, B, w->chain_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     } else {

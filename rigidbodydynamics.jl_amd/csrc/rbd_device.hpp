@@ -61,6 +61,19 @@ struct ChainModel {
   double gravity[3];
 };
 
+// ---- banked lane-per-body ABA (aba_bank_kernel, rbd_bank.hpp): lane j of a state carries body j of bank 0 (levels < L0) and
+// body j of bank 1 (levels >= L0).  ib[k] / rb[k] are the IB_* / RB_* records of bank k by bank slot (DFS pre-order within
+// the bank); IB_PARENT is the parent's slot in the PARENT's bank, IB_CHILD* the children's slots in the CHILDREN's bank.
+struct BankModel {
+  int32_t lps, nlevels, L0;
+  int32_t nbk[2];
+  const int32_t* ib[2];
+  const void* rb[2];
+  uint64_t perm_down;          // bit l: the in-bank top-down hop at level l needs ds_bpermute (some parent is not the previous lane)
+  uint8_t nslots[MAX_LEVELS];  // child slots to gather at level l
+  double gravity[3];
+};
+
 // element (k, b) of an n x B batch buffer
 struct Layout {
   long sk, sb;  // SOA: sk = B, sb = 1;  AOS: sk = 1, sb = n

