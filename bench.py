@@ -202,7 +202,7 @@ def main():
                    "gather_every_step": bool(args.gather_every_step)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "aba_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": alg_bytes},
+                     "kernel": (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": alg_bytes},
         "alu": {"bound": "fp64 vector ALU" if args.dtype == "f64" else "fp32 vector ALU", "achieved": achieved_tf, "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": achieved_tf / peak_tf, "flops_per_eval": ABA_FLOPS_PER_EVAL,
                 "note": "the path is ALU/latency bound, not HBM bound (SURVEY.md F8): compulsory traffic is ~1.5 KB/eval"},

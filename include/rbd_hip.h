@@ -216,6 +216,8 @@ const char* rbd_last_hip_error(void);   /* thread-local text of the last HIP fai
  * Timing is off by default; enable=1 brackets every launch with events.            */
 int rbd_workspace_enable_timing(rbd_ws_t* ws, int32_t enable);
 int rbd_workspace_last_kernel_ms(rbd_ws_t* ws, float* ms);
+/* name of the articulated-body kernel (lane mapping) the last rbd_dynamics / rbd_simulate / rbd_mass_matrix_solve call launched */
+const char* rbd_workspace_last_kernel(const rbd_ws_t* ws);
 int rbd_version(void);
 
 #ifdef __cplusplus

@@ -146,21 +146,33 @@ template <typename T> RBD_DEV void bank_joint_accel(BankRegs<T>& r, const T* a_p
 // wavefronts per SIMD interleave.
 enum { PARK_KIN = 0 /* R 9, p 3, Tw 6, vJ 6 of bank 0 */, PARK_FWD = 12 /* U 6, 1/D, u, S 6, cb 6 of bank 1 */, PARK_SLOTS = 32 };
 
+#ifdef RBD_PROFILE_PHASES
+__device__ long long rbd_bank_phase_clock[16];
+#define RBD_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) rbd_bank_phase_clock[i] = clock64(); } while (0)
+#else
+#define RBD_MARK(i)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
                                                          const T* __restrict__ tau, const T* __restrict__ fext, T* __restrict__ vdot,
-                                                         T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
+                                                         T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, MkFuse F) {
   extern __shared__ double park_raw[];
   T* const park = reinterpret_cast<T*>(park_raw) + threadIdx.x;  // slot i of this lane: park[i * 256]
   BankRegs<T> r0, r1;
   // ---- per-body set-up (once per bank, every lane busy): joint transform and joint twist in the joint frame ----
-  auto setup = [&](int k, BankRegs<T>& c, T* XR, T* Xp, T* tl) {
+  // The global loads of BOTH banks are issued up front (two dependent round trips: body record, then q / v / tau), so that
+  // bank 1's latency hides behind bank 0's sweep; the arithmetic of a bank runs right before its own sweep.
+  auto fetch = [&](int k, BankRegs<T>& c, T* qj, T* vj) {
     load_bank_body(M, k, B, c.b);
     c.rb = reinterpret_cast<const T*>(M.rb[k]) + (c.b.sub < M.nbk[k] ? c.b.sub : 0) * RB_STRIDE;
-    T qj[7], vj[6];
     load_joint_q(c.b, q, Lq, qj);
     load_joint_v(c.b, v, Lv, vj);
     load_joint_v(c.b, tau, Lv, c.tj);
+  };
+  auto setup = [&](BankRegs<T>& c, T* qj, T* vj, T* XR, T* Xp, T* tl) {
+    if (F.stage >= 0)  // `simulate` fusion: this launch is stage F.stage of a Munthe-Kaas RK4 step (see aba_kernel)
+      mk_stage_lane(c.b, F.stage, (T)F.dt, qj, vj, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
     store_qdot(c.b, qdot, Lq, qj, vj);
     local_transform(c.b, c.rb, qj, XR, Xp);
     local_joint_motion(c.b, c.rb, vj, tl);
@@ -209,15 +221,22 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
   };
 
   // ---- top-down: transforms to root and twists (update_transforms!, update_twists_wrt_world!) ----
+  RBD_MARK(0);
+  T qj0[7], vj0[6], qj1[7], vj1[6];
+  fetch(0, r0, qj0, vj0);
+  fetch(1, r1, qj1, vj1);
   {
     T XR[9], Xp[3], tl[6];
-    setup(0, r0, XR, Xp, tl);
+    setup(r0, qj0, vj0, XR, Xp, tl);
+    RBD_MARK(1);
 #pragma unroll 1
     for (int l = 1; l < M.L0; ++l) bank_fk_step<T, false>(M, l, r0, r0, XR, Xp, tl);
   }
   {
     T XR[9], Xp[3], tl[6];
-    setup(1, r1, XR, Xp, tl);
+    RBD_MARK(2);
+    setup(r1, qj1, vj1, XR, Xp, tl);
+    RBD_MARK(3);
     bank_fk_step<T, true>(M, M.L0, r0, r1, XR, Xp, tl);
     // bank 0 rests until bank 1 has been swept bottom-up
 #pragma unroll
@@ -229,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
 #pragma unroll 1
     for (int l = M.L0 + 1; l < M.nlevels; ++l) bank_fk_step<T, false>(M, l, r1, r1, XR, Xp, tl);
   }
+  RBD_MARK(4);
   terms(r1, false);
+  RBD_MARK(5);
 
   // ---- bottom-up: articulated-body inertias and bias forces ----
 #pragma unroll 1
@@ -238,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     bank_handoff<T, false>(l, (int)M.nslots[l], r1, r1);
   }
   bank_finish_joint(M.L0, r1);
+  RBD_MARK(6);
   // across the banks: the children's hand-off lands in bank 0's (still empty) accumulators; bank 1 then keeps only what the
   // top-down sweep needs, parked while bank 0 is swept; only then does bank 0 wake up and add its own inertia and bias force
 #pragma unroll
@@ -260,13 +282,16 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
   }
   park[(PARK_FWD + 6) * 256] = r1.Dinv;
   park[(PARK_FWD + 7) * 256] = r1.u;
+  RBD_MARK(7);
   terms(r0, true);
+  RBD_MARK(8);
 #pragma unroll 1
   for (int l = M.L0 - 1; l >= 1; --l) {
     bank_finish_joint(l, r0);
     bank_handoff<T, false>(l, (int)M.nslots[l], r0, r0);
   }
   bank_finish_joint(0, r0);
+  RBD_MARK(9);
 
   // ---- top-down: accelerations and v̇ ----
 #pragma unroll
@@ -299,7 +324,9 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     bank_pull<T, 6, false>(M, r0.b, l, r0.acc, ap);
     if (r0.b.level == l) bank_joint_accel(r0, ap);
   }
-  store_joint_v(r0.b, vdot, Lv, r0.vd);
+  RBD_MARK(10);
+  if (vdot) store_joint_v(r0.b, vdot, Lv, r0.vd);
+  if (F.stage >= 0) store_joint_v(r0.b, (T*)F.W.vd[F.stage], Lv, r0.vd);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     r1.U[i] = park[(PARK_FWD + i) * 256];
@@ -321,7 +348,9 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     bank_pull<T, 6, false>(M, r1.b, l, r1.acc, ap);
     if (r1.b.level == l) bank_joint_accel(r1, ap);
   }
-  store_joint_v(r1.b, vdot, Lv, r1.vd);
+  RBD_MARK(11);
+  if (vdot) store_joint_v(r1.b, vdot, Lv, r1.vd);
+  if (F.stage >= 0) store_joint_v(r1.b, (T*)F.W.vd[F.stage], Lv, r1.vd);
 }
 
 }  // namespace rbd

@@ -79,7 +79,7 @@ struct rbd_ws {
   hipStream_t stream = nullptr;
   DevModel dm{};
   BankModel bm{}; void* d_bank_ib[2] = {nullptr, nullptr}; void* d_bank_rb[2] = {nullptr, nullptr};
-  ChainModel cm{}; void* d_chain_tab = nullptr; void* d_chain_cb = nullptr; size_t chain_lds_bytes = 0; long chain_min_batch = 0; int bank_auto = 0;
+  ChainModel cm{}; void* d_chain_tab = nullptr; void* d_chain_cb = nullptr; size_t chain_lds_bytes = 0; long bank_min_batch = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
   // staging for RBD_MEM_HOST (lazy)
   void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -96,6 +96,7 @@ struct rbd_ws {
   int32_t timing = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_pending = false;
+  const char* last_kernel = "";  // dominant kernel of the last rbd_dynamics / rbd_simulate / rbd_mass_matrix_solve call
 };
 
 extern "C" {
@@ -425,6 +426,10 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     bm.lps = m->bank_lps; bm.nlevels = m->nlevels; bm.L0 = m->bank_L0; bm.perm_down = m->bank_perm_down;
     for (int l = 0; l < MAX_LEVELS; ++l) bm.nslots[l] = (uint8_t)m->nslots[l];
     memcpy(bm.gravity, m->gravity, sizeof bm.gravity);
+    // one body per lane keeps the lower latency while its wavefronts still have a SIMD each (measured: 19.4 vs 23.4 us for a
+    // lone wavefront); the banked mapping takes over once the batch would put two of those on a SIMD
+    w->bank_min_batch = 1536L * (64 / m->lps);
+    if (const char* e = getenv("RBD_BANK_MIN_BATCH")) w->bank_min_batch = atol(e);
   }
   if (m->chain.ok) {
     const ChainPlan& P = m->chain;
@@ -438,11 +443,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     memcpy(cm.gravity, m->gravity, sizeof cm.gravity);
     w->chain_lds_bytes = P.lds_fields(m->nb) * (size_t)(64 / P.G) * (dtype == RBD_F64 ? 8 : 4);
     if (w->chain_lds_bytes > 160 * 1024) w->chain_lds_bytes = 0;  // does not fit: lanes mapping only
-    // RBD_ALGO_ABA picks the chain mapping where it measured faster than lane-per-body on MI355X (profiles/r01_chain_sweep.txt):
-    // fp32 from 16384 states up (6 wavefronts per CU fit the LDS budget); in fp64 the 48 KB per wavefront leave one wavefront
-    // per SIMD and the lanes mapping stays ahead at every batch size, so it is opt-in there (RBD_ALGO_ABA_CHAINS).
-    w->chain_min_batch = dtype == RBD_F32 ? 16384 : (1L << 40);
-    if (const char* e = getenv("RBD_CHAIN_MIN_BATCH")) w->chain_min_batch = atol(e);
+    // opt-in only (RBD_ALGO_ABA_CHAINS): the banked mapping is ahead of it at every measured batch size (profiles/r01_mapping_sweep.txt)
   }
   {
     const char* e = getenv("RBD_ABA_STOP_AFTER");  // profiling aid only
@@ -497,6 +498,8 @@ int rbd_workspace_enable_timing(rbd_ws_t* w, int32_t enable) {
   w->timing = enable ? 1 : 0;
   return RBD_OK;
 }
+
+const char* rbd_workspace_last_kernel(const rbd_ws_t* w) { return w ? w->last_kernel : ""; }
 
 int rbd_workspace_last_kernel_ms(rbd_ws_t* w, float* ms) {
   if (!w || !ms || !w->ev_pending) return RBD_ERR_INVALID_ARGUMENT;
@@ -613,6 +616,38 @@ int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const vo
 }
 }  // namespace
 
+// The fused articulated-body pass through whichever lane mapping fits: `algorithm` RBD_ALGO_ABA chooses by batch size
+// (measured crossovers, profiles/r01_mapping_sweep.txt), the RBD_ALGO_ABA_* values force one.  `gravity` overrides the
+// model's (the M^-1 solve runs the pass with g = 0); `fuse` folds a Munthe-Kaas stage into the launch (lanes / banks only).
+static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd,
+                   Layout Lq, Layout Lv, Layout Lf, const double* gravity, const MkFuse* fuse) {
+  const rbd_model* m = w->model;
+  const bool can_chain = m->chain.ok && w->chain_lds_bytes > 0 && !fuse, can_bank = m->bank_lps > 0;
+  if (algorithm == RBD_ALGO_ABA_CHAINS && !can_chain) return RBD_ERR_UNSUPPORTED;
+  if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
+  int pick = algorithm;
+  if (algorithm == RBD_ALGO_ABA) pick = (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
+  Timed t(w);
+  w->last_kernel = pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : pick == RBD_ALGO_ABA_CHAINS ? "aba_chain_kernel" : "aba_kernel";
+  if (pick == RBD_ALGO_ABA_BANKS) {
+    BankModel bm = w->bm;
+    if (gravity) memcpy(bm.gravity, gravity, sizeof bm.gravity);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_bank<double>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
+    else HIP_TRY(launch_aba_bank<float>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
+  } else if (pick == RBD_ALGO_ABA_CHAINS) {
+    ChainModel cm = w->cm;
+    if (gravity) memcpy(cm.gravity, gravity, sizeof cm.gravity);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_chain<double>(cm, B, w->chain_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_aba_chain<float>(cm, B, w->chain_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+  } else {
+    DevModel dm = w->dm;
+    if (gravity) memcpy(dm.gravity, gravity, sizeof dm.gravity);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_aba<double>(dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
+    else HIP_TRY(launch_aba<float>(dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
+  }
+  return RBD_OK;
+}
+
 // dynamics! on device pointers: ABA, the reference's CRBA + Cholesky route, or the loop-joint branch
 static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd,
                         void* dqd, void* dlam) {
@@ -641,23 +676,7 @@ static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, con
       HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_M, dtau, w->d_c, dvd, nullptr, Lm, Lv, w->d_notpd, w->stream));
     }
   } else {
-    const bool can_chain = m->chain.ok && w->chain_lds_bytes > 0;
-    if (o.algorithm == RBD_ALGO_ABA_CHAINS && !can_chain) return RBD_ERR_UNSUPPORTED;
-    const bool chains = o.algorithm == RBD_ALGO_ABA_CHAINS || (o.algorithm == RBD_ALGO_ABA && can_chain && B >= w->chain_min_batch);
-    const bool can_bank = m->bank_lps > 0;
-    if (o.algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
-    const bool banks = !chains && (o.algorithm == RBD_ALGO_ABA_BANKS || (o.algorithm == RBD_ALGO_ABA && can_bank && w->bank_auto));
-    Timed t(w);
-    if (banks) {
-      if (w->dtype == RBD_F64) HIP_TRY(launch_aba_bank<double>(w->bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-      else HIP_TRY(launch_aba_bank<float>(w->bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-    } else if (chains) {
-      if (w->dtype == RBD_F64) HIP_TRY(launch_aba_chain<double>(w->cm, B, w->chain_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-      else HIP_TRY(launch_aba_chain<float>(w->cm, B, w->chain_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-    } else {
-      if (w->dtype == RBD_F64) HIP_TRY(launch_aba<double>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-      else HIP_TRY(launch_aba<float>(w->dm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-    }
+    if ((st = run_aba(w, B, o.algorithm, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, nullptr, nullptr))) return st;
   }
   return RBD_OK;
 }
@@ -790,16 +809,12 @@ int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs
   } else {
     // O(n) solve: x = M(q)^-1 rhs is forward dynamics with v = 0, no gravity and tau = rhs (then c = 0), i.e. one pass of
     // the articulated-body kernel — no matrix is formed unless the caller asked for it.
-    DevModel dm0 = w->dm;
-    dm0.gravity[0] = dm0.gravity[1] = dm0.gravity[2] = 0.0;
+    const double g0[3] = {0.0, 0.0, 0.0};
     const Layout Lf = layout_of(o.layout, 6L * m->nb, B);
-    Timed t(w);
-    if (w->dtype == RBD_F64) {
-      HIP_TRY(launch_aba<double>(dm0, B, dq, nullptr, dr, nullptr, dx, nullptr, Lq, Lv, Lf, w->stream));
-      if (dM) HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
-    } else {
-      HIP_TRY(launch_aba<float>(dm0, B, dq, nullptr, dr, nullptr, dx, nullptr, Lq, Lv, Lf, w->stream));
-      if (dM) HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
+    if ((st = run_aba(w, B, RBD_ALGO_ABA, dq, nullptr, dr, nullptr, dx, nullptr, Lq, Lv, Lf, g0, nullptr))) return st;
+    if (dM) {
+      if (w->dtype == RBD_F64) HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
+      else HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
     }
   }
   if (o.memory == RBD_MEM_HOST) {
@@ -885,8 +900,7 @@ int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, cons
     for (int stage = 0; stage < 4; ++stage) {
       MkFuse F{};
       F.stage = stage; F.dt = dt; F.W = w->mk; F.q_state = dq; F.v_state = dv;
-      if (w->dtype == RBD_F64) HIP_TRY(launch_aba<double>(w->dm, B, dq, dv, dtau, df, nullptr, nullptr, Lq, Lv, Lf, w->stream, &F));
-      else HIP_TRY(launch_aba<float>(w->dm, B, dq, dv, dtau, df, nullptr, nullptr, Lq, Lv, Lf, w->stream, &F));
+      if ((st = run_aba(w, B, RBD_ALGO_ABA, dq, dv, dtau, df, nullptr, nullptr, Lq, Lv, Lf, nullptr, &F))) return st;
     }
     if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, 4, dt, dq, dv, nullptr, w->mk, Lq, Lv, w->stream));
     else HIP_TRY(launch_mk_stage<float>(w->dm, B, 4, dt, dq, dv, nullptr, w->mk, Lq, Lv, w->stream));

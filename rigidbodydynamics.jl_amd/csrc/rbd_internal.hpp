@@ -42,5 +42,5 @@ hipError_t launch_aba_chain(const ChainModel& C, long B, size_t lds_bytes, const
 namespace rbd {
 template <typename T>
 hipError_t launch_aba_bank(const BankModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
-                           Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+                           Layout Lq, Layout Lv, Layout Lf, hipStream_t s, const MkFuse* fuse = nullptr);
 }

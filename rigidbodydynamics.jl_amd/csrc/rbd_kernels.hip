@@ -947,7 +947,10 @@ template hipError_t launch_aba_chain<float>(const ChainModel&, long, size_t, con
 
 template <typename T>
 hipError_t launch_aba_bank(const BankModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
-                           Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+                           Layout Lq, Layout Lv, Layout Lf, hipStream_t s, const MkFuse* fuse) {
+  MkFuse F{};
+  F.stage = -1;
+  if (fuse) F = *fuse;
   const long spw = 64 / M.lps, waves = (B + spw - 1) / spw;
   const size_t lds = (size_t)PARK_SLOTS * 256 * sizeof(T);
   static thread_local bool raised = false;
@@ -957,11 +960,16 @@ hipError_t launch_aba_bank(const BankModel& M, long B, const void* q, const void
     raised = true;
   }
   hipLaunchKernelGGL(aba_bank_kernel<T>, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
-                     (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
+                     (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf, F);
   return hipGetLastError();
 }
-template hipError_t launch_aba_bank<double>(const BankModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
-template hipError_t launch_aba_bank<float>(const BankModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+#ifdef RBD_PROFILE_PHASES
+extern "C" int rbd_debug_bank_phase_clock(long long* out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(rbd_bank_phase_clock), sizeof(long long) * 16);
+}
+#endif
+template hipError_t launch_aba_bank<double>(const BankModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t, const MkFuse*);
+template hipError_t launch_aba_bank<float>(const BankModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t, const MkFuse*);
 
 template <typename T>
 hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,

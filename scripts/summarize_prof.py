@@ -9,11 +9,11 @@ for d in sorted(glob.glob("gpurun_out/pmc*/")):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "aba_kernel" in r["Kernel_Name"]:
+            if "aba_" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             tot[k] = sum(v) / len(v)
-print("== PMC (per aba_kernel launch, averaged):")
+print("== PMC (per ABA kernel launch, averaged):")
 for k in sorted(tot):
     print(f"  {k:24s} {tot[k]:16.1f}")
 if "SQ_WAVES" in tot:

@@ -701,7 +701,7 @@ def test_dynamics_chains_scope_and_auto_selection(rbd, oracle, models):
         rbd.dynamics_(result, state, algorithm="aba_chains")
     rbd.dynamics_(result, state)  # default still works (lanes)
     # full size: both mappings agree with each other and the dynamics! -> inverse_dynamics round trip closes
-    # (test/test_mechanism_algorithms.jl:729-740); in fp32 the default picks the chain mapping from 16384 states up
+    # (test/test_mechanism_algorithms.jl:729-740); at this size the default (RBD_ALGO_ABA) picks the banked mapping
     model = models["atlas_floating"]
     B = 32768
     state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 61)
