@@ -353,4 +353,147 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
   if (F.stage >= 0) store_joint_v(r1.b, (T*)F.W.vd[F.stage], Lv, r1.vd);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Banked RNEA: inverse_dynamics! (vdot != nullptr) and dynamics_bias! (vdot == nullptr), src/mechanism_algorithms.jl:542-553,
+// :484-498 — the same two-bodies-per-lane mapping as aba_bank_kernel.  RNEA is sums only, so every tree joint type is in scope.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T> struct RneaRegs {
+  Body<T> b;
+  const T* rb;
+  T R[9], p[3], Tw[6], acc[6], w[6];
+};
+
+// kinematics step at level l with spatial accelerations (spatial_accelerations! :387-417): a_b = a_p + (-T_b) x T_p + X a_joint
+template <typename T, bool CROSS>
+RBD_DEV void rnea_fk_step(const BankModel& M, int l, const RneaRegs<T>& par, RneaRegs<T>& c, const T* XR, const T* Xp, const T* tl, const T* al) {
+  T pR[9], pp[3], pT[6], pa[6];
+  bank_pull<T, 9, CROSS>(M, c.b, l, par.R, pR);
+  bank_pull<T, 3, CROSS>(M, c.b, l, par.p, pp);
+  bank_pull<T, 6, CROSS>(M, c.b, l, par.Tw, pT);
+  bank_pull<T, 6, CROSS>(M, c.b, l, par.acc, pa);
+  if (c.b.level == l) {
+    matmul3(pR, XR, c.R);
+    matvec3(pR, Xp, c.p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c.p[k] += pp[k];
+    T vJ[6], nT[6], cr[6], aj[6];
+    xmotion(c.R, c.p, tl, vJ);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { c.Tw[k] = pT[k] + vJ[k]; nT[k] = -c.Tw[k]; }
+    se3_comm(nT, pT, cr);
+    xmotion(c.R, c.p, al, aj);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c.acc[k] = pa[k] + cr[k] + aj[k];
+  }
+}
+
+// joint_wrenches_and_torques! (:442-459): lanes of `tk` at level l-1 add the wrenches of their children (lanes of `gv` at level l)
+template <typename T, bool CROSS> RBD_DEV void rnea_gather(int l, int ns, const RneaRegs<T>& gv, RneaRegs<T>& tk) {
+  const bool takes = (tk.b.level == l - 1);
+  if (!CROSS) {
+    const T m0 = (takes && tk.b.nchild >= 1) ? T(1) : T(0);
+    T t[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] = from_next_lane(gv.w[k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tk.w[k] += t[k] * m0;
+  }
+#pragma unroll 1
+  for (int s = CROSS ? 0 : 1; s < ns; ++s) {
+    const bool take = takes && (s < tk.b.nchild);
+    const int src = take ? tk.b.base + child_sel(tk.b, s) : tk.b.lane;
+    const T mask = take ? T(1) : T(0);
+    T t[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] = shfl(gv.w[k], src);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tk.w[k] += t[k] * mask;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, int ncol, const T* __restrict__ q, const T* __restrict__ v,
+                                                          const T* __restrict__ vdot, const T* __restrict__ fext, T* __restrict__ tau,
+                                                          T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
+  RneaRegs<T> r0, r1;
+  auto fetch = [&](int k, RneaRegs<T>& c, T* qj, T* vj, T* aj) {
+    load_bank_body(M, k, B, c.b);
+    c.rb = reinterpret_cast<const T*>(M.rb[k]) + (c.b.sub < M.nbk[k] ? c.b.sub : 0) * RB_STRIDE;
+    load_joint_q(c.b, q, Lq, qj);
+    load_joint_v(c.b, v, Lv, vj);
+    load_joint_v(c.b, vdot, Lv, aj);
+  };
+  auto setup = [&](RneaRegs<T>& c, const T* qj, const T* vj, const T* aj, T* XR, T* Xp, T* tl, T* al) {
+    store_qdot(c.b, qdot, Lq, qj, vj);
+    local_transform(c.b, c.rb, qj, XR, Xp);
+    local_joint_motion(c.b, c.rb, vj, tl);
+    local_joint_motion(c.b, c.rb, aj, al);  // joint_spatial_acceleration: S_local * v̇
+    // as if at level 0: H = XL, T = vJ, a = -g + X a_joint; deeper lanes overwrite at their level
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = XR[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.p[i] = Xp[i];
+    xmotion(c.R, c.p, tl, c.Tw);
+    xmotion(c.R, c.p, al, c.acc);
+    c.acc[3] -= T(M.gravity[0]); c.acc[4] -= T(M.gravity[1]); c.acc[5] -= T(M.gravity[2]);
+  };
+  // newton_euler! (:428-439): w = I a + T x* I T - wext
+  auto newton_euler = [&](RneaRegs<T>& c) {
+    RInertia<T> I;
+    T Jb[6], mc[3], Ia[6], x[6], fe[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jb[k] = c.rb[RB_J + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mc[k] = c.rb[RB_MC + k];
+    inertia_to_root(Jb, mc, c.rb[RB_M], c.R, c.p, I);
+    mul_inertia(I, c.acc, Ia);
+    momentum_cross(I, c.Tw, x);
+    load_body_wrench(c.b, fext, Lf, fe);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c.w[k] = c.b.valid ? (Ia[k] + x[k] - fe[k]) : T(0);
+  };
+  auto project = [&](RneaRegs<T>& c) {  // tau = S' w
+    T out[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    if (c.b.jtype == RBD_JOINT_QUAT_FLOATING) {
+      xforce_inv(c.R, c.p, c.w, out);
+    } else {
+      const T ax[3] = {c.rb[RB_AXIS], c.rb[RB_AXIS + 1], c.rb[RB_AXIS + 2]}, ay[3] = {c.rb[RB_AXIS2], c.rb[RB_AXIS2 + 1], c.rb[RB_AXIS2 + 2]};
+      for (int k = 0; k < ncol; ++k) {  // ncol (uniform): 3 when the mechanism has QuaternionSpherical / Planar joints, else 1
+        T sl[6], S[6];
+        subspace_col(c.b.jtype, ax, ay, k, sl);
+        xmotion(c.R, c.p, sl, S);
+        const T d = dot6(S, c.w);
+        if (k == 0) out[0] = d; else if (k == 1) out[1] = d; else out[2] = d;
+      }
+    }
+    store_joint_v(c.b, tau, Lv, out);
+  };
+
+  T qj0[7], vj0[6], aj0[6], qj1[7], vj1[6], aj1[6];
+  fetch(0, r0, qj0, vj0, aj0);
+  fetch(1, r1, qj1, vj1, aj1);
+  {
+    T XR[9], Xp[3], tl[6], al[6];
+    setup(r0, qj0, vj0, aj0, XR, Xp, tl, al);
+#pragma unroll 1
+    for (int l = 1; l < M.L0; ++l) rnea_fk_step<T, false>(M, l, r0, r0, XR, Xp, tl, al);
+  }
+  {
+    T XR[9], Xp[3], tl[6], al[6];
+    setup(r1, qj1, vj1, aj1, XR, Xp, tl, al);
+    rnea_fk_step<T, true>(M, M.L0, r0, r1, XR, Xp, tl, al);
+#pragma unroll 1
+    for (int l = M.L0 + 1; l < M.nlevels; ++l) rnea_fk_step<T, false>(M, l, r1, r1, XR, Xp, tl, al);
+  }
+  newton_euler(r1);
+  newton_euler(r0);
+#pragma unroll 1
+  for (int l = M.nlevels - 1; l > M.L0; --l) rnea_gather<T, false>(l, (int)M.nslots[l], r1, r1);
+  rnea_gather<T, true>(M.L0, (int)M.nslots[M.L0], r1, r0);
+#pragma unroll 1
+  for (int l = M.L0 - 1; l >= 1; --l) rnea_gather<T, false>(l, (int)M.nslots[l], r0, r0);
+  project(r0);
+  project(r1);
+}
+
 }  // namespace rbd

@@ -66,7 +66,7 @@ struct rbd_model {
   std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref;  // loop tables (reference body indices)
   std::vector<double> loop_r, axis_ref, axis2_ref;
   // banked lane-per-body mapping (aba_bank_kernel): two bodies per lane, split at level bank_L0; bank_lps == 0: not applicable
-  int32_t bank_lps = 0, bank_L0 = 0, bank_nb[2] = {0, 0};
+  int32_t bank_lps = 0, bank_L0 = 0, bank_nb[2] = {0, 0}, bank_aba_ok = 0;
   std::vector<int32_t> bank_ib[2];
   std::vector<double> bank_rb[2];
   uint64_t bank_perm_down = 0;
@@ -275,8 +275,9 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     m->nc += ncl;
     m->loops.push_back(lj);
   }
-  if (m->nloops == 0 && !m->has3dof && !m->inner_floating && m->nlevels >= 2) {
-    // banked mapping: split the levels so that both banks fit the fewest lanes
+  m->bank_aba_ok = (m->nloops == 0 && !m->has3dof && !m->inner_floating);  // the banked ABA handles 1-dof / fixed joints and 6-dof joints on the world
+  if (m->nlevels >= 2) {
+    // banked mapping (the RNEA variant takes every joint type): split the levels so that both banks fit the fewest lanes
     std::vector<int> per_level(m->nlevels, 0);
     for (int s = 0; s < nb; ++s) per_level[level[s]]++;
     int best_L0 = 0, best_lanes = 1 << 30, best_diff = 1 << 30;
@@ -622,7 +623,7 @@ int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const vo
 static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd,
                    Layout Lq, Layout Lv, Layout Lf, const double* gravity, const MkFuse* fuse) {
   const rbd_model* m = w->model;
-  const bool can_chain = m->chain.ok && w->chain_lds_bytes > 0 && !fuse, can_bank = m->bank_lps > 0;
+  const bool can_chain = m->chain.ok && w->chain_lds_bytes > 0 && !fuse, can_bank = m->bank_lps > 0 && m->bank_aba_ok;
   if (algorithm == RBD_ALGO_ABA_CHAINS && !can_chain) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   int pick = algorithm;
@@ -731,9 +732,18 @@ static int rnea_common(rbd_ws_t* w, int32_t B, const void* q, const void* v, con
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
   {
+    if (o.algorithm == RBD_ALGO_ABA_BANKS && m->bank_lps == 0) return RBD_ERR_UNSUPPORTED;
+    // same batch-size rule as the ABA mappings: two bodies per lane once one body per lane would put two wavefronts on a SIMD
+    const bool banks = m->bank_lps > 0 && (o.algorithm == RBD_ALGO_ABA_BANKS || (o.algorithm != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
     Timed t(w);
-    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dt, nullptr, nullptr, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dt, nullptr, nullptr, Lq, Lv, Lf, w->stream));
+    if (banks) {
+      const int ncol = m->has3dof ? 3 : 1;
+      if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_bank<double>(w->bm, B, ncol, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf, w->stream));
+      else HIP_TRY(launch_rnea_bank<float>(w->bm, B, ncol, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf, w->stream));
+    } else {
+      if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dt, nullptr, nullptr, Lq, Lv, Lf, w->stream));
+      else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dt, nullptr, nullptr, Lq, Lv, Lf, w->stream));
+    }
   }
   if (o.memory == RBD_MEM_HOST) return stage_out_copy(w, tau_out, dt, es * m->nv * B);
   return RBD_OK;

@@ -44,3 +44,8 @@ template <typename T>
 hipError_t launch_aba_bank(const BankModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
                            Layout Lq, Layout Lv, Layout Lf, hipStream_t s, const MkFuse* fuse = nullptr);
 }
+namespace rbd {
+template <typename T>
+hipError_t launch_rnea_bank(const BankModel& M, long B, int ncol, const void* q, const void* v, const void* vdot, const void* fext, void* tau, void* qdot,
+                            Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+}

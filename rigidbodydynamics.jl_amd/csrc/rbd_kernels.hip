@@ -972,6 +972,17 @@ template hipError_t launch_aba_bank<double>(const BankModel&, long, const void*,
 template hipError_t launch_aba_bank<float>(const BankModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t, const MkFuse*);
 
 template <typename T>
+hipError_t launch_rnea_bank(const BankModel& M, long B, int ncol, const void* q, const void* v, const void* vdot, const void* fext, void* tau, void* qdot,
+                            Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+  const long spw = 64 / M.lps, waves = (B + spw - 1) / spw;
+  hipLaunchKernelGGL(rnea_bank_kernel<T>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, M, B, ncol, (const T*)q, (const T*)v, (const T*)vdot,
+                     (const T*)fext, (T*)tau, (T*)qdot, Lq, Lv, Lf);
+  return hipGetLastError();
+}
+template hipError_t launch_rnea_bank<double>(const BankModel&, long, int, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea_bank<float>(const BankModel&, long, int, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+
+template <typename T>
 hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
                       void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s, const MkFuse* fuse) {
   MkFuse F{};

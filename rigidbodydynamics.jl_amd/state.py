@@ -236,29 +236,33 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
     return None
 
 
+_MAPPING = {"auto": _capi.ALGO_ABA, "lanes": _capi.ALGO_ABA_LANES, "banks": _capi.ALGO_ABA_BANKS}
+
+
 def inverse_dynamics_(torquesout: torch.Tensor, state: MechanismState, vd: torch.Tensor,
-                      externalwrenches: Optional[torch.Tensor] = None):
-    """`inverse_dynamics!(torquesout, jointwrenchesout, accelerations, state, v̇, externalwrenches)` (:542-553)."""
+                      externalwrenches: Optional[torch.Tensor] = None, mapping: str = "auto"):
+    """`inverse_dynamics!(torquesout, jointwrenchesout, accelerations, state, v̇, externalwrenches)` (:542-553).
+    mapping: lane mapping of the kernel ("auto": by batch size; "lanes" / "banks" force one — tests, benchmarks)."""
     f = state.flat
     state._check(torquesout, f.nv, "torquesout")
     state._check(vd, f.nv, "v̇")
     state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
     state.ws.use_current_stream()
-    opts = state._opts()
+    opts = state._opts(_MAPPING[mapping])
     st = _capi.lib().rbd_inverse_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(vd), _ptr(externalwrenches),
                                           _ptr(torquesout), ctypes.byref(opts))
     _raise(st, "rbd_inverse_dynamics")
     return torquesout
 
 
-def dynamics_bias_(result_or_out, state: MechanismState, externalwrenches: Optional[torch.Tensor] = None):
+def dynamics_bias_(result_or_out, state: MechanismState, externalwrenches: Optional[torch.Tensor] = None, mapping: str = "auto"):
     """`dynamics_bias!(result, state)` / `dynamics_bias!(torques, …, state, externalwrenches)` (:484-498)."""
     out = result_or_out.dynamicsbias if isinstance(result_or_out, DynamicsResult) else result_or_out
     f = state.flat
     state._check(out, f.nv, "dynamicsbias")
     state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
     state.ws.use_current_stream()
-    opts = state._opts()
+    opts = state._opts(_MAPPING[mapping])
     st = _capi.lib().rbd_dynamics_bias(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(externalwrenches), _ptr(out),
                                        ctypes.byref(opts))
     _raise(st, "rbd_dynamics_bias")

@@ -719,3 +719,47 @@ def test_dynamics_chains_scope_and_auto_selection(rbd, oracle, models):
     rbd.dynamics_(r0, state, t)
     rbd.dynamics_(r1, state, t, algorithm="aba_lanes")
     assert float((r0.vd - r1.vd).abs().max()) <= 2e-3 * float(r1.vd.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", MODELS)
+def test_inverse_dynamics_and_bias_banked_f64(rbd, oracle, models, name, layout):
+    """The two-bodies-per-lane RNEA (every tree joint type) against the oracle and against the one-body-per-lane kernel."""
+    model = models[name]
+    B = 45
+    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 71)
+    rng = np.random.default_rng(72)
+    vd = rng.standard_normal((B, model.nv))
+    out = torch.zeros_like(dev(tau, state))
+    try:
+        rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state), mapping="banks")
+    except Exception:
+        pytest.skip("tree too small to split into two banks")
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+    assert np.abs(host(out, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    out2 = torch.zeros_like(out)
+    rbd.dynamics_bias_(out, state, mapping="banks")
+    rbd.dynamics_bias_(out2, state, mapping="lanes")
+    ref = oracle.dynamics_bias(model, q, v)
+    assert np.abs(host(out, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert float((out - out2).abs().max()) <= 1e-10 * max(1.0, float(out2.abs().max()))
+
+
+@pytest.mark.gpu
+def test_inverse_dynamics_banked_f32_and_full_size(rbd, oracle, models):
+    model = models["atlas_floating"]
+    state, q, v, tau, fe = make(rbd, model, 64, "f32", "aos", 73)
+    vd = np.random.default_rng(74).standard_normal((64, model.nv)).astype(np.float32).astype(np.float64)
+    out = torch.zeros_like(dev(tau, state))
+    rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state), mapping="banks")
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+    assert np.abs(host(out, state) - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+    B = 16384  # auto picks the banked kernels; dynamics! -> inverse_dynamics closes (test/test_mechanism_algorithms.jl:729-740)
+    state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 75)
+    res = rbd.DynamicsResult(model, B)
+    t = dev(tau, state)
+    rbd.dynamics_(res, state, t)
+    back = torch.zeros_like(t)
+    rbd.inverse_dynamics_(back, state, res.vd)
+    assert float((back - t).abs().max()) <= 1e-8 * max(1.0, float(t.abs().max()))
