@@ -208,6 +208,11 @@ int rbd_mk_stage(rbd_ws_t* ws, int32_t B, int32_t stage, double dt, void* q, voi
 int rbd_kinematics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* momentum_matrix, void* com, void* energy,
                    const rbd_opts_t* opts);
 
+/* geometric_jacobian!(jac, state, path(mechanism, base, target)) in the root frame — src/mechanism_algorithms.jl:80-99, :126-131.
+ * base_body / target_body: body indices of the flat model, -1 = the root body.  jac: 6×nv column-major per state, (angular; linear);
+ * columns off the path are written as zeros.  Device pointers. */
+int rbd_geometric_jacobian(rbd_ws_t* ws, int32_t B, const void* q, int32_t base_body, int32_t target_body, void* jac, const rbd_opts_t* opts);
+
 /* ---- diagnostics ------------------------------------------------------------ */
 const char* rbd_status_string(int status);
 const char* rbd_last_hip_error(void);   /* thread-local text of the last HIP failure     */

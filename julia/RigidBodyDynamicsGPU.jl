@@ -64,9 +64,14 @@ const LAYOUT_AOS = Int32(1)    # Julia n × B column-major == one state per colu
 const MEM_DEVICE, MEM_HOST = Int32(0), Int32(1)
 
 jointtag(::Fixed) = Int32(0); jointtag(::Revolute) = Int32(1); jointtag(::Prismatic) = Int32(2)
-jointtag(::QuaternionFloating) = Int32(3); jointtag(::SinCosRevolute) = Int32(6)
+jointtag(::QuaternionFloating) = Int32(3); jointtag(::Planar) = Int32(4); jointtag(::QuaternionSpherical) = Int32(5)
+jointtag(::SinCosRevolute) = Int32(6)
+jointtag(jt::JointType) = throw(ArgumentError("joint type $(typeof(jt)) is not supported by librbd_hip (e.g. SPQuatFloating)"))
 jointaxis(jt::Union{Revolute, Prismatic, SinCosRevolute}) = Tuple(Float64.(jt.axis))
+jointaxis(jt::Planar) = Tuple(Float64.(jt.x_axis))          # planar.jl: translation along x_axis / y_axis, rotation about x × y
 jointaxis(::JointType) = (0.0, 0.0, 0.0)
+jointaxis2(jt::Planar) = Tuple(Float64.(jt.y_axis))
+jointaxis2(::JointType) = (0.0, 0.0, 0.0)
 rowmajor(R) = Float64[R[i, j] for i in 1:3 for j in 1:3]    # the C side stores rotations row-major
 
 # ---- flatten once on the host: exactly the tables MechanismState tabulates (mechanism_state.jl:85-118) -----------
@@ -86,7 +91,7 @@ function FlatModelHandle(mechanism::Mechanism)
     qoff = Int32[0; cumsum(num_positions.(tj))[1:end-1]]
     voff = Int32[0; cumsum(num_velocities.(tj))[1:end-1]]
     axis = reduce(vcat, [collect(jointaxis(joint_type(j))) for j in tj]; init = Float64[])
-    axis2 = zeros(3nb)
+    axis2 = reduce(vcat, [collect(jointaxis2(joint_type(j))) for j in tj]; init = Float64[])
     prot = reduce(vcat, [rowmajor(rotation(joint_to_predecessor(j))) for j in tj]; init = Float64[])
     ptrans = reduce(vcat, [Float64.(translation(joint_to_predecessor(j))) for j in tj]; init = Float64[])
     inertias = [spatial_inertia(successor(j, mechanism)) for j in tj]      # expressed in frame_after(joint) after canonicalization
@@ -152,7 +157,7 @@ function BatchedDynamicsResult(mechanism::Mechanism, B::Integer; T::Type = Float
     BatchedDynamicsResult{T}(zeros(T, nv, nv, B), zeros(T, nv, B), zeros(T, nq, B), zeros(T, nv, B), zeros(T, nc, B), zeros(T, nc, nv, B), zeros(T, nc, B))
 end
 
-opts(; algorithm = 0, stabilization = 1) = Ref(RbdOpts(LAYOUT_AOS, MEM_HOST, algorithm, stabilization))
+opts(; algorithm = 0, stabilization = 1, memory = MEM_HOST) = Ref(RbdOpts(LAYOUT_AOS, memory, algorithm, stabilization))
 nullable(x::AbstractArray) = pointer(x)
 nullable(::Nothing) = C_NULL
 batchsize(state) = size(state.q, 2)
@@ -226,5 +231,17 @@ function RigidBodyDynamics.simulate(state::BatchedMechanismState{T}, final_time;
     check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
     range(zero(T), step = T(Δt), length = nsteps + 1)
 end
+
+
+# ---- kinematics by-products of the same forward-kinematics pass (device or host buffers as above) --------------------------------
+# momentum_matrix!(out, state) mechanism_algorithms.jl:313-327, center_of_mass :28-50, kinetic_energy / gravitational_potential_energy
+# mechanism_state.jl:886-903 -> rbd_kinematics;  geometric_jacobian!(out, state, path) :80-99 -> rbd_geometric_jacobian (base / target
+# body indices as in FlatModelHandle, -1 = root body);  x = M \ rhs as in dynamics_solve! :764/:819 -> rbd_mass_matrix_solve;  the dense
+# potrf!/potrs! step alone -> rbd_cholesky_solve.  They take device pointers (RBD_MEM_DEVICE), i.e. ROCArrays from AMDGPU.jl:
+#
+#   ccall((:rbd_kinematics, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+#         state.ws, B, q, v, A #= 6nv × B or C_NULL =#, com #= 3 × B =#, energy #= 2 × B =#, opts(memory = MEM_DEVICE))
+#   ccall((:rbd_geometric_jacobian, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Int32, Int32, Ptr{T}, Ref{RbdOpts}),
+#         state.ws, B, q, base, target, J #= 6nv × B =#, opts(memory = MEM_DEVICE))
 
 end # module

@@ -162,3 +162,17 @@ def momentum_matrix(model, q, v=None, dtype=np.float64):
     for b in range(B):
         assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(None if v is None else v[b], ct), _ptr(A[b], ct), _ptr(h[b], ct), _ptr(com[b], ct)) == 0
     return A.transpose(0, 2, 1), h, com
+
+
+def geometric_jacobian(model, q, base, body, v=None, dtype=np.float64):
+    """(J [B, 6, nv] of path(base -> body) in the root frame, relative twist [B, 6] when v is given)."""
+    sfx, ct = _sfx(dtype)
+    f = getattr(lib(), "rbdo_geometric_jacobian" + sfx)
+    f.restype = ctypes.c_int
+    B = q.shape[0]
+    q = np.ascontiguousarray(q, dtype)
+    v = None if v is None else np.ascontiguousarray(v, dtype)
+    J = np.zeros((B, model.nv, 6), dtype); t = np.zeros((B, 6), dtype)
+    for b in range(B):
+        assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(None if v is None else v[b], ct), int(base), int(body), _ptr(J[b], ct), _ptr(t[b], ct)) == 0
+    return J.transpose(0, 2, 1), t

@@ -886,6 +886,34 @@ int FN(rbdo_momentum_matrix)(const rbd_flat_model_t* m, const REAL* q, const REA
   return RBD_OK;
 }
 
+/* geometric_jacobian!(jac, state, path) in the root frame: src/mechanism_algorithms.jl:80-99 with path(mechanism, base, body)
+ * (src/graphs/tree_path.jl:41-63): columns of the joints from `base` up to the lowest common ancestor get -S (direction up),
+ * those from the ancestor down to `body` +S, every other column 0.  base / body: body indices, -1 = the root body.
+ * J: 6 x nv column-major (angular; linear).  trel (optional, needs v): relative_twist(state, body, base) in the root frame,
+ * for the check of test/test_mechanism_algorithms.jl:310-327 (J v == relative twist).                                      */
+int FN(rbdo_geometric_jacobian)(const rbd_flat_model_t* m, const REAL* q, const REAL* v, int base, int body, REAL* J, REAL* trel) {
+  CACHE c;
+  if (FN(cache_alloc)(m, &c)) return RBD_ERR_OUT_OF_MEMORY;
+  FN(update_transforms)(m, q, &c);
+  FN(update_motion_subspaces)(m, q, &c);
+  for (int i = 0; i < 6 * m->nv; ++i) J[i] = 0;
+  int a = base, b = body;
+  while (a != b) {
+    const int up = a > b; /* parents come first, so the deeper side is the larger index (tree_path.jl:47-58) */
+    const int x = up ? a : b;
+    const int nvi = FN(joint_nv)(m->joint_type[x]);
+    for (int k = 0; k < nvi; ++k)
+      for (int r = 0; r < 6; ++r) J[6 * (m->v_offset[x] + k) + r] = (up ? -1 : 1) * c.S[6 * (m->v_offset[x] + k) + r];
+    if (up) a = m->parent[a]; else b = m->parent[b];
+  }
+  if (trel && v) {
+    FN(update_twists)(m, v, &c);
+    for (int r = 0; r < 6; ++r) trel[r] = (body >= 0 ? c.T[6 * body + r] : 0) - (base >= 0 ? c.T[6 * base + r] : 0);
+  }
+  FN(cache_free)(&c);
+  return RBD_OK;
+}
+
 /* transforms_to_root of every moving body, for FK checks: out[b*12 ..] = R (9, row-major), p (3) */
 int FN(rbdo_transforms)(const rbd_flat_model_t* m, const REAL* q, REAL* out) {
   CACHE c;

@@ -63,7 +63,7 @@ struct rbd_model {
   std::vector<int32_t> anc;     // nb * nlevels
   std::vector<uint64_t> row_mask;  // nv
   std::vector<rbd_loop_joint_t> loops;
-  std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref;  // loop tables (reference body indices)
+  std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref, parent_ref;  // loop tables (reference body indices)
   std::vector<double> loop_r, axis_ref, axis2_ref;
   // banked lane-per-body mapping (aba_bank_kernel): two bodies per lane, split at level bank_L0; bank_lps == 0: not applicable
   int32_t bank_lps = 0, bank_L0 = 0, bank_nb[2] = {0, 0}, bank_aba_ok = 0;
@@ -234,6 +234,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   } else { delete m; return RBD_ERR_UNSUPPORTED; }
   m->nc = 0;
   m->jt_ref.assign(d->joint_type, d->joint_type + nb);
+  m->parent_ref.assign(d->parent, d->parent + nb);
   m->voff_ref.assign(d->v_offset, d->v_offset + nb);
   m->axis_ref.assign(d->joint_axis, d->joint_axis + 3 * nb);
   if (d->joint_axis2) m->axis2_ref.assign(d->joint_axis2, d->joint_axis2 + 3 * nb); else m->axis2_ref.assign(3 * nb, 0.0);
@@ -956,8 +957,34 @@ int rbd_kinematics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* m
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), La = layout_of(o.layout, 6L * m->nv, B);
   const Layout L3 = layout_of(o.layout, 3, B), L2 = layout_of(o.layout, 2, B);
   Timed t(w);
-  if (w->dtype == RBD_F64) HIP_TRY(launch_kin<double>(w->dm, B, q, v, momentum_matrix, com, energy, Lq, Lv, La, L3, L2, w->stream));
-  else HIP_TRY(launch_kin<float>(w->dm, B, q, v, momentum_matrix, com, energy, Lq, Lv, La, L3, L2, w->stream));
+  if (w->dtype == RBD_F64) HIP_TRY(launch_kin<double>(w->dm, B, q, v, momentum_matrix, com, energy, nullptr, 0, 0, Lq, Lv, La, L3, L2, w->stream));
+  else HIP_TRY(launch_kin<float>(w->dm, B, q, v, momentum_matrix, com, energy, nullptr, 0, 0, Lq, Lv, La, L3, L2, w->stream));
+  return RBD_OK;
+}
+
+
+int rbd_geometric_jacobian(rbd_ws_t* w, int32_t B, const void* q, int32_t base_body, int32_t target_body, void* jac, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!q || !jac || o.memory != RBD_MEM_DEVICE) return RBD_ERR_INVALID_ARGUMENT;
+  const rbd_model* m = w->model;
+  if (base_body < -1 || base_body >= m->nb || target_body < -1 || target_body >= m->nb) return RBD_ERR_INVALID_ARGUMENT;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  // path(mechanism, base, target): walk both ends up to the lowest common ancestor (src/graphs/tree_path.jl:41-63); the joints on the
+  // base side are traversed upwards (-S), those on the target side downwards (+S)
+  uint64_t plus = 0, minus = 0;
+  int a = base_body, b = target_body;
+  while (a != b) {
+    if (a > b) { minus |= (uint64_t)1 << m->slot_of[a]; a = m->parent_ref[a]; }
+    else { plus |= (uint64_t)1 << m->slot_of[b]; b = m->parent_ref[b]; }
+  }
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), La = layout_of(o.layout, 6L * m->nv, B);
+  const Layout L3 = layout_of(o.layout, 3, B), L2 = layout_of(o.layout, 2, B);
+  Timed t(w);
+  if (w->dtype == RBD_F64) HIP_TRY(launch_kin<double>(w->dm, B, q, nullptr, nullptr, nullptr, nullptr, jac, plus, minus, Lq, Lv, La, L3, L2, w->stream));
+  else HIP_TRY(launch_kin<float>(w->dm, B, q, nullptr, nullptr, nullptr, nullptr, jac, plus, minus, Lq, Lv, La, L3, L2, w->stream));
   return RBD_OK;
 }
 

@@ -31,8 +31,8 @@ hipError_t launch_mk_stage(const DevModel& M, long B, int stage, double dt, void
 }
 namespace rbd {
 template <typename T>
-hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, void* A, void* com, void* energy, Layout Lq, Layout Lv, Layout La,
-                      Layout L3, Layout L2, hipStream_t s);
+hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, void* A, void* com, void* energy, void* J, uint64_t jplus,
+                      uint64_t jminus, Layout Lq, Layout Lv, Layout La, Layout L3, Layout L2, hipStream_t s);
 }
 namespace rbd {
 template <typename T>

@@ -814,8 +814,8 @@ template <typename T> RBD_DEV T group_sum(T x, int lps) {  // sum over the lanes
 
 template <typename T>
 __global__ __launch_bounds__(256) void kin_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v, T* __restrict__ A_out,
-                                                  T* __restrict__ com_out, T* __restrict__ energy_out, Layout Lq, Layout Lv, Layout La,
-                                                  Layout L3, Layout L2) {
+                                                  T* __restrict__ com_out, T* __restrict__ energy_out, T* __restrict__ J_out, uint64_t jplus,
+                                                  uint64_t jminus, Layout Lq, Layout Lv, Layout La, Layout L3, Layout L2) {
   Body<T> b;
   load_body(M, B, b);
   const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
@@ -857,6 +857,23 @@ __global__ __launch_bounds__(256) void kin_kernel(DevModel M, long B, const T* _
       if (com_out) { com_out[0 * L3.sk + b.state * L3.sb] = cx / ms; com_out[1 * L3.sk + b.state * L3.sb] = cy / ms; com_out[2 * L3.sk + b.state * L3.sb] = cz / ms; }
     }
   }
+  const int nvi = joint_nv(b.jtype);
+  const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
+  if (J_out != nullptr) {
+    // geometric_jacobian!(jac, state, path) in the root frame (src/mechanism_algorithms.jl:80-99): -S for the joints walked
+    // upwards (bit of jminus), +S downwards (jplus), zero off the path — every column is written (fill!(jac, 0))
+    const T sg = ((jplus >> b.sub) & 1) ? T(1) : ((jminus >> b.sub) & 1) ? T(-1) : T(0);
+#pragma unroll 1
+    for (int ci = 0; ci < nvi; ++ci) {
+      T sl[6], Si[6];
+      subspace_col(b.jtype, ax, ay, ci, sl);
+      xmotion(R, p, sl, Si);
+      if (b.valid) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J_out[((long)(b.voff + ci) * 6 + k) * La.sk + b.state * La.sb] = sg * Si[k];
+      }
+    }
+  }
   if (A_out == nullptr) return;  // uniform
   for (int l = M.nlevels - 1; l >= 1; --l) {
     const int ns = (int)M.nslots[l];
@@ -876,8 +893,6 @@ __global__ __launch_bounds__(256) void kin_kernel(DevModel M, long B, const T* _
       Ic.m = acc[9];
     }
   }
-  const int nvi = joint_nv(b.jtype);
-  const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
 #pragma unroll 1
   for (int ci = 0; ci < nvi; ++ci) {
     T sl[6], Si[6], F[6];
@@ -905,14 +920,14 @@ static inline dim3 grid_for(const DevModel& M, long B, int block) {
 }
 
 template <typename T>
-hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, void* A, void* com, void* energy, Layout Lq, Layout Lv, Layout La,
-                      Layout L3, Layout L2, hipStream_t s) {
-  hipLaunchKernelGGL(kin_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (T*)A, (T*)com, (T*)energy, Lq, Lv, La,
-                     L3, L2);
+hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, void* A, void* com, void* energy, void* J, uint64_t jplus,
+                      uint64_t jminus, Layout Lq, Layout Lv, Layout La, Layout L3, Layout L2, hipStream_t s) {
+  hipLaunchKernelGGL(kin_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (T*)A, (T*)com, (T*)energy, (T*)J, jplus,
+                     jminus, Lq, Lv, La, L3, L2);
   return hipGetLastError();
 }
-template hipError_t launch_kin<double>(const DevModel&, long, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, Layout, Layout, hipStream_t);
-template hipError_t launch_kin<float>(const DevModel&, long, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_kin<double>(const DevModel&, long, const void*, const void*, void*, void*, void*, void*, uint64_t, uint64_t, Layout, Layout, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_kin<float>(const DevModel&, long, const void*, const void*, void*, void*, void*, void*, uint64_t, uint64_t, Layout, Layout, Layout, Layout, Layout, hipStream_t);
 
 template <typename T, int G>
 static hipError_t launch_aba_chain_g(const ChainModel& C, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,

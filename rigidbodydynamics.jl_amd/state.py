@@ -431,3 +431,15 @@ def chain_plan(flat):
         return {"tracks": g.value, "steps": ns.value, "lds_fields": nf.value, "table": tab.reshape(ns.value, g.value)}
     finally:
         L.rbd_model_destroy(h)
+
+
+def geometric_jacobian_(out: torch.Tensor, state: MechanismState, base: int, body: int):
+    """`geometric_jacobian!(out, state, path(mechanism, base, body))` in the root frame (src/mechanism_algorithms.jl:80-99):
+    out is (B, 6*nv), each row a 6×nv column-major matrix, (angular; linear); `base` / `body` are body indices of the flat
+    model (-1 = the root body).  J·v is `relative_twist(state, body, base)`."""
+    state._check(out, 6 * state.flat.nv, "jacobian")
+    state.ws.use_current_stream()
+    opts = state._opts()
+    _raise(_capi.lib().rbd_geometric_jacobian(state.ws.handle, state.batch, _ptr(state.q), int(base), int(body), _ptr(out), ctypes.byref(opts)),
+           "rbd_geometric_jacobian")
+    return out

@@ -763,3 +763,24 @@ def test_inverse_dynamics_banked_f32_and_full_size(rbd, oracle, models):
     back = torch.zeros_like(t)
     rbd.inverse_dynamics_(back, state, res.vd)
     assert float((back - t).abs().max()) <= 1e-8 * max(1.0, float(t.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", MODELS)
+def test_geometric_jacobian_f64(rbd, oracle, models, name, layout):
+    """geometric_jacobian!(out, state, path) in the root frame against the oracle (test/test_mechanism_algorithms.jl:310-327)."""
+    model = models[name]
+    B = 37
+    state, q, v, _, _ = make(rbd, model, B, "f64", layout, 81)
+    rng = np.random.default_rng(82)
+    J = torch.full((B, 6 * model.nv) if layout == "aos" else (6 * model.nv, B), 7.0, dtype=torch.float64, device="cuda")  # off-path columns must be zeroed
+    for _ in range(6):
+        base, body = rng.choice(np.arange(-1, model.n_bodies), 2, replace=False)
+        rbd.geometric_jacobian_(J, state, int(base), int(body))
+        ref, trel = oracle.geometric_jacobian(model, q, base, body, v)
+        got = host(J, state).reshape(B, model.nv, 6).transpose(0, 2, 1)
+        assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+        assert np.abs(np.einsum("bkn,bn->bk", got, v) - trel).max() <= 1e-11 * max(1.0, np.abs(trel).max())
+    with pytest.raises(ValueError):
+        rbd.geometric_jacobian_(J, state, 0, model.n_bodies)

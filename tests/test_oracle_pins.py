@@ -9,6 +9,7 @@ vectors and Julia is unavailable, so the pins are its closed-form
   test/test_mechanism_algorithms.jl:654-675  gravity term = d PE / d q
   test/test_mechanism_algorithms.jl:729-740  dynamics! -> inverse_dynamics round trip, atol 1e-10
   test/test_mechanism_algorithms.jl:742-753  dynamics_bias = inverse_dynamics(vdot = 0)
+  test/test_mechanism_algorithms.jl:310-327  geometric Jacobian: J v = relative twist, atol 1e-12
   test/test_mechanism_algorithms.jl:527-545  momentum matrix: A v = sum_b I_b T_b, atol 1e-12
   test/test_mechanism_algorithms.jl:707-727  momentum-rate balance with external wrenches (through the
                                               floating-base rows of tau)
@@ -202,3 +203,18 @@ def test_momentum_matrix_times_v_is_total_momentum(rbd, oracle, models, name):
     for b in range(8):
         assert np.abs(A[b] @ v[b] - h[b]).max() <= 1e-12 * max(1.0, np.abs(h[b]).max())
         assert abs(-mass * g @ com[b] - pe[b]) <= 1e-12 * max(1.0, abs(pe[b]))
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_geometric_jacobian_times_v_is_relative_twist(rbd, oracle, models, name):
+    """test/test_mechanism_algorithms.jl:310-327: random (base, body) pairs, the root body included."""
+    model = models[name]
+    q, v, _ = rand_inputs(rbd, model, 4, 6)
+    rng = np.random.default_rng(7)
+    for _ in range(10):
+        base, body = rng.choice(np.arange(-1, model.n_bodies), 2, replace=False)
+        J, t = oracle.geometric_jacobian(model, q, base, body, v)
+        for b in range(4):
+            assert np.abs(J[b] @ v[b] - t[b]).max() <= 1e-12 * max(1.0, np.abs(t[b]).max())
+    J, t = oracle.geometric_jacobian(model, q, 0, 0, v)
+    assert np.abs(J).max() == 0.0
