@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
                                                          T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, MkFuse F) {
   extern __shared__ double park_raw[];
   T* const park = reinterpret_cast<T*>(park_raw) + threadIdx.x;  // slot i of this lane: park[i * 256]
+  RBD_MARK(0);
   BankRegs<T> r0, r1;
   // ---- per-body set-up (once per bank, every lane busy): joint transform and joint twist in the joint frame ----
   // The global loads of BOTH banks are issued up front (two dependent round trips: body record, then q / v / tau), so that
@@ -221,7 +222,6 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
   };
 
   // ---- top-down: transforms to root and twists (update_transforms!, update_twists_wrt_world!) ----
-  RBD_MARK(0);
   T qj0[7], vj0[6], qj1[7], vj1[6];
   fetch(0, r0, qj0, vj0);
   fetch(1, r1, qj1, vj1);

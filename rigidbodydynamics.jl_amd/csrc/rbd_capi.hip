@@ -448,6 +448,11 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     // opt-in only (RBD_ALGO_ABA_CHAINS): the banked mapping is ahead of it at every measured batch size (profiles/r01_mapping_sweep.txt)
   }
   {
+    const int G = (m->chain.ok && w->chain_lds_bytes > 0) ? m->chain.G : 0;
+    const hipError_t e = dtype == RBD_F64 ? configure_kernels<double>(G, w->chain_lds_bytes) : configure_kernels<float>(G, w->chain_lds_bytes);
+    if (e != hipSuccess) { g_last_hip_error = std::string("configure_kernels: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
+  }
+  {
     const char* e = getenv("RBD_ABA_STOP_AFTER");  // profiling aid only
     dm.debug_stop = e ? atoi(e) : 0;
   }

@@ -49,3 +49,6 @@ template <typename T>
 hipError_t launch_rnea_bank(const BankModel& M, long B, int ncol, const void* q, const void* v, const void* vdot, const void* fext, void* tau, void* qdot,
                             Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 }
+namespace rbd {
+template <typename T> hipError_t configure_kernels(int chain_G, size_t chain_lds_bytes);
+}

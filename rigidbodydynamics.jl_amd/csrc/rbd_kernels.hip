@@ -932,14 +932,6 @@ template hipError_t launch_kin<float>(const DevModel&, long, const void*, const 
 template <typename T, int G>
 static hipError_t launch_aba_chain_g(const ChainModel& C, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
                                      void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
-  if (lds_bytes > 64 * 1024) {
-    static thread_local size_t raised = 0;
-    if (raised < lds_bytes) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_chain_kernel<T, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) return e;
-      raised = lds_bytes;
-    }
-  }
   const long spw = 64 / G;
   hipLaunchKernelGGL((aba_chain_kernel<T, G>), dim3((unsigned)((B + spw - 1) / spw)), dim3(64), lds_bytes, s, C, B, (const T*)q, (const T*)v,
                      (const T*)tau, (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
@@ -968,16 +960,26 @@ hipError_t launch_aba_bank(const BankModel& M, long B, const void* q, const void
   if (fuse) F = *fuse;
   const long spw = 64 / M.lps, waves = (B + spw - 1) / spw;
   const size_t lds = (size_t)PARK_SLOTS * 256 * sizeof(T);
-  static thread_local bool raised = false;
-  if (lds > 48 * 1024 && !raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_bank_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    raised = true;
-  }
   hipLaunchKernelGGL(aba_bank_kernel<T>, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
                      (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf, F);
   return hipGetLastError();
 }
+// Dynamic-LDS limits of the kernels that ask for more than the default; a function attribute of the CURRENT device, so
+// rbd_workspace_create calls this once per workspace (after hipSetDevice) rather than the launchers guessing.
+template <typename T> static hipError_t raise_chain_lds(int G, size_t bytes) {
+  const void* f = G == 1 ? (const void*)&aba_chain_kernel<T, 1> : G == 2 ? (const void*)&aba_chain_kernel<T, 2> : G == 4 ? (const void*)&aba_chain_kernel<T, 4>
+                : G == 8 ? (const void*)&aba_chain_kernel<T, 8> : (const void*)&aba_chain_kernel<T, 16>;
+  return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+template <typename T> hipError_t configure_kernels(int chain_G, size_t chain_lds_bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_bank_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)((size_t)PARK_SLOTS * 256 * sizeof(T)));
+  if (e == hipSuccess && chain_G > 0 && chain_lds_bytes > 48 * 1024) e = raise_chain_lds<T>(chain_G, chain_lds_bytes);
+  return e;
+}
+template hipError_t configure_kernels<double>(int, size_t);
+template hipError_t configure_kernels<float>(int, size_t);
+
 #ifdef RBD_PROFILE_PHASES
 extern "C" int rbd_debug_bank_phase_clock(long long* out16) {
   return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(rbd_bank_phase_clock), sizeof(long long) * 16);
