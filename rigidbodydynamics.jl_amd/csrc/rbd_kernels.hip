@@ -1408,7 +1408,11 @@ __global__ __launch_bounds__(64) void loop_solve_kernel(LoopView<T> V, long B, i
   const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (st >= B) return;
   const int nv = V.nv, nc = V.nc, nb = V.nb;
-  T* L = scratch + st * scratch_stride;  // nv*nv (column-major, lower)
+  // Per-state work arrays.  The solve is a long chain of dependent small-matrix steps, so where the arrays live sets its speed:
+  // in LDS (scratch == nullptr: one odd-strided column per thread, 100-cycle accesses) when a block's worth fits, else in the
+  // HBM scratch of the workspace (one cache line per thread and access — 8x slower on the four-bar benchmark configuration).
+  extern __shared__ double loop_lds_raw[];
+  T* L = scratch ? scratch + st * scratch_stride : reinterpret_cast<T*>(loop_lds_raw) + (long)threadIdx.x * scratch_stride;  // nv*nv (column-major, lower)
   T* K = L + nv * nv;                    // nc*nv row-major
   T* Y = K + nc * nv;                    // nc*nv row-major
   T* A = Y + nc * nv;                    // nc*nc
@@ -1550,9 +1554,16 @@ template <typename T>
 hipError_t launch_loop_solve(const LoopView<T>& V, long B, int stabilize, const void* body, const void* M, const void* c, const void* tau, void* vdot,
                              void* lambda, void* K, void* k, void* scratch, long scratch_stride, Layout Lm, Layout Lv, Layout Lc, Layout Lk,
                              const double* gravity, int* notpd, hipStream_t s) {
-  hipLaunchKernelGGL(loop_solve_kernel<T>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, V, B, stabilize, (const T*)body, (const T*)M, (const T*)c,
-                     (const T*)tau, (T*)vdot, (T*)lambda, (T*)K, (T*)k, (T*)scratch, scratch_stride, Lm, Lv, Lc, Lk, gravity[0], gravity[1],
-                     gravity[2], notpd);
+  const long lds_stride = scratch_stride | 1;  // odd: consecutive threads start in different LDS banks
+  const size_t lds = (size_t)64 * lds_stride * sizeof(T);
+  if (lds <= 64 * 1024)
+    hipLaunchKernelGGL(loop_solve_kernel<T>, dim3((unsigned)((B + 63) / 64)), dim3(64), lds, s, V, B, stabilize, (const T*)body, (const T*)M, (const T*)c,
+                       (const T*)tau, (T*)vdot, (T*)lambda, (T*)K, (T*)k, (T*)nullptr, lds_stride, Lm, Lv, Lc, Lk, gravity[0], gravity[1],
+                       gravity[2], notpd);
+  else
+    hipLaunchKernelGGL(loop_solve_kernel<T>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, V, B, stabilize, (const T*)body, (const T*)M, (const T*)c,
+                       (const T*)tau, (T*)vdot, (T*)lambda, (T*)K, (T*)k, (T*)scratch, scratch_stride, Lm, Lv, Lc, Lk, gravity[0], gravity[1],
+                       gravity[2], notpd);
   return hipGetLastError();
 }
 template hipError_t launch_loop_solve<double>(const LoopView<double>&, long, int, const void*, const void*, const void*, const void*, void*, void*, void*, void*, void*, long, Layout, Layout, Layout, Layout, const double*, int*, hipStream_t);
