@@ -161,6 +161,10 @@ RBD_DEV void mk_stage_lane(const Body<T>& b, int stage, T dt, T* qj, T* vj, cons
   const int t = b.jtype;
   const int nq = joint_nq<T>(t), nv = joint_nv(t);
   T q0j[7], v0j[6];
+  T rate[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};  // local-coordinate rates of the stage just evaluated (kept in registers: the
+                                                     // tableau below needs them again, and reading them back from phid[stage-1]
+                                                     // would be a store -> load round trip through L2 on the critical path)
+  T vdp[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // v̇ of the stage just evaluated, when the caller hands it over (un-fused launches)
   T* q0 = (T*)W.q0; T* v0 = (T*)W.v0;
   if (stage == 0) {
 #pragma unroll
@@ -171,14 +175,12 @@ RBD_DEV void mk_stage_lane(const Body<T>& b, int stage, T dt, T* qj, T* vj, cons
     load_joint_q(b, q0, Lq, q0j);
     load_joint_v(b, v0, Lv, v0j);
     // rates of the stage that has just been evaluated
-    T rate[6];
     joint_local_rate(t, q0j, qj, vj, rate);
     T* pd = (T*)W.phid[stage - 1];
 #pragma unroll
     for (int k = 0; k < 6; ++k)
       if (b.valid && k < nv) pd[(long)(b.voff + k) * Lv.sk + b.state * Lv.sb] = rate[k];
     if (vdot_prev != nullptr) {
-      T vdp[6];
       load_joint_v(b, vdot_prev, Lv, vdp);
       T* vs = (T*)W.vd[stage - 1];
 #pragma unroll
@@ -202,7 +204,11 @@ RBD_DEV void mk_stage_lane(const Body<T>& b, int stage, T dt, T* qj, T* vj, cons
       const T* pd = (const T*)W.phid[j]; const T* vs = (const T*)W.vd[j];
 #pragma unroll
       for (int k = 0; k < 6; ++k)
-        if (b.valid && k < nv) { const long a = (long)(b.voff + k) * Lv.sk + b.state * Lv.sb; phi[k] += wj * pd[a]; vn[k] += wj * vs[a]; }
+        if (b.valid && k < nv) {
+          const long a = (long)(b.voff + k) * Lv.sk + b.state * Lv.sb;
+          phi[k] += wj * ((j == stage - 1) ? rate[k] : pd[a]);
+          vn[k] += wj * ((j == stage - 1 && vdot_prev != nullptr) ? vdp[k] : vs[a]);
+        }
     }
   }
   T qn[7];
