@@ -11,6 +11,8 @@ vectors and Julia is unavailable, so the pins are its closed-form
   test/test_mechanism_algorithms.jl:742-753  dynamics_bias = inverse_dynamics(vdot = 0)
   test/test_mechanism_algorithms.jl:310-327  geometric Jacobian: J v = relative twist, atol 1e-12
   test/test_mechanism_algorithms.jl:527-545  momentum matrix: A v = sum_b I_b T_b, atol 1e-12
+  test/test_mechanism_algorithms.jl:616-652  Coriolis term: dM/dt - 2C is skew-symmetric (finite differences instead of ForwardDiff)
+  test/test_mechanism_algorithms.jl:773-797  power flow with external wrenches: tau.v + sum wext.T = d(PE + KE)/dt
   test/test_mechanism_algorithms.jl:707-727  momentum-rate balance with external wrenches (through the
                                               floating-base rows of tau)
 """
@@ -218,3 +220,86 @@ def test_geometric_jacobian_times_v_is_relative_twist(rbd, oracle, models, name)
             assert np.abs(J[b] @ v[b] - t[b]).max() <= 1e-12 * max(1.0, np.abs(t[b]).max())
     J, t = oracle.geometric_jacobian(model, q, 0, 0, v)
     assert np.abs(J).max() == 0.0
+
+
+@pytest.mark.parametrize("name", ["randmech1", "randmech2", "randmech3", "atlas_floating", "inner_floating"])
+def test_power_flow_with_external_wrenches(rbd, oracle, models, name):
+    """test/test_mechanism_algorithms.jl:773-797: the power of the joint torques and of the external wrenches equals the rate of the
+    total energy along (q̇, v̇) of dynamics!.  The reference differentiates with dual numbers; here a central difference (h = 1e-6,
+    quaternion blocks drift off the unit sphere only by O(h²))."""
+    model = models[name]
+    B = 4
+    q, v, tau, fe = rand_inputs(rbd, model, B, 21, fext=True)
+    vd, qd = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    power = np.einsum("bi,bi->b", tau, v)
+    for body in range(model.n_bodies):
+        _, twist = oracle.geometric_jacobian(model, q, -1, body, v)  # twist_wrt_world of the body, root frame
+        power += np.einsum("bk,bk->b", fe[:, 6 * body:6 * body + 6], twist)
+    h = 1e-6
+    kp, pp = oracle.energy(model, q + h * qd, v + h * vd)
+    km, pm = oracle.energy(model, q - h * qd, v - h * vd)
+    dE = (kp + pp - km - pm) / (2 * h)
+    assert np.allclose(dE, power, rtol=1e-6, atol=1e-5 * max(1.0, np.abs(power).max()))
+
+
+def test_coriolis_matrix_skew_symmetry(rbd, oracle):
+    """test/test_mechanism_algorithms.jl:616-652 on the same kind of mechanism (10 revolute + 10 prismatic joints, where q̇ = v):
+    with C = ½ ∂c/∂v (c = inverse_dynamics(v̇ = 0)) and Ṁ = Σ ∂M/∂q_k q̇_k, Ṁ - 2C is skew-symmetric."""
+    rng = np.random.default_rng(36)
+    model = rbd.flatten(rbd.rand_tree_mechanism(rng, ["Revolute"] * 10 + ["Prismatic"] * 10))
+    q, v, _ = rand_inputs(rbd, model, 1, 37)
+    nv = model.nv
+    h = 1e-5
+
+    def sym(M):
+        return np.tril(M) + np.tril(M, -1).T
+
+    Mdot = np.zeros((nv, nv))
+    for k in range(nv):
+        dq = np.zeros_like(q); dq[0, k] = h
+        Mdot += (sym(oracle.mass_matrix(model, q + dq)[0]) - sym(oracle.mass_matrix(model, q - dq)[0])) / (2 * h) * v[0, k]
+    C = np.zeros((nv, nv))
+    zero = np.zeros_like(v)
+    for k in range(nv):
+        dv = np.zeros_like(v); dv[0, k] = h
+        C[:, k] = (oracle.inverse_dynamics(model, q, v + dv, zero)[0] - oracle.inverse_dynamics(model, q, v - dv, zero)[0]) / (2 * h)
+    C *= 0.5
+    skew = Mdot - 2 * C
+    scale = max(1.0, np.abs(Mdot).max(), np.abs(C).max())
+    assert np.abs(skew + skew.T).max() <= 1e-6 * scale
+
+
+def rand_floating_tree(rbd, seed):
+    """rand_floating_tree_mechanism (src/mechanism_modification.jl:416-426) with the joint mix of the reference test: every body
+    descends from one QuaternionFloating joint on the world."""
+    rng = np.random.default_rng(seed)
+    non_root = lambda mech, r: mech.bodies[1 + r.integers(len(mech.bodies) - 1)]
+    return rbd.flatten(rbd.rand_tree_mechanism(rng, ["QuaternionFloating"] + ["Revolute"] * 10 + ["Planar"] * 10 + ["SinCosRevolute"] * 5, non_root))
+
+
+@pytest.mark.parametrize("name", ["rand_floating_tree", "atlas_floating", "valkyrie_floating"])
+def test_inverse_dynamics_external_wrenches_momentum_rate(rbd, oracle, models, name):
+    """test/test_mechanism_algorithms.jl:707-727: for a mechanism on a floating joint, the floating joint's wrench (its rows of
+    inverse_dynamics, moved to the root frame) + gravity + the external wrenches is the rate of change of the total momentum
+    A(q) v.  Ties inverse_dynamics! with wrenches, momentum_matrix!, center_of_mass and the transforms together.  The momentum
+    rate is a central difference along (q̇, v̇) here (the reference uses momentum_rate_bias)."""
+    model = rand_floating_tree(rbd, 39) if name == "rand_floating_tree" else models[name]
+    assert int(model.joint_type[0]) == 3 and list(model.parent).count(-1) == 1  # one body on the world, through the QuaternionFloating joint
+    B = 3
+    q, v, _, fe = rand_inputs(rbd, model, B, 39, fext=True)
+    vd = np.random.default_rng(40).random((B, model.nv))
+    tau = oracle.inverse_dynamics(model, q, v, vd, fe)
+    H = oracle.transforms(model, q)[:, 0]  # the floating body's frame = frame_after of its joint
+    R, p = H[:, :9].reshape(B, 3, 3), H[:, 9:]
+    Rt, Rf = np.einsum("bij,bj->bi", R, tau[:, 0:3]), np.einsum("bij,bj->bi", R, tau[:, 3:6])
+    total = np.concatenate([Rt + np.cross(p, Rf), Rf], axis=1)  # wrench transform (torque; force)
+    _, _, com = oracle.momentum_matrix(model, q, v)
+    mg = float(np.sum(model.inertia_mass)) * np.asarray(model.gravity, float)
+    total += np.concatenate([np.cross(com, mg[None, :]), np.tile(mg, (B, 1))], axis=1)
+    total += fe.reshape(B, model.n_bodies, 6).sum(axis=1)
+    _, qd = oracle.dynamics(model, q, v, want_qdot=True)
+    h = 1e-6
+    _, hp, _ = oracle.momentum_matrix(model, q + h * qd, v + h * vd)
+    _, hm, _ = oracle.momentum_matrix(model, q - h * qd, v - h * vd)
+    hdot = (hp - hm) / (2 * h)
+    assert np.abs(total - hdot).max() <= 1e-6 * max(1.0, np.abs(hdot).max())
