@@ -12,9 +12,13 @@
  * Parity pin: the reference stores NO golden vectors and Julia
  * cannot run here, so this restatement is pinned by the reference's own
  * closed-form and invariant tests, re-run against it in tests/test_oracle_*.py:
- * test/test_double_pendulum.jl:54-75 (M, C, G closed form, atol 1e-12),
- * test/test_mechanism_algorithms.jl:564-572, 600-614, 729-753 (invariants),
- * test/test_urdf.jl:85-101 (RPY golden matrices).
+ * test/test_double_pendulum.jl:54-75 (M, C, G closed form, atol 1e-12 — the known answers),
+ * test/test_mechanism_algorithms.jl:310-327 (J v = relative twist), 527-545 (A v = total momentum),
+ * 564-572, 600-614, 616-652 (Coriolis skew symmetry), 654-675, 707-727 (momentum rate with external
+ * wrenches on random floating trees), 729-753, 773-797 (power flow) — the invariants,
+ * test/test_urdf.jl:85-101 (RPY golden matrices), test/test_simulate.jl:203-222 (four-bar loop closure).
+ * Not pinned: outputs of the Julia implementation itself (no Julia toolchain in the image, so no
+ * oracle/_ref and no generated golden vectors).
  */
 
 #define CAT_(a, b) a##b
