@@ -664,9 +664,19 @@ __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* 
 // ancestor-or-self joint (support set), zero elsewhere; only the lower triangle is written.
 // M_out: element (i, j) of state b at M[(j*nv + i)*Lm.sk + b*Lm.sb].
 // ---------------------------------------------------------------------------------------------
+#ifdef RBD_PROFILE_PHASES
+__device__ long long rbd_crba_phase_clock[16];
+#define RBD_CMARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) rbd_crba_phase_clock[i] = clock64(); } while (0)
+extern "C" int rbd_debug_crba_phase_clock(long long* out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(rbd_crba_phase_clock), sizeof(long long) * 16);
+}
+#else
+#define RBD_CMARK(i)
+#endif
 template <typename T, int NDOF>
 __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* __restrict__ q, T* __restrict__ Mout,
                                                    Layout Lq, Layout Lm, int zero_fill) {
+  RBD_CMARK(0);
   Body<T> b;
   load_body(M, B, b);
   const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
@@ -674,7 +684,9 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
   load_joint_q(b, q, Lq, qj);
   T XR[9], Xp[3], R[9], p[3], zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, Tw[6], vJ[6];
   local_transform(b, rb, qj, XR, Xp);
+  RBD_CMARK(1);
   sweep_kinematics<T, false>(M, b, XR, Xp, R, p, zero6, Tw, vJ, nullptr, nullptr);
+  RBD_CMARK(2);
   RInertia<T> Ic;
   {
     T Jb[6], mc[3];
@@ -710,6 +722,7 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
       Ic.m = acc[9];
     }
   }
+  RBD_CMARK(3);
   const int jt = b.jtype;
   const int nvi = joint_nv(jt);
   const long nv = M.nv;
@@ -762,6 +775,7 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
       }
     }
   };
+  RBD_CMARK(4);
 #pragma unroll 1
   for (int k = 0; k < M.nlevels; ++k) {
     if (k > 0) {
@@ -787,6 +801,7 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
       }
     }
   }
+  RBD_CMARK(5);
   // structural zeros of the lower triangle (the reference writes them too: mechanism_algorithms.jl:266-267)
   if (zero_fill && b.valid) {
     for (int ci = 0; ci < nvi; ++ci) {
