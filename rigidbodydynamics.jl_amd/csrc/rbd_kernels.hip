@@ -673,7 +673,9 @@ extern "C" int rbd_debug_crba_phase_clock(long long* out16) {
 #else
 #define RBD_CMARK(i)
 #endif
-template <typename T, int NDOF>
+// ROOTREC (1-dof mechanisms whose 6-dof joints all sit on the world): the only 12-value record a chain can meet is the one of its
+// level-0 ancestor, so every lane fetches that once and the walk passes 6-value records — half the ds_bpermute traffic per round.
+template <typename T, int NDOF, bool ROOTREC>
 __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* __restrict__ q, T* __restrict__ Mout,
                                                    Layout Lq, Layout Lm, int zero_fill) {
   RBD_CMARK(0);
@@ -704,23 +706,37 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
     }
   }
   // composite-rigid-body inertias, bottom-up (10 scalars per child; first child by DPP): update_crb_inertias!
+  // In place: at step l only lanes at level l-1 change, and what they read (level l) was finished one step earlier.
+#pragma unroll 1
   for (int l = M.nlevels - 1; l >= 1; --l) {
+    const bool takes = (b.level == l - 1);
+    const T m0 = (takes && b.nchild >= 1) ? T(1) : T(0);
+    T t[10];  // what this lane's children hand up (zero for lanes that take nothing at this step)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] = from_next_lane(Ic.J[k]) * m0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[6 + k] = from_next_lane(Ic.c[k]) * m0;
+    t[9] = from_next_lane(Ic.m) * m0;
     const int ns = (int)M.nslots[l];
 #pragma unroll 1
-    for (int s = 0; s < ns; ++s) {
-      T give[10], acc[10];
+    for (int s = 1; s < ns; ++s) {
+      const bool take = takes && (s < b.nchild);
+      const int src = take ? b.base + child_sel(b, s) : b.lane;
+      const T mask = take ? T(1) : T(0);
+      T u[10];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) give[k] = acc[k] = Ic.J[k];
+      for (int k = 0; k < 6; ++k) u[k] = shfl(Ic.J[k], src);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) give[6 + k] = acc[6 + k] = Ic.c[k];
-      give[9] = acc[9] = Ic.m;
-      gather_add<T, 10>(b, l, s, give, acc);
+      for (int k = 0; k < 3; ++k) u[6 + k] = shfl(Ic.c[k], src);
+      u[9] = shfl(Ic.m, src);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Ic.J[k] = acc[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) Ic.c[k] = acc[6 + k];
-      Ic.m = acc[9];
+      for (int k = 0; k < 10; ++k) t[k] += u[k] * mask;
     }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Ic.J[k] += t[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Ic.c[k] += t[6 + k];
+    Ic.m += t[9];
   }
   RBD_CMARK(3);
   const int jt = b.jtype;
@@ -731,15 +747,25 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
   // What a lane publishes about its own joint: a 6-dof joint publishes its transform (R, p); a joint with <= NDOF degrees of
   // freedom publishes its root-frame motion subspace columns.  Walking up the support chain (support_set_masks,
   // src/mechanism_state.jl:95-98) is then "pull the record my parent currently holds", tree-depth times.
-  constexpr int RS = NDOF * 6 > 12 ? NDOF * 6 : 12;
+  constexpr int RS = ROOTREC ? 6 : (NDOF * 6 > 12 ? NDOF * 6 : 12);
   T rec[RS];
+  T root[12];  // ROOTREC: transform (R, p) of this body's level-0 ancestor
 #pragma unroll
   for (int k = 0; k < RS; ++k) rec[k] = T(0);
+  if (ROOTREC) {
+    const int a0 = b.valid ? M.anc[(b.sub < M.nb ? b.sub : 0) * M.nlevels + b.level] : b.sub;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) root[k] = shfl(R[k], b.base + a0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) root[9 + k] = shfl(p[k], b.base + a0);
+  }
   if (own_floating) {
+    if (!ROOTREC) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) rec[k] = R[k];
+      for (int k = 0; k < 9; ++k) rec[k] = R[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) rec[9 + k] = p[k];
+      for (int k = 0; k < 3; ++k) rec[(9 + k) % RS] = p[k];
+    }
   } else {
 #pragma unroll
     for (int c = 0; c < NDOF; ++c) {
@@ -760,7 +786,8 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
   auto emit = [&](const T* Fc, long row) {  // M[row, cols of the recorded joint] = Fc · S_col, lower triangle only
     if (rjt == RBD_JOINT_QUAT_FLOATING) {
       T o6[6];
-      xforce_inv(rec, rec + 9, Fc, o6);  // S' F for S = Xm(H): the inverse wrench transform
+      const T* H = ROOTREC ? root : rec;
+      xforce_inv(H, H + 9, Fc, o6);  // S' F for S = Xm(H): the inverse wrench transform
 #pragma unroll
       for (int cj = 0; cj < 6; ++cj) {
         const long col = rvoff + cj;
@@ -790,7 +817,8 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
         for (int ci = 0; ci < 6; ++ci) {
           T sl[6], Si[6], Fc[6];
           subspace_col(jt, ax, ay, ci, sl);
-          xmotion(R, p, sl, Si);
+          if (ROOTREC) xmotion(root, root + 9, sl, Si);  // a 6-dof joint on the world is its own level-0 ancestor
+          else xmotion(R, p, sl, Si);
           mul_inertia(Ic, Si, Fc);
           emit(Fc, (long)b.voff + ci);
         }
@@ -1037,8 +1065,9 @@ hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, 
 }
 template <typename T>
 hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill, hipStream_t s) {
-  if (M.has3dof) hipLaunchKernelGGL((crba_kernel<T, 3>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (T*)Mout, Lq, Lm, zero_fill);
-  else hipLaunchKernelGGL((crba_kernel<T, 1>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (T*)Mout, Lq, Lm, zero_fill);
+  if (M.has3dof) hipLaunchKernelGGL((crba_kernel<T, 3, false>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (T*)Mout, Lq, Lm, zero_fill);
+  else if (M.inner_floating) hipLaunchKernelGGL((crba_kernel<T, 1, false>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (T*)Mout, Lq, Lm, zero_fill);
+  else hipLaunchKernelGGL((crba_kernel<T, 1, true>), grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (T*)Mout, Lq, Lm, zero_fill);
   return hipGetLastError();
 }
 
