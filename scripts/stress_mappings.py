@@ -1,0 +1,49 @@
+"""One-off stress: many random tree topologies, every ABA / RNEA lane mapping against the oracle (fp64)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+import rbd_amd as rbd, oracle
+from test_chain_plan import random_tree
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(2024)
+worst = {}
+skipped = {"aba_banks": 0, "aba_chains": 0}
+for trial in range(N):
+    n = int(rng.integers(1, 45))
+    mech = random_tree(rbd, rng, n, bool(rng.integers(2)), float(rng.uniform(0, 1)))
+    model = rbd.flatten(mech)
+    B = int(rng.integers(1, 70))
+    r2 = np.random.default_rng(trial)
+    q, v = rbd.rand_configuration(model, B, r2), rbd.rand_velocity(model, B, r2)
+    tau, fe = r2.random((B, model.nv)), r2.random((B, 6 * model.n_bodies))
+    vd = r2.standard_normal((B, model.nv))
+    try:
+        state = rbd.MechanismState(model, B)
+    except Exception as e:  # more than 6 children on one body: outside the library's limits
+        skipped["model"] = skipped.get("model", 0) + 1
+        continue
+    res = rbd.DynamicsResult(model, B)
+    rbd.set_configuration_(state, q); rbd.set_velocity_(state, v)
+    ref = oracle.dynamics(model, q, v, tau, fe)
+    t, f = torch.as_tensor(tau).cuda(), torch.as_tensor(fe).cuda()
+    for algo in ("aba_lanes", "aba_banks", "aba_chains"):
+        try:
+            rbd.dynamics_(res, state, t, f, algorithm=algo)
+        except Exception:
+            skipped[algo] += 1
+            continue
+        err = np.abs(res.vd.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+        worst[algo] = max(worst.get(algo, 0.0), err)
+        assert err < 1e-8, (trial, algo, n, B, err)
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+    out = torch.zeros_like(t)
+    for mp in ("lanes", "banks"):
+        try:
+            rbd.inverse_dynamics_(out, state, torch.as_tensor(vd).cuda(), f, mapping=mp)
+        except Exception:
+            continue
+        err = np.abs(out.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
+        worst["rnea_" + mp] = max(worst.get("rnea_" + mp, 0.0), err)
+        assert err < 1e-9, (trial, mp, n, B, err)
+print(f"{N} random trees ok; worst relative errors {worst}; out of scope: {skipped}")
