@@ -176,3 +176,17 @@ def geometric_jacobian(model, q, base, body, v=None, dtype=np.float64):
     for b in range(B):
         assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(None if v is None else v[b], ct), int(base), int(body), _ptr(J[b], ct), _ptr(t[b], ct)) == 0
     return J.transpose(0, 2, 1), t
+
+
+def body_kinematics(model, q, v, vdot, dtype=np.float64):
+    """Per body: transform_to_root (B, nb, 12: R row-major, p), twist_wrt_world (B, nb, 6) and spatial acceleration relative to
+    the root (B, nb, 6), all in the root frame."""
+    sfx, ct = _sfx(dtype)
+    f = getattr(lib(), "rbdo_body_kinematics" + sfx)
+    f.restype = ctypes.c_int
+    B = q.shape[0]
+    q, v, vdot = (np.ascontiguousarray(a, dtype) for a in (q, v, vdot))
+    H = np.zeros((B, model.n_bodies, 12), dtype); T = np.zeros((B, model.n_bodies, 6), dtype); A = np.zeros((B, model.n_bodies, 6), dtype)
+    for b in range(B):
+        assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(v[b], ct), _ptr(vdot[b], ct), _ptr(H[b], ct), _ptr(T[b], ct), _ptr(A[b], ct)) == 0
+    return H, T, A

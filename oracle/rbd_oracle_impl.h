@@ -918,6 +918,29 @@ int FN(rbdo_geometric_jacobian)(const rbd_flat_model_t* m, const REAL* q, const 
   return RBD_OK;
 }
 
+/* spatial_accelerations!(result, state) with result.v̇ = vd (src/mechanism_algorithms.jl:387-417), then
+ * relative_acceleration(result, body, root_body) (src/dynamics_result.jl accessor): the root's fictitious -gravity is subtracted,
+ * so acc[6*i .. 6*i+5] is the true spatial acceleration of body i in the root frame.  Also returns transforms_to_root
+ * (R row-major 9, p 3) and twists_wrt_world (6) per body — what the maximal-coordinates test needs to build the equivalent state
+ * (test/test_mechanism_modification.jl:274-318).                                                                          */
+int FN(rbdo_body_kinematics)(const rbd_flat_model_t* m, const REAL* q, const REAL* v, const REAL* vd, REAL* H12, REAL* twist, REAL* acc) {
+  CACHE c;
+  if (FN(cache_alloc)(m, &c)) return RBD_ERR_OUT_OF_MEMORY;
+  FN(update_transforms)(m, q, &c);
+  FN(update_motion_subspaces)(m, q, &c);
+  FN(update_twists)(m, v, &c);
+  FN(accelerations)(m, vd, &c);
+  for (int i = 0; i < c.nb; ++i) {
+    if (H12) { memcpy(H12 + 12 * i, c.H[i].R, sizeof(REAL) * 9); memcpy(H12 + 12 * i + 9, c.H[i].p, sizeof(REAL) * 3); }
+    for (int j = 0; j < 6; ++j) {
+      if (twist) twist[6 * i + j] = c.T[6 * i + j];
+      if (acc) acc[6 * i + j] = c.A[6 * i + j] - (j >= 3 ? -(REAL)m->gravity[j - 3] : (REAL)0);
+    }
+  }
+  FN(cache_free)(&c);
+  return RBD_OK;
+}
+
 /* transforms_to_root of every moving body, for FK checks: out[b*12 ..] = R (9, row-major), p (3) */
 int FN(rbdo_transforms)(const rbd_flat_model_t* m, const REAL* q, REAL* out) {
   CACHE c;

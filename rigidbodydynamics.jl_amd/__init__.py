@@ -10,7 +10,7 @@ from .mechanism import (DEFAULT_GRAVITATIONAL_ACCELERATION, CartesianFrame3D, Fi
                         SpatialInertia, Transform3D, attach_, flatten, rand_configuration, rand_velocity,
                         remove_fixed_tree_joints_, rot_z_y_x, rotation_between)
 from .urdf import default_urdf_joint_types, parse_pose, parse_urdf
-from .builders import (FOUR_BAR_INITIAL_Q, FOUR_BAR_INITIAL_V, double_pendulum, four_bar_linkage, quickstart_double_pendulum,
+from .builders import (maximal_coordinates, FOUR_BAR_INITIAL_Q, FOUR_BAR_INITIAL_V, double_pendulum, four_bar_linkage, quickstart_double_pendulum,
                        rand_tree_mechanism, randmech)
 from .flatio import load_flat_model, save_flat_model
 from . import _capi

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .mechanism import (CartesianFrame3D, Joint, Mechanism, Revolute, RigidBody, SpatialInertia, Transform3D, attach_)
+from .mechanism import (CartesianFrame3D, Joint, Mechanism, QuaternionFloating, Revolute, RigidBody, SpatialInertia, Transform3D, attach_)
 
 
 def double_pendulum(lc1=-0.5, l1=-1.0, m1=1.0, I1=0.333, lc2=-1.0, m2=1.0, I2=1.33, g=-9.81) -> Mechanism:
@@ -116,3 +116,29 @@ def randmech(rng) -> Mechanism:
     """test/test_mechanism_algorithms.jl:1-11 with SPQuatFloating (out of scope) replaced by QuaternionSpherical."""
     return rand_tree_mechanism(rng, ["QuaternionFloating"] + ["Revolute"] * 5 + ["Fixed"] * 5 + ["Prismatic"] * 5 + ["Planar"] * 5 +
                                ["QuaternionSpherical"] * 2 + ["SinCosRevolute"] * 2)
+
+
+def maximal_coordinates(mechanism: Mechanism):
+    """`maximal_coordinates(mechanism)` src/mechanism_modification.jl:335-362: a dynamically equivalent mechanism with a flat
+    tree — every body hangs off the root on its own QuaternionFloating joint (frame_before = the root's frame, frame_after = the
+    body's default frame) and the joints of the input become non-tree joints enforced with Lagrange multipliers.  Bodies and
+    joints keep their order, so body i / loop joint i of the result corresponds to body i / tree joint i of the input."""
+    import copy
+    old_joints = mechanism.tree_joints + mechanism.non_tree_joints
+    bodies, joints = copy.deepcopy((mechanism.bodies, old_joints))  # one deepcopy: shared frame objects stay shared
+    bodymap = {id(o): n for o, n in zip(mechanism.bodies, bodies)}
+    root = bodies[0]
+    ret = Mechanism(root, gravity=mechanism.gravitational_acceleration)
+    for body in bodies[1:]:
+        fj = Joint(body.name, QuaternionFloating())
+        fj.frame_before, fj.frame_after = root.default_frame, body.default_frame
+        attach_(ret, root, body, fj, joint_pose=Transform3D(root.default_frame, root.default_frame),
+                successor_pose=Transform3D(body.default_frame, body.default_frame))
+    for oj, nj in zip(old_joints, joints):  # _copyjoint!: mechanism_modification.jl:48-61
+        sp, ss = mechanism.predecessor(oj), mechanism.successor(oj)
+        j2p = sp.fixed_transform(oj.frame_before, sp.default_frame)
+        s2j = ss.fixed_transform(ss.default_frame, oj.frame_after)
+        dp, ds = bodymap[id(sp)], bodymap[id(ss)]
+        attach_(ret, dp, ds, nj, joint_pose=Transform3D(nj.frame_before, dp.default_frame, j2p.R, j2p.p),
+                successor_pose=Transform3D(ds.default_frame, nj.frame_after, s2j.R, s2j.p))
+    return ret

@@ -784,3 +784,37 @@ def test_geometric_jacobian_f64(rbd, oracle, models, name, layout):
         assert np.abs(np.einsum("bkn,bn->bk", got, v) - trel).max() <= 1e-11 * max(1.0, np.abs(trel).max())
     with pytest.raises(ValueError):
         rbd.geometric_jacobian_(J, state, 0, model.n_bodies)
+
+
+@pytest.mark.gpu
+def test_maximal_coordinates_loop_dynamics(rbd, oracle):
+    """A mechanism in maximal coordinates (test/test_mechanism_modification.jl:274-318): 8 floating bodies, 8 loop joints of every
+    supported type, nv = 48, nc = 34 — the loop branch of dynamics! at sizes where its work arrays fall back to the HBM scratch.
+    v̇ and the constraint Jacobian / bias against the oracle; the Schur matrix is rank-deficient here, so λ is the minimum-norm one."""
+    from test_oracle_loops import MC_JOINTS, maximal_state
+    rng = np.random.default_rng(53)
+    tree = rbd.rand_tree_mechanism(rng, MC_JOINTS)
+    mt, mc = rbd.flatten(tree), rbd.flatten(rbd.maximal_coordinates(tree))
+    B = 33
+    q, v = rbd.rand_configuration(mt, B, rng), rbd.rand_velocity(mt, B, rng)
+    H, T, _ = oracle.body_kinematics(mt, q, v, np.zeros((B, mt.nv)))
+    qm, vm = maximal_state(H, T)
+    tau = rng.random((B, mc.nv))
+    state = rbd.MechanismState(mc, B)
+    result = rbd.DynamicsResult(mc, B)
+    rbd.set_configuration_(state, qm)
+    rbd.set_velocity_(state, vm)
+    rbd.dynamics_(result, state, dev(tau, state))
+    assert rbd.sync(state) == 0
+    ref = oracle.dynamics_loops(mc, qm, vm, tau)
+    got = host(result.vd, state)
+    assert np.abs(got - ref["vdot"]).max() <= 1e-8 * max(1.0, np.abs(ref["vdot"]).max())
+    K = host(result.constraintjacobian, state).reshape(B, mc.nv, mc.nc).transpose(0, 2, 1)
+    assert np.abs(K - ref["K"]).max() <= 1e-11
+    assert np.abs(host(result.constraintbias, state) - ref["k"]).max() <= 1e-9 * max(1.0, np.abs(ref["k"]).max())
+    # KKT residuals at the GPU solution (independent of the λ choice)
+    Mg = host(result.massmatrix, state).reshape(B, mc.nv, mc.nv).transpose(0, 2, 1)
+    Ms = np.tril(Mg) + np.transpose(np.tril(Mg, -1), (0, 2, 1))
+    lam = host(result.lambda_, state)
+    r1 = np.einsum("bij,bj->bi", Ms, got) + host(result.dynamicsbias, state) + np.einsum("bcv,bc->bv", K, lam) - tau
+    assert np.abs(r1).max() <= 1e-8 * max(1.0, np.abs(tau).max())
