@@ -1,13 +1,15 @@
 // rbd_device.hpp — device-side model view and spatial-algebra primitives for the gfx950 kernels.
 //
-// Execution model (all kernels in rbd_kernels.hip): ONE LANE PER (state, body).  A state of a
+// Execution model (kernels in rbd_kernels.hip): ONE LANE PER (state, body).  A state of a
 // mechanism with n_bodies moving bodies occupies LPS = next_pow2(n_bodies) adjacent lanes of a
 // 64-wide wavefront (Atlas: 31 bodies -> 32 lanes -> 2 states per wave).  Every per-body quantity
 // of the Featherstone passes lives in that lane's VGPRs for the whole kernel; the tree sweeps are
-// level-synchronous and parent<->child traffic is wave shuffles (ds_bpermute), so the only HBM
-// traffic is the algorithmic q/v/tau in, vdot out.  All quantities are expressed in the ROOT
-// frame, as in the reference (src/mechanism_state.jl:744-748, :776, :842), so the backward sweeps
-// are plain sums.
+// level-synchronous; the parent<->first-child hop is a DPP wave shift (bodies are in DFS pre-order),
+// other children go through ds_bpermute — so the only HBM traffic is the algorithmic q/v/tau in,
+// vdot out.  All quantities are expressed in the ROOT frame, as in the reference
+// (src/mechanism_state.jl:744-748, :776, :842), so the backward sweeps are plain sums.
+// Two further mappings of the same sweeps: two bodies per lane (rbd_bank.hpp: BankModel) and chains of
+// the tree on a few lanes per state (rbd_chain.hpp: ChainModel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -3,8 +3,11 @@
 //                  articulated-body algorithm (same v̇ = M⁻¹(τ − c))
 //   rnea_kernel  : inverse_dynamics! (:542-553) and dynamics_bias! (:484-498)
 //   crba_kernel  : mass_matrix!      (:248-272)
-// Mapping: one lane per (state, body); level-synchronous sweeps; parent/child exchange by wave
-// shuffles; per-body quantities stay in VGPRs (see rbd_device.hpp).
+//   kin_kernel   : momentum_matrix!, center_of_mass, energies, geometric_jacobian!   (by-products of the FK pass)
+//   chol_*_kernel, loop_solve_kernel, mk_stage_kernel : dynamics_solve! (dense / loop-joint branch), Munthe-Kaas RK4 stage
+//   rbd_bank.hpp (aba_bank_kernel, rnea_bank_kernel) and rbd_chain.hpp (aba_chain_kernel): the other lane mappings
+// Mapping here: one lane per (state, body); level-synchronous sweeps; parent/child exchange by DPP wave
+// shifts (first child) and ds_bpermute; per-body quantities stay in VGPRs (see rbd_device.hpp).
 #include "rbd_device.hpp"
 #include "rbd_internal.hpp"
 #include "rbd_hip.h"
