@@ -18,6 +18,7 @@ rng = np.random.default_rng(1)
 state = rbd.MechanismState(model, B, dtype=tdt); result = rbd.DynamicsResult(model, B, dtype=tdt)
 rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng)); rbd.set_velocity_(state, rbd.rand_velocity(model, B, rng))
 tau = torch.rand(B, model.nv, dtype=tdt, device="cuda"); out = torch.zeros_like(tau)
+Abuf = torch.zeros(B, 6 * model.nv, dtype=tdt, device="cuda")
 ops = {
     "dynamics! (ABA)": lambda: rbd.dynamics_(result, state, tau),
     "dynamics! (CRBA+Cholesky route)": lambda: rbd.dynamics_(result, state, tau, algorithm="crba"),
@@ -26,6 +27,10 @@ ops = {
     "mass_matrix!": lambda: rbd.mass_matrix_(result, state),
     "mass_matrix! + Cholesky solve": lambda: rbd.mass_matrix_solve_(out, state, tau, result.massmatrix),
     "M^-1 rhs via the articulated-body solve": lambda: rbd.mass_matrix_solve_(out, state, tau, algorithm="aba"),
+    "momentum_matrix!": lambda: rbd.momentum_matrix_(Abuf, state),
+    "geometric_jacobian! (root -> last body)": lambda: rbd.geometric_jacobian_(Abuf, state, -1, model.n_bodies - 1),
+    "center_of_mass": lambda: rbd.center_of_mass(state),
+    "kinetic_energy": lambda: rbd.kinetic_energy(state),
 }
 res = {}
 for name, f in ops.items():
