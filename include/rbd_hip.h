@@ -208,6 +208,11 @@ int rbd_mk_stage(rbd_ws_t* ws, int32_t B, int32_t stage, double dt, void* q, voi
 int rbd_kinematics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* momentum_matrix, void* com, void* energy,
                    const rbd_opts_t* opts);
 
+/* momentum(state) and momentum_rate_bias(state), root frame — src/mechanism_state.jl:878-884, :975-987.  out: 12×B per state =
+ * (momentum: angular 3, linear 3; momentum_rate_bias: torque 3, force 3).  d/dt momentum = momentum_matrix·v̇ + momentum_rate_bias.
+ * Device pointers. */
+int rbd_momentum(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* out, const rbd_opts_t* opts);
+
 /* geometric_jacobian!(jac, state, path(mechanism, base, target)) in the root frame — src/mechanism_algorithms.jl:80-99, :126-131.
  * base_body / target_body: body indices of the flat model, -1 = the root body.  jac: 6×nv column-major per state, (angular; linear);
  * columns off the path are written as zeros.  Device pointers. */

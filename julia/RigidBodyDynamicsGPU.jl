@@ -235,7 +235,7 @@ end
 
 # ---- kinematics by-products of the same forward-kinematics pass (device or host buffers as above) --------------------------------
 # momentum_matrix!(out, state) mechanism_algorithms.jl:313-327, center_of_mass :28-50, kinetic_energy / gravitational_potential_energy
-# mechanism_state.jl:886-903 -> rbd_kinematics;  geometric_jacobian!(out, state, path) :80-99 -> rbd_geometric_jacobian (base / target
+# mechanism_state.jl:886-903 -> rbd_kinematics;  momentum / momentum_rate_bias :975-987 -> rbd_momentum (12 × B);  geometric_jacobian!(out, state, path) :80-99 -> rbd_geometric_jacobian (base / target
 # body indices as in FlatModelHandle, -1 = root body);  x = M \ rhs as in dynamics_solve! :764/:819 -> rbd_mass_matrix_solve;  the dense
 # potrf!/potrs! step alone -> rbd_cholesky_solve.  They take device pointers (RBD_MEM_DEVICE), i.e. ROCArrays from AMDGPU.jl:
 #

@@ -190,3 +190,16 @@ def body_kinematics(model, q, v, vdot, dtype=np.float64):
     for b in range(B):
         assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(v[b], ct), _ptr(vdot[b], ct), _ptr(H[b], ct), _ptr(T[b], ct), _ptr(A[b], ct)) == 0
     return H, T, A
+
+
+def momentum(model, q, v, dtype=np.float64):
+    """(momentum [B, 6], momentum_rate_bias [B, 6]) in the root frame."""
+    sfx, ct = _sfx(dtype)
+    f = getattr(lib(), "rbdo_momentum" + sfx)
+    f.restype = ctypes.c_int
+    B = q.shape[0]
+    q, v = np.ascontiguousarray(q, dtype), np.ascontiguousarray(v, dtype)
+    h, hb = np.zeros((B, 6), dtype), np.zeros((B, 6), dtype)
+    for b in range(B):
+        assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(v[b], ct), _ptr(h[b], ct), _ptr(hb[b], ct)) == 0
+    return h, hb

@@ -918,6 +918,30 @@ int FN(rbdo_geometric_jacobian)(const rbd_flat_model_t* m, const REAL* q, const 
   return RBD_OK;
 }
 
+/* momentum(state) and momentum_rate_bias(state), root frame: src/mechanism_state.jl:878-884, :975-987 —
+ * h = sum_b I_b T_b ;  hdot_bias = sum_b newton_euler(I_b, bias_acceleration_b, T_b) with the bias accelerations wrt world WITHOUT
+ * gravity (update_bias_accelerations_wrt_world!).  The rate of change of momentum is then momentum_matrix * vdot + hdot_bias
+ * (test/test_mechanism_algorithms.jl:719).                                                                                      */
+int FN(rbdo_momentum)(const rbd_flat_model_t* m, const REAL* q, const REAL* v, REAL* h, REAL* hdot_bias) {
+  CACHE c;
+  if (FN(cache_alloc)(m, &c)) return RBD_ERR_OUT_OF_MEMORY;
+  FN(update_transforms)(m, q, &c);
+  FN(update_motion_subspaces)(m, q, &c);
+  FN(update_twists)(m, v, &c);
+  FN(update_inertias)(m, &c);
+  FN(accelerations)(m, NULL, &c);
+  for (int j = 0; j < 6; ++j) { h[j] = 0; hdot_bias[j] = 0; }
+  for (int i = 0; i < c.nb; ++i) {
+    REAL hb[6], ab[6], w[6];
+    FN(mul_inertia)(&c.I[i], c.T + 6 * i, hb);
+    for (int j = 0; j < 6; ++j) ab[j] = c.A[6 * i + j] - (j >= 3 ? -(REAL)m->gravity[j - 3] : (REAL)0);  /* c.A carries -g from the root */
+    FN(newton_euler)(&c.I[i], ab, c.T + 6 * i, w);
+    for (int j = 0; j < 6; ++j) { h[j] += hb[j]; hdot_bias[j] += w[j]; }
+  }
+  FN(cache_free)(&c);
+  return RBD_OK;
+}
+
 /* spatial_accelerations!(result, state) with result.v̇ = vd (src/mechanism_algorithms.jl:387-417), then
  * relative_acceleration(result, body, root_body) (src/dynamics_result.jl accessor): the root's fictitious -gravity is subtracted,
  * so acc[6*i .. 6*i+5] is the true spatial acceleration of body i in the root frame.  Also returns transforms_to_root

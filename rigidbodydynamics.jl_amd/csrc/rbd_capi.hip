@@ -993,4 +993,20 @@ int rbd_geometric_jacobian(rbd_ws_t* w, int32_t B, const void* q, int32_t base_b
   return RBD_OK;
 }
 
+
+int rbd_momentum(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* out12, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if (!q || !v || !out12 || o.memory != RBD_MEM_DEVICE) return RBD_ERR_INVALID_ARGUMENT;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const rbd_model* m = w->model;
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), L12 = layout_of(o.layout, 12, B);
+  Timed t(w);
+  if (w->dtype == RBD_F64) HIP_TRY(launch_momentum<double>(w->dm, B, q, v, out12, Lq, Lv, L12, w->stream));
+  else HIP_TRY(launch_momentum<float>(w->dm, B, q, v, out12, Lq, Lv, L12, w->stream));
+  return RBD_OK;
+}
+
 }  // extern "C"

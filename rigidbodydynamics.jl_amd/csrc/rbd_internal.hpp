@@ -52,3 +52,7 @@ hipError_t launch_rnea_bank(const BankModel& M, long B, int ncol, const void* q,
 namespace rbd {
 template <typename T> hipError_t configure_kernels(int chain_G, size_t chain_lds_bytes);
 }
+namespace rbd {
+template <typename T>
+hipError_t launch_momentum(const DevModel& M, long B, const void* q, const void* v, void* mom, Layout Lq, Layout Lv, Layout L12, hipStream_t s);
+}

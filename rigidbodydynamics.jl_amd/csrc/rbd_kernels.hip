@@ -858,6 +858,43 @@ template <typename T> RBD_DEV T group_sum(T x, int lps) {  // sum over the lanes
   return x;
 }
 
+// momentum(state), momentum_rate_bias(state) in the root frame (src/mechanism_state.jl:878-884, :975-987): mom_out [12 x B] =
+// (sum_b I_b T_b ; sum_b I_b a_bias_b + T_b x* I_b T_b) with the bias accelerations of update_bias_accelerations_wrt_world!
+template <typename T>
+__global__ __launch_bounds__(256) void momentum_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v, T* __restrict__ mom_out,
+                                                       Layout Lq, Layout Lv, Layout L12) {
+  Body<T> b;
+  load_body(M, B, b);
+  const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
+  T qj[7], vj[6];
+  load_joint_q(b, q, Lq, qj);
+  load_joint_v(b, v, Lv, vj);
+  T XR[9], Xp[3], R[9], p[3], tl[6], Tw[6], vJ[6], acc[6];
+  const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  local_transform(b, rb, qj, XR, Xp);
+  local_joint_motion(b, rb, vj, tl);
+  sweep_kinematics<T, true>(M, b, XR, Xp, R, p, tl, Tw, vJ, zero6, acc);  // joint accelerations 0: bias accelerations (+ the root's -g)
+  acc[3] += T(M.gravity[0]); acc[4] += T(M.gravity[1]); acc[5] += T(M.gravity[2]);  // every body carries the root term exactly once
+  RInertia<T> I;
+  T Jb[6], mc[3], h[6], Ia[6], x[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Jb[k] = rb[RB_J + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) mc[k] = rb[RB_MC + k];
+  inertia_to_root(Jb, mc, rb[RB_M], R, p, I);
+  mul_inertia(I, Tw, h);
+  mul_inertia(I, acc, Ia);
+  momentum_cross(I, Tw, x);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const T hs = group_sum(b.valid ? h[k] : T(0), M.lps), ws = group_sum(b.valid ? Ia[k] + x[k] : T(0), M.lps);
+    if (b.valid && b.sub == 0) {
+      mom_out[(long)k * L12.sk + b.state * L12.sb] = hs;
+      mom_out[(long)(6 + k) * L12.sk + b.state * L12.sb] = ws;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void kin_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v, T* __restrict__ A_out,
                                                   T* __restrict__ com_out, T* __restrict__ energy_out, T* __restrict__ J_out, uint64_t jplus,
@@ -972,6 +1009,13 @@ hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, v
                      jminus, Lq, Lv, La, L3, L2);
   return hipGetLastError();
 }
+template <typename T>
+hipError_t launch_momentum(const DevModel& M, long B, const void* q, const void* v, void* mom, Layout Lq, Layout Lv, Layout L12, hipStream_t s) {
+  hipLaunchKernelGGL(momentum_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (T*)mom, Lq, Lv, L12);
+  return hipGetLastError();
+}
+template hipError_t launch_momentum<double>(const DevModel&, long, const void*, const void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_momentum<float>(const DevModel&, long, const void*, const void*, void*, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_kin<double>(const DevModel&, long, const void*, const void*, void*, void*, void*, void*, uint64_t, uint64_t, Layout, Layout, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_kin<float>(const DevModel&, long, const void*, const void*, void*, void*, void*, void*, uint64_t, uint64_t, Layout, Layout, Layout, Layout, Layout, hipStream_t);
 

@@ -443,3 +443,21 @@ def geometric_jacobian_(out: torch.Tensor, state: MechanismState, base: int, bod
     _raise(_capi.lib().rbd_geometric_jacobian(state.ws.handle, state.batch, _ptr(state.q), int(base), int(body), _ptr(out), ctypes.byref(opts)),
            "rbd_geometric_jacobian")
     return out
+
+
+def _momentum(state: MechanismState) -> torch.Tensor:
+    out = state._zeros(12)
+    state.ws.use_current_stream()
+    opts = state._opts()
+    _raise(_capi.lib().rbd_momentum(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(out), ctypes.byref(opts)), "rbd_momentum")
+    return out if state.layout == "aos" else out.t()
+
+
+def momentum(state: MechanismState) -> torch.Tensor:
+    """`momentum(state)` in the root frame (src/mechanism_state.jl:975-980): (B, 6) = (angular; linear)."""
+    return _momentum(state)[:, :6]
+
+
+def momentum_rate_bias(state: MechanismState) -> torch.Tensor:
+    """`momentum_rate_bias(state)` (src/mechanism_state.jl:982-987): (B, 6) wrench (torque; force); d/dt momentum = A v̇ + this."""
+    return _momentum(state)[:, 6:]

@@ -818,3 +818,22 @@ def test_maximal_coordinates_loop_dynamics(rbd, oracle):
     lam = host(result.lambda_, state)
     r1 = np.einsum("bij,bj->bi", Ms, got) + host(result.dynamicsbias, state) + np.einsum("bcv,bc->bv", K, lam) - tau
     assert np.abs(r1).max() <= 1e-8 * max(1.0, np.abs(tau).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", MODELS)
+def test_momentum_and_rate_bias_f64(rbd, oracle, models, name, layout):
+    """momentum(state), momentum_rate_bias(state) (src/mechanism_state.jl:975-987) against the oracle; and momentum = A v."""
+    model = models[name]
+    B = 41
+    state, q, v, _, _ = make(rbd, model, B, "f64", layout, 95)
+    h, hb = rbd.momentum(state), rbd.momentum_rate_bias(state)
+    torch.cuda.synchronize()
+    h_ref, hb_ref = oracle.momentum(model, q, v)
+    assert np.abs(h.cpu().numpy() - h_ref).max() <= 1e-11 * max(1.0, np.abs(h_ref).max())
+    assert np.abs(hb.cpu().numpy() - hb_ref).max() <= 1e-10 * max(1.0, np.abs(hb_ref).max())
+    A = torch.zeros((B, 6 * model.nv) if layout == "aos" else (6 * model.nv, B), dtype=torch.float64, device="cuda")
+    rbd.momentum_matrix_(A, state)
+    Av = np.einsum("bkn,bn->bk", host(A, state).reshape(B, model.nv, 6).transpose(0, 2, 1), v)
+    assert np.abs(Av - h.cpu().numpy()).max() <= 1e-11 * max(1.0, np.abs(Av).max())

@@ -281,8 +281,7 @@ def rand_floating_tree(rbd, seed):
 def test_inverse_dynamics_external_wrenches_momentum_rate(rbd, oracle, models, name):
     """test/test_mechanism_algorithms.jl:707-727: for a mechanism on a floating joint, the floating joint's wrench (its rows of
     inverse_dynamics, moved to the root frame) + gravity + the external wrenches is the rate of change of the total momentum
-    A(q) v.  Ties inverse_dynamics! with wrenches, momentum_matrix!, center_of_mass and the transforms together.  The momentum
-    rate is a central difference along (q̇, v̇) here (the reference uses momentum_rate_bias)."""
+    A(q) v.  Ties inverse_dynamics! with wrenches, momentum_matrix!, momentum_rate_bias, center_of_mass and the transforms together."""
     model = rand_floating_tree(rbd, 39) if name == "rand_floating_tree" else models[name]
     assert int(model.joint_type[0]) == 3 and list(model.parent).count(-1) == 1  # one body on the world, through the QuaternionFloating joint
     B = 3
@@ -297,9 +296,15 @@ def test_inverse_dynamics_external_wrenches_momentum_rate(rbd, oracle, models, n
     mg = float(np.sum(model.inertia_mass)) * np.asarray(model.gravity, float)
     total += np.concatenate([np.cross(com, mg[None, :]), np.tile(mg, (B, 1))], axis=1)
     total += fe.reshape(B, model.n_bodies, 6).sum(axis=1)
+    # the reference's own formula (:719): ḣ = Wrench(momentum_matrix, v̇) + momentum_rate_bias, atol 1e-10
+    A, hsum, _ = oracle.momentum_matrix(model, q, v)
+    hmom, hbias = oracle.momentum(model, q, v)
+    assert np.abs(hmom - hsum).max() <= 1e-12 * max(1.0, np.abs(hsum).max())  # momentum(state) = Σ I_b T_b = A v (:527-545)
+    hdot = np.einsum("bkn,bn->bk", A, vd) + hbias
+    assert np.abs(total - hdot).max() <= 1e-10 * max(1.0, np.abs(hdot).max())
+    # and the rate really is the time derivative of the momentum along (q̇, v̇) (central difference)
     _, qd = oracle.dynamics(model, q, v, want_qdot=True)
     h = 1e-6
     _, hp, _ = oracle.momentum_matrix(model, q + h * qd, v + h * vd)
     _, hm, _ = oracle.momentum_matrix(model, q - h * qd, v - h * vd)
-    hdot = (hp - hm) / (2 * h)
-    assert np.abs(total - hdot).max() <= 1e-6 * max(1.0, np.abs(hdot).max())
+    assert np.abs((hp - hm) / (2 * h) - hdot).max() <= 1e-6 * max(1.0, np.abs(hdot).max())
