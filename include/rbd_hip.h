@@ -201,7 +201,7 @@ int rbd_simulate(rbd_ws_t* ws, int32_t B, void* q, void* v, const void* tau, con
                  const rbd_opts_t* opts);
 int rbd_mk_stage(rbd_ws_t* ws, int32_t B, int32_t stage, double dt, void* q, void* v, const void* vdot_prev, const rbd_opts_t* opts);
 
-/* ---- kinematics by-products of the same forward-kinematics pass (device pointers; every output nullable) ---------------
+/* ---- kinematics by-products of the same forward-kinematics pass (every output nullable; opts->memory as for rbd_dynamics) ---------------
  * momentum_matrix: 6×nv column-major per state, root frame, (angular; linear) — momentum_matrix!(out, state)
  *   src/mechanism_algorithms.jl:313-327;  com: 3×B — center_of_mass(state) :28-50;  energy: 2×B = (kinetic_energy,
  *   gravitational_potential_energy) src/mechanism_state.jl:886-903 (needs v).                                          */
@@ -210,12 +210,12 @@ int rbd_kinematics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* 
 
 /* momentum(state) and momentum_rate_bias(state), root frame — src/mechanism_state.jl:878-884, :975-987.  out: 12×B per state =
  * (momentum: angular 3, linear 3; momentum_rate_bias: torque 3, force 3).  d/dt momentum = momentum_matrix·v̇ + momentum_rate_bias.
- * Device pointers. */
+*/
 int rbd_momentum(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* out, const rbd_opts_t* opts);
 
 /* geometric_jacobian!(jac, state, path(mechanism, base, target)) in the root frame — src/mechanism_algorithms.jl:80-99, :126-131.
  * base_body / target_body: body indices of the flat model, -1 = the root body.  jac: 6×nv column-major per state, (angular; linear);
- * columns off the path are written as zeros.  Device pointers. */
+ * columns off the path are written as zeros. */
 int rbd_geometric_jacobian(rbd_ws_t* ws, int32_t B, const void* q, int32_t base_body, int32_t target_body, void* jac, const rbd_opts_t* opts);
 
 /* ---- diagnostics ------------------------------------------------------------ */

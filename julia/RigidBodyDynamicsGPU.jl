@@ -79,6 +79,7 @@ mutable struct FlatModelHandle
     handle::Ptr{Cvoid}
     modcount::Int
     nq::Int; nv::Int; nc::Int; nb::Int
+    bodyindex::Dict{RigidBody, Int32}   # body -> index in the flat model (-1 = root body)
 end
 
 function FlatModelHandle(mechanism::Mechanism)
@@ -116,7 +117,7 @@ function FlatModelHandle(mechanism::Mechanism)
         check(ccall((:rbd_model_create, librbd_hip[]), Cint, (Ref{RbdFlatModel}, Ref{Ptr{Cvoid}}), desc, handle), "rbd_model_create")
     end
     m = FlatModelHandle(handle[], modcount(mechanism), num_positions(mechanism), num_velocities(mechanism),
-        sum(num_constraints, non_tree_joints(mechanism); init = 0), nb)
+        sum(num_constraints, non_tree_joints(mechanism); init = 0), nb, Dict{RigidBody, Int32}(bodyindex))
     finalizer(x -> ccall((:rbd_model_destroy, librbd_hip[]), Cint, (Ptr{Cvoid},), x.handle), m)
     m
 end
@@ -233,15 +234,56 @@ function RigidBodyDynamics.simulate(state::BatchedMechanismState{T}, final_time;
 end
 
 
-# ---- kinematics by-products of the same forward-kinematics pass (device or host buffers as above) --------------------------------
-# momentum_matrix!(out, state) mechanism_algorithms.jl:313-327, center_of_mass :28-50, kinetic_energy / gravitational_potential_energy
-# mechanism_state.jl:886-903 -> rbd_kinematics;  momentum / momentum_rate_bias :975-987 -> rbd_momentum (12 × B);  geometric_jacobian!(out, state, path) :80-99 -> rbd_geometric_jacobian (base / target
-# body indices as in FlatModelHandle, -1 = root body);  x = M \ rhs as in dynamics_solve! :764/:819 -> rbd_mass_matrix_solve;  the dense
-# potrf!/potrs! step alone -> rbd_cholesky_solve.  They take device pointers (RBD_MEM_DEVICE), i.e. ROCArrays from AMDGPU.jl:
-#
-#   ccall((:rbd_kinematics, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
-#         state.ws, B, q, v, A #= 6nv × B or C_NULL =#, com #= 3 × B =#, energy #= 2 × B =#, opts(memory = MEM_DEVICE))
-#   ccall((:rbd_geometric_jacobian, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Int32, Int32, Ptr{T}, Ref{RbdOpts}),
-#         state.ws, B, q, base, target, J #= 6nv × B =#, opts(memory = MEM_DEVICE))
+# ---- kinematics by-products of the same forward-kinematics pass (root frame; host buffers like the methods above) ---------------
+# momentum_matrix!(out, state) mechanism_algorithms.jl:313-327: out is 6 × nv × B
+function momentum_matrix!(out::Array{T, 3}, state::BatchedMechanismState{T}) where {T}
+    checkmodcount(state)
+    B = size(state.q, 2)
+    size(out) == (6, state.model.nv, B) || throw(DimensionMismatch())
+    check(ccall((:rbd_kinematics, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+        state.ws, B, state.q, state.v, out, C_NULL, C_NULL, opts()), "rbd_kinematics")
+    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+    out
+end
+
+# center_of_mass(state) :28-50 -> 3 × B;  kinetic_energy / gravitational_potential_energy mechanism_state.jl:886-903 -> B each
+function center_of_mass(state::BatchedMechanismState{T}) where {T}
+    B = size(state.q, 2); com = Matrix{T}(undef, 3, B)
+    check(ccall((:rbd_kinematics, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+        state.ws, B, state.q, state.v, C_NULL, com, C_NULL, opts()), "rbd_kinematics")
+    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+    com
+end
+function energies(state::BatchedMechanismState{T}) where {T}   # row 1: kinetic_energy, row 2: gravitational_potential_energy
+    B = size(state.q, 2); e = Matrix{T}(undef, 2, B)
+    check(ccall((:rbd_kinematics, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+        state.ws, B, state.q, state.v, C_NULL, C_NULL, e, opts()), "rbd_kinematics")
+    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+    e
+end
+kinetic_energy(state::BatchedMechanismState) = energies(state)[1, :]
+gravitational_potential_energy(state::BatchedMechanismState) = energies(state)[2, :]
+
+# momentum(state), momentum_rate_bias(state) mechanism_state.jl:975-987 -> 6 × B each
+function momenta(state::BatchedMechanismState{T}) where {T}
+    B = size(state.q, 2); out = Matrix{T}(undef, 12, B)
+    check(ccall((:rbd_momentum, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}), state.ws, B, state.q, state.v, out, opts()),
+        "rbd_momentum")
+    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+    out
+end
+momentum(state::BatchedMechanismState) = momenta(state)[1:6, :]
+momentum_rate_bias(state::BatchedMechanismState) = momenta(state)[7:12, :]
+
+# geometric_jacobian!(out, state, path) :80-99 in the root frame; the path is given by its end bodies (path(mechanism, base, body))
+function geometric_jacobian!(out::Array{T, 3}, state::BatchedMechanismState{T}, base::RigidBody, body::RigidBody) where {T}
+    checkmodcount(state)
+    B = size(state.q, 2)
+    size(out) == (6, state.model.nv, B) || throw(DimensionMismatch())
+    check(ccall((:rbd_geometric_jacobian, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Int32, Int32, Ptr{T}, Ref{RbdOpts}),
+        state.ws, B, state.q, state.model.bodyindex[base], state.model.bodyindex[body], out, opts()), "rbd_geometric_jacobian")
+    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+    out
+end
 
 end # module

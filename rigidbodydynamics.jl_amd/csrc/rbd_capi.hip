@@ -955,15 +955,31 @@ int rbd_kinematics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* m
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
-  if (!q || o.memory != RBD_MEM_DEVICE || (energy && !v)) return RBD_ERR_INVALID_ARGUMENT;
+  if (!q || (energy && !v)) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   const rbd_model* m = w->model;
+  const size_t es = esize(w);
+  const void *dq = q, *dv = v;
+  void *dA = momentum_matrix, *dcom = com, *den = energy;
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_in(w, 1, v, es * m->nv * B, &dv)) ||
+        (st = stage_out_alloc(w, 4, momentum_matrix, es * 6 * m->nv * B, &dA)) || (st = stage_out_alloc(w, 5, com, es * 3 * B, &dcom)) ||
+        (st = stage_out_alloc(w, 6, energy, es * 2 * B, &den)))
+      return st;
+  }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), La = layout_of(o.layout, 6L * m->nv, B);
   const Layout L3 = layout_of(o.layout, 3, B), L2 = layout_of(o.layout, 2, B);
-  Timed t(w);
-  if (w->dtype == RBD_F64) HIP_TRY(launch_kin<double>(w->dm, B, q, v, momentum_matrix, com, energy, nullptr, 0, 0, Lq, Lv, La, L3, L2, w->stream));
-  else HIP_TRY(launch_kin<float>(w->dm, B, q, v, momentum_matrix, com, energy, nullptr, 0, 0, Lq, Lv, La, L3, L2, w->stream));
+  {
+    Timed t(w);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_kin<double>(w->dm, B, dq, dv, dA, dcom, den, nullptr, 0, 0, Lq, Lv, La, L3, L2, w->stream));
+    else HIP_TRY(launch_kin<float>(w->dm, B, dq, dv, dA, dcom, den, nullptr, 0, 0, Lq, Lv, La, L3, L2, w->stream));
+  }
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_out_copy(w, momentum_matrix, dA, es * 6 * m->nv * B)) || (st = stage_out_copy(w, com, dcom, es * 3 * B)) ||
+        (st = stage_out_copy(w, energy, den, es * 2 * B)))
+      return st;
+  }
   return RBD_OK;
 }
 
@@ -972,7 +988,7 @@ int rbd_geometric_jacobian(rbd_ws_t* w, int32_t B, const void* q, int32_t base_b
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
-  if (!q || !jac || o.memory != RBD_MEM_DEVICE) return RBD_ERR_INVALID_ARGUMENT;
+  if (!q || !jac) return RBD_ERR_INVALID_ARGUMENT;
   const rbd_model* m = w->model;
   if (base_body < -1 || base_body >= m->nb || target_body < -1 || target_body >= m->nb) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0) return RBD_OK;
@@ -987,9 +1003,18 @@ int rbd_geometric_jacobian(rbd_ws_t* w, int32_t B, const void* q, int32_t base_b
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), La = layout_of(o.layout, 6L * m->nv, B);
   const Layout L3 = layout_of(o.layout, 3, B), L2 = layout_of(o.layout, 2, B);
-  Timed t(w);
-  if (w->dtype == RBD_F64) HIP_TRY(launch_kin<double>(w->dm, B, q, nullptr, nullptr, nullptr, nullptr, jac, plus, minus, Lq, Lv, La, L3, L2, w->stream));
-  else HIP_TRY(launch_kin<float>(w->dm, B, q, nullptr, nullptr, nullptr, nullptr, jac, plus, minus, Lq, Lv, La, L3, L2, w->stream));
+  const size_t es = esize(w);
+  const void* dq = q;
+  void* dJ = jac;
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_out_alloc(w, 4, jac, es * 6 * m->nv * B, &dJ))) return st;
+  }
+  {
+    Timed t(w);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_kin<double>(w->dm, B, dq, nullptr, nullptr, nullptr, nullptr, dJ, plus, minus, Lq, Lv, La, L3, L2, w->stream));
+    else HIP_TRY(launch_kin<float>(w->dm, B, dq, nullptr, nullptr, nullptr, nullptr, dJ, plus, minus, Lq, Lv, La, L3, L2, w->stream));
+  }
+  if (o.memory == RBD_MEM_HOST) return stage_out_copy(w, jac, dJ, es * 6 * m->nv * B);
   return RBD_OK;
 }
 
@@ -998,14 +1023,25 @@ int rbd_momentum(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* out
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
-  if (!q || !v || !out12 || o.memory != RBD_MEM_DEVICE) return RBD_ERR_INVALID_ARGUMENT;
+  if (!q || !v || !out12) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   const rbd_model* m = w->model;
+  const size_t es = esize(w);
+  const void *dq = q, *dv = v;
+  void* dout = out12;
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_in(w, 1, v, es * m->nv * B, &dv)) ||
+        (st = stage_out_alloc(w, 4, out12, es * 12 * B, &dout)))
+      return st;
+  }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), L12 = layout_of(o.layout, 12, B);
-  Timed t(w);
-  if (w->dtype == RBD_F64) HIP_TRY(launch_momentum<double>(w->dm, B, q, v, out12, Lq, Lv, L12, w->stream));
-  else HIP_TRY(launch_momentum<float>(w->dm, B, q, v, out12, Lq, Lv, L12, w->stream));
+  {
+    Timed t(w);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_momentum<double>(w->dm, B, dq, dv, dout, Lq, Lv, L12, w->stream));
+    else HIP_TRY(launch_momentum<float>(w->dm, B, dq, dv, dout, Lq, Lv, L12, w->stream));
+  }
+  if (o.memory == RBD_MEM_HOST) return stage_out_copy(w, out12, dout, es * 12 * B);
   return RBD_OK;
 }
 

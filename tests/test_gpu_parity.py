@@ -376,6 +376,20 @@ def test_c_abi_host_memory_mode(rbd, oracle, models):
     il = np.tril_indices(model.nv)
     got = Mh.reshape(B, model.nv, model.nv).transpose(0, 2, 1)
     assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= 1e-10 * np.abs(Mr).max()
+    # kinematics by-products through host buffers
+    A, com, en, mom, J = (np.zeros((B, 6 * model.nv)), np.zeros((B, 3)), np.zeros((B, 2)), np.zeros((B, 12)), np.zeros((B, 6 * model.nv)))
+    assert L.rbd_kinematics(ws, B, P(q), P(v), P(A), P(com), P(en), ctypes.byref(opts)) == 0
+    assert L.rbd_momentum(ws, B, P(q), P(v), P(mom), ctypes.byref(opts)) == 0
+    assert L.rbd_geometric_jacobian(ws, B, P(q), -1, model.n_bodies - 1, P(J), ctypes.byref(opts)) == 0
+    assert L.rbd_sync(ws) == 0
+    A_ref, h_ref, com_ref = oracle.momentum_matrix(model, q, v)
+    ke_ref, pe_ref = oracle.energy(model, q, v)
+    J_ref, _ = oracle.geometric_jacobian(model, q, -1, model.n_bodies - 1)
+    assert np.abs(A.reshape(B, model.nv, 6).transpose(0, 2, 1) - A_ref).max() <= 1e-11 * np.abs(A_ref).max()
+    assert np.abs(com - com_ref).max() <= 1e-12 and np.abs(en[:, 0] - ke_ref).max() <= 1e-11 * np.abs(ke_ref).max()
+    assert np.abs(en[:, 1] - pe_ref).max() <= 1e-11 * np.abs(pe_ref).max()
+    assert np.abs(mom[:, :6] - h_ref).max() <= 1e-11 * np.abs(h_ref).max()
+    assert np.abs(J.reshape(B, model.nv, 6).transpose(0, 2, 1) - J_ref).max() <= 1e-12
     # B = 0 is a no-op; B > max_batch is a DimensionMismatch; null q is an ArgumentError
     assert L.rbd_dynamics(ws, 0, P(q), P(v), None, None, P(vd), None, None, ctypes.byref(opts)) == 0
     assert L.rbd_dynamics(ws, B + 1, P(q), P(v), None, None, P(vd), None, None, ctypes.byref(opts)) == 2
