@@ -172,8 +172,10 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     load_joint_v(c.b, tau, Lv, c.tj);
   };
   auto setup = [&](BankRegs<T>& c, T* qj, T* vj, T* XR, T* Xp, T* tl) {
-    if (F.stage >= 0)  // `simulate` fusion: this launch is stage F.stage of a Munthe-Kaas RK4 step (see aba_kernel)
+    if (F.stage >= 0) {  // `simulate` fusion: this launch is stage F.stage of a Munthe-Kaas RK4 step (see aba_kernel)
+      if (F.close_prev) mk_stage_lane(c.b, 4, (T)F.dt, qj, vj, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
       mk_stage_lane(c.b, F.stage, (T)F.dt, qj, vj, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
+    }
     store_qdot(c.b, qdot, Lq, qj, vj);
     local_transform(c.b, c.rb, qj, XR, Xp);
     local_joint_motion(c.b, c.rb, vj, tl);

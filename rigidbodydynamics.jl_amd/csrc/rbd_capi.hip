@@ -913,13 +913,16 @@ int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, cons
   const Layout Lf = layout_of(o.layout, 6L * m->nb, B);
   for (int step = 0; fused && step < nsteps; ++step) {
     // tree mechanism, articulated-body route: each of the four stages is ONE launch (stage bookkeeping fused into aba_kernel)
+    // (the closing stage of a step rides in the first launch of the next one; only the last step needs its own closing launch)
     for (int stage = 0; stage < 4; ++stage) {
       MkFuse F{};
-      F.stage = stage; F.dt = dt; F.W = w->mk; F.q_state = dq; F.v_state = dv;
+      F.stage = stage; F.close_prev = (stage == 0 && step > 0) ? 1 : 0; F.dt = dt; F.W = w->mk; F.q_state = dq; F.v_state = dv;
       if ((st = run_aba(w, B, RBD_ALGO_ABA, dq, dv, dtau, df, nullptr, nullptr, Lq, Lv, Lf, nullptr, &F))) return st;
     }
-    if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, 4, dt, dq, dv, nullptr, w->mk, Lq, Lv, w->stream));
-    else HIP_TRY(launch_mk_stage<float>(w->dm, B, 4, dt, dq, dv, nullptr, w->mk, Lq, Lv, w->stream));
+    if (step == nsteps - 1) {
+      if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, 4, dt, dq, dv, nullptr, w->mk, Lq, Lv, w->stream));
+      else HIP_TRY(launch_mk_stage<float>(w->dm, B, 4, dt, dq, dv, nullptr, w->mk, Lq, Lv, w->stream));
+    }
   }
   for (int step = 0; !fused && step < nsteps; ++step) {
     for (int stage = 0; stage <= 4; ++stage) {

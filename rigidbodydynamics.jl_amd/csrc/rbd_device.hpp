@@ -103,6 +103,7 @@ struct MkBuffers {
 
 struct MkFuse {
   int32_t stage;  // 0..3, or -1
+  int32_t close_prev;  // with stage 0: first close the PREVIOUS step (stage 4: combine its four stages into the new q, v) — saves a launch per step
   double dt;
   MkBuffers W;
   void* q_state; void* v_state;

@@ -336,7 +336,9 @@ void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict
   if (F.stage >= 0) {
     // `simulate` fusion: this launch is stage F.stage of a Munthe-Kaas RK4 step.  (q, v) hold the previous stage state: close
     // that stage (its v̇ is already in W.vd[stage-1]), form this stage's state in registers and in the state buffers, and
-    // evaluate the dynamics there; v̇ goes to W.vd[stage].
+    // evaluate the dynamics there; v̇ goes to W.vd[stage].  With close_prev (stage 0 of every step but the first) the previous
+    // step is closed first — its four stages combined into the new (q, v) — instead of by a launch of its own.
+    if (F.close_prev) mk_stage_lane(b, 4, (T)F.dt, qj, vj, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
     mk_stage_lane(b, F.stage, (T)F.dt, qj, vj, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
   }
   store_qdot(b, qdot, Lq, qj, vj);
