@@ -172,10 +172,6 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     load_joint_v(c.b, tau, Lv, c.tj);
   };
   auto setup = [&](BankRegs<T>& c, T* qj, T* vj, T* XR, T* Xp, T* tl) {
-    if (F.stage >= 0) {  // `simulate` fusion: this launch is stage F.stage of a Munthe-Kaas RK4 step (see aba_kernel)
-      if (F.close_prev) mk_stage_lane(c.b, 4, (T)F.dt, qj, vj, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
-      mk_stage_lane(c.b, F.stage, (T)F.dt, qj, vj, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
-    }
     store_qdot(c.b, qdot, Lq, qj, vj);
     local_transform(c.b, c.rb, qj, XR, Xp);
     local_joint_motion(c.b, c.rb, vj, tl);
@@ -227,6 +223,17 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
   T qj0[7], vj0[6], qj1[7], vj1[6];
   fetch(0, r0, qj0, vj0);
   fetch(1, r1, qj1, vj1);
+  if (F.stage >= 0) {
+    // `simulate` fusion: this launch is stage F.stage of a Munthe-Kaas RK4 step (see aba_kernel).  Both banks' stage bookkeeping
+    // runs here, back to back, so that their loads of the integrator buffers share one round trip and bank 1's hide behind the
+    // SE(3) log/exp of bank 0's floating joint.
+    if (F.close_prev) {
+      mk_stage_lane(r0.b, 4, (T)F.dt, qj0, vj0, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
+      mk_stage_lane(r1.b, 4, (T)F.dt, qj1, vj1, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
+    }
+    mk_stage_lane(r0.b, F.stage, (T)F.dt, qj0, vj0, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
+    mk_stage_lane(r1.b, F.stage, (T)F.dt, qj1, vj1, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
+  }
   {
     T XR[9], Xp[3], tl[6];
     setup(r0, qj0, vj0, XR, Xp, tl);

@@ -71,30 +71,37 @@ template <typename T> RBD_DEV void joint_local_rate(int t, const T* q0, const T*
       for (int k = 0; k < 3; ++k) o[k] += f * c2[k];
     }
   } else if (t == RBD_JOINT_QUAT_FLOATING) {
-    // relative transform inv(T0) T, then log_with_time_derivative with the body twist (ω, v)
+    // relative transform inv(T0) T, then log_with_time_derivative with the body twist (ω, v).  This branch sits on the critical path
+    // of the fused `simulate` launches (one lane per state runs it while the wavefront waits), so it spends one atan2, two
+    // square roots and three reciprocals: sin/cos of θ/2 are the relative quaternion's own (normalised) parts, θ is not
+    // re-derived from ψ, and every division by θ, θ², θ⁴, sin(θ/2) is a multiplication by a reciprocal formed once.
     const T q0c[4] = {q0[0], -q0[1], -q0[2], -q0[3]};
     T dq[4], d[3], dp[3], psi[3];
     quat_mul(q0c, q, dq);
 #pragma unroll
     for (int k = 0; k < 3; ++k) d[k] = q[4 + k] - q0[4 + k];
     quat_rotate(q0c, d, dp);
-    rotvec_from_quat(dq, psi);
-    const T th = norm3(psi);
+    const T sv = norm3(dq + 1);                      // |vector part| = |dq| sin(θ/2)
+    const T th = 2 * atan2_t(sv, dq[0]);             // rotation angle (RotationVec(quat))
+    const T kq = sv < eps_t<T>() ? T(2) : th * rcp_nr(sv);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) psi[k] = kq * dq[1 + k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = v[k];
     if (th > eps_t<T>()) {
-      T s2, c2;
-      sincos_t(th / 2, &s2, &c2);
-      const T alpha = (th / 2) * c2 / s2;
+      const T inorm = rcp_nr(SqrtT<T>::f(dq[0] * dq[0] + sv * sv));
+      const T s2 = sv * inorm, c2 = dq[0] * inorm;   // sin(θ/2), cos(θ/2)
+      const T is2 = rcp_nr(s2), ith2 = rcp_nr(th * th), h = th / 2;
+      const T alpha = h * c2 * is2;
       T x1[3], x2[3], qv[3];
       cross3(psi, dp, x1);
       cross3(psi, x1, x2);
-      const T th2 = th * th;
+      const T ca = (1 - alpha) * ith2;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) qv[k] = dp[k] - x1[k] / 2 + (1 - alpha) / th2 * x2[k];
-      const T beta = (th / 2) * (th / 2) / (s2 * s2);
-      const T A = (2 * (1 - alpha) + (alpha - beta) / 2) / th2;
-      const T Bc = ((1 - alpha) + (alpha - beta) / 2) / (th2 * th2);
+      for (int k = 0; k < 3; ++k) qv[k] = dp[k] - x1[k] / 2 + ca * x2[k];
+      const T beta = h * h * is2 * is2;
+      const T A = (2 * (1 - alpha) + (alpha - beta) / 2) * ith2;
+      const T Bc = ((1 - alpha) + (alpha - beta) / 2) * ith2 * ith2;
       T X[6], a1[6], a2[6], a3[6], a4[6];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { X[k] = psi[k]; X[3 + k] = qv[k]; }
@@ -128,15 +135,20 @@ template <typename T> RBD_DEV void joint_global(int t, const T* q0, const T* phi
     quat_mul(q0, dq, q);
   } else if (t == RBD_JOINT_QUAT_FLOATING) {
     T dq[4], tr[3], w[3];
-    quat_from_rotvec(phi, dq);
     const T th = norm3(phi);
     if (th < eps_t<T>()) {
+      dq[0] = T(1); dq[1] = phi[0] / 2; dq[2] = phi[1] / 2; dq[3] = phi[2] / 2;  // quat_from_rotvec in the small-angle branch
 #pragma unroll
       for (int k = 0; k < 3; ++k) tr[k] = phi[3 + k];
-    } else {  // exp(::Twist), spatialmotion.jl:311-332 (2.36)
+    } else {  // exp(::Twist), spatialmotion.jl:311-332 (2.36); one reciprocal of θ serves the quaternion, ω/θ and v/θ
+      const T ith = rcp_nr(th);
+      T sh, ch;
+      sincos_t(th / 2, &sh, &ch);
+      const T kq = sh * ith;
+      dq[0] = ch; dq[1] = kq * phi[0]; dq[2] = kq * phi[1]; dq[3] = kq * phi[2];
       T om[3], vv[3], c[3], Rc[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { om[k] = phi[k] / th; vv[k] = phi[3 + k] / th; }
+      for (int k = 0; k < 3; ++k) { om[k] = phi[k] * ith; vv[k] = phi[3 + k] * ith; }
       cross3(om, vv, c);
       quat_rotate(dq, c, Rc);
       const T d = (om[0] * vv[0] + om[1] * vv[1] + om[2] * vv[2]) * th;

@@ -13,8 +13,11 @@ model = flatio.load_flat_model(os.path.join(os.path.dirname(__file__), "..", "te
 state = rbd.MechanismState(model, B, dtype=dt)
 rbd.rand_(state, seed=1)
 res = rbd.DynamicsResult(model, B, dtype=dt)
-for _ in range(20):
-    rbd.dynamics_(res, state, algorithm="aba_banks")
+if len(sys.argv) > 3 and sys.argv[3] == "simulate":  # timeline of the last fused launch of a simulate run (stage 3 of the last step)
+    rbd.simulate_(state, 0.0195, dt=1e-3)
+else:
+    for _ in range(20):
+        rbd.dynamics_(res, state, algorithm="aba_banks")
 torch.cuda.synchronize()
 L = _capi.lib()
 buf = (ctypes.c_longlong * 16)()
