@@ -206,12 +206,11 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     sym6_from_inertia(I, Io);
     momentum_cross(I, c.Tw, po);
     load_body_wrench(c.b, fext, Lf, fe);
-    const T keep = c.b.valid ? T(1) : T(0);  // idle lanes carry zeros (their values may be shifted into masked-off neighbours)
+    // idle lanes carry zeros (their values may be shifted into masked-off neighbours)
 #pragma unroll
     for (int i = 0; i < 21; ++i) c.IA[i] = (accumulate ? c.IA[i] : T(0)) + (c.b.valid ? Io[i] : T(0));
 #pragma unroll
     for (int i = 0; i < 6; ++i) c.pA[i] = (accumulate ? c.pA[i] : T(0)) + (c.b.valid ? po[i] - fe[i] : T(0));
-    (void)keep;
 #pragma unroll
     for (int i = 0; i < 6; ++i) c.U[i] = T(0);
     c.Dinv = T(0);
