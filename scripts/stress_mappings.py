@@ -46,4 +46,27 @@ for trial in range(N):
         err = np.abs(out.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())
         worst["rnea_" + mp] = max(worst.get("rnea_" + mp, 0.0), err)
         assert err < 1e-9, (trial, mp, n, B, err)
+    # kinematics by-products on the same tree
+    A = torch.zeros(B, 6 * model.nv, dtype=torch.float64, device="cuda")
+    rbd.momentum_matrix_(A, state)
+    A_ref, h_ref, com_ref = oracle.momentum_matrix(model, q, v)
+    err = np.abs(A.cpu().numpy().reshape(B, model.nv, 6).transpose(0, 2, 1) - A_ref).max() / max(1.0, np.abs(A_ref).max())
+    worst["momentum_matrix"] = max(worst.get("momentum_matrix", 0.0), err)
+    assert err < 1e-10, (trial, "momentum_matrix", err)
+    hb_ref = oracle.momentum(model, q, v)[1]
+    err = np.abs(rbd.momentum_rate_bias(state).cpu().numpy() - hb_ref).max() / max(1.0, np.abs(hb_ref).max())
+    worst["momentum_rate_bias"] = max(worst.get("momentum_rate_bias", 0.0), err)
+    assert err < 1e-9, (trial, "momentum_rate_bias", err)
+    base, body = (int(x) for x in r2.choice(np.arange(-1, model.n_bodies), 2, replace=model.n_bodies < 1))
+    rbd.geometric_jacobian_(A, state, base, body)
+    J_ref, _ = oracle.geometric_jacobian(model, q, base, body)
+    err = np.abs(A.cpu().numpy().reshape(B, model.nv, 6).transpose(0, 2, 1) - J_ref).max()
+    assert err < 1e-11, (trial, "jacobian", err)
+    # mass matrix (lower triangle) and fp32 ABA backward error
+    rbd.mass_matrix_(res, state)
+    M_ref = oracle.mass_matrix(model, q)
+    Mg = res.massmatrix.cpu().numpy().reshape(B, model.nv, model.nv).transpose(0, 2, 1)
+    err = np.abs(np.tril(Mg) - np.tril(M_ref)).max() / max(1.0, np.abs(M_ref).max())
+    worst["mass_matrix"] = max(worst.get("mass_matrix", 0.0), err)
+    assert err < 1e-10, (trial, "mass_matrix", err)
 print(f"{N} random trees ok; worst relative errors {worst}; out of scope: {skipped}")
