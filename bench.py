@@ -249,7 +249,7 @@ def main():
         except Exception as e:  # never lose the headline line to the extra measurement
             out["pipelined_independent_batches"] = f"failed: {type(e).__name__}: {e}"
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only (rank 0 of a multi-GPU run would time it while its peers wait)
         # host threads actually available to this process: affinity mask, capped by the cgroup CPU quota when there is one
         ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         try:
