@@ -141,6 +141,10 @@ int rbd_model_destroy(rbd_model_t* model);
 /* Introspection of the chain-scheduled ABA plan (RBD_ALGO_ABA_CHAINS): tracks (lanes) per state, steps per pass, LDS fields
  * per state, and the steps×tracks table of reference body indices (-1 = idle).  RBD_ERR_UNSUPPORTED when the mechanism is
  * outside that mapping's scope.  Host-only, no device needed. */
+/* ... and of the two-bodies-per-lane ("banked") mapping: lanes per state, the level at which bank 1 starts, bodies per bank, and whether
+ * the banked ABA (not only the banked RNEA) takes the mechanism.  RBD_ERR_UNSUPPORTED when the split would not save lanes. */
+int rbd_model_bank_plan(const rbd_model_t* model, int32_t* lanes, int32_t* first_level_of_bank1, int32_t* bodies_bank0, int32_t* bodies_bank1,
+                        int32_t* aba_in_scope);
 int rbd_model_chain_plan(const rbd_model_t* model, int32_t* tracks, int32_t* steps, int32_t* lds_fields, int32_t* table, int32_t capacity);
 int rbd_model_dims(const rbd_model_t* model, int32_t* n_bodies, int32_t* nq, int32_t* nv, int32_t* nc);
 

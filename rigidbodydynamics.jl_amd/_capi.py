@@ -19,7 +19,7 @@ SYMBOLS = (
     "rbd_model_create", "rbd_model_destroy", "rbd_model_dims", "rbd_workspace_create", "rbd_workspace_destroy",
     "rbd_workspace_set_stream", "rbd_sync", "rbd_dynamics", "rbd_inverse_dynamics", "rbd_dynamics_bias", "rbd_mass_matrix",
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
-    "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum",
+    "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan",
 )
 
 
@@ -66,6 +66,7 @@ def lib():
         L.rbd_workspace_last_kernel.restype = ctypes.c_char_p
         L.rbd_geometric_jacobian.argtypes = [vp, i32, vp, i32, i32, vp, ctypes.POINTER(Opts)]
         L.rbd_momentum.argtypes = [vp, i32, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_model_bank_plan.argtypes = [vp] + [ctypes.POINTER(i32)] * 5
         L.rbd_kinematics.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_simulate.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.c_double, i32, ctypes.POINTER(Opts)]
         L.rbd_mk_stage.argtypes = [vp, i32, i32, ctypes.c_double, vp, vp, vp, ctypes.POINTER(Opts)]

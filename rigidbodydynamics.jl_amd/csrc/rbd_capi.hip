@@ -333,6 +333,18 @@ int rbd_model_destroy(rbd_model_t* m) {
   return RBD_OK;
 }
 
+int rbd_model_bank_plan(const rbd_model_t* m, int32_t* lanes, int32_t* first_level_of_bank1, int32_t* bodies_bank0, int32_t* bodies_bank1,
+                        int32_t* aba_in_scope) {
+  if (!m) return RBD_ERR_INVALID_ARGUMENT;
+  if (m->bank_lps <= 0) return RBD_ERR_UNSUPPORTED;  // two bodies per lane would not pack more states into a wavefront
+  if (lanes) *lanes = m->bank_lps;
+  if (first_level_of_bank1) *first_level_of_bank1 = m->bank_L0;
+  if (bodies_bank0) *bodies_bank0 = m->bank_nb[0];
+  if (bodies_bank1) *bodies_bank1 = m->bank_nb[1];
+  if (aba_in_scope) *aba_in_scope = m->bank_aba_ok;
+  return RBD_OK;
+}
+
 int rbd_model_chain_plan(const rbd_model_t* m, int32_t* tracks, int32_t* steps, int32_t* lds_fields, int32_t* table, int32_t capacity) {
   if (!m) return RBD_ERR_INVALID_ARGUMENT;
   if (!m->chain.ok) return RBD_ERR_UNSUPPORTED;

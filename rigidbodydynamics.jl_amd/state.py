@@ -461,3 +461,20 @@ def momentum(state: MechanismState) -> torch.Tensor:
 def momentum_rate_bias(state: MechanismState) -> torch.Tensor:
     """`momentum_rate_bias(state)` (src/mechanism_state.jl:982-987): (B, 6) wrench (torque; force); d/dt momentum = A v̇ + this."""
     return _momentum(state)[:, 6:]
+
+
+def bank_plan(flat):
+    """The two-bodies-per-lane plan of a mechanism (`rbd_model_bank_plan`): dict(lanes, L0, bodies=(n0, n1), aba) or None when the split
+    would not pack more states into a wavefront.  Host-only."""
+    L = _capi.lib()
+    h = ctypes.c_void_p()
+    _raise(L.rbd_model_create(ctypes.cast(ctypes.byref(flat.c_struct()), ctypes.c_void_p), ctypes.byref(h)), "rbd_model_create")
+    try:
+        v = [ctypes.c_int32() for _ in range(5)]
+        st = L.rbd_model_bank_plan(h, *[ctypes.byref(x) for x in v])
+        if st == 3:
+            return None
+        _raise(st, "rbd_model_bank_plan")
+        return {"lanes": v[0].value, "L0": v[1].value, "bodies": (v[2].value, v[3].value), "aba": bool(v[4].value)}
+    finally:
+        L.rbd_model_destroy(h)

@@ -74,3 +74,23 @@ def test_chain_plan_random_trees(rbd):
         plan = rbd.chain_plan(flat)
         assert plan is not None
         check_plan(flat, plan)
+
+
+def test_bank_plan(rbd, models):
+    """Two bodies per lane: Atlas splits at level 5 into 15 + 16 bodies on 16 lanes (4 states per wavefront instead of 2)."""
+    plan = rbd.bank_plan(models["atlas_floating"])
+    assert plan == {"lanes": 16, "L0": 5, "bodies": (15, 16), "aba": True}
+    assert rbd.bank_plan(models["randmech1"])["aba"] is False  # 3-dof joints: banked RNEA only
+    rng = np.random.default_rng(6)
+    for trial in range(30):
+        flat = rbd.flatten(random_tree(rbd, rng, int(rng.integers(1, 40)), bool(trial % 2), float(rng.uniform(0, 1))))
+        plan = rbd.bank_plan(flat)
+        lps = 1
+        while lps < flat.n_bodies:
+            lps <<= 1
+        if plan is None:
+            continue
+        lv = flat.levels()
+        n0, n1 = int((lv < plan["L0"]).sum()), int((lv >= plan["L0"]).sum())
+        assert plan["bodies"] == (n0, n1) and n0 + n1 == flat.n_bodies
+        assert max(n0, n1) <= plan["lanes"] < lps  # fits, and saves lanes over one body per lane
