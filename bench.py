@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[1]): Atlas v5 URDF with floating base (nq 37, nv 36, 31 bodies; the reference's
 perf/runbenchmarks.jl:14-19 mechanism, from the vendored test/urdf/atlas.urdf), batch = 4096 states per GPU, fp64,
 random (q, v, τ) drawn with the reference's distributions.  One *step* = one `dynamics!` over the whole batch
-(one aba_kernel launch); inputs are resident in HBM before the timed region.  N > 1: one process per GPU, the
+(one ABA kernel launch — aba_bank_kernel at this batch); inputs are resident in HBM before the timed region.  N > 1: one process per GPU, the
 batch is sharded (weak scaling: 4096 states per GPU), no data-path collective; the RCCL all-gather of v̇ is run
 once after the timed region (and inside it with --gather-every-step).
 
@@ -22,6 +22,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+# Kernel arguments in device memory: with them in host memory every wavefront's first scalar loads cross PCIe and a 24 µs launch
+# becomes 28 µs (measured).  It is this image's default; set explicitly so the number does not depend on it.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
