@@ -851,3 +851,25 @@ def test_momentum_and_rate_bias_f64(rbd, oracle, models, name, layout):
     rbd.momentum_matrix_(A, state)
     Av = np.einsum("bkn,bn->bk", host(A, state).reshape(B, model.nv, 6).transpose(0, 2, 1), v)
     assert np.abs(Av - h.cpu().numpy()).max() <= 1e-11 * max(1.0, np.abs(Av).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "valkyrie_floating"])
+def test_simulate_banked_fused_path_matches_oracle(rbd, oracle, models, name, monkeypatch):
+    """`simulate` through the two-bodies-per-lane kernel with the integrator stage fused in (what large batches run): forced at a
+    small batch with RBD_BANK_MIN_BATCH so that every state can be compared with the numpy restatement of the Munthe-Kaas step."""
+    import simulate_np
+    monkeypatch.setenv("RBD_BANK_MIN_BATCH", "1")  # read when the workspace is created
+    model = models[name]
+    B, dt, T = 5, 1e-3, 0.0045  # 5 steps: first (stage 0 alone), middle ones (previous step closed inside stage 0), closing launch
+    q, v, tau, _ = rand_inputs(rbd, model, B, 97, fext=True)
+    state = rbd.MechanismState(model, B)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    rbd.simulate_(state, T, dt=dt, torques=dev(tau, state))
+    from rigidbodydynamics_jl_amd import _capi
+    assert _capi.lib().rbd_workspace_last_kernel(state.ws.handle) == b"aba_bank_kernel"
+    _, q_ref, v_ref = simulate_np.simulate(model, q, v, T, dt, tau)
+    qg, vg = host(state.q, state), host(state.v, state)
+    assert np.abs(canon_q(model, qg) - canon_q(model, q_ref)).max() <= 1e-11 * max(1.0, np.abs(q_ref).max())
+    assert np.abs(vg - v_ref).max() <= 1e-9 * max(1.0, np.abs(v_ref).max())
