@@ -18,7 +18,7 @@ from __future__ import annotations
 import ctypes
 import itertools
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional
 
 import numpy as np
 

@@ -1,11 +1,10 @@
 """Throughput of every hot-path entry point (not the headline line — bench.py is): evals/s and µs per launch, graph-replayed so
 the GPU is the bottleneck.  usage: python scripts/bench_ops.py [--batch 4096] [--dtype f64] [--model atlas_floating]"""
-import argparse, ctypes, json, os, sys
+import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
 import rbd_amd as rbd
-from rigidbodydynamics_jl_amd import _capi
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--dtype", default="f64"); ap.add_argument("--model", default="atlas_floating")

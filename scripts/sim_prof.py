@@ -1,6 +1,6 @@
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import numpy as np, torch, time
+import torch, time
 import rbd_amd as rbd
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
