@@ -540,6 +540,9 @@ Layout layout_of(int layout, long n, long B) {
   return L;
 }
 
+// a buffer with n scalars per state may only be missing when n == 0 (a mechanism whose tree joints are all Fixed has nq = nv = 0)
+inline bool missing(const void* p, long n) { return p == nullptr && n > 0; }
+
 struct Opts { int layout, memory, algorithm, stabilization; };
 Opts read_opts(const rbd_opts_t* o) {
   Opts r{RBD_LAYOUT_SOA, RBD_MEM_DEVICE, RBD_ALGO_ABA, 1};
@@ -707,8 +710,8 @@ int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const voi
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
-  if (!q || !v || !vdot) return RBD_ERR_INVALID_ARGUMENT;
   const rbd_model* m = w->model;
+  if (missing(q, m->nq) || missing(v, m->nv) || missing(vdot, m->nv)) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   const size_t es = esize(w);
@@ -735,8 +738,8 @@ static int rnea_common(rbd_ws_t* w, int32_t B, const void* q, const void* v, con
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
-  if (!q || !v || !tau_out) return RBD_ERR_INVALID_ARGUMENT;
   const rbd_model* m = w->model;
+  if (missing(q, m->nq) || missing(v, m->nv) || missing(tau_out, m->nv)) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   const size_t es = esize(w);
@@ -770,7 +773,7 @@ static int rnea_common(rbd_ws_t* w, int32_t B, const void* q, const void* v, con
 int rbd_inverse_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* vdot, const void* fext, void* tau_out,
                          const rbd_opts_t* opts) {
   if (w && w->model->nloops > 0) return RBD_ERR_HAS_LOOPS;  // src/mechanism_algorithms.jl:549
-  if (!vdot) return RBD_ERR_INVALID_ARGUMENT;
+  if (!vdot && w && w->model->nv > 0) return RBD_ERR_INVALID_ARGUMENT;
   return rnea_common(w, B, q, v, vdot, fext, tau_out, opts);
 }
 
@@ -782,8 +785,8 @@ int rbd_mass_matrix(rbd_ws_t* w, int32_t B, const void* q, void* M_out, const rb
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
-  if (!q || !M_out) return RBD_ERR_INVALID_ARGUMENT;
   const rbd_model* m = w->model;
+  if (missing(q, m->nq) || missing(M_out, m->nv)) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   const size_t es = esize(w);
@@ -807,8 +810,8 @@ int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
-  if (!q || !rhs || !x) return RBD_ERR_INVALID_ARGUMENT;
   const rbd_model* m = w->model;
+  if (missing(q, m->nq) || missing(rhs, m->nv) || missing(x, m->nv)) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   const size_t es = esize(w);
@@ -970,10 +973,10 @@ int rbd_kinematics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* m
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
-  if (!q || (energy && !v)) return RBD_ERR_INVALID_ARGUMENT;
+  const rbd_model* m = w->model;
+  if (missing(q, m->nq) || (energy && missing(v, m->nv))) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
-  const rbd_model* m = w->model;
   const size_t es = esize(w);
   const void *dq = q, *dv = v;
   void *dA = momentum_matrix, *dcom = com, *den = energy;
@@ -1003,8 +1006,8 @@ int rbd_geometric_jacobian(rbd_ws_t* w, int32_t B, const void* q, int32_t base_b
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
-  if (!q || !jac) return RBD_ERR_INVALID_ARGUMENT;
   const rbd_model* m = w->model;
+  if (missing(q, m->nq) || missing(jac, m->nv)) return RBD_ERR_INVALID_ARGUMENT;
   if (base_body < -1 || base_body >= m->nb || target_body < -1 || target_body >= m->nb) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
@@ -1038,10 +1041,10 @@ int rbd_momentum(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* out
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
-  if (!q || !v || !out12) return RBD_ERR_INVALID_ARGUMENT;
+  const rbd_model* m = w->model;
+  if (missing(q, m->nq) || missing(v, m->nv) || !out12) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
-  const rbd_model* m = w->model;
   const size_t es = esize(w);
   const void *dq = q, *dv = v;
   void* dout = out12;

@@ -13,6 +13,8 @@ for trial in range(N):
     n = int(rng.integers(1, 45))
     mech = random_tree(rbd, rng, n, bool(rng.integers(2)), float(rng.uniform(0, 1)))
     model = rbd.flatten(mech)
+    if model.nv == 0:  # all joints Fixed: nothing to compare (tests/test_gpu_parity.py::test_mechanism_without_degrees_of_freedom)
+        continue
     B = int(rng.integers(1, 70))
     r2 = np.random.default_rng(trial)
     q, v = rbd.rand_configuration(model, B, r2), rbd.rand_velocity(model, B, r2)
@@ -31,6 +33,7 @@ for trial in range(N):
         try:
             rbd.dynamics_(res, state, t, f, algorithm=algo)
         except Exception:
+            assert algo != "aba_lanes", (trial, n, B)  # the one-body-per-lane mapping takes every tree
             skipped[algo] += 1
             continue
         err = np.abs(res.vd.cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())

@@ -873,3 +873,23 @@ def test_simulate_banked_fused_path_matches_oracle(rbd, oracle, models, name, mo
     qg, vg = host(state.q, state), host(state.v, state)
     assert np.abs(canon_q(model, qg) - canon_q(model, q_ref)).max() <= 1e-11 * max(1.0, np.abs(q_ref).max())
     assert np.abs(vg - v_ref).max() <= 1e-9 * max(1.0, np.abs(v_ref).max())
+
+
+@pytest.mark.gpu
+def test_mechanism_without_degrees_of_freedom(rbd, oracle):
+    """All tree joints Fixed: nq = nv = 0 — every entry point is a no-op on empty buffers, as with the reference's empty vectors."""
+    rng = np.random.default_rng(3)
+    model = rbd.flatten(rbd.rand_tree_mechanism(rng, ["Fixed"] * 3))
+    assert (model.nq, model.nv) == (0, 0)
+    B = 5
+    state = rbd.MechanismState(model, B)
+    result = rbd.DynamicsResult(model, B)
+    rbd.dynamics_(result, state)
+    out = torch.zeros((B, 0), dtype=torch.float64, device="cuda")
+    rbd.inverse_dynamics_(out, state, out)
+    rbd.dynamics_bias_(out, state)
+    torch.cuda.synchronize()
+    assert result.vd.shape == (B, 0)
+    com = rbd.center_of_mass(state)
+    _, _, com_ref = oracle.momentum_matrix(model, np.zeros((B, 0)), np.zeros((B, 0)))
+    assert np.abs(com.cpu().numpy() - com_ref).max() <= 1e-13
