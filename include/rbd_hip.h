@@ -94,7 +94,8 @@ typedef struct rbd_loop_joint {
   double pred_trans[3];
   double succ_rot[9];       /* joint_to_successor:  frame_after  -> successor body frame, row-major R   */
   double succ_trans[3];
-  double rotation_from_z_aligned[9]; /* Revolute.rotation_from_z_aligned, src/joint_types/revolute.jl:12-17 */
+  double rotation_from_z_aligned[9]; /* Revolute / Prismatic: rotation_from_z_aligned, src/joint_types/revolute.jl:12-17;
+                                        Planar: the matrix with columns (x_axis, y_axis, x_axis × y_axis), planar.jl:22-35 */
   double gains[4];          /* Baumgarte SE3PDGains: angular k, d; linear k, d (default 100,20,100,20:
                                src/mechanism_algorithms.jl:610-612); all zero = stabilization off */
 } rbd_loop_joint_t;

@@ -102,7 +102,9 @@ function FlatModelHandle(mechanism::Mechanism)
     loops = RbdLoopJoint[]
     for j in non_tree_joints(mechanism)
         jt = joint_type(j)
-        Rz = jt isa Union{Revolute, Prismatic} ? rowmajor(jt.rotation_from_z_aligned) : rowmajor(Matrix(1.0I, 3, 3))
+        Rz = jt isa Union{Revolute, Prismatic} ? rowmajor(jt.rotation_from_z_aligned) :
+             jt isa Planar ? rowmajor(hcat(jt.x_axis, jt.y_axis, jt.rot_axis)) :      # columns (x, y, x × y): include/rbd_hip.h
+             rowmajor(Matrix(1.0I, 3, 3))
         push!(loops, RbdLoopJoint(bodyindex[predecessor(j, mechanism)], bodyindex[successor(j, mechanism)], jointtag(jt), 0,
             jointaxis(jt), Tuple(rowmajor(rotation(joint_to_predecessor(j)))), Tuple(Float64.(translation(joint_to_predecessor(j)))),
             Tuple(rowmajor(rotation(joint_to_successor(j)))), Tuple(Float64.(translation(joint_to_successor(j)))),

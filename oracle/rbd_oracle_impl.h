@@ -566,6 +566,9 @@ static int FN(constraint_basis)(const rbd_loop_joint_t* lj, REAL* Tl /* 6 x nc, 
     case RBD_JOINT_QUAT_SPHERICAL: /* quaternion_spherical.jl:50-55 */
       for (int c = 0; c < 3; ++c) Tl[6 * c + 3 + c] = 1;
       return nc;
+    case RBD_JOINT_PLANAR: /* planar.jl:96-101: (0; rot_axis), (x_axis; 0), (y_axis; 0); the columns of R are (x_axis, y_axis, x × y) */
+      for (int r = 0; r < 3; ++r) { Tl[6 * 0 + 3 + r] = (REAL)R[3 * r + 2]; Tl[6 * 1 + r] = (REAL)R[3 * r + 0]; Tl[6 * 2 + r] = (REAL)R[3 * r + 1]; }
+      return nc;
     case RBD_JOINT_QUAT_FLOATING: return 0;
     default: return -1;
   }

@@ -255,8 +255,10 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
       for (int c = 0; c < 6; ++c) Tl[6 * c + c] = 1;
     } else if (lj.joint_type == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl:50-55: angular 0, linear identity
       for (int c = 0; c < 3; ++c) Tl[6 * c + 3 + c] = 1;
+    } else if (lj.joint_type == RBD_JOINT_PLANAR) {  // planar.jl:96-101: (0; rot_axis), (x_axis; 0), (y_axis; 0); R columns = (x, y, x × y)
+      for (int r = 0; r < 3; ++r) { Tl[0 + 3 + r] = R[3 * r + 2]; Tl[6 + r] = R[3 * r]; Tl[12 + r] = R[3 * r + 1]; }
     } else if (lj.joint_type != RBD_JOINT_QUAT_FLOATING) {
-      delete m; return RBD_ERR_UNSUPPORTED;  // Planar loop joints carry no axes in rbd_loop_joint_t yet
+      delete m; return RBD_ERR_UNSUPPORTED;
     }
     const int path_begin = (int)m->loop_path.size() / 2;
     int a = lj.predecessor, b = lj.successor;  // TreePath(pred, succ): src/graphs/tree_path.jl:41-63

@@ -175,7 +175,8 @@ def QuaternionSpherical() -> JointType:  # quaternion_spherical.jl
 def Planar(x_axis, y_axis) -> JointType:  # planar.jl:22-35
     x, y = _normalized(x_axis), _normalized(y_axis)
     assert abs(x @ y) < 1e-12
-    return JointType(JOINT_PLANAR, 3, 3, x, y)
+    # as a loop joint its constraint wrench basis needs both axes: carried in `rotation_from_z_aligned` as the columns (x, y, x × y)
+    return JointType(JOINT_PLANAR, 3, 3, x, y, np.column_stack([x, y, np.cross(x, y)]))
 
 
 class Joint:

@@ -8,7 +8,7 @@ import rbd_amd as rbd, oracle
 from test_oracle_loops import maximal_state
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(99)
-TYPES = ["Revolute", "Prismatic", "Fixed", "QuaternionSpherical", "SinCosRevolute"]
+TYPES = ["Revolute", "Prismatic", "Fixed", "QuaternionSpherical", "SinCosRevolute", "Planar"]
 worst = {"vdot_vs_oracle": 0.0, "acc_vs_tree": 0.0}
 for trial in range(N):
     n = int(rng.integers(1, 9))

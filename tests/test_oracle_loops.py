@@ -117,7 +117,7 @@ def maximal_state(H, T):
     return q, v
 
 
-MC_JOINTS = ["QuaternionFloating"] + ["Revolute"] * 3 + ["Prismatic"] * 2 + ["Fixed"] + ["QuaternionSpherical"]  # loop-joint types the library takes
+MC_JOINTS = ["QuaternionFloating"] + ["Revolute"] * 2 + ["Prismatic"] + ["Fixed"] + ["QuaternionSpherical"] + ["Planar"] + ["SinCosRevolute"]  # as the reference test: every joint type
 
 
 @pytest.mark.parametrize("seed", [53, 54, 55])
