@@ -1598,38 +1598,65 @@ __global__ __launch_bounds__(64) void loop_solve_kernel(LoopView<T> V, long B, i
       for (int j = 0; j < nc; ++j) { T s = T(0); for (int k = 0; k < nv; ++k) s += Y[i * nv + k] * Y[j * nv + k]; A[i * nc + j] = s; }
       T s = kk[i]; for (int k = 0; k < nv; ++k) s += Y[i * nv + k] * z[k]; bv[i] = s;
     }
-    // cyclic Jacobi eigen-decomposition of the PSD Schur matrix
-    for (int i = 0; i < nc; ++i) for (int j = 0; j < nc; ++j) E[i * nc + j] = (i == j) ? T(1) : T(0);
+    // λ = A⁺ bv, the minimum-norm solution LAPACK's gelsy! returns for the (often rank-deficient) PSD Schur matrix A = Y Y'.
+    // The eigen-decomposition is done on the SMALLER Gram matrix: A itself (nc x nc) when nc <= nv, else G = Y'Y (nv x nv) —
+    // A and G share their non-zero eigenvalues s_j, A's eigenvectors are Y v_j / sqrt(s_j), so A⁺ bv = Y V diag(1/s²) V' Y' bv.
+    // (A four-bar linkage has nc = 5, nv = 3: 3 Jacobi rotations per sweep instead of 10.)
+    const bool gram = nv < nc;
+    const int n = gram ? nv : nc;
+    if (gram) {
+      for (int i = 0; i < nv; ++i)
+        for (int j = 0; j < nv; ++j) { T sacc = T(0); for (int c = 0; c < nc; ++c) sacc += Y[c * nv + i] * Y[c * nv + j]; A[i * n + j] = sacc; }
+    }
+    // cyclic Jacobi eigen-decomposition of the PSD matrix (n x n, in A; eigenvectors in the columns of E)
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) E[i * n + j] = (i == j) ? T(1) : T(0);
     const T tiny = sizeof(T) == 8 ? T(1e-34) : T(1e-16);
     for (int sweep = 0; sweep < 60; ++sweep) {
       T off = T(0), dg = T(0);
-      for (int i = 0; i < nc; ++i) { dg += A[i * nc + i] * A[i * nc + i]; for (int j = i + 1; j < nc; ++j) off += A[i * nc + j] * A[i * nc + j]; }
+      for (int i = 0; i < n; ++i) { dg += A[i * n + i] * A[i * n + i]; for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j]; }
       if (off <= dg * tiny) break;
-      for (int p = 0; p < nc - 1; ++p)
-        for (int q = p + 1; q < nc; ++q) {
-          const T apq = A[p * nc + q];
+      for (int p = 0; p < n - 1; ++p)
+        for (int q = p + 1; q < n; ++q) {
+          const T apq = A[p * n + q];
           if (apq == T(0)) continue;
-          const T theta = (A[q * nc + q] - A[p * nc + p]) / (2 * apq);
+          const T theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
           const T at = theta >= T(0) ? theta : -theta;
           const T t = (theta >= T(0) ? T(1) : T(-1)) / (at + SqrtT<T>::f(theta * theta + 1));
           const T c = 1 / SqrtT<T>::f(t * t + 1), sn = t * c;
-          for (int k = 0; k < nc; ++k) { const T a = A[k * nc + p], b2 = A[k * nc + q]; A[k * nc + p] = c * a - sn * b2; A[k * nc + q] = sn * a + c * b2; }
-          for (int k = 0; k < nc; ++k) { const T a = A[p * nc + k], b2 = A[q * nc + k]; A[p * nc + k] = c * a - sn * b2; A[q * nc + k] = sn * a + c * b2; }
-          for (int k = 0; k < nc; ++k) { const T a = E[k * nc + p], b2 = E[k * nc + q]; E[k * nc + p] = c * a - sn * b2; E[k * nc + q] = sn * a + c * b2; }
+          for (int k = 0; k < n; ++k) { const T a = A[k * n + p], b2 = A[k * n + q]; A[k * n + p] = c * a - sn * b2; A[k * n + q] = sn * a + c * b2; }
+          for (int k = 0; k < n; ++k) { const T a = A[p * n + k], b2 = A[q * n + k]; A[p * n + k] = c * a - sn * b2; A[q * n + k] = sn * a + c * b2; }
+          for (int k = 0; k < n; ++k) { const T a = E[k * n + p], b2 = E[k * n + q]; E[k * n + p] = c * a - sn * b2; E[k * n + q] = sn * a + c * b2; }
         }
     }
     T emax = T(0);
-    for (int i = 0; i < nc; ++i) if (A[i * nc + i] > emax) emax = A[i * nc + i];
-    for (int i = 0; i < nc; ++i) kk[i] = kk[i];  // (k kept for output below)
-    for (int i = 0; i < nc; ++i) Y[i] = T(0);    // reuse Y[0..nc) as lambda accumulator (Y no longer needed)
+    for (int i = 0; i < n; ++i) if (A[i * n + i] > emax) emax = A[i * n + i];
     const T rcond = sizeof(T) == 8 ? T(1e-10) : T(1e-6);
-    for (int e = 0; e < nc; ++e) {
-      const T ev = A[e * nc + e];
-      if (ev > rcond * emax) {
-        T d = T(0);
-        for (int i = 0; i < nc; ++i) d += E[i * nc + e] * bv[i];
-        d /= ev;
-        for (int i = 0; i < nc; ++i) Y[i] += E[i * nc + e] * d;
+    if (gram) {
+      // z = Y' bv (z itself is no longer needed), w = V diag(1/s²) V' z, λ = Y w
+      for (int i = 0; i < nv; ++i) { T sacc = T(0); for (int c = 0; c < nc; ++c) sacc += Y[c * nv + i] * bv[c]; z[i] = sacc; }
+      T* w = E + n * n;                           // E was sized nc*nc >= nv*nv + nv when nv < nc
+      for (int i = 0; i < nv; ++i) w[i] = T(0);
+      for (int e = 0; e < n; ++e) {
+        const T ev = A[e * n + e];
+        if (ev > rcond * emax) {
+          T d = T(0);
+          for (int i = 0; i < n; ++i) d += E[i * n + e] * z[i];
+          d /= ev * ev;
+          for (int i = 0; i < n; ++i) w[i] += E[i * n + e] * d;
+        }
+      }
+      for (int c = 0; c < nc; ++c) { T sacc = T(0); for (int i = 0; i < nv; ++i) sacc += Y[c * nv + i] * w[i]; bv[c] = sacc; }
+      for (int c = 0; c < nc; ++c) Y[c] = bv[c];  // λ where the common code below expects it
+    } else {
+      for (int i = 0; i < nc; ++i) Y[i] = T(0);    // reuse Y[0..nc) as lambda accumulator (Y no longer needed)
+      for (int e = 0; e < nc; ++e) {
+        const T ev = A[e * nc + e];
+        if (ev > rcond * emax) {
+          T d = T(0);
+          for (int i = 0; i < nc; ++i) d += E[i * nc + e] * bv[i];
+          d /= ev;
+          for (int i = 0; i < nc; ++i) Y[i] += E[i * nc + e] * d;
+        }
       }
     }
     for (int vi = 0; vi < nv; ++vi) { T s = T(0); for (int ci = 0; ci < nc; ++ci) s += K[ci * nv + vi] * Y[ci]; rhs[vi] -= s; }
@@ -1643,10 +1670,267 @@ __global__ __launch_bounds__(64) void loop_solve_kernel(LoopView<T> V, long B, i
   for (int i = 0; i < nv; ++i) vdot[(long)i * Lv.sk + st * Lv.sb] = rhs[i];
 }
 
+// The same solve for SMALL loop mechanisms (nv <= NV, nc <= NC; the four-bar linkage of BASELINE configs[4] has nv 3, nc 5): every matrix
+// is a fixed-size local array and every loop has a compile-time bound with an `i < nv` predicate, so the whole chain of dependent
+// small-matrix steps runs out of VGPRs instead of LDS/HBM work arrays.  Indices that are only known at run time (constraint row,
+// velocity column) are resolved by predicated writes over the compile-time range.
+template <typename T, int NV, int NC>
+__global__ __launch_bounds__(64) void loop_solve_small_kernel(LoopView<T> V, long B, int stabilize, const T* __restrict__ body, const T* __restrict__ Mg,
+                                                              const T* __restrict__ cg, const T* __restrict__ tau, T* __restrict__ vdot,
+                                                              T* __restrict__ lambda, T* __restrict__ Kg, T* __restrict__ kg, Layout Lm, Layout Lv,
+                                                              Layout Lc, Layout Lk, double g0, double g1, double g2, int* __restrict__ notpd) {
+  const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (st >= B) return;
+  const int nv = V.nv, nc = V.nc, nb = V.nb;
+  T L[NV][NV], K[NC][NV], Y[NC][NV], kk[NC], bv[NC], z[NV], rhs[NV], lam[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    kk[c] = T(0); bv[c] = T(0); lam[c] = T(0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { K[c][i] = T(0); Y[c][i] = T(0); }
+  }
+  const T* bd = body + st * nb * 24;
+  const T I3[9] = {T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1)};
+  const T Z3[3] = {T(0), T(0), T(0)};
+  for (int l = 0; l < V.nloops; ++l) {
+    const int32_t* li = V.li + 8 * l;
+    const T* lr = V.lr + 64 * l;
+    const int pred = li[0], succ = li[1], row0 = li[3], ncl = li[4];
+    const T* HpR = pred >= 0 ? bd + pred * 24 : I3; const T* Hpp = pred >= 0 ? bd + pred * 24 + 9 : Z3;
+    const T* HsR = succ >= 0 ? bd + succ * 24 : I3; const T* Hsp = succ >= 0 ? bd + succ * 24 + 9 : Z3;
+    T FbR[9], Fbp[3], FaR[9], Fap[3];
+    xf_compose(HpR, Hpp, lr, lr + 9, FbR, Fbp);
+    xf_compose(HsR, Hsp, lr + 12, lr + 21, FaR, Fap);
+    T Tw[6][6];
+#pragma unroll
+    for (int ci = 0; ci < 6; ++ci) {
+      const T zero6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+      xforce(FaR, Fap, ci < ncl ? lr + 28 + 6 * ci : zero6, Tw[ci]);
+    }
+    for (int e = li[5]; e < li[6]; ++e) {
+      const int bj = V.path[2 * e], sign = V.path[2 * e + 1];
+      const int t = V.jt[bj];
+      const int nvj = joint_nv(t);
+      const T* R = bd + bj * 24; const T* p = R + 9;
+      for (int col = 0; col < nvj; ++col) {
+        T sl[6], S[6];
+        subspace_col(t, V.axis + 3 * bj, V.axis2 + 3 * bj, col, sl);
+        xmotion(R, p, sl, S);
+        const int vi = V.voff[bj] + col;
+#pragma unroll
+        for (int ci = 0; ci < 6; ++ci) {
+          const T d = dot6(Tw[ci], S);
+          const T val = sign < 0 ? -d : d;
+#pragma unroll
+          for (int r = 0; r < NC; ++r)
+#pragma unroll
+            for (int cc = 0; cc < NV; ++cc)
+              if (ci < ncl && r == row0 + ci && cc == vi) K[r][cc] = val;
+        }
+      }
+    }
+    T Tp[6], Ts[6], Ap[6], As[6], cr[6], ba[6];
+    const T grav[6] = {T(0), T(0), T(0), T(-g0), T(-g1), T(-g2)};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      Tp[j] = pred >= 0 ? bd[pred * 24 + 12 + j] : T(0); Ts[j] = succ >= 0 ? bd[succ * 24 + 12 + j] : T(0);
+      Ap[j] = pred >= 0 ? bd[pred * 24 + 18 + j] - grav[j] : T(0); As[j] = succ >= 0 ? bd[succ * 24 + 18 + j] - grav[j] : T(0);
+    }
+    se3_comm(Ts, Tp, cr);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) ba[j] = cr[j] + (As[j] - Ap[j]);
+    if (stabilize) {
+      T TnR[9], d3[3], Tnp[3], jt[6], jl[6], stab[6], sw[6], Rtp[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) TnR[3 * i + j] = FbR[i] * FaR[j] + FbR[3 + i] * FaR[3 + j] + FbR[6 + i] * FaR[6 + j];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) d3[k] = Fap[k] - Fbp[k];
+      matTvec3(FbR, d3, Tnp);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) jt[j] = Ts[j] - Tp[j];
+      xmotion_inv(FaR, Fap, jt, jl);
+      const T psi[3] = {(TnR[7] - TnR[5]) / 2, (TnR[2] - TnR[6]) / 2, (TnR[3] - TnR[1]) / 2};
+      matTvec3(TnR, Tnp, Rtp);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { stab[i] = -lr[24] * psi[i] - lr[25] * jl[i]; stab[3 + i] = -lr[26] * Rtp[i] - lr[27] * jl[3 + i]; }
+      xmotion(FaR, Fap, stab, sw);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ba[j] -= sw[j];
+    }
+#pragma unroll
+    for (int ci = 0; ci < 6; ++ci) {
+      const T d = dot6(Tw[ci], ba);
+#pragma unroll
+      for (int r = 0; r < NC; ++r)
+        if (ci < ncl && r == row0 + ci) kk[r] = d;
+    }
+  }
+  // L = chol(M), identity-padded beyond nv so that the padded rows / columns are inert
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) L[j][i] = (i >= j && i < nv && j < nv) ? Mg[((long)j * nv + i) * Lm.sk + st * Lm.sb] : ((i == j) ? T(1) : T(0));
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    T d = L[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[k][j] * L[k][j];
+    if (!(d > T(0))) bad = true;
+    d = SqrtT<T>::f(d);
+    L[j][j] = d;
+    const T id = T(1) / d;
+#pragma unroll
+    for (int i = j + 1; i < NV; ++i) {
+      T s2 = L[j][i];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s2 -= L[k][i] * L[k][j];
+      L[j][i] = s2 * id;
+    }
+  }
+  if (bad) atomicOr(notpd, 1);
+  auto fwd = [&](T* x) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { T s2 = x[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) s2 -= L[k][i] * x[k];
+      x[i] = s2 / L[i][i]; }
+  };
+  auto bwd = [&](T* x) {
+#pragma unroll
+    for (int i = NV - 1; i >= 0; --i) { T s2 = x[i];
+#pragma unroll
+      for (int k = i + 1; k < NV; ++k) s2 -= L[i][k] * x[k];
+      x[i] = s2 / L[i][i]; }
+  };
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const T t = (tau && i < nv) ? tau[(long)i * Lv.sk + st * Lv.sb] : T(0);
+    z[i] = i < nv ? t - cg[(long)i * Lv.sk + st * Lv.sb] : T(0);
+    rhs[i] = z[i];
+  }
+  if (nc > 0) {
+    fwd(z);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) Y[c][k] = K[c][k];
+      fwd(Y[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      T s2 = kk[c];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) s2 += Y[c][k] * z[k];
+      bv[c] = s2;
+    }
+    // minimum-norm lambda through the eigen-decomposition of G = Y'Y (NV x NV; zero rows / columns beyond nv): A⁺ bv = Y V diag(1/s²) V' Y' bv
+    T G[NV][NV], E[NV][NV], t2[NV], w[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        T s2 = T(0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s2 += Y[c][i] * Y[c][j];
+        G[i][j] = s2;
+        E[i][j] = (i == j) ? T(1) : T(0);
+      }
+    const T tiny = sizeof(T) == 8 ? T(1e-34) : T(1e-16);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+      T off = T(0), dg = T(0);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        dg += G[i][i] * G[i][i];
+#pragma unroll
+        for (int j = i + 1; j < NV; ++j) off += G[i][j] * G[i][j];
+      }
+      if (off <= dg * tiny) break;
+#pragma unroll
+      for (int p = 0; p < NV - 1; ++p)
+#pragma unroll
+        for (int q = p + 1; q < NV; ++q) {
+          const T apq = G[p][q];
+          if (apq != T(0)) {
+            const T theta = (G[q][q] - G[p][p]) / (2 * apq);
+            const T at = theta >= T(0) ? theta : -theta;
+            const T t = (theta >= T(0) ? T(1) : T(-1)) / (at + SqrtT<T>::f(theta * theta + 1));
+            const T c = 1 / SqrtT<T>::f(t * t + 1), sn = t * c;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { const T a = G[k][p], b2 = G[k][q]; G[k][p] = c * a - sn * b2; G[k][q] = sn * a + c * b2; }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { const T a = G[p][k], b2 = G[q][k]; G[p][k] = c * a - sn * b2; G[q][k] = sn * a + c * b2; }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { const T a = E[k][p], b2 = E[k][q]; E[k][p] = c * a - sn * b2; E[k][q] = sn * a + c * b2; }
+          }
+        }
+    }
+    T emax = T(0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) if (G[i][i] > emax) emax = G[i][i];
+    const T rcond = sizeof(T) == 8 ? T(1e-10) : T(1e-6);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      T s2 = T(0);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) s2 += Y[c][i] * bv[c];
+      t2[i] = s2;
+      w[i] = T(0);
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const T ev = G[e][e];
+      if (ev > rcond * emax) {
+        T d = T(0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) d += E[i][e] * t2[i];
+        d /= ev * ev;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) w[i] += E[i][e] * d;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      T s2 = T(0);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) s2 += Y[c][i] * w[i];
+      lam[c] = s2;
+    }
+#pragma unroll
+    for (int vi = 0; vi < NV; ++vi) {
+      T s2 = T(0);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) s2 += K[c][vi] * lam[c];
+      rhs[vi] -= s2;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (c < nc) {
+        if (lambda) lambda[(long)c * Lc.sk + st * Lc.sb] = lam[c];
+        kg[(long)c * Lc.sk + st * Lc.sb] = kk[c];
+#pragma unroll
+        for (int vi = 0; vi < NV; ++vi)
+          if (vi < nv) Kg[((long)vi * nc + c) * Lk.sk + st * Lk.sb] = K[c][vi];
+      }
+    }
+  }
+  fwd(rhs); bwd(rhs);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (i < nv) vdot[(long)i * Lv.sk + st * Lv.sb] = rhs[i];
+}
+
 template <typename T>
 hipError_t launch_loop_solve(const LoopView<T>& V, long B, int stabilize, const void* body, const void* M, const void* c, const void* tau, void* vdot,
                              void* lambda, void* K, void* k, void* scratch, long scratch_stride, Layout Lm, Layout Lv, Layout Lc, Layout Lk,
                              const double* gravity, int* notpd, hipStream_t s) {
+  if (V.nv <= 4 && V.nc <= 6 && V.nv < V.nc) {  // small loop mechanisms (four-bar: nv 3, nc 5): everything in registers
+    hipLaunchKernelGGL((loop_solve_small_kernel<T, 4, 6>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, V, B, stabilize, (const T*)body, (const T*)M,
+                       (const T*)c, (const T*)tau, (T*)vdot, (T*)lambda, (T*)K, (T*)k, Lm, Lv, Lc, Lk, gravity[0], gravity[1], gravity[2], notpd);
+    return hipGetLastError();
+  }
   const long lds_stride = scratch_stride | 1;  // odd: consecutive threads start in different LDS banks
   const size_t lds = (size_t)64 * lds_stride * sizeof(T);
   if (lds <= 64 * 1024)
