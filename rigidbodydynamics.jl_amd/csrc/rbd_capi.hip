@@ -640,6 +640,23 @@ int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const vo
 }
 }  // namespace
 
+// inverse_dynamics! / dynamics_bias! (vdot == nullptr) through the lane mapping that fits the batch: same rule as run_aba
+static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const void* dv, const void* dvd, const void* df, void* dtau, void* dqd,
+                    Layout Lq, Layout Lv, Layout Lf) {
+  const rbd_model* m = w->model;
+  if (mapping == RBD_ALGO_ABA_BANKS && m->bank_lps == 0) return RBD_ERR_UNSUPPORTED;
+  const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
+  if (banks) {
+    const int ncol = m->has3dof ? 3 : 1;
+    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_bank<double>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_rnea_bank<float>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
+  } else {
+    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dtau, dqd, nullptr, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dtau, dqd, nullptr, Lq, Lv, Lf, w->stream));
+  }
+  return RBD_OK;
+}
+
 // The fused articulated-body pass through whichever lane mapping fits: `algorithm` RBD_ALGO_ABA chooses by batch size
 // (measured crossovers, profiles/r01_mapping_sweep.txt), the RBD_ALGO_ABA_* values force one.  `gravity` overrides the
 // model's (the M^-1 solve runs the pass with g = 0); `fuse` folds a Munthe-Kaas stage into the launch (lanes / banks only).
@@ -690,12 +707,11 @@ static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, con
       return st;
     w->result_layout = o.layout; w->result_B = B;
     Timed t(w);
+    if ((st = run_rnea(w, B, RBD_ALGO_ABA, dq, dv, nullptr, df, w->d_c, dqd, Lq, Lv, Lf))) return st;
     if (w->dtype == RBD_F64) {
-      HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, nullptr, Lq, Lv, Lf, w->stream));
       HIP_TRY(launch_crba<double>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
       HIP_TRY(launch_chol_solve<double>(m->nv, B, w->d_M, dtau, w->d_c, dvd, nullptr, Lm, Lv, w->d_notpd, w->stream));
     } else {
-      HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, nullptr, Lq, Lv, Lf, w->stream));
       HIP_TRY(launch_crba<float>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
       HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_M, dtau, w->d_c, dvd, nullptr, Lm, Lv, w->d_notpd, w->stream));
     }
@@ -755,18 +771,8 @@ static int rnea_common(rbd_ws_t* w, int32_t B, const void* q, const void* v, con
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
   {
-    if (o.algorithm == RBD_ALGO_ABA_BANKS && m->bank_lps == 0) return RBD_ERR_UNSUPPORTED;
-    // same batch-size rule as the ABA mappings: two bodies per lane once one body per lane would put two wavefronts on a SIMD
-    const bool banks = m->bank_lps > 0 && (o.algorithm == RBD_ALGO_ABA_BANKS || (o.algorithm != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
     Timed t(w);
-    if (banks) {
-      const int ncol = m->has3dof ? 3 : 1;
-      if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_bank<double>(w->bm, B, ncol, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf, w->stream));
-      else HIP_TRY(launch_rnea_bank<float>(w->bm, B, ncol, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf, w->stream));
-    } else {
-      if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dt, nullptr, nullptr, Lq, Lv, Lf, w->stream));
-      else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dt, nullptr, nullptr, Lq, Lv, Lf, w->stream));
-    }
+    if ((st = run_rnea(w, B, o.algorithm, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf))) return st;
   }
   if (o.memory == RBD_MEM_HOST) return stage_out_copy(w, tau_out, dt, es * m->nv * B);
   return RBD_OK;
