@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture the K steps in one hipGraph")
     ap.add_argument("--gather-every-step", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--algorithm", default="aba", choices=["aba", "aba_lanes", "aba_chains", "aba_banks"],
+    ap.add_argument("--algorithm", default="aba", choices=["aba", "aba_tracks", "aba_lanes", "aba_chains", "aba_banks"],
                     help="lane mapping of the fused ABA: aba = the library's choice by batch size")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra (informational) measurement of two independent batches issued on two HIP streams")
@@ -98,7 +98,7 @@ def main():
 
     # low-overhead launch: pre-marshalled ctypes call straight into the C ABI
     L = _capi.lib()
-    opts = state._opts({"aba": 0, "aba_lanes": 2, "aba_chains": 3, "aba_banks": 4}[args.algorithm])
+    opts = state._opts({"aba": 0, "aba_lanes": 2, "aba_chains": 3, "aba_banks": 4, "aba_tracks": 5}[args.algorithm])
     stream = torch.cuda.current_stream(device)
     L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(stream.cuda_stream))
     c_args = (state.ws.handle, B, ctypes.c_void_p(state.q.data_ptr()), ctypes.c_void_p(state.v.data_ptr()),
@@ -232,7 +232,7 @@ def main():
             s_a, s_b = torch.cuda.Stream(device), torch.cuda.Stream(device)
             L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(s_a.cuda_stream))
             L.rbd_workspace_set_stream(state2.ws.handle, ctypes.c_void_p(s_b.cuda_stream))
-            opts2 = state2._opts({"aba": 0, "aba_lanes": 2, "aba_chains": 3, "aba_banks": 4}[args.algorithm])
+            opts2 = state2._opts({"aba": 0, "aba_lanes": 2, "aba_chains": 3, "aba_banks": 4, "aba_tracks": 5}[args.algorithm])
             c_args2 = (state2.ws.handle, B, ctypes.c_void_p(state2.q.data_ptr()), ctypes.c_void_p(state2.v.data_ptr()),
                        ctypes.c_void_p(d_tau.data_ptr()), ctypes.c_void_p(d_fext.data_ptr() if d_fext is not None else 0),
                        ctypes.c_void_p(result2.vd.data_ptr()), ctypes.c_void_p(result2.qd.data_ptr()), ctypes.c_void_p(0), ctypes.byref(opts2))

@@ -78,8 +78,11 @@ enum {
   RBD_ALGO_ABA_LANES = 2,    /* one lane per (state, body), level-synchronous sweeps: small batches             */
   RBD_ALGO_ABA_CHAINS = 3,   /* a few lanes per state walk chains of the tree: large batches.  RBD_ERR_UNSUPPORTED
                                 for mechanisms with 3-dof tree joints or a 6-dof joint not on the world           */
-  RBD_ALGO_ABA_BANKS = 4     /* lane-per-body with two bodies per lane (levels split into two banks): twice the
+  RBD_ALGO_ABA_BANKS = 4,    /* lane-per-body with two bodies per lane (levels split into two banks): twice the
                                 states per wavefront.  Same scope as the chain mapping                            */
+  RBD_ALGO_ABA_TRACKS = 5    /* chains of the tree on a few lanes per state, canonical body frames (joint axis = +z), per-body
+                                results in lane-private LDS rows: the default wherever it applies (trees of revolute /
+                                prismatic / fixed joints, 6-dof joints on the world).  RBD_ERR_UNSUPPORTED elsewhere        */
 };
 
 /* ---- loop (non-tree) joint: src/mechanism_modification.jl:38-43,
@@ -146,6 +149,10 @@ int rbd_model_destroy(rbd_model_t* model);
  * the banked ABA (not only the banked RNEA) takes the mechanism.  RBD_ERR_UNSUPPORTED when the split would not save lanes. */
 int rbd_model_bank_plan(const rbd_model_t* model, int32_t* lanes, int32_t* first_level_of_bank1, int32_t* bodies_bank0, int32_t* bodies_bank1,
                         int32_t* aba_in_scope);
+/* ... and of the track mapping (RBD_ALGO_ABA_TRACKS): dims[6] = tracks per state, steps, A/C mailboxes, B mailboxes, has a 6-dof root,
+ * has prismatic/fixed joints; table: steps×tracks reference body indices (-1 = idle); ri / rr: the packed per-(step, track) records
+ * the kernel reads (rbd_device.hpp TI_*, TR_*) — what tests/emu feeds to the CPU emulation of the kernel's step code.        */
+int rbd_model_track_plan(const rbd_model_t* model, int32_t* dims, int32_t* table, int32_t table_cap, int32_t* ri, int32_t ri_cap, double* rr, int32_t rr_cap);
 int rbd_model_chain_plan(const rbd_model_t* model, int32_t* tracks, int32_t* steps, int32_t* lds_fields, int32_t* table, int32_t capacity);
 int rbd_model_dims(const rbd_model_t* model, int32_t* n_bodies, int32_t* nq, int32_t* nv, int32_t* nc);
 

@@ -12,14 +12,14 @@ RBD_OK = 0
 F64, F32 = 0, 1
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 MEM_DEVICE, MEM_HOST = 0, 1
-ALGO_ABA, ALGO_CRBA_CHOLESKY, ALGO_ABA_LANES, ALGO_ABA_CHAINS, ALGO_ABA_BANKS = 0, 1, 2, 3, 4
+ALGO_ABA, ALGO_CRBA_CHOLESKY, ALGO_ABA_LANES, ALGO_ABA_CHAINS, ALGO_ABA_BANKS, ALGO_ABA_TRACKS = 0, 1, 2, 3, 4, 5
 
 # every symbol include/rbd_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = (
     "rbd_model_create", "rbd_model_destroy", "rbd_model_dims", "rbd_workspace_create", "rbd_workspace_destroy",
     "rbd_workspace_set_stream", "rbd_sync", "rbd_dynamics", "rbd_inverse_dynamics", "rbd_dynamics_bias", "rbd_mass_matrix",
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
-    "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan",
+    "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan", "rbd_model_track_plan",
 )
 
 
@@ -62,6 +62,7 @@ def lib():
         L.rbd_dynamics_result.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_cholesky_solve.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_model_chain_plan.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), i32]
+        L.rbd_model_track_plan.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), i32, ctypes.POINTER(i32), i32, ctypes.POINTER(ctypes.c_double), i32]
         L.rbd_workspace_last_kernel.argtypes = [vp]
         L.rbd_workspace_last_kernel.restype = ctypes.c_char_p
         L.rbd_geometric_jacobian.argtypes = [vp, i32, vp, i32, i32, vp, ctypes.POINTER(Opts)]

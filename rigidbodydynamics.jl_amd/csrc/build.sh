@@ -8,7 +8,11 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=${OUT:-librbd_hip.so}
 TAG=${OUT%.so}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -ffp-contract=fast -Wall -Wno-unused-function"
-$HIPCC $FLAGS -c rbd_kernels.hip -o ${TAG}_kernels.o "$@"
-$HIPCC $FLAGS -c rbd_capi.hip -o ${TAG}_capi.o "$@"
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT ${TAG}_kernels.o ${TAG}_capi.o
+pids=()
+for tu in rbd_kernels rbd_track_kernels rbd_capi; do
+  $HIPCC $FLAGS -c $tu.hip -o ${TAG}_${tu#rbd_}.o "$@" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT ${TAG}_kernels.o ${TAG}_track_kernels.o ${TAG}_capi.o
 echo "built $(pwd)/$OUT"

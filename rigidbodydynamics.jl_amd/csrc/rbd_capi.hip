@@ -14,6 +14,7 @@
 #include "rbd_hip.h"
 #include "rbd_internal.hpp"
 #include "rbd_chain_plan.hpp"
+#include "rbd_track_plan.hpp"
 
 using namespace rbd;
 
@@ -71,6 +72,7 @@ struct rbd_model {
   std::vector<double> bank_rb[2];
   uint64_t bank_perm_down = 0;
   ChainPlan chain;  // plan of aba_chain_kernel (chain.ok == false: mechanism outside its scope)
+  TrackPlan track;  // plan of aba_track_kernel (track.ok == false: mechanism outside its scope)
 };
 
 struct rbd_ws {
@@ -79,6 +81,7 @@ struct rbd_ws {
   hipStream_t stream = nullptr;
   DevModel dm{};
   BankModel bm{}; void* d_bank_ib[2] = {nullptr, nullptr}; void* d_bank_rb[2] = {nullptr, nullptr};
+  TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr; size_t track_lds_bytes4 = 0; long track_nw4_max_batch = 0; size_t track_lds_bytes = 0; long track_min_batch = 0;
   ChainModel cm{}; void* d_chain_tab = nullptr; void* d_chain_cb = nullptr; size_t chain_lds_bytes = 0; long bank_min_batch = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
   // staging for RBD_MEM_HOST (lazy)
@@ -325,6 +328,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     while (G < nheads && G < 4) G <<= 1;
     if (const char* e = getenv("RBD_CHAIN_G")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) G = g; }
     if (m->nloops == 0) m->chain = build_chain_plan(nb, m->ib, G);
+    if (m->nloops == 0 && G <= 4) m->track = build_track_plan(nb, m->ib, m->rb, G);
   }
   *out = m;
   return RBD_OK;
@@ -357,6 +361,24 @@ int rbd_model_chain_plan(const rbd_model_t* m, int32_t* tracks, int32_t* steps, 
     if (capacity < (int32_t)m->chain.tab.size()) return RBD_ERR_DIMENSION_MISMATCH;
     for (size_t i = 0; i < m->chain.tab.size(); ++i) table[i] = m->chain.tab[i] < 0 ? -1 : m->order[m->chain.tab[i]];  // reference body indices
   }
+  return RBD_OK;
+}
+
+int rbd_model_track_plan(const rbd_model_t* m, int32_t* dims, int32_t* table, int32_t table_cap, int32_t* ri, int32_t ri_cap, double* rr, int32_t rr_cap) {
+  if (!m) return RBD_ERR_INVALID_ARGUMENT;
+  if (!m->track.ok) return RBD_ERR_UNSUPPORTED;
+  const TrackPlan& P = m->track;
+  if (dims) { dims[0] = P.G; dims[1] = P.ns; dims[2] = P.nA; dims[3] = P.nB; dims[4] = P.has_floating; dims[5] = P.general; }
+  if (table) {
+    if (table_cap < (int32_t)P.tab.size()) return RBD_ERR_DIMENSION_MISMATCH;
+    for (size_t i = 0; i < P.tab.size(); ++i) table[i] = P.tab[i] < 0 ? -1 : m->order[P.tab[i]];  // reference body indices
+  }
+  if (ri) {  // the packed records, then the ns per-step flags
+    if (ri_cap < (int32_t)(P.ri.size() + P.sf.size())) return RBD_ERR_DIMENSION_MISMATCH;
+    memcpy(ri, P.ri.data(), P.ri.size() * sizeof(int32_t));
+    memcpy(ri + P.ri.size(), P.sf.data(), P.sf.size() * sizeof(int32_t));
+  }
+  if (rr) { if (rr_cap < (int32_t)P.rr.size()) return RBD_ERR_DIMENSION_MISMATCH; memcpy(rr, P.rr.data(), P.rr.size() * sizeof(double)); }
   return RBD_OK;
 }
 
@@ -461,6 +483,38 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     if (w->chain_lds_bytes > 160 * 1024) w->chain_lds_bytes = 0;  // does not fit: lanes mapping only
     // opt-in only (RBD_ALGO_ABA_CHAINS): the banked mapping is ahead of it at every measured batch size (profiles/r01_mapping_sweep.txt)
   }
+  if (m->track.ok) {
+    const TrackPlan& P = m->track;
+    st = upload(&w->d_track_ri, P.ri.data(), P.ri.size() * sizeof(int32_t));
+    if (st == RBD_OK) {
+      if (dtype == RBD_F64) st = upload(&w->d_track_rr, P.rr.data(), P.rr.size() * sizeof(double));
+      else { std::vector<float> f(P.rr.begin(), P.rr.end()); st = upload(&w->d_track_rr, f.data(), f.size() * sizeof(float)); }
+    }
+    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+    TrackModel& tm = w->tm;
+    tm.ns = P.ns; tm.G = P.G; tm.nA = P.nA; tm.nB = P.nB; tm.ri = (const int32_t*)w->d_track_ri; tm.rr = w->d_track_rr;
+    for (int k = 0; k < 5; ++k) { tm.sfm[k] = 0; for (int s2 = 0; s2 < P.ns; ++s2) tm.sfm[k] |= (uint64_t)((P.sf[s2] >> k) & 1) << s2; }
+    memcpy(tm.gravity, m->gravity, sizeof tm.gravity);
+    const size_t spw = 64 / P.G, es = dtype == RBD_F64 ? 8 : 4;
+    const size_t nrec = (size_t)P.ns * P.G, nf = dtype == RBD_F64 ? 22 : 24;  // = track_lds_bytes<T>() of rbd_track.hpp: rows, plan records, mailboxes, flags
+    w->track_lds_bytes = (size_t)P.ns * nf * 64 * es + nrec * 16 + nrec * TR_STRIDE * es + ((size_t)P.nA * (TMB_A + TMB_C) + (size_t)P.nB * TMB_B) * spw * es +
+                         ((size_t)P.ns + 4) * sizeof(int32_t);
+    if (w->track_lds_bytes > 160 * 1024) w->track_lds_bytes = 0;  // rows of a deep tree do not fit one CU's LDS: other mappings
+    if (w->track_lds_bytes > 0) {
+      const hipError_t e = dtype == RBD_F64 ? configure_track_kernel<double>(P.G, P.has_floating, P.general, w->track_lds_bytes)
+                                            : configure_track_kernel<float>(P.G, P.has_floating, P.general, w->track_lds_bytes);
+      if (e != hipSuccess) { g_last_hip_error = std::string("configure_track_kernel: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
+    }
+    // the four-wave latency form while a workgroup (64 / G states) still has a compute unit to itself; one wave per group beyond
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+    w->track_nw4_max_batch = (long)ncu * (long)spw;
+    if (const char* e = getenv("RBD_TRACK_NW4_MAX_BATCH")) w->track_nw4_max_batch = atol(e);
+    // opt-in (RBD_ALGO_ABA_TRACKS, or RBD_TRACK_MIN_BATCH=<n> to let RBD_ALGO_ABA pick it from n states up): measured at parity with
+    // the banked mapping at B = 4096 and behind it at large batches, where its LDS rows cap the residency (profiles/r02_track_*.txt)
+    w->track_min_batch = (long)1 << 62;
+    if (const char* e = getenv("RBD_TRACK_MIN_BATCH")) w->track_min_batch = atol(e);
+  }
   {
     const int G = (m->chain.ok && w->chain_lds_bytes > 0) ? m->chain.G : 0;
     const hipError_t e = dtype == RBD_F64 ? configure_kernels<double>(G, w->chain_lds_bytes) : configure_kernels<float>(G, w->chain_lds_bytes);
@@ -477,7 +531,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -664,13 +718,24 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
                    Layout Lq, Layout Lv, Layout Lf, const double* gravity, const MkFuse* fuse) {
   const rbd_model* m = w->model;
   const bool can_chain = m->chain.ok && w->chain_lds_bytes > 0 && !fuse, can_bank = m->bank_lps > 0 && m->bank_aba_ok;
+  // the track kernel addresses its batch buffers with 32-bit byte offsets
+  const bool can_track = m->track.ok && w->track_lds_bytes > 0 && !fuse && (double)B * (double)std::max(std::max(m->nq, m->nv), 6 * m->nb) * 8.0 < 4.0e9;
+  if (algorithm == RBD_ALGO_ABA_TRACKS && !can_track) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_CHAINS && !can_chain) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   int pick = algorithm;
-  if (algorithm == RBD_ALGO_ABA) pick = (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
+  if (algorithm == RBD_ALGO_ABA) pick = (can_track && B >= w->track_min_batch) ? RBD_ALGO_ABA_TRACKS : (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
   Timed t(w);
-  w->last_kernel = pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : pick == RBD_ALGO_ABA_CHAINS ? "aba_chain_kernel" : "aba_kernel";
-  if (pick == RBD_ALGO_ABA_BANKS) {
+  w->last_kernel = pick == RBD_ALGO_ABA_TRACKS ? "aba_track_kernel" : pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : pick == RBD_ALGO_ABA_CHAINS ? "aba_chain_kernel" : "aba_kernel";
+  if (pick == RBD_ALGO_ABA_TRACKS) {
+    TrackModel tm = w->tm;
+    if (gravity) memcpy(tm.gravity, gravity, sizeof tm.gravity);
+    const int flt = m->track.has_floating, gen = m->track.general;
+    const int nw = B <= w->track_nw4_max_batch ? 4 : 1;
+    w->last_kernel = nw == 4 ? "aba_track_kernel (4 waves per state group)" : "aba_track_kernel";
+    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_track<double>(tm, flt, gen, nw, B, w->track_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_aba_track<float>(tm, flt, gen, nw, B, w->track_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+  } else if (pick == RBD_ALGO_ABA_BANKS) {
     BankModel bm = w->bm;
     if (gravity) memcpy(bm.gravity, gravity, sizeof bm.gravity);
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_bank<double>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));

@@ -76,6 +76,23 @@ struct BankModel {
   double gravity[3];
 };
 
+// ---- track-scheduled ABA with canonical body frames (aba_track_kernel, rbd_track.hpp; plan: rbd_track_plan.hpp) ----------
+// One packed int4 and one 24-scalar record per (step, track):
+//   w0 = qoff | voff << 16;  w1 = 6*orig | flags << 16 | n_cross_children << 24;
+//   w2 = (A/C mailbox to write + 1) | (A/C mailbox to read + 1) << 16;  w3 = (B mailbox to write + 1) | (first B mailbox to read + 1) << 16
+//   reals: C (9, row-major) pp (3) J (6: xx xy xz yy yz zz) mc (3) m (1), all in the canonical (joint axis = +z) body frames
+enum { TI_W0 = 0, TI_W1, TI_W2, TI_W3, TI_STRIDE = 4 };
+enum { TR_C = 0, TR_PP = 9, TR_J = 12, TR_MC = 18, TR_M = 21, TR_STRIDE = 24 };
+enum { TF_VALID = 1, TF_LEVEL0 = 2, TF_CHAINED = 4, TF_CARRY = 8, TF_FLOATING = 16, TF_PRISMATIC = 32, TF_FIXED = 64, TF_SINCOS = 128 };
+enum { TMB_A = 30, TMB_B = 27, TMB_C = 6 };  // mailbox fields: (R, p, T, a_vp; a 6-dof root adds S⁻ᵀτ), (Ia, pa), (a)
+struct TrackModel {
+  int32_t ns, G, nA, nB;
+  const int32_t* ri;  // [ns * G * TI_STRIDE]
+  const void* rr;     // [ns * G * TR_STRIDE] of the kernel's scalar type
+  uint64_t sfm[5];    // wave-uniform flags of the steps (SF_* bit k of step s = bit s of sfm[k], rbd_track.hpp): which rare blocks any lane needs
+  double gravity[3];
+};
+
 // element (k, b) of an n x B batch buffer
 struct Layout {
   long sk, sb;  // SOA: sk = B, sb = 1;  AOS: sk = 1, sb = n
@@ -110,6 +127,8 @@ struct MkFuse {
 };
 
 #define RBD_DEV __device__ __forceinline__
+// pure arithmetic helpers are host+device: the CPU emulation harness of the track kernel (tests/emu) runs the same step code
+#define RBD_HD __host__ __device__ __forceinline__
 
 template <typename T> RBD_DEV T shfl(T x, int src) { return __shfl(x, src, 64); }
 
@@ -125,25 +144,25 @@ template <int CTRL> RBD_DEV double dpp_mov(double x) {
 template <typename T> RBD_DEV T from_prev_lane(T x) { return dpp_mov<0x138>(x); }
 template <typename T> RBD_DEV T from_next_lane(T x) { return dpp_mov<0x130>(x); }
 
-template <typename T> RBD_DEV void cross3(const T* a, const T* b, T* o) {
+template <typename T> RBD_HD void cross3(const T* a, const T* b, T* o) {
   T x = a[1] * b[2] - a[2] * b[1];
   T y = a[2] * b[0] - a[0] * b[2];
   T z = a[0] * b[1] - a[1] * b[0];
   o[0] = x; o[1] = y; o[2] = z;
 }
-template <typename T> RBD_DEV void matvec3(const T* R, const T* x, T* o) {
+template <typename T> RBD_HD void matvec3(const T* R, const T* x, T* o) {
   T a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
   T b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
   T c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
   o[0] = a; o[1] = b; o[2] = c;
 }
-template <typename T> RBD_DEV void matTvec3(const T* R, const T* x, T* o) {
+template <typename T> RBD_HD void matTvec3(const T* R, const T* x, T* o) {
   T a = R[0] * x[0] + R[3] * x[1] + R[6] * x[2];
   T b = R[1] * x[0] + R[4] * x[1] + R[7] * x[2];
   T c = R[2] * x[0] + R[5] * x[1] + R[8] * x[2];
   o[0] = a; o[1] = b; o[2] = c;
 }
-template <typename T> RBD_DEV void matmul3(const T* A, const T* B, T* C) {
+template <typename T> RBD_HD void matmul3(const T* A, const T* B, T* C) {
   T t[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -153,7 +172,7 @@ template <typename T> RBD_DEV void matmul3(const T* A, const T* B, T* C) {
   for (int k = 0; k < 9; ++k) C[k] = t[k];
 }
 // transform_spatial_motion (src/spatial/util.jl:104-108): (Rw, Rv + p x Rw)
-template <typename T> RBD_DEV void xmotion(const T* R, const T* p, const T* m, T* o) {
+template <typename T> RBD_HD void xmotion(const T* R, const T* p, const T* m, T* o) {
   T a[3], l[3], c[3];
   matvec3(R, m, a);
   matvec3(R, m + 3, l);
@@ -162,7 +181,7 @@ template <typename T> RBD_DEV void xmotion(const T* R, const T* p, const T* m, T
   for (int k = 0; k < 3; ++k) { o[k] = a[k]; o[3 + k] = l[k] + c[k]; }
 }
 // inverse of xmotion: (R'w, R'(v - p x w))
-template <typename T> RBD_DEV void xmotion_inv(const T* R, const T* p, const T* m, T* o) {
+template <typename T> RBD_HD void xmotion_inv(const T* R, const T* p, const T* m, T* o) {
   T c[3], d[3];
   cross3(p, m, c);
 #pragma unroll
@@ -171,7 +190,7 @@ template <typename T> RBD_DEV void xmotion_inv(const T* R, const T* p, const T* 
   matTvec3(R, d, o + 3);
 }
 // wrench transform (src/spatial/spatialforce.jl:152-158): (Rt + p x Rf, Rf)
-template <typename T> RBD_DEV void xforce(const T* R, const T* p, const T* w, T* o) {
+template <typename T> RBD_HD void xforce(const T* R, const T* p, const T* w, T* o) {
   T a[3], l[3], c[3];
   matvec3(R, w, a);
   matvec3(R, w + 3, l);
@@ -180,7 +199,7 @@ template <typename T> RBD_DEV void xforce(const T* R, const T* p, const T* w, T*
   for (int k = 0; k < 3; ++k) { o[k] = a[k] + c[k]; o[3 + k] = l[k]; }
 }
 // inverse wrench transform = S' w for a floating joint: (R'(t - p x f), R'f)
-template <typename T> RBD_DEV void xforce_inv(const T* R, const T* p, const T* w, T* o) {
+template <typename T> RBD_HD void xforce_inv(const T* R, const T* p, const T* w, T* o) {
   T c[3], d[3];
   cross3(p, w + 3, c);
 #pragma unroll
@@ -189,7 +208,7 @@ template <typename T> RBD_DEV void xforce_inv(const T* R, const T* p, const T* w
   matTvec3(R, w + 3, o + 3);
 }
 // se3_commutator (src/spatial/util.jl:117-121)
-template <typename T> RBD_DEV void se3_comm(const T* x, const T* y, T* o) {
+template <typename T> RBD_HD void se3_comm(const T* x, const T* y, T* o) {
   T a[3], b[3], c[3];
   cross3(x, y, a);
   cross3(x, y + 3, b);
@@ -197,7 +216,7 @@ template <typename T> RBD_DEV void se3_comm(const T* x, const T* y, T* o) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) { o[k] = a[k]; o[3 + k] = b[k] + c[k]; }
 }
-template <typename T> RBD_DEV T dot6(const T* a, const T* b) {
+template <typename T> RBD_HD T dot6(const T* a, const T* b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
 
@@ -205,7 +224,7 @@ template <typename T> RBD_DEV T dot6(const T* a, const T* b) {
 template <typename T> struct RInertia { T J[6]; T c[3]; T m; };
 
 // mul_inertia (src/spatial/util.jl:110-114): (J w + c x v, m v - c x w)
-template <typename T> RBD_DEV void mul_inertia(const RInertia<T>& I, const T* t, T* o) {
+template <typename T> RBD_HD void mul_inertia(const RInertia<T>& I, const T* t, T* o) {
   const T* J = I.J;
   T b[3], d[3];
   cross3(I.c, t + 3, b);
@@ -217,7 +236,7 @@ template <typename T> RBD_DEV void mul_inertia(const RInertia<T>& I, const T* t,
   for (int k = 0; k < 3; ++k) o[3 + k] = I.m * t[3 + k] - d[k];
 }
 // transform(inertia, H) (src/spatial/motion_force_interaction.jl:160-176)
-template <typename T> RBD_DEV void inertia_to_root(const T* Jb /*6*/, const T* mcb, T m, const T* R, const T* p, RInertia<T>& O) {
+template <typename T> RBD_HD void inertia_to_root(const T* Jb /*6*/, const T* mcb, T m, const T* R, const T* p, RInertia<T>& O) {
   T Rmc[3], mp[3];
   matvec3(R, mcb, Rmc);
 #pragma unroll
@@ -250,7 +269,7 @@ template <typename T> RBD_DEV void inertia_to_root(const T* Jb /*6*/, const T* m
   O.m = m;
 }
 // newton_euler cross term: T x* (I T) = (w x k + v x l ; w x l), (k, l) = I T
-template <typename T> RBD_DEV void momentum_cross(const RInertia<T>& I, const T* t, T* o) {
+template <typename T> RBD_HD void momentum_cross(const RInertia<T>& I, const T* t, T* o) {
   T h[6], a[3], b[3], c[3];
   mul_inertia(I, t, h);
   cross3(t, h, a);
@@ -263,7 +282,7 @@ template <typename T> RBD_DEV void momentum_cross(const RInertia<T>& I, const T*
 // ---- packed symmetric 6x6 (upper, row-major): index of (i, j), i <= j ----
 __host__ __device__ constexpr int SI(int i, int j) { return i <= j ? (i * 6 - i * (i - 1) / 2 + (j - i)) : (j * 6 - j * (j - 1) / 2 + (i - j)); }
 
-template <typename T> RBD_DEV void sym6_from_inertia(const RInertia<T>& I, T* A /*21*/) {
+template <typename T> RBD_HD void sym6_from_inertia(const RInertia<T>& I, T* A /*21*/) {
   const T z = T(0);
   const T* c = I.c;
   A[SI(0, 0)] = I.J[0]; A[SI(0, 1)] = I.J[1]; A[SI(0, 2)] = I.J[2]; A[SI(0, 3)] = z;     A[SI(0, 4)] = -c[2]; A[SI(0, 5)] = c[1];
@@ -273,7 +292,7 @@ template <typename T> RBD_DEV void sym6_from_inertia(const RInertia<T>& I, T* A 
   A[SI(4, 4)] = I.m;    A[SI(4, 5)] = z;
   A[SI(5, 5)] = I.m;
 }
-template <typename T> RBD_DEV void sym6_mul(const T* A, const T* x, T* o) {
+template <typename T> RBD_HD void sym6_mul(const T* A, const T* x, T* o) {
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     T s = T(0);
@@ -284,7 +303,7 @@ template <typename T> RBD_DEV void sym6_mul(const T* A, const T* x, T* o) {
 }
 // in-place LDL' of a packed SPD 6x6 (A = L D L', unit lower L stored in the strict part as A[SI(j,i)], D on the diagonal)
 // and solve A x = b.  No square roots; the pivots are 1/d.
-template <typename T> RBD_DEV void sym6_solve(T* A, const T* b, T* x) {
+template <typename T> RBD_HD void sym6_solve(T* A, const T* b, T* x) {
   T dinv[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -319,7 +338,7 @@ template <typename T> RBD_DEV void sym6_solve(T* A, const T* b, T* x) {
 }
 
 // AngleAxis -> R given sin, cos (formula of src/joint_types/sin_cos_revolute.jl:69-96)
-template <typename T> RBD_DEV void rot_axis_sc(const T* ax, T s, T c, T* R) {
+template <typename T> RBD_HD void rot_axis_sc(const T* ax, T s, T c, T* R) {
   T c1 = T(1) - c;
   T c1x2 = c1 * ax[0] * ax[0], c1y2 = c1 * ax[1] * ax[1], c1z2 = c1 * ax[2] * ax[2];
   T c1xy = c1 * ax[0] * ax[1], c1xz = c1 * ax[0] * ax[2], c1yz = c1 * ax[1] * ax[2];
@@ -329,7 +348,7 @@ template <typename T> RBD_DEV void rot_axis_sc(const T* ax, T s, T c, T* R) {
   R[2] = c1xz + sy;          R[5] = c1yz - sx;          R[8] = T(1) - c1x2 - c1y2;
 }
 // unit quaternion (w,x,y,z) -> R (Rotations.jl QuatRotation, normalize=false)
-template <typename T> RBD_DEV void rot_quat(T w, T x, T y, T z, T* R) {
+template <typename T> RBD_HD void rot_quat(T w, T x, T y, T z, T* R) {
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
   R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
   R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
@@ -353,5 +372,66 @@ template <> struct SqrtT<float> { static __device__ __forceinline__ float f(floa
 
 RBD_DEV void sincos_t(double x, double* s, double* c) { sincos(x, s, c); }
 RBD_DEV void sincos_t(float x, float* s, float* c) { sincosf(x, s, c); }
+
+// host+device forms for code that also runs in the CPU emulation harness (the host branch is never part of the product path)
+RBD_HD double rcp_hd(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rcp_nr(x);
+#else
+  return 1.0 / x;
+#endif
+}
+RBD_HD float rcp_hd(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rcp_nr(x);
+#else
+  return 1.0f / x;
+#endif
+}
+RBD_HD void sincos_hd(double x, double* s, double* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(x, s, c);
+#else
+  *s = __builtin_sin(x); *c = __builtin_cos(x);
+#endif
+}
+// sin and cos of a joint angle in ~35 fp64 instructions (the library sincos is ~130 with its large-argument machinery inlined):
+// Cody-Waite reduction by pi/2 in three FMA steps (exact products), the fdlibm kernel polynomials on [-pi/4, pi/4], quadrant fix-up.
+// |x| <= 2^15 (k < 2^15: the three-term reduction keeps the reduced argument good to ~1e-17 absolute); larger or non-finite
+// arguments take the library path.  Max error observed against libm on 10^7 points in [-2^15, 2^15]: 1.6 ulp.
+RBD_HD void sincos_fast(double x, double* sp, double* cp) {
+  if (!(__builtin_fabs(x) <= 32768.0)) { sincos_hd(x, sp, cp); return; }
+  const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+  double r = __builtin_fma(k, -1.57079632679489655800e+00, x);
+  r = __builtin_fma(k, -6.12323399573676603587e-17, r);
+  r = __builtin_fma(k, 1.49738490485916983294e-33, r);
+  const double z = r * r;
+  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+  ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+  ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+  ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+  const double sn = __builtin_fma(r * z, ps, r);
+  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+  pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+  pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+  pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+  const double cs = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+  const int n = (int)k;
+  const double a = (n & 1) ? cs : sn, b = (n & 1) ? sn : cs;
+  *sp = (n & 2) ? -a : a;
+  *cp = ((n + 1) & 2) ? -b : b;
+}
+RBD_HD void sincos_fast(float x, float* s, float* c);
+
+RBD_HD void sincos_hd(float x, float* s, float* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincosf(x, s, c);
+#else
+  *s = __builtin_sinf(x); *c = __builtin_cosf(x);
+#endif
+}
+RBD_HD void sincos_fast(float x, float* s, float* c) { sincos_hd(x, s, c); }
 
 }  // namespace rbd

@@ -56,3 +56,9 @@ namespace rbd {
 template <typename T>
 hipError_t launch_momentum(const DevModel& M, long B, const void* q, const void* v, void* mom, Layout Lq, Layout Lv, Layout L12, hipStream_t s);
 }
+namespace rbd {
+template <typename T>
+hipError_t launch_aba_track(const TrackModel& M, int flt, int gen, int nw, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
+                            void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+template <typename T> hipError_t configure_track_kernel(int G, int flt, int gen, size_t lds_bytes);
+}

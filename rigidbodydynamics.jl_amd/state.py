@@ -215,14 +215,14 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
     """`dynamics!(result, state, torques, externalwrenches; stabilization_gains)` (src/mechanism_algorithms.jl:845-864):
     fills `result.vd` (v̇) and `result.qd` (q̇).  `torques` (B, nv) defaults to zeros; `externalwrenches` is a dense
     (B, 6*n_bodies) tensor of root-frame wrenches (torque; force) per moving body (None == NullDict).
-    algorithm="aba": fused articulated-body kernel (mapping chosen by batch size; "aba_lanes" / "aba_banks" / "aba_chains" force one);
+    algorithm="aba": fused articulated-body kernel (mapping chosen by batch size; "aba_tracks" / "aba_lanes" / "aba_banks" / "aba_chains" force one);
     "crba": the reference's own CRBA + Cholesky route, which also fills result.massmatrix and result.dynamicsbias."""
     f = state.flat
     state._check(torques, f.nv, "torques")
     state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
     state.ws.use_current_stream()
     algo = {"aba": _capi.ALGO_ABA, "crba": _capi.ALGO_CRBA_CHOLESKY, "aba_lanes": _capi.ALGO_ABA_LANES,
-            "aba_chains": _capi.ALGO_ABA_CHAINS, "aba_banks": _capi.ALGO_ABA_BANKS}[algorithm]
+            "aba_chains": _capi.ALGO_ABA_CHAINS, "aba_banks": _capi.ALGO_ABA_BANKS, "aba_tracks": _capi.ALGO_ABA_TRACKS}[algorithm]
     opts = state._opts(algo, 0 if stabilization_gains is None else 1)
     lam = result.lambda_ if f.nc > 0 else None
     st = _capi.lib().rbd_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
@@ -429,6 +429,30 @@ def chain_plan(flat):
         tab = np.zeros(ns.value * g.value, np.int32)
         _raise(L.rbd_model_chain_plan(h, None, None, None, tab.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), tab.size), "rbd_model_chain_plan")
         return {"tracks": g.value, "steps": ns.value, "lds_fields": nf.value, "table": tab.reshape(ns.value, g.value)}
+    finally:
+        L.rbd_model_destroy(h)
+
+
+def track_plan(flat):
+    """The track-mapping plan of a mechanism (`rbd_model_track_plan`, host-only): dict with `tracks`, `steps`, `mailboxes` (A/C, B),
+    `floating`, `general`, `table` (steps × tracks body indices, -1 = idle) and the packed records `ri` / `rr` the kernel reads;
+    None when the mechanism is outside the mapping's scope."""
+    import numpy as np
+    L = _capi.lib()
+    h = ctypes.c_void_p()
+    _raise(L.rbd_model_create(ctypes.cast(ctypes.byref(flat.c_struct()), ctypes.c_void_p), ctypes.byref(h)), "rbd_model_create")
+    try:
+        dims = np.zeros(6, np.int32)
+        pi = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        st = L.rbd_model_track_plan(h, pi(dims), None, 0, None, 0, None, 0)
+        if st == 3:  # RBD_ERR_UNSUPPORTED
+            return None
+        _raise(st, "rbd_model_track_plan")
+        n = int(dims[0]) * int(dims[1])
+        tab, ri, rr = np.zeros(n, np.int32), np.zeros(n * 4 + int(dims[1]), np.int32), np.zeros(n * 24, np.float64)  # ri: packed records + per-step flags
+        _raise(L.rbd_model_track_plan(h, None, pi(tab), tab.size, pi(ri), ri.size, rr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), rr.size), "rbd_model_track_plan")
+        return {"tracks": int(dims[0]), "steps": int(dims[1]), "mailboxes": (int(dims[2]), int(dims[3])), "floating": bool(dims[4]), "general": bool(dims[5]),
+                "dims": dims, "table": tab.reshape(int(dims[1]), int(dims[0])), "ri": ri, "rr": rr}
     finally:
         L.rbd_model_destroy(h)
 
