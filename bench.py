@@ -1,21 +1,32 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark: batched forward dynamics (`dynamics!`, fused ABA) on Atlas.
 
-Workload (BASELINE.json configs[1]): Atlas v5 URDF with floating base (nq 37, nv 36, 31 bodies; the reference's
-perf/runbenchmarks.jl:14-19 mechanism, from the vendored test/urdf/atlas.urdf), batch = 4096 states per GPU, fp64,
-random (q, v, τ) drawn with the reference's distributions.  One *step* = one `dynamics!` over the whole batch
-(one ABA kernel launch — aba_bank_kernel at this batch); inputs are resident in HBM before the timed region.  N > 1: one process per GPU, the
-batch is sharded (weak scaling: 4096 states per GPU), no data-path collective; the RCCL all-gather of v̇ is run
-once after the timed region (and inside it with --gather-every-step).
+Default workload (BASELINE.json configs[1], `--config 2`): Atlas v5 URDF with floating base (nq 37, nv 36, 31 bodies; the reference's
+perf/runbenchmarks.jl:14-19 mechanism, from the vendored test/urdf/atlas.urdf), batch = 4096 states per GPU, fp64, random (q, v, τ)
+drawn with the reference's distributions.  One *step* = one `dynamics!` over the whole batch (one ABA kernel launch); inputs are
+resident in HBM before the timed region (and, being re-evaluated every step, in L2 / Infinity Cache: the HBM-axis figure is a cache
+figure — irrelevant while the kernel is ALU/latency bound, but said here).  The same line also carries the run WITH a random external
+wrench on every body (what the reference's published 9.874 µs is measured with, perf/runbenchmarks.jl:59-67).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM with the ALGORITHMIC bytes
-(sizeof(T)·(nq + 3·nv) per evaluation, SURVEY.md §8 d); `alu` gives the honest binding roof (fp64 vector ALU).
-`cpu_baseline` times the oracle's restatement of the reference route (CRBA + RNEA + Cholesky) on the host cores.
+Other BASELINE configs: `--config 3` (65 536 states fp32, mass_matrix! + Cholesky solve), `--config 4` (65 536 states per GPU fp32 ABA,
+v̇ gathered over RCCL: both the compute-only rate and the rate with the all-gather inside every step), `--config 5` (four-bar linkage
+with its loop joint, 4096 states fp64).
+
+N > 1: `python bench.py --gpus N` re-executes itself under torch.distributed.run (one process per GPU, RCCL); launched by the driver
+under torch.distributed.run it reads RANK / WORLD_SIZE from the environment.  The batch is sharded (weak scaling: the per-GPU batch is
+fixed), no data-path collective; `n_gpus` is the world size RCCL reports.  It refuses to run when fewer GPUs are visible than asked for.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM with the ALGORITHMIC bytes (sizeof(T)·(nq + 3·nv)
+per evaluation + q̇, SURVEY.md §8 d); `alu` gives the binding roof (vector ALU).  The result of the timed launches is compared with
+the oracle over the WHOLE batch.  `cpu_baseline` times the oracle's restatement of the reference route on the host cores (N = 1 only).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,42 +37,114 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 # becomes 28 µs (measured).  It is this image's default; set explicitly so the number does not depend on it.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X public spec (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 FP32_VECTOR_PEAK_TF = 157.3
 ABA_FLOPS_PER_EVAL = 27.0e3  # fused world-frame ABA, Atlas floating
+CONFIGS = {
+    2: dict(model="atlas_floating", batch=4096, dtype="f64", op="dynamics", label="BASELINE configs[1]"),
+    3: dict(model="atlas_floating", batch=65536, dtype="f32", op="mass_matrix_solve", label="BASELINE configs[2]"),
+    4: dict(model="atlas_floating", batch=65536, dtype="f32", op="dynamics", label="BASELINE configs[3]: 65536 states per GPU"),
+    5: dict(model="four_bar", batch=4096, dtype="f64", op="dynamics", label="BASELINE configs[4]"),
+}
 
 
-def main():
+def kernel_source_hash():
+    """Identifies the kernel sources a PMC traffic figure was measured on (profiles/r02_pmc_traffic.json records it)."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "rigidbodydynamics.jl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=4096, help="states per GPU")
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--model", default="atlas_floating")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (2 = the headline, configs[1])")
+    ap.add_argument("--batch", type=int, default=None, help="states per GPU (default: the config's)")
+    ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
+    ap.add_argument("--model", default=None)
     ap.add_argument("--layout", default="aos", choices=["aos", "soa"])
     ap.add_argument("--graph", action="store_true", help="capture the K steps in one hipGraph")
-    ap.add_argument("--gather-every-step", action="store_true")
+    ap.add_argument("--gather-every-step", action="store_true", help="RCCL all-gather of v̇ inside every timed step (config 4 reports both anyway)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algorithm", default="aba", choices=["aba", "aba_tracks", "aba_lanes", "aba_chains", "aba_banks"],
                     help="lane mapping of the fused ABA: aba = the library's choice by batch size")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra (informational) measurement of two independent batches issued on two HIP streams")
-    ap.add_argument("--wrenches", action="store_true", help="random external wrench on every body (as perf/runbenchmarks.jl:59-67)")
+    ap.add_argument("--wrenches", action="store_true", help="headline WITH a random external wrench on every body (reported next to it otherwise)")
+    ap.add_argument("--selftest-launch", action="store_true", help="only exercise the N-rank launcher (gloo on CPU): prints the world size the ranks saw")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.model = args.model or cfg["model"]
+    args.batch = args.batch or cfg["batch"]
+    args.dtype = args.dtype or cfg["dtype"]
+    args.op = cfg["op"]
+    if args.steps is None:
+        args.steps = 2000 if args.batch <= 8192 else 200
+    if args.warmup is None:
+        args.warmup = 100 if args.batch <= 8192 else 20
+    return args
+
+
+def maybe_spawn(args):
+    """`--gpus N` without a torch.distributed.run environment: start the N ranks ourselves and relay rank 0's line."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    if not args.selftest_launch:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(json.dumps({"error": f"--gpus {args.gpus} but only {have} GPU(s) visible: refusing to run fewer ranks than asked for"}))
+            sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def selftest_launch(args):
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if dist.get_rank() == 0:
+        print(json.dumps({"selftest": "launcher", "asked": args.gpus, "n_gpus": dist.get_world_size(), "ranks_counted": int(t.item())}))
+    dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    maybe_spawn(args)
+    if args.selftest_launch:
+        return selftest_launch(args)
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: reporting the world size actually running", file=sys.stderr)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()  # what RCCL sees
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -69,16 +152,27 @@ def main():
 
     import rbd_amd as rbd
     from rigidbodydynamics_jl_amd import _capi
+    import oracle
 
-    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
+    if args.model == "four_bar":
+        model = rbd.flatten(rbd.four_bar_linkage())
+    else:
+        model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
     B = args.batch
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    ndt = np.float64 if args.dtype == "f64" else np.float32
     es = 8 if args.dtype == "f64" else 4
     rng = np.random.default_rng(1 + rank)
-    q = rbd.rand_configuration(model, B, rng)
-    v = rbd.rand_velocity(model, B, rng)
+    if args.model == "four_bar":
+        # the consistent initial state of test/test_simulate.jl:195-200, joint 1 perturbed (exercises the Baumgarte term; SURVEY.md §8 d config 5)
+        q = np.tile(np.asarray(rbd.FOUR_BAR_INITIAL_Q, float), (B, 1))
+        q[:, 0] += rng.uniform(-0.05, 0.05, B)
+        v = np.tile(np.asarray(rbd.FOUR_BAR_INITIAL_V, float), (B, 1))
+    else:
+        q = rbd.rand_configuration(model, B, rng)
+        v = rbd.rand_velocity(model, B, rng)
     tau = rng.random((B, model.nv))
-    fext = rng.random((B, 6 * model.n_bodies)) if args.wrenches else None
+    fext_all = rng.random((B, 6 * model.n_bodies))
 
     state = rbd.MechanismState(model, B, dtype=tdt, device=device, layout=args.layout)
     result = rbd.DynamicsResult(model, B, dtype=tdt, device=device, layout=args.layout)
@@ -86,73 +180,136 @@ def main():
     rbd.set_velocity_(state, v)
 
     def to_dev(a):
-        if a is None:
-            return None
         t = torch.as_tensor(a, dtype=tdt)
         if args.layout == "soa":
             t = t.t().contiguous()
         return t.to(device)
 
-    d_tau, d_fext = to_dev(tau), to_dev(fext)
+    d_tau, d_fext = to_dev(tau), to_dev(fext_all)
+    x_out = torch.zeros_like(d_tau)
     gathered = torch.empty((world * B, model.nv) if args.layout == "aos" else (world, model.nv, B), dtype=tdt, device=device) if world > 1 else None
 
     # low-overhead launch: pre-marshalled ctypes call straight into the C ABI
     L = _capi.lib()
-    opts = state._opts({"aba": 0, "aba_lanes": 2, "aba_chains": 3, "aba_banks": 4, "aba_tracks": 5}[args.algorithm])
+    algo_id = {"aba": 0, "aba_lanes": 2, "aba_chains": 3, "aba_banks": 4, "aba_tracks": 5}[args.algorithm]
     stream = torch.cuda.current_stream(device)
     L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(stream.cuda_stream))
-    c_args = (state.ws.handle, B, ctypes.c_void_p(state.q.data_ptr()), ctypes.c_void_p(state.v.data_ptr()),
-              ctypes.c_void_p(d_tau.data_ptr()), ctypes.c_void_p(d_fext.data_ptr() if d_fext is not None else 0),
-              ctypes.c_void_p(result.vd.data_ptr()), ctypes.c_void_p(result.qd.data_ptr()), ctypes.c_void_p(0), ctypes.byref(opts))
-    dyn = L.rbd_dynamics
+    vp = ctypes.c_void_p
 
-    def step():
-        st = dyn(*c_args)
-        if st != 0:
-            raise RuntimeError(f"rbd_dynamics status {st}: {L.rbd_status_string(st)} {L.rbd_last_hip_error()}")
-        if args.gather_every_step and world > 1:
-            dist.all_gather_into_tensor(gathered, result.vd)
+    def make_step(with_fext, st=state, res=result, out=x_out):
+        if args.op == "mass_matrix_solve":
+            opts = st._opts(_capi.ALGO_CRBA_CHOLESKY)
+            c_args = (st.ws.handle, B, vp(st.q.data_ptr()), vp(d_tau.data_ptr()), vp(out.data_ptr()), vp(res.massmatrix.data_ptr()), ctypes.byref(opts))
+            fn, name = L.rbd_mass_matrix_solve, "rbd_mass_matrix_solve"
+        else:
+            opts = st._opts(algo_id)
+            lam = res.lambda_.data_ptr() if model.nc > 0 else 0
+            c_args = (st.ws.handle, B, vp(st.q.data_ptr()), vp(st.v.data_ptr()), vp(d_tau.data_ptr()), vp(d_fext.data_ptr() if with_fext else 0),
+                      vp(res.vd.data_ptr()), vp(res.qd.data_ptr()), vp(lam), ctypes.byref(opts))
+            fn, name = L.rbd_dynamics, "rbd_dynamics"
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(device)
+        def step(_keep=(opts, c_args)):
+            s = fn(*c_args)
+            if s != 0:
+                raise RuntimeError(f"{name} status {s}: {L.rbd_status_string(s)} {L.rbd_last_hip_error()}")
+        return step
 
-    graph = None
-    if args.graph:
-        graph = torch.cuda.CUDAGraph()
-        cap = torch.cuda.Stream(device)
-        with torch.cuda.stream(cap):
-            L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(cap.cuda_stream))
-            with torch.cuda.graph(graph, stream=cap):
-                for _ in range(args.steps):
-                    step()
-        L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(stream.cuda_stream))
-        torch.cuda.synchronize(device)
-
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(args.steps):
+    def timed(step, gather_each):
+        """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; (wall seconds, kernel ms per step by HIP events)."""
+        def one():
             step()
-    ev1.record(stream)
-    torch.cuda.synchronize(device)
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    wall = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average duration of one aba_kernel launch (HIP events on its stream)
+            if gather_each:
+                dist.all_gather_into_tensor(gathered, result.vd)
+        for _ in range(args.warmup):
+            one()
+        torch.cuda.synchronize(device)
+        graph = None
+        if args.graph and not gather_each:
+            graph = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device)
+            with torch.cuda.stream(cap):
+                L.rbd_workspace_set_stream(state.ws.handle, vp(cap.cuda_stream))
+                with torch.cuda.graph(graph, stream=cap):
+                    for _ in range(args.steps):
+                        step()
+            L.rbd_workspace_set_stream(state.ws.handle, vp(stream.cuda_stream))
+            torch.cuda.synchronize(device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(args.steps):
+                one()
+        ev1.record(stream)
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            tw = torch.tensor([wall], dtype=torch.float64, device=device)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            wall = float(tw.item())
+        return wall, ev0.elapsed_time(ev1) / args.steps
 
+    headline_fext = bool(args.wrenches)
+    step = make_step(headline_fext)
+    wall, kernel_ms = timed(step, args.gather_every_step and world > 1)
+
+    # ---- parity of the timed work against the oracle over the WHOLE batch (outside the timed region) ----
+    qf, vf, tf = [a.astype(ndt).astype(np.float64) for a in (q, v, tau)]
+    ff = fext_all.astype(ndt).astype(np.float64) if headline_fext else None
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    check = {}
+    if args.op == "mass_matrix_solve":
+        n = min(B, 4096)  # M is nv x nv per state: the full 65 536-state comparison would need 0.7 GB of host doubles
+        Mref = oracle.mass_matrix(model, qf[:n], nthreads=ncores)
+        Mref = np.tril(Mref) + np.transpose(np.tril(Mref, -1), (0, 2, 1))
+        xref = np.linalg.solve(Mref, tf[:n, :, None])[:, :, 0]
+        got_M = result.massmatrix if args.layout == "aos" else result.massmatrix.t()
+        got_M = got_M[:n].double().cpu().numpy().reshape(n, model.nv, model.nv).transpose(0, 2, 1)
+        got_x = (x_out if args.layout == "aos" else x_out.t())[:n].double().cpu().numpy()
+        il = np.tril_indices(model.nv)
+        err_M = float(np.abs(got_M[:, il[0], il[1]] - Mref[:, il[0], il[1]]).max() / np.abs(Mref).max())
+        res = np.einsum("bij,bj->bi", Mref, got_x) - tf[:n]
+        # normwise backward error of the solve (Rigal–Gaches): ||M x − r|| / (||M|| ||x|| + ||r||) with the ORACLE's M
+        berr = float((np.linalg.norm(res, axis=1) / (np.linalg.norm(Mref, axis=(1, 2)) * np.linalg.norm(got_x, axis=1) + np.linalg.norm(tf[:n], axis=1))).max())
+        check = {"states_compared": n, "mass_matrix_rel_err": err_M, "solve_backward_err": berr,
+                 "forward_err_rel_max": float(np.abs(got_x - xref).max() / np.abs(xref).max())}
+        err = max(err_M, berr)
+        tol = 1e-10 if args.dtype == "f64" else 2e-5
+    elif model.nc > 0:
+        n = min(B, 1024)  # the loop-joint oracle is one state per call
+        ref = oracle.dynamics_loops(model, qf[:n], vf[:n], tf[:n], ff[:n] if ff is not None else None)["vdot"]
+        got = (result.vd if args.layout == "aos" else result.vd.t())[:n].double().cpu().numpy()
+        err = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+        check = {"states_compared": n}
+        tol = 1e-9
+    else:
+        ref = oracle.dynamics(model, qf, vf, tf, ff, nthreads=ncores)
+        got = (result.vd if args.layout == "aos" else result.vd.t()).double().cpu().numpy()
+        if args.dtype == "f64":
+            err = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+            tol = 1e-10
+        else:  # fp32: backward error against the fp64 oracle's M, c on a sample (cond(M) ~ 5e5: the forward error is not the criterion)
+            n = min(B, 4096)
+            Mref = oracle.mass_matrix(model, qf[:n], nthreads=ncores)
+            Mref = np.tril(Mref) + np.transpose(np.tril(Mref, -1), (0, 2, 1))
+            c = oracle.dynamics_bias(model, qf[:n], vf[:n], ff[:n] if ff is not None else None)
+            r = tf[:n] - c
+            err = float((np.linalg.norm(np.einsum("bij,bj->bi", Mref, got[:n]) - r, axis=1) / np.linalg.norm(r, axis=1)).max())
+            check = {"backward_err_states": n, "forward_err_rel_max_whole_batch": float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))}
+            tol = 2e-5
+        check["states_compared"] = B
+    assert err < tol, f"parity lost in bench: {err} (tolerance {tol})"
+
+    extra = {}
     gather_ms = None
-    if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device=device)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
+    if dist is not None and args.op == "dynamics":
         torch.cuda.synchronize(device)
         try:
             dist.all_gather_into_tensor(gathered, result.vd)  # warm-up (RCCL channel setup)
@@ -161,17 +318,20 @@ def main():
             dist.all_gather_into_tensor(gathered, result.vd)  # the RCCL gather of DynamicsResult.v̇ over xGMI
             torch.cuda.synchronize(device)
             gather_ms = (time.perf_counter() - g0) * 1e3
-        except Exception as e:  # the gather is outside the timed region: never lose the measurement to it
+            if not args.gather_every_step:
+                w2, _ = timed(step, True)
+                extra["with_gather_every_step"] = {"value": world * B * args.steps / w2, "unit": "evals/s", "ms_per_step": w2 / args.steps * 1e3}
+        except Exception as e:  # the gather is outside the headline's timed region: never lose the measurement to it
             gather_ms = f"failed: {type(e).__name__}: {e}"
 
-    # sanity: the timed work produced the right answer (checked outside the timed region, small sample)
-    import oracle
-    n = 32
-    got = result.vd if args.layout == "aos" else result.vd.t()
-    ref = oracle.dynamics(model, q[:n], v[:n], tau[:n], fext[:n] if fext is not None else None)
-    err = float(np.abs(got[:n].double().cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max()))
-    tol = 1e-10 if args.dtype == "f64" else 3e-2
-    assert err < tol, f"parity lost in bench: {err}"
+    if args.op == "dynamics" and model.nc == 0 and world == 1:
+        # the same K steps with / without a random external wrench on every body, so that the line carries both
+        try:
+            w2, k2 = timed(make_step(not headline_fext), False)
+            extra["with_external_wrenches" if not headline_fext else "without_external_wrenches"] = {
+                "value": B * args.steps / w2, "unit": "evals/s", "ms_per_step": w2 / args.steps * 1e3, "kernel_ms": k2}
+        except Exception as e:
+            extra["with_external_wrenches"] = f"failed: {type(e).__name__}: {e}"
 
     if rank != 0:
         if dist is not None:
@@ -180,47 +340,63 @@ def main():
 
     evals = world * B * args.steps
     value = evals / wall
-    alg_bytes = es * (model.nq + 3 * model.nv + (model.nq if True else 0))  # q, v, τ in; v̇ and q̇ out
-    if fext is not None:
-        alg_bytes += es * 6 * model.n_bodies
+    if args.op == "mass_matrix_solve":
+        alg_bytes = es * (model.nq + model.nv + model.nv * (model.nv + 1) // 2 + model.nv)  # q, rhs in; lower M, x out
+        flops = 5.8e3 + 18.2e3
+        metric = "mass_matrix! + Cholesky solves/sec (Atlas 30-DoF, batch)"
+        opname = f"{args.dtype} mass_matrix! + Cholesky solve"
+    else:
+        alg_bytes = es * (model.nq + 3 * model.nv + model.nq + (model.nc if model.nc else 0))  # q, v, τ in; v̇ and q̇ out (+ λ)
+        if headline_fext:
+            alg_bytes += es * 6 * model.n_bodies
+        flops = ABA_FLOPS_PER_EVAL if model.nc == 0 else 43.0e3 * model.nv / 36.0
+        metric = "ABA dynamics! evals/sec (Atlas 30-DoF, batch)" if args.model.startswith("atlas") else f"dynamics! evals/sec ({args.model}, batch)"
+        opname = f"{args.dtype} " + ("fused ABA dynamics!" if model.nc == 0 else "dynamics! with loop joints (RNEA + CRBA + constrained solve)")
     achieved_gbs = alg_bytes * B / (kernel_ms * 1e-3) / 1e9
     peak_tf = FP64_VECTOR_PEAK_TF if args.dtype == "f64" else FP32_VECTOR_PEAK_TF
-    achieved_tf = ABA_FLOPS_PER_EVAL * B / (kernel_ms * 1e-3) / 1e12
+    achieved_tf = flops * B / (kernel_ms * 1e-3) / 1e12
 
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    # HBM traffic from the PMC passes (scripts/gpu_profile.sh writes it with the hash of the kernel sources it was measured on):
+    # a figure from other sources is not passed along
+    traffic, traffic_stale = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(f"{args.model}_{args.dtype}_B{B}")
+            rec = json.load(open(pmc))
+            traffic_stale = rec.get("source_hash") != kernel_source_hash()
+            if not traffic_stale:
+                traffic = rec.get(f"{args.model}_{args.dtype}_B{B}_{args.op}")
         except Exception:
             traffic = None
 
     out = {
-        "metric": "ABA dynamics! evals/sec (Atlas 30-DoF, batch)", "value": value, "unit": "evals/s",
+        "metric": metric, "value": value, "unit": "evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{args.model} nq={model.nq} nv={model.nv} bodies={model.n_bodies}, batch={B}/GPU, "
-                               f"{args.dtype} fused ABA dynamics! (BASELINE configs[1])",
-                   "batch_per_gpu": B, "layout": args.layout, "external_wrenches": bool(args.wrenches),
+        "config": {"workload": f"{args.model} nq={model.nq} nv={model.nv} bodies={model.n_bodies}, batch={B}/GPU, {opname} ({CONFIGS[args.config]['label']})",
+                   "batch_per_gpu": B, "layout": args.layout, "external_wrenches": headline_fext,
                    "hip_graph": bool(args.graph), "parallelism": f"batch-sharded x{world}, no data-path collective",
-                   "gather_every_step": bool(args.gather_every_step)},
+                   "gather_every_step": bool(args.gather_every_step and world > 1), "inputs": "resident in HBM, re-evaluated every step (L2 / Infinity-Cache hits)"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode(), "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": alg_bytes},
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
+                     "kernel": (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode() if args.op == "dynamics" and model.nc == 0 else
+                     ("crba_kernel + chol_mfma_kernel" if args.op == "mass_matrix_solve" else "rnea_kernel + crba_kernel + loop_solve_small_kernel"),
+                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": alg_bytes},
         "alu": {"bound": "fp64 vector ALU" if args.dtype == "f64" else "fp32 vector ALU", "achieved": achieved_tf, "peak": peak_tf,
-                "unit": "TFLOP/s", "frac": achieved_tf / peak_tf, "flops_per_eval": ABA_FLOPS_PER_EVAL,
+                "unit": "TFLOP/s", "frac": achieved_tf / peak_tf, "flops_per_eval": flops,
                 "note": "the path is ALU/latency bound, not HBM bound (SURVEY.md F8): compulsory traffic is ~1.5 KB/eval"},
-        "parity_rel_err_vs_oracle": err,
-        "published_reference": {"dynamics!_us_per_eval": 9.874, "evals_per_s": 1.01e5, "hardware": "Apple M2, 1 thread, Julia 1.11",
+        "parity_rel_err_vs_oracle": err, "parity_check": check,
+        "published_reference": {"dynamics!_us_per_eval": 9.874, "evals_per_s": 1.01e5, "hardware": "Apple M2, 1 thread, Julia 1.11, WITH external wrenches",
                                 "source": "docs/src/benchmarks.md:71-78"},
     }
+    out.update(extra)
     if gather_ms is not None:
         out["rccl_all_gather_vdot_ms"] = gather_ms
 
-    if not args.no_pipelined and world == 1:
+    if not args.no_pipelined and world == 1 and args.op == "dynamics" and model.nc == 0:
         # Informational, NOT `value`: the same step count with two INDEPENDENT batches of B states alternating on two HIP streams
-        # (one workspace each).  At B = 4096 a single launch leaves every SIMD with one wavefront (latency-bound, VALU busy ~36 %);
+        # (one workspace each).  At B = 4096 a single launch leaves every SIMD with one wavefront (latency-bound);
         # a second launch in flight gives each SIMD a second wavefront to interleave.  Callers whose batches do not depend on each
         # other (sampling-based control, the reference's own benchmark loop) can run this way; `simulate` cannot.
         try:
@@ -230,31 +406,26 @@ def main():
             rbd.set_configuration_(state2, rbd.rand_configuration(model, B, rng2))
             rbd.set_velocity_(state2, rbd.rand_velocity(model, B, rng2))
             s_a, s_b = torch.cuda.Stream(device), torch.cuda.Stream(device)
-            L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(s_a.cuda_stream))
-            L.rbd_workspace_set_stream(state2.ws.handle, ctypes.c_void_p(s_b.cuda_stream))
-            opts2 = state2._opts({"aba": 0, "aba_lanes": 2, "aba_chains": 3, "aba_banks": 4, "aba_tracks": 5}[args.algorithm])
-            c_args2 = (state2.ws.handle, B, ctypes.c_void_p(state2.q.data_ptr()), ctypes.c_void_p(state2.v.data_ptr()),
-                       ctypes.c_void_p(d_tau.data_ptr()), ctypes.c_void_p(d_fext.data_ptr() if d_fext is not None else 0),
-                       ctypes.c_void_p(result2.vd.data_ptr()), ctypes.c_void_p(result2.qd.data_ptr()), ctypes.c_void_p(0), ctypes.byref(opts2))
-            both = (c_args, c_args2)
+            L.rbd_workspace_set_stream(state.ws.handle, vp(s_a.cuda_stream))
+            L.rbd_workspace_set_stream(state2.ws.handle, vp(s_b.cuda_stream))
+            both = (make_step(headline_fext), make_step(headline_fext, state2, result2))
             for k in range(args.warmup):
-                dyn(*both[k & 1])
+                both[k & 1]()
             torch.cuda.synchronize(device)
             p0 = time.perf_counter()
             for k in range(args.steps):
-                dyn(*both[k & 1])
+                both[k & 1]()
             torch.cuda.synchronize(device)
             p1 = time.perf_counter()
-            L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(stream.cuda_stream))
+            L.rbd_workspace_set_stream(state.ws.handle, vp(stream.cuda_stream))
             out["pipelined_independent_batches"] = {"streams": 2, "value": B * args.steps / (p1 - p0), "unit": "evals/s",
                                                     "ms_per_step": (p1 - p0) / args.steps * 1e3,
                                                     "note": "informational: two independent batches in flight; not the headline value"}
         except Exception as e:  # never lose the headline line to the extra measurement
             out["pipelined_independent_batches"] = f"failed: {type(e).__name__}: {e}"
 
-    if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only (rank 0 of a multi-GPU run would time it while its peers wait)
+    if not args.no_cpu_baseline and world == 1 and model.nc == 0:  # the CPU leg is reported at N = 1 only (rank 0 of a multi-GPU run would time it while its peers wait)
         # host threads actually available to this process: affinity mask, capped by the cgroup CPU quota when there is one
-        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         try:
             quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
             if quota != "max":
@@ -262,9 +433,9 @@ def main():
         except Exception:
             pass
         os.environ.setdefault("OMP_PROC_BIND", "close")
-        S1 = 2048
+        S1 = min(B, 2048)
         qs, vs, ts = q[:S1], v[:S1], tau[:S1]
-        fs = fext[:S1] if fext is not None else None
+        fs = fext_all[:S1] if headline_fext else None
         oracle.dynamics(model, qs[:64], vs[:64], ts[:64], fs[:64] if fs is not None else None)  # warm
         reps1 = 0
         c0 = time.perf_counter()
@@ -275,7 +446,7 @@ def main():
         # all cores: a sample large enough that the OpenMP fork/join is amortised (2048 states per thread per call)
         tile = max(1, (ncores * 2048 + B - 1) // B)
         qN, vN, tN = np.tile(q, (tile, 1)), np.tile(v, (tile, 1)), np.tile(tau, (tile, 1))
-        fN = np.tile(fext, (tile, 1)) if fext is not None else None
+        fN = np.tile(fext_all, (tile, 1)) if headline_fext else None
         SN = qN.shape[0]
         oracle.dynamics(model, qN, vN, tN, fN, nthreads=ncores)  # warm (thread pool, per-thread scratch)
         repsN = 0

@@ -179,6 +179,19 @@ int rbd_inverse_dynamics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, 
 int rbd_dynamics_bias(rbd_ws_t* ws, int32_t B, const void* q, const void* v, const void* fext,
                       void* c_out, const rbd_opts_t* opts);
 
+/* The same two entry points with the per-body outputs the reference fills beside the torques (every output nullable):
+ *   jointwrenches_out[6*n_bodies×B]  jointwrenchesout of inverse_dynamics! / result.jointwrenches of dynamics_bias! — the wrench across
+ *                                    the joint above each body after joint_wrenches_and_torques! (src/mechanism_algorithms.jl:442-459);
+ *   accelerations_out[6*n_bodies×B]  accelerations of inverse_dynamics! (spatial_accelerations!, :387-417: root acceleration −g included)
+ *                                    / result.accelerations of dynamics_bias! (bias_accelerations!, :377-385);
+ * both in the ROOT frame, (angular; linear) / (torque; force), bodies in the flat model's order, layout as fext.  With them
+ * DynamicsResult's accelerations / jointwrenches / totalwrenches (src/dynamics_result.jl:26-29) are complete: totalwrenches of a
+ * mechanism without contact points is the caller's own fext (mechanism_algorithms.jl:851-855).                                  */
+int rbd_inverse_dynamics_bodies(rbd_ws_t* ws, int32_t B, const void* q, const void* v, const void* vdot, const void* fext, void* tau_out,
+                                void* jointwrenches_out, void* accelerations_out, const rbd_opts_t* opts);
+int rbd_dynamics_bias_bodies(rbd_ws_t* ws, int32_t B, const void* q, const void* v, const void* fext, void* c_out, void* jointwrenches_out,
+                             void* accelerations_out, const rbd_opts_t* opts);
+
 /* M_out: nv×nv column-major per state (element (i,j) of state b at
  * M[(j*nv+i)*B + b] for SOA, M[b*nv*nv + j*nv + i] for AOS). Like the
  * reference (Symmetric, uplo 'L') only the LOWER triangle i>=j is written.     */

@@ -192,6 +192,23 @@ def body_kinematics(model, q, v, vdot, dtype=np.float64):
     return H, T, A
 
 
+def inverse_dynamics_bodies(model, q, v, vdot=None, fext=None, dtype=np.float64):
+    """(tau [B, nv], jointwrenches [B, nb, 6], accelerations [B, nb, 6]) of inverse_dynamics! (vdot given) / dynamics_bias! (vdot None),
+    root frame; accelerations include the root's −gravity as the reference's spatial_accelerations! / bias_accelerations! leave them."""
+    sfx, ct = _sfx(dtype)
+    f = getattr(lib(), "rbdo_inverse_dynamics_bodies" + sfx)
+    f.restype = ctypes.c_int
+    B, nb = q.shape[0], model.n_bodies
+    q, v = np.ascontiguousarray(q, dtype), np.ascontiguousarray(v, dtype)
+    vdot = None if vdot is None else np.ascontiguousarray(vdot, dtype)
+    fext = None if fext is None else np.ascontiguousarray(fext, dtype)
+    tau, jw, acc = np.zeros((B, model.nv), dtype), np.zeros((B, nb, 6), dtype), np.zeros((B, nb, 6), dtype)
+    for b in range(B):
+        assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(v[b], ct), _ptr(None if vdot is None else vdot[b], ct),
+                 _ptr(None if fext is None else fext[b], ct), _ptr(tau[b], ct), _ptr(jw[b], ct), _ptr(acc[b], ct)) == 0
+    return tau, jw, acc
+
+
 def momentum(model, q, v, dtype=np.float64):
     """(momentum [B, 6], momentum_rate_bias [B, 6]) in the root frame."""
     sfx, ct = _sfx(dtype)

@@ -375,6 +375,24 @@ int FN(rbdo_inverse_dynamics)(const rbd_flat_model_t* m, const REAL* q, const RE
 int FN(rbdo_dynamics_bias)(const rbd_flat_model_t* m, const REAL* q, const REAL* v, const REAL* fext, REAL* cvec) {
   return FN(rbdo_inverse_dynamics)(m, q, v, NULL, fext, cvec);
 }
+/* inverse_dynamics!(τ, jointwrenchesout, accelerations, state, v̇, externalwrenches) with its per-body outputs (:542-553): accelerations[b]
+ * as spatial_accelerations! leaves them (root acceleration −gravity included, :405-415; vd == NULL: bias_accelerations! :377-385) and
+ * jointwrenchesout[b] after joint_wrenches_and_torques! (:442-459); both in the root frame, 6 per body.                               */
+int FN(rbdo_inverse_dynamics_bodies)(const rbd_flat_model_t* m, const REAL* q, const REAL* v, const REAL* vd, const REAL* fext, REAL* tau,
+                                     REAL* jointwrenches, REAL* accelerations) {
+  CACHE c;
+  if (FN(cache_alloc)(m, &c)) return RBD_ERR_OUT_OF_MEMORY;
+  FN(update_transforms)(m, q, &c);
+  FN(update_motion_subspaces)(m, q, &c);
+  FN(update_twists)(m, v, &c);
+  FN(update_inertias)(m, &c);
+  FN(accelerations)(m, vd, &c);
+  FN(wrenches_and_torques)(m, fext, &c, tau);
+  if (accelerations) memcpy(accelerations, c.A, sizeof(REAL) * 6 * c.nb);
+  if (jointwrenches) memcpy(jointwrenches, c.W, sizeof(REAL) * 6 * c.nb);
+  FN(cache_free)(&c);
+  return RBD_OK;
+}
 
 static int FN(supports)(const rbd_flat_model_t* m, int jointj, int bodyi) {
   /* support_set_masks: src/mechanism_state.jl:95-98 — joint j supports body i iff body(j) is i or an ancestor */

@@ -19,7 +19,7 @@ SYMBOLS = (
     "rbd_model_create", "rbd_model_destroy", "rbd_model_dims", "rbd_workspace_create", "rbd_workspace_destroy",
     "rbd_workspace_set_stream", "rbd_sync", "rbd_dynamics", "rbd_inverse_dynamics", "rbd_dynamics_bias", "rbd_mass_matrix",
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
-    "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan", "rbd_model_track_plan",
+    "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan", "rbd_model_track_plan", "rbd_inverse_dynamics_bodies", "rbd_dynamics_bias_bodies",
 )
 
 
@@ -57,6 +57,8 @@ def lib():
         L.rbd_dynamics.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_inverse_dynamics.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_dynamics_bias.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_inverse_dynamics_bodies.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_dynamics_bias_bodies.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_mass_matrix.argtypes = [vp, i32, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_mass_matrix_solve.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_dynamics_result.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]

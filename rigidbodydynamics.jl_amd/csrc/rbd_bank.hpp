@@ -100,13 +100,13 @@ template <typename T, bool CROSS> RBD_DEV void bank_handoff(int l, int ns, const
       const T g = gv.IA[SI(i, j)] - W[i] * gv.U[j];
       Iac[i] += g * gv.cb[j];
       if (j > i) Iac[j] += g * gv.cb[i];
-      if (!CROSS) tk.IA[SI(i, j)] += from_next_lane(g) * m0;
+      if (!CROSS) tk.IA[SI(i, j)] += keep(from_next_lane(g), m0);
     }
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     gp[k] = gv.pA[k] + Iac[k] + W[k] * gv.u;
-    if (!CROSS) tk.pA[k] += from_next_lane(gp[k]) * m0;
+    if (!CROSS) tk.pA[k] += keep(from_next_lane(gp[k]), m0);
   }
 #pragma unroll 1
   for (int s = CROSS ? 0 : 1; s < ns; ++s) {
@@ -119,13 +119,13 @@ template <typename T, bool CROSS> RBD_DEV void bank_handoff(int l, int ns, const
 #pragma unroll
       for (int j = i; j < 6; ++j) tmp[j] = shfl(gv.IA[SI(i, j)] - W[i] * gv.U[j], src);
 #pragma unroll
-      for (int j = i; j < 6; ++j) tk.IA[SI(i, j)] += tmp[j] * mask;
+      for (int j = i; j < 6; ++j) tk.IA[SI(i, j)] += keep(tmp[j], mask);
     }
     T tp[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) tp[k] = shfl(gp[k], src);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) tk.pA[k] += tp[k] * mask;
+    for (int k = 0; k < 6; ++k) tk.pA[k] += keep(tp[k], mask);
   }
 }
 
@@ -404,7 +404,7 @@ template <typename T, bool CROSS> RBD_DEV void rnea_gather(int l, int ns, const 
 #pragma unroll
     for (int k = 0; k < 6; ++k) t[k] = from_next_lane(gv.w[k]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) tk.w[k] += t[k] * m0;
+    for (int k = 0; k < 6; ++k) tk.w[k] += keep(t[k], m0);
   }
 #pragma unroll 1
   for (int s = CROSS ? 0 : 1; s < ns; ++s) {
@@ -415,7 +415,7 @@ template <typename T, bool CROSS> RBD_DEV void rnea_gather(int l, int ns, const 
 #pragma unroll
     for (int k = 0; k < 6; ++k) t[k] = shfl(gv.w[k], src);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) tk.w[k] += t[k] * mask;
+    for (int k = 0; k < 6; ++k) tk.w[k] += keep(t[k], mask);
   }
 }
 

@@ -696,17 +696,18 @@ int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const vo
 
 // inverse_dynamics! / dynamics_bias! (vdot == nullptr) through the lane mapping that fits the batch: same rule as run_aba
 static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const void* dv, const void* dvd, const void* df, void* dtau, void* dqd,
-                    Layout Lq, Layout Lv, Layout Lf) {
+                    Layout Lq, Layout Lv, Layout Lf, void* dacc = nullptr, void* djw = nullptr) {
   const rbd_model* m = w->model;
   if (mapping == RBD_ALGO_ABA_BANKS && m->bank_lps == 0) return RBD_ERR_UNSUPPORTED;
-  const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
+  // the per-body outputs (accelerations, joint wrenches) are written by the one-body-per-lane kernel
+  const bool banks = !dacc && !djw && m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
   if (banks) {
     const int ncol = m->has3dof ? 3 : 1;
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_bank<double>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_rnea_bank<float>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
   } else {
-    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dtau, dqd, nullptr, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dtau, dqd, nullptr, Lq, Lv, Lf, w->stream));
+    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dtau, dqd, nullptr, Lq, Lv, Lf, w->stream, dacc, djw));
+    else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dtau, dqd, nullptr, Lq, Lv, Lf, w->stream, dacc, djw));
   }
   return RBD_OK;
 }
@@ -817,7 +818,7 @@ int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const voi
 }
 
 static int rnea_common(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* vdot, const void* fext, void* tau_out,
-                       const rbd_opts_t* opts) {
+                       const rbd_opts_t* opts, void* jw_out = nullptr, void* acc_out = nullptr) {
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
@@ -827,19 +828,23 @@ static int rnea_common(rbd_ws_t* w, int32_t B, const void* q, const void* v, con
   HIP_TRY(hipSetDevice(w->device));
   const size_t es = esize(w);
   const void *dq = q, *dv = v, *dvd = vdot, *df = fext;
-  void* dt = tau_out;
+  void *dt = tau_out, *djw = jw_out, *dacc = acc_out;
+  const size_t bbytes = es * 6 * (size_t)m->nb * B;
   if (o.memory == RBD_MEM_HOST) {
     if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_in(w, 1, v, es * m->nv * B, &dv)) ||
         (st = stage_in(w, 2, vdot, es * m->nv * B, &dvd)) || (st = stage_in(w, 3, fext, es * 6 * m->nb * B, &df)) ||
-        (st = stage_out_alloc(w, 4, tau_out, es * m->nv * B, &dt)))
+        (st = stage_out_alloc(w, 4, tau_out, es * m->nv * B, &dt)) || (st = stage_out_alloc(w, 5, jw_out, bbytes, &djw)) ||
+        (st = stage_out_alloc(w, 6, acc_out, bbytes, &dacc)))
       return st;
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
   {
     Timed t(w);
-    if ((st = run_rnea(w, B, o.algorithm, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf))) return st;
+    if ((st = run_rnea(w, B, o.algorithm, dq, dv, dvd, df, dt, nullptr, Lq, Lv, Lf, dacc, djw))) return st;
   }
-  if (o.memory == RBD_MEM_HOST) return stage_out_copy(w, tau_out, dt, es * m->nv * B);
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_out_copy(w, tau_out, dt, es * m->nv * B)) || (st = stage_out_copy(w, jw_out, djw, bbytes)) || (st = stage_out_copy(w, acc_out, dacc, bbytes))) return st;
+  }
   return RBD_OK;
 }
 
@@ -852,6 +857,18 @@ int rbd_inverse_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, c
 
 int rbd_dynamics_bias(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* fext, void* c_out, const rbd_opts_t* opts) {
   return rnea_common(w, B, q, v, nullptr, fext, c_out, opts);
+}
+
+int rbd_inverse_dynamics_bodies(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* vdot, const void* fext, void* tau_out,
+                                void* jointwrenches_out, void* accelerations_out, const rbd_opts_t* opts) {
+  if (w && w->model->nloops > 0) return RBD_ERR_HAS_LOOPS;  // src/mechanism_algorithms.jl:549
+  if (!vdot && w && w->model->nv > 0) return RBD_ERR_INVALID_ARGUMENT;
+  return rnea_common(w, B, q, v, vdot, fext, tau_out, opts, jointwrenches_out, accelerations_out);
+}
+
+int rbd_dynamics_bias_bodies(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* fext, void* c_out, void* jointwrenches_out,
+                             void* accelerations_out, const rbd_opts_t* opts) {
+  return rnea_common(w, B, q, v, nullptr, fext, c_out, opts, jointwrenches_out, accelerations_out);
 }
 
 int rbd_mass_matrix(rbd_ws_t* w, int32_t B, const void* q, void* M_out, const rbd_opts_t* opts) {

@@ -144,6 +144,11 @@ template <int CTRL> RBD_DEV double dpp_mov(double x) {
 template <typename T> RBD_DEV T from_prev_lane(T x) { return dpp_mov<0x138>(x); }
 template <typename T> RBD_DEV T from_next_lane(T x) { return dpp_mov<0x130>(x); }
 
+// x where the mask is set, exactly 0 elsewhere.  The sweeps used to multiply a neighbour lane's value by a 0/1 mask; with several
+// states in one wavefront the neighbour can belong to ANOTHER state, and NaN * 0 = NaN let one diverged state poison the state packed
+// next to it.  A select keeps the states of a batch independent, as they are in the reference (one evaluation per call).
+template <typename T> RBD_HD T keep(T x, T mask) { return mask != T(0) ? x : T(0); }
+
 template <typename T> RBD_HD void cross3(const T* a, const T* b, T* o) {
   T x = a[1] * b[2] - a[2] * b[1];
   T y = a[2] * b[0] - a[0] * b[2];

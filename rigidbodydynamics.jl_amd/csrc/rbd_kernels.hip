@@ -47,7 +47,7 @@ template <typename T, int N> RBD_DEV void gather_add(const Body<T>& b, int l, in
   constexpr int CH = 9;  // moves in flight per batch (bounds the temporaries)
   if (s == 0) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) acc[k] += from_next_lane(give[k]) * mask;
+    for (int k = 0; k < N; ++k) acc[k] += keep(from_next_lane(give[k]), mask);
   } else {
     const int c = child_sel(b, s);
     const int src = take ? b.base + c : b.lane;
@@ -59,7 +59,7 @@ template <typename T, int N> RBD_DEV void gather_add(const Body<T>& b, int l, in
         if (k0 + k < N) tmp[k] = shfl(give[k0 + k], src);
 #pragma unroll
       for (int k = 0; k < CH; ++k)
-        if (k0 + k < N) acc[k0 + k] += tmp[k] * mask;
+        if (k0 + k < N) acc[k0 + k] += keep(tmp[k], mask);
     }
   }
 }
@@ -474,7 +474,7 @@ void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict
         if (INNER_FLOAT) g *= kI;
         Iac[i] += g * cb[j];
         if (j > i) Iac[j] += g * cb[i];
-        IA[SI(i, j)] += from_next_lane(g) * m0;
+        IA[SI(i, j)] += keep(from_next_lane(g), m0);
       }
     }
     T gp[6];
@@ -485,7 +485,7 @@ void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict
       for (int m = 0; m < NDOF; ++m) x += W[m][k] * u[m];
       gp[k] = x;
       if (INNER_FLOAT) gp[k] = inner_floating ? U[0][k] : gp[k];
-      pA[k] += from_next_lane(gp[k]) * m0;
+      pA[k] += keep(from_next_lane(gp[k]), m0);
     }
     const int ns = (int)M.nslots[l];
 #pragma unroll 1
@@ -505,13 +505,13 @@ void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict
           tmp[j] = shfl(g, src);
         }
 #pragma unroll
-        for (int j = i; j < 6; ++j) IA[SI(i, j)] += tmp[j] * mask;
+        for (int j = i; j < 6; ++j) IA[SI(i, j)] += keep(tmp[j], mask);
       }
       T tp[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) tp[k] = shfl(gp[k], src);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) pA[k] += tp[k] * mask;
+      for (int k = 0; k < 6; ++k) pA[k] += keep(tp[k], mask);
     }
   }
   if (b.level == 0 && ndof > 0) finish_joint();
@@ -589,7 +589,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
                                                    const T* __restrict__ vdot, const T* __restrict__ fext,
                                                    T* __restrict__ tau, T* __restrict__ qdot, T* __restrict__ body_out,
-                                                   Layout Lq, Layout Lv, Layout Lf) {
+                                                   Layout Lq, Layout Lv, Layout Lf, T* __restrict__ acc_out, T* __restrict__ jw_out) {
   Body<T> b;
   load_body(M, B, b);
   const T* rb = reinterpret_cast<const T*>(M.rb) + (b.sub < M.nb ? b.sub : 0) * RB_STRIDE;
@@ -615,6 +615,12 @@ __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* 
     for (int k = 0; k < 6; ++k) { o[12 + k] = Tw[k]; o[18 + k] = acc[k]; }
   }
 
+  if (acc_out != nullptr && b.valid) {
+    // accelerations[body] of inverse_dynamics! / the bias accelerations of dynamics_bias! (spatial_accelerations!, bias_accelerations!:
+    // mechanism_algorithms.jl:377-417), root frame, (angular; linear), 6 x n_bodies per state in the reference's body order
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc_out[(long)(6 * b.orig + k) * Lf.sk + b.state * Lf.sb] = acc[k];
+  }
   // newton_euler! (mechanism_algorithms.jl:428-439): w = I a + T x* I T - wext
   T w[6];
   {
@@ -642,6 +648,11 @@ __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* 
       for (int k = 0; k < 6; ++k) give[k] = w[k];
       gather_add<T, 6>(b, l, s, give, w);
     }
+  }
+  if (jw_out != nullptr && b.valid) {
+    // jointwrenchesout[body] (joint_wrenches_and_torques!, :442-459): the wrench across the joint above each body, root frame, (torque; force)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) jw_out[(long)(6 * b.orig + k) * Lf.sk + b.state * Lf.sb] = w[k];
   }
   // tau = S' w
   T out[6];
@@ -718,10 +729,10 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
     const T m0 = (takes && b.nchild >= 1) ? T(1) : T(0);
     T t[10];  // what this lane's children hand up (zero for lanes that take nothing at this step)
 #pragma unroll
-    for (int k = 0; k < 6; ++k) t[k] = from_next_lane(Ic.J[k]) * m0;
+    for (int k = 0; k < 6; ++k) t[k] = keep(from_next_lane(Ic.J[k]), m0);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) t[6 + k] = from_next_lane(Ic.c[k]) * m0;
-    t[9] = from_next_lane(Ic.m) * m0;
+    for (int k = 0; k < 3; ++k) t[6 + k] = keep(from_next_lane(Ic.c[k]), m0);
+    t[9] = keep(from_next_lane(Ic.m), m0);
     const int ns = (int)M.nslots[l];
 #pragma unroll 1
     for (int s = 1; s < ns; ++s) {
@@ -735,7 +746,7 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
       for (int k = 0; k < 3; ++k) u[6 + k] = shfl(Ic.c[k], src);
       u[9] = shfl(Ic.m, src);
 #pragma unroll
-      for (int k = 0; k < 10; ++k) t[k] += u[k] * mask;
+      for (int k = 0; k < 10; ++k) t[k] += keep(u[k], mask);
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) Ic.J[k] += t[k];
@@ -1107,9 +1118,9 @@ hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, c
 }
 template <typename T>
 hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
-                       void* qdot, void* body_out, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+                       void* qdot, void* body_out, Layout Lq, Layout Lv, Layout Lf, hipStream_t s, void* acc_out, void* jw_out) {
   hipLaunchKernelGGL(rnea_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)vdot,
-                     (const T*)fext, (T*)tau, (T*)qdot, (T*)body_out, Lq, Lv, Lf);
+                     (const T*)fext, (T*)tau, (T*)qdot, (T*)body_out, Lq, Lv, Lf, (T*)acc_out, (T*)jw_out);
   return hipGetLastError();
 }
 template <typename T>
@@ -1122,8 +1133,8 @@ hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Lay
 
 template hipError_t launch_aba<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t, const MkFuse*);
 template hipError_t launch_aba<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t, const MkFuse*);
-template hipError_t launch_rnea<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, hipStream_t);
-template hipError_t launch_rnea<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, hipStream_t, void*, void*);
+template hipError_t launch_rnea<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, hipStream_t, void*, void*);
 template hipError_t launch_crba<double>(const DevModel&, long, const void*, void*, Layout, Layout, int, hipStream_t);
 template hipError_t launch_crba<float>(const DevModel&, long, const void*, void*, Layout, Layout, int, hipStream_t);
 

@@ -185,11 +185,16 @@ def rand_(state: MechanismState, seed: int = 0):
 class DynamicsResult:
     """Output container with the reference's field names (src/dynamics_result.jl:11-36), batched."""
 
-    def __init__(self, mechanism, batch: int = 1, dtype: torch.dtype = torch.float64, device="cuda", layout: str = "aos"):
+    def __init__(self, mechanism, batch: int = 1, dtype: torch.dtype = torch.float64, device="cuda", layout: str = "aos", bodies: bool = False):
+        """bodies=True also allocates the per-body fields `accelerations`, `jointwrenches`, `totalwrenches` (src/dynamics_result.jl:26-29;
+        (B, 6*n_bodies) each, root frame) and makes `dynamics_` / `dynamics_bias_` fill them like the reference does."""
         self.model = _as_model(mechanism)
         f = self.model.flat
         self.batch, self.dtype, self.device, self.layout = int(batch), dtype, torch.device(device), layout
         z = lambda n: torch.zeros((batch, n) if layout == "aos" else (n, batch), dtype=dtype, device=self.device)
+        self.accelerations = z(6 * f.n_bodies) if bodies else None   # bias accelerations after dynamics! / dynamics_bias! (mechanism_algorithms.jl:377-385)
+        self.jointwrenches = z(6 * f.n_bodies) if bodies else None   # joint wrenches of the bias run (:442-459)
+        self.totalwrenches = z(6 * f.n_bodies) if bodies else None   # external + contact wrenches (:851-855)
         self.massmatrix = z(f.nv * f.nv)       # nv×nv column-major per state, lower triangle valid (Symmetric 'L')
         self.dynamicsbias = z(f.nv)
         self.qd = z(f.nq)                        # q̇
@@ -210,6 +215,21 @@ def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _check_result(result: DynamicsResult, state: MechanismState):
+    """A result built for another batch size, dtype, layout or device would be written out of bounds (the reference raises DimensionMismatch)."""
+    if result.batch != state.batch or result.dtype != state.dtype or result.layout != state.layout:
+        raise DimensionMismatch(f"DynamicsResult(batch={result.batch}, dtype={result.dtype}, layout={result.layout}) does not match "
+                                f"MechanismState(batch={state.batch}, dtype={state.dtype}, layout={state.layout})")
+    f = state.flat
+    for t, n, name in ((result.vd, f.nv, "v̇"), (result.qd, f.nq, "q̇"), (result.dynamicsbias, f.nv, "dynamicsbias"), (result.massmatrix, f.nv * f.nv, "massmatrix"),
+                       (result.accelerations, 6 * f.n_bodies, "accelerations"), (result.jointwrenches, 6 * f.n_bodies, "jointwrenches"),
+                       (result.totalwrenches, 6 * f.n_bodies, "totalwrenches")):
+        state._check(t, n, name)
+    if f.nc > 0:
+        state._check(result.constraintjacobian, f.nc * f.nv, "constraintjacobian")
+        state._check(result.constraintbias, f.nc, "constraintbias")
+
+
 def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[torch.Tensor] = None,
               externalwrenches: Optional[torch.Tensor] = None, stabilization_gains="default", algorithm: str = "aba"):
     """`dynamics!(result, state, torques, externalwrenches; stabilization_gains)` (src/mechanism_algorithms.jl:845-864):
@@ -218,6 +238,7 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
     algorithm="aba": fused articulated-body kernel (mapping chosen by batch size; "aba_tracks" / "aba_lanes" / "aba_banks" / "aba_chains" force one);
     "crba": the reference's own CRBA + Cholesky route, which also fills result.massmatrix and result.dynamicsbias."""
     f = state.flat
+    _check_result(result, state)
     state._check(torques, f.nv, "torques")
     state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
     state.ws.use_current_stream()
@@ -233,6 +254,17 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
                                              _ptr(result.constraintjacobian if f.nc else None),
                                              _ptr(result.constraintbias if f.nc else None), ctypes.byref(opts))
         _raise(st, "rbd_dynamics_result")
+    if result.accelerations is not None:
+        # what dynamics! leaves in the per-body fields: totalwrenches = externalwrenches (+ contact wrenches: none here), and the bias
+        # accelerations / joint wrenches of its dynamics_bias! call (mechanism_algorithms.jl:851-856)
+        if externalwrenches is None:
+            result.totalwrenches.zero_()
+        else:
+            result.totalwrenches.copy_(externalwrenches)
+        o2 = state._opts()
+        st = _capi.lib().rbd_dynamics_bias_bodies(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(externalwrenches), _ptr(result.dynamicsbias),
+                                                  _ptr(result.jointwrenches), _ptr(result.accelerations), ctypes.byref(o2))
+        _raise(st, "rbd_dynamics_bias_bodies")
     return None
 
 
@@ -240,17 +272,26 @@ _MAPPING = {"auto": _capi.ALGO_ABA, "lanes": _capi.ALGO_ABA_LANES, "banks": _cap
 
 
 def inverse_dynamics_(torquesout: torch.Tensor, state: MechanismState, vd: torch.Tensor,
-                      externalwrenches: Optional[torch.Tensor] = None, mapping: str = "auto"):
-    """`inverse_dynamics!(torquesout, jointwrenchesout, accelerations, state, v̇, externalwrenches)` (:542-553).
+                      externalwrenches: Optional[torch.Tensor] = None, mapping: str = "auto",
+                      jointwrenchesout: Optional[torch.Tensor] = None, accelerations: Optional[torch.Tensor] = None):
+    """`inverse_dynamics!(torquesout, jointwrenchesout, accelerations, state, v̇, externalwrenches)` (:542-553).  `jointwrenchesout` /
+    `accelerations` (optional, (B, 6*n_bodies), root frame): the per-body outputs the reference fills — the wrench across the joint above each
+    body and each body's spatial acceleration (root acceleration −gravity included, as `spatial_accelerations!` leaves it).
     mapping: lane mapping of the kernel ("auto": by batch size; "lanes" / "banks" force one — tests, benchmarks)."""
     f = state.flat
     state._check(torquesout, f.nv, "torquesout")
     state._check(vd, f.nv, "v̇")
     state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
+    state._check(jointwrenchesout, 6 * f.n_bodies, "jointwrenchesout")
+    state._check(accelerations, 6 * f.n_bodies, "accelerations")
     state.ws.use_current_stream()
     opts = state._opts(_MAPPING[mapping])
-    st = _capi.lib().rbd_inverse_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(vd), _ptr(externalwrenches),
-                                          _ptr(torquesout), ctypes.byref(opts))
+    if jointwrenchesout is None and accelerations is None:
+        st = _capi.lib().rbd_inverse_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(vd), _ptr(externalwrenches),
+                                              _ptr(torquesout), ctypes.byref(opts))
+    else:
+        st = _capi.lib().rbd_inverse_dynamics_bodies(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(vd), _ptr(externalwrenches),
+                                                     _ptr(torquesout), _ptr(jointwrenchesout), _ptr(accelerations), ctypes.byref(opts))
     _raise(st, "rbd_inverse_dynamics")
     return torquesout
 
@@ -263,8 +304,13 @@ def dynamics_bias_(result_or_out, state: MechanismState, externalwrenches: Optio
     state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
     state.ws.use_current_stream()
     opts = state._opts(_MAPPING[mapping])
-    st = _capi.lib().rbd_dynamics_bias(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(externalwrenches), _ptr(out),
-                                       ctypes.byref(opts))
+    if isinstance(result_or_out, DynamicsResult) and result_or_out.accelerations is not None:
+        _check_result(result_or_out, state)
+        st = _capi.lib().rbd_dynamics_bias_bodies(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(externalwrenches), _ptr(out),
+                                                  _ptr(result_or_out.jointwrenches), _ptr(result_or_out.accelerations), ctypes.byref(opts))
+    else:
+        st = _capi.lib().rbd_dynamics_bias(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(externalwrenches), _ptr(out),
+                                           ctypes.byref(opts))
     _raise(st, "rbd_dynamics_bias")
     return out
 

@@ -58,3 +58,28 @@ def test_shard_ranges_cover_batch():
             assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in rs]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launcher_spawns_the_ranks_it_is_asked_for():
+    """`python bench.py --gpus N` must start N ranks itself (it used to run one process whatever N said): the launcher path, on gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["ranks_counted"] == 2 and rec["asked"] == 2
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 2
+    assert "refusing" in json.loads(out.stdout.strip().splitlines()[-1])["error"]

@@ -8,6 +8,8 @@ Tolerances (stated per BASELINE.md §4):
         (SURVEY.md App. B; precedent atol 1e-3, test/test_mechanism_modification.jl:339);
         τ (RNEA) and M (CRBA) have no solve: relative 2e-5.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -18,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf", "randmech1", "randmech2", "randmech3", "inner_floating"]
 TD = {"f64": torch.float64, "f32": torch.float32}
+NT = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 1  # host threads for full-batch oracle runs
 ND = {"f64": np.float64, "f32": np.float32}
 
 
@@ -173,9 +176,8 @@ def test_batch_sizes_and_round_trip(rbd, oracle, models, B):
     rbd.dynamics_bias_(c, state, f)
     scale = float((t - c).abs().max())
     assert float((back - t).abs().max()) <= 1e-10 * max(1.0, scale)
-    n = min(B, 64)
-    ref = oracle.dynamics(model, q[:n], v[:n], tau[:n], fe[:n])
-    assert np.abs(host(result.vd, state)[:n] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    ref = oracle.dynamics(model, q, v, tau, fe, nthreads=NT)  # every state of the batch, also at the BASELINE size
+    assert np.abs(host(result.vd, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
 
 
 def test_kinetic_energy_identity_full_size(rbd, models):
@@ -256,9 +258,10 @@ def test_mass_matrix_solve_f32_config3(rbd, oracle, models):
     assert np.abs(xg - xr).max() <= 3e-2 * np.abs(xr).max()
 
 
-def test_mass_matrix_solve_full_size_property(rbd, models):
-    """configs[2] at full size (B = 65536 fp32): size-independent property M (M^-1 r) = r, checked on the GPU with the
-    GPU's own mass matrix (torch fp64 matmul as the checker)."""
+def test_mass_matrix_solve_full_size_property(rbd, oracle, models):
+    """configs[2] at full size (B = 65536 fp32): the GPU's M against the oracle's on 8192 states spread over the batch and x through
+    the backward error with the ORACLE's M there (a wrong-but-SPD M cannot pass), plus the size-independent property M (M^-1 r) = r
+    over the whole batch (torch fp64 matmul as the checker)."""
     model = models["atlas_floating"]
     B = 65536
     state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 23)
@@ -272,6 +275,16 @@ def test_mass_matrix_solve_full_size_property(rbd, models):
     res = torch.einsum("bij,bj->bi", Ms, x.double()) - rhs.double()
     eta = res.norm(dim=1) / (torch.linalg.matrix_norm(Ms) * x.double().norm(dim=1) + rhs.double().norm(dim=1))
     assert float(eta.max()) <= 1e-5
+    idx = np.arange(0, B, 8)  # 8192 states, every wavefront of the launch represented
+    Mo = oracle.mass_matrix(model, q[idx], nthreads=NT)
+    Mo = np.tril(Mo) + np.transpose(np.tril(Mo, -1), (0, 2, 1))
+    Mg = Ms[torch.as_tensor(idx, device=Ms.device)].cpu().numpy()
+    assert np.abs(Mg - Mo).max() <= 2e-5 * np.abs(Mo).max()  # fp32 CRBA, no solve involved
+    xg = x[torch.as_tensor(idx, device=x.device)].double().cpu().numpy()
+    r = tau[idx]
+    res = np.einsum("bij,bj->bi", Mo, xg) - r
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Mo, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(r, axis=1))
+    assert eta.max() <= 1e-5
 
 
 def test_not_positive_definite_is_reported(rbd, models):
@@ -581,11 +594,10 @@ def test_config4_shard_f32_full_size_round_trip(rbd, oracle, models):
     rbd.dynamics_bias_(c, state)
     rel = (back - t).norm(dim=1) / (t - c).norm(dim=1)
     assert float(rel.max()) <= 5e-4          # fp32 RNEA(ABA(τ)) − τ, cond(M) ≈ 5e5
-    n = 128
-    vd = host(result.vd, state)[:n]
-    resid = oracle.inverse_dynamics(model, q[:n], v[:n], vd) - tau[:n]
-    cc = oracle.dynamics_bias(model, q[:n], v[:n])
-    assert (np.linalg.norm(resid, axis=1) / np.linalg.norm(tau[:n] - cc, axis=1)).max() <= 2e-5
+    vd = host(result.vd, state)  # the whole shard against the oracle: fp32 backward error ||M v̇ + c − τ|| / ||τ − c|| with the fp64 oracle's RNEA
+    resid = oracle.inverse_dynamics(model, q, v, vd, nthreads=NT) - tau
+    cc = oracle.dynamics_bias(model, q, v, nthreads=NT)
+    assert (np.linalg.norm(resid, axis=1) / np.linalg.norm(tau - cc, axis=1)).max() <= 2e-5
 
 
 @pytest.mark.gpu
@@ -895,3 +907,91 @@ def test_mechanism_without_degrees_of_freedom(rbd, oracle):
     com = rbd.center_of_mass(state)
     _, _, com_ref = oracle.momentum_matrix(model, np.zeros((B, 0)), np.zeros((B, 0)))
     assert np.abs(com.cpu().numpy() - com_ref).max() <= 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "double_pendulum", "randmech1"])
+def test_batch_states_are_isolated_from_a_nan_state(rbd, models, name, dtype):
+    """The reference evaluates one state per call; here several states share a wavefront.  A state with NaN / Inf inputs (a diverged
+    trajectory) must not change its neighbours by one bit: every entry point and every lane mapping, against a clean run."""
+    model = models[name]
+    B = 37
+    state, q, v, tau, fe = make(rbd, model, B, dtype, "aos", 123)
+    t, f = dev(tau, state), dev(fe, state)
+    algos = ["aba_lanes"] + [a for a in ("aba_banks", "aba_chains", "aba_tracks") if name != "randmech1" and (a != "aba_banks" or rbd.bank_plan(model))]
+
+    def run_all():
+        out = {}
+        for a in algos:
+            r = rbd.DynamicsResult(model, B, dtype=TD[dtype])
+            rbd.dynamics_(r, state, t, f, algorithm=a)
+            out[a] = r.vd.clone()
+        tau_out = torch.zeros_like(state.v)
+        rbd.inverse_dynamics_(tau_out, state, t, f)
+        out["rnea"] = tau_out
+        r = rbd.DynamicsResult(model, B, dtype=TD[dtype])
+        rbd.mass_matrix_(r, state)
+        out["crba"] = torch.tril(r.massmatrix.reshape(B, model.nv, model.nv).transpose(1, 2)).clone()
+        torch.cuda.synchronize()
+        return out
+
+    clean = run_all()
+    bad = [5, 20]  # neighbours inside a wavefront for every states-per-wave of these models
+    state.q[bad[0]] = float("nan")
+    state.v[bad[1]] = float("inf")
+    dirty = run_all()
+    ok = torch.ones(B, dtype=torch.bool)
+    ok[bad] = False
+    for k in clean:
+        a, b = clean[k][ok.to(clean[k].device)], dirty[k][ok.to(clean[k].device)]
+        assert torch.equal(a, b), (k, float((a - b).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", MODELS)
+def test_per_body_outputs_of_inverse_dynamics_and_dynamics_f64(rbd, oracle, models, name, layout):
+    """The per-body results the reference leaves beside the torques: jointwrenchesout / accelerations of inverse_dynamics!
+    (src/mechanism_algorithms.jl:542-553) and result.accelerations / jointwrenches / totalwrenches after dynamics! (:851-856,
+    src/dynamics_result.jl:26-29), root frame, reference body order, at the reference's own atol 1e-10."""
+    model = models[name]
+    B, nb = 21, model.n_bodies
+    state, q, v, vd, fe = make(rbd, model, B, "f64", layout, 131)
+    tau = torch.zeros_like(state.v)
+    jw = torch.full_like(dev(fe, state), float("nan"))
+    acc = torch.full_like(jw, float("nan"))
+    rbd.inverse_dynamics_(tau, state, dev(vd, state), dev(fe, state), jointwrenchesout=jw, accelerations=acc)
+    t_ref, jw_ref, acc_ref = oracle.inverse_dynamics_bodies(model, q, v, vd, fe)
+    tol = lambda r: 1e-10 * max(1.0, np.abs(r).max())
+    assert np.abs(host(tau, state) - t_ref).max() <= tol(t_ref)
+    assert np.abs(host(jw, state).reshape(B, nb, 6) - jw_ref).max() <= tol(jw_ref)
+    assert np.abs(host(acc, state).reshape(B, nb, 6) - acc_ref).max() <= tol(acc_ref)
+    # dynamics!: v̇ as before, and the per-body fields hold what its dynamics_bias! call computed, totalwrenches = the external wrenches
+    for algorithm in ("aba", "crba"):
+        result = rbd.DynamicsResult(model, B, layout=layout, bodies=True)
+        rbd.dynamics_(result, state, dev(vd, state), dev(fe, state), algorithm=algorithm)
+        c_ref, jw_ref, acc_ref = oracle.inverse_dynamics_bodies(model, q, v, None, fe)
+        assert np.abs(host(result.vd, state) - oracle.dynamics(model, q, v, vd, fe)).max() <= 1e-10 * max(1.0, np.abs(oracle.dynamics(model, q, v, vd, fe)).max())
+        assert np.abs(host(result.dynamicsbias, state) - c_ref).max() <= tol(c_ref)
+        assert np.abs(host(result.jointwrenches, state).reshape(B, nb, 6) - jw_ref).max() <= tol(jw_ref)
+        assert np.abs(host(result.accelerations, state).reshape(B, nb, 6) - acc_ref).max() <= tol(acc_ref)
+        assert np.array_equal(host(result.totalwrenches, state), fe)
+    result = rbd.DynamicsResult(model, B, layout=layout, bodies=True)
+    rbd.dynamics_(result, state)  # no external wrenches: totalwrenches are zero
+    assert float(result.totalwrenches.abs().max()) == 0.0 if nb else True
+
+
+@pytest.mark.gpu
+def test_result_must_match_state(rbd, models):
+    """A DynamicsResult of another batch size / dtype / layout is refused (the reference would raise DimensionMismatch) instead of being
+    written out of bounds."""
+    model = models["atlas_floating"]
+    state, *_ = make(rbd, model, 8, "f64", "aos", 140)
+    for bad in (rbd.DynamicsResult(model), rbd.DynamicsResult(model, 8, dtype=torch.float32), rbd.DynamicsResult(model, 8, layout="soa")):
+        with pytest.raises((rbd.DimensionMismatch, ValueError)):
+            rbd.dynamics_(bad, state)
+    good = rbd.DynamicsResult(model, 8)
+    good.vd = torch.zeros(4, model.nv, dtype=torch.float64, device="cuda")
+    with pytest.raises(rbd.DimensionMismatch):
+        rbd.dynamics_(good, state)
