@@ -243,6 +243,20 @@ int rbd_momentum(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* ou
  * columns off the path are written as zeros. */
 int rbd_geometric_jacobian(rbd_ws_t* ws, int32_t B, const void* q, int32_t base_body, int32_t target_body, void* jac, const rbd_opts_t* opts);
 
+/* ---- multi-GPU: the one exchange step (SURVEY.md §8 e) -------------------------------------------------------------------------
+ * The batch shards by state — rank g of G owns states [g·B/G, (g+1)·B/G), model constants replicated, NO collective inside the
+ * dynamics — and the shards of DynamicsResult.v̇ are brought together by one RCCL all-gather (or gather to one rank) over xGMI.
+ * One process per GPU.  rbd_comm_unique_id on one rank, the 128 bytes handed to the others by the caller (as with ncclGetUniqueId),
+ * then rbd_comm_create on every rank.  rbd_gather is asynchronous on `stream`; gathered holds world × count scalars in rank order
+ * (AOS buffers: the (world·B/G) × n matrix; SOA: one n × B/G block per rank).  librccl is opened on first use.                  */
+typedef struct rbd_comm rbd_comm_t;
+int rbd_comm_unique_id(void* id128);
+int rbd_comm_create(const void* id128, int32_t world, int32_t rank, int32_t device, rbd_comm_t** out);
+int rbd_comm_destroy(rbd_comm_t* comm);
+int rbd_comm_info(const rbd_comm_t* comm, int32_t* world, int32_t* rank);
+int rbd_gather(rbd_comm_t* comm, int32_t dtype, const void* shard, void* gathered, int64_t count, int32_t root /* < 0: every rank */, void* stream);
+const char* rbd_comm_last_error(void);
+
 /* ---- diagnostics ------------------------------------------------------------ */
 const char* rbd_status_string(int status);
 const char* rbd_last_hip_error(void);   /* thread-local text of the last HIP failure     */

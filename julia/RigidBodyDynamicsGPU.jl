@@ -1,30 +1,36 @@
 # RigidBodyDynamicsGPU.jl — thin `ccall` shim that places librbd_hip.so (include/rbd_hip.h) under
 # RigidBodyDynamics.jl's own generics for the batched hot path.
 #
-# NOT EXECUTED IN THIS REPO: the build image has no Julia toolchain (SURVEY.md F3). The file shows the binding a
-# maintainer of the reference would add; the tested boundary is the C ABI itself (tests/ drive it through ctypes).
+# EXPERIMENTAL / NOT EXECUTED IN THIS REPO: the build image has no Julia toolchain (SURVEY.md F3).  The file shows the binding a
+# maintainer of the reference would add; the tested boundary is the C ABI itself (tests/ drive it through ctypes), and
+# scripts/check_julia_ccalls.py (run by tests/test_capi_symbols.py) checks every `ccall` here against include/rbd_hip.h — symbol
+# name, argument count, pointer-vs-integer kind of every argument — so the shim cannot drift from the header unnoticed.
 #
 # Usage sketch:
 #     using RigidBodyDynamics, RigidBodyDynamicsGPU
 #     mechanism = parse_urdf("atlas.urdf", floating = true)
-#     state  = BatchedMechanismState(mechanism, 4096)            # q :: nq × B, v :: nv × B   (one state per column)
+#     state  = BatchedMechanismState(mechanism, 4096)            # q :: nq × B, v :: nv × B (one state per column), DEVICE resident
 #     result = BatchedDynamicsResult(mechanism, 4096)
-#     rand!(state)
-#     dynamics!(result, state, τ)                                 # τ :: nv × B ; fills result.v̇, result.q̇
-#     inverse_dynamics!(τout, state, v̇) ; mass_matrix!(result, state) ; dynamics_bias!(result, state)
+#     copyto!(state.q, qhost); copyto!(state.v, vhost)           # or storage = :host for plain Matrix buffers (PCIe inside every call)
+#     dynamics!(result, state, τ)                                 # τ :: nv × B ; fills result.v̇, result.q̇ (asynchronous; synchronize(state))
+#     inverse_dynamics!(τout, jointwrenches, accelerations, state, v̇, externalwrenches)
+#     mass_matrix!(result, state) ; dynamics_bias!(result, state) ; dynamics!(ẋ, result, state, x)
 module RigidBodyDynamicsGPU
 
 using RigidBodyDynamics
-using RigidBodyDynamics: Mechanism, MechanismState, DynamicsResult, Joint, JointType, Revolute, Prismatic, Fixed,
-    QuaternionFloating, SinCosRevolute, tree_joints, non_tree_joints, predecessor, successor, joint_to_predecessor,
-    joint_to_successor, spatial_inertia, joint_type, num_positions, num_velocities, num_constraints, root_body, modcount
-using RigidBodyDynamics.Spatial: rotation, translation
-import RigidBodyDynamics: dynamics!, inverse_dynamics!, mass_matrix!, dynamics_bias!
+using RigidBodyDynamics: Mechanism, MechanismState, DynamicsResult, Joint, JointType, Revolute, Prismatic, Fixed, Planar, QuaternionSpherical,
+    QuaternionFloating, SinCosRevolute, RigidBody, BodyID, Wrench, tree_joints, non_tree_joints, predecessor, successor, joint_to_predecessor,
+    joint_to_successor, spatial_inertia, joint_type, num_positions, num_velocities, num_constraints, root_body, modcount, bodies
+using RigidBodyDynamics.Spatial: rotation, translation, angular, linear
+# the generics this file adds methods to (src/RigidBodyDynamics.jl:143-155 exports them)
+import RigidBodyDynamics: dynamics!, inverse_dynamics!, mass_matrix!, dynamics_bias!, momentum_matrix!, geometric_jacobian!, center_of_mass,
+    kinetic_energy, gravitational_potential_energy, momentum, momentum_rate_bias, simulate
 using LinearAlgebra
 
-export BatchedMechanismState, BatchedDynamicsResult, librbd_hip
+export BatchedMechanismState, BatchedDynamicsResult, DeviceMatrix, RbdComm, gather!, synchronize, librbd_hip
 
 const librbd_hip = Ref("librbd_hip.so")   # set to <repo>/rigidbodydynamics.jl_amd/csrc/librbd_hip.so
+const libhip = Ref("libamdhip64.so")
 
 # ---- status codes -> Julia exceptions (same types the reference throws) --------------------------------------
 function check(status::Cint, where::String)
@@ -36,6 +42,39 @@ function check(status::Cint, where::String)
     status == 8 && throw(PosDefException(0))                                          # LAPACK.potrf!
     error("$where: $msg ($(unsafe_string(ccall((:rbd_last_hip_error, librbd_hip[]), Cstring, ()))))")
 end
+
+# ---- device-resident n × B buffers without a GPU array package: hipMalloc / hipMemcpy straight from libamdhip64 -------------------
+mutable struct DeviceMatrix{T}
+    ptr::Ptr{T}
+    dims::NTuple{2, Int}
+end
+function DeviceMatrix{T}(n::Integer, B::Integer) where {T}
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    ccall((:hipMalloc, libhip[]), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, max(1, n * B) * sizeof(T)) == 0 || error("hipMalloc failed")
+    ccall((:hipMemset, libhip[]), Cint, (Ptr{Cvoid}, Cint, Csize_t), p[], 0, max(1, n * B) * sizeof(T))
+    d = DeviceMatrix{T}(Ptr{T}(p[]), (Int(n), Int(B)))
+    finalizer(x -> ccall((:hipFree, libhip[]), Cint, (Ptr{Cvoid},), x.ptr), d)
+    d
+end
+Base.size(d::DeviceMatrix) = d.dims
+Base.size(d::DeviceMatrix, i) = d.dims[i]
+Base.pointer(d::DeviceMatrix) = d.ptr
+Base.unsafe_convert(::Type{Ptr{T}}, d::DeviceMatrix{T}) where {T} = d.ptr
+function Base.copyto!(d::DeviceMatrix{T}, h::AbstractMatrix{T}) where {T}     # host -> device
+    size(h) == d.dims || throw(DimensionMismatch())
+    hc = Matrix{T}(h)
+    ccall((:hipMemcpy, libhip[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), d.ptr, hc, sizeof(hc), 1) == 0 || error("hipMemcpy failed")
+    d
+end
+function Base.copyto!(h::Matrix{T}, d::DeviceMatrix{T}) where {T}             # device -> host
+    size(h) == d.dims || throw(DimensionMismatch())
+    ccall((:hipMemcpy, libhip[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), h, d.ptr, sizeof(h), 2) == 0 || error("hipMemcpy failed")
+    h
+end
+Base.Array(d::DeviceMatrix{T}) where {T} = copyto!(Matrix{T}(undef, d.dims...), d)
+const Buffer{T} = Union{Matrix{T}, DeviceMatrix{T}}
+newbuffer(::Val{:device}, ::Type{T}, n, B) where {T} = DeviceMatrix{T}(n, B)
+newbuffer(::Val{:host}, ::Type{T}, n, B) where {T} = zeros(T, n, B)
 
 # ---- C structs (field order == include/rbd_hip.h) -------------------------------------------------------------
 struct RbdLoopJoint
@@ -80,6 +119,7 @@ mutable struct FlatModelHandle
     modcount::Int
     nq::Int; nv::Int; nc::Int; nb::Int
     bodyindex::Dict{RigidBody, Int32}   # body -> index in the flat model (-1 = root body)
+    bodyids::Dict{BodyID, Int32}
 end
 
 function FlatModelHandle(mechanism::Mechanism)
@@ -102,7 +142,9 @@ function FlatModelHandle(mechanism::Mechanism)
     loops = RbdLoopJoint[]
     for j in non_tree_joints(mechanism)
         jt = joint_type(j)
-        Rz = jt isa Union{Revolute, Prismatic} ? rowmajor(jt.rotation_from_z_aligned) :
+        # rotation_from_z_aligned: revolute.jl:12-17, prismatic.jl, sin_cos_revolute.jl:13 (all three carry the field; the C side builds
+        # the constraint wrench basis of a loop joint from its columns)
+        Rz = jt isa Union{Revolute, Prismatic, SinCosRevolute} ? rowmajor(jt.rotation_from_z_aligned) :
              jt isa Planar ? rowmajor(hcat(jt.x_axis, jt.y_axis, jt.rot_axis)) :      # columns (x, y, x × y): include/rbd_hip.h
              rowmajor(Matrix(1.0I, 3, 3))
         push!(loops, RbdLoopJoint(bodyindex[predecessor(j, mechanism)], bodyindex[successor(j, mechanism)], jointtag(jt), 0,
@@ -119,110 +161,165 @@ function FlatModelHandle(mechanism::Mechanism)
         check(ccall((:rbd_model_create, librbd_hip[]), Cint, (Ref{RbdFlatModel}, Ref{Ptr{Cvoid}}), desc, handle), "rbd_model_create")
     end
     m = FlatModelHandle(handle[], modcount(mechanism), num_positions(mechanism), num_velocities(mechanism),
-        sum(num_constraints, non_tree_joints(mechanism); init = 0), nb, Dict{RigidBody, Int32}(bodyindex))
+        sum(num_constraints, non_tree_joints(mechanism); init = 0), nb, Dict{RigidBody, Int32}(bodyindex),
+        Dict{BodyID, Int32}(BodyID(b) => i for (b, i) in bodyindex))
     finalizer(x -> ccall((:rbd_model_destroy, librbd_hip[]), Cint, (Ptr{Cvoid},), x.handle), m)
     m
 end
 
 # ---- batched state / result: same field names as the reference types -------------------------------------------
-mutable struct BatchedMechanismState{T}
+mutable struct BatchedMechanismState{T, A <: Buffer{T}}
     mechanism::Mechanism
     model::FlatModelHandle
     ws::Ptr{Cvoid}
-    q::Matrix{T}      # nq × B   (host buffers here; with AMDGPU.jl pass ROCArray pointers and MEM_DEVICE instead)
-    v::Matrix{T}      # nv × B
+    memory::Int32     # MEM_DEVICE: q, v (and every buffer handed to a call) are device pointers — the default; MEM_HOST: plain Matrix
+    q::A              # nq × B
+    v::A              # nv × B
 end
 
-function BatchedMechanismState(mechanism::Mechanism, B::Integer; T::Type = Float64, device::Integer = 0)
+"""`storage = :device` (default): q, v are `DeviceMatrix` — resident in HBM, calls are asynchronous on the workspace's stream;
+`storage = :host`: plain `Matrix` buffers, staged through PCIe inside every call (convenient, ~5× slower than the kernel)."""
+function BatchedMechanismState(mechanism::Mechanism, B::Integer; T::Type = Float64, device::Integer = 0, storage::Symbol = :device)
     model = FlatModelHandle(mechanism)
     ws = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:rbd_workspace_create, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
         model.handle, B, device, T === Float64 ? 0 : 1, C_NULL, ws), "rbd_workspace_create")
-    s = BatchedMechanismState{T}(mechanism, model, ws[], zeros(T, model.nq, B), zeros(T, model.nv, B))
+    q, v = newbuffer(Val(storage), T, model.nq, B), newbuffer(Val(storage), T, model.nv, B)
+    s = BatchedMechanismState{T, typeof(q)}(mechanism, model, ws[], storage === :device ? MEM_DEVICE : MEM_HOST, q, v)
     finalizer(x -> ccall((:rbd_workspace_destroy, librbd_hip[]), Cint, (Ptr{Cvoid},), x.ws), s)
     s
 end
+
+"wait for the asynchronous calls issued on this state's workspace; PosDefException if a mass matrix was not positive definite"
+synchronize(state::BatchedMechanismState) = check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+finish(state::BatchedMechanismState) = state.memory == MEM_HOST ? synchronize(state) : nothing   # host buffers must be complete on return
 
 # @modcountcheck (src/util.jl:61): re-flatten when the mechanism was modified
 function checkmodcount(state::BatchedMechanismState)
     modcount(state.mechanism) == state.model.modcount || throw(RigidBodyDynamics.ModificationCountMismatch("state out of date with mechanism"))
 end
 
-struct BatchedDynamicsResult{T}
-    massmatrix::Array{T, 3}     # nv × nv × B, lower triangles valid (Symmetric(…, :L) per state)
-    dynamicsbias::Matrix{T}     # nv × B
-    q̇::Matrix{T}; v̇::Matrix{T}; λ::Matrix{T}
-    constraintjacobian::Array{T, 3}; constraintbias::Matrix{T}
+struct BatchedDynamicsResult{T, A <: Buffer{T}}
+    massmatrix::A               # (nv·nv) × B: per state an nv × nv column-major matrix, lower triangle valid (Symmetric(…, :L))
+    dynamicsbias::A             # nv × B
+    q̇::A; v̇::A; λ::A
+    constraintjacobian::A; constraintbias::A
+    accelerations::A            # (6·n_bodies) × B — src/dynamics_result.jl:26-29, root frame, (angular; linear) per body
+    jointwrenches::A
+    totalwrenches::A
 end
-function BatchedDynamicsResult(mechanism::Mechanism, B::Integer; T::Type = Float64)
-    nq, nv = num_positions(mechanism), num_velocities(mechanism)
+function BatchedDynamicsResult(mechanism::Mechanism, B::Integer; T::Type = Float64, storage::Symbol = :device)
+    nq, nv, nb = num_positions(mechanism), num_velocities(mechanism), length(collect(tree_joints(mechanism)))
     nc = sum(num_constraints, non_tree_joints(mechanism); init = 0)
-    BatchedDynamicsResult{T}(zeros(T, nv, nv, B), zeros(T, nv, B), zeros(T, nq, B), zeros(T, nv, B), zeros(T, nc, B), zeros(T, nc, nv, B), zeros(T, nc, B))
+    z(n) = newbuffer(Val(storage), T, n, B)
+    r = (z(nv * nv), z(nv), z(nq), z(nv), z(nc), z(nc * nv), z(nc), z(6nb), z(6nb), z(6nb))
+    BatchedDynamicsResult{T, typeof(r[1])}(r...)
 end
 
-opts(; algorithm = 0, stabilization = 1, memory = MEM_HOST) = Ref(RbdOpts(LAYOUT_AOS, memory, algorithm, stabilization))
-nullable(x::AbstractArray) = pointer(x)
+opts(state; algorithm = 0, stabilization = 1) = Ref(RbdOpts(LAYOUT_AOS, state.memory, algorithm, stabilization))
+nullable(x) = pointer(x)
 nullable(::Nothing) = C_NULL
 batchsize(state) = size(state.q, 2)
 
+# externalwrenches: `nothing` (NullDict), a dense (6·n_bodies) × B buffer of root-frame wrenches (torque; force) per body, or the
+# reference's own `AbstractDict{BodyID, <:Wrench}` (root frame; applied to every state of the batch) which is densified here
+function densewrenches(state::BatchedMechanismState{T}, w::AbstractDict{BodyID, <:Wrench}) where {T}
+    nb, B = state.model.nb, batchsize(state)
+    h = zeros(T, 6nb, B)
+    for (id, wrench) in w
+        i = state.model.bodyids[id]
+        i < 0 && continue
+        h[6i+1:6i+3, :] .= angular(wrench); h[6i+4:6i+6, :] .= linear(wrench)
+    end
+    state.memory == MEM_HOST ? h : copyto!(DeviceMatrix{T}(6nb, B), h)
+end
+densewrenches(state, w) = w
+
 # ---- the four generics -----------------------------------------------------------------------------------------
 """`dynamics!(result, state, torques, externalwrenches; stabilization_gains)` — src/mechanism_algorithms.jl:845-864.
-`torques`: nv × B or `nothing` (zeros); `externalwrenches`: 6·n_bodies × B root-frame wrenches (torque; force) or `nothing`."""
+`torques`: nv × B or `nothing` (zeros).  Fills result.v̇, q̇ (λ, M, c, K, k on the reference's CRBA route) and, like the reference, the
+per-body fields: totalwrenches, and the bias accelerations / joint wrenches of its dynamics_bias! call."""
 function dynamics!(result::BatchedDynamicsResult{T}, state::BatchedMechanismState{T}, torques = nothing, externalwrenches = nothing;
-        stabilization_gains = :default, algorithm::Symbol = :aba) where {T}
+        stabilization_gains = :default, algorithm::Symbol = :aba, bodies::Bool = false) where {T}
     checkmodcount(state)
     B = batchsize(state)
     torques === nothing || size(torques) == (state.model.nv, B) || throw(DimensionMismatch("torques"))
-    o = opts(algorithm = algorithm === :aba ? 0 : 1, stabilization = stabilization_gains === nothing ? 0 : 1)
+    wext = densewrenches(state, externalwrenches)
+    o = opts(state; algorithm = algorithm === :aba ? 0 : 1, stabilization = stabilization_gains === nothing ? 0 : 1)
     λptr = state.model.nc > 0 ? pointer(result.λ) : C_NULL
     check(ccall((:rbd_dynamics, librbd_hip[]), Cint,
         (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
-        state.ws, B, state.q, state.v, nullable(torques), nullable(externalwrenches), result.v̇, result.q̇, λptr, o), "rbd_dynamics")
+        state.ws, B, state.q, state.v, nullable(torques), nullable(wext), result.v̇, result.q̇, λptr, o), "rbd_dynamics")
     if algorithm !== :aba || state.model.nc > 0
         check(ccall((:rbd_dynamics_result, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
             state.ws, B, result.massmatrix, result.dynamicsbias, state.model.nc > 0 ? pointer(result.constraintjacobian) : C_NULL,
             state.model.nc > 0 ? pointer(result.constraintbias) : C_NULL, o), "rbd_dynamics_result")
     end
-    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+    if bodies   # result.accelerations / jointwrenches as dynamics!'s own dynamics_bias! call leaves them (:851-856)
+        check(ccall((:rbd_dynamics_bias_bodies, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+            state.ws, B, state.q, state.v, nullable(wext), result.dynamicsbias, result.jointwrenches, result.accelerations, opts(state)), "rbd_dynamics_bias_bodies")
+    end
+    finish(state)
     nothing
 end
 
-"""`inverse_dynamics!(torquesout, jointwrenchesout, accelerations, state, v̇, externalwrenches)` — :542-553 (the per-body
-wrench/acceleration dictionaries are workspace-internal on the device)."""
-function inverse_dynamics!(torquesout::Matrix{T}, state::BatchedMechanismState{T}, v̇::Matrix{T}, externalwrenches = nothing) where {T}
+"""`dynamics!(ẋ, result, state, x, torques, externalwrenches; stabilization_gains)` — the ODE form, :880-889: x = [q; v] per column,
+ẋ = [q̇; v̇] (no additional state: there are no contact points)."""
+function dynamics!(ẋ::Matrix{T}, result::BatchedDynamicsResult{T}, state::BatchedMechanismState{T}, x::Matrix{T}, torques = nothing,
+        externalwrenches = nothing; stabilization_gains = :default) where {T}
+    nq, nv = state.model.nq, state.model.nv
+    size(x) == (nq + nv, batchsize(state)) || throw(DimensionMismatch("x"))
+    copyto!(state.q, x[1:nq, :]); copyto!(state.v, x[nq+1:end, :])          # copyto!(state, x), mechanism_state.jl:465-491
+    dynamics!(result, state, torques, externalwrenches; stabilization_gains = stabilization_gains)
+    synchronize(state)
+    ẋ[1:nq, :] .= result.q̇ isa Matrix ? result.q̇ : Array(result.q̇)          # copyto!(ẋ, result), dynamics_result.jl:89
+    ẋ[nq+1:end, :] .= result.v̇ isa Matrix ? result.v̇ : Array(result.v̇)
+    ẋ
+end
+
+"""`inverse_dynamics!(torquesout, jointwrenchesout, accelerations, state, v̇, externalwrenches)` — :542-553, the reference's own
+arity: `jointwrenchesout` / `accelerations` are (6·n_bodies) × B buffers (root frame) or `nothing`."""
+function inverse_dynamics!(torquesout::Buffer{T}, jointwrenchesout, accelerations, state::BatchedMechanismState{T}, v̇::Buffer{T},
+        externalwrenches = nothing) where {T}
     checkmodcount(state)
     B = batchsize(state)
     size(torquesout) == (state.model.nv, B) || error("length of torque vector is wrong")
-    check(ccall((:rbd_inverse_dynamics, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
-        state.ws, B, state.q, state.v, v̇, nullable(externalwrenches), torquesout, opts()), "rbd_inverse_dynamics")
-    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+    check(ccall((:rbd_inverse_dynamics_bodies, librbd_hip[]), Cint,
+        (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+        state.ws, B, state.q, state.v, v̇, nullable(densewrenches(state, externalwrenches)), torquesout, nullable(jointwrenchesout),
+        nullable(accelerations), opts(state)), "rbd_inverse_dynamics_bodies")
+    finish(state)
     torquesout
 end
+# the short form many callers use: inverse_dynamics!(τ, state, v̇, wext)
+inverse_dynamics!(torquesout::Buffer{T}, state::BatchedMechanismState{T}, v̇::Buffer{T}, externalwrenches = nothing) where {T} =
+    inverse_dynamics!(torquesout, nothing, nothing, state, v̇, externalwrenches)
 
-"""`dynamics_bias!(result, state)` — :496-498."""
+"""`dynamics_bias!(result, state)` — :496-498 (external wrenches = result.totalwrenches, as in the reference)."""
 function dynamics_bias!(result::BatchedDynamicsResult{T}, state::BatchedMechanismState{T}, externalwrenches = nothing) where {T}
     checkmodcount(state)
-    check(ccall((:rbd_dynamics_bias, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
-        state.ws, batchsize(state), state.q, state.v, nullable(externalwrenches), result.dynamicsbias, opts()), "rbd_dynamics_bias")
-    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+    check(ccall((:rbd_dynamics_bias_bodies, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+        state.ws, batchsize(state), state.q, state.v, nullable(densewrenches(state, externalwrenches)), result.dynamicsbias, result.jointwrenches,
+        result.accelerations, opts(state)), "rbd_dynamics_bias_bodies")
+    finish(state)
     result.dynamicsbias
 end
 
 """`mass_matrix!(M, state)` / `mass_matrix!(result, state)` — :248-274; lower triangles written (uplo == 'L')."""
-function mass_matrix!(M::Array{T, 3}, state::BatchedMechanismState{T}) where {T}
+function mass_matrix!(M::Buffer{T}, state::BatchedMechanismState{T}) where {T}
     checkmodcount(state)
     nv, B = state.model.nv, batchsize(state)
-    size(M) == (nv, nv, B) || throw(DimensionMismatch("mass matrix has wrong size"))
+    size(M) == (nv * nv, B) || throw(DimensionMismatch("mass matrix has wrong size"))
     check(ccall((:rbd_mass_matrix, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
-        state.ws, B, state.q, M, opts()), "rbd_mass_matrix")
-    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+        state.ws, B, state.q, M, opts(state)), "rbd_mass_matrix")
+    finish(state)
     M
 end
 mass_matrix!(result::BatchedDynamicsResult, state::BatchedMechanismState) = mass_matrix!(result.massmatrix, state)
 
 """`simulate(state0, final_time; Δt, stabilization_gains)` — src/simulate.jl:36-55 for the whole batch: Munthe-Kaas RK4 on the
 device (`rbd_simulate`), constant `torques` (the default control is `zero_torque!`); `state.q`, `state.v` are advanced in place."""
-function RigidBodyDynamics.simulate(state::BatchedMechanismState{T}, final_time; Δt = 1e-4, torques = nothing, stabilization_gains = :default) where {T}
+function simulate(state::BatchedMechanismState{T}, final_time; Δt = 1e-4, torques = nothing, stabilization_gains = :default) where {T}
     checkmodcount(state)
     nsteps, t = 0, zero(T)
     while t < final_time            # same loop as integrate(), src/ode_integrators.jl:311-314
@@ -230,62 +327,83 @@ function RigidBodyDynamics.simulate(state::BatchedMechanismState{T}, final_time;
     end
     check(ccall((:rbd_simulate, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
         state.ws, batchsize(state), state.q, state.v, nullable(torques), C_NULL, Float64(Δt), nsteps,
-        opts(stabilization = stabilization_gains === nothing ? 0 : 1)), "rbd_simulate")
-    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+        opts(state; stabilization = stabilization_gains === nothing ? 0 : 1)), "rbd_simulate")
+    finish(state)
     range(zero(T), step = T(Δt), length = nsteps + 1)
 end
 
-
-# ---- kinematics by-products of the same forward-kinematics pass (root frame; host buffers like the methods above) ---------------
-# momentum_matrix!(out, state) mechanism_algorithms.jl:313-327: out is 6 × nv × B
-function momentum_matrix!(out::Array{T, 3}, state::BatchedMechanismState{T}) where {T}
+# ---- kinematics by-products of the same forward-kinematics pass (root frame) -------------------------------------------------------
+# momentum_matrix!(out, state) mechanism_algorithms.jl:313-327: out is (6·nv) × B, per state a 6 × nv column-major matrix
+function momentum_matrix!(out::Buffer{T}, state::BatchedMechanismState{T}) where {T}
     checkmodcount(state)
-    B = size(state.q, 2)
-    size(out) == (6, state.model.nv, B) || throw(DimensionMismatch())
+    B = batchsize(state)
+    size(out) == (6 * state.model.nv, B) || throw(DimensionMismatch())
     check(ccall((:rbd_kinematics, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
-        state.ws, B, state.q, state.v, out, C_NULL, C_NULL, opts()), "rbd_kinematics")
-    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+        state.ws, B, state.q, state.v, out, C_NULL, C_NULL, opts(state)), "rbd_kinematics")
+    finish(state)
     out
 end
 
 # center_of_mass(state) :28-50 -> 3 × B;  kinetic_energy / gravitational_potential_energy mechanism_state.jl:886-903 -> B each
-function center_of_mass(state::BatchedMechanismState{T}) where {T}
-    B = size(state.q, 2); com = Matrix{T}(undef, 3, B)
+function kin(state::BatchedMechanismState{T}, n::Int, slot::Int) where {T}
+    B = batchsize(state)
+    out = newbuffer(Val(state.memory == MEM_HOST ? :host : :device), T, n, B)
+    ptrs = (C_NULL, C_NULL, C_NULL)
     check(ccall((:rbd_kinematics, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
-        state.ws, B, state.q, state.v, C_NULL, com, C_NULL, opts()), "rbd_kinematics")
-    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
-    com
+        state.ws, B, state.q, state.v, C_NULL, slot == 2 ? pointer(out) : Ptr{T}(C_NULL), slot == 3 ? pointer(out) : Ptr{T}(C_NULL), opts(state)), "rbd_kinematics")
+    synchronize(state)
+    out isa Matrix ? out : Array(out)
 end
-function energies(state::BatchedMechanismState{T}) where {T}   # row 1: kinetic_energy, row 2: gravitational_potential_energy
-    B = size(state.q, 2); e = Matrix{T}(undef, 2, B)
-    check(ccall((:rbd_kinematics, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
-        state.ws, B, state.q, state.v, C_NULL, C_NULL, e, opts()), "rbd_kinematics")
-    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
-    e
-end
-kinetic_energy(state::BatchedMechanismState) = energies(state)[1, :]
-gravitational_potential_energy(state::BatchedMechanismState) = energies(state)[2, :]
+center_of_mass(state::BatchedMechanismState) = kin(state, 3, 2)
+kinetic_energy(state::BatchedMechanismState) = kin(state, 2, 3)[1, :]
+gravitational_potential_energy(state::BatchedMechanismState) = kin(state, 2, 3)[2, :]
 
 # momentum(state), momentum_rate_bias(state) mechanism_state.jl:975-987 -> 6 × B each
 function momenta(state::BatchedMechanismState{T}) where {T}
-    B = size(state.q, 2); out = Matrix{T}(undef, 12, B)
-    check(ccall((:rbd_momentum, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}), state.ws, B, state.q, state.v, out, opts()),
+    B = batchsize(state)
+    out = newbuffer(Val(state.memory == MEM_HOST ? :host : :device), T, 12, B)
+    check(ccall((:rbd_momentum, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}), state.ws, B, state.q, state.v, out, opts(state)),
         "rbd_momentum")
-    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
-    out
+    synchronize(state)
+    out isa Matrix ? out : Array(out)
 end
 momentum(state::BatchedMechanismState) = momenta(state)[1:6, :]
 momentum_rate_bias(state::BatchedMechanismState) = momenta(state)[7:12, :]
 
 # geometric_jacobian!(out, state, path) :80-99 in the root frame; the path is given by its end bodies (path(mechanism, base, body))
-function geometric_jacobian!(out::Array{T, 3}, state::BatchedMechanismState{T}, base::RigidBody, body::RigidBody) where {T}
+function geometric_jacobian!(out::Buffer{T}, state::BatchedMechanismState{T}, base::RigidBody, body::RigidBody) where {T}
     checkmodcount(state)
-    B = size(state.q, 2)
-    size(out) == (6, state.model.nv, B) || throw(DimensionMismatch())
+    B = batchsize(state)
+    size(out) == (6 * state.model.nv, B) || throw(DimensionMismatch())
     check(ccall((:rbd_geometric_jacobian, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Int32, Int32, Ptr{T}, Ref{RbdOpts}),
-        state.ws, B, state.q, state.model.bodyindex[base], state.model.bodyindex[body], out, opts()), "rbd_geometric_jacobian")
-    check(ccall((:rbd_sync, librbd_hip[]), Cint, (Ptr{Cvoid},), state.ws), "rbd_sync")
+        state.ws, B, state.q, state.model.bodyindex[base], state.model.bodyindex[body], out, opts(state)), "rbd_geometric_jacobian")
+    finish(state)
     out
+end
+
+# ---- multi-GPU: one process per GPU, the batch sharded by state, v̇ gathered over RCCL (SURVEY.md §8 e) ------------------------------
+mutable struct RbdComm
+    handle::Ptr{Cvoid}
+    world::Int; rank::Int
+end
+"128-byte unique id (call on one rank, hand to the others by whatever means the launcher offers — MPI, a file, a socket)"
+function unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:rbd_comm_unique_id, librbd_hip[]), Cint, (Ptr{Cvoid},), id), "rbd_comm_unique_id")
+    id
+end
+function RbdComm(id::Vector{UInt8}, world::Integer, rank::Integer; device::Integer = 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:rbd_comm_create, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Ref{Ptr{Cvoid}}), id, world, rank, device, h), "rbd_comm_create")
+    c = RbdComm(h[], world, rank)
+    finalizer(x -> ccall((:rbd_comm_destroy, librbd_hip[]), Cint, (Ptr{Cvoid},), x.handle), c)
+    c
+end
+"gathered (n × world·B_local) ← every rank's shard (n × B_local); `root = nothing`: on every rank, else on that rank only"
+function gather!(gathered::Union{DeviceMatrix{T}, Nothing}, comm::RbdComm, shard::DeviceMatrix{T}; root = nothing) where {T}
+    check(ccall((:rbd_gather, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}),
+        comm.handle, T === Float64 ? 0 : 1, shard.ptr, gathered === nothing ? C_NULL : gathered.ptr, prod(size(shard)), root === nothing ? -1 : root, C_NULL), "rbd_gather")
+    gathered
 end
 
 end # module

@@ -9,11 +9,11 @@ from .mechanism import (DEFAULT_GRAVITATIONAL_ACCELERATION, CartesianFrame3D, Fi
                         Planar, Prismatic, QuaternionFloating, QuaternionSpherical, Revolute, RigidBody, SinCosRevolute,
                         SpatialInertia, Transform3D, attach_, flatten, rand_configuration, rand_velocity,
                         remove_fixed_tree_joints_, rot_z_y_x, rotation_between)
-from .urdf import default_urdf_joint_types, parse_pose, parse_urdf
+from .urdf import default_urdf_joint_types, parse_pose, parse_urdf, write_urdf
 from .builders import (maximal_coordinates, FOUR_BAR_INITIAL_Q, FOUR_BAR_INITIAL_V, double_pendulum, four_bar_linkage, quickstart_double_pendulum,
                        rand_tree_mechanism, randmech)
 from .flatio import load_flat_model, save_flat_model
 from . import _capi
 from .state import (bank_plan, track_plan, momentum, momentum_rate_bias, geometric_jacobian_, chain_plan, center_of_mass, gravitational_potential_energy, kinetic_energy, momentum_matrix_, DimensionMismatch, DynamicsResult, MechanismState, dynamics_, dynamics_bias_, dynamics_ode_, inverse_dynamics_, mass_matrix_,
                     mass_matrix_solve_, rand_, set_configuration_, set_velocity_, simulate_, sync, zero_configuration_)
-from .distributed import gather_results, shard_range, shard_sizes
+from .distributed import Comm, gather_results, shard_range, shard_sizes

@@ -20,6 +20,7 @@ SYMBOLS = (
     "rbd_workspace_set_stream", "rbd_sync", "rbd_dynamics", "rbd_inverse_dynamics", "rbd_dynamics_bias", "rbd_mass_matrix",
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
     "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan", "rbd_model_track_plan", "rbd_inverse_dynamics_bodies", "rbd_dynamics_bias_bodies",
+    "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_comm_last_error",
 )
 
 
@@ -65,6 +66,12 @@ def lib():
         L.rbd_cholesky_solve.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_model_chain_plan.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), i32]
         L.rbd_model_track_plan.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), i32, ctypes.POINTER(i32), i32, ctypes.POINTER(ctypes.c_double), i32]
+        L.rbd_comm_unique_id.argtypes = [vp]
+        L.rbd_comm_create.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
+        L.rbd_comm_destroy.argtypes = [vp]
+        L.rbd_comm_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+        L.rbd_gather.argtypes = [vp, i32, vp, vp, ctypes.c_int64, i32, vp]
+        L.rbd_comm_last_error.restype = ctypes.c_char_p
         L.rbd_workspace_last_kernel.argtypes = [vp]
         L.rbd_workspace_last_kernel.restype = ctypes.c_char_p
         L.rbd_geometric_jacobian.argtypes = [vp, i32, vp, i32, i32, vp, ctypes.POINTER(Opts)]

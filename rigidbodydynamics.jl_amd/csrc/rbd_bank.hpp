@@ -154,7 +154,7 @@ __device__ long long rbd_bank_phase_clock[16];
 #endif
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, const T* __restrict__ q, const T* __restrict__ v,
+__global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, const T* q, const T* v,  /* no restrict: F.q_state / F.v_state alias them when fused */
                                                          const T* __restrict__ tau, const T* __restrict__ fext, T* __restrict__ vdot,
                                                          T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, MkFuse F) {
   extern __shared__ double park_raw[];

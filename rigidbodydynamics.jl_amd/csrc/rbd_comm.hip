@@ -1,0 +1,131 @@
+// rbd_comm.hip — the one exchange step of the path when the batch is sharded over the GPUs of a node (SURVEY.md §8 e, BASELINE
+// configs[3]): an RCCL all-gather (or gather to one rank) of each rank's shard of DynamicsResult.v̇ over xGMI, behind the C ABI so that
+// a non-Python caller (the Julia shim) can run it without torch.distributed.  States are independent: there is no collective inside
+// the dynamics itself.  One process per GPU; the caller distributes the 128-byte unique id among its ranks (as with ncclGetUniqueId).
+// librccl is opened on first use (dlopen): single-GPU users never load it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "rbd_hip.h"
+
+namespace {
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+Rccl& rccl() {
+  static Rccl R;
+  if (R.h || R.ok) return R;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (R.h) break;
+  }
+  if (!R.h) return R;
+  auto sym = [&](const char* n) { return dlsym(R.h, n); };
+  R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+  R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+  R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+  R.AllGather = (decltype(R.AllGather))sym("ncclAllGather");
+  R.Send = (decltype(R.Send))sym("ncclSend");
+  R.Recv = (decltype(R.Recv))sym("ncclRecv");
+  R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
+  R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
+  R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+  R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.AllGather && R.Send && R.Recv && R.GroupStart && R.GroupEnd;
+  return R;
+}
+thread_local std::string g_comm_error;
+}  // namespace
+
+struct rbd_comm {
+  ncclComm_t comm = nullptr;
+  int32_t world = 0, rank = 0, device = 0;
+};
+
+extern "C" {
+
+const char* rbd_comm_last_error(void) { return g_comm_error.c_str(); }
+
+int rbd_comm_unique_id(void* id128) {
+  if (!id128) return RBD_ERR_INVALID_ARGUMENT;
+  Rccl& R = rccl();
+  if (!R.ok) { g_comm_error = "librccl.so could not be opened"; return RBD_ERR_UNSUPPORTED; }
+  ncclUniqueId id;
+  const ncclResult_t r = R.GetUniqueId(&id);
+  if (r != ncclSuccess) { g_comm_error = R.GetErrorString ? R.GetErrorString(r) : "ncclGetUniqueId failed"; return RBD_ERR_HIP; }
+  static_assert(sizeof(ncclUniqueId) == 128, "unique id size");
+  memcpy(id128, &id, sizeof id);
+  return RBD_OK;
+}
+
+int rbd_comm_create(const void* id128, int32_t world, int32_t rank, int32_t device, rbd_comm_t** out) {
+  if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return RBD_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  Rccl& R = rccl();
+  if (!R.ok) { g_comm_error = "librccl.so could not be opened"; return RBD_ERR_UNSUPPORTED; }
+  if (hipSetDevice(device) != hipSuccess) return RBD_ERR_NO_DEVICE;
+  rbd_comm* c = new (std::nothrow) rbd_comm();
+  if (!c) return RBD_ERR_OUT_OF_MEMORY;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  const ncclResult_t r = R.CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) { g_comm_error = R.GetErrorString ? R.GetErrorString(r) : "ncclCommInitRank failed"; delete c; return RBD_ERR_HIP; }
+  c->world = world; c->rank = rank; c->device = device;
+  *out = c;
+  return RBD_OK;
+}
+
+int rbd_comm_destroy(rbd_comm_t* c) {
+  if (!c) return RBD_OK;
+  if (c->comm) (void)rccl().CommDestroy(c->comm);
+  delete c;
+  return RBD_OK;
+}
+
+int rbd_comm_info(const rbd_comm_t* c, int32_t* world, int32_t* rank) {
+  if (!c) return RBD_ERR_INVALID_ARGUMENT;
+  if (world) *world = c->world;
+  if (rank) *rank = c->rank;
+  return RBD_OK;
+}
+
+// gathered[r * count .. (r+1) * count) = rank r's shard (count scalars of dtype); root < 0: on every rank (ncclAllGather);
+// root >= 0: on that rank only (grouped ncclSend / ncclRecv).  Asynchronous on `stream` (a hipStream_t; NULL = default stream).
+int rbd_gather(rbd_comm_t* c, int32_t dtype, const void* shard, void* gathered, int64_t count, int32_t root, void* stream) {
+  if (!c || !shard || count < 0 || (dtype != RBD_F64 && dtype != RBD_F32) || root >= c->world) return RBD_ERR_INVALID_ARGUMENT;
+  if ((root < 0 || root == c->rank) && !gathered) return RBD_ERR_INVALID_ARGUMENT;
+  Rccl& R = rccl();
+  const ncclDataType_t t = dtype == RBD_F64 ? ncclDouble : ncclFloat;
+  const size_t es = dtype == RBD_F64 ? 8 : 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipSetDevice(c->device) != hipSuccess) return RBD_ERR_NO_DEVICE;
+  ncclResult_t r = ncclSuccess;
+  if (root < 0) {
+    r = R.AllGather(shard, gathered, (size_t)count, t, c->comm, s);
+  } else {
+    r = R.GroupStart();
+    if (r == ncclSuccess) r = R.Send(shard, (size_t)count, t, root, c->comm, s);
+    if (c->rank == root)
+      for (int p = 0; p < c->world && r == ncclSuccess; ++p) r = R.Recv((char*)gathered + (size_t)p * count * es, (size_t)count, t, p, c->comm, s);
+    const ncclResult_t e = R.GroupEnd();
+    if (r == ncclSuccess) r = e;
+  }
+  if (r != ncclSuccess) { g_comm_error = R.GetErrorString ? R.GetErrorString(r) : "rccl call failed"; return RBD_ERR_HIP; }
+  return RBD_OK;
+}
+
+}  // extern "C"

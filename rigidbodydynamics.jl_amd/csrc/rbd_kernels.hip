@@ -8,6 +8,7 @@
 //   rbd_bank.hpp (aba_bank_kernel, rnea_bank_kernel) and rbd_chain.hpp (aba_chain_kernel): the other lane mappings
 // Mapping here: one lane per (state, body); level-synchronous sweeps; parent/child exchange by DPP wave
 // shifts (first child) and ds_bpermute; per-body quantities stay in VGPRs (see rbd_device.hpp).
+#include <atomic>
 #include "rbd_device.hpp"
 #include "rbd_internal.hpp"
 #include "rbd_hip.h"
@@ -322,7 +323,7 @@ __host__ __device__ constexpr int DI(int k, int m, int n) { return k <= m ? (k *
 // NDOF = 3: the mechanism also has QuaternionSpherical / Planar tree joints (S is 6x3, D a 3x3 SPD block).
 template <typename T, bool INNER_FLOAT, int NDOF>
 __global__ __launch_bounds__(256, (sizeof(T) == 8 ? (NDOF == 1 ? 2 : 1) : (NDOF == 1 ? RBD_ABA_F32_WAVES : 2)))
-void aba_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau,
+void aba_kernel(DevModel M, long B, const T* q, const T* v, const T* __restrict__ tau,  // q, v: the fused simulate path also writes them (F.q_state)
                 const T* __restrict__ fext, T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, MkFuse F) {
   constexpr int ND2 = NDOF * (NDOF + 1) / 2;
   Body<T> b;
@@ -1474,8 +1475,21 @@ hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, con
   // larger systems: the LDS-resident kernel
   int stride = ((nv + 3) / 4) * 4;  // 4*odd words: 16-byte row alignment, rows spread over the banks
   if (((stride / 4) & 1) == 0) stride += 4;
-  const int wpb = 4;
-  const size_t shmem = (size_t)wpb * ((size_t)nv * stride + 64) * sizeof(T);
+  int wpb = 4;
+  size_t shmem = (size_t)wpb * ((size_t)nv * stride + 64) * sizeof(T);
+  while (shmem > 160u * 1024u && wpb > 1) {  // one CU's LDS: fewer states per workgroup for the largest systems
+    wpb >>= 1;
+    shmem = (size_t)wpb * ((size_t)nv * stride + 64) * sizeof(T);
+  }
+  if (shmem > 160u * 1024u) return hipErrorInvalidValue;
+  if (shmem > 64u * 1024u) {  // above the default dynamic-LDS limit (nv 49..64 in fp64 already is): raise it once per size
+    static std::atomic<size_t> raised{0};
+    if (raised.load(std::memory_order_relaxed) < shmem) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160u * 1024u));
+      if (e != hipSuccess) return e;
+      raised.store(160u * 1024u, std::memory_order_relaxed);
+    }
+  }
   const dim3 grid((unsigned)((B + wpb - 1) / wpb));
   hipLaunchKernelGGL(chol_solve_kernel<T>, grid, dim3(64 * wpb), shmem, s, nv, stride, B, (const T*)M, (const T*)tau, (const T*)c, (T*)x,
                      (T*)Lout, Lm, Lv, notpd);

@@ -51,3 +51,49 @@ def gather_results(local: torch.Tensor, B: int, group: Optional[dist.ProcessGrou
     if all(s == smax for s in sizes):
         return out
     return torch.cat([out[r * smax: r * smax + sizes[r]] for r in range(world)], dim=0)
+
+
+# ---- the same exchange step through the C ABI (rbd_comm_* / rbd_gather: RCCL opened by librbd_hip itself, no torch.distributed) ----
+class Comm:
+    """RCCL communicator of include/rbd_hip.h.  `Comm.unique_id()` on one rank, the 128 bytes handed to the others by the caller,
+    then `Comm(id, world, rank, device)` on every rank (one process per GPU)."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, device: int = 0):
+        import ctypes
+        from . import _capi
+        self._L = _capi.lib()
+        self.handle = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        st = self._L.rbd_comm_create(ctypes.cast(buf, ctypes.c_void_p), world, rank, device, ctypes.byref(self.handle))
+        if st != 0:
+            raise _capi.RBDError(st, "rbd_comm_create", (self._L.rbd_comm_last_error() or b"").decode())
+        self.world, self.rank = world, rank
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        from . import _capi
+        buf = ctypes.create_string_buffer(128)
+        st = _capi.lib().rbd_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p))
+        if st != 0:
+            raise _capi.RBDError(st, "rbd_comm_unique_id", (_capi.lib().rbd_comm_last_error() or b"").decode())
+        return buf.raw
+
+    def gather(self, shard: torch.Tensor, root: Optional[int] = None) -> Optional[torch.Tensor]:
+        """All-gather (root None) or gather to `root` of equal-size shards (B_local, n) on the current stream."""
+        import ctypes
+        from . import _capi
+        shard = shard.contiguous()
+        want = root is None or root == self.rank
+        out = torch.empty((self.world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device) if want else None
+        dt = _capi.F64 if shard.dtype == torch.float64 else _capi.F32
+        st = self._L.rbd_gather(self.handle, dt, ctypes.c_void_p(shard.data_ptr()), ctypes.c_void_p(out.data_ptr() if out is not None else 0),
+                                ctypes.c_int64(shard.numel()), -1 if root is None else int(root), ctypes.c_void_p(torch.cuda.current_stream(shard.device).cuda_stream))
+        if st != 0:
+            raise _capi.RBDError(st, "rbd_gather", (self._L.rbd_comm_last_error() or b"").decode())
+        return out
+
+    def close(self):
+        if self.handle:
+            self._L.rbd_comm_destroy(self.handle)
+            self.handle = None

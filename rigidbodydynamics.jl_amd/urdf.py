@@ -129,3 +129,81 @@ def parse_urdf(filename: str, floating: bool = False, joint_types=None, root_joi
     if remove_fixed_tree_joints:
         remove_fixed_tree_joints_(mechanism)
     return mechanism
+
+
+# ---- write_urdf (src/urdf/write.jl) ---------------------------------------------------------------------------------------------
+def _fmt(vec) -> str:
+    return " ".join(repr(float(x)) for x in vec)
+
+
+def _rpy_of(R: np.ndarray):
+    """RotZYX(R) -> (roll, pitch, yaw) with R = Rz(yaw) Ry(pitch) Rx(roll) (write.jl:108, 119; parse.jl:47-48 is its inverse)."""
+    pitch = np.arctan2(-R[2, 0], np.hypot(R[0, 0], R[1, 0]))
+    yaw = np.arctan2(R[1, 0], R[0, 0])
+    roll = np.arctan2(R[2, 1], R[2, 2])
+    return roll, pitch, yaw
+
+
+def _link_xml(body: RigidBody, is_root: bool) -> ET.Element:  # to_urdf(body): write.jl:5-37
+    x = ET.Element("link", {"name": body.name})
+    if not is_root and body.inertia is not None:
+        inertia = body.inertia
+        xi = ET.SubElement(x, "inertial")
+        if inertia.mass > 0:
+            com = inertia.cross_part / inertia.mass
+            centroidal = CartesianFrame3D("centroidal")
+            inertia = inertia.transform(Transform3D(inertia.frame, centroidal, np.eye(3), -com))  # moment about the centre of mass
+        else:
+            com = np.zeros(3)
+        ET.SubElement(xi, "origin", {"xyz": _fmt(com), "rpy": _fmt(np.zeros(3))})
+        ET.SubElement(xi, "mass", {"value": repr(float(inertia.mass))})
+        J = inertia.moment
+        ET.SubElement(xi, "inertia", {"ixx": repr(float(J[0, 0])), "ixy": repr(float(J[0, 1])), "ixz": repr(float(J[0, 2])),
+                                      "iyy": repr(float(J[1, 1])), "iyz": repr(float(J[1, 2])), "izz": repr(float(J[2, 2]))})
+    return x
+
+
+def _joint_xml(joint: Joint, mechanism: Mechanism) -> ET.Element:  # to_urdf(joint, mechanism): write.jl:102-123
+    from .mechanism import (JOINT_FIXED, JOINT_PLANAR, JOINT_PRISMATIC, JOINT_QUAT_FLOATING, JOINT_REVOLUTE)
+    to_parent = joint.joint_to_predecessor
+    x = ET.Element("joint", {"name": joint.name})
+    ET.SubElement(x, "parent", {"link": mechanism.predecessor(joint).name})
+    ET.SubElement(x, "child", {"link": mechanism.successor(joint).name})
+    ET.SubElement(x, "origin", {"xyz": _fmt(to_parent.p), "rpy": _fmt(_rpy_of(to_parent.R))})
+    jt = joint.joint_type
+    if jt.tag == JOINT_QUAT_FLOATING:
+        x.set("type", "floating")
+    elif jt.tag == JOINT_FIXED:
+        x.set("type", "fixed")
+    elif jt.tag == JOINT_PLANAR:
+        x.set("type", "planar")
+        ET.SubElement(x, "axis", {"xyz": _fmt(np.cross(jt.axis, jt.axis2))})
+    elif jt.tag in (JOINT_REVOLUTE, JOINT_PRISMATIC):
+        ET.SubElement(x, "axis", {"xyz": _fmt(jt.axis)})
+        # joint bounds are not part of the hot path's model: every revolute joint is written as the reference writes an unbounded one
+        x.set("type", "continuous" if jt.tag == JOINT_REVOLUTE else "prismatic")
+        lim = {"effort": "Inf", "velocity": "Inf"}
+        if jt.tag == JOINT_PRISMATIC:
+            lim.update({"lower": "-Inf", "upper": "Inf"})
+        ET.SubElement(x, "limit", lim)
+    else:
+        raise ValueError(f"Joint type of {joint.name} not handled.")  # write.jl:46
+    return x
+
+
+def write_urdf(filename: str, mechanism: Mechanism, robot_name: Optional[str] = None, include_root: bool = True) -> None:
+    """`write_urdf(filename, mechanism; robot_name, include_root)` (src/urdf/write.jl:125-200): <link> with <inertial> (origin at the centre
+    of mass, centroidal moment), <joint> with <origin>, <parent>, <child>, <axis>, <limit>.  Tree mechanisms only."""
+    assert not mechanism.has_loops()
+    root = ET.Element("robot")
+    if robot_name is not None:
+        root.set("name", robot_name)
+    for body in mechanism.bodies:
+        if body is mechanism.root_body and not include_root:
+            continue
+        root.append(_link_xml(body, body is mechanism.root_body))
+    for joint in mechanism.tree_joints:
+        if mechanism.predecessor(joint) is mechanism.root_body and not include_root:
+            continue
+        root.append(_joint_xml(joint, mechanism))
+    ET.ElementTree(root).write(filename, encoding="utf-8", xml_declaration=True)

@@ -57,3 +57,12 @@ def test_no_cpu_fallback(rbd, models):
     h = ctypes.c_void_p()
     st = rbd._capi.lib().rbd_workspace_create(m.handle, 4, 0, 0, None, ctypes.byref(h))
     assert st == 4
+
+
+def test_julia_shim_ccalls_match_the_header():
+    """julia/RigidBodyDynamicsGPU.jl cannot be executed here (no Julia): its ccall signatures are checked against include/rbd_hip.h."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_julia_ccalls.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -579,6 +579,30 @@ def test_cholesky_solve_factor_and_solution(rbd, models, dtype, name):
     assert np.abs(x.double().cpu().numpy() - xr).max() <= tol * max(1.0, np.abs(xr).max())
 
 
+@pytest.mark.parametrize("dtype,n_rev", [("f64", 44), ("f64", 58), ("f32", 50), ("f32", 58)])
+def test_cholesky_route_lds_kernel_nv_49_to_64(rbd, oracle, dtype, n_rev):
+    """Systems with 49..64 velocities take chol_solve_kernel (factor resident in LDS, one state per wavefront); in fp64 its four states per
+    workgroup need up to 141 KB of LDS, above the default 64 KB dynamic limit, so the launcher must raise the kernel's limit first."""
+    rng = np.random.default_rng(31 + n_rev)
+    mech = rbd.rand_tree_mechanism(rng, ["QuaternionFloating"] + ["Revolute"] * n_rev, lambda m, r: m.bodies[max(1, len(m.bodies) - 1 - int(r.integers(0, 3)))])  # at most 3 children per body
+    model = rbd.flatten(mech)
+    assert 49 <= model.nv <= 64
+    B = 21
+    state, q, v, tau, fe = make(rbd, model, B, dtype, "aos", 77)
+    result = rbd.DynamicsResult(model, B, dtype=TD[dtype])
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="crba")
+    ref = oracle.dynamics(model, q, v, tau, fe)
+    got = host(result.vd, state)
+    if dtype == "f64":
+        assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    else:  # fp32: backward error of the solve against the oracle's M and bias
+        Mr, cr = oracle.mass_matrix(model, q), oracle.dynamics_bias(model, q, v, fe)
+        Mr = np.tril(Mr) + np.transpose(np.tril(Mr, -1), (0, 2, 1))  # the oracle fills the lower triangle, like the reference
+        r = np.einsum("bij,bj->bi", Mr, got) - (tau - cr)
+        denom = np.linalg.norm(Mr, axis=(1, 2)) * np.linalg.norm(got, axis=1) + np.linalg.norm(tau - cr, axis=1)
+        assert (np.linalg.norm(r, axis=1) / denom).max() <= 2e-5
+
+
 def test_config4_shard_f32_full_size_round_trip(rbd, oracle, models):
     """BASELINE configs[3]: one GPU's shard of the 524 288-state fp32 batch (65 536 states).  Size-independent property on the
     GPU (dynamics! then inverse_dynamics! returns τ, in fp32 backward-error terms) plus an oracle check on a sample."""
@@ -995,3 +1019,25 @@ def test_result_must_match_state(rbd, models):
     good.vd = torch.zeros(4, model.nv, dtype=torch.float64, device="cuda")
     with pytest.raises(rbd.DimensionMismatch):
         rbd.dynamics_(good, state)
+
+
+@pytest.mark.gpu
+def test_c_abi_rccl_gather_single_rank(rbd, models):
+    """rbd_comm_* / rbd_gather (the exchange step of the sharded batch through the C ABI, RCCL opened by the library itself): a world of
+    one rank — all that a 1-GPU box can hold — must hand back the shard, as an all-gather and as a gather to rank 0."""
+    model = models["atlas_floating"]
+    B = 257
+    state, q, v, tau, _ = make(rbd, model, B, "f64", "aos", 150)
+    result = rbd.DynamicsResult(model, B)
+    rbd.dynamics_(result, state, dev(tau, state))
+    comm = rbd.Comm(rbd.Comm.unique_id(), 1, 0, 0)
+    try:
+        for root in (None, 0):
+            out = comm.gather(result.vd, root)
+            torch.cuda.synchronize()
+            assert torch.equal(out, result.vd)
+        out32 = comm.gather(result.vd.float())
+        torch.cuda.synchronize()
+        assert torch.equal(out32, result.vd.float())
+    finally:
+        comm.close()
