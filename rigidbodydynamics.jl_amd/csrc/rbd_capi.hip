@@ -15,6 +15,7 @@
 #include "rbd_internal.hpp"
 #include "rbd_chain_plan.hpp"
 #include "rbd_track_plan.hpp"
+#include "rbd_state_plan.hpp"
 
 using namespace rbd;
 
@@ -73,6 +74,7 @@ struct rbd_model {
   uint64_t bank_perm_down = 0;
   ChainPlan chain;  // plan of aba_chain_kernel (chain.ok == false: mechanism outside its scope)
   TrackPlan track;  // plan of aba_track_kernel (track.ok == false: mechanism outside its scope)
+  StatePlan state;  // plan of the one-lane-per-state kernels (state.ok == false: mechanism outside their scope)
 };
 
 struct rbd_ws {
@@ -82,6 +84,8 @@ struct rbd_ws {
   DevModel dm{};
   BankModel bm{}; void* d_bank_ib[2] = {nullptr, nullptr}; void* d_bank_rb[2] = {nullptr, nullptr};
   TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr; size_t track_lds_bytes4 = 0; long track_nw4_max_batch = 0; size_t track_lds_bytes = 0; long track_min_batch = 0;
+  StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
+  void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   ChainModel cm{}; void* d_chain_tab = nullptr; void* d_chain_cb = nullptr; size_t chain_lds_bytes = 0; long bank_min_batch = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
   // staging for RBD_MEM_HOST (lazy)
@@ -329,6 +333,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     if (const char* e = getenv("RBD_CHAIN_G")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) G = g; }
     if (m->nloops == 0) m->chain = build_chain_plan(nb, m->ib, G);
     if (m->nloops == 0 && G <= 4) m->track = build_track_plan(nb, m->ib, m->rb, G);
+    if (m->nloops == 0) m->state = build_state_plan(nb, m->ib, m->rb);
   }
   *out = m;
   return RBD_OK;
@@ -515,6 +520,28 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->track_min_batch = (long)1 << 62;
     if (const char* e = getenv("RBD_TRACK_MIN_BATCH")) w->track_min_batch = atol(e);
   }
+  if (m->state.ok && m->state.nlevels <= state_max_levels(dtype == RBD_F64 ? 8 : 4)) {
+    const StatePlan& P = m->state;
+    st = upload(&w->d_state_ops, P.ops.data(), P.ops.size() * sizeof(int32_t));
+    if (st == RBD_OK) st = upload(&w->d_state_cols, P.cols.data(), P.cols.size() * sizeof(int32_t));
+    if (st == RBD_OK) {
+      if (dtype == RBD_F64) st = upload(&w->d_state_sr, P.sr.data(), P.sr.size() * sizeof(double));
+      else { std::vector<float> f(P.sr.begin(), P.sr.end()); st = upload(&w->d_state_sr, f.data(), f.size() * sizeof(float)); }
+    }
+    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+    StateModel& sm = w->sm;
+    sm.nb = m->nb; sm.nq = m->nq; sm.nv = m->nv; sm.nops = P.nops; sm.nlevels = P.nlevels;
+    sm.ops = (const int32_t*)w->d_state_ops; sm.cols = (const int32_t*)w->d_state_cols; sm.sr = w->d_state_sr; sm.row_mask = (const uint64_t*)w->d_row_mask;
+    memcpy(sm.gravity, m->gravity, sizeof sm.gravity);
+    // a lane per state pays once every SIMD of the chip has a wavefront of them (64 states x 4 SIMDs x CUs); below that the
+    // lane-per-body kernels spread a small batch over more of the chip
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+    w->state_min_batch = (long)ncu * 4 * 64 / 2;
+    if (const char* e = getenv("RBD_STATE_MIN_BATCH")) w->state_min_batch = atol(e);
+  } else {
+    w->state_min_batch = (long)1 << 62;
+  }
   {
     const int G = (m->chain.ok && w->chain_lds_bytes > 0) ? m->chain.G : 0;
     const hipError_t e = dtype == RBD_F64 ? configure_kernels<double>(G, w->chain_lds_bytes) : configure_kernels<float>(G, w->chain_lds_bytes);
@@ -531,7 +558,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -701,7 +728,10 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   if (mapping == RBD_ALGO_ABA_BANKS && m->bank_lps == 0) return RBD_ERR_UNSUPPORTED;
   // the per-body outputs (accelerations, joint wrenches) are written by the one-body-per-lane kernel
   const bool banks = !dacc && !djw && m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
-  if (banks) {
+  if (!dacc && !djw && mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->state_min_batch) {  // one lane per state
+    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_state<double>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_rnea_state<float>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
+  } else if (banks) {
     const int ncol = m->has3dof ? 3 : 1;
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_bank<double>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_rnea_bank<float>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
@@ -755,6 +785,47 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   return RBD_OK;
 }
 
+// mass_matrix! alone, into the caller's buffer
+static int run_crba(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, Layout Lq, Layout Lm) {
+  if (B >= w->state_min_batch && layout == RBD_LAYOUT_SOA) {  // one lane per state: its stores are coalesced when the batch is innermost
+    if (w->dtype == RBD_F64) HIP_TRY(launch_crba_state<double>(w->sm, B, dq, dM, Lq, Lm, 1, w->stream));
+    else HIP_TRY(launch_crba_state<float>(w->sm, B, dq, dM, Lq, Lm, 1, w->stream));
+  } else {
+    if (w->dtype == RBD_F64) HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
+    else HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
+  }
+  return RBD_OK;
+}
+
+// mass_matrix! into dM (caller's layout) followed by the Cholesky solve of M x = tau - c (either may be null).  Large batches
+// build M with one lane per state; for an AOS caller that kernel writes a batch-innermost staging copy which the tile Cholesky
+// reads (coalesced) and re-emits as the caller's M.
+static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, const void* dtau, const void* dc, void* dx, Layout Lq,
+                         Layout Lm, Layout Lv) {
+  const rbd_model* m = w->model;
+  const size_t es = esize(w);
+  int st;
+  const bool state = B >= w->state_min_batch;
+  if (state && layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv)) {
+    void* const before = w->d_Msoa;
+    if ((st = ensure(&w->d_Msoa, &w->d_Msoa_bytes, es * (size_t)m->nv * m->nv * B))) return st;
+    if (w->Msoa_B != B || w->d_Msoa != before) {  // the structural zeros of M are written once per batch size: the kernel below only stores the non-zeros
+      HIP_TRY(hipMemsetAsync(w->d_Msoa, 0, es * (size_t)m->nv * m->nv * B, w->stream));
+      w->Msoa_B = B;
+    }
+    const Layout Ls = layout_of(RBD_LAYOUT_SOA, (long)m->nv * m->nv, B);
+    HIP_TRY(launch_crba_state<float>(w->sm, B, dq, w->d_Msoa, Lq, Ls, 0, w->stream));  // structural zeros: never read by the solve, written below
+    HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_Msoa, dtau, dc, dx, nullptr, Ls, Lv, w->d_notpd, w->stream, dM, Lm));
+    w->last_kernel = "crba_state_kernel + chol_mfma_kernel";
+    return RBD_OK;
+  }
+  if ((st = run_crba(w, B, layout, dq, dM, Lq, Lm))) return st;
+  if (w->dtype == RBD_F64) HIP_TRY(launch_chol_solve<double>(m->nv, B, dM, dtau, dc, dx, nullptr, Lm, Lv, w->d_notpd, w->stream));
+  else HIP_TRY(launch_chol_solve<float>(m->nv, B, dM, dtau, dc, dx, nullptr, Lm, Lv, w->d_notpd, w->stream));
+  w->last_kernel = (state && layout == RBD_LAYOUT_SOA) ? "crba_state_kernel + chol kernel" : "crba_kernel + chol kernel";
+  return RBD_OK;
+}
+
 // dynamics! on device pointers: ABA, the reference's CRBA + Cholesky route, or the loop-joint branch
 static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd,
                         void* dqd, void* dlam) {
@@ -774,13 +845,7 @@ static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, con
     w->result_layout = o.layout; w->result_B = B;
     Timed t(w);
     if ((st = run_rnea(w, B, RBD_ALGO_ABA, dq, dv, nullptr, df, w->d_c, dqd, Lq, Lv, Lf))) return st;
-    if (w->dtype == RBD_F64) {
-      HIP_TRY(launch_crba<double>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
-      HIP_TRY(launch_chol_solve<double>(m->nv, B, w->d_M, dtau, w->d_c, dvd, nullptr, Lm, Lv, w->d_notpd, w->stream));
-    } else {
-      HIP_TRY(launch_crba<float>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
-      HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_M, dtau, w->d_c, dvd, nullptr, Lm, Lv, w->d_notpd, w->stream));
-    }
+    if ((st = run_crba_chol(w, B, o.layout, dq, w->d_M, dtau, w->d_c, dvd, Lq, Lm, Lv))) return st;
   } else {
     if ((st = run_aba(w, B, o.algorithm, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, nullptr, nullptr))) return st;
   }
@@ -889,8 +954,7 @@ int rbd_mass_matrix(rbd_ws_t* w, int32_t B, const void* q, void* M_out, const rb
   const Layout Lq = layout_of(o.layout, m->nq, B), Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
   {
     Timed t(w);
-    if (w->dtype == RBD_F64) HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
-    else HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
+    if ((st = run_crba(w, B, o.layout, dq, dM, Lq, Lm))) return st;
   }
   if (o.memory == RBD_MEM_HOST) return stage_out_copy(w, M_out, dM, mbytes);
   return RBD_OK;
@@ -920,23 +984,14 @@ int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
   if (o.algorithm == RBD_ALGO_CRBA_CHOLESKY) {
     Timed t(w);
-    if (w->dtype == RBD_F64) {
-      HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
-      HIP_TRY(launch_chol_solve<double>(m->nv, B, dM, dr, nullptr, dx, nullptr, Lm, Lv, w->d_notpd, w->stream));
-    } else {
-      HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
-      HIP_TRY(launch_chol_solve<float>(m->nv, B, dM, dr, nullptr, dx, nullptr, Lm, Lv, w->d_notpd, w->stream));
-    }
+    if ((st = run_crba_chol(w, B, o.layout, dq, dM, dr, nullptr, dx, Lq, Lm, Lv))) return st;
   } else {
     // O(n) solve: x = M(q)^-1 rhs is forward dynamics with v = 0, no gravity and tau = rhs (then c = 0), i.e. one pass of
     // the articulated-body kernel — no matrix is formed unless the caller asked for it.
     const double g0[3] = {0.0, 0.0, 0.0};
     const Layout Lf = layout_of(o.layout, 6L * m->nb, B);
     if ((st = run_aba(w, B, RBD_ALGO_ABA, dq, nullptr, dr, nullptr, dx, nullptr, Lq, Lv, Lf, g0, nullptr))) return st;
-    if (dM) {
-      if (w->dtype == RBD_F64) HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
-      else HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
-    }
+    if (dM && (st = run_crba(w, B, o.layout, dq, dM, Lq, Lm))) return st;
   }
   if (o.memory == RBD_MEM_HOST) {
     if ((st = stage_out_copy(w, x, dx, es * m->nv * B)) || (st = stage_out_copy(w, M_out, dM, mbytes))) return st;

@@ -16,7 +16,8 @@ hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Lay
 namespace rbd {
 template <typename T>
 hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv,
-                             int* notpd, hipStream_t s);
+                             int* notpd, hipStream_t s, void* Mcopy = nullptr, Layout Lc = Layout{0, 0});
+bool chol_copies_m(int element_size, int nv);  // the kernel launch_chol_solve picks can also write M in a second layout (Mcopy)
 }
 namespace rbd {
 template <typename T>
@@ -61,4 +62,11 @@ template <typename T>
 hipError_t launch_aba_track(const TrackModel& M, int flt, int gen, int nw, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
                             void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 template <typename T> hipError_t configure_track_kernel(int G, int flt, int gen, size_t lds_bytes);
+// rbd_state_kernels.hip: one lane per state
+int state_max_levels(int element_size);
+template <typename T>
+hipError_t launch_crba_state(const StateModel& M, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill, hipStream_t s);
+template <typename T>
+hipError_t launch_rnea_state(const StateModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau, void* qdot,
+                             Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 }

@@ -1308,7 +1308,7 @@ RBD_DEV float quad_sum(float x) {
 template <int NT>
 __global__ __launch_bounds__(64) void chol_mfma_kernel(int nv, long B, const float* __restrict__ Mg, const float* __restrict__ tau,
                                                        const float* __restrict__ c, float* __restrict__ x, float* __restrict__ Lout,
-                                                       Layout Lm, Layout Lv, int* __restrict__ notpd) {
+                                                       Layout Lm, Layout Lv, int* __restrict__ notpd, float* __restrict__ Mcopy, Layout Lc) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 3;
   const long state = (long)blockIdx.x * 16 + (lane >> 2);
@@ -1325,6 +1325,19 @@ __global__ __launch_bounds__(64) void chol_mfma_kernel(int nv, long B, const flo
         if (live && row < nv && col <= row) a = Mg[((long)col * nv + row) * Lm.sk + state * Lm.sb];
         t[I][J][cc] = a;
       }
+  // M itself in the caller's layout, when the matrix was built in a staging buffer (one-lane-per-state CRBA writes batch-innermost):
+  // a quad stores 16 contiguous bytes per (tile, column) and a state's columns come from this one wavefront back to back
+  if (Mcopy && live) {
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int row = 4 * I + r, col = 4 * J + cc;
+          if (row < nv && col <= row) Mcopy[((long)col * nv + row) * Lc.sk + state * Lc.sb] = t[I][J][cc];
+        }
+  }
   float y[NT];
 #pragma unroll
   for (int I = 0; I < NT; ++I) {
@@ -1441,16 +1454,16 @@ __global__ __launch_bounds__(64) void chol_mfma_kernel(int nv, long B, const flo
 }
 
 template <typename T> struct MfmaChol {
-  static bool launch(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t) { return false; }
+  static bool launch(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t, void*, Layout) { return false; }
 };
 template <> struct MfmaChol<float> {
   static bool launch(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv, int* notpd,
-                     hipStream_t s) {
+                     hipStream_t s, void* Mcopy, Layout Lc) {
     const dim3 grid((unsigned)((B + 15) / 16));
 #define RBD_CHOL_MFMA(NT)                                                                                                           \
     if (nv <= 4 * NT) {                                                                                                             \
       hipLaunchKernelGGL((chol_mfma_kernel<NT>), grid, dim3(64), 0, s, nv, B, (const float*)M, (const float*)tau, (const float*)c,  \
-                         (float*)x, (float*)Lout, Lm, Lv, notpd);                                                                   \
+                         (float*)x, (float*)Lout, Lm, Lv, notpd, (float*)Mcopy, Lc);                                                \
       return true;                                                                                                                  \
     }
     RBD_CHOL_MFMA(1) RBD_CHOL_MFMA(2) RBD_CHOL_MFMA(4) RBD_CHOL_MFMA(6) RBD_CHOL_MFMA(8) RBD_CHOL_MFMA(9) RBD_CHOL_MFMA(10)
@@ -1461,8 +1474,9 @@ template <> struct MfmaChol<float> {
 
 template <typename T>
 hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv,
-                             int* notpd, hipStream_t s) {
-  if (MfmaChol<T>::launch(nv, B, M, tau, c, x, Lout, Lm, Lv, notpd, s)) return hipGetLastError();  // fp32, nv <= 40: matrix cores
+                             int* notpd, hipStream_t s, void* Mcopy, Layout Lc) {
+  if (MfmaChol<T>::launch(nv, B, M, tau, c, x, Lout, Lm, Lv, notpd, s, Mcopy, Lc)) return hipGetLastError();  // fp32, nv <= 40: matrix cores
+  if (Mcopy) return hipErrorInvalidValue;  // only the tile kernel re-emits M (chol_copies_m())
   const dim3 grid4((unsigned)((B + 3) / 4));
 #define RBD_CHOL_REG(NVP)                                                                                                      \
   if (nv <= NVP) {                                                                                                            \
@@ -1495,8 +1509,9 @@ hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, con
                      (T*)Lout, Lm, Lv, notpd);
   return hipGetLastError();
 }
-template hipError_t launch_chol_solve<double>(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t);
-template hipError_t launch_chol_solve<float>(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t);
+template hipError_t launch_chol_solve<double>(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t, void*, Layout);
+template hipError_t launch_chol_solve<float>(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t, void*, Layout);
+bool chol_copies_m(int es, int nv) { return es == 4 && nv <= 40; }
 
 }  // namespace rbd
 

@@ -350,6 +350,11 @@ def sync(state: MechanismState) -> int:
     return int(_capi.lib().rbd_sync(state.ws.handle))
 
 
+def last_kernel(state: MechanismState) -> str:
+    """Name(s) of the kernel(s) the last dynamics / solve call on this state's workspace was dispatched to (`rbd_workspace_last_kernel`)."""
+    return (_capi.lib().rbd_workspace_last_kernel(state.ws.handle) or b"").decode()
+
+
 RK4_C = (0.0, 0.5, 0.5, 1.0)  # c = row sums of the runge_kutta_4 tableau (src/ode_integrators.jl:48-55)
 
 

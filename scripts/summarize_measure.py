@@ -1,0 +1,96 @@
+"""Condenses what scripts/gpu_measure.sh collected under gpurun_out/measure into the files that are committed under profiles/:
+r02_kernel_stats_c<C>.csv (rocprofv3 --kernel-trace --stats, our kernels), r02_pmc_c<C>.txt (PMC per launch and per wavefront) and
+r02_pmc_traffic.json (HBM bytes per step from FETCH_SIZE / WRITE_SIZE, keyed like bench.py looks it up, with the kernel-source hash)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (CONFIGS, kernel_source_hash)
+
+OUT = os.path.join(ROOT, "gpurun_out", "measure")
+OURS = ("aba_", "rnea_", "crba_", "chol_", "loop_", "mk_", "kin_", "momentum_")
+
+
+def short(name):
+    n = name.split("(")[0]
+    for pre in ("void rbd::", "rbd::", "void "):
+        if n.startswith(pre):
+            n = n[len(pre):]
+    return n[:80]
+
+
+def pmc(dirname):
+    """kernel -> counter -> mean per dispatch (rows of one dispatch summed first)"""
+    per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k.startswith(OURS):
+                per[k][r["Counter_Name"]][r.get("Dispatch_Id", "0")] += float(r["Counter_Value"])
+    return {k: {c: (sum(v.values()) / len(v), len(v)) for c, v in d.items()} for k, d in per.items()}
+
+
+def main():
+    configs = [int(c) for c in sys.argv[1:]] or [2, 3, 4, 5]
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    h = bench.kernel_source_hash()
+    rec = {}
+    if os.path.exists(path):
+        old = json.load(open(path))
+        if old.get("source_hash") == h:
+            rec = old
+    rec["source_hash"] = h
+    rec["_note"] = ("HBM bytes per bench step (all kernels of one step) from rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, collected in separate passes by "
+                    "scripts/gpu_measure.sh; FETCH_SIZE (KiB) doubled for gfx950 as MI355X_MICROARCH.md (HBM) prescribes, which is exact for wide coalesced "
+                    "reads and an upper bound for the 8-byte strided ones; WRITE_SIZE is uncalibrated.  Infinity-Cache hits are counted, so with inputs "
+                    "re-read every step this is fabric traffic, an upper bound of DRAM traffic.")
+    rec.setdefault("detail", {})
+    for C in configs:
+        cfg = bench.CONFIGS[C]
+        key = f"{cfg['model']}_{cfg['dtype']}_B{cfg['batch']}_{cfg['op']}"
+        # --- kernel stats
+        rows = []
+        for f in glob.glob(os.path.join(OUT, f"stats_c{C}", "**", "*kernel_stats.csv"), recursive=True):
+            rows += list(csv.DictReader(open(f)))
+        with open(os.path.join(ROOT, "profiles", f"r02_kernel_stats_c{C}.csv"), "w") as fo:
+            fo.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {C} --no-cpu-baseline --no-pipelined --steps 60 --warmup 10 ; sources {h}\n")
+            fo.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+            for r in rows:
+                fo.write(",".join(['"' + short(r["Name"]) + '"'] + [r[c] for c in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
+        calls = {short(r["Name"]): int(r["Calls"]) for r in rows}
+        avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+        # --- PMC
+        fetch, write = pmc(os.path.join(OUT, f"pmc_fetch_c{C}")), pmc(os.path.join(OUT, f"pmc_write_c{C}"))
+        sq = pmc(os.path.join(OUT, f"pmc_sq1_c{C}"))
+        for k, d in pmc(os.path.join(OUT, f"pmc_sq2_c{C}")).items():
+            sq.setdefault(k, {}).update(d)
+        step_kernels = [k for k, n in calls.items() if k.startswith(OURS) and n >= 60]
+        total, detail = 0.0, {}
+        with open(os.path.join(ROOT, "profiles", f"r02_pmc_c{C}.txt"), "w") as fo:
+            fo.write(f"# config {C}: {key}; sources {h}; rocprofv3 --pmc (scripts/gpu_measure.sh); per launch, averaged over the launches of the run\n")
+            for k in sorted(set(fetch) | set(write) | set(sq)):
+                fr = fetch.get(k, {}).get("FETCH_SIZE", (0.0, 0))[0] * 1024
+                wr = write.get(k, {}).get("WRITE_SIZE", (0.0, 0))[0] * 1024
+                fo.write(f"{k}  calls={calls.get(k)} avg_ns={avg_ns.get(k)}\n")
+                fo.write(f"  FETCH_SIZE {fr:14.0f} B raw, {2 * fr:14.0f} B with the gfx950 x2 correction; WRITE_SIZE {wr:14.0f} B\n")
+                d = sq.get(k, {})
+                w = d.get("SQ_WAVES", (0, 0))[0]
+                for c in sorted(d):
+                    fo.write(f"  {c:24s} {d[c][0]:16.0f}" + (f"   per wave {d[c][0] / w:12.1f}" if w else "") + "\n")
+                if k in step_kernels:
+                    total += 2 * fr + wr
+                    detail[k] = {"fetch_bytes_raw": fr, "fetch_bytes_x2": 2 * fr, "write_bytes": wr, "avg_ns": avg_ns.get(k),
+                                 "valu_insts_per_wave": (d["SQ_INSTS_VALU"][0] / w) if w and "SQ_INSTS_VALU" in d else None}
+        rec[key] = total if detail else None
+        rec["detail"][key] = detail
+        print(f"config {C} ({key}): step kernels {step_kernels}; traffic {total:.0f} B/step")
+    json.dump(rec, open(path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

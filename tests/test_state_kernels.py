@@ -1,0 +1,128 @@
+"""One-lane-per-state kernels (csrc/rbd_state.hpp: crba_state_kernel, rnea_state_kernel) against the oracle.  They serve large batches
+(default: from half a chip-full of wavefronts up); RBD_STATE_MIN_BATCH=1 routes every batch size through them here, so that the same
+small seeded cases the lane-per-body kernels are tested on apply.  reference: src/mechanism_algorithms.jl:248-272, :387-459, :542-553."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import TD, dev, host, make
+
+pytestmark = pytest.mark.gpu
+IN_SCOPE = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf", "quickstart_pendulum"]
+
+
+@pytest.fixture()
+def states_everywhere(monkeypatch):
+    monkeypatch.setenv("RBD_STATE_MIN_BATCH", "1")
+
+
+def sym(M):
+    return np.tril(M) + np.transpose(np.tril(M, -1), (0, 2, 1))
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", IN_SCOPE)
+def test_state_kernels_f64(rbd, oracle, models, name, layout, states_everywhere):
+    model = models[name]
+    B, nv = 70, model.nv  # two wavefronts, the second partly filled
+    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 41)
+    rng = np.random.default_rng(3)
+    vd = rng.standard_normal((B, nv))
+    # inverse_dynamics! with v̇ and external wrenches; dynamics_bias!
+    out = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state))
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+    assert np.abs(host(out, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    rbd.dynamics_bias_(out, state)
+    ref = oracle.dynamics_bias(model, q, v, None)
+    assert np.abs(host(out, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    # mass_matrix! (batch-innermost layout: straight from the state kernel), structural zeros included
+    result = rbd.DynamicsResult(model, B, layout=layout)
+    result.massmatrix.fill_(float("nan"))
+    rbd.mass_matrix_(result, state)
+    got = host(result.massmatrix, state).reshape(B, nv, nv).transpose(0, 2, 1)
+    Mr = oracle.mass_matrix(model, q)
+    il = np.tril_indices(nv)
+    assert np.isfinite(got[:, il[0], il[1]]).all()
+    assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= 1e-10 * max(1.0, np.abs(Mr).max())
+    # dynamics! through the reference's route: bias + mass matrix + Cholesky, q̇ included
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="crba")
+    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    assert np.abs(host(result.vd, state) - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    assert np.abs(host(result.qd, state) - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
+    assert rbd.sync(state) == 0
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating", "double_pendulum"])
+def test_state_kernels_f32_solve(rbd, oracle, models, name, layout, states_everywhere):
+    """fp32: mass_matrix! + Cholesky solve (BASELINE configs[2] shape).  AOS callers get M re-emitted by the tile Cholesky from the staging copy."""
+    model = models[name]
+    B, nv = 200, model.nv
+    state, q, v, tau, fe = make(rbd, model, B, "f32", layout, 43)
+    x = torch.zeros_like(state.v)
+    Mout = torch.full(((B, nv * nv) if layout == "aos" else (nv * nv, B)), float("nan"), dtype=torch.float32, device="cuda")
+    rbd.mass_matrix_solve_(x, state, dev(tau, state), Mout)
+    assert rbd.sync(state) == 0
+    Mr = oracle.mass_matrix(model, q)
+    got = host(Mout, state).reshape(B, nv, nv).transpose(0, 2, 1)
+    il = np.tril_indices(nv)
+    assert np.isfinite(got[:, il[0], il[1]]).all()
+    assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= 2e-6 * np.abs(Mr).max()
+    Ms, xg = sym(Mr), host(x, state)
+    res = np.einsum("bij,bj->bi", Ms, xg) - tau
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau, axis=1))
+    assert eta.max() <= 1e-5, eta.max()
+    # dynamics! (reference route) in fp32: backward error of M v̇ = τ − c
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32, layout=layout)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="crba")
+    cr = oracle.dynamics_bias(model, q, v, fe)
+    vg = host(result.vd, state)
+    res = np.einsum("bij,bj->bi", Ms, vg) - (tau - cr)
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(vg, axis=1) + np.linalg.norm(tau - cr, axis=1))
+    assert eta.max() <= 2e-5, eta.max()
+
+
+def test_state_kernels_random_trees(rbd, oracle, states_everywhere):
+    """Random revolute / prismatic / fixed / sin-cos trees, with and without a 6-dof root, up to the 12 tree levels the kernels keep in registers."""
+    from test_chain_plan import random_tree
+    rng = np.random.default_rng(19)
+    done = 0
+    for trial in range(16):
+        mech = random_tree(rbd, rng, int(rng.integers(1, 26)), bool(trial % 2), float(rng.uniform(0, 0.6)))
+        model = rbd.flatten(mech)
+        B, nv = 65, model.nv
+        state, q, v, tau, fe = make(rbd, model, B, "f64", "soa", 60 + trial)
+        out = torch.zeros_like(state.v)
+        rbd.dynamics_bias_(out, state, dev(fe, state))
+        ref = oracle.dynamics_bias(model, q, v, fe)
+        assert np.abs(host(out, state) - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), trial
+        result = rbd.DynamicsResult(model, B, layout="soa")
+        rbd.mass_matrix_(result, state)
+        got = host(result.massmatrix, state).reshape(B, nv, nv).transpose(0, 2, 1)
+        Mr = oracle.mass_matrix(model, q)
+        il = np.tril_indices(nv)
+        assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= 1e-9 * max(1.0, np.abs(Mr).max()), trial
+        done += 1
+    assert done == 16
+
+
+def test_state_kernels_take_large_batches_by_default(rbd, oracle, models):
+    """Without the override: B = 65536 fp32 Atlas (BASELINE configs[2]) goes through the state kernels; whole-batch M and solve checked on a sample."""
+    model = models["atlas_floating"]
+    B, nv = 65536, model.nv
+    state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 5)
+    x = torch.zeros_like(state.v)
+    Mout = torch.zeros(B, nv * nv, dtype=torch.float32, device="cuda")
+    rbd.mass_matrix_solve_(x, state, dev(tau, state), Mout)
+    assert rbd.sync(state) == 0
+    assert "crba_state_kernel" in rbd.last_kernel(state)
+    idx = np.arange(0, B, 16)
+    Mr = oracle.mass_matrix(model, q[idx], nthreads=8)
+    got = Mout[torch.as_tensor(idx, device="cuda")].double().cpu().numpy().reshape(len(idx), nv, nv).transpose(0, 2, 1)
+    il = np.tril_indices(nv)
+    assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= 2e-6 * np.abs(Mr).max()
+    Ms, xg = sym(Mr), x[torch.as_tensor(idx, device="cuda")].double().cpu().numpy()
+    res = np.einsum("bij,bj->bi", Ms, xg) - tau[idx]
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau[idx], axis=1))
+    assert eta.max() <= 1e-5, eta.max()
