@@ -80,9 +80,13 @@ enum {
                                 for mechanisms with 3-dof tree joints or a 6-dof joint not on the world           */
   RBD_ALGO_ABA_BANKS = 4,    /* lane-per-body with two bodies per lane (levels split into two banks): twice the
                                 states per wavefront.  Same scope as the chain mapping                            */
-  RBD_ALGO_ABA_TRACKS = 5    /* chains of the tree on a few lanes per state, canonical body frames (joint axis = +z), per-body
+  RBD_ALGO_ABA_TRACKS = 5,   /* chains of the tree on a few lanes per state, canonical body frames (joint axis = +z), per-body
                                 results in lane-private LDS rows: the default wherever it applies (trees of revolute /
                                 prismatic / fixed joints, 6-dof joints on the world).  RBD_ERR_UNSUPPORTED elsewhere        */
+  RBD_ALGO_ABA_WALK = 6      /* the track schedule with one WAVEFRONT per track and one lane per state: a workgroup is up to four
+                                wavefronts over the same 64 states, q / v / tau staged through LDS, per-joint results in accumulation
+                                registers.  Same scope as the track mapping, at most 14 steps per track; RBD_ERR_UNSUPPORTED
+                                elsewhere or when the rows of 64 states do not fit one compute unit's LDS                      */
 };
 
 /* ---- loop (non-tree) joint: src/mechanism_modification.jl:38-43,

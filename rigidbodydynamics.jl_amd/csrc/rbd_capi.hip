@@ -15,6 +15,7 @@
 #include "rbd_internal.hpp"
 #include "rbd_chain_plan.hpp"
 #include "rbd_track_plan.hpp"
+#include "rbd_walk_plan.hpp"
 #include "rbd_state_plan.hpp"
 
 using namespace rbd;
@@ -74,6 +75,7 @@ struct rbd_model {
   uint64_t bank_perm_down = 0;
   ChainPlan chain;  // plan of aba_chain_kernel (chain.ok == false: mechanism outside its scope)
   TrackPlan track;  // plan of aba_track_kernel (track.ok == false: mechanism outside its scope)
+  WalkPlan walk;    // parking slots of aba_walk_kernel on top of the track plan (walk.ok == false: track plan missing or too many steps)
   StatePlan state;  // plan of the one-lane-per-state kernels (state.ok == false: mechanism outside their scope)
 };
 
@@ -84,6 +86,7 @@ struct rbd_ws {
   DevModel dm{};
   BankModel bm{}; void* d_bank_ib[2] = {nullptr, nullptr}; void* d_bank_rb[2] = {nullptr, nullptr};
   TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr; size_t track_lds_bytes4 = 0; long track_nw4_max_batch = 0; size_t track_lds_bytes = 0; long track_min_batch = 0;
+  WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0; long walk_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   ChainModel cm{}; void* d_chain_tab = nullptr; void* d_chain_cb = nullptr; size_t chain_lds_bytes = 0; long bank_min_batch = 0;
@@ -333,6 +336,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     if (const char* e = getenv("RBD_CHAIN_G")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) G = g; }
     if (m->nloops == 0) m->chain = build_chain_plan(nb, m->ib, G);
     if (m->nloops == 0 && G <= 4) m->track = build_track_plan(nb, m->ib, m->rb, G);
+    if (m->track.ok) m->walk = build_walk_plan(m->track.ns, m->track.G, m->track.ri);
     if (m->nloops == 0) m->state = build_state_plan(nb, m->ib, m->rb);
   }
   *out = m;
@@ -520,6 +524,26 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->track_min_batch = (long)1 << 62;
     if (const char* e = getenv("RBD_TRACK_MIN_BATCH")) w->track_min_batch = atol(e);
   }
+  if (m->track.ok && m->walk.ok) {
+    const TrackPlan& P = m->track;
+    st = upload(&w->d_walk_wk, m->walk.wk.data(), m->walk.wk.size() * sizeof(int32_t));
+    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+    WalkModel& wm = w->wm;
+    wm.ns = P.ns; wm.G = P.G; wm.nA = P.nA; wm.nB = P.nB; wm.nS = m->walk.nS; wm.nq = m->nq; wm.nv = m->nv;
+    wm.ri = (const int32_t*)w->d_track_ri; wm.rr = w->d_track_rr; wm.wk = (const int32_t*)w->d_walk_wk;
+    for (int k = 0; k < 5; ++k) wm.sfm[k] = w->tm.sfm[k];
+    memcpy(wm.gravity, m->gravity, sizeof wm.gravity);
+    w->walk_lds_bytes = walk_lds_bytes(P.ns, P.G, m->nq, m->nv, P.nA, P.nB, m->walk.nS, dtype == RBD_F64 ? 8 : 4);
+    if (w->walk_lds_bytes > 160 * 1024) w->walk_lds_bytes = 0;  // the rows of 64 states do not fit one CU's LDS: other mappings
+    if (w->walk_lds_bytes > 0) {
+      const hipError_t e = dtype == RBD_F64 ? configure_walk_kernel<double>(P.has_floating, P.general, w->walk_lds_bytes)
+                                            : configure_walk_kernel<float>(P.has_floating, P.general, w->walk_lds_bytes);
+      if (e != hipSuccess) { g_last_hip_error = std::string("configure_walk_kernel: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
+    }
+    // RBD_ALGO_ABA picks it from this batch size up (RBD_WALK_MIN_BATCH overrides; profiles/r02_walk_sweep.txt)
+    w->walk_min_batch = (long)1 << 62;
+    if (const char* e = getenv("RBD_WALK_MIN_BATCH")) w->walk_min_batch = atol(e);
+  }
   if (m->state.ok && m->state.nlevels <= state_max_levels(dtype == RBD_F64 ? 8 : 4)) {
     const StatePlan& P = m->state;
     st = upload(&w->d_state_ops, P.ops.data(), P.ops.size() * sizeof(int32_t));
@@ -558,7 +582,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_walk_wk, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -751,14 +775,22 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   const bool can_chain = m->chain.ok && w->chain_lds_bytes > 0 && !fuse, can_bank = m->bank_lps > 0 && m->bank_aba_ok;
   // the track kernel addresses its batch buffers with 32-bit byte offsets
   const bool can_track = m->track.ok && w->track_lds_bytes > 0 && !fuse && (double)B * (double)std::max(std::max(m->nq, m->nv), 6 * m->nb) * 8.0 < 4.0e9;
+  const bool can_walk = m->track.ok && m->walk.ok && w->walk_lds_bytes > 0 && !fuse;
+  if (algorithm == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_TRACKS && !can_track) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_CHAINS && !can_chain) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   int pick = algorithm;
-  if (algorithm == RBD_ALGO_ABA) pick = (can_track && B >= w->track_min_batch) ? RBD_ALGO_ABA_TRACKS : (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
+  if (algorithm == RBD_ALGO_ABA) pick = (can_walk && B >= w->walk_min_batch) ? RBD_ALGO_ABA_WALK : (can_track && B >= w->track_min_batch) ? RBD_ALGO_ABA_TRACKS : (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
   Timed t(w);
   w->last_kernel = pick == RBD_ALGO_ABA_TRACKS ? "aba_track_kernel" : pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : pick == RBD_ALGO_ABA_CHAINS ? "aba_chain_kernel" : "aba_kernel";
-  if (pick == RBD_ALGO_ABA_TRACKS) {
+  if (pick == RBD_ALGO_ABA_WALK) {
+    WalkModel wm = w->wm;
+    if (gravity) memcpy(wm.gravity, gravity, sizeof wm.gravity);
+    w->last_kernel = "aba_walk_kernel";
+    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, m->track.has_floating, m->track.general, B, w->walk_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_aba_walk<float>(wm, m->track.has_floating, m->track.general, B, w->walk_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+  } else if (pick == RBD_ALGO_ABA_TRACKS) {
     TrackModel tm = w->tm;
     if (gravity) memcpy(tm.gravity, gravity, sizeof tm.gravity);
     const int flt = m->track.has_floating, gen = m->track.general;

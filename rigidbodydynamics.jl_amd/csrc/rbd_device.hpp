@@ -93,6 +93,16 @@ struct TrackModel {
   double gravity[3];
 };
 
+// ---- the track schedule with one wavefront per track and one lane per state (aba_walk_kernel, rbd_walk.hpp; rbd_walk_plan.hpp) ----
+struct WalkModel {
+  int32_t ns, G, nA, nB, nS, nq, nv;
+  const int32_t* ri;  // [ns * G * TI_STRIDE]  track-plan records
+  const void* rr;     // [ns * G * TR_STRIDE]  ... constants, kernel scalar type
+  const int32_t* wk;  // [ns * G]              parking slots (rbd_walk_plan.hpp)
+  uint64_t sfm[5];    // wave-uniform step flags (SF_* of rbd_track.hpp)
+  double gravity[3];
+};
+
 // ---- one lane per state (crba_state_kernel / rnea_state_kernel, rbd_state.hpp; plan: rbd_state_plan.hpp) ------------------------
 // The depth-first walk of the tree as a flat op list: ENTER(body) on the way down, EXIT(body) when its subtree is done.
 //   op words: w0 = kind | level << 8 | joint type << 16, slot, q offset, v offset, 6 * reference body index

@@ -62,6 +62,11 @@ template <typename T>
 hipError_t launch_aba_track(const TrackModel& M, int flt, int gen, int nw, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
                             void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 template <typename T> hipError_t configure_track_kernel(int G, int flt, int gen, size_t lds_bytes);
+// rbd_walk_kernels.hip: one wavefront per track, one lane per state
+template <typename T>
+hipError_t launch_aba_walk(const WalkModel& M, int flt, int gen, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
+                           void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+template <typename T> hipError_t configure_walk_kernel(int flt, int gen, size_t lds_bytes);
 // rbd_state_kernels.hip: one lane per state
 int state_max_levels(int element_size);
 template <typename T>

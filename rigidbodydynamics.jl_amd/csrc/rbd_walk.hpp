@@ -1,0 +1,676 @@
+// rbd_walk.hpp — aba_walk_kernel: the fused articulated-body algorithm with ONE WAVEFRONT PER TRACK and ONE LANE PER STATE.
+//
+// Same result as the reference's dynamics! (src/mechanism_algorithms.jl:845-864: v̇ = M⁻¹(τ − c), q̇) and as the other mappings; all
+// quantities in the ROOT frame like the reference (src/mechanism_state.jl:744-748, :776, :842).  Same schedule and records as the
+// track mapping (rbd_track_plan.hpp: the tree cut into chains, the chains packed on G <= 4 tracks, canonical body frames with every
+// 1-dof joint axis = +z, bias accelerations folded into the bias force) — but a workgroup is G wavefronts over the same 64 states:
+//   * wavefront g walks track g; lane l is state l of the workgroup.  Which body, which joint type, which mailboxes: all of it is
+//     wave-uniform, so the control flow runs on the scalar unit and every vector instruction does 64 states' worth of useful work
+//     (the lane-per-body sweeps keep ~15 % of their lanes busy, the lane-per-track mapping ~70 % of a quarter-filled chip);
+//   * NOTHING IS READ FROM OR WRITTEN TO GLOBAL MEMORY INSIDE THE PASSES (measured on the one-lane-per-state RNEA of rbd_state.hpp: a
+//     wavefront that owns its SIMD pays every dependent global round trip in full).  q, v, τ of the 64 states are transposed into
+//     LDS rows by the whole workgroup with coalesced loads; v̇ is written over the τ rows, q̇ over the q rows, and both leave the same way;
+//   * no per-body results of pass A are kept.  Pass A only runs the kinematic chain (transform, twist, velocity-product acceleration);
+//     pass B starts at the leaf of a chain with those in registers, computes the body's root-frame inertia and bias force on the spot
+//     and then UN-COMPOSES the joint (H_parent = H X_joint⁻¹, T_parent = T − S q̇, a_parent = a − [T, S q̇]) to arrive at the parent;
+//     pass C composes the transforms again on the way down to get the motion subspace.  What a body leaves behind is 9 scalars
+//     (sin q, cos q, U D⁻¹, D⁻¹u) in ACCUMULATION REGISTERS (a wavefront that owns its SIMD has 256 of them besides the 256 VGPRs;
+//     the step index selects them through a scalar `switch` — registers cannot be indexed at run time);
+//   * edges between tracks go through LDS mailboxes as in the track mapping, fenced by workgroup barriers at exactly the steps whose
+//     wave-uniform flags say a mailbox is written (3–4 per pass for a humanoid).
+// LDS per workgroup (fp64 Atlas: 158 KB of the CU's 160 KB; fp32: half): rbd_walk_plan.hpp.
+//
+// The step functions are __host__ __device__: tests/emu/walk_emu.hip runs the same code lane by lane on the CPU, wavefront by
+// wavefront between barriers (in both orders, so that a missing barrier reads a never-written mailbox and fails).
+#pragma once
+#include "rbd_device.hpp"
+#include "rbd_track.hpp"
+#include "rbd_walk_plan.hpp"
+
+namespace rbd {
+
+// `switch (s)` with the step index as a compile-time constant SV inside every case
+#define RBD_WALK_CASE(N, ...) case N: { constexpr int SV = N; __VA_ARGS__ } break;
+#define RBD_WALK_SWITCH(s, ...)                                                                                                   \
+  switch (s) {                                                                                                                    \
+    RBD_WALK_CASE(0, __VA_ARGS__) RBD_WALK_CASE(1, __VA_ARGS__) RBD_WALK_CASE(2, __VA_ARGS__) RBD_WALK_CASE(3, __VA_ARGS__)        \
+    RBD_WALK_CASE(4, __VA_ARGS__) RBD_WALK_CASE(5, __VA_ARGS__) RBD_WALK_CASE(6, __VA_ARGS__) RBD_WALK_CASE(7, __VA_ARGS__)        \
+    RBD_WALK_CASE(8, __VA_ARGS__) RBD_WALK_CASE(9, __VA_ARGS__) RBD_WALK_CASE(10, __VA_ARGS__) RBD_WALK_CASE(11, __VA_ARGS__)      \
+    RBD_WALK_CASE(12, __VA_ARGS__)                                                                                                \
+    default: break;                                                                                                               \
+  }
+
+// What a body leaves behind between the passes: 9 scalars per step of the track.
+//   0 sin q · 1 cos q · [2, 8) U D⁻¹ (a 6-dof root: its a_Δ) · 8 D⁻¹u
+// Device: accumulation registers addressed by immediates, counted DOWN from a255 — the register allocator hands out accumulation registers from
+// a0 upwards when it runs out of VGPRs (it parks a few loop-invariant values there in the fp64 kernels), and build.sh checks on the generated
+// assembly (scripts/check_walk_agprs.py) that what it takes stays below the WALK_MAX_STEPS steps' worth reserved here.  Host (emulation): an array.
+enum { WS_SN = 0, WS_CS = 1, WS_W = 2, WS_UD = 8, WS_N = 9 };
+template <typename T> struct WalkStash {
+#if defined(__HIP_DEVICE_COMPILE__)
+  template <int S, int K> RBD_DEV void put(T x);
+  template <int S, int K> RBD_DEV T get() const;
+#else
+  T v[WALK_MAX_STEPS][WS_N];
+  template <int S, int K> void put(T x) { v[S][K] = x; }
+  template <int S, int K> T get() const { return v[S][K]; }
+#endif
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <> template <int S, int K> RBD_DEV void WalkStash<float>::put(float x) { asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(x), "n"(255 - (S * WS_N + K))); }
+template <> template <int S, int K> RBD_DEV float WalkStash<float>::get() const {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(255 - (S * WS_N + K)));
+  return x;
+}
+template <> template <int S, int K> RBD_DEV void WalkStash<double>::put(double x) {
+  asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(__double2loint(x)), "n"(254 - 2 * (S * WS_N + K)));
+  asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(__double2hiint(x)), "n"(255 - 2 * (S * WS_N + K)));
+}
+template <> template <int S, int K> RBD_DEV double WalkStash<double>::get() const {
+  int lo, hi;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(lo) : "n"(254 - 2 * (S * WS_N + K)));
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(hi) : "n"(255 - 2 * (S * WS_N + K)));
+  return __hiloint2double(hi, lo);
+}
+#endif
+
+RBD_HD int walk_uniform(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_readfirstlane(x);
+#else
+  return x;
+#endif
+}
+
+template <typename T> struct WalkCtx {
+  WalkModel M;
+  // LDS (rows are [field][WR_STRIDE], a lane's value of a field at row[lane])
+  const I4* tri; const int32_t* twk; const T* trr;
+  T* rows;
+  int rq, rv, rt, rA, rS, rB;  // first row of q | v | τ / v̇ | A mailboxes | parking slots | B mailboxes (pass C: its mailboxes)
+  T a0[6];
+};
+
+template <typename T> RBD_HD void walk_ctx_lds(WalkCtx<T>& c, void* lds) {
+  const size_t nrec = (size_t)c.M.ns * c.M.G;
+  c.tri = reinterpret_cast<const I4*>(lds);
+  c.trr = reinterpret_cast<const T*>(c.tri + nrec);
+  c.twk = reinterpret_cast<const int32_t*>(c.trr + nrec * TR_STRIDE);
+  c.rows = reinterpret_cast<T*>(reinterpret_cast<char*>(lds) + nrec * 16 + nrec * TR_STRIDE * sizeof(T) + ((nrec * 4 + 15) & ~(size_t)15));
+  c.rq = 0; c.rv = c.M.nq; c.rt = c.rv + c.M.nv; c.rA = c.rt + c.M.nv; c.rS = c.rA + c.M.nA * WMB_A; c.rB = c.rS + c.M.nS * WMB_S;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { c.a0[k] = T(0); c.a0[3 + k] = T(-c.M.gravity[k]); }  // a_world = −gravity (mechanism_algorithms.jl:405)
+}
+template <typename T> RBD_HD T* walk_row(const WalkCtx<T>& c, int row, int lane) { return c.rows + (long)row * WR_STRIDE + lane; }
+
+// per-lane recursion state of a track
+template <typename T> struct WalkRegs {
+  T R[9], p[3], Tw[6], av[6];  // kinematics of the body last visited: transform to root, twist, velocity-product acceleration
+  T cI[21], cP[6];             // pass B: hand-off of the chained child (zero at the leaf of a chain)
+  T ad[6];                     // pass C: a_Δ of the body last visited
+};
+template <typename T> RBD_HD void walk_init(WalkRegs<T>& W) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) W.R[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) W.p[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { W.Tw[k] = T(0); W.av[k] = T(0); }
+}
+// the hand-off registers start their life with pass B, a_Δ with pass C (kept out of the earlier passes' register pressure)
+template <typename T> RBD_HD void walk_init_b(WalkRegs<T>& W) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) W.cP[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < 21; ++k) W.cI[k] = T(0);
+}
+template <typename T> RBD_HD void walk_init_c(WalkRegs<T>& W) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) W.ad[k] = T(0);
+}
+
+struct WalkRec { int flags, qoff, voff, orig6, nbr, a_w, a_r, b_w, b_r0, park; };
+// the raw words of a record: read from LDS a step ahead (walk_raw), made wave-uniform scalars when the step starts (walk_rec)
+struct WalkRaw { I4 w; int32_t k; };
+template <typename T> RBD_HD WalkRaw walk_raw(const WalkCtx<T>& c, int s, int g) {
+  WalkRaw x;
+  x.w = c.tri[s * c.M.G + g];
+  x.k = c.twk[s * c.M.G + g];
+  return x;
+}
+RBD_HD WalkRec walk_rec(const WalkRaw& raw) {
+  WalkRec r;
+  const int x = walk_uniform(raw.w.x), y = walk_uniform(raw.w.y), z = walk_uniform(raw.w.z), ww = walk_uniform(raw.w.w);
+  r.flags = (y >> 16) & 0xff; r.qoff = x & 0xffff; r.voff = (x >> 16) & 0xffff; r.orig6 = y & 0xffff; r.nbr = (y >> 24) & 0x7f;
+  r.a_w = (z & 0xffff) - 1; r.a_r = ((z >> 16) & 0xffff) - 1; r.b_w = (ww & 0xffff) - 1; r.b_r0 = ((ww >> 16) & 0xffff) - 1;
+  r.park = walk_uniform(raw.k) - 1;
+  if (r.flags & TF_FIXED) { r.qoff = 0; r.voff = 0; }  // a fixed joint has no coordinates: its offsets may be one past the end
+  return r;
+}
+// the constants of a record, LDS -> registers
+template <typename T, int N> RBD_HD void walk_consts(const WalkCtx<T>& c, int s, int g, T* rr) {  // the first N: (C, pp) = 12 is all passes A and C need
+  const T* src = c.trr + (long)(s * c.M.G + g) * TR_STRIDE;
+#pragma unroll
+  for (int k = 0; k < N; ++k) rr[k] = src[k];
+}
+
+template <typename T> RBD_HD void walk_put_kin(T* m, const WalkRegs<T>& W) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) m[k * WR_STRIDE] = W.R[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) m[(9 + k) * WR_STRIDE] = W.p[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { m[(12 + k) * WR_STRIDE] = W.Tw[k]; m[(18 + k) * WR_STRIDE] = W.av[k]; }
+}
+template <typename T> RBD_HD void walk_get_kin(const T* m, WalkRegs<T>& W) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) W.R[k] = m[k * WR_STRIDE];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) W.p[k] = m[(9 + k) * WR_STRIDE];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { W.Tw[k] = m[(12 + k) * WR_STRIDE]; W.av[k] = m[(18 + k) * WR_STRIDE]; }
+}
+
+// 1-dof joint in the canonical frame: (Rn, pn) = (R, p) * (C, pp) * joint(q), joint = rotation by (sn, cs) about z, or translation d along z
+template <typename T, bool GEN>
+RBD_HD void walk_compose(const T* R, const T* p, const T* rr, int flags, T sn, T cs, T d, T* Rn, T* pn) {
+  T Mx[9], u3[3];
+  matmul3(R, rr + TR_C, Mx);
+  matvec3(R, rr + TR_PP, u3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pn[k] = p[k] + u3[k];
+  if (GEN) {
+    if (flags & TF_PRISMATIC) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pn[k] += Mx[3 * k + 2] * d;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {  // revolute.jl:59-62 in the canonical frame: columns 0 and 1 are mixed
+    Rn[3 * i] = cs * Mx[3 * i] + sn * Mx[3 * i + 1];
+    Rn[3 * i + 1] = cs * Mx[3 * i + 1] - sn * Mx[3 * i];
+    Rn[3 * i + 2] = Mx[3 * i + 2];
+  }
+}
+// root-frame motion subspace of a 1-dof joint from its body's transform (axis = +z column of R)
+template <typename T, bool GEN> RBD_HD void walk_subspace(const T* R, const T* p, int flags, T* S) {
+  const T z[3] = {R[2], R[5], R[8]};
+  if (GEN && (flags & TF_PRISMATIC)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { S[k] = T(0); S[3 + k] = z[k]; }
+  } else if (GEN && (flags & TF_FIXED)) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S[k] = T(0);
+  } else {
+    cross3(p, z, S + 3);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S[k] = z[k];
+  }
+}
+// 6-dof joint on a parent (quaternion_floating.jl:81-83): H = H_parent * (C, pp) * (R(quat), trans)
+template <typename T> RBD_HD void walk_compose_floating(const T* R, const T* p, const T* rr, const T* q7, T* Rn, T* pn) {
+  T Rq[9], CR[9], t3[3], u3[3];
+  rot_quat(q7[0], q7[1], q7[2], q7[3], Rq);
+  matmul3(rr + TR_C, Rq, CR);
+  matmul3(R, CR, Rn);
+  matvec3(rr + TR_C, q7 + 4, t3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t3[k] += rr[TR_PP + k];
+  matvec3(R, t3, u3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pn[k] = p[k] + u3[k];
+}
+
+// the parent's kinematics: nothing to do when chained (the registers hold them); the world; or the parent's A mailbox
+template <typename T> RBD_HD void walk_parent_kin(const WalkCtx<T>& c, const WalkRec& r, int lane, WalkRegs<T>& W) {
+  if (r.flags & TF_CHAINED) return;
+  if (r.flags & TF_LEVEL0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) W.R[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) W.p[k] = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { W.Tw[k] = T(0); W.av[k] = c.a0[k]; }
+  } else {
+    walk_get_kin(walk_row(c, c.rA + r.a_r * WMB_A, lane), W);
+  }
+}
+
+// ---------------- pass A (root -> leaves): the kinematic chain ----------------
+template <typename T, bool FLT, bool GEN>
+RBD_HD void walk_step_a(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, bool want_qdot) {
+  if (!(r.flags & TF_VALID)) return;
+  walk_parent_kin(c, r, lane, W);
+  T Rn[9], pn[3], vJ[6], cb[6];
+  bool done = false;
+  if (FLT) {
+    if (r.flags & TF_FLOATING) {
+      T q7[7], v6[6];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) q7[k] = *walk_row(c, c.rq + r.qoff + k, lane);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v6[k] = *walk_row(c, c.rv + r.voff + k, lane);
+      walk_compose_floating(W.R, W.p, rr, q7, Rn, pn);
+      xmotion(Rn, pn, v6, vJ);  // twist of the joint: X(H) v, v the body-frame twist
+      if (want_qdot) {  // velocity_to_configuration_derivative! (quaternion_floating.jl:126-136, spatial/util.jl:127-134), over the q rows
+        const T qw = q7[0], qx = q7[1], qy = q7[2], qz = q7[3];
+        T o[7], Rq[9];
+        o[0] = (-qx * v6[0] - qy * v6[1] - qz * v6[2]) / 2;
+        o[1] = (qw * v6[0] - qz * v6[1] + qy * v6[2]) / 2;
+        o[2] = (qz * v6[0] + qw * v6[1] - qx * v6[2]) / 2;
+        o[3] = (-qy * v6[0] + qx * v6[1] + qw * v6[2]) / 2;
+        rot_quat(qw, qx, qy, qz, Rq);
+        matvec3(Rq, v6 + 3, o + 4);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) *walk_row(c, c.rq + r.qoff + k, lane) = o[k];
+      }
+      done = true;
+    }
+  }
+  if (!done) {
+    const T q0 = *walk_row(c, c.rq + r.qoff, lane);
+    const T qd = (GEN && (r.flags & TF_FIXED)) ? T(0) : *walk_row(c, c.rv + r.voff, lane);
+    T sn, cs;  // what the later passes need of q: (sin, cos) of a rotation — or, in the sin slot, the displacement of a prismatic joint
+    if (GEN && (r.flags & TF_SINCOS)) {  // sin_cos_revolute.jl:69-96: q = (sin θ, cos θ); d/dt (sin θ, cos θ) = (cos θ, −sin θ) θ̇
+      sn = q0; cs = *walk_row(c, c.rq + r.qoff + 1, lane);
+      if (want_qdot) { *walk_row(c, c.rq + r.qoff, lane) = cs * qd; *walk_row(c, c.rq + r.qoff + 1, lane) = -sn * qd; }
+    } else {
+      if (GEN && (r.flags & (TF_PRISMATIC | TF_FIXED))) { sn = T(0); cs = T(1); }
+      else sincos_fast(q0, &sn, &cs);
+      if (want_qdot && !(GEN && (r.flags & TF_FIXED))) *walk_row(c, c.rq + r.qoff, lane) = qd;
+    }
+    walk_compose<T, GEN>(W.R, W.p, rr, r.flags, sn, cs, q0, Rn, pn);
+    T S[6];
+    walk_subspace<T, GEN>(Rn, pn, r.flags, S);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
+    if (GEN && (r.flags & TF_PRISMATIC)) sn = q0;
+    RBD_WALK_SWITCH(s, { St.template put<SV, WS_SN>(sn); St.template put<SV, WS_CS>(cs); })
+  }
+  se3_comm(W.Tw, vJ, cb);  // [T_parent, vJ] = [T_b, vJ]: bias acceleration increment (mechanism_state.jl:814-830)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { W.av[k] += cb[k]; W.Tw[k] += vJ[k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) W.R[k] = Rn[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) W.p[k] = pn[k];
+  if (r.a_w >= 0) walk_put_kin(walk_row(c, c.rA + r.a_w * WMB_A, lane), W);  // some child is not next on this track
+  if (r.park >= 0) walk_put_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);  // pass B will not arrive here from a chained child
+}
+
+// ---------------- pass B (leaves -> root): articulated-body inertias and bias forces ----------------
+// fe: this body's external wrench (zero without); the caller has it in registers before the step (prefetched a step ahead)
+template <typename T, bool FLT, bool GEN>
+RBD_HD void walk_step_b(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, const T* fe) {
+  if (!(r.flags & TF_VALID)) return;
+  if (r.park >= 0) walk_get_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);
+  // spatial inertia in the root frame (mechanism_state.jl:836-846), p̃A = I a_vp + T ×* I T − w_ext (newton_euler, :872-876)
+  T IA[21], pA[6];
+  {
+    RInertia<T> I;
+    inertia_to_root(rr + TR_J, rr + TR_MC, rr[TR_M], W.R, W.p, I);
+    T h[6];
+    mul_inertia(I, W.av, pA);
+    momentum_cross(I, W.Tw, h);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pA[k] += h[k] - fe[k] + W.cP[k];
+    sym6_from_inertia(I, IA);
+  }
+#pragma unroll
+  for (int k = 0; k < 21; ++k) IA[k] += W.cI[k];
+  for (int j = 0; j < r.nbr; ++j) {  // hand-offs of the children that finished on other tracks (or earlier on this one)
+    const T* m = walk_row(c, c.rB + (r.b_r0 + j) * WMB_B, lane);
+#pragma unroll
+    for (int k = 0; k < 21; ++k) IA[k] += m[k * WR_STRIDE];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pA[k] += m[(21 + k) * WR_STRIDE];
+  }
+  bool done = false;
+  if (FLT) {
+    if (r.flags & TF_FLOATING) {
+      // 6-dof joint on the world: IA a_Δ = S⁻ᵀτ − p̃A, v̇ = S⁻¹ a_Δ  (S = X(H): the body-frame twist basis seen from the root)
+      T t6[6], f6[6], a[6], vd[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t6[k] = *walk_row(c, c.rt + r.voff + k, lane);
+      xforce(W.R, W.p, t6, f6);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) f6[k] -= pA[k];
+      sym6_solve(IA, f6, a);
+      xmotion_inv(W.R, W.p, a, vd);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) *walk_row(c, c.rt + r.voff + k, lane) = vd[k];
+      RBD_WALK_SWITCH(s, {
+        St.template put<SV, WS_W + 0>(a[0]); St.template put<SV, WS_W + 1>(a[1]); St.template put<SV, WS_W + 2>(a[2]);
+        St.template put<SV, WS_W + 3>(a[3]); St.template put<SV, WS_W + 4>(a[4]); St.template put<SV, WS_W + 5>(a[5]);
+      })
+      done = true;
+    }
+  }
+  T S[6], qd = T(0);
+  if (!done) {
+    walk_subspace<T, GEN>(W.R, W.p, r.flags, S);
+    T U[6], Wd[6];
+    sym6_mul(IA, S, U);
+    T Dinv = rcp_hd(dot6(S, U));
+    T tq = *walk_row(c, c.rt + r.voff, lane);
+    qd = *walk_row(c, c.rv + r.voff, lane);
+    if (GEN) {
+      if (r.flags & TF_FIXED) { Dinv = T(0); tq = T(0); qd = T(0); }  // a fixed joint has S = 0: the body hands its whole inertia up
+    }
+    const T ud = (tq - dot6(S, pA)) * Dinv;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Wd[k] = U[k] * Dinv;
+    RBD_WALK_SWITCH(s, {
+      St.template put<SV, WS_W + 0>(Wd[0]); St.template put<SV, WS_W + 1>(Wd[1]); St.template put<SV, WS_W + 2>(Wd[2]);
+      St.template put<SV, WS_W + 3>(Wd[3]); St.template put<SV, WS_W + 4>(Wd[4]); St.template put<SV, WS_W + 5>(Wd[5]);
+      St.template put<SV, WS_UD>(ud);
+    })
+    // hand-off: Ia = IA − U D⁻¹ U', p̃a = p̃A + U D⁻¹ u
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) W.cI[SI(i, j)] = IA[SI(i, j)] - Wd[i] * U[j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) W.cP[k] = pA[k] + U[k] * ud;
+  }
+  if (r.b_w >= 0 || (r.flags & TF_LEVEL0)) {  // the parent is not next on this track (or is the world): the hand-off leaves the registers
+    if (r.b_w >= 0) {
+      T* m = walk_row(c, c.rB + r.b_w * WMB_B, lane);
+#pragma unroll
+      for (int k = 0; k < 21; ++k) m[k * WR_STRIDE] = W.cI[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) m[(21 + k) * WR_STRIDE] = W.cP[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 21; ++k) W.cI[k] = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) W.cP[k] = T(0);
+  }
+  if (r.flags & TF_CHAINED) {
+    // un-compose the joint: the next step of this track is the parent.  T_parent = T − S q̇, a_parent = a − [T, S q̇],
+    // R_parent = (R rot_z(q)⁻¹) C', p_parent = p − d z − R_parent pp
+    T vJ[6], cb[6], sn = T(0), cs = T(1);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
+    se3_comm(W.Tw, vJ, cb);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { W.av[k] -= cb[k]; W.Tw[k] -= vJ[k]; }
+    RBD_WALK_SWITCH(s, { sn = St.template get<SV, WS_SN>(); cs = St.template get<SV, WS_CS>(); })
+    if (GEN) {
+      if (r.flags & TF_PRISMATIC) {  // the sin slot holds the displacement
+        const T d = sn;
+        sn = T(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) W.p[k] -= W.R[3 * k + 2] * d;
+      }
+    }
+    T Mx[9], u3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Mx[3 * i] = cs * W.R[3 * i] - sn * W.R[3 * i + 1];
+      Mx[3 * i + 1] = sn * W.R[3 * i] + cs * W.R[3 * i + 1];
+      Mx[3 * i + 2] = W.R[3 * i + 2];
+    }
+    const T* C = rr + TR_C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) W.R[3 * i + j] = Mx[3 * i] * C[3 * j] + Mx[3 * i + 1] * C[3 * j + 1] + Mx[3 * i + 2] * C[3 * j + 2];  // Mx C'
+    matvec3(W.R, rr + TR_PP, u3);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) W.p[k] -= u3[k];
+  }
+}
+
+// ---------------- pass C (root -> leaves): v̇ and a_Δ ----------------
+template <typename T, bool FLT, bool GEN>
+RBD_HD void walk_step_c(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane) {
+  if (!(r.flags & TF_VALID)) return;
+  if (!(r.flags & TF_CHAINED)) {
+    if (r.flags & TF_LEVEL0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) W.R[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) W.p[k] = T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W.ad[k] = T(0);
+    } else {
+      const T* m = walk_row(c, c.rA + r.a_r * WMB_A, lane);  // the parent's transform is still in its A mailbox
+#pragma unroll
+      for (int k = 0; k < 9; ++k) W.R[k] = m[k * WR_STRIDE];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) W.p[k] = m[(9 + k) * WR_STRIDE];
+      const T* mc = walk_row(c, c.rB + r.a_r * WMB_C, lane);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W.ad[k] = mc[k * WR_STRIDE];
+    }
+  }
+  bool done = false;
+  if (FLT) {
+    if (r.flags & TF_FLOATING) {  // a_Δ was solved for in pass B (v̇ is already in its rows); the body's transform is in its own A mailbox
+      RBD_WALK_SWITCH(s, {
+        W.ad[0] = St.template get<SV, WS_W + 0>(); W.ad[1] = St.template get<SV, WS_W + 1>(); W.ad[2] = St.template get<SV, WS_W + 2>();
+        W.ad[3] = St.template get<SV, WS_W + 3>(); W.ad[4] = St.template get<SV, WS_W + 4>(); W.ad[5] = St.template get<SV, WS_W + 5>();
+      })
+      const T* m = walk_row(c, c.rA + r.a_w * WMB_A, lane);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) W.R[k] = m[k * WR_STRIDE];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) W.p[k] = m[(9 + k) * WR_STRIDE];
+      done = true;
+    }
+  }
+  if (!done) {
+    T sn = T(0), cs = T(1), Wd[6], ud = T(0);
+    RBD_WALK_SWITCH(s, {
+      sn = St.template get<SV, WS_SN>(); cs = St.template get<SV, WS_CS>(); ud = St.template get<SV, WS_UD>();
+      Wd[0] = St.template get<SV, WS_W + 0>(); Wd[1] = St.template get<SV, WS_W + 1>(); Wd[2] = St.template get<SV, WS_W + 2>();
+      Wd[3] = St.template get<SV, WS_W + 3>(); Wd[4] = St.template get<SV, WS_W + 4>(); Wd[5] = St.template get<SV, WS_W + 5>();
+    })
+    T d = T(0);
+    if (GEN) {
+      if (r.flags & TF_PRISMATIC) { d = sn; sn = T(0); }  // the sin slot holds the displacement
+    }
+    T Rn[9], pn[3], S[6];
+    walk_compose<T, GEN>(W.R, W.p, rr, r.flags, sn, cs, d, Rn, pn);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) W.R[k] = Rn[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) W.p[k] = pn[k];
+    if (!(GEN && (r.flags & TF_FIXED))) {
+      walk_subspace<T, GEN>(W.R, W.p, r.flags, S);
+      const T vd = ud - dot6(Wd, W.ad);  // v̇ = D⁻¹u − (U D⁻¹)' a_Δ,parent
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W.ad[k] += S[k] * vd;
+      *walk_row(c, c.rt + r.voff, lane) = vd;
+    }
+  }
+  if (r.a_w >= 0) {
+    T* m = walk_row(c, c.rB + r.a_w * WMB_C, lane);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m[k * WR_STRIDE] = W.ad[k];
+  }
+}
+
+#if defined(__HIPCC__)
+#ifdef RBD_PROFILE_PHASES
+__device__ long long rbd_walk_phase_clock[16];
+#define RBD_WMARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) rbd_walk_phase_clock[i] = clock64(); } while (0)
+#else
+#define RBD_WMARK(i)
+#endif
+
+// Staging.  Rows [row0, row0 + n) hold the n x 64 block of a batch buffer that belongs to this workgroup's states.  A state-major buffer
+// (sk == 1) is ONE contiguous run of 64 n scalars: thread t takes elements t, t + nthreads, ... (coalesced) and element e belongs to row
+// (e mod n), column (e div n) — consecutive lanes hit consecutive rows, WR_STRIDE = 65 scalars apart: no bank conflicts.  A batch-innermost
+// buffer is taken row by row.  States past the end of the batch read the last state's values (finite, never stored).
+// All loads of a round are issued before the first LDS write (a wavefront pays every dependent global round trip in full).
+struct WalkSlot { int k, st; long off; bool ok; };
+RBD_DEV WalkSlot walk_slot(Layout L, long state0, long B, int n, int e, unsigned inv) {
+  WalkSlot x;
+  x.ok = e < n * 64;
+  if (L.sk == 1) {
+    x.st = (int)(((unsigned)e * inv) >> 22);  // e / n for e < 2^13, n < 2^9
+    x.k = e - x.st * n;
+  } else {
+    x.k = e >> 6; x.st = e & 63;
+  }
+  const long sc = state0 + x.st < B ? state0 + x.st : B - 1;
+  x.off = (long)x.k * L.sk + sc * L.sb;
+  return x;
+}
+template <typename T, int UB>
+__device__ __forceinline__ void walk_stage_in(const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau, Layout Lq, Layout Lv, long state0,
+                                              long B, int nq, int nv, T* rows, int rq, int rv, int rt, int tid, int nth) {
+  const unsigned invq = (1u << 22) / (unsigned)nq + 1, invv = (1u << 22) / (unsigned)(nv > 0 ? nv : 1) + 1;
+  const int nmax = (nq > nv ? nq : nv) * 64;
+  for (int e0 = 0; e0 < nmax; e0 += UB * nth) {
+    T a[UB], b[UB], d[UB];
+    WalkSlot sa[UB], sb[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * nth + tid;
+      sa[u] = walk_slot(Lq, state0, B, nq, e, invq);
+      sb[u] = walk_slot(Lv, state0, B, nv, e, invv);
+      a[u] = sa[u].ok ? q[sa[u].off] : T(0);
+      b[u] = (v && sb[u].ok) ? v[sb[u].off] : T(0);
+      d[u] = (tau && sb[u].ok) ? tau[sb[u].off] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (sa[u].ok) rows[(long)(rq + sa[u].k) * WR_STRIDE + sa[u].st] = a[u];
+      if (sb[u].ok) { rows[(long)(rv + sb[u].k) * WR_STRIDE + sb[u].st] = b[u]; rows[(long)(rt + sb[u].k) * WR_STRIDE + sb[u].st] = d[u]; }
+    }
+  }
+}
+template <typename T, int UB>
+__device__ __forceinline__ void walk_stage_out(T* __restrict__ dst, Layout L, long state0, long B, int n, const T* rows, int row0, int tid, int nth) {
+  if (!dst) return;
+  const unsigned inv = (1u << 22) / (unsigned)(n > 0 ? n : 1) + 1;
+  for (int e0 = 0; e0 < n * 64; e0 += UB * nth) {
+    T a[UB];
+    WalkSlot sl[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      sl[u] = walk_slot(L, state0, B, n, e0 + u * nth + tid, inv);
+      a[u] = sl[u].ok ? rows[(long)(row0 + sl[u].k) * WR_STRIDE + sl[u].st] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (sl[u].ok && state0 + sl[u].st < B) dst[sl[u].off] = a[u];
+  }
+}
+
+template <typename T, bool FLT, bool GEN>
+__global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau,
+                                                      const T* __restrict__ fext, T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv,
+                                                      Layout Lf) {
+  extern __shared__ __align__(16) unsigned char walk_lds_raw[];
+  WalkCtx<T> c;
+  c.M = M;
+  walk_ctx_lds(c, walk_lds_raw);
+  const int lane = threadIdx.x & 63, tid = threadIdx.x, nth = blockDim.x;
+  const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long state0 = (long)blockIdx.x * 64;
+  RBD_WMARK(0);
+  {  // the plan records -> LDS; q, v, τ of this workgroup's 64 states -> rows
+    const int nrec = M.ns * M.G;
+    I4* tri = const_cast<I4*>(c.tri);
+    T* trr = const_cast<T*>(c.trr);
+    int32_t* twk = const_cast<int32_t*>(c.twk);
+    const I4* gi = reinterpret_cast<const I4*>(M.ri);
+    const T* gr = reinterpret_cast<const T*>(M.rr);
+    for (int i = tid; i < nrec; i += nth) { tri[i] = gi[i]; twk[i] = M.wk[i]; }
+    for (int i = tid; i < nrec * TR_STRIDE; i += nth) trr[i] = gr[i];
+    walk_stage_in<T, 10>(q, v, tau, Lq, Lv, state0, B, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
+  }
+  __syncthreads();
+  RBD_WMARK(1);
+  asm volatile("" ::: "a255");  // the kernel descriptor covers every accumulation register (WalkStash addresses them by number)
+  WalkRegs<T> W;
+  WalkStash<T> St;
+  walk_init(W);
+  const int ns = M.ns;
+  const bool want_qdot = qdot != nullptr;
+  const long stl = state0 + lane < B ? state0 + lane : B - 1;
+  const T* fel = fext ? fext + stl * Lf.sb : nullptr;
+  const long fsk = Lf.sk;
+  // every pass reads the record (and passes A and C the constants) of its next step while the current one computes
+  {
+    WalkRaw raw = walk_raw(c, 0, g);
+    T rr[TR_J];
+    walk_consts<T, TR_J>(c, 0, g, rr);
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) {
+      const int s1 = s + 1 < ns ? s + 1 : s;
+      const WalkRec r = walk_rec(raw);
+      raw = walk_raw(c, s1, g);
+      T rn[TR_J];
+      walk_consts<T, TR_J>(c, s1, g, rn);
+      walk_step_a<T, FLT, GEN>(c, W, St, s, r, rr, lane, want_qdot);
+#pragma unroll
+      for (int k = 0; k < TR_J; ++k) rr[k] = rn[k];
+      if ((M.sfm[1] >> s) & 1) __syncthreads();  // SF_AW: an A mailbox was written at this step
+    }
+  }
+  RBD_WMARK(2);
+  {
+    // pass B: the external wrench of the body of step s − 1 is requested while step s computes
+    walk_init_b(W);
+    T fe[6], fn[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { fe[k] = T(0); fn[k] = T(0); }
+    WalkRaw raw = walk_raw(c, ns - 1, g);
+    if (fel) {
+      const int o6 = walk_uniform(raw.w.y) & 0xffff;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fe[k] = fel[(long)(o6 + k) * fsk];
+    }
+#pragma unroll 1
+    for (int s = ns - 1; s >= 0; --s) {
+      const int s1 = s > 0 ? s - 1 : 0;
+      const WalkRec r = walk_rec(raw);
+      T rr[TR_STRIDE];
+      walk_consts<T, TR_STRIDE>(c, s, g, rr);
+      raw = walk_raw(c, s1, g);
+      if (fel) {
+        const int o6 = walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) fn[k] = fel[(long)(o6 + k) * fsk];
+      }
+      walk_step_b<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fe[k] = fn[k];
+      if ((M.sfm[3] >> s) & 1) __syncthreads();  // SF_BW: a hand-off left its track at this step
+    }
+  }
+  __syncthreads();  // pass C re-uses the B mailboxes
+  RBD_WMARK(3);
+  {
+    walk_init_c(W);
+    WalkRaw raw = walk_raw(c, 0, g);
+    T rr[TR_J];
+    walk_consts<T, TR_J>(c, 0, g, rr);
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) {
+      const int s1 = s + 1 < ns ? s + 1 : s;
+      const WalkRec r = walk_rec(raw);
+      raw = walk_raw(c, s1, g);
+      T rn[TR_J];
+      walk_consts<T, TR_J>(c, s1, g, rn);
+      walk_step_c<T, FLT, GEN>(c, W, St, s, r, rr, lane);
+#pragma unroll
+      for (int k = 0; k < TR_J; ++k) rr[k] = rn[k];
+      if ((M.sfm[1] >> s) & 1) __syncthreads();
+    }
+  }
+  __syncthreads();
+  RBD_WMARK(4);
+  walk_stage_out<T, 10>(vdot, Lv, state0, B, M.nv, c.rows, c.rt, tid, nth);
+  walk_stage_out<T, 10>(qdot, Lq, state0, B, M.nq, c.rows, c.rq, tid, nth);
+  RBD_WMARK(5);
+}
+#endif
+
+}  // namespace rbd

@@ -1,0 +1,42 @@
+// rbd_walk_kernels.hip — instantiations and launcher of aba_walk_kernel (rbd_walk.hpp): dynamics! (src/mechanism_algorithms.jl:845-864)
+// with one wavefront per track and one lane per state.  A translation unit of its own so that it builds in parallel with the others.
+#include "rbd_walk.hpp"
+#include "rbd_internal.hpp"
+
+namespace rbd {
+
+template <typename T, bool FLT, bool GEN>
+static hipError_t launch_walk_fg(const WalkModel& M, long B, size_t lds, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
+                                 Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+  const unsigned grid = (unsigned)((B + 63) / 64);
+  aba_walk_kernel<T, FLT, GEN><<<grid, 64 * M.G, lds, s>>>(M, B, (const T*)q, (const T*)v, (const T*)tau, (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_aba_walk(const WalkModel& M, int flt, int gen, long B, size_t lds, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
+                           void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+  if (flt) return gen ? launch_walk_fg<T, true, true>(M, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s)
+                      : launch_walk_fg<T, true, false>(M, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+  return gen ? launch_walk_fg<T, false, true>(M, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s)
+             : launch_walk_fg<T, false, false>(M, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+}
+template hipError_t launch_aba_walk<double>(const WalkModel&, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_aba_walk<float>(const WalkModel&, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+
+// dynamic LDS above the 64 KB default needs the per-function limit raised (per device; done at workspace creation)
+template <typename T, bool FLT, bool GEN> static hipError_t set_walk_lds(size_t lds) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_walk_kernel<T, FLT, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+template <typename T> hipError_t configure_walk_kernel(int flt, int gen, size_t lds) {
+  if (flt) return gen ? set_walk_lds<T, true, true>(lds) : set_walk_lds<T, true, false>(lds);
+  return gen ? set_walk_lds<T, false, true>(lds) : set_walk_lds<T, false, false>(lds);
+}
+template hipError_t configure_walk_kernel<double>(int, int, size_t);
+template hipError_t configure_walk_kernel<float>(int, int, size_t);
+#ifdef RBD_PROFILE_PHASES
+extern "C" int rbd_debug_walk_phase_clock(long long* out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(rbd_walk_phase_clock), sizeof(long long) * 16);
+}
+#endif
+
+}  // namespace rbd

@@ -1,0 +1,57 @@
+// rbd_walk_plan.hpp — host-side additions to the track plan (rbd_track_plan.hpp) for aba_walk_kernel (rbd_walk.hpp).
+//
+// The walk kernel runs the SAME schedule as the track mapping (track g works on body tab[s][g] at step s, same packed records, same
+// mailbox numbering) but gives every track a whole wavefront whose 64 lanes are 64 states.  It keeps no per-body results of pass A:
+// pass B re-derives a body's kinematics from its chained child's ("un-composing" the joint), so only a body WITHOUT a chained child
+// needs its kinematics parked between the passes — except the body a track visits last in pass A, which pass B meets first with the
+// registers still holding it.  This file numbers those parking slots and sizes the workgroup's LDS.
+// Index bookkeeping only.
+#pragma once
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "rbd_device.hpp"
+
+namespace rbd {
+
+struct WalkPlan {
+  bool ok = false;
+  int nS = 0;                // parking slots
+  std::vector<int32_t> wk;   // [ns * G]: parking slot + 1 of the body of (step, track), 0 = none
+};
+
+// rows of 64 states (padded to WR_STRIDE scalars): q | v | tau (v̇ written over it) | A mailboxes | parking slots | B mailboxes (pass C re-uses
+// them for its 6-value mailboxes); then the plan records.  Must agree with walk_ctx_lds() of rbd_walk.hpp.
+enum { WR_STRIDE = 65, WMB_A = 24, WMB_B = 27, WMB_C = 6, WMB_S = 24, WALK_MAX_STEPS = 13 };
+inline size_t walk_rows(int nq, int nv, int nA, int nB, int nS) {
+  const size_t bc = std::max((size_t)nB * WMB_B, (size_t)nA * WMB_C);
+  return (size_t)nq + 2 * (size_t)nv + (size_t)nA * WMB_A + (size_t)nS * WMB_S + bc;
+}
+inline size_t walk_lds_bytes(int ns, int G, int nq, int nv, int nA, int nB, int nS, size_t es) {
+  const size_t nrec = (size_t)ns * G;
+  return nrec * 16 + nrec * TR_STRIDE * es + ((nrec * 4 + 15) & ~(size_t)15) + walk_rows(nq, nv, nA, nB, nS) * WR_STRIDE * es;
+}
+
+// ri: the packed records of the track plan ([ns * G * TI_STRIDE])
+inline WalkPlan build_walk_plan(int ns, int G, const std::vector<int32_t>& ri) {
+  WalkPlan P;
+  if (ns > WALK_MAX_STEPS || G < 1 || G > 4) return P;
+  P.wk.assign((size_t)ns * G, 0);
+  for (int g = 0; g < G; ++g) {
+    int last = -1;
+    for (int s = 0; s < ns; ++s)
+      if ((ri[((size_t)s * G + g) * TI_STRIDE + TI_W1] >> 16) & TF_VALID) last = s;
+    for (int s = 0; s < ns; ++s) {
+      const int flags = (ri[((size_t)s * G + g) * TI_STRIDE + TI_W1] >> 16) & 0xff;
+      if (!(flags & TF_VALID) || (flags & TF_CARRY) || s == last) continue;
+      P.wk[(size_t)s * G + g] = ++P.nS;
+    }
+  }
+  if (P.nS > 255) return P;
+  P.ok = true;
+  return P;
+}
+
+}  // namespace rbd

@@ -1,0 +1,128 @@
+// walk_emu.hip — CPU emulation of aba_walk_kernel (rigidbodydynamics.jl_amd/csrc/rbd_walk.hpp) — TEST INFRASTRUCTURE ONLY.
+// The kernel's step functions are __host__ __device__; this harness runs them lane by lane with the LDS replaced by a host buffer
+// (pre-filled with a NaN pattern) on the plan records exported by rbd_model_track_plan.  Between two workgroup barriers of the
+// kernel the wavefronts are run ONE AFTER THE OTHER to the next barrier — in ascending or descending order (`reverse`) — so a mailbox
+// read that the kernel's barriers do not order after its write meets the NaN pattern in one of the two orders.
+// Built on demand by tests/test_walk_emu.py with `hipcc --cuda-host-only`; never linked into librbd_hip.so.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "rbd_walk.hpp"
+
+using namespace rbd;
+
+template <typename T, bool FLT, bool GEN>
+static int emu_run(const WalkModel& M, int reverse, long B, const T* q, const T* v, const T* tau, const T* fext, T* vdot, T* qdot, Layout Lq, Layout Lv, Layout Lf) {
+  const size_t lds_bytes = walk_lds_bytes(M.ns, M.G, M.nq, M.nv, M.nA, M.nB, M.nS, sizeof(T));
+  std::vector<char> lds(lds_bytes + 64);
+  void* base = (void*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+  const int ns = M.ns, G = M.G;
+  const size_t nrec = (size_t)ns * G;
+  for (long group = 0; group * 64 < B; ++group) {
+    memset(base, 0xff, lds_bytes);
+    WalkCtx<T> c;
+    c.M = M;
+    walk_ctx_lds(c, base);
+    memcpy(const_cast<I4*>(c.tri), M.ri, nrec * 16);
+    memcpy(const_cast<T*>(c.trr), M.rr, nrec * TR_STRIDE * sizeof(T));
+    memcpy(const_cast<int32_t*>(c.twk), M.wk, nrec * 4);
+    auto state_of = [&](int l) { const long st = group * 64 + l; return st < B ? st : B - 1; };
+    for (int l = 0; l < 64; ++l) {
+      const long st = state_of(l);
+      for (int k = 0; k < M.nq; ++k) *walk_row(c, c.rq + k, l) = q[k * Lq.sk + st * Lq.sb];
+      for (int k = 0; k < M.nv; ++k) *walk_row(c, c.rv + k, l) = v ? v[k * Lv.sk + st * Lv.sb] : T(0);
+      for (int k = 0; k < M.nv; ++k) *walk_row(c, c.rt + k, l) = tau ? tau[k * Lv.sk + st * Lv.sb] : T(0);
+    }
+    std::vector<WalkRegs<T>> W((size_t)G * 64);
+    std::vector<WalkStash<T>> St((size_t)G * 64);
+    for (auto& w : W) { memset(&w, 0xff, sizeof w); walk_init(w); }
+    for (auto& s : St) memset(&s, 0xff, sizeof s);
+    auto each_wave = [&](auto&& f) {
+      for (int i = 0; i < G; ++i) f(reverse ? G - 1 - i : i);
+    };
+    // pass A: segments end after a step whose SF_AW flag is set
+    for (int s0 = 0; s0 < ns;) {
+      int s1 = s0;
+      while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
+      each_wave([&](int g) {
+        for (int s = s0; s <= s1; ++s)
+          for (int l = 0; l < 64; ++l) walk_step_a<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), c.trr + (long)(s * G + g) * TR_STRIDE, l, qdot != nullptr);
+      });
+      s0 = s1 + 1;
+    }
+    for (auto& w : W) walk_init_b(w);
+    // pass B (no barrier between A and B in the kernel either: a wave enters pass B as soon as its own pass A is done — every
+    // wave has finished pass A here, which is one of the legal interleavings; the A mailboxes and parking slots are only read)
+    for (int s0 = ns - 1; s0 >= 0;) {
+      int s1 = s0;
+      while (s1 > 0 && !((M.sfm[3] >> s1) & 1)) --s1;
+      each_wave([&](int g) {
+        for (int s = s0; s >= s1; --s)
+          for (int l = 0; l < 64; ++l) {
+            T fe[6] = {0, 0, 0, 0, 0, 0};
+            if (fext) {
+              const int o6 = c.tri[s * G + g].y & 0xffff;
+              for (int k = 0; k < 6; ++k) fe[k] = fext[(o6 + k) * Lf.sk + state_of(l) * Lf.sb];
+            }
+            walk_step_b<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), c.trr + (long)(s * G + g) * TR_STRIDE, l, fe);
+          }
+      });
+      s0 = s1 - 1;
+    }
+    for (auto& w : W) walk_init_c(w);
+    for (int s0 = 0; s0 < ns;) {
+      int s1 = s0;
+      while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
+      each_wave([&](int g) {
+        for (int s = s0; s <= s1; ++s)
+          for (int l = 0; l < 64; ++l) walk_step_c<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), c.trr + (long)(s * G + g) * TR_STRIDE, l);
+      });
+      s0 = s1 + 1;
+    }
+    for (int l = 0; l < 64; ++l) {
+      const long st = group * 64 + l;
+      if (st >= B) continue;
+      for (int k = 0; k < M.nv; ++k) vdot[k * Lv.sk + st * Lv.sb] = *walk_row(c, c.rt + k, l);
+    }
+    if (qdot) {
+      for (int l = 0; l < 64; ++l) {
+        const long st = group * 64 + l;
+        if (st >= B) continue;
+        for (int k = 0; k < M.nq; ++k) qdot[k * Lq.sk + st * Lq.sb] = *walk_row(c, c.rq + k, l);
+      }
+    }
+  }
+  return 0;
+}
+
+template <typename T>
+static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const double* gravity, int reverse, int aos, long B, int nq, int nv, int nb, const void* q,
+                 const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info) {
+  WalkModel M;
+  M.G = dims[0]; M.ns = dims[1]; M.nA = dims[2]; M.nB = dims[3]; M.nq = nq; M.nv = nv;
+  const size_t nrec = (size_t)M.ns * M.G;
+  std::vector<int32_t> riv(ri, ri + nrec * TI_STRIDE);
+  const WalkPlan P = build_walk_plan(M.ns, M.G, riv);
+  if (!P.ok) return 2;
+  M.nS = P.nS;
+  if (info) { info[0] = P.nS; info[1] = (int32_t)walk_lds_bytes(M.ns, M.G, nq, nv, M.nA, M.nB, M.nS, sizeof(T)); }
+  std::vector<T> rrt(rr, rr + nrec * TR_STRIDE);
+  M.ri = riv.data(); M.rr = rrt.data(); M.wk = P.wk.data();
+  const int32_t* sf = ri + nrec * TI_STRIDE;  // the per-step flags follow the packed records
+  for (int k = 0; k < 5; ++k) { M.sfm[k] = 0; for (int s = 0; s < M.ns; ++s) M.sfm[k] |= (uint64_t)((sf[s] >> k) & 1) << s; }
+  memcpy(M.gravity, gravity, sizeof M.gravity);
+  auto lay = [&](long n) { Layout L; if (aos) { L.sk = 1; L.sb = n; } else { L.sk = B; L.sb = 1; } return L; };
+  const Layout Lq = lay(nq), Lv = lay(nv), Lf = lay(6L * nb);
+  const int flt = dims[4], gen = dims[5];
+#define RUN(F, GN) emu_run<T, F, GN>(M, reverse, B, (const T*)q, (const T*)v, (const T*)tau, (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf)
+  if (flt) return gen ? RUN(true, true) : RUN(true, false);
+  return gen ? RUN(false, true) : RUN(false, false);
+#undef RUN
+}
+
+extern "C" int walk_emu_dynamics(const int32_t* dims, const int32_t* ri, const double* rr, const double* gravity, int f32, int reverse, int aos, long B, int nq,
+                                 int nv, int nb, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info) {
+  return f32 ? emu_t<float>(dims, ri, rr, gravity, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info)
+             : emu_t<double>(dims, ri, rr, gravity, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info);
+}

@@ -678,7 +678,7 @@ CHAIN_MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pe
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algorithm", ["aba_tracks", "aba_chains", "aba_banks"])
+@pytest.mark.parametrize("algorithm", ["aba_walk", "aba_tracks", "aba_chains", "aba_banks"])
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("name", CHAIN_MODELS)
 def test_dynamics_chains_f64(rbd, oracle, models, name, layout, algorithm):
@@ -701,7 +701,7 @@ def test_dynamics_chains_f64(rbd, oracle, models, name, layout, algorithm):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algorithm", ["aba_tracks", "aba_chains", "aba_banks"])
+@pytest.mark.parametrize("algorithm", ["aba_walk", "aba_tracks", "aba_chains", "aba_banks"])
 @pytest.mark.parametrize("B", [1, 3, 4, 5, 15, 16, 17, 1000])
 def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B, algorithm):
     model = models["atlas_floating"]
@@ -720,7 +720,7 @@ def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B, algorithm):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algorithm", ["aba_tracks", "aba_chains", "aba_banks"])
+@pytest.mark.parametrize("algorithm", ["aba_walk", "aba_tracks", "aba_chains", "aba_banks"])
 def test_dynamics_chains_random_trees(rbd, oracle, algorithm):
     """Random revolute / prismatic / fixed / sin-cos trees (with and without a floating root), as the reference's randomized tests do."""
     from test_chain_plan import random_tree
@@ -736,7 +736,7 @@ def test_dynamics_chains_random_trees(rbd, oracle, algorithm):
         except Exception:
             # banks: a tree too shallow or too small to split into two banks that save lanes; tracks: a chain so long that its
             # per-step LDS rows exceed one CU's 160 KB (RBD_ERR_UNSUPPORTED, the default then takes another mapping)
-            assert algorithm in ("aba_banks", "aba_tracks")
+            assert algorithm in ("aba_banks", "aba_tracks", "aba_walk")  # walk: more than 14 steps per track
             continue
         ref = oracle.dynamics(model, q, v, tau, fe)
         got = host(result.vd, state)
@@ -943,7 +943,7 @@ def test_batch_states_are_isolated_from_a_nan_state(rbd, models, name, dtype):
     B = 37
     state, q, v, tau, fe = make(rbd, model, B, dtype, "aos", 123)
     t, f = dev(tau, state), dev(fe, state)
-    algos = ["aba_lanes"] + [a for a in ("aba_banks", "aba_chains", "aba_tracks") if name != "randmech1" and (a != "aba_banks" or rbd.bank_plan(model))]
+    algos = ["aba_lanes"] + [a for a in ("aba_banks", "aba_chains", "aba_tracks", "aba_walk") if name != "randmech1" and (a != "aba_banks" or rbd.bank_plan(model))]
 
     def run_all():
         out = {}
