@@ -85,7 +85,7 @@ enum {
                                 prismatic / fixed joints, 6-dof joints on the world).  RBD_ERR_UNSUPPORTED elsewhere        */
   RBD_ALGO_ABA_WALK = 6      /* the track schedule with one WAVEFRONT per track and one lane per state: a workgroup is up to four
                                 wavefronts over the same 64 states, q / v / tau staged through LDS, per-joint results in accumulation
-                                registers.  Same scope as the track mapping, at most 14 steps per track; RBD_ERR_UNSUPPORTED
+                                registers.  Same scope as the track mapping, at most 12 steps per track; RBD_ERR_UNSUPPORTED
                                 elsewhere or when the rows of 64 states do not fit one compute unit's LDS                      */
 };
 

@@ -86,7 +86,7 @@ struct rbd_ws {
   DevModel dm{};
   BankModel bm{}; void* d_bank_ib[2] = {nullptr, nullptr}; void* d_bank_rb[2] = {nullptr, nullptr};
   TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr; size_t track_lds_bytes4 = 0; long track_nw4_max_batch = 0; size_t track_lds_bytes = 0; long track_min_batch = 0;
-  WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0; long walk_min_batch = 0;
+  WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   ChainModel cm{}; void* d_chain_tab = nullptr; void* d_chain_cb = nullptr; size_t chain_lds_bytes = 0; long bank_min_batch = 0;
@@ -533,15 +533,32 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     wm.ri = (const int32_t*)w->d_track_ri; wm.rr = w->d_track_rr; wm.wk = (const int32_t*)w->d_walk_wk;
     for (int k = 0; k < 5; ++k) wm.sfm[k] = w->tm.sfm[k];
     memcpy(wm.gravity, m->gravity, sizeof wm.gravity);
-    w->walk_lds_bytes = walk_lds_bytes(P.ns, P.G, m->nq, m->nv, P.nA, P.nB, m->walk.nS, dtype == RBD_F64 ? 8 : 4);
+    const size_t es = dtype == RBD_F64 ? 8 : 4;
+    w->walk_lds_bytes = walk_lds_bytes(P.ns, P.G, m->nq, m->nv, P.nA, P.nB, m->walk.nS, es, es);
     if (w->walk_lds_bytes > 160 * 1024) w->walk_lds_bytes = 0;  // the rows of 64 states do not fit one CU's LDS: other mappings
-    if (w->walk_lds_bytes > 0) {
-      const hipError_t e = dtype == RBD_F64 ? configure_walk_kernel<double>(P.has_floating, P.general, w->walk_lds_bytes)
-                                            : configure_walk_kernel<float>(P.has_floating, P.general, w->walk_lds_bytes);
+    // fp32: two states per lane (packed arithmetic), 128 states per workgroup
+    w->walk_lds_bytes_pair = dtype == RBD_F32 ? walk_lds_bytes(P.ns, P.G, m->nq, m->nv, P.nA, P.nB, m->walk.nS, 8, 4) : 0;
+    if (w->walk_lds_bytes_pair > 160 * 1024) w->walk_lds_bytes_pair = 0;
+    {
+      const hipError_t e = dtype == RBD_F64 ? configure_walk_kernel<double>(P.has_floating, P.general, w->walk_lds_bytes, 0)
+                                            : configure_walk_kernel<float>(P.has_floating, P.general, w->walk_lds_bytes, w->walk_lds_bytes_pair);
       if (e != hipSuccess) { g_last_hip_error = std::string("configure_walk_kernel: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
     }
-    // RBD_ALGO_ABA picks it from this batch size up (RBD_WALK_MIN_BATCH overrides; profiles/r02_walk_sweep.txt)
-    w->walk_min_batch = (long)1 << 62;
+    // the packed form from the batch size at which the 64-state workgroups no longer fit the chip in one round (RBD_WALK_PAIR_MIN_BATCH overrides)
+    {
+      int ncu = 256;
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+      w->walk_pair_min_batch = (long)ncu * 64 + 1;
+      if (const char* e = getenv("RBD_WALK_PAIR_MIN_BATCH")) w->walk_pair_min_batch = atol(e);
+    }
+    // RBD_ALGO_ABA picks it from this batch size up (RBD_WALK_MIN_BATCH overrides).  Measured on Atlas (profiles/r02_walk_sweep.txt): a launch takes
+    // the same ~37 us from 64 to 16 384 states (one workgroup per 64 states, one per CU), the banked lane-per-body kernel 25 us at 4096, 35 us at
+    // 8192, 63 us at 16 384 — the crossover is where the workgroups of the walk kernel cover 3/4 of the chip
+    {
+      int ncu = 256;
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+      w->walk_min_batch = (long)ncu * 48;
+    }
     if (const char* e = getenv("RBD_WALK_MIN_BATCH")) w->walk_min_batch = atol(e);
   }
   if (m->state.ok && m->state.nlevels <= state_max_levels(dtype == RBD_F64 ? 8 : 4)) {
@@ -775,7 +792,7 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   const bool can_chain = m->chain.ok && w->chain_lds_bytes > 0 && !fuse, can_bank = m->bank_lps > 0 && m->bank_aba_ok;
   // the track kernel addresses its batch buffers with 32-bit byte offsets
   const bool can_track = m->track.ok && w->track_lds_bytes > 0 && !fuse && (double)B * (double)std::max(std::max(m->nq, m->nv), 6 * m->nb) * 8.0 < 4.0e9;
-  const bool can_walk = m->track.ok && m->walk.ok && w->walk_lds_bytes > 0 && !fuse;
+  const bool can_walk = m->track.ok && m->walk.ok && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch)) && !fuse;
   if (algorithm == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_TRACKS && !can_track) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_CHAINS && !can_chain) return RBD_ERR_UNSUPPORTED;
@@ -788,8 +805,10 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     WalkModel wm = w->wm;
     if (gravity) memcpy(wm.gravity, gravity, sizeof wm.gravity);
     w->last_kernel = "aba_walk_kernel";
-    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, m->track.has_floating, m->track.general, B, w->walk_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_aba_walk<float>(wm, m->track.has_floating, m->track.general, B, w->walk_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
+    if (pair) w->last_kernel = "aba_walk_kernel (two fp32 states per lane)";
+    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, m->track.has_floating, m->track.general, 0, B, w->walk_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_aba_walk<float>(wm, m->track.has_floating, m->track.general, pair, B, pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
   } else if (pick == RBD_ALGO_ABA_TRACKS) {
     TrackModel tm = w->tm;
     if (gravity) memcpy(tm.gravity, gravity, sizeof tm.gravity);

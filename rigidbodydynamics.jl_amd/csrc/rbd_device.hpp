@@ -466,4 +466,18 @@ RBD_HD void sincos_hd(float x, float* s, float* c) {
 }
 RBD_HD void sincos_fast(float x, float* s, float* c) { sincos_hd(x, s, c); }
 
+// ---- two fp32 states per lane: every arithmetic instruction becomes a packed v_pk_{fma,mul,add}_f32 (aba_walk_kernel, rbd_walk.hpp).
+// A clang extended vector: + - * / act element-wise, a scalar operand is splat, T(x) converts and splats.
+typedef float f2 __attribute__((ext_vector_type(2)));
+RBD_HD f2 rcp_hd(f2 x) { f2 r; r.x = rcp_hd(x.x); r.y = rcp_hd(x.y); return r; }
+RBD_HD void sincos_fast(f2 x, f2* s, f2* c) {
+  float s0, c0, s1, c1;
+  sincos_hd(x.x, &s0, &c0);
+  sincos_hd(x.y, &s1, &c1);
+  s->x = s0; s->y = s1; c->x = c0; c->y = c1;
+}
+// scalar type and states per lane of a kernel value type
+template <typename T> struct Lanes { using S = T; enum { N = 1 }; };
+template <> struct Lanes<f2> { using S = float; enum { N = 2 }; };
+
 }  // namespace rbd

@@ -64,9 +64,9 @@ hipError_t launch_aba_track(const TrackModel& M, int flt, int gen, int nw, long 
 template <typename T> hipError_t configure_track_kernel(int G, int flt, int gen, size_t lds_bytes);
 // rbd_walk_kernels.hip: one wavefront per track, one lane per state
 template <typename T>
-hipError_t launch_aba_walk(const WalkModel& M, int flt, int gen, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
+hipError_t launch_aba_walk(const WalkModel& M, int flt, int gen, int pair, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
                            void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
-template <typename T> hipError_t configure_walk_kernel(int flt, int gen, size_t lds_bytes);
+template <typename T> hipError_t configure_walk_kernel(int flt, int gen, size_t lds_bytes, size_t lds_bytes_pair);
 // rbd_state_kernels.hip: one lane per state
 int state_max_levels(int element_size);
 template <typename T>

@@ -36,7 +36,6 @@ namespace rbd {
     RBD_WALK_CASE(0, __VA_ARGS__) RBD_WALK_CASE(1, __VA_ARGS__) RBD_WALK_CASE(2, __VA_ARGS__) RBD_WALK_CASE(3, __VA_ARGS__)        \
     RBD_WALK_CASE(4, __VA_ARGS__) RBD_WALK_CASE(5, __VA_ARGS__) RBD_WALK_CASE(6, __VA_ARGS__) RBD_WALK_CASE(7, __VA_ARGS__)        \
     RBD_WALK_CASE(8, __VA_ARGS__) RBD_WALK_CASE(9, __VA_ARGS__) RBD_WALK_CASE(10, __VA_ARGS__) RBD_WALK_CASE(11, __VA_ARGS__)      \
-    RBD_WALK_CASE(12, __VA_ARGS__)                                                                                                \
     default: break;                                                                                                               \
   }
 
@@ -67,6 +66,18 @@ template <> template <int S, int K> RBD_DEV void WalkStash<double>::put(double x
   asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(__double2loint(x)), "n"(254 - 2 * (S * WS_N + K)));
   asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(__double2hiint(x)), "n"(255 - 2 * (S * WS_N + K)));
 }
+template <> template <int S, int K> RBD_DEV void WalkStash<f2>::put(f2 x) {
+  asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(x.x), "n"(254 - 2 * (S * WS_N + K)));
+  asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(x.y), "n"(255 - 2 * (S * WS_N + K)));
+}
+template <> template <int S, int K> RBD_DEV f2 WalkStash<f2>::get() const {
+  f2 x;
+  float lo, hi;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(lo) : "n"(254 - 2 * (S * WS_N + K)));
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(hi) : "n"(255 - 2 * (S * WS_N + K)));
+  x.x = lo; x.y = hi;
+  return x;
+}
 template <> template <int S, int K> RBD_DEV double WalkStash<double>::get() const {
   int lo, hi;
   asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(lo) : "n"(254 - 2 * (S * WS_N + K)));
@@ -86,7 +97,7 @@ RBD_HD int walk_uniform(int x) {
 template <typename T> struct WalkCtx {
   WalkModel M;
   // LDS (rows are [field][WR_STRIDE], a lane's value of a field at row[lane])
-  const I4* tri; const int32_t* twk; const T* trr;
+  const I4* tri; const int32_t* twk; const typename Lanes<T>::S* trr;  // the constants are scalars: the states of a lane share them
   T* rows;
   int rq, rv, rt, rA, rS, rB;  // first row of q | v | τ / v̇ | A mailboxes | parking slots | B mailboxes (pass C: its mailboxes)
   T a0[6];
@@ -95,14 +106,19 @@ template <typename T> struct WalkCtx {
 template <typename T> RBD_HD void walk_ctx_lds(WalkCtx<T>& c, void* lds) {
   const size_t nrec = (size_t)c.M.ns * c.M.G;
   c.tri = reinterpret_cast<const I4*>(lds);
-  c.trr = reinterpret_cast<const T*>(c.tri + nrec);
+  using S = typename Lanes<T>::S;
+  c.trr = reinterpret_cast<const S*>(c.tri + nrec);
   c.twk = reinterpret_cast<const int32_t*>(c.trr + nrec * TR_STRIDE);
-  c.rows = reinterpret_cast<T*>(reinterpret_cast<char*>(lds) + nrec * 16 + nrec * TR_STRIDE * sizeof(T) + ((nrec * 4 + 15) & ~(size_t)15));
+  c.rows = reinterpret_cast<T*>(reinterpret_cast<char*>(lds) + nrec * 16 + nrec * TR_STRIDE * sizeof(S) + ((nrec * 4 + 15) & ~(size_t)15));
   c.rq = 0; c.rv = c.M.nq; c.rt = c.rv + c.M.nv; c.rA = c.rt + c.M.nv; c.rS = c.rA + c.M.nA * WMB_A; c.rB = c.rS + c.M.nS * WMB_S;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { c.a0[k] = T(0); c.a0[3 + k] = T(-c.M.gravity[k]); }  // a_world = −gravity (mechanism_algorithms.jl:405)
 }
 template <typename T> RBD_HD T* walk_row(const WalkCtx<T>& c, int row, int lane) { return c.rows + (long)row * WR_STRIDE + lane; }
+// the scalar of state st (0 <= st < 64 N) of the workgroup in a row: lane st mod 64, component st div 64
+template <typename T> RBD_HD typename Lanes<T>::S* walk_cell(T* rows, int row, int st) {
+  return reinterpret_cast<typename Lanes<T>::S*>(rows + (long)row * WR_STRIDE + (st & 63)) + (st >> 6);
+}
 
 // per-lane recursion state of a track
 template <typename T> struct WalkRegs {
@@ -150,9 +166,9 @@ RBD_HD WalkRec walk_rec(const WalkRaw& raw) {
 }
 // the constants of a record, LDS -> registers
 template <typename T, int N> RBD_HD void walk_consts(const WalkCtx<T>& c, int s, int g, T* rr) {  // the first N: (C, pp) = 12 is all passes A and C need
-  const T* src = c.trr + (long)(s * c.M.G + g) * TR_STRIDE;
+  const typename Lanes<T>::S* src = c.trr + (long)(s * c.M.G + g) * TR_STRIDE;
 #pragma unroll
-  for (int k = 0; k < N; ++k) rr[k] = src[k];
+  for (int k = 0; k < N; ++k) rr[k] = T(src[k]);
 }
 
 template <typename T> RBD_HD void walk_put_kin(T* m, const WalkRegs<T>& W) {
@@ -501,60 +517,65 @@ __device__ long long rbd_walk_phase_clock[16];
 #define RBD_WMARK(i)
 #endif
 
-// Staging.  Rows [row0, row0 + n) hold the n x 64 block of a batch buffer that belongs to this workgroup's states.  A state-major buffer
-// (sk == 1) is ONE contiguous run of 64 n scalars: thread t takes elements t, t + nthreads, ... (coalesced) and element e belongs to row
-// (e mod n), column (e div n) — consecutive lanes hit consecutive rows, WR_STRIDE = 65 scalars apart: no bank conflicts.  A batch-innermost
-// buffer is taken row by row.  States past the end of the batch read the last state's values (finite, never stored).
-// All loads of a round are issued before the first LDS write (a wavefront pays every dependent global round trip in full).
+// Staging.  Rows [row0, row0 + n) hold the n x (64 N) block of a batch buffer that belongs to this workgroup's states (N states per lane).
+// A state-major buffer (sk == 1) is ONE contiguous run of 64 N n scalars: thread t takes elements t, t + nthreads, ... (coalesced) and element e
+// belongs to row (e mod n), state (e div n) — consecutive lanes hit consecutive rows, WR_STRIDE = 65 values apart: no bank conflicts.  A
+// batch-innermost buffer is taken row by row.  States past the end of the batch read the last state's values (finite, never stored).
+// All global loads of the prologue are in flight before its first LDS write (a wavefront pays every dependent global round trip in full).
 struct WalkSlot { int k, st; long off; bool ok; };
-RBD_DEV WalkSlot walk_slot(Layout L, long state0, long B, int n, int e, unsigned inv) {
+template <int N> RBD_DEV WalkSlot walk_slot(Layout L, long state0, long B, int n, int e, unsigned inv) {
   WalkSlot x;
-  x.ok = e < n * 64;
+  x.ok = e < n * 64 * N;
   if (L.sk == 1) {
-    x.st = (int)(((unsigned)e * inv) >> 22);  // e / n for e < 2^13, n < 2^9
+    x.st = (int)(((unsigned)e * inv) >> 22);  // e / n for e < 2^14, n < 2^8
     x.k = e - x.st * n;
+    const long lim = (B - state0) * n;        // elements of this block that exist
+    x.off = state0 * n + (e < lim ? e : lim - n + x.k);
   } else {
-    x.k = e >> 6; x.st = e & 63;
+    x.k = e / (64 * N); x.st = e % (64 * N);
+    const long sc = state0 + x.st < B ? state0 + x.st : B - 1;
+    x.off = (long)x.k * L.sk + sc * L.sb;
   }
-  const long sc = state0 + x.st < B ? state0 + x.st : B - 1;
-  x.off = (long)x.k * L.sk + sc * L.sb;
   return x;
 }
-template <typename T, int UB>
-__device__ __forceinline__ void walk_stage_in(const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau, Layout Lq, Layout Lv, long state0,
-                                              long B, int nq, int nv, T* rows, int rq, int rv, int rt, int tid, int nth) {
-  const unsigned invq = (1u << 22) / (unsigned)nq + 1, invv = (1u << 22) / (unsigned)(nv > 0 ? nv : 1) + 1;
-  const int nmax = (nq > nv ? nq : nv) * 64;
-  for (int e0 = 0; e0 < nmax; e0 += UB * nth) {
-    T a[UB], b[UB], d[UB];
-    WalkSlot sa[UB], sb[UB];
+template <typename T, int UB> struct WalkStageIn {
+  using S = typename Lanes<T>::S;
+  S a[UB], b[UB], d[UB];
+  WalkSlot sa[UB], sb[UB];
+  __device__ __forceinline__ void load(const S* __restrict__ q, const S* __restrict__ v, const S* __restrict__ tau, Layout Lq, Layout Lv, long state0, long B,
+                                       int nq, int nv, int e0, int tid, int nth) {
+    const unsigned invq = (1u << 22) / (unsigned)nq + 1, invv = (1u << 22) / (unsigned)(nv > 0 ? nv : 1) + 1;
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int e = e0 + u * nth + tid;
-      sa[u] = walk_slot(Lq, state0, B, nq, e, invq);
-      sb[u] = walk_slot(Lv, state0, B, nv, e, invv);
-      a[u] = sa[u].ok ? q[sa[u].off] : T(0);
-      b[u] = (v && sb[u].ok) ? v[sb[u].off] : T(0);
-      d[u] = (tau && sb[u].ok) ? tau[sb[u].off] : T(0);
-    }
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      if (sa[u].ok) rows[(long)(rq + sa[u].k) * WR_STRIDE + sa[u].st] = a[u];
-      if (sb[u].ok) { rows[(long)(rv + sb[u].k) * WR_STRIDE + sb[u].st] = b[u]; rows[(long)(rt + sb[u].k) * WR_STRIDE + sb[u].st] = d[u]; }
+      sa[u] = walk_slot<Lanes<T>::N>(Lq, state0, B, nq, e, invq);
+      sb[u] = walk_slot<Lanes<T>::N>(Lv, state0, B, nv, e, invv);
+      a[u] = sa[u].ok ? q[sa[u].off] : S(0);
+      b[u] = (v && sb[u].ok) ? v[sb[u].off] : S(0);
+      d[u] = (tau && sb[u].ok) ? tau[sb[u].off] : S(0);
     }
   }
-}
+  __device__ __forceinline__ void store(T* rows, int rq, int rv, int rt) const {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (sa[u].ok) *walk_cell(rows, rq + sa[u].k, sa[u].st) = a[u];
+      if (sb[u].ok) { *walk_cell(rows, rv + sb[u].k, sb[u].st) = b[u]; *walk_cell(rows, rt + sb[u].k, sb[u].st) = d[u]; }
+    }
+  }
+};
 template <typename T, int UB>
-__device__ __forceinline__ void walk_stage_out(T* __restrict__ dst, Layout L, long state0, long B, int n, const T* rows, int row0, int tid, int nth) {
+__device__ __forceinline__ void walk_stage_out(typename Lanes<T>::S* __restrict__ dst, Layout L, long state0, long B, int n, T* rows, int row0, int tid, int nth) {
+  using S = typename Lanes<T>::S;
+  constexpr int N = Lanes<T>::N;
   if (!dst) return;
   const unsigned inv = (1u << 22) / (unsigned)(n > 0 ? n : 1) + 1;
-  for (int e0 = 0; e0 < n * 64; e0 += UB * nth) {
-    T a[UB];
+  for (int e0 = 0; e0 < n * 64 * N; e0 += UB * nth) {
+    S a[UB];
     WalkSlot sl[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      sl[u] = walk_slot(L, state0, B, n, e0 + u * nth + tid, inv);
-      a[u] = sl[u].ok ? rows[(long)(row0 + sl[u].k) * WR_STRIDE + sl[u].st] : T(0);
+      sl[u] = walk_slot<N>(L, state0, B, n, e0 + u * nth + tid, inv);
+      a[u] = sl[u].ok ? *walk_cell(rows, row0 + sl[u].k, sl[u].st) : S(0);
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u)
@@ -562,28 +583,119 @@ __device__ __forceinline__ void walk_stage_out(T* __restrict__ dst, Layout L, lo
   }
 }
 
+// The common case — state-major buffers, every state of the workgroup inside the batch — without per-element divisions or 64-bit offsets:
+// thread t walks elements t, t + nthreads, ... of the contiguous block; (row, state) of an element advance by (nthreads mod n, nthreads div n)
+// with a carry.  cell: index of a scalar in the rows, ((row) WR_STRIDE + state mod 64) N + state div 64.
+template <int N> struct WalkCursor {
+  int k, st, dk, ds, n;
+  __device__ __forceinline__ void init(int n_, int tid, int nth) { n = n_ > 0 ? n_ : 1; k = tid % n; st = tid / n; dk = nth % n; ds = nth / n; }
+  __device__ __forceinline__ int cell(int row0) const { return ((row0 + k) * WR_STRIDE + (st & 63)) * N + (st >> 6); }
+  __device__ __forceinline__ void next() {
+    k += dk; st += ds;
+    const bool c = k >= n;
+    k -= c ? n : 0; st += c ? 1 : 0;
+  }
+};
+template <typename T, int UB>
+__device__ __forceinline__ void walk_stage_in_fast(const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v,
+                                                   const typename Lanes<T>::S* __restrict__ tau, long state0, int nq, int nv, T* rows, int rq, int rv, int rt,
+                                                   int tid, int nth) {
+  using S = typename Lanes<T>::S;
+  constexpr int N = Lanes<T>::N;
+  const S* bq = q + state0 * nq;
+  const S* bv = v ? v + state0 * nv : nullptr;
+  const S* bt = tau ? tau + state0 * nv : nullptr;
+  S* cells = reinterpret_cast<S*>(rows);
+  const int totq = nq * 64 * N, totv = nv * 64 * N, tot = totq > totv ? totq : totv;
+  WalkCursor<N> cq, cv;
+  cq.init(nq, tid, nth); cv.init(nv, tid, nth);
+  for (int e0 = tid; e0 < tot + tid; e0 += UB * nth) {
+    S a[UB], b[UB], d[UB];
+    int iq[UB], iv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * nth;
+      const bool okq = e < totq, okv = e < totv;
+      a[u] = okq ? bq[e] : S(0);
+      b[u] = (bv && okv) ? bv[e] : S(0);
+      d[u] = (bt && okv) ? bt[e] : S(0);
+      iq[u] = okq ? cq.cell(rq) : -1;
+      iv[u] = okv ? cv.cell(0) : -1;
+      cq.next(); cv.next();
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (iq[u] >= 0) cells[iq[u]] = a[u];
+      if (iv[u] >= 0) { cells[iv[u] + rv * WR_STRIDE * N] = b[u]; cells[iv[u] + rt * WR_STRIDE * N] = d[u]; }
+    }
+  }
+}
+template <typename T, int UB>
+__device__ __forceinline__ void walk_stage_out_fast(typename Lanes<T>::S* __restrict__ dst, long state0, int n, const T* rows, int row0, int tid, int nth) {
+  using S = typename Lanes<T>::S;
+  constexpr int N = Lanes<T>::N;
+  if (!dst) return;
+  S* base = dst + state0 * n;
+  const S* cells = reinterpret_cast<const S*>(rows);
+  const int tot = n * 64 * N;
+  WalkCursor<N> cu;
+  cu.init(n, tid, nth);
+  for (int e0 = tid; e0 < tot + tid; e0 += UB * nth) {
+    S a[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      a[u] = e0 + u * nth < tot ? cells[cu.cell(row0)] : S(0);
+      cu.next();
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (e0 + u * nth < tot) base[e0 + u * nth] = a[u];
+  }
+}
+
 template <typename T, bool FLT, bool GEN>
-__global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau,
-                                                      const T* __restrict__ fext, T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv,
+__global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v,
+                                                      const typename Lanes<T>::S* __restrict__ tau, const typename Lanes<T>::S* __restrict__ fext,
+                                                      typename Lanes<T>::S* __restrict__ vdot, typename Lanes<T>::S* __restrict__ qdot, Layout Lq, Layout Lv,
                                                       Layout Lf) {
+  using S = typename Lanes<T>::S;
+  constexpr int N = Lanes<T>::N;
   extern __shared__ __align__(16) unsigned char walk_lds_raw[];
   WalkCtx<T> c;
   c.M = M;
   walk_ctx_lds(c, walk_lds_raw);
   const int lane = threadIdx.x & 63, tid = threadIdx.x, nth = blockDim.x;
   const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long state0 = (long)blockIdx.x * 64;
+  const long state0 = (long)blockIdx.x * (64 * N);
   RBD_WMARK(0);
-  {  // the plan records -> LDS; q, v, τ of this workgroup's 64 states -> rows
-    const int nrec = M.ns * M.G;
-    I4* tri = const_cast<I4*>(c.tri);
-    T* trr = const_cast<T*>(c.trr);
-    int32_t* twk = const_cast<int32_t*>(c.twk);
+  {  // the plan records -> LDS; q, v, τ of this workgroup's states -> rows.  Loads first, all of them; then the LDS writes.
+    constexpr int UB = 10 * N, TB = 6;
+    const int nrec = M.ns * M.G, ntr = nrec * TR_STRIDE;  // nrec <= 13 G <= nth
     const I4* gi = reinterpret_cast<const I4*>(M.ri);
-    const T* gr = reinterpret_cast<const T*>(M.rr);
-    for (int i = tid; i < nrec; i += nth) { tri[i] = gi[i]; twk[i] = M.wk[i]; }
-    for (int i = tid; i < nrec * TR_STRIDE; i += nth) trr[i] = gr[i];
-    walk_stage_in<T, 10>(q, v, tau, Lq, Lv, state0, B, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
+    const S* gr = reinterpret_cast<const S*>(M.rr);
+    I4 ti = gi[tid < nrec ? tid : 0];
+    const int32_t tw = M.wk[tid < nrec ? tid : 0];
+    S tr[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) tr[u] = gr[tid + u * nth < ntr ? tid + u * nth : 0];
+    const bool fast = Lq.sk == 1 && Lv.sk == 1 && state0 + 64 * N <= B;  // wave-uniform
+    WalkStageIn<T, UB> in;
+    if (!fast) in.load(q, v, tau, Lq, Lv, state0, B, M.nq, M.nv, 0, tid, nth);
+    if (tid < nrec) { const_cast<I4*>(c.tri)[tid] = ti; const_cast<int32_t*>(c.twk)[tid] = tw; }
+#pragma unroll
+    for (int u = 0; u < TB; ++u)
+      if (tid + u * nth < ntr) const_cast<S*>(c.trr)[tid + u * nth] = tr[u];
+    for (int i = tid + TB * nth; i < ntr; i += nth) const_cast<S*>(c.trr)[i] = gr[i];
+    if (fast) {
+      walk_stage_in_fast<T, UB>(q, v, tau, state0, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
+    } else {
+      in.store(c.rows, c.rq, c.rv, c.rt);
+      const int nmax = (M.nq > M.nv ? M.nq : M.nv) * 64 * N;
+      for (int e0 = UB * nth; e0 < nmax; e0 += UB * nth) {
+        in.load(q, v, tau, Lq, Lv, state0, B, M.nq, M.nv, e0, tid, nth);
+        in.store(c.rows, c.rq, c.rv, c.rt);
+      }
+    }
   }
   __syncthreads();
   RBD_WMARK(1);
@@ -593,9 +705,24 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
   walk_init(W);
   const int ns = M.ns;
   const bool want_qdot = qdot != nullptr;
-  const long stl = state0 + lane < B ? state0 + lane : B - 1;
-  const T* fel = fext ? fext + stl * Lf.sb : nullptr;
+  // external wrenches: requested from global memory a step ahead (one load per state of the lane)
   const long fsk = Lf.sk;
+  const S* fel[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const long st = state0 + 64 * j + lane;
+    fel[j] = fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr;
+  }
+  auto wrench = [&](int o6, T* f) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      S x[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] = fel[j][(long)(o6 + k) * fsk];
+      if constexpr (N == 1) f[k] = x[0];
+      else { f[k].x = x[0]; f[k].y = x[1]; }
+    }
+  };
   // every pass reads the record (and passes A and C the constants) of its next step while the current one computes
   {
     WalkRaw raw = walk_raw(c, 0, g);
@@ -622,11 +749,7 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
 #pragma unroll
     for (int k = 0; k < 6; ++k) { fe[k] = T(0); fn[k] = T(0); }
     WalkRaw raw = walk_raw(c, ns - 1, g);
-    if (fel) {
-      const int o6 = walk_uniform(raw.w.y) & 0xffff;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) fe[k] = fel[(long)(o6 + k) * fsk];
-    }
+    if (fext) wrench(walk_uniform(raw.w.y) & 0xffff, fe);
 #pragma unroll 1
     for (int s = ns - 1; s >= 0; --s) {
       const int s1 = s > 0 ? s - 1 : 0;
@@ -634,11 +757,7 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
       T rr[TR_STRIDE];
       walk_consts<T, TR_STRIDE>(c, s, g, rr);
       raw = walk_raw(c, s1, g);
-      if (fel) {
-        const int o6 = walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) fn[k] = fel[(long)(o6 + k) * fsk];
-      }
+      if (fext) wrench(walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff, fn);
       walk_step_b<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe);
 #pragma unroll
       for (int k = 0; k < 6; ++k) fe[k] = fn[k];
@@ -667,8 +786,13 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
   }
   __syncthreads();
   RBD_WMARK(4);
-  walk_stage_out<T, 10>(vdot, Lv, state0, B, M.nv, c.rows, c.rt, tid, nth);
-  walk_stage_out<T, 10>(qdot, Lq, state0, B, M.nq, c.rows, c.rq, tid, nth);
+  if (Lq.sk == 1 && Lv.sk == 1 && state0 + 64 * N <= B) {
+    walk_stage_out_fast<T, 10 * N>(vdot, state0, M.nv, c.rows, c.rt, tid, nth);
+    walk_stage_out_fast<T, 10 * N>(qdot, state0, M.nq, c.rows, c.rq, tid, nth);
+  } else {
+    walk_stage_out<T, 10>(vdot, Lv, state0, B, M.nv, c.rows, c.rt, tid, nth);
+    walk_stage_out<T, 10>(qdot, Lq, state0, B, M.nq, c.rows, c.rq, tid, nth);
+  }
   RBD_WMARK(5);
 }
 #endif

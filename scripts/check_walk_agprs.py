@@ -21,7 +21,7 @@ for line in open(src):
         worst[name][1] = min(worst[name][1], int(tok, 0))
 bad = 0
 for k, (alloc_hi, stash_lo) in worst.items():
-    words = 2 if "kernelId" in k else 1
+    words = 2 if ("kernelId" in k or "kernelIDv2_f" in k) else 1
     floor = 256 - max_steps * 9 * words
     ok = alloc_hi < floor and stash_lo >= floor
     print(f"{'ok ' if ok else 'BAD'} {k[:44]}: allocator uses a0..a{alloc_hi}, stash lowest a{stash_lo}, reserved from a{floor}")

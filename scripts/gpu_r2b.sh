@@ -2,8 +2,9 @@
 # round-2 call B: aba_walk_kernel — parity, mapping sweep, in-kernel phase timeline, PMC of a launch
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-echo "== pytest gpu (mappings)"; timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_golden_vectors.py -x -q -m gpu -k "chains or isolated or vectors" 2>&1 | tail -8 | tee gpurun_out/pytest_walk.log
+echo "== pytest gpu (mappings)"; timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_golden_vectors.py -x -q -m gpu -k "chains or isolated or vectors or walk" 2>&1 | tail -8 | tee gpurun_out/pytest_walk.log
 echo "== sweep"; timeout 900 python scripts/mapping_sweep.py --algos aba_walk,aba_banks,aba_tracks --batches 512,4096,8192,16384,32768,65536,262144 2>&1 | tee gpurun_out/walk_sweep.txt
+echo "== sweep f32, two states per lane at every size"; RBD_WALK_PAIR_MIN_BATCH=1 timeout 600 python scripts/mapping_sweep.py --algos aba_walk --dtypes f32 --batches 4096,8192,16384,32768,65536,262144 2>&1 | tee gpurun_out/walk_sweep_pair.txt
 echo "== sweep wrenches"; timeout 600 python scripts/mapping_sweep.py --algos aba_walk,aba_banks --batches 4096,65536 --wrenches 2>&1 | tee gpurun_out/walk_sweep_wrenches.txt
 echo "== phases"; RBD_LIB=$R/rigidbodydynamics.jl_amd/csrc/librbd_hip_prof.so timeout 300 python scripts/walk_phases.py 2>&1 | tee gpurun_out/walk_phases.txt
 echo "== pmc"

@@ -7,15 +7,16 @@ import numpy as np, torch
 import rbd_amd as rbd
 from rigidbodydynamics_jl_amd import _capi
 model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
-for dt, tdt in (("f64", torch.float64), ("f32", torch.float32)):
-    for B in (4096, 65536):
-        rng = np.random.default_rng(1)
-        state = rbd.MechanismState(model, B, dtype=tdt); result = rbd.DynamicsResult(model, B, dtype=tdt)
-        rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng)); rbd.set_velocity_(state, rbd.rand_velocity(model, B, rng))
-        tau = torch.rand(B, model.nv, dtype=tdt, device="cuda")
-        for _ in range(5): rbd.dynamics_(result, state, tau, algorithm="aba_walk")
-        torch.cuda.synchronize()
-        out = (ctypes.c_longlong * 16)()
-        assert _capi.lib().rbd_debug_walk_phase_clock(out) == 0
-        t = list(out)
-        print(dt, "B", B, "cycles: staging in", t[1] - t[0], "pass A", t[2] - t[1], "pass B", t[3] - t[2], "pass C", t[4] - t[3], "out", t[5] - t[4], "total", t[5] - t[0], flush=True)
+for dt, tdt, B, pair in (("f64", torch.float64, 4096, False), ("f64", torch.float64, 65536, False), ("f32", torch.float32, 4096, False),
+                         ("f32", torch.float32, 65536, False), ("f32", torch.float32, 65536, True)):
+    os.environ["RBD_WALK_PAIR_MIN_BATCH"] = "1" if pair else str(1 << 40)
+    rng = np.random.default_rng(1)
+    state = rbd.MechanismState(model, B, dtype=tdt); result = rbd.DynamicsResult(model, B, dtype=tdt)
+    rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng)); rbd.set_velocity_(state, rbd.rand_velocity(model, B, rng))
+    tau = torch.rand(B, model.nv, dtype=tdt, device="cuda")
+    for _ in range(5): rbd.dynamics_(result, state, tau, algorithm="aba_walk")
+    torch.cuda.synchronize()
+    out = (ctypes.c_longlong * 16)()
+    assert _capi.lib().rbd_debug_walk_phase_clock(out) == 0
+    t = list(out)
+    print(dt, "two states per lane" if pair else "", "B", B, "cycles: staging in", t[1] - t[0], "pass A", t[2] - t[1], "pass B", t[3] - t[2], "pass C", t[4] - t[3], "out", t[5] - t[4], "total", t[5] - t[0], flush=True)

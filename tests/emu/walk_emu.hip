@@ -12,27 +12,31 @@
 
 using namespace rbd;
 
+template <typename T> static void set_lane(T& x, int j, typename Lanes<T>::S v) { if constexpr (Lanes<T>::N == 1) x = v; else x[j] = v; }
 template <typename T, bool FLT, bool GEN>
-static int emu_run(const WalkModel& M, int reverse, long B, const T* q, const T* v, const T* tau, const T* fext, T* vdot, T* qdot, Layout Lq, Layout Lv, Layout Lf) {
-  const size_t lds_bytes = walk_lds_bytes(M.ns, M.G, M.nq, M.nv, M.nA, M.nB, M.nS, sizeof(T));
+static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes<T>::S* q, const typename Lanes<T>::S* v, const typename Lanes<T>::S* tau,
+                   const typename Lanes<T>::S* fext, typename Lanes<T>::S* vdot, typename Lanes<T>::S* qdot, Layout Lq, Layout Lv, Layout Lf) {
+  using S = typename Lanes<T>::S;
+  constexpr int N = Lanes<T>::N, SPW = 64 * N;
+  const size_t lds_bytes = walk_lds_bytes(M.ns, M.G, M.nq, M.nv, M.nA, M.nB, M.nS, sizeof(T), sizeof(S));
   std::vector<char> lds(lds_bytes + 64);
   void* base = (void*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
   const int ns = M.ns, G = M.G;
   const size_t nrec = (size_t)ns * G;
-  for (long group = 0; group * 64 < B; ++group) {
+  for (long group = 0; group * SPW < B; ++group) {
     memset(base, 0xff, lds_bytes);
     WalkCtx<T> c;
     c.M = M;
     walk_ctx_lds(c, base);
     memcpy(const_cast<I4*>(c.tri), M.ri, nrec * 16);
-    memcpy(const_cast<T*>(c.trr), M.rr, nrec * TR_STRIDE * sizeof(T));
+    memcpy(const_cast<S*>(c.trr), M.rr, nrec * TR_STRIDE * sizeof(S));
     memcpy(const_cast<int32_t*>(c.twk), M.wk, nrec * 4);
-    auto state_of = [&](int l) { const long st = group * 64 + l; return st < B ? st : B - 1; };
-    for (int l = 0; l < 64; ++l) {
+    auto state_of = [&](int l) { const long st = group * SPW + l; return st < B ? st : B - 1; };  // l: state of the workgroup, 0 <= l < 64 N
+    for (int l = 0; l < SPW; ++l) {
       const long st = state_of(l);
-      for (int k = 0; k < M.nq; ++k) *walk_row(c, c.rq + k, l) = q[k * Lq.sk + st * Lq.sb];
-      for (int k = 0; k < M.nv; ++k) *walk_row(c, c.rv + k, l) = v ? v[k * Lv.sk + st * Lv.sb] : T(0);
-      for (int k = 0; k < M.nv; ++k) *walk_row(c, c.rt + k, l) = tau ? tau[k * Lv.sk + st * Lv.sb] : T(0);
+      for (int k = 0; k < M.nq; ++k) *walk_cell(c.rows, c.rq + k, l) = q[k * Lq.sk + st * Lq.sb];
+      for (int k = 0; k < M.nv; ++k) *walk_cell(c.rows, c.rv + k, l) = v ? v[k * Lv.sk + st * Lv.sb] : S(0);
+      for (int k = 0; k < M.nv; ++k) *walk_cell(c.rows, c.rt + k, l) = tau ? tau[k * Lv.sk + st * Lv.sb] : S(0);
     }
     std::vector<WalkRegs<T>> W((size_t)G * 64);
     std::vector<WalkStash<T>> St((size_t)G * 64);
@@ -47,7 +51,7 @@ static int emu_run(const WalkModel& M, int reverse, long B, const T* q, const T*
       while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
       each_wave([&](int g) {
         for (int s = s0; s <= s1; ++s)
-          for (int l = 0; l < 64; ++l) walk_step_a<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), c.trr + (long)(s * G + g) * TR_STRIDE, l, qdot != nullptr);
+          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_a<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, qdot != nullptr); }
       });
       s0 = s1 + 1;
     }
@@ -60,12 +64,14 @@ static int emu_run(const WalkModel& M, int reverse, long B, const T* q, const T*
       each_wave([&](int g) {
         for (int s = s0; s >= s1; --s)
           for (int l = 0; l < 64; ++l) {
-            T fe[6] = {0, 0, 0, 0, 0, 0};
+            T fe[6];
+            for (int k = 0; k < 6; ++k) fe[k] = T(0);
             if (fext) {
               const int o6 = c.tri[s * G + g].y & 0xffff;
-              for (int k = 0; k < 6; ++k) fe[k] = fext[(o6 + k) * Lf.sk + state_of(l) * Lf.sb];
+              for (int k = 0; k < 6; ++k)
+                for (int j = 0; j < N; ++j) set_lane(fe[k], j, fext[(o6 + k) * Lf.sk + state_of(l + 64 * j) * Lf.sb]);
             }
-            walk_step_b<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), c.trr + (long)(s * G + g) * TR_STRIDE, l, fe);
+            T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_b<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
           }
       });
       s0 = s1 - 1;
@@ -76,27 +82,27 @@ static int emu_run(const WalkModel& M, int reverse, long B, const T* q, const T*
       while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
       each_wave([&](int g) {
         for (int s = s0; s <= s1; ++s)
-          for (int l = 0; l < 64; ++l) walk_step_c<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), c.trr + (long)(s * G + g) * TR_STRIDE, l);
+          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_c<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l); }
       });
       s0 = s1 + 1;
     }
-    for (int l = 0; l < 64; ++l) {
-      const long st = group * 64 + l;
+    for (int l = 0; l < SPW; ++l) {
+      const long st = group * SPW + l;
       if (st >= B) continue;
-      for (int k = 0; k < M.nv; ++k) vdot[k * Lv.sk + st * Lv.sb] = *walk_row(c, c.rt + k, l);
+      for (int k = 0; k < M.nv; ++k) vdot[k * Lv.sk + st * Lv.sb] = *walk_cell(c.rows, c.rt + k, l);
     }
     if (qdot) {
-      for (int l = 0; l < 64; ++l) {
-        const long st = group * 64 + l;
+      for (int l = 0; l < SPW; ++l) {
+        const long st = group * SPW + l;
         if (st >= B) continue;
-        for (int k = 0; k < M.nq; ++k) qdot[k * Lq.sk + st * Lq.sb] = *walk_row(c, c.rq + k, l);
+        for (int k = 0; k < M.nq; ++k) qdot[k * Lq.sk + st * Lq.sb] = *walk_cell(c.rows, c.rq + k, l);
       }
     }
   }
   return 0;
 }
 
-template <typename T>
+template <typename T>  // T: double, float, or f2 (two fp32 states per lane)
 static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const double* gravity, int reverse, int aos, long B, int nq, int nv, int nb, const void* q,
                  const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info) {
   WalkModel M;
@@ -106,8 +112,9 @@ static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const
   const WalkPlan P = build_walk_plan(M.ns, M.G, riv);
   if (!P.ok) return 2;
   M.nS = P.nS;
-  if (info) { info[0] = P.nS; info[1] = (int32_t)walk_lds_bytes(M.ns, M.G, nq, nv, M.nA, M.nB, M.nS, sizeof(T)); }
-  std::vector<T> rrt(rr, rr + nrec * TR_STRIDE);
+  using S = typename Lanes<T>::S;
+  if (info) { info[0] = P.nS; info[1] = (int32_t)walk_lds_bytes(M.ns, M.G, nq, nv, M.nA, M.nB, M.nS, sizeof(T), sizeof(S)); }
+  std::vector<S> rrt(rr, rr + nrec * TR_STRIDE);
   M.ri = riv.data(); M.rr = rrt.data(); M.wk = P.wk.data();
   const int32_t* sf = ri + nrec * TI_STRIDE;  // the per-step flags follow the packed records
   for (int k = 0; k < 5; ++k) { M.sfm[k] = 0; for (int s = 0; s < M.ns; ++s) M.sfm[k] |= (uint64_t)((sf[s] >> k) & 1) << s; }
@@ -115,7 +122,7 @@ static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const
   auto lay = [&](long n) { Layout L; if (aos) { L.sk = 1; L.sb = n; } else { L.sk = B; L.sb = 1; } return L; };
   const Layout Lq = lay(nq), Lv = lay(nv), Lf = lay(6L * nb);
   const int flt = dims[4], gen = dims[5];
-#define RUN(F, GN) emu_run<T, F, GN>(M, reverse, B, (const T*)q, (const T*)v, (const T*)tau, (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf)
+#define RUN(F, GN) emu_run<T, F, GN>(M, reverse, B, (const S*)q, (const S*)v, (const S*)tau, (const S*)fext, (S*)vdot, (S*)qdot, Lq, Lv, Lf)
   if (flt) return gen ? RUN(true, true) : RUN(true, false);
   return gen ? RUN(false, true) : RUN(false, false);
 #undef RUN
@@ -123,6 +130,7 @@ static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const
 
 extern "C" int walk_emu_dynamics(const int32_t* dims, const int32_t* ri, const double* rr, const double* gravity, int f32, int reverse, int aos, long B, int nq,
                                  int nv, int nb, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info) {
+  if (f32 == 2) return emu_t<f2>(dims, ri, rr, gravity, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info);  // two fp32 states per lane
   return f32 ? emu_t<float>(dims, ri, rr, gravity, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info)
              : emu_t<double>(dims, ri, rr, gravity, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info);
 }

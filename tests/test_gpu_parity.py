@@ -736,7 +736,7 @@ def test_dynamics_chains_random_trees(rbd, oracle, algorithm):
         except Exception:
             # banks: a tree too shallow or too small to split into two banks that save lanes; tracks: a chain so long that its
             # per-step LDS rows exceed one CU's 160 KB (RBD_ERR_UNSUPPORTED, the default then takes another mapping)
-            assert algorithm in ("aba_banks", "aba_tracks", "aba_walk")  # walk: more than 14 steps per track
+            assert algorithm in ("aba_banks", "aba_tracks", "aba_walk")  # walk: more than 12 steps per track
             continue
         ref = oracle.dynamics(model, q, v, tau, fe)
         got = host(result.vd, state)
@@ -1041,3 +1041,56 @@ def test_c_abi_rccl_gather_single_rank(rbd, models):
         assert torch.equal(out32, result.vd.float())
     finally:
         comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "double_pendulum"])
+def test_dynamics_walk_two_states_per_lane_f32(rbd, oracle, models, name, layout, monkeypatch):
+    """aba_walk_kernel's packed fp32 form (two states per lane, 128 per workgroup; default from 16 385 states up) forced at a small ragged batch:
+    backward error of M v̇ = τ − c against the fp64 oracle's M and c, q̇, and agreement with the one-state-per-lane form."""
+    monkeypatch.setenv("RBD_WALK_PAIR_MIN_BATCH", "1")
+    model = models[name]
+    B = 300
+    state, q, v, tau, fe = make(rbd, model, B, "f32", layout, 77)
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32, layout=layout)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_walk")
+    assert rbd.sync(state) == 0
+    assert "two fp32 states per lane" in rbd.last_kernel(state)
+    got, qd = host(result.vd, state), host(result.qd, state)
+    assert np.isfinite(got).all()
+    M, c = oracle.mass_matrix(model, q), oracle.dynamics_bias(model, q, v, fe)
+    Ms = np.tril(M) + np.transpose(np.tril(M, -1), (0, 2, 1))
+    res = np.einsum("bij,bj->bi", Ms, got) - (tau - c)
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(got, axis=1) + np.linalg.norm(tau - c, axis=1))
+    assert eta.max() <= 2e-5, eta.max()
+    _, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    assert np.abs(qd - qd_ref).max() <= 1e-5 * max(1.0, np.abs(qd_ref).max())
+    monkeypatch.setenv("RBD_WALK_PAIR_MIN_BATCH", str(1 << 40))
+    state1, *_ = make(rbd, model, B, "f32", layout, 77)
+    r1 = rbd.DynamicsResult(model, B, dtype=torch.float32, layout=layout)
+    rbd.dynamics_(r1, state1, dev(tau, state1), dev(fe, state1), algorithm="aba_walk")
+    assert "two fp32" not in rbd.last_kernel(state1)
+    ref = oracle.dynamics(model, q, v, tau, fe)
+    assert np.abs(host(r1.vd, state1) - got).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,B", [("f64", 16384), ("f32", 65536)])
+def test_dynamics_walk_full_size(rbd, oracle, models, dtype, B):
+    """The walk mapping at the batch sizes it is chosen for: the whole batch against the oracle (fp64: 1e-10; fp32: backward error on every state)."""
+    model = models["atlas_floating"]
+    state, q, v, tau, fe = make(rbd, model, B, dtype, "aos", 88)
+    result = rbd.DynamicsResult(model, B, dtype=TD[dtype])
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_walk")
+    assert rbd.sync(state) == 0
+    got = host(result.vd, state)
+    if dtype == "f64":
+        ref = oracle.dynamics(model, q, v, tau, fe, nthreads=NT)
+        assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    else:
+        M, c = oracle.mass_matrix(model, q, nthreads=NT), oracle.dynamics_bias(model, q, v, fe, nthreads=NT)
+        Ms = np.tril(M) + np.transpose(np.tril(M, -1), (0, 2, 1))
+        res = np.einsum("bij,bj->bi", Ms, got) - (tau - c)
+        eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(got, axis=1) + np.linalg.norm(tau - c, axis=1))
+        assert eta.max() <= 2e-5, eta.max()
