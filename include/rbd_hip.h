@@ -107,6 +107,24 @@ typedef struct rbd_loop_joint {
                                src/mechanism_algorithms.jl:610-612); all zero = stabilization off */
 } rbd_loop_joint_t;
 
+/* ---- soft contact (src/contact.jl): contact points on bodies against half-spaces of the environment --------------------------
+ * DefaultContactPoint = ContactPoint{SoftContactModel{HuntCrossleyModel, ViscoelasticCoulombModel}} (src/contact.jl:196) and
+ * HalfSpace3D (:202-222).  Every (contact point, half-space) pair owns 3 additional states (the tangential displacement of the
+ * friction model; the normal model has none): s has 3 * n_contact_points * n_halfspaces entries per state of the batch, ordered
+ * point-major as MechanismState lays them out (src/mechanism_state.jl:139-152: for body, for point, for half-space) — i.e. in the
+ * order the points are listed here.                                                                                              */
+typedef struct rbd_contact_point {
+  int32_t body;            /* moving-body index                                                        */
+  int32_t _pad;
+  double location[3];      /* Point3D in the body's default frame (= frame_after of its joint)         */
+  double hc_k, hc_lambda, hc_n;   /* HuntCrossleyModel k, λ, n   (hunt_crossley_hertz: λ = 3/2 α k, n = 3/2)   */
+  double mu, k, b;         /* ViscoelasticCoulombModel μ, k, b                                         */
+} rbd_contact_point_t;
+typedef struct rbd_halfspace {
+  double point[3];          /* root frame */
+  double outward_normal[3]; /* root frame; normalized on model creation like HalfSpace3D's constructor */
+} rbd_halfspace_t;
+
 /* ---- the flattened mechanism ---------------------------------------------
  * Exactly the tables MechanismState builds once (src/mechanism_state.jl:85-118):
  * moving body i (0-based) is the successor of tree joint i; bodies are in the
@@ -130,6 +148,10 @@ typedef struct rbd_flat_model {
   const double* inertia_mass;  /* [n_bodies]                                           */
   double gravity[3];           /* gravitational_acceleration in the root frame (default 0,0,-9.81: src/mechanism.jl:1) */
   const rbd_loop_joint_t* loops; /* [n_loops] or NULL                                  */
+  int32_t n_contact_points;    /* contact_points of all bodies (0: none, like every URDF-parsed mechanism) */
+  int32_t n_halfspaces;        /* mechanism.environment.halfspaces                     */
+  const rbd_contact_point_t* contact_points; /* [n_contact_points] or NULL, in the order of the additional state */
+  const rbd_halfspace_t* halfspaces;         /* [n_halfspaces] or NULL                 */
 } rbd_flat_model_t;
 
 typedef struct rbd_model rbd_model_t; /* opaque, immutable after create               */
@@ -229,6 +251,22 @@ int rbd_dynamics_result(rbd_ws_t* ws, int32_t B, void* M, void* c, void* K, void
 int rbd_simulate(rbd_ws_t* ws, int32_t B, void* q, void* v, const void* tau, const void* fext, double dt, int32_t nsteps,
                  const rbd_opts_t* opts);
 int rbd_mk_stage(rbd_ws_t* ws, int32_t B, int32_t stage, double dt, void* q, void* v, const void* vdot_prev, const rbd_opts_t* opts);
+
+/* ---- soft contact: contact_dynamics! (src/mechanism_algorithms.jl:680-723) and the entry points that include it --------------------
+ * rbd_contact_dynamics: for every contact point inside a half-space the force of contact_dynamics! (src/contact.jl:79-93: Hunt–Crossley
+ *   normal force, viscoelastic Coulomb friction) as a wrench on its body in the ROOT frame, and the state derivative of the friction
+ *   model; for a pair that is not in contact the reference resets the state and zeroes the derivative — so `s` is IN/OUT.
+ *   s, sdot: ns×B with ns = 3·n_contact_points·n_halfspaces; contactwrenches[6·n_bodies×B] = result.contactwrenches (nullable).
+ * rbd_dynamics_contact: dynamics!(result, state, τ, wext) of a mechanism with contact points (:845-864): contact_dynamics!, then
+ *   totalwrenches = wext + contactwrenches (:851-856), then forward dynamics with those.  totalwrenches nullable.
+ * rbd_simulate_contact: simulate (src/simulate.jl:36-55) with the additional state integrated beside (q, v) by the same Runge–Kutta
+ *   tableau (src/ode_integrators.jl:233-299).  Tree mechanisms.                                                                */
+int rbd_model_contact_dims(const rbd_model_t* model, int32_t* n_contact_points, int32_t* n_halfspaces, int32_t* n_additional_states);
+int rbd_contact_dynamics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* s, void* contactwrenches, void* sdot, const rbd_opts_t* opts);
+int rbd_dynamics_contact(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* s, const void* tau, const void* fext, void* vdot, void* qdot,
+                         void* sdot, void* contactwrenches, void* totalwrenches, const rbd_opts_t* opts);
+int rbd_simulate_contact(rbd_ws_t* ws, int32_t B, void* q, void* v, void* s, const void* tau, const void* fext, double dt, int32_t nsteps,
+                         const rbd_opts_t* opts);
 
 /* ---- kinematics by-products of the same forward-kinematics pass (every output nullable; opts->memory as for rbd_dynamics) ---------------
  * momentum_matrix: 6×nv column-major per state, root frame, (angular; linear) — momentum_matrix!(out, state)

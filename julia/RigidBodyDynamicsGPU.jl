@@ -86,6 +86,16 @@ struct RbdLoopJoint
     gains::NTuple{4, Float64}
 end
 
+struct RbdContactPoint        # DefaultContactPoint: src/contact.jl:72-77, :196
+    body::Int32; _pad::Int32
+    location::NTuple{3, Float64}
+    hc_k::Float64; hc_lambda::Float64; hc_n::Float64     # HuntCrossleyModel
+    mu::Float64; k::Float64; b::Float64                  # ViscoelasticCoulombModel
+end
+struct RbdHalfSpace           # HalfSpace3D: src/contact.jl:202-222
+    point::NTuple{3, Float64}; outward_normal::NTuple{3, Float64}
+end
+
 struct RbdFlatModel
     n_bodies::Int32; nq::Int32; nv::Int32; n_loops::Int32
     parent::Ptr{Int32}; joint_type::Ptr{Int32}; q_offset::Ptr{Int32}; v_offset::Ptr{Int32}
@@ -94,6 +104,8 @@ struct RbdFlatModel
     inertia_moment::Ptr{Float64}; inertia_cross::Ptr{Float64}; inertia_mass::Ptr{Float64}
     gravity::NTuple{3, Float64}
     loops::Ptr{RbdLoopJoint}
+    n_contact_points::Int32; n_halfspaces::Int32
+    contact_points::Ptr{RbdContactPoint}; halfspaces::Ptr{RbdHalfSpace}
 end
 
 struct RbdOpts
@@ -152,12 +164,22 @@ function FlatModelHandle(mechanism::Mechanism)
             Tuple(rowmajor(rotation(joint_to_successor(j)))), Tuple(Float64.(translation(joint_to_successor(j)))),
             Tuple(Rz), (100.0, 20.0, 100.0, 20.0)))     # default_constraint_stabilization_gains (mechanism_algorithms.jl:610-612)
     end
+    # soft contact: points in the order of the additional state (for body in bodies(m), for point: mechanism_state.jl:143), half-spaces
+    cps = RbdContactPoint[]
+    for body in bodies(mechanism), point in RigidBodyDynamics.contact_points(body)
+        model = RigidBodyDynamics.Contact.contact_model(point)
+        loc = RigidBodyDynamics.Contact.location(point).v
+        push!(cps, RbdContactPoint(bodyindex[body], 0, (loc[1], loc[2], loc[3]), model.normal.k, model.normal.λ, model.normal.n,
+            model.friction.μ, model.friction.k, model.friction.b))
+    end
+    hss = [RbdHalfSpace(Tuple(Float64.(h.point.v)), Tuple(Float64.(h.outward_normal.v))) for h in mechanism.environment.halfspaces]
     g = mechanism.gravitational_acceleration.v
     handle = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve parent jtype qoff voff axis axis2 prot ptrans moment cross mass loops begin
+    GC.@preserve parent jtype qoff voff axis axis2 prot ptrans moment cross mass loops cps hss begin
         desc = Ref(RbdFlatModel(nb, sum(num_positions, tj; init = 0), sum(num_velocities, tj; init = 0), length(loops),
             pointer(parent), pointer(jtype), pointer(qoff), pointer(voff), pointer(axis), pointer(axis2), pointer(prot), pointer(ptrans),
-            pointer(moment), pointer(cross), pointer(mass), (g[1], g[2], g[3]), isempty(loops) ? C_NULL : pointer(loops)))
+            pointer(moment), pointer(cross), pointer(mass), (g[1], g[2], g[3]), isempty(loops) ? C_NULL : pointer(loops),
+            length(cps), length(hss), isempty(cps) ? C_NULL : pointer(cps), isempty(hss) ? C_NULL : pointer(hss)))
         check(ccall((:rbd_model_create, librbd_hip[]), Cint, (Ref{RbdFlatModel}, Ref{Ptr{Cvoid}}), desc, handle), "rbd_model_create")
     end
     m = FlatModelHandle(handle[], modcount(mechanism), num_positions(mechanism), num_velocities(mechanism),
@@ -175,6 +197,7 @@ mutable struct BatchedMechanismState{T, A <: Buffer{T}}
     memory::Int32     # MEM_DEVICE: q, v (and every buffer handed to a call) are device pointers — the default; MEM_HOST: plain Matrix
     q::A              # nq × B
     v::A              # nv × B
+    s::A              # num_additional_states × B: the soft-contact friction states (mechanism_state.jl:64, :139-152)
 end
 
 """`storage = :device` (default): q, v are `DeviceMatrix` — resident in HBM, calls are asynchronous on the workspace's stream;
@@ -185,7 +208,8 @@ function BatchedMechanismState(mechanism::Mechanism, B::Integer; T::Type = Float
     check(ccall((:rbd_workspace_create, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
         model.handle, B, device, T === Float64 ? 0 : 1, C_NULL, ws), "rbd_workspace_create")
     q, v = newbuffer(Val(storage), T, model.nq, B), newbuffer(Val(storage), T, model.nv, B)
-    s = BatchedMechanismState{T, typeof(q)}(mechanism, model, ws[], storage === :device ? MEM_DEVICE : MEM_HOST, q, v)
+    s = BatchedMechanismState{T, typeof(q)}(mechanism, model, ws[], storage === :device ? MEM_DEVICE : MEM_HOST, q, v,
+        newbuffer(Val(storage), T, RigidBodyDynamics.num_additional_states(mechanism), B))
     finalizer(x -> ccall((:rbd_workspace_destroy, librbd_hip[]), Cint, (Ptr{Cvoid},), x.ws), s)
     s
 end
@@ -207,12 +231,14 @@ struct BatchedDynamicsResult{T, A <: Buffer{T}}
     accelerations::A            # (6·n_bodies) × B — src/dynamics_result.jl:26-29, root frame, (angular; linear) per body
     jointwrenches::A
     totalwrenches::A
+    ṡ::A                        # num_additional_states × B (dynamics_result.jl:20)
+    contactwrenches::A          # (6·n_bodies) × B (dynamics_result.jl:25)
 end
 function BatchedDynamicsResult(mechanism::Mechanism, B::Integer; T::Type = Float64, storage::Symbol = :device)
     nq, nv, nb = num_positions(mechanism), num_velocities(mechanism), length(collect(tree_joints(mechanism)))
     nc = sum(num_constraints, non_tree_joints(mechanism); init = 0)
     z(n) = newbuffer(Val(storage), T, n, B)
-    r = (z(nv * nv), z(nv), z(nq), z(nv), z(nc), z(nc * nv), z(nc), z(6nb), z(6nb), z(6nb))
+    r = (z(nv * nv), z(nv), z(nq), z(nv), z(nc), z(nc * nv), z(nc), z(6nb), z(6nb), z(6nb), z(RigidBodyDynamics.num_additional_states(mechanism)), z(6nb))
     BatchedDynamicsResult{T, typeof(r[1])}(r...)
 end
 
@@ -247,6 +273,16 @@ function dynamics!(result::BatchedDynamicsResult{T}, state::BatchedMechanismStat
     wext = densewrenches(state, externalwrenches)
     o = opts(state; algorithm = algorithm === :aba ? 0 : 1, stabilization = stabilization_gains === nothing ? 0 : 1)
     λptr = state.model.nc > 0 ? pointer(result.λ) : C_NULL
+    if size(state.s, 1) > 0
+        # contact points: contact_dynamics! (:680-723), totalwrenches = externalwrenches + contactwrenches (:851-856), then forward dynamics.
+        # state.s is reset where a point is not in contact, exactly as the reference resets the contact state in place.  Device buffers only.
+        check(ccall((:rbd_dynamics_contact, librbd_hip[]), Cint,
+            (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+            state.ws, B, state.q, state.v, state.s, nullable(torques), nullable(wext), result.v̇, result.q̇, result.ṡ, result.contactwrenches,
+            result.totalwrenches, o), "rbd_dynamics_contact")
+        finish(state)
+        return nothing
+    end
     check(ccall((:rbd_dynamics, librbd_hip[]), Cint,
         (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
         state.ws, B, state.q, state.v, nullable(torques), nullable(wext), result.v̇, result.q̇, λptr, o), "rbd_dynamics")
@@ -325,9 +361,14 @@ function simulate(state::BatchedMechanismState{T}, final_time; Δt = 1e-4, torqu
     while t < final_time            # same loop as integrate(), src/ode_integrators.jl:311-314
         t += Δt; nsteps += 1
     end
-    check(ccall((:rbd_simulate, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
-        state.ws, batchsize(state), state.q, state.v, nullable(torques), C_NULL, Float64(Δt), nsteps,
-        opts(state; stabilization = stabilization_gains === nothing ? 0 : 1)), "rbd_simulate")
+    if size(state.s, 1) > 0     # contact points: the additional state is integrated beside (q, v) with the same tableau
+        check(ccall((:rbd_simulate_contact, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
+            state.ws, batchsize(state), state.q, state.v, state.s, nullable(torques), C_NULL, Float64(Δt), nsteps, opts(state)), "rbd_simulate_contact")
+    else
+        check(ccall((:rbd_simulate, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
+            state.ws, batchsize(state), state.q, state.v, nullable(torques), C_NULL, Float64(Δt), nsteps,
+            opts(state; stabilization = stabilization_gains === nothing ? 0 : 1)), "rbd_simulate")
+    end
     finish(state)
     range(zero(T), step = T(Δt), length = nsteps + 1)
 end

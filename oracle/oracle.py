@@ -220,3 +220,24 @@ def momentum(model, q, v, dtype=np.float64):
     for b in range(B):
         assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(v[b], ct), _ptr(h[b], ct), _ptr(hb[b], ct)) == 0
     return h, hb
+
+
+def contact_dynamics(model, q, v, s, dtype=np.float64):
+    """contact_dynamics!(result, state): returns (s after the resets [B, ns], sdot [B, ns], contactwrenches [B, 6 n_bodies])."""
+    sfx, ct = _sfx(dtype)
+    f = getattr(lib(), "rbdo_contact_dynamics" + sfx)
+    f.restype = ctypes.c_int
+    B, ns = q.shape[0], model.ns
+    q, v = np.ascontiguousarray(q, dtype), np.ascontiguousarray(v, dtype)
+    s = np.array(s, dtype).reshape(B, ns).copy()
+    sd, cw = np.zeros((B, ns), dtype), np.zeros((B, 6 * model.n_bodies), dtype)
+    for b in range(B):
+        assert f(ctypes.byref(model.c_struct()), _ptr(q[b], ct), _ptr(v[b], ct), _ptr(s[b], ct), _ptr(sd[b], ct), _ptr(cw[b], ct)) == 0
+    return s, sd, cw
+
+
+def dynamics_contact(model, q, v, s, tau=None, fext=None, dtype=np.float64):
+    """dynamics!(result, state, τ, wext) with contact points (mechanism_algorithms.jl:845-864): (vdot, s after resets, sdot, contactwrenches, totalwrenches)."""
+    s2, sd, cw = contact_dynamics(model, q, v, s, dtype)
+    tw = cw if fext is None else cw + np.asarray(fext, dtype)
+    return dynamics(model, q, v, tau, tw, dtype=dtype), s2, sd, cw, tw

@@ -996,6 +996,62 @@ int FN(rbdo_transforms)(const rbd_flat_model_t* m, const REAL* q, REAL* out) {
   return RBD_OK;
 }
 
+/* ---- soft contact --------------------------------------------------------------------------------------------------------------
+ * contact_dynamics!(result, state) (src/mechanism_algorithms.jl:680-723) with the reference's default point model
+ * SoftContactModel{HuntCrossleyModel, ViscoelasticCoulombModel} (src/contact.jl:79-93, :98-119, :122-178) and HalfSpace3D (:202-228).
+ * s (in/out: reset! for pairs not in contact), sdot, contactwrenches [6 n_bodies] in the root frame (torque about the root origin; force). */
+int FN(rbdo_contact_dynamics)(const rbd_flat_model_t* m, const REAL* q, const REAL* v, REAL* s, REAL* sdot, REAL* cw) {
+  CACHE c;
+  if (FN(cache_alloc)(m, &c)) return RBD_ERR_OUT_OF_MEMORY;
+  FN(update_transforms)(m, q, &c);          /* :681 */
+  FN(update_motion_subspaces)(m, q, &c);
+  FN(update_twists)(m, v, &c);              /* :682 */
+  for (int i = 0; i < 6 * c.nb; ++i) cw[i] = 0;
+  const int nh = m->n_halfspaces;
+  for (int ip = 0; ip < m->n_contact_points; ++ip) {
+    const rbd_contact_point_t* cp = &m->contact_points[ip];
+    const XF* H = &c.H[cp->body];
+    const REAL* tw = &c.T[6 * cp->body];
+    REAL loc[3] = {(REAL)cp->location[0], (REAL)cp->location[1], (REAL)cp->location[2]}, pt[3], vel[3], t3[3];
+    FN(matvec3)(H->R, loc, pt);                                   /* point = body_to_root * location(c)   :697 */
+    for (int j = 0; j < 3; ++j) pt[j] += H->p[j];
+    FN(cross3)(tw, pt, t3);                                       /* point_velocity(twist, point)          :698 */
+    for (int j = 0; j < 3; ++j) vel[j] = t3[j] + tw[3 + j];
+    for (int h = 0; h < nh; ++h) {
+      const rbd_halfspace_t* hs = &m->halfspaces[h];
+      REAL n[3] = {(REAL)hs->outward_normal[0], (REAL)hs->outward_normal[1], (REAL)hs->outward_normal[2]};
+      const REAL nn = SQRT(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);  /* HalfSpace3D normalizes its normal (contact.jl:208-211) */
+      for (int j = 0; j < 3; ++j) n[j] /= nn;
+      REAL* x = s + 3 * (ip * nh + h);
+      REAL* xd = sdot + 3 * (ip * nh + h);
+      REAL sep = 0;                                               /* separation (contact.jl:224) */
+      for (int j = 0; j < 3; ++j) sep += (pt[j] - (REAL)hs->point[j]) * n[j];
+      if (sep <= 0) {                                             /* point_inside (:225) */
+        const REAL z = -sep;                                      /* penetration */
+        REAL zd = 0;
+        for (int j = 0; j < 3; ++j) zd -= vel[j] * n[j];          /* ż = −dot(velocity, normal)   contact.jl:84 */
+        const REAL zn = (REAL)pow((double)z, cp->hc_n);
+        REAL fn = (REAL)cp->hc_lambda * zn * zd + (REAL)cp->hc_k * zn;   /* normal_force :115-118 */
+        if (!(fn > 0)) fn = 0;                                    /* max(., 0) :85 */
+        REAL vt[3], fs[3], n2 = 0;
+        for (int j = 0; j < 3; ++j) vt[j] = vel[j] + zd * n[j];   /* tangential_velocity :88 */
+        for (int j = 0; j < 3; ++j) { fs[j] = -(REAL)cp->k * x[j] - (REAL)cp->b * vt[j]; n2 += fs[j] * fs[j]; }   /* fstick :159 */
+        const REAL m2 = ((REAL)cp->mu * fn) * ((REAL)cp->mu * fn);
+        if (n2 > m2) { const REAL sc = SQRT(m2 / n2); for (int j = 0; j < 3; ++j) fs[j] *= sc; }                    /* :163-167 */
+        for (int j = 0; j < 3; ++j) xd[j] = (-(REAL)cp->k * x[j] - fs[j]) / (REAL)cp->b;                             /* :171-178 */
+        REAL f[3], tq[3];
+        for (int j = 0; j < 3; ++j) f[j] = fn * n[j] + fs[j];     /* :92 */
+        FN(cross3)(pt, f, tq);                                    /* Wrench(point, force) */
+        for (int j = 0; j < 3; ++j) { cw[6 * cp->body + j] += tq[j]; cw[6 * cp->body + 3 + j] += f[j]; }
+      } else {
+        for (int j = 0; j < 3; ++j) { x[j] = 0; xd[j] = 0; }      /* reset!, zero!  :714-715 */
+      }
+    }
+  }
+  FN(cache_free)(&c);
+  return RBD_OK;
+}
+
 /* ---- batch drivers (AOS: one state per column, x[b*n + k]); OpenMP over states.  Used by the parity
  * tests and by bench.py's cpu_baseline leg. what: 0 dynamics (reference route), 1 inverse dynamics,
  * 2 dynamics_bias, 3 mass matrix, 4 ABA cross-check ------------------------------------------- */

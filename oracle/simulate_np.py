@@ -176,3 +176,39 @@ def simulate(model, q, v, final_time, dt, tau=None, stabilize=True):
         t += dt
         ts.append(t)
     return np.array(ts), q, v
+
+
+def vdot_contact(model, q, v, s, tau):
+    vd, _, sd, _, _ = oracle.dynamics_contact(model, q[None], v[None], s[None], None if tau is None else tau[None])
+    return vd[0], sd[0]
+
+
+def step_contact(model, q0, v0, s0, dt, tau=None):
+    """MuntheKaasIntegrator.step with additional states (ode_integrators.jl:233-299): s goes through the tableau like v."""
+    phids, vds, sds = [], [], []
+    for i in range(4):
+        phi = sum((dt * RK4_A[i, j] * phids[j] for j in range(i) if RK4_A[i, j] != 0), np.zeros(model.nv))
+        v = v0 + sum((dt * RK4_A[i, j] * vds[j] for j in range(i) if RK4_A[i, j] != 0), np.zeros(model.nv))
+        s = s0 + sum((dt * RK4_A[i, j] * sds[j] for j in range(i) if RK4_A[i, j] != 0), np.zeros(model.ns))
+        q = global_coordinates(model, q0, phi)
+        vd, sd = vdot_contact(model, q, v, s, tau)
+        vds.append(vd); sds.append(sd)
+        phids.append(local_rate(model, q0, q, v))
+    phi = sum(dt * RK4_B[i] * phids[i] for i in range(4))
+    v = v0 + sum(dt * RK4_B[i] * vds[i] for i in range(4))
+    s = s0 + sum(dt * RK4_B[i] * sds[i] for i in range(4))
+    return global_coordinates(model, q0, phi), v, s
+
+
+def simulate_contact(model, q, v, s, final_time, dt, tau=None, record=False):
+    """`simulate` of a mechanism with contact points. q, v, s: (B, n). Returns ts, q_end, v_end, s_end (and the trajectory when record)."""
+    q, v, s = np.array(q, float), np.array(v, float), np.array(s, float)
+    t, ts, traj = 0.0, [0.0], [(q.copy(), v.copy(), s.copy())]
+    while t < final_time:
+        for b in range(q.shape[0]):
+            q[b], v[b], s[b] = step_contact(model, q[b], v[b], s[b], dt, None if tau is None else tau[b])
+        t += dt
+        ts.append(t)
+        if record:
+            traj.append((q.copy(), v.copy(), s.copy()))
+    return (np.array(ts), q, v, s, traj) if record else (np.array(ts), q, v, s)

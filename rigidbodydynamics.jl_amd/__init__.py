@@ -8,7 +8,8 @@ hand-written HIP kernels; there is no CPU fallback."""
 from .mechanism import (DEFAULT_GRAVITATIONAL_ACCELERATION, CartesianFrame3D, Fixed, FlatModel, Joint, JointType, Mechanism,
                         Planar, Prismatic, QuaternionFloating, QuaternionSpherical, Revolute, RigidBody, SinCosRevolute,
                         SpatialInertia, Transform3D, attach_, flatten, rand_configuration, rand_velocity,
-                        remove_fixed_tree_joints_, rot_z_y_x, rotation_between)
+                        remove_fixed_tree_joints_, rot_z_y_x, rotation_between, ContactPoint, HalfSpace3D, HuntCrossleyModel, SoftContactModel,
+                        ViscoelasticCoulombModel, add_contact_point_, add_environment_primitive_, hunt_crossley_hertz)
 from .urdf import default_urdf_joint_types, parse_pose, parse_urdf, write_urdf
 from .builders import (maximal_coordinates, FOUR_BAR_INITIAL_Q, FOUR_BAR_INITIAL_V, double_pendulum, four_bar_linkage, quickstart_double_pendulum,
                        rand_tree_mechanism, randmech)

@@ -75,6 +75,10 @@ struct rbd_model {
   uint64_t bank_perm_down = 0;
   ChainPlan chain;  // plan of aba_chain_kernel (chain.ok == false: mechanism outside its scope)
   TrackPlan track;  // plan of aba_track_kernel (track.ok == false: mechanism outside its scope)
+  // soft contact (src/contact.jl): points in the order of the additional state, half-spaces with unit normals
+  int32_t ncp = 0, nhs = 0;
+  std::vector<int32_t> cp_body;
+  std::vector<double> cp_r, hs_r;  // ncp * CP_STRIDE, nhs * 6
   WalkPlan walk;    // parking slots of aba_walk_kernel on top of the track plan (walk.ok == false: track plan missing or too many steps)
   StatePlan state;  // plan of the one-lane-per-state kernels (state.ok == false: mechanism outside their scope)
 };
@@ -86,6 +90,8 @@ struct rbd_ws {
   DevModel dm{};
   BankModel bm{}; void* d_bank_ib[2] = {nullptr, nullptr}; void* d_bank_rb[2] = {nullptr, nullptr};
   TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr; size_t track_lds_bytes4 = 0; long track_nw4_max_batch = 0; size_t track_lds_bytes = 0; long track_min_batch = 0;
+  ContactModel ctm{}; void* d_cp_body = nullptr; void* d_cp_r = nullptr; void* d_hs_r = nullptr;  // soft contact tables
+  void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; size_t d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
@@ -142,6 +148,25 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   const int nb = d->n_bodies;
   m->nb = nb; m->nq = d->nq; m->nv = d->nv; m->nloops = d->n_loops;
   memcpy(m->gravity, d->gravity, sizeof m->gravity);
+  if (d->n_contact_points < 0 || d->n_halfspaces < 0 || (d->n_contact_points > 0 && !d->contact_points) || (d->n_halfspaces > 0 && !d->halfspaces)) {
+    delete m;
+    return RBD_ERR_INVALID_ARGUMENT;
+  }
+  m->ncp = d->n_contact_points; m->nhs = d->n_halfspaces;
+  for (int i = 0; i < m->ncp; ++i) {
+    const rbd_contact_point_t& c = d->contact_points[i];
+    if (c.body < 0 || c.body >= nb || !(c.b != 0.0)) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
+    m->cp_body.push_back(c.body);
+    const double r[CP_STRIDE] = {c.location[0], c.location[1], c.location[2], c.hc_k, c.hc_lambda, c.hc_n, c.mu, c.k, c.b};
+    m->cp_r.insert(m->cp_r.end(), r, r + CP_STRIDE);
+  }
+  for (int i = 0; i < m->nhs; ++i) {  // HalfSpace3D's constructor normalizes the outward normal (src/contact.jl:208-211)
+    const rbd_halfspace_t& h = d->halfspaces[i];
+    const double nn = std::sqrt(h.outward_normal[0] * h.outward_normal[0] + h.outward_normal[1] * h.outward_normal[1] + h.outward_normal[2] * h.outward_normal[2]);
+    if (!(nn > 0.0)) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
+    const double r[6] = {h.point[0], h.point[1], h.point[2], h.outward_normal[0] / nn, h.outward_normal[1] / nn, h.outward_normal[2] / nn};
+    m->hs_r.insert(m->hs_r.end(), r, r + 6);
+  }
   int lps = 1;
   while (lps < nb) lps <<= 1;
   m->lps = lps;
@@ -524,6 +549,19 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->track_min_batch = (long)1 << 62;
     if (const char* e = getenv("RBD_TRACK_MIN_BATCH")) w->track_min_batch = atol(e);
   }
+  if (m->ncp > 0) {
+    st = upload(&w->d_cp_body, m->cp_body.data(), m->cp_body.size() * sizeof(int32_t));
+    auto up = [&](void** dst, const std::vector<double>& src) {
+      if (dtype == RBD_F64) return upload(dst, src.data(), src.size() * sizeof(double));
+      std::vector<float> f(src.begin(), src.end());
+      return upload(dst, f.data(), f.size() * sizeof(float));
+    };
+    if (st == RBD_OK) st = up(&w->d_cp_r, m->cp_r);
+    if (st == RBD_OK) st = up(&w->d_hs_r, m->hs_r);
+    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+    w->ctm.nb = m->nb; w->ctm.np = m->ncp; w->ctm.nh = m->nhs;
+    w->ctm.cbody = (const int32_t*)w->d_cp_body; w->ctm.cp = w->d_cp_r; w->ctm.hs = w->d_hs_r;
+  }
   if (m->track.ok && m->walk.ok) {
     const TrackPlan& P = m->track;
     st = upload(&w->d_walk_wk, m->walk.wk.data(), m->walk.wk.size() * sizeof(int32_t));
@@ -599,7 +637,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_walk_wk, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -1148,6 +1186,106 @@ int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, cons
   return RBD_OK;
 }
 
+
+// ---- soft contact ------------------------------------------------------------------------------------------------------------------
+int rbd_model_contact_dims(const rbd_model_t* m, int32_t* n_contact_points, int32_t* n_halfspaces, int32_t* n_additional_states) {
+  if (!m) return RBD_ERR_INVALID_ARGUMENT;
+  if (n_contact_points) *n_contact_points = m->ncp;
+  if (n_halfspaces) *n_halfspaces = m->nhs;
+  if (n_additional_states) *n_additional_states = 3 * m->ncp * m->nhs;  // num_additional_states (src/mechanism.jl:143-149)
+  return RBD_OK;
+}
+
+// contact_dynamics! on device pointers: per-body kinematics (the RNEA launch exports them; its bias torques go to the workspace),
+// then the contact kernel.  dcw / dtw nullable.
+static int run_contact(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const void* dv, void* ds, void* dsd, const void* df, void* dcw, void* dtw) {
+  const rbd_model* m = w->model;
+  const size_t es = esize(w);
+  int st;
+  if ((st = ensure(&w->d_body, &w->d_body_bytes, es * (size_t)m->nb * 24 * B)) || (st = ensure(&w->d_c, &w->d_c_bytes, es * (size_t)m->nv * B))) return st;
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
+  const Layout Ls = layout_of(o.layout, 3L * m->ncp * m->nhs, B);
+  if (w->dtype == RBD_F64) {
+    HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, nullptr, nullptr, w->d_c, nullptr, w->d_body, Lq, Lv, Lf, w->stream));
+    HIP_TRY(launch_contact<double>(w->ctm, B, w->d_body, ds, dsd, df, dcw, dtw, Ls, Lf, w->stream));
+  } else {
+    HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, nullptr, nullptr, w->d_c, nullptr, w->d_body, Lq, Lv, Lf, w->stream));
+    HIP_TRY(launch_contact<float>(w->ctm, B, w->d_body, ds, dsd, df, dcw, dtw, Ls, Lf, w->stream));
+  }
+  return RBD_OK;
+}
+
+static int contact_scope(const rbd_ws* w, const Opts& o) {
+  if (w->model->ncp == 0 || w->model->nhs == 0) return RBD_ERR_INVALID_ARGUMENT;  // nothing to do: use rbd_dynamics
+  if (w->model->nloops > 0) return RBD_ERR_UNSUPPORTED;
+  if (o.memory != RBD_MEM_DEVICE) return RBD_ERR_UNSUPPORTED;  // device pointers only
+  return RBD_OK;
+}
+
+int rbd_contact_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* s, void* contactwrenches, void* sdot, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if ((st = contact_scope(w, o))) return st;
+  if (!q || !v || !s) return RBD_ERR_INVALID_ARGUMENT;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  return run_contact(w, B, o, q, v, s, sdot, nullptr, contactwrenches, nullptr);
+}
+
+int rbd_dynamics_contact(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* s, const void* tau, const void* fext, void* vdot, void* qdot,
+                         void* sdot, void* contactwrenches, void* totalwrenches, const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if ((st = contact_scope(w, o))) return st;
+  if (!q || !v || !s || !vdot) return RBD_ERR_INVALID_ARGUMENT;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const rbd_model* m = w->model;
+  void* dtw = totalwrenches;
+  if (!dtw) {
+    if ((st = ensure(&w->d_tw, &w->d_tw_bytes, esize(w) * (size_t)6 * m->nb * B))) return st;
+    dtw = w->d_tw;
+  }
+  if ((st = run_contact(w, B, o, q, v, s, sdot, fext, contactwrenches, dtw))) return st;
+  return run_dynamics(w, B, o, q, v, tau, dtw, vdot, qdot, nullptr);
+}
+
+int rbd_simulate_contact(rbd_ws_t* w, int32_t B, void* q, void* v, void* s, const void* tau, const void* fext, double dt, int32_t nsteps,
+                         const rbd_opts_t* opts) {
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  if ((st = contact_scope(w, o))) return st;
+  if (!q || !v || !s || nsteps < 0 || !(dt > 0)) return RBD_ERR_INVALID_ARGUMENT;
+  if (B == 0 || nsteps == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const rbd_model* m = w->model;
+  const size_t es = esize(w);
+  const long ns = 3L * m->ncp * m->nhs * B;
+  if ((st = mk_ensure(w, B)) || (st = ensure(&w->d_tw, &w->d_tw_bytes, es * (size_t)6 * m->nb * B)) || (st = ensure(&w->d_s0, &w->d_s0_bytes, es * (size_t)ns)) ||
+      (st = ensure(&w->d_sacc, &w->d_sacc_bytes, es * (size_t)ns)) || (st = ensure(&w->d_sdot, &w->d_sdot_bytes, es * (size_t)ns)))
+    return st;
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B);
+  for (int step = 0; step < nsteps; ++step) {
+    // MuntheKaasIntegrator.step (src/ode_integrators.jl:233-299): (q, v) through mk_stage_kernel, s beside them with the same tableau
+    for (int stage = 0; stage <= 4; ++stage) {
+      if (w->dtype == RBD_F64) {
+        HIP_TRY(launch_mk_stage<double>(w->dm, B, stage, dt, q, v, w->d_vdwork, w->mk, Lq, Lv, w->stream));
+        HIP_TRY(launch_contact_stage<double>(ns, stage, dt, s, w->d_sdot, w->d_s0, w->d_sacc, w->stream));
+      } else {
+        HIP_TRY(launch_mk_stage<float>(w->dm, B, stage, dt, q, v, w->d_vdwork, w->mk, Lq, Lv, w->stream));
+        HIP_TRY(launch_contact_stage<float>(ns, stage, dt, s, w->d_sdot, w->d_s0, w->d_sacc, w->stream));
+      }
+      if (stage < 4) {
+        if ((st = run_contact(w, B, o, q, v, s, w->d_sdot, fext, nullptr, w->d_tw))) return st;
+        if ((st = run_dynamics(w, B, o, q, v, tau, w->d_tw, w->d_vdwork, nullptr, nullptr))) return st;
+      }
+    }
+  }
+  return RBD_OK;
+}
 
 int rbd_cholesky_solve(rbd_ws_t* w, int32_t B, const void* M, const void* rhs, void* x, void* L_out, const rbd_opts_t* opts) {
   const Opts o = read_opts(opts);

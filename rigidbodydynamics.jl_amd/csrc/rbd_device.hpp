@@ -120,6 +120,16 @@ struct StateModel {
   double gravity[3];
 };
 
+// ---- soft contact (contact_kernel, rbd_contact_kernels.hip): contact points grouped by body, half-spaces of the environment ----------
+//   cp[point * CP_STRIDE]: location (3, body frame), Hunt–Crossley k, λ, n, viscoelastic Coulomb μ, k, b;  hs[halfspace * 6]: point, unit outward normal
+enum { CP_LOC = 0, CP_HCK = 3, CP_HCL = 4, CP_HCN = 5, CP_MU = 6, CP_K = 7, CP_B = 8, CP_STRIDE = 9 };
+struct ContactModel {
+  int32_t nb, np, nh;
+  const int32_t* cbody;  // [np] reference body index of each point
+  const void* cp;        // [np * CP_STRIDE] of the kernel's scalar type
+  const void* hs;        // [nh * 6]
+};
+
 // element (k, b) of an n x B batch buffer
 struct Layout {
   long sk, sb;  // SOA: sk = B, sb = 1;  AOS: sk = 1, sb = n

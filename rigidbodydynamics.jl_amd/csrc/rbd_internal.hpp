@@ -62,6 +62,11 @@ template <typename T>
 hipError_t launch_aba_track(const TrackModel& M, int flt, int gen, int nw, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
                             void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 template <typename T> hipError_t configure_track_kernel(int G, int flt, int gen, size_t lds_bytes);
+// rbd_contact_kernels.hip: soft contact
+template <typename T>
+hipError_t launch_contact(const ContactModel& M, long B, const void* body, void* s, void* sdot, const void* fext, void* contactwrenches, void* totalwrenches,
+                          Layout Ls, Layout Lf, hipStream_t st);
+template <typename T> hipError_t launch_contact_stage(long n, int stage, double dt, void* s, const void* sdot, void* s0, void* acc, hipStream_t st);
 // rbd_walk_kernels.hip: one wavefront per track, one lane per state
 template <typename T>
 hipError_t launch_aba_walk(const WalkModel& M, int flt, int gen, int pair, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,

@@ -17,6 +17,9 @@ def save_flat_model(model: FlatModel, path: str, meta=None):
     d.update(n_bodies=model.n_bodies, nq=model.nq, nv=model.nv, body_names=model.body_names, joint_names=model.joint_names,
              loops=[{k: (np.asarray(v).tolist() if isinstance(v, (np.ndarray, tuple)) else v) for k, v in l.items()} for l in model.loops],
              meta=meta or {})
+    if getattr(model, "contact_points", None) or getattr(model, "halfspaces", None):  # only mechanisms that have them (the URDF fixtures do not)
+        d["contact_points"] = [dict(c, location=np.asarray(c["location"]).tolist()) for c in model.contact_points]
+        d["halfspaces"] = [dict(point=np.asarray(h["point"]).tolist(), outward_normal=np.asarray(h["outward_normal"]).tolist()) for h in model.halfspaces]
     with open(path, "w") as f:
         json.dump(d, f, indent=0)
 
@@ -50,5 +53,8 @@ def load_flat_model(path: str) -> FlatModel:
     m.n_loops = len(m.loops)
     from .mechanism import _NV
     m.nc = sum(6 - _NV[l["joint_type"]] for l in m.loops)
+    m.contact_points = [dict(c, location=np.array(c["location"], dtype=np.float64)) for c in d.get("contact_points", [])]
+    m.halfspaces = [dict(point=np.array(h["point"], dtype=np.float64), outward_normal=np.array(h["outward_normal"], dtype=np.float64)) for h in d.get("halfspaces", [])]
+    m.ns = 3 * len(m.contact_points) * len(m.halfspaces)
     m._c = None
     return m

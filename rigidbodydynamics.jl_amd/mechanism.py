@@ -210,6 +210,7 @@ class RigidBody:
         self.default_frame = inertia.frame if inertia is not None else CartesianFrame3D(name)
         # frame definitions: transforms from body-fixed frames to the default frame (rigid_body.jl:24)
         self.frame_definitions: Dict[int, Transform3D] = {self.default_frame.id: Transform3D(self.default_frame, self.default_frame)}
+        self.contact_points: List["ContactPoint"] = []  # rigid_body.jl:25
 
     def __repr__(self):
         return f"RigidBody({self.name!r})"
@@ -236,6 +237,9 @@ class RigidBody:
         self.frame_definitions = {k: old_to_new * tf for k, tf in self.frame_definitions.items()}
         if self.inertia is not None:
             self.inertia = self.inertia.transform(old_to_new)
+        for point in self.contact_points:  # rigid_body.jl:161-163
+            point.location = old_to_new.R @ point.location + old_to_new.p
+            point.frame = new_default
         self.default_frame = new_default
 
 
@@ -250,6 +254,7 @@ class Mechanism:
         self.non_tree_joints: List[Joint] = []
         self._pred: Dict[int, RigidBody] = {}
         self._succ: Dict[int, RigidBody] = {}
+        self.environment: List["HalfSpace3D"] = []  # ContactEnvironment (mechanism.jl:13, contact.jl:231-238)
         self.modcount = 0
 
     # -- graph accessors
@@ -363,6 +368,67 @@ def remove_fixed_tree_joints_(mechanism: Mechanism) -> Mechanism:
 
 
 # ---- the flat model ---------------------------------------------------------------------------------
+# ---- soft contact (src/contact.jl) -------------------------------------------------------------------------------------------
+class HuntCrossleyModel:  # contact.jl:98-119
+    def __init__(self, k, lam, n):
+        self.k, self.lam, self.n = float(k), float(lam), float(n)
+
+
+def hunt_crossley_hertz(k=50e3, alpha=0.2) -> HuntCrossleyModel:  # contact.jl:104-107: λ = 3/2 α k  ((12) in Marhefka, Orin), n = 3/2
+    return HuntCrossleyModel(k, 1.5 * alpha * k, 1.5)
+
+
+class ViscoelasticCoulombModel:  # contact.jl:122-126
+    def __init__(self, mu, k, b):
+        self.mu, self.k, self.b = float(mu), float(k), float(b)
+
+
+class SoftContactModel:  # contact.jl:38-41
+    def __init__(self, normal: HuntCrossleyModel, friction: ViscoelasticCoulombModel):
+        self.normal, self.friction = normal, friction
+
+
+class ContactPoint:
+    """ContactPoint(location::Point3D, model) (contact.jl:72-77): `location` is a 3-vector in `frame` (default: the body's default frame
+    at the time it is added)."""
+
+    def __init__(self, location, model: SoftContactModel, frame: Optional[CartesianFrame3D] = None):
+        self.location = np.asarray(location, float).reshape(3).copy()
+        self.model = model
+        self.frame = frame
+
+
+class HalfSpace3D:
+    """HalfSpace3D(point, outward_normal) in the root frame; the normal is normalized (contact.jl:202-222)."""
+
+    def __init__(self, point, outward_normal):
+        self.point = np.asarray(point, float).reshape(3).copy()
+        n = np.asarray(outward_normal, float).reshape(3)
+        self.outward_normal = n / np.linalg.norm(n)
+
+
+def add_contact_point_(body: RigidBody, point: ContactPoint):  # add_contact_point!: rigid_body.jl:173-179
+    if point.frame is not None and point.frame is not body.default_frame:
+        tf = body.fixed_transform(point.frame, body.default_frame)
+        point.location = tf.R @ point.location + tf.p
+    point.frame = body.default_frame
+    body.contact_points.append(point)
+
+
+def add_environment_primitive_(mechanism: "Mechanism", halfspace: HalfSpace3D):  # mechanism_modification.jl:375
+    mechanism.environment.append(halfspace)
+
+
+class _ContactPointC(ctypes.Structure):
+    _fields_ = [("body", ctypes.c_int32), ("_pad", ctypes.c_int32), ("location", ctypes.c_double * 3),
+                ("hc_k", ctypes.c_double), ("hc_lambda", ctypes.c_double), ("hc_n", ctypes.c_double),
+                ("mu", ctypes.c_double), ("k", ctypes.c_double), ("b", ctypes.c_double)]
+
+
+class _HalfSpaceC(ctypes.Structure):
+    _fields_ = [("point", ctypes.c_double * 3), ("outward_normal", ctypes.c_double * 3)]
+
+
 class _LoopJointC(ctypes.Structure):
     _fields_ = [
         ("predecessor", ctypes.c_int32), ("successor", ctypes.c_int32), ("joint_type", ctypes.c_int32), ("_pad", ctypes.c_int32),
@@ -383,6 +449,8 @@ class _FlatModelC(ctypes.Structure):
         ("inertia_mass", ctypes.POINTER(ctypes.c_double)),
         ("gravity", ctypes.c_double * 3),
         ("loops", ctypes.POINTER(_LoopJointC)),
+        ("n_contact_points", ctypes.c_int32), ("n_halfspaces", ctypes.c_int32),
+        ("contact_points", ctypes.POINTER(_ContactPointC)), ("halfspaces", ctypes.POINTER(_HalfSpaceC)),
     ]
 
 
@@ -437,6 +505,17 @@ class FlatModel:
                 rotation_from_z_aligned=j.joint_type.rotation_from_z_aligned.copy(), gains=tuple(j.stabilization_gains)))
         self.n_loops = len(self.loops)
         self.nc = sum(6 - _NV[l["joint_type"]] for l in self.loops)
+        # soft contact: points in the order MechanismState lays out their states (for body in bodies(m), for point: mechanism_state.jl:143)
+        self.contact_points = []
+        for body in mechanism.bodies:
+            for pt in body.contact_points:
+                if body is mechanism.root_body:
+                    raise ValueError("contact points on the root body are not supported")
+                assert pt.frame is body.default_frame
+                self.contact_points.append(dict(body=body_index[id(body)], location=pt.location.copy(), hc_k=pt.model.normal.k, hc_lambda=pt.model.normal.lam,
+                                                hc_n=pt.model.normal.n, mu=pt.model.friction.mu, k=pt.model.friction.k, b=pt.model.friction.b))
+        self.halfspaces = [dict(point=h.point.copy(), outward_normal=h.outward_normal.copy()) for h in mechanism.environment]
+        self.ns = 3 * len(self.contact_points) * len(self.halfspaces)  # num_additional_states (mechanism.jl:143-149)
         self._c = None
 
     # levels (BFS depth) — used by docs/tests; the kernels only need parents-first order
@@ -480,6 +559,23 @@ class FlatModel:
                     arr[k].gains = (ctypes.c_double * 4)(*l["gains"])
                 self._loops_c = arr
                 c.loops = ctypes.cast(arr, ctypes.POINTER(_LoopJointC))
+            c.n_contact_points, c.n_halfspaces = len(self.contact_points), len(self.halfspaces)
+            if self.contact_points:
+                arr = (_ContactPointC * len(self.contact_points))()
+                for k, d in enumerate(self.contact_points):
+                    arr[k].body = d["body"]
+                    arr[k].location = (ctypes.c_double * 3)(*d["location"])
+                    arr[k].hc_k, arr[k].hc_lambda, arr[k].hc_n = d["hc_k"], d["hc_lambda"], d["hc_n"]
+                    arr[k].mu, arr[k].k, arr[k].b = d["mu"], d["k"], d["b"]
+                self._cp_c = arr
+                c.contact_points = ctypes.cast(arr, ctypes.POINTER(_ContactPointC))
+            if self.halfspaces:
+                arr = (_HalfSpaceC * len(self.halfspaces))()
+                for k, d in enumerate(self.halfspaces):
+                    arr[k].point = (ctypes.c_double * 3)(*d["point"])
+                    arr[k].outward_normal = (ctypes.c_double * 3)(*d["outward_normal"])
+                self._hs_c = arr
+                c.halfspaces = ctypes.cast(arr, ctypes.POINTER(_HalfSpaceC))
             self._c = c
         return self._c
 

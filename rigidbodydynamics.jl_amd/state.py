@@ -115,6 +115,7 @@ class MechanismState:
         self.ws = _Workspace(self.model, self.batch, dtype, self.device)
         self.q = self._zeros(self.flat.nq)
         self.v = self._zeros(self.flat.nv)
+        self.s = self._zeros(getattr(self.flat, "ns", 0))  # additional states: the soft-contact friction states (mechanism_state.jl:64, :139-152)
         zero_configuration_(self)
 
     def _zeros(self, n):
@@ -138,6 +139,9 @@ class MechanismState:
 
     def num_velocities(self):
         return self.flat.nv
+
+    def num_additional_states(self):
+        return getattr(self.flat, "ns", 0)
 
 
 def _from_host(state: MechanismState, a: np.ndarray) -> torch.Tensor:
@@ -200,6 +204,11 @@ class DynamicsResult:
         self.qd = z(f.nq)                        # q̇
         self.vd = z(f.nv)                        # v̇
         self.lambda_ = z(max(f.nc, 1))[:, :f.nc] if layout == "aos" else z(max(f.nc, 1))[:f.nc]  # λ
+        ns = getattr(f, "ns", 0)
+        self.sd = z(ns)                                               # ṡ (dynamics_result.jl:20)
+        self.contactwrenches = z(6 * f.n_bodies) if ns > 0 else None  # (dynamics_result.jl:25), root frame
+        if ns > 0 and self.totalwrenches is None:
+            self.totalwrenches = z(6 * f.n_bodies)
         self.constraintjacobian = z(f.nc * f.nv)
         self.constraintbias = z(f.nc)
 
@@ -246,6 +255,16 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
             "aba_chains": _capi.ALGO_ABA_CHAINS, "aba_banks": _capi.ALGO_ABA_BANKS, "aba_tracks": _capi.ALGO_ABA_TRACKS, "aba_walk": _capi.ALGO_ABA_WALK}[algorithm]
     opts = state._opts(algo, 0 if stabilization_gains is None else 1)
     lam = result.lambda_ if f.nc > 0 else None
+    if getattr(f, "ns", 0) > 0:
+        # a mechanism with contact points: contact_dynamics! first, totalwrenches = externalwrenches + contactwrenches (:849-856); state.s is
+        # reset where a point is not in contact, result.sd / contactwrenches / totalwrenches are filled
+        state._check(state.s, f.ns, "s")
+        state._check(result.sd, f.ns, "ṡ")
+        st = _capi.lib().rbd_dynamics_contact(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(state.s), _ptr(torques), _ptr(externalwrenches),
+                                              _ptr(result.vd), _ptr(result.qd), _ptr(result.sd), _ptr(result.contactwrenches), _ptr(result.totalwrenches),
+                                              ctypes.byref(opts))
+        _raise(st, "rbd_dynamics_contact")
+        return None
     st = _capi.lib().rbd_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
                                   _ptr(result.vd), _ptr(result.qd), _ptr(lam), ctypes.byref(opts))
     _raise(st, "rbd_dynamics")
@@ -381,6 +400,16 @@ def simulate_(state: MechanismState, final_time: float, control_=None, dt: float
         t += dt
         ts.append(t)
         nsteps += 1
+    if getattr(f, "ns", 0) > 0:  # soft contact: the additional state is integrated beside (q, v)
+        if control_ is not None:
+            raise NotImplementedError("control callbacks with contact points: use dynamics_ per stage")
+        ss = [state.s.clone()] if store else None
+        for _ in range(nsteps if store else 1):
+            _raise(L.rbd_simulate_contact(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(state.s), _ptr(torques), _ptr(externalwrenches),
+                                          ctypes.c_double(dt), 1 if store else nsteps, ctypes.byref(opts)), "rbd_simulate_contact")
+            if store:
+                qs.append(state.q.clone()); vs.append(state.v.clone()); ss.append(state.s.clone())
+        return (np.array(ts), qs, vs, ss) if store else np.array(ts)
     if control_ is None and not store:
         _raise(L.rbd_simulate(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
                               ctypes.c_double(dt), nsteps, ctypes.byref(opts)), "rbd_simulate")
