@@ -807,7 +807,14 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   if (mapping == RBD_ALGO_ABA_BANKS && m->bank_lps == 0) return RBD_ERR_UNSUPPORTED;
   // the per-body outputs (accelerations, joint wrenches) are written by the one-body-per-lane kernel
   const bool banks = !dacc && !djw && m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
-  if (!dacc && !djw && mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->state_min_batch) {  // one lane per state
+  const bool can_walk = m->track.ok && m->walk.ok && !dacc && !djw && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch));
+  if (mapping == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
+  if (can_walk && (mapping == RBD_ALGO_ABA_WALK || (mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->walk_min_batch))) {
+    // one wavefront per track, one lane per state (rnea_walk_kernel): large batches
+    const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
+    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_walk<double>(w->wm, m->track.has_floating, m->track.general, 0, B, w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_rnea_walk<float>(w->wm, m->track.has_floating, m->track.general, pair, B, pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
+  } else if (!dacc && !djw && mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->state_min_batch) {  // one lane per state
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_state<double>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_rnea_state<float>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
   } else if (banks) {
@@ -1158,7 +1165,10 @@ int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, cons
   if ((st = mk_ensure(w, B))) return st;
   Opts od = o; od.memory = RBD_MEM_DEVICE;
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B);
-  const bool fused = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA);
+  // large batches: the walk kernel (one wavefront per track, §3.4 of DESIGN.md) with the stage bookkeeping in its own launches beats the
+  // lane-per-body kernels with the stage fused in (fp64 Atlas, 65 536 states: 4 x 147 us + 5 stage launches vs 4 x 290 us)
+  const bool walk_sim = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && m->track.ok && m->walk.ok && w->walk_lds_bytes > 0 && B >= w->walk_min_batch;
+  const bool fused = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && !walk_sim;
   const Layout Lf = layout_of(o.layout, 6L * m->nb, B);
   for (int step = 0; fused && step < nsteps; ++step) {
     // tree mechanism, articulated-body route: each of the four stages is ONE launch (stage bookkeeping fused into aba_kernel)

@@ -254,11 +254,15 @@ template <typename T> RBD_HD void walk_parent_kin(const WalkCtx<T>& c, const Wal
 }
 
 // ---------------- pass A (root -> leaves): the kinematic chain ----------------
-template <typename T, bool FLT, bool GEN>
+// RNEA = true (rnea_walk_kernel): the τ rows hold v̇ on the way in, and the acceleration carried down is the full spatial acceleration
+// a_b = a_parent + [T_parent, S q̇] + S v̇ (spatial_accelerations!, mechanism_algorithms.jl:387-417) instead of its velocity-product part
+template <typename T, bool FLT, bool GEN, bool RNEA = false>
 RBD_HD void walk_step_a(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, bool want_qdot) {
   if (!(r.flags & TF_VALID)) return;
   walk_parent_kin(c, r, lane, W);
-  T Rn[9], pn[3], vJ[6], cb[6];
+  T Rn[9], pn[3], vJ[6], cb[6], aJ[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) aJ[k] = T(0);
   bool done = false;
   if (FLT) {
     if (r.flags & TF_FLOATING) {
@@ -269,6 +273,12 @@ RBD_HD void walk_step_a(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
       for (int k = 0; k < 6; ++k) v6[k] = *walk_row(c, c.rv + r.voff + k, lane);
       walk_compose_floating(W.R, W.p, rr, q7, Rn, pn);
       xmotion(Rn, pn, v6, vJ);  // twist of the joint: X(H) v, v the body-frame twist
+      if (RNEA) {
+        T a6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a6[k] = *walk_row(c, c.rt + r.voff + k, lane);
+        xmotion(Rn, pn, a6, aJ);
+      }
       if (want_qdot) {  // velocity_to_configuration_derivative! (quaternion_floating.jl:126-136, spatial/util.jl:127-134), over the q rows
         const T qw = q7[0], qx = q7[1], qy = q7[2], qz = q7[3];
         T o[7], Rq[9];
@@ -301,12 +311,17 @@ RBD_HD void walk_step_a(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
     walk_subspace<T, GEN>(Rn, pn, r.flags, S);
 #pragma unroll
     for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
+    if (RNEA) {
+      const T vd = (GEN && (r.flags & TF_FIXED)) ? T(0) : *walk_row(c, c.rt + r.voff, lane);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) aJ[k] = S[k] * vd;
+    }
     if (GEN && (r.flags & TF_PRISMATIC)) sn = q0;
     RBD_WALK_SWITCH(s, { St.template put<SV, WS_SN>(sn); St.template put<SV, WS_CS>(cs); })
   }
   se3_comm(W.Tw, vJ, cb);  // [T_parent, vJ] = [T_b, vJ]: bias acceleration increment (mechanism_state.jl:814-830)
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { W.av[k] += cb[k]; W.Tw[k] += vJ[k]; }
+  for (int k = 0; k < 6; ++k) { W.av[k] += cb[k] + aJ[k]; W.Tw[k] += vJ[k]; }
 #pragma unroll
   for (int k = 0; k < 9; ++k) W.R[k] = Rn[k];
 #pragma unroll
@@ -433,6 +448,87 @@ RBD_HD void walk_step_b(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) W.R[3 * i + j] = Mx[3 * i] * C[3 * j] + Mx[3 * i + 1] * C[3 * j + 1] + Mx[3 * i + 2] * C[3 * j + 2];  // Mx C'
+    matvec3(W.R, rr + TR_PP, u3);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) W.p[k] -= u3[k];
+  }
+}
+
+// ---------------- inverse dynamics, pass B (leaves -> root): net wrenches and joint torques (rnea_walk_kernel) ----------------
+// f_b = I a + T ×* I T − w_ext (newton_euler!, mechanism_algorithms.jl:428-439) + Σ_children f; τ = S' f (joint_wrenches_and_torques! :442-459).
+// The hand-off is the 6-value wrench (W.cP; mailboxes use the first 6 rows of a B slot); the τ rows hold v̇ until this body overwrites its own.
+template <typename T, bool FLT, bool GEN>
+RBD_HD void walk_step_rb(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, const T* fe) {
+  if (!(r.flags & TF_VALID)) return;
+  if (r.park >= 0) walk_get_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);
+  T f[6];
+  {
+    RInertia<T> I;
+    inertia_to_root(rr + TR_J, rr + TR_MC, rr[TR_M], W.R, W.p, I);
+    T h[6];
+    mul_inertia(I, W.av, f);
+    momentum_cross(I, W.Tw, h);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f[k] += h[k] - fe[k] + W.cP[k];
+  }
+  for (int j = 0; j < r.nbr; ++j) {
+    const T* m = walk_row(c, c.rB + (r.b_r0 + j) * WMB_B, lane);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f[k] += m[k * WR_STRIDE];
+  }
+  T S[6], qd = T(0), vd = T(0);
+  if (FLT && (r.flags & TF_FLOATING)) {  // τ = S' f with S = X(H): the wrench seen from the body frame
+    T o6[6];
+    xforce_inv(W.R, W.p, f, o6);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) *walk_row(c, c.rt + r.voff + k, lane) = o6[k];
+  } else {
+    walk_subspace<T, GEN>(W.R, W.p, r.flags, S);
+    if (!(GEN && (r.flags & TF_FIXED))) {
+      qd = *walk_row(c, c.rv + r.voff, lane);
+      vd = *walk_row(c, c.rt + r.voff, lane);
+      *walk_row(c, c.rt + r.voff, lane) = dot6(S, f);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) W.cP[k] = f[k];
+  if (r.b_w >= 0 || (r.flags & TF_LEVEL0)) {
+    if (r.b_w >= 0) {
+      T* m = walk_row(c, c.rB + r.b_w * WMB_B, lane);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) m[k * WR_STRIDE] = f[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) W.cP[k] = T(0);
+  }
+  if (r.flags & TF_CHAINED) {  // un-compose the joint (see walk_step_b); the acceleration also gives back S v̇
+    T vJ[6], cb[6], sn = T(0), cs = T(1);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
+    se3_comm(W.Tw, vJ, cb);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { W.av[k] -= cb[k] + S[k] * vd; W.Tw[k] -= vJ[k]; }
+    RBD_WALK_SWITCH(s, { sn = St.template get<SV, WS_SN>(); cs = St.template get<SV, WS_CS>(); })
+    if (GEN) {
+      if (r.flags & TF_PRISMATIC) {
+        const T d = sn;
+        sn = T(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) W.p[k] -= W.R[3 * k + 2] * d;
+      }
+    }
+    T Mx[9], u3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Mx[3 * i] = cs * W.R[3 * i] - sn * W.R[3 * i + 1];
+      Mx[3 * i + 1] = sn * W.R[3 * i] + cs * W.R[3 * i + 1];
+      Mx[3 * i + 2] = W.R[3 * i + 2];
+    }
+    const T* C = rr + TR_C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) W.R[3 * i + j] = Mx[3 * i] * C[3 * j] + Mx[3 * i + 1] * C[3 * j + 1] + Mx[3 * i + 2] * C[3 * j + 2];
     matvec3(W.R, rr + TR_PP, u3);
 #pragma unroll
     for (int k = 0; k < 3; ++k) W.p[k] -= u3[k];
@@ -791,6 +887,131 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     walk_stage_out_fast<T, 10 * N>(qdot, state0, M.nq, c.rows, c.rq, tid, nth);
   } else {
     walk_stage_out<T, 10>(vdot, Lv, state0, B, M.nv, c.rows, c.rt, tid, nth);
+    walk_stage_out<T, 10>(qdot, Lq, state0, B, M.nq, c.rows, c.rq, tid, nth);
+  }
+  RBD_WMARK(5);
+}
+// inverse_dynamics! (vdot given) / dynamics_bias! (vdot == nullptr) through the same schedule: pass A with the full accelerations, then the
+// wrench pass (walk_step_rb).  src/mechanism_algorithms.jl:542-553, :484-498.
+template <typename T, bool FLT, bool GEN>
+__global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v,
+                                                      const typename Lanes<T>::S* __restrict__ vdot, const typename Lanes<T>::S* __restrict__ fext,
+                                                      typename Lanes<T>::S* __restrict__ tau, typename Lanes<T>::S* __restrict__ qdot, Layout Lq, Layout Lv,
+                                                      Layout Lf) {
+  using S = typename Lanes<T>::S;
+  constexpr int N = Lanes<T>::N;
+  extern __shared__ __align__(16) unsigned char walk_lds_raw[];
+  WalkCtx<T> c;
+  c.M = M;
+  walk_ctx_lds(c, walk_lds_raw);
+  const int lane = threadIdx.x & 63, tid = threadIdx.x, nth = blockDim.x;
+  const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long state0 = (long)blockIdx.x * (64 * N);
+  RBD_WMARK(0);
+  {  // the plan records -> LDS; q, v, τ of this workgroup's states -> rows.  Loads first, all of them; then the LDS writes.
+    constexpr int UB = 10 * N, TB = 6;
+    const int nrec = M.ns * M.G, ntr = nrec * TR_STRIDE;  // nrec <= 13 G <= nth
+    const I4* gi = reinterpret_cast<const I4*>(M.ri);
+    const S* gr = reinterpret_cast<const S*>(M.rr);
+    I4 ti = gi[tid < nrec ? tid : 0];
+    const int32_t tw = M.wk[tid < nrec ? tid : 0];
+    S tr[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) tr[u] = gr[tid + u * nth < ntr ? tid + u * nth : 0];
+    const bool fast = Lq.sk == 1 && Lv.sk == 1 && state0 + 64 * N <= B;  // wave-uniform
+    WalkStageIn<T, UB> in;
+    if (!fast) in.load(q, v, vdot, Lq, Lv, state0, B, M.nq, M.nv, 0, tid, nth);
+    if (tid < nrec) { const_cast<I4*>(c.tri)[tid] = ti; const_cast<int32_t*>(c.twk)[tid] = tw; }
+#pragma unroll
+    for (int u = 0; u < TB; ++u)
+      if (tid + u * nth < ntr) const_cast<S*>(c.trr)[tid + u * nth] = tr[u];
+    for (int i = tid + TB * nth; i < ntr; i += nth) const_cast<S*>(c.trr)[i] = gr[i];
+    if (fast) {
+      walk_stage_in_fast<T, UB>(q, v, vdot, state0, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
+    } else {
+      in.store(c.rows, c.rq, c.rv, c.rt);
+      const int nmax = (M.nq > M.nv ? M.nq : M.nv) * 64 * N;
+      for (int e0 = UB * nth; e0 < nmax; e0 += UB * nth) {
+        in.load(q, v, vdot, Lq, Lv, state0, B, M.nq, M.nv, e0, tid, nth);
+        in.store(c.rows, c.rq, c.rv, c.rt);
+      }
+    }
+  }
+  __syncthreads();
+  RBD_WMARK(1);
+  asm volatile("" ::: "a255");  // the kernel descriptor covers every accumulation register (WalkStash addresses them by number)
+  WalkRegs<T> W;
+  WalkStash<T> St;
+  walk_init(W);
+  const int ns = M.ns;
+  const bool want_qdot = qdot != nullptr;
+  // external wrenches: requested from global memory a step ahead (one load per state of the lane)
+  const long fsk = Lf.sk;
+  const S* fel[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const long st = state0 + 64 * j + lane;
+    fel[j] = fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr;
+  }
+  auto wrench = [&](int o6, T* f) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      S x[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] = fel[j][(long)(o6 + k) * fsk];
+      if constexpr (N == 1) f[k] = x[0];
+      else { f[k].x = x[0]; f[k].y = x[1]; }
+    }
+  };
+  // every pass reads the record (and passes A and C the constants) of its next step while the current one computes
+  {
+    WalkRaw raw = walk_raw(c, 0, g);
+    T rr[TR_J];
+    walk_consts<T, TR_J>(c, 0, g, rr);
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) {
+      const int s1 = s + 1 < ns ? s + 1 : s;
+      const WalkRec r = walk_rec(raw);
+      raw = walk_raw(c, s1, g);
+      T rn[TR_J];
+      walk_consts<T, TR_J>(c, s1, g, rn);
+      walk_step_a<T, FLT, GEN, true>(c, W, St, s, r, rr, lane, want_qdot);
+#pragma unroll
+      for (int k = 0; k < TR_J; ++k) rr[k] = rn[k];
+      if ((M.sfm[1] >> s) & 1) __syncthreads();  // SF_AW: an A mailbox was written at this step
+    }
+  }
+  RBD_WMARK(2);
+  {
+    // pass B: the external wrench of the body of step s − 1 is requested while step s computes
+#pragma unroll
+    for (int k = 0; k < 6; ++k) W.cP[k] = T(0);
+    T fe[6], fn[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { fe[k] = T(0); fn[k] = T(0); }
+    WalkRaw raw = walk_raw(c, ns - 1, g);
+    if (fext) wrench(walk_uniform(raw.w.y) & 0xffff, fe);
+#pragma unroll 1
+    for (int s = ns - 1; s >= 0; --s) {
+      const int s1 = s > 0 ? s - 1 : 0;
+      const WalkRec r = walk_rec(raw);
+      T rr[TR_STRIDE];
+      walk_consts<T, TR_STRIDE>(c, s, g, rr);
+      raw = walk_raw(c, s1, g);
+      if (fext) wrench(walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff, fn);
+      walk_step_rb<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fe[k] = fn[k];
+      if ((M.sfm[3] >> s) & 1) __syncthreads();  // SF_BW: a hand-off left its track at this step
+    }
+  }
+  __syncthreads();
+  RBD_WMARK(4);
+  if (Lq.sk == 1 && Lv.sk == 1 && state0 + 64 * N <= B) {
+    walk_stage_out_fast<T, 10 * N>(tau, state0, M.nv, c.rows, c.rt, tid, nth);
+    walk_stage_out_fast<T, 10 * N>(qdot, state0, M.nq, c.rows, c.rq, tid, nth);
+  } else {
+    walk_stage_out<T, 10>(tau, Lv, state0, B, M.nv, c.rows, c.rt, tid, nth);
     walk_stage_out<T, 10>(qdot, Lq, state0, B, M.nq, c.rows, c.rq, tid, nth);
   }
   RBD_WMARK(5);

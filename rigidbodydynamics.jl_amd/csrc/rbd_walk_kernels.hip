@@ -6,38 +6,53 @@
 namespace rbd {
 
 // T: the kernel's value type — double, float, or f2 = two fp32 states per lane (S = float buffers, 128 states per workgroup)
-template <typename T, bool FLT, bool GEN>
-static hipError_t launch_walk_fg(const WalkModel& M, long B, size_t lds, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
+// T: the kernel's value type — double, float, or f2 = two fp32 states per lane (S = float buffers, 128 states per workgroup).
+// RNEA: rnea_walk_kernel (x = v̇ in, y = τ out) instead of aba_walk_kernel (x = τ in, y = v̇ out)
+template <typename T, bool FLT, bool GEN, bool RNEA>
+static hipError_t launch_walk_fg(const WalkModel& M, long B, size_t lds, const void* q, const void* v, const void* x, const void* fext, void* y, void* qdot,
                                  Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
   using S = typename Lanes<T>::S;
   constexpr int SPW = 64 * Lanes<T>::N;
   const unsigned grid = (unsigned)((B + SPW - 1) / SPW);
-  aba_walk_kernel<T, FLT, GEN><<<grid, 64 * M.G, lds, s>>>(M, B, (const S*)q, (const S*)v, (const S*)tau, (const S*)fext, (S*)vdot, (S*)qdot, Lq, Lv, Lf);
+  if (RNEA) rnea_walk_kernel<T, FLT, GEN><<<grid, 64 * M.G, lds, s>>>(M, B, (const S*)q, (const S*)v, (const S*)x, (const S*)fext, (S*)y, (S*)qdot, Lq, Lv, Lf);
+  else aba_walk_kernel<T, FLT, GEN><<<grid, 64 * M.G, lds, s>>>(M, B, (const S*)q, (const S*)v, (const S*)x, (const S*)fext, (S*)y, (S*)qdot, Lq, Lv, Lf);
   return hipGetLastError();
 }
-template <typename T>
-static hipError_t launch_walk_t(const WalkModel& M, int flt, int gen, long B, size_t lds, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
+template <typename T, bool RNEA>
+static hipError_t launch_walk_t(const WalkModel& M, int flt, int gen, long B, size_t lds, const void* q, const void* v, const void* x, const void* fext, void* y,
                                 void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
-  if (flt) return gen ? launch_walk_fg<T, true, true>(M, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s)
-                      : launch_walk_fg<T, true, false>(M, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
-  return gen ? launch_walk_fg<T, false, true>(M, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s)
-             : launch_walk_fg<T, false, false>(M, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+  if (flt) return gen ? launch_walk_fg<T, true, true, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s)
+                      : launch_walk_fg<T, true, false, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s);
+  return gen ? launch_walk_fg<T, false, true, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s)
+             : launch_walk_fg<T, false, false, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s);
 }
 // pair: (fp32 only) two states per lane
 template <typename T>
 hipError_t launch_aba_walk(const WalkModel& M, int flt, int gen, int pair, long B, size_t lds, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
                            void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
   if constexpr (sizeof(T) == 4) {
-    if (pair) return launch_walk_t<f2>(M, flt, gen, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+    if (pair) return launch_walk_t<f2, false>(M, flt, gen, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
   }
-  return launch_walk_t<T>(M, flt, gen, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+  return launch_walk_t<T, false>(M, flt, gen, B, lds, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
+}
+template <typename T>
+hipError_t launch_rnea_walk(const WalkModel& M, int flt, int gen, int pair, long B, size_t lds, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
+                            void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+  if constexpr (sizeof(T) == 4) {
+    if (pair) return launch_walk_t<f2, true>(M, flt, gen, B, lds, q, v, vdot, fext, tau, qdot, Lq, Lv, Lf, s);
+  }
+  return launch_walk_t<T, true>(M, flt, gen, B, lds, q, v, vdot, fext, tau, qdot, Lq, Lv, Lf, s);
 }
 template hipError_t launch_aba_walk<double>(const WalkModel&, int, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_aba_walk<float>(const WalkModel&, int, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea_walk<double>(const WalkModel&, int, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea_walk<float>(const WalkModel&, int, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
 
 // dynamic LDS above the 64 KB default needs the per-function limit raised (per device; done at workspace creation)
 template <typename T, bool FLT, bool GEN> static hipError_t set_walk_lds(size_t lds) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_walk_kernel<T, FLT, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_walk_kernel<T, FLT, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&rnea_walk_kernel<T, FLT, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 template <typename T> static hipError_t configure_walk_t(int flt, int gen, size_t lds) {
   if (flt) return gen ? set_walk_lds<T, true, true>(lds) : set_walk_lds<T, true, false>(lds);

@@ -287,7 +287,7 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
     return None
 
 
-_MAPPING = {"auto": _capi.ALGO_ABA, "lanes": _capi.ALGO_ABA_LANES, "banks": _capi.ALGO_ABA_BANKS}
+_MAPPING = {"auto": _capi.ALGO_ABA, "lanes": _capi.ALGO_ABA_LANES, "banks": _capi.ALGO_ABA_BANKS, "walk": _capi.ALGO_ABA_WALK}
 
 
 def inverse_dynamics_(torquesout: torch.Tensor, state: MechanismState, vd: torch.Tensor,
@@ -296,7 +296,7 @@ def inverse_dynamics_(torquesout: torch.Tensor, state: MechanismState, vd: torch
     """`inverse_dynamics!(torquesout, jointwrenchesout, accelerations, state, v̇, externalwrenches)` (:542-553).  `jointwrenchesout` /
     `accelerations` (optional, (B, 6*n_bodies), root frame): the per-body outputs the reference fills — the wrench across the joint above each
     body and each body's spatial acceleration (root acceleration −gravity included, as `spatial_accelerations!` leaves it).
-    mapping: lane mapping of the kernel ("auto": by batch size; "lanes" / "banks" force one — tests, benchmarks)."""
+    mapping: lane mapping of the kernel ("auto": by batch size; "lanes" / "banks" / "walk" force one — tests, benchmarks)."""
     f = state.flat
     state._check(torquesout, f.nv, "torquesout")
     state._check(vd, f.nv, "v̇")

@@ -8,7 +8,7 @@ import re, sys
 src, max_steps = sys.argv[1], int(sys.argv[2])
 name, worst = None, {}
 for line in open(src):
-    m = re.match(r"^(_Z\S*aba_walk_kernel\S*):", line)
+    m = re.match(r"^(_Z\S*(?:aba|rnea)_walk_kernel\S*):", line)
     if m:
         name = m.group(1); worst[name] = [-1, 256]
         continue
@@ -21,7 +21,7 @@ for line in open(src):
         worst[name][1] = min(worst[name][1], int(tok, 0))
 bad = 0
 for k, (alloc_hi, stash_lo) in worst.items():
-    words = 2 if ("kernelId" in k or "kernelIDv2_f" in k) else 1
+    words = 2 if ("kernelId" in k or "kernelIDv2_f" in k) else 1  # fp64 and the packed pair take two registers per value
     floor = 256 - max_steps * 9 * words
     ok = alloc_hi < floor and stash_lo >= floor
     print(f"{'ok ' if ok else 'BAD'} {k[:44]}: allocator uses a0..a{alloc_hi}, stash lowest a{stash_lo}, reserved from a{floor}")

@@ -13,7 +13,7 @@
 using namespace rbd;
 
 template <typename T> static void set_lane(T& x, int j, typename Lanes<T>::S v) { if constexpr (Lanes<T>::N == 1) x = v; else x[j] = v; }
-template <typename T, bool FLT, bool GEN>
+template <typename T, bool FLT, bool GEN, bool RNEA>
 static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes<T>::S* q, const typename Lanes<T>::S* v, const typename Lanes<T>::S* tau,
                    const typename Lanes<T>::S* fext, typename Lanes<T>::S* vdot, typename Lanes<T>::S* qdot, Layout Lq, Layout Lv, Layout Lf) {
   using S = typename Lanes<T>::S;
@@ -51,7 +51,7 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
       while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
       each_wave([&](int g) {
         for (int s = s0; s <= s1; ++s)
-          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_a<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, qdot != nullptr); }
+          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_a<T, FLT, GEN, RNEA>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, qdot != nullptr); }
       });
       s0 = s1 + 1;
     }
@@ -71,13 +71,15 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
               for (int k = 0; k < 6; ++k)
                 for (int j = 0; j < N; ++j) set_lane(fe[k], j, fext[(o6 + k) * Lf.sk + state_of(l + 64 * j) * Lf.sb]);
             }
-            T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_b<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
+            T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr);
+            if (RNEA) walk_step_rb<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
+            else walk_step_b<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
           }
       });
       s0 = s1 - 1;
     }
     for (auto& w : W) walk_init_c(w);
-    for (int s0 = 0; s0 < ns;) {
+    for (int s0 = 0; !RNEA && s0 < ns;) {
       int s1 = s0;
       while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
       each_wave([&](int g) {
@@ -103,7 +105,7 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
 }
 
 template <typename T>  // T: double, float, or f2 (two fp32 states per lane)
-static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const double* gravity, int reverse, int aos, long B, int nq, int nv, int nb, const void* q,
+static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const double* gravity, int rnea, int reverse, int aos, long B, int nq, int nv, int nb, const void* q,
                  const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info) {
   WalkModel M;
   M.G = dims[0]; M.ns = dims[1]; M.nA = dims[2]; M.nB = dims[3]; M.nq = nq; M.nv = nv;
@@ -122,15 +124,16 @@ static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const
   auto lay = [&](long n) { Layout L; if (aos) { L.sk = 1; L.sb = n; } else { L.sk = B; L.sb = 1; } return L; };
   const Layout Lq = lay(nq), Lv = lay(nv), Lf = lay(6L * nb);
   const int flt = dims[4], gen = dims[5];
-#define RUN(F, GN) emu_run<T, F, GN>(M, reverse, B, (const S*)q, (const S*)v, (const S*)tau, (const S*)fext, (S*)vdot, (S*)qdot, Lq, Lv, Lf)
+#define RUN(F, GN) (rnea ? emu_run<T, F, GN, true>(M, reverse, B, (const S*)q, (const S*)v, (const S*)tau, (const S*)fext, (S*)vdot, (S*)qdot, Lq, Lv, Lf) : emu_run<T, F, GN, false>(M, reverse, B, (const S*)q, (const S*)v, (const S*)tau, (const S*)fext, (S*)vdot, (S*)qdot, Lq, Lv, Lf))
   if (flt) return gen ? RUN(true, true) : RUN(true, false);
   return gen ? RUN(false, true) : RUN(false, false);
 #undef RUN
 }
 
+// rnea = 0: dynamics! (x = τ in, y = v̇ out);  rnea = 1: inverse_dynamics! / dynamics_bias! (x = v̇ in or NULL, y = τ out)
 extern "C" int walk_emu_dynamics(const int32_t* dims, const int32_t* ri, const double* rr, const double* gravity, int f32, int reverse, int aos, long B, int nq,
-                                 int nv, int nb, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info) {
-  if (f32 == 2) return emu_t<f2>(dims, ri, rr, gravity, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info);  // two fp32 states per lane
-  return f32 ? emu_t<float>(dims, ri, rr, gravity, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info)
-             : emu_t<double>(dims, ri, rr, gravity, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info);
+                                 int nv, int nb, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info, int rnea) {
+  if (f32 == 2) return emu_t<f2>(dims, ri, rr, gravity, rnea, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info);  // two fp32 states per lane
+  return f32 ? emu_t<float>(dims, ri, rr, gravity, rnea, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info)
+             : emu_t<double>(dims, ri, rr, gravity, rnea, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info);
 }

@@ -1094,3 +1094,49 @@ def test_dynamics_walk_full_size(rbd, oracle, models, dtype, B):
         res = np.einsum("bij,bj->bi", Ms, got) - (tau - c)
         eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(got, axis=1) + np.linalg.norm(tau - c, axis=1))
         assert eta.max() <= 2e-5, eta.max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", CHAIN_MODELS)
+def test_inverse_dynamics_walk_f64(rbd, oracle, models, name, layout):
+    """rnea_walk_kernel (one wavefront per track, one lane per state) forced at a small ragged batch: inverse_dynamics! with v̇ and wrenches,
+    dynamics_bias!, q̇ untouched paths; and its packed fp32 form."""
+    model = models[name]
+    B = 70
+    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 91)
+    vd = np.random.default_rng(6).standard_normal((B, model.nv))
+    out = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state), mapping="walk")
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+    assert np.abs(host(out, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    rbd.dynamics_bias_(out, state, mapping="walk")
+    ref = oracle.dynamics_bias(model, q, v, None)
+    assert np.abs(host(out, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_inverse_dynamics_walk_full_size_and_pairs(rbd, oracle, models, monkeypatch):
+    """At the sizes where RBD_ALGO_ABA picks it by itself: fp64 16 384 states against the oracle on the whole batch; fp32 65 536 states
+    (two states per lane) against the fp64 oracle at fp32 accuracy; the dynamics! → inverse_dynamics! round trip closes (test_mechanism_algorithms.jl:729-740)."""
+    model = models["atlas_floating"]
+    B = 16384
+    state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 92)
+    result = rbd.DynamicsResult(model, B)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state))
+    assert "aba_walk_kernel" in rbd.last_kernel(state)
+    back = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(back, state, result.vd, dev(fe, state))
+    assert float((back - dev(tau, state)).abs().max()) <= 1e-9 * max(1.0, float(np.abs(tau).max()))
+    vdh = host(result.vd, state)
+    ref = oracle.inverse_dynamics(model, q, v, vdh, fe, nthreads=NT)
+    # τ = M v̇ + c with |v̇| up to ~1e3 here: the rounding of the sum scales with its largest term, not with |τ| ≤ 1
+    assert np.abs(host(back, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max(), np.abs(vdh).max())
+    B = 65536
+    state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 93)
+    vd = np.random.default_rng(7).standard_normal((B, model.nv))
+    out = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state))
+    cast = lambda a: a.astype(np.float32).astype(np.float64)
+    ref = oracle.inverse_dynamics(model, cast(q), cast(v), cast(vd), cast(fe), nthreads=NT)
+    assert np.abs(host(out, state) - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())

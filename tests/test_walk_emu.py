@@ -29,7 +29,7 @@ def emu():
     return L
 
 
-def run_emu(emu, rbd, model, q, v, tau, fe, dtype=np.float64, aos=True, want_qdot=True, reverse=0, pair=False):
+def run_emu(emu, rbd, model, q, v, tau, fe, dtype=np.float64, aos=True, want_qdot=True, reverse=0, pair=False, rnea=False):
     plan = rbd.track_plan(model)
     assert plan is not None
     B = q.shape[0]
@@ -41,7 +41,7 @@ def run_emu(emu, rbd, model, q, v, tau, fe, dtype=np.float64, aos=True, want_qdo
     info = np.zeros(2, np.int32)
     p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
     st = emu.walk_emu_dynamics(p(plan["dims"]), p(plan["ri"]), p(plan["rr"]), p(g), (2 if pair else 1) if dtype == np.float32 else 0, int(reverse), int(aos), ctypes.c_long(B),
-                               model.nq, model.nv, model.n_bodies, p(q_), p(v_), p(t_), p(f_), p(vd), p(qd) if want_qdot else None, p(info))
+                               model.nq, model.nv, model.n_bodies, p(q_), p(v_), p(t_), p(f_), p(vd), p(qd) if want_qdot else None, p(info), int(rnea))
     assert st == 0
     return (vd if aos else vd.T).astype(np.float64), (qd if aos else qd.T).astype(np.float64), info
 
@@ -115,3 +115,44 @@ def test_walk_emulation_random_trees(emu, rbd, oracle):
         assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), (trial, plan["tracks"], plan["steps"])
         assert np.abs(qd - qd_ref).max() <= 1e-12 * max(1.0, np.abs(qd_ref).max()), trial
     assert done >= 25
+
+
+@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum"])
+def test_walk_emulation_inverse_dynamics(emu, rbd, oracle, models, name, reverse):
+    """rnea_walk_kernel's step code: inverse_dynamics! with v̇ and external wrenches, and dynamics_bias! (no v̇), against the oracle."""
+    model = models[name]
+    B = 70
+    q, v, tau, fe = rand_inputs(rbd, model, B, 81, fext=True)
+    vd = np.random.default_rng(4).standard_normal((B, model.nv))
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+    got, qd, _ = run_emu(emu, rbd, model, q, v, vd, fe, reverse=reverse, rnea=True)
+    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    _, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    assert np.abs(qd - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
+    ref = oracle.dynamics_bias(model, q, v, None)
+    got, _, _ = run_emu(emu, rbd, model, q, v, None, None, reverse=reverse, rnea=True, want_qdot=False)
+    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+def test_walk_emulation_inverse_dynamics_random_trees_and_pairs(emu, rbd, oracle):
+    from test_chain_plan import random_tree
+    rng = np.random.default_rng(29)
+    done = 0
+    for trial in range(30):
+        mech = random_tree(rbd, rng, int(rng.integers(1, 30)), bool(trial % 2), float(rng.uniform(0, 1)))
+        model = rbd.flatten(mech)
+        plan = rbd.track_plan(model)
+        if plan is None or plan["steps"] > 12 or model.nv == 0:
+            continue
+        done += 1
+        B = 5
+        q, v, tau, fe = rand_inputs(rbd, model, B, 300 + trial, fext=True)
+        vd = rng.standard_normal((B, model.nv))
+        ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+        got, _, _ = run_emu(emu, rbd, model, q, v, vd, fe, reverse=trial % 2, rnea=True)
+        assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), trial
+        if trial % 3 == 0:  # the packed fp32 form
+            got32, _, _ = run_emu(emu, rbd, model, q, v, vd, fe, dtype=np.float32, pair=True, rnea=True)
+            assert np.abs(got32 - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), trial
+    assert done >= 20
