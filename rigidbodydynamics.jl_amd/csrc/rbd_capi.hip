@@ -904,12 +904,13 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
   const bool state = B >= w->state_min_batch;
   if (state && layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv)) {
     void* const before = w->d_Msoa;
-    if ((st = ensure(&w->d_Msoa, &w->d_Msoa_bytes, es * (size_t)m->nv * m->nv * B))) return st;
+    const size_t Bpad = ((size_t)B + 15) & ~(size_t)15;
+    if ((st = ensure(&w->d_Msoa, &w->d_Msoa_bytes, es * (size_t)m->nv * m->nv * Bpad))) return st;
     if (w->Msoa_B != B || w->d_Msoa != before) {  // the structural zeros of M are written once per batch size: the kernel below only stores the non-zeros
-      HIP_TRY(hipMemsetAsync(w->d_Msoa, 0, es * (size_t)m->nv * m->nv * B, w->stream));
+      HIP_TRY(hipMemsetAsync(w->d_Msoa, 0, es * (size_t)m->nv * m->nv * Bpad, w->stream));
       w->Msoa_B = B;
     }
-    const Layout Ls = layout_of(RBD_LAYOUT_SOA, (long)m->nv * m->nv, B);
+    const Layout Ls{16, -(long)m->nv * m->nv};  // grouped by 16 states = one wavefront of the tile Cholesky (layout_base, rbd_device.hpp)
     HIP_TRY(launch_crba_state<float>(w->sm, B, dq, w->d_Msoa, Lq, Ls, 0, w->stream));  // structural zeros: never read by the solve, written below
     HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_Msoa, dtau, dc, dx, nullptr, Ls, Lv, w->d_notpd, w->stream, dM, Lm));
     w->last_kernel = "crba_state_kernel + chol_mfma_kernel";

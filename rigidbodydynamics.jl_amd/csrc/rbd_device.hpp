@@ -132,8 +132,13 @@ struct ContactModel {
 
 // element (k, b) of an n x B batch buffer
 struct Layout {
-  long sk, sb;  // SOA: sk = B, sb = 1;  AOS: sk = 1, sb = n
+  long sk, sb;  // SOA: sk = B, sb = 1;  AOS: sk = 1, sb = n;  internal staging buffers: sk = 16, sb = -n (grouped by 16 states, below)
 };
+// offset of state b's column.  A staging buffer the library owns may be GROUPED BY 16 STATES — element (k, b) at (b / 16)(16 n) + 16 k + b % 16,
+// encoded as Layout{16, -n}: a wavefront of the tile Cholesky (16 states) then reads ONE contiguous block, whole cache lines, and the
+// one-lane-per-state CRBA that fills it still writes 64-byte runs (measured with the batch-innermost staging: 4x the bytes fetched, half of
+// every line belonging to the neighbouring wavefront on another XCD's L2).
+__host__ __device__ inline long layout_base(Layout L, long b) { return L.sb >= 0 ? b * L.sb : (b >> 4) * (16 * -L.sb) + (b & 15); }
 
 // loop (non-tree) joint tables for loop_solve_kernel; indices are REFERENCE body indices (not slots)
 template <typename T> struct LoopView {

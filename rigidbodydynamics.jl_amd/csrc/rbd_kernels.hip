@@ -1306,7 +1306,7 @@ RBD_DEV float quad_sum(float x) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(64) void chol_mfma_kernel(int nv, long B, const float* __restrict__ Mg, const float* __restrict__ tau,
+__global__ __launch_bounds__(64, (NT <= 9 ? 2 : 1)) void chol_mfma_kernel(int nv, long B, const float* __restrict__ Mg, const float* __restrict__ tau,
                                                        const float* __restrict__ c, float* __restrict__ x, float* __restrict__ Lout,
                                                        Layout Lm, Layout Lv, int* __restrict__ notpd, float* __restrict__ Mcopy, Layout Lc) {
   const int lane = threadIdx.x & 63;
@@ -1322,18 +1322,21 @@ __global__ __launch_bounds__(64) void chol_mfma_kernel(int nv, long B, const flo
       for (int cc = 0; cc < 4; ++cc) {
         const int row = 4 * I + r, col = 4 * J + cc;
         float a = (row == col) ? 1.0f : 0.0f;
-        if (live && row < nv && col <= row) a = Mg[((long)col * nv + row) * Lm.sk + state * Lm.sb];
+        if (live && row < nv && col <= row) a = Mg[((long)col * nv + row) * Lm.sk + layout_base(Lm, state)];
         t[I][J][cc] = a;
       }
   // M itself in the caller's layout, when the matrix was built in a staging buffer (one-lane-per-state CRBA writes batch-innermost):
   // a quad stores 16 contiguous bytes per (tile, column) and a state's columns come from this one wavefront back to back
+  // (column by column, rows ascending: the 16-byte pieces of a cache line of the caller's column-major M are stored back to back, so the line
+  // is complete in L2 long before it is evicted — tile by tile they were spread over the whole store phase, and with 128 wavefronts x 83 KB of
+  // output in flight per 4 MB L2 most lines went out partially written: 2.4x the bytes, read-modify-write at the memory)
   if (Mcopy && live) {
 #pragma unroll
-    for (int I = 0; I < NT; ++I)
+    for (int J = 0; J < NT; ++J)
 #pragma unroll
-      for (int J = 0; J <= I; ++J)
+      for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
+        for (int I = J; I < NT; ++I) {
           const int row = 4 * I + r, col = 4 * J + cc;
           if (row < nv && col <= row) Mcopy[((long)col * nv + row) * Lc.sk + state * Lc.sb] = t[I][J][cc];
         }
@@ -1448,7 +1451,7 @@ __global__ __launch_bounds__(64) void chol_mfma_kernel(int nv, long B, const flo
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
           const int row = 4 * I + r, col = 4 * J + cc;
-          if (row < nv && col <= row) Lout[((long)col * nv + row) * Lm.sk + state * Lm.sb] = t[I][J][cc];
+          if (row < nv && col <= row) Lout[((long)col * nv + row) * Lm.sk + layout_base(Lm, state)] = t[I][J][cc];
         }
   }
 }

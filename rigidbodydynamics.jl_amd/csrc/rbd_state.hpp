@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void crba_state_kernel(StateModel M, long B, c
   const bool live = state_raw < B;
   const long state = live ? state_raw : B - 1;
   state_stage(q, Lq, state, M.nq, qs - lane);
-  T* Mlane = Mout + state * Lm.sb;
+  T* Mlane = Mout + layout_base(Lm, state);
   const long nv = M.nv, msk = Lm.sk;
   auto put = [&](long row, long col, T x) {
     if (live) Mlane[(col * nv + row) * msk] = x;
