@@ -4,7 +4,7 @@ Tolerances (stated per BASELINE.md §4):
   fp64: max |x_gpu - x_oracle| <= 1e-10 * max(1, max|x_oracle|)   (the reference's own atol is 1e-10,
         test/test_mechanism_algorithms.jl:739; GPU ABA vs the oracle's CRBA+Cholesky route differ by ~1e-13 rel.)
   fp32: v̇ is cond(M)-limited (cond ≈ 5e5 on Atlas) so parity is stated as backward error
-        ||M v̇ - (τ - c)|| / ||τ - c|| <= 2e-5 with M, c from the fp64 oracle, plus a loose forward bound 3e-2·max|v̇|
+        ||M v̇ - (τ - c)|| / ||τ - c|| <= 2e-5 with M, c from the fp64 oracle, plus the forward bound 8·cond₂(M_b)·eps32 state by state
         (SURVEY.md App. B; precedent atol 1e-3, test/test_mechanism_modification.jl:339);
         τ (RNEA) and M (CRBA) have no solve: relative 2e-5.
 """
@@ -21,6 +21,19 @@ pytestmark = pytest.mark.gpu
 MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf", "randmech1", "randmech2", "randmech3", "inner_floating"]
 TD = {"f64": torch.float64, "f32": torch.float32}
 NT = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 1  # host threads for full-batch oracle runs
+
+
+def assert_fp32_forward(oracle, model, q, got, ref, C=8.0, what=""):
+    """Forward error of an fp32 solve of M v̇ = τ − c, state by state: ||got − ref|| / ||ref|| <= C · cond₂(M_b) · eps32 — what a backward-stable
+    fp32 algorithm on fp32-rounded inputs can deliver for THAT state's mass matrix (round-1 review: not a blanket constant)."""
+    M = oracle.mass_matrix(model, q, nthreads=NT)
+    Ms = np.tril(M) + np.transpose(np.tril(M, -1), (0, 2, 1))
+    kappa = np.linalg.cond(Ms)
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-30)
+    bound = C * kappa * np.finfo(np.float32).eps
+    worst = int(np.argmax(err / bound))
+    assert (err <= bound).all(), (what, worst, float(err[worst]), float(bound[worst]), float(kappa[worst]))
+
 ND = {"f64": np.float64, "f32": np.float32}
 
 
@@ -140,7 +153,7 @@ def test_dynamics_f32(rbd, oracle, models, name):
     c = oracle.dynamics_bias(model, q, v, fe)
     rel = np.linalg.norm(back - tau, axis=1) / np.linalg.norm(tau - c, axis=1)
     assert rel.max() <= 2e-5, rel.max()
-    assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max()
+    assert_fp32_forward(oracle, model, q, got, ref, what=name)
 
 
 @pytest.mark.parametrize("name", ["atlas_floating", "double_pendulum"])
@@ -255,7 +268,7 @@ def test_mass_matrix_solve_f32_config3(rbd, oracle, models):
     eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau, axis=1))
     assert eta.max() <= 1e-5, eta.max()
     xr = np.linalg.solve(Ms, tau[..., None])[..., 0]
-    assert np.abs(xg - xr).max() <= 3e-2 * np.abs(xr).max()
+    assert_fp32_forward(oracle, model, q, xg, xr, what="config3")
 
 
 def test_mass_matrix_solve_full_size_property(rbd, oracle, models):
@@ -716,7 +729,7 @@ def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B, algorithm):
     ref = oracle.dynamics(model, q, v, tau, fe)
     got = host(result.vd, state)
     assert np.isfinite(got).all()
-    assert np.abs(got - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())  # same bound as test_dynamics_f32
+    assert_fp32_forward(oracle, model, q, got, ref, what=algorithm)  # same criterion as test_dynamics_f32
 
 
 @pytest.mark.gpu
