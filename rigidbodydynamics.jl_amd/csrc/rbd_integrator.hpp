@@ -44,16 +44,18 @@ template <typename T> RBD_DEV void quat_rotate(const T* q, const T* x, T* o) {  
 }
 
 // ϕ̇ of local_coordinates! for one joint
-template <typename T> RBD_DEV void joint_local_rate(int t, const T* q0, const T* q, const T* v, T* o) {
+// MODE 0: every joint type (the fused launches); 1: only the element-wise types (revolute, prismatic, sin-cos, planar); 2: only the
+// quaternion types — mk_stage_kernel runs as two launches so that the light one keeps few registers and many wavefronts in flight
+template <typename T, int MODE = 0> RBD_DEV void joint_local_rate(int t, const T* q0, const T* q, const T* v, T* o) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) o[k] = T(0);
-  if (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC || t == RBD_JOINT_SINCOS_REVOLUTE) {
+  if (MODE != 2 && (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC || t == RBD_JOINT_SINCOS_REVOLUTE)) {
     o[0] = v[0];
-  } else if (t == RBD_JOINT_PLANAR) {
+  } else if (MODE != 2 && t == RBD_JOINT_PLANAR) {
     T s, c;
     sincos_t(q[2], &s, &c);
     o[0] = c * v[0] - s * v[1]; o[1] = s * v[0] + c * v[1]; o[2] = v[2];
-  } else if (t == RBD_JOINT_QUAT_SPHERICAL) {
+  } else if (MODE != 1 && t == RBD_JOINT_QUAT_SPHERICAL) {
     const T q0c[4] = {q0[0], -q0[1], -q0[2], -q0[3]};
     T dq[4], phi[3], c1[3], c2[3];
     quat_mul(q0c, q, dq);
@@ -70,7 +72,7 @@ template <typename T> RBD_DEV void joint_local_rate(int t, const T* q0, const T*
 #pragma unroll
       for (int k = 0; k < 3; ++k) o[k] += f * c2[k];
     }
-  } else if (t == RBD_JOINT_QUAT_FLOATING) {
+  } else if (MODE != 1 && t == RBD_JOINT_QUAT_FLOATING) {
     // relative transform inv(T0) T, then log_with_time_derivative with the body twist (ω, v).  This branch sits on the critical path
     // of the fused `simulate` launches (one lane per state runs it while the wavefront waits), so it spends one atan2, two
     // square roots and three reciprocals: sin/cos of θ/2 are the relative quaternion's own (normalised) parts, θ is not
@@ -116,24 +118,24 @@ template <typename T> RBD_DEV void joint_local_rate(int t, const T* q0, const T*
 }
 
 // global_coordinates! for one joint
-template <typename T> RBD_DEV void joint_global(int t, const T* q0, const T* phi, T* q) {
+template <typename T, int MODE = 0> RBD_DEV void joint_global(int t, const T* q0, const T* phi, T* q) {
 #pragma unroll
   for (int k = 0; k < 7; ++k) q[k] = T(0);
-  if (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC) {
+  if (MODE != 2 && (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC)) {
     q[0] = q0[0] + phi[0];
-  } else if (t == RBD_JOINT_PLANAR) {
+  } else if (MODE != 2 && t == RBD_JOINT_PLANAR) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) q[k] = q0[k] + phi[k];
-  } else if (t == RBD_JOINT_SINCOS_REVOLUTE) {
+  } else if (MODE != 2 && t == RBD_JOINT_SINCOS_REVOLUTE) {
     T sd, cd;
     sincos_t(phi[0], &sd, &cd);
     q[0] = q0[0] * cd + q0[1] * sd;
     q[1] = q0[1] * cd - q0[0] * sd;
-  } else if (t == RBD_JOINT_QUAT_SPHERICAL) {
+  } else if (MODE != 1 && t == RBD_JOINT_QUAT_SPHERICAL) {
     T dq[4];
     quat_from_rotvec(phi, dq);
     quat_mul(q0, dq, q);
-  } else if (t == RBD_JOINT_QUAT_FLOATING) {
+  } else if (MODE != 1 && t == RBD_JOINT_QUAT_FLOATING) {
     T dq[4], tr[3], w[3];
     const T th = norm3(phi);
     if (th < eps_t<T>()) {
@@ -167,7 +169,7 @@ template <typename T> RBD_DEV void joint_global(int t, const T* q0, const T* phi
 // One lane's share of stage `stage` (0..4) of a step: see mk_stage_kernel.  qj / vj: the lane's joint state as loaded from the
 // state buffers (previous stage state) in, the new stage state out; the new state is also written to q_state / v_state.
 // vdot_prev == nullptr means W.vd[stage-1] already holds the previous stage's v̇ (fused launches).
-template <typename T>
+template <typename T, int MODE = 0>
 RBD_DEV void mk_stage_lane(const Body<T>& b, int stage, T dt, T* qj, T* vj, const T* __restrict__ vdot_prev, const MkBuffers& W,
                            T* __restrict__ q_state, T* __restrict__ v_state, Layout Lq, Layout Lv) {
   const int t = b.jtype;
@@ -187,7 +189,7 @@ RBD_DEV void mk_stage_lane(const Body<T>& b, int stage, T dt, T* qj, T* vj, cons
     load_joint_q(b, q0, Lq, q0j);
     load_joint_v(b, v0, Lv, v0j);
     // rates of the stage that has just been evaluated
-    joint_local_rate(t, q0j, qj, vj, rate);
+    joint_local_rate<T, MODE>(t, q0j, qj, vj, rate);
     T* pd = (T*)W.phid[stage - 1];
 #pragma unroll
     for (int k = 0; k < 6; ++k)
@@ -224,7 +226,7 @@ RBD_DEV void mk_stage_lane(const Body<T>& b, int stage, T dt, T* qj, T* vj, cons
     }
   }
   T qn[7];
-  joint_global(t, q0j, phi, qn);
+  joint_global<T, MODE>(t, q0j, phi, qn);
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
     qj[k] = qn[k];

@@ -2008,21 +2008,47 @@ template hipError_t launch_loop_solve<float>(const LoopView<float>&, long, int, 
 // ---------------------------------------------------------------------------------------------
 namespace rbd {
 
-template <typename T>
+// Two launches per stage.  mk_stage_kernel<T, 1>: the element-wise joint types (revolute, prismatic, sin-cos, planar), one lane per (state,
+// body) as everywhere else — ~50 registers, 7-8 wavefronts per SIMD in flight.  mk_stage_heavy_kernel: the quaternion joints (SE(3) / SO(3)
+// log and exp: ~2 000 instructions with their atan2 / sincos / divisions), ONE THREAD PER STATE looping over the model's bodies — a humanoid
+// has one such joint, and one-lane-per-(state, body) left 2 of 64 lanes busy through all of it (measured as one kernel: 94 us per stage at
+// 65 536 Atlas states, 89 of them this branch).
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void mk_stage_kernel(DevModel M, long B, int stage, T dt, T* __restrict__ q, T* __restrict__ v,
                                                        const T* __restrict__ vdot_prev, MkBuffers W, Layout Lq, Layout Lv) {
   Body<T> b;
   load_body(M, B, b);
+  const bool heavy = b.jtype == RBD_JOINT_QUAT_FLOATING || b.jtype == RBD_JOINT_QUAT_SPHERICAL;
+  if (heavy != (MODE == 2)) return;
   T qj[7], vj[6];
   load_joint_q(b, q, Lq, qj);
   load_joint_v(b, v, Lv, vj);
-  mk_stage_lane(b, stage, dt, qj, vj, vdot_prev, W, q, v, Lq, Lv);
+  mk_stage_lane<T, MODE>(b, stage, dt, qj, vj, vdot_prev, W, q, v, Lq, Lv);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mk_stage_heavy_kernel(DevModel M, long B, int stage, T dt, T* __restrict__ q, T* __restrict__ v,
+                                                             const T* __restrict__ vdot_prev, MkBuffers W, Layout Lq, Layout Lv) {
+  const long state = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (state >= B) return;
+  for (int s = 0; s < M.nb; ++s) {
+    const int32_t* ib = M.ib + s * IB_STRIDE;
+    const int jt = ib[IB_JTYPE];  // wave-uniform
+    if (jt != RBD_JOINT_QUAT_FLOATING && jt != RBD_JOINT_QUAT_SPHERICAL) continue;
+    Body<T> b{};
+    b.jtype = jt; b.qoff = ib[IB_QOFF]; b.voff = ib[IB_VOFF]; b.state = state; b.valid = true;
+    T qj[7], vj[6];
+    load_joint_q(b, q, Lq, qj);
+    load_joint_v(b, v, Lv, vj);
+    mk_stage_lane<T, 2>(b, stage, dt, qj, vj, vdot_prev, W, q, v, Lq, Lv);
+  }
 }
 
 template <typename T>
 hipError_t launch_mk_stage(const DevModel& M, long B, int stage, double dt, void* q, void* v, const void* vdot_prev, const MkBuffers& W,
                            Layout Lq, Layout Lv, hipStream_t s) {
-  hipLaunchKernelGGL(mk_stage_kernel<T>, grid_for(M, B, 256), dim3(256), 0, s, M, B, stage, (T)dt, (T*)q, (T*)v, (const T*)vdot_prev, W, Lq, Lv);
+  hipLaunchKernelGGL((mk_stage_kernel<T, 1>), grid_for(M, B, 256), dim3(256), 0, s, M, B, stage, (T)dt, (T*)q, (T*)v, (const T*)vdot_prev, W, Lq, Lv);
+  if (M.maxnvj > 3 || M.has3dof)  // some joint is (or may be) a quaternion joint
+    hipLaunchKernelGGL((mk_stage_heavy_kernel<T>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, M, B, stage, (T)dt, (T*)q, (T*)v, (const T*)vdot_prev, W, Lq, Lv);
   return hipGetLastError();
 }
 template hipError_t launch_mk_stage<double>(const DevModel&, long, int, double, void*, void*, const void*, const MkBuffers&, Layout, Layout, hipStream_t);
