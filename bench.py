@@ -36,6 +36,11 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 # Kernel arguments in device memory: with them in host memory every wavefront's first scalar loads cross PCIe and a 24 µs launch
 # becomes 28 µs (measured).  It is this image's default; set explicitly so the number does not depend on it.
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# The oracle (parity check, cpu_baseline) is OpenMP code on every host core.  With libgomp's default wait policy its worker threads keep
+# spinning after a parallel region; a GPU timing leg that follows is then launched from a starved host thread (seen once: 65 us per step for
+# the with-wrenches leg of a 25 us kernel).  Passive waiting; the timed headline region also runs BEFORE the first oracle call.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X public spec (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
