@@ -219,7 +219,7 @@ def main():
                 raise RuntimeError(f"{name} status {s}: {L.rbd_status_string(s)} {L.rbd_last_hip_error()}")
         return step
 
-    def timed(step, gather_each):
+    def timed(step, gather_each, use_graph=False):
         """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; (wall seconds, kernel ms per step by HIP events)."""
         def one():
             step()
@@ -229,7 +229,7 @@ def main():
             one()
         torch.cuda.synchronize(device)
         graph = None
-        if args.graph and not gather_each:
+        if (args.graph or use_graph) and not gather_each:
             graph = torch.cuda.CUDAGraph()
             cap = torch.cuda.Stream(device)
             with torch.cuda.stream(cap):
@@ -337,6 +337,14 @@ def main():
                 "value": B * args.steps / w2, "unit": "evals/s", "ms_per_step": w2 / args.steps * 1e3, "kernel_ms": k2}
         except Exception as e:
             extra["with_external_wrenches"] = f"failed: {type(e).__name__}: {e}"
+    if world == 1 and not args.graph:
+        # informational: the same K steps captured once in a hipGraph and replayed (what a caller with a fixed step loop would do); `value` stays
+        # the plain stream-launch figure
+        try:
+            w3, k3 = timed(step, False, use_graph=True)
+            extra["hip_graph_replay"] = {"value": B * args.steps / w3, "unit": "evals/s", "ms_per_step": w3 / args.steps * 1e3, "kernel_ms": k3}
+        except Exception as e:
+            extra["hip_graph_replay"] = f"failed: {type(e).__name__}: {e}"
 
     if rank != 0:
         if dist is not None:

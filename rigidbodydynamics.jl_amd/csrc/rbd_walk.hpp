@@ -749,6 +749,57 @@ __device__ __forceinline__ void walk_stage_out_fast(typename Lanes<T>::S* __rest
   }
 }
 
+// ... and the batch-innermost layout (sk = B, sb = 1), every state inside the batch: row k of the workgroup's block is 64 N contiguous scalars
+template <typename T, int UB>
+__device__ __forceinline__ void walk_stage_in_rows(const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v,
+                                                   const typename Lanes<T>::S* __restrict__ tau, long B, long state0, int nq, int nv, T* rows, int rq, int rv,
+                                                   int rt, int tid, int nth) {
+  using S = typename Lanes<T>::S;
+  constexpr int N = Lanes<T>::N, W = 64 * N;
+  S* cells = reinterpret_cast<S*>(rows);
+  const int totq = nq * W, totv = nv * W, tot = totq > totv ? totq : totv;
+  for (int e0 = tid; e0 < tot + tid; e0 += UB * nth) {
+    S a[UB], b[UB], d[UB];
+    int ic[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * nth, k = e / W, st = e % W;
+      const long off = (long)k * B + state0 + st;
+      a[u] = e < totq ? q[off] : S(0);
+      b[u] = (v && e < totv) ? v[off] : S(0);
+      d[u] = (tau && e < totv) ? tau[off] : S(0);
+      ic[u] = (k * WR_STRIDE + (st & 63)) * N + (st >> 6);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * nth;
+      if (e < totq) cells[ic[u] + rq * WR_STRIDE * N] = a[u];
+      if (e < totv) { cells[ic[u] + rv * WR_STRIDE * N] = b[u]; cells[ic[u] + rt * WR_STRIDE * N] = d[u]; }
+    }
+  }
+}
+template <typename T, int UB>
+__device__ __forceinline__ void walk_stage_out_rows(typename Lanes<T>::S* __restrict__ dst, long B, long state0, int n, const T* rows, int row0, int tid, int nth) {
+  using S = typename Lanes<T>::S;
+  constexpr int N = Lanes<T>::N, W = 64 * N;
+  if (!dst) return;
+  const S* cells = reinterpret_cast<const S*>(rows);
+  const int tot = n * W;
+  for (int e0 = tid; e0 < tot + tid; e0 += UB * nth) {
+    S a[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * nth, k = e / W, st = e % W;
+      a[u] = e < tot ? cells[((row0 + k) * WR_STRIDE + (st & 63)) * N + (st >> 6)] : S(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * nth, k = e / W, st = e % W;
+      if (e < tot) dst[(long)k * B + state0 + st] = a[u];
+    }
+  }
+}
+
 template <typename T, bool FLT, bool GEN>
 __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v,
                                                       const typename Lanes<T>::S* __restrict__ tau, const typename Lanes<T>::S* __restrict__ fext,
@@ -774,9 +825,11 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     S tr[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) tr[u] = gr[tid + u * nth < ntr ? tid + u * nth : 0];
-    const bool fast = Lq.sk == 1 && Lv.sk == 1 && state0 + 64 * N <= B;  // wave-uniform
+    const bool inside = state0 + 64 * N <= B;  // wave-uniform
+    const bool fast = Lq.sk == 1 && Lv.sk == 1 && inside;
+    const bool fast_rows = Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && inside && !fast;
     WalkStageIn<T, UB> in;
-    if (!fast) in.load(q, v, tau, Lq, Lv, state0, B, M.nq, M.nv, 0, tid, nth);
+    if (!fast && !fast_rows) in.load(q, v, tau, Lq, Lv, state0, B, M.nq, M.nv, 0, tid, nth);
     if (tid < nrec) { const_cast<I4*>(c.tri)[tid] = ti; const_cast<int32_t*>(c.twk)[tid] = tw; }
 #pragma unroll
     for (int u = 0; u < TB; ++u)
@@ -784,6 +837,8 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     for (int i = tid + TB * nth; i < ntr; i += nth) const_cast<S*>(c.trr)[i] = gr[i];
     if (fast) {
       walk_stage_in_fast<T, UB>(q, v, tau, state0, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
+    } else if (fast_rows) {
+      walk_stage_in_rows<T, UB>(q, v, tau, B, state0, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
     } else {
       in.store(c.rows, c.rq, c.rv, c.rt);
       const int nmax = (M.nq > M.nv ? M.nq : M.nv) * 64 * N;
@@ -885,6 +940,9 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
   if (Lq.sk == 1 && Lv.sk == 1 && state0 + 64 * N <= B) {
     walk_stage_out_fast<T, 10 * N>(vdot, state0, M.nv, c.rows, c.rt, tid, nth);
     walk_stage_out_fast<T, 10 * N>(qdot, state0, M.nq, c.rows, c.rq, tid, nth);
+  } else if (Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && state0 + 64 * N <= B) {
+    walk_stage_out_rows<T, 10 * N>(vdot, B, state0, M.nv, c.rows, c.rt, tid, nth);
+    walk_stage_out_rows<T, 10 * N>(qdot, B, state0, M.nq, c.rows, c.rq, tid, nth);
   } else {
     walk_stage_out<T, 10>(vdot, Lv, state0, B, M.nv, c.rows, c.rt, tid, nth);
     walk_stage_out<T, 10>(qdot, Lq, state0, B, M.nq, c.rows, c.rq, tid, nth);
@@ -918,9 +976,11 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
     S tr[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) tr[u] = gr[tid + u * nth < ntr ? tid + u * nth : 0];
-    const bool fast = Lq.sk == 1 && Lv.sk == 1 && state0 + 64 * N <= B;  // wave-uniform
+    const bool inside = state0 + 64 * N <= B;  // wave-uniform
+    const bool fast = Lq.sk == 1 && Lv.sk == 1 && inside;
+    const bool fast_rows = Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && inside && !fast;
     WalkStageIn<T, UB> in;
-    if (!fast) in.load(q, v, vdot, Lq, Lv, state0, B, M.nq, M.nv, 0, tid, nth);
+    if (!fast && !fast_rows) in.load(q, v, vdot, Lq, Lv, state0, B, M.nq, M.nv, 0, tid, nth);
     if (tid < nrec) { const_cast<I4*>(c.tri)[tid] = ti; const_cast<int32_t*>(c.twk)[tid] = tw; }
 #pragma unroll
     for (int u = 0; u < TB; ++u)
@@ -928,6 +988,8 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
     for (int i = tid + TB * nth; i < ntr; i += nth) const_cast<S*>(c.trr)[i] = gr[i];
     if (fast) {
       walk_stage_in_fast<T, UB>(q, v, vdot, state0, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
+    } else if (fast_rows) {
+      walk_stage_in_rows<T, UB>(q, v, vdot, B, state0, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
     } else {
       in.store(c.rows, c.rq, c.rv, c.rt);
       const int nmax = (M.nq > M.nv ? M.nq : M.nv) * 64 * N;
@@ -1010,6 +1072,9 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
   if (Lq.sk == 1 && Lv.sk == 1 && state0 + 64 * N <= B) {
     walk_stage_out_fast<T, 10 * N>(tau, state0, M.nv, c.rows, c.rt, tid, nth);
     walk_stage_out_fast<T, 10 * N>(qdot, state0, M.nq, c.rows, c.rq, tid, nth);
+  } else if (Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && state0 + 64 * N <= B) {
+    walk_stage_out_rows<T, 10 * N>(tau, B, state0, M.nv, c.rows, c.rt, tid, nth);
+    walk_stage_out_rows<T, 10 * N>(qdot, B, state0, M.nq, c.rows, c.rq, tid, nth);
   } else {
     walk_stage_out<T, 10>(tau, Lv, state0, B, M.nv, c.rows, c.rt, tid, nth);
     walk_stage_out<T, 10>(qdot, Lq, state0, B, M.nq, c.rows, c.rq, tid, nth);
