@@ -590,12 +590,13 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       if (const char* e = getenv("RBD_WALK_PAIR_MIN_BATCH")) w->walk_pair_min_batch = atol(e);
     }
     // RBD_ALGO_ABA picks it from this batch size up (RBD_WALK_MIN_BATCH overrides).  Measured on Atlas (profiles/r02_walk_sweep.txt): a launch takes
-    // the same ~37 us from 64 to 16 384 states (one workgroup per 64 states, one per CU), the banked lane-per-body kernel 25 us at 4096, 35 us at
-    // 8192, 63 us at 16 384 — the crossover is where the workgroups of the walk kernel cover 3/4 of the chip
+    // the same ~37 us from 64 to 16 384 states (one workgroup per 64 states, one per CU); the banked lane-per-body kernel takes 25 us at 4096,
+    // 35 us at 8192 (two wavefronts on every SIMD) and 52 us from 8704 on (a third wavefront on some) — the crossover is one state past
+    // 32 states per CU
     {
       int ncu = 256;
       (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-      w->walk_min_batch = (long)ncu * 48;
+      w->walk_min_batch = (long)ncu * 32 + 1;
     }
     if (const char* e = getenv("RBD_WALK_MIN_BATCH")) w->walk_min_batch = atol(e);
   }

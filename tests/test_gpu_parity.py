@@ -820,7 +820,7 @@ def test_inverse_dynamics_banked_f32_and_full_size(rbd, oracle, models):
     rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state), mapping="banks")
     ref = oracle.inverse_dynamics(model, q, v, vd, fe)
     assert np.abs(host(out, state) - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
-    B = 16384  # auto picks the banked kernels; dynamics! -> inverse_dynamics closes (test/test_mechanism_algorithms.jl:729-740)
+    B = 16384  # auto picks the walk kernels (banked below 8193 states); dynamics! -> inverse_dynamics closes (test/test_mechanism_algorithms.jl:729-740)
     state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 75)
     res = rbd.DynamicsResult(model, B)
     t = dev(tau, state)
