@@ -85,7 +85,7 @@ enum {
                                 prismatic / fixed joints, 6-dof joints on the world).  RBD_ERR_UNSUPPORTED elsewhere        */
   RBD_ALGO_ABA_WALK = 6      /* the track schedule with one WAVEFRONT per track and one lane per state: a workgroup is up to four
                                 wavefronts over the same 64 states, q / v / tau staged through LDS, per-joint results in accumulation
-                                registers.  Same scope as the track mapping, at most 12 steps per track; RBD_ERR_UNSUPPORTED
+                                registers.  Same scope as the track mapping, at most 11 steps per track; RBD_ERR_UNSUPPORTED
                                 elsewhere or when the rows of 64 states do not fit one compute unit's LDS                      */
 };
 
@@ -179,6 +179,14 @@ int rbd_model_bank_plan(const rbd_model_t* model, int32_t* lanes, int32_t* first
  * has prismatic/fixed joints; table: steps×tracks reference body indices (-1 = idle); ri / rr: the packed per-(step, track) records
  * the kernel reads (rbd_device.hpp TI_*, TR_*) — what tests/emu feeds to the CPU emulation of the kernel's step code.        */
 int rbd_model_track_plan(const rbd_model_t* model, int32_t* dims, int32_t* table, int32_t table_cap, int32_t* ri, int32_t ri_cap, double* rr, int32_t rr_cap);
+/* ... and of the plan the walk kernels run when the mechanism hangs on the world by one 6-dof joint and is shallower seen from another
+ * body: the tree RE-ROOTED at its centre (csrc/rbd_reroot.hpp; the floating joint's coordinates stay where they are).
+ * dims[12] = tracks, steps, A/C mailboxes, B mailboxes, 6-dof root, prismatic/fixed joints, parking slots, chain length, q / v offset of the
+ * floating joint, new root body, old floating body;  ri: packed records followed by the per-step flags;  rr: constants;  wk: parking words
+ * (BFD_* flags in bits 8..9);  chain_i[4·chain], chain_r[15·chain], fxp[12]: the joints between the old floating body and the new root.
+ * RBD_ERR_UNSUPPORTED when the mechanism is not re-rooted.  Host-only. */
+int rbd_model_reroot_plan(const rbd_model_t* model, int32_t* dims, int32_t* ri, int32_t ri_cap, double* rr, int32_t rr_cap, int32_t* wk, int32_t wk_cap,
+                          int32_t* chain_i, double* chain_r, double* fxp);
 int rbd_model_chain_plan(const rbd_model_t* model, int32_t* tracks, int32_t* steps, int32_t* lds_fields, int32_t* table, int32_t capacity);
 int rbd_model_dims(const rbd_model_t* model, int32_t* n_bodies, int32_t* nq, int32_t* nv, int32_t* nc);
 

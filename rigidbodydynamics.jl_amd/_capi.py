@@ -20,7 +20,7 @@ SYMBOLS = (
     "rbd_workspace_set_stream", "rbd_sync", "rbd_dynamics", "rbd_inverse_dynamics", "rbd_dynamics_bias", "rbd_mass_matrix",
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
     "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan", "rbd_model_track_plan", "rbd_inverse_dynamics_bodies", "rbd_dynamics_bias_bodies",
-    "rbd_model_contact_dims", "rbd_contact_dynamics", "rbd_dynamics_contact", "rbd_simulate_contact",
+    "rbd_model_reroot_plan", "rbd_model_contact_dims", "rbd_contact_dynamics", "rbd_dynamics_contact", "rbd_simulate_contact",
     "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_comm_last_error",
 )
 
@@ -81,6 +81,8 @@ def lib():
         L.rbd_kinematics.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_simulate.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.c_double, i32, ctypes.POINTER(Opts)]
         L.rbd_mk_stage.argtypes = [vp, i32, i32, ctypes.c_double, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_model_reroot_plan.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), i32, ctypes.POINTER(ctypes.c_double), i32, ctypes.POINTER(i32), i32,
+                                            ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.rbd_model_contact_dims.argtypes = [vp] + [ctypes.POINTER(i32)] * 3
         L.rbd_contact_dynamics.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_dynamics_contact.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]

@@ -17,6 +17,6 @@ $HIPCC $FLAGS --cuda-device-only -S rbd_walk_kernels.hip -o ${TAG}_walk_kernels.
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 # the walk kernel addresses accumulation registers by number: the register allocator must stay clear of them (scripts/check_walk_agprs.py)
-python3 ../../scripts/check_walk_agprs.py ${TAG}_walk_kernels.s 12
+python3 ../../scripts/check_walk_agprs.py ${TAG}_walk_kernels.s 11
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT ${TAG}_kernels.o ${TAG}_track_kernels.o ${TAG}_walk_kernels.o ${TAG}_state_kernels.o ${TAG}_contact_kernels.o ${TAG}_capi.o ${TAG}_comm.o -ldl
 echo "built $(pwd)/$OUT"

@@ -41,6 +41,7 @@ template <typename T> RBD_DEV void load_bank_body(const BankModel& M, int k, lon
   b.level = b.valid ? ib[IB_LEVEL] : -1;
   b.nchild = ib[IB_NCHILD];
   b.orig = ib[IB_ORIG];
+  b.flags = ib[IB_FLAGS];
 #pragma unroll
   for (int c = 0; c < IB_MAXCHILD; ++c) b.child[c] = ib[IB_CHILD0 + c];
   b.plane = b.parent >= 0 ? b.base + b.parent : b.lane;  // parent slot (of the parent's bank) in this state's lane group
@@ -144,7 +145,8 @@ template <typename T> RBD_DEV void bank_joint_accel(BankRegs<T>& r, const T* a_p
 // wavefront issues at only ~5 cycles per instruction.  The bank that is not being swept therefore parks its live values in a
 // lane-private LDS column (PARK_SLOTS values per lane, no synchronisation needed): the kernel fits 256 VGPRs and two
 // wavefronts per SIMD interleave.
-enum { PARK_KIN = 0 /* R 9, p 3, Tw 6, vJ 6 of bank 0 */, PARK_FWD = 12 /* U 6, 1/D, u, S 6, cb 6 of bank 1 */, PARK_SLOTS = 32 };
+enum { PARK_KIN = 0 /* R 9, p 3, Tw 6, vJ 6 of bank 0 */, PARK_FWD = 12 /* U 6, 1/D, u, S 6, cb 6 of bank 1 */, PARK_SLOTS = 32,
+       PARK_WF = 32 /* re-rooted tree: S^-T tau of the floating joint, left by the root lane for the old floating body */, PARK_SLOTS_RR = 38 };
 
 #ifdef RBD_PROFILE_PHASES
 __device__ long long rbd_bank_phase_clock[16];
@@ -153,7 +155,11 @@ __device__ long long rbd_bank_phase_clock[16];
 #define RBD_MARK(i)
 #endif
 
-template <typename T>
+// RR = true: the tree re-rooted at its centre (rbd_reroot.hpp).  The level-0 body is then a VIRTUAL floating base — its pose and twist come
+// from the old floating body's coordinates through the chain of original joints, its acceleration solves IA a = −pA — and the old floating
+// body (flag BFD_FCARRY, now somewhere down the tree) takes the floating joint's force as an external wrench and gives back v̇ of the floating
+// joint from its own spatial acceleration.  Everything else is the same code on different records (reversed joints are ordinary records).
+template <typename T, bool RR = false>
 __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, const T* q, const T* v,  /* no restrict: F.q_state / F.v_state alias them when fused */
                                                          const T* __restrict__ tau, const T* __restrict__ fext, T* __restrict__ vdot,
                                                          T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, MkFuse F) {
@@ -161,6 +167,19 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
   T* const park = reinterpret_cast<T*>(park_raw) + threadIdx.x;  // slot i of this lane: park[i * 256]
   RBD_MARK(0);
   BankRegs<T> r0, r1;
+  // RR: coordinates of the chain joints between the old floating body and the new root, requested with the first loads of the launch
+  T cq[RC_MAX], cv[RC_MAX];
+  if (RR) {
+    const long st = ((long)blockIdx.x * blockDim.x + threadIdx.x) / M.lps;
+    const long stc = st < B ? st : B - 1;
+#pragma unroll
+    for (int j = 0; j < RC_MAX; ++j) {
+      const bool on = j < M.reroot.nchain;
+      const int qo = on ? M.reroot.chain_i[4 * j + 1] : 0, vo = on ? M.reroot.chain_i[4 * j + 2] : 0;
+      cq[j] = on ? q[(long)qo * Lq.sk + stc * Lq.sb] : T(0);
+      cv[j] = (on && v) ? v[(long)vo * Lv.sk + stc * Lv.sb] : T(0);
+    }
+  }
   // ---- per-body set-up (once per bank, every lane busy): joint transform and joint twist in the joint frame ----
   // The global loads of BOTH banks are issued up front (two dependent round trips: body record, then q / v / tau), so that
   // bank 1's latency hides behind bank 0's sweep; the arithmetic of a bank runs right before its own sweep.
@@ -183,6 +202,21 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     xmotion(c.R, c.p, tl, c.vJ);
 #pragma unroll
     for (int i = 0; i < 6; ++i) c.Tw[i] = c.vJ[i];
+    if (RR) {
+      if (c.b.valid && (c.b.flags & BFD_VROOT)) {  // qj, vj of this lane ARE the floating joint's coordinates (its record carries their offsets)
+        {  // the floating joint's force as a wrench in the root frame, S^-T tau_f: this lane holds tau_f (c.tj) and is about to build the old
+           // floating body's pose anyway; the old floating body picks the wrench up from this lane's LDS column in terms()
+          T Rf[9], pf[3], wf[6];
+          reroot_fb_pose(M.reroot, qj, Rf, pf);
+          xforce(Rf, pf, c.tj, wf);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) park[(PARK_WF + i) * 256] = wf[i];
+        }
+        reroot_root_kinematics<T, T>(M.reroot, qj, vj, cq, cv, c.R, c.p, c.Tw);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c.vJ[i] = c.Tw[i];  // as for a floating joint on the world: [T, vJ] = 0
+      }
+    }
   };
   // ---- per-body terms in the root frame: motion subspace, bias acceleration, inertia, bias force ----
   auto terms = [&](BankRegs<T>& c, bool accumulate) {  // accumulate: IA, pA already hold what the children handed up
@@ -215,7 +249,39 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     for (int i = 0; i < 6; ++i) c.U[i] = T(0);
     c.Dinv = T(0);
     c.u = T(0);
-    if (floating) xforce(c.R, c.p, c.tj, c.U);  // 6-dof joints (level 0): U carries S^-T tau; R, p stay parked for the top-down sweep
+    if (floating && !RR) xforce(c.R, c.p, c.tj, c.U);  // 6-dof joints (level 0): U carries S^-T tau; R, p stay parked for the top-down sweep
+    if (RR) {
+      if (c.b.valid && (c.b.flags & BFD_FCARRY)) {  // the floating joint's force acts on the old floating body: pA -= S^-T tau_f
+        const T* rootcol = park - c.b.sub;          // the root is slot 0 of bank 0 of this state: its LDS column
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c.pA[k] -= rootcol[(PARK_WF + k) * 256];
+      }
+    }
+  };
+  // RR: v̇ of the floating joint from the old floating body's spatial acceleration, v̇_f = S^-1 (a - a_world)
+  auto fb_accel_out = [&](const BankRegs<T>& c, bool bank0) {
+    if (c.b.valid && (c.b.flags & BFD_FCARRY)) {
+      T Rn[9], pn[3], Rf[9], pf[3], dd[6], vf[6];
+      if (bank0) {  // bank 0's transforms stay parked through the sweeps
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rn[i] = park[(PARK_KIN + i) * 256];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pn[i] = park[(PARK_KIN + 9 + i) * 256];
+        reroot_fb_pose_from_rebased<T, T>(M.reroot, Rn, pn, Rf, pf);
+      } else {  // (a tree whose old floating body ends up in bank 1: its pose again from the coordinates)
+        T q7[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) q7[k] = q[(long)(M.reroot.fq + k) * Lq.sk + c.b.state * Lq.sb];
+        reroot_fb_pose(M.reroot, q7, Rf, pf);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { dd[k] = c.acc[k]; dd[3 + k] = c.acc[3 + k] + T(M.gravity[k]); }
+      xmotion_inv(Rf, pf, dd, vf);
+      if (vdot) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vdot[(long)(M.reroot.fv + k) * Lv.sk + c.b.state * Lv.sb] = vf[k];
+      }
+    }
   };
 
   // ---- top-down: transforms to root and twists (update_transforms!, update_twists_wrt_world!) ----
@@ -314,13 +380,15 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
 #pragma unroll
         for (int i = 0; i < 6; ++i) rhs[i] = c.U[i] - c.pA[i];
         sym6_solve(c.IA, rhs, c.acc);
+        if (!RR) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) d[i] = c.acc[i] - a0[i];
+          for (int i = 0; i < 6; ++i) d[i] = c.acc[i] - a0[i];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Rs[i] = park[(PARK_KIN + i) * 256];
+          for (int i = 0; i < 9; ++i) Rs[i] = park[(PARK_KIN + i) * 256];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ps[i] = park[(PARK_KIN + 9 + i) * 256];
-        xmotion_inv(Rs, ps, d, c.vd);
+          for (int i = 0; i < 3; ++i) ps[i] = park[(PARK_KIN + 9 + i) * 256];
+          xmotion_inv(Rs, ps, d, c.vd);
+        }
       } else {
         bank_joint_accel(c, a0);
       }
@@ -333,8 +401,13 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     if (r0.b.level == l) bank_joint_accel(r0, ap);
   }
   RBD_MARK(10);
-  if (vdot) store_joint_v(r0.b, vdot, Lv, r0.vd);
-  if (F.stage >= 0) store_joint_v(r0.b, (T*)F.W.vd[F.stage], Lv, r0.vd);
+  if (RR) {
+    if (vdot && !(r0.b.flags & BFD_VROOT)) store_joint_v(r0.b, vdot, Lv, r0.vd);  // the virtual root owns no coordinates
+    fb_accel_out(r0, true);
+  } else {
+    if (vdot) store_joint_v(r0.b, vdot, Lv, r0.vd);
+    if (F.stage >= 0) store_joint_v(r0.b, (T*)F.W.vd[F.stage], Lv, r0.vd);
+  }
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     r1.U[i] = park[(PARK_FWD + i) * 256];
@@ -358,7 +431,8 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
   }
   RBD_MARK(11);
   if (vdot) store_joint_v(r1.b, vdot, Lv, r1.vd);
-  if (F.stage >= 0) store_joint_v(r1.b, (T*)F.W.vd[F.stage], Lv, r1.vd);
+  if (RR) fb_accel_out(r1, false);
+  else if (F.stage >= 0) store_joint_v(r1.b, (T*)F.W.vd[F.stage], Lv, r1.vd);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 #include "rbd_chain_plan.hpp"
 #include "rbd_track_plan.hpp"
 #include "rbd_walk_plan.hpp"
+#include "rbd_reroot.hpp"
 #include "rbd_state_plan.hpp"
 
 using namespace rbd;
@@ -75,6 +76,17 @@ struct rbd_model {
   uint64_t bank_perm_down = 0;
   ChainPlan chain;  // plan of aba_chain_kernel (chain.ok == false: mechanism outside its scope)
   TrackPlan track;  // plan of aba_track_kernel (track.ok == false: mechanism outside its scope)
+  // the tree re-rooted at its centre (rbd_reroot.hpp): its own slots, banks and track / walk plans; used by the ABA kernels that support it
+  Reroot rr;
+  struct RrSlots {
+    bool ok = false;
+    int32_t nlevels = 0, bank_lps = 0, bank_L0 = 0, bank_nb[2] = {0, 0};
+    uint64_t bank_perm_down = 0;
+    std::vector<int32_t> ib, nslots, bank_ib[2];
+    std::vector<double> rb, bank_rb[2];
+    TrackPlan track;
+    WalkPlan walk;
+  } rrs;
   // soft contact (src/contact.jl): points in the order of the additional state, half-spaces with unit normals
   int32_t ncp = 0, nhs = 0;
   std::vector<int32_t> cp_body;
@@ -89,6 +101,9 @@ struct rbd_ws {
   hipStream_t stream = nullptr;
   DevModel dm{};
   BankModel bm{}; void* d_bank_ib[2] = {nullptr, nullptr}; void* d_bank_rb[2] = {nullptr, nullptr};
+  // the re-rooted tree (rbd_reroot.hpp): banked records, chain table, walk plan
+  BankModel bm_rr{}; bool bank_rr = false; void* d_rrbank_ib[2] = {nullptr, nullptr}; void* d_rrbank_rb[2] = {nullptr, nullptr}; void* d_rr_chain_i = nullptr; void* d_rr_chain_r = nullptr;
+  WalkModel wm_rr{}; bool walk_rr = false; void* d_rrtrack_ri = nullptr; void* d_rrtrack_rr = nullptr; void* d_rrwalk_wk = nullptr; size_t walk_rr_lds_bytes = 0, walk_rr_lds_bytes_pair = 0;
   TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr; size_t track_lds_bytes4 = 0; long track_nw4_max_batch = 0; size_t track_lds_bytes = 0; long track_min_batch = 0;
   ContactModel ctm{}; void* d_cp_body = nullptr; void* d_cp_r = nullptr; void* d_hs_r = nullptr;  // soft contact tables
   void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; size_t d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
@@ -209,7 +224,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     if (level[s] + 1 > m->nlevels) m->nlevels = level[s] + 1;
     int32_t* ib = &m->ib[(size_t)s * IB_STRIDE];
     ib[IB_PARENT] = ps; ib[IB_JTYPE] = d->joint_type[i]; ib[IB_QOFF] = d->q_offset[i]; ib[IB_VOFF] = d->v_offset[i];
-    ib[IB_LEVEL] = level[s]; ib[IB_ORIG] = i;
+    ib[IB_LEVEL] = level[s]; ib[IB_ORIG] = i; ib[IB_FLAGS] = 0;
     if (d->joint_type[i] == RBD_JOINT_QUAT_FLOATING && ps >= 0) m->inner_floating = 1;
     const int nc = (int)kids[i].size();
     if (nc > IB_MAXCHILD) { delete m; return RBD_ERR_UNSUPPORTED; }
@@ -364,6 +379,101 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     if (m->track.ok) m->walk = build_walk_plan(m->track.ns, m->track.G, m->track.ri);
     if (m->nloops == 0) m->state = build_state_plan(nb, m->ib, m->rb);
   }
+  // ---- the same tree re-rooted at its centre, for the ABA kernels that take it (RBD_NO_REROOT=1 disables) ----
+  if (m->bank_aba_ok && !getenv("RBD_NO_REROOT")) {
+    m->rr = build_reroot(d);
+    if (m->rr.ok) {
+      const Reroot& R = m->rr;
+      rbd_model::RrSlots& S = m->rrs;
+      std::vector<std::vector<int>> kd(nb);
+      for (int i = 0; i < nb; ++i) if (R.parent[i] >= 0) kd[R.parent[i]].push_back(i);
+      std::vector<int> ord, slot(nb, -1), lev(nb, 0);
+      {
+        std::vector<int> stack{R.root};
+        while (!stack.empty()) {
+          const int i = stack.back(); stack.pop_back();
+          slot[i] = (int)ord.size();
+          ord.push_back(i);
+          for (auto it = kd[i].rbegin(); it != kd[i].rend(); ++it) stack.push_back(*it);
+        }
+      }
+      bool fits = (int)ord.size() == nb;
+      for (int i = 0; i < nb && fits; ++i) fits = (int)kd[i].size() <= IB_MAXCHILD;
+      if (fits) {
+        S.ib.assign((size_t)nb * IB_STRIDE, -1);
+        S.rb.assign((size_t)nb * RB_STRIDE, 0.0);
+        S.nslots.assign(MAX_LEVELS, 0);
+        for (int s2 = 0; s2 < nb; ++s2) {
+          const int i = ord[s2], p = R.parent[i], ps = p < 0 ? -1 : slot[p];
+          lev[s2] = ps < 0 ? 0 : lev[ps] + 1;
+          if (lev[s2] + 1 > S.nlevels) S.nlevels = lev[s2] + 1;
+          int32_t* ib = &S.ib[(size_t)s2 * IB_STRIDE];
+          ib[IB_PARENT] = ps; ib[IB_JTYPE] = R.jtype[i]; ib[IB_QOFF] = R.qoff[i]; ib[IB_VOFF] = R.voff[i]; ib[IB_LEVEL] = lev[s2]; ib[IB_ORIG] = i;
+          ib[IB_FLAGS] = R.flags[i];
+          ib[IB_NCHILD] = (int)kd[i].size();
+          for (int k = 0; k < (int)kd[i].size(); ++k) ib[IB_CHILD0 + k] = slot[kd[i][k]];
+          double* rb = &S.rb[(size_t)s2 * RB_STRIDE];
+          for (int k = 0; k < 3; ++k) { rb[RB_AXIS + k] = R.axis[3 * i + k]; rb[RB_AXIS2 + k] = R.axis2[3 * i + k]; rb[RB_XPP + k] = R.Xpp[3 * i + k]; rb[RB_MC + k] = R.mc[3 * i + k]; }
+          for (int k = 0; k < 9; ++k) rb[RB_XPR + k] = R.XpR[9 * i + k];
+          for (int k = 0; k < 6; ++k) rb[RB_J + k] = R.J6[6 * i + k];
+          rb[RB_M] = R.mass[i];
+        }
+        for (int s2 = 0; s2 < nb; ++s2) {
+          const int nc = S.ib[(size_t)s2 * IB_STRIDE + IB_NCHILD];
+          if (nc > 0 && nc > S.nslots[lev[s2] + 1]) S.nslots[lev[s2] + 1] = nc;
+        }
+        // banks (same rule as above)
+        std::vector<int> per_level(S.nlevels, 0);
+        for (int s2 = 0; s2 < nb; ++s2) per_level[lev[s2]]++;
+        int best_L0 = 0, best_lanes = 1 << 30, best_diff = 1 << 30;
+        for (int L0 = 1; L0 < S.nlevels; ++L0) {
+          int cA = 0, cB = 0;
+          for (int l = 0; l < S.nlevels; ++l) (l < L0 ? cA : cB) += per_level[l];
+          int lanes = 1;
+          while (lanes < std::max(cA, cB)) lanes <<= 1;
+          const int diff = std::abs(cA - cB);
+          if (lanes < best_lanes || (lanes == best_lanes && diff < best_diff)) { best_lanes = lanes; best_L0 = L0; best_diff = diff; }
+        }
+        if (S.nlevels >= 2 && best_lanes < m->lps && best_lanes <= (m->bank_lps > 0 ? m->bank_lps : best_lanes)) {
+          S.bank_lps = best_lanes; S.bank_L0 = best_L0;
+          std::vector<int> bslot(nb, -1);
+          int cnt[2] = {0, 0};
+          for (int s2 = 0; s2 < nb; ++s2) bslot[s2] = cnt[lev[s2] >= best_L0]++;
+          S.bank_nb[0] = cnt[0]; S.bank_nb[1] = cnt[1];
+          for (int k = 0; k < 2; ++k) { S.bank_ib[k].assign((size_t)std::max(cnt[k], 1) * IB_STRIDE, -1); S.bank_rb[k].assign((size_t)std::max(cnt[k], 1) * RB_STRIDE, 0.0); }
+          for (int s2 = 0; s2 < nb; ++s2) {
+            const int k = lev[s2] >= best_L0, j = bslot[s2];
+            const int32_t* src = &S.ib[(size_t)s2 * IB_STRIDE];
+            int32_t* dst = &S.bank_ib[k][(size_t)j * IB_STRIDE];
+            memcpy(dst, src, sizeof(int32_t) * IB_STRIDE);
+            const int ps = src[IB_PARENT];
+            dst[IB_PARENT] = ps < 0 ? -1 : bslot[ps];
+            for (int c2 = 0; c2 < src[IB_NCHILD]; ++c2) dst[IB_CHILD0 + c2] = bslot[src[IB_CHILD0 + c2]];
+            if (ps >= 0 && lev[s2] != best_L0 && bslot[ps] != j - 1) S.bank_perm_down |= (uint64_t)1 << lev[s2];
+            memcpy(&S.bank_rb[k][(size_t)j * RB_STRIDE], &S.rb[(size_t)s2 * RB_STRIDE], sizeof(double) * RB_STRIDE);
+          }
+        }
+        // track / walk plans of the re-rooted tree (the walk kernels)
+        int nheads = 0;
+        for (int s2 = 0; s2 < nb; ++s2) {
+          const int ps = S.ib[(size_t)s2 * IB_STRIDE + IB_PARENT];
+          if (ps < 0 || S.ib[(size_t)ps * IB_STRIDE + IB_CHILD0] != s2) ++nheads;
+        }
+        int G = 1;
+        while (G < nheads && G < 4) G <<= 1;
+        S.track = build_track_plan(nb, S.ib, S.rb, G);
+        if (S.track.ok) {
+          S.walk = build_walk_plan(S.track.ns, S.track.G, S.track.ri);
+          if (S.walk.ok)
+            for (size_t k = 0; k < S.walk.wk.size(); ++k) {
+              const int e = S.track.tab[k];
+              if (e >= 0) S.walk.wk[k] |= S.ib[(size_t)e * IB_STRIDE + IB_FLAGS] << 8;
+            }
+        }
+        S.ok = true;
+      }
+    }
+  }
   *out = m;
   return RBD_OK;
 }
@@ -413,6 +523,30 @@ int rbd_model_track_plan(const rbd_model_t* m, int32_t* dims, int32_t* table, in
     memcpy(ri + P.ri.size(), P.sf.data(), P.sf.size() * sizeof(int32_t));
   }
   if (rr) { if (rr_cap < (int32_t)P.rr.size()) return RBD_ERR_DIMENSION_MISMATCH; memcpy(rr, P.rr.data(), P.rr.size() * sizeof(double)); }
+  return RBD_OK;
+}
+
+int rbd_model_reroot_plan(const rbd_model_t* m, int32_t* dims, int32_t* ri, int32_t ri_cap, double* rr, int32_t rr_cap, int32_t* wk, int32_t wk_cap,
+                          int32_t* chain_i, double* chain_r, double* fxp) {
+  if (!m) return RBD_ERR_INVALID_ARGUMENT;
+  if (!m->rrs.ok || !m->rrs.track.ok || !m->rrs.walk.ok) return RBD_ERR_UNSUPPORTED;
+  const TrackPlan& P = m->rrs.track;
+  const Reroot& R = m->rr;
+  const int nch = (int)(R.chain_i.size() / RC_I_STRIDE);
+  if (dims) {
+    const int32_t d[12] = {P.G, P.ns, P.nA, P.nB, P.has_floating, P.general, m->rrs.walk.nS, nch, R.fq, R.fv, R.root, R.fb};
+    memcpy(dims, d, sizeof d);
+  }
+  if (ri) {
+    if (ri_cap < (int32_t)(P.ri.size() + P.sf.size())) return RBD_ERR_DIMENSION_MISMATCH;
+    memcpy(ri, P.ri.data(), P.ri.size() * sizeof(int32_t));
+    memcpy(ri + P.ri.size(), P.sf.data(), P.sf.size() * sizeof(int32_t));
+  }
+  if (rr) { if (rr_cap < (int32_t)P.rr.size()) return RBD_ERR_DIMENSION_MISMATCH; memcpy(rr, P.rr.data(), P.rr.size() * sizeof(double)); }
+  if (wk) { if (wk_cap < (int32_t)m->rrs.walk.wk.size()) return RBD_ERR_DIMENSION_MISMATCH; memcpy(wk, m->rrs.walk.wk.data(), m->rrs.walk.wk.size() * sizeof(int32_t)); }
+  if (chain_i) memcpy(chain_i, R.chain_i.data(), R.chain_i.size() * sizeof(int32_t));
+  if (chain_r) memcpy(chain_r, R.chain_r.data(), R.chain_r.size() * sizeof(double));
+  if (fxp) memcpy(fxp, R.fXp, sizeof R.fXp);
   return RBD_OK;
 }
 
@@ -503,6 +637,51 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->bank_min_batch = 1536L * (64 / m->lps);
     if (const char* e = getenv("RBD_BANK_MIN_BATCH")) w->bank_min_batch = atol(e);
   }
+  if (m->rrs.ok) {
+    const Reroot& R = m->rr;
+    const rbd_model::RrSlots& S = m->rrs;
+    auto up_real = [&](void** dst, const std::vector<double>& src) {
+      if (dtype == RBD_F64) return upload(dst, src.data(), src.size() * sizeof(double));
+      std::vector<float> f(src.begin(), src.end());
+      return upload(dst, f.data(), f.size() * sizeof(float));
+    };
+    st = upload(&w->d_rr_chain_i, R.chain_i.data(), R.chain_i.size() * sizeof(int32_t));
+    if (st == RBD_OK) st = up_real(&w->d_rr_chain_r, R.chain_r);
+    RerootView V{};
+    V.nchain = (int32_t)(R.chain_i.size() / RC_I_STRIDE); V.fq = R.fq; V.fv = R.fv;
+    V.chain_i = (const int32_t*)w->d_rr_chain_i; V.chain_r = w->d_rr_chain_r;
+    memcpy(V.fXp, R.fXp, sizeof V.fXp);
+    if (st == RBD_OK && S.bank_lps > 0) {
+      BankModel& bm = w->bm_rr;
+      for (int k = 0; k < 2 && st == RBD_OK; ++k) {
+        st = upload(&w->d_rrbank_ib[k], S.bank_ib[k].data(), S.bank_ib[k].size() * sizeof(int32_t));
+        if (st == RBD_OK) st = up_real(&w->d_rrbank_rb[k], S.bank_rb[k]);
+        bm.ib[k] = (const int32_t*)w->d_rrbank_ib[k]; bm.rb[k] = w->d_rrbank_rb[k]; bm.nbk[k] = S.bank_nb[k];
+      }
+      bm.lps = S.bank_lps; bm.nlevels = S.nlevels; bm.L0 = S.bank_L0; bm.perm_down = S.bank_perm_down; bm.reroot = V;
+      for (int l = 0; l < MAX_LEVELS; ++l) bm.nslots[l] = (uint8_t)S.nslots[l];
+      memcpy(bm.gravity, m->gravity, sizeof bm.gravity);
+      w->bank_rr = st == RBD_OK;
+    }
+    if (st == RBD_OK && S.track.ok && S.walk.ok) {
+      const TrackPlan& P = S.track;
+      st = upload(&w->d_rrtrack_ri, P.ri.data(), P.ri.size() * sizeof(int32_t));
+      if (st == RBD_OK) st = up_real(&w->d_rrtrack_rr, P.rr);
+      if (st == RBD_OK) st = upload(&w->d_rrwalk_wk, S.walk.wk.data(), S.walk.wk.size() * sizeof(int32_t));
+      WalkModel& wm = w->wm_rr;
+      wm.ns = P.ns; wm.G = P.G; wm.nA = P.nA; wm.nB = P.nB; wm.nS = S.walk.nS; wm.nq = m->nq; wm.nv = m->nv; wm.reroot = V;
+      wm.ri = (const int32_t*)w->d_rrtrack_ri; wm.rr = w->d_rrtrack_rr; wm.wk = (const int32_t*)w->d_rrwalk_wk;
+      for (int k = 0; k < 5; ++k) { wm.sfm[k] = 0; for (int s2 = 0; s2 < P.ns; ++s2) wm.sfm[k] |= (uint64_t)((P.sf[s2] >> k) & 1) << s2; }
+      memcpy(wm.gravity, m->gravity, sizeof wm.gravity);
+      const size_t es2 = dtype == RBD_F64 ? 8 : 4;
+      w->walk_rr_lds_bytes = walk_lds_bytes(P.ns, P.G, m->nq, m->nv, P.nA, P.nB, S.walk.nS, es2, es2);
+      if (w->walk_rr_lds_bytes > 160 * 1024) w->walk_rr_lds_bytes = 0;
+      w->walk_rr_lds_bytes_pair = dtype == RBD_F32 ? walk_lds_bytes(P.ns, P.G, m->nq, m->nv, P.nA, P.nB, S.walk.nS, 8, 4) : 0;
+      if (w->walk_rr_lds_bytes_pair > 160 * 1024) w->walk_rr_lds_bytes_pair = 0;
+      w->walk_rr = st == RBD_OK && (w->walk_rr_lds_bytes > 0 || w->walk_rr_lds_bytes_pair > 0);
+    }
+    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+  }
   if (m->chain.ok) {
     const ChainPlan& P = m->chain;
     st = upload(&w->d_chain_tab, P.tab.data(), P.tab.size() * sizeof(int32_t));
@@ -578,8 +757,9 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->walk_lds_bytes_pair = dtype == RBD_F32 ? walk_lds_bytes(P.ns, P.G, m->nq, m->nv, P.nA, P.nB, m->walk.nS, 8, 4) : 0;
     if (w->walk_lds_bytes_pair > 160 * 1024) w->walk_lds_bytes_pair = 0;
     {
-      const hipError_t e = dtype == RBD_F64 ? configure_walk_kernel<double>(P.has_floating, P.general, w->walk_lds_bytes, 0)
-                                            : configure_walk_kernel<float>(P.has_floating, P.general, w->walk_lds_bytes, w->walk_lds_bytes_pair);
+      const size_t l1 = std::max(w->walk_lds_bytes, w->walk_rr ? w->walk_rr_lds_bytes : (size_t)0), l2 = std::max(w->walk_lds_bytes_pair, w->walk_rr ? w->walk_rr_lds_bytes_pair : (size_t)0);
+      const hipError_t e = dtype == RBD_F64 ? configure_walk_kernel<double>(P.has_floating, P.general, l1, 0)
+                                            : configure_walk_kernel<float>(P.has_floating, P.general, l1, l2);
       if (e != hipSuccess) { g_last_hip_error = std::string("configure_walk_kernel: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
     }
     // the packed form from the batch size at which the 64-state workgroups no longer fit the chip in one round (RBD_WALK_PAIR_MIN_BATCH overrides)
@@ -638,7 +818,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_rrbank_ib[0], w->d_rrbank_ib[1], w->d_rrbank_rb[0], w->d_rrbank_rb[1], w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -848,13 +1028,17 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   Timed t(w);
   w->last_kernel = pick == RBD_ALGO_ABA_TRACKS ? "aba_track_kernel" : pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : pick == RBD_ALGO_ABA_CHAINS ? "aba_chain_kernel" : "aba_kernel";
   if (pick == RBD_ALGO_ABA_WALK) {
-    WalkModel wm = w->wm;
-    if (gravity) memcpy(wm.gravity, gravity, sizeof wm.gravity);
-    w->last_kernel = "aba_walk_kernel";
+    // the tree re-rooted at its centre (rbd_reroot.hpp) when there is one: fewer steps per track, better balanced tracks (RBD_WALK_NO_REROOT=1: the original tree)
+    static const bool no_rr = getenv("RBD_WALK_NO_REROOT") != nullptr;
     const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
-    if (pair) w->last_kernel = "aba_walk_kernel (two fp32 states per lane)";
-    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, m->track.has_floating, m->track.general, 0, B, w->walk_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_aba_walk<float>(wm, m->track.has_floating, m->track.general, pair, B, pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    const bool rr = w->walk_rr && !no_rr && (pair ? w->walk_rr_lds_bytes_pair : w->walk_rr_lds_bytes) > 0;
+    WalkModel wm = rr ? w->wm_rr : w->wm;
+    if (gravity) memcpy(wm.gravity, gravity, sizeof wm.gravity);
+    w->last_kernel = pair ? "aba_walk_kernel (two fp32 states per lane)" : "aba_walk_kernel";
+    const TrackPlan& TP = rr ? m->rrs.track : m->track;
+    const size_t lds = rr ? (pair ? w->walk_rr_lds_bytes_pair : w->walk_rr_lds_bytes) : (pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, TP.has_floating, TP.general, 0, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_aba_walk<float>(wm, TP.has_floating, TP.general, pair, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
   } else if (pick == RBD_ALGO_ABA_TRACKS) {
     TrackModel tm = w->tm;
     if (gravity) memcpy(tm.gravity, gravity, sizeof tm.gravity);
@@ -864,7 +1048,13 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_track<double>(tm, flt, gen, nw, B, w->track_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba_track<float>(tm, flt, gen, nw, B, w->track_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
   } else if (pick == RBD_ALGO_ABA_BANKS) {
-    BankModel bm = w->bm;
+    // the tree re-rooted at its centre (fewer levels to sweep) whenever the launch is a plain dynamics! (rbd_reroot.hpp)
+    // Opt-in (RBD_BANK_REROOT=1): measured on Atlas at 26.8 vs 27.0 us — the two levels saved in the bottom-up and top-down sweeps (-6.4 k
+    // cycles) are paid back by the root's pose, which is the forward kinematics of the reversed chain run serially on one lane (+9 k)
+    static const bool bank_reroot = getenv("RBD_BANK_REROOT") != nullptr;
+    const bool rr = w->bank_rr && !fuse && bank_reroot;
+    BankModel bm = rr ? w->bm_rr : w->bm;
+    if (rr) w->last_kernel = "aba_bank_kernel (tree re-rooted at its centre)";
     if (gravity) memcpy(bm.gravity, gravity, sizeof bm.gravity);
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_bank<double>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
     else HIP_TRY(launch_aba_bank<float>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));

@@ -14,10 +14,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rbd_hip.h"  // RBD_JOINT_*
+
 namespace rbd {
 
 // per-body integer record
-enum { IB_PARENT = 0, IB_JTYPE = 1, IB_QOFF = 2, IB_VOFF = 3, IB_LEVEL = 4, IB_NCHILD = 5, IB_ORIG = 6, IB_CHILD0 = 7, IB_MAXCHILD = 6, IB_STRIDE = IB_CHILD0 + IB_MAXCHILD };
+enum { IB_PARENT = 0, IB_JTYPE = 1, IB_QOFF = 2, IB_VOFF = 3, IB_LEVEL = 4, IB_NCHILD = 5, IB_ORIG = 6, IB_CHILD0 = 7, IB_MAXCHILD = 6, IB_FLAGS = IB_CHILD0 + IB_MAXCHILD /* BF_* of a re-rooted tree (rbd_reroot.hpp), 0 otherwise */, IB_STRIDE = IB_FLAGS + 1 };
+// A floating-base tree re-rooted at its centre (rbd_reroot.hpp): what the kernels need beyond the ordinary per-body records.
+//   chain_i[k * 4] = joint type, q offset, v offset of the k-th joint on the way from the old floating body to the new root;
+//   chain_r[k * 15] = its axis (3) and joint_to_predecessor R (9), p (3) — ORIGINAL constants, kernel scalar type
+enum { BFD_VROOT = 1, BFD_FCARRY = 2 };
+struct RerootView {
+  int32_t nchain, fq, fv, _pad;
+  const int32_t* chain_i;
+  const void* chain_r;
+  double fXp[12];  // the floating joint's joint_to_predecessor (R row-major, p)
+};
 // per-body real record: axis(3) axis2(3) XpR(9) Xpp(3) J(6: xx xy xz yy yz zz) mc(3) m(1)
 enum { RB_AXIS = 0, RB_AXIS2 = 3, RB_XPR = 6, RB_XPP = 15, RB_J = 18, RB_MC = 24, RB_M = 27, RB_STRIDE = 28 };
 enum { MAX_LEVELS = 64 };
@@ -69,6 +81,7 @@ struct ChainModel {
 struct BankModel {
   int32_t lps, nlevels, L0;
   int32_t nbk[2];
+  RerootView reroot;           // aba_bank_kernel<T, true> only (nchain > 0)
   const int32_t* ib[2];
   const void* rb[2];
   uint64_t perm_down;          // bit l: the in-bank top-down hop at level l needs ds_bpermute (some parent is not the previous lane)
@@ -96,6 +109,7 @@ struct TrackModel {
 // ---- the track schedule with one wavefront per track and one lane per state (aba_walk_kernel, rbd_walk.hpp; rbd_walk_plan.hpp) ----
 struct WalkModel {
   int32_t ns, G, nA, nB, nS, nq, nv;
+  RerootView reroot;  // nchain > 0: the plan is that of the re-rooted tree (wk carries BFD_* in bits 8..9)
   const int32_t* ri;  // [ns * G * TI_STRIDE]  track-plan records
   const void* rr;     // [ns * G * TR_STRIDE]  ... constants, kernel scalar type
   const int32_t* wk;  // [ns * G]              parking slots (rbd_walk_plan.hpp)
@@ -494,5 +508,79 @@ RBD_HD void sincos_fast(f2 x, f2* s, f2* c) {
 // scalar type and states per lane of a kernel value type
 template <typename T> struct Lanes { using S = T; enum { N = 1 }; };
 template <> struct Lanes<f2> { using S = float; enum { N = 2 }; };
+
+// ---- the floating base of a re-rooted tree (rbd_reroot.hpp) ------------------------------------------------------------------------
+// pose of the OLD floating body in the world from its coordinates: H = joint_to_predecessor ∘ (R(quat), trans)  (quaternion_floating.jl:81-83)
+template <typename T> RBD_HD void reroot_fb_pose(const RerootView& V, const T* q7, T* R, T* p) {
+  T Rq[9], X[9], t3[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) X[k] = T(V.fXp[k]);
+  rot_quat(q7[0], q7[1], q7[2], q7[3], Rq);
+  matmul3(X, Rq, R);
+  matvec3(X, q7 + 4, t3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) p[k] = t3[k] + T(V.fXp[9 + k]);
+}
+// pose and twist of the NEW root: walk the chain of original joints from the old floating body.  q7 / v6: the floating joint's coordinates;
+// cq[j] / cv[j]: coordinate and velocity of the j-th chain joint (the caller fetched them with its first batch of loads — a dependent
+// global round trip here would sit on the critical path of the launch).  S: the scalar type of the chain table.
+enum { RC_MAX = 4 };  // longest chain the kernels take (the host does not re-root beyond it)
+template <typename T, typename S>
+RBD_HD void reroot_root_kinematics(const RerootView& V, const T* q7, const T* v6, const T* cq, const T* cv, T* R, T* p, T* Tw) {
+  reroot_fb_pose(V, q7, R, p);
+  xmotion(R, p, v6, Tw);
+  const S* cr = reinterpret_cast<const S*>(V.chain_r);
+#pragma unroll
+  for (int j = 0; j < RC_MAX; ++j) {
+    if (j < V.nchain) {
+      const int jt = V.chain_i[4 * j];
+      const S* c = cr + 15 * j;
+      const T ax[3] = {T(c[0]), T(c[1]), T(c[2])};
+      T XR[9], Xp[3], Rj[9], pj[3] = {T(0), T(0), T(0)}, tl[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { XR[k] = T(c[3 + k]); Rj[k] = (k % 4 == 0) ? T(1) : T(0); }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Xp[k] = T(c[12 + k]);
+      if (jt == RBD_JOINT_REVOLUTE) {
+        T sn, cs;
+        sincos_fast(cq[j], &sn, &cs);
+        rot_axis_sc(ax, sn, cs, Rj);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tl[k] = ax[k] * cv[j];
+      } else if (jt == RBD_JOINT_PRISMATIC) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pj[k] = ax[k] * cq[j]; tl[3 + k] = ax[k] * cv[j]; }
+      }
+      // H <- H ∘ (XR, Xp) ∘ (Rj, pj)
+      T A[9], a3[3], b3[3], vJ[6];
+      matmul3(R, XR, A);
+      matvec3(R, Xp, a3);
+      matvec3(A, pj, b3);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p[k] += a3[k] + b3[k];
+      matmul3(A, Rj, R);
+      xmotion(R, p, tl, vJ);  // the joint's twist is given in its frame_after = the body frame just reached
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Tw[k] += vJ[k];
+    }
+  }
+}
+// pose of the old floating body in its ORIGINAL frame from its pose in the re-based frame: H = H' ∘ E⁻¹, E = joint_to_predecessor of the
+// first chain joint (chain_r[3..14])
+template <typename T, typename S> RBD_HD void reroot_fb_pose_from_rebased(const RerootView& V, const T* Rn, const T* pn, T* R, T* p) {
+  const S* c = reinterpret_cast<const S*>(V.chain_r);
+  T E[9], Ep[3], t3[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) E[k] = T(c[3 + k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) Ep[k] = T(c[12 + k]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = Rn[3 * i] * E[3 * j] + Rn[3 * i + 1] * E[3 * j + 1] + Rn[3 * i + 2] * E[3 * j + 2];  // Rn E'
+  matvec3(R, Ep, t3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) p[k] = pn[k] - t3[k];
+}
 
 }  // namespace rbd

@@ -20,6 +20,7 @@ template <typename T> struct Body {
   int parent, jtype, qoff, voff, level, nchild, orig;
   int child[IB_MAXCHILD];
   int plane;  // lane of the parent body (own lane if parent is the world)
+  int flags;  // BFD_* of a re-rooted tree (0 otherwise)
   // lane bookkeeping
   int lane, sub, base;
   long state;
@@ -93,6 +94,7 @@ template <typename T> RBD_DEV void load_body(const DevModel& M, long B, Body<T>&
   b.level = b.valid ? ib[IB_LEVEL] : -1;  // idle lanes never commit
   b.nchild = ib[IB_NCHILD];
   b.orig = ib[IB_ORIG];
+  b.flags = ib[IB_FLAGS];
 #pragma unroll
   for (int k = 0; k < IB_MAXCHILD; ++k) b.child[k] = ib[IB_CHILD0 + k];
   b.plane = b.parent >= 0 ? b.base + b.parent : b.lane;
@@ -1063,9 +1065,13 @@ hipError_t launch_aba_bank(const BankModel& M, long B, const void* q, const void
   F.stage = -1;
   if (fuse) F = *fuse;
   const long spw = 64 / M.lps, waves = (B + spw - 1) / spw;
-  const size_t lds = (size_t)PARK_SLOTS * 256 * sizeof(T);
-  hipLaunchKernelGGL(aba_bank_kernel<T>, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
-                     (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf, F);
+  const size_t lds = (size_t)(M.reroot.nchain > 0 ? PARK_SLOTS_RR : PARK_SLOTS) * 256 * sizeof(T);
+  if (M.reroot.nchain > 0)  // the records are those of the re-rooted tree (never with a fused integrator stage)
+    hipLaunchKernelGGL((aba_bank_kernel<T, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
+                       (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf, F);
+  else
+    hipLaunchKernelGGL((aba_bank_kernel<T, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, M, B, (const T*)q, (const T*)v, (const T*)tau,
+                       (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf, F);
   return hipGetLastError();
 }
 // Dynamic-LDS limits of the kernels that ask for more than the default; a function attribute of the CURRENT device, so
@@ -1076,8 +1082,11 @@ template <typename T> static hipError_t raise_chain_lds(int G, size_t bytes) {
   return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 template <typename T> hipError_t configure_kernels(int chain_G, size_t chain_lds_bytes) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_bank_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_bank_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)((size_t)PARK_SLOTS * 256 * sizeof(T)));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_bank_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)PARK_SLOTS_RR * 256 * sizeof(T)));
   if (e == hipSuccess && chain_G > 0 && chain_lds_bytes > 48 * 1024) e = raise_chain_lds<T>(chain_G, chain_lds_bytes);
   return e;
 }

@@ -35,7 +35,7 @@ namespace rbd {
   switch (s) {                                                                                                                    \
     RBD_WALK_CASE(0, __VA_ARGS__) RBD_WALK_CASE(1, __VA_ARGS__) RBD_WALK_CASE(2, __VA_ARGS__) RBD_WALK_CASE(3, __VA_ARGS__)        \
     RBD_WALK_CASE(4, __VA_ARGS__) RBD_WALK_CASE(5, __VA_ARGS__) RBD_WALK_CASE(6, __VA_ARGS__) RBD_WALK_CASE(7, __VA_ARGS__)        \
-    RBD_WALK_CASE(8, __VA_ARGS__) RBD_WALK_CASE(9, __VA_ARGS__) RBD_WALK_CASE(10, __VA_ARGS__) RBD_WALK_CASE(11, __VA_ARGS__)      \
+    RBD_WALK_CASE(8, __VA_ARGS__) RBD_WALK_CASE(9, __VA_ARGS__) RBD_WALK_CASE(10, __VA_ARGS__)                                    \
     default: break;                                                                                                               \
   }
 
@@ -100,6 +100,7 @@ template <typename T> struct WalkCtx {
   const I4* tri; const int32_t* twk; const typename Lanes<T>::S* trr;  // the constants are scalars: the states of a lane share them
   T* rows;
   int rq, rv, rt, rA, rS, rB;  // first row of q | v | τ / v̇ | A mailboxes | parking slots | B mailboxes (pass C: its mailboxes)
+  RerootView rrv;              // the re-rooted tree's floating base (M.reroot with the chain table where this code can read it fast)
   T a0[6];
 };
 
@@ -109,10 +110,23 @@ template <typename T> RBD_HD void walk_ctx_lds(WalkCtx<T>& c, void* lds) {
   using S = typename Lanes<T>::S;
   c.trr = reinterpret_cast<const S*>(c.tri + nrec);
   c.twk = reinterpret_cast<const int32_t*>(c.trr + nrec * TR_STRIDE);
-  c.rows = reinterpret_cast<T*>(reinterpret_cast<char*>(lds) + nrec * 16 + nrec * TR_STRIDE * sizeof(S) + ((nrec * 4 + 15) & ~(size_t)15));
+  char* after = reinterpret_cast<char*>(lds) + nrec * 16 + nrec * TR_STRIDE * sizeof(S) + ((nrec * 4 + 15) & ~(size_t)15);
+  c.rrv = c.M.reroot;  // the chain table of a re-rooted tree is copied behind the parking words by the prologue (walk_stage_chain)
+  c.rrv.chain_i = reinterpret_cast<const int32_t*>(after);
+  c.rrv.chain_r = after + 64;
+  c.rows = reinterpret_cast<T*>(after + 64 + ((RC_MAX * 15 * sizeof(S) + 15) & ~(size_t)15));
   c.rq = 0; c.rv = c.M.nq; c.rt = c.rv + c.M.nv; c.rA = c.rt + c.M.nv; c.rS = c.rA + c.M.nA * WMB_A; c.rB = c.rS + c.M.nS * WMB_S;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { c.a0[k] = T(0); c.a0[3 + k] = T(-c.M.gravity[k]); }  // a_world = −gravity (mechanism_algorithms.jl:405)
+}
+template <typename T> RBD_HD void walk_stage_chain(const WalkCtx<T>& c, int tid, int nth) {
+  using S = typename Lanes<T>::S;
+  const int n = c.M.reroot.nchain;
+  int32_t* di = const_cast<int32_t*>(c.rrv.chain_i);
+  S* dr = reinterpret_cast<S*>(const_cast<void*>(c.rrv.chain_r));
+  const S* sr = reinterpret_cast<const S*>(c.M.reroot.chain_r);
+  for (int i = tid; i < n * 4; i += nth) di[i] = c.M.reroot.chain_i[i];
+  for (int i = tid; i < n * 15; i += nth) dr[i] = sr[i];
 }
 template <typename T> RBD_HD T* walk_row(const WalkCtx<T>& c, int row, int lane) { return c.rows + (long)row * WR_STRIDE + lane; }
 // the scalar of state st (0 <= st < 64 N) of the workgroup in a row: lane st mod 64, component st div 64
@@ -146,7 +160,7 @@ template <typename T> RBD_HD void walk_init_c(WalkRegs<T>& W) {
   for (int k = 0; k < 6; ++k) W.ad[k] = T(0);
 }
 
-struct WalkRec { int flags, qoff, voff, orig6, nbr, a_w, a_r, b_w, b_r0, park; };
+struct WalkRec { int flags, qoff, voff, orig6, nbr, a_w, a_r, b_w, b_r0, park, rrf; };  // rrf: BFD_* of a re-rooted tree
 // the raw words of a record: read from LDS a step ahead (walk_raw), made wave-uniform scalars when the step starts (walk_rec)
 struct WalkRaw { I4 w; int32_t k; };
 template <typename T> RBD_HD WalkRaw walk_raw(const WalkCtx<T>& c, int s, int g) {
@@ -160,7 +174,9 @@ RBD_HD WalkRec walk_rec(const WalkRaw& raw) {
   const int x = walk_uniform(raw.w.x), y = walk_uniform(raw.w.y), z = walk_uniform(raw.w.z), ww = walk_uniform(raw.w.w);
   r.flags = (y >> 16) & 0xff; r.qoff = x & 0xffff; r.voff = (x >> 16) & 0xffff; r.orig6 = y & 0xffff; r.nbr = (y >> 24) & 0x7f;
   r.a_w = (z & 0xffff) - 1; r.a_r = ((z >> 16) & 0xffff) - 1; r.b_w = (ww & 0xffff) - 1; r.b_r0 = ((ww >> 16) & 0xffff) - 1;
-  r.park = walk_uniform(raw.k) - 1;
+  const int kk = walk_uniform(raw.k);
+  r.park = (kk & 0xff) - 1;
+  r.rrf = (kk >> 8) & 3;
   if (r.flags & TF_FIXED) { r.qoff = 0; r.voff = 0; }  // a fixed joint has no coordinates: its offsets may be one past the end
   return r;
 }
@@ -265,6 +281,30 @@ RBD_HD void walk_step_a(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
   for (int k = 0; k < 6; ++k) aJ[k] = T(0);
   bool done = false;
   if (FLT) {
+    if ((r.flags & TF_FLOATING) && (r.rrf & BFD_VROOT)) {
+      // the root of a tree re-rooted at its centre (rbd_reroot.hpp): pose and twist through the chain of original joints from the old
+      // floating body's coordinates; a_vp = a_world.  q̇ of the floating joint is written by the old floating body in pass C.
+      using SS = typename Lanes<T>::S;
+      T q7[7], v6[6], cq[RC_MAX], cv[RC_MAX];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) q7[k] = *walk_row(c, c.rq + c.rrv.fq + k, lane);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v6[k] = *walk_row(c, c.rv + c.rrv.fv + k, lane);
+#pragma unroll
+      for (int j = 0; j < RC_MAX; ++j) {
+        const bool on = j < c.rrv.nchain;
+        cq[j] = on ? *walk_row(c, c.rq + c.rrv.chain_i[4 * j + 1], lane) : T(0);
+        cv[j] = on ? *walk_row(c, c.rv + c.rrv.chain_i[4 * j + 2], lane) : T(0);
+      }
+      reroot_root_kinematics<T, SS>(c.rrv, q7, v6, cq, cv, W.R, W.p, W.Tw);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W.av[k] = c.a0[k];
+      if (RNEA) {  // the full acceleration of the new root would need the chain's v̇ as well: the inverse-dynamics kernel keeps the original tree
+      }
+      if (r.a_w >= 0) walk_put_kin(walk_row(c, c.rA + r.a_w * WMB_A, lane), W);
+      if (r.park >= 0) walk_put_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);
+      return;
+    }
     if (r.flags & TF_FLOATING) {
       T q7[7], v6[6];
 #pragma unroll
@@ -330,6 +370,22 @@ RBD_HD void walk_step_a(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
   if (r.park >= 0) walk_put_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);  // pass B will not arrive here from a chained child
 }
 
+// Pass B, re-rooted tree, the OLD floating body (before its ordinary step, and before that step's constants are fetched — few values are
+// live here, and the register allocator must stay clear of WalkStash's accumulation registers): the floating joint's force is one more
+// external wrench S⁻ᵀτ_f on the body (S = X(H) of its original frame, from q_f); the rows of τ_f then take the part of v̇_f this pass knows,
+// a_vp − a_world in the root frame (pass C adds a_Δ).  fx: the body's external wrench, updated in place.
+template <typename T> RBD_HD void walk_fcarry_b(const WalkCtx<T>& c, const WalkRegs<T>& W, int lane, T* fx) {
+  T q7[7], t6[6], Rf[9], pf[3], wf[6];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) q7[k] = *walk_row(c, c.rq + c.rrv.fq + k, lane);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) t6[k] = *walk_row(c, c.rt + c.rrv.fv + k, lane);
+  reroot_fb_pose(c.rrv, q7, Rf, pf);
+  xforce(Rf, pf, t6, wf);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { fx[k] += wf[k]; *walk_row(c, c.rt + c.rrv.fv + k, lane) = W.av[k] - c.a0[k]; }
+}
+
 // ---------------- pass B (leaves -> root): articulated-body inertias and bias forces ----------------
 // fe: this body's external wrench (zero without); the caller has it in registers before the step (prefetched a step ahead)
 template <typename T, bool FLT, bool GEN>
@@ -361,16 +417,19 @@ RBD_HD void walk_step_b(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
   if (FLT) {
     if (r.flags & TF_FLOATING) {
       // 6-dof joint on the world: IA a_Δ = S⁻ᵀτ − p̃A, v̇ = S⁻¹ a_Δ  (S = X(H): the body-frame twist basis seen from the root)
+      // (the virtual root of a re-rooted tree: no joint force, and v̇ of the floating joint is read off the old floating body instead)
       T t6[6], f6[6], a[6], vd[6];
+      const bool vroot = r.rrf & BFD_VROOT;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) t6[k] = *walk_row(c, c.rt + r.voff + k, lane);
-      xforce(W.R, W.p, t6, f6);
+      for (int k = 0; k < 6; ++k) { t6[k] = vroot ? T(0) : *walk_row(c, c.rt + r.voff + k, lane); f6[k] = T(0); }
+      if (!vroot) xforce(W.R, W.p, t6, f6);
 #pragma unroll
       for (int k = 0; k < 6; ++k) f6[k] -= pA[k];
       sym6_solve(IA, f6, a);
       xmotion_inv(W.R, W.p, a, vd);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) *walk_row(c, c.rt + r.voff + k, lane) = vd[k];
+      for (int k = 0; k < 6; ++k)
+        if (!vroot) *walk_row(c, c.rt + r.voff + k, lane) = vd[k];
       RBD_WALK_SWITCH(s, {
         St.template put<SV, WS_W + 0>(a[0]); St.template put<SV, WS_W + 1>(a[1]); St.template put<SV, WS_W + 2>(a[2]);
         St.template put<SV, WS_W + 3>(a[3]); St.template put<SV, WS_W + 4>(a[4]); St.template put<SV, WS_W + 5>(a[5]);
@@ -537,7 +596,7 @@ RBD_HD void walk_step_rb(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, 
 
 // ---------------- pass C (root -> leaves): v̇ and a_Δ ----------------
 template <typename T, bool FLT, bool GEN>
-RBD_HD void walk_step_c(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane) {
+RBD_HD void walk_step_c(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, bool want_qdot = false) {
   if (!(r.flags & TF_VALID)) return;
   if (!(r.flags & TF_CHAINED)) {
     if (r.flags & TF_LEVEL0) {
@@ -602,6 +661,33 @@ RBD_HD void walk_step_c(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
     T* m = walk_row(c, c.rB + r.a_w * WMB_C, lane);
 #pragma unroll
     for (int k = 0; k < 6; ++k) m[k * WR_STRIDE] = W.ad[k];
+  }
+  if (FLT) {
+    if (r.rrf & BFD_FCARRY) {  // v̇_f = S⁻¹ (a − a_world) = S⁻¹ ((a_vp − a_world) + a_Δ); then q̇ of the floating joint over its q rows
+      T q7[7], v6[6], Rf[9], pf[3], d6[6], vf[6];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) q7[k] = *walk_row(c, c.rq + c.rrv.fq + k, lane);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d6[k] = *walk_row(c, c.rt + c.rrv.fv + k, lane) + W.ad[k];
+      reroot_fb_pose(c.rrv, q7, Rf, pf);
+      xmotion_inv(Rf, pf, d6, vf);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) *walk_row(c, c.rt + c.rrv.fv + k, lane) = vf[k];
+      if (want_qdot) {  // velocity_to_configuration_derivative! (quaternion_floating.jl:126-136)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v6[k] = *walk_row(c, c.rv + c.rrv.fv + k, lane);
+        const T qw = q7[0], qx = q7[1], qy = q7[2], qz = q7[3];
+        T o[7], Rq[9];
+        o[0] = (-qx * v6[0] - qy * v6[1] - qz * v6[2]) / 2;
+        o[1] = (qw * v6[0] - qz * v6[1] + qy * v6[2]) / 2;
+        o[2] = (qz * v6[0] + qw * v6[1] - qx * v6[2]) / 2;
+        o[3] = (-qy * v6[0] + qx * v6[1] + qw * v6[2]) / 2;
+        rot_quat(qw, qx, qy, qz, Rq);
+        matvec3(Rq, v6 + 3, o + 4);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) *walk_row(c, c.rq + c.rrv.fq + k, lane) = o[k];
+      }
+    }
   }
 }
 
@@ -835,6 +921,7 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     for (int u = 0; u < TB; ++u)
       if (tid + u * nth < ntr) const_cast<S*>(c.trr)[tid + u * nth] = tr[u];
     for (int i = tid + TB * nth; i < ntr; i += nth) const_cast<S*>(c.trr)[i] = gr[i];
+    walk_stage_chain(c, tid, nth);
     if (fast) {
       walk_stage_in_fast<T, UB>(q, v, tau, state0, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
     } else if (fast_rows) {
@@ -905,6 +992,12 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     for (int s = ns - 1; s >= 0; --s) {
       const int s1 = s > 0 ? s - 1 : 0;
       const WalkRec r = walk_rec(raw);
+      if (FLT) {
+        if ((r.rrf & BFD_FCARRY) && (r.flags & TF_VALID)) {
+          if (r.park >= 0) walk_get_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);
+          walk_fcarry_b(c, W, lane, fe);
+        }
+      }
       T rr[TR_STRIDE];
       walk_consts<T, TR_STRIDE>(c, s, g, rr);
       raw = walk_raw(c, s1, g);
@@ -929,7 +1022,7 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
       raw = walk_raw(c, s1, g);
       T rn[TR_J];
       walk_consts<T, TR_J>(c, s1, g, rn);
-      walk_step_c<T, FLT, GEN>(c, W, St, s, r, rr, lane);
+      walk_step_c<T, FLT, GEN>(c, W, St, s, r, rr, lane, want_qdot);
 #pragma unroll
       for (int k = 0; k < TR_J; ++k) rr[k] = rn[k];
       if ((M.sfm[1] >> s) & 1) __syncthreads();
@@ -986,6 +1079,7 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
     for (int u = 0; u < TB; ++u)
       if (tid + u * nth < ntr) const_cast<S*>(c.trr)[tid + u * nth] = tr[u];
     for (int i = tid + TB * nth; i < ntr; i += nth) const_cast<S*>(c.trr)[i] = gr[i];
+    walk_stage_chain(c, tid, nth);
     if (fast) {
       walk_stage_in_fast<T, UB>(q, v, vdot, state0, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
     } else if (fast_rows) {

@@ -24,7 +24,7 @@ struct WalkPlan {
 
 // rows of 64 states (padded to WR_STRIDE scalars): q | v | tau (v̇ written over it) | A mailboxes | parking slots | B mailboxes (pass C re-uses
 // them for its 6-value mailboxes); then the plan records.  Must agree with walk_ctx_lds() of rbd_walk.hpp.
-enum { WR_STRIDE = 65, WMB_A = 24, WMB_B = 27, WMB_C = 6, WMB_S = 24, WALK_MAX_STEPS = 12 };
+enum { WR_STRIDE = 65, WMB_A = 24, WMB_B = 27, WMB_C = 6, WMB_S = 24, WALK_MAX_STEPS = 11 };
 inline size_t walk_rows(int nq, int nv, int nA, int nB, int nS) {
   const size_t bc = std::max((size_t)nB * WMB_B, (size_t)nA * WMB_C);
   return (size_t)nq + 2 * (size_t)nv + (size_t)nA * WMB_A + (size_t)nS * WMB_S + bc;
@@ -32,7 +32,8 @@ inline size_t walk_rows(int nq, int nv, int nA, int nB, int nS) {
 // es: bytes of a row value (one per lane: 8 for fp64 and for the packed pair of fp32 states), ss: bytes of a plan constant
 inline size_t walk_lds_bytes(int ns, int G, int nq, int nv, int nA, int nB, int nS, size_t es, size_t ss) {
   const size_t nrec = (size_t)ns * G;
-  return nrec * 16 + nrec * TR_STRIDE * ss + ((nrec * 4 + 15) & ~(size_t)15) + walk_rows(nq, nv, nA, nB, nS) * WR_STRIDE * es;
+  // plan records | constants | parking words | chain table of a re-rooted tree (RC_MAX joints: 4 ints + 15 constants each) | rows
+  return nrec * 16 + nrec * TR_STRIDE * ss + ((nrec * 4 + 15) & ~(size_t)15) + 64 + ((4 * 15 * ss + 15) & ~(size_t)15) + walk_rows(nq, nv, nA, nB, nS) * WR_STRIDE * es;
 }
 
 // ri: the packed records of the track plan ([ns * G * TI_STRIDE])

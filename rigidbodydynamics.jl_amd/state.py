@@ -513,6 +513,32 @@ def chain_plan(flat):
         L.rbd_model_destroy(h)
 
 
+def reroot_plan(flat):
+    """The walk kernels' plan for the tree re-rooted at its centre (`rbd_model_reroot_plan`, host-only; csrc/rbd_reroot.hpp): dict with `tracks`,
+    `steps`, `root` / `floating_body` (body indices), the packed records `ri` / `rr`, the parking words `wk` and the chain table; None when the
+    mechanism is not re-rooted (no floating base, already as shallow as it gets, chain too long or with joints that cannot be reversed)."""
+    import numpy as np
+    L = _capi.lib()
+    h = ctypes.c_void_p()
+    _raise(L.rbd_model_create(ctypes.cast(ctypes.byref(flat.c_struct()), ctypes.c_void_p), ctypes.byref(h)), "rbd_model_create")
+    try:
+        dims = np.zeros(12, np.int32)
+        pi = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        pd = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        st = L.rbd_model_reroot_plan(h, pi(dims), None, 0, None, 0, None, 0, None, None, None)
+        if st == 3:  # RBD_ERR_UNSUPPORTED
+            return None
+        _raise(st, "rbd_model_reroot_plan")
+        n, nch = int(dims[0]) * int(dims[1]), int(dims[7])
+        ri, rr, wk = np.zeros(n * 4 + int(dims[1]), np.int32), np.zeros(n * 24, np.float64), np.zeros(n, np.int32)
+        ci, cr, fxp = np.zeros(max(4 * nch, 1), np.int32), np.zeros(max(15 * nch, 1), np.float64), np.zeros(12, np.float64)
+        _raise(L.rbd_model_reroot_plan(h, None, pi(ri), ri.size, pd(rr), rr.size, pi(wk), wk.size, pi(ci), pd(cr), pd(fxp)), "rbd_model_reroot_plan")
+        return {"tracks": int(dims[0]), "steps": int(dims[1]), "root": int(dims[10]), "floating_body": int(dims[11]), "chain": nch, "dims": dims,
+                "ri": ri, "rr": rr, "wk": wk, "chain_i": ci, "chain_r": cr, "fxp": fxp}
+    finally:
+        L.rbd_model_destroy(h)
+
+
 def track_plan(flat):
     """The track-mapping plan of a mechanism (`rbd_model_track_plan`, host-only): dict with `tracks`, `steps`, `mailboxes` (A/C, B),
     `floating`, `general`, `table` (steps × tracks body indices, -1 = idle) and the packed records `ri` / `rr` the kernel reads;

@@ -31,6 +31,7 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
     memcpy(const_cast<I4*>(c.tri), M.ri, nrec * 16);
     memcpy(const_cast<S*>(c.trr), M.rr, nrec * TR_STRIDE * sizeof(S));
     memcpy(const_cast<int32_t*>(c.twk), M.wk, nrec * 4);
+    for (int t = 0; t < 64; ++t) walk_stage_chain(c, t, 64);
     auto state_of = [&](int l) { const long st = group * SPW + l; return st < B ? st : B - 1; };  // l: state of the workgroup, 0 <= l < 64 N
     for (int l = 0; l < SPW; ++l) {
       const long st = state_of(l);
@@ -72,6 +73,7 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
                 for (int j = 0; j < N; ++j) set_lane(fe[k], j, fext[(o6 + k) * Lf.sk + state_of(l + 64 * j) * Lf.sb]);
             }
             T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr);
+            if (FLT && !RNEA) { const WalkRec rc = walk_rec(walk_raw(c, s, g)); if ((rc.rrf & BFD_FCARRY) && (rc.flags & TF_VALID)) { if (rc.park >= 0) walk_get_kin(walk_row(c, c.rS + rc.park * WMB_S, l), W[g * 64 + l]); walk_fcarry_b(c, W[g * 64 + l], l, fe); } }
             if (RNEA) walk_step_rb<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
             else walk_step_b<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
           }
@@ -84,7 +86,7 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
       while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
       each_wave([&](int g) {
         for (int s = s0; s <= s1; ++s)
-          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_c<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l); }
+          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_c<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, qdot != nullptr); }
       });
       s0 = s1 + 1;
     }
@@ -106,13 +108,24 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
 
 template <typename T>  // T: double, float, or f2 (two fp32 states per lane)
 static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const double* gravity, int rnea, int reverse, int aos, long B, int nq, int nv, int nb, const void* q,
-                 const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info) {
+                 const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info, const int32_t* wk_rr, const int32_t* chain_i,
+                 const double* chain_r, const double* fxp) {
   WalkModel M;
+  memset(&M, 0, sizeof M);
   M.G = dims[0]; M.ns = dims[1]; M.nA = dims[2]; M.nB = dims[3]; M.nq = nq; M.nv = nv;
   const size_t nrec = (size_t)M.ns * M.G;
   std::vector<int32_t> riv(ri, ri + nrec * TI_STRIDE);
-  const WalkPlan P = build_walk_plan(M.ns, M.G, riv);
+  WalkPlan P = build_walk_plan(M.ns, M.G, riv);
   if (!P.ok) return 2;
+  using S0 = typename Lanes<T>::S;
+  std::vector<S0> crt;
+  if (wk_rr) {  // the plan of the tree re-rooted at its centre (rbd_model_reroot_plan): parking words with the BFD_* flags, chain table
+    P.wk.assign(wk_rr, wk_rr + nrec);
+    M.reroot.nchain = dims[7]; M.reroot.fq = dims[8]; M.reroot.fv = dims[9];
+    crt.assign(chain_r, chain_r + 15 * (size_t)dims[7]);
+    M.reroot.chain_i = chain_i; M.reroot.chain_r = crt.data();
+    memcpy(M.reroot.fXp, fxp, sizeof M.reroot.fXp);
+  }
   M.nS = P.nS;
   using S = typename Lanes<T>::S;
   if (info) { info[0] = P.nS; info[1] = (int32_t)walk_lds_bytes(M.ns, M.G, nq, nv, M.nA, M.nB, M.nS, sizeof(T), sizeof(S)); }
@@ -132,8 +145,9 @@ static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const
 
 // rnea = 0: dynamics! (x = τ in, y = v̇ out);  rnea = 1: inverse_dynamics! / dynamics_bias! (x = v̇ in or NULL, y = τ out)
 extern "C" int walk_emu_dynamics(const int32_t* dims, const int32_t* ri, const double* rr, const double* gravity, int f32, int reverse, int aos, long B, int nq,
-                                 int nv, int nb, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info, int rnea) {
-  if (f32 == 2) return emu_t<f2>(dims, ri, rr, gravity, rnea, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info);  // two fp32 states per lane
-  return f32 ? emu_t<float>(dims, ri, rr, gravity, rnea, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info)
-             : emu_t<double>(dims, ri, rr, gravity, rnea, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info);
+                                 int nv, int nb, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot, int32_t* info, int rnea,
+                                 const int32_t* wk_rr, const int32_t* chain_i, const double* chain_r, const double* fxp) {
+  if (f32 == 2) return emu_t<f2>(dims, ri, rr, gravity, rnea, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info, wk_rr, chain_i, chain_r, fxp);  // two fp32 states per lane
+  return f32 ? emu_t<float>(dims, ri, rr, gravity, rnea, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info, wk_rr, chain_i, chain_r, fxp)
+             : emu_t<double>(dims, ri, rr, gravity, rnea, reverse, aos, B, nq, nv, nb, q, v, tau, fext, vdot, qdot, info, wk_rr, chain_i, chain_r, fxp);
 }

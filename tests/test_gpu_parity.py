@@ -749,7 +749,7 @@ def test_dynamics_chains_random_trees(rbd, oracle, algorithm):
         except Exception:
             # banks: a tree too shallow or too small to split into two banks that save lanes; tracks: a chain so long that its
             # per-step LDS rows exceed one CU's 160 KB (RBD_ERR_UNSUPPORTED, the default then takes another mapping)
-            assert algorithm in ("aba_banks", "aba_tracks", "aba_walk")  # walk: more than 12 steps per track
+            assert algorithm in ("aba_banks", "aba_tracks", "aba_walk")  # walk: more than 11 steps per track
             continue
         ref = oracle.dynamics(model, q, v, tau, fe)
         got = host(result.vd, state)

@@ -29,8 +29,8 @@ def emu():
     return L
 
 
-def run_emu(emu, rbd, model, q, v, tau, fe, dtype=np.float64, aos=True, want_qdot=True, reverse=0, pair=False, rnea=False):
-    plan = rbd.track_plan(model)
+def run_emu(emu, rbd, model, q, v, tau, fe, dtype=np.float64, aos=True, want_qdot=True, reverse=0, pair=False, rnea=False, reroot=False):
+    plan = rbd.reroot_plan(model) if reroot else rbd.track_plan(model)
     assert plan is not None
     B = q.shape[0]
     conv = (lambda a: None if a is None else np.ascontiguousarray(a if aos else a.T, dtype=dtype))
@@ -41,7 +41,9 @@ def run_emu(emu, rbd, model, q, v, tau, fe, dtype=np.float64, aos=True, want_qdo
     info = np.zeros(2, np.int32)
     p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
     st = emu.walk_emu_dynamics(p(plan["dims"]), p(plan["ri"]), p(plan["rr"]), p(g), (2 if pair else 1) if dtype == np.float32 else 0, int(reverse), int(aos), ctypes.c_long(B),
-                               model.nq, model.nv, model.n_bodies, p(q_), p(v_), p(t_), p(f_), p(vd), p(qd) if want_qdot else None, p(info), int(rnea))
+                               model.nq, model.nv, model.n_bodies, p(q_), p(v_), p(t_), p(f_), p(vd), p(qd) if want_qdot else None, p(info), int(rnea),
+                               p(plan["wk"]) if reroot else None, p(plan["chain_i"]) if reroot else None, p(plan["chain_r"]) if reroot else None,
+                               p(plan["fxp"]) if reroot else None)
     assert st == 0
     return (vd if aos else vd.T).astype(np.float64), (qd if aos else qd.T).astype(np.float64), info
 
@@ -104,7 +106,7 @@ def test_walk_emulation_random_trees(emu, rbd, oracle):
         model = rbd.flatten(mech)
         plan = rbd.track_plan(model)
         assert plan is not None
-        if plan["steps"] > 12:
+        if plan["steps"] > 11:
             continue  # deeper than the accumulation registers hold: the library routes such trees to the other mappings
         done += 1
         B = 5
@@ -143,7 +145,7 @@ def test_walk_emulation_inverse_dynamics_random_trees_and_pairs(emu, rbd, oracle
         mech = random_tree(rbd, rng, int(rng.integers(1, 30)), bool(trial % 2), float(rng.uniform(0, 1)))
         model = rbd.flatten(mech)
         plan = rbd.track_plan(model)
-        if plan is None or plan["steps"] > 12 or model.nv == 0:
+        if plan is None or plan["steps"] > 11 or model.nv == 0:
             continue
         done += 1
         B = 5
@@ -156,3 +158,49 @@ def test_walk_emulation_inverse_dynamics_random_trees_and_pairs(emu, rbd, oracle
             got32, _, _ = run_emu(emu, rbd, model, q, v, vd, fe, dtype=np.float32, pair=True, rnea=True)
             assert np.abs(got32 - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), trial
     assert done >= 20
+
+
+@pytest.mark.parametrize("reverse", [0, 1])
+@pytest.mark.parametrize("aos", [True, False])
+@pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating"])
+def test_walk_emulation_rerooted_tree(emu, rbd, oracle, models, name, aos, reverse):
+    """The walk kernel's step code on the plan of the tree RE-ROOTED at its centre (csrc/rbd_reroot.hpp): Atlas is 11 bodies deep from the pelvis
+    and 9 from its middle torso link.  Same v̇ and q̇ as the oracle (whose tree hangs from the pelvis), torques and wrenches on every body."""
+    model = models[name]
+    plan = rbd.reroot_plan(model)
+    assert plan is not None and plan["steps"] < rbd.track_plan(model)["steps"] and plan["chain"] >= 1
+    B = 70
+    q, v, tau, fe = rand_inputs(rbd, model, B, 171, fext=True)
+    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    got, qd, _ = run_emu(emu, rbd, model, q, v, tau, fe, aos=aos, reverse=reverse, reroot=True)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(qd - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
+    ref = oracle.dynamics(model, q, v)
+    got, _, _ = run_emu(emu, rbd, model, q, v, None, None, aos=aos, want_qdot=False, reverse=reverse, reroot=True)
+    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+def test_walk_emulation_rerooted_random_floating_trees(emu, rbd, oracle):
+    from test_chain_plan import random_tree
+    rng = np.random.default_rng(31)
+    done = 0
+    for trial in range(60):
+        mech = random_tree(rbd, rng, int(rng.integers(4, 30)), True, float(rng.uniform(0, 1)))
+        model = rbd.flatten(mech)
+        plan = rbd.reroot_plan(model)
+        if plan is None or plan["steps"] > 11:
+            continue
+        done += 1
+        B = 5
+        q, v, tau, fe = rand_inputs(rbd, model, B, 500 + trial, fext=True)
+        ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+        got, qd, _ = run_emu(emu, rbd, model, q, v, tau, fe, reverse=trial % 2, reroot=True)
+        assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), (trial, plan["root"], plan["chain"])
+        assert np.abs(qd - qd_ref).max() <= 1e-12 * max(1.0, np.abs(qd_ref).max()), trial
+        if trial % 3 == 0:
+            got32, _, _ = run_emu(emu, rbd, model, q, v, tau, fe, dtype=np.float32, pair=True, reroot=True)
+            back = oracle.inverse_dynamics(model, q, v, got32, fe)
+            cb = oracle.dynamics_bias(model, q, v, fe)
+            assert (np.linalg.norm(back - tau, axis=1) / np.linalg.norm(tau - cb, axis=1)).max() <= 2e-4, trial
+    assert done >= 10, done
