@@ -187,21 +187,38 @@ template <typename T, int N> RBD_HD void walk_consts(const WalkCtx<T>& c, int s,
   for (int k = 0; k < N; ++k) rr[k] = T(src[k]);
 }
 
-template <typename T> RBD_HD void walk_put_kin(T* m, const WalkRegs<T>& W) {
+// m: transform (9 + 3 rows), mt: twist and velocity-product acceleration (6 + 6 rows)
+template <typename T> RBD_HD void walk_put_kin(T* m, T* mt, const WalkRegs<T>& W) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) m[k * WR_STRIDE] = W.R[k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) m[(9 + k) * WR_STRIDE] = W.p[k];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { m[(12 + k) * WR_STRIDE] = W.Tw[k]; m[(18 + k) * WR_STRIDE] = W.av[k]; }
+  for (int k = 0; k < 6; ++k) { mt[k * WR_STRIDE] = W.Tw[k]; mt[(6 + k) * WR_STRIDE] = W.av[k]; }
 }
-template <typename T> RBD_HD void walk_get_kin(const T* m, WalkRegs<T>& W) {
+template <typename T> RBD_HD void walk_get_kin(const T* m, const T* mt, WalkRegs<T>& W) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) W.R[k] = m[k * WR_STRIDE];
 #pragma unroll
   for (int k = 0; k < 3; ++k) W.p[k] = m[(9 + k) * WR_STRIDE];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { W.Tw[k] = m[(12 + k) * WR_STRIDE]; W.av[k] = m[(18 + k) * WR_STRIDE]; }
+  for (int k = 0; k < 6; ++k) { W.Tw[k] = mt[k * WR_STRIDE]; W.av[k] = mt[(6 + k) * WR_STRIDE]; }
+}
+// An A mailbox: the transform half lives until pass C has read it; the twist half is dead when pass A ends and sits in the rows the B
+// mailboxes take over (the kernels put a workgroup barrier between the two passes).  A parking slot is the two halves back to back.
+template <typename T> RBD_HD void walk_put_box(const WalkCtx<T>& c, int a, int lane, const WalkRegs<T>& W) {
+  walk_put_kin(walk_row(c, c.rA + a * WMB_A, lane), walk_row(c, c.rB + a * WMB_AT, lane), W);
+}
+template <typename T> RBD_HD void walk_get_box(const WalkCtx<T>& c, int a, int lane, WalkRegs<T>& W) {
+  walk_get_kin(walk_row(c, c.rA + a * WMB_A, lane), walk_row(c, c.rB + a * WMB_AT, lane), W);
+}
+template <typename T> RBD_HD void walk_put_park(const WalkCtx<T>& c, int k, int lane, const WalkRegs<T>& W) {
+  T* m = walk_row(c, c.rS + k * WMB_S, lane);
+  walk_put_kin(m, m + 12 * WR_STRIDE, W);
+}
+template <typename T> RBD_HD void walk_get_park(const WalkCtx<T>& c, int k, int lane, WalkRegs<T>& W) {
+  const T* m = walk_row(c, c.rS + k * WMB_S, lane);
+  walk_get_kin(m, m + 12 * WR_STRIDE, W);
 }
 
 // 1-dof joint in the canonical frame: (Rn, pn) = (R, p) * (C, pp) * joint(q), joint = rotation by (sn, cs) about z, or translation d along z
@@ -265,14 +282,14 @@ template <typename T> RBD_HD void walk_parent_kin(const WalkCtx<T>& c, const Wal
 #pragma unroll
     for (int k = 0; k < 6; ++k) { W.Tw[k] = T(0); W.av[k] = c.a0[k]; }
   } else {
-    walk_get_kin(walk_row(c, c.rA + r.a_r * WMB_A, lane), W);
+    walk_get_box(c, r.a_r, lane, W);
   }
 }
 
 // ---------------- pass A (root -> leaves): the kinematic chain ----------------
 // RNEA = true (rnea_walk_kernel): the τ rows hold v̇ on the way in, and the acceleration carried down is the full spatial acceleration
 // a_b = a_parent + [T_parent, S q̇] + S v̇ (spatial_accelerations!, mechanism_algorithms.jl:387-417) instead of its velocity-product part
-template <typename T, bool FLT, bool GEN, bool RNEA = false>
+template <typename T, bool FLT, bool GEN, bool RNEA = false, bool RR = false>
 RBD_HD void walk_step_a(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, bool want_qdot) {
   if (!(r.flags & TF_VALID)) return;
   walk_parent_kin(c, r, lane, W);
@@ -281,7 +298,7 @@ RBD_HD void walk_step_a(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
   for (int k = 0; k < 6; ++k) aJ[k] = T(0);
   bool done = false;
   if (FLT) {
-    if ((r.flags & TF_FLOATING) && (r.rrf & BFD_VROOT)) {
+    if (RR && (r.flags & TF_FLOATING) && (r.rrf & BFD_VROOT)) {
       // the root of a tree re-rooted at its centre (rbd_reroot.hpp): pose and twist through the chain of original joints from the old
       // floating body's coordinates; a_vp = a_world.  q̇ of the floating joint is written by the old floating body in pass C.
       using SS = typename Lanes<T>::S;
@@ -299,10 +316,8 @@ RBD_HD void walk_step_a(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
       reroot_root_kinematics<T, SS>(c.rrv, q7, v6, cq, cv, W.R, W.p, W.Tw);
 #pragma unroll
       for (int k = 0; k < 6; ++k) W.av[k] = c.a0[k];
-      if (RNEA) {  // the full acceleration of the new root would need the chain's v̇ as well: the inverse-dynamics kernel keeps the original tree
-      }
-      if (r.a_w >= 0) walk_put_kin(walk_row(c, c.rA + r.a_w * WMB_A, lane), W);
-      if (r.park >= 0) walk_put_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);
+      if (r.a_w >= 0) walk_put_box(c, r.a_w, lane, W);
+      if (r.park >= 0) walk_put_park(c, r.park, lane, W);
       return;
     }
     if (r.flags & TF_FLOATING) {
@@ -366,8 +381,8 @@ RBD_HD void walk_step_a(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
   for (int k = 0; k < 9; ++k) W.R[k] = Rn[k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) W.p[k] = pn[k];
-  if (r.a_w >= 0) walk_put_kin(walk_row(c, c.rA + r.a_w * WMB_A, lane), W);  // some child is not next on this track
-  if (r.park >= 0) walk_put_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);  // pass B will not arrive here from a chained child
+  if (r.a_w >= 0) walk_put_box(c, r.a_w, lane, W);  // some child is not next on this track
+  if (r.park >= 0) walk_put_park(c, r.park, lane, W);  // pass B will not arrive here from a chained child
 }
 
 // Pass B, re-rooted tree, the OLD floating body (before its ordinary step, and before that step's constants are fetched — few values are
@@ -388,10 +403,10 @@ template <typename T> RBD_HD void walk_fcarry_b(const WalkCtx<T>& c, const WalkR
 
 // ---------------- pass B (leaves -> root): articulated-body inertias and bias forces ----------------
 // fe: this body's external wrench (zero without); the caller has it in registers before the step (prefetched a step ahead)
-template <typename T, bool FLT, bool GEN>
+template <typename T, bool FLT, bool GEN, bool RR = false>
 RBD_HD void walk_step_b(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, const T* fe) {
   if (!(r.flags & TF_VALID)) return;
-  if (r.park >= 0) walk_get_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);
+  if (r.park >= 0) walk_get_park(c, r.park, lane, W);
   // spatial inertia in the root frame (mechanism_state.jl:836-846), p̃A = I a_vp + T ×* I T − w_ext (newton_euler, :872-876)
   T IA[21], pA[6];
   {
@@ -419,7 +434,7 @@ RBD_HD void walk_step_b(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
       // 6-dof joint on the world: IA a_Δ = S⁻ᵀτ − p̃A, v̇ = S⁻¹ a_Δ  (S = X(H): the body-frame twist basis seen from the root)
       // (the virtual root of a re-rooted tree: no joint force, and v̇ of the floating joint is read off the old floating body instead)
       T t6[6], f6[6], a[6], vd[6];
-      const bool vroot = r.rrf & BFD_VROOT;
+      const bool vroot = RR && (r.rrf & BFD_VROOT);
 #pragma unroll
       for (int k = 0; k < 6; ++k) { t6[k] = vroot ? T(0) : *walk_row(c, c.rt + r.voff + k, lane); f6[k] = T(0); }
       if (!vroot) xforce(W.R, W.p, t6, f6);
@@ -519,7 +534,7 @@ RBD_HD void walk_step_b(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
 template <typename T, bool FLT, bool GEN>
 RBD_HD void walk_step_rb(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, const T* fe) {
   if (!(r.flags & TF_VALID)) return;
-  if (r.park >= 0) walk_get_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);
+  if (r.park >= 0) walk_get_park(c, r.park, lane, W);
   T f[6];
   {
     RInertia<T> I;
@@ -595,7 +610,7 @@ RBD_HD void walk_step_rb(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, 
 }
 
 // ---------------- pass C (root -> leaves): v̇ and a_Δ ----------------
-template <typename T, bool FLT, bool GEN>
+template <typename T, bool FLT, bool GEN, bool RR = false>
 RBD_HD void walk_step_c(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, bool want_qdot = false) {
   if (!(r.flags & TF_VALID)) return;
   if (!(r.flags & TF_CHAINED)) {
@@ -662,7 +677,7 @@ RBD_HD void walk_step_c(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
 #pragma unroll
     for (int k = 0; k < 6; ++k) m[k * WR_STRIDE] = W.ad[k];
   }
-  if (FLT) {
+  if (FLT && RR) {
     if (r.rrf & BFD_FCARRY) {  // v̇_f = S⁻¹ (a − a_world) = S⁻¹ ((a_vp − a_world) + a_Δ); then q̇ of the floating joint over its q rows
       T q7[7], v6[6], Rf[9], pf[3], d6[6], vf[6];
 #pragma unroll
@@ -693,8 +708,8 @@ RBD_HD void walk_step_c(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
 
 #if defined(__HIPCC__)
 #ifdef RBD_PROFILE_PHASES
-__device__ long long rbd_walk_phase_clock[16];
-#define RBD_WMARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) rbd_walk_phase_clock[i] = clock64(); } while (0)
+__device__ long long rbd_walk_phase_clock[32];  // [wave][mark]
+#define RBD_WMARK(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) rbd_walk_phase_clock[(threadIdx.x >> 6) * 8 + (i)] = clock64(); } while (0)
 #else
 #define RBD_WMARK(i)
 #endif
@@ -886,7 +901,8 @@ __device__ __forceinline__ void walk_stage_out_rows(typename Lanes<T>::S* __rest
   }
 }
 
-template <typename T, bool FLT, bool GEN>
+// RR: the plan is that of a floating-base tree re-rooted at its centre (rbd_reroot.hpp)
+template <typename T, bool FLT, bool GEN, bool RR = false>
 __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v,
                                                       const typename Lanes<T>::S* __restrict__ tau, const typename Lanes<T>::S* __restrict__ fext,
                                                       typename Lanes<T>::S* __restrict__ vdot, typename Lanes<T>::S* __restrict__ qdot, Layout Lq, Layout Lv,
@@ -921,7 +937,7 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     for (int u = 0; u < TB; ++u)
       if (tid + u * nth < ntr) const_cast<S*>(c.trr)[tid + u * nth] = tr[u];
     for (int i = tid + TB * nth; i < ntr; i += nth) const_cast<S*>(c.trr)[i] = gr[i];
-    walk_stage_chain(c, tid, nth);
+    if (RR) walk_stage_chain(c, tid, nth);
     if (fast) {
       walk_stage_in_fast<T, UB>(q, v, tau, state0, M.nq, M.nv, c.rows, c.rq, c.rv, c.rt, tid, nth);
     } else if (fast_rows) {
@@ -973,12 +989,13 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
       raw = walk_raw(c, s1, g);
       T rn[TR_J];
       walk_consts<T, TR_J>(c, s1, g, rn);
-      walk_step_a<T, FLT, GEN>(c, W, St, s, r, rr, lane, want_qdot);
+      walk_step_a<T, FLT, GEN, false, RR>(c, W, St, s, r, rr, lane, want_qdot);
 #pragma unroll
       for (int k = 0; k < TR_J; ++k) rr[k] = rn[k];
       if ((M.sfm[1] >> s) & 1) __syncthreads();  // SF_AW: an A mailbox was written at this step
     }
   }
+  __syncthreads();  // the B mailboxes take over the rows of the A mailboxes' twist halves
   RBD_WMARK(2);
   {
     // pass B: the external wrench of the body of step s − 1 is requested while step s computes
@@ -992,9 +1009,9 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     for (int s = ns - 1; s >= 0; --s) {
       const int s1 = s > 0 ? s - 1 : 0;
       const WalkRec r = walk_rec(raw);
-      if (FLT) {
+      if (FLT && RR) {
         if ((r.rrf & BFD_FCARRY) && (r.flags & TF_VALID)) {
-          if (r.park >= 0) walk_get_kin(walk_row(c, c.rS + r.park * WMB_S, lane), W);
+          if (r.park >= 0) walk_get_park(c, r.park, lane, W);
           walk_fcarry_b(c, W, lane, fe);
         }
       }
@@ -1002,7 +1019,7 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
       walk_consts<T, TR_STRIDE>(c, s, g, rr);
       raw = walk_raw(c, s1, g);
       if (fext) wrench(walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff, fn);
-      walk_step_b<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe);
+      walk_step_b<T, FLT, GEN, RR>(c, W, St, s, r, rr, lane, fe);
 #pragma unroll
       for (int k = 0; k < 6; ++k) fe[k] = fn[k];
       if ((M.sfm[3] >> s) & 1) __syncthreads();  // SF_BW: a hand-off left its track at this step
@@ -1022,7 +1039,7 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
       raw = walk_raw(c, s1, g);
       T rn[TR_J];
       walk_consts<T, TR_J>(c, s1, g, rn);
-      walk_step_c<T, FLT, GEN>(c, W, St, s, r, rr, lane, want_qdot);
+      walk_step_c<T, FLT, GEN, RR>(c, W, St, s, r, rr, lane, want_qdot);
 #pragma unroll
       for (int k = 0; k < TR_J; ++k) rr[k] = rn[k];
       if ((M.sfm[1] >> s) & 1) __syncthreads();
@@ -1137,6 +1154,7 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
       if ((M.sfm[1] >> s) & 1) __syncthreads();  // SF_AW: an A mailbox was written at this step
     }
   }
+  __syncthreads();  // the B mailboxes take over the rows of the A mailboxes' twist halves
   RBD_WMARK(2);
   {
     // pass B: the external wrench of the body of step s − 1 is requested while step s computes

@@ -15,6 +15,7 @@ static hipError_t launch_walk_fg(const WalkModel& M, long B, size_t lds, const v
   constexpr int SPW = 64 * Lanes<T>::N;
   const unsigned grid = (unsigned)((B + SPW - 1) / SPW);
   if (RNEA) rnea_walk_kernel<T, FLT, GEN><<<grid, 64 * M.G, lds, s>>>(M, B, (const S*)q, (const S*)v, (const S*)x, (const S*)fext, (S*)y, (S*)qdot, Lq, Lv, Lf);
+  else if (FLT && M.reroot.nchain > 0) aba_walk_kernel<T, FLT, GEN, FLT><<<grid, 64 * M.G, lds, s>>>(M, B, (const S*)q, (const S*)v, (const S*)x, (const S*)fext, (S*)y, (S*)qdot, Lq, Lv, Lf);
   else aba_walk_kernel<T, FLT, GEN><<<grid, 64 * M.G, lds, s>>>(M, B, (const S*)q, (const S*)v, (const S*)x, (const S*)fext, (S*)y, (S*)qdot, Lq, Lv, Lf);
   return hipGetLastError();
 }
@@ -52,6 +53,10 @@ template hipError_t launch_rnea_walk<float>(const WalkModel&, int, int, int, lon
 template <typename T, bool FLT, bool GEN> static hipError_t set_walk_lds(size_t lds) {
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_walk_kernel<T, FLT, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  if (FLT) {  // the form for a tree re-rooted at its centre
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_walk_kernel<T, FLT, GEN, FLT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e2 != hipSuccess) return e2;
+  }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&rnea_walk_kernel<T, FLT, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 template <typename T> static hipError_t configure_walk_t(int flt, int gen, size_t lds) {
@@ -68,8 +73,8 @@ template <typename T> hipError_t configure_walk_kernel(int flt, int gen, size_t 
 template hipError_t configure_walk_kernel<double>(int, int, size_t, size_t);
 template hipError_t configure_walk_kernel<float>(int, int, size_t, size_t);
 #ifdef RBD_PROFILE_PHASES
-extern "C" int rbd_debug_walk_phase_clock(long long* out16) {
-  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(rbd_walk_phase_clock), sizeof(long long) * 16);
+extern "C" int rbd_debug_walk_phase_clock(long long* out32) {
+  return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(rbd_walk_phase_clock), sizeof(long long) * 32);
 }
 #endif
 

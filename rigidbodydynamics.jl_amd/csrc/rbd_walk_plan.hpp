@@ -22,11 +22,12 @@ struct WalkPlan {
   std::vector<int32_t> wk;   // [ns * G]: parking slot + 1 of the body of (step, track), 0 = none
 };
 
-// rows of 64 states (padded to WR_STRIDE scalars): q | v | tau (v̇ written over it) | A mailboxes | parking slots | B mailboxes (pass C re-uses
-// them for its 6-value mailboxes); then the plan records.  Must agree with walk_ctx_lds() of rbd_walk.hpp.
-enum { WR_STRIDE = 65, WMB_A = 24, WMB_B = 27, WMB_C = 6, WMB_S = 24, WALK_MAX_STEPS = 11 };
+// rows of 64 states (padded to WR_STRIDE scalars): q | v | tau (v̇ written over it) | A mailboxes, transform halves | parking slots | B mailboxes
+// (pass A has the twist halves of its A mailboxes there, pass C its 6-value mailboxes); then the plan records.  Must agree with walk_ctx_lds()
+// of rbd_walk.hpp.
+enum { WR_STRIDE = 65, WMB_A = 12, WMB_AT = 12, WMB_B = 27, WMB_C = 6, WMB_S = 24, WALK_MAX_STEPS = 11 };
 inline size_t walk_rows(int nq, int nv, int nA, int nB, int nS) {
-  const size_t bc = std::max((size_t)nB * WMB_B, (size_t)nA * WMB_C);
+  const size_t bc = std::max((size_t)nB * WMB_B, (size_t)nA * WMB_AT);
   return (size_t)nq + 2 * (size_t)nv + (size_t)nA * WMB_A + (size_t)nS * WMB_S + bc;
 }
 // es: bytes of a row value (one per lane: 8 for fp64 and for the packed pair of fp32 states), ss: bytes of a plan constant

@@ -16,7 +16,9 @@ for dt, tdt, B, pair in (("f64", torch.float64, 4096, False), ("f64", torch.floa
     tau = torch.rand(B, model.nv, dtype=tdt, device="cuda")
     for _ in range(5): rbd.dynamics_(result, state, tau, algorithm="aba_walk")
     torch.cuda.synchronize()
-    out = (ctypes.c_longlong * 16)()
+    out = (ctypes.c_longlong * 32)()
     assert _capi.lib().rbd_debug_walk_phase_clock(out) == 0
-    t = list(out)
-    print(dt, "two states per lane" if pair else "", "B", B, "cycles: staging in", t[1] - t[0], "pass A", t[2] - t[1], "pass B", t[3] - t[2], "pass C", t[4] - t[3], "out", t[5] - t[4], "total", t[5] - t[0], flush=True)
+    for g in range(4):  # one line per wavefront (= track) of block 0; all clocks relative to wave 0's start
+        t = list(out)[8 * g:8 * g + 8]
+        print(dt, "two states per lane" if pair else "", "B", B, "track", g, "start", t[0] - out[0], "cycles: staging in", t[1] - t[0], "pass A", t[2] - t[1], "pass B", t[3] - t[2],
+              "pass C", t[4] - t[3], "out", t[5] - t[4], "total", t[5] - t[0], flush=True)

@@ -52,13 +52,14 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
       while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
       each_wave([&](int g) {
         for (int s = s0; s <= s1; ++s)
-          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_a<T, FLT, GEN, RNEA>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, qdot != nullptr); }
+          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_a<T, FLT, GEN, RNEA, FLT && !RNEA>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, qdot != nullptr); }
       });
       s0 = s1 + 1;
     }
     for (auto& w : W) walk_init_b(w);
-    // pass B (no barrier between A and B in the kernel either: a wave enters pass B as soon as its own pass A is done — every
-    // wave has finished pass A here, which is one of the legal interleavings; the A mailboxes and parking slots are only read)
+    // pass B (behind a workgroup barrier in the kernels): the B mailboxes take over the rows that held the twist halves of the A mailboxes
+    // — poisoned here, nothing after pass A may read them
+    memset(walk_row(c, c.rB, 0), 0xff, (walk_rows(M.nq, M.nv, M.nA, M.nB, M.nS) - c.rB) * WR_STRIDE * sizeof(T));
     for (int s0 = ns - 1; s0 >= 0;) {
       int s1 = s0;
       while (s1 > 0 && !((M.sfm[3] >> s1) & 1)) --s1;
@@ -73,9 +74,9 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
                 for (int j = 0; j < N; ++j) set_lane(fe[k], j, fext[(o6 + k) * Lf.sk + state_of(l + 64 * j) * Lf.sb]);
             }
             T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr);
-            if (FLT && !RNEA) { const WalkRec rc = walk_rec(walk_raw(c, s, g)); if ((rc.rrf & BFD_FCARRY) && (rc.flags & TF_VALID)) { if (rc.park >= 0) walk_get_kin(walk_row(c, c.rS + rc.park * WMB_S, l), W[g * 64 + l]); walk_fcarry_b(c, W[g * 64 + l], l, fe); } }
+            if (FLT && !RNEA) { const WalkRec rc = walk_rec(walk_raw(c, s, g)); if ((rc.rrf & BFD_FCARRY) && (rc.flags & TF_VALID)) { if (rc.park >= 0) walk_get_park(c, rc.park, l, W[g * 64 + l]); walk_fcarry_b(c, W[g * 64 + l], l, fe); } }
             if (RNEA) walk_step_rb<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
-            else walk_step_b<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
+            else walk_step_b<T, FLT, GEN, FLT>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
           }
       });
       s0 = s1 - 1;
@@ -86,7 +87,7 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
       while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
       each_wave([&](int g) {
         for (int s = s0; s <= s1; ++s)
-          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_c<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, qdot != nullptr); }
+          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_c<T, FLT, GEN, FLT>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, qdot != nullptr); }
       });
       s0 = s1 + 1;
     }
