@@ -97,7 +97,7 @@ RBD_HD int walk_uniform(int x) {
 template <typename T> struct WalkCtx {
   WalkModel M;
   // LDS (rows are [field][WR_STRIDE], a lane's value of a field at row[lane])
-  const I4* tri; const int32_t* twk; const typename Lanes<T>::S* trr;  // the constants are scalars: the states of a lane share them
+  const typename Lanes<T>::S* trr;  // the constants are scalars: the states of a lane share them
   T* rows;
   int rq, rv, rt, rA, rS, rB;  // first row of q | v | τ / v̇ | A mailboxes | parking slots | B mailboxes (pass C: its mailboxes)
   RerootView rrv;              // the re-rooted tree's floating base (M.reroot with the chain table where this code can read it fast)
@@ -106,12 +106,10 @@ template <typename T> struct WalkCtx {
 
 template <typename T> RBD_HD void walk_ctx_lds(WalkCtx<T>& c, void* lds) {
   const size_t nrec = (size_t)c.M.ns * c.M.G;
-  c.tri = reinterpret_cast<const I4*>(lds);
   using S = typename Lanes<T>::S;
-  c.trr = reinterpret_cast<const S*>(c.tri + nrec);
-  c.twk = reinterpret_cast<const int32_t*>(c.trr + nrec * TR_STRIDE);
-  char* after = reinterpret_cast<char*>(lds) + nrec * 16 + nrec * TR_STRIDE * sizeof(S) + ((nrec * 4 + 15) & ~(size_t)15);
-  c.rrv = c.M.reroot;  // the chain table of a re-rooted tree is copied behind the parking words by the prologue (walk_stage_chain)
+  c.trr = reinterpret_cast<const S*>(lds);
+  char* after = reinterpret_cast<char*>(lds) + ((nrec * TR_STRIDE * sizeof(S) + 15) & ~(size_t)15);
+  c.rrv = c.M.reroot;  // the chain table of a re-rooted tree is copied behind the constants by the prologue (walk_stage_chain)
   c.rrv.chain_i = reinterpret_cast<const int32_t*>(after);
   c.rrv.chain_r = after + 64;
   c.rows = reinterpret_cast<T*>(after + 64 + ((RC_MAX * 15 * sizeof(S) + 15) & ~(size_t)15));
@@ -161,23 +159,18 @@ template <typename T> RBD_HD void walk_init_c(WalkRegs<T>& W) {
 }
 
 struct WalkRec { int flags, qoff, voff, orig6, nbr, a_w, a_r, b_w, b_r0, park, rrf; };  // rrf: BFD_* of a re-rooted tree
-// the raw words of a record: read from LDS a step ahead (walk_raw), made wave-uniform scalars when the step starts (walk_rec)
-struct WalkRaw { I4 w; int32_t k; };
-template <typename T> RBD_HD WalkRaw walk_raw(const WalkCtx<T>& c, int s, int g) {
-  WalkRaw x;
-  x.w = c.tri[s * c.M.G + g];
-  x.k = c.twk[s * c.M.G + g];
-  return x;
-}
-RBD_HD WalkRec walk_rec(const WalkRaw& raw) {
+// The record of (step s, track g): a wave-uniform address in the constant address space, i.e. scalar loads into scalar registers (the
+// kernels ask for a record one step ahead of its use).  Layout: walk_unpack (rbd_walk_plan.hpp).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RBD_SCALAR_MEM __attribute__((address_space(4)))
+#else
+#define RBD_SCALAR_MEM
+#endif
+template <typename T> RBD_HD WalkRec walk_rec(const WalkCtx<T>& c, int s, int g) {
+  const int32_t RBD_SCALAR_MEM* p = (const int32_t RBD_SCALAR_MEM*)(c.M.wk) + (s * c.M.G + g) * WREC_STRIDE;
   WalkRec r;
-  const int x = walk_uniform(raw.w.x), y = walk_uniform(raw.w.y), z = walk_uniform(raw.w.z), ww = walk_uniform(raw.w.w);
-  r.flags = (y >> 16) & 0xff; r.qoff = x & 0xffff; r.voff = (x >> 16) & 0xffff; r.orig6 = y & 0xffff; r.nbr = (y >> 24) & 0x7f;
-  r.a_w = (z & 0xffff) - 1; r.a_r = ((z >> 16) & 0xffff) - 1; r.b_w = (ww & 0xffff) - 1; r.b_r0 = ((ww >> 16) & 0xffff) - 1;
-  const int kk = walk_uniform(raw.k);
-  r.park = (kk & 0xff) - 1;
-  r.rrf = (kk >> 8) & 3;
-  if (r.flags & TF_FIXED) { r.qoff = 0; r.voff = 0; }  // a fixed joint has no coordinates: its offsets may be one past the end
+  r.flags = p[WREC_FLAGS]; r.qoff = p[WREC_QOFF]; r.voff = p[WREC_VOFF]; r.orig6 = p[WREC_ORIG6]; r.nbr = p[WREC_NBR];
+  r.a_w = p[WREC_AW]; r.a_r = p[WREC_AR]; r.b_w = p[WREC_BW]; r.b_r0 = p[WREC_BR0]; r.park = p[WREC_PARK]; r.rrf = p[WREC_RRF];
   return r;
 }
 // the constants of a record, LDS -> registers
@@ -920,10 +913,7 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
   {  // the plan records -> LDS; q, v, τ of this workgroup's states -> rows.  Loads first, all of them; then the LDS writes.
     constexpr int UB = 10 * N, TB = 6;
     const int nrec = M.ns * M.G, ntr = nrec * TR_STRIDE;  // nrec <= 13 G <= nth
-    const I4* gi = reinterpret_cast<const I4*>(M.ri);
     const S* gr = reinterpret_cast<const S*>(M.rr);
-    I4 ti = gi[tid < nrec ? tid : 0];
-    const int32_t tw = M.wk[tid < nrec ? tid : 0];
     S tr[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) tr[u] = gr[tid + u * nth < ntr ? tid + u * nth : 0];
@@ -932,7 +922,6 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     const bool fast_rows = Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && inside && !fast;
     WalkStageIn<T, UB> in;
     if (!fast && !fast_rows) in.load(q, v, tau, Lq, Lv, state0, B, M.nq, M.nv, 0, tid, nth);
-    if (tid < nrec) { const_cast<I4*>(c.tri)[tid] = ti; const_cast<int32_t*>(c.twk)[tid] = tw; }
 #pragma unroll
     for (int u = 0; u < TB; ++u)
       if (tid + u * nth < ntr) const_cast<S*>(c.trr)[tid + u * nth] = tr[u];
@@ -979,14 +968,14 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
   };
   // every pass reads the record (and passes A and C the constants) of its next step while the current one computes
   {
-    WalkRaw raw = walk_raw(c, 0, g);
+    WalkRec rnext = walk_rec(c, 0, g);
     T rr[TR_J];
     walk_consts<T, TR_J>(c, 0, g, rr);
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) {
       const int s1 = s + 1 < ns ? s + 1 : s;
-      const WalkRec r = walk_rec(raw);
-      raw = walk_raw(c, s1, g);
+      const WalkRec r = rnext;
+      rnext = walk_rec(c, s1, g);
       T rn[TR_J];
       walk_consts<T, TR_J>(c, s1, g, rn);
       walk_step_a<T, FLT, GEN, false, RR>(c, W, St, s, r, rr, lane, want_qdot);
@@ -1003,12 +992,12 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     T fe[6], fn[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { fe[k] = T(0); fn[k] = T(0); }
-    WalkRaw raw = walk_raw(c, ns - 1, g);
-    if (fext) wrench(walk_uniform(raw.w.y) & 0xffff, fe);
+    WalkRec rnext = walk_rec(c, ns - 1, g);
+    if (fext) wrench(rnext.orig6, fe);
 #pragma unroll 1
     for (int s = ns - 1; s >= 0; --s) {
       const int s1 = s > 0 ? s - 1 : 0;
-      const WalkRec r = walk_rec(raw);
+      const WalkRec r = rnext;
       if (FLT && RR) {
         if ((r.rrf & BFD_FCARRY) && (r.flags & TF_VALID)) {
           if (r.park >= 0) walk_get_park(c, r.park, lane, W);
@@ -1017,8 +1006,8 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
       }
       T rr[TR_STRIDE];
       walk_consts<T, TR_STRIDE>(c, s, g, rr);
-      raw = walk_raw(c, s1, g);
-      if (fext) wrench(walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff, fn);
+      rnext = walk_rec(c, s1, g);
+      if (fext) wrench(rnext.orig6, fn);
       walk_step_b<T, FLT, GEN, RR>(c, W, St, s, r, rr, lane, fe);
 #pragma unroll
       for (int k = 0; k < 6; ++k) fe[k] = fn[k];
@@ -1029,14 +1018,14 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
   RBD_WMARK(3);
   {
     walk_init_c(W);
-    WalkRaw raw = walk_raw(c, 0, g);
+    WalkRec rnext = walk_rec(c, 0, g);
     T rr[TR_J];
     walk_consts<T, TR_J>(c, 0, g, rr);
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) {
       const int s1 = s + 1 < ns ? s + 1 : s;
-      const WalkRec r = walk_rec(raw);
-      raw = walk_raw(c, s1, g);
+      const WalkRec r = rnext;
+      rnext = walk_rec(c, s1, g);
       T rn[TR_J];
       walk_consts<T, TR_J>(c, s1, g, rn);
       walk_step_c<T, FLT, GEN, RR>(c, W, St, s, r, rr, lane, want_qdot);
@@ -1079,10 +1068,7 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
   {  // the plan records -> LDS; q, v, τ of this workgroup's states -> rows.  Loads first, all of them; then the LDS writes.
     constexpr int UB = 10 * N, TB = 6;
     const int nrec = M.ns * M.G, ntr = nrec * TR_STRIDE;  // nrec <= 13 G <= nth
-    const I4* gi = reinterpret_cast<const I4*>(M.ri);
     const S* gr = reinterpret_cast<const S*>(M.rr);
-    I4 ti = gi[tid < nrec ? tid : 0];
-    const int32_t tw = M.wk[tid < nrec ? tid : 0];
     S tr[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) tr[u] = gr[tid + u * nth < ntr ? tid + u * nth : 0];
@@ -1091,7 +1077,6 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
     const bool fast_rows = Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && inside && !fast;
     WalkStageIn<T, UB> in;
     if (!fast && !fast_rows) in.load(q, v, vdot, Lq, Lv, state0, B, M.nq, M.nv, 0, tid, nth);
-    if (tid < nrec) { const_cast<I4*>(c.tri)[tid] = ti; const_cast<int32_t*>(c.twk)[tid] = tw; }
 #pragma unroll
     for (int u = 0; u < TB; ++u)
       if (tid + u * nth < ntr) const_cast<S*>(c.trr)[tid + u * nth] = tr[u];
@@ -1138,14 +1123,14 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
   };
   // every pass reads the record (and passes A and C the constants) of its next step while the current one computes
   {
-    WalkRaw raw = walk_raw(c, 0, g);
+    WalkRec rnext = walk_rec(c, 0, g);
     T rr[TR_J];
     walk_consts<T, TR_J>(c, 0, g, rr);
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) {
       const int s1 = s + 1 < ns ? s + 1 : s;
-      const WalkRec r = walk_rec(raw);
-      raw = walk_raw(c, s1, g);
+      const WalkRec r = rnext;
+      rnext = walk_rec(c, s1, g);
       T rn[TR_J];
       walk_consts<T, TR_J>(c, s1, g, rn);
       walk_step_a<T, FLT, GEN, true>(c, W, St, s, r, rr, lane, want_qdot);
@@ -1163,16 +1148,16 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
     T fe[6], fn[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { fe[k] = T(0); fn[k] = T(0); }
-    WalkRaw raw = walk_raw(c, ns - 1, g);
-    if (fext) wrench(walk_uniform(raw.w.y) & 0xffff, fe);
+    WalkRec rnext = walk_rec(c, ns - 1, g);
+    if (fext) wrench(rnext.orig6, fe);
 #pragma unroll 1
     for (int s = ns - 1; s >= 0; --s) {
       const int s1 = s > 0 ? s - 1 : 0;
-      const WalkRec r = walk_rec(raw);
+      const WalkRec r = rnext;
       T rr[TR_STRIDE];
       walk_consts<T, TR_STRIDE>(c, s, g, rr);
-      raw = walk_raw(c, s1, g);
-      if (fext) wrench(walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff, fn);
+      rnext = walk_rec(c, s1, g);
+      if (fext) wrench(rnext.orig6, fn);
       walk_step_rb<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe);
 #pragma unroll
       for (int k = 0; k < 6; ++k) fe[k] = fn[k];
