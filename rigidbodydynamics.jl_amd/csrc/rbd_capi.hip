@@ -1109,7 +1109,8 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
     }
     const Layout Ls{16, -(long)m->nv * m->nv};  // grouped by 16 states = one wavefront of the tile Cholesky (layout_base, rbd_device.hpp)
     HIP_TRY(launch_crba_state<float>(w->sm, B, dq, w->d_Msoa, Lq, Ls, 0, w->stream));  // structural zeros: never read by the solve, written below
-    HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_Msoa, dtau, dc, dx, nullptr, Ls, Lv, w->d_notpd, w->stream, dM, Lm));
+    static const bool exp_no_mcopy = getenv("RBD_EXP_NO_MCOPY") != nullptr, exp_no_chol = getenv("RBD_EXP_NO_CHOL") != nullptr;  // timing experiments only
+    if (!exp_no_chol) HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_Msoa, dtau, dc, dx, nullptr, Ls, Lv, w->d_notpd, w->stream, exp_no_mcopy ? nullptr : dM, Lm));
     w->last_kernel = "crba_state_kernel + chol_mfma_kernel";
     return RBD_OK;
   }

@@ -1334,12 +1334,42 @@ __global__ __launch_bounds__(64, (NT <= 9 ? 2 : 1)) void chol_mfma_kernel(int nv
         if (live && row < nv && col <= row) a = Mg[((long)col * nv + row) * Lm.sk + layout_base(Lm, state)];
         t[I][J][cc] = a;
       }
-  // M itself in the caller's layout, when the matrix was built in a staging buffer (one-lane-per-state CRBA writes batch-innermost):
-  // a quad stores 16 contiguous bytes per (tile, column) and a state's columns come from this one wavefront back to back
-  // (column by column, rows ascending: the 16-byte pieces of a cache line of the caller's column-major M are stored back to back, so the line
-  // is complete in L2 long before it is evicted — tile by tile they were spread over the whole store phase, and with 128 wavefronts x 83 KB of
-  // output in flight per 4 MB L2 most lines went out partially written: 2.4x the bytes, read-modify-write at the memory)
-  if (Mcopy && live) {
+  // M itself in the caller's layout, when the matrix was built in a staging buffer (one-lane-per-state CRBA writes batch-innermost).
+  // Measured at 65 536 states: storing the lower triangle straight from the tiles (a quad = 16 contiguous bytes per (tile, column), 16 such
+  // pieces 5 KB apart per instruction) took 160 of the launch's 225 us — partially written cache lines, 1.1 TB/s; the lower triangle alone in
+  // 16-byte pieces of contiguous column runs was no better (133 us for 189 MB).  Instead the whole square is
+  // written, block column by block column: the four columns 4J..4J+3 of a state are 16 nv contiguous bytes of the caller's column-major M;
+  // they are assembled in LDS (lower tiles as they are, the part above the diagonal from the transposed tiles (J, I < J): the reference
+  // leaves the strict upper triangle of a Symmetric(:L) undefined, here it receives the mirror image) and leave as 16-byte pieces of complete,
+  // contiguous runs.  16 consecutive states = one contiguous region of the output, every byte of which this wavefront writes.
+  constexpr int CB = 16 * NT, MST = CB + 4;  // floats of a block column per state; LDS stride per state (bank spread, 16-byte aligned)
+  __shared__ __align__(16) float mst[16 * MST];
+  if (Mcopy && nv == 4 * NT && Lc.sk == 1 && (Lc.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(Mcopy) & 15) == 0) {
+    float* mine = mst + (lane >> 2) * MST;
+#pragma unroll
+    for (int J = 0; J < NT; ++J) {
+#pragma unroll
+      for (int I = J; I < NT; ++I)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          if (I > J || cc <= r) mine[cc * 4 * NT + 4 * I + r] = t[I][J][cc];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        if (cc < r) mine[r * 4 * NT + 4 * J + cc] = t[J][J][cc];  // above the diagonal inside the diagonal tile
+#pragma unroll
+      for (int I = 0; I < J; ++I) *reinterpret_cast<f32x4_t*>(mine + r * 4 * NT + 4 * I) = t[J][I];  // M[4I + c][4J + r] = M[4J + r][4I + c]
+      __syncthreads();
+#pragma unroll 3
+      for (int c0 = 0; c0 < 16 * 4 * NT; c0 += 64) {
+        const int ch = c0 + lane, st = ch / (4 * NT), piece = ch - st * (4 * NT);
+        const long gs = (long)blockIdx.x * 16 + st;
+        if (ch < 16 * 4 * NT && gs < B)
+          // streamed out past the L2 (nontemporal): 269 -> 237 us per launch at 65 536 states
+          __builtin_nontemporal_store(*reinterpret_cast<const f32x4_t*>(mst + st * MST + piece * 4), reinterpret_cast<f32x4_t*>(Mcopy + gs * Lc.sb + (long)J * CB + piece * 4));
+      }
+      __syncthreads();
+    }
+  } else if (Mcopy && live) {  // any other shape: the lower triangle, column by column
 #pragma unroll
     for (int J = 0; J < NT; ++J)
 #pragma unroll

@@ -212,12 +212,16 @@ __global__ __launch_bounds__(256) void crba_state_kernel(StateModel M, long B, c
   Path<T, ML, 9, 0> PX;           // path: transforms to root
   Path<T, ML, 10, 9 * ML> PI;     // path: inertias being accumulated (J 6, c 3, m)
   T R0[9], p0[3];                 // transform of the level-0 body (a 6-dof root's columns are S' F with S = Ad(H0))
-#pragma unroll 1
-  for (int o = 0; o < M.nops; ++o) {
-    const int32_t* op = ti + o * SI_STRIDE;
-    T r[TR_STRIDE];
+  // An op's words and constants are asked for while the op before it computes (registers, two sets taken in turn): read at the top of
+  // their own op, every LDS -> scalar-register hop (kind, level, offsets, each ancestor column) was a round trip the lone wavefront sat out.
+  auto fetch = [&](int o, int32_t* w, T* r) {
+    const int oo = o < M.nops ? o : M.nops - 1;
     _Pragma("unroll")
-    for (int k = 0; k < TR_STRIDE; ++k) r[k] = tr[o * TR_STRIDE + k];
+    for (int k = 0; k < 4 + ML; ++k) w[k] = ti[oo * SI_STRIDE + k];
+    _Pragma("unroll")
+    for (int k = 0; k < TR_STRIDE; ++k) r[k] = tr[oo * TR_STRIDE + k];
+  };
+  auto step = [&](const int32_t* op, const T* r) {
     const int w0 = state_uniform(op[0]), lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = state_uniform(op[2]);
     if ((w0 & 0xff) == SK_ENTER) {
       T Rl[9], pl[3], R[9], p[3], S[6];
@@ -271,24 +275,47 @@ __global__ __launch_bounds__(256) void crba_state_kernel(StateModel M, long B, c
         mul_inertia(Ic, S, F);
         const long row = voff;
         put(row, row, dot6(F, S));
-        const int32_t* cols = op + 4;
-#pragma unroll 1
-        for (int k = 0; k < lvl; ++k) {
-          const int col = state_uniform(cols[k]);
-          if (col < 0) continue;
-          if (col & SC_FLOATING) {
-            T o6[6];
-            xforce_inv(R0, p0, F, o6);
+        // the ancestors of the path, level by level (unrolled: the columns of several levels are in flight from LDS together)
     _Pragma("unroll")
-            for (int cj = 0; cj < 6; ++cj) put(row, (col & ~SC_FLOATING) + cj, o6[cj]);
-          } else {
-            T Sk[6];
+        for (int k = 0; k < ML; ++k) {
+          if (k < lvl) {
+            const int col = state_uniform(op[4 + k]);
+            if (col >= 0) {
+              if (col & SC_FLOATING) {
+                T o6[6];
+                xforce_inv(R0, p0, F, o6);
     _Pragma("unroll")
-            for (int j = 0; j < 6; ++j) Sk[j] = Sl[(6 * k + j) * 64];
-            put(row, col, dot6(F, Sk));
+                for (int cj = 0; cj < 6; ++cj) put(row, (col & ~SC_FLOATING) + cj, o6[cj]);
+              } else {
+                T Sk[6];
+    _Pragma("unroll")
+                for (int j = 0; j < 6; ++j) Sk[j] = Sl[(6 * k + j) * 64];
+                put(row, col, dot6(F, Sk));
+              }
+            }
           }
         }
       }
+    }
+  };
+  int32_t wa[4 + ML];
+  T ra[TR_STRIDE];
+  if constexpr (sizeof(T) == 4) {
+    int32_t wb[4 + ML];
+    T rb[TR_STRIDE];
+    fetch(0, wa, ra);
+#pragma unroll 1
+    for (int o = 0; o < M.nops; o += 2) {
+      fetch(o + 1, wb, rb);
+      step(wa, ra);
+      fetch(o + 2, wa, ra);
+      if (o + 1 < M.nops) step(wb, rb);
+    }
+  } else {  // fp64 keeps the path in VGPRs (no accumulation-register form): no room for a second set
+#pragma unroll 1
+    for (int o = 0; o < M.nops; ++o) {
+      fetch(o, wa, ra);
+      step(wa, ra);
     }
   }
 }
