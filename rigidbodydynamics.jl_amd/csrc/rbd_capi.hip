@@ -667,10 +667,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       const TrackPlan& P = S.track;
       st = upload(&w->d_rrtrack_ri, P.ri.data(), P.ri.size() * sizeof(int32_t));
       if (st == RBD_OK) st = up_real(&w->d_rrtrack_rr, P.rr);
-      if (st == RBD_OK) {
-        const std::vector<int32_t> rec = walk_unpack(P.ns, P.G, P.ri, S.walk.wk);
-        st = upload(&w->d_rrwalk_wk, rec.data(), rec.size() * sizeof(int32_t));
-      }
+      if (st == RBD_OK) st = upload(&w->d_rrwalk_wk, S.walk.wk.data(), S.walk.wk.size() * sizeof(int32_t));
       WalkModel& wm = w->wm_rr;
       wm.ns = P.ns; wm.G = P.G; wm.nA = P.nA; wm.nB = P.nB; wm.nS = S.walk.nS; wm.nq = m->nq; wm.nv = m->nv; wm.reroot = V;
       wm.ri = (const int32_t*)w->d_rrtrack_ri; wm.rr = w->d_rrtrack_rr; wm.wk = (const int32_t*)w->d_rrwalk_wk;
@@ -746,10 +743,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   }
   if (m->track.ok && m->walk.ok) {
     const TrackPlan& P = m->track;
-    {
-      const std::vector<int32_t> rec = walk_unpack(P.ns, P.G, P.ri, m->walk.wk);
-      st = upload(&w->d_walk_wk, rec.data(), rec.size() * sizeof(int32_t));
-    }
+    st = upload(&w->d_walk_wk, m->walk.wk.data(), m->walk.wk.size() * sizeof(int32_t));
     if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
     WalkModel& wm = w->wm;
     wm.ns = P.ns; wm.G = P.G; wm.nA = P.nA; wm.nB = P.nB; wm.nS = m->walk.nS; wm.nq = m->nq; wm.nv = m->nv;

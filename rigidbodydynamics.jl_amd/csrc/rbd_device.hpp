@@ -112,7 +112,7 @@ struct WalkModel {
   RerootView reroot;  // nchain > 0: the plan is that of the re-rooted tree (wk carries BFD_* in bits 8..9)
   const int32_t* ri;  // [ns * G * TI_STRIDE]  track-plan records
   const void* rr;     // [ns * G * TR_STRIDE]  ... constants, kernel scalar type
-  const int32_t* wk;  // [ns * G * WREC_STRIDE] the records as the kernels read them: one word per field (walk_unpack, rbd_walk_plan.hpp)
+  const int32_t* wk;  // [ns * G]              parking slots (rbd_walk_plan.hpp)
   uint64_t sfm[5];    // wave-uniform step flags (SF_* of rbd_track.hpp)
   double gravity[3];
 };

@@ -97,23 +97,27 @@ RBD_HD int walk_uniform(int x) {
 template <typename T> struct WalkCtx {
   WalkModel M;
   // LDS (rows are [field][WR_STRIDE], a lane's value of a field at row[lane])
-  const typename Lanes<T>::S* trr;  // the constants are scalars: the states of a lane share them
+  const I4* tri; const int32_t* twk; const typename Lanes<T>::S* trr;  // the constants are scalars: the states of a lane share them
   T* rows;
   int rq, rv, rt, rA, rS, rB;  // first row of q | v | τ / v̇ | A mailboxes | parking slots | B mailboxes (pass C: its mailboxes)
+  int rT, sT;                  // twist halves of the A mailboxes: first row, rows from one to the next (walk_twist_rows)
   RerootView rrv;              // the re-rooted tree's floating base (M.reroot with the chain table where this code can read it fast)
   T a0[6];
 };
 
 template <typename T> RBD_HD void walk_ctx_lds(WalkCtx<T>& c, void* lds) {
   const size_t nrec = (size_t)c.M.ns * c.M.G;
+  c.tri = reinterpret_cast<const I4*>(lds);
   using S = typename Lanes<T>::S;
-  c.trr = reinterpret_cast<const S*>(lds);
-  char* after = reinterpret_cast<char*>(lds) + ((nrec * TR_STRIDE * sizeof(S) + 15) & ~(size_t)15);
-  c.rrv = c.M.reroot;  // the chain table of a re-rooted tree is copied behind the constants by the prologue (walk_stage_chain)
+  c.trr = reinterpret_cast<const S*>(c.tri + nrec);
+  c.twk = reinterpret_cast<const int32_t*>(c.trr + nrec * TR_STRIDE);
+  char* after = reinterpret_cast<char*>(lds) + nrec * 16 + nrec * TR_STRIDE * sizeof(S) + ((nrec * 4 + 15) & ~(size_t)15);
+  c.rrv = c.M.reroot;  // the chain table of a re-rooted tree is copied behind the parking words by the prologue (walk_stage_chain)
   c.rrv.chain_i = reinterpret_cast<const int32_t*>(after);
   c.rrv.chain_r = after + 64;
   c.rows = reinterpret_cast<T*>(after + 64 + ((RC_MAX * 15 * sizeof(S) + 15) & ~(size_t)15));
   c.rq = 0; c.rv = c.M.nq; c.rt = c.rv + c.M.nv; c.rA = c.rt + c.M.nv; c.rS = c.rA + c.M.nA * WMB_A; c.rB = c.rS + c.M.nS * WMB_S;
+  c.rT = c.rB; c.sT = WMB_AT;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { c.a0[k] = T(0); c.a0[3 + k] = T(-c.M.gravity[k]); }  // a_world = −gravity (mechanism_algorithms.jl:405)
 }
@@ -159,18 +163,23 @@ template <typename T> RBD_HD void walk_init_c(WalkRegs<T>& W) {
 }
 
 struct WalkRec { int flags, qoff, voff, orig6, nbr, a_w, a_r, b_w, b_r0, park, rrf; };  // rrf: BFD_* of a re-rooted tree
-// The record of (step s, track g): a wave-uniform address in the constant address space, i.e. scalar loads into scalar registers (the
-// kernels ask for a record one step ahead of its use).  Layout: walk_unpack (rbd_walk_plan.hpp).
-#if defined(__HIP_DEVICE_COMPILE__)
-#define RBD_SCALAR_MEM __attribute__((address_space(4)))
-#else
-#define RBD_SCALAR_MEM
-#endif
-template <typename T> RBD_HD WalkRec walk_rec(const WalkCtx<T>& c, int s, int g) {
-  const int32_t RBD_SCALAR_MEM* p = (const int32_t RBD_SCALAR_MEM*)(c.M.wk) + (s * c.M.G + g) * WREC_STRIDE;
+// the raw words of a record: read from LDS a step ahead (walk_raw), made wave-uniform scalars when the step starts (walk_rec)
+struct WalkRaw { I4 w; int32_t k; };
+template <typename T> RBD_HD WalkRaw walk_raw(const WalkCtx<T>& c, int s, int g) {
+  WalkRaw x;
+  x.w = c.tri[s * c.M.G + g];
+  x.k = c.twk[s * c.M.G + g];
+  return x;
+}
+RBD_HD WalkRec walk_rec(const WalkRaw& raw) {
   WalkRec r;
-  r.flags = p[WREC_FLAGS]; r.qoff = p[WREC_QOFF]; r.voff = p[WREC_VOFF]; r.orig6 = p[WREC_ORIG6]; r.nbr = p[WREC_NBR];
-  r.a_w = p[WREC_AW]; r.a_r = p[WREC_AR]; r.b_w = p[WREC_BW]; r.b_r0 = p[WREC_BR0]; r.park = p[WREC_PARK]; r.rrf = p[WREC_RRF];
+  const int x = walk_uniform(raw.w.x), y = walk_uniform(raw.w.y), z = walk_uniform(raw.w.z), ww = walk_uniform(raw.w.w);
+  r.flags = (y >> 16) & 0xff; r.qoff = x & 0xffff; r.voff = (x >> 16) & 0xffff; r.orig6 = y & 0xffff; r.nbr = (y >> 24) & 0x7f;
+  r.a_w = (z & 0xffff) - 1; r.a_r = ((z >> 16) & 0xffff) - 1; r.b_w = (ww & 0xffff) - 1; r.b_r0 = ((ww >> 16) & 0xffff) - 1;
+  const int kk = walk_uniform(raw.k);
+  r.park = (kk & 0xff) - 1;
+  r.rrf = (kk >> 8) & 3;
+  if (r.flags & TF_FIXED) { r.qoff = 0; r.voff = 0; }  // a fixed joint has no coordinates: its offsets may be one past the end
   return r;
 }
 // the constants of a record, LDS -> registers
@@ -198,12 +207,19 @@ template <typename T> RBD_HD void walk_get_kin(const T* m, const T* mt, WalkRegs
   for (int k = 0; k < 6; ++k) { W.Tw[k] = mt[k * WR_STRIDE]; W.av[k] = mt[(6 + k) * WR_STRIDE]; }
 }
 // An A mailbox: the transform half lives until pass C has read it; the twist half is dead when pass A ends and sits in the rows the B
-// mailboxes take over (the kernels put a workgroup barrier between the two passes).  A parking slot is the two halves back to back.
+// mailboxes take over (aba_walk_kernel puts a workgroup barrier between the two passes).  A parking slot is the two halves back to back.
+// The inverse-dynamics kernel hands 6 values up per B mailbox, not 27: there the twist half of A mailbox a lives in the unused rows of B
+// mailbox a (walk_twist_rows) and no barrier is needed — unless there are more A than B mailboxes (a 6-dof root without cross children).
+template <typename T> RBD_HD bool walk_twist_rows_rnea(WalkCtx<T>& c) {
+  if (c.M.nA > c.M.nB) return false;  // keep the shared rows and the barrier
+  c.rT = c.rB + 6; c.sT = WMB_B;
+  return true;
+}
 template <typename T> RBD_HD void walk_put_box(const WalkCtx<T>& c, int a, int lane, const WalkRegs<T>& W) {
-  walk_put_kin(walk_row(c, c.rA + a * WMB_A, lane), walk_row(c, c.rB + a * WMB_AT, lane), W);
+  walk_put_kin(walk_row(c, c.rA + a * WMB_A, lane), walk_row(c, c.rT + a * c.sT, lane), W);
 }
 template <typename T> RBD_HD void walk_get_box(const WalkCtx<T>& c, int a, int lane, WalkRegs<T>& W) {
-  walk_get_kin(walk_row(c, c.rA + a * WMB_A, lane), walk_row(c, c.rB + a * WMB_AT, lane), W);
+  walk_get_kin(walk_row(c, c.rA + a * WMB_A, lane), walk_row(c, c.rT + a * c.sT, lane), W);
 }
 template <typename T> RBD_HD void walk_put_park(const WalkCtx<T>& c, int k, int lane, const WalkRegs<T>& W) {
   T* m = walk_row(c, c.rS + k * WMB_S, lane);
@@ -913,7 +929,10 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
   {  // the plan records -> LDS; q, v, τ of this workgroup's states -> rows.  Loads first, all of them; then the LDS writes.
     constexpr int UB = 10 * N, TB = 6;
     const int nrec = M.ns * M.G, ntr = nrec * TR_STRIDE;  // nrec <= 13 G <= nth
+    const I4* gi = reinterpret_cast<const I4*>(M.ri);
     const S* gr = reinterpret_cast<const S*>(M.rr);
+    I4 ti = gi[tid < nrec ? tid : 0];
+    const int32_t tw = M.wk[tid < nrec ? tid : 0];
     S tr[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) tr[u] = gr[tid + u * nth < ntr ? tid + u * nth : 0];
@@ -922,6 +941,7 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     const bool fast_rows = Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && inside && !fast;
     WalkStageIn<T, UB> in;
     if (!fast && !fast_rows) in.load(q, v, tau, Lq, Lv, state0, B, M.nq, M.nv, 0, tid, nth);
+    if (tid < nrec) { const_cast<I4*>(c.tri)[tid] = ti; const_cast<int32_t*>(c.twk)[tid] = tw; }
 #pragma unroll
     for (int u = 0; u < TB; ++u)
       if (tid + u * nth < ntr) const_cast<S*>(c.trr)[tid + u * nth] = tr[u];
@@ -968,14 +988,14 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
   };
   // every pass reads the record (and passes A and C the constants) of its next step while the current one computes
   {
-    WalkRec rnext = walk_rec(c, 0, g);
+    WalkRaw raw = walk_raw(c, 0, g);
     T rr[TR_J];
     walk_consts<T, TR_J>(c, 0, g, rr);
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) {
       const int s1 = s + 1 < ns ? s + 1 : s;
-      const WalkRec r = rnext;
-      rnext = walk_rec(c, s1, g);
+      const WalkRec r = walk_rec(raw);
+      raw = walk_raw(c, s1, g);
       T rn[TR_J];
       walk_consts<T, TR_J>(c, s1, g, rn);
       walk_step_a<T, FLT, GEN, false, RR>(c, W, St, s, r, rr, lane, want_qdot);
@@ -992,12 +1012,12 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     T fe[6], fn[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { fe[k] = T(0); fn[k] = T(0); }
-    WalkRec rnext = walk_rec(c, ns - 1, g);
-    if (fext) wrench(rnext.orig6, fe);
+    WalkRaw raw = walk_raw(c, ns - 1, g);
+    if (fext) wrench(walk_uniform(raw.w.y) & 0xffff, fe);
 #pragma unroll 1
     for (int s = ns - 1; s >= 0; --s) {
       const int s1 = s > 0 ? s - 1 : 0;
-      const WalkRec r = rnext;
+      const WalkRec r = walk_rec(raw);
       if (FLT && RR) {
         if ((r.rrf & BFD_FCARRY) && (r.flags & TF_VALID)) {
           if (r.park >= 0) walk_get_park(c, r.park, lane, W);
@@ -1006,8 +1026,8 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
       }
       T rr[TR_STRIDE];
       walk_consts<T, TR_STRIDE>(c, s, g, rr);
-      rnext = walk_rec(c, s1, g);
-      if (fext) wrench(rnext.orig6, fn);
+      raw = walk_raw(c, s1, g);
+      if (fext) wrench(walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff, fn);
       walk_step_b<T, FLT, GEN, RR>(c, W, St, s, r, rr, lane, fe);
 #pragma unroll
       for (int k = 0; k < 6; ++k) fe[k] = fn[k];
@@ -1018,14 +1038,14 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
   RBD_WMARK(3);
   {
     walk_init_c(W);
-    WalkRec rnext = walk_rec(c, 0, g);
+    WalkRaw raw = walk_raw(c, 0, g);
     T rr[TR_J];
     walk_consts<T, TR_J>(c, 0, g, rr);
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) {
       const int s1 = s + 1 < ns ? s + 1 : s;
-      const WalkRec r = rnext;
-      rnext = walk_rec(c, s1, g);
+      const WalkRec r = walk_rec(raw);
+      raw = walk_raw(c, s1, g);
       T rn[TR_J];
       walk_consts<T, TR_J>(c, s1, g, rn);
       walk_step_c<T, FLT, GEN, RR>(c, W, St, s, r, rr, lane, want_qdot);
@@ -1061,6 +1081,7 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
   WalkCtx<T> c;
   c.M = M;
   walk_ctx_lds(c, walk_lds_raw);
+  const bool shared_rows = !walk_twist_rows_rnea(c);  // wave-uniform
   const int lane = threadIdx.x & 63, tid = threadIdx.x, nth = blockDim.x;
   const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long state0 = (long)blockIdx.x * (64 * N);
@@ -1068,7 +1089,10 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
   {  // the plan records -> LDS; q, v, τ of this workgroup's states -> rows.  Loads first, all of them; then the LDS writes.
     constexpr int UB = 10 * N, TB = 6;
     const int nrec = M.ns * M.G, ntr = nrec * TR_STRIDE;  // nrec <= 13 G <= nth
+    const I4* gi = reinterpret_cast<const I4*>(M.ri);
     const S* gr = reinterpret_cast<const S*>(M.rr);
+    I4 ti = gi[tid < nrec ? tid : 0];
+    const int32_t tw = M.wk[tid < nrec ? tid : 0];
     S tr[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) tr[u] = gr[tid + u * nth < ntr ? tid + u * nth : 0];
@@ -1077,6 +1101,7 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
     const bool fast_rows = Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && inside && !fast;
     WalkStageIn<T, UB> in;
     if (!fast && !fast_rows) in.load(q, v, vdot, Lq, Lv, state0, B, M.nq, M.nv, 0, tid, nth);
+    if (tid < nrec) { const_cast<I4*>(c.tri)[tid] = ti; const_cast<int32_t*>(c.twk)[tid] = tw; }
 #pragma unroll
     for (int u = 0; u < TB; ++u)
       if (tid + u * nth < ntr) const_cast<S*>(c.trr)[tid + u * nth] = tr[u];
@@ -1123,14 +1148,14 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
   };
   // every pass reads the record (and passes A and C the constants) of its next step while the current one computes
   {
-    WalkRec rnext = walk_rec(c, 0, g);
+    WalkRaw raw = walk_raw(c, 0, g);
     T rr[TR_J];
     walk_consts<T, TR_J>(c, 0, g, rr);
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) {
       const int s1 = s + 1 < ns ? s + 1 : s;
-      const WalkRec r = rnext;
-      rnext = walk_rec(c, s1, g);
+      const WalkRec r = walk_rec(raw);
+      raw = walk_raw(c, s1, g);
       T rn[TR_J];
       walk_consts<T, TR_J>(c, s1, g, rn);
       walk_step_a<T, FLT, GEN, true>(c, W, St, s, r, rr, lane, want_qdot);
@@ -1139,7 +1164,7 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
       if ((M.sfm[1] >> s) & 1) __syncthreads();  // SF_AW: an A mailbox was written at this step
     }
   }
-  __syncthreads();  // the B mailboxes take over the rows of the A mailboxes' twist halves
+  if (shared_rows) __syncthreads();  // only then do the B mailboxes take over the rows of the A mailboxes' twist halves
   RBD_WMARK(2);
   {
     // pass B: the external wrench of the body of step s − 1 is requested while step s computes
@@ -1148,16 +1173,16 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
     T fe[6], fn[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { fe[k] = T(0); fn[k] = T(0); }
-    WalkRec rnext = walk_rec(c, ns - 1, g);
-    if (fext) wrench(rnext.orig6, fe);
+    WalkRaw raw = walk_raw(c, ns - 1, g);
+    if (fext) wrench(walk_uniform(raw.w.y) & 0xffff, fe);
 #pragma unroll 1
     for (int s = ns - 1; s >= 0; --s) {
       const int s1 = s > 0 ? s - 1 : 0;
-      const WalkRec r = rnext;
+      const WalkRec r = walk_rec(raw);
       T rr[TR_STRIDE];
       walk_consts<T, TR_STRIDE>(c, s, g, rr);
-      rnext = walk_rec(c, s1, g);
-      if (fext) wrench(rnext.orig6, fn);
+      raw = walk_raw(c, s1, g);
+      if (fext) wrench(walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff, fn);
       walk_step_rb<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe);
 #pragma unroll
       for (int k = 0; k < 6; ++k) fe[k] = fn[k];

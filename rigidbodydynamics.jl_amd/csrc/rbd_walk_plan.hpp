@@ -33,9 +33,8 @@ inline size_t walk_rows(int nq, int nv, int nA, int nB, int nS) {
 // es: bytes of a row value (one per lane: 8 for fp64 and for the packed pair of fp32 states), ss: bytes of a plan constant
 inline size_t walk_lds_bytes(int ns, int G, int nq, int nv, int nA, int nB, int nS, size_t es, size_t ss) {
   const size_t nrec = (size_t)ns * G;
-  // constants | chain table of a re-rooted tree (RC_MAX joints: 4 ints + 15 constants each) | rows.  (The records are not staged: the kernels
-  // read them through the scalar cache, walk_unpack below.)
-  return ((nrec * TR_STRIDE * ss + 15) & ~(size_t)15) + 64 + ((4 * 15 * ss + 15) & ~(size_t)15) + walk_rows(nq, nv, nA, nB, nS) * WR_STRIDE * es;
+  // plan records | constants | parking words | chain table of a re-rooted tree (RC_MAX joints: 4 ints + 15 constants each) | rows
+  return nrec * 16 + nrec * TR_STRIDE * ss + ((nrec * 4 + 15) & ~(size_t)15) + 64 + ((4 * 15 * ss + 15) & ~(size_t)15) + walk_rows(nq, nv, nA, nB, nS) * WR_STRIDE * es;
 }
 
 // ri: the packed records of the track plan ([ns * G * TI_STRIDE])
@@ -56,24 +55,6 @@ inline WalkPlan build_walk_plan(int ns, int G, const std::vector<int32_t>& ri) {
   if (P.nS > 255) return P;
   P.ok = true;
   return P;
-}
-
-// What the kernels read: one record of WREC_STRIDE ints per (step, track), every field in a word of its own — a record is fetched with
-// scalar loads (wave-uniform address, constant address space) straight into scalar registers, one step ahead of its use; nothing is left
-// to shift or mask.  wk: the parking words (slot + 1 | BFD_* << 8, the latter for a re-rooted tree).
-enum { WREC_FLAGS = 0, WREC_QOFF, WREC_VOFF, WREC_ORIG6, WREC_NBR, WREC_AW, WREC_AR, WREC_BW, WREC_BR0, WREC_PARK, WREC_RRF, WREC_STRIDE = 12 };
-inline std::vector<int32_t> walk_unpack(int ns, int G, const std::vector<int32_t>& ri, const std::vector<int32_t>& wk) {
-  std::vector<int32_t> out((size_t)ns * G * WREC_STRIDE, 0);
-  for (size_t i = 0; i < (size_t)ns * G; ++i) {
-    const int32_t* w = &ri[i * TI_STRIDE];
-    int32_t* o = &out[i * WREC_STRIDE];
-    const int x = w[0], y = w[1], z = w[2], ww = w[3], kk = wk[i];
-    o[WREC_FLAGS] = (y >> 16) & 0xff; o[WREC_QOFF] = x & 0xffff; o[WREC_VOFF] = (x >> 16) & 0xffff; o[WREC_ORIG6] = y & 0xffff; o[WREC_NBR] = (y >> 24) & 0x7f;
-    o[WREC_AW] = (z & 0xffff) - 1; o[WREC_AR] = ((z >> 16) & 0xffff) - 1; o[WREC_BW] = (ww & 0xffff) - 1; o[WREC_BR0] = ((ww >> 16) & 0xffff) - 1;
-    o[WREC_PARK] = (kk & 0xff) - 1; o[WREC_RRF] = (kk >> 8) & 3;
-    if (o[WREC_FLAGS] & TF_FIXED) { o[WREC_QOFF] = 0; o[WREC_VOFF] = 0; }  // a fixed joint has no coordinates: its offsets may be one past the end
-  }
-  return out;
 }
 
 }  // namespace rbd

@@ -8,7 +8,7 @@ import rbd_amd as rbd
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--dtype", default="f64"); ap.add_argument("--model", default="atlas_floating")
-ap.add_argument("--reps", type=int, default=200)
+ap.add_argument("--reps", type=int, default=200); ap.add_argument("--only", default="", help="substring filter on the op names")
 args = ap.parse_args()
 tdt = torch.float64 if args.dtype == "f64" else torch.float32
 model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
@@ -33,6 +33,7 @@ ops = {
 }
 res = {}
 for name, f in ops.items():
+    if args.only and args.only not in name: continue
     for _ in range(3): f()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(); cap = torch.cuda.Stream()

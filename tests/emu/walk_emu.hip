@@ -28,7 +28,10 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
     WalkCtx<T> c;
     c.M = M;
     walk_ctx_lds(c, base);
+    if (RNEA) walk_twist_rows_rnea(c);
+    memcpy(const_cast<I4*>(c.tri), M.ri, nrec * 16);
     memcpy(const_cast<S*>(c.trr), M.rr, nrec * TR_STRIDE * sizeof(S));
+    memcpy(const_cast<int32_t*>(c.twk), M.wk, nrec * 4);
     for (int t = 0; t < 64; ++t) walk_stage_chain(c, t, 64);
     auto state_of = [&](int l) { const long st = group * SPW + l; return st < B ? st : B - 1; };  // l: state of the workgroup, 0 <= l < 64 N
     for (int l = 0; l < SPW; ++l) {
@@ -50,7 +53,7 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
       while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
       each_wave([&](int g) {
         for (int s = s0; s <= s1; ++s)
-          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_a<T, FLT, GEN, RNEA, FLT && !RNEA>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(c, s, g), rr, l, qdot != nullptr); }
+          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_a<T, FLT, GEN, RNEA, FLT && !RNEA>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, qdot != nullptr); }
       });
       s0 = s1 + 1;
     }
@@ -67,14 +70,14 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
             T fe[6];
             for (int k = 0; k < 6; ++k) fe[k] = T(0);
             if (fext) {
-              const int o6 = walk_rec(c, s, g).orig6;
+              const int o6 = c.tri[s * G + g].y & 0xffff;
               for (int k = 0; k < 6; ++k)
                 for (int j = 0; j < N; ++j) set_lane(fe[k], j, fext[(o6 + k) * Lf.sk + state_of(l + 64 * j) * Lf.sb]);
             }
             T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr);
-            if (FLT && !RNEA) { const WalkRec rc = walk_rec(c, s, g); if ((rc.rrf & BFD_FCARRY) && (rc.flags & TF_VALID)) { if (rc.park >= 0) walk_get_park(c, rc.park, l, W[g * 64 + l]); walk_fcarry_b(c, W[g * 64 + l], l, fe); } }
-            if (RNEA) walk_step_rb<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(c, s, g), rr, l, fe);
-            else walk_step_b<T, FLT, GEN, FLT>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(c, s, g), rr, l, fe);
+            if (FLT && !RNEA) { const WalkRec rc = walk_rec(walk_raw(c, s, g)); if ((rc.rrf & BFD_FCARRY) && (rc.flags & TF_VALID)) { if (rc.park >= 0) walk_get_park(c, rc.park, l, W[g * 64 + l]); walk_fcarry_b(c, W[g * 64 + l], l, fe); } }
+            if (RNEA) walk_step_rb<T, FLT, GEN>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
+            else walk_step_b<T, FLT, GEN, FLT>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, fe);
           }
       });
       s0 = s1 - 1;
@@ -85,7 +88,7 @@ static int emu_run(const WalkModel& M, int reverse, long B, const typename Lanes
       while (s1 < ns - 1 && !((M.sfm[1] >> s1) & 1)) ++s1;
       each_wave([&](int g) {
         for (int s = s0; s <= s1; ++s)
-          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_c<T, FLT, GEN, FLT>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(c, s, g), rr, l, qdot != nullptr); }
+          for (int l = 0; l < 64; ++l) { T rr[TR_STRIDE]; walk_consts<T, TR_STRIDE>(c, s, g, rr); walk_step_c<T, FLT, GEN, FLT>(c, W[g * 64 + l], St[g * 64 + l], s, walk_rec(walk_raw(c, s, g)), rr, l, qdot != nullptr); }
       });
       s0 = s1 + 1;
     }
@@ -129,8 +132,7 @@ static int emu_t(const int32_t* dims, const int32_t* ri, const double* rr, const
   using S = typename Lanes<T>::S;
   if (info) { info[0] = P.nS; info[1] = (int32_t)walk_lds_bytes(M.ns, M.G, nq, nv, M.nA, M.nB, M.nS, sizeof(T), sizeof(S)); }
   std::vector<S> rrt(rr, rr + nrec * TR_STRIDE);
-  const std::vector<int32_t> recs = walk_unpack(M.ns, M.G, riv, P.wk);
-  M.ri = riv.data(); M.rr = rrt.data(); M.wk = recs.data();
+  M.ri = riv.data(); M.rr = rrt.data(); M.wk = P.wk.data();
   const int32_t* sf = ri + nrec * TI_STRIDE;  // the per-step flags follow the packed records
   for (int k = 0; k < 5; ++k) { M.sfm[k] = 0; for (int s = 0; s < M.ns; ++s) M.sfm[k] |= (uint64_t)((sf[s] >> k) & 1) << s; }
   memcpy(M.gravity, gravity, sizeof M.gravity);
