@@ -83,10 +83,14 @@ enum {
   RBD_ALGO_ABA_TRACKS = 5,   /* chains of the tree on a few lanes per state, canonical body frames (joint axis = +z), per-body
                                 results in lane-private LDS rows: the default wherever it applies (trees of revolute /
                                 prismatic / fixed joints, 6-dof joints on the world).  RBD_ERR_UNSUPPORTED elsewhere        */
-  RBD_ALGO_ABA_WALK = 6      /* the track schedule with one WAVEFRONT per track and one lane per state: a workgroup is up to four
+  RBD_ALGO_ABA_WALK = 6,     /* the track schedule with one WAVEFRONT per track and one lane per state: a workgroup is up to four
                                 wavefronts over the same 64 states, q / v / tau staged through LDS, per-joint results in accumulation
                                 registers.  Same scope as the track mapping, at most 11 steps per track; RBD_ERR_UNSUPPORTED
                                 elsewhere or when the rows of 64 states do not fit one compute unit's LDS                      */
+  RBD_ALGO_ABA_PIPE = 7      /* small batches: a workgroup is four wavefronts over 16 states x 4 tracks, and a body-step is cut into stages
+                                (transform chain | inertia | twist chain + bias force | articulated-body recursion) that run on the four
+                                SIMDs of a compute unit one step apart.  Trees of revolute joints with or without a 6-dof root, at most
+                                4 tracks of 11 steps; RBD_ERR_UNSUPPORTED elsewhere                                              */
 };
 
 /* ---- loop (non-tree) joint: src/mechanism_modification.jl:38-43,

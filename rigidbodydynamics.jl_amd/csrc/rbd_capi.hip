@@ -107,6 +107,7 @@ struct rbd_ws {
   TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr; size_t track_lds_bytes4 = 0; long track_nw4_max_batch = 0; size_t track_lds_bytes = 0; long track_min_batch = 0;
   ContactModel ctm{}; void* d_cp_body = nullptr; void* d_cp_r = nullptr; void* d_hs_r = nullptr;  // soft contact tables
   void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; size_t d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
+  WalkModel pm{}; void* d_pipe_rr = nullptr; void* d_pipe_rec = nullptr; size_t pipe_lds_bytes = 0; long pipe_max_batch = 0;  // role-pipelined mapping (rbd_pipe.hpp)
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
@@ -779,6 +780,28 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       w->walk_min_batch = (long)ncu * 32 + 1;
     }
     if (const char* e = getenv("RBD_WALK_MIN_BATCH")) w->walk_min_batch = atol(e);
+    // the role-pipelined form for small batches: revolute trees (with or without a 6-dof root) on at most 4 tracks
+    if (!P.general && P.G <= 4) {
+      const std::vector<int32_t> rec = walk_unpack4(P.ns, P.G, P.ri, m->walk.wk);
+      st = upload(&w->d_pipe_rec, rec.data(), rec.size() * sizeof(int32_t));
+      if (st == RBD_OK) {
+        if (dtype == RBD_F64) { const std::vector<double> c4 = walk_consts4<double>(P.ns, P.G, P.rr); st = upload(&w->d_pipe_rr, c4.data(), c4.size() * sizeof(double)); }
+        else { const std::vector<float> c4 = walk_consts4<float>(P.ns, P.G, P.rr); st = upload(&w->d_pipe_rr, c4.data(), c4.size() * sizeof(float)); }
+      }
+      if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+      WalkModel& pm = w->pm;
+      pm = w->wm;
+      pm.G = 4; pm.ri = nullptr; pm.rr = w->d_pipe_rr; pm.wk = (const int32_t*)w->d_pipe_rec;
+      w->pipe_lds_bytes = pipe_lds_bytes(P.ns, m->nq, m->nv, P.nA, P.nB, m->walk.nS, es);
+      if (w->pipe_lds_bytes > 160 * 1024) w->pipe_lds_bytes = 0;
+      if (w->pipe_lds_bytes > 0) {
+        const hipError_t e = dtype == RBD_F64 ? configure_pipe_kernel<double>(w->pipe_lds_bytes) : configure_pipe_kernel<float>(w->pipe_lds_bytes);
+        if (e != hipSuccess) { g_last_hip_error = std::string("configure_pipe_kernel: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
+      }
+      // RBD_ALGO_ABA picks it up to this batch size (RBD_PIPE_MAX_BATCH; 0 = never): one workgroup of 16 states per compute unit in one round
+      w->pipe_max_batch = 0;
+      if (const char* e = getenv("RBD_PIPE_MAX_BATCH")) w->pipe_max_batch = atol(e);
+    }
   }
   if (m->state.ok && m->state.nlevels <= state_max_levels(dtype == RBD_F64 ? 8 : 4)) {
     const StatePlan& P = m->state;
@@ -818,7 +841,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_rrbank_ib[0], w->d_rrbank_ib[1], w->d_rrbank_rb[0], w->d_rrbank_rb[1], w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_rrbank_ib[0], w->d_rrbank_ib[1], w->d_rrbank_rb[0], w->d_rrbank_rb[1], w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -1019,15 +1042,23 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   // the track kernel addresses its batch buffers with 32-bit byte offsets
   const bool can_track = m->track.ok && w->track_lds_bytes > 0 && !fuse && (double)B * (double)std::max(std::max(m->nq, m->nv), 6 * m->nb) * 8.0 < 4.0e9;
   const bool can_walk = m->track.ok && m->walk.ok && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch)) && !fuse;
+  const bool can_pipe = m->track.ok && m->walk.ok && w->pipe_lds_bytes > 0 && !fuse;
+  if (algorithm == RBD_ALGO_ABA_PIPE && !can_pipe) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_TRACKS && !can_track) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_CHAINS && !can_chain) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   int pick = algorithm;
-  if (algorithm == RBD_ALGO_ABA) pick = (can_walk && B >= w->walk_min_batch) ? RBD_ALGO_ABA_WALK : (can_track && B >= w->track_min_batch) ? RBD_ALGO_ABA_TRACKS : (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
+  if (algorithm == RBD_ALGO_ABA) pick = (can_pipe && B <= w->pipe_max_batch) ? RBD_ALGO_ABA_PIPE : (can_walk && B >= w->walk_min_batch) ? RBD_ALGO_ABA_WALK : (can_track && B >= w->track_min_batch) ? RBD_ALGO_ABA_TRACKS : (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
   Timed t(w);
   w->last_kernel = pick == RBD_ALGO_ABA_TRACKS ? "aba_track_kernel" : pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : pick == RBD_ALGO_ABA_CHAINS ? "aba_chain_kernel" : "aba_kernel";
-  if (pick == RBD_ALGO_ABA_WALK) {
+  if (pick == RBD_ALGO_ABA_PIPE) {
+    WalkModel pm = w->pm;
+    if (gravity) memcpy(pm.gravity, gravity, sizeof pm.gravity);
+    w->last_kernel = "aba_pipe_kernel";
+    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_pipe<double>(pm, B, w->pipe_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_aba_pipe<float>(pm, B, w->pipe_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+  } else if (pick == RBD_ALGO_ABA_WALK) {
     // the tree re-rooted at its centre (rbd_reroot.hpp) when there is one: fewer steps per track, better balanced tracks (RBD_WALK_NO_REROOT=1: the original tree)
     static const bool no_rr = getenv("RBD_WALK_NO_REROOT") != nullptr;
     const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;

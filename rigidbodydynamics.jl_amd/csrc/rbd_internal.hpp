@@ -75,6 +75,10 @@ template <typename T>
 hipError_t launch_rnea_walk(const WalkModel& M, int flt, int gen, int pair, long B, size_t lds_bytes, const void* q, const void* v, const void* vdot, const void* fext,
                             void* tau, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 template <typename T> hipError_t configure_walk_kernel(int flt, int gen, size_t lds_bytes, size_t lds_bytes_pair);
+template <typename T>
+hipError_t launch_aba_pipe(const WalkModel& M, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
+                           Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+template <typename T> hipError_t configure_pipe_kernel(size_t lds_bytes);
 // rbd_state_kernels.hip: one lane per state
 int state_max_levels(int element_size);
 template <typename T>

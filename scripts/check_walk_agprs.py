@@ -8,7 +8,7 @@ import re, sys
 src, max_steps = sys.argv[1], int(sys.argv[2])
 name, worst = None, {}
 for line in open(src):
-    m = re.match(r"^(_Z\S*(?:aba|rnea)_walk_kernel\S*):", line)
+    m = re.match(r"^(_Z\S*(?:aba|rnea)_(?:walk|pipe)_kernel\S*):", line)
     if m:
         name = m.group(1); worst[name] = [-1, 256]
         continue

@@ -1,7 +1,8 @@
 #!/bin/bash
-# per-kernel split of a simulate step at 65 536 states
-mkdir -p gpurun_out; export TMPDIR=/tmp; R=$PWD; cd /tmp
-for dt in f64 f32; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/simprof_$dt -- python $R/scripts/sim_prof.py 65536 $dt 2>&1 | grep "us per step"
-  f=$(find /tmp/simprof_$dt -name "*kernel_stats.csv" | head -1); echo "== $dt"; cut -d, -f1-4 $f | head -8; cp $f $R/gpurun_out/sim_kernel_stats_$dt.csv
-done
+# simulate with the quaternion-joint stage launch on a side stream: parity, then µs per RK4 step with and without
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests -x -q -m gpu -k "simulate or contact or mk_stage or integr" 2>&1 | tail -3
+for dt in f64 f32; do for B in 4096 65536; do
+  echo "side   $(python scripts/sim_prof.py $B $dt 2>&1 | grep 'us per step')"
+  echo "serial $(RBD_NO_SIDE_STREAM=1 python scripts/sim_prof.py $B $dt 2>&1 | grep 'us per step')"
+done; done

@@ -1153,3 +1153,50 @@ def test_inverse_dynamics_walk_full_size_and_pairs(rbd, oracle, models, monkeypa
     cast = lambda a: a.astype(np.float32).astype(np.float64)
     ref = oracle.inverse_dynamics(model, cast(q), cast(v), cast(vd), cast(fe), nthreads=NT)
     assert np.abs(host(out, state) - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum"])
+def test_dynamics_pipe_f64(rbd, oracle, models, name, layout):
+    """aba_pipe_kernel (a body-step cut into stages on the four SIMDs of a compute unit, 16 states x 4 tracks per wavefront), forced: ragged batch,
+    torques + a wrench on every body + q̇; then no torques / no wrenches; fp64 at the reference's 1e-10."""
+    model = models[name]
+    B = 4096 + 5
+    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 93)
+    result = rbd.DynamicsResult(model, B, layout=layout)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_pipe")
+    assert rbd.sync(state) == 0
+    assert rbd.last_kernel(state) == "aba_pipe_kernel"
+    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True, nthreads=NT)
+    got = host(result.vd, state)
+    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max(), np.abs(got).max())
+    assert np.abs(host(result.qd, state) - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
+    rbd.dynamics_(result, state, algorithm="aba_pipe")
+    assert rbd.sync(state) == 0
+    ref = oracle.dynamics(model, q, v, nthreads=NT)
+    got = host(result.vd, state)
+    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max(), np.abs(got).max())
+
+
+@pytest.mark.gpu
+def test_dynamics_pipe_f32_and_scope(rbd, oracle, models):
+    """fp32: backward error of M v̇ = τ − c on every state; mechanisms outside the mapping's scope (prismatic / fixed / 3-dof joints) are refused, not mis-evaluated."""
+    model = models["atlas_floating"]
+    B = 1000
+    state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 94)
+    result = rbd.DynamicsResult(model, B, dtype=TD["f32"])
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_pipe")
+    assert rbd.sync(state) == 0
+    got = host(result.vd, state)
+    M, c = oracle.mass_matrix(model, q, nthreads=NT), oracle.dynamics_bias(model, q, v, fe, nthreads=NT)
+    Ms = np.tril(M) + np.transpose(np.tril(M, -1), (0, 2, 1))
+    res = np.einsum("bij,bj->bi", Ms, got) - (tau - c)
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(got, axis=1) + np.linalg.norm(tau - c, axis=1))
+    assert eta.max() <= 2e-5, eta.max()
+    for other in ("acrobot_urdf", "randmech1"):
+        m2 = models[other]
+        s2, _, _, t2, _ = make(rbd, m2, 8, "f64", "aos", 95)
+        r2 = rbd.DynamicsResult(m2, 8)
+        with pytest.raises(Exception):
+            rbd.dynamics_(r2, s2, dev(t2, s2), algorithm="aba_pipe")
