@@ -107,9 +107,8 @@ template <typename T> RBD_HD void pipe_parent_k(const PipeCtx<T>& c, const WalkR
 
 // ---------------- pass A ----------------
 // K, step s: transform to root of the body (mechanism_state.jl:687-700), sin/cos kept for the later passes; -> ring slot, A mailbox, parking
-template <typename T> RBD_HD void pipe_a_k(const PipeCtx<T>& c, PipeK<T>& W, WalkStash<T>& St, int s, int slot, int lane) {
+template <typename T> RBD_HD void pipe_a_k(const PipeCtx<T>& c, PipeK<T>& W, WalkStash<T>& St, int s, int slot, const WalkRec& r, int lane) {
   const int track = lane & 3, st = lane >> 2;
-  const WalkRec r = pipe_rec(c, s, track);
   if (!(r.flags & TF_VALID)) return;
   T rr[TR_J];
   pipe_consts<T, 0, TR_J>(c, s, track, rr);
@@ -141,9 +140,8 @@ template <typename T> RBD_HD void pipe_a_k(const PipeCtx<T>& c, PipeK<T>& W, Wal
   if (r.park >= 0) { T* b = pipe_box(c.parkK, 12, r.park, st); pipe_put<T, 9>(b, PIPE_STATES, W.R); pipe_put<T, 3>(b + 9 * PIPE_STATES, PIPE_STATES, W.p); }
 }
 // I, for step s (one step AHEAD of K): sin q, cos q of the joint -> ring (nothing in the chain depends on them being computed late)
-template <typename T> RBD_HD void pipe_a_i(const PipeCtx<T>& c, int s, int lane) {
+template <typename T> RBD_HD void pipe_a_i(const PipeCtx<T>& c, int s, const WalkRec& r, int lane) {
   const int track = lane & 3, st = lane >> 2;
-  const WalkRec r = pipe_rec(c, s, track);
   if (!(r.flags & TF_VALID) || (r.flags & TF_FLOATING)) return;
   T sn, cs;
   sincos_fast(*pipe_row(c, c.rq + r.qoff, st), &sn, &cs);
@@ -151,9 +149,8 @@ template <typename T> RBD_HD void pipe_a_i(const PipeCtx<T>& c, int s, int lane)
   mq[0] = sn; mq[64] = cs;
 }
 // T, step s (one step behind K): twist and velocity-product acceleration (mechanism_state.jl:769-780, :814-830); q̇ over the q rows
-template <typename T> RBD_HD void pipe_a_t(const PipeCtx<T>& c, PipeT<T>& W, int s, int slot, int lane, bool want_qdot) {
+template <typename T> RBD_HD void pipe_a_t(const PipeCtx<T>& c, PipeT<T>& W, int s, int slot, const WalkRec& r, int lane, bool want_qdot) {
   const int track = lane & 3, st = lane >> 2;
-  const WalkRec r = pipe_rec(c, s, track);
   if (!(r.flags & TF_VALID)) return;
   if (!(r.flags & TF_CHAINED)) {
     if (r.flags & TF_LEVEL0) {
@@ -202,9 +199,8 @@ template <typename T> RBD_HD void pipe_a_t(const PipeCtx<T>& c, PipeT<T>& W, int
 
 // ---------------- pass B ----------------
 // K, step s: publish the body's transform, then un-compose the joint towards the parent (H_parent = H X_joint⁻¹)
-template <typename T> RBD_HD void pipe_b_k(const PipeCtx<T>& c, PipeK<T>& W, WalkStash<T>& St, int s, int slot, int lane) {
+template <typename T> RBD_HD void pipe_b_k(const PipeCtx<T>& c, PipeK<T>& W, WalkStash<T>& St, int s, int slot, const WalkRec& r, int lane) {
   const int track = lane & 3, st = lane >> 2;
-  const WalkRec r = pipe_rec(c, s, track);
   if (!(r.flags & TF_VALID)) return;
   if (r.park >= 0) { const T* b = pipe_box(c.parkK, 12, r.park, st); pipe_get<T, 9>(b, PIPE_STATES, W.R); pipe_get<T, 3>(b + 9 * PIPE_STATES, PIPE_STATES, W.p); }
   T* m = pipe_ring(c.ringK, PRK_N, slot, lane);
@@ -232,9 +228,8 @@ template <typename T> RBD_HD void pipe_b_k(const PipeCtx<T>& c, PipeK<T>& W, Wal
   }
 }
 // I, step s (one behind K): the body's spatial inertia in the root frame (mechanism_state.jl:836-846)
-template <typename T> RBD_HD void pipe_b_i(const PipeCtx<T>& c, int s, int slot_k, int slot_i, int lane) {
+template <typename T> RBD_HD void pipe_b_i(const PipeCtx<T>& c, int s, int slot_k, int slot_i, const WalkRec& r, int lane) {
   const int track = lane & 3;
-  const WalkRec r = pipe_rec(c, s, track);
   if (!(r.flags & TF_VALID)) return;
   T rr[10], R[9], p[3];
   pipe_consts<T, TR_J, 10>(c, s, track, rr);  // J (6) | m c (3) | m
@@ -250,9 +245,8 @@ template <typename T> RBD_HD void pipe_b_i(const PipeCtx<T>& c, int s, int slot_
 }
 // T, step s (two behind K): p̃A = I a_vp + T ×* I T − w_ext (newton_euler, mechanism_state.jl:872-876), the motion subspace, then the
 // twist chain un-composed towards the parent (T_parent = T − S q̇, a_parent = a − [T, S q̇]).  fe: the body's external wrench.
-template <typename T> RBD_HD void pipe_b_t(const PipeCtx<T>& c, PipeT<T>& W, int s, int slot_k, int slot_i, int slot_t, int lane, const T* fe) {
+template <typename T> RBD_HD void pipe_b_t(const PipeCtx<T>& c, PipeT<T>& W, int s, int slot_k, int slot_i, int slot_t, const WalkRec& r, int lane, const T* fe) {
   const int track = lane & 3, st = lane >> 2;
-  const WalkRec r = pipe_rec(c, s, track);
   if (!(r.flags & TF_VALID)) return;
   if (r.park >= 0) { const T* b = pipe_box(c.parkT, 12, r.park, st); pipe_get<T, 6>(b, PIPE_STATES, W.Tw); pipe_get<T, 6>(b + 6 * PIPE_STATES, PIPE_STATES, W.av); }
   RInertia<T> I;
@@ -297,9 +291,8 @@ template <typename T> RBD_HD void pipe_b_t(const PipeCtx<T>& c, PipeT<T>& W, int
 }
 // S, step s (three behind K): the articulated-body step.  IA = I + Σ children's Ia; U = IA S, D = S'U, u = τ − S'p̃A;
 // hand-off Ia = IA − U D⁻¹ U', p̃a = p̃A + U D⁻¹ u.  A 6-dof root: IA a_Δ = S⁻ᵀτ − p̃A, v̇ = S⁻¹ a_Δ.
-template <typename T> RBD_HD void pipe_b_s(const PipeCtx<T>& c, PipeS<T>& W, WalkStash<T>& St, int s, int slot_t, int lane) {
+template <typename T> RBD_HD void pipe_b_s(const PipeCtx<T>& c, PipeS<T>& W, WalkStash<T>& St, int s, int slot_t, const WalkRec& r, int lane) {
   const int track = lane & 3, st = lane >> 2;
-  const WalkRec r = pipe_rec(c, s, track);
   if (!(r.flags & TF_VALID)) return;
   const T* m = pipe_ring(c.ringT, PRT_N, slot_t, lane);
   T IA[21], pA[6], S[6];
@@ -373,9 +366,8 @@ template <typename T> RBD_HD void pipe_b_s(const PipeCtx<T>& c, PipeS<T>& W, Wal
 // ---------------- pass C ----------------
 // S alone (the motion subspaces were kept by pass B; the tracks' edges are lanes of this one wavefront: no barrier inside the pass):
 // v̇ = D⁻¹u − (U D⁻¹)' a_Δ,parent; a_Δ += S v̇
-template <typename T> RBD_HD void pipe_c_s(const PipeCtx<T>& c, PipeS<T>& W, WalkStash<T>& St, int s, int lane) {
+template <typename T> RBD_HD void pipe_c_s(const PipeCtx<T>& c, PipeS<T>& W, WalkStash<T>& St, int s, const WalkRec& r, int lane) {
   const int track = lane & 3, st = lane >> 2;
-  const WalkRec r = pipe_rec(c, s, track);
   if (!(r.flags & TF_VALID)) return;
   if (!(r.flags & TF_CHAINED)) {
     if (r.flags & TF_LEVEL0) {
@@ -505,34 +497,43 @@ __global__ __launch_bounds__(256) void aba_pipe_kernel(WalkModel M, long B, cons
   // Every role passes the same number of barriers: (ns + 1) + (ns + 3) + 1.
   // Ring slots, pass B (iteration j, K at step ns − 1 − j, I one step behind, T two, S three): K writes j mod 3; I reads (j + 2) mod 3 and
   // writes j mod 2; T reads K's (j + 1) mod 3 and I's (j + 1) mod 2 and writes j mod 2; S reads (j + 1) mod 2.  Pass A: slot = step mod 2.
+  const int track = lane & 3;
+  // the record of a stage's NEXT step is read before the barrier that ends the current one (it depends on nothing the other stages produce)
+  auto rec_at = [&](int s) { return pipe_rec(c, s < 0 ? 0 : (s >= ns ? ns - 1 : s), track); };
   if (role == PIPE_K) {
     WalkStash<T> St;
     PipeK<T> W;
     pipe_identity(W);
+    WalkRec r = rec_at(0);
 #pragma unroll 1
     for (int i = 0; i <= ns; ++i) {
-      if (i < ns) pipe_a_k(c, W, St, i, i & 1, lane);
+      if (i < ns) pipe_a_k(c, W, St, i, i & 1, r, lane);
+      r = rec_at(i + 1 < ns ? i + 1 : ns - 1);  // after the last step: the first record of pass B
       __syncthreads();
     }
     RBD_PMARK(2);
 #pragma unroll 1
     for (int j = 0; j < ns + 3; ++j) {
       const int s = ns - 1 - j;
-      if (s >= 0) pipe_b_k(c, W, St, s, j % 3, lane);
+      if (s >= 0) pipe_b_k(c, W, St, s, j % 3, r, lane);
+      r = rec_at(s - 1);
       __syncthreads();
     }
     RBD_PMARK(3);
   } else if (role == PIPE_I) {
+    WalkRec r = rec_at(1);
 #pragma unroll 1
     for (int i = 0; i <= ns; ++i) {
-      if (i + 1 < ns) pipe_a_i(c, i + 1, lane);
+      if (i + 1 < ns) pipe_a_i(c, i + 1, r, lane);
+      r = rec_at(i + 2 < ns ? i + 2 : ns - 1);
       __syncthreads();
     }
     RBD_PMARK(2);
 #pragma unroll 1
     for (int j = 0; j < ns + 3; ++j) {
       const int s = ns - j;
-      if (s >= 0 && s < ns) pipe_b_i(c, s, (j + 2) % 3, j & 1, lane);
+      if (s >= 0 && s < ns) pipe_b_i(c, s, (j + 2) % 3, j & 1, r, lane);
+      r = rec_at(s - 1);
       __syncthreads();
     }
     RBD_PMARK(3);
@@ -540,14 +541,15 @@ __global__ __launch_bounds__(256) void aba_pipe_kernel(WalkModel M, long B, cons
     PipeT<T> W;
 #pragma unroll
     for (int k = 0; k < 6; ++k) { W.Tw[k] = T(0); W.av[k] = T(0); }
+    WalkRec r = rec_at(0);
 #pragma unroll 1
     for (int i = 0; i <= ns; ++i) {
-      if (i >= 1) pipe_a_t(c, W, i - 1, (i - 1) & 1, lane, want_qdot);
+      if (i >= 1) pipe_a_t(c, W, i - 1, (i - 1) & 1, r, lane, want_qdot);
+      r = rec_at(i < ns ? i : ns - 1);
       __syncthreads();
     }
     RBD_PMARK(2);
     // the external wrench of a body is asked for (global memory) one step before its turn
-    const int track = lane & 3;
     long gs = state0 + (lane >> 2);
     gs = gs < B ? gs : B - 1;
     const T* fel = fext ? fext + gs * Lf.sb : nullptr;
@@ -555,23 +557,23 @@ __global__ __launch_bounds__(256) void aba_pipe_kernel(WalkModel M, long B, cons
 #pragma unroll
     for (int k = 0; k < 6; ++k) { fe[k] = T(0); fn[k] = T(0); }
     if (fext) {
-      const int o6 = c.rec[((ns - 1) * 4 + track) * WREC_STRIDE + WREC_ORIG6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) fe[k] = fel[(long)(o6 + k) * Lf.sk];
+      for (int k = 0; k < 6; ++k) fe[k] = fel[(long)(r.orig6 + k) * Lf.sk];  // r: the record of step ns − 1
     }
 #pragma unroll 1
     for (int j = 0; j < ns + 3; ++j) {
       const int s = ns + 1 - j;
+      const WalkRec rn = rec_at(s >= ns ? ns - 1 : s - 1);
       if (s >= 0 && s < ns) {
         if (fext && s > 0) {
-          const int o6 = c.rec[((s - 1) * 4 + track) * WREC_STRIDE + WREC_ORIG6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) fn[k] = fel[(long)(o6 + k) * Lf.sk];
+          for (int k = 0; k < 6; ++k) fn[k] = fel[(long)(rn.orig6 + k) * Lf.sk];
         }
-        pipe_b_t(c, W, s, (j + 1) % 3, (j + 1) & 1, j & 1, lane, fe);
+        pipe_b_t(c, W, s, (j + 1) % 3, (j + 1) & 1, j & 1, r, lane, fe);
 #pragma unroll
         for (int k = 0; k < 6; ++k) fe[k] = fn[k];
       }
+      r = rn;
       __syncthreads();
     }
     RBD_PMARK(3);
@@ -585,16 +587,24 @@ __global__ __launch_bounds__(256) void aba_pipe_kernel(WalkModel M, long B, cons
 #pragma unroll 1
     for (int i = 0; i <= ns; ++i) __syncthreads();
     RBD_PMARK(2);
+    WalkRec r = rec_at(ns - 1);
 #pragma unroll 1
     for (int j = 0; j < ns + 3; ++j) {
       const int s = ns + 2 - j;
-      if (s >= 0 && s < ns) pipe_b_s(c, W, St, s, (j + 1) & 1, lane);
+      const WalkRec rn = rec_at(s >= ns ? ns - 1 : s - 1);
+      if (s >= 0 && s < ns) pipe_b_s(c, W, St, s, (j + 1) & 1, r, lane);
+      r = rn;
       __syncthreads();
     }
     RBD_PMARK(3);
-    // pass C: this wavefront alone
+    // pass C: this wavefront alone; the record and the motion subspace of the next step are in flight while the current one computes
+    r = rec_at(0);
 #pragma unroll 1
-    for (int s = 0; s < ns; ++s) pipe_c_s(c, W, St, s, lane);
+    for (int s = 0; s < ns; ++s) {
+      const WalkRec rn = rec_at(s + 1);
+      pipe_c_s(c, W, St, s, r, lane);
+      r = rn;
+    }
   }
   __syncthreads();
   RBD_PMARK(4);

@@ -51,17 +51,17 @@ static int emu_run(const WalkModel& M, int reverse, long B, const T* q, const T*
     for (int i = 0; i <= ns; ++i)
       each_role([&](int role) {
         for (int l = 0; l < 64; ++l) {
-          if (role == PIPE_K) { if (i < ns) pipe_a_k(c, WK[l], StK[l], i, i & 1, l); }
-          else if (role == PIPE_I) { if (i + 1 < ns) pipe_a_i(c, i + 1, l); }
-          else if (role == PIPE_T) { if (i >= 1) pipe_a_t(c, WT[l], i - 1, (i - 1) & 1, l, qdot != nullptr); }
+          if (role == PIPE_K) { if (i < ns) pipe_a_k(c, WK[l], StK[l], i, i & 1, pipe_rec(c, i, l & 3), l); }
+          else if (role == PIPE_I) { if (i + 1 < ns) pipe_a_i(c, i + 1, pipe_rec(c, i + 1, l & 3), l); }
+          else if (role == PIPE_T) { if (i >= 1) pipe_a_t(c, WT[l], i - 1, (i - 1) & 1, pipe_rec(c, i - 1, l & 3), l, qdot != nullptr); }
         }
       });
     for (int j = 0; j < ns + 3; ++j) {
       const int sk = ns - 1 - j;
       each_role([&](int role) {
         for (int l = 0; l < 64; ++l) {
-          if (role == PIPE_K) { if (sk >= 0) pipe_b_k(c, WK[l], StK[l], sk, j % 3, l); }
-          else if (role == PIPE_I) { if (sk + 1 >= 0 && sk + 1 < ns) pipe_b_i(c, sk + 1, (j + 2) % 3, j & 1, l); }
+          if (role == PIPE_K) { if (sk >= 0) pipe_b_k(c, WK[l], StK[l], sk, j % 3, pipe_rec(c, sk, l & 3), l); }
+          else if (role == PIPE_I) { if (sk + 1 >= 0 && sk + 1 < ns) pipe_b_i(c, sk + 1, (j + 2) % 3, j & 1, pipe_rec(c, sk + 1, l & 3), l); }
           else if (role == PIPE_T) {
             const int s = sk + 2;
             if (s >= 0 && s < ns) {
@@ -71,17 +71,17 @@ static int emu_run(const WalkModel& M, int reverse, long B, const T* q, const T*
                 const int o6 = c.rec[(s * 4 + (l & 3)) * WREC_STRIDE + WREC_ORIG6];
                 for (int k = 0; k < 6; ++k) fe[k] = fext[(o6 + k) * Lf.sk + state_of(l >> 2) * Lf.sb];
               }
-              pipe_b_t(c, WT[l], s, (j + 1) % 3, (j + 1) & 1, j & 1, l, fe);
+              pipe_b_t(c, WT[l], s, (j + 1) % 3, (j + 1) & 1, j & 1, pipe_rec(c, s, l & 3), l, fe);
             }
           } else {
             const int s = sk + 3;
-            if (s >= 0 && s < ns) pipe_b_s(c, WS[l], StS[l], s, (j + 1) & 1, l);
+            if (s >= 0 && s < ns) pipe_b_s(c, WS[l], StS[l], s, (j + 1) & 1, pipe_rec(c, s, l & 3), l);
           }
         }
       });
     }
     for (int s2 = 0; s2 < ns; ++s2)  // pass C: the S wavefront alone, no barriers
-      for (int l = 0; l < 64; ++l) pipe_c_s(c, WS[l], StS[l], s2, l);
+      for (int l = 0; l < 64; ++l) pipe_c_s(c, WS[l], StS[l], s2, pipe_rec(c, s2, l & 3), l);
     for (int st = 0; st < PIPE_STATES; ++st) {
       const long gs = group * PIPE_STATES + st;
       if (gs >= B) continue;
