@@ -41,7 +41,9 @@ for name, f in ops.items():
         f()
         with torch.cuda.graph(g, stream=cap):
             for _ in range(args.reps): f()
-    torch.cuda.synchronize(); g.replay(); torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    for _ in range(3): g.replay()  # untimed: clocks up, caches warm (the first op of a fresh process otherwise reads ~20 % high)
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / args.reps * 1e3
