@@ -1200,3 +1200,34 @@ def test_dynamics_pipe_f32_and_scope(rbd, oracle, models):
         r2 = rbd.DynamicsResult(m2, 8)
         with pytest.raises(Exception):
             rbd.dynamics_(r2, s2, dev(t2, s2), algorithm="aba_pipe")
+
+
+@pytest.mark.gpu
+def test_mass_matrix_solve_large_ragged_batch_whole_square(rbd, oracle, models):
+    """The large-batch fp32 route of mass_matrix! + Cholesky (one-lane-per-state CRBA into a staging buffer, tile Cholesky that re-emits M as
+    whole block columns through LDS) on a batch that is NOT a multiple of the 16 states of a Cholesky wavefront, with canaries around the
+    outputs: the lower triangle against the oracle, the strict upper triangle = its mirror image (what this route documents), nothing written
+    outside the B states."""
+    model = models["atlas_floating"]
+    B, nv = 32768 + 7, model.nv
+    state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 29)
+    rhs = dev(tau, state)
+    pad = 3
+    xbuf = torch.full((B + pad, nv), 777.0, dtype=torch.float32, device="cuda")
+    Mbuf = torch.full((B + pad, nv * nv), 777.0, dtype=torch.float32, device="cuda")
+    x, Mout = xbuf[:B], Mbuf[:B]
+    rbd.mass_matrix_solve_(x, state, rhs, Mout)
+    assert rbd.sync(state) == 0
+    assert float((xbuf[B:] - 777.0).abs().max()) == 0.0 and float((Mbuf[B:] - 777.0).abs().max()) == 0.0
+    Mfull = Mout.reshape(B, nv, nv).transpose(1, 2).double()  # column-major per state
+    assert float((Mfull - Mfull.transpose(1, 2)).abs().max()) == 0.0  # the mirror image, bit for bit
+    idx = np.concatenate([np.arange(0, B, 16), np.arange(B - 7, B)])  # a state of every wavefront + the ragged tail
+    Mo = oracle.mass_matrix(model, q[idx], nthreads=NT)
+    Mo = np.tril(Mo) + np.transpose(np.tril(Mo, -1), (0, 2, 1))
+    Mg = Mfull[torch.as_tensor(idx, device=Mfull.device)].cpu().numpy()
+    assert np.abs(Mg - Mo).max() <= 2e-5 * np.abs(Mo).max()
+    xg = x[torch.as_tensor(idx, device=x.device)].double().cpu().numpy()
+    r = tau[idx]
+    res = np.einsum("bij,bj->bi", Mo, xg) - r
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Mo, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(r, axis=1))
+    assert eta.max() <= 1e-5
