@@ -75,3 +75,56 @@ def test_revolute_only_is_classical_rk4(rbd, oracle, models, sim):
     vr = v + dt / 6 * (k1v + 2 * k2v + 2 * k3v + k4v)
     qs, vs = sim.step(m, q[0], v[0], dt, tau[0])
     assert np.allclose(qs, qr[0], atol=1e-14) and np.allclose(vs, vr[0], atol=1e-13)
+
+
+def _hat(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def test_se3_exp_is_the_matrix_exponential(sim):
+    """test/test_spatial.jl:248-270: exp(ξ) against the exponential of the 4 x 4 matrix [hat(φ_rot) φ_trans; 0 0] (scipy's expm — no formula
+    shared with the restatement), log(exp(ξ)) = ξ, for rotation angles from 0 (100 values within 10 eps) to π − eps, and for a pure translation."""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(74)
+    thetas = np.concatenate([np.linspace(0.0, 10 * np.finfo(float).eps, 100), np.linspace(0.0, np.pi - np.finfo(float).eps, 100)])
+    for th in thetas:
+        u, w = rng.random(3), rng.random(3)
+        prot = u / np.linalg.norm(u) * th * 2 * (rng.random() - 0.5)
+        ptrans = w / np.linalg.norm(w) * th * 2 * (rng.random() - 0.5)
+        dq, dp = sim.se3_exp(prot, ptrans)
+        xi = np.zeros((4, 4)); xi[:3, :3] = _hat(prot); xi[:3, 3] = ptrans
+        H = expm(xi)
+        assert np.allclose(sim.qrot(dq), H[:3, :3], atol=1e-12) and np.allclose(dp, H[:3, 3], atol=1e-12)
+        psi, qv, _, _ = sim.se3_log_with_rate(dq, dp, np.zeros(3), np.zeros(3))
+        assert np.allclose(psi, prot, atol=1e-9) and np.allclose(qv, ptrans, atol=1e-9)
+    ptrans = rng.random(3)
+    dq, dp = sim.se3_exp(np.zeros(3), ptrans)
+    psi, qv, _, _ = sim.se3_log_with_rate(dq, dp, np.zeros(3), np.zeros(3))
+    assert np.allclose(psi, 0) and np.allclose(qv, ptrans)
+
+
+def test_se3_exp_wraps_beyond_pi(sim):
+    """test/test_spatial.jl:272-278: a rotation by θ > π is the rotation by θ mod 2π (as transforms)."""
+    rng = np.random.default_rng(75)
+    eps = np.finfo(float).eps
+    for th in np.concatenate([np.linspace(np.pi - 10 * eps, np.pi + 10 * eps, 100), np.linspace(np.pi, 6 * np.pi, 100)]):
+        w = rng.random(3); w /= np.linalg.norm(w)
+        q1, p1 = sim.se3_exp(w * th, np.zeros(3))
+        q2, p2 = sim.se3_exp(w * np.mod(th, 2 * np.pi), np.zeros(3))
+        assert np.allclose(sim.qrot(q1), sim.qrot(q2), atol=1e-9) and np.allclose(p1, p2, atol=1e-12)
+
+
+def test_rotation_vector_rate_is_the_derivative_of_the_rotation(sim):
+    """test/test_spatial.jl:13-33 (Bortz equation): with φ̇ = rotation_vector_rate(φ, ω), d/dt R(φ) = R hat(ω) — central differences stand in
+    for the reference's dual numbers; at φ = 0 the rate is ω itself."""
+    rng = np.random.default_rng(62)
+    for phi in (rng.random(3), 2.5 * rng.random(3), np.zeros(3)):
+        w = rng.random(3)
+        phid = sim.rotation_vector_rate(phi, w)
+        if np.linalg.norm(phi) == 0:
+            assert np.allclose(phid, w)
+            continue
+        R = sim.qrot(sim.quat_from_rotvec(phi))
+        h = 1e-6
+        Rd = (sim.qrot(sim.quat_from_rotvec(phi + h * phid)) - sim.qrot(sim.quat_from_rotvec(phi - h * phid))) / (2 * h)
+        assert np.allclose(Rd, R @ _hat(w), atol=1e-8)
