@@ -128,3 +128,23 @@ def test_rotation_vector_rate_is_the_derivative_of_the_rotation(sim):
         h = 1e-6
         Rd = (sim.qrot(sim.quat_from_rotvec(phi + h * phid)) - sim.qrot(sim.quat_from_rotvec(phi - h * phid))) / (2 * h)
         assert np.allclose(Rd, R @ _hat(w), atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["randmech1", "randmech2", "randmech3", "inner_floating", "atlas_floating"])
+def test_local_and_global_coordinates_are_consistent(rbd, oracle, models, sim, name):
+    """test/test_mechanism_algorithms.jl:800-843 for every joint type at once: global_coordinates(q0, 0) = q0 (Duindam, def. 2.9), and with
+    q = global_coordinates(q0, ϕ) and ϕ̇ = the rate local_coordinates! returns for (q, v), moving ϕ along ϕ̇ moves q along
+    q̇ = velocity_to_configuration_derivative(q, v) (central differences where the reference uses dual numbers; q̇ from the C oracle)."""
+    m = models[name]
+    rng = np.random.default_rng(44)
+    q0 = rbd.rand_configuration(m, 1, rng)[0]
+    assert np.allclose(sim.global_coordinates(m, q0, np.zeros(m.nv)), q0, atol=1e-15)
+    for _ in range(5):
+        phi = 0.4 * rng.standard_normal(m.nv)
+        q = sim.global_coordinates(m, q0, phi)
+        v = rng.standard_normal(m.nv)
+        phid = sim.local_rate(m, q0, q, v)
+        h = 1e-6
+        qd_fd = (sim.global_coordinates(m, q0, phi + h * phid) - sim.global_coordinates(m, q0, phi - h * phid)) / (2 * h)
+        _, qd = oracle.dynamics(m, q[None], v[None], want_qdot=True)
+        assert np.allclose(qd_fd, qd[0], atol=2e-8), np.abs(qd_fd - qd[0]).max()
