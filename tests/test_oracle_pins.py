@@ -308,3 +308,27 @@ def test_inverse_dynamics_external_wrenches_momentum_rate(rbd, oracle, models, n
     _, hp, _ = oracle.momentum_matrix(model, q + h * qd, v + h * vd)
     _, hm, _ = oracle.momentum_matrix(model, q - h * qd, v - h * vd)
     assert np.abs((hp - hm) / (2 * h) - hdot).max() <= 1e-6 * max(1.0, np.abs(hdot).max())
+
+
+@pytest.mark.parametrize("name", ["atlas_floating", "randmech1", "randmech2", "inner_floating"])
+def test_spatial_accelerations_are_twist_derivatives(rbd, oracle, models, name):
+    """test/test_mechanism_algorithms.jl:459-490 (relative_acceleration vs the autodiff of relative_twist), with the root as base and central
+    differences for the dual numbers: along q(t) = global_coordinates(q, t ϕ̇), v(t) = v + t v̇ the root-frame twist of every body changes at the
+    rate spatial_accelerations! reports; inverse_dynamics!'s `accelerations` are those plus the root's −gravity (:387-417)."""
+    import importlib
+    sim = importlib.import_module("simulate_np")
+    m = models[name]
+    q, v, _ = rand_inputs(rbd, m, 1, 29)
+    q, v = q[0], v[0]
+    vd = np.random.default_rng(29).random(m.nv)
+    _, _, A = oracle.body_kinematics(m, q[None], v[None], vd[None])
+    h = 1e-6
+    phid = sim.local_rate(m, q, q, v)  # the local-coordinate rates at ϕ = 0 (= v but for Planar joints, whose rates are world-aligned)
+    qp, qm = sim.global_coordinates(m, q, h * phid), sim.global_coordinates(m, q, -h * phid)
+    _, Tp, _ = oracle.body_kinematics(m, qp[None], (v + h * vd)[None], vd[None])
+    _, Tm, _ = oracle.body_kinematics(m, qm[None], (v - h * vd)[None], vd[None])
+    fd = (Tp - Tm) / (2 * h)
+    assert np.abs(fd - A).max() <= 1e-7 * max(1.0, np.abs(A).max()), np.abs(fd - A).max()
+    _, _, acc = oracle.inverse_dynamics_bodies(m, q[None], v[None], vd[None])
+    g = np.asarray(m.gravity, float)
+    assert np.abs(acc[0] - A[0] - np.r_[np.zeros(3), -g]).max() <= 1e-12 * max(1.0, np.abs(A).max())
