@@ -332,3 +332,24 @@ def test_spatial_accelerations_are_twist_derivatives(rbd, oracle, models, name):
     _, _, acc = oracle.inverse_dynamics_bodies(m, q[None], v[None], vd[None])
     g = np.asarray(m.gravity, float)
     assert np.abs(acc[0] - A[0] - np.r_[np.zeros(3), -g]).max() <= 1e-12 * max(1.0, np.abs(A).max())
+
+
+@pytest.mark.parametrize("name", ["atlas_floating", "randmech1", "randmech3", "inner_floating"])
+def test_momentum_rate_is_A_vdot_plus_bias(rbd, oracle, models, name):
+    """test/test_mechanism_algorithms.jl:677-705: momentum two ways (A v = Σ I_b T_b), and its rate of change along a trajectory — central
+    differences of momentum(q(t), v(t)) for the reference's dual numbers — equals momentum_matrix · v̇ + momentum_rate_bias."""
+    import importlib
+    sim = importlib.import_module("simulate_np")
+    m = models[name]
+    q, v, _ = rand_inputs(rbd, m, 1, 38)
+    q, v = q[0], v[0]
+    vd = np.random.default_rng(38).random(m.nv)
+    A, hsum, _ = oracle.momentum_matrix(m, q[None], v[None])
+    h0, bias = oracle.momentum(m, q[None], v[None])
+    assert np.abs(A[0] @ v - h0[0]).max() <= 1e-12 * max(1.0, np.abs(h0).max()) and np.abs(hsum - h0).max() <= 1e-12 * max(1.0, np.abs(h0).max())
+    h = 1e-6
+    phid = sim.local_rate(m, q, q, v)
+    hp, _ = oracle.momentum(m, sim.global_coordinates(m, q, h * phid)[None], (v + h * vd)[None])
+    hm, _ = oracle.momentum(m, sim.global_coordinates(m, q, -h * phid)[None], (v - h * vd)[None])
+    rate = A[0] @ vd + bias[0]
+    assert np.abs((hp - hm)[0] / (2 * h) - rate).max() <= 1e-7 * max(1.0, np.abs(rate).max())
