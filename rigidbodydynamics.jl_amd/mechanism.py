@@ -347,6 +347,8 @@ def remove_fixed_tree_joints_(mechanism: Mechanism) -> Mechanism:
         pred.add_frame(Transform3D(fj.frame_after, fj.frame_before))  # identity joint transform :276-277
         for tf in list(succ.frame_definitions.values()):               # migrate frames :280-282
             pred.add_frame(tf)
+        for point in list(succ.contact_points):                         # migrate contact points :284-287
+            add_contact_point_(pred, point)
         if pred.inertia is not None:                                    # :286-291 (root has no inertia)
             inertia = succ.inertia
             toparent = pred.fixed_transform(inertia.frame, pred.inertia.frame)

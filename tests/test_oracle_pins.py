@@ -353,3 +353,39 @@ def test_momentum_rate_is_A_vdot_plus_bias(rbd, oracle, models, name):
     hm, _ = oracle.momentum(m, sim.global_coordinates(m, q, -h * phid)[None], (v - h * vd)[None])
     rate = A[0] @ vd + bias[0]
     assert np.abs((hp - hm)[0] / (2 * h) - rate).max() <= 1e-7 * max(1.0, np.abs(rate).max())
+
+
+def test_remove_fixed_tree_joints_keeps_the_mass_matrix_and_the_contact_points(rbd, oracle):
+    """test/test_mechanism_modification.jl:114-143: a random tree of 6-dof, revolute, spherical, planar, sin-cos AND fixed joints with 1-3 contact
+    points per body; after remove_fixed_tree_joints! the tree joints are the non-fixed ones in their old order, no contact point is lost, and
+    mass_matrix at the same q is unchanged to 1e-12 (pins the host-side merge of bodies the flattener relies on: src/mechanism_modification.jl:260-317)."""
+    rng = np.random.default_rng(49)
+    types = ["QuaternionFloating"] + ["Revolute"] * 10 + ["QuaternionSpherical", "Planar"] + ["Fixed"] * 10 + ["SinCosRevolute"] * 5
+    rng.shuffle(types)
+    mech = rbd.rand_tree_mechanism(rng, list(types))
+    model = rbd.SoftContactModel(rbd.hunt_crossley_hertz(), rbd.ViscoelasticCoulombModel(0.8, 20e3, 100.0))
+    npts = 0
+    for body in mech.bodies[1:]:
+        for _ in range(int(rng.integers(1, 4))):
+            rbd.add_contact_point_(body, rbd.ContactPoint(rng.random(3), model, body.default_frame))
+            npts += 1
+    before = rbd.flatten(mech)
+    q = rbd.rand_configuration(before, 3, rng)
+    M0 = oracle.mass_matrix(before, q)
+    nonfixed = [j.name for j in mech.tree_joints if j.joint_type.nv > 0]  # a Fixed joint is the one type without velocities
+    rbd.remove_fixed_tree_joints_(mech)
+    assert [j.name for j in mech.tree_joints] == nonfixed
+    assert sum(len(b.contact_points) for b in mech.bodies) == npts
+    mech.bodies[0].contact_points.clear()  # bodies that were fixed to the world left theirs on the root, where they act on nothing (the flat model takes none there)
+    after = rbd.flatten(mech)
+    assert after.nq == before.nq and after.nv == before.nv and after.n_bodies == len(nonfixed)
+    M1 = oracle.mass_matrix(after, q)
+    assert np.abs(np.tril(M1) - np.tril(M0)).max() <= 1e-12 * max(1.0, np.abs(M0).max())
+    # ... and the points that are left sit where they sat in the world (their locations were re-expressed in the predecessor's frame)
+    def world_points(flat):
+        H = oracle.transforms(flat, q[:1])[0]
+        pts = [H[c["body"]][:9].reshape(3, 3) @ c["location"] + H[c["body"]][9:] for c in flat.contact_points]
+        return np.array(sorted(map(tuple, np.round(pts, 9))))
+    kept = world_points(after)
+    was = world_points(before)
+    assert len(kept) <= len(was) and all(np.abs(was - p).sum(axis=1).min() < 1e-8 for p in kept)
