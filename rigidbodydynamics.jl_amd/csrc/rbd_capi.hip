@@ -617,6 +617,13 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   dm.perm_down = m->perm_down;
   dm.inner_floating = m->inner_floating;
   dm.has3dof = m->has3dof;
+  dm.nheavy = 0;
+  for (int s2 = 0; s2 < m->nb; ++s2) {
+    const int jt = m->ib[(size_t)s2 * IB_STRIDE + IB_JTYPE];
+    if (jt != RBD_JOINT_QUAT_FLOATING && jt != RBD_JOINT_QUAT_SPHERICAL) continue;
+    if (dm.nheavy < 4) { dm.heavy[dm.nheavy][0] = jt; dm.heavy[dm.nheavy][1] = m->ib[(size_t)s2 * IB_STRIDE + IB_QOFF]; dm.heavy[dm.nheavy][2] = m->ib[(size_t)s2 * IB_STRIDE + IB_VOFF]; }
+    ++dm.nheavy;
+  }
   for (int l = 0; l < MAX_LEVELS; ++l) dm.nslots[l] = (uint8_t)m->nslots[l];
   dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc; dm.row_mask = (const uint64_t*)w->d_row_mask;
   memcpy(dm.gravity, m->gravity, sizeof dm.gravity);

@@ -46,6 +46,8 @@ struct DevModel {
   int32_t has3dof;     // some tree joint is QuaternionSpherical / Planar (selects the NDOF = 3 aba_kernel instantiation)
   int32_t inner_floating;  // some 6-dof joint is not attached to the world (selects the general aba_kernel instantiation)
   int32_t debug_stop; // profiling aid (env RBD_ABA_STOP_AFTER): aba_kernel exits after phase 1..5 with a checksum store; 0 = full
+  int32_t nheavy;     // quaternion joints (QuaternionFloating / QuaternionSpherical) of the tree, and for the first HEAVY_MAX of them:
+  int32_t heavy[4][3];  // joint type, q offset, v offset — the integrator's one-thread-per-state stage reads them from the kernel arguments
   const int32_t* ib;  // [nb * IB_STRIDE], indexed by slot; parent/children are slots, IB_ORIG the reference body index
   const void* rb;     // [nb * RB_STRIDE] of the kernel's scalar type, indexed by slot
   const int32_t* dof_body;  // [nv] slot of velocity index

@@ -2069,16 +2069,27 @@ __global__ __launch_bounds__(256) void mk_stage_heavy_kernel(DevModel M, long B,
                                                              const T* __restrict__ vdot_prev, MkBuffers W, Layout Lq, Layout Lv) {
   const long state = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (state >= B) return;
-  for (int s = 0; s < M.nb; ++s) {
-    const int32_t* ib = M.ib + s * IB_STRIDE;
-    const int jt = ib[IB_JTYPE];  // wave-uniform
-    if (jt != RBD_JOINT_QUAT_FLOATING && jt != RBD_JOINT_QUAT_SPHERICAL) continue;
+  auto one = [&](int jt, int qoff, int voff) {
     Body<T> b{};
-    b.jtype = jt; b.qoff = ib[IB_QOFF]; b.voff = ib[IB_VOFF]; b.state = state; b.valid = true;
+    b.jtype = jt; b.qoff = qoff; b.voff = voff; b.state = state; b.valid = true;
     T qj[7], vj[6];
     load_joint_q(b, q, Lq, qj);
     load_joint_v(b, v, Lv, vj);
     mk_stage_lane<T, 2>(b, stage, dt, qj, vj, vdot_prev, W, q, v, Lq, Lv);
+  };
+  if (M.nheavy <= 4) {
+    // which joints, and where their coordinates are, from the kernel arguments: scanning the body table for them was one dependent global
+    // load per body (31 for Atlas) in front of the one joint that has work
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < M.nheavy) one(M.heavy[k][0], M.heavy[k][1], M.heavy[k][2]);
+  } else {
+    for (int s = 0; s < M.nb; ++s) {
+      const int32_t* ib = M.ib + s * IB_STRIDE;
+      const int jt = ib[IB_JTYPE];  // wave-uniform
+      if (jt != RBD_JOINT_QUAT_FLOATING && jt != RBD_JOINT_QUAT_SPHERICAL) continue;
+      one(jt, ib[IB_QOFF], ib[IB_VOFF]);
+    }
   }
 }
 
