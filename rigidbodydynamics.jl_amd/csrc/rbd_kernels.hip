@@ -1495,8 +1495,169 @@ __global__ __launch_bounds__(64, (NT <= 9 ? 2 : 1)) void chol_mfma_kernel(int nv
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA tile Cholesky, fp64: 4 states per wavefront on v_mfma_f64_4x4x4f64 (4 blocks of D(4x4) = A(4x4) B(4x4) + C, one f64 per lane and
+// operand).  Lane layout of that instruction, probed on gfx950 (scripts/ubench/mfma_f64_4x4x4.hip): lane = 16 x + 4 block + y, and
+//   D[i][j] at (x = i, y = j)      B[k][j] at (x = k, y = j)      A[i][k] at (x = k, y = i)
+// i.e. with tiles kept in the D layout (element (r, c) at x = r, y = c), mfma(a, b, c) = a' b + c.  The lower tiles are therefore kept
+// TRANSPOSED, Tt(I,J) = T(I,J)': with W = (L_d^-1)' the panel is Xt_I = L_d^-1 Tt(I,J) = mfma(W, Tt(I,J), 0) and the trailing update
+// Tt(I,J') -= X_J' X_I' = mfma(-Xt_J', Xt_I, Tt(I,J')) — one instruction per tile of all 4 states, no transposes.  The 4x4 diagonal tile
+// is gathered through LDS to the 16 lanes of its state, which factor and invert it redundantly in registers.  Vectors come in two forms:
+// Y (u[c] on the lanes with y = c) and X (u[r] on the lanes with x = r); a tile-vector product consumes one and leaves the other (sum over
+// y: inside a quad of lanes; sum over x: two cross-row shuffles), and forward / backward substitution are arranged so that the forms chain.
+// (dynamics_solve!, src/mechanism_algorithms.jl:764-819; replaces chol_reg_kernel<double>, 72 us at 4096 states.)
+// ---------------------------------------------------------------------------------------------
+RBD_DEV double sel16(const double (&a)[4][4], int x, int y) {  // a[x][y] for a run-time (x, y): selects, no indexed registers
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r = (x == i && y == j) ? a[i][j] : r;
+  return r;
+}
+RBD_DEV double sum_over_y(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v; }
+RBD_DEV double sum_over_x(double v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+
+template <int NT>
+__global__ __launch_bounds__(64, 2) void chol_mfma64_kernel(int nv, long B, const double* __restrict__ Mg, const double* __restrict__ tau,
+                                                           const double* __restrict__ c, double* __restrict__ xout, double* __restrict__ Lout,
+                                                           Layout Lm, Layout Lv, int* __restrict__ notpd) {
+  __shared__ double dsh[64];
+  const int lane = threadIdx.x & 63, x = lane >> 4, blk = (lane >> 2) & 3, y = lane & 3;
+  const long state = (long)blockIdx.x * 4 + blk;
+  const bool live = state < B;
+  const long mbase = live ? layout_base(Lm, state) : 0;
+  double t[NT][NT];  // Tt(I,J), I >= J: this lane's element = M[4I + y][4J + x]
+#pragma unroll
+  for (int I = 0; I < NT; ++I)
+#pragma unroll
+    for (int J = 0; J <= I; ++J) {
+      int row = 4 * I + y, col = 4 * J + x;
+      if (I == J && col > row) { const int tmp = row; row = col; col = tmp; }  // only the lower triangle of M is there to read
+      double a = (row == col) ? 1.0 : 0.0;  // identity padding beyond nv
+      if (live && row < nv) a = Mg[((long)col * nv + row) * Lm.sk + mbase];
+      t[I][J] = a;
+    }
+  double bY[NT];  // right-hand side, Y form
+#pragma unroll
+  for (int I = 0; I < NT; ++I) {
+    const int row = 4 * I + y;
+    double v = 0.0;
+    if (live && row < nv) {
+      if (tau) v = tau[(long)row * Lv.sk + state * Lv.sb];
+      if (c) v -= c[(long)row * Lv.sk + state * Lv.sb];
+    }
+    bY[I] = v;
+  }
+  double linv[NT];  // L_d^-1 of block column J: element [x][y]
+  bool bad = false;
+#pragma unroll
+  for (int J = 0; J < NT; ++J) {
+    // (1) the diagonal tile on every lane of its state
+    dsh[lane] = t[J][J];
+    __syncthreads();
+    double d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc <= r; ++cc) d[r][cc] = dsh[16 * r + 4 * blk + cc];
+    __syncthreads();
+    double L[4][4] = {}, Mi[4][4] = {};
+    {
+      const double p0 = d[0][0];
+      bad |= !(p0 > 0.0);
+      const double i0 = 1.0 / sqrt(p0);
+      L[0][0] = p0 * i0; L[1][0] = d[1][0] * i0; L[2][0] = d[2][0] * i0; L[3][0] = d[3][0] * i0;
+      const double p1 = d[1][1] - L[1][0] * L[1][0];
+      bad |= !(p1 > 0.0);
+      const double i1 = 1.0 / sqrt(p1);
+      L[1][1] = p1 * i1; L[2][1] = (d[2][1] - L[2][0] * L[1][0]) * i1; L[3][1] = (d[3][1] - L[3][0] * L[1][0]) * i1;
+      const double p2 = d[2][2] - L[2][0] * L[2][0] - L[2][1] * L[2][1];
+      bad |= !(p2 > 0.0);
+      const double i2 = 1.0 / sqrt(p2);
+      L[2][2] = p2 * i2; L[3][2] = (d[3][2] - L[3][0] * L[2][0] - L[3][1] * L[2][1]) * i2;
+      const double p3 = d[3][3] - L[3][0] * L[3][0] - L[3][1] * L[3][1] - L[3][2] * L[3][2];
+      bad |= !(p3 > 0.0);
+      const double i3 = 1.0 / sqrt(p3);
+      L[3][3] = p3 * i3;
+      Mi[0][0] = i0; Mi[1][1] = i1; Mi[2][2] = i2; Mi[3][3] = i3;
+      Mi[1][0] = -L[1][0] * Mi[0][0] * i1;
+      Mi[2][0] = -(L[2][0] * Mi[0][0] + L[2][1] * Mi[1][0]) * i2;
+      Mi[2][1] = -L[2][1] * Mi[1][1] * i2;
+      Mi[3][0] = -(L[3][0] * Mi[0][0] + L[3][1] * Mi[1][0] + L[3][2] * Mi[2][0]) * i3;
+      Mi[3][1] = -(L[3][1] * Mi[1][1] + L[3][2] * Mi[2][1]) * i3;
+      Mi[3][2] = -L[3][2] * Mi[2][2] * i3;
+    }
+    t[J][J] = sel16(L, y, x);            // Tt(J,J) = L_d': element (x, y) = L_d[y][x]
+    linv[J] = sel16(Mi, x, y);
+    const double W = sel16(Mi, y, x);    // (L_d^-1)'
+    // (2) panel, (3) trailing update
+#pragma unroll
+    for (int I = J + 1; I < NT; ++I) t[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(W, t[I][J], 0.0, 0, 0, 0);
+#pragma unroll
+    for (int Jp = J + 1; Jp < NT; ++Jp) {
+      const double nx = -t[Jp][J];
+#pragma unroll
+      for (int I = Jp; I < NT; ++I) t[I][Jp] = __builtin_amdgcn_mfma_f64_4x4x4f64(nx, t[I][J], t[I][Jp], 0, 0, 0);
+    }
+  }
+  if (live && bad && x == 0 && y == 0) atomicOr(notpd, 1);
+  // forward substitution L yv = b (left-looking): yv_I = L_d^-1 (b_I - sum_{J<I} L(I,J) yv_J);  L(I,J) u = Tt(I,J)' u: u in X form, sum over x
+  double vX[NT];  // yv, then x, in X form ... and their Y forms where the next product needs them
+#pragma unroll
+  for (int I = 0; I < NT; ++I) {
+    double part = 0.0;
+#pragma unroll
+    for (int J = 0; J < I; ++J) part += t[I][J] * vX[J];
+    const double rhs = bY[I] - sum_over_x(part);              // Y form
+    vX[I] = sum_over_y(linv[I] * rhs);                          // (L_d^-1 rhs)[x]: element [x][y] times rhs[y], summed over y -> X form
+  }
+  // backward substitution L' xv = yv: xv_J = L_d^-T (yv_J - sum_{I>J} L(I,J)' xv_I);  L(I,J)' u = Tt(I,J) u: u in Y form, sum over y
+  double xY[NT];
+#pragma unroll
+  for (int J = NT - 1; J >= 0; --J) {
+    double part = 0.0;
+#pragma unroll
+    for (int I = J + 1; I < NT; ++I) part += t[I][J] * xY[I];
+    const double rhs = vX[J] - sum_over_y(part);               // X form
+    xY[J] = sum_over_x(linv[J] * rhs);                          // (L_d^-T rhs)[y] = sum_x L_d^-1[x][y] rhs[x] -> Y form
+  }
+#pragma unroll
+  for (int J = 0; J < NT; ++J) {
+    const int row = 4 * J + y;
+    if (live && x == 0 && row < nv) xout[(long)row * Lv.sk + state * Lv.sb] = xY[J];
+  }
+  if (Lout && live) {
+    const long lbase = layout_base(Lm, state);
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J) {
+        const int row = 4 * I + y, col = 4 * J + x;
+        if (row < nv && col <= row) Lout[((long)col * nv + row) * Lm.sk + lbase] = t[I][J];
+      }
+  }
+}
+
 template <typename T> struct MfmaChol {
   static bool launch(int, long, const void*, const void*, const void*, void*, void*, Layout, Layout, int*, hipStream_t, void*, Layout) { return false; }
+};
+template <> struct MfmaChol<double> {
+  static bool launch(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv, int* notpd,
+                     hipStream_t s, void* Mcopy, Layout) {
+    static const bool off = getenv("RBD_NO_MFMA64") != nullptr;  // A/B against chol_reg_kernel
+    if (Mcopy || off) return false;
+    const dim3 grid((unsigned)((B + 3) / 4));
+#define RBD_CHOL_MFMA64(NT)                                                                                                            \
+    if (nv <= 4 * NT) {                                                                                                               \
+      hipLaunchKernelGGL((chol_mfma64_kernel<NT>), grid, dim3(64), 0, s, nv, B, (const double*)M, (const double*)tau, (const double*)c, \
+                         (double*)x, (double*)Lout, Lm, Lv, notpd);                                                                   \
+      return true;                                                                                                                    \
+    }
+    RBD_CHOL_MFMA64(1) RBD_CHOL_MFMA64(2) RBD_CHOL_MFMA64(4) RBD_CHOL_MFMA64(6) RBD_CHOL_MFMA64(8) RBD_CHOL_MFMA64(9) RBD_CHOL_MFMA64(10)
+#undef RBD_CHOL_MFMA64
+    return false;
+  }
 };
 template <> struct MfmaChol<float> {
   static bool launch(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv, int* notpd,
