@@ -1415,10 +1415,16 @@ int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, cons
     }
   }
   for (int step = 0; !fused && step < nsteps; ++step) {
-    for (int stage = 0; stage <= 4; ++stage) {
-      if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));
-      else HIP_TRY(launch_mk_stage<float>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));
-      if (stage < 4 && (st = run_dynamics(w, B, od, dq, dv, dtau, df, w->d_vdwork, nullptr, nullptr))) return st;
+    // the closing stage of a step rides in the stage-0 launch of the next one (as in the fused kernels); only the last step closes on its own
+    for (int stage = 0; stage < 4; ++stage) {
+      const int close_prev = (stage == 0 && step > 0) ? 1 : 0;
+      if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream, close_prev));
+      else HIP_TRY(launch_mk_stage<float>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream, close_prev));
+      if ((st = run_dynamics(w, B, od, dq, dv, dtau, df, w->d_vdwork, nullptr, nullptr))) return st;
+    }
+    if (step == nsteps - 1) {
+      if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, 4, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));
+      else HIP_TRY(launch_mk_stage<float>(w->dm, B, 4, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));
     }
   }
   if (o.memory == RBD_MEM_HOST) {

@@ -28,7 +28,7 @@ hipError_t launch_loop_solve(const LoopView<T>& V, long B, int stabilize, const 
 namespace rbd {
 template <typename T>
 hipError_t launch_mk_stage(const DevModel& M, long B, int stage, double dt, void* q, void* v, const void* vdot_prev, const MkBuffers& W,
-                           Layout Lq, Layout Lv, hipStream_t s);
+                           Layout Lq, Layout Lv, hipStream_t s, int close_prev = 0);
 }
 namespace rbd {
 template <typename T>

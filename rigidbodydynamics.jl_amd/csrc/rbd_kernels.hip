@@ -2217,7 +2217,7 @@ namespace rbd {
 // 65 536 Atlas states, 89 of them this branch).
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void mk_stage_kernel(DevModel M, long B, int stage, T dt, T* __restrict__ q, T* __restrict__ v,
-                                                       const T* __restrict__ vdot_prev, MkBuffers W, Layout Lq, Layout Lv) {
+                                                       const T* __restrict__ vdot_prev, MkBuffers W, Layout Lq, Layout Lv, int close_prev) {
   Body<T> b;
   load_body(M, B, b);
   const bool heavy = b.jtype == RBD_JOINT_QUAT_FLOATING || b.jtype == RBD_JOINT_QUAT_SPHERICAL;
@@ -2225,11 +2225,12 @@ __global__ __launch_bounds__(256) void mk_stage_kernel(DevModel M, long B, int s
   T qj[7], vj[6];
   load_joint_q(b, q, Lq, qj);
   load_joint_v(b, v, Lv, vj);
+  if (close_prev) mk_stage_lane<T, MODE>(b, 4, dt, qj, vj, vdot_prev, W, q, v, Lq, Lv);  // the step before closes in this launch (as in the fused kernels)
   mk_stage_lane<T, MODE>(b, stage, dt, qj, vj, vdot_prev, W, q, v, Lq, Lv);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void mk_stage_heavy_kernel(DevModel M, long B, int stage, T dt, T* __restrict__ q, T* __restrict__ v,
-                                                             const T* __restrict__ vdot_prev, MkBuffers W, Layout Lq, Layout Lv) {
+                                                             const T* __restrict__ vdot_prev, MkBuffers W, Layout Lq, Layout Lv, int close_prev) {
   const long state = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (state >= B) return;
   auto one = [&](int jt, int qoff, int voff) {
@@ -2238,6 +2239,7 @@ __global__ __launch_bounds__(256) void mk_stage_heavy_kernel(DevModel M, long B,
     T qj[7], vj[6];
     load_joint_q(b, q, Lq, qj);
     load_joint_v(b, v, Lv, vj);
+    if (close_prev) mk_stage_lane<T, 2>(b, 4, dt, qj, vj, vdot_prev, W, q, v, Lq, Lv);
     mk_stage_lane<T, 2>(b, stage, dt, qj, vj, vdot_prev, W, q, v, Lq, Lv);
   };
   if (M.nheavy <= 4) {
@@ -2258,13 +2260,13 @@ __global__ __launch_bounds__(256) void mk_stage_heavy_kernel(DevModel M, long B,
 
 template <typename T>
 hipError_t launch_mk_stage(const DevModel& M, long B, int stage, double dt, void* q, void* v, const void* vdot_prev, const MkBuffers& W,
-                           Layout Lq, Layout Lv, hipStream_t s) {
-  hipLaunchKernelGGL((mk_stage_kernel<T, 1>), grid_for(M, B, 256), dim3(256), 0, s, M, B, stage, (T)dt, (T*)q, (T*)v, (const T*)vdot_prev, W, Lq, Lv);
+                           Layout Lq, Layout Lv, hipStream_t s, int close_prev) {
+  hipLaunchKernelGGL((mk_stage_kernel<T, 1>), grid_for(M, B, 256), dim3(256), 0, s, M, B, stage, (T)dt, (T*)q, (T*)v, (const T*)vdot_prev, W, Lq, Lv, close_prev);
   if (M.maxnvj > 3 || M.has3dof)  // some joint is (or may be) a quaternion joint
-    hipLaunchKernelGGL((mk_stage_heavy_kernel<T>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, M, B, stage, (T)dt, (T*)q, (T*)v, (const T*)vdot_prev, W, Lq, Lv);
+    hipLaunchKernelGGL((mk_stage_heavy_kernel<T>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, M, B, stage, (T)dt, (T*)q, (T*)v, (const T*)vdot_prev, W, Lq, Lv, close_prev);
   return hipGetLastError();
 }
-template hipError_t launch_mk_stage<double>(const DevModel&, long, int, double, void*, void*, const void*, const MkBuffers&, Layout, Layout, hipStream_t);
-template hipError_t launch_mk_stage<float>(const DevModel&, long, int, double, void*, void*, const void*, const MkBuffers&, Layout, Layout, hipStream_t);
+template hipError_t launch_mk_stage<double>(const DevModel&, long, int, double, void*, void*, const void*, const MkBuffers&, Layout, Layout, hipStream_t, int);
+template hipError_t launch_mk_stage<float>(const DevModel&, long, int, double, void*, void*, const void*, const MkBuffers&, Layout, Layout, hipStream_t, int);
 
 }  // namespace rbd
