@@ -1528,10 +1528,11 @@ __global__ __launch_bounds__(64, 2) void chol_mfma64_kernel(int nv, long B, cons
   const bool live = state < B;
   const long mbase = live ? layout_base(Lm, state) : 0;
   double t[NT][NT];  // Tt(I,J), I >= J: this lane's element = M[4I + y][4J + x]
+  // (column by column: the tiles (I, J), (I + 1, J), ... of a block column continue each other's cache lines — rows 4I + y of column 4J + x)
 #pragma unroll
-  for (int I = 0; I < NT; ++I)
+  for (int J = 0; J < NT; ++J)
 #pragma unroll
-    for (int J = 0; J <= I; ++J) {
+    for (int I = J; I < NT; ++I) {
       int row = 4 * I + y, col = 4 * J + x;
       if (I == J && col > row) { const int tmp = row; row = col; col = tmp; }  // only the lower triangle of M is there to read
       double a = (row == col) ? 1.0 : 0.0;  // identity padding beyond nv
