@@ -1231,3 +1231,34 @@ def test_mass_matrix_solve_large_ragged_batch_whole_square(rbd, oracle, models):
     res = np.einsum("bij,bj->bi", Mo, xg) - r
     eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Mo, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(r, axis=1))
     assert eta.max() <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("nv", [7, 14, 22, 30, 38])
+def test_tile_cholesky_every_instantiation(rbd, dtype, nv):
+    """The MFMA tile kernels (fp32: chol_mfma_kernel, 16 states per wavefront; fp64: chol_mfma64_kernel, 4 states per wavefront) exist in
+    one instantiation per number of 4 x 4 tile rows: sizes that land in the 2-, 4-, 6-, 8- and 10-tile forms (identity padding inside the last
+    tile), on a batch that fills neither a whole wavefront nor a multiple of one; factor vs LAPACK's, solution vs numpy."""
+    import ctypes
+    from rigidbodydynamics_jl_amd import _capi
+    rng = np.random.default_rng(100 + nv)
+    model = rbd.flatten(rbd.rand_tree_mechanism(rng, ["Revolute"] * nv, lambda m, r: m.bodies[-1]))
+    assert model.nv == nv
+    B = 13
+    A = rng.standard_normal((B, nv, nv))
+    A = A @ A.transpose(0, 2, 1) + nv * np.eye(nv)
+    b = rng.standard_normal((B, nv))
+    st = rbd.MechanismState(model, B, dtype=TD[dtype])
+    M = torch.as_tensor(np.tril(A).transpose(0, 2, 1).reshape(B, nv * nv).copy(), dtype=TD[dtype]).cuda()
+    rhs = torch.as_tensor(b, dtype=TD[dtype]).cuda()
+    x, L = torch.zeros_like(rhs), torch.zeros_like(M)
+    opts = st._opts()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert _capi.lib().rbd_cholesky_solve(st.ws.handle, B, P(M), P(rhs), P(x), P(L), ctypes.byref(opts)) == 0
+    assert rbd.sync(st) == 0
+    Lg = np.tril(L.double().cpu().numpy().reshape(B, nv, nv).transpose(0, 2, 1))
+    tol = 1e-12 if dtype == "f64" else 2e-5
+    assert np.abs(Lg - np.linalg.cholesky(A)).max() <= tol * np.abs(A).max() ** 0.5
+    xr = np.linalg.solve(A, b[..., None])[..., 0]
+    assert np.abs(x.double().cpu().numpy() - xr).max() <= tol * max(1.0, np.abs(xr).max())
