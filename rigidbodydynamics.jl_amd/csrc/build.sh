@@ -9,7 +9,7 @@ OUT=${OUT:-librbd_hip.so}
 TAG=${OUT%.so}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -ffp-contract=fast -Wall -Wno-unused-function"
 pids=()
-for tu in rbd_kernels rbd_track_kernels rbd_walk_kernels rbd_pipe_kernels rbd_state_kernels rbd_contact_kernels rbd_capi rbd_comm; do
+for tu in rbd_kernels rbd_bank_kernels rbd_track_kernels rbd_walk_kernels rbd_pipe_kernels rbd_state_kernels rbd_contact_kernels rbd_capi rbd_comm; do
   $HIPCC $FLAGS -c $tu.hip -o ${TAG}_${tu#rbd_}.o "$@" &
   pids+=($!)
 done
@@ -21,5 +21,5 @@ for p in "${pids[@]}"; do wait $p; done
 # the walk kernel addresses accumulation registers by number: the register allocator must stay clear of them (scripts/check_walk_agprs.py)
 python3 ../../scripts/check_walk_agprs.py ${TAG}_walk_kernels.s 11
 python3 ../../scripts/check_walk_agprs.py ${TAG}_pipe_kernels.s 11
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT ${TAG}_kernels.o ${TAG}_track_kernels.o ${TAG}_walk_kernels.o ${TAG}_pipe_kernels.o ${TAG}_state_kernels.o ${TAG}_contact_kernels.o ${TAG}_capi.o ${TAG}_comm.o -ldl
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT ${TAG}_kernels.o ${TAG}_bank_kernels.o ${TAG}_track_kernels.o ${TAG}_walk_kernels.o ${TAG}_pipe_kernels.o ${TAG}_state_kernels.o ${TAG}_contact_kernels.o ${TAG}_capi.o ${TAG}_comm.o -ldl
 echo "built $(pwd)/$OUT"

@@ -1,4 +1,4 @@
-// rbd_bank.hpp — "banked" lane-per-body ABA: every lane carries TWO bodies (included by rbd_kernels.hip after aba_kernel).
+// rbd_bank.hpp — "banked" lane-per-body kernels: every lane carries TWO bodies (translation unit: rbd_bank_kernels.hip).
 //
 // aba_kernel keeps one body per lane, so a state of n bodies needs next_pow2(n) lanes and each level-synchronous sweep
 // step is issued for all of them although only the bodies of one level do useful work.  The sweeps are issue-bound
@@ -6,18 +6,79 @@
 // wavefront halves the instruction issue of the sweeps.  Here the bodies are split by level into two banks — bank 0 =
 // levels [0, L0), bank 1 = levels [L0, nlevels) — and lane j of a state carries body j of bank 0 AND body j of bank 1, each
 // with its own register set (Atlas: 15 + 16 bodies on 16 lanes, 4 states per wavefront instead of 2).  A sweep step at
-// level l touches only the register set of the bank that owns l, so the level loops are the same code as aba_kernel's,
-// run once per bank range; the single hop that crosses banks (level L0-1 <-> L0) is a ds_bpermute between the two register
-// sets.  Within a bank the bodies are in DFS pre-order, so the first-child hop stays a DPP wave shift.
-// The per-body set-up (joint transform, inertia, bias terms) runs once per bank with all lanes busy.
+// level l touches only the register set of the bank that owns l.  Within a bank the bodies are in DFS pre-order, so the
+// first-child hop is a DPP wave shift.
+//
+// Round 3 (this file was rebuilt):
+//  * what a lane TAKES from a neighbour is added under the lane's own exec mask (`if (takes) x += h`, kept a branch by
+//    RBD_KEEP_BRANCH) instead of being selected against zero: the states of a wavefront stay independent (a NaN state cannot reach
+//    its wave-mate, round 2) without the two v_cndmask per fp64 value the selects cost (+713 VALU per wavefront, the round-2 regression);
+//  * every hop that is not "first child <-> previous lane" — second / third children, the hop between the banks — goes through an
+//    LDS exchange column per lane as 16-byte pairs (ds_write_b128 / ds_read_b128: 14 + 14 instructions for the 27 values of a hand-off)
+//    instead of two ds_bpermute_b32 + two selects per value; the hop between the banks of the FK sweep reads the parent's PARKED values;
+//  * the bank that is not being swept parks its live values in LDS as pairs too (half the LDS instructions);
+//  * SIMPLE instantiation for mechanisms whose tree joints are all revolute apart from 6-dof joints on the world (Atlas, Valkyrie,
+//    most arms): no joint-type interpretation per lane, motion subspace = (R a; p x R a), sin/cos by sincos_fast;
+//  * the integrator-fused form is its own instantiation (FUSED): the plain dynamics! launch keeps __restrict__ on q / v and carries
+//    none of the stage code; the re-rooted variant of round 2 (no gain at any size) is gone.
 // Scope: 1-dof and fixed tree joints, 6-dof joints on the world (everything else stays with aba_kernel).
 #pragma once
 
+// experiment switches (scripts/build_bank_variant.sh; defaults = the measured best)
+#ifndef RBD_BANK_WAVES
+#define RBD_BANK_WAVES 2     // wavefronts per SIMD the register budget allows (2: 256 VGPRs)
+#endif
+#ifndef RBD_BANK_FK_LDS
+#define RBD_BANK_FK_LDS 0    // 1: every top-down hop through the exchange columns (no DPP shifts)
+#endif
+#ifndef RBD_BANK_HANDOFF_LDS
+#define RBD_BANK_HANDOFF_LDS 0  // 1: every bottom-up hand-off through the exchange columns
+#endif
+
 namespace rbd {
+
+template <typename T> struct alignas(2 * sizeof(T)) Pair2 { T a, b; };
+
+// an `if` whose body must stay a branch (exec mask), not be turned into selects by if-conversion
+#define RBD_KEEP_BRANCH() asm volatile("" ::)
+// LDS written by some lanes of the wavefront and read by others: same-wave LDS operations execute in order; this only stops the compiler
+RBD_DEV void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS layout, in pairs per lane (pair i of thread t at lds[i * 256 + t]):
+//   parked kinematics of bank 0: R 9, p 3 (pairs 0..5: stay for the 6-dof joints), Tw 6, vJ 6 (pairs 6..11)
+//   parked forward data of bank 1 (after bank 0's Tw, vJ are back in registers): U 6 (6..8), 1/D, u (9), S 6 (10..12), cb 6 (13..15)
+//   exchange column: 14 pairs (a hand-off is 21 + 6 values)
+enum { PK_KIN = 0, PK_FWD = 6, PARK_PAIRS = 16, PK_XCH = 16, XCH_PAIRS = 14, BANK_LDS_PAIRS = PARK_PAIRS + XCH_PAIRS };
+
+template <typename T, int N> RBD_DEV void lds_put(Pair2<T>* col, int pair0, const T* x) {
+#pragma unroll
+  for (int i = 0; i < (N + 1) / 2; ++i) {
+    Pair2<T> v;
+    v.a = x[2 * i];
+    v.b = (2 * i + 1 < N) ? x[2 * i + 1] : T(0);
+    col[(pair0 + i) * 256] = v;
+  }
+}
+template <typename T, int N> RBD_DEV void lds_get(const Pair2<T>* col, int pair0, T* x) {
+#pragma unroll
+  for (int i = 0; i < (N + 1) / 2; ++i) {
+    const Pair2<T> v = col[(pair0 + i) * 256];
+    x[2 * i] = v.a;
+    if (2 * i + 1 < N) x[2 * i + 1] = v.b;
+  }
+}
+
+__host__ __device__ constexpr int sym_row(int e) { return e < 6 ? 0 : e < 11 ? 1 : e < 15 ? 2 : e < 18 ? 3 : e < 20 ? 4 : 5; }
+__host__ __device__ constexpr int sym_col(int e) { return e - SI(sym_row(e), sym_row(e)) + sym_row(e); }
 
 template <typename T> struct BankRegs {
   Body<T> b;
   const T* rb;
+  int pcol;  // LDS column (thread index in the block) of the lane that carries the parent body
   T R[9], p[3], Tw[6], vJ[6];
   T S[6], cb[6], IA[21], pA[6], U[6], Dinv, u;
   T tj[6];  // joint torques (6 for the floating joint)
@@ -47,7 +108,7 @@ template <typename T> RBD_DEV void load_bank_body(const BankModel& M, int k, lon
   b.plane = b.parent >= 0 ? b.base + b.parent : b.lane;  // parent slot (of the parent's bank) in this state's lane group
 }
 
-// top-down hop of N values: lanes of `cb` read their parent's copy of x (the parent's bank register set)
+// top-down hop of N values (rnea_bank_kernel): lanes of `cb` read their parent's copy of x (the parent's bank register set)
 template <typename T, int N, bool CROSS> RBD_DEV void bank_pull(const BankModel& M, const Body<T>& cb, int l, const T* x, T* out) {
   if (CROSS || ((M.perm_down >> l) & 1)) {
 #pragma unroll
@@ -58,75 +119,147 @@ template <typename T, int N, bool CROSS> RBD_DEV void bank_pull(const BankModel&
   }
 }
 
-// forward-kinematics step at level l: `c` (bodies at level l) from `par` (their parents' bank)
-template <typename T, bool CROSS> RBD_DEV void bank_fk_step(const BankModel& M, int l, const BankRegs<T>& par, BankRegs<T>& c, const T* XR, const T* Xp, const T* tl) {
-  T pR[9], pp[3], pT[6];
-  bank_pull<T, 9, CROSS>(M, c.b, l, par.R, pR);
-  bank_pull<T, 3, CROSS>(M, c.b, l, par.p, pp);
-  bank_pull<T, 6, CROSS>(M, c.b, l, par.Tw, pT);
-  if (c.b.level == l) {
-    matmul3(pR, XR, c.R);
-    matvec3(pR, Xp, c.p);
+// ---- forward kinematics -------------------------------------------------------------------------------------------------------
+template <typename T> RBD_DEV void bank_fk_commit(BankRegs<T>& c, const T* k18 /* the parent's R 9, p 3, Tw 6 */, const T* XR, const T* Xp, const T* tl) {
+  const T* pR = k18;
+  const T* pp = k18 + 9;
+  const T* pT = k18 + 12;
+  matmul3(pR, XR, c.R);
+  matvec3(pR, Xp, c.p);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) c.p[k] += pp[k];
-    xmotion(c.R, c.p, tl, c.vJ);
+  for (int k = 0; k < 3; ++k) c.p[k] += pp[k];
+  xmotion(c.R, c.p, tl, c.vJ);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) c.Tw[k] = pT[k] + c.vJ[k];
+  for (int k = 0; k < 6; ++k) c.Tw[k] = pT[k] + c.vJ[k];
+}
+// level l inside a bank.  On most levels every body is the first child of its parent = the previous lane: (R, p, Tw) arrive by DPP.  On the
+// levels where some body is a later child (perm_down) the parents leave theirs in their exchange column and every child reads its parent's
+// column (two code paths chosen by a wave-uniform flag, each with its own commit: merging them would cost a register copy per value).
+template <typename T> RBD_DEV void bank_fk_step(const BankModel& M, int l, BankRegs<T>& c, Pair2<T>* lds, const T* XR, const T* Xp, const T* tl) {
+  if (RBD_BANK_FK_LDS || ((M.perm_down >> l) & 1)) {  // uniform
+    if (c.b.level == l - 1 && c.b.nchild >= 1) {
+      RBD_KEEP_BRANCH();
+      T o[18];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) o[k] = c.R[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) o[9 + k] = c.p[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) o[12 + k] = c.Tw[k];
+      lds_put<T, 18>(lds + threadIdx.x, PK_XCH, o);
+    }
+    wave_lds_sync();
+    if (c.b.level == l) {
+      RBD_KEEP_BRANCH();
+      T k18[18];
+      lds_get<T, 18>(lds + c.pcol, PK_XCH, k18);
+      bank_fk_commit(c, k18, XR, Xp, tl);
+    }
+    wave_lds_sync();
+  } else {
+    T k18[18];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) k18[k] = from_prev_lane(c.R[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) k18[9 + k] = from_prev_lane(c.p[k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) k18[12 + k] = from_prev_lane(c.Tw[k]);
+    if (c.b.level == l) {
+      RBD_KEEP_BRANCH();
+      bank_fk_commit(c, k18, XR, Xp, tl);
+    }
+  }
+}
+// level L0: the parents are bank-0 bodies, whose (R, p, Tw) have just been parked — the children read their parent's parked pairs
+template <typename T> RBD_DEV void bank_fk_cross(int L0, BankRegs<T>& c, const Pair2<T>* lds, const T* XR, const T* Xp, const T* tl) {
+  if (c.b.level == L0) {
+    RBD_KEEP_BRANCH();
+    T k18[18];
+    lds_get<T, 18>(lds + c.pcol, PK_KIN, k18);
+    bank_fk_commit(c, k18, XR, Xp, tl);
   }
 }
 
 // U = IA S, D = S'U, u = tau - S'pA for the lanes of `r` at level l (1-dof joints; fixed joints keep U = 0, 1/D = 0)
-template <typename T> RBD_DEV void bank_finish_joint(int l, BankRegs<T>& r) {
-  if (r.b.level == l && joint_nv(r.b.jtype) == 1) {
+template <typename T, bool SIMPLE> RBD_DEV void bank_finish_joint(int l, BankRegs<T>& r) {
+  if (r.b.level == l && (SIMPLE ? r.b.jtype != RBD_JOINT_QUAT_FLOATING : joint_nv(r.b.jtype) == 1)) {
     sym6_mul(r.IA, r.S, r.U);
     r.u = r.tj[0] - dot6(r.S, r.pA);
     r.Dinv = rcp_nr(dot6(r.S, r.U));
   }
 }
 
-// bottom-up hand-off: lanes of `gv` at level l give (Ia, pa) = (IA - U D^-1 U', pA + Ia cb + U D^-1 u); lanes of `tk` at level
-// l-1 add what their children give.  In-bank (gv and tk are the same register set): first child by DPP, the others by
-// ds_bpermute; across banks every child by ds_bpermute.  Entries are formed and consumed one at a time (see aba_kernel).
-template <typename T, bool CROSS> RBD_DEV void bank_handoff(int l, int ns, const BankRegs<T>& gv, BankRegs<T>& tk) {
+// ---- bottom-up hand-off ---------------------------------------------------------------------------------------------------------
+// Lanes of `gv` at level l give (Ia, pa) = (IA - U D^-1 U', pA + Ia cb + U D^-1 u); lanes of `tk` at level l-1 add what their children
+// give.  MODE 0, inside a bank (gv and tk are the same register set): the first child is the next lane — DPP shift, added under the
+// taker's exec mask; when some body of level l-1 has more children (ns > 1) every lane also leaves its hand-off in its exchange column and
+// the takers read their later children's columns.  MODE 1, across the banks: every child through the exchange columns.
+// The 27 values are formed, moved and consumed in three chunks (10 + 10 + 7) to bound the temporaries.
+template <typename T, int MODE> RBD_DEV void bank_handoff(int l, int ns, const BankRegs<T>& gv, BankRegs<T>& tk, Pair2<T>* lds) {
   const bool takes = (tk.b.level == l - 1);
-  T W[6];  // U D^-1 (6-dof joints sit at level 0 and never give: their 1/D stays 0)
+  const bool take0 = takes && tk.b.nchild >= 1;
+  const bool xw = MODE == 1 || ns > 1;  // uniform
+  Pair2<T>* const mycol = lds + threadIdx.x;
+  T W[6];  // U D^-1 (6-dof joints sit at level 0 and never give)
 #pragma unroll
   for (int k = 0; k < 6; ++k) W[k] = gv.U[k] * gv.Dinv;
-  const T m0 = (!CROSS && takes && tk.b.nchild >= 1) ? T(1) : T(0);
-  T Iac[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, gp[6];
+  T Iac[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int c0 = 0; c0 < 20; c0 += 10) {
+    T g[10], h[10];
 #pragma unroll
-    for (int j = i; j < 6; ++j) {
-      const T g = gv.IA[SI(i, j)] - W[i] * gv.U[j];
-      Iac[i] += g * gv.cb[j];
-      if (j > i) Iac[j] += g * gv.cb[i];
-      if (!CROSS) tk.IA[SI(i, j)] += keep(from_next_lane(g), m0);
+    for (int e = 0; e < 10; ++e) {
+      const int i = sym_row(c0 + e), j = sym_col(c0 + e);
+      g[e] = gv.IA[c0 + e] - W[i] * gv.U[j];
+      Iac[i] += g[e] * gv.cb[j];
+      if (j > i) Iac[j] += g[e] * gv.cb[i];
+      if (MODE == 0) h[e] = from_next_lane(g[e]);
+    }
+    if (xw) lds_put<T, 10>(mycol, PK_XCH + c0 / 2, g);
+    if (MODE == 0) {
+      if (take0) {
+        RBD_KEEP_BRANCH();
+#pragma unroll
+        for (int e = 0; e < 10; ++e) tk.IA[c0 + e] += h[e];
+      }
     }
   }
+  {
+    T g[7], h[7];
+    g[0] = gv.IA[20] - W[5] * gv.U[5];
+    Iac[5] += g[0] * gv.cb[5];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    gp[k] = gv.pA[k] + Iac[k] + W[k] * gv.u;
-    if (!CROSS) tk.pA[k] += keep(from_next_lane(gp[k]), m0);
+    for (int k = 0; k < 6; ++k) g[1 + k] = gv.pA[k] + Iac[k] + W[k] * gv.u;
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 7; ++e) h[e] = from_next_lane(g[e]);
+    }
+    if (xw) lds_put<T, 7>(mycol, PK_XCH + 10, g);
+    if (MODE == 0) {
+      if (take0) {
+        RBD_KEEP_BRANCH();
+        tk.IA[20] += h[0];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) tk.pA[k] += h[1 + k];
+      }
+    }
   }
+  if (xw) {
+    wave_lds_sync();
 #pragma unroll 1
-  for (int s = CROSS ? 0 : 1; s < ns; ++s) {
-    const bool take = takes && (s < tk.b.nchild);
-    const int src = take ? tk.b.base + child_sel(tk.b, s) : tk.b.lane;
-    const T mask = take ? T(1) : T(0);
+    for (int s = (MODE == 1 ? 0 : 1); s < ns; ++s) {
+      if (takes && s < tk.b.nchild) {
+        RBD_KEEP_BRANCH();
+        const Pair2<T>* src = lds + (threadIdx.x - tk.b.sub + child_sel(tk.b, s));
+        T x[28];
+        lds_get<T, 28>(src, PK_XCH, x);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      T tmp[6];
+        for (int e = 0; e < 21; ++e) tk.IA[e] += x[e];
 #pragma unroll
-      for (int j = i; j < 6; ++j) tmp[j] = shfl(gv.IA[SI(i, j)] - W[i] * gv.U[j], src);
-#pragma unroll
-      for (int j = i; j < 6; ++j) tk.IA[SI(i, j)] += keep(tmp[j], mask);
+        for (int k = 0; k < 6; ++k) tk.pA[k] += x[21 + k];
+      }
     }
-    T tp[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) tp[k] = shfl(gp[k], src);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) tk.pA[k] += keep(tp[k], mask);
+    wave_lds_sync();
   }
 }
 
@@ -140,13 +273,31 @@ template <typename T> RBD_DEV void bank_joint_accel(BankRegs<T>& r, const T* a_p
 #pragma unroll
   for (int k = 0; k < 6; ++k) r.acc[k] = ap[k] + r.S[k] * x;
 }
-
-// Register budget: both banks' recursion state would need ~300 VGPRs in fp64, i.e. one wavefront per SIMD, and a lone
-// wavefront issues at only ~5 cycles per instruction.  The bank that is not being swept therefore parks its live values in a
-// lane-private LDS column (PARK_SLOTS values per lane, no synchronisation needed): the kernel fits 256 VGPRs and two
-// wavefronts per SIMD interleave.
-enum { PARK_KIN = 0 /* R 9, p 3, Tw 6, vJ 6 of bank 0 */, PARK_FWD = 12 /* U 6, 1/D, u, S 6, cb 6 of bank 1 */, PARK_SLOTS = 32,
-       PARK_WF = 32 /* re-rooted tree: S^-T tau of the floating joint, left by the root lane for the old floating body */, PARK_SLOTS_RR = 38 };
+// top-down acceleration step at level l inside a bank (same hop rules as bank_fk_step)
+template <typename T> RBD_DEV void bank_accel_step(const BankModel& M, int l, BankRegs<T>& c, Pair2<T>* lds) {
+  if (RBD_BANK_FK_LDS || ((M.perm_down >> l) & 1)) {  // uniform
+    if (c.b.level == l - 1 && c.b.nchild >= 1) {
+      RBD_KEEP_BRANCH();
+      lds_put<T, 6>(lds + threadIdx.x, PK_XCH, c.acc);
+    }
+    wave_lds_sync();
+    if (c.b.level == l) {
+      RBD_KEEP_BRANCH();
+      T ap[6];
+      lds_get<T, 6>(lds + c.pcol, PK_XCH, ap);
+      bank_joint_accel(c, ap);
+    }
+    wave_lds_sync();
+  } else {
+    T ap[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ap[k] = from_prev_lane(c.acc[k]);
+    if (c.b.level == l) {
+      RBD_KEEP_BRANCH();
+      bank_joint_accel(c, ap);
+    }
+  }
+}
 
 #ifdef RBD_PROFILE_PHASES
 __device__ long long rbd_bank_phase_clock[16];
@@ -155,45 +306,90 @@ __device__ long long rbd_bank_phase_clock[16];
 #define RBD_MARK(i)
 #endif
 
-// RR = true: the tree re-rooted at its centre (rbd_reroot.hpp).  The level-0 body is then a VIRTUAL floating base — its pose and twist come
-// from the old floating body's coordinates through the chain of original joints, its acceleration solves IA a = −pA — and the old floating
-// body (flag BFD_FCARRY, now somewhere down the tree) takes the floating joint's force as an external wrench and gives back v̇ of the floating
-// joint from its own spatial acceleration.  Everything else is the same code on different records (reversed joints are ordinary records).
-template <typename T, bool RR = false>
-__global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, const T* q, const T* v,  /* no restrict: F.q_state / F.v_state alias them when fused */
+template <typename T, bool R> struct InPtr { typedef const T* type; };
+template <typename T> struct InPtr<T, true> { typedef const T* __restrict__ type; };
+
+// FUSED: the launch is also a stage of a Munthe-Kaas RK4 step (`simulate`): q / v alias F.q_state / F.v_state, so no __restrict__ on them.
+// SIMPLE: every tree joint is revolute, apart from 6-dof joints on the world (BankModel::simple, set by the host).
+template <typename T, bool FUSED, bool SIMPLE>
+__global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel M, long B, typename InPtr<T, !FUSED>::type q, typename InPtr<T, !FUSED>::type v,
                                                          const T* __restrict__ tau, const T* __restrict__ fext, T* __restrict__ vdot,
                                                          T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, MkFuse F) {
-  extern __shared__ double park_raw[];
-  T* const park = reinterpret_cast<T*>(park_raw) + threadIdx.x;  // slot i of this lane: park[i * 256]
+  extern __shared__ double bank_lds_raw[];
+  Pair2<T>* const lds = reinterpret_cast<Pair2<T>*>(bank_lds_raw);
+  Pair2<T>* const col = lds + threadIdx.x;
   RBD_MARK(0);
   BankRegs<T> r0, r1;
-  // RR: coordinates of the chain joints between the old floating body and the new root, requested with the first loads of the launch
-  T cq[RC_MAX], cv[RC_MAX];
-  if (RR) {
-    const long st = ((long)blockIdx.x * blockDim.x + threadIdx.x) / M.lps;
-    const long stc = st < B ? st : B - 1;
-#pragma unroll
-    for (int j = 0; j < RC_MAX; ++j) {
-      const bool on = j < M.reroot.nchain;
-      const int qo = on ? M.reroot.chain_i[4 * j + 1] : 0, vo = on ? M.reroot.chain_i[4 * j + 2] : 0;
-      cq[j] = on ? q[(long)qo * Lq.sk + stc * Lq.sb] : T(0);
-      cv[j] = (on && v) ? v[(long)vo * Lv.sk + stc * Lv.sb] : T(0);
-    }
-  }
   // ---- per-body set-up (once per bank, every lane busy): joint transform and joint twist in the joint frame ----
   // The global loads of BOTH banks are issued up front (two dependent round trips: body record, then q / v / tau), so that
   // bank 1's latency hides behind bank 0's sweep; the arithmetic of a bank runs right before its own sweep.
   auto fetch = [&](int k, BankRegs<T>& c, T* qj, T* vj) {
     load_bank_body(M, k, B, c.b);
     c.rb = reinterpret_cast<const T*>(M.rb[k]) + (c.b.sub < M.nbk[k] ? c.b.sub : 0) * RB_STRIDE;
-    load_joint_q(c.b, q, Lq, qj);
-    load_joint_v(c.b, v, Lv, vj);
-    load_joint_v(c.b, tau, Lv, c.tj);
+    c.pcol = (int)threadIdx.x - c.b.sub + (c.b.parent >= 0 ? c.b.parent : c.b.sub);
+    if (SIMPLE) {
+      const bool fl = c.b.jtype == RBD_JOINT_QUAT_FLOATING;
+      const long qa = (long)c.b.qoff * Lq.sk + c.b.state * Lq.sb, va = (long)c.b.voff * Lv.sk + c.b.state * Lv.sb;
+      qj[0] = c.b.valid ? q[qa] : T(0);
+      vj[0] = (v != nullptr && c.b.valid) ? v[va] : T(0);
+      c.tj[0] = (tau != nullptr && c.b.valid) ? tau[va] : T(0);
+#pragma unroll
+      for (int k2 = 1; k2 < 7; ++k2) qj[k2] = (fl && c.b.valid) ? q[qa + k2 * Lq.sk] : T(0);
+#pragma unroll
+      for (int k2 = 1; k2 < 6; ++k2) {
+        vj[k2] = (fl && v != nullptr && c.b.valid) ? v[va + k2 * Lv.sk] : T(0);
+        c.tj[k2] = (fl && tau != nullptr && c.b.valid) ? tau[va + k2 * Lv.sk] : T(0);
+      }
+    } else {
+      load_joint_q(c.b, q, Lq, qj);
+      load_joint_v(c.b, v, Lv, vj);
+      load_joint_v(c.b, tau, Lv, c.tj);
+    }
   };
   auto setup = [&](BankRegs<T>& c, T* qj, T* vj, T* XR, T* Xp, T* tl) {
-    store_qdot(c.b, qdot, Lq, qj, vj);
-    local_transform(c.b, c.rb, qj, XR, Xp);
-    local_joint_motion(c.b, c.rb, vj, tl);
+    if (SIMPLE) {
+      const bool fl = c.b.jtype == RBD_JOINT_QUAT_FLOATING;
+      const T ax[3] = {c.rb[RB_AXIS], c.rb[RB_AXIS + 1], c.rb[RB_AXIS + 2]};
+      T Rj[9], pj[3] = {T(0), T(0), T(0)};
+      T sn, cs;
+      sincos_fast(qj[0], &sn, &cs);
+      rot_axis_sc(ax, sn, cs, Rj);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { tl[k] = ax[k] * vj[0]; tl[3 + k] = T(0); }
+      if (fl) {  // level-0 lanes only (quaternion_floating.jl:81-83, :126-136, :182-188)
+        RBD_KEEP_BRANCH();
+        rot_quat(qj[0], qj[1], qj[2], qj[3], Rj);
+        pj[0] = qj[4]; pj[1] = qj[5]; pj[2] = qj[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) tl[k] = vj[k];
+        if (qdot != nullptr && c.b.valid) {
+          const T w = qj[0], x = qj[1], y = qj[2], z = qj[3];
+          T o[7];
+          o[0] = (-x * vj[0] - y * vj[1] - z * vj[2]) * T(0.5);
+          o[1] = (w * vj[0] - z * vj[1] + y * vj[2]) * T(0.5);
+          o[2] = (z * vj[0] + w * vj[1] - x * vj[2]) * T(0.5);
+          o[3] = (-y * vj[0] + x * vj[1] + w * vj[2]) * T(0.5);
+          matvec3(Rj, vj + 3, o + 4);
+#pragma unroll
+          for (int k = 0; k < 7; ++k) qdot[(long)(c.b.qoff + k) * Lq.sk + c.b.state * Lq.sb] = o[k];
+        }
+      } else if (qdot != nullptr && c.b.valid) {
+        qdot[(long)c.b.qoff * Lq.sk + c.b.state * Lq.sb] = vj[0];
+      }
+      T XpR[9], Xpp[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) XpR[k] = c.rb[RB_XPR + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Xpp[k] = c.rb[RB_XPP + k];
+      matmul3(XpR, Rj, XR);
+      matvec3(XpR, pj, Xp);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Xp[k] += Xpp[k];
+    } else {
+      store_qdot(c.b, qdot, Lq, qj, vj);
+      local_transform(c.b, c.rb, qj, XR, Xp);
+      local_joint_motion(c.b, c.rb, vj, tl);
+    }
     // as if at level 0 (transform to root = local transform); deeper lanes overwrite at their level
 #pragma unroll
     for (int i = 0; i < 9; ++i) c.R[i] = XR[i];
@@ -202,29 +398,20 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     xmotion(c.R, c.p, tl, c.vJ);
 #pragma unroll
     for (int i = 0; i < 6; ++i) c.Tw[i] = c.vJ[i];
-    if (RR) {
-      if (c.b.valid && (c.b.flags & BFD_VROOT)) {  // qj, vj of this lane ARE the floating joint's coordinates (its record carries their offsets)
-        {  // the floating joint's force as a wrench in the root frame, S^-T tau_f: this lane holds tau_f (c.tj) and is about to build the old
-           // floating body's pose anyway; the old floating body picks the wrench up from this lane's LDS column in terms()
-          T Rf[9], pf[3], wf[6];
-          reroot_fb_pose(M.reroot, qj, Rf, pf);
-          xforce(Rf, pf, c.tj, wf);
-#pragma unroll
-          for (int i = 0; i < 6; ++i) park[(PARK_WF + i) * 256] = wf[i];
-        }
-        reroot_root_kinematics<T, T>(M.reroot, qj, vj, cq, cv, c.R, c.p, c.Tw);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) c.vJ[i] = c.Tw[i];  // as for a floating joint on the world: [T, vJ] = 0
-      }
-    }
   };
   // ---- per-body terms in the root frame: motion subspace, bias acceleration, inertia, bias force ----
   auto terms = [&](BankRegs<T>& c, bool accumulate) {  // accumulate: IA, pA already hold what the children handed up
-    T e1[6] = {T(1), T(0), T(0), T(0), T(0), T(0)}, sl[6];
-    local_joint_motion(c.b, c.rb, e1, sl);
-    xmotion(c.R, c.p, sl, c.S);
     const bool floating = c.b.jtype == RBD_JOINT_QUAT_FLOATING;
-    if (floating || joint_nv(c.b.jtype) == 0) {
+    if (SIMPLE) {  // S = X (axis; 0) = (R a; p x R a)
+      const T ax[3] = {c.rb[RB_AXIS], c.rb[RB_AXIS + 1], c.rb[RB_AXIS + 2]};
+      matvec3(c.R, ax, c.S);
+      cross3(c.p, c.S, c.S + 3);
+    } else {
+      T e1[6] = {T(1), T(0), T(0), T(0), T(0), T(0)}, sl[6];
+      local_joint_motion(c.b, c.rb, e1, sl);
+      xmotion(c.R, c.p, sl, c.S);
+    }
+    if (floating || (!SIMPLE && joint_nv(c.b.jtype) == 0)) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) c.S[i] = T(0);
     }
@@ -240,55 +427,23 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     sym6_from_inertia(I, Io);
     momentum_cross(I, c.Tw, po);
     load_body_wrench(c.b, fext, Lf, fe);
-    // idle lanes carry zeros (their values may be shifted into masked-off neighbours)
+    // (lanes without a body are never read by anyone: takers add only what their own children give, under their exec mask)
 #pragma unroll
-    for (int i = 0; i < 21; ++i) c.IA[i] = (accumulate ? c.IA[i] : T(0)) + (c.b.valid ? Io[i] : T(0));
+    for (int i = 0; i < 21; ++i) c.IA[i] = accumulate ? c.IA[i] + Io[i] : Io[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) c.pA[i] = (accumulate ? c.pA[i] : T(0)) + (c.b.valid ? po[i] - fe[i] : T(0));
+    for (int i = 0; i < 6; ++i) c.pA[i] = accumulate ? c.pA[i] + (po[i] - fe[i]) : po[i] - fe[i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) c.U[i] = T(0);
     c.Dinv = T(0);
     c.u = T(0);
-    if (floating && !RR) xforce(c.R, c.p, c.tj, c.U);  // 6-dof joints (level 0): U carries S^-T tau; R, p stay parked for the top-down sweep
-    if (RR) {
-      if (c.b.valid && (c.b.flags & BFD_FCARRY)) {  // the floating joint's force acts on the old floating body: pA -= S^-T tau_f
-        const T* rootcol = park - c.b.sub;          // the root is slot 0 of bank 0 of this state: its LDS column
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c.pA[k] -= rootcol[(PARK_WF + k) * 256];
-      }
-    }
-  };
-  // RR: v̇ of the floating joint from the old floating body's spatial acceleration, v̇_f = S^-1 (a - a_world)
-  auto fb_accel_out = [&](const BankRegs<T>& c, bool bank0) {
-    if (c.b.valid && (c.b.flags & BFD_FCARRY)) {
-      T Rn[9], pn[3], Rf[9], pf[3], dd[6], vf[6];
-      if (bank0) {  // bank 0's transforms stay parked through the sweeps
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Rn[i] = park[(PARK_KIN + i) * 256];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) pn[i] = park[(PARK_KIN + 9 + i) * 256];
-        reroot_fb_pose_from_rebased<T, T>(M.reroot, Rn, pn, Rf, pf);
-      } else {  // (a tree whose old floating body ends up in bank 1: its pose again from the coordinates)
-        T q7[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) q7[k] = q[(long)(M.reroot.fq + k) * Lq.sk + c.b.state * Lq.sb];
-        reroot_fb_pose(M.reroot, q7, Rf, pf);
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { dd[k] = c.acc[k]; dd[3 + k] = c.acc[3 + k] + T(M.gravity[k]); }
-      xmotion_inv(Rf, pf, dd, vf);
-      if (vdot) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) vdot[(long)(M.reroot.fv + k) * Lv.sk + c.b.state * Lv.sb] = vf[k];
-      }
-    }
+    if (floating) xforce(c.R, c.p, c.tj, c.U);  // 6-dof joints (level 0): U carries S^-T tau; R, p stay parked for the top-down sweep
   };
 
   // ---- top-down: transforms to root and twists (update_transforms!, update_twists_wrt_world!) ----
   T qj0[7], vj0[6], qj1[7], vj1[6];
   fetch(0, r0, qj0, vj0);
   fetch(1, r1, qj1, vj1);
-  if (F.stage >= 0) {
+  if (FUSED) {
     // `simulate` fusion: this launch is stage F.stage of a Munthe-Kaas RK4 step (see aba_kernel).  Both banks' stage bookkeeping
     // runs here, back to back, so that their loads of the integrator buffers share one round trip and bank 1's hide behind the
     // SE(3) log/exp of bank 0's floating joint.
@@ -304,23 +459,28 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     setup(r0, qj0, vj0, XR, Xp, tl);
     RBD_MARK(1);
 #pragma unroll 1
-    for (int l = 1; l < M.L0; ++l) bank_fk_step<T, false>(M, l, r0, r0, XR, Xp, tl);
+    for (int l = 1; l < M.L0; ++l) bank_fk_step<T>(M, l, r0, lds, XR, Xp, tl);
   }
   {
     T XR[9], Xp[3], tl[6];
     RBD_MARK(2);
     setup(r1, qj1, vj1, XR, Xp, tl);
     RBD_MARK(3);
-    bank_fk_step<T, true>(M, M.L0, r0, r1, XR, Xp, tl);
-    // bank 0 rests until bank 1 has been swept bottom-up
+    // bank 0 rests until bank 1 has been swept bottom-up; its parked (R, p, Tw) are what bank 1's first level reads
+    {
+      T k24[24];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) park[(PARK_KIN + i) * 256] = r0.R[i];
+      for (int i = 0; i < 9; ++i) k24[i] = r0.R[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) park[(PARK_KIN + 9 + i) * 256] = r0.p[i];
+      for (int i = 0; i < 3; ++i) k24[9 + i] = r0.p[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { park[(PARK_KIN + 12 + i) * 256] = r0.Tw[i]; park[(PARK_KIN + 18 + i) * 256] = r0.vJ[i]; }
+      for (int i = 0; i < 6; ++i) { k24[12 + i] = r0.Tw[i]; k24[18 + i] = r0.vJ[i]; }
+      lds_put<T, 24>(col, PK_KIN, k24);
+    }
+    wave_lds_sync();
+    bank_fk_cross<T>(M.L0, r1, lds, XR, Xp, tl);
 #pragma unroll 1
-    for (int l = M.L0 + 1; l < M.nlevels; ++l) bank_fk_step<T, false>(M, l, r1, r1, XR, Xp, tl);
+    for (int l = M.L0 + 1; l < M.nlevels; ++l) bank_fk_step<T>(M, l, r1, lds, XR, Xp, tl);
   }
   RBD_MARK(4);
   terms(r1, false);
@@ -329,10 +489,10 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
   // ---- bottom-up: articulated-body inertias and bias forces ----
 #pragma unroll 1
   for (int l = M.nlevels - 1; l > M.L0; --l) {
-    bank_finish_joint(l, r1);
-    bank_handoff<T, false>(l, (int)M.nslots[l], r1, r1);
+    bank_finish_joint<T, SIMPLE>(l, r1);
+    bank_handoff<T, RBD_BANK_HANDOFF_LDS>(l, (int)M.nslots[l], r1, r1, lds);
   }
-  bank_finish_joint(M.L0, r1);
+  bank_finish_joint<T, SIMPLE>(M.L0, r1);
   RBD_MARK(6);
   // across the banks: the children's hand-off lands in bank 0's (still empty) accumulators; bank 1 then keeps only what the
   // top-down sweep needs, parked while bank 0 is swept; only then does bank 0 wake up and add its own inertia and bias force
@@ -340,31 +500,33 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
   for (int i = 0; i < 21; ++i) r0.IA[i] = T(0);
 #pragma unroll
   for (int i = 0; i < 6; ++i) r0.pA[i] = T(0);
-  bank_handoff<T, true>(M.L0, (int)M.nslots[M.L0], r1, r0);
+  bank_handoff<T, 1>(M.L0, (int)M.nslots[M.L0], r1, r0, lds);
+  {
+    T k24[24];
+    lds_get<T, 24>(col, PK_KIN, k24);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) r0.R[i] = park[(PARK_KIN + i) * 256];
+    for (int i = 0; i < 9; ++i) r0.R[i] = k24[i];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) r0.p[i] = park[(PARK_KIN + 9 + i) * 256];
+    for (int i = 0; i < 3; ++i) r0.p[i] = k24[9 + i];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { r0.Tw[i] = park[(PARK_KIN + 12 + i) * 256]; r0.vJ[i] = park[(PARK_KIN + 18 + i) * 256]; }
-  // (bank 0's Tw, vJ slots are free again: bank 1's set takes them; R, p stay for the 6-dof joints)
+    for (int i = 0; i < 6; ++i) { r0.Tw[i] = k24[12 + i]; r0.vJ[i] = k24[18 + i]; }
+    // (bank 0's Tw, vJ pairs are free again: bank 1's set takes them; R, p stay for the 6-dof joints)
+    T f20[20];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    park[(PARK_FWD + i) * 256] = r1.U[i];
-    park[(PARK_FWD + 8 + i) * 256] = r1.S[i];
-    park[(PARK_FWD + 14 + i) * 256] = r1.cb[i];
+    for (int i = 0; i < 6; ++i) { f20[i] = r1.U[i]; f20[8 + i] = r1.S[i]; f20[14 + i] = r1.cb[i]; }
+    f20[6] = r1.Dinv;
+    f20[7] = r1.u;
+    lds_put<T, 20>(col, PK_FWD, f20);
   }
-  park[(PARK_FWD + 6) * 256] = r1.Dinv;
-  park[(PARK_FWD + 7) * 256] = r1.u;
   RBD_MARK(7);
   terms(r0, true);
   RBD_MARK(8);
 #pragma unroll 1
   for (int l = M.L0 - 1; l >= 1; --l) {
-    bank_finish_joint(l, r0);
-    bank_handoff<T, false>(l, (int)M.nslots[l], r0, r0);
+    bank_finish_joint<T, SIMPLE>(l, r0);
+    bank_handoff<T, RBD_BANK_HANDOFF_LDS>(l, (int)M.nslots[l], r0, r0, lds);
   }
-  bank_finish_joint(0, r0);
+  bank_finish_joint<T, SIMPLE>(0, r0);
   RBD_MARK(9);
 
   // ---- top-down: accelerations and v̇ ----
@@ -376,63 +538,53 @@ __global__ __launch_bounds__(256, 2) void aba_bank_kernel(BankModel M, long B, c
     if (c.b.level == 0) {
       if (c.b.jtype == RBD_JOINT_QUAT_FLOATING) {
         // IA a = S^-T tau - pA;  v̇ = S^-1 (a - a_world)   ([T, vJ] = 0 on the world)
-        T rhs[6], d[6], Rs[9], ps[3];
+        T rhs[6], d[6], k12[12];
 #pragma unroll
         for (int i = 0; i < 6; ++i) rhs[i] = c.U[i] - c.pA[i];
         sym6_solve(c.IA, rhs, c.acc);
-        if (!RR) {
 #pragma unroll
-          for (int i = 0; i < 6; ++i) d[i] = c.acc[i] - a0[i];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) Rs[i] = park[(PARK_KIN + i) * 256];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) ps[i] = park[(PARK_KIN + 9 + i) * 256];
-          xmotion_inv(Rs, ps, d, c.vd);
-        }
+        for (int i = 0; i < 6; ++i) d[i] = c.acc[i] - a0[i];
+        lds_get<T, 12>(col, PK_KIN, k12);
+        xmotion_inv(k12, k12 + 9, d, c.vd);
       } else {
         bank_joint_accel(c, a0);
       }
     }
   }
 #pragma unroll 1
-  for (int l = 1; l < M.L0; ++l) {
-    T ap[6];
-    bank_pull<T, 6, false>(M, r0.b, l, r0.acc, ap);
-    if (r0.b.level == l) bank_joint_accel(r0, ap);
-  }
+  for (int l = 1; l < M.L0; ++l) bank_accel_step<T>(M, l, r0, lds);
   RBD_MARK(10);
-  if (RR) {
-    if (vdot && !(r0.b.flags & BFD_VROOT)) store_joint_v(r0.b, vdot, Lv, r0.vd);  // the virtual root owns no coordinates
-    fb_accel_out(r0, true);
-  } else {
-    if (vdot) store_joint_v(r0.b, vdot, Lv, r0.vd);
-    if (F.stage >= 0) store_joint_v(r0.b, (T*)F.W.vd[F.stage], Lv, r0.vd);
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    r1.U[i] = park[(PARK_FWD + i) * 256];
-    r1.S[i] = park[(PARK_FWD + 8 + i) * 256];
-    r1.cb[i] = park[(PARK_FWD + 14 + i) * 256];
-    r1.acc[i] = T(0);
-    r1.vd[i] = T(0);
-  }
-  r1.Dinv = park[(PARK_FWD + 6) * 256];
-  r1.u = park[(PARK_FWD + 7) * 256];
+  if (vdot) store_joint_v(r0.b, vdot, Lv, r0.vd);
+  if (FUSED) store_joint_v(r0.b, (T*)F.W.vd[F.stage], Lv, r0.vd);
   {
-    T ap[6];
-    bank_pull<T, 6, true>(M, r1.b, M.L0, r0.acc, ap);
-    if (r1.b.level == M.L0) bank_joint_accel(r1, ap);
+    T f20[20];
+    lds_get<T, 20>(col, PK_FWD, f20);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      r1.U[i] = f20[i];
+      r1.S[i] = f20[8 + i];
+      r1.cb[i] = f20[14 + i];
+      r1.acc[i] = T(0);
+      r1.vd[i] = T(0);
+    }
+    r1.Dinv = f20[6];
+    r1.u = f20[7];
+  }
+  {  // across the banks: every bank-0 lane leaves its acceleration in its exchange column, the bodies of level L0 read their parent's
+    lds_put<T, 6>(col, PK_XCH, r0.acc);
+    wave_lds_sync();
+    if (r1.b.level == M.L0) {
+      T ap[6];
+      lds_get<T, 6>(lds + r1.pcol, PK_XCH, ap);
+      bank_joint_accel(r1, ap);
+    }
+    wave_lds_sync();
   }
 #pragma unroll 1
-  for (int l = M.L0 + 1; l < M.nlevels; ++l) {
-    T ap[6];
-    bank_pull<T, 6, false>(M, r1.b, l, r1.acc, ap);
-    if (r1.b.level == l) bank_joint_accel(r1, ap);
-  }
+  for (int l = M.L0 + 1; l < M.nlevels; ++l) bank_accel_step<T>(M, l, r1, lds);
   RBD_MARK(11);
   if (vdot) store_joint_v(r1.b, vdot, Lv, r1.vd);
-  if (RR) fb_accel_out(r1, false);
-  else if (F.stage >= 0) store_joint_v(r1.b, (T*)F.W.vd[F.stage], Lv, r1.vd);
+  if (FUSED) store_joint_v(r1.b, (T*)F.W.vd[F.stage], Lv, r1.vd);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -473,30 +625,37 @@ RBD_DEV void rnea_fk_step(const BankModel& M, int l, const RneaRegs<T>& par, Rne
 template <typename T, bool CROSS> RBD_DEV void rnea_gather(int l, int ns, const RneaRegs<T>& gv, RneaRegs<T>& tk) {
   const bool takes = (tk.b.level == l - 1);
   if (!CROSS) {
-    const T m0 = (takes && tk.b.nchild >= 1) ? T(1) : T(0);
     T t[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) t[k] = from_next_lane(gv.w[k]);
+    if (takes && tk.b.nchild >= 1) {
+      RBD_KEEP_BRANCH();
 #pragma unroll
-    for (int k = 0; k < 6; ++k) tk.w[k] += keep(t[k], m0);
+      for (int k = 0; k < 6; ++k) tk.w[k] += t[k];
+    }
   }
 #pragma unroll 1
   for (int s = CROSS ? 0 : 1; s < ns; ++s) {
     const bool take = takes && (s < tk.b.nchild);
     const int src = take ? tk.b.base + child_sel(tk.b, s) : tk.b.lane;
-    const T mask = take ? T(1) : T(0);
     T t[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) t[k] = shfl(gv.w[k], src);
+    if (take) {
+      RBD_KEEP_BRANCH();
 #pragma unroll
-    for (int k = 0; k < 6; ++k) tk.w[k] += keep(t[k], mask);
+      for (int k = 0; k < 6; ++k) tk.w[k] += t[k];
+    }
   }
 }
 
+// acc_out / jw_out (nullable): spatial accelerations of the bodies (spatial_accelerations! :387-417, the gravitational acceleration of
+// the root included, as result.accelerations holds them) and joint wrenches (:442-459), 6 x n_bodies x B in reference body order, root frame
 template <typename T>
 __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, int ncol, const T* __restrict__ q, const T* __restrict__ v,
                                                           const T* __restrict__ vdot, const T* __restrict__ fext, T* __restrict__ tau,
-                                                          T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf) {
+                                                          T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T* __restrict__ acc_out,
+                                                          T* __restrict__ jw_out) {
   RneaRegs<T> r0, r1;
   auto fetch = [&](int k, RneaRegs<T>& c, T* qj, T* vj, T* aj) {
     load_bank_body(M, k, B, c.b);
@@ -532,7 +691,11 @@ __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, 
     momentum_cross(I, c.Tw, x);
     load_body_wrench(c.b, fext, Lf, fe);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) c.w[k] = c.b.valid ? (Ia[k] + x[k] - fe[k]) : T(0);
+    for (int k = 0; k < 6; ++k) c.w[k] = Ia[k] + x[k] - fe[k];
+    if (acc_out != nullptr && c.b.valid) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc_out[(long)(6 * c.b.orig + k) * Lf.sk + c.b.state * Lf.sb] = c.acc[k];
+    }
   };
   auto project = [&](RneaRegs<T>& c) {  // tau = S' w
     T out[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
@@ -549,6 +712,10 @@ __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, 
       }
     }
     store_joint_v(c.b, tau, Lv, out);
+    if (jw_out != nullptr && c.b.valid) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) jw_out[(long)(6 * c.b.orig + k) * Lf.sk + c.b.state * Lf.sb] = c.w[k];
+    }
   };
 
   T qj0[7], vj0[6], aj0[6], qj1[7], vj1[6], aj1[6];

@@ -80,10 +80,9 @@ struct rbd_model {
   Reroot rr;
   struct RrSlots {
     bool ok = false;
-    int32_t nlevels = 0, bank_lps = 0, bank_L0 = 0, bank_nb[2] = {0, 0};
-    uint64_t bank_perm_down = 0;
-    std::vector<int32_t> ib, nslots, bank_ib[2];
-    std::vector<double> rb, bank_rb[2];
+    int32_t nlevels = 0;
+    std::vector<int32_t> ib, nslots;
+    std::vector<double> rb;
     TrackPlan track;
     WalkPlan walk;
   } rrs;
@@ -102,7 +101,7 @@ struct rbd_ws {
   DevModel dm{};
   BankModel bm{}; void* d_bank_ib[2] = {nullptr, nullptr}; void* d_bank_rb[2] = {nullptr, nullptr};
   // the re-rooted tree (rbd_reroot.hpp): banked records, chain table, walk plan
-  BankModel bm_rr{}; bool bank_rr = false; void* d_rrbank_ib[2] = {nullptr, nullptr}; void* d_rrbank_rb[2] = {nullptr, nullptr}; void* d_rr_chain_i = nullptr; void* d_rr_chain_r = nullptr;
+  void* d_rr_chain_i = nullptr; void* d_rr_chain_r = nullptr;
   WalkModel wm_rr{}; bool walk_rr = false; void* d_rrtrack_ri = nullptr; void* d_rrtrack_rr = nullptr; void* d_rrwalk_wk = nullptr; size_t walk_rr_lds_bytes = 0, walk_rr_lds_bytes_pair = 0;
   TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr; size_t track_lds_bytes4 = 0; long track_nw4_max_batch = 0; size_t track_lds_bytes = 0; long track_min_batch = 0;
   ContactModel ctm{}; void* d_cp_body = nullptr; void* d_cp_r = nullptr; void* d_hs_r = nullptr;  // soft contact tables
@@ -359,7 +358,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
         const int ps = src[IB_PARENT];
         dst[IB_PARENT] = ps < 0 ? -1 : bslot[ps];
         for (int c2 = 0; c2 < src[IB_NCHILD]; ++c2) dst[IB_CHILD0 + c2] = bslot[src[IB_CHILD0 + c2]];
-        if (ps >= 0 && level[s] != best_L0 && bslot[ps] != j - 1) m->bank_perm_down |= (uint64_t)1 << level[s];
+        if (ps >= 0 && level[s] != best_L0 && bslot[ps] != j - 1) { m->bank_perm_down |= (uint64_t)1 << level[s]; dst[IB_FLAGS] |= BFD_NOTFIRST; }
         memcpy(&m->bank_rb[k][(size_t)j * RB_STRIDE], &m->rb[(size_t)s * RB_STRIDE], sizeof(double) * RB_STRIDE);
       }
     }
@@ -422,37 +421,6 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
         for (int s2 = 0; s2 < nb; ++s2) {
           const int nc = S.ib[(size_t)s2 * IB_STRIDE + IB_NCHILD];
           if (nc > 0 && nc > S.nslots[lev[s2] + 1]) S.nslots[lev[s2] + 1] = nc;
-        }
-        // banks (same rule as above)
-        std::vector<int> per_level(S.nlevels, 0);
-        for (int s2 = 0; s2 < nb; ++s2) per_level[lev[s2]]++;
-        int best_L0 = 0, best_lanes = 1 << 30, best_diff = 1 << 30;
-        for (int L0 = 1; L0 < S.nlevels; ++L0) {
-          int cA = 0, cB = 0;
-          for (int l = 0; l < S.nlevels; ++l) (l < L0 ? cA : cB) += per_level[l];
-          int lanes = 1;
-          while (lanes < std::max(cA, cB)) lanes <<= 1;
-          const int diff = std::abs(cA - cB);
-          if (lanes < best_lanes || (lanes == best_lanes && diff < best_diff)) { best_lanes = lanes; best_L0 = L0; best_diff = diff; }
-        }
-        if (S.nlevels >= 2 && best_lanes < m->lps && best_lanes <= (m->bank_lps > 0 ? m->bank_lps : best_lanes)) {
-          S.bank_lps = best_lanes; S.bank_L0 = best_L0;
-          std::vector<int> bslot(nb, -1);
-          int cnt[2] = {0, 0};
-          for (int s2 = 0; s2 < nb; ++s2) bslot[s2] = cnt[lev[s2] >= best_L0]++;
-          S.bank_nb[0] = cnt[0]; S.bank_nb[1] = cnt[1];
-          for (int k = 0; k < 2; ++k) { S.bank_ib[k].assign((size_t)std::max(cnt[k], 1) * IB_STRIDE, -1); S.bank_rb[k].assign((size_t)std::max(cnt[k], 1) * RB_STRIDE, 0.0); }
-          for (int s2 = 0; s2 < nb; ++s2) {
-            const int k = lev[s2] >= best_L0, j = bslot[s2];
-            const int32_t* src = &S.ib[(size_t)s2 * IB_STRIDE];
-            int32_t* dst = &S.bank_ib[k][(size_t)j * IB_STRIDE];
-            memcpy(dst, src, sizeof(int32_t) * IB_STRIDE);
-            const int ps = src[IB_PARENT];
-            dst[IB_PARENT] = ps < 0 ? -1 : bslot[ps];
-            for (int c2 = 0; c2 < src[IB_NCHILD]; ++c2) dst[IB_CHILD0 + c2] = bslot[src[IB_CHILD0 + c2]];
-            if (ps >= 0 && lev[s2] != best_L0 && bslot[ps] != j - 1) S.bank_perm_down |= (uint64_t)1 << lev[s2];
-            memcpy(&S.bank_rb[k][(size_t)j * RB_STRIDE], &S.rb[(size_t)s2 * RB_STRIDE], sizeof(double) * RB_STRIDE);
-          }
         }
         // track / walk plans of the re-rooted tree (the walk kernels)
         int nheads = 0;
@@ -638,6 +606,10 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     }
     if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
     bm.lps = m->bank_lps; bm.nlevels = m->nlevels; bm.L0 = m->bank_L0; bm.perm_down = m->bank_perm_down;
+    bm.simple = 1;  // every tree joint revolute, apart from 6-dof joints on the world
+    for (int i = 0; i < m->nb; ++i)
+      if (m->jt_ref[i] != RBD_JOINT_REVOLUTE && !(m->jt_ref[i] == RBD_JOINT_QUAT_FLOATING && m->parent_ref[i] < 0)) bm.simple = 0;
+    if (getenv("RBD_BANK_GENERIC")) bm.simple = 0;  // tests: the generic instantiation on a mechanism the SIMPLE one would take
     for (int l = 0; l < MAX_LEVELS; ++l) bm.nslots[l] = (uint8_t)m->nslots[l];
     memcpy(bm.gravity, m->gravity, sizeof bm.gravity);
     // one body per lane keeps the lower latency while its wavefronts still have a SIMD each (measured: 19.4 vs 23.4 us for a
@@ -659,18 +631,6 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     V.nchain = (int32_t)(R.chain_i.size() / RC_I_STRIDE); V.fq = R.fq; V.fv = R.fv;
     V.chain_i = (const int32_t*)w->d_rr_chain_i; V.chain_r = w->d_rr_chain_r;
     memcpy(V.fXp, R.fXp, sizeof V.fXp);
-    if (st == RBD_OK && S.bank_lps > 0) {
-      BankModel& bm = w->bm_rr;
-      for (int k = 0; k < 2 && st == RBD_OK; ++k) {
-        st = upload(&w->d_rrbank_ib[k], S.bank_ib[k].data(), S.bank_ib[k].size() * sizeof(int32_t));
-        if (st == RBD_OK) st = up_real(&w->d_rrbank_rb[k], S.bank_rb[k]);
-        bm.ib[k] = (const int32_t*)w->d_rrbank_ib[k]; bm.rb[k] = w->d_rrbank_rb[k]; bm.nbk[k] = S.bank_nb[k];
-      }
-      bm.lps = S.bank_lps; bm.nlevels = S.nlevels; bm.L0 = S.bank_L0; bm.perm_down = S.bank_perm_down; bm.reroot = V;
-      for (int l = 0; l < MAX_LEVELS; ++l) bm.nslots[l] = (uint8_t)S.nslots[l];
-      memcpy(bm.gravity, m->gravity, sizeof bm.gravity);
-      w->bank_rr = st == RBD_OK;
-    }
     if (st == RBD_OK && S.track.ok && S.walk.ok) {
       const TrackPlan& P = S.track;
       st = upload(&w->d_rrtrack_ri, P.ri.data(), P.ri.size() * sizeof(int32_t));
@@ -848,7 +808,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_rrbank_ib[0], w->d_rrbank_ib[1], w->d_rrbank_rb[0], w->d_rrbank_rb[1], w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -1016,8 +976,8 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
                     Layout Lq, Layout Lv, Layout Lf, void* dacc = nullptr, void* djw = nullptr) {
   const rbd_model* m = w->model;
   if (mapping == RBD_ALGO_ABA_BANKS && m->bank_lps == 0) return RBD_ERR_UNSUPPORTED;
-  // the per-body outputs (accelerations, joint wrenches) are written by the one-body-per-lane kernel
-  const bool banks = !dacc && !djw && m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
+  // the per-body outputs (accelerations, joint wrenches) are written by the lane-per-body kernels (one or two bodies per lane)
+  const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
   const bool can_walk = m->track.ok && m->walk.ok && !dacc && !djw && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch));
   if (mapping == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (can_walk && (mapping == RBD_ALGO_ABA_WALK || (mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->walk_min_batch))) {
@@ -1030,8 +990,8 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
     else HIP_TRY(launch_rnea_state<float>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
   } else if (banks) {
     const int ncol = m->has3dof ? 3 : 1;
-    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_bank<double>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_rnea_bank<float>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
+    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_bank<double>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
+    else HIP_TRY(launch_rnea_bank<float>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
   } else {
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dtau, dqd, nullptr, Lq, Lv, Lf, w->stream, dacc, djw));
     else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dtau, dqd, nullptr, Lq, Lv, Lf, w->stream, dacc, djw));
@@ -1086,13 +1046,7 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_track<double>(tm, flt, gen, nw, B, w->track_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba_track<float>(tm, flt, gen, nw, B, w->track_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
   } else if (pick == RBD_ALGO_ABA_BANKS) {
-    // the tree re-rooted at its centre (fewer levels to sweep) whenever the launch is a plain dynamics! (rbd_reroot.hpp)
-    // Opt-in (RBD_BANK_REROOT=1): measured on Atlas at 26.8 vs 27.0 us — the two levels saved in the bottom-up and top-down sweeps (-6.4 k
-    // cycles) are paid back by the root's pose, which is the forward kinematics of the reversed chain run serially on one lane (+9 k)
-    static const bool bank_reroot = getenv("RBD_BANK_REROOT") != nullptr;
-    const bool rr = w->bank_rr && !fuse && bank_reroot;
-    BankModel bm = rr ? w->bm_rr : w->bm;
-    if (rr) w->last_kernel = "aba_bank_kernel (tree re-rooted at its centre)";
+    BankModel bm = w->bm;
     if (gravity) memcpy(bm.gravity, gravity, sizeof bm.gravity);
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_bank<double>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
     else HIP_TRY(launch_aba_bank<float>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));

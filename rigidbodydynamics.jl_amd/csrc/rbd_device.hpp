@@ -23,7 +23,7 @@ enum { IB_PARENT = 0, IB_JTYPE = 1, IB_QOFF = 2, IB_VOFF = 3, IB_LEVEL = 4, IB_N
 // A floating-base tree re-rooted at its centre (rbd_reroot.hpp): what the kernels need beyond the ordinary per-body records.
 //   chain_i[k * 4] = joint type, q offset, v offset of the k-th joint on the way from the old floating body to the new root;
 //   chain_r[k * 15] = its axis (3) and joint_to_predecessor R (9), p (3) — ORIGINAL constants, kernel scalar type
-enum { BFD_VROOT = 1, BFD_FCARRY = 2 };
+enum { BFD_VROOT = 1, BFD_FCARRY = 2, BFD_NOTFIRST = 4 /* banked records: the body is not the first child of its parent (its parent is not the previous lane) */ };
 struct RerootView {
   int32_t nchain, fq, fv, _pad;
   const int32_t* chain_i;
@@ -83,7 +83,7 @@ struct ChainModel {
 struct BankModel {
   int32_t lps, nlevels, L0;
   int32_t nbk[2];
-  RerootView reroot;           // aba_bank_kernel<T, true> only (nchain > 0)
+  int32_t simple;              // every tree joint is revolute, apart from 6-dof joints on the world: selects the SIMPLE instantiation of aba_bank_kernel
   const int32_t* ib[2];
   const void* rb[2];
   uint64_t perm_down;          // bit l: the in-bank top-down hop at level l needs ds_bpermute (some parent is not the previous lane)
@@ -189,6 +189,12 @@ struct MkFuse {
 #define RBD_HD __host__ __device__ __forceinline__
 
 template <typename T> RBD_DEV T shfl(T x, int src) { return __shfl(x, src, 64); }
+
+// two fp32 states per lane (aba_walk_kernel); reciprocals of well-scaled positive numbers (defined below)
+typedef float f2 __attribute__((ext_vector_type(2)));
+RBD_HD double rcp_hd(double x);
+RBD_HD float rcp_hd(float x);
+RBD_HD f2 rcp_hd(f2 x);
 
 // DPP wave shifts (gfx9 DPP_WF_SR1 = 0x138: lane i <- lane i-1; DPP_WF_SL1 = 0x130: lane i <- lane i+1; lanes shifted in read 0)
 template <int CTRL> RBD_DEV float dpp_mov(float x) {
@@ -374,7 +380,8 @@ template <typename T> RBD_HD void sym6_solve(T* A, const T* b, T* x) {
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= A[SI(k, j)] * A[SI(k, j)] * A[SI(k, k)];
     A[SI(j, j)] = d;
-    dinv[j] = T(1) / d;
+    dinv[j] = rcp_hd(d);  // hardware estimate + Newton steps: the IEEE division expansion is ~5x the instructions, and the pivots of a
+                          // physical articulated inertia are well scaled
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       T s = A[SI(j, i)];
@@ -499,7 +506,6 @@ RBD_HD void sincos_fast(float x, float* s, float* c) { sincos_hd(x, s, c); }
 
 // ---- two fp32 states per lane: every arithmetic instruction becomes a packed v_pk_{fma,mul,add}_f32 (aba_walk_kernel, rbd_walk.hpp).
 // A clang extended vector: + - * / act element-wise, a scalar operand is splat, T(x) converts and splats.
-typedef float f2 __attribute__((ext_vector_type(2)));
 RBD_HD f2 rcp_hd(f2 x) { f2 r; r.x = rcp_hd(x.x); r.y = rcp_hd(x.y); return r; }
 RBD_HD void sincos_fast(f2 x, f2* s, f2* c) {
   float s0, c0, s1, c1;

@@ -48,10 +48,11 @@ hipError_t launch_aba_bank(const BankModel& M, long B, const void* q, const void
 namespace rbd {
 template <typename T>
 hipError_t launch_rnea_bank(const BankModel& M, long B, int ncol, const void* q, const void* v, const void* vdot, const void* fext, void* tau, void* qdot,
-                            Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+                            Layout Lq, Layout Lv, Layout Lf, hipStream_t s, void* acc_out = nullptr, void* jw_out = nullptr);
 }
 namespace rbd {
 template <typename T> hipError_t configure_kernels(int chain_G, size_t chain_lds_bytes);
+template <typename T> hipError_t configure_bank_kernels();  // rbd_bank_kernels.hip
 }
 namespace rbd {
 template <typename T>
