@@ -48,6 +48,28 @@ RBD_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+
+// dst[k] = src[k] in the lanes of `mask`, the other lanes keep dst — as ONE in-place operation.  The C++ form `if (m) dst = src` leaves a
+// phi per value; with two code paths per level in the sweep loops the register allocator reconciled those with two full copies of the
+// loop-carried state per level (60 v_mov_b64 in the FK loop).  Here the values are computed for every lane (the instruction issue is per
+// wavefront anyway; lanes outside the mask compute on stale operands and drop the result) and committed by exec-masked moves.
+// (s_nop: a DPP read of dst may follow; the hazard recognizer does not look inside inline asm.)
+#define RBD_MASSIGN6(MOV)                                                                                                              \
+  unsigned long long sv;                                                                                                               \
+  asm volatile("s_and_saveexec_b64 %[sv], %[mk]\n\t" MOV " %[d0], %[s0]\n\t" MOV " %[d1], %[s1]\n\t" MOV " %[d2], %[s2]\n\t" MOV          \
+               " %[d3], %[s3]\n\t" MOV " %[d4], %[s4]\n\t" MOV " %[d5], %[s5]\n\ts_mov_b64 exec, %[sv]\n\ts_nop 0"                         \
+               : [sv] "=&s"(sv), [d0] "+v"(d[0]), [d1] "+v"(d[1]), [d2] "+v"(d[2]), [d3] "+v"(d[3]), [d4] "+v"(d[4]), [d5] "+v"(d[5])    \
+               : [mk] "s"(mask), [s0] "v"(s[0]), [s1] "v"(s[1]), [s2] "v"(s[2]), [s3] "v"(s[3]), [s4] "v"(s[4]), [s5] "v"(s[5])          \
+               : "scc")
+RBD_DEV void massign6(unsigned long long mask, double* d, const double* s) { RBD_MASSIGN6("v_mov_b64"); }
+RBD_DEV void massign6(unsigned long long mask, float* d, const float* s) { RBD_MASSIGN6("v_mov_b32"); }
+template <typename T, int N> RBD_DEV void massign(bool m, T* d, const T* s) {  // N a multiple of 6 (or padded by the caller)
+  static_assert(N % 6 == 0, "blocks of 6");
+  const unsigned long long mask = __builtin_amdgcn_ballot_w64(m);
+#pragma unroll
+  for (int k = 0; k < N; k += 6) massign6(mask, d + k, s + k);
+}
+
 // LDS layout, in pairs per lane (pair i of thread t at lds[i * 256 + t]):
 //   parked kinematics of bank 0: R 9, p 3 (pairs 0..5: stay for the 6-dof joints), Tw 6, vJ 6 (pairs 6..11)
 //   parked forward data of bank 1 (after bank 0's Tw, vJ are back in registers): U 6 (6..8), 1/D, u (9), S 6 (10..12), cb 6 (13..15)
@@ -79,7 +101,11 @@ template <typename T> struct BankRegs {
   Body<T> b;
   const T* rb;
   int pcol;  // LDS column (thread index in the block) of the lane that carries the parent body
-  T R[9], p[3], Tw[6], vJ[6];
+  T K[24];  // kinematics: transform to root R 9, p 3, twist Tw 6, joint twist in the root frame vJ 6 (generic form only; SIMPLE keeps the joint velocity in K[18])
+  RBD_DEV T* R() { return K; }
+  RBD_DEV T* p() { return K + 9; }
+  RBD_DEV T* Tw() { return K + 12; }
+  RBD_DEV T* vJ() { return K + 18; }
   T S[6], cb[6], IA[21], pA[6], U[6], Dinv, u;
   T tj[6];  // joint torques (6 for the floating joint)
   T acc[6], vd[6];
@@ -94,17 +120,15 @@ template <typename T> RBD_DEV void load_bank_body(const BankModel& M, int k, lon
   b.base = b.lane - b.sub;
   b.state = wave * (64 / lps) + (b.lane / lps);
   b.valid = (b.sub < M.nbk[k]) && (b.state < B);
-  const int32_t* ib = M.ib[k] + (b.sub < M.nbk[k] ? b.sub : 0) * IB_STRIDE;
-  b.parent = ib[IB_PARENT];
-  b.jtype = ib[IB_JTYPE];
-  b.qoff = ib[IB_QOFF];
-  b.voff = ib[IB_VOFF];
-  b.level = b.valid ? ib[IB_LEVEL] : -1;
-  b.nchild = ib[IB_NCHILD];
-  b.orig = ib[IB_ORIG];
-  b.flags = ib[IB_FLAGS];
-#pragma unroll
-  for (int c = 0; c < IB_MAXCHILD; ++c) b.child[c] = ib[IB_CHILD0 + c];
+  const int4* ib4 = reinterpret_cast<const int4*>(M.ib[k] + (b.sub < M.nbk[k] ? b.sub : 0) * IB_STRIDE);  // hipMalloc'ed: 16-byte aligned
+  const int4 w0 = ib4[0], w1 = ib4[1], w2 = ib4[2], w3 = ib4[3];
+  static_assert(IB_PARENT == 0 && IB_JTYPE == 1 && IB_QOFF == 2 && IB_VOFF == 3 && IB_LEVEL == 4 && IB_NCHILD == 5 && IB_ORIG == 6 && IB_CHILD0 == 7 &&
+                IB_FLAGS == 13 && IB_STRIDE == 16, "record layout");
+  b.parent = w0.x; b.jtype = w0.y; b.qoff = w0.z; b.voff = w0.w;
+  b.level = b.valid ? w1.x : -1;
+  b.nchild = w1.y; b.orig = w1.z;
+  b.child[0] = w1.w; b.child[1] = w2.x; b.child[2] = w2.y; b.child[3] = w2.z; b.child[4] = w2.w; b.child[5] = w3.x;
+  b.flags = w3.y;
   b.plane = b.parent >= 0 ? b.base + b.parent : b.lane;  // parent slot (of the parent's bank) in this state's lane group
 }
 
@@ -120,64 +144,56 @@ template <typename T, int N, bool CROSS> RBD_DEV void bank_pull(const BankModel&
 }
 
 // ---- forward kinematics -------------------------------------------------------------------------------------------------------
-template <typename T> RBD_DEV void bank_fk_commit(BankRegs<T>& c, const T* k18 /* the parent's R 9, p 3, Tw 6 */, const T* XR, const T* Xp, const T* tl) {
+// The sweep carries K = (R 9, p 3, Tw 6) per lane [+ vJ 6 in the generic form].  SIMPLE (revolute joints below level 0): ta = (axis, joint
+// velocity), the joint twist is S v with S = X (a; 0) = (R a; p x R a); S itself and the bias term are formed after the sweep, for every lane
+// at once (terms()).  The new values are computed by EVERY lane and committed in the lanes at level l (massign).
+template <typename T, bool SIMPLE>
+RBD_DEV void bank_fk_commit(bool mine, BankRegs<T>& c, const T* k18 /* the parent's R 9, p 3, Tw 6 */, const T* XR, const T* Xp, const T* tl) {
   const T* pR = k18;
   const T* pp = k18 + 9;
   const T* pT = k18 + 12;
-  matmul3(pR, XR, c.R);
-  matvec3(pR, Xp, c.p);
+  T n[24];
+  matmul3(pR, XR, n);
+  matvec3(pR, Xp, n + 9);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) c.p[k] += pp[k];
-  xmotion(c.R, c.p, tl, c.vJ);
+  for (int k = 0; k < 3; ++k) n[9 + k] += pp[k];
+  if (SIMPLE) {
+    T S[6];
+    matvec3(n, tl, S);
+    cross3(n + 9, S, S + 3);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) c.Tw[k] = pT[k] + c.vJ[k];
+    for (int k = 0; k < 6; ++k) n[12 + k] = pT[k] + S[k] * tl[3];
+    massign<T, 18>(mine, c.K, n);
+  } else {
+    xmotion(n, n + 9, tl, n + 18);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) n[12 + k] = pT[k] + n[18 + k];
+    massign<T, 24>(mine, c.K, n);
+  }
 }
 // level l inside a bank.  On most levels every body is the first child of its parent = the previous lane: (R, p, Tw) arrive by DPP.  On the
-// levels where some body is a later child (perm_down) the parents leave theirs in their exchange column and every child reads its parent's
-// column (two code paths chosen by a wave-uniform flag, each with its own commit: merging them would cost a register copy per value).
-template <typename T> RBD_DEV void bank_fk_step(const BankModel& M, int l, BankRegs<T>& c, Pair2<T>* lds, const T* XR, const T* Xp, const T* tl) {
+// levels where some body is a later child (perm_down) the parents leave theirs in their exchange column and every child reads its parent's.
+template <typename T, bool SIMPLE> RBD_DEV void bank_fk_step(const BankModel& M, int l, BankRegs<T>& c, Pair2<T>* lds, const T* XR, const T* Xp, const T* tl) {
+  T k18[18];
   if (RBD_BANK_FK_LDS || ((M.perm_down >> l) & 1)) {  // uniform
     if (c.b.level == l - 1 && c.b.nchild >= 1) {
       RBD_KEEP_BRANCH();
-      T o[18];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) o[k] = c.R[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) o[9 + k] = c.p[k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) o[12 + k] = c.Tw[k];
-      lds_put<T, 18>(lds + threadIdx.x, PK_XCH, o);
+      lds_put<T, 18>(lds + threadIdx.x, PK_XCH, c.K);
     }
     wave_lds_sync();
-    if (c.b.level == l) {
-      RBD_KEEP_BRANCH();
-      T k18[18];
-      lds_get<T, 18>(lds + c.pcol, PK_XCH, k18);
-      bank_fk_commit(c, k18, XR, Xp, tl);
-    }
+    lds_get<T, 18>(lds + c.pcol, PK_XCH, k18);  // (lanes that are not at level l read their parent's column too: whatever it holds is dropped)
     wave_lds_sync();
   } else {
-    T k18[18];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) k18[k] = from_prev_lane(c.R[k]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) k18[9 + k] = from_prev_lane(c.p[k]);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) k18[12 + k] = from_prev_lane(c.Tw[k]);
-    if (c.b.level == l) {
-      RBD_KEEP_BRANCH();
-      bank_fk_commit(c, k18, XR, Xp, tl);
-    }
+    for (int k = 0; k < 18; ++k) k18[k] = from_prev_lane(c.K[k]);
   }
+  bank_fk_commit<T, SIMPLE>(c.b.level == l, c, k18, XR, Xp, tl);
 }
 // level L0: the parents are bank-0 bodies, whose (R, p, Tw) have just been parked — the children read their parent's parked pairs
-template <typename T> RBD_DEV void bank_fk_cross(int L0, BankRegs<T>& c, const Pair2<T>* lds, const T* XR, const T* Xp, const T* tl) {
-  if (c.b.level == L0) {
-    RBD_KEEP_BRANCH();
-    T k18[18];
-    lds_get<T, 18>(lds + c.pcol, PK_KIN, k18);
-    bank_fk_commit(c, k18, XR, Xp, tl);
-  }
+template <typename T, bool SIMPLE> RBD_DEV void bank_fk_cross(int L0, BankRegs<T>& c, const Pair2<T>* lds, const T* XR, const T* Xp, const T* tl) {
+  T k18[18];
+  lds_get<T, 18>(lds + c.pcol, PK_KIN, k18);
+  bank_fk_commit<T, SIMPLE>(c.b.level == L0, c, k18, XR, Xp, tl);
 }
 
 // U = IA S, D = S'U, u = tau - S'pA for the lanes of `r` at level l (1-dof joints; fixed joints keep U = 0, 1/D = 0)
@@ -263,40 +279,33 @@ template <typename T, int MODE> RBD_DEV void bank_handoff(int l, int ns, const B
   }
 }
 
-// v̇ = D^-1 (u - U'a'), a = a' + S v̇ with a' = a_parent + cb
-template <typename T> RBD_DEV void bank_joint_accel(BankRegs<T>& r, const T* a_parent) {
-  T ap[6];
+// v̇ = D^-1 (u - U'a'), a = a' + S v̇ with a' = a_parent + cb — computed by every lane, committed in the lanes of `mine`
+template <typename T> RBD_DEV void bank_joint_accel(bool mine, BankRegs<T>& r, const T* a_parent) {
+  T ap[6], n[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) ap[k] = a_parent[k] + r.cb[k];
   const T x = r.Dinv * (r.u - dot6(r.U, ap));
-  r.vd[0] = x;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) r.acc[k] = ap[k] + r.S[k] * x;
+  for (int k = 0; k < 6; ++k) n[k] = ap[k] + r.S[k] * x;
+  massign<T, 6>(mine, r.acc, n);
+  r.vd[0] = mine ? x : r.vd[0];
 }
 // top-down acceleration step at level l inside a bank (same hop rules as bank_fk_step)
 template <typename T> RBD_DEV void bank_accel_step(const BankModel& M, int l, BankRegs<T>& c, Pair2<T>* lds) {
+  T ap[6];
   if (RBD_BANK_FK_LDS || ((M.perm_down >> l) & 1)) {  // uniform
     if (c.b.level == l - 1 && c.b.nchild >= 1) {
       RBD_KEEP_BRANCH();
       lds_put<T, 6>(lds + threadIdx.x, PK_XCH, c.acc);
     }
     wave_lds_sync();
-    if (c.b.level == l) {
-      RBD_KEEP_BRANCH();
-      T ap[6];
-      lds_get<T, 6>(lds + c.pcol, PK_XCH, ap);
-      bank_joint_accel(c, ap);
-    }
+    lds_get<T, 6>(lds + c.pcol, PK_XCH, ap);
     wave_lds_sync();
   } else {
-    T ap[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) ap[k] = from_prev_lane(c.acc[k]);
-    if (c.b.level == l) {
-      RBD_KEEP_BRANCH();
-      bank_joint_accel(c, ap);
-    }
   }
+  bank_joint_accel(c.b.level == l, c, ap);
 }
 
 #ifdef RBD_PROFILE_PHASES
@@ -328,17 +337,32 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
     c.rb = reinterpret_cast<const T*>(M.rb[k]) + (c.b.sub < M.nbk[k] ? c.b.sub : 0) * RB_STRIDE;
     c.pcol = (int)threadIdx.x - c.b.sub + (c.b.parent >= 0 ? c.b.parent : c.b.sub);
     if (SIMPLE) {
+      // lanes without a body (sub >= nbk, state >= B) load some real body's coordinates of the last state — legal addresses, no branches;
+      // their level is -1, so nothing they compute is committed, taken or stored
       const bool fl = c.b.jtype == RBD_JOINT_QUAT_FLOATING;
-      const long qa = (long)c.b.qoff * Lq.sk + c.b.state * Lq.sb, va = (long)c.b.voff * Lv.sk + c.b.state * Lv.sb;
-      qj[0] = c.b.valid ? q[qa] : T(0);
-      vj[0] = (v != nullptr && c.b.valid) ? v[va] : T(0);
-      c.tj[0] = (tau != nullptr && c.b.valid) ? tau[va] : T(0);
+      const long sc = c.b.state < B ? c.b.state : B - 1;
+      const T* qp = q + ((long)c.b.qoff * Lq.sk + sc * Lq.sb);
+      const long va = (long)c.b.voff * Lv.sk + sc * Lv.sb;
+      const bool hv = v != nullptr, ht = tau != nullptr;  // uniform
+      qj[0] = qp[0];
+      vj[0] = hv ? v[va] : T(0);
+      c.tj[0] = ht ? tau[va] : T(0);
 #pragma unroll
-      for (int k2 = 1; k2 < 7; ++k2) qj[k2] = (fl && c.b.valid) ? q[qa + k2 * Lq.sk] : T(0);
+      for (int k2 = 1; k2 < 7; ++k2) qj[k2] = T(0);
 #pragma unroll
-      for (int k2 = 1; k2 < 6; ++k2) {
-        vj[k2] = (fl && v != nullptr && c.b.valid) ? v[va + k2 * Lv.sk] : T(0);
-        c.tj[k2] = (fl && tau != nullptr && c.b.valid) ? tau[va + k2 * Lv.sk] : T(0);
+      for (int k2 = 1; k2 < 6; ++k2) { vj[k2] = T(0); c.tj[k2] = T(0); }
+      if (fl) {
+        RBD_KEEP_BRANCH();
+#pragma unroll
+        for (int k2 = 1; k2 < 7; ++k2) qj[k2] = qp[k2 * Lq.sk];
+        if (hv) {
+#pragma unroll
+          for (int k2 = 1; k2 < 6; ++k2) vj[k2] = v[va + k2 * Lv.sk];
+        }
+        if (ht) {
+#pragma unroll
+          for (int k2 = 1; k2 < 6; ++k2) c.tj[k2] = tau[va + k2 * Lv.sk];
+        }
       }
     } else {
       load_joint_q(c.b, q, Lq, qj);
@@ -346,12 +370,13 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
       load_joint_v(c.b, tau, Lv, c.tj);
     }
   };
-  auto setup = [&](BankRegs<T>& c, T* qj, T* vj, T* XR, T* Xp, T* tl) {
+  auto setup = [&](BankRegs<T>& c, T* qj, T* vj, T* XR, T* Xp, T* tl, T* ta /* SIMPLE: axis, joint velocity */) {
     if (SIMPLE) {
       const bool fl = c.b.jtype == RBD_JOINT_QUAT_FLOATING;
       const T ax[3] = {c.rb[RB_AXIS], c.rb[RB_AXIS + 1], c.rb[RB_AXIS + 2]};
       T Rj[9], pj[3] = {T(0), T(0), T(0)};
       T sn, cs;
+      ta[0] = ax[0]; ta[1] = ax[1]; ta[2] = ax[2]; ta[3] = vj[0];
       sincos_fast(qj[0], &sn, &cs);
       rot_axis_sc(ax, sn, cs, Rj);
 #pragma unroll
@@ -390,42 +415,53 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
       local_transform(c.b, c.rb, qj, XR, Xp);
       local_joint_motion(c.b, c.rb, vj, tl);
     }
-    // as if at level 0 (transform to root = local transform); deeper lanes overwrite at their level
+    // as if at level 0 (transform to root = local transform, twist = joint twist); deeper lanes overwrite at their level
 #pragma unroll
-    for (int i = 0; i < 9; ++i) c.R[i] = XR[i];
+    for (int i = 0; i < 9; ++i) c.R()[i] = XR[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) c.p[i] = Xp[i];
-    xmotion(c.R, c.p, tl, c.vJ);
+    for (int i = 0; i < 3; ++i) c.p()[i] = Xp[i];
+    xmotion(c.R(), c.p(), tl, c.Tw());
+    if (SIMPLE) {
+      c.K[18] = ta[3];  // the joint velocity, for the bias term
+      c.K[19] = T(0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) c.Tw[i] = c.vJ[i];
+      for (int i = 0; i < 6; ++i) c.vJ()[i] = c.Tw()[i];
+    }
   };
   // ---- per-body terms in the root frame: motion subspace, bias acceleration, inertia, bias force ----
   auto terms = [&](BankRegs<T>& c, bool accumulate) {  // accumulate: IA, pA already hold what the children handed up
     const bool floating = c.b.jtype == RBD_JOINT_QUAT_FLOATING;
-    if (SIMPLE) {  // S = X (axis; 0) = (R a; p x R a)
+    if (SIMPLE) {  // S = X (a; 0) = (R a; p x R a); bias term [T, vJ] = [T, S] v
       const T ax[3] = {c.rb[RB_AXIS], c.rb[RB_AXIS + 1], c.rb[RB_AXIS + 2]};
-      matvec3(c.R, ax, c.S);
-      cross3(c.p, c.S, c.S + 3);
+      matvec3(c.R(), ax, c.S);
+      cross3(c.p(), c.S, c.S + 3);
     } else {
       T e1[6] = {T(1), T(0), T(0), T(0), T(0), T(0)}, sl[6];
       local_joint_motion(c.b, c.rb, e1, sl);
-      xmotion(c.R, c.p, sl, c.S);
+      xmotion(c.R(), c.p(), sl, c.S);
     }
-    if (floating || (!SIMPLE && joint_nv(c.b.jtype) == 0)) {
+    if (floating || (!SIMPLE && joint_nv(c.b.jtype) == 0)) {  // (a 6-dof joint on the world: vJ = T, so [T, vJ] = 0 either way)
 #pragma unroll
       for (int i = 0; i < 6; ++i) c.S[i] = T(0);
     }
-    se3_comm(c.Tw, c.vJ, c.cb);
+    if (SIMPLE) {
+      se3_comm(c.Tw(), c.S, c.cb);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) c.cb[i] *= c.K[18];
+    } else {
+      se3_comm(c.Tw(), c.vJ(), c.cb);
+    }
     RInertia<T> I;
     T Jb[6], mc[3], fe[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) Jb[i] = c.rb[RB_J + i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) mc[i] = c.rb[RB_MC + i];
-    inertia_to_root(Jb, mc, c.rb[RB_M], c.R, c.p, I);
+    inertia_to_root(Jb, mc, c.rb[RB_M], c.R(), c.p(), I);
     T Io[21], po[6];
     sym6_from_inertia(I, Io);
-    momentum_cross(I, c.Tw, po);
+    momentum_cross(I, c.Tw(), po);
     load_body_wrench(c.b, fext, Lf, fe);
     // (lanes without a body are never read by anyone: takers add only what their own children give, under their exec mask)
 #pragma unroll
@@ -436,7 +472,7 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
     for (int i = 0; i < 6; ++i) c.U[i] = T(0);
     c.Dinv = T(0);
     c.u = T(0);
-    if (floating) xforce(c.R, c.p, c.tj, c.U);  // 6-dof joints (level 0): U carries S^-T tau; R, p stay parked for the top-down sweep
+    if (floating) xforce(c.R(), c.p(), c.tj, c.U);  // 6-dof joints (level 0): U carries S^-T tau; R, p stay parked for the top-down sweep
   };
 
   // ---- top-down: transforms to root and twists (update_transforms!, update_twists_wrt_world!) ----
@@ -455,42 +491,34 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
     mk_stage_lane(r1.b, F.stage, (T)F.dt, qj1, vj1, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
   }
   {
-    T XR[9], Xp[3], tl[6];
-    setup(r0, qj0, vj0, XR, Xp, tl);
+    T XR[9], Xp[3], tl[6], ta[4];
+    setup(r0, qj0, vj0, XR, Xp, tl, ta);
     RBD_MARK(1);
 #pragma unroll 1
-    for (int l = 1; l < M.L0; ++l) bank_fk_step<T>(M, l, r0, lds, XR, Xp, tl);
+    for (int l = 1; l < M.L0; ++l) bank_fk_step<T, SIMPLE>(M, l, r0, lds, XR, Xp, SIMPLE ? ta : tl);
   }
   {
-    T XR[9], Xp[3], tl[6];
+    T XR[9], Xp[3], tl[6], ta[4];
     RBD_MARK(2);
-    setup(r1, qj1, vj1, XR, Xp, tl);
+    setup(r1, qj1, vj1, XR, Xp, tl, ta);
     RBD_MARK(3);
     // bank 0 rests until bank 1 has been swept bottom-up; its parked (R, p, Tw) are what bank 1's first level reads
-    {
-      T k24[24];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) k24[i] = r0.R[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) k24[9 + i] = r0.p[i];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { k24[12 + i] = r0.Tw[i]; k24[18 + i] = r0.vJ[i]; }
-      lds_put<T, 24>(col, PK_KIN, k24);
-    }
+    lds_put<T, (SIMPLE ? 20 : 24)>(col, PK_KIN, r0.K);
     wave_lds_sync();
-    bank_fk_cross<T>(M.L0, r1, lds, XR, Xp, tl);
+    bank_fk_cross<T, SIMPLE>(M.L0, r1, lds, XR, Xp, SIMPLE ? ta : tl);
 #pragma unroll 1
-    for (int l = M.L0 + 1; l < M.nlevels; ++l) bank_fk_step<T>(M, l, r1, lds, XR, Xp, tl);
+    for (int l = M.L0 + 1; l < M.nlevels; ++l) bank_fk_step<T, SIMPLE>(M, l, r1, lds, XR, Xp, SIMPLE ? ta : tl);
   }
   RBD_MARK(4);
   terms(r1, false);
   RBD_MARK(5);
 
   // ---- bottom-up: articulated-body inertias and bias forces ----
+  NsStream nss = ns_begin(M.ns_desc);
 #pragma unroll 1
   for (int l = M.nlevels - 1; l > M.L0; --l) {
     bank_finish_joint<T, SIMPLE>(l, r1);
-    bank_handoff<T, RBD_BANK_HANDOFF_LDS>(l, (int)M.nslots[l], r1, r1, lds);
+    bank_handoff<T, RBD_BANK_HANDOFF_LDS>(l, ns_next(nss, M.ns_desc), r1, r1, lds);
   }
   bank_finish_joint<T, SIMPLE>(M.L0, r1);
   RBD_MARK(6);
@@ -500,16 +528,9 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
   for (int i = 0; i < 21; ++i) r0.IA[i] = T(0);
 #pragma unroll
   for (int i = 0; i < 6; ++i) r0.pA[i] = T(0);
-  bank_handoff<T, 1>(M.L0, (int)M.nslots[M.L0], r1, r0, lds);
+  bank_handoff<T, 1>(M.L0, ns_next(nss, M.ns_desc), r1, r0, lds);
   {
-    T k24[24];
-    lds_get<T, 24>(col, PK_KIN, k24);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r0.R[i] = k24[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) r0.p[i] = k24[9 + i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { r0.Tw[i] = k24[12 + i]; r0.vJ[i] = k24[18 + i]; }
+    lds_get<T, (SIMPLE ? 20 : 24)>(col, PK_KIN, r0.K);
     // (bank 0's Tw, vJ pairs are free again: bank 1's set takes them; R, p stay for the 6-dof joints)
     T f20[20];
 #pragma unroll
@@ -524,7 +545,7 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
 #pragma unroll 1
   for (int l = M.L0 - 1; l >= 1; --l) {
     bank_finish_joint<T, SIMPLE>(l, r0);
-    bank_handoff<T, RBD_BANK_HANDOFF_LDS>(l, (int)M.nslots[l], r0, r0, lds);
+    bank_handoff<T, RBD_BANK_HANDOFF_LDS>(l, ns_next(nss, M.ns_desc), r0, r0, lds);
   }
   bank_finish_joint<T, SIMPLE>(0, r0);
   RBD_MARK(9);
@@ -535,21 +556,23 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
   {
     const T a0[6] = {T(0), T(0), T(0), T(-M.gravity[0]), T(-M.gravity[1]), T(-M.gravity[2])};  // a_world = -gravity
     BankRegs<T>& c = r0;
-    if (c.b.level == 0) {
-      if (c.b.jtype == RBD_JOINT_QUAT_FLOATING) {
-        // IA a = S^-T tau - pA;  v̇ = S^-1 (a - a_world)   ([T, vJ] = 0 on the world)
-        T rhs[6], d[6], k12[12];
+    const bool fl0 = c.b.level == 0 && c.b.jtype == RBD_JOINT_QUAT_FLOATING;
+    T fa[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, fv[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    if (fl0) {
+      // IA a = S^-T tau - pA;  v̇ = S^-1 (a - a_world)   ([T, vJ] = 0 on the world)
+      RBD_KEEP_BRANCH();
+      T rhs[6], d[6], k12[12];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) rhs[i] = c.U[i] - c.pA[i];
-        sym6_solve(c.IA, rhs, c.acc);
+      for (int i = 0; i < 6; ++i) rhs[i] = c.U[i] - c.pA[i];
+      sym6_solve(c.IA, rhs, fa);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) d[i] = c.acc[i] - a0[i];
-        lds_get<T, 12>(col, PK_KIN, k12);
-        xmotion_inv(k12, k12 + 9, d, c.vd);
-      } else {
-        bank_joint_accel(c, a0);
-      }
+      for (int i = 0; i < 6; ++i) d[i] = fa[i] - a0[i];
+      lds_get<T, 12>(col, PK_KIN, k12);
+      xmotion_inv(k12, k12 + 9, d, fv);
     }
+    massign<T, 6>(fl0, c.acc, fa);
+    massign<T, 6>(fl0, c.vd, fv);
+    bank_joint_accel(c.b.level == 0 && !fl0, c, a0);
   }
 #pragma unroll 1
   for (int l = 1; l < M.L0; ++l) bank_accel_step<T>(M, l, r0, lds);
@@ -573,12 +596,10 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
   {  // across the banks: every bank-0 lane leaves its acceleration in its exchange column, the bodies of level L0 read their parent's
     lds_put<T, 6>(col, PK_XCH, r0.acc);
     wave_lds_sync();
-    if (r1.b.level == M.L0) {
-      T ap[6];
-      lds_get<T, 6>(lds + r1.pcol, PK_XCH, ap);
-      bank_joint_accel(r1, ap);
-    }
+    T ap[6];
+    lds_get<T, 6>(lds + r1.pcol, PK_XCH, ap);
     wave_lds_sync();
+    bank_joint_accel(r1.b.level == M.L0, r1, ap);
   }
 #pragma unroll 1
   for (int l = M.L0 + 1; l < M.nlevels; ++l) bank_accel_step<T>(M, l, r1, lds);
@@ -736,11 +757,12 @@ __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, 
   }
   newton_euler(r1);
   newton_euler(r0);
+  NsStream nss = ns_begin(M.ns_desc);
 #pragma unroll 1
-  for (int l = M.nlevels - 1; l > M.L0; --l) rnea_gather<T, false>(l, (int)M.nslots[l], r1, r1);
-  rnea_gather<T, true>(M.L0, (int)M.nslots[M.L0], r1, r0);
+  for (int l = M.nlevels - 1; l > M.L0; --l) rnea_gather<T, false>(l, ns_next(nss, M.ns_desc), r1, r1);
+  rnea_gather<T, true>(M.L0, ns_next(nss, M.ns_desc), r1, r0);
 #pragma unroll 1
-  for (int l = M.L0 - 1; l >= 1; --l) rnea_gather<T, false>(l, (int)M.nslots[l], r0, r0);
+  for (int l = M.L0 - 1; l >= 1; --l) rnea_gather<T, false>(l, ns_next(nss, M.ns_desc), r0, r0);
   project(r0);
   project(r1);
 }

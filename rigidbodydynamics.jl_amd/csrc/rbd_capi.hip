@@ -592,7 +592,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     if (dm.nheavy < 4) { dm.heavy[dm.nheavy][0] = jt; dm.heavy[dm.nheavy][1] = m->ib[(size_t)s2 * IB_STRIDE + IB_QOFF]; dm.heavy[dm.nheavy][2] = m->ib[(size_t)s2 * IB_STRIDE + IB_VOFF]; }
     ++dm.nheavy;
   }
-  for (int l = 0; l < MAX_LEVELS; ++l) dm.nslots[l] = (uint8_t)m->nslots[l];
+  nslots_pack_desc(dm.ns_desc, m->nslots.data(), m->nlevels);
   dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc; dm.row_mask = (const uint64_t*)w->d_row_mask;
   memcpy(dm.gravity, m->gravity, sizeof dm.gravity);
   if (m->bank_lps > 0) {
@@ -610,7 +610,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     for (int i = 0; i < m->nb; ++i)
       if (m->jt_ref[i] != RBD_JOINT_REVOLUTE && !(m->jt_ref[i] == RBD_JOINT_QUAT_FLOATING && m->parent_ref[i] < 0)) bm.simple = 0;
     if (getenv("RBD_BANK_GENERIC")) bm.simple = 0;  // tests: the generic instantiation on a mechanism the SIMPLE one would take
-    for (int l = 0; l < MAX_LEVELS; ++l) bm.nslots[l] = (uint8_t)m->nslots[l];
+    nslots_pack_desc(bm.ns_desc, m->nslots.data(), m->nlevels);
     memcpy(bm.gravity, m->gravity, sizeof bm.gravity);
     // one body per lane keeps the lower latency while its wavefronts still have a SIMD each (measured: 19.4 vs 23.4 us for a
     // lone wavefront); the banked mapping takes over once the batch would put two of those on a SIMD

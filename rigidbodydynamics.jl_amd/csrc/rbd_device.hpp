@@ -19,7 +19,7 @@
 namespace rbd {
 
 // per-body integer record
-enum { IB_PARENT = 0, IB_JTYPE = 1, IB_QOFF = 2, IB_VOFF = 3, IB_LEVEL = 4, IB_NCHILD = 5, IB_ORIG = 6, IB_CHILD0 = 7, IB_MAXCHILD = 6, IB_FLAGS = IB_CHILD0 + IB_MAXCHILD /* BF_* of a re-rooted tree (rbd_reroot.hpp), 0 otherwise */, IB_STRIDE = IB_FLAGS + 1 };
+enum { IB_PARENT = 0, IB_JTYPE = 1, IB_QOFF = 2, IB_VOFF = 3, IB_LEVEL = 4, IB_NCHILD = 5, IB_ORIG = 6, IB_CHILD0 = 7, IB_MAXCHILD = 6, IB_FLAGS = IB_CHILD0 + IB_MAXCHILD /* BF_* of a re-rooted tree (rbd_reroot.hpp), 0 otherwise */, IB_STRIDE = 16 /* 14 fields padded to 64 bytes: a record is four 16-byte loads */ };
 // A floating-base tree re-rooted at its centre (rbd_reroot.hpp): what the kernels need beyond the ordinary per-body records.
 //   chain_i[k * 4] = joint type, q offset, v offset of the k-th joint on the way from the old floating body to the new root;
 //   chain_r[k * 15] = its axis (3) and joint_to_predecessor R (9), p (3) — ORIGINAL constants, kernel scalar type
@@ -37,6 +37,26 @@ enum { MAX_LEVELS = 64 };
 // Bodies are renumbered on the host into DFS PRE-ORDER "slots": the first child of slot s is slot s+1, so the
 // parent->first-child hop of every sweep is a DPP wave shift (v_mov_b32_dpp wave_shr:1 / wave_shl:1, VALU rate)
 // instead of an LDS-crossbar ds_bpermute; only branch points (2nd, 3rd ... child) use ds_bpermute.
+// Per-level child-slot counts (nslots of level l = max #children of the level l-1 bodies) travel in the kernel arguments as a STREAM of
+// 4-bit fields in the order the bottom-up sweeps consume them — level nlevels-1 first — and are shifted out of a scalar register.
+// (As a byte array indexed by the level, the compiler fetched nslots[l] from the kernel-argument segment inside every level of the sweep,
+// with a full s_waitcnt behind it: a memory round trip per level on the critical path of every lane-per-body kernel.  Found in round 3.)
+struct NsStream {
+  uint64_t w;
+  int j;
+};
+__host__ __device__ inline NsStream ns_begin(const uint64_t (&desc)[4]) { return NsStream{desc[0], 0}; }
+__host__ __device__ inline int ns_next(NsStream& s, const uint64_t (&desc)[4]) {  // nslots of the next level down the stream
+  if (s.j != 0 && (s.j & 15) == 0) s.w = desc[(s.j >> 4) & 3];  // every 16 levels (never for a humanoid)
+  const int ns = (int)(s.w & 15);
+  s.w >>= 4;
+  ++s.j;
+  return ns;
+}
+inline void nslots_pack_desc(uint64_t (&desc)[4], const int32_t* per_level, int nlevels) {
+  desc[0] = desc[1] = desc[2] = desc[3] = 0;
+  for (int l = nlevels - 1, j = 0; l >= 1 && j < 64; --l, ++j) desc[j >> 4] |= (uint64_t)(per_level[l] & 15) << ((j & 15) * 4);
+}
 struct DevModel {
   int32_t nb, nq, nv;
   int32_t lps;        // lanes per state (power of two, <= 64)
@@ -54,7 +74,7 @@ struct DevModel {
   const uint64_t* row_mask; // [nv] bit c of row_mask[r]: M[r, c] is structurally non-zero (joint of dof c supports the body of dof r), c <= r
   const int32_t* anc;       // [nb * nlevels] anc[s*nlevels + k] = k-th ancestor slot of s (k=0: s itself), -1 past the root
   uint64_t perm_down;       // bit l set: some body at level l has parent slot != s-1 (top-down hop needs ds_bpermute at level l)
-  uint8_t nslots[MAX_LEVELS];  // child slots to gather when the bottom-up sweep processes level l (max #children of level l-1 parents)
+  uint64_t ns_desc[4];  // child slots to gather when the bottom-up sweep processes level l (max #children of level l-1 parents): NsStream
   double gravity[3];
 };
 
@@ -87,7 +107,7 @@ struct BankModel {
   const int32_t* ib[2];
   const void* rb[2];
   uint64_t perm_down;          // bit l: the in-bank top-down hop at level l needs ds_bpermute (some parent is not the previous lane)
-  uint8_t nslots[MAX_LEVELS];  // child slots to gather at level l
+  uint64_t ns_desc[4];         // child slots to gather at level l: NsStream
   double gravity[3];
 };
 

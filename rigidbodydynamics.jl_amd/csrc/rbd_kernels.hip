@@ -164,6 +164,7 @@ void aba_kernel(DevModel M, long B, const T* q, const T* v, const T* __restrict_
       }
     }
   };
+  NsStream nss = ns_begin(M.ns_desc);
 #pragma unroll 1
   for (int l = M.nlevels - 1; l >= 1; --l) {
     if (b.level == l && ndof > 0) finish_joint();
@@ -206,7 +207,7 @@ void aba_kernel(DevModel M, long B, const T* q, const T* v, const T* __restrict_
       if (INNER_FLOAT) gp[k] = inner_floating ? U[0][k] : gp[k];
       pA[k] += keep(from_next_lane(gp[k]), m0);
     }
-    const int ns = (int)M.nslots[l];
+    const int ns = ns_next(nss, M.ns_desc);
 #pragma unroll 1
     for (int s = 1; s < ns; ++s) {
       const bool take = (b.level == l - 1) && (s < b.nchild);
@@ -358,8 +359,9 @@ __global__ __launch_bounds__(256) void rnea_kernel(DevModel M, long B, const T* 
     for (int k = 0; k < 6; ++k) w[k] = b.valid ? (Ia[k] + x[k] - fe[k]) : T(0);
   }
   // joint_wrenches_and_torques! (:442-459): w_parent += w_child, bottom-up
+  NsStream nss = ns_begin(M.ns_desc);
   for (int l = M.nlevels - 1; l >= 1; --l) {
-    const int ns = (int)M.nslots[l];
+    const int ns = ns_next(nss, M.ns_desc);
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) {
       T give[6];
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
   }
   // composite-rigid-body inertias, bottom-up (10 scalars per child; first child by DPP): update_crb_inertias!
   // In place: at step l only lanes at level l-1 change, and what they read (level l) was finished one step earlier.
+  NsStream nss = ns_begin(M.ns_desc);
 #pragma unroll 1
   for (int l = M.nlevels - 1; l >= 1; --l) {
     const bool takes = (b.level == l - 1);
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
 #pragma unroll
     for (int k = 0; k < 3; ++k) t[6 + k] = keep(from_next_lane(Ic.c[k]), m0);
     t[9] = keep(from_next_lane(Ic.m), m0);
-    const int ns = (int)M.nslots[l];
+    const int ns = ns_next(nss, M.ns_desc);
 #pragma unroll 1
     for (int s = 1; s < ns; ++s) {
       const bool take = takes && (s < b.nchild);
@@ -690,8 +693,9 @@ __global__ __launch_bounds__(256) void kin_kernel(DevModel M, long B, const T* _
     }
   }
   if (A_out == nullptr) return;  // uniform
+  NsStream nss = ns_begin(M.ns_desc);
   for (int l = M.nlevels - 1; l >= 1; --l) {
-    const int ns = (int)M.nslots[l];
+    const int ns = ns_next(nss, M.ns_desc);
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) {
       T give[10], acc[10];
