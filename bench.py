@@ -85,7 +85,7 @@ def parse_args():
     ap.add_argument("--graph", action="store_true", help="capture the K steps in one hipGraph")
     ap.add_argument("--gather-every-step", action="store_true", help="RCCL all-gather of v̇ inside every timed step (config 4 reports both anyway)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--algorithm", default="aba", choices=["aba", "aba_pipe", "aba_walk", "aba_tracks", "aba_lanes", "aba_chains", "aba_banks"],
+    ap.add_argument("--algorithm", default="aba", choices=["aba", "aba_walk", "aba_lanes", "aba_banks", "aba_tracks", "aba_pipe"],
                     help="lane mapping of the fused ABA: aba = the library's choice by batch size")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra (informational) measurement of two independent batches issued on two HIP streams")
@@ -196,7 +196,7 @@ def main():
 
     # low-overhead launch: pre-marshalled ctypes call straight into the C ABI
     L = _capi.lib()
-    algo_id = {"aba": 0, "aba_lanes": 2, "aba_chains": 3, "aba_banks": 4, "aba_tracks": 5, "aba_walk": 6, "aba_pipe": 7}[args.algorithm]
+    algo_id = {"aba": 0, "aba_lanes": 2, "aba_banks": 4, "aba_tracks": 5, "aba_walk": 6, "aba_pipe": 7}[args.algorithm]  # tracks / pipe: RBD_EXPERIMENTAL builds only
     stream = torch.cuda.current_stream(device)
     L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(stream.cuda_stream))
     vp = ctypes.c_void_p

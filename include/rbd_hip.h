@@ -74,23 +74,21 @@ enum {
   RBD_ALGO_ABA = 0,          /* fused articulated-body algorithm (default; tree mechanisms)   */
   RBD_ALGO_CRBA_CHOLESKY = 1,/* the reference's own route: bias-RNEA + CRBA + Cholesky; also
                                 fills M and c in the workspace; the only route with loop joints */
-  /* RBD_ALGO_ABA picks between two mappings of the same algorithm by batch size; these force one (tests, benchmarks): */
-  RBD_ALGO_ABA_LANES = 2,    /* one lane per (state, body), level-synchronous sweeps: small batches             */
-  RBD_ALGO_ABA_CHAINS = 3,   /* a few lanes per state walk chains of the tree: large batches.  RBD_ERR_UNSUPPORTED
-                                for mechanisms with 3-dof tree joints or a 6-dof joint not on the world           */
-  RBD_ALGO_ABA_BANKS = 4,    /* lane-per-body with two bodies per lane (levels split into two banks): twice the
-                                states per wavefront.  Same scope as the chain mapping                            */
-  RBD_ALGO_ABA_TRACKS = 5,   /* chains of the tree on a few lanes per state, canonical body frames (joint axis = +z), per-body
-                                results in lane-private LDS rows: the default wherever it applies (trees of revolute /
-                                prismatic / fixed joints, 6-dof joints on the world).  RBD_ERR_UNSUPPORTED elsewhere        */
+  /* RBD_ALGO_ABA picks between three lane mappings of the same algorithm by how many wavefronts the batch makes of each
+     (rbd_capi.hip run_aba); these force one (tests, benchmarks): */
+  RBD_ALGO_ABA_LANES = 2,    /* one lane per (state, body), level-synchronous sweeps: small batches, every tree joint type          */
+  RBD_ALGO_ABA_CHAINS = 3,   /* (round 1: chains of the tree on a few lanes per state.  Removed in round 3 — it lost at every batch
+                                size; the value stays reserved and returns RBD_ERR_UNSUPPORTED)                                     */
+  RBD_ALGO_ABA_BANKS = 4,    /* lane-per-body with two bodies per lane (levels split into two banks): twice the states per
+                                wavefront; 1-dof / fixed tree joints, 6-dof joints on the world.  The bench workload (4096 Atlas states) */
+  RBD_ALGO_ABA_TRACKS = 5,   /* EXPERIMENTAL build only (csrc/build.sh RBD_EXPERIMENTAL=1; rbd_experimental() == 1): chains of the tree on a
+                                few lanes per state, per-body results in lane-private LDS rows.  RBD_ERR_UNSUPPORTED otherwise        */
   RBD_ALGO_ABA_WALK = 6,     /* the track schedule with one WAVEFRONT per track and one lane per state: a workgroup is up to four
                                 wavefronts over the same 64 states, q / v / tau staged through LDS, per-joint results in accumulation
-                                registers.  Same scope as the track mapping, at most 11 steps per track; RBD_ERR_UNSUPPORTED
-                                elsewhere or when the rows of 64 states do not fit one compute unit's LDS                      */
-  RBD_ALGO_ABA_PIPE = 7      /* small batches: a workgroup is four wavefronts over 16 states x 4 tracks, and a body-step is cut into stages
-                                (transform chain | inertia | twist chain + bias force | articulated-body recursion) that run on the four
-                                SIMDs of a compute unit one step apart.  Trees of revolute joints with or without a 6-dof root, at most
-                                4 tracks of 11 steps; RBD_ERR_UNSUPPORTED elsewhere                                              */
+                                registers.  Trees of revolute / prismatic / fixed joints, 6-dof joints on the world, at most 11 steps per
+                                track; RBD_ERR_UNSUPPORTED elsewhere or when the rows of 64 states do not fit one compute unit's LDS.
+                                Large batches                                                                                       */
+  RBD_ALGO_ABA_PIPE = 7      /* EXPERIMENTAL build only: a body-step cut into stages on the four SIMDs of a compute unit            */
 };
 
 /* ---- loop (non-tree) joint: src/mechanism_modification.jl:38-43,
@@ -172,9 +170,9 @@ typedef struct rbd_opts {
 /* ---- model / workspace lifetime ------------------------------------------ */
 int rbd_model_create(const rbd_flat_model_t* desc, rbd_model_t** out); /* deep-copies desc */
 int rbd_model_destroy(rbd_model_t* model);
-/* Introspection of the chain-scheduled ABA plan (RBD_ALGO_ABA_CHAINS): tracks (lanes) per state, steps per pass, LDS fields
- * per state, and the steps×tracks table of reference body indices (-1 = idle).  RBD_ERR_UNSUPPORTED when the mechanism is
- * outside that mapping's scope.  Host-only, no device needed. */
+/* Introspection of the chain schedule under the track / walk plans: tracks per state, steps per pass, (lds_fields: 0, kept for ABI
+ * stability), and the steps×tracks table of reference body indices (-1 = idle).  RBD_ERR_UNSUPPORTED when the mechanism is
+ * outside the scope of those mappings.  Host-only, no device needed. */
 /* ... and of the two-bodies-per-lane ("banked") mapping: lanes per state, the level at which bank 1 starts, bodies per bank, and whether
  * the banked ABA (not only the banked RNEA) takes the mechanism.  RBD_ERR_UNSUPPORTED when the split would not save lanes. */
 int rbd_model_bank_plan(const rbd_model_t* model, int32_t* lanes, int32_t* first_level_of_bank1, int32_t* bodies_bank0, int32_t* bodies_bank1,
@@ -323,7 +321,12 @@ int rbd_workspace_enable_timing(rbd_ws_t* ws, int32_t enable);
 int rbd_workspace_last_kernel_ms(rbd_ws_t* ws, float* ms);
 /* name of the articulated-body kernel (lane mapping) the last rbd_dynamics / rbd_simulate / rbd_mass_matrix_solve call launched */
 const char* rbd_workspace_last_kernel(const rbd_ws_t* ws);
+/* 100·round + revision of this header.  rbd_flat_model_t grew its four contact fields at 200; a caller built against an older header must
+ * not call a newer library (the Python and Julia loaders compare this with the value they were written for). */
+#define RBD_HIP_H_VERSION 300
 int rbd_version(void);
+/* 1 when the library was built with RBD_EXPERIMENTAL=1 (RBD_ALGO_ABA_TRACKS / RBD_ALGO_ABA_PIPE available), else 0 */
+int rbd_experimental(void);
 
 #ifdef __cplusplus
 }

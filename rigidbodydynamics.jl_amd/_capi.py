@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RBD_LIB") or os.path.join(_HERE, "csrc", "librbd_hip.so")  # RBD_LIB: A/B kernel variants (experiments only)
 
 RBD_OK = 0
+HEADER_VERSION = 300  # RBD_HIP_H_VERSION of the include/rbd_hip.h this binding was written against
 F64, F32 = 0, 1
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 MEM_DEVICE, MEM_HOST = 0, 1
@@ -21,7 +22,7 @@ SYMBOLS = (
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
     "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan", "rbd_model_track_plan", "rbd_inverse_dynamics_bodies", "rbd_dynamics_bias_bodies",
     "rbd_model_reroot_plan", "rbd_model_contact_dims", "rbd_contact_dynamics", "rbd_dynamics_contact", "rbd_simulate_contact",
-    "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_comm_last_error",
+    "rbd_experimental", "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_comm_last_error",
 )
 
 
@@ -45,6 +46,8 @@ def lib():
             raise FileNotFoundError(f"{LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
                                     "(rigidbodydynamics.jl_amd has no CPU fallback)")
         L = ctypes.CDLL(LIB_PATH)
+        if L.rbd_version() != HEADER_VERSION:  # struct layouts (rbd_flat_model_t) change with the header version
+            raise RuntimeError(f"{LIB_PATH} reports rbd_version {L.rbd_version()}, this binding is for {HEADER_VERSION}: rebuild (csrc/build.sh)")
         vp, i32 = ctypes.c_void_p, ctypes.c_int32
         L.rbd_status_string.restype = ctypes.c_char_p
         L.rbd_status_string.argtypes = [ctypes.c_int]

@@ -7,6 +7,7 @@
 
 namespace rbd {
 
+static_assert(BANK_LDS_PAIRS == 30, "rbd_capi.hip sizes the resident batch of the banked kernel with BANK_LDS_PAIRS_HOST = 30");
 template <typename T> static size_t bank_lds_bytes() { return (size_t)BANK_LDS_PAIRS * 256 * sizeof(Pair2<T>); }
 
 template <typename T>

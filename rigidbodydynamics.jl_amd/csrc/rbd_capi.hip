@@ -18,6 +18,7 @@
 #include "rbd_walk_plan.hpp"
 #include "rbd_reroot.hpp"
 #include "rbd_state_plan.hpp"
+enum { BANK_LDS_PAIRS_HOST = 30 };  // = BANK_LDS_PAIRS of rbd_bank.hpp (16 parked + 14 exchange pairs per lane; checked in rbd_bank_kernels.hip)
 
 using namespace rbd;
 
@@ -74,7 +75,7 @@ struct rbd_model {
   std::vector<int32_t> bank_ib[2];
   std::vector<double> bank_rb[2];
   uint64_t bank_perm_down = 0;
-  ChainPlan chain;  // plan of aba_chain_kernel (chain.ok == false: mechanism outside its scope)
+  ChainPlan chain;  // the chains of the tree packed on G tracks by list scheduling: what the track / walk plans are built on (rbd_model_chain_plan exposes it)
   TrackPlan track;  // plan of aba_track_kernel (track.ok == false: mechanism outside its scope)
   // the tree re-rooted at its centre (rbd_reroot.hpp): its own slots, banks and track / walk plans; used by the ABA kernels that support it
   Reroot rr;
@@ -110,7 +111,7 @@ struct rbd_ws {
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
-  ChainModel cm{}; void* d_chain_tab = nullptr; void* d_chain_cb = nullptr; size_t chain_lds_bytes = 0; long bank_min_batch = 0;
+  long bank_min_batch = 0, bank_resident_states = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
   // staging for RBD_MEM_HOST (lazy)
   void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -132,7 +133,14 @@ struct rbd_ws {
 
 extern "C" {
 
-int rbd_version(void) { return 100; }
+int rbd_version(void) { return RBD_HIP_H_VERSION; }
+int rbd_experimental(void) {
+#ifdef RBD_EXPERIMENTAL
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 const char* rbd_status_string(int s) {
   switch (s) {
@@ -469,7 +477,7 @@ int rbd_model_chain_plan(const rbd_model_t* m, int32_t* tracks, int32_t* steps, 
   if (!m->chain.ok) return RBD_ERR_UNSUPPORTED;
   if (tracks) *tracks = m->chain.G;
   if (steps) *steps = m->chain.ns;
-  if (lds_fields) *lds_fields = (int32_t)m->chain.lds_fields(m->nb);
+  if (lds_fields) *lds_fields = 0;  // (LDS footprint of the removed chain kernel; kept for ABI stability)
   if (table) {
     if (capacity < (int32_t)m->chain.tab.size()) return RBD_ERR_DIMENSION_MISMATCH;
     for (size_t i = 0; i < m->chain.tab.size(); ++i) table[i] = m->chain.tab[i] < 0 ? -1 : m->order[m->chain.tab[i]];  // reference body indices
@@ -612,10 +620,19 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     if (getenv("RBD_BANK_GENERIC")) bm.simple = 0;  // tests: the generic instantiation on a mechanism the SIMPLE one would take
     nslots_pack_desc(bm.ns_desc, m->nslots.data(), m->nlevels);
     memcpy(bm.gravity, m->gravity, sizeof bm.gravity);
-    // one body per lane keeps the lower latency while its wavefronts still have a SIMD each (measured: 19.4 vs 23.4 us for a
-    // lone wavefront); the banked mapping takes over once the batch would put two of those on a SIMD
-    w->bank_min_batch = 1536L * (64 / m->lps);
+    // Two bodies per lane wherever the mechanism is in its scope: since round 3 it is ahead of one body per lane at every batch size
+    // (profiles/r03_mapping_sweep.txt: 18.8 vs 21.0 us at 512 Atlas states, 19.1 vs 30.1 at 4096).  RBD_BANK_MIN_BATCH: tests.
+    w->bank_min_batch = 0;
     if (const char* e = getenv("RBD_BANK_MIN_BATCH")) w->bank_min_batch = atol(e);
+    // ... up to the batch whose workgroups (256 lanes) are all resident at once: per compute unit as many as the LDS columns allow
+    // (park + exchange pairs: 120 KB in fp64 -> one, 60 KB in fp32 -> two), at most the two the register budget allows
+    {
+      int ncu = 256;
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+      const size_t lds = (size_t)BANK_LDS_PAIRS_HOST * 256 * 2 * (dtype == RBD_F64 ? 8 : 4);
+      const long per_cu = std::max<long>(1, std::min<long>(2, (long)(160 * 1024 / lds)));
+      w->bank_resident_states = (long)ncu * per_cu * (256 / m->bank_lps);
+    }
   }
   if (m->rrs.ok) {
     const Reroot& R = m->rr;
@@ -650,20 +667,6 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     }
     if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
   }
-  if (m->chain.ok) {
-    const ChainPlan& P = m->chain;
-    st = upload(&w->d_chain_tab, P.tab.data(), P.tab.size() * sizeof(int32_t));
-    if (st == RBD_OK) st = upload(&w->d_chain_cb, P.cb.data(), P.cb.size() * sizeof(int32_t));
-    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
-    ChainModel& cm = w->cm;
-    cm.nb = m->nb; cm.ns = P.ns; cm.G = P.G; cm.spw = 64 / P.G; cm.nfl = P.nfl; cm.nfs = P.nfs;
-    cm.tab = (const int32_t*)w->d_chain_tab; cm.cb = (const int32_t*)w->d_chain_cb; cm.rb = w->d_rb;
-    for (int l = 0; l < MAX_LEVELS; ++l) cm.nrounds[l] = P.nrounds[l];
-    memcpy(cm.gravity, m->gravity, sizeof cm.gravity);
-    w->chain_lds_bytes = P.lds_fields(m->nb) * (size_t)(64 / P.G) * (dtype == RBD_F64 ? 8 : 4);
-    if (w->chain_lds_bytes > 160 * 1024) w->chain_lds_bytes = 0;  // does not fit: lanes mapping only
-    // opt-in only (RBD_ALGO_ABA_CHAINS): the banked mapping is ahead of it at every measured batch size (profiles/r01_mapping_sweep.txt)
-  }
   if (m->track.ok) {
     const TrackPlan& P = m->track;
     st = upload(&w->d_track_ri, P.ri.data(), P.ri.size() * sizeof(int32_t));
@@ -681,11 +684,15 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->track_lds_bytes = (size_t)P.ns * nf * 64 * es + nrec * 16 + nrec * TR_STRIDE * es + ((size_t)P.nA * (TMB_A + TMB_C) + (size_t)P.nB * TMB_B) * spw * es +
                          ((size_t)P.ns + 4) * sizeof(int32_t);
     if (w->track_lds_bytes > 160 * 1024) w->track_lds_bytes = 0;  // rows of a deep tree do not fit one CU's LDS: other mappings
+#ifndef RBD_EXPERIMENTAL
+    w->track_lds_bytes = 0;  // aba_track_kernel is built only with RBD_EXPERIMENTAL=1 (build.sh): it lost to the banked / walk kernels at every size
+#else
     if (w->track_lds_bytes > 0) {
       const hipError_t e = dtype == RBD_F64 ? configure_track_kernel<double>(P.G, P.has_floating, P.general, w->track_lds_bytes)
                                             : configure_track_kernel<float>(P.G, P.has_floating, P.general, w->track_lds_bytes);
       if (e != hipSuccess) { g_last_hip_error = std::string("configure_track_kernel: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
     }
+#endif
     // the four-wave latency form while a workgroup (64 / G states) still has a compute unit to itself; one wave per group beyond
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
@@ -737,16 +744,17 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       w->walk_pair_min_batch = (long)ncu * 64 + 1;
       if (const char* e = getenv("RBD_WALK_PAIR_MIN_BATCH")) w->walk_pair_min_batch = atol(e);
     }
-    // RBD_ALGO_ABA picks it from this batch size up (RBD_WALK_MIN_BATCH overrides).  Measured on Atlas (profiles/r02_walk_sweep.txt): a launch takes
-    // the same ~37 us from 64 to 16 384 states (one workgroup per 64 states, one per CU); the banked lane-per-body kernel takes 25 us at 4096,
-    // 35 us at 8192 (two wavefronts on every SIMD) and 52 us from 8704 on (a third wavefront on some) — the crossover is one state past
-    // 32 states per CU
+    // RBD_ALGO_ABA picks it from this batch size up (RBD_WALK_MIN_BATCH overrides): one state past what the lane-per-body kernels run in ONE
+    // round of resident wavefronts — the banked kernel's resident workgroups when the mechanism has banks, else two one-body-per-lane
+    // wavefronts per SIMD.  (profiles/r03_mapping_sweep.txt, Atlas: a walk launch takes the same ~37 us from 64 to 16 384 states; banked fp64
+    // 19 us to 4096 states and 36 us from there to 8192; banked fp32 18 us to 4096, 26 to 8192, 36 at 12 288.)
     {
       int ncu = 256;
       (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-      w->walk_min_batch = (long)ncu * 32 + 1;
+      w->walk_min_batch = (m->bank_lps > 0 && m->bank_aba_ok ? w->bank_resident_states : (long)ncu * 4 * 2 * (64 / m->lps)) + 1;
     }
     if (const char* e = getenv("RBD_WALK_MIN_BATCH")) w->walk_min_batch = atol(e);
+#ifdef RBD_EXPERIMENTAL
     // the role-pipelined form for small batches: revolute trees (with or without a 6-dof root) on at most 4 tracks
     if (!P.general && P.G <= 4) {
       const std::vector<int32_t> rec = walk_unpack4(P.ns, P.G, P.ri, m->walk.wk);
@@ -769,6 +777,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       w->pipe_max_batch = 0;
       if (const char* e = getenv("RBD_PIPE_MAX_BATCH")) w->pipe_max_batch = atol(e);
     }
+#endif
   }
   if (m->state.ok && m->state.nlevels <= state_max_levels(dtype == RBD_F64 ? 8 : 4)) {
     const StatePlan& P = m->state;
@@ -793,9 +802,8 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->state_min_batch = (long)1 << 62;
   }
   {
-    const int G = (m->chain.ok && w->chain_lds_bytes > 0) ? m->chain.G : 0;
-    const hipError_t e = dtype == RBD_F64 ? configure_kernels<double>(G, w->chain_lds_bytes) : configure_kernels<float>(G, w->chain_lds_bytes);
-    if (e != hipSuccess) { g_last_hip_error = std::string("configure_kernels: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
+    const hipError_t e = dtype == RBD_F64 ? configure_bank_kernels<double>() : configure_bank_kernels<float>();
+    if (e != hipSuccess) { g_last_hip_error = std::string("configure_bank_kernels: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
   }
   {
     const char* e = getenv("RBD_ABA_STOP_AFTER");  // profiling aid only
@@ -808,7 +816,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_chain_tab, w->d_chain_cb, w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -978,13 +986,13 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   if (mapping == RBD_ALGO_ABA_BANKS && m->bank_lps == 0) return RBD_ERR_UNSUPPORTED;
   // the per-body outputs (accelerations, joint wrenches) are written by the lane-per-body kernels (one or two bodies per lane)
   const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
-  const bool can_walk = m->track.ok && m->walk.ok && !dacc && !djw && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch));
+  const bool can_walk = m->track.ok && m->walk.ok && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch));
   if (mapping == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (can_walk && (mapping == RBD_ALGO_ABA_WALK || (mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->walk_min_batch))) {
     // one wavefront per track, one lane per state (rnea_walk_kernel): large batches
     const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
-    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_walk<double>(w->wm, m->track.has_floating, m->track.general, 0, B, w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_rnea_walk<float>(w->wm, m->track.has_floating, m->track.general, pair, B, pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
+    if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_walk<double>(w->wm, m->track.has_floating, m->track.general, 0, B, w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
+    else HIP_TRY(launch_rnea_walk<float>(w->wm, m->track.has_floating, m->track.general, pair, B, pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
   } else if (!dacc && !djw && mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->state_min_batch) {  // one lane per state
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_state<double>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_rnea_state<float>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
@@ -1005,7 +1013,7 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
 static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd,
                    Layout Lq, Layout Lv, Layout Lf, const double* gravity, const MkFuse* fuse) {
   const rbd_model* m = w->model;
-  const bool can_chain = m->chain.ok && w->chain_lds_bytes > 0 && !fuse, can_bank = m->bank_lps > 0 && m->bank_aba_ok;
+  const bool can_bank = m->bank_lps > 0 && m->bank_aba_ok;
   // the track kernel addresses its batch buffers with 32-bit byte offsets
   const bool can_track = m->track.ok && w->track_lds_bytes > 0 && !fuse && (double)B * (double)std::max(std::max(m->nq, m->nv), 6 * m->nb) * 8.0 < 4.0e9;
   const bool can_walk = m->track.ok && m->walk.ok && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch)) && !fuse;
@@ -1013,19 +1021,22 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   if (algorithm == RBD_ALGO_ABA_PIPE && !can_pipe) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_TRACKS && !can_track) return RBD_ERR_UNSUPPORTED;
-  if (algorithm == RBD_ALGO_ABA_CHAINS && !can_chain) return RBD_ERR_UNSUPPORTED;
+  if (algorithm == RBD_ALGO_ABA_CHAINS) return RBD_ERR_UNSUPPORTED;  // the chain mapping of round 1 lost at every batch size and was removed
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   int pick = algorithm;
   if (algorithm == RBD_ALGO_ABA) pick = (can_pipe && B <= w->pipe_max_batch) ? RBD_ALGO_ABA_PIPE : (can_walk && B >= w->walk_min_batch) ? RBD_ALGO_ABA_WALK : (can_track && B >= w->track_min_batch) ? RBD_ALGO_ABA_TRACKS : (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
   Timed t(w);
-  w->last_kernel = pick == RBD_ALGO_ABA_TRACKS ? "aba_track_kernel" : pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : pick == RBD_ALGO_ABA_CHAINS ? "aba_chain_kernel" : "aba_kernel";
+  w->last_kernel = pick == RBD_ALGO_ABA_TRACKS ? "aba_track_kernel" : pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : "aba_kernel";
+#ifdef RBD_EXPERIMENTAL
   if (pick == RBD_ALGO_ABA_PIPE) {
     WalkModel pm = w->pm;
     if (gravity) memcpy(pm.gravity, gravity, sizeof pm.gravity);
     w->last_kernel = "aba_pipe_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_pipe<double>(pm, B, w->pipe_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba_pipe<float>(pm, B, w->pipe_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-  } else if (pick == RBD_ALGO_ABA_WALK) {
+  } else
+#endif
+  if (pick == RBD_ALGO_ABA_WALK) {
     // the tree re-rooted at its centre (rbd_reroot.hpp) when there is one: fewer steps per track, better balanced tracks (RBD_WALK_NO_REROOT=1: the original tree)
     static const bool no_rr = getenv("RBD_WALK_NO_REROOT") != nullptr;
     const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
@@ -1037,6 +1048,7 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     const size_t lds = rr ? (pair ? w->walk_rr_lds_bytes_pair : w->walk_rr_lds_bytes) : (pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes);
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, TP.has_floating, TP.general, 0, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba_walk<float>(wm, TP.has_floating, TP.general, pair, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+#ifdef RBD_EXPERIMENTAL
   } else if (pick == RBD_ALGO_ABA_TRACKS) {
     TrackModel tm = w->tm;
     if (gravity) memcpy(tm.gravity, gravity, sizeof tm.gravity);
@@ -1045,16 +1057,12 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     w->last_kernel = nw == 4 ? "aba_track_kernel (4 waves per state group)" : "aba_track_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_track<double>(tm, flt, gen, nw, B, w->track_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba_track<float>(tm, flt, gen, nw, B, w->track_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
+#endif
   } else if (pick == RBD_ALGO_ABA_BANKS) {
     BankModel bm = w->bm;
     if (gravity) memcpy(bm.gravity, gravity, sizeof bm.gravity);
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_bank<double>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
     else HIP_TRY(launch_aba_bank<float>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
-  } else if (pick == RBD_ALGO_ABA_CHAINS) {
-    ChainModel cm = w->cm;
-    if (gravity) memcpy(cm.gravity, gravity, sizeof cm.gravity);
-    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_chain<double>(cm, B, w->chain_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_aba_chain<float>(cm, B, w->chain_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
   } else {
     DevModel dm = w->dm;
     if (gravity) memcpy(dm.gravity, gravity, sizeof dm.gravity);

@@ -8,8 +8,7 @@
 // other children go through ds_bpermute — so the only HBM traffic is the algorithmic q/v/tau in,
 // vdot out.  All quantities are expressed in the ROOT frame, as in the reference
 // (src/mechanism_state.jl:744-748, :776, :842), so the backward sweeps are plain sums.
-// Two further mappings of the same sweeps: two bodies per lane (rbd_bank.hpp: BankModel) and chains of
-// the tree on a few lanes per state (rbd_chain.hpp: ChainModel).
+// A further mapping of the same sweeps: two bodies per lane (rbd_bank.hpp: BankModel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -75,25 +74,6 @@ struct DevModel {
   const int32_t* anc;       // [nb * nlevels] anc[s*nlevels + k] = k-th ancestor slot of s (k=0: s itself), -1 past the root
   uint64_t perm_down;       // bit l set: some body at level l has parent slot != s-1 (top-down hop needs ds_bpermute at level l)
   uint64_t ns_desc[4];  // child slots to gather when the bottom-up sweep processes level l (max #children of level l-1 parents): NsStream
-  double gravity[3];
-};
-
-// ---- chain-scheduled ABA (aba_chain_kernel, rbd_chain.hpp) -------------------------------------------------------------
-// G "tracks" (lanes) per state walk chains of the tree: at step s track g works on body tab[s*G + g] (or idles).  A body
-// whose parent ran on the same track at the previous step takes/gives its recursion data in registers ("chained");
-// every other edge goes through an LDS mailbox.  The plan is built on the host (rbd_chain_plan.hpp).
-enum { CB_JTYPE = 0, CB_QOFF, CB_VOFF, CB_ORIG, CB_FLAGS, CB_MBA_W, CB_MBA_R, CB_ACC_W, CB_ACC_R, CB_ROUND, CB_MBC_W, CB_MBC_R, CB_STRIDE };
-enum { CF_LEVEL0 = 1, CF_CHAINED = 2, CF_RESTART = 4, CF_CARRY = 8 };
-// stash row of a body (fields of SPW values): joint sin/cos (or prismatic displacement), U (6), 1/D, u
-enum { CS_SC = 0, CS_U = 2, CS_DINV = 8, CS_u = 9, CS_FIELDS = 10 };
-enum { MB_A_FIELDS = 18, MB_B_FIELDS = 27, MB_C_FIELDS = 24 };
-struct ChainModel {
-  int32_t nb, ns, G, spw;  // bodies, steps, tracks per state, states per wavefront (64 / G)
-  int32_t nfl, nfs;        // mailbox fields: long-lived (pass A -> pass B restarts) and shared (re-used by each pass)
-  const int32_t* tab;      // [ns * G] body slot or -1
-  const int32_t* cb;       // [nb * CB_STRIDE]
-  const void* rb;          // [nb * RB_STRIDE] (same records as DevModel::rb)
-  uint8_t nrounds[MAX_LEVELS];  // per step: sequential rounds of hand-off accumulation (siblings finishing at the same step)
   double gravity[3];
 };
 

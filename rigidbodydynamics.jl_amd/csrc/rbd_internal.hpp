@@ -37,11 +37,6 @@ hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, v
 }
 namespace rbd {
 template <typename T>
-hipError_t launch_aba_chain(const ChainModel& C, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
-                            void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
-}
-namespace rbd {
-template <typename T>
 hipError_t launch_aba_bank(const BankModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
                            Layout Lq, Layout Lv, Layout Lf, hipStream_t s, const MkFuse* fuse = nullptr);
 }
@@ -51,7 +46,6 @@ hipError_t launch_rnea_bank(const BankModel& M, long B, int ncol, const void* q,
                             Layout Lq, Layout Lv, Layout Lf, hipStream_t s, void* acc_out = nullptr, void* jw_out = nullptr);
 }
 namespace rbd {
-template <typename T> hipError_t configure_kernels(int chain_G, size_t chain_lds_bytes);
 template <typename T> hipError_t configure_bank_kernels();  // rbd_bank_kernels.hip
 }
 namespace rbd {
@@ -74,7 +68,7 @@ hipError_t launch_aba_walk(const WalkModel& M, int flt, int gen, int pair, long 
                            void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 template <typename T>
 hipError_t launch_rnea_walk(const WalkModel& M, int flt, int gen, int pair, long B, size_t lds_bytes, const void* q, const void* v, const void* vdot, const void* fext,
-                            void* tau, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+                            void* tau, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s, void* acc_out = nullptr, void* jw_out = nullptr);
 template <typename T> hipError_t configure_walk_kernel(int flt, int gen, size_t lds_bytes, size_t lds_bytes_pair);
 template <typename T>
 hipError_t launch_aba_pipe(const WalkModel& M, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,

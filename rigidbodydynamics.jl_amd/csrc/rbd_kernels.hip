@@ -5,7 +5,7 @@
 //   crba_kernel  : mass_matrix!      (:248-272)
 //   kin_kernel   : momentum_matrix!, center_of_mass, energies, geometric_jacobian!   (by-products of the FK pass)
 //   chol_*_kernel, loop_solve_kernel, mk_stage_kernel : dynamics_solve! (dense / loop-joint branch), Munthe-Kaas RK4 stage
-//   rbd_bank.hpp (aba_bank_kernel, rnea_bank_kernel) and rbd_chain.hpp (aba_chain_kernel): the other lane mappings
+//   (two bodies per lane: rbd_bank_kernels.hip; one lane per state: rbd_walk_kernels.hip, rbd_state_kernels.hip)
 // Mapping here: one lane per (state, body); level-synchronous sweeps; parent/child exchange by DPP wave
 // shifts (first child) and ds_bpermute; per-body quantities stay in VGPRs (see rbd_device.hpp).
 #include <atomic>
@@ -726,7 +726,6 @@ __global__ __launch_bounds__(256) void kin_kernel(DevModel M, long B, const T* _
 }
 
 }  // namespace rbd
-#include "rbd_chain.hpp"
 namespace rbd {
 
 // ---- launchers -----------------------------------------------------------------------------
@@ -753,44 +752,6 @@ template hipError_t launch_momentum<double>(const DevModel&, long, const void*, 
 template hipError_t launch_momentum<float>(const DevModel&, long, const void*, const void*, void*, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_kin<double>(const DevModel&, long, const void*, const void*, void*, void*, void*, void*, uint64_t, uint64_t, Layout, Layout, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_kin<float>(const DevModel&, long, const void*, const void*, void*, void*, void*, void*, uint64_t, uint64_t, Layout, Layout, Layout, Layout, Layout, hipStream_t);
-
-template <typename T, int G>
-static hipError_t launch_aba_chain_g(const ChainModel& C, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
-                                     void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
-  const long spw = 64 / G;
-  hipLaunchKernelGGL((aba_chain_kernel<T, G>), dim3((unsigned)((B + spw - 1) / spw)), dim3(64), lds_bytes, s, C, B, (const T*)q, (const T*)v,
-                     (const T*)tau, (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf);
-  return hipGetLastError();
-}
-template <typename T>
-hipError_t launch_aba_chain(const ChainModel& C, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext, void* vdot,
-                            void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
-  switch (C.G) {
-    case 1: return launch_aba_chain_g<T, 1>(C, B, lds_bytes, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
-    case 2: return launch_aba_chain_g<T, 2>(C, B, lds_bytes, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
-    case 4: return launch_aba_chain_g<T, 4>(C, B, lds_bytes, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
-    case 8: return launch_aba_chain_g<T, 8>(C, B, lds_bytes, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
-    case 16: return launch_aba_chain_g<T, 16>(C, B, lds_bytes, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-template hipError_t launch_aba_chain<double>(const ChainModel&, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
-template hipError_t launch_aba_chain<float>(const ChainModel&, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
-
-// Dynamic-LDS limits of the kernels that ask for more than the default; a function attribute of the CURRENT device, so
-// rbd_workspace_create calls this once per workspace (after hipSetDevice) rather than the launchers guessing.
-template <typename T> static hipError_t raise_chain_lds(int G, size_t bytes) {
-  const void* f = G == 1 ? (const void*)&aba_chain_kernel<T, 1> : G == 2 ? (const void*)&aba_chain_kernel<T, 2> : G == 4 ? (const void*)&aba_chain_kernel<T, 4>
-                : G == 8 ? (const void*)&aba_chain_kernel<T, 8> : (const void*)&aba_chain_kernel<T, 16>;
-  return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-template <typename T> hipError_t configure_kernels(int chain_G, size_t chain_lds_bytes) {
-  hipError_t e = configure_bank_kernels<T>();
-  if (e == hipSuccess && chain_G > 0 && chain_lds_bytes > 48 * 1024) e = raise_chain_lds<T>(chain_G, chain_lds_bytes);
-  return e;
-}
-template hipError_t configure_kernels<double>(int, size_t);
-template hipError_t configure_kernels<float>(int, size_t);
 
 template <typename T>
 hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, const void* tau, const void* fext, void* vdot,

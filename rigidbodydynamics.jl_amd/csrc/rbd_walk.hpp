@@ -541,9 +541,14 @@ RBD_HD void walk_step_b(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, i
 // f_b = I a + T ×* I T − w_ext (newton_euler!, mechanism_algorithms.jl:428-439) + Σ_children f; τ = S' f (joint_wrenches_and_torques! :442-459).
 // The hand-off is the 6-value wrench (W.cP; mailboxes use the first 6 rows of a B slot); the τ rows hold v̇ until this body overwrites its own.
 template <typename T, bool FLT, bool GEN>
-RBD_HD void walk_step_rb(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, const T* fe) {
+RBD_HD void walk_step_rb(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, int s, const WalkRec& r, const T* rr, int lane, const T* fe,
+                         T* acc_o = nullptr, T* jw_o = nullptr /* per-body outputs, 6 each: spatial acceleration, joint wrench (root frame) */) {
   if (!(r.flags & TF_VALID)) return;
   if (r.park >= 0) walk_get_park(c, r.park, lane, W);
+  if (acc_o) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc_o[k] = W.av[k];
+  }
   T f[6];
   {
     RInertia<T> I;
@@ -575,6 +580,10 @@ RBD_HD void walk_step_rb(const WalkCtx<T>& c, WalkRegs<T>& W, WalkStash<T>& St, 
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) W.cP[k] = f[k];
+  if (jw_o) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) jw_o[k] = f[k];
+  }
   if (r.b_w >= 0 || (r.flags & TF_LEVEL0)) {
     if (r.b_w >= 0) {
       T* m = walk_row(c, c.rB + r.b_w * WMB_B, lane);
@@ -1074,7 +1083,10 @@ template <typename T, bool FLT, bool GEN>
 __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v,
                                                       const typename Lanes<T>::S* __restrict__ vdot, const typename Lanes<T>::S* __restrict__ fext,
                                                       typename Lanes<T>::S* __restrict__ tau, typename Lanes<T>::S* __restrict__ qdot, Layout Lq, Layout Lv,
-                                                      Layout Lf) {
+                                                      Layout Lf, typename Lanes<T>::S* __restrict__ acc_out, typename Lanes<T>::S* __restrict__ jw_out) {
+  // acc_out / jw_out (nullable): accelerations[body] and jointwrenches[body] of inverse_dynamics! / dynamics_bias! (spatial_accelerations!
+  // src/mechanism_algorithms.jl:387-417, joint_wrenches_and_torques! :442-459), 6 x n_bodies per state in the layout of fext, root frame.  Both are
+  // in registers when pass B reaches the body (its acceleration restored, its wrench summed): written from there, nothing is recomputed.
   using S = typename Lanes<T>::S;
   constexpr int N = Lanes<T>::N;
   extern __shared__ __align__(16) unsigned char walk_lds_raw[];
@@ -1183,7 +1195,29 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
       walk_consts<T, TR_STRIDE>(c, s, g, rr);
       raw = walk_raw(c, s1, g);
       if (fext) wrench(walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff, fn);
-      walk_step_rb<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe);
+      if (acc_out != nullptr || jw_out != nullptr) {  // uniform
+        T ao[6], jo[6];
+        walk_step_rb<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe, ao, jo);
+        if (r.flags & TF_VALID) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const long st = state0 + 64 * j + lane;
+            if (st < B) {
+#pragma unroll
+              for (int k = 0; k < 6; ++k) {
+                const long a = (long)(r.orig6 + k) * fsk + st * Lf.sb;
+                S av, jv;
+                if constexpr (N == 1) { av = ao[k]; jv = jo[k]; }
+                else { av = j == 0 ? ao[k].x : ao[k].y; jv = j == 0 ? jo[k].x : jo[k].y; }
+                if (acc_out) acc_out[a] = av;
+                if (jw_out) jw_out[a] = jv;
+              }
+            }
+          }
+        }
+      } else {
+        walk_step_rb<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe);
+      }
 #pragma unroll
       for (int k = 0; k < 6; ++k) fe[k] = fn[k];
       if ((M.sfm[3] >> s) & 1) __syncthreads();  // SF_BW: a hand-off left its track at this step

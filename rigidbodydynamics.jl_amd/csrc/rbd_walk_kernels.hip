@@ -10,22 +10,22 @@ namespace rbd {
 // RNEA: rnea_walk_kernel (x = v̇ in, y = τ out) instead of aba_walk_kernel (x = τ in, y = v̇ out)
 template <typename T, bool FLT, bool GEN, bool RNEA>
 static hipError_t launch_walk_fg(const WalkModel& M, long B, size_t lds, const void* q, const void* v, const void* x, const void* fext, void* y, void* qdot,
-                                 Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+                                 Layout Lq, Layout Lv, Layout Lf, hipStream_t s, void* acc_out = nullptr, void* jw_out = nullptr) {
   using S = typename Lanes<T>::S;
   constexpr int SPW = 64 * Lanes<T>::N;
   const unsigned grid = (unsigned)((B + SPW - 1) / SPW);
-  if (RNEA) rnea_walk_kernel<T, FLT, GEN><<<grid, 64 * M.G, lds, s>>>(M, B, (const S*)q, (const S*)v, (const S*)x, (const S*)fext, (S*)y, (S*)qdot, Lq, Lv, Lf);
+  if (RNEA) rnea_walk_kernel<T, FLT, GEN><<<grid, 64 * M.G, lds, s>>>(M, B, (const S*)q, (const S*)v, (const S*)x, (const S*)fext, (S*)y, (S*)qdot, Lq, Lv, Lf, (S*)acc_out, (S*)jw_out);
   else if (FLT && M.reroot.nchain > 0) aba_walk_kernel<T, FLT, GEN, FLT><<<grid, 64 * M.G, lds, s>>>(M, B, (const S*)q, (const S*)v, (const S*)x, (const S*)fext, (S*)y, (S*)qdot, Lq, Lv, Lf);
   else aba_walk_kernel<T, FLT, GEN><<<grid, 64 * M.G, lds, s>>>(M, B, (const S*)q, (const S*)v, (const S*)x, (const S*)fext, (S*)y, (S*)qdot, Lq, Lv, Lf);
   return hipGetLastError();
 }
 template <typename T, bool RNEA>
 static hipError_t launch_walk_t(const WalkModel& M, int flt, int gen, long B, size_t lds, const void* q, const void* v, const void* x, const void* fext, void* y,
-                                void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
-  if (flt) return gen ? launch_walk_fg<T, true, true, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s)
-                      : launch_walk_fg<T, true, false, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s);
-  return gen ? launch_walk_fg<T, false, true, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s)
-             : launch_walk_fg<T, false, false, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s);
+                                void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s, void* acc_out = nullptr, void* jw_out = nullptr) {
+  if (flt) return gen ? launch_walk_fg<T, true, true, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s, acc_out, jw_out)
+                      : launch_walk_fg<T, true, false, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s, acc_out, jw_out);
+  return gen ? launch_walk_fg<T, false, true, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s, acc_out, jw_out)
+             : launch_walk_fg<T, false, false, RNEA>(M, B, lds, q, v, x, fext, y, qdot, Lq, Lv, Lf, s, acc_out, jw_out);
 }
 // pair: (fp32 only) two states per lane
 template <typename T>
@@ -38,16 +38,16 @@ hipError_t launch_aba_walk(const WalkModel& M, int flt, int gen, int pair, long 
 }
 template <typename T>
 hipError_t launch_rnea_walk(const WalkModel& M, int flt, int gen, int pair, long B, size_t lds, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
-                            void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+                            void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s, void* acc_out, void* jw_out) {
   if constexpr (sizeof(T) == 4) {
-    if (pair) return launch_walk_t<f2, true>(M, flt, gen, B, lds, q, v, vdot, fext, tau, qdot, Lq, Lv, Lf, s);
+    if (pair) return launch_walk_t<f2, true>(M, flt, gen, B, lds, q, v, vdot, fext, tau, qdot, Lq, Lv, Lf, s, acc_out, jw_out);
   }
-  return launch_walk_t<T, true>(M, flt, gen, B, lds, q, v, vdot, fext, tau, qdot, Lq, Lv, Lf, s);
+  return launch_walk_t<T, true>(M, flt, gen, B, lds, q, v, vdot, fext, tau, qdot, Lq, Lv, Lf, s, acc_out, jw_out);
 }
 template hipError_t launch_aba_walk<double>(const WalkModel&, int, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
 template hipError_t launch_aba_walk<float>(const WalkModel&, int, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
-template hipError_t launch_rnea_walk<double>(const WalkModel&, int, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
-template hipError_t launch_rnea_walk<float>(const WalkModel&, int, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_rnea_walk<double>(const WalkModel&, int, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t, void*, void*);
+template hipError_t launch_rnea_walk<float>(const WalkModel&, int, int, int, long, size_t, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t, void*, void*);
 
 // dynamic LDS above the 64 KB default needs the per-function limit raised (per device; done at workspace creation)
 template <typename T, bool FLT, bool GEN> static hipError_t set_walk_lds(size_t lds) {

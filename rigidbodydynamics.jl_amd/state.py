@@ -492,8 +492,13 @@ def gravitational_potential_energy(state: MechanismState) -> torch.Tensor:
     return e[:, 1] if state.layout == "aos" else e[1]
 
 
+def experimental():
+    """True when the library carries the two experimental lane mappings (`aba_tracks`, `aba_pipe`; csrc/build.sh RBD_EXPERIMENTAL=1)."""
+    return bool(_capi.lib().rbd_experimental())
+
+
 def chain_plan(flat):
-    """The chain-scheduled ABA plan of a mechanism (host-side introspection of `rbd_model_chain_plan`): dict with `tracks`,
+    """The chain schedule under the track / walk plans of a mechanism (host-side introspection of `rbd_model_chain_plan`): dict with `tracks`,
     `steps`, `lds_fields` and `table` (steps × tracks array of body indices, -1 = idle); None when the mechanism is outside
     that mapping's scope."""
     import numpy as np

@@ -18,10 +18,14 @@ state = rbd.MechanismState(model, B, dtype=tdt); result = rbd.DynamicsResult(mod
 rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng)); rbd.set_velocity_(state, rbd.rand_velocity(model, B, rng))
 tau = torch.rand(B, model.nv, dtype=tdt, device="cuda"); out = torch.zeros_like(tau)
 Abuf = torch.zeros(B, 6 * model.nv, dtype=tdt, device="cuda")
+jwbuf = torch.zeros(B, 6 * model.n_bodies, dtype=tdt, device="cuda"); accbuf = torch.zeros_like(jwbuf)
+result_b = rbd.DynamicsResult(model, B, dtype=tdt, bodies=True)
 ops = {
     "dynamics! (ABA)": lambda: rbd.dynamics_(result, state, tau),
     "dynamics! (CRBA+Cholesky route)": lambda: rbd.dynamics_(result, state, tau, algorithm="crba"),
     "inverse_dynamics!": lambda: rbd.inverse_dynamics_(out, state, tau),
+    "inverse_dynamics! with jointwrenches + accelerations (the reference benchmark's call)": lambda: rbd.inverse_dynamics_(out, state, tau, jointwrenchesout=jwbuf, accelerations=accbuf),
+    "dynamics! into a DynamicsResult with per-body fields": lambda: rbd.dynamics_(result_b, state, tau),
     "dynamics_bias!": lambda: rbd.dynamics_bias_(result, state),
     "mass_matrix!": lambda: rbd.mass_matrix_(result, state),
     "mass_matrix! + Cholesky solve": lambda: rbd.mass_matrix_solve_(out, state, tau, result.massmatrix),

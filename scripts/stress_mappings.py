@@ -8,7 +8,7 @@ from test_chain_plan import random_tree
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(2024)
 worst = {}
-skipped = {"aba_banks": 0, "aba_chains": 0, "aba_tracks": 0, "aba_walk": 0, "aba_pipe": 0}
+skipped = {"aba_banks": 0, "aba_tracks": 0, "aba_walk": 0, "aba_pipe": 0}
 for trial in range(N):
     n = int(rng.integers(1, 45))
     mech = random_tree(rbd, rng, n, bool(rng.integers(2)), float(rng.uniform(0, 1)))
@@ -29,7 +29,7 @@ for trial in range(N):
     rbd.set_configuration_(state, q); rbd.set_velocity_(state, v)
     ref = oracle.dynamics(model, q, v, tau, fe)
     t, f = torch.as_tensor(tau).cuda(), torch.as_tensor(fe).cuda()
-    for algo in ("aba_lanes", "aba_banks", "aba_chains", "aba_tracks", "aba_walk", "aba_pipe"):
+    for algo in ("aba_lanes", "aba_banks", "aba_walk") + (("aba_tracks", "aba_pipe") if rbd.experimental() else ()):
         try:
             rbd.dynamics_(res, state, t, f, algorithm=algo)
         except Exception:

@@ -688,13 +688,22 @@ def test_kinematics_byproducts_f32_and_full_size(rbd, oracle, models):
 
 # ---- chain-scheduled ABA (RBD_ALGO_ABA_CHAINS): the same dynamics! through the other lane mapping -------------------------
 CHAIN_MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf"]
+# the lane mappings of the fused ABA beside one body per lane.  aba_tracks / aba_pipe exist only in an RBD_EXPERIMENTAL=1 build (csrc/build.sh):
+# they lost to the banked / walk kernels at every batch size; the round-1 chain mapping was removed.
+MAPPINGS = ["aba_walk", "aba_banks", "aba_tracks"]
+
+
+def need(rbd, algorithm):
+    if algorithm in ("aba_tracks", "aba_pipe") and not rbd.experimental():
+        pytest.skip(f"{algorithm}: RBD_EXPERIMENTAL build only")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algorithm", ["aba_walk", "aba_tracks", "aba_chains", "aba_banks"])
+@pytest.mark.parametrize("algorithm", MAPPINGS)
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("name", CHAIN_MODELS)
 def test_dynamics_chains_f64(rbd, oracle, models, name, layout, algorithm):
+    need(rbd, algorithm)
     model = models[name]
     B = 67  # ragged against every states-per-wave (64, 32, 16, 4)
     state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 41)
@@ -714,9 +723,10 @@ def test_dynamics_chains_f64(rbd, oracle, models, name, layout, algorithm):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algorithm", ["aba_walk", "aba_tracks", "aba_chains", "aba_banks"])
+@pytest.mark.parametrize("algorithm", MAPPINGS)
 @pytest.mark.parametrize("B", [1, 3, 4, 5, 15, 16, 17, 1000])
 def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B, algorithm):
+    need(rbd, algorithm)
     model = models["atlas_floating"]
     state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 42 + B)
     result = rbd.DynamicsResult(model, B)
@@ -733,10 +743,11 @@ def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B, algorithm):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algorithm", ["aba_walk", "aba_tracks", "aba_chains", "aba_banks"])
+@pytest.mark.parametrize("algorithm", MAPPINGS)
 def test_dynamics_chains_random_trees(rbd, oracle, algorithm):
     """Random revolute / prismatic / fixed / sin-cos trees (with and without a floating root), as the reference's randomized tests do."""
     from test_chain_plan import random_tree
+    need(rbd, algorithm)
     rng = np.random.default_rng(9)
     for trial in range(12):
         mech = random_tree(rbd, rng, int(rng.integers(1, 30)), bool(trial % 2), float(rng.uniform(0, 1)))
@@ -759,11 +770,13 @@ def test_dynamics_chains_random_trees(rbd, oracle, algorithm):
 
 @pytest.mark.gpu
 def test_dynamics_chains_scope_and_auto_selection(rbd, oracle, models):
-    model = models["randmech1"]  # has 3-dof joints: outside the chain mapping
+    model = models["randmech1"]  # has 3-dof joints: outside the walk mapping
     state, *_ = make(rbd, model, 8, "f64", "aos", 60)
     result = rbd.DynamicsResult(model, 8)
     with pytest.raises(Exception):
-        rbd.dynamics_(result, state, algorithm="aba_chains")
+        rbd.dynamics_(result, state, algorithm="aba_walk")
+    with pytest.raises(Exception):
+        rbd.dynamics_(result, state, algorithm="aba_chains")  # the removed round-1 mapping: RBD_ERR_UNSUPPORTED
     rbd.dynamics_(result, state)  # default still works (lanes)
     # full size: both mappings agree with each other and the dynamics! -> inverse_dynamics round trip closes
     # (test/test_mechanism_algorithms.jl:729-740); at this size the default (RBD_ALGO_ABA) picks the banked mapping
@@ -772,7 +785,7 @@ def test_dynamics_chains_scope_and_auto_selection(rbd, oracle, models):
     state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 61)
     r0, r1 = rbd.DynamicsResult(model, B), rbd.DynamicsResult(model, B)
     t = dev(tau, state)
-    rbd.dynamics_(r0, state, t, algorithm="aba_chains")
+    rbd.dynamics_(r0, state, t, algorithm="aba_walk")
     rbd.dynamics_(r1, state, t, algorithm="aba_lanes")
     assert float((r0.vd - r1.vd).abs().max()) <= 1e-9 * float(r1.vd.abs().max())
     back = torch.zeros_like(t)
@@ -956,7 +969,7 @@ def test_batch_states_are_isolated_from_a_nan_state(rbd, models, name, dtype):
     B = 37
     state, q, v, tau, fe = make(rbd, model, B, dtype, "aos", 123)
     t, f = dev(tau, state), dev(fe, state)
-    algos = ["aba_lanes"] + [a for a in ("aba_banks", "aba_chains", "aba_tracks", "aba_walk") if name != "randmech1" and (a != "aba_banks" or rbd.bank_plan(model))]
+    algos = ["aba_lanes"] + [a for a in ("aba_banks", "aba_walk") + (("aba_tracks",) if rbd.experimental() else ()) if name != "randmech1" and (a != "aba_banks" or rbd.bank_plan(model))]
 
     def run_all():
         out = {}
@@ -1017,6 +1030,34 @@ def test_per_body_outputs_of_inverse_dynamics_and_dynamics_f64(rbd, oracle, mode
     result = rbd.DynamicsResult(model, B, layout=layout, bodies=True)
     rbd.dynamics_(result, state)  # no external wrenches: totalwrenches are zero
     assert float(result.totalwrenches.abs().max()) == 0.0 if nb else True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("mapping", ["lanes", "banks", "walk"])
+def test_per_body_outputs_from_every_mapping(rbd, oracle, models, mapping, dtype):
+    """inverse_dynamics!(τ, jointwrenches, accelerations, …) — the call the reference's own benchmark makes (perf/runbenchmarks.jl:49-57) — from the
+    one-body-per-lane, two-bodies-per-lane and walk kernels (fp32: two states per lane), ragged batches, with and without v̇ / wrenches."""
+    model = models["atlas_floating"]
+    nb = model.n_bodies
+    for B, layout in ((131, "aos"), (259, "soa")):
+        state, q, v, vd, fe = make(rbd, model, B, dtype, layout, 140 + B)
+        tau = torch.zeros_like(state.v)
+        jw = torch.full_like(dev(fe, state), float("nan"))
+        acc = torch.full_like(jw, float("nan"))
+        rbd.inverse_dynamics_(tau, state, dev(vd, state), dev(fe, state), mapping=mapping, jointwrenchesout=jw, accelerations=acc)
+        t_ref, jw_ref, acc_ref = oracle.inverse_dynamics_bodies(model, q, v, vd, fe)
+        rt = 1e-10 if dtype == "f64" else 2e-4
+        tol = lambda r: rt * max(1.0, np.abs(r).max())
+        assert np.abs(host(tau, state) - t_ref).max() <= tol(t_ref)
+        assert np.abs(host(jw, state).reshape(B, nb, 6) - jw_ref).max() <= tol(jw_ref)
+        assert np.abs(host(acc, state).reshape(B, nb, 6) - acc_ref).max() <= tol(acc_ref)
+        # only one of the two, no v̇ (dynamics_bias!), no wrenches
+        acc2 = torch.full_like(jw, float("nan"))
+        rbd.inverse_dynamics_(tau, state, torch.zeros_like(state.v), None, mapping=mapping, accelerations=acc2)
+        t_ref, jw_ref, acc_ref = oracle.inverse_dynamics_bodies(model, q, v, None, None)
+        assert np.abs(host(tau, state) - t_ref).max() <= tol(t_ref)
+        assert np.abs(host(acc2, state).reshape(B, nb, 6) - acc_ref).max() <= tol(acc_ref)
 
 
 @pytest.mark.gpu
@@ -1161,6 +1202,7 @@ def test_inverse_dynamics_walk_full_size_and_pairs(rbd, oracle, models, monkeypa
 def test_dynamics_pipe_f64(rbd, oracle, models, name, layout):
     """aba_pipe_kernel (a body-step cut into stages on the four SIMDs of a compute unit, 16 states x 4 tracks per wavefront), forced: ragged batch,
     torques + a wrench on every body + q̇; then no torques / no wrenches; fp64 at the reference's 1e-10."""
+    need(rbd, "aba_pipe")
     model = models[name]
     B = 4096 + 5
     state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 93)
@@ -1182,6 +1224,7 @@ def test_dynamics_pipe_f64(rbd, oracle, models, name, layout):
 @pytest.mark.gpu
 def test_dynamics_pipe_f32_and_scope(rbd, oracle, models):
     """fp32: backward error of M v̇ = τ − c on every state; mechanisms outside the mapping's scope (prismatic / fixed / 3-dof joints) are refused, not mis-evaluated."""
+    need(rbd, "aba_pipe")
     model = models["atlas_floating"]
     B = 1000
     state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 94)
