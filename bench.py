@@ -46,6 +46,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X public spec (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 FP32_VECTOR_PEAK_TF = 157.3
 ABA_FLOPS_PER_EVAL = 27.0e3  # fused world-frame ABA, Atlas floating
+KERNELS = {"inverse_dynamics": "rnea_bank_kernel (<= one resident round of workgroups) / rnea_walk_kernel", "mass_matrix_solve": "crba_state_kernel + chol_mfma_kernel"}
 CONFIGS = {
     2: dict(model="atlas_floating", batch=4096, dtype="f64", op="dynamics", label="BASELINE configs[1]"),
     3: dict(model="atlas_floating", batch=65536, dtype="f32", op="mass_matrix_solve", label="BASELINE configs[2]"),
@@ -55,7 +56,7 @@ CONFIGS = {
 
 
 def kernel_source_hash():
-    """Identifies the kernel sources a PMC traffic figure was measured on (profiles/r02_pmc_traffic.json records it)."""
+    """Identifies the kernel sources a PMC traffic figure was measured on (profiles/r03_pmc_traffic.json records it)."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "rigidbodydynamics.jl_amd", "csrc")
     for f in sorted(os.listdir(d)):
@@ -90,6 +91,7 @@ def parse_args():
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra (informational) measurement of two independent batches issued on two HIP streams")
     ap.add_argument("--wrenches", action="store_true", help="headline WITH a random external wrench on every body (reported next to it otherwise)")
+    ap.add_argument("--no-other-configs", action="store_true", help="headline only: skip the config3 / config4_shard / config5 / inverse_dynamics blocks")
     ap.add_argument("--selftest-launch", action="store_true", help="only exercise the N-rank launcher (gloo on CPU): prints the world size the ranks saw")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -97,6 +99,7 @@ def parse_args():
     args.batch = args.batch or cfg["batch"]
     args.dtype = args.dtype or cfg["dtype"]
     args.op = cfg["op"]
+    args.no_extra_legs = False
     if args.steps is None:
         args.steps = 2000 if args.batch <= 8192 else 200
     if args.warmup is None:
@@ -131,11 +134,8 @@ def selftest_launch(args):
     dist.destroy_process_group()
 
 
-def main():
-    args = parse_args()
-    maybe_spawn(args)
-    if args.selftest_launch:
-        return selftest_launch(args)
+def setup(args):
+    """Process-wide state: distributed init (one rank per GPU over RCCL), device, the library."""
     import numpy as np
     import torch
 
@@ -154,10 +154,16 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
-
     import rbd_amd as rbd
     from rigidbodydynamics_jl_amd import _capi
     import oracle
+    return dict(np=np, torch=torch, world=world, rank=rank, dist=dist, device=device, rbd=rbd, _capi=_capi, oracle=oracle)
+
+
+def run(args, env):
+    """One BASELINE config: W warm-up steps, K timed steps, whole-batch parity against the oracle; returns the JSON line as a dict (rank 0) or None."""
+    np, torch, world, rank, dist, device = env["np"], env["torch"], env["world"], env["rank"], env["dist"], env["device"]
+    rbd, _capi, oracle = env["rbd"], env["_capi"], env["oracle"]
 
     if args.model == "four_bar":
         model = rbd.flatten(rbd.four_bar_linkage())
@@ -206,6 +212,11 @@ def main():
             opts = st._opts(_capi.ALGO_CRBA_CHOLESKY)
             c_args = (st.ws.handle, B, vp(st.q.data_ptr()), vp(d_tau.data_ptr()), vp(out.data_ptr()), vp(res.massmatrix.data_ptr()), ctypes.byref(opts))
             fn, name = L.rbd_mass_matrix_solve, "rbd_mass_matrix_solve"
+        elif args.op == "inverse_dynamics":  # the RNEA half of BASELINE configs[1]: v̇ ~ U[0,1) (the `tau` draw) in, τ out
+            opts = st._opts(0)
+            c_args = (st.ws.handle, B, vp(st.q.data_ptr()), vp(st.v.data_ptr()), vp(d_tau.data_ptr()), vp(d_fext.data_ptr() if with_fext else 0),
+                      vp(out.data_ptr()), ctypes.byref(opts))
+            fn, name = L.rbd_inverse_dynamics, "rbd_inverse_dynamics"
         else:
             opts = st._opts(algo_id)
             lam = res.lambda_.data_ptr() if model.nc > 0 else 0
@@ -287,6 +298,12 @@ def main():
                  "forward_err_rel_max": float(np.abs(got_x - xref).max() / np.abs(xref).max())}
         err = max(err_M, berr)
         tol = 1e-10 if args.dtype == "f64" else 2e-5
+    elif args.op == "inverse_dynamics":
+        ref = oracle.inverse_dynamics(model, qf, vf, tf, ff, nthreads=ncores)
+        got = (x_out if args.layout == "aos" else x_out.t()).double().cpu().numpy()
+        err = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+        check = {"states_compared": B}
+        tol = 1e-10 if args.dtype == "f64" else 2e-4
     elif model.nc > 0:
         n = min(B, 1024)  # the loop-joint oracle is one state per call
         ref = oracle.dynamics_loops(model, qf[:n], vf[:n], tf[:n], ff[:n] if ff is not None else None)["vdot"]
@@ -329,7 +346,7 @@ def main():
         except Exception as e:  # the gather is outside the headline's timed region: never lose the measurement to it
             gather_ms = f"failed: {type(e).__name__}: {e}"
 
-    if args.op == "dynamics" and model.nc == 0 and world == 1:
+    if args.op == "dynamics" and model.nc == 0 and world == 1 and not args.no_extra_legs:
         # the same K steps with / without a random external wrench on every body, so that the line carries both
         try:
             w2, k2 = timed(make_step(not headline_fext), False)
@@ -337,7 +354,7 @@ def main():
                 "value": B * args.steps / w2, "unit": "evals/s", "ms_per_step": w2 / args.steps * 1e3, "kernel_ms": k2}
         except Exception as e:
             extra["with_external_wrenches"] = f"failed: {type(e).__name__}: {e}"
-    if world == 1 and not args.graph:
+    if world == 1 and not args.graph and not args.no_extra_legs:
         # informational: the same K steps captured once in a hipGraph and replayed (what a caller with a fixed step loop would do); `value` stays
         # the plain stream-launch figure
         try:
@@ -347,9 +364,7 @@ def main():
             extra["hip_graph_replay"] = f"failed: {type(e).__name__}: {e}"
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
     evals = world * B * args.steps
     value = evals / wall
@@ -358,6 +373,11 @@ def main():
         flops = 5.8e3 + 18.2e3
         metric = "mass_matrix! + Cholesky solves/sec (Atlas 30-DoF, batch)"
         opname = f"{args.dtype} mass_matrix! + Cholesky solve"
+    elif args.op == "inverse_dynamics":
+        alg_bytes = es * (model.nq + 3 * model.nv)  # q, v, v̇ in; τ out
+        flops = 18.6e3
+        metric = "inverse_dynamics! evals/sec (Atlas 30-DoF, batch)"
+        opname = f"{args.dtype} inverse_dynamics! (RNEA)"
     else:
         alg_bytes = es * (model.nq + 3 * model.nv + model.nq + (model.nc if model.nc else 0))  # q, v, τ in; v̇ and q̇ out (+ λ)
         if headline_fext:
@@ -372,7 +392,7 @@ def main():
     # HBM traffic from the PMC passes (scripts/gpu_profile.sh writes it with the hash of the kernel sources it was measured on):
     # a figure from other sources is not passed along
     traffic, traffic_stale = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
@@ -393,8 +413,8 @@ def main():
                    "gather_every_step": bool(args.gather_every_step and world > 1), "inputs": "resident in HBM, re-evaluated every step (L2 / Infinity-Cache hits)"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
-                     "kernel": (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode() if model.nc == 0 else
-                     "rnea_kernel + crba_kernel + loop_solve_small_kernel",
+                     "kernel": KERNELS.get(args.op) or ((L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode() if model.nc == 0 else
+                                                        "rnea_kernel + crba_kernel + loop_solve_small_kernel"),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": alg_bytes},
         "alu": {"bound": "fp64 vector ALU" if args.dtype == "f64" else "fp32 vector ALU", "achieved": achieved_tf, "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": achieved_tf / peak_tf, "flops_per_eval": flops,
@@ -475,9 +495,62 @@ def main():
                       f"{t1t * 1e6:.2f} us/eval = {1.0 / t1t:.3e} evals/s",
             "single_thread_us_per_eval": t1t * 1e6,
         }
-    print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
+
+
+def sub_args(args, config, **over):
+    """The arguments of another BASELINE config run inside this process (short: it rides on the headline's line)."""
+    import copy
+    a = copy.copy(args)
+    cfg = CONFIGS[config]
+    a.config, a.model, a.batch, a.dtype, a.op = config, cfg["model"], cfg["batch"], cfg["dtype"], cfg["op"]
+    a.steps, a.warmup = (200, 20) if a.batch <= 8192 else (40, 8)
+    a.no_cpu_baseline = a.no_pipelined = a.no_extra_legs = True
+    a.wrenches = a.graph = False
+    a.algorithm = "aba"
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def block(d):
+    """What of a config's line rides along under the headline: rate, times, roofline, parity."""
+    if d is None:
+        return None
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "alu", "parity_rel_err_vs_oracle", "parity_check",
+            "rccl_all_gather_vdot_ms", "with_gather_every_step")
+    o = {k: d[k] for k in keep if k in d}
+    o["workload"] = d["config"]["workload"]
+    return o
+
+
+def main():
+    args = parse_args()
+    maybe_spawn(args)
+    if args.selftest_launch:
+        return selftest_launch(args)
+    env = setup(args)
+    out = run(args, env)
+    headline = args.config == 2 and not args.no_other_configs and args.batch == CONFIGS[2]["batch"] and args.dtype == CONFIGS[2]["dtype"]
+    if headline:
+        # The other BASELINE configs ride on the driver's line (round-2 review): each with its own ms_per_step, roofline and whole-batch parity;
+        # `value` stays configs[1].  N > 1: only configs[3] (the sharded one) — with the RCCL gather outside and inside the timed region.
+        extra = {}
+        todo = [("config4_shard", sub_args(args, 4))]
+        if env["world"] == 1:
+            todo = [("inverse_dynamics", sub_args(args, 2, op="inverse_dynamics")), ("config3", sub_args(args, 3)), ("config4_shard", sub_args(args, 4)),
+                    ("config5", sub_args(args, 5))]
+        for name, a in todo:
+            try:
+                extra[name] = block(run(a, env))
+            except Exception as e:  # never lose the headline to a rider
+                extra[name] = f"failed: {type(e).__name__}: {e}"
+        if out is not None:
+            out.update(extra)
+    if out is not None:
+        print(json.dumps(out))
+    if env["dist"] is not None:
+        env["dist"].destroy_process_group()
 
 
 if __name__ == "__main__":

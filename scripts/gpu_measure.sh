@@ -1,12 +1,12 @@
 #!/bin/bash
 # ONE measurement pass for the build that is in the tree (run on the GPU box: gpurun --timeout 1500 -- 'bash scripts/gpu_measure.sh [configs]'):
 #   for every BASELINE config asked for (default "2 3 4 5")
-#     1. rocprofv3 --kernel-trace --stats of `bench.py --config C`      -> profiles/r02_kernel_stats_cC.csv
+#     1. rocprofv3 --kernel-trace --stats of `bench.py --config C`      -> profiles/r03_kernel_stats_cC.csv
 #     2. rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate passes, then two SQ passes; no trace domains mixed in)
-#                                                                       -> profiles/r02_pmc_cC.txt and one entry of profiles/r02_pmc_traffic.json
+#                                                                       -> profiles/r03_pmc_cC.txt and one entry of profiles/r03_pmc_traffic.json
 #     3. `bench.py --config C` (the line the driver would record, now carrying roofline.traffic measured on THESE sources)
-#                                                                       -> profiles/r02_bench_cC.json
-# profiles/r02_pmc_traffic.json records bench.kernel_source_hash(); bench.py ignores the file when the sources have changed since.
+#                                                                       -> profiles/r03_bench_cC.json
+# profiles/r03_pmc_traffic.json records bench.kernel_source_hash(); bench.py ignores the file when the sources have changed since.
 # Everything is also copied to gpurun_out/profiles/ so that it comes back from the box; copy it from there into profiles/ and commit.
 CONFIGS=${*:-2 3 4 5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -24,12 +24,12 @@ done
 cd $R
 python scripts/summarize_measure.py $CONFIGS
 for C in $CONFIGS; do
-  python bench.py --config $C > profiles/r02_bench_c$C.json 2> $OUT/bench_c$C.err
-  tail -c 600 profiles/r02_bench_c$C.json | head -c 0
+  python bench.py --config $C > profiles/r03_bench_c$C.json 2> $OUT/bench_c$C.err
+  tail -c 600 profiles/r03_bench_c$C.json | head -c 0
   python - <<PY
 import json
-d = json.load(open("profiles/r02_bench_c$C.json"))
+d = json.load(open("profiles/r03_bench_c$C.json"))
 print("config $C:", d["value"], d["unit"], "ms/step", round(d["ms_per_step"], 4), "kernel_ms", d["roofline"]["kernel_ms"], "traffic", d["roofline"]["traffic"], "stale", d["roofline"]["traffic_stale"])
 PY
 done
-cp profiles/r02_kernel_stats_c*.csv profiles/r02_pmc_c*.txt profiles/r02_pmc_traffic.json profiles/r02_bench_c*.json gpurun_out/profiles/ 2>/dev/null
+cp profiles/r03_kernel_stats_c*.csv profiles/r03_pmc_c*.txt profiles/r03_pmc_traffic.json profiles/r03_bench_c*.json gpurun_out/profiles/ 2>/dev/null

@@ -1,6 +1,6 @@
 """Condenses what scripts/gpu_measure.sh collected under gpurun_out/measure into the files that are committed under profiles/:
-r02_kernel_stats_c<C>.csv (rocprofv3 --kernel-trace --stats, our kernels), r02_pmc_c<C>.txt (PMC per launch and per wavefront) and
-r02_pmc_traffic.json (HBM bytes per step from FETCH_SIZE / WRITE_SIZE, keyed like bench.py looks it up, with the kernel-source hash)."""
+r03_kernel_stats_c<C>.csv (rocprofv3 --kernel-trace --stats, our kernels), r03_pmc_c<C>.txt (PMC per launch and per wavefront) and
+r03_pmc_traffic.json (HBM bytes per step from FETCH_SIZE / WRITE_SIZE, keyed like bench.py looks it up, with the kernel-source hash)."""
 import collections
 import csv
 import glob
@@ -37,7 +37,7 @@ def pmc(dirname):
 
 def main():
     configs = [int(c) for c in sys.argv[1:]] or [2, 3, 4, 5]
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     h = bench.kernel_source_hash()
     rec = {}
     if os.path.exists(path):
@@ -57,7 +57,7 @@ def main():
         rows = []
         for f in glob.glob(os.path.join(OUT, f"stats_c{C}", "**", "*kernel_stats.csv"), recursive=True):
             rows += list(csv.DictReader(open(f)))
-        with open(os.path.join(ROOT, "profiles", f"r02_kernel_stats_c{C}.csv"), "w") as fo:
+        with open(os.path.join(ROOT, "profiles", f"r03_kernel_stats_c{C}.csv"), "w") as fo:
             fo.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {C} --no-cpu-baseline --no-pipelined --steps 60 --warmup 10 ; sources {h}\n")
             fo.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
             for r in rows:
@@ -71,7 +71,7 @@ def main():
             sq.setdefault(k, {}).update(d)
         step_kernels = [k for k, n in calls.items() if k.startswith(OURS) and n >= 60]
         total, detail = 0.0, {}
-        with open(os.path.join(ROOT, "profiles", f"r02_pmc_c{C}.txt"), "w") as fo:
+        with open(os.path.join(ROOT, "profiles", f"r03_pmc_c{C}.txt"), "w") as fo:
             fo.write(f"# config {C}: {key}; sources {h}; rocprofv3 --pmc (scripts/gpu_measure.sh); per launch, averaged over the launches of the run\n")
             for k in sorted(set(fetch) | set(write) | set(sq)):
                 fr = fetch.get(k, {}).get("FETCH_SIZE", (0.0, 0))[0] * 1024
