@@ -204,6 +204,9 @@ int rbd_sync(rbd_ws_t* ws);
  * fext[6*n_bodies×B] external wrench on each moving body in the ROOT frame,
  * (torque; force) (NULL => none, like NullDict); outputs vdot[nv×B],
  * qdot[nq×B] (nullable), lambda[nc×B] (nullable).                              */
+/* Mechanisms WITH contact points and an environment: rbd_dynamics / rbd_simulate / rbd_mk_stage return RBD_ERR_UNSUPPORTED — the reference's
+ * dynamics! always adds the contact wrenches (src/mechanism_algorithms.jl:849-856), which needs the additional state: use
+ * rbd_dynamics_contact / rbd_simulate_contact. */
 int rbd_dynamics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, const void* tau,
                  const void* fext, void* vdot, void* qdot, void* lambda, const rbd_opts_t* opts);
 

@@ -134,7 +134,11 @@ mutable struct FlatModelHandle
     bodyids::Dict{BodyID, Int32}
 end
 
+const HEADER_VERSION = 300    # RBD_HIP_H_VERSION of the include/rbd_hip.h these structs mirror (rbd_flat_model_t grew its contact fields at 200)
+
 function FlatModelHandle(mechanism::Mechanism)
+    ccall((:rbd_version, librbd_hip[]), Cint, ()) == HEADER_VERSION ||
+        error("librbd_hip.so reports another header version than this shim was written for ($HEADER_VERSION): struct layouts may differ")
     tj = collect(tree_joints(mechanism))
     nb = length(tj)
     bodyindex = Dict(successor(j, mechanism) => Int32(i - 1) for (i, j) in enumerate(tj))

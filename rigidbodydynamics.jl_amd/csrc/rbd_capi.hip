@@ -1150,6 +1150,9 @@ int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const voi
   if (st != RBD_OK) return st;
   const rbd_model* m = w->model;
   if (missing(q, m->nq) || missing(v, m->nv) || missing(vdot, m->nv)) return RBD_ERR_INVALID_ARGUMENT;
+  // the reference's dynamics! always runs contact_dynamics! (src/mechanism_algorithms.jl:849-856): a mechanism with contact points and an
+  // environment needs its additional state s — rbd_dynamics_contact; this entry point must not silently leave the contact wrenches out
+  if (m->ncp > 0 && m->nhs > 0) return RBD_ERR_UNSUPPORTED;
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   const size_t es = esize(w);
@@ -1327,6 +1330,7 @@ int rbd_mk_stage(rbd_ws_t* w, int32_t B, int32_t stage, double dt, void* q, void
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
   if (!q || !v || stage < 0 || stage > 4 || (stage > 0 && !vdot_prev) || o.memory != RBD_MEM_DEVICE) return RBD_ERR_INVALID_ARGUMENT;
+  if (w->model->ncp > 0 && w->model->nhs > 0) return RBD_ERR_UNSUPPORTED;  // the additional contact state is not part of this stage form
   if (B == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   if ((st = mk_ensure(w, B))) return st;
@@ -1342,6 +1346,7 @@ int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, cons
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
   if (!q || !v || nsteps < 0 || !(dt > 0)) return RBD_ERR_INVALID_ARGUMENT;
+  if (w->model->ncp > 0 && w->model->nhs > 0) return RBD_ERR_UNSUPPORTED;  // contact points: rbd_simulate_contact (carries the additional state)
   if (B == 0 || nsteps == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   const rbd_model* m = w->model;

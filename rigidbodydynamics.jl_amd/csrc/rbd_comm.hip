@@ -11,6 +11,7 @@
 #include <new>
 #include <string>
 
+#include <mutex>
 #include "rbd_hip.h"
 
 namespace {
@@ -27,14 +28,19 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
 };
+void rccl_open(Rccl& R);
 Rccl& rccl() {
   static Rccl R;
-  if (R.h || R.ok) return R;
+  static std::once_flag once;  // two threads creating communicators at once must not race on the function pointers
+  std::call_once(once, [] { rccl_open(R); });
+  return R;
+}
+void rccl_open(Rccl& R) {
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
     R.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (R.h) break;
   }
-  if (!R.h) return R;
+  if (!R.h) return;
   auto sym = [&](const char* n) { return dlsym(R.h, n); };
   R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
   R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
@@ -46,7 +52,6 @@ Rccl& rccl() {
   R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
   R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
   R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.AllGather && R.Send && R.Recv && R.GroupStart && R.GroupEnd;
-  return R;
 }
 thread_local std::string g_comm_error;
 }  // namespace
@@ -91,7 +96,7 @@ int rbd_comm_create(const void* id128, int32_t world, int32_t rank, int32_t devi
 
 int rbd_comm_destroy(rbd_comm_t* c) {
   if (!c) return RBD_OK;
-  if (c->comm) (void)rccl().CommDestroy(c->comm);
+  if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
   delete c;
   return RBD_OK;
 }
@@ -109,6 +114,7 @@ int rbd_gather(rbd_comm_t* c, int32_t dtype, const void* shard, void* gathered, 
   if (!c || !shard || count < 0 || (dtype != RBD_F64 && dtype != RBD_F32) || root >= c->world) return RBD_ERR_INVALID_ARGUMENT;
   if ((root < 0 || root == c->rank) && !gathered) return RBD_ERR_INVALID_ARGUMENT;
   Rccl& R = rccl();
+  if (!R.ok) { g_comm_error = "librccl.so could not be opened"; return RBD_ERR_UNSUPPORTED; }
   const ncclDataType_t t = dtype == RBD_F64 ? ncclDouble : ncclFloat;
   const size_t es = dtype == RBD_F64 ? 8 : 4;
   hipStream_t s = (hipStream_t)stream;

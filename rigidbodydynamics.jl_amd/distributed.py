@@ -67,7 +67,7 @@ class Comm:
         st = self._L.rbd_comm_create(ctypes.cast(buf, ctypes.c_void_p), world, rank, device, ctypes.byref(self.handle))
         if st != 0:
             raise _capi.RBDError(st, "rbd_comm_create", (self._L.rbd_comm_last_error() or b"").decode())
-        self.world, self.rank = world, rank
+        self.world, self.rank, self.device = world, rank, device
 
     @staticmethod
     def unique_id() -> bytes:
@@ -83,6 +83,10 @@ class Comm:
         """All-gather (root None) or gather to `root` of equal-size shards (B_local, n) on the current stream."""
         import ctypes
         from . import _capi
+        if shard.dtype not in (torch.float64, torch.float32):
+            raise TypeError(f"Comm.gather moves float64 / float32 results, not {shard.dtype}")
+        if not shard.is_cuda or shard.device.index != self.device:
+            raise ValueError(f"the shard lives on {shard.device}, the communicator on cuda:{self.device}")
         shard = shard.contiguous()
         want = root is None or root == self.rank
         out = torch.empty((self.world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device) if want else None
@@ -97,3 +101,15 @@ class Comm:
         if self.handle:
             self._L.rbd_comm_destroy(self.handle)
             self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

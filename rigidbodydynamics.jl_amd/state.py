@@ -264,6 +264,7 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
                                               _ptr(result.vd), _ptr(result.qd), _ptr(result.sd), _ptr(result.contactwrenches), _ptr(result.totalwrenches),
                                               ctypes.byref(opts))
         _raise(st, "rbd_dynamics_contact")
+        _fill_result_fields(result, state, algo, result.totalwrenches, totalwrenches_done=True)
         return None
     st = _capi.lib().rbd_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
                                   _ptr(result.vd), _ptr(result.qd), _ptr(lam), ctypes.byref(opts))
@@ -273,18 +274,28 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
                                              _ptr(result.constraintjacobian if f.nc else None),
                                              _ptr(result.constraintbias if f.nc else None), ctypes.byref(opts))
         _raise(st, "rbd_dynamics_result")
+    _fill_result_fields(result, state, None, externalwrenches)
+    return None
+
+
+def _fill_result_fields(result, state, algo, wrenches, totalwrenches_done=False):
+    """What dynamics! leaves in a DynamicsResult beside v̇: totalwrenches = externalwrenches + contact wrenches, and the bias accelerations /
+    joint wrenches of its dynamics_bias! call with those total wrenches (src/mechanism_algorithms.jl:851-856); with algo (the contact path,
+    where the forward dynamics ran as ABA whatever was asked for) the mass matrix of the "crba" route as well."""
     if result.accelerations is not None:
-        # what dynamics! leaves in the per-body fields: totalwrenches = externalwrenches (+ contact wrenches: none here), and the bias
-        # accelerations / joint wrenches of its dynamics_bias! call (mechanism_algorithms.jl:851-856)
-        if externalwrenches is None:
-            result.totalwrenches.zero_()
-        else:
-            result.totalwrenches.copy_(externalwrenches)
+        if not totalwrenches_done:
+            if wrenches is None:
+                result.totalwrenches.zero_()
+            else:
+                result.totalwrenches.copy_(wrenches)
         o2 = state._opts()
-        st = _capi.lib().rbd_dynamics_bias_bodies(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(externalwrenches), _ptr(result.dynamicsbias),
+        st = _capi.lib().rbd_dynamics_bias_bodies(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(wrenches), _ptr(result.dynamicsbias),
                                                   _ptr(result.jointwrenches), _ptr(result.accelerations), ctypes.byref(o2))
         _raise(st, "rbd_dynamics_bias_bodies")
-    return None
+    if algo == _capi.ALGO_CRBA_CHOLESKY:
+        mass_matrix_(result, state)
+        if result.accelerations is None:
+            dynamics_bias_(result.dynamicsbias, state, wrenches)
 
 
 _MAPPING = {"auto": _capi.ALGO_ABA, "lanes": _capi.ALGO_ABA_LANES, "banks": _capi.ALGO_ABA_BANKS, "walk": _capi.ALGO_ABA_WALK, "pipe": _capi.ALGO_ABA_PIPE}
@@ -441,18 +452,25 @@ def simulate_(state: MechanismState, final_time: float, control_=None, dt: float
 def dynamics_ode_(xd: torch.Tensor, result: DynamicsResult, state: MechanismState, x: torch.Tensor, torques: Optional[torch.Tensor] = None,
                   externalwrenches: Optional[torch.Tensor] = None, stabilization_gains="default"):
     """`dynamics!(ẋ, result, state, x, torques, externalwrenches)` (src/mechanism_algorithms.jl:880-889), the form used with
-    off-the-shelf ODE solvers: x = [q; v] per state, (B, nq + nv); `copyto!(state, x)`, `dynamics!`, `copyto!(ẋ, result)` with
-    ẋ = [q̇; v̇] (src/dynamics_result.jl:89-95; no additional contact state in scope)."""
+    off-the-shelf ODE solvers: x = [q; v; s] per state, (B, nq + nv + ns) with s the additional (contact) state — empty without contact
+    points; `copyto!(state, x)`, `dynamics!`, `copyto!(ẋ, result)` with ẋ = [q̇; v̇; ṡ] (src/mechanism_state.jl:419-426,
+    src/dynamics_result.jl:89-95)."""
     f = state.flat
+    ns = getattr(f, "ns", 0)
     if state.layout != "aos":
         raise ValueError("dynamics_ode_ expects the AOS layout (one state vector per row)")
-    if tuple(x.shape) != (state.batch, f.nq + f.nv) or tuple(xd.shape) != (state.batch, f.nq + f.nv):
-        raise DimensionMismatch(f"x / ẋ must be ({state.batch}, {f.nq + f.nv})")
+    n = f.nq + f.nv + ns
+    if tuple(x.shape) != (state.batch, n) or tuple(xd.shape) != (state.batch, n):
+        raise DimensionMismatch(f"x / ẋ must be ({state.batch}, {n}) = [q; v{'; s' if ns else ''}]")
     state.q.copy_(x[:, :f.nq])
-    state.v.copy_(x[:, f.nq:])
+    state.v.copy_(x[:, f.nq:f.nq + f.nv])
+    if ns:
+        state.s.copy_(x[:, f.nq + f.nv:])
     dynamics_(result, state, torques, externalwrenches, stabilization_gains=stabilization_gains)
     xd[:, :f.nq].copy_(result.qd)
-    xd[:, f.nq:].copy_(result.vd)
+    xd[:, f.nq:f.nq + f.nv].copy_(result.vd)
+    if ns:
+        xd[:, f.nq + f.nv:].copy_(result.sd)
     return xd
 
 

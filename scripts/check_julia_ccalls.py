@@ -1,7 +1,10 @@
-"""Checks every `ccall` of julia/RigidBodyDynamicsGPU.jl against include/rbd_hip.h: the symbol exists, the argument count matches the
-prototype and every argument is of the same kind (pointer / 32-bit integer / 64-bit integer / double).  Julia is not available in the
-build image, so this is what keeps the shim's bindings from drifting off the header.  Exit status 0 = consistent; run by
-tests/test_capi_symbols.py."""
+"""Checks julia/RigidBodyDynamicsGPU.jl against include/rbd_hip.h without Julia (the build image has none):
+  * every `ccall`: the symbol exists, the argument count matches the prototype and every argument is of the same kind (pointer / 32-bit
+    integer / 64-bit integer / double);
+  * every C struct the shim mirrors (RbdLoopJoint, RbdContactPoint, RbdHalfSpace, RbdFlatModel, RbdOpts): field by field, the offset and
+    size Julia's isbits layout rules give (= the platform C rules) against `offsetof` / `sizeof` printed by a g++-compiled dump of the
+    header, and the field names.
+Exit status 0 = consistent; run by tests/test_capi_symbols.py."""
 import os
 import re
 import sys
@@ -77,6 +80,99 @@ def julia_ccalls():
     return calls
 
 
+STRUCTS = {"RbdLoopJoint": "rbd_loop_joint_t", "RbdContactPoint": "rbd_contact_point_t", "RbdHalfSpace": "rbd_halfspace_t",
+           "RbdFlatModel": "rbd_flat_model_t", "RbdOpts": "rbd_opts_t"}
+
+
+def header_struct_fields():
+    """{c struct: [field names in declaration order]} from the header text."""
+    h = open(os.path.join(ROOT, "include", "rbd_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", " ", h, flags=re.S)
+    out = {}
+    for m in re.finditer(r"typedef struct \w+\s*\{(.*?)\}\s*(\w+)\s*;", h, flags=re.S):
+        names = []
+        for decl in m.group(1).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            first, *rest = split_top(decl)
+            names.append(re.sub(r"\[.*", "", first.split()[-1].lstrip("*")))
+            names += [re.sub(r"\[.*", "", r.strip().lstrip("*")) for r in rest]
+        out[m.group(2)] = names
+    return out
+
+
+def c_layout(fields):
+    """{c struct: (sizeof, [(name, offset, size)])} by compiling a dump of the header with g++."""
+    import subprocess, tempfile
+    lines = ['#include <cstdio>', '#include <cstddef>', '#include "rbd_hip.h"', "int main() {"]
+    for cs, names in fields.items():
+        lines.append(f'  std::printf("S {cs} %zu\\n", sizeof({cs}));')
+        for n in names:
+            lines.append(f'  std::printf("F {cs} {n} %zu %zu\\n", offsetof({cs}, {n}), sizeof((({cs}*)0)->{n}));')
+    lines += ["  return 0;", "}"]
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "dump.cpp"), os.path.join(d, "dump")
+        open(src, "w").write("\n".join(lines))
+        subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        txt = subprocess.check_output([exe], text=True)
+    out = {}
+    for ln in txt.splitlines():
+        p = ln.split()
+        if p[0] == "S":
+            out[p[1]] = (int(p[2]), [])
+        else:
+            out[p[1]][1].append((p[2], int(p[3]), int(p[4])))
+    return out
+
+
+def jl_layout(name):
+    """(sizeof, [(field, offset, size)]) of an isbits Julia struct by the C layout rules Julia follows."""
+    src = open(os.path.join(ROOT, "julia", "RigidBodyDynamicsGPU.jl")).read()
+    m = re.search(r"^struct %s\b[^\n]*\n(.*?)^end" % name, src, flags=re.S | re.M)
+    if not m:
+        raise ValueError(f"struct {name} not found in the Julia shim")
+    body = re.sub(r"#[^\n]*", "", m.group(1))
+    off, fields, maxal = 0, [], 1
+    for item in re.split(r"[;\n]", body):
+        item = item.strip()
+        if not item:
+            continue
+        fname, ftype = [x.strip() for x in item.split("::")]
+        if ftype in ("Int32", "Cint", "UInt32"):
+            size, al = 4, 4
+        elif ftype in ("Float64", "Cdouble", "Int64") or ftype.startswith("Ptr{"):
+            size, al = 8, 8
+        else:
+            t = re.match(r"NTuple\{\s*(\d+)\s*,\s*(Float64|Int32)\s*\}", ftype)
+            if not t:
+                raise ValueError(f"{name}.{fname}: unclassified Julia field type {ftype!r}")
+            al = 8 if t.group(2) == "Float64" else 4
+            size = int(t.group(1)) * al
+        off = (off + al - 1) // al * al
+        fields.append((fname, off, size))
+        off += size
+        maxal = max(maxal, al)
+    return (off + maxal - 1) // maxal * maxal, fields
+
+
+def check_structs():
+    hf = header_struct_fields()
+    cl = c_layout({cs: hf[cs] for cs in STRUCTS.values()})
+    bad = []
+    for js, cs in STRUCTS.items():
+        jsize, jf = jl_layout(js)
+        csize, cf = cl[cs]
+        if jsize != csize:
+            bad.append(f"{js}: sizeof {jsize} in Julia, {csize} in C ({cs})")
+        if len(jf) != len(cf):
+            bad.append(f"{js}: {len(jf)} fields in Julia, {len(cf)} in C ({cs})")
+        for (jn, jo, jz), (cn, co, cz) in zip(jf, cf):
+            if (jo, jz) != (co, cz) or jn != cn:
+                bad.append(f"{js}.{jn}: offset {jo} size {jz} in Julia; {cs}.{cn}: offset {co} size {cz} in C")
+    return bad, sum(len(v[1]) for v in cl.values())
+
+
 def main():
     protos = header_prototypes()
     bad = []
@@ -90,9 +186,11 @@ def main():
         elif kinds != protos[name]:
             bad.append(f"line {line}: {name} is bound as {kinds}, the header declares {protos[name]}")
     print(f"{n} ccalls into librbd_hip checked against {len(protos)} prototypes; {len(bad)} mismatches")
-    for b in bad:
+    sbad, nf = check_structs()
+    print(f"{len(STRUCTS)} structs ({nf} fields) checked against offsetof / sizeof of the header; {len(sbad)} mismatches")
+    for b in bad + sbad:
         print("  " + b)
-    return 1 if bad or n == 0 else 0
+    return 1 if bad or sbad or n == 0 else 0
 
 
 if __name__ == "__main__":

@@ -175,3 +175,47 @@ def test_contact_entry_points_reject_what_they_cannot_do(rbd, models):
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     st = _capi.lib().rbd_contact_dynamics(state.ws.handle, 4, p(state.q), p(state.v), p(z), None, p(z), ctypes.byref(state._opts()))
     assert st == 1  # RBD_ERR_INVALID_ARGUMENT: the mechanism has no contact points
+
+
+@pytest.mark.gpu
+def test_contact_ode_form_and_result_fields(rbd, oracle):
+    """Round-2 advisor findings: dynamics!(ẋ, result, state, x) of a mechanism with contact points takes x = [q; v; s] and returns ẋ = [q̇; v̇; ṡ]
+    (src/mechanism_state.jl:419-426, src/dynamics_result.jl:89-95); a DynamicsResult with per-body fields gets the bias accelerations / joint
+    wrenches computed WITH the total (external + contact) wrenches, and the "crba" route its mass matrix; the plain C entry points refuse the
+    model instead of leaving the contact wrenches out."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(15)
+    flat = rbd.flatten(walker(rbd, rng))
+    B = 37
+    q, v = rbd.rand_configuration(flat, B, rng), rbd.rand_velocity(flat, B, rng)
+    q[:, 4:7] *= 0.5
+    s = 1e-3 * rng.standard_normal((B, flat.ns))
+    tau, fe = rng.random((B, flat.nv)), rng.random((B, 6 * flat.n_bodies))
+    vd_ref, s_ref, sd_ref, cw_ref, tw_ref = oracle.dynamics_contact(flat, q, v, s, tau, fe)
+    state = rbd.MechanismState(flat, B)
+    result = rbd.DynamicsResult(flat, B, bodies=True)
+    x = torch.as_tensor(np.concatenate([q, v, s], axis=1)).cuda()
+    xd = torch.zeros_like(x)
+    rbd.dynamics_ode_(xd, result, state, x, torch.as_tensor(tau).cuda(), torch.as_tensor(fe).cuda())
+    got = xd.cpu().numpy()
+    rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    assert rel(got[:, flat.nq:flat.nq + flat.nv], vd_ref) <= 1e-10 and rel(got[:, flat.nq + flat.nv:], sd_ref) <= 1e-10
+    with pytest.raises(rbd.DimensionMismatch):
+        rbd.dynamics_ode_(xd[:, :flat.nq + flat.nv], result, state, x[:, :flat.nq + flat.nv])
+    c_ref, jw_ref, acc_ref = oracle.inverse_dynamics_bodies(flat, q, v, None, tw_ref)
+    assert rel(result.jointwrenches.cpu().numpy().reshape(B, -1, 6), jw_ref) <= 1e-10
+    assert rel(result.accelerations.cpu().numpy().reshape(B, -1, 6), acc_ref) <= 1e-10
+    assert rel(result.dynamicsbias.cpu().numpy(), c_ref) <= 1e-10
+    state.s.copy_(torch.as_tensor(s).cuda())
+    rbd.dynamics_(result, state, torch.as_tensor(tau).cuda(), torch.as_tensor(fe).cuda(), algorithm="crba")
+    M = result.massmatrix.cpu().numpy().reshape(B, flat.nv, flat.nv).transpose(0, 2, 1)
+    assert rel(np.tril(M), np.tril(oracle.mass_matrix(flat, q))) <= 1e-10
+    # the C ABI without the additional state: refused (RBD_ERR_UNSUPPORTED = 3), not mis-evaluated
+    from rigidbodydynamics_jl_amd import _capi
+    L, vp = _capi.lib(), ctypes.c_void_p
+    opts = state._opts(0)
+    st = L.rbd_dynamics(state.ws.handle, B, vp(state.q.data_ptr()), vp(state.v.data_ptr()), None, None, vp(result.vd.data_ptr()), None, None, ctypes.byref(opts))
+    assert st == 3
+    st = L.rbd_simulate(state.ws.handle, B, vp(state.q.data_ptr()), vp(state.v.data_ptr()), None, None, ctypes.c_double(1e-3), 2, ctypes.byref(opts))
+    assert st == 3
