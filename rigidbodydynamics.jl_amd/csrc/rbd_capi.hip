@@ -66,7 +66,8 @@ struct rbd_model {
   std::vector<int32_t> slot_of, order;  // reference body index <-> DFS pre-order slot
   std::vector<int32_t> dof_body;
   std::vector<int32_t> anc;     // nb * nlevels
-  std::vector<uint64_t> row_mask;  // nv
+  std::vector<uint64_t> row_mask;  // nv x row_words
+  int32_t row_words = 1;
   std::vector<rbd_loop_joint_t> loops;
   std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref, parent_ref;  // loop tables (reference body indices)
   std::vector<double> loop_r, axis_ref, axis2_ref;
@@ -276,20 +277,19 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     int a = s;
     for (int k = 0; k < m->nlevels && a >= 0; ++k) { m->anc[(size_t)s * m->nlevels + k] = a; a = m->ib[(size_t)a * IB_STRIDE + IB_PARENT]; }
   }
-  // support structure per dof row (support_set_masks, src/mechanism_state.jl:95-98); nv <= 64 here is guaranteed by nb <= 64 only
-  // for 1-dof joints, so wider mechanisms fall back to an empty mask (then every lower entry is written as computed or zero-filled)
-  m->row_mask.assign(m->nv > 0 ? m->nv : 1, 0);
-  if (m->nv <= 64) {
-    for (int r = 0; r < m->nv; ++r) {
-      const int sr = m->dof_body[r];
-      for (int c = 0; c <= r; ++c) {
-        const int sc = m->dof_body[c];
-        bool sup = false;
-        for (int k = 0; k < m->nlevels; ++k) sup |= (m->anc[(size_t)sr * m->nlevels + k] == sc);
-        if (sup) m->row_mask[r] |= (uint64_t)1 << c;
-      }
+  // support structure per dof row (support_set_masks, src/mechanism_state.jl:95-98): row r is row_words 64-bit words, bit c of word c / 64.
+  // (64 bodies of 6-dof joints — a mechanism in maximal coordinates, test/test_mechanism_modification.jl:274-318 — make nv up to 384.)
+  m->row_words = std::max(1, (m->nv + 63) / 64);
+  m->row_mask.assign((size_t)(m->nv > 0 ? m->nv : 1) * m->row_words, 0);
+  for (int r = 0; r < m->nv; ++r) {
+    const int sr = m->dof_body[r];
+    for (int c = 0; c <= r; ++c) {
+      const int sc = m->dof_body[c];
+      bool sup = false;
+      for (int k = 0; k < m->nlevels; ++k) sup |= (m->anc[(size_t)sr * m->nlevels + k] == sc);
+      if (sup) m->row_mask[(size_t)r * m->row_words + c / 64] |= (uint64_t)1 << (c % 64);
     }
-  } else { delete m; return RBD_ERR_UNSUPPORTED; }
+  }
   m->nc = 0;
   m->jt_ref.assign(d->joint_type, d->joint_type + nb);
   m->parent_ref.assign(d->parent, d->parent + nb);
@@ -385,7 +385,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     if (m->nloops == 0) m->chain = build_chain_plan(nb, m->ib, G);
     if (m->nloops == 0 && G <= 4) m->track = build_track_plan(nb, m->ib, m->rb, G);
     if (m->track.ok) m->walk = build_walk_plan(m->track.ns, m->track.G, m->track.ri);
-    if (m->nloops == 0) m->state = build_state_plan(nb, m->ib, m->rb);
+    if (m->nloops == 0 && m->nv <= 64) m->state = build_state_plan(nb, m->ib, m->rb);  // (the lane-per-state kernels keep one mask word per row)
   }
   // ---- the same tree re-rooted at its centre, for the ABA kernels that take it (RBD_NO_REROOT=1 disables) ----
   if (m->bank_aba_ok && !getenv("RBD_NO_REROOT")) {
@@ -601,7 +601,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     ++dm.nheavy;
   }
   nslots_pack_desc(dm.ns_desc, m->nslots.data(), m->nlevels);
-  dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc; dm.row_mask = (const uint64_t*)w->d_row_mask;
+  dm.dof_body = (const int32_t*)w->d_dof_body; dm.anc = (const int32_t*)w->d_anc; dm.row_mask = (const uint64_t*)w->d_row_mask; dm.row_words = m->row_words;
   memcpy(dm.gravity, m->gravity, sizeof dm.gravity);
   if (m->bank_lps > 0) {
     BankModel& bm = w->bm;

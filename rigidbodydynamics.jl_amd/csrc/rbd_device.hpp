@@ -70,7 +70,8 @@ struct DevModel {
   const int32_t* ib;  // [nb * IB_STRIDE], indexed by slot; parent/children are slots, IB_ORIG the reference body index
   const void* rb;     // [nb * RB_STRIDE] of the kernel's scalar type, indexed by slot
   const int32_t* dof_body;  // [nv] slot of velocity index
-  const uint64_t* row_mask; // [nv] bit c of row_mask[r]: M[r, c] is structurally non-zero (joint of dof c supports the body of dof r), c <= r
+  const uint64_t* row_mask; // [nv * row_words] bit c % 64 of word c / 64 of row r: M[r, c] is structurally non-zero (joint of dof c supports the body of dof r), c <= r
+  int32_t row_words;        // 64-bit words per row = ceil(nv / 64)
   const int32_t* anc;       // [nb * nlevels] anc[s*nlevels + k] = k-th ancestor slot of s (k=0: s itself), -1 past the root
   uint64_t perm_down;       // bit l set: some body at level l has parent slot != s-1 (top-down hop needs ds_bpermute at level l)
   uint64_t ns_desc[4];  // child slots to gather when the bottom-up sweep processes level l (max #children of level l-1 parents): NsStream
@@ -435,6 +436,18 @@ RBD_DEV double rcp_nr(double x) {
 RBD_DEV float rcp_nr(float x) {
   float r = __builtin_amdgcn_rcpf(x);
   return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r);
+}
+// 1/sqrt of a positive, well-scaled number: hardware estimate + Newton steps (the IEEE sqrt + division pair is ~70 instructions in fp64)
+RBD_DEV double rsqrt_nr(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  r = r * __builtin_fma(-h * r, r, 1.5);
+  r = r * __builtin_fma(-h * r, r, 1.5);
+  return r;
+}
+RBD_DEV float rsqrt_nr(float x) {
+  float r = __builtin_amdgcn_rsqf(x);
+  return r * __builtin_fmaf(-0.5f * x * r, r, 1.5f);
 }
 template <typename T> struct SqrtT;
 template <> struct SqrtT<double> { static __device__ __forceinline__ double f(double x) { return sqrt(x); } };

@@ -572,11 +572,14 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
   if (zero_fill && b.valid) {
     for (int ci = 0; ci < nvi; ++ci) {
       const long row = b.voff + ci;
-      unsigned long long m = ~M.row_mask[row] & ((row >= 63) ? ~0ull : ((2ull << row) - 1));
-      while (m) {
-        const long col = __builtin_ctzll(m);
-        m &= m - 1;
-        Mout[(col * nv + row) * Lm.sk + b.state * Lm.sb] = T(0);
+      for (int wd = 0; wd <= (int)(row >> 6); ++wd) {  // columns 0..row, 64 per mask word
+        const long top = row - 64L * wd;               // highest column of this word that is <= row
+        unsigned long long m = ~M.row_mask[row * M.row_words + wd] & ((top >= 63) ? ~0ull : ((2ull << top) - 1));
+        while (m) {
+          const long col = 64L * wd + __builtin_ctzll(m);
+          m &= m - 1;
+          Mout[(col * nv + row) * Lm.sk + b.state * Lm.sb] = T(0);
+        }
       }
     }
   }
@@ -1660,15 +1663,16 @@ __global__ __launch_bounds__(64) void loop_solve_small_kernel(LoopView<T> V, lon
 #pragma unroll
     for (int i = 0; i < NV; ++i) L[j][i] = (i >= j && i < nv && j < nv) ? Mg[((long)j * nv + i) * Lm.sk + st * Lm.sb] : ((i == j) ? T(1) : T(0));
   bool bad = false;
+  T invd[NV];  // 1 / L[j][j]: the substitutions multiply (seven of them per state: a division each time was ~30 instructions in fp64)
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     T d = L[j][j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= L[k][j] * L[k][j];
     if (!(d > T(0))) bad = true;
-    d = SqrtT<T>::f(d);
-    L[j][j] = d;
-    const T id = T(1) / d;
+    const T id = bad ? T(0) : rsqrt_nr(d);
+    L[j][j] = d * id;
+    invd[j] = id;
 #pragma unroll
     for (int i = j + 1; i < NV; ++i) {
       T s2 = L[j][i];
@@ -1683,14 +1687,14 @@ __global__ __launch_bounds__(64) void loop_solve_small_kernel(LoopView<T> V, lon
     for (int i = 0; i < NV; ++i) { T s2 = x[i];
 #pragma unroll
       for (int k = 0; k < i; ++k) s2 -= L[k][i] * x[k];
-      x[i] = s2 / L[i][i]; }
+      x[i] = s2 * invd[i]; }
   };
   auto bwd = [&](T* x) {
 #pragma unroll
     for (int i = NV - 1; i >= 0; --i) { T s2 = x[i];
 #pragma unroll
       for (int k = i + 1; k < NV; ++k) s2 -= L[i][k] * x[k];
-      x[i] = s2 / L[i][i]; }
+      x[i] = s2 * invd[i]; }
   };
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -1741,10 +1745,14 @@ __global__ __launch_bounds__(64) void loop_solve_small_kernel(LoopView<T> V, lon
         for (int q = p + 1; q < NV; ++q) {
           const T apq = G[p][q];
           if (apq != T(0)) {
-            const T theta = (G[q][q] - G[p][p]) / (2 * apq);
-            const T at = theta >= T(0) ? theta : -theta;
-            const T t = (theta >= T(0) ? T(1) : T(-1)) / (at + SqrtT<T>::f(theta * theta + 1));
-            const T c = 1 / SqrtT<T>::f(t * t + 1), sn = t * c;
+            // the rotation that annihilates G[p][q]: t = sgn(θ) / (|θ| + sqrt(θ² + 1)), θ = (G_qq − G_pp) / (2 G_pq) — with t written over a
+            // common denominator so that one reciprocal square root and one reciprocal replace two divisions and two square roots:
+            // t = 2 G_pq sgn(d) / (|d| + sqrt(d² + 4 G_pq²)), d = G_qq − G_pp
+            const T d = G[q][q] - G[p][p], ad = d >= T(0) ? d : -d;
+            const T h2 = d * d + 4 * apq * apq;
+            const T hyp = h2 * rsqrt_nr(h2);
+            const T t = (d >= T(0) ? T(2) : T(-2)) * apq * rcp_nr(ad + hyp);
+            const T c = rsqrt_nr(t * t + 1), sn = t * c;
 #pragma unroll
             for (int k = 0; k < NV; ++k) { const T a = G[k][p], b2 = G[k][q]; G[k][p] = c * a - sn * b2; G[k][q] = sn * a + c * b2; }
 #pragma unroll
@@ -1813,7 +1821,12 @@ template <typename T>
 hipError_t launch_loop_solve(const LoopView<T>& V, long B, int stabilize, const void* body, const void* M, const void* c, const void* tau, void* vdot,
                              void* lambda, void* K, void* k, void* scratch, long scratch_stride, Layout Lm, Layout Lv, Layout Lc, Layout Lk,
                              const double* gravity, int* notpd, hipStream_t s) {
-  if (V.nv <= 4 && V.nc <= 6 && V.nv < V.nc) {  // small loop mechanisms (four-bar: nv 3, nc 5): everything in registers
+  if (V.nv <= 3 && V.nc <= 6 && V.nv < V.nc) {  // the four-bar linkage itself (nv 3, nc 5): a 3 x 3 eigenproblem, three rotations per sweep
+    hipLaunchKernelGGL((loop_solve_small_kernel<T, 3, 6>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, V, B, stabilize, (const T*)body, (const T*)M,
+                       (const T*)c, (const T*)tau, (T*)vdot, (T*)lambda, (T*)K, (T*)k, Lm, Lv, Lc, Lk, gravity[0], gravity[1], gravity[2], notpd);
+    return hipGetLastError();
+  }
+  if (V.nv <= 4 && V.nc <= 6 && V.nv < V.nc) {  // small loop mechanisms: everything in registers
     hipLaunchKernelGGL((loop_solve_small_kernel<T, 4, 6>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, V, B, stabilize, (const T*)body, (const T*)M,
                        (const T*)c, (const T*)tau, (T*)vdot, (T*)lambda, (T*)K, (T*)k, Lm, Lv, Lc, Lk, gravity[0], gravity[1], gravity[2], notpd);
     return hipGetLastError();

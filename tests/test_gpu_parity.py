@@ -899,6 +899,43 @@ def test_maximal_coordinates_loop_dynamics(rbd, oracle):
 
 
 @pytest.mark.gpu
+def test_maximal_coordinates_at_the_reference_size(rbd, oracle):
+    """The reference's own pin of constraint_jacobian! / constraint_bias! / the loop branch of dynamics_solve! at ITS size
+    (test/test_mechanism_modification.jl:274-318): QuaternionFloating + 10 Revolute + QuaternionSpherical + Planar + 10 Fixed + 5 SinCosRevolute
+    = 28 joints, every body on a floating joint in maximal coordinates — nv = 168 (three mask words per mass-matrix row), nc = 141.  The body
+    accelerations of the tree and of the maximal-coordinates mechanism agree (the reference's assertion, atol 1e-10 there), and v̇, K, k match the oracle."""
+    rng = np.random.default_rng(53)
+    joints = ["QuaternionFloating"] + ["Revolute"] * 10 + ["QuaternionSpherical", "Planar"] + ["Fixed"] * 10 + ["SinCosRevolute"] * 5
+    tree = rbd.rand_tree_mechanism(rng, joints)
+    mt, mc = rbd.flatten(tree), rbd.flatten(rbd.maximal_coordinates(tree))
+    assert mc.n_bodies == 28 and mc.nv == 168 and mc.n_loops == 28
+    from test_oracle_loops import maximal_state
+    B = 6
+    q, v = rbd.rand_configuration(mt, B, rng), rbd.rand_velocity(mt, B, rng)
+    vd_tree = oracle.dynamics(mt, q, v)
+    H, T, A_tree = oracle.body_kinematics(mt, q, v, vd_tree)
+    qm, vm = maximal_state(H, T)
+    state = rbd.MechanismState(mc, B)
+    result = rbd.DynamicsResult(mc, B)
+    rbd.set_configuration_(state, qm)
+    rbd.set_velocity_(state, vm)
+    rbd.dynamics_(result, state)
+    assert rbd.sync(state) == 0
+    got = host(result.vd, state)
+    ref = oracle.dynamics_loops(mc, qm, vm)
+    assert np.abs(got - ref["vdot"]).max() <= 1e-8 * max(1.0, np.abs(ref["vdot"]).max())
+    K = host(result.constraintjacobian, state).reshape(B, mc.nv, mc.nc).transpose(0, 2, 1)
+    assert np.abs(K - ref["K"]).max() <= 1e-11
+    assert np.abs(host(result.constraintbias, state) - ref["k"]).max() <= 1e-9 * max(1.0, np.abs(ref["k"]).max())
+    _, _, A_mc = oracle.body_kinematics(mc, qm, vm, got)  # body accelerations with the GPU's v̇
+    assert np.abs(A_mc - A_tree).max() <= 1e-8 * max(1.0, np.abs(A_tree).max())
+    # the mass matrix with its structural zeros (three 64-bit mask words per row)
+    Mg = host(result.massmatrix, state).reshape(B, mc.nv, mc.nv).transpose(0, 2, 1)
+    Mref = oracle.mass_matrix(mc, qm)
+    assert np.abs(np.tril(Mg) - np.tril(Mref)).max() <= 1e-10 * max(1.0, np.abs(Mref).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("name", MODELS)
 def test_momentum_and_rate_bias_f64(rbd, oracle, models, name, layout):
