@@ -267,6 +267,29 @@ int rbd_simulate(rbd_ws_t* ws, int32_t B, void* q, void* v, const void* tau, con
                  const rbd_opts_t* opts);
 int rbd_mk_stage(rbd_ws_t* ws, int32_t B, int32_t stage, double dt, void* q, void* v, const void* vdot_prev, const rbd_opts_t* opts);
 
+/* ---- `simulate(state, T, control!)` without a host round trip per stage (src/simulate.jl:36-48: the reference calls control!(τ, t, state)
+ *      before every stage's dynamics!).  Two device-side controller forms cover the common cases; anything else keeps the
+ *      rbd_mk_stage + rbd_dynamics loop with the controller on the host.
+ *   RBD_CONTROL_CONSTANT : τ = tau (nv × B, NULL = 0) — what rbd_simulate does.
+ *   RBD_CONTROL_TABLE    : an open-loop τ(t): `tau` holds entries of nv × B each (batch layout of opts), entry 4·step + stage when
+ *                          per_stage = 1 — the stage times t, t + h/2, t + h/2, t + h control! is called with — or entry `step` when
+ *                          per_stage = 0 (zero-order hold over the step).
+ *   RBD_CONTROL_PD       : τ_i = tau_i − kp_i (q_i − q_des_i) − kd_i v_i on every Revolute / Prismatic joint, evaluated on the STAGE state inside
+ *                          the dynamics launch (other joint types: τ = tau).  kp, kd: [nv] gains, q_des: nq × B (NULL = 0), all DEVICE arrays of
+ *                          the workspace's scalar type.
+ * Device memory only (opts->memory = RBD_MEM_DEVICE); tree mechanisms without contact points. */
+enum { RBD_CONTROL_CONSTANT = 0, RBD_CONTROL_TABLE = 1, RBD_CONTROL_PD = 2 };
+typedef struct rbd_control {
+  int32_t kind;       /* RBD_CONTROL_*                                   */
+  int32_t per_stage;  /* TABLE: 1 = four entries per step, 0 = one       */
+  const void* tau;    /* see above                                       */
+  const void* q_des;  /* PD                                              */
+  const void* kp;     /* PD                                              */
+  const void* kd;     /* PD                                              */
+} rbd_control_t;
+int rbd_simulate_controlled(rbd_ws_t* ws, int32_t B, void* q, void* v, const rbd_control_t* control, const void* fext, double dt, int32_t nsteps,
+                            const rbd_opts_t* opts);
+
 /* ---- soft contact: contact_dynamics! (src/mechanism_algorithms.jl:680-723) and the entry points that include it --------------------
  * rbd_contact_dynamics: for every contact point inside a half-space the force of contact_dynamics! (src/contact.jl:79-93: Hunt–Crossley
  *   normal force, viscoelastic Coulomb friction) as a wrench on its body in the ROOT frame, and the state derivative of the friction

@@ -27,7 +27,7 @@ import RigidBodyDynamics: dynamics!, inverse_dynamics!, mass_matrix!, dynamics_b
     kinetic_energy, gravitational_potential_energy, momentum, momentum_rate_bias, simulate
 using LinearAlgebra
 
-export BatchedMechanismState, BatchedDynamicsResult, DeviceMatrix, RbdComm, gather!, synchronize, librbd_hip
+export BatchedMechanismState, BatchedDynamicsResult, DeviceMatrix, RbdComm, gather!, synchronize, librbd_hip, TorqueTable, PDControl
 
 const librbd_hip = Ref("librbd_hip.so")   # set to <repo>/rigidbodydynamics.jl_amd/csrc/librbd_hip.so
 const libhip = Ref("libamdhip64.so")
@@ -110,6 +110,10 @@ end
 
 struct RbdOpts
     layout::Int32; memory::Int32; algorithm::Int32; stabilization::Int32
+end
+struct RbdControl             # device-side controllers of rbd_simulate_controlled (include/rbd_hip.h)
+    kind::Int32; per_stage::Int32
+    tau::Ptr{Cvoid}; q_des::Ptr{Cvoid}; kp::Ptr{Cvoid}; kd::Ptr{Cvoid}
 end
 const LAYOUT_AOS = Int32(1)    # Julia n × B column-major == one state per column
 const MEM_DEVICE, MEM_HOST = Int32(0), Int32(1)
@@ -373,6 +377,27 @@ function simulate(state::BatchedMechanismState{T}, final_time; Δt = 1e-4, torqu
             state.ws, batchsize(state), state.q, state.v, nullable(torques), C_NULL, Float64(Δt), nsteps,
             opts(state; stabilization = stabilization_gains === nothing ? 0 : 1)), "rbd_simulate")
     end
+    finish(state)
+    range(zero(T), step = T(Δt), length = nsteps + 1)
+end
+
+"""`simulate(state0, final_time, control; Δt)` with a controller that runs on the device (no host round trip per Runge-Kutta stage — the
+reference calls `control!(τ, t, state)` before every stage's `dynamics!`, src/simulate.jl:42-48):
+`TorqueTable(τ, per_stage)` — τ :: (nv·B) × entries, entry 4·step + stage (the stage times) or entry `step` (zero-order hold);
+`PDControl(kp, kd, q_des, τff)` — τ = τff − kp (q − q_des) − kd v on Revolute / Prismatic joints, on the stage state."""
+struct TorqueTable{T}; torques::DeviceMatrix{T}; per_stage::Bool; end
+struct PDControl{T}; kp::DeviceMatrix{T}; kd::DeviceMatrix{T}; q_des::Union{Nothing, DeviceMatrix{T}}; torques::Union{Nothing, DeviceMatrix{T}}; end
+function simulate(state::BatchedMechanismState{T}, final_time, control::Union{TorqueTable{T}, PDControl{T}}; Δt = 1e-4) where {T}
+    checkmodcount(state)
+    nsteps, t = 0, zero(T)
+    while t < final_time
+        t += Δt; nsteps += 1
+    end
+    vp(x) = x === nothing ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(x))
+    ctl = control isa TorqueTable ? RbdControl(1, control.per_stage ? 1 : 0, vp(control.torques), C_NULL, C_NULL, C_NULL) :
+                                    RbdControl(2, 0, vp(control.torques), vp(control.q_des), vp(control.kp), vp(control.kd))
+    check(ccall((:rbd_simulate_controlled, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ref{RbdControl}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
+        state.ws, batchsize(state), state.q, state.v, ctl, C_NULL, Float64(Δt), nsteps, opts(state)), "rbd_simulate_controlled")
     finish(state)
     range(zero(T), step = T(Δt), length = nsteps + 1)
 end

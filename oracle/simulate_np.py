@@ -152,13 +152,19 @@ def vdot(model, q, v, tau, stabilize):
     return oracle.dynamics(model, q[None], v[None], None if tau is None else tau[None])[0]
 
 
-def step(model, q0, v0, dt, tau=None, stabilize=True):
-    """One MuntheKaasIntegrator step with the RK4 tableau (ode_integrators.jl:233-299)."""
+RK4_C = np.array([0.0, 0.5, 0.5, 1.0])
+
+
+def step(model, q0, v0, dt, tau=None, stabilize=True, control=None, t0=0.0):
+    """One MuntheKaasIntegrator step with the RK4 tableau (ode_integrators.jl:233-299).  control(t, q, v) -> τ is called with every stage's time
+    and state, as the reference's closure calls control!(τ, t, state) (src/simulate.jl:42-48)."""
     phids, vds = [], []
     for i in range(4):
         phi = sum((dt * RK4_A[i, j] * phids[j] for j in range(i) if RK4_A[i, j] != 0), np.zeros(model.nv))
         v = v0 + sum((dt * RK4_A[i, j] * vds[j] for j in range(i) if RK4_A[i, j] != 0), np.zeros(model.nv))
         q = global_coordinates(model, q0, phi)
+        if control is not None:
+            tau = control(t0 + RK4_C[i] * dt, q, v)
         vds.append(vdot(model, q, v, tau, stabilize))
         phids.append(local_rate(model, q0, q, v))
     phi = sum(dt * RK4_B[i] * phids[i] for i in range(4))
@@ -166,13 +172,15 @@ def step(model, q0, v0, dt, tau=None, stabilize=True):
     return global_coordinates(model, q0, phi), v
 
 
-def simulate(model, q, v, final_time, dt, tau=None, stabilize=True):
-    """`simulate`: steps while t < final_time (ode_integrators.jl:307-316). q, v: (B, n). Returns ts, q_end, v_end."""
+def simulate(model, q, v, final_time, dt, tau=None, stabilize=True, control=None):
+    """`simulate`: steps while t < final_time (ode_integrators.jl:307-316). q, v: (B, n). Returns ts, q_end, v_end.
+    control(b, t, q_b, v_b) -> τ_b: a controller evaluated at every stage of every state."""
     q, v = np.array(q, float), np.array(v, float)
     t, ts = 0.0, [0.0]
     while t < final_time:
         for b in range(q.shape[0]):
-            q[b], v[b] = step(model, q[b], v[b], dt, None if tau is None else tau[b], stabilize)
+            cb = None if control is None else (lambda tt, qq, vv, b=b: control(b, tt, qq, vv))
+            q[b], v[b] = step(model, q[b], v[b], dt, None if tau is None else tau[b], stabilize, cb, t)
         t += dt
         ts.append(t)
     return np.array(ts), q, v

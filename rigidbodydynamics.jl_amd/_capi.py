@@ -22,12 +22,20 @@ SYMBOLS = (
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
     "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan", "rbd_model_track_plan", "rbd_inverse_dynamics_bodies", "rbd_dynamics_bias_bodies",
     "rbd_model_reroot_plan", "rbd_model_contact_dims", "rbd_contact_dynamics", "rbd_dynamics_contact", "rbd_simulate_contact",
-    "rbd_experimental", "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_comm_last_error",
+    "rbd_experimental", "rbd_simulate_controlled", "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_comm_last_error",
 )
 
 
 class Opts(ctypes.Structure):
     _fields_ = [("layout", ctypes.c_int32), ("memory", ctypes.c_int32), ("algorithm", ctypes.c_int32), ("stabilization", ctypes.c_int32)]
+
+
+class Control(ctypes.Structure):  # rbd_control_t
+    _fields_ = [("kind", ctypes.c_int32), ("per_stage", ctypes.c_int32), ("tau", ctypes.c_void_p), ("q_des", ctypes.c_void_p), ("kp", ctypes.c_void_p),
+                ("kd", ctypes.c_void_p)]
+
+
+CONTROL_CONSTANT, CONTROL_TABLE, CONTROL_PD = 0, 1, 2
 
 
 class RBDError(RuntimeError):
@@ -84,6 +92,7 @@ def lib():
         L.rbd_kinematics.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_simulate.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.c_double, i32, ctypes.POINTER(Opts)]
         L.rbd_mk_stage.argtypes = [vp, i32, i32, ctypes.c_double, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_simulate_controlled.argtypes = [vp, i32, vp, vp, ctypes.POINTER(Control), vp, ctypes.c_double, i32, ctypes.POINTER(Opts)]
         L.rbd_model_reroot_plan.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), i32, ctypes.POINTER(ctypes.c_double), i32, ctypes.POINTER(i32), i32,
                                             ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.rbd_model_contact_dims.argtypes = [vp] + [ctypes.POINTER(i32)] * 3

@@ -489,6 +489,8 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
     }
     mk_stage_lane(r0.b, F.stage, (T)F.dt, qj0, vj0, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
     mk_stage_lane(r1.b, F.stage, (T)F.dt, qj1, vj1, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
+    pd_control_lane(r0.b, F, Lq, qj0, vj0, r0.tj);
+    pd_control_lane(r1.b, F, Lq, qj1, vj1, r1.tj);
   }
   {
     T XR[9], Xp[3], tl[6], ta[4];

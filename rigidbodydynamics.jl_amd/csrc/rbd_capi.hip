@@ -123,6 +123,7 @@ struct rbd_ws {
   void* d_body = nullptr; void* d_scratch = nullptr; size_t d_body_bytes = 0, d_scratch_bytes = 0;
   void* d_loop_i = nullptr; void* d_loop_r = nullptr; void* d_loop_path = nullptr; void* d_jt_ref = nullptr; void* d_voff_ref = nullptr; void* d_axis_ref = nullptr; void* d_axis2_ref = nullptr;
   MkBuffers mk{}; void* d_vdwork = nullptr; size_t mk_elems = 0;  // Munthe-Kaas integrator scratch (lazy)
+  void* d_tauwork = nullptr; size_t d_tauwork_bytes = 0;  // torques of the device-side PD controller (un-fused integrator path)
   int* d_notpd = nullptr;  // device flag: some state's mass matrix was not positive definite (checked by rbd_sync)
   int32_t result_layout = RBD_LAYOUT_SOA; int32_t result_B = 0;
   // timing
@@ -816,7 +817,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -1341,53 +1342,73 @@ int rbd_mk_stage(rbd_ws_t* w, int32_t B, int32_t stage, double dt, void* q, void
   return RBD_OK;
 }
 
-int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, const void* fext, double dt, int32_t nsteps, const rbd_opts_t* opts) {
+// simulate with a controller descriptor (rbd_simulate: constant τ)
+static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_control_t& ctl, const void* fext, double dt, int32_t nsteps, const rbd_opts_t* opts) {
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
   if (!q || !v || nsteps < 0 || !(dt > 0)) return RBD_ERR_INVALID_ARGUMENT;
   if (w->model->ncp > 0 && w->model->nhs > 0) return RBD_ERR_UNSUPPORTED;  // contact points: rbd_simulate_contact (carries the additional state)
+  if (ctl.kind != RBD_CONTROL_CONSTANT && (o.memory != RBD_MEM_DEVICE || w->model->nloops > 0)) return RBD_ERR_UNSUPPORTED;
+  if (ctl.kind == RBD_CONTROL_TABLE && !ctl.tau) return RBD_ERR_INVALID_ARGUMENT;
+  if (ctl.kind == RBD_CONTROL_PD && (!ctl.kp || !ctl.kd)) return RBD_ERR_INVALID_ARGUMENT;
+  if (ctl.kind < RBD_CONTROL_CONSTANT || ctl.kind > RBD_CONTROL_PD) return RBD_ERR_INVALID_ARGUMENT;
   if (B == 0 || nsteps == 0) return RBD_OK;
   HIP_TRY(hipSetDevice(w->device));
   const rbd_model* m = w->model;
   const size_t es = esize(w);
   void *dq = q, *dv = v;
-  const void *dtau = tau, *df = fext;
+  const void *dtau = ctl.tau, *df = fext;
   if (o.memory == RBD_MEM_HOST) {
     const void *cq, *cv;
     if ((st = stage_in(w, 0, q, es * m->nq * B, &cq)) || (st = stage_in(w, 1, v, es * m->nv * B, &cv)) ||
-        (st = stage_in(w, 2, tau, es * m->nv * B, &dtau)) || (st = stage_in(w, 3, fext, es * 6 * m->nb * B, &df)))
+        (st = stage_in(w, 2, ctl.tau, es * m->nv * B, &dtau)) || (st = stage_in(w, 3, fext, es * 6 * m->nb * B, &df)))
       return st;
     dq = const_cast<void*>(cq); dv = const_cast<void*>(cv);
   }
   if ((st = mk_ensure(w, B))) return st;
   Opts od = o; od.memory = RBD_MEM_DEVICE;
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B);
+  // the torques of (step, stage): constant / PD feed-forward, or an entry of the table
+  const size_t entry = es * (size_t)m->nv * B;
+  auto tau_at = [&](int step, int stage) -> const void* {
+    if (ctl.kind != RBD_CONTROL_TABLE) return dtau;
+    return (const char*)dtau + entry * (size_t)(ctl.per_stage ? 4 * step + stage : step);
+  };
+  const bool pd = ctl.kind == RBD_CONTROL_PD;
   // large batches: the walk kernel (one wavefront per track, §3.4 of DESIGN.md) with the stage bookkeeping in its own launches beats the
   // lane-per-body kernels with the stage fused in (fp64 Atlas, 65 536 states: 4 x 147 us + 5 stage launches vs 4 x 290 us)
   const bool walk_sim = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && m->track.ok && m->walk.ok && w->walk_lds_bytes > 0 && B >= w->walk_min_batch;
   const bool fused = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && !walk_sim;
   const Layout Lf = layout_of(o.layout, 6L * m->nb, B);
   for (int step = 0; fused && step < nsteps; ++step) {
-    // tree mechanism, articulated-body route: each of the four stages is ONE launch (stage bookkeeping fused into aba_kernel)
-    // (the closing stage of a step rides in the first launch of the next one; only the last step needs its own closing launch)
+    // tree mechanism, articulated-body route: each of the four stages is ONE launch (stage bookkeeping — and the PD law, on the stage state —
+    // fused into the ABA kernel; the closing stage of a step rides in the first launch of the next one; only the last step closes on its own)
     for (int stage = 0; stage < 4; ++stage) {
       MkFuse F{};
       F.stage = stage; F.close_prev = (stage == 0 && step > 0) ? 1 : 0; F.dt = dt; F.W = w->mk; F.q_state = dq; F.v_state = dv;
-      if ((st = run_aba(w, B, RBD_ALGO_ABA, dq, dv, dtau, df, nullptr, nullptr, Lq, Lv, Lf, nullptr, &F))) return st;
+      if (pd) { F.pd_kp = ctl.kp; F.pd_kd = ctl.kd; F.pd_qdes = ctl.q_des; }
+      if ((st = run_aba(w, B, RBD_ALGO_ABA, dq, dv, tau_at(step, stage), df, nullptr, nullptr, Lq, Lv, Lf, nullptr, &F))) return st;
     }
     if (step == nsteps - 1) {
       if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, 4, dt, dq, dv, nullptr, w->mk, Lq, Lv, w->stream));
       else HIP_TRY(launch_mk_stage<float>(w->dm, B, 4, dt, dq, dv, nullptr, w->mk, Lq, Lv, w->stream));
     }
   }
+  if (!fused && pd && (st = ensure(&w->d_tauwork, &w->d_tauwork_bytes, entry))) return st;
   for (int step = 0; !fused && step < nsteps; ++step) {
     // the closing stage of a step rides in the stage-0 launch of the next one (as in the fused kernels); only the last step closes on its own
     for (int stage = 0; stage < 4; ++stage) {
       const int close_prev = (stage == 0 && step > 0) ? 1 : 0;
       if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream, close_prev));
       else HIP_TRY(launch_mk_stage<float>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream, close_prev));
-      if ((st = run_dynamics(w, B, od, dq, dv, dtau, df, w->d_vdwork, nullptr, nullptr))) return st;
+      const void* ts = tau_at(step, stage);
+      if (pd) {  // the PD law on the stage state the launch above left in (q, v): one element-wise launch, no host round trip
+        if (w->dtype == RBD_F64) HIP_TRY(launch_pd_control<double>(w->dm, B, dq, dv, ts, ctl.q_des, ctl.kp, ctl.kd, w->d_tauwork, Lq, Lv, w->stream));
+        else HIP_TRY(launch_pd_control<float>(w->dm, B, dq, dv, ts, ctl.q_des, ctl.kp, ctl.kd, w->d_tauwork, Lq, Lv, w->stream));
+        ts = w->d_tauwork;
+      }
+      if ((st = run_dynamics(w, B, od, dq, dv, ts, df, w->d_vdwork, nullptr, nullptr))) return st;
     }
     if (step == nsteps - 1) {
       if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, 4, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));
@@ -1398,6 +1419,17 @@ int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, cons
     if ((st = stage_out_copy(w, q, dq, es * m->nq * B)) || (st = stage_out_copy(w, v, dv, es * m->nv * B))) return st;
   }
   return RBD_OK;
+}
+int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, const void* fext, double dt, int32_t nsteps, const rbd_opts_t* opts) {
+  rbd_control_t ctl{};
+  ctl.kind = RBD_CONTROL_CONSTANT;
+  ctl.tau = tau;
+  return simulate_core(w, B, q, v, ctl, fext, dt, nsteps, opts);
+}
+int rbd_simulate_controlled(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_control_t* control, const void* fext, double dt, int32_t nsteps,
+                            const rbd_opts_t* opts) {
+  if (!control) return RBD_ERR_INVALID_ARGUMENT;
+  return simulate_core(w, B, q, v, *control, fext, dt, nsteps, opts);
 }
 
 

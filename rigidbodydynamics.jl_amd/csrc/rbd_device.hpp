@@ -183,6 +183,8 @@ struct MkFuse {
   double dt;
   MkBuffers W;
   void* q_state; void* v_state;
+  // device-side PD controller (rbd_simulate_controlled, RBD_CONTROL_PD): tau -= kp (q − q_des) + kd v on the 1-dof joints, on the stage state
+  const void* pd_kp; const void* pd_kd; const void* pd_qdes;  // [nv], [nv], nq x B (nullable); pd_kp == nullptr: off
 };
 
 #define RBD_DEV __device__ __forceinline__

@@ -32,6 +32,11 @@ hipError_t launch_mk_stage(const DevModel& M, long B, int stage, double dt, void
 }
 namespace rbd {
 template <typename T>
+hipError_t launch_pd_control(const DevModel& M, long B, const void* q, const void* v, const void* tau_ff, const void* qdes, const void* kp, const void* kd,
+                             void* tau_out, Layout Lq, Layout Lv, hipStream_t s);
+}
+namespace rbd {
+template <typename T>
 hipError_t launch_kin(const DevModel& M, long B, const void* q, const void* v, void* A, void* com, void* energy, void* J, uint64_t jplus,
                       uint64_t jminus, Layout Lq, Layout Lv, Layout La, Layout L3, Layout L2, hipStream_t s);
 }

@@ -59,6 +59,7 @@ void aba_kernel(DevModel M, long B, const T* q, const T* v, const T* __restrict_
     // step is closed first — its four stages combined into the new (q, v) — instead of by a launch of its own.
     if (F.close_prev) mk_stage_lane(b, 4, (T)F.dt, qj, vj, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
     mk_stage_lane(b, F.stage, (T)F.dt, qj, vj, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
+    pd_control_lane(b, F, Lq, qj, vj, tj);
   }
   store_qdot(b, qdot, Lq, qj, vj);
   RBD_DEBUG_STOP(1, qj[0] + vj[0] + tj[0]);
@@ -730,6 +731,38 @@ __global__ __launch_bounds__(256) void kin_kernel(DevModel M, long B, const T* _
 
 }  // namespace rbd
 namespace rbd {
+
+// PD controller of rbd_simulate_controlled for the un-fused integrator path (large batches: the walk kernel does not carry the stage): one
+// thread per (dof, state), tau_out = tau_ff − kp (q − q_des) − kd v on Revolute / Prismatic joints, tau_ff elsewhere
+template <typename T>
+__global__ __launch_bounds__(256) void pd_control_kernel(DevModel M, long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau_ff,
+                                                         const T* __restrict__ qdes, const T* __restrict__ kp, const T* __restrict__ kd, T* __restrict__ tau_out,
+                                                         Layout Lq, Layout Lv) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M.nv * B) return;
+  // consecutive threads walk the fastest-varying index of the layout
+  const long r = Lv.sk == 1 ? i % M.nv : i / B, st = Lv.sk == 1 ? i / M.nv : i % B;
+  const long a = r * Lv.sk + st * Lv.sb;
+  T t = tau_ff ? tau_ff[a] : T(0);
+  const int32_t* ib = M.ib + (long)M.dof_body[r] * IB_STRIDE;
+  const int jt = ib[IB_JTYPE];
+  if (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_PRISMATIC) {
+    const long qa = (long)ib[IB_QOFF] * Lq.sk + st * Lq.sb;
+    t -= kp[r] * (q[qa] - (qdes ? qdes[qa] : T(0))) + kd[r] * v[a];
+  }
+  tau_out[a] = t;
+}
+template <typename T>
+hipError_t launch_pd_control(const DevModel& M, long B, const void* q, const void* v, const void* tau_ff, const void* qdes, const void* kp, const void* kd,
+                             void* tau_out, Layout Lq, Layout Lv, hipStream_t s) {
+  const long n = (long)M.nv * B;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(pd_control_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)tau_ff, (const T*)qdes,
+                     (const T*)kp, (const T*)kd, (T*)tau_out, Lq, Lv);
+  return hipGetLastError();
+}
+template hipError_t launch_pd_control<double>(const DevModel&, long, const void*, const void*, const void*, const void*, const void*, const void*, void*, Layout, Layout, hipStream_t);
+template hipError_t launch_pd_control<float>(const DevModel&, long, const void*, const void*, const void*, const void*, const void*, const void*, void*, Layout, Layout, hipStream_t);
 
 // ---- launchers -----------------------------------------------------------------------------
 static inline dim3 grid_for(const DevModel& M, long B, int block) {

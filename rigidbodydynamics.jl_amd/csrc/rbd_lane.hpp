@@ -289,4 +289,15 @@ RBD_DEV void sweep_kinematics(const DevModel& M, const Body<T>& b, const T* XR, 
 }
 
 }  // namespace rbd
+namespace rbd {
+// PD law of rbd_simulate_controlled on one lane's joint (stage state qj, vj): tau -= kp (q − q_des) + kd v for Revolute / Prismatic joints
+template <typename T> RBD_DEV void pd_control_lane(const Body<T>& b, const MkFuse& F, Layout Lq, const T* qj, const T* vj, T* tj) {
+  if (F.pd_kp == nullptr) return;  // uniform
+  if (b.valid && (b.jtype == RBD_JOINT_REVOLUTE || b.jtype == RBD_JOINT_PRISMATIC)) {
+    const T kp = ((const T*)F.pd_kp)[b.voff], kd = ((const T*)F.pd_kd)[b.voff];
+    const T qd = F.pd_qdes ? ((const T*)F.pd_qdes)[(long)b.qoff * Lq.sk + b.state * Lq.sb] : T(0);
+    tj[0] -= kp * (qj[0] - qd) + kd * vj[0];
+  }
+}
+}  // namespace rbd
 #include "rbd_integrator.hpp"

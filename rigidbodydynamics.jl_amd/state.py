@@ -388,6 +388,23 @@ def last_kernel(state: MechanismState) -> str:
 RK4_C = (0.0, 0.5, 0.5, 1.0)  # c = row sums of the runge_kutta_4 tableau (src/ode_integrators.jl:48-55)
 
 
+class TorqueTable:
+    """Device-side open-loop controller for `simulate_`: `torques[k]` is the (B, nv) torque of entry k — entry 4·step + stage with
+    `per_stage=True` (the stage times t, t + h/2, t + h/2, t + h at which the reference calls control!(τ, t, state), src/simulate.jl:42-48), entry
+    `step` otherwise (zero-order hold).  No host round trip per stage (`rbd_simulate_controlled`, RBD_CONTROL_TABLE)."""
+
+    def __init__(self, torques: torch.Tensor, per_stage: bool = True):
+        self.torques, self.per_stage = torques, bool(per_stage)
+
+
+class PDControl:
+    """Device-side PD controller for `simulate_`: τ_i = torques_i − kp_i (q_i − q_des_i) − kd_i v_i on every Revolute / Prismatic joint, evaluated on the
+    stage state inside the dynamics launch (`rbd_simulate_controlled`, RBD_CONTROL_PD).  kp, kd: (nv,) tensors; q_des: (B, nq) or None (zero)."""
+
+    def __init__(self, kp: torch.Tensor, kd: torch.Tensor, q_des: Optional[torch.Tensor] = None, torques: Optional[torch.Tensor] = None):
+        self.kp, self.kd, self.q_des, self.torques = kp, kd, q_des, torques
+
+
 def simulate_(state: MechanismState, final_time: float, control_=None, dt: float = 1e-4, torques: Optional[torch.Tensor] = None,
               externalwrenches: Optional[torch.Tensor] = None, stabilization_gains="default", store: bool = False):
     """`simulate(state0, final_time, control!; Δt, stabilization_gains)` (src/simulate.jl:36-55) for a whole batch in lockstep:
@@ -421,7 +438,35 @@ def simulate_(state: MechanismState, final_time: float, control_=None, dt: float
             if store:
                 qs.append(state.q.clone()); vs.append(state.v.clone()); ss.append(state.s.clone())
         return (np.array(ts), qs, vs, ss) if store else np.array(ts)
-    if control_ is None and not store:
+    if isinstance(control_, (TorqueTable, PDControl)):
+        if torques is not None:
+            raise ValueError("pass the torques through the controller object")
+        ctl = _capi.Control()
+        if isinstance(control_, TorqueTable):
+            per = 4 if control_.per_stage else 1
+            tt = control_.torques
+            if tt.dtype != state.dtype or not tt.is_cuda or not tt.is_contiguous() or tt.dim() != 3 or tt.shape[0] < per * nsteps:
+                raise DimensionMismatch(f"TorqueTable needs a contiguous device tensor of at least {per * nsteps} entries of the batch's (B, nv) shape")
+            state._check(tt[0], f.nv, "torque table entry")
+            ctl.kind, ctl.per_stage, ctl.tau = _capi.CONTROL_TABLE, int(control_.per_stage), tt.data_ptr()
+            keep = (tt,)
+        else:
+            kp = control_.kp.to(device=state.device, dtype=state.dtype).contiguous()
+            kd = control_.kd.to(device=state.device, dtype=state.dtype).contiguous()
+            if tuple(kp.shape) != (f.nv,) or tuple(kd.shape) != (f.nv,):
+                raise DimensionMismatch(f"PDControl gains must be ({f.nv},)")
+            state._check(control_.q_des, f.nq, "q_des")
+            state._check(control_.torques, f.nv, "torques")
+            ctl.kind, ctl.kp, ctl.kd = _capi.CONTROL_PD, kp.data_ptr(), kd.data_ptr()
+            ctl.q_des = control_.q_des.data_ptr() if control_.q_des is not None else None
+            ctl.tau = control_.torques.data_ptr() if control_.torques is not None else None
+            keep = (kp, kd)
+        if store:
+            raise NotImplementedError("store=True with a device-side controller: call simulate_ once per step")
+        _raise(L.rbd_simulate_controlled(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), ctypes.byref(ctl), _ptr(externalwrenches),
+                                         ctypes.c_double(dt), nsteps, ctypes.byref(opts)), "rbd_simulate_controlled")
+        del keep
+    elif control_ is None and not store:
         _raise(L.rbd_simulate(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
                               ctypes.c_double(dt), nsteps, ctypes.byref(opts)), "rbd_simulate")
     elif control_ is None:

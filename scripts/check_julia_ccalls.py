@@ -81,7 +81,7 @@ def julia_ccalls():
 
 
 STRUCTS = {"RbdLoopJoint": "rbd_loop_joint_t", "RbdContactPoint": "rbd_contact_point_t", "RbdHalfSpace": "rbd_halfspace_t",
-           "RbdFlatModel": "rbd_flat_model_t", "RbdOpts": "rbd_opts_t"}
+           "RbdFlatModel": "rbd_flat_model_t", "RbdOpts": "rbd_opts_t", "RbdControl": "rbd_control_t"}
 
 
 def header_struct_fields():

@@ -480,6 +480,49 @@ def test_simulate_with_controller_and_store(rbd, oracle, models):
     assert torch.equal(qs[-1], state.q)
 
 
+@pytest.mark.parametrize("path", ["fused", "unfused"])
+def test_simulate_device_side_controllers(rbd, oracle, models, path, monkeypatch):
+    """simulate(state, T, control!) without the per-stage host round trip (round-2 review): an open-loop τ(t) table sampled at the four stage
+    times control! is called with (src/simulate.jl:42-48, ode_integrators.jl:48-55) and a PD law evaluated on the stage state inside the
+    dynamics launch — against the numpy Munthe-Kaas restatement driving the same controllers.  `fused`: the stage rides in the lane-per-body
+    ABA launches; `unfused`: the large-batch arrangement (stage kernel, element-wise PD kernel, walk kernel), forced at a small batch."""
+    import simulate_np
+    if path == "unfused":
+        monkeypatch.setenv("RBD_WALK_MIN_BATCH", "1")  # read when the workspace is created
+    model = models["atlas_fixed"]
+    B, dt, T = 5, 2e-3, 0.0075
+    nsteps = 4
+    q, v, _ = rand_inputs(rbd, model, B, 57)
+    rng = np.random.default_rng(58)
+    # ---- table, per stage: τ(t) = A sin(ω t + φ) per dof and state
+    A, om, ph = rng.random((B, model.nv)), 40 * rng.random((B, model.nv)), rng.random((B, model.nv))
+    tau_of = lambda b, t: A[b] * np.sin(om[b] * t + ph[b])
+    stage_t = np.array([k * dt + c * dt for k in range(nsteps) for c in (0.0, 0.5, 0.5, 1.0)])
+    table = np.stack([A * np.sin(om * t + ph) for t in stage_t])  # (4 nsteps, B, nv)
+    state = rbd.MechanismState(model, B)
+    rbd.set_configuration_(state, q); rbd.set_velocity_(state, v)
+    rbd.simulate_(state, T, control_=rbd.TorqueTable(torch.as_tensor(table).cuda(), per_stage=True), dt=dt)
+    _, q_ref, v_ref = simulate_np.simulate(model, q, v, T, dt, control=lambda b, t, qq, vv: tau_of(b, t))
+    assert np.abs(host(state.q, state) - q_ref).max() <= 1e-10 and np.abs(host(state.v, state) - v_ref).max() <= 1e-9
+    # zero-order hold: one entry per step
+    rbd.set_configuration_(state, q); rbd.set_velocity_(state, v)
+    rbd.simulate_(state, T, control_=rbd.TorqueTable(torch.as_tensor(table[::4].copy()).cuda(), per_stage=False), dt=dt)
+    # (the hold's reference: the step index is known by construction, so integrate step by step with constant torques)
+    qh, vh = q.copy(), v.copy()
+    for k in range(nsteps):
+        _, qh, vh = simulate_np.simulate(model, qh, vh, dt / 2, dt, table[4 * k])
+    assert np.abs(host(state.q, state) - qh).max() <= 1e-10 and np.abs(host(state.v, state) - vh).max() <= 1e-9
+    # ---- PD law with a feed-forward term
+    kp, kd = 2 * rng.random(model.nv), 0.02 * rng.random(model.nv)  # (the wrist links have 4e-4 kg m^2 about their axes: stiff gains would need a smaller step)
+    qdes, tff = 0.3 * rng.standard_normal((B, model.nq)), rng.random((B, model.nv))
+    rbd.set_configuration_(state, q); rbd.set_velocity_(state, v)
+    rbd.simulate_(state, T, control_=rbd.PDControl(torch.as_tensor(kp), torch.as_tensor(kd), torch.as_tensor(qdes).cuda(), torch.as_tensor(tff).cuda()), dt=dt)
+    _, q_ref, v_ref = simulate_np.simulate(model, q, v, T, dt, control=lambda b, t, qq, vv: tff[b] - kp * (qq - qdes[b]) - kd * vv)
+    assert np.abs(host(state.q, state) - q_ref).max() <= 1e-10 and np.abs(host(state.v, state) - v_ref).max() <= 1e-9
+    k = rbd.last_kernel(state)
+    assert ("walk" in k) == (path == "unfused"), k
+
+
 def test_simulate_four_bar_loops(rbd, oracle, models):
     """The loop-joint branch inside the integrator: closure is kept (no stabilization) like test/test_simulate.jl:203-213, here
     for 0.1 s on the GPU, against the oracle's integration of the same states."""
