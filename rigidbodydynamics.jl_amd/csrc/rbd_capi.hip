@@ -1270,7 +1270,11 @@ int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs
         (st = stage_out_alloc(w, 4, x, es * m->nv * B, &dx)) || (st = stage_out_alloc(w, 6, M_out, mbytes, &dM)))
       return st;
   }
-  if (!dM && o.algorithm == RBD_ALGO_CRBA_CHOLESKY) {
+  // M_out == NULL: the caller wants x only.  The lane-per-state route (large batches) then skips the emission of M altogether — its factorization
+  // reads the staged triangle, and the whole-square store is 340 MB of the route's ~560 MB at 65 536 Atlas states; the other routes factor M in
+  // place and need a buffer of their own
+  const bool state_route = B >= w->state_min_batch && o.layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv);
+  if (!dM && o.algorithm == RBD_ALGO_CRBA_CHOLESKY && !state_route) {
     if ((st = ensure(&w->d_M, &w->d_M_bytes, mbytes))) return st;
     dM = w->d_M;
   }
