@@ -39,8 +39,6 @@ namespace rbd {
 
 template <typename T> struct alignas(2 * sizeof(T)) Pair2 { T a, b; };
 
-// an `if` whose body must stay a branch (exec mask), not be turned into selects by if-conversion
-#define RBD_KEEP_BRANCH() asm volatile("" ::)
 // LDS written by some lanes of the wavefront and read by others: same-wave LDS operations execute in order; this only stops the compiler
 RBD_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -130,17 +128,6 @@ template <typename T> RBD_DEV void load_bank_body(const BankModel& M, int k, lon
   b.child[0] = w1.w; b.child[1] = w2.x; b.child[2] = w2.y; b.child[3] = w2.z; b.child[4] = w2.w; b.child[5] = w3.x;
   b.flags = w3.y;
   b.plane = b.parent >= 0 ? b.base + b.parent : b.lane;  // parent slot (of the parent's bank) in this state's lane group
-}
-
-// top-down hop of N values (rnea_bank_kernel): lanes of `cb` read their parent's copy of x (the parent's bank register set)
-template <typename T, int N, bool CROSS> RBD_DEV void bank_pull(const BankModel& M, const Body<T>& cb, int l, const T* x, T* out) {
-  if (CROSS || ((M.perm_down >> l) & 1)) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) out[k] = shfl(x[k], cb.plane);
-  } else {
-#pragma unroll
-    for (int k = 0; k < N; ++k) out[k] = from_prev_lane(x[k]);
-  }
 }
 
 // ---- forward kinematics -------------------------------------------------------------------------------------------------------
@@ -612,36 +599,70 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Banked RNEA: inverse_dynamics! (vdot != nullptr) and dynamics_bias! (vdot == nullptr), src/mechanism_algorithms.jl:542-553,
-// :484-498 — the same two-bodies-per-lane mapping as aba_bank_kernel.  RNEA is sums only, so every tree joint type is in scope.
+// :484-498 — the same two-bodies-per-lane mapping as aba_bank_kernel.  RNEA is sums only, so every tree joint type is in scope;
+// SIMPLE (revolute joints + 6-dof joints on the world) drops the joint-type interpretation as in aba_bank_kernel.
+// The kinematics sweep carries K = (R 9, p 3, Tw 6, acc 6) per lane, committed by exec-masked moves; hops that are not "previous lane"
+// (later children, the hop between the banks) go through the LDS exchange columns.
 // ---------------------------------------------------------------------------------------------------------------------
+enum { RNEA_LDS_PAIRS = 12 };
 template <typename T> struct RneaRegs {
   Body<T> b;
   const T* rb;
-  T R[9], p[3], Tw[6], acc[6], w[6];
+  int pcol;
+  T K[24], w[6];
+  RBD_DEV T* R() { return K; }
+  RBD_DEV T* p() { return K + 9; }
+  RBD_DEV T* Tw() { return K + 12; }
+  RBD_DEV T* acc() { return K + 18; }
 };
 
-// kinematics step at level l with spatial accelerations (spatial_accelerations! :387-417): a_b = a_p + (-T_b) x T_p + X a_joint
-template <typename T, bool CROSS>
-RBD_DEV void rnea_fk_step(const BankModel& M, int l, const RneaRegs<T>& par, RneaRegs<T>& c, const T* XR, const T* Xp, const T* tl, const T* al) {
-  T pR[9], pp[3], pT[6], pa[6];
-  bank_pull<T, 9, CROSS>(M, c.b, l, par.R, pR);
-  bank_pull<T, 3, CROSS>(M, c.b, l, par.p, pp);
-  bank_pull<T, 6, CROSS>(M, c.b, l, par.Tw, pT);
-  bank_pull<T, 6, CROSS>(M, c.b, l, par.acc, pa);
-  if (c.b.level == l) {
-    matmul3(pR, XR, c.R);
-    matvec3(pR, Xp, c.p);
+// kinematics step with spatial accelerations (spatial_accelerations! :387-417): a_b = a_p + (-T_b) x T_p + X a_joint — computed by every lane
+// from the parent's values k24, committed in the lanes of `mine`
+// SIMPLE: tl = (axis, joint velocity, joint acceleration): joint twist and acceleration are S v, S v̇ with S = (R a; p x R a)
+template <typename T, bool SIMPLE>
+RBD_DEV void rnea_fk_commit(bool mine, RneaRegs<T>& c, const T* k24, const T* XR, const T* Xp, const T* tl, const T* al) {
+  const T* pR = k24;
+  const T* pp = k24 + 9;
+  const T* pT = k24 + 12;
+  const T* pa = k24 + 18;
+  T n[24], vJ[6], nT[6], cr[6], aj[6];
+  matmul3(pR, XR, n);
+  matvec3(pR, Xp, n + 9);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) c.p[k] += pp[k];
-    T vJ[6], nT[6], cr[6], aj[6];
-    xmotion(c.R, c.p, tl, vJ);
+  for (int k = 0; k < 3; ++k) n[9 + k] += pp[k];
+  if (SIMPLE) {
+    T S[6];
+    matvec3(n, tl, S);
+    cross3(n + 9, S, S + 3);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { c.Tw[k] = pT[k] + vJ[k]; nT[k] = -c.Tw[k]; }
-    se3_comm(nT, pT, cr);
-    xmotion(c.R, c.p, al, aj);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) c.acc[k] = pa[k] + cr[k] + aj[k];
+    for (int k = 0; k < 6; ++k) { vJ[k] = S[k] * tl[3]; aj[k] = S[k] * tl[4]; }
+  } else {
+    xmotion(n, n + 9, tl, vJ);
+    xmotion(n, n + 9, al, aj);
   }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { n[12 + k] = pT[k] + vJ[k]; nT[k] = -n[12 + k]; }
+  se3_comm(nT, pT, cr);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) n[18 + k] = pa[k] + cr[k] + aj[k];
+  massign<T, 24>(mine, c.K, n);
+}
+template <typename T, bool SIMPLE>
+RBD_DEV void rnea_fk_step(const BankModel& M, int l, RneaRegs<T>& c, Pair2<T>* lds, const T* XR, const T* Xp, const T* tl, const T* al) {
+  T k24[24];
+  if ((M.perm_down >> l) & 1) {  // uniform
+    if (c.b.level == l - 1 && c.b.nchild >= 1) {
+      RBD_KEEP_BRANCH();
+      lds_put<T, 24>(lds + threadIdx.x, 0, c.K);
+    }
+    wave_lds_sync();
+    lds_get<T, 24>(lds + c.pcol, 0, k24);
+    wave_lds_sync();
+  } else {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) k24[k] = from_prev_lane(c.K[k]);
+  }
+  rnea_fk_commit<T, SIMPLE>(c.b.level == l, c, k24, XR, Xp, tl, al);
 }
 
 // joint_wrenches_and_torques! (:442-459): lanes of `tk` at level l-1 add the wrenches of their children (lanes of `gv` at level l)
@@ -674,32 +695,103 @@ template <typename T, bool CROSS> RBD_DEV void rnea_gather(int l, int ns, const 
 
 // acc_out / jw_out (nullable): spatial accelerations of the bodies (spatial_accelerations! :387-417, the gravitational acceleration of
 // the root included, as result.accelerations holds them) and joint wrenches (:442-459), 6 x n_bodies x B in reference body order, root frame
-template <typename T>
+template <typename T, bool SIMPLE>
 __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, int ncol, const T* __restrict__ q, const T* __restrict__ v,
                                                           const T* __restrict__ vdot, const T* __restrict__ fext, T* __restrict__ tau,
                                                           T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T* __restrict__ acc_out,
                                                           T* __restrict__ jw_out) {
+  extern __shared__ double bank_lds_raw[];
+  Pair2<T>* const lds = reinterpret_cast<Pair2<T>*>(bank_lds_raw);
   RneaRegs<T> r0, r1;
   auto fetch = [&](int k, RneaRegs<T>& c, T* qj, T* vj, T* aj) {
     load_bank_body(M, k, B, c.b);
     c.rb = reinterpret_cast<const T*>(M.rb[k]) + (c.b.sub < M.nbk[k] ? c.b.sub : 0) * RB_STRIDE;
-    load_joint_q(c.b, q, Lq, qj);
-    load_joint_v(c.b, v, Lv, vj);
-    load_joint_v(c.b, vdot, Lv, aj);
+    c.pcol = (int)threadIdx.x - c.b.sub + (c.b.parent >= 0 ? c.b.parent : c.b.sub);
+    if (SIMPLE) {  // unconditional loads at clamped addresses (see aba_bank_kernel)
+      const bool fl = c.b.jtype == RBD_JOINT_QUAT_FLOATING;
+      const long sc = c.b.state < B ? c.b.state : B - 1;
+      const T* qp = q + ((long)c.b.qoff * Lq.sk + sc * Lq.sb);
+      const long va = (long)c.b.voff * Lv.sk + sc * Lv.sb;
+      const bool hv = v != nullptr, ha = vdot != nullptr;  // uniform
+      qj[0] = qp[0];
+      vj[0] = hv ? v[va] : T(0);
+      aj[0] = ha ? vdot[va] : T(0);
+#pragma unroll
+      for (int k2 = 1; k2 < 7; ++k2) qj[k2] = T(0);
+#pragma unroll
+      for (int k2 = 1; k2 < 6; ++k2) { vj[k2] = T(0); aj[k2] = T(0); }
+      if (fl) {
+        RBD_KEEP_BRANCH();
+#pragma unroll
+        for (int k2 = 1; k2 < 7; ++k2) qj[k2] = qp[k2 * Lq.sk];
+        if (hv) {
+#pragma unroll
+          for (int k2 = 1; k2 < 6; ++k2) vj[k2] = v[va + k2 * Lv.sk];
+        }
+        if (ha) {
+#pragma unroll
+          for (int k2 = 1; k2 < 6; ++k2) aj[k2] = vdot[va + k2 * Lv.sk];
+        }
+      }
+    } else {
+      load_joint_q(c.b, q, Lq, qj);
+      load_joint_v(c.b, v, Lv, vj);
+      load_joint_v(c.b, vdot, Lv, aj);
+    }
   };
-  auto setup = [&](RneaRegs<T>& c, const T* qj, const T* vj, const T* aj, T* XR, T* Xp, T* tl, T* al) {
-    store_qdot(c.b, qdot, Lq, qj, vj);
-    local_transform(c.b, c.rb, qj, XR, Xp);
-    local_joint_motion(c.b, c.rb, vj, tl);
-    local_joint_motion(c.b, c.rb, aj, al);  // joint_spatial_acceleration: S_local * v̇
+  auto setup = [&](RneaRegs<T>& c, const T* qj, const T* vj, const T* aj, T* XR, T* Xp, T* tl, T* al, T* ta) {
+    if (SIMPLE) {
+      const bool fl = c.b.jtype == RBD_JOINT_QUAT_FLOATING;
+      const T ax[3] = {c.rb[RB_AXIS], c.rb[RB_AXIS + 1], c.rb[RB_AXIS + 2]};
+      ta[0] = ax[0]; ta[1] = ax[1]; ta[2] = ax[2]; ta[3] = vj[0]; ta[4] = aj[0];
+      T Rj[9], pj[3] = {T(0), T(0), T(0)}, sn, cs;
+      sincos_fast(qj[0], &sn, &cs);
+      rot_axis_sc(ax, sn, cs, Rj);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { tl[k] = ax[k] * vj[0]; tl[3 + k] = T(0); al[k] = ax[k] * aj[0]; al[3 + k] = T(0); }
+      if (fl) {
+        RBD_KEEP_BRANCH();
+        rot_quat(qj[0], qj[1], qj[2], qj[3], Rj);
+        pj[0] = qj[4]; pj[1] = qj[5]; pj[2] = qj[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { tl[k] = vj[k]; al[k] = aj[k]; }
+        if (qdot != nullptr && c.b.valid) {
+          const T w = qj[0], x = qj[1], y = qj[2], z = qj[3];
+          T o[7];
+          o[0] = (-x * vj[0] - y * vj[1] - z * vj[2]) * T(0.5);
+          o[1] = (w * vj[0] - z * vj[1] + y * vj[2]) * T(0.5);
+          o[2] = (z * vj[0] + w * vj[1] - x * vj[2]) * T(0.5);
+          o[3] = (-y * vj[0] + x * vj[1] + w * vj[2]) * T(0.5);
+          matvec3(Rj, vj + 3, o + 4);
+#pragma unroll
+          for (int k = 0; k < 7; ++k) qdot[(long)(c.b.qoff + k) * Lq.sk + c.b.state * Lq.sb] = o[k];
+        }
+      } else if (qdot != nullptr && c.b.valid) {
+        qdot[(long)c.b.qoff * Lq.sk + c.b.state * Lq.sb] = vj[0];
+      }
+      T XpR[9], Xpp[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) XpR[k] = c.rb[RB_XPR + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Xpp[k] = c.rb[RB_XPP + k];
+      matmul3(XpR, Rj, XR);
+      matvec3(XpR, pj, Xp);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Xp[k] += Xpp[k];
+    } else {
+      store_qdot(c.b, qdot, Lq, qj, vj);
+      local_transform(c.b, c.rb, qj, XR, Xp);
+      local_joint_motion(c.b, c.rb, vj, tl);
+      local_joint_motion(c.b, c.rb, aj, al);  // joint_spatial_acceleration: S_local * v̇
+    }
     // as if at level 0: H = XL, T = vJ, a = -g + X a_joint; deeper lanes overwrite at their level
 #pragma unroll
-    for (int i = 0; i < 9; ++i) c.R[i] = XR[i];
+    for (int i = 0; i < 9; ++i) c.R()[i] = XR[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) c.p[i] = Xp[i];
-    xmotion(c.R, c.p, tl, c.Tw);
-    xmotion(c.R, c.p, al, c.acc);
-    c.acc[3] -= T(M.gravity[0]); c.acc[4] -= T(M.gravity[1]); c.acc[5] -= T(M.gravity[2]);
+    for (int i = 0; i < 3; ++i) c.p()[i] = Xp[i];
+    xmotion(c.R(), c.p(), tl, c.Tw());
+    xmotion(c.R(), c.p(), al, c.acc());
+    c.acc()[3] -= T(M.gravity[0]); c.acc()[4] -= T(M.gravity[1]); c.acc()[5] -= T(M.gravity[2]);
   };
   // newton_euler! (:428-439): w = I a + T x* I T - wext
   auto newton_euler = [&](RneaRegs<T>& c) {
@@ -709,27 +801,33 @@ __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, 
     for (int k = 0; k < 6; ++k) Jb[k] = c.rb[RB_J + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) mc[k] = c.rb[RB_MC + k];
-    inertia_to_root(Jb, mc, c.rb[RB_M], c.R, c.p, I);
-    mul_inertia(I, c.acc, Ia);
-    momentum_cross(I, c.Tw, x);
+    inertia_to_root(Jb, mc, c.rb[RB_M], c.R(), c.p(), I);
+    mul_inertia(I, c.acc(), Ia);
+    momentum_cross(I, c.Tw(), x);
     load_body_wrench(c.b, fext, Lf, fe);
 #pragma unroll
     for (int k = 0; k < 6; ++k) c.w[k] = Ia[k] + x[k] - fe[k];
     if (acc_out != nullptr && c.b.valid) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) acc_out[(long)(6 * c.b.orig + k) * Lf.sk + c.b.state * Lf.sb] = c.acc[k];
+      for (int k = 0; k < 6; ++k) acc_out[(long)(6 * c.b.orig + k) * Lf.sk + c.b.state * Lf.sb] = c.acc()[k];
     }
   };
   auto project = [&](RneaRegs<T>& c) {  // tau = S' w
     T out[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     if (c.b.jtype == RBD_JOINT_QUAT_FLOATING) {
-      xforce_inv(c.R, c.p, c.w, out);
+      xforce_inv(c.R(), c.p(), c.w, out);
+    } else if (SIMPLE) {  // S = (R a; p x R a)
+      const T ax[3] = {c.rb[RB_AXIS], c.rb[RB_AXIS + 1], c.rb[RB_AXIS + 2]};
+      T S[6];
+      matvec3(c.R(), ax, S);
+      cross3(c.p(), S, S + 3);
+      out[0] = dot6(S, c.w);
     } else {
       const T ax[3] = {c.rb[RB_AXIS], c.rb[RB_AXIS + 1], c.rb[RB_AXIS + 2]}, ay[3] = {c.rb[RB_AXIS2], c.rb[RB_AXIS2 + 1], c.rb[RB_AXIS2 + 2]};
       for (int k = 0; k < ncol; ++k) {  // ncol (uniform): 3 when the mechanism has QuaternionSpherical / Planar joints, else 1
         T sl[6], S[6];
         subspace_col(c.b.jtype, ax, ay, k, sl);
-        xmotion(c.R, c.p, sl, S);
+        xmotion(c.R(), c.p(), sl, S);
         const T d = dot6(S, c.w);
         if (k == 0) out[0] = d; else if (k == 1) out[1] = d; else out[2] = d;
       }
@@ -745,17 +843,24 @@ __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, 
   fetch(0, r0, qj0, vj0, aj0);
   fetch(1, r1, qj1, vj1, aj1);
   {
-    T XR[9], Xp[3], tl[6], al[6];
-    setup(r0, qj0, vj0, aj0, XR, Xp, tl, al);
+    T XR[9], Xp[3], tl[6], al[6], ta[5];
+    setup(r0, qj0, vj0, aj0, XR, Xp, tl, al, ta);
 #pragma unroll 1
-    for (int l = 1; l < M.L0; ++l) rnea_fk_step<T, false>(M, l, r0, r0, XR, Xp, tl, al);
+    for (int l = 1; l < M.L0; ++l) rnea_fk_step<T, SIMPLE>(M, l, r0, lds, XR, Xp, SIMPLE ? ta : tl, al);
   }
   {
-    T XR[9], Xp[3], tl[6], al[6];
-    setup(r1, qj1, vj1, aj1, XR, Xp, tl, al);
-    rnea_fk_step<T, true>(M, M.L0, r0, r1, XR, Xp, tl, al);
+    T XR[9], Xp[3], tl[6], al[6], ta[5];
+    setup(r1, qj1, vj1, aj1, XR, Xp, tl, al, ta);
+    {  // across the banks: every bank-0 lane leaves its kinematics in its exchange column, the bodies of level L0 read their parent's
+      T k24[24];
+      lds_put<T, 24>(lds + threadIdx.x, 0, r0.K);
+      wave_lds_sync();
+      lds_get<T, 24>(lds + r1.pcol, 0, k24);
+      wave_lds_sync();
+      rnea_fk_commit<T, SIMPLE>(r1.b.level == M.L0, r1, k24, XR, Xp, SIMPLE ? ta : tl, al);
+    }
 #pragma unroll 1
-    for (int l = M.L0 + 1; l < M.nlevels; ++l) rnea_fk_step<T, false>(M, l, r1, r1, XR, Xp, tl, al);
+    for (int l = M.L0 + 1; l < M.nlevels; ++l) rnea_fk_step<T, SIMPLE>(M, l, r1, lds, XR, Xp, SIMPLE ? ta : tl, al);
   }
   newton_euler(r1);
   newton_euler(r0);

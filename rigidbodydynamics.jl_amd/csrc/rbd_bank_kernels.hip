@@ -50,8 +50,13 @@ template <typename T>
 hipError_t launch_rnea_bank(const BankModel& M, long B, int ncol, const void* q, const void* v, const void* vdot, const void* fext, void* tau, void* qdot,
                             Layout Lq, Layout Lv, Layout Lf, hipStream_t s, void* acc_out, void* jw_out) {
   const long spw = 64 / M.lps, waves = (B + spw - 1) / spw;
-  hipLaunchKernelGGL(rnea_bank_kernel<T>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, M, B, ncol, (const T*)q, (const T*)v, (const T*)vdot,
-                     (const T*)fext, (T*)tau, (T*)qdot, Lq, Lv, Lf, (T*)acc_out, (T*)jw_out);
+  const size_t lds = (size_t)RNEA_LDS_PAIRS * 256 * sizeof(Pair2<T>);  // exchange columns: 48 KB in fp64 (the default dynamic-LDS limit is 64 KB)
+  if (M.simple)
+    hipLaunchKernelGGL((rnea_bank_kernel<T, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, M, B, ncol, (const T*)q, (const T*)v, (const T*)vdot,
+                       (const T*)fext, (T*)tau, (T*)qdot, Lq, Lv, Lf, (T*)acc_out, (T*)jw_out);
+  else
+    hipLaunchKernelGGL((rnea_bank_kernel<T, false>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, s, M, B, ncol, (const T*)q, (const T*)v, (const T*)vdot,
+                       (const T*)fext, (T*)tau, (T*)qdot, Lq, Lv, Lf, (T*)acc_out, (T*)jw_out);
   return hipGetLastError();
 }
 template hipError_t launch_rnea_bank<double>(const BankModel&, long, int, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t, void*, void*);

@@ -215,6 +215,14 @@ template <typename T> RBD_DEV T from_next_lane(T x) { return dpp_mov<0x130>(x); 
 // states in one wavefront the neighbour can belong to ANOTHER state, and NaN * 0 = NaN let one diverged state poison the state packed
 // next to it.  A select keeps the states of a batch independent, as they are in the reference (one evaluation per call).
 template <typename T> RBD_HD T keep(T x, T mask) { return mask != T(0) ? x : T(0); }
+// An `if` whose body must stay a branch (exec mask) and not be turned into selects by if-conversion: what a lane TAKES from another lane is added
+// under the lane's own exec mask — `if (takes) { RBD_KEEP_BRANCH(); acc += moved; }` — which keeps the states of a wavefront independent (no
+// arithmetic ever touches a value the lane does not own) without the two v_cndmask per fp64 value that keep() costs (round 3).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RBD_KEEP_BRANCH() asm volatile("" ::)
+#else
+#define RBD_KEEP_BRANCH()
+#endif
 
 template <typename T> RBD_HD void cross3(const T* a, const T* b, T* o) {
   T x = a[1] * b[2] - a[2] * b[1];

@@ -173,7 +173,7 @@ void aba_kernel(DevModel M, long B, const T* q, const T* v, const T* __restrict_
     // next lane (DPP shift); further children (branch points only) re-form the entries and pull them with ds_bpermute.
     // Givers sit at level l (mask 0: their own IA/pA are untouched), takers at level l-1.
     const T kI = (INNER_FLOAT && inner_floating) ? T(0) : T(1);
-    const T m0 = ((b.level == l - 1) && (b.nchild >= 1)) ? T(1) : T(0);
+    const bool take0 = (b.level == l - 1) && (b.nchild >= 1);
     T W[NDOF][6];  // W = U D^-1
 #pragma unroll
     for (int k = 0; k < NDOF; ++k)
@@ -184,55 +184,73 @@ void aba_kernel(DevModel M, long B, const T* q, const T* v, const T* __restrict_
         for (int m = 0; m < NDOF; ++m) w += U[m][i] * Dinv[DI(k, m, NDOF)];
         W[k][i] = w;
       }
+    auto entry = [&](int i, int j) {  // (Ia)_ij = IA_ij - sum_k W_k,i U_k,j
+      T g = IA[SI(i, j)];
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) g -= W[k][i] * U[k][j];
+      if (INNER_FLOAT) g *= kI;
+      return g;
+    };
     T Iac[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    // the first child is the next lane: row by row, formed, shifted, and added under the taker's exec mask
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
+      T h[6];
 #pragma unroll
       for (int j = i; j < 6; ++j) {
-        T g = IA[SI(i, j)];
-#pragma unroll
-        for (int k = 0; k < NDOF; ++k) g -= W[k][i] * U[k][j];
-        if (INNER_FLOAT) g *= kI;
+        const T g = entry(i, j);
         Iac[i] += g * cb[j];
         if (j > i) Iac[j] += g * cb[i];
-        IA[SI(i, j)] += keep(from_next_lane(g), m0);
+        h[j] = from_next_lane(g);
+      }
+      if (take0) {
+        RBD_KEEP_BRANCH();
+#pragma unroll
+        for (int j = i; j < 6; ++j) IA[SI(i, j)] += h[j];
       }
     }
     T gp[6];
+    {
+      T h[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      T x = pA[k] + Iac[k];
+      for (int k = 0; k < 6; ++k) {
+        T x = pA[k] + Iac[k];
 #pragma unroll
-      for (int m = 0; m < NDOF; ++m) x += W[m][k] * u[m];
-      gp[k] = x;
-      if (INNER_FLOAT) gp[k] = inner_floating ? U[0][k] : gp[k];
-      pA[k] += keep(from_next_lane(gp[k]), m0);
+        for (int m = 0; m < NDOF; ++m) x += W[m][k] * u[m];
+        gp[k] = x;
+        if (INNER_FLOAT) gp[k] = inner_floating ? U[0][k] : gp[k];
+        h[k] = from_next_lane(gp[k]);
+      }
+      if (take0) {
+        RBD_KEEP_BRANCH();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pA[k] += h[k];
+      }
     }
     const int ns = ns_next(nss, M.ns_desc);
 #pragma unroll 1
     for (int s = 1; s < ns; ++s) {
       const bool take = (b.level == l - 1) && (s < b.nchild);
       const int src = take ? b.base + child_sel(b, s) : b.lane;
-      const T mask = take ? T(1) : T(0);
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         T tmp[6];
 #pragma unroll
-        for (int j = i; j < 6; ++j) {
-          T g = IA[SI(i, j)];
+        for (int j = i; j < 6; ++j) tmp[j] = shfl(entry(i, j), src);
+        if (take) {
+          RBD_KEEP_BRANCH();
 #pragma unroll
-          for (int k = 0; k < NDOF; ++k) g -= W[k][i] * U[k][j];
-          if (INNER_FLOAT) g *= kI;
-          tmp[j] = shfl(g, src);
+          for (int j = i; j < 6; ++j) IA[SI(i, j)] += tmp[j];
         }
-#pragma unroll
-        for (int j = i; j < 6; ++j) IA[SI(i, j)] += keep(tmp[j], mask);
       }
       T tp[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) tp[k] = shfl(gp[k], src);
+      if (take) {
+        RBD_KEEP_BRANCH();
 #pragma unroll
-      for (int k = 0; k < 6; ++k) pA[k] += keep(tp[k], mask);
+        for (int k = 0; k < 6; ++k) pA[k] += tp[k];
+      }
     }
   }
   if (b.level == 0 && ndof > 0) finish_joint();
@@ -449,33 +467,40 @@ __global__ __launch_bounds__(256) void crba_kernel(DevModel M, long B, const T* 
 #pragma unroll 1
   for (int l = M.nlevels - 1; l >= 1; --l) {
     const bool takes = (b.level == l - 1);
-    const T m0 = (takes && b.nchild >= 1) ? T(1) : T(0);
-    T t[10];  // what this lane's children hand up (zero for lanes that take nothing at this step)
+    T t[10];  // what the first child (the next lane) hands up
 #pragma unroll
-    for (int k = 0; k < 6; ++k) t[k] = keep(from_next_lane(Ic.J[k]), m0);
+    for (int k = 0; k < 6; ++k) t[k] = from_next_lane(Ic.J[k]);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) t[6 + k] = keep(from_next_lane(Ic.c[k]), m0);
-    t[9] = keep(from_next_lane(Ic.m), m0);
+    for (int k = 0; k < 3; ++k) t[6 + k] = from_next_lane(Ic.c[k]);
+    t[9] = from_next_lane(Ic.m);
+    if (takes && b.nchild >= 1) {
+      RBD_KEEP_BRANCH();
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Ic.J[k] += t[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ic.c[k] += t[6 + k];
+      Ic.m += t[9];
+    }
     const int ns = ns_next(nss, M.ns_desc);
 #pragma unroll 1
     for (int s = 1; s < ns; ++s) {
       const bool take = takes && (s < b.nchild);
       const int src = take ? b.base + child_sel(b, s) : b.lane;
-      const T mask = take ? T(1) : T(0);
       T u[10];
 #pragma unroll
       for (int k = 0; k < 6; ++k) u[k] = shfl(Ic.J[k], src);
 #pragma unroll
       for (int k = 0; k < 3; ++k) u[6 + k] = shfl(Ic.c[k], src);
       u[9] = shfl(Ic.m, src);
+      if (take) {
+        RBD_KEEP_BRANCH();
 #pragma unroll
-      for (int k = 0; k < 10; ++k) t[k] += keep(u[k], mask);
+        for (int k = 0; k < 6; ++k) Ic.J[k] += u[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Ic.c[k] += u[6 + k];
+        Ic.m += u[9];
+      }
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Ic.J[k] += t[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) Ic.c[k] += t[6 + k];
-    Ic.m += t[9];
   }
   RBD_CMARK(3);
   const int jt = b.jtype;

@@ -34,14 +34,19 @@ template <typename T> RBD_DEV int child_sel(const Body<T>& b, int s) {
 }
 // Parents at level l-1 pull N values from their s-th child (all children of a parent sit at level l) and add them.
 // Slot 0 (first child == next lane in DFS pre-order) is a DPP wave shift; further children use ds_bpermute.
-// All moves are issued before any is consumed; non-takers add x*0 (x is always finite).
+// All moves are issued before any is consumed; only the takers add (under their exec mask).
 template <typename T, int N> RBD_DEV void gather_add(const Body<T>& b, int l, int s, const T* give, T* acc) {
   const bool take = (b.level == l - 1) && (s < b.nchild);
-  const T mask = take ? T(1) : T(0);
   constexpr int CH = 9;  // moves in flight per batch (bounds the temporaries)
   if (s == 0) {
+    T t[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) acc[k] += keep(from_next_lane(give[k]), mask);
+    for (int k = 0; k < N; ++k) t[k] = from_next_lane(give[k]);
+    if (take) {
+      RBD_KEEP_BRANCH();
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] += t[k];
+    }
   } else {
     const int c = child_sel(b, s);
     const int src = take ? b.base + c : b.lane;
@@ -51,9 +56,12 @@ template <typename T, int N> RBD_DEV void gather_add(const Body<T>& b, int l, in
 #pragma unroll
       for (int k = 0; k < CH; ++k)
         if (k0 + k < N) tmp[k] = shfl(give[k0 + k], src);
+      if (take) {
+        RBD_KEEP_BRANCH();
 #pragma unroll
-      for (int k = 0; k < CH; ++k)
-        if (k0 + k < N) acc[k0 + k] += keep(tmp[k], mask);
+        for (int k = 0; k < CH; ++k)
+          if (k0 + k < N) acc[k0 + k] += tmp[k];
+      }
     }
   }
 }
