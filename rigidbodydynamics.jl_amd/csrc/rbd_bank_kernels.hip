@@ -21,7 +21,7 @@ hipError_t launch_aba_bank(const BankModel& M, long B, const void* q, const void
   const size_t lds = bank_lds_bytes<T>();
 #define RBD_LAUNCH_BANK(FU, SI) \
   hipLaunchKernelGGL((aba_bank_kernel<T, FU, SI>), grid, block, lds, s, M, B, (const T*)q, (const T*)v, (const T*)tau, (const T*)fext, (T*)vdot, (T*)qdot, Lq, Lv, Lf, F)
-  if (F.stage >= 0) RBD_LAUNCH_BANK(true, false);
+  if (F.stage >= 0) { if (M.simple) RBD_LAUNCH_BANK(true, true); else RBD_LAUNCH_BANK(true, false); }
   else if (M.simple) RBD_LAUNCH_BANK(false, true);
   else RBD_LAUNCH_BANK(false, false);
 #undef RBD_LAUNCH_BANK
@@ -33,6 +33,7 @@ template <typename T> hipError_t configure_bank_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_bank_kernel<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_bank_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_bank_kernel<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aba_bank_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   return e;
 }
 template hipError_t configure_bank_kernels<double>();
