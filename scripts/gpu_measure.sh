@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 OUT=$R/gpurun_out/measure; rm -rf $OUT; mkdir -p $OUT $R/gpurun_out/profiles
 cd /tmp
 for C in $CONFIGS; do
-  SHORT="--config $C --no-cpu-baseline --no-pipelined --steps 60 --warmup 10"
+  SHORT="--config $C --no-cpu-baseline --no-pipelined --no-other-configs --steps 60 --warmup 10"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c$C -- python $R/bench.py $SHORT > $OUT/stats_c$C.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_c$C -- python $R/bench.py $SHORT > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_c$C -- python $R/bench.py $SHORT > /dev/null 2>&1
