@@ -420,8 +420,7 @@ def run(args, env):
                    "gather_every_step": bool(args.gather_every_step and world > 1), "inputs": "resident in HBM, re-evaluated every step (L2 / Infinity-Cache hits)"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
-                     "kernel": KERNELS.get(args.op) or ((L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode() if model.nc == 0 else
-                                                        "rnea_kernel + crba_kernel + loop_solve_small_kernel"),
+                     "kernel": KERNELS.get(args.op) or (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode(),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": alg_bytes},
         "alu": {"bound": "fp64 vector ALU" if args.dtype == "f64" else "fp32 vector ALU", "achieved": achieved_tf, "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": achieved_tf / peak_tf, "flops_per_eval": flops,

@@ -69,7 +69,8 @@ struct rbd_model {
   std::vector<uint64_t> row_mask;  // nv x row_words
   int32_t row_words = 1;
   std::vector<rbd_loop_joint_t> loops;
-  std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref, parent_ref;  // loop tables (reference body indices)
+  std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref, parent_ref, qoff_ref;  // loop tables (reference body indices)
+  bool loop_fused_ok = false;  // small enough, and only 1-dof / fixed tree joints with parents before children: loop_fused_small_kernel
   std::vector<double> loop_r, axis_ref, axis2_ref;
   // banked lane-per-body mapping (aba_bank_kernel): two bodies per lane, split at level bank_L0; bank_lps == 0: not applicable
   int32_t bank_lps = 0, bank_L0 = 0, bank_nb[2] = {0, 0}, bank_aba_ok = 0;
@@ -121,6 +122,7 @@ struct rbd_ws {
   void* d_M = nullptr; void* d_c = nullptr; void* d_K = nullptr; void* d_k = nullptr;
   size_t d_M_bytes = 0, d_c_bytes = 0, d_K_bytes = 0, d_k_bytes = 0;
   void* d_body = nullptr; void* d_scratch = nullptr; size_t d_body_bytes = 0, d_scratch_bytes = 0;
+  void* d_fused_i = nullptr;  // loop_fused_small_kernel: parent, q offset, slot by reference body index
   void* d_loop_i = nullptr; void* d_loop_r = nullptr; void* d_loop_path = nullptr; void* d_jt_ref = nullptr; void* d_voff_ref = nullptr; void* d_axis_ref = nullptr; void* d_axis2_ref = nullptr;
   MkBuffers mk{}; void* d_vdwork = nullptr; size_t mk_elems = 0;  // Munthe-Kaas integrator scratch (lazy)
   void* d_tauwork = nullptr; size_t d_tauwork_bytes = 0;  // torques of the device-side PD controller (un-fused integrator path)
@@ -295,6 +297,12 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   m->jt_ref.assign(d->joint_type, d->joint_type + nb);
   m->parent_ref.assign(d->parent, d->parent + nb);
   m->voff_ref.assign(d->v_offset, d->v_offset + nb);
+  m->qoff_ref.assign(d->q_offset, d->q_offset + nb);
+  m->loop_fused_ok = d->n_loops > 0 && nb <= 4 && m->nv <= 4;
+  for (int i = 0; i < nb && m->loop_fused_ok; ++i) {
+    const int t = d->joint_type[i];
+    m->loop_fused_ok = d->parent[i] < i && (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC || t == RBD_JOINT_SINCOS_REVOLUTE || t == RBD_JOINT_FIXED);
+  }
   m->axis_ref.assign(d->joint_axis, d->joint_axis + 3 * nb);
   if (d->joint_axis2) m->axis2_ref.assign(d->joint_axis2, d->joint_axis2 + 3 * nb); else m->axis2_ref.assign(3 * nb, 0.0);
   for (int l = 0; l < d->n_loops; ++l) {
@@ -574,6 +582,11 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     if (st == RBD_OK) st = upload(&w->d_loop_path, m->loop_path.data(), m->loop_path.size() * sizeof(int32_t));
     if (st == RBD_OK) st = upload(&w->d_jt_ref, m->jt_ref.data(), m->jt_ref.size() * sizeof(int32_t));
     if (st == RBD_OK) st = upload(&w->d_voff_ref, m->voff_ref.data(), m->voff_ref.size() * sizeof(int32_t));
+    if (st == RBD_OK && m->loop_fused_ok) {
+      std::vector<int32_t> xi(3 * (size_t)m->nb);
+      for (int i = 0; i < m->nb; ++i) { xi[3 * i] = m->parent_ref[i]; xi[3 * i + 1] = m->qoff_ref[i]; xi[3 * i + 2] = m->slot_of[i]; }
+      st = upload(&w->d_fused_i, xi.data(), xi.size() * sizeof(int32_t));
+    }
     if (st == RBD_OK) {
       if (dtype == RBD_F64) {
         st = upload(&w->d_loop_r, m->loop_r.data(), m->loop_r.size() * sizeof(double));
@@ -817,7 +830,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_fused_i, w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -967,11 +980,21 @@ int dynamics_loops_t(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const 
   V.nloops = m->nloops; V.nc = nc; V.nv = nv; V.nb = m->nb;
   V.li = (const int32_t*)w->d_loop_i; V.lr = (const T*)w->d_loop_r; V.path = (const int32_t*)w->d_loop_path;
   V.jt = (const int32_t*)w->d_jt_ref; V.voff = (const int32_t*)w->d_voff_ref; V.axis = (const T*)w->d_axis_ref; V.axis2 = (const T*)w->d_axis2_ref;
+  V.xi = (const int32_t*)w->d_fused_i; V.rb = (const T*)w->d_rb;
   Timed t(w);
+  static const bool no_fused = getenv("RBD_LOOP_NO_FUSED") != nullptr;  // tests: the three-launch route on a mechanism the fused kernel would take
+  if (m->loop_fused_ok && !no_fused &&
+      launch_loop_fused<T>(V, B, o.stabilization, dq, dv, dtau, df, w->d_body, w->d_M, w->d_c, dvd, dqd, dlam, w->d_K, w->d_k, Lq, Lm, Lv, Lf, Lc, Lk, m->gravity,
+                           w->d_notpd, w->stream)) {
+    HIP_TRY(hipGetLastError());
+    w->last_kernel = "loop_fused_small_kernel";
+    return RBD_OK;
+  }
   HIP_TRY(launch_rnea<T>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, w->d_body, Lq, Lv, Lf, w->stream));
   HIP_TRY(launch_crba<T>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
   HIP_TRY(launch_loop_solve<T>(V, B, o.stabilization, w->d_body, w->d_M, w->d_c, dtau, dvd, dlam, w->d_K, w->d_k, w->d_scratch, stride, Lm, Lv, Lc, Lk,
                                m->gravity, w->d_notpd, w->stream));
+  w->last_kernel = "rnea_kernel + crba_kernel + loop_solve kernel";
   return RBD_OK;
 }
 int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd, void* dlam) {

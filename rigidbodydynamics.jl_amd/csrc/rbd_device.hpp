@@ -167,6 +167,9 @@ template <typename T> struct LoopView {
   const int32_t* voff; // [nb]
   const T* axis;       // [nb*3]
   const T* axis2;      // [nb*3] (Planar y axis)
+  // loop_fused_small_kernel only: parent, q offset and DFS slot by reference body index, and the slot-ordered body constants (RB_*)
+  const int32_t* xi;   // [nb*3]
+  const T* rb;
 };
 
 // integrator scratch of mk_stage_kernel (same layout as the caller's q / v)

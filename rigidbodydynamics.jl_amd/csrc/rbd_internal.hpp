@@ -27,6 +27,12 @@ hipError_t launch_loop_solve(const LoopView<T>& V, long B, int stabilize, const 
 }
 namespace rbd {
 template <typename T>
+bool launch_loop_fused(const LoopView<T>& V, long B, int stabilize, const void* q, const void* v, const void* tau, const void* fext, void* body, void* M, void* c,
+                       void* vdot, void* qdot, void* lambda, void* K, void* k, Layout Lq, Layout Lm, Layout Lv, Layout Lf, Layout Lc, Layout Lk,
+                       const double* gravity, int* notpd, hipStream_t s);
+}
+namespace rbd {
+template <typename T>
 hipError_t launch_mk_stage(const DevModel& M, long B, int stage, double dt, void* q, void* v, const void* vdot_prev, const MkBuffers& W,
                            Layout Lq, Layout Lv, hipStream_t s, int close_prev = 0);
 }

@@ -1622,13 +1622,12 @@ __global__ __launch_bounds__(64) void loop_solve_kernel(LoopView<T> V, long B, i
 // is a fixed-size local array and every loop has a compile-time bound with an `i < nv` predicate, so the whole chain of dependent
 // small-matrix steps runs out of VGPRs instead of LDS/HBM work arrays.  Indices that are only known at run time (constraint row,
 // velocity column) are resolved by predicated writes over the compile-time range.
+// the per-state work of loop_solve_small_kernel; also the second half of loop_fused_small_kernel, where body / Mg / cg are what the same thread
+// has just written (hence no __restrict__ on them here)
 template <typename T, int NV, int NC>
-__global__ __launch_bounds__(64) void loop_solve_small_kernel(LoopView<T> V, long B, int stabilize, const T* __restrict__ body, const T* __restrict__ Mg,
-                                                              const T* __restrict__ cg, const T* __restrict__ tau, T* __restrict__ vdot,
-                                                              T* __restrict__ lambda, T* __restrict__ Kg, T* __restrict__ kg, Layout Lm, Layout Lv,
-                                                              Layout Lc, Layout Lk, double g0, double g1, double g2, int* __restrict__ notpd) {
-  const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (st >= B) return;
+RBD_DEV void loop_solve_small_state(const LoopView<T>& V, long st, int stabilize, const T* body, const T* Mg, const T* cg, const T* __restrict__ tau,
+                                    T* __restrict__ vdot, T* __restrict__ lambda, T* __restrict__ Kg, T* __restrict__ kg, Layout Lm, Layout Lv, Layout Lc,
+                                    Layout Lk, double g0, double g1, double g2, int* __restrict__ notpd) {
   const int nv = V.nv, nc = V.nc, nb = V.nb;
   T L[NV][NV], K[NC][NV], Y[NC][NV], kk[NC], bv[NC], z[NV], rhs[NV], lam[NC];
 #pragma unroll
@@ -1874,6 +1873,157 @@ __global__ __launch_bounds__(64) void loop_solve_small_kernel(LoopView<T> V, lon
   for (int i = 0; i < NV; ++i)
     if (i < nv) vdot[(long)i * Lv.sk + st * Lv.sb] = rhs[i];
 }
+
+template <typename T, int NV, int NC>
+__global__ __launch_bounds__(64) void loop_solve_small_kernel(LoopView<T> V, long B, int stabilize, const T* __restrict__ body, const T* __restrict__ Mg,
+                                                              const T* __restrict__ cg, const T* __restrict__ tau, T* __restrict__ vdot,
+                                                              T* __restrict__ lambda, T* __restrict__ Kg, T* __restrict__ kg, Layout Lm, Layout Lv,
+                                                              Layout Lc, Layout Lk, double g0, double g1, double g2, int* __restrict__ notpd) {
+  const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (st >= B) return;
+  loop_solve_small_state<T, NV, NC>(V, st, stabilize, body, Mg, cg, tau, vdot, lambda, Kg, kg, Lm, Lv, Lc, Lk, g0, g1, g2, notpd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small loop mechanisms in ONE launch (the four-bar linkage of BASELINE configs[4]: 3 bodies, nv 3, nc 5): one thread per state runs the whole
+// dynamics! of the reference — forward kinematics, bias accelerations, dynamics_bias! (RNEA), mass_matrix! (CRBA), constraint_jacobian!,
+// constraint_bias!, the constrained solve (src/mechanism_algorithms.jl:845-864 with :484-498, :248-272, :574-673, :747-822).  Round 2 ran it as three
+// launches (rnea_kernel, crba_kernel, loop_solve_small_kernel: 7.5 + 5.4 + 14.3 us, each a lone wavefront's latency plus a launch); here the first
+// two are the prologue of the third.  Per-body kinematics, M and c go through the workspace buffers the three-launch form used (so that
+// rbd_dynamics_result finds them) and are read back by the thread that wrote them.  Bodies are visited in the reference's order (parents first);
+// at most NB of them, 1-dof or fixed tree joints.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NB, int NV, int NC>
+__global__ __launch_bounds__(64) void loop_fused_small_kernel(LoopView<T> V, long B, int stabilize, const T* __restrict__ q, const T* __restrict__ v,
+                                                              const T* __restrict__ tau, const T* __restrict__ fext, T* body, T* Mg, T* cg,
+                                                              T* __restrict__ vdot, T* __restrict__ qdot, T* __restrict__ lambda, T* __restrict__ Kg,
+                                                              T* __restrict__ kg, Layout Lq, Layout Lm, Layout Lv, Layout Lf, Layout Lc, Layout Lk, double g0,
+                                                              double g1, double g2, int* __restrict__ notpd) {
+  const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (st >= B) return;
+  const int nb = V.nb, nv = V.nv;
+  T* bd = body + st * nb * 24;
+  T S[NB][6], w[NB][6], Kb[NB][24];  // Kb: (R, p, T, a) of every body — a child takes its parent's from here (exported to `body` as well, for the solve)
+  RInertia<T> Ic[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { S[i][k] = T(0); w[i][k] = T(0); Ic[i].J[k] = T(0); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Ic[i].c[k] = T(0);
+    Ic[i].m = T(0);
+  }
+  // ---- top-down: transforms, twists, bias accelerations (mechanism_state.jl:687-700, :769-780, :814-830), Newton-Euler wrench of every body
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    if (i < nb) {  // uniform
+      Body<T> b{};
+      b.jtype = V.jt[i]; b.qoff = V.xi[3 * i + 1]; b.voff = V.voff[i]; b.state = st; b.valid = true;
+      const int p = V.xi[3 * i];
+      const T* rb = V.rb + (long)V.xi[3 * i + 2] * RB_STRIDE;
+      T qj[7], vj[6];
+      load_joint_q(b, q, Lq, qj);
+      load_joint_v(b, v, Lv, vj);
+      store_qdot(b, qdot, Lq, qj, vj);
+      T XR[9], Xp[3], tl[6], K[24], pk[24];
+      local_transform(b, rb, qj, XR, Xp);
+      local_joint_motion(b, rb, vj, tl);
+#pragma unroll
+      for (int k = 0; k < 24; ++k) pk[k] = (k < 9 && k % 4 == 0) ? T(1) : T(0);  // the world: identity, at rest, accelerating against gravity
+      pk[21] = T(-g0); pk[22] = T(-g1); pk[23] = T(-g2);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        if (r < i && r == p) {  // uniform: the parent's values, from registers
+#pragma unroll
+          for (int k = 0; k < 24; ++k) pk[k] = Kb[r][k];
+        }
+      }
+      matmul3(pk, XR, K);
+      matvec3(pk, Xp, K + 9);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) K[9 + k] += pk[9 + k];
+      T vJ[6], nT[6], cr[6];
+      xmotion(K, K + 9, tl, vJ);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { K[12 + k] = pk[12 + k] + vJ[k]; nT[k] = -K[12 + k]; }
+      se3_comm(nT, pk + 12, cr);  // a_b = a_p + (-T_b) x T_p  (v̇ = 0: spatial_accelerations! with zero joint accelerations)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) K[18 + k] = pk[18 + k] + cr[k];
+#pragma unroll
+      for (int k = 0; k < 24; ++k) { bd[i * 24 + k] = K[k]; Kb[i][k] = K[k]; }
+      T Jb[6], mc[3], Ia[6], x[6], fe[6], e1[6] = {T(1), T(0), T(0), T(0), T(0), T(0)}, sl[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Jb[k] = rb[RB_J + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) mc[k] = rb[RB_MC + k];
+      inertia_to_root(Jb, mc, rb[RB_M], K, K + 9, Ic[i]);
+      mul_inertia(Ic[i], K + 18, Ia);
+      momentum_cross(Ic[i], K + 12, x);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fe[k] = fext ? fext[(long)(6 * i + k) * Lf.sk + st * Lf.sb] : T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w[i][k] = Ia[k] + x[k] - fe[k];
+      local_joint_motion(b, rb, e1, sl);
+      xmotion(K, K + 9, sl, S[i]);
+      if (joint_nv(b.jtype) == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[i][k] = T(0);
+      }
+    }
+  }
+  // ---- structural zeros of the lower triangle first (the reference writes them: mechanism_algorithms.jl:266-267), then bottom-up: joint wrenches
+  //      and composite inertias to the parents, c = S'w (dynamics_bias!), M[i, ancestors] = (Ic_i S_i)'S_a (mass_matrix!)
+  for (int c2 = 0; c2 < nv; ++c2)
+    for (int r = c2; r < nv; ++r) Mg[((long)c2 * nv + r) * Lm.sk + st * Lm.sb] = T(0);
+#pragma unroll
+  for (int i = NB - 1; i >= 0; --i) {
+    if (i < nb) {
+      const int p = V.xi[3 * i], vo = V.voff[i];
+      const bool dof = joint_nv(V.jt[i]) == 1;
+      if (dof) cg[(long)vo * Lv.sk + st * Lv.sb] = dot6(S[i], w[i]);
+      if (dof) {
+        T F[6];
+        mul_inertia(Ic[i], S[i], F);
+        int a = i;
+#pragma unroll
+        for (int r = NB - 1; r >= 0; --r) {
+          if (r <= i && r == a) {  // r walks down the indices, a up the ancestors (a parent has a smaller index than its child)
+            if (joint_nv(V.jt[r]) == 1) Mg[((long)V.voff[r] * nv + vo) * Lm.sk + st * Lm.sb] = dot6(F, S[r]);
+            a = V.xi[3 * r];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        if (r < i && r == p) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { w[r][k] += w[i][k]; Ic[r].J[k] += Ic[i].J[k]; }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) Ic[r].c[k] += Ic[i].c[k];
+          Ic[r].m += Ic[i].m;
+        }
+      }
+    }
+  }
+  loop_solve_small_state<T, NV, NC>(V, st, stabilize, bd - st * nb * 24, Mg, cg, tau, vdot, lambda, Kg, kg, Lm, Lv, Lc, Lk, g0, g1, g2, notpd);
+}
+
+// one launch for small loop mechanisms (see loop_fused_small_kernel); false: out of its scope, the caller takes the three-launch route
+template <typename T>
+bool launch_loop_fused(const LoopView<T>& V, long B, int stabilize, const void* q, const void* v, const void* tau, const void* fext, void* body, void* M, void* c,
+                       void* vdot, void* qdot, void* lambda, void* K, void* k, Layout Lq, Layout Lm, Layout Lv, Layout Lf, Layout Lc, Layout Lk,
+                       const double* gravity, int* notpd, hipStream_t s) {
+  if (!(V.nb <= 4 && V.nv <= 4 && V.nc <= 6 && V.nv < V.nc && V.xi != nullptr)) return false;
+  const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+#define RBD_FUSED(NVV)                                                                                                                              \
+  hipLaunchKernelGGL((loop_fused_small_kernel<T, 4, NVV, 6>), grid, block, 0, s, V, B, stabilize, (const T*)q, (const T*)v, (const T*)tau, (const T*)fext, \
+                     (T*)body, (T*)M, (T*)c, (T*)vdot, (T*)qdot, (T*)lambda, (T*)K, (T*)k, Lq, Lm, Lv, Lf, Lc, Lk, gravity[0], gravity[1], gravity[2], notpd)
+  if (V.nv <= 3) RBD_FUSED(3); else RBD_FUSED(4);
+#undef RBD_FUSED
+  return true;
+}
+template bool launch_loop_fused<double>(const LoopView<double>&, long, int, const void*, const void*, const void*, const void*, void*, void*, void*, void*, void*, void*, void*, void*, Layout, Layout, Layout, Layout, Layout, Layout, const double*, int*, hipStream_t);
+template bool launch_loop_fused<float>(const LoopView<float>&, long, int, const void*, const void*, const void*, const void*, void*, void*, void*, void*, void*, void*, void*, void*, Layout, Layout, Layout, Layout, Layout, Layout, const double*, int*, hipStream_t);
 
 template <typename T>
 hipError_t launch_loop_solve(const LoopView<T>& V, long B, int stabilize, const void* body, const void* M, const void* c, const void* tau, void* vdot,

@@ -109,7 +109,7 @@ template <typename T> RBD_DEV void local_transform(const Body<T>& b, const T* rb
   const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]};
   if (b.jtype == RBD_JOINT_REVOLUTE) {
     T s, c;
-    sincos_t(qj[0], &s, &c);
+    sincos_fast(qj[0], &s, &c);  // ~35 instructions in fp64 against ~130 of the library's (rbd_device.hpp; 1.6 ulp)
     rot_axis_sc(ax, s, c, Rj);
   } else if (b.jtype == RBD_JOINT_SINCOS_REVOLUTE) {
     rot_axis_sc(ax, qj[0], qj[1], Rj);
