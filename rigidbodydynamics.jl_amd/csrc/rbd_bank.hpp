@@ -121,12 +121,12 @@ template <typename T> RBD_DEV void load_bank_body(const BankModel& M, int k, lon
   const int4* ib4 = reinterpret_cast<const int4*>(M.ib[k] + (b.sub < M.nbk[k] ? b.sub : 0) * IB_STRIDE);  // hipMalloc'ed: 16-byte aligned
   const int4 w0 = ib4[0], w1 = ib4[1], w2 = ib4[2], w3 = ib4[3];
   static_assert(IB_PARENT == 0 && IB_JTYPE == 1 && IB_QOFF == 2 && IB_VOFF == 3 && IB_LEVEL == 4 && IB_NCHILD == 5 && IB_ORIG == 6 && IB_CHILD0 == 7 &&
-                IB_FLAGS == 13 && IB_STRIDE == 16, "record layout");
+                IB_MAXCHILD == 8 && IB_FLAGS == 15 && IB_STRIDE == 16, "record layout");
   b.parent = w0.x; b.jtype = w0.y; b.qoff = w0.z; b.voff = w0.w;
   b.level = b.valid ? w1.x : -1;
   b.nchild = w1.y; b.orig = w1.z;
-  b.child[0] = w1.w; b.child[1] = w2.x; b.child[2] = w2.y; b.child[3] = w2.z; b.child[4] = w2.w; b.child[5] = w3.x;
-  b.flags = w3.y;
+  b.child[0] = w1.w; b.child[1] = w2.x; b.child[2] = w2.y; b.child[3] = w2.z; b.child[4] = w2.w; b.child[5] = w3.x; b.child[6] = w3.y; b.child[7] = w3.z;
+  b.flags = w3.w;
   b.plane = b.parent >= 0 ? b.base + b.parent : b.lane;  // parent slot (of the parent's bank) in this state's lane group
 }
 

@@ -1,0 +1,270 @@
+// rbd_big_kernels.hip — the fallback for trees the wavefront-shaped kernels do not take: more than 64 moving bodies (a state of the lane-per-body
+// kernels lives in one wavefront; the walk / state kernels are bounded by their register stashes).  The reference has no such limit — its own
+// `rand_chain_mechanism` (src/mechanism_modification.jl:402) is used with 100 joints — so these kernels restate the reference's route
+//   dynamics_bias! / inverse_dynamics! (src/mechanism_algorithms.jl:484-498, :542-553), mass_matrix! (:248-272), dynamics_solve! (:764, :819)
+// with ONE THREAD PER STATE and the per-body quantities in an HBM scratch laid out [field][body][state] (coalesced across the wavefront).
+// Correct at any size, no speed claim: every per-body value makes a round trip through memory.  Bodies are visited in the reference's order
+// (parents before children).  Tree mechanisms, every tree joint type.
+#include "rbd_lane.hpp"
+#include "rbd_internal.hpp"
+
+namespace rbd {
+
+// scratch fields per body: K = R 9, p 3, T 6, a 6 (24), w 6, composite inertia J 6, c 3, m 1 (10)
+enum { BIG_K = 0, BIG_W = 24, BIG_IC = 30, BIG_FIELDS = 40 };
+
+template <typename T> struct BigCtx {
+  const BigModel& M;
+  long B, st;
+  T* sc;  // scratch base
+  RBD_DEV T& at(int field, int body) const { return sc[((long)field * M.nb + body) * B + st]; }
+};
+
+template <typename T> RBD_DEV Body<T> big_body(const BigModel& M, int i, long st) {
+  Body<T> b{};
+  b.parent = M.tbl[4 * i]; b.jtype = M.tbl[4 * i + 1]; b.qoff = M.tbl[4 * i + 2]; b.voff = M.tbl[4 * i + 3];
+  b.state = st; b.valid = true; b.orig = i;
+  return b;
+}
+
+// forward kinematics of body i from its parent's scratch entry (the world: identity, at rest, a = -g): K = (R, p, T, a); WITH_ACC adds the
+// joint acceleration X S_local v̇ (spatial_accelerations! :387-417)
+template <typename T> RBD_DEV void big_fk(const BigCtx<T>& C, const Body<T>& b, const T* rb, const T* qj, const T* vj, const T* aj, T* K) {
+  T XR[9], Xp[3], tl[6], al[6], pk[24];
+  local_transform(b, rb, qj, XR, Xp);
+  local_joint_motion(b, rb, vj, tl);
+  local_joint_motion(b, rb, aj, al);
+  if (b.parent >= 0) {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) pk[k] = C.at(BIG_K + k, b.parent);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) pk[k] = (k < 9 && k % 4 == 0) ? T(1) : T(0);
+    pk[21] = T(-C.M.gravity[0]); pk[22] = T(-C.M.gravity[1]); pk[23] = T(-C.M.gravity[2]);
+  }
+  matmul3(pk, XR, K);
+  matvec3(pk, Xp, K + 9);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) K[9 + k] += pk[9 + k];
+  T vJ[6], nT[6], cr[6], ajw[6];
+  xmotion(K, K + 9, tl, vJ);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { K[12 + k] = pk[12 + k] + vJ[k]; nT[k] = -K[12 + k]; }
+  se3_comm(nT, pk + 12, cr);
+  xmotion(K, K + 9, al, ajw);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) K[18 + k] = pk[18 + k] + cr[k] + ajw[k];
+}
+
+// inverse_dynamics! (vdot != nullptr) / dynamics_bias! (vdot == nullptr); acc_out / jw_out as in rnea_kernel
+template <typename T>
+__global__ __launch_bounds__(64) void big_rnea_kernel(BigModel M, long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ vdot,
+                                                      const T* __restrict__ fext, T* __restrict__ tau, T* __restrict__ qdot, T* __restrict__ scratch,
+                                                      T* __restrict__ acc_out, T* __restrict__ jw_out, Layout Lq, Layout Lv, Layout Lf) {
+  const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (st >= B) return;
+  const BigCtx<T> C{M, B, st, scratch};
+  const T* rbase = reinterpret_cast<const T*>(M.rb);
+  for (int i = 0; i < M.nb; ++i) {
+    const Body<T> b = big_body<T>(M, i, st);
+    const T* rb = rbase + (long)i * RB_STRIDE;
+    T qj[7], vj[6], aj[6], K[24];
+    load_joint_q(b, q, Lq, qj);
+    load_joint_v(b, v, Lv, vj);
+    load_joint_v(b, vdot, Lv, aj);
+    store_qdot(b, qdot, Lq, qj, vj);
+    big_fk(C, b, rb, qj, vj, aj, K);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) C.at(BIG_K + k, i) = K[k];
+    RInertia<T> I;
+    T Jb[6], mc[3], Ia[6], x[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jb[k] = rb[RB_J + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mc[k] = rb[RB_MC + k];
+    inertia_to_root(Jb, mc, rb[RB_M], K, K + 9, I);
+    mul_inertia(I, K + 18, Ia);
+    momentum_cross(I, K + 12, x);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const T fe = fext ? fext[(long)(6 * i + k) * Lf.sk + st * Lf.sb] : T(0);
+      C.at(BIG_W + k, i) = Ia[k] + x[k] - fe;
+      if (acc_out) acc_out[(long)(6 * i + k) * Lf.sk + st * Lf.sb] = K[18 + k];
+    }
+  }
+  for (int i = M.nb - 1; i >= 0; --i) {  // joint_wrenches_and_torques! (:442-459)
+    const Body<T> b = big_body<T>(M, i, st);
+    const T* rb = rbase + (long)i * RB_STRIDE;
+    T w[6], K[12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w[k] = C.at(BIG_W + k, i);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) K[k] = C.at(BIG_K + k, i);
+    if (jw_out) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) jw_out[(long)(6 * i + k) * Lf.sk + st * Lf.sb] = w[k];
+    }
+    T out[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+    if (b.jtype == RBD_JOINT_QUAT_FLOATING) {
+      xforce_inv(K, K + 9, w, out);
+    } else {
+      const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
+      for (int k = 0; k < joint_nv(b.jtype); ++k) {
+        T sl[6], S[6];
+        subspace_col(b.jtype, ax, ay, k, sl);
+        xmotion(K, K + 9, sl, S);
+        const T d = dot6(S, w);
+        if (k == 0) out[0] = d; else if (k == 1) out[1] = d; else out[2] = d;
+      }
+    }
+    store_joint_v(b, tau, Lv, out);
+    if (b.parent >= 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) C.at(BIG_W + k, b.parent) += w[k];
+    }
+  }
+}
+
+// mass_matrix! (:248-272): lower triangle, structural zeros written
+template <typename T>
+__global__ __launch_bounds__(64) void big_crba_kernel(BigModel M, long B, const T* __restrict__ q, T* __restrict__ Mout, T* __restrict__ scratch, Layout Lq,
+                                                      Layout Lm) {
+  const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (st >= B) return;
+  const BigCtx<T> C{M, B, st, scratch};
+  const T* rbase = reinterpret_cast<const T*>(M.rb);
+  const int nv = M.nv;
+  for (int c2 = 0; c2 < nv; ++c2)
+    for (int r = c2; r < nv; ++r) Mout[((long)c2 * nv + r) * Lm.sk + st * Lm.sb] = T(0);
+  const T z6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  for (int i = 0; i < M.nb; ++i) {
+    const Body<T> b = big_body<T>(M, i, st);
+    const T* rb = rbase + (long)i * RB_STRIDE;
+    T qj[7], K[24];
+    load_joint_q(b, q, Lq, qj);
+    big_fk(C, b, rb, qj, z6, z6, K);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) C.at(BIG_K + k, i) = K[k];
+#pragma unroll
+    for (int k = 12; k < 24; ++k) C.at(BIG_K + k, i) = T(0);  // (twists are not needed; keep the parent reads of big_fk defined)
+    RInertia<T> I;
+    T Jb[6], mc[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jb[k] = rb[RB_J + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mc[k] = rb[RB_MC + k];
+    inertia_to_root(Jb, mc, rb[RB_M], K, K + 9, I);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) C.at(BIG_IC + k, i) = I.J[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) C.at(BIG_IC + 6 + k, i) = I.c[k];
+    C.at(BIG_IC + 9, i) = I.m;
+  }
+  auto subspace = [&](int a, int col, T* S) {  // column `col` of the motion subspace of body a's joint, root frame
+    const T* rb = rbase + (long)a * RB_STRIDE;
+    const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
+    T sl[6], K[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) K[k] = C.at(BIG_K + k, a);
+    subspace_col(M.tbl[4 * a + 1], ax, ay, col, sl);
+    xmotion(K, K + 9, sl, S);
+  };
+  for (int i = M.nb - 1; i >= 0; --i) {  // composite inertias bottom-up (update_crb_inertias!), then row block of body i
+    RInertia<T> Ic;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Ic.J[k] = C.at(BIG_IC + k, i);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Ic.c[k] = C.at(BIG_IC + 6 + k, i);
+    Ic.m = C.at(BIG_IC + 9, i);
+    const int p = M.tbl[4 * i];
+    if (p >= 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) C.at(BIG_IC + k, p) += Ic.J[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) C.at(BIG_IC + 6 + k, p) += Ic.c[k];
+      C.at(BIG_IC + 9, p) += Ic.m;
+    }
+    const int nvi = joint_nv(M.tbl[4 * i + 1]), vi = M.tbl[4 * i + 3];
+    for (int ci = 0; ci < nvi; ++ci) {
+      T Si[6], F[6];
+      subspace(i, ci, Si);
+      mul_inertia(Ic, Si, F);
+      for (int a = i; a >= 0; a = M.tbl[4 * a]) {  // the joints that support body i (support_set_masks, mechanism_state.jl:95-98)
+        const int nva = joint_nv(M.tbl[4 * a + 1]), va = M.tbl[4 * a + 3];
+        for (int ca = 0; ca < nva; ++ca) {
+          const int row = vi + ci, col = va + ca;
+          if (col <= row) {
+            T Sa[6];
+            subspace(a, ca, Sa);
+            Mout[((long)col * nv + row) * Lm.sk + st * Lm.sb] = dot6(F, Sa);
+          }
+        }
+      }
+    }
+  }
+}
+
+// dynamics_solve! without loop joints (:764, :819): L = chol(M) in place (lower triangle of the caller's / workspace's M), x = M^-1 (rhs - c)
+template <typename T>
+__global__ __launch_bounds__(64) void big_chol_solve_kernel(int nv, long B, T* __restrict__ Mg, const T* __restrict__ rhs, const T* __restrict__ c, T* __restrict__ x,
+                                                            Layout Lm, Layout Lv, int* __restrict__ notpd) {
+  const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (st >= B) return;
+  auto M = [&](int row, int col) -> T& { return Mg[((long)col * nv + row) * Lm.sk + st * Lm.sb]; };
+  bool bad = false;
+  for (int j = 0; j < nv; ++j) {
+    T d = M(j, j);
+    for (int k = 0; k < j; ++k) d -= M(j, k) * M(j, k);
+    if (!(d > T(0))) bad = true;
+    d = SqrtT<T>::f(d);
+    M(j, j) = d;
+    const T id = T(1) / d;
+    for (int i = j + 1; i < nv; ++i) {
+      T s = M(i, j);
+      for (int k = 0; k < j; ++k) s -= M(i, k) * M(j, k);
+      M(i, j) = s * id;
+    }
+  }
+  if (bad) atomicOr(notpd, 1);
+  auto X = [&](int i) -> T& { return x[(long)i * Lv.sk + st * Lv.sb]; };
+  for (int i = 0; i < nv; ++i) {
+    const long a = (long)i * Lv.sk + st * Lv.sb;
+    T s = (rhs ? rhs[a] : T(0)) - (c ? c[a] : T(0));
+    for (int k = 0; k < i; ++k) s -= M(i, k) * X(k);
+    X(i) = s / M(i, i);
+  }
+  for (int i = nv - 1; i >= 0; --i) {
+    T s = X(i);
+    for (int k = i + 1; k < nv; ++k) s -= M(k, i) * X(k);
+    X(i) = s / M(i, i);
+  }
+}
+
+size_t big_scratch_elems(const BigModel& M, long B) { return (size_t)BIG_FIELDS * (size_t)M.nb * (size_t)B; }
+
+template <typename T>
+hipError_t launch_big_rnea(const BigModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau, void* qdot, void* scratch,
+                           void* acc_out, void* jw_out, Layout Lq, Layout Lv, Layout Lf, hipStream_t s) {
+  hipLaunchKernelGGL(big_rnea_kernel<T>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, M, B, (const T*)q, (const T*)v, (const T*)vdot, (const T*)fext, (T*)tau,
+                     (T*)qdot, (T*)scratch, (T*)acc_out, (T*)jw_out, Lq, Lv, Lf);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_big_crba(const BigModel& M, long B, const void* q, void* Mout, void* scratch, Layout Lq, Layout Lm, hipStream_t s) {
+  hipLaunchKernelGGL(big_crba_kernel<T>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, M, B, (const T*)q, (T*)Mout, (T*)scratch, Lq, Lm);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_big_chol_solve(int nv, long B, void* Mg, const void* rhs, const void* c, void* x, Layout Lm, Layout Lv, int* notpd, hipStream_t s) {
+  hipLaunchKernelGGL(big_chol_solve_kernel<T>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, nv, B, (T*)Mg, (const T*)rhs, (const T*)c, (T*)x, Lm, Lv, notpd);
+  return hipGetLastError();
+}
+#define RBD_BIG_INST(T)                                                                                                                                     \
+  template hipError_t launch_big_rnea<T>(const BigModel&, long, const void*, const void*, const void*, const void*, void*, void*, void*, void*, void*, Layout, \
+                                         Layout, Layout, hipStream_t);                                                                                       \
+  template hipError_t launch_big_crba<T>(const BigModel&, long, const void*, void*, void*, Layout, Layout, hipStream_t);                                    \
+  template hipError_t launch_big_chol_solve<T>(int, long, void*, const void*, const void*, void*, Layout, Layout, int*, hipStream_t);
+RBD_BIG_INST(double)
+RBD_BIG_INST(float)
+
+}  // namespace rbd

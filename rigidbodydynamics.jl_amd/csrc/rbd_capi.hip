@@ -70,7 +70,10 @@ struct rbd_model {
   int32_t row_words = 1;
   std::vector<rbd_loop_joint_t> loops;
   std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref, parent_ref, qoff_ref;  // loop tables (reference body indices)
-  bool loop_fused_ok = false;  // small enough, and only 1-dof / fixed tree joints with parents before children: loop_fused_small_kernel
+  bool loop_fused_ok = false;
+  bool big = false;  // more than 64 bodies: only the any-size kernels of rbd_big_kernels.hip apply (reference-order tables below)
+  std::vector<int32_t> big_tbl;
+  std::vector<double> big_rb;  // small enough, and only 1-dof / fixed tree joints with parents before children: loop_fused_small_kernel
   std::vector<double> loop_r, axis_ref, axis2_ref;
   // banked lane-per-body mapping (aba_bank_kernel): two bodies per lane, split at level bank_L0; bank_lps == 0: not applicable
   int32_t bank_lps = 0, bank_L0 = 0, bank_nb[2] = {0, 0}, bank_aba_ok = 0;
@@ -122,6 +125,7 @@ struct rbd_ws {
   void* d_M = nullptr; void* d_c = nullptr; void* d_K = nullptr; void* d_k = nullptr;
   size_t d_M_bytes = 0, d_c_bytes = 0, d_K_bytes = 0, d_k_bytes = 0;
   void* d_body = nullptr; void* d_scratch = nullptr; size_t d_body_bytes = 0, d_scratch_bytes = 0;
+  BigModel big{}; void* d_big_tbl = nullptr; void* d_big_rb = nullptr; void* d_big_scratch = nullptr; size_t d_big_scratch_bytes = 0;  // rbd_big_kernels.hip
   void* d_fused_i = nullptr;  // loop_fused_small_kernel: parent, q offset, slot by reference body index
   void* d_loop_i = nullptr; void* d_loop_r = nullptr; void* d_loop_path = nullptr; void* d_jt_ref = nullptr; void* d_voff_ref = nullptr; void* d_axis_ref = nullptr; void* d_axis2_ref = nullptr;
   MkBuffers mk{}; void* d_vdwork = nullptr; size_t mk_elems = 0;  // Munthe-Kaas integrator scratch (lazy)
@@ -168,7 +172,6 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   if (d->n_bodies < 1 || !d->parent || !d->joint_type || !d->q_offset || !d->v_offset || !d->joint_axis || !d->pred_rot ||
       !d->pred_trans || !d->inertia_moment || !d->inertia_cross || !d->inertia_mass)
     return RBD_ERR_INVALID_ARGUMENT;
-  if (d->n_bodies > 64) return RBD_ERR_UNSUPPORTED;  // one wavefront per state is the current limit
   if (d->n_loops < 0 || (d->n_loops > 0 && !d->loops)) return RBD_ERR_INVALID_ARGUMENT;
   rbd_model* m = new (std::nothrow) rbd_model();
   if (!m) return RBD_ERR_OUT_OF_MEMORY;
@@ -193,6 +196,37 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     if (!(nn > 0.0)) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
     const double r[6] = {h.point[0], h.point[1], h.point[2], h.outward_normal[0] / nn, h.outward_normal[1] / nn, h.outward_normal[2] / nn};
     m->hs_r.insert(m->hs_r.end(), r, r + 6);
+  }
+  if (nb > 64) {
+    // More bodies than a wavefront has lanes: the any-size fallback (rbd_big_kernels.hip) — tree mechanisms without contact points; dynamics!,
+    // inverse_dynamics!, dynamics_bias!, mass_matrix!, mass_matrix_solve.  Everything else returns RBD_ERR_UNSUPPORTED for such a model.
+    if (d->n_loops > 0 || m->ncp > 0) { delete m; return RBD_ERR_UNSUPPORTED; }
+    int qs = 0, vs = 0;
+    m->big_tbl.resize(4 * (size_t)nb);
+    m->big_rb.assign((size_t)nb * RB_STRIDE, 0.0);
+    for (int i = 0; i < nb; ++i) {
+      const int t = d->joint_type[i], nqi = joint_nq_host(t), nvi = joint_nv_host(t);
+      if (nqi < 0 || (t == RBD_JOINT_PLANAR && !d->joint_axis2)) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
+      if (d->q_offset[i] != qs || d->v_offset[i] != vs) { delete m; return RBD_ERR_DIMENSION_MISMATCH; }
+      if (d->parent[i] >= i || d->parent[i] < -1) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
+      qs += nqi; vs += nvi;
+      int32_t* tb = &m->big_tbl[4 * (size_t)i];
+      tb[0] = d->parent[i]; tb[1] = t; tb[2] = d->q_offset[i]; tb[3] = d->v_offset[i];
+      double* rb = &m->big_rb[(size_t)i * RB_STRIDE];
+      for (int k = 0; k < 3; ++k) rb[RB_AXIS + k] = d->joint_axis[3 * i + k];
+      if (d->joint_axis2) for (int k = 0; k < 3; ++k) rb[RB_AXIS2 + k] = d->joint_axis2[3 * i + k];
+      for (int k = 0; k < 9; ++k) rb[RB_XPR + k] = d->pred_rot[9 * i + k];
+      for (int k = 0; k < 3; ++k) rb[RB_XPP + k] = d->pred_trans[3 * i + k];
+      const double* J = d->inertia_moment + 9 * i;
+      rb[RB_J + 0] = J[0]; rb[RB_J + 1] = J[1]; rb[RB_J + 2] = J[2]; rb[RB_J + 3] = J[4]; rb[RB_J + 4] = J[5]; rb[RB_J + 5] = J[8];
+      for (int k = 0; k < 3; ++k) rb[RB_MC + k] = d->inertia_cross[3 * i + k];
+      rb[RB_M] = d->inertia_mass[i];
+    }
+    if (qs != d->nq || vs != d->nv) { delete m; return RBD_ERR_DIMENSION_MISMATCH; }
+    m->big = true;
+    m->nc = 0;
+    *out = m;
+    return RBD_OK;
   }
   int lps = 1;
   while (lps < nb) lps <<= 1;
@@ -564,6 +598,20 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   rbd_ws* w = new (std::nothrow) rbd_ws();
   if (!w) return RBD_ERR_OUT_OF_MEMORY;
   w->model = m; w->device = device; w->dtype = dtype; w->max_batch = max_batch; w->stream = (hipStream_t)stream;
+  if (m->big) {  // the any-size fallback needs its two tables only
+    int st = upload(&w->d_big_tbl, m->big_tbl.data(), m->big_tbl.size() * sizeof(int32_t));
+    if (st == RBD_OK) {
+      if (dtype == RBD_F64) st = upload(&w->d_big_rb, m->big_rb.data(), m->big_rb.size() * sizeof(double));
+      else { std::vector<float> f(m->big_rb.begin(), m->big_rb.end()); st = upload(&w->d_big_rb, f.data(), f.size() * sizeof(float)); }
+    }
+    if (st == RBD_OK) { int zero = 0; st = upload((void**)&w->d_notpd, &zero, sizeof(int)); }
+    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+    w->big.nb = m->nb; w->big.nq = m->nq; w->big.nv = m->nv; w->big.tbl = (const int32_t*)w->d_big_tbl; w->big.rb = w->d_big_rb;
+    memcpy(w->big.gravity, m->gravity, sizeof w->big.gravity);
+    w->last_kernel = "big_* kernels (one thread per state, HBM scratch)";
+    *out = w;
+    return RBD_OK;
+  }
   int st = upload(&w->d_ib, m->ib.data(), m->ib.size() * sizeof(int32_t));
   if (st == RBD_OK) {
     if (dtype == RBD_F64) {
@@ -830,7 +878,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_fused_i, w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_big_tbl, w->d_big_rb, w->d_big_scratch, w->d_fused_i, w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -905,8 +953,12 @@ Opts read_opts(const rbd_opts_t* o) {
   return r;
 }
 
+// a model of more than 64 bodies is taken by the entry points that declare a BigOk (the four hot-path functions and the solve); all others refuse it
+thread_local int g_big_ok = 0;
+struct BigOk { BigOk() { ++g_big_ok; } ~BigOk() { --g_big_ok; } };
 int check_common(rbd_ws* w, int32_t B, const Opts& o) {
   if (!w) return RBD_ERR_INVALID_ARGUMENT;
+  if (w->model->big && g_big_ok == 0) return RBD_ERR_UNSUPPORTED;
   if (B < 0 || B > w->max_batch) return RBD_ERR_DIMENSION_MISMATCH;
   if (o.layout != RBD_LAYOUT_SOA && o.layout != RBD_LAYOUT_AOS) return RBD_ERR_INVALID_ARGUMENT;
   if (o.memory != RBD_MEM_DEVICE && o.memory != RBD_MEM_HOST) return RBD_ERR_INVALID_ARGUMENT;
@@ -1003,10 +1055,20 @@ int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const vo
 }
 }  // namespace
 
+// scratch of the any-size kernels (rbd_big_kernels.hip)
+static int big_scratch(rbd_ws* w, int32_t B) { return ensure(&w->d_big_scratch, &w->d_big_scratch_bytes, esize(w) * big_scratch_elems(w->big, B)); }
+
 // inverse_dynamics! / dynamics_bias! (vdot == nullptr) through the lane mapping that fits the batch: same rule as run_aba
 static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const void* dv, const void* dvd, const void* df, void* dtau, void* dqd,
                     Layout Lq, Layout Lv, Layout Lf, void* dacc = nullptr, void* djw = nullptr) {
   const rbd_model* m = w->model;
+  if (m->big) {
+    int st = big_scratch(w, B);
+    if (st) return st;
+    if (w->dtype == RBD_F64) HIP_TRY(launch_big_rnea<double>(w->big, B, dq, dv, dvd, df, dtau, dqd, w->d_big_scratch, dacc, djw, Lq, Lv, Lf, w->stream));
+    else HIP_TRY(launch_big_rnea<float>(w->big, B, dq, dv, dvd, df, dtau, dqd, w->d_big_scratch, dacc, djw, Lq, Lv, Lf, w->stream));
+    return RBD_OK;
+  }
   if (mapping == RBD_ALGO_ABA_BANKS && m->bank_lps == 0) return RBD_ERR_UNSUPPORTED;
   // the per-body outputs (accelerations, joint wrenches) are written by the lane-per-body kernels (one or two bodies per lane)
   const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
@@ -1098,6 +1160,13 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
 
 // mass_matrix! alone, into the caller's buffer
 static int run_crba(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, Layout Lq, Layout Lm) {
+  if (w->model->big) {
+    int st = big_scratch(w, B);
+    if (st) return st;
+    if (w->dtype == RBD_F64) HIP_TRY(launch_big_crba<double>(w->big, B, dq, dM, w->d_big_scratch, Lq, Lm, w->stream));
+    else HIP_TRY(launch_big_crba<float>(w->big, B, dq, dM, w->d_big_scratch, Lq, Lm, w->stream));
+    return RBD_OK;
+  }
   if (B >= w->state_min_batch && layout == RBD_LAYOUT_SOA) {  // one lane per state: its stores are coalesced when the batch is innermost
     if (w->dtype == RBD_F64) HIP_TRY(launch_crba_state<double>(w->sm, B, dq, dM, Lq, Lm, 1, w->stream));
     else HIP_TRY(launch_crba_state<float>(w->sm, B, dq, dM, Lq, Lm, 1, w->stream));
@@ -1116,6 +1185,12 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
   const rbd_model* m = w->model;
   const size_t es = esize(w);
   int st;
+  if (m->big) {  // any-size fallback: M in place (dM is never null here), then one thread per state factors and solves
+    if ((st = run_crba(w, B, layout, dq, dM, Lq, Lm))) return st;
+    if (w->dtype == RBD_F64) HIP_TRY(launch_big_chol_solve<double>(m->nv, B, dM, dtau, dc, dx, Lm, Lv, w->d_notpd, w->stream));
+    else HIP_TRY(launch_big_chol_solve<float>(m->nv, B, dM, dtau, dc, dx, Lm, Lv, w->d_notpd, w->stream));
+    return RBD_OK;
+  }
   const bool state = B >= w->state_min_batch;
   if (state && layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv)) {
     void* const before = w->d_Msoa;
@@ -1149,7 +1224,7 @@ static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, con
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
   if (loops) {
     if ((st = dynamics_loops(w, B, o, dq, dv, dtau, df, dvd, dqd, dlam))) return st;
-  } else if (o.algorithm == RBD_ALGO_CRBA_CHOLESKY) {
+  } else if (o.algorithm == RBD_ALGO_CRBA_CHOLESKY || m->big) {  // (more than 64 bodies: the reference's route is the only one built for any size)
     // the reference's own route (src/mechanism_algorithms.jl:856-862): c = dynamics_bias!, M = mass_matrix!, then
     // potrf!/potrs!.  M and c stay in the workspace (layout of this call) for rbd_dynamics_result.
     const Layout Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
@@ -1169,6 +1244,7 @@ extern "C" {
 
 int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
                  void* lambda, const rbd_opts_t* opts) {
+  BigOk big_ok;
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
@@ -1200,6 +1276,7 @@ int rbd_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, const voi
 
 static int rnea_common(rbd_ws_t* w, int32_t B, const void* q, const void* v, const void* vdot, const void* fext, void* tau_out,
                        const rbd_opts_t* opts, void* jw_out = nullptr, void* acc_out = nullptr) {
+  BigOk big_ok;
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
@@ -1253,6 +1330,7 @@ int rbd_dynamics_bias_bodies(rbd_ws_t* w, int32_t B, const void* q, const void* 
 }
 
 int rbd_mass_matrix(rbd_ws_t* w, int32_t B, const void* q, void* M_out, const rbd_opts_t* opts) {
+  BigOk big_ok;
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
@@ -1277,6 +1355,7 @@ int rbd_mass_matrix(rbd_ws_t* w, int32_t B, const void* q, void* M_out, const rb
 }
 
 int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs, void* x, void* M_out, const rbd_opts_t* opts) {
+  BigOk big_ok;
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
@@ -1296,13 +1375,14 @@ int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs
   // M_out == NULL: the caller wants x only.  The lane-per-state route (large batches) then skips the emission of M altogether — its factorization
   // reads the staged triangle, and the whole-square store is 340 MB of the route's ~560 MB at 65 536 Atlas states; the other routes factor M in
   // place and need a buffer of their own
-  const bool state_route = B >= w->state_min_batch && o.layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv);
-  if (!dM && o.algorithm == RBD_ALGO_CRBA_CHOLESKY && !state_route) {
+  const bool crba_route = o.algorithm == RBD_ALGO_CRBA_CHOLESKY || m->big;
+  const bool state_route = !m->big && B >= w->state_min_batch && o.layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv);
+  if (!dM && crba_route && !state_route) {
     if ((st = ensure(&w->d_M, &w->d_M_bytes, mbytes))) return st;
     dM = w->d_M;
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
-  if (o.algorithm == RBD_ALGO_CRBA_CHOLESKY) {
+  if (crba_route) {
     Timed t(w);
     if ((st = run_crba_chol(w, B, o.layout, dq, dM, dr, nullptr, dx, Lq, Lm, Lv))) return st;
   } else {
@@ -1320,6 +1400,7 @@ int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs
 }
 
 int rbd_dynamics_result(rbd_ws_t* w, int32_t B, void* M, void* c, void* K, void* k, const rbd_opts_t* opts) {
+  BigOk big_ok;
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;

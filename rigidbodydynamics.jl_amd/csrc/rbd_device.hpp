@@ -18,7 +18,7 @@
 namespace rbd {
 
 // per-body integer record
-enum { IB_PARENT = 0, IB_JTYPE = 1, IB_QOFF = 2, IB_VOFF = 3, IB_LEVEL = 4, IB_NCHILD = 5, IB_ORIG = 6, IB_CHILD0 = 7, IB_MAXCHILD = 6, IB_FLAGS = IB_CHILD0 + IB_MAXCHILD /* BF_* of a re-rooted tree (rbd_reroot.hpp), 0 otherwise */, IB_STRIDE = 16 /* 14 fields padded to 64 bytes: a record is four 16-byte loads */ };
+enum { IB_PARENT = 0, IB_JTYPE = 1, IB_QOFF = 2, IB_VOFF = 3, IB_LEVEL = 4, IB_NCHILD = 5, IB_ORIG = 6, IB_CHILD0 = 7, IB_MAXCHILD = 8, IB_FLAGS = IB_CHILD0 + IB_MAXCHILD /* BFD_* */, IB_STRIDE = 16 /* 64 bytes: a record is four 16-byte loads */ };
 // A floating-base tree re-rooted at its centre (rbd_reroot.hpp): what the kernels need beyond the ordinary per-body records.
 //   chain_i[k * 4] = joint type, q offset, v offset of the k-th joint on the way from the old floating body to the new root;
 //   chain_r[k * 15] = its axis (3) and joint_to_predecessor R (9), p (3) — ORIGINAL constants, kernel scalar type
@@ -134,6 +134,15 @@ struct StateModel {
   const int32_t* cols;
   const void* sr;            // [nops * TR_STRIDE] of the kernel's scalar type
   const uint64_t* row_mask;  // DevModel::row_mask
+  double gravity[3];
+};
+
+// ---- trees of more than 64 bodies (rbd_big_kernels.hip): one thread per state, per-body quantities in an HBM scratch ----------------------
+//   tbl[4 * i] = parent, joint type, q offset, v offset of body i in the reference's order (parents first); rb: RB_* records in the same order
+struct BigModel {
+  int32_t nb, nq, nv, _pad;
+  const int32_t* tbl;
+  const void* rb;
   double gravity[3];
 };
 

@@ -93,3 +93,14 @@ template <typename T>
 hipError_t launch_rnea_state(const StateModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau, void* qdot,
                              Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 }
+namespace rbd {
+// rbd_big_kernels.hip: the any-size fallback (one thread per state, HBM scratch of big_scratch_elems() scalars)
+size_t big_scratch_elems(const BigModel& M, long B);
+template <typename T>
+hipError_t launch_big_rnea(const BigModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau, void* qdot, void* scratch,
+                           void* acc_out, void* jw_out, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
+template <typename T>
+hipError_t launch_big_crba(const BigModel& M, long B, const void* q, void* Mout, void* scratch, Layout Lq, Layout Lm, hipStream_t s);
+template <typename T>
+hipError_t launch_big_chol_solve(int nv, long B, void* Mg, const void* rhs, const void* c, void* x, Layout Lm, Layout Lv, int* notpd, hipStream_t s);
+}

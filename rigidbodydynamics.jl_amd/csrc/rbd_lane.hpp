@@ -30,7 +30,7 @@ RBD_DEV int joint_nv(int t) {
 
 
 template <typename T> RBD_DEV int child_sel(const Body<T>& b, int s) {
-  return (s == 0) ? b.child[0] : (s == 1) ? b.child[1] : (s == 2) ? b.child[2] : (s == 3) ? b.child[3] : (s == 4) ? b.child[4] : b.child[5];
+  return (s == 0) ? b.child[0] : (s == 1) ? b.child[1] : (s == 2) ? b.child[2] : (s == 3) ? b.child[3] : (s == 4) ? b.child[4] : (s == 5) ? b.child[5] : (s == 6) ? b.child[6] : b.child[7];
 }
 // Parents at level l-1 pull N values from their s-th child (all children of a parent sit at level l) and add them.
 // Slot 0 (first child == next lane in DFS pre-order) is a DPP wave shift; further children use ds_bpermute.

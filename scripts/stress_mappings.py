@@ -22,7 +22,7 @@ for trial in range(N):
     vd = r2.standard_normal((B, model.nv))
     try:
         state = rbd.MechanismState(model, B)
-    except Exception as e:  # more than 6 children on one body: outside the library's limits
+    except Exception as e:  # more than 8 children on one body: outside the library's limits
         skipped["model"] = skipped.get("model", 0) + 1
         continue
     res = rbd.DynamicsResult(model, B)

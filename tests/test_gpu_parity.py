@@ -942,6 +942,59 @@ def test_maximal_coordinates_loop_dynamics(rbd, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_trees_of_more_than_64_bodies(rbd, oracle, dtype):
+    """The reference has no size limit (its `rand_chain_mechanism`, src/mechanism_modification.jl:402, is used with 100 joints); the wavefront-shaped
+    kernels stop at 64 bodies.  Beyond that the any-size kernels of rbd_big_kernels.hip (one thread per state, HBM scratch) run the reference's own route:
+    a 100-joint chain and a 150-body random tree of every joint type — inverse_dynamics! with its per-body outputs, dynamics_bias!, mass_matrix!,
+    mass_matrix_solve and dynamics! against the oracle; entry points outside the four hot-path functions refuse such a model."""
+    rng = np.random.default_rng(402)
+    chain = ["QuaternionFloating"] + ["Revolute"] * 60 + ["Prismatic"] * 15 + ["SinCosRevolute"] * 10 + ["Fixed"] * 6 + ["Planar"] * 4 + ["QuaternionSpherical"] * 4
+    tree = ["QuaternionFloating"] + ["Revolute"] * 100 + ["Prismatic"] * 20 + ["Fixed"] * 10 + ["QuaternionSpherical"] * 9 + ["Planar"] * 10
+    for joints, sel in ((chain, lambda m, r: m.bodies[-1]), (tree, None)):
+        order = rng.permutation(len(joints) - 1)
+        joints = [joints[0]] + [joints[1 + k] for k in order]
+        model = rbd.flatten(rbd.rand_tree_mechanism(rng, joints, sel))
+        assert model.n_bodies == len(joints) > 64
+        B = 70 if dtype == "f64" else 33
+        state, q, v, vd, fe = make(rbd, model, B, dtype, "aos", 403)
+        nb = model.n_bodies
+        rt = 1e-10 if dtype == "f64" else 5e-4
+        rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+        tau = torch.zeros_like(state.v)
+        jw = torch.full_like(dev(fe, state), float("nan"))
+        acc = torch.full_like(jw, float("nan"))
+        rbd.inverse_dynamics_(tau, state, dev(vd, state), dev(fe, state), jointwrenchesout=jw, accelerations=acc)
+        t_ref, jw_ref, acc_ref = oracle.inverse_dynamics_bodies(model, q, v, vd, fe)
+        assert rel(host(tau, state), t_ref) <= rt and rel(host(jw, state).reshape(B, nb, 6), jw_ref) <= rt and rel(host(acc, state).reshape(B, nb, 6), acc_ref) <= rt
+        result = rbd.DynamicsResult(model, B, dtype=TD[dtype])
+        rbd.dynamics_bias_(result, state, dev(fe, state))
+        assert rel(host(result.dynamicsbias, state), oracle.dynamics_bias(model, q, v, fe)) <= rt
+        rbd.mass_matrix_(result, state)
+        Mg = host(result.massmatrix, state).reshape(B, model.nv, model.nv).transpose(0, 2, 1)
+        Mref = oracle.mass_matrix(model, q)
+        assert rel(np.tril(Mg), np.tril(Mref)) <= rt
+        if dtype == "f64":  # the dense solve of a 100-dof chain: hold it to the backward error of M v̇ = τ − c, and to the oracle up to the conditioning
+            rbd.dynamics_(result, state, dev(vd, state), dev(fe, state))
+            assert rbd.sync(state) == 0
+            got = host(result.vd, state)
+            Ms = np.tril(Mref) + np.transpose(np.tril(Mref, -1), (0, 2, 1))
+            rhs = vd - oracle.dynamics_bias(model, q, v, fe)
+            res = np.einsum("bij,bj->bi", Ms, got) - rhs
+            eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(got, axis=1) + np.linalg.norm(rhs, axis=1))
+            assert eta.max() <= 1e-13, eta.max()
+            ref = oracle.dynamics(model, q, v, vd, fe)
+            cond = np.linalg.cond(Ms).max()
+            assert rel(got, ref) <= 1e-14 * cond, (rel(got, ref), cond)
+            x = torch.zeros_like(state.v)
+            rbd.mass_matrix_solve_(x, state, dev(vd, state))
+            xr = np.linalg.solve(Ms, vd[..., None])[..., 0]
+            assert rel(host(x, state), xr) <= 1e-14 * cond
+        with pytest.raises(Exception):
+            rbd.kinetic_energy(state)  # a by-product outside the four hot-path functions: RBD_ERR_UNSUPPORTED for such a model, not a wrong answer
+
+
+@pytest.mark.gpu
 def test_maximal_coordinates_at_the_reference_size(rbd, oracle):
     """The reference's own pin of constraint_jacobian! / constraint_bias! / the loop branch of dynamics_solve! at ITS size
     (test/test_mechanism_modification.jl:274-318): QuaternionFloating + 10 Revolute + QuaternionSpherical + Planar + 10 Fixed + 5 SinCosRevolute
