@@ -87,7 +87,7 @@ template <typename T> RBD_DEV void state_local_transform(int jt, const T* r, con
   for (int k = 0; k < 3; ++k) pl[k] = r[TR_PP + k];
   if (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_SINCOS_REVOLUTE) {
     T s, c;
-    if (jt == RBD_JOINT_REVOLUTE) sincos_t(qs[qoff * 64], &s, &c);
+    if (jt == RBD_JOINT_REVOLUTE) sincos_fast(qs[qoff * 64], &s, &c);
     else { s = qs[qoff * 64]; c = qs[(qoff + 1) * 64]; }
     _Pragma("unroll")
     for (int i = 0; i < 3; ++i) {
