@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X public spec (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 FP32_VECTOR_PEAK_TF = 157.3
 ABA_FLOPS_PER_EVAL = 27.0e3  # fused world-frame ABA, Atlas floating
-KERNELS = {"inverse_dynamics": "rnea_bank_kernel (<= one resident round of workgroups) / rnea_walk_kernel", "mass_matrix_solve": "crba_state_kernel + chol_mfma_kernel"}
+KERNELS = {"inverse_dynamics": "rnea_bank_kernel (<= one resident round of workgroups) / rnea_walk_kernel"}
 CONFIGS = {
     2: dict(model="atlas_floating", batch=4096, dtype="f64", op="dynamics", label="BASELINE configs[1]"),
     3: dict(model="atlas_floating", batch=65536, dtype="f32", op="mass_matrix_solve", label="BASELINE configs[2]"),

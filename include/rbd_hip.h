@@ -357,6 +357,14 @@ const char* rbd_workspace_last_kernel(const rbd_ws_t* ws);
 int rbd_version(void);
 /* 1 when the library was built with RBD_EXPERIMENTAL=1 (RBD_ALGO_ABA_TRACKS / RBD_ALGO_ABA_PIPE available), else 0 */
 int rbd_experimental(void);
+/* Run-time specialisation.  The one-lane-per-state kernels (mass_matrix! and mass_matrix! + Cholesky at large batches) exist in a second form
+ * that is compiled for the mechanism at hand with hiprtc the first time a workspace needs it (the walk of the tree, joint types, offsets and
+ * body constants become compile-time constants — what Julia's JIT does for the reference's `mass_matrix!`), cached on disk beside the library
+ * (jit_cache/) or in $RBD_JIT_CACHE.  Without libhiprtc, or with RBD_JIT=0, the interpreting kernels run instead; results agree to rounding.
+ * rbd_jit_precompile compiles a model's kernels of one scalar type (RBD_F32 / RBD_F64) into the cache ahead of time (no device needed);
+ * rbd_jit_source returns the generated source (length without the terminator; buf may be NULL; -1: no specialised kernels for this mechanism). */
+int rbd_jit_precompile(const rbd_model_t* model, int32_t dtype, char* log, int64_t log_capacity);
+int64_t rbd_jit_source(const rbd_model_t* model, int32_t dtype, char* buf, int64_t capacity);
 
 #ifdef __cplusplus
 }

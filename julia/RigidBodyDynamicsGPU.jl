@@ -197,6 +197,17 @@ function FlatModelHandle(mechanism::Mechanism)
     m
 end
 
+# Run-time specialised kernels (csrc/rbd_jit.hip): `mass_matrix!` at large batches runs code compiled for this mechanism by hiprtc the first time a
+# workspace needs it; `precompile_kernels` pays for the compilation up front (no device needed, the code object is cached on disk).
+function precompile_kernels(mechanism::Mechanism; T::Type = Float64)
+    model = FlatModelHandle(mechanism)
+    log = Vector{UInt8}(undef, 1 << 16)
+    status = ccall((:rbd_jit_precompile, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{UInt8}, Int64), model.handle, T === Float64 ? 0 : 1, log, length(log))
+    status == 3 && return false    # RBD_ERR_UNSUPPORTED: outside the specialised kernels' scope, or no hiprtc — the generic kernels run
+    status == 0 || error("rbd_jit_precompile: " * unsafe_string(pointer(log)))
+    true
+end
+
 # ---- batched state / result: same field names as the reference types -------------------------------------------
 mutable struct BatchedMechanismState{T, A <: Buffer{T}}
     mechanism::Mechanism

@@ -22,7 +22,7 @@ SYMBOLS = (
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
     "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan", "rbd_model_track_plan", "rbd_inverse_dynamics_bodies", "rbd_dynamics_bias_bodies",
     "rbd_model_reroot_plan", "rbd_model_contact_dims", "rbd_contact_dynamics", "rbd_dynamics_contact", "rbd_simulate_contact",
-    "rbd_experimental", "rbd_simulate_controlled", "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_comm_last_error",
+    "rbd_experimental", "rbd_jit_precompile", "rbd_jit_source", "rbd_simulate_controlled", "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_comm_last_error",
 )
 
 
@@ -100,6 +100,9 @@ def lib():
         L.rbd_dynamics_contact.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_simulate_contact.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.c_double, i32, ctypes.POINTER(Opts)]
         L.rbd_workspace_enable_timing.argtypes = [vp, i32]
+        L.rbd_jit_precompile.argtypes = [vp, i32, ctypes.c_char_p, ctypes.c_int64]
+        L.rbd_jit_source.argtypes = [vp, i32, ctypes.c_char_p, ctypes.c_int64]
+        L.rbd_jit_source.restype = ctypes.c_int64
         L.rbd_workspace_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         _lib = L
     return _lib

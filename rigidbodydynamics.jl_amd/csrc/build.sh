@@ -10,7 +10,9 @@ TAG=${OUT%.so}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -ffp-contract=fast -Wall -Wno-unused-function"
 pids=()
 # RBD_EXPERIMENTAL=1 adds the two mappings that lost everywhere and are kept for the record (aba_track_kernel, aba_pipe_kernel)
-TUS="rbd_kernels rbd_bank_kernels rbd_big_kernels rbd_walk_kernels rbd_state_kernels rbd_contact_kernels rbd_capi rbd_comm"
+# the headers the run-time compiled kernels include, as string literals for hiprtc (rbd_jit.hip)
+python3 ../../scripts/embed_jit_headers.py
+TUS="rbd_kernels rbd_bank_kernels rbd_big_kernels rbd_walk_kernels rbd_state_kernels rbd_contact_kernels rbd_capi rbd_comm rbd_jit"
 if [ -n "$RBD_EXPERIMENTAL" ]; then TUS="$TUS rbd_track_kernels rbd_pipe_kernels"; FLAGS="$FLAGS -DRBD_EXPERIMENTAL"; fi
 for tu in $TUS; do
   $HIPCC $FLAGS -c $tu.hip -o ${TAG}_${tu#rbd_}.o "$@" &

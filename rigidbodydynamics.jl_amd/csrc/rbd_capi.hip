@@ -18,6 +18,7 @@
 #include "rbd_walk_plan.hpp"
 #include "rbd_reroot.hpp"
 #include "rbd_state_plan.hpp"
+#include "rbd_jit.hpp"
 enum { BANK_LDS_PAIRS_HOST = 30 };  // = BANK_LDS_PAIRS of rbd_bank.hpp (16 parked + 14 exchange pairs per lane; checked in rbd_bank_kernels.hip)
 
 using namespace rbd;
@@ -114,8 +115,10 @@ struct rbd_ws {
   void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; size_t d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
   WalkModel pm{}; void* d_pipe_rr = nullptr; void* d_pipe_rec = nullptr; size_t pipe_lds_bytes = 0; long pipe_max_batch = 0;  // role-pipelined mapping (rbd_pipe.hpp)
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
+  // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
+  bool spec_tried = false; hipModule_t spec_mod = nullptr; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
-  void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
+  void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   long bank_min_batch = 0, bank_resident_states = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
   // staging for RBD_MEM_HOST (lazy)
@@ -148,6 +151,22 @@ int rbd_experimental(void) {
 #else
   return 0;
 #endif
+}
+// run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
+int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, char* buf, int64_t cap) {
+  if (!m || !m->state.ok || (dtype != RBD_F32 && dtype != RBD_F64)) return -1;
+  const std::string s = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype);
+  if (buf && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)s.size()); memcpy(buf, s.data(), (size_t)n); buf[n] = 0; }
+  return (int64_t)s.size();
+}
+int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t cap) {
+  if (log && cap > 0) log[0] = 0;
+  if (!m || (dtype != RBD_F32 && dtype != RBD_F64)) return RBD_ERR_INVALID_ARGUMENT;
+  if (!m->state.ok || !jit_available()) return RBD_ERR_UNSUPPORTED;
+  std::string lg;
+  const std::vector<char> code = jit_code_object(spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype), &lg);
+  if (log && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)lg.size()); memcpy(log, lg.data(), (size_t)n); log[n] = 0; }
+  return code.empty() ? RBD_ERR_HIP : RBD_OK;
 }
 
 const char* rbd_status_string(int s) {
@@ -885,6 +904,7 @@ int rbd_workspace_destroy(rbd_ws_t* w) {
     void* mkp[] = {w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.phid[1], w->mk.phid[2], w->mk.phid[3], w->mk.vd[0], w->mk.vd[1], w->mk.vd[2], w->mk.vd[3], w->d_vdwork};
     for (void* p : mkp) if (p) (void)hipFree(p);
   }
+  if (w->spec_mod) (void)hipModuleUnload(w->spec_mod);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   delete w;
@@ -1158,6 +1178,61 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   return RBD_OK;
 }
 
+// The run-time specialised form of the one-lane-per-state kernels (rbd_spec.hpp): compiled for this mechanism on the workspace's first use of
+// them (or loaded from the on-disk cache), nullptr when hiprtc is unavailable, RBD_JIT=0, or the compile failed — callers then keep the
+// interpreting kernels.  Its stores address M with a 32-bit lane offset: buffers of 4 GB and more stay with the interpreting kernel.
+static void spec_load(rbd_ws* w) {
+  if (w->spec_tried) return;
+  w->spec_tried = true;
+  const rbd_model* m = w->model;
+  if (!m->state.ok || !jit_available()) return;
+  std::string log;
+  const std::vector<char> code = jit_code_object(spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype), &log);
+  if (code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernels are used): " + log; return; }
+  if (hipModuleLoadData(&w->spec_mod, code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_mod = nullptr; return; }
+  auto get = [&](hipFunction_t* f, const char* name) { if (hipModuleGetFunction(f, w->spec_mod, name) != hipSuccess) { (void)hipGetLastError(); *f = nullptr; } };
+  get(&w->spec_crba, w->dtype == RBD_F64 ? "crba_spec_f64" : "crba_spec_f32");
+  if (w->dtype == RBD_F32 && m->nv > 0 && m->nv % 4 == 0 && m->nv <= 40) {  // (the condition under which spec_source emits them)
+    get(&w->spec_crba_perm, "crba_spec_perm_f32");
+    get(&w->spec_chol, "chol_spec_f32");
+    get(&w->spec_emit, "emit_spec_f32");
+    if (!w->spec_crba_perm || !w->spec_chol || !w->spec_emit) w->spec_crba_perm = w->spec_chol = w->spec_emit = nullptr;
+  }
+}
+static hipFunction_t spec_crba(rbd_ws* w, size_t buffer_bytes) {
+  spec_load(w);
+  return buffer_bytes < ((size_t)1 << 32) ? w->spec_crba : nullptr;
+}
+static hipError_t launch_crba_spec(rbd_ws* w, hipFunction_t f, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill) {
+  const unsigned lds = (unsigned)((size_t)w->model->nq * 256 * esize(w));  // four wavefronts' staged q
+  void* args[] = {&B, &q, &Mout, &Lq, &Lm, &zero_fill};
+  return hipModuleLaunchKernel(f, (unsigned)((B + 255) / 256), 1, 1, 256, 1, 1, lds, w->stream, args, nullptr);
+}
+
+// the sparsity-specialised tile Cholesky on the permuted staging buffer (and, before it, the caller's M from the same buffer)
+static hipError_t launch_chol_spec(rbd_ws* w, long B, const void* Mg, const void* tau, const void* c, void* x, Layout Lv, void* Mcopy, Layout Lc) {
+  int* notpd = w->d_notpd;
+  void* args[] = {&B, &Mg, &tau, &c, &x, &Lv, &notpd, &Mcopy, &Lc};
+  return hipModuleLaunchKernel(w->spec_chol, (unsigned)((B + 15) / 16), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr);
+}
+
+// The staging buffer of M for the one-lane-per-state CRBA when the caller's layout is AOS: grouped by 16 states (Layout{16, -nv nv}).  Its
+// structural zeros are written once per batch size and ordering (the specialised route stores M in the factorisation's order): the CRBA kernels
+// only store the non-zeros.
+static int stage_m(rbd_ws* w, int32_t B, bool permuted) {
+  const rbd_model* m = w->model;
+  void* const before = w->d_Msoa;
+  const size_t bytes = esize(w) * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15);
+  int st;
+  if ((st = ensure(&w->d_Msoa, &w->d_Msoa_bytes, bytes))) return st;
+  if (w->Msoa_B != B || w->d_Msoa != before || w->Msoa_perm != (int)permuted) {
+    HIP_TRY(hipMemsetAsync(w->d_Msoa, 0, bytes, w->stream));
+    w->Msoa_B = B;
+    w->Msoa_perm = (int)permuted;
+  }
+  return RBD_OK;
+}
+
 // mass_matrix! alone, into the caller's buffer
 static int run_crba(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, Layout Lq, Layout Lm) {
   if (w->model->big) {
@@ -1167,8 +1242,22 @@ static int run_crba(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, 
     else HIP_TRY(launch_big_crba<float>(w->big, B, dq, dM, w->d_big_scratch, Lq, Lm, w->stream));
     return RBD_OK;
   }
+  if (B >= w->state_min_batch && layout == RBD_LAYOUT_AOS && w->dtype == RBD_F32 && Lm.sk == 1 && (Lm.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0 &&
+      esize(w) * (size_t)w->model->nv * w->model->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && (spec_load(w), w->spec_emit != nullptr)) {
+    // one lane per state into the staging buffer, then whole cache lines of the caller's column-per-state M (the full square: emit_spec, rbd_spec.hpp)
+    int st = stage_m(w, B, true);
+    if (st) return st;
+    const Layout Ls{16, -(long)w->model->nv * w->model->nv};
+    HIP_TRY(launch_crba_spec(w, w->spec_crba_perm, B, dq, w->d_Msoa, Lq, Ls, 0));
+    long Bl = B;
+    void* args[] = {&Bl, &w->d_Msoa, &dM, &Lm};
+    HIP_TRY(hipModuleLaunchKernel(w->spec_emit, (unsigned)((B + 15) / 16), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
+    w->last_kernel = "crba_spec_perm_f32 + emit_spec_f32 (compiled for the mechanism at run time)";
+    return RBD_OK;
+  }
   if (B >= w->state_min_batch && layout == RBD_LAYOUT_SOA) {  // one lane per state: its stores are coalesced when the batch is innermost
-    if (w->dtype == RBD_F64) HIP_TRY(launch_crba_state<double>(w->sm, B, dq, dM, Lq, Lm, 1, w->stream));
+    if (hipFunction_t f = spec_crba(w, esize(w) * (size_t)w->model->nv * w->model->nv * B)) HIP_TRY(launch_crba_spec(w, f, B, dq, dM, Lq, Lm, 1));
+    else if (w->dtype == RBD_F64) HIP_TRY(launch_crba_state<double>(w->sm, B, dq, dM, Lq, Lm, 1, w->stream));
     else HIP_TRY(launch_crba_state<float>(w->sm, B, dq, dM, Lq, Lm, 1, w->stream));
   } else {
     if (w->dtype == RBD_F64) HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
@@ -1193,18 +1282,25 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
   }
   const bool state = B >= w->state_min_batch;
   if (state && layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv)) {
-    void* const before = w->d_Msoa;
-    const size_t Bpad = ((size_t)B + 15) & ~(size_t)15;
-    if ((st = ensure(&w->d_Msoa, &w->d_Msoa_bytes, es * (size_t)m->nv * m->nv * Bpad))) return st;
-    if (w->Msoa_B != B || w->d_Msoa != before) {  // the structural zeros of M are written once per batch size: the kernel below only stores the non-zeros
-      HIP_TRY(hipMemsetAsync(w->d_Msoa, 0, es * (size_t)m->nv * m->nv * Bpad, w->stream));
-      w->Msoa_B = B;
-    }
+    spec_load(w);
+    const bool mcopy_ok = !dM || (Lm.sk == 1 && (Lm.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0);
+    const bool spec_route = w->spec_chol && es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && mcopy_ok && !getenv("RBD_EXP_NO_SPEC_CHOL");
+    if ((st = stage_m(w, B, spec_route))) return st;
     const Layout Ls{16, -(long)m->nv * m->nv};  // grouped by 16 states = one wavefront of the tile Cholesky (layout_base, rbd_device.hpp)
-    HIP_TRY(launch_crba_state<float>(w->sm, B, dq, w->d_Msoa, Lq, Ls, 0, w->stream));  // structural zeros: never read by the solve, written below
+    if (spec_route) {
+      // both kernels compiled for the mechanism: M in the factorisation's own order (children before parents: no fill-in), only the tiles
+      // that hold non-zeros are factored; the same launch writes the caller's M
+      HIP_TRY(launch_crba_spec(w, w->spec_crba_perm, B, dq, w->d_Msoa, Lq, Ls, 0));
+      HIP_TRY(launch_chol_spec(w, B, w->d_Msoa, dtau, dc, dx, Lv, dM, Lm));
+      w->last_kernel = "crba_spec_perm_f32 + chol_spec_f32 (compiled for the mechanism at run time)";
+      return RBD_OK;
+    }
+    hipFunction_t const spec = spec_crba(w, w->d_Msoa_bytes);
+    if (spec) HIP_TRY(launch_crba_spec(w, spec, B, dq, w->d_Msoa, Lq, Ls, 0));
+    else HIP_TRY(launch_crba_state<float>(w->sm, B, dq, w->d_Msoa, Lq, Ls, 0, w->stream));
     static const bool exp_no_mcopy = getenv("RBD_EXP_NO_MCOPY") != nullptr, exp_no_chol = getenv("RBD_EXP_NO_CHOL") != nullptr;  // timing experiments only
     if (!exp_no_chol) HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_Msoa, dtau, dc, dx, nullptr, Ls, Lv, w->d_notpd, w->stream, exp_no_mcopy ? nullptr : dM, Lm));
-    w->last_kernel = "crba_state_kernel + chol_mfma_kernel";
+    w->last_kernel = spec ? "crba_spec_f32 (compiled for the mechanism at run time) + chol_mfma_kernel" : "crba_state_kernel + chol_mfma_kernel";
     return RBD_OK;
   }
   if ((st = run_crba(w, B, layout, dq, dM, Lq, Lm))) return st;

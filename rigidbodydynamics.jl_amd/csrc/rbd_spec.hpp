@@ -1,0 +1,410 @@
+// rbd_spec.hpp — MODEL-SPECIALISED kernels: device code that is compiled at run time (hiprtc, rbd_jit.hip) for ONE mechanism.
+//
+// The one-lane-per-state kernels of rbd_state.hpp interpret the tree: every op of the depth-first walk costs the scalar unit a decode
+// (kind, level, joint type, offsets, ancestor columns), a `switch (level)` around the registers of the path, and LDS reads of the body's
+// constants — for Atlas 8.7 k scalar + 1.3 k LDS instructions beside 14.5 k vector ones, on a wavefront that is alone on its SIMD and
+// issues one instruction at a time (89 us for mass_matrix! at 65 536 fp32 states, however few wavefronts run).  Here the walk is a
+// compile-time constant: rbd_jit.hip writes the plan of the mechanism (rbd_state_plan.hpp) out as `constexpr` tables in namespace
+// rbd_plan, includes this header and compiles the result for gfx950.  Every op becomes straight-line code with its level, joint type,
+// offsets and body constants folded in; the path of transforms / inertias / motion subspaces is a set of statically indexed arrays, i.e.
+// registers the allocator places; nothing is decoded at run time.  (The reference gets the same effect from Julia's JIT, which
+// specialises mass_matrix! on the mechanism's joint-type tuple: src/mechanism_algorithms.jl:248-272, TypeSortedCollections.)
+//
+// Expected before inclusion:  namespace rbd_plan { constexpr int NB, NQ, NV, NOPS, NLEVELS; constexpr int OPW[NOPS][4] (word 0, q offset,
+// v offset, 6 * reference body index); constexpr int COLS[NOPS][16]; constexpr double TR[NOPS][24]; constexpr unsigned long long
+// ROWMASK[NV]; constexpr double GRAVITY[3]; }
+// and, when the dense step is specialised too (RBD_SPEC_CHOL defined: fp32, NV a multiple of 4, NV <= 40): constexpr int NT = NV / 4, PERM[NV] (the
+// position of a velocity coordinate in the factorisation order), INV[NV] (its inverse), constexpr unsigned char TMASK[NT][NT] (tile (I, J) of the
+// permuted lower triangle holds a non-zero), EMIT_KMAX, EMIT_K[NT], and __constant__ unsigned EMIT[NT][4 * EMIT_KMAX] (staged entry << 16 | slot in the tile).
+#pragma once
+#include "rbd_device.hpp"
+
+namespace rbd {
+namespace spec {
+
+template <int I> struct Ix { static constexpr int value = I; };
+template <int... Is> struct Seq {};
+template <int N, int... Is> struct MakeSeq : MakeSeq<N - 1, N - 1, Is...> {};
+template <int... Is> struct MakeSeq<0, Is...> { using type = Seq<Is...>; };
+template <typename F, int... Is> RBD_DEV void sfor_impl(F&& f, Seq<Is...>) { (f(Ix<Is>{}), ...); }
+template <int N, typename F> RBD_DEV void sfor(F&& f) { sfor_impl(f, typename MakeSeq<N>::type{}); }
+
+namespace P = rbd_plan;
+
+// (Rl, pl) = joint_to_predecessor * joint_transform(q) of op O in canonical frames (joint axis +z); qs: this lane's column of the staged q
+template <typename T, int O> RBD_DEV void local_transform(const T* qs, T* Rl, T* pl) {
+  constexpr int jt = P::OPW[O][0] >> 16, qoff = P::OPW[O][1];
+  T C[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) C[k] = T(P::TR[O][TR_C + k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pl[k] = T(P::TR[O][TR_PP + k]);
+  if constexpr (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_SINCOS_REVOLUTE) {
+    T s, c;
+    if constexpr (jt == RBD_JOINT_REVOLUTE) sincos_fast(qs[qoff * 64], &s, &c);
+    else { s = qs[qoff * 64]; c = qs[(qoff + 1) * 64]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Rl[3 * i] = c * C[3 * i] + s * C[3 * i + 1];
+      Rl[3 * i + 1] = c * C[3 * i + 1] - s * C[3 * i];
+      Rl[3 * i + 2] = C[3 * i + 2];
+    }
+  } else if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+    T Rq[9], pq[3], t[3];
+    rot_quat(qs[qoff * 64], qs[(qoff + 1) * 64], qs[(qoff + 2) * 64], qs[(qoff + 3) * 64], Rq);
+    pq[0] = qs[(qoff + 4) * 64]; pq[1] = qs[(qoff + 5) * 64]; pq[2] = qs[(qoff + 6) * 64];
+    matmul3(C, Rq, Rl);
+    matvec3(C, pq, t);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pl[k] += t[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rl[k] = C[k];
+    if constexpr (jt == RBD_JOINT_PRISMATIC) {
+      const T d = qs[qoff * 64];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pl[k] += d * C[3 * k + 2];
+    }
+  }
+}
+
+// mass_matrix! (src/mechanism_algorithms.jl:248-272) of rbd_plan's mechanism, one lane per state.  Mout: any Layout (the caller's SOA
+// buffer, or the staging buffer grouped by 16 states the tile Cholesky reads); zero_fill: also write the structural zeros of the lower triangle.
+// PERMUTED (the staging buffer of chol_spec below): entry (row, col) goes to (max, min) of (PERM[row], PERM[col]).
+template <typename T, bool PERMUTED = false>
+RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, Layout Lq, Layout Lm, int zero_fill, T* lds) {
+  constexpr int ML = P::NLEVELS, NQ = P::NQ, NV = P::NV;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* qs = lds + (size_t)wave * NQ * 64;
+  const long state_raw = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64 + lane;
+  const bool live = state_raw < B;
+  const long state = live ? state_raw : B - 1;
+  {
+    const T* base = q + state * Lq.sb;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) qs[k * 64 + lane] = base[(long)k * Lq.sk];
+  }
+  qs += lane;
+  // byte offset of this lane's column; an entry adds a wave-uniform (row, col) term.  32-bit offsets (the host keeps buffers of 4 GB and more
+  // away from this kernel): one scalar multiply and one vector add per store, scalar base address
+  const unsigned lane_off = (unsigned)(layout_base(Lm, state) * (long)sizeof(T));
+  const unsigned mskb = (unsigned)(Lm.sk * (long)sizeof(T));
+  auto put = [&](int row, int col, T x) __attribute__((always_inline)) {
+#ifdef RBD_SPEC_CHOL
+    if constexpr (PERMUTED) {
+      const int pr = P::PERM[row], pc = P::PERM[col];
+      row = pr > pc ? pr : pc;
+      col = pr > pc ? pc : pr;
+    }
+#endif
+    if (live) *reinterpret_cast<T*>(reinterpret_cast<char*>(Mout) + (unsigned long)(lane_off + (unsigned)(col * NV + row) * mskb)) = x;
+  };
+  if (zero_fill) {
+    sfor<NV>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int row = rc.value;
+      sfor<row + 1>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int col = cc.value;
+        if constexpr (!((P::ROWMASK[row] >> col) & 1ull)) put(row, col, T(0));
+      });
+    });
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the staged q column is this wave's own
+  __builtin_amdgcn_wave_barrier();
+  T X[ML][12];   // path: transforms to root (R row-major, p)
+  T IC[ML][10];  // path: inertias being accumulated (J 6, c 3, m)
+  T S[ML][6];    // path: motion subspace columns (1-dof joints)
+  sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
+    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
+    if constexpr (kind == SK_ENTER) {
+      T Rl[9], pl[3];
+      local_transform<T, O>(qs, Rl, pl);
+      T* R = X[lvl];
+      T* p = X[lvl] + 9;
+      if constexpr (lvl == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = Rl[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = pl[k];
+      } else {
+        T t[3];
+        matmul3(X[lvl - 1], Rl, R);
+        matvec3(X[lvl - 1], pl, t);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = X[lvl - 1][9 + k] + t[k];
+      }
+      if constexpr (jt == RBD_JOINT_PRISMATIC) {
+        S[lvl][0] = S[lvl][1] = S[lvl][2] = T(0); S[lvl][3] = R[2]; S[lvl][4] = R[5]; S[lvl][5] = R[8];
+      } else if constexpr (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_SINCOS_REVOLUTE) {
+        const T z[3] = {R[2], R[5], R[8]};
+        S[lvl][0] = z[0]; S[lvl][1] = z[1]; S[lvl][2] = z[2];
+        cross3(p, z, S[lvl] + 3);
+      }
+      T Jb[6], mc[3];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Jb[k] = T(P::TR[O][TR_J + k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) mc[k] = T(P::TR[O][TR_MC + k]);
+      RInertia<T> Ib;
+      inertia_to_root(Jb, mc, T(P::TR[O][TR_M]), R, p, Ib);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) IC[lvl][k] = Ib.J[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) IC[lvl][6 + k] = Ib.c[k];
+      IC[lvl][9] = Ib.m;
+    } else {
+      RInertia<T> Ic;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Ic.J[k] = IC[lvl][k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ic.c[k] = IC[lvl][6 + k];
+      Ic.m = IC[lvl][9];
+      if constexpr (lvl > 0) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) IC[lvl - 1][k] += IC[lvl][k];
+      }
+      if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {  // level 0: the 6 x 6 block S' Ic S with S = Ad(H)
+        sfor<6>([&](auto cic) __attribute__((always_inline)) {
+          constexpr int ci = cic.value;
+          T e[6], Si[6], Fc[6], o6[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) e[k] = (k == ci) ? T(1) : T(0);
+          xmotion(X[0], X[0] + 9, e, Si);
+          mul_inertia(Ic, Si, Fc);
+          xforce_inv(X[0], X[0] + 9, Fc, o6);
+#pragma unroll
+          for (int cj = 0; cj <= ci; ++cj) put(voff + ci, voff + cj, o6[cj]);
+        });
+      } else if constexpr (jt != RBD_JOINT_FIXED) {
+        T F[6];
+        mul_inertia(Ic, S[lvl], F);
+        put(voff, voff, dot6(F, S[lvl]));
+        sfor<lvl>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = kc.value, col = P::COLS[O][k];
+          if constexpr (col >= 0) {
+            if constexpr ((col & SC_FLOATING) != 0) {
+              T o6[6];
+              xforce_inv(X[0], X[0] + 9, F, o6);
+#pragma unroll
+              for (int cj = 0; cj < 6; ++cj) put(voff, (col & ~SC_FLOATING) + cj, o6[cj]);
+            } else {
+              put(voff, col, dot6(F, S[k]));
+            }
+          }
+        });
+      }
+    }
+  });
+}
+
+
+#ifdef RBD_SPEC_CHOL
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The dense step of `dynamics_solve!` (potrf! / potrs!, src/mechanism_algorithms.jl:764, :819) specialised on the SPARSITY of the mechanism's
+// mass matrix.  M[i][j] is non-zero only when one of the two coordinates is an ancestor of the other (mass_matrix!'s support sets,
+// src/mechanism_state.jl:95-98); ordered children-before-parents (PERM: reverse depth-first pre-order) the Cholesky factor has exactly the same
+// pattern — no fill-in (Featherstone's branch-induced sparsity) — so every 4 x 4 tile of the permuted lower triangle that is structurally zero
+// (TMASK) stays zero and is skipped at compile time: in the loads, the panel solves, the matrix-core updates and both substitutions.  Atlas:
+// 45 lower tiles -> TMASK keeps about half.  x = M^-1 (tau - c) is the same vector whatever the elimination order; it is stored un-permuted.
+// The tile algorithm itself is chol_mfma_kernel's (rbd_kernels.hip): 16 states per wavefront, a quad of lanes per state, lane r of the quad
+// keeps row r of every tile, rank-4 updates as v_mfma_f32_4x4x1 — one instruction for the tile of all 16 states.
+// Mg: the staging buffer crba_spec<PERMUTED> fills (permuted lower triangle, grouped by 16 states, structural zeros never written: the host
+// zeroes the buffer once).
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int K> RBD_DEV float qbcast(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), K | (K << 2) | (K << 4) | (K << 6), 0xf, 0xf, true));
+}
+RBD_DEV float qsum(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+  return x;
+}
+RBD_DEV int sel4(int r, int a, int b, int c, int d) { return r == 0 ? a : r == 1 ? b : r == 2 ? c : d; }
+// LDS written by some lanes of the wavefront, read by others: order the accesses for the compiler (the hardware executes a wavefront's LDS
+// instructions in order)
+RBD_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const float* __restrict__ tau, const float* __restrict__ c,
+                       float* __restrict__ x, Layout Lv, int* __restrict__ notpd) {
+  constexpr int NT = P::NT, NV = P::NV;
+  const int lane = threadIdx.x & 63, r = lane & 3;
+  const long state_raw = group * 16 + (lane >> 2);
+  const bool live = state_raw < B;
+  const long state = live ? state_raw : B - 1;
+  const float* Mb = Mg + (state >> 4) * (16L * NV * NV) + (state & 15) + r * 16;  // row 4I + r of column col: Mb[(col * NV + 4I) * 16]
+  f32x4 t[NT][NT];  // tiles of the mask only (the others are never touched: the optimiser drops them)
+  sfor<NT>([&](auto Ic) __attribute__((always_inline)) {
+    constexpr int I = Ic.value;
+    sfor<I + 1>([&](auto Jc) __attribute__((always_inline)) {
+      constexpr int J = Jc.value;
+      if constexpr (P::TMASK[I][J] != 0) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          float a = Mb[((4 * J + cc) * NV + 4 * I) * 16];
+          if (I == J && cc > r) a = 0.0f;  // above the diagonal: not part of the staged triangle
+          t[I][J][cc] = a;
+        }
+      }
+    });
+  });
+  float y[NT];
+  int od[NT];  // the velocity coordinate this lane's row of block I stands for
+  sfor<NT>([&](auto Ic) __attribute__((always_inline)) {
+    constexpr int I = Ic.value;
+    od[I] = sel4(r, P::INV[4 * I], P::INV[4 * I + 1], P::INV[4 * I + 2], P::INV[4 * I + 3]);
+    float b = 0.0f;
+    if (tau) b = tau[(long)od[I] * Lv.sk + state * Lv.sb];
+    if (c) b -= c[(long)od[I] * Lv.sk + state * Lv.sb];
+    y[I] = b;
+  });
+  bool bad = false;
+  sfor<NT>([&](auto Jc) __attribute__((always_inline)) {
+    constexpr int J = Jc.value;
+    float dinv[4];
+#define RBD_DIAG_STEP(K)                                                              \
+    {                                                                                 \
+      const float d = qbcast<K>(t[J][J][K]);                                          \
+      bad |= !(d > 0.0f);                                                             \
+      const float rs = rsqrt_nr(d); /* v_rsq + one Newton step; a pivot that is not positive is reported */ \
+      dinv[K] = rs;                                                                   \
+      const float lk = (r == K) ? d * rs : t[J][J][K] * rs;                           \
+      t[J][J][K] = lk;                                                                \
+      if (K < 1) t[J][J][1] -= lk * qbcast<1>(lk);                                    \
+      if (K < 2) t[J][J][2] -= lk * qbcast<2>(lk);                                    \
+      if (K < 3) t[J][J][3] -= lk * qbcast<3>(lk);                                    \
+    }
+    RBD_DIAG_STEP(0) RBD_DIAG_STEP(1) RBD_DIAG_STEP(2) RBD_DIAG_STEP(3)
+#undef RBD_DIAG_STEP
+    const float l10 = qbcast<1>(t[J][J][0]), l20 = qbcast<2>(t[J][J][0]), l30 = qbcast<3>(t[J][J][0]);
+    const float l21 = qbcast<2>(t[J][J][1]), l31 = qbcast<3>(t[J][J][1]), l32 = qbcast<3>(t[J][J][2]);
+    // panel: X = T L_d^-T, one row per lane
+    sfor<NT - J - 1>([&](auto Ic) __attribute__((always_inline)) {
+      constexpr int I = J + 1 + Ic.value;
+      if constexpr (P::TMASK[I][J] != 0) {
+        const float x0 = t[I][J][0] * dinv[0];
+        const float x1 = (t[I][J][1] - x0 * l10) * dinv[1];
+        const float x2 = (t[I][J][2] - x0 * l20 - x1 * l21) * dinv[2];
+        const float x3 = (t[I][J][3] - x0 * l30 - x1 * l31 - x2 * l32) * dinv[3];
+        t[I][J][0] = x0; t[I][J][1] = x1; t[I][J][2] = x2; t[I][J][3] = x3;
+      }
+    });
+    // trailing update on the matrix cores: T(I,J') -= X_I X_J'^T for J < J' <= I, where both factors (and then the target) are in the mask
+    sfor<NT - J - 1>([&](auto Jpc) __attribute__((always_inline)) {
+      constexpr int Jp = J + 1 + Jpc.value;
+      if constexpr (P::TMASK[Jp][J] != 0) {
+        const float n0 = -t[Jp][J][0], n1 = -t[Jp][J][1], n2 = -t[Jp][J][2], n3 = -t[Jp][J][3];
+        sfor<NT - Jp>([&](auto Ic) __attribute__((always_inline)) {
+          constexpr int I = Jp + Ic.value;
+          if constexpr (P::TMASK[I][J] != 0 && P::TMASK[I][Jp] != 0) {
+            f32x4 acc = t[I][Jp];
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(n0, t[I][J][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(n1, t[I][J][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(n2, t[I][J][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(n3, t[I][J][3], acc, 0, 0, 0);
+            t[I][Jp] = acc;
+          }
+        });
+      }
+    });
+    // forward substitution for this block column
+    {
+      float v0 = qbcast<0>(y[J]) * dinv[0];
+      y[J] = (r == 0) ? v0 : y[J] - t[J][J][0] * v0;
+      float v1 = qbcast<1>(y[J]) * dinv[1];
+      y[J] = (r == 1) ? v1 : ((r > 1) ? y[J] - t[J][J][1] * v1 : y[J]);
+      float v2 = qbcast<2>(y[J]) * dinv[2];
+      y[J] = (r == 2) ? v2 : ((r > 2) ? y[J] - t[J][J][2] * v2 : y[J]);
+      float v3 = qbcast<3>(y[J]) * dinv[3];
+      y[J] = (r == 3) ? v3 : y[J];
+      sfor<NT - J - 1>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int I = J + 1 + Ic.value;
+        if constexpr (P::TMASK[I][J] != 0) y[I] -= t[I][J][0] * v0 + t[I][J][1] * v1 + t[I][J][2] * v2 + t[I][J][3] * v3;
+      });
+    }
+  });
+  if (live && bad && r == 0) atomicOr(notpd, 1);
+  // backward substitution L' x = y, block columns in reverse
+  sfor<NT>([&](auto Jr) __attribute__((always_inline)) {
+    constexpr int J = NT - 1 - Jr.value;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    bool any = false;
+    sfor<NT - J - 1>([&](auto Ic) __attribute__((always_inline)) {
+      constexpr int I = J + 1 + Ic.value;
+      if constexpr (P::TMASK[I][J] != 0) { a0 += t[I][J][0] * y[I]; a1 += t[I][J][1] * y[I]; a2 += t[I][J][2] * y[I]; a3 += t[I][J][3] * y[I]; any = true; }
+    });
+    if (any) { a0 = qsum(a0); a1 = qsum(a1); a2 = qsum(a2); a3 = qsum(a3); }
+    float yj = y[J] - ((r == 0) ? a0 : (r == 1) ? a1 : (r == 2) ? a2 : a3);
+    const float d0 = qbcast<0>(t[J][J][0]), d1 = qbcast<1>(t[J][J][1]), d2 = qbcast<2>(t[J][J][2]), d3 = qbcast<3>(t[J][J][3]);
+    const float b30 = qbcast<3>(t[J][J][0]), b31 = qbcast<3>(t[J][J][1]), b32 = qbcast<3>(t[J][J][2]);
+    const float b20 = qbcast<2>(t[J][J][0]), b21 = qbcast<2>(t[J][J][1]);
+    const float x3 = qbcast<3>(yj) * rcp_nr(d3);
+    const float l3r = (r == 0) ? b30 : (r == 1) ? b31 : b32;
+    yj = (r == 3) ? x3 : yj - l3r * x3;
+    const float x2 = qbcast<2>(yj) * rcp_nr(d2);
+    const float l2r = (r == 0) ? b20 : b21;
+    yj = (r == 2) ? x2 : ((r < 2) ? yj - l2r * x2 : yj);
+    const float x1 = qbcast<1>(yj) * rcp_nr(d1);
+    const float l1r = qbcast<1>(t[J][J][0]);
+    yj = (r == 1) ? x1 : ((r < 1) ? yj - l1r * x1 : yj);
+    const float x0 = qbcast<0>(yj) * rcp_nr(d0);
+    yj = (r == 0) ? x0 : yj;
+    y[J] = yj;
+  });
+  if (live) {
+    sfor<NT>([&](auto Ic) __attribute__((always_inline)) { x[(long)od[Ic.value] * Lv.sk + state * Lv.sb] = y[Ic.value]; });
+  }
+}
+
+// The caller's M from the staging buffer: the WHOLE nv x nv square per state, column-major, in the ORIGINAL coordinate order (the reference leaves
+// the strict upper triangle of its Symmetric(:L) undefined; here it holds the mirror image — chol_mfma_kernel's choice, kept: complete cache lines
+// written with nontemporal 16-byte stores are more than twice as fast as the lower triangle's partial lines).  16 states per wavefront; per block
+// of four columns (16 nv contiguous bytes per state) the non-zeros are gathered from the staging buffer into an LDS tile (EMIT: entry -> slot,
+// four entries x 16 states per load instruction), the zeros come from clearing the tile, and the tile leaves as whole runs.
+constexpr int EMIT_MST = 4 * P::NV + 4;  // floats per state of the LDS tile (one spare slot for the list's padding; 16-byte aligned rows)
+RBD_DEV void emit_spec(long B, long group, const float* __restrict__ Mg, float* __restrict__ Mc, Layout Lc, float* mst) {
+  constexpr int NT = P::NT, NV = P::NV, MST = EMIT_MST, CB = 4 * NV;
+  const int lane = threadIdx.x & 63, qd = lane >> 4, s = lane & 15;
+  const long gs = group * 16 + s;
+  const long gsl = gs < B ? gs : B - 1;
+  const float* src = Mg + (gsl >> 4) * (16L * NV * NV) + (gsl & 15);
+  float* mine = mst + s * MST;
+  const unsigned* tab = &P::EMIT[0][0] + qd;
+  // the gathers of block Jo + 1 are in flight while block Jo goes through the tile and out
+  float v[2][P::EMIT_KMAX];
+  int dst[2][P::EMIT_KMAX];
+  auto gather = [&](auto Jc) __attribute__((always_inline)) {
+    constexpr int Jo = Jc.value;
+#pragma unroll
+    for (int k = 0; k < P::EMIT_K[Jo]; ++k) {
+      const unsigned e = tab[(Jo * P::EMIT_KMAX + k) * 4];  // staged entry << 16 | slot in the tile
+      v[Jo & 1][k] = src[(long)(e >> 16) * 16];
+      dst[Jo & 1][k] = (int)(e & 0xffffu);
+    }
+  };
+  gather(Ix<0>{});
+  sfor<NT>([&](auto Jc) __attribute__((always_inline)) {
+    constexpr int Jo = Jc.value, K = P::EMIT_K[Jo];
+    if constexpr (Jo + 1 < NT) gather(Ix<Jo + 1>{});
+    wave_sync();  // the tile of the block before has been read out
+    for (int i = lane * 4; i < 16 * MST; i += 256) *reinterpret_cast<f32x4*>(mst + i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < K; ++k) mine[dst[Jo & 1][k]] = v[Jo & 1][k];
+    wave_sync();
+#pragma unroll 3
+    for (int c0 = 0; c0 < 16 * NV; c0 += 64) {
+      const int ch = c0 + lane, st = ch / NV, piece = ch - st * NV;
+      const long g2 = group * 16 + st;
+      if (ch < 16 * NV && g2 < B)
+        __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(mst + st * MST + piece * 4), reinterpret_cast<f32x4*>(Mc + g2 * Lc.sb + (long)Jo * CB + piece * 4));
+    }
+  });
+}
+#endif  // RBD_SPEC_CHOL
+
+}  // namespace spec
+}  // namespace rbd

@@ -560,6 +560,38 @@ def experimental():
     return bool(_capi.lib().rbd_experimental())
 
 
+def jit_source(flat, dtype=torch.float32):
+    """The source `rbd_jit_source` generates for a mechanism's run-time specialised kernels (csrc/rbd_jit.hip, rbd_spec.hpp); None when the
+    mechanism is outside the one-lane-per-state kernels' scope.  Host only."""
+    L = _capi.lib()
+    h = ctypes.c_void_p()
+    _raise(L.rbd_model_create(ctypes.cast(ctypes.byref(flat.c_struct()), ctypes.c_void_p), ctypes.byref(h)), "rbd_model_create")
+    try:
+        dt = _capi.F64 if dtype == torch.float64 else _capi.F32
+        n = L.rbd_jit_source(h, dt, None, 0)
+        if n < 0:
+            return None
+        buf = ctypes.create_string_buffer(n + 1)
+        L.rbd_jit_source(h, dt, buf, n + 1)
+        return buf.value.decode()
+    finally:
+        L.rbd_model_destroy(h)
+
+
+def jit_precompile(flat, dtype=torch.float32):
+    """Compiles a mechanism's specialised kernels into the on-disk cache ahead of time (`rbd_jit_precompile`; no device needed).  Returns
+    (ok, compiler log); ok is None when the mechanism has no specialised kernels or hiprtc is not available."""
+    L = _capi.lib()
+    h = ctypes.c_void_p()
+    _raise(L.rbd_model_create(ctypes.cast(ctypes.byref(flat.c_struct()), ctypes.c_void_p), ctypes.byref(h)), "rbd_model_create")
+    try:
+        log = ctypes.create_string_buffer(1 << 16)
+        st = L.rbd_jit_precompile(h, _capi.F64 if dtype == torch.float64 else _capi.F32, log, len(log))
+        return (None if st == 3 else st == 0), log.value.decode(errors="replace")
+    finally:
+        L.rbd_model_destroy(h)
+
+
 def chain_plan(flat):
     """The chain schedule under the track / walk plans of a mechanism (host-side introspection of `rbd_model_chain_plan`): dict with `tracks`,
     `steps`, `lds_fields` and `table` (steps × tracks array of body indices, -1 = idle); None when the mechanism is outside

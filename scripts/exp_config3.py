@@ -1,4 +1,5 @@
-"""Timing experiments on config 3 (mass_matrix! + tile Cholesky, fp32, 65 536 states): graph-replayed µs per call."""
+"""Timing experiments on config 3 (mass_matrix! + tile Cholesky, fp32, 65 536 states): graph-replayed µs per call.
+OP = solve (default: mass_matrix! + Cholesky solve, M emitted) | solve_nom (M_out = None) | mm (mass_matrix! alone)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -6,12 +7,15 @@ import numpy as np, torch
 import rbd_amd as rbd
 model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+op = os.environ.get("OP", "solve")
 tdt = torch.float32
 rng = np.random.default_rng(2)
 state = rbd.MechanismState(model, B, dtype=tdt); result = rbd.DynamicsResult(model, B, dtype=tdt)
 rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng))
 tau = torch.rand(B, model.nv, dtype=tdt, device="cuda"); out = torch.zeros_like(tau)
-f = lambda: rbd.mass_matrix_solve_(out, state, tau, result.massmatrix)
+if op == "solve": f = lambda: rbd.mass_matrix_solve_(out, state, tau, result.massmatrix)
+elif op == "solve_nom": f = lambda: rbd.mass_matrix_solve_(out, state, tau, None)
+else: f = lambda: rbd.mass_matrix_(result, state)
 for _ in range(5): f()
 torch.cuda.synchronize()
 cap = torch.cuda.Stream()
@@ -26,4 +30,4 @@ g.replay(); torch.cuda.synchronize()
 e0.record()
 for _ in range(5): g.replay()
 e1.record(); torch.cuda.synchronize()
-print(os.environ.get("TAG", ""), "B", B, "us per call", round(e0.elapsed_time(e1) * 1000 / 50, 2), flush=True)
+print(os.environ.get("TAG", ""), op, "B", B, "us per call", round(e0.elapsed_time(e1) * 1000 / 50, 2), rbd.last_kernel(state), flush=True)

@@ -1,0 +1,128 @@
+"""Run-time specialisation, host side (csrc/rbd_jit.hip, rbd_spec.hpp): the generated source of a mechanism's kernels — plan tables, the
+factorisation order, the tile mask, the gather lists of the M emitter — checked against the mechanism's own structure, and its compilation by
+hiprtc, which needs no GPU.  What the compiled kernels compute is checked on the GPU (tests/test_state_kernels.py)."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def rbd():
+    import rbd_amd
+    return rbd_amd
+
+
+def table(src, name):
+    m = re.search(r"\b%s(?:\[[^\]]*\])+ = \{(.*?)\};" % re.escape(name), src, re.S)
+    assert m, name
+    rows = [r for r in re.findall(r"\{([^{}]*)\}", m.group(1))]
+    if not rows:
+        rows = [m.group(1)]
+    return [[int(x, 0) if not re.search(r"[.eE]|inf|nan", x) or x.strip().startswith("0x") else float(x) for x in re.split(r",", r.replace("ull", "")) if x.strip()] for r in rows]
+
+
+def ancestors(model):
+    """anc[i][j]: velocity coordinate j belongs to a joint on the path from coordinate i's joint to the root (or to the same joint)."""
+    nb, nv = model.n_bodies, model.nv
+    nvs = [(int(model.v_offset[b + 1]) if b + 1 < nb else nv) - int(model.v_offset[b]) for b in range(nb)]
+    body_of = np.concatenate([[b] * nvs[b] for b in range(nb)]).astype(int) if nv else np.zeros(0, int)
+    anc = np.zeros((nv, nv), bool)
+    for i in range(nv):
+        b = body_of[i]
+        while b >= 0:
+            anc[i, body_of == b] = True
+            b = int(model.parent[b])
+    return anc
+
+
+@pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating", "atlas_fixed"])
+def test_generated_plan_matches_the_mechanism(rbd, name):
+    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", name + ".json"))
+    src = rbd.jit_source(model, torch.float32)
+    assert src is not None
+    dims = re.search(r"constexpr int NB = (\d+), NQ = (\d+), NV = (\d+), NOPS = (\d+), NLEVELS = (\d+);", src)
+    nb, nq, nv, nops, nlev = map(int, dims.groups())
+    assert (nb, nq, nv, nops) == (model.n_bodies, model.nq, model.nv, 2 * model.n_bodies)
+    opw = table(src, "OPW")
+    assert len(opw) == nops
+    enter = [w for w in opw if (w[0] & 0xff) == 0]
+    assert sorted(w[2] for w in enter) == sorted(int(v) for v in model.v_offset)  # every body entered once
+    anc = ancestors(model)
+    nz = anc | anc.T  # support of the mass matrix (src/mechanism_state.jl:95-98)
+    rowmask = table(src, "ROWMASK")[0]
+    for i in range(nv):
+        for j in range(i + 1):
+            assert bool((rowmask[i] >> j) & 1) == bool(nz[i, j])
+    if "RBD_SPEC_CHOL" not in src:
+        assert nv % 4 or nv > 40
+        return
+    perm, inv = np.array(table(src, "PERM")[0]), np.array(table(src, "INV")[0])
+    assert sorted(perm) == list(range(nv)) and (inv[perm] == np.arange(nv)).all()
+    # children before parents: a proper ancestor's coordinate comes later in the factorisation order -> no fill-in
+    for i in range(nv):
+        for j in range(nv):
+            if anc[i, j] and not anc[j, i]:
+                assert perm[j] > perm[i]
+    nt = nv // 4
+    tmask = np.array(table(src, "TMASK"))
+    want = np.zeros((nt, nt), int)
+    for pr in range(nv):
+        for pc in range(pr + 1):
+            if nz[inv[pr], inv[pc]]:
+                want[pr // 4, pc // 4] = 1
+    assert (tmask == want).all()
+    # no fill-in, tile by tile: whenever two tiles of a block column are in the mask and hold a common descendant, their product's target is too
+    L = np.zeros((nv, nv), bool)
+    for pr in range(nv):
+        for pc in range(pr + 1):
+            L[pr, pc] = nz[inv[pr], inv[pc]]
+    for k in range(nv):  # symbolic Cholesky
+        rows = [i for i in range(k + 1, nv) if L[i, k]]
+        for a in rows:
+            for b_ in rows:
+                if a >= b_:
+                    assert L[a, b_], "fill-in at (%d, %d)" % (a, b_)
+    # the emitter's gather lists: every non-zero of the full square exactly once, from the right staged entry, to the right slot
+    emit = table(src, "EMIT")
+    ks = table(src, "EMIT_K")[0]
+    seen = set()
+    for jo in range(nt):
+        for e in emit[jo][:4 * ks[jo]]:
+            srce, dst = e >> 16, e & 0xffff
+            if dst == 4 * nv:
+                continue  # padding
+            col, row = 4 * jo + dst // nv, dst % nv
+            hi, lo = max(perm[row], perm[col]), min(perm[row], perm[col])
+            assert srce == lo * nv + hi and nz[row, col] and (row, col) not in seen
+            seen.add((row, col))
+        assert all((e & 0xffff) == 4 * nv for e in emit[jo][4 * ks[jo]:])
+    assert len(seen) == int(nz.sum())
+
+
+def test_out_of_scope_mechanisms_have_no_specialised_kernels(rbd):
+    mech = rbd.builders.four_bar_linkage()  # loop joints: the state plan does not apply
+    assert rbd.jit_source(rbd.flatten(mech), torch.float32) is None
+
+
+def test_precompile_without_a_device(rbd, tmp_path, monkeypatch):
+    """hiprtc cross-compiles for gfx950 with no GPU present: the code object lands in the cache, a second call finds it there."""
+    monkeypatch.setenv("RBD_JIT_CACHE", str(tmp_path))
+    model = rbd.flatten(rbd.builders.double_pendulum())
+    ok, log = rbd.jit_precompile(model, torch.float64)
+    if ok is None:
+        pytest.skip("libhiprtc not available")
+    assert ok, log
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert len(files) == 1 and os.path.getsize(tmp_path / files[0]) > 1000
+    stamp = os.path.getmtime(tmp_path / files[0])
+    ok, _ = rbd.jit_precompile(model, torch.float64)
+    assert ok and os.path.getmtime(tmp_path / files[0]) == stamp
+    monkeypatch.setenv("RBD_JIT", "0")
+    assert rbd.jit_precompile(model, torch.float64)[0] is None

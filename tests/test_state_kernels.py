@@ -1,6 +1,8 @@
-"""One-lane-per-state kernels (csrc/rbd_state.hpp: crba_state_kernel, rnea_state_kernel) against the oracle.  They serve large batches
-(default: from half a chip-full of wavefronts up); RBD_STATE_MIN_BATCH=1 routes every batch size through them here, so that the same
-small seeded cases the lane-per-body kernels are tested on apply.  reference: src/mechanism_algorithms.jl:248-272, :387-459, :542-553."""
+"""One-lane-per-state kernels against the oracle: the interpreting ones (csrc/rbd_state.hpp: crba_state_kernel, rnea_state_kernel) and the
+ones compiled for the mechanism at run time (csrc/rbd_spec.hpp through rbd_jit.hip: crba_spec, chol_spec, emit_spec; RBD_JIT=0 switches them
+off).  They serve large batches (default: from half a chip-full of wavefronts up); RBD_STATE_MIN_BATCH=1 routes every batch size through them
+here, so that the same small seeded cases the lane-per-body kernels are tested on apply.
+reference: src/mechanism_algorithms.jl:248-272, :387-459, :542-553, :764, :819."""
 import numpy as np
 import pytest
 import torch
@@ -11,9 +13,11 @@ pytestmark = pytest.mark.gpu
 IN_SCOPE = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf", "quickstart_pendulum"]
 
 
-@pytest.fixture()
-def states_everywhere(monkeypatch):
+@pytest.fixture(params=["compiled", "interpreted"])
+def states_everywhere(monkeypatch, request):
     monkeypatch.setenv("RBD_STATE_MIN_BATCH", "1")
+    monkeypatch.setenv("RBD_JIT", "1" if request.param == "compiled" else "0")  # read when a workspace first needs the kernels
+    return request.param
 
 
 def sym(M):
@@ -91,6 +95,9 @@ def test_state_kernels_random_trees(rbd, oracle, states_everywhere):
     for trial in range(16):
         mech = random_tree(rbd, rng, int(rng.integers(1, 26)), bool(trial % 2), float(rng.uniform(0, 0.6)))
         model = rbd.flatten(mech)
+        if states_everywhere == "compiled" and trial % 4:  # a run-time compile is seconds: every fourth tree
+            done += 1
+            continue
         B, nv = 65, model.nv
         state, q, v, tau, fe = make(rbd, model, B, "f64", "soa", 60 + trial)
         out = torch.zeros_like(state.v)
@@ -116,7 +123,7 @@ def test_state_kernels_take_large_batches_by_default(rbd, oracle, models):
     Mout = torch.zeros(B, nv * nv, dtype=torch.float32, device="cuda")
     rbd.mass_matrix_solve_(x, state, dev(tau, state), Mout)
     assert rbd.sync(state) == 0
-    assert "crba_state_kernel" in rbd.last_kernel(state)
+    assert "chol_spec_f32" in rbd.last_kernel(state) or "crba_state_kernel" in rbd.last_kernel(state)  # (the latter without hiprtc)
     idx = np.arange(0, B, 16)
     Mr = oracle.mass_matrix(model, q[idx], nthreads=8)
     got = Mout[torch.as_tensor(idx, device="cuda")].double().cpu().numpy().reshape(len(idx), nv, nv).transpose(0, 2, 1)
@@ -126,3 +133,64 @@ def test_state_kernels_take_large_batches_by_default(rbd, oracle, models):
     res = np.einsum("bij,bj->bi", Ms, xg) - tau[idx]
     eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau[idx], axis=1))
     assert eta.max() <= 1e-5, eta.max()
+
+
+def test_compiled_route_is_the_default_and_matches_the_interpreting_one(rbd, oracle, models, monkeypatch):
+    """Atlas, fp32, AOS at a batch the state kernels take by default: `mass_matrix!` + Cholesky through the kernels compiled for the mechanism
+    (M staged in the factorisation's order, sparse tile Cholesky, M re-emitted as the full square) against the interpreting CRBA + dense
+    tile Cholesky on the same inputs, and `mass_matrix!` alone (crba_spec + emit_spec) against the oracle."""
+    model = models["atlas_floating"]
+    B, nv = 32768 + 7, model.nv  # a ragged last group of 16
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RBD_JIT", mode)
+        state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 11)
+        x = torch.zeros_like(state.v)
+        Mout = torch.full((B, nv * nv), float("nan"), dtype=torch.float32, device="cuda")
+        rbd.mass_matrix_solve_(x, state, dev(tau, state), Mout)
+        assert rbd.sync(state) == 0
+        out[mode] = (x.double().cpu().numpy(), Mout.double().cpu().numpy().reshape(B, nv, nv).transpose(0, 2, 1), rbd.last_kernel(state))
+        if mode == "1":
+            x2 = torch.zeros_like(state.v)
+            rbd.mass_matrix_solve_(x2, state, dev(tau, state), None)  # M_out = NULL: no emission
+            assert rbd.sync(state) == 0
+            assert torch.equal(x2, x)
+            M2 = torch.full((B, nv * nv), float("nan"), dtype=torch.float32, device="cuda")
+            rbd.mass_matrix_(M2, state)
+            assert "emit_spec_f32" in rbd.last_kernel(state)
+            assert torch.equal(M2, Mout)  # the same kernels produce it
+    if "chol_spec_f32" not in out["1"][2]:
+        pytest.skip("hiprtc not available: " + out["1"][2])
+    assert "crba_state_kernel" in out["0"][2]
+    (xc, Mc, _), (xi, Mi, _) = out["1"], out["0"]
+    il = np.tril_indices(nv)
+    assert np.isfinite(Mc).all()  # the compiled route writes the whole square
+    assert np.abs(Mc - np.transpose(Mc, (0, 2, 1))).max() == 0.0
+    scale = np.abs(Mi[:, il[0], il[1]]).max()
+    assert np.abs(Mc[:, il[0], il[1]] - Mi[:, il[0], il[1]]).max() <= 2e-6 * scale
+    idx = np.arange(0, B, 64)
+    Mr = oracle.mass_matrix(model, q[idx], nthreads=8)
+    assert np.abs(Mc[idx][:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= 2e-6 * np.abs(Mr).max()
+    Ms = sym(Mr)
+    for xg in (xc, xi):
+        res = np.einsum("bij,bj->bi", Ms, xg[idx]) - tau[idx]
+        eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg[idx], axis=1) + np.linalg.norm(tau[idx], axis=1))
+        assert eta.max() <= 1e-5, eta.max()
+
+
+def test_not_positive_definite_is_reported_by_the_compiled_cholesky(rbd, models, monkeypatch):
+    """`rbd_cholesky_solve` keeps the dense kernel; the compiled one sits behind mass_matrix! — a NaN configuration must surface as status 8
+    (PosDefException's batched analogue) there too, and must not disturb the other states."""
+    monkeypatch.setenv("RBD_STATE_MIN_BATCH", "1")
+    model = models["atlas_floating"]
+    B = 64
+    state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 12)
+    x = torch.zeros_like(state.v)
+    rbd.mass_matrix_solve_(x, state, dev(tau, state), None)
+    assert rbd.sync(state) == 0
+    good = x.clone()
+    state.q[5, 9] = float("nan")
+    rbd.mass_matrix_solve_(x, state, dev(tau, state), None)
+    assert rbd.sync(state) == 8
+    keep = [i for i in range(B) if i != 5]
+    assert torch.equal(x[keep], good[keep])
