@@ -88,7 +88,10 @@ enum {
                                 registers.  Trees of revolute / prismatic / fixed joints, 6-dof joints on the world, at most 11 steps per
                                 track; RBD_ERR_UNSUPPORTED elsewhere or when the rows of 64 states do not fit one compute unit's LDS.
                                 Large batches                                                                                       */
-  RBD_ALGO_ABA_PIPE = 7      /* EXPERIMENTAL build only: a body-step cut into stages on the four SIMDs of a compute unit            */
+  RBD_ALGO_ABA_PIPE = 7,     /* EXPERIMENTAL build only: a body-step cut into stages on the four SIMDs of a compute unit            */
+  RBD_ALGO_ABA_COMPILED = 8  /* one lane per state, straight-line code compiled for the mechanism at run time (rbd_jit_* below): fp32,
+                                trees the one-lane-per-state kernels take; RBD_ALGO_ABA picks it from half a chip-full of wavefronts up.
+                                RBD_ERR_UNSUPPORTED without hiprtc or outside that scope                                            */
 };
 
 /* ---- loop (non-tree) joint: src/mechanism_modification.jl:38-43,

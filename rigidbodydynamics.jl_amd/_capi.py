@@ -13,7 +13,7 @@ HEADER_VERSION = 300  # RBD_HIP_H_VERSION of the include/rbd_hip.h this binding 
 F64, F32 = 0, 1
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 MEM_DEVICE, MEM_HOST = 0, 1
-ALGO_ABA, ALGO_CRBA_CHOLESKY, ALGO_ABA_LANES, ALGO_ABA_CHAINS, ALGO_ABA_BANKS, ALGO_ABA_TRACKS, ALGO_ABA_WALK, ALGO_ABA_PIPE = 0, 1, 2, 3, 4, 5, 6, 7
+ALGO_ABA, ALGO_CRBA_CHOLESKY, ALGO_ABA_LANES, ALGO_ABA_CHAINS, ALGO_ABA_BANKS, ALGO_ABA_TRACKS, ALGO_ABA_WALK, ALGO_ABA_PIPE, ALGO_ABA_COMPILED = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 # every symbol include/rbd_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = (

@@ -116,7 +116,8 @@ struct rbd_ws {
   WalkModel pm{}; void* d_pipe_rr = nullptr; void* d_pipe_rec = nullptr; size_t pipe_lds_bytes = 0; long pipe_max_batch = 0;  // role-pipelined mapping (rbd_pipe.hpp)
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
-  bool spec_tried = false; hipModule_t spec_mod = nullptr; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr;
+  bool spec_tried = false; hipModule_t spec_mod = nullptr; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr;
+  long spec_aba_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   long bank_min_batch = 0, bank_resident_states = 0;
@@ -1113,6 +1114,8 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   return RBD_OK;
 }
 
+static void spec_load(rbd_ws* w);  // the kernels compiled for the mechanism (below)
+
 // The fused articulated-body pass through whichever lane mapping fits: `algorithm` RBD_ALGO_ABA chooses by batch size
 // (measured crossovers, profiles/r01_mapping_sweep.txt), the RBD_ALGO_ABA_* values force one.  `gravity` overrides the
 // model's (the M^-1 solve runs the pass with g = 0); `fuse` folds a Munthe-Kaas stage into the launch (lanes / banks only).
@@ -1129,6 +1132,18 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   if (algorithm == RBD_ALGO_ABA_TRACKS && !can_track) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_CHAINS) return RBD_ERR_UNSUPPORTED;  // the chain mapping of round 1 lost at every batch size and was removed
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
+  if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !gravity && !fuse && w->dtype == RBD_F32) {
+    spec_load(w);
+    if (w->spec_aba && (algorithm == RBD_ALGO_ABA_COMPILED || B >= w->spec_aba_min_batch)) {
+      Timed t(w);
+      long Bl = B;
+      void* args[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf};
+      HIP_TRY(hipModuleLaunchKernel(w->spec_aba, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
+      w->last_kernel = "aba_spec_f32 (compiled for the mechanism at run time)";
+      return RBD_OK;
+    }
+  }
+  if (algorithm == RBD_ALGO_ABA_COMPILED) return RBD_ERR_UNSUPPORTED;
   int pick = algorithm;
   if (algorithm == RBD_ALGO_ABA) pick = (can_pipe && B <= w->pipe_max_batch) ? RBD_ALGO_ABA_PIPE : (can_walk && B >= w->walk_min_batch) ? RBD_ALGO_ABA_WALK : (can_track && B >= w->track_min_batch) ? RBD_ALGO_ABA_TRACKS : (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
   Timed t(w);
@@ -1197,6 +1212,20 @@ static void spec_load(rbd_ws* w) {
     get(&w->spec_chol, "chol_spec_f32");
     get(&w->spec_emit, "emit_spec_f32");
     if (!w->spec_crba_perm || !w->spec_chol || !w->spec_emit) w->spec_crba_perm = w->spec_chol = w->spec_emit = nullptr;
+  }
+  if (w->dtype == RBD_F32) {  // dynamics!, one lane per state (absent from the program for mechanisms spec_source leaves it out for)
+    if (hipModuleGetFunction(&w->spec_aba, w->spec_mod, "aba_spec_f32") != hipSuccess) { (void)hipGetLastError(); w->spec_aba = nullptr; }
+    int scratch = 0;
+    if (w->spec_aba && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_aba) != hipSuccess || scratch > 512)) {
+      (void)hipGetLastError();
+      w->spec_aba = nullptr;  // the per-body registers did not fit: the walk kernel is the better choice
+    }
+    // a wavefront of 64 states per SIMD: one round of them takes the same time from one wavefront to a chip-full, and beats the walk kernel's
+    // rounds of half as many states from the second of those on
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, w->device);
+    w->spec_aba_min_batch = (long)ncu * 4 * 64 / 2 + 1;
+    if (const char* e = getenv("RBD_SPEC_ABA_MIN_BATCH")) w->spec_aba_min_batch = atol(e);
   }
 }
 static hipFunction_t spec_crba(rbd_ws* w, size_t buffer_bytes) {

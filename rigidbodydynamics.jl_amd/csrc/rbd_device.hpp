@@ -542,7 +542,10 @@ RBD_HD void sincos_hd(float x, float* s, float* c) {
 // of the two-term constant, ~1e-15 k, stays below 1e-11); beyond that and for non-finite arguments the library.  Max error observed against libm
 // (fp64 reference) on 10^7 points in [-8192, 8192]: 9.3e-8 absolute.
 RBD_HD void sincos_fast(float x, float* sp, float* cp) {
+#ifndef RBD_JIT_COMPILE  // (the run-time compiled kernels are straight-line code with a sin/cos per joint and pass: beyond 8192 rad, where one fp32 ulp
+                         //  of the ANGLE is 1e-3 rad, they take the two-term reduction's error instead of a copy of the library path at every site)
   if (!(__builtin_fabsf(x) <= 8192.0f)) { sincos_hd(x, sp, cp); return; }
+#endif
   const float k = __builtin_rintf(x * 6.36619772e-01f);
   float r = __builtin_fmaf(k, -1.57079637e+00f, x);
   r = __builtin_fmaf(k, 4.37113883e-08f, r);

@@ -31,8 +31,16 @@ template <int N, typename F> RBD_DEV void sfor(F&& f) { sfor_impl(f, typename Ma
 
 namespace P = rbd_plan;
 
+// LDS written by some lanes of the wavefront, read by others: order the accesses for the compiler (the hardware executes a wavefront's LDS
+// instructions in order)
+RBD_DEV void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // (Rl, pl) = joint_to_predecessor * joint_transform(q) of op O in canonical frames (joint axis +z); qs: this lane's column of the staged q
-template <typename T, int O> RBD_DEV void local_transform(const T* qs, T* Rl, T* pl) {
+template <typename T, int O, int QS = 64> RBD_DEV void local_transform(const T* qs, T* Rl, T* pl) {
   constexpr int jt = P::OPW[O][0] >> 16, qoff = P::OPW[O][1];
   T C[9];
 #pragma unroll
@@ -41,8 +49,8 @@ template <typename T, int O> RBD_DEV void local_transform(const T* qs, T* Rl, T*
   for (int k = 0; k < 3; ++k) pl[k] = T(P::TR[O][TR_PP + k]);
   if constexpr (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_SINCOS_REVOLUTE) {
     T s, c;
-    if constexpr (jt == RBD_JOINT_REVOLUTE) sincos_fast(qs[qoff * 64], &s, &c);
-    else { s = qs[qoff * 64]; c = qs[(qoff + 1) * 64]; }
+    if constexpr (jt == RBD_JOINT_REVOLUTE) sincos_fast(qs[qoff * QS], &s, &c);
+    else { s = qs[qoff * QS]; c = qs[(qoff + 1) * QS]; }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       Rl[3 * i] = c * C[3 * i] + s * C[3 * i + 1];
@@ -51,8 +59,8 @@ template <typename T, int O> RBD_DEV void local_transform(const T* qs, T* Rl, T*
     }
   } else if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
     T Rq[9], pq[3], t[3];
-    rot_quat(qs[qoff * 64], qs[(qoff + 1) * 64], qs[(qoff + 2) * 64], qs[(qoff + 3) * 64], Rq);
-    pq[0] = qs[(qoff + 4) * 64]; pq[1] = qs[(qoff + 5) * 64]; pq[2] = qs[(qoff + 6) * 64];
+    rot_quat(qs[qoff * QS], qs[(qoff + 1) * QS], qs[(qoff + 2) * QS], qs[(qoff + 3) * QS], Rq);
+    pq[0] = qs[(qoff + 4) * QS]; pq[1] = qs[(qoff + 5) * QS]; pq[2] = qs[(qoff + 6) * QS];
     matmul3(C, Rq, Rl);
     matvec3(C, pq, t);
 #pragma unroll
@@ -61,7 +69,7 @@ template <typename T, int O> RBD_DEV void local_transform(const T* qs, T* Rl, T*
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rl[k] = C[k];
     if constexpr (jt == RBD_JOINT_PRISMATIC) {
-      const T d = qs[qoff * 64];
+      const T d = qs[qoff * QS];
 #pragma unroll
       for (int k = 0; k < 3; ++k) pl[k] += d * C[3 * k + 2];
     }
@@ -197,6 +205,345 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
 }
 
 
+
+#ifdef RBD_SPEC_ABA
+// ---------------------------------------------------------------------------------------------------------------------------------
+// dynamics! (the articulated-body algorithm, src/mechanism_algorithms.jl:845-864 through the world-frame recursion of the other ABA kernels),
+// one lane per state, compiled for rbd_plan's mechanism.  The depth-first walk is straight-line code, so everything the walk kernel
+// (rbd_walk.hpp) keeps in LDS rows, mailboxes and switch-addressed accumulation registers is here a plain local the allocator places:
+//   * ONE kinematic state (transform to root, twist, velocity-product acceleration a_vp with the world's -g folded in) walks down the tree
+//     and back up: leaving a body towards its parent the joint is UN-COMPOSED (H_parent = H X_joint^-1, T_parent = T - S q', a_parent =
+//     a - [T, S q']) — the walk kernel's device; a body with several children (a branch point) keeps a copy that its later children start from;
+//   * bottom-up, a chain body takes the hand-off (Ia = IA - U D^-1 U', pa = pA + U D^-1 u; the bias acceleration is folded into pA = I a_vp +
+//     T x* I T - w_ext, so there is no Ia c term) straight from the registers its child left it in; a branch point sums its children's in its slot;
+//   * what a body leaves behind for the top-down pass is U D^-1 (6) and D^-1 u (1): three in LDS rows the walk has no more use for, four in
+//     registers named by the body; that pass composes the
+//     transforms again (S is read off the body's transform), starting later children of a branch point from its saved (transform, a_delta).
+// Extra plan tables: BODY[NOPS] (depth-first ordinal of the op's body), NCH[NOPS] (its children), BS[NOPS] (its branch slot, or -1), PBS[NOPS]
+// (its parent's branch slot, or -1), CIDX[NOPS] (its rank among its siblings), NBS (slots), NEXT_EXIT[NOPS] (the next EXIT op after this one, or -1).
+// q, v, tau of the wavefront's 64 states are staged through LDS rows (stride 65: conflict-free both ways); v̇ and q̇ leave the same way, q̇ first.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int RS = 65;  // LDS row stride in values
+constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB);  // q, v, tau, spare
+
+// rows [0, n) <- the n x 64 block of a batch buffer that belongs to this wavefront's states (states past the end read the last one)
+template <typename T, int n> RBD_DEV void rows_in(const T* __restrict__ src, Layout L, long state0, long B, T* rows) {
+  const int lane = threadIdx.x & 63;
+  if (L.sk == 1 && L.sb == n) {  // state-major: one contiguous run of 64 n scalars, element e = (state e / n, row e % n)
+    const long lim = (B - state0) * n;  // elements of the block that exist
+#pragma unroll 4
+    for (int e0 = 0; e0 < 64 * n; e0 += 64) {
+      const int e = e0 + lane, st = e / n, k = e - st * n;
+      rows[k * RS + st] = src[state0 * n + (e < lim ? e : lim - n + k)];
+    }
+  } else {
+    const long sc = state0 + lane < B ? state0 + lane : B - 1;
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) rows[k * RS + lane] = src[(long)k * L.sk + sc * L.sb];
+  }
+}
+template <typename T, int n> RBD_DEV void rows_out(const T* rows, T* __restrict__ dst, Layout L, long state0, long B) {
+  const int lane = threadIdx.x & 63;
+  if (L.sk == 1 && L.sb == n) {
+    const long lim = (B - state0) * n;
+#pragma unroll 4
+    for (int e0 = 0; e0 < 64 * n; e0 += 64) {
+      const int e = e0 + lane, st = e / n, k = e - st * n;
+      if (e < lim) dst[state0 * n + e] = rows[k * RS + st];
+    }
+  } else if (state0 + lane < B) {
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) dst[(long)k * L.sk + (state0 + lane) * L.sb] = rows[k * RS + lane];
+  }
+}
+
+template <typename T> struct Kin { T R[9], p[3], Tw[6], av[6]; };
+template <typename T> struct Hand { T I[21], p[6]; };
+
+template <typename T>
+RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau, const T* __restrict__ fext,
+                      T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T* lds) {
+  constexpr int NQ = P::NQ, NV = P::NV, NB = P::NB, NBS = P::NBS > 0 ? P::NBS : 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* rq = lds + (size_t)wave * ABA_ROWS * RS;
+  T* rv = rq + NQ * RS;
+  T* rt = rv + NV * RS;
+  T* rx = rt + NV * RS;  // max(NQ, NB) rows: q̇ on its way out first, then one value per body for the top-down pass
+  const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
+  if (state0 >= B) return;
+  rows_in<T, NQ>(q, Lq, state0, B, rq);
+  rows_in<T, NV>(v, Lv, state0, B, rv);
+  if (tau) rows_in<T, NV>(tau, Lv, state0, B, rt);
+  else {
+#pragma unroll 4
+    for (int k = 0; k < NV; ++k) rt[k * RS + lane] = T(0);
+  }
+  wave_sync();
+  const T* qs = rq + lane;
+  T* vs = rv + lane;
+  T* ts = rt + lane;
+  T* xs = rx + lane;
+  // q̇ (configuration_derivative!, src/mechanism_state.jl:905-910) depends on q and v alone: assembled in the spare rows and sent off before the
+  // passes start (its stores drain while they run; the rows are free again long before pass 2 writes them)
+  if (qdot) {
+    sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
+      constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, jt = w0 >> 16, qoff = P::OPW[O][1], voff = P::OPW[O][2];
+      if constexpr (kind == SK_ENTER) {
+        if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {  // velocity_to_configuration_derivative! (quaternion_floating.jl:126-136)
+          T v6[6], Rq[9], lin[3];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v6[k] = vs[(voff + k) * RS];
+          const T qw = qs[qoff * RS], qx = qs[(qoff + 1) * RS], qy = qs[(qoff + 2) * RS], qz = qs[(qoff + 3) * RS];
+          xs[qoff * RS] = (-qx * v6[0] - qy * v6[1] - qz * v6[2]) / 2;
+          xs[(qoff + 1) * RS] = (qw * v6[0] - qz * v6[1] + qy * v6[2]) / 2;
+          xs[(qoff + 2) * RS] = (qz * v6[0] + qw * v6[1] - qx * v6[2]) / 2;
+          xs[(qoff + 3) * RS] = (-qy * v6[0] + qx * v6[1] + qw * v6[2]) / 2;
+          rot_quat(qw, qx, qy, qz, Rq);
+          matvec3(Rq, v6 + 3, lin);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) xs[(qoff + 4 + k) * RS] = lin[k];
+        } else if constexpr (jt == RBD_JOINT_SINCOS_REVOLUTE) {  // d/dt (sin, cos) = (cos, -sin) q'
+          const T qd = vs[voff * RS];
+          xs[qoff * RS] = qs[(qoff + 1) * RS] * qd;
+          xs[(qoff + 1) * RS] = -qs[qoff * RS] * qd;
+        } else if constexpr (jt != RBD_JOINT_FIXED) {
+          xs[qoff * RS] = vs[voff * RS];
+        }
+      }
+    });
+    wave_sync();
+    rows_out<T, NQ>(rx, qdot, Lq, state0, B);
+    wave_sync();
+  }
+  const long sc = state0 + lane < B ? state0 + lane : B - 1;
+  const T* fel = fext ? fext + sc * Lf.sb : nullptr;
+  const long fsk = Lf.sk;
+  const T a0[6] = {T(0), T(0), T(0), T(-P::GRAVITY[0]), T(-P::GRAVITY[1]), T(-P::GRAVITY[2])};  // the world's acceleration: -g (mechanism_algorithms.jl:396)
+
+  Kin<T> K;               // the body the walk is at
+  Hand<T> C;              // hand-off of the child just finished, on its way to a chain parent
+  Kin<T> SK[NBS];         // branch points: their kinematics ...
+  Hand<T> SH[NBS];        // ... and the sum of their children's hand-offs
+  // per body, for the top-down pass: D^-1 u and U D^-1.  The first goes to the body's tau row (read for the last time when u is formed, written again
+  // only by that pass), two of the others to its spare row and its v row (free once the joint is un-composed), four stay in registers
+  T Ud[NB][4];
+  T fe[6];                // external wrench of the body the next EXIT finishes (asked for one EXIT ahead)
+  auto load_fe = [&](auto oc) __attribute__((always_inline)) {
+    constexpr int O = oc.value;
+    if constexpr (O >= 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fe[k] = fel ? fel[(long)(P::OPW[O][3] + k) * fsk] : T(0);
+    }
+  };
+  load_fe(Ix<P::FIRST_EXIT>{});
+
+  // ---- passes 1 + 2: down with the kinematics, up with the articulated inertias ----
+  sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
+    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
+    constexpr int body = P::BODY[O], nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
+    if constexpr (kind == SK_ENTER) {
+      if constexpr (lvl == 0) {  // the parent is the world
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) K.p[k] = T(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { K.Tw[k] = T(0); K.av[k] = a0[k]; }
+      }  // (otherwise K is the parent's: it was just entered, or the sibling finished before this body restored it from the parent's slot)
+      T Rl[9], pl[3], Rn[9], pn[3], t3[3], vJ[6], cb[6];
+      local_transform<T, O, RS>(qs, Rl, pl);
+      matmul3(K.R, Rl, Rn);
+      matvec3(K.R, pl, t3);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pn[k] = K.p[k] + t3[k];
+      if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+        T v6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v6[k] = vs[(voff + k) * RS];
+        xmotion(Rn, pn, v6, vJ);  // twist of the joint: X(H) v, v the body-frame twist
+      } else if constexpr (jt == RBD_JOINT_FIXED) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vJ[k] = T(0);
+      } else {
+        const T qd = vs[voff * RS];
+        T S[6];
+        if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = T(0); S[3] = Rn[2]; S[4] = Rn[5]; S[5] = Rn[8]; }
+        else { S[0] = Rn[2]; S[1] = Rn[5]; S[2] = Rn[8]; cross3(pn, S, S + 3); }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
+      }
+      se3_comm(K.Tw, vJ, cb);  // [T_parent, vJ]: the bias acceleration increment (mechanism_state.jl:814-830)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { K.av[k] += cb[k]; K.Tw[k] += vJ[k]; }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) K.p[k] = pn[k];
+      if constexpr (nch >= 2) SK[bs] = K;
+    } else {
+      // the walk is back at this body: K is its kinematic state (un-composed from its only child, restored from its slot, or — a leaf — just entered)
+      RInertia<T> I;
+      T J6[6], mc[3];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) J6[k] = T(P::TR[O][TR_J + k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) mc[k] = T(P::TR[O][TR_MC + k]);
+      inertia_to_root(J6, mc, T(P::TR[O][TR_M]), K.R, K.p, I);
+      T IA[21], pA[6], h[6];
+      mul_inertia(I, K.av, pA);
+      momentum_cross(I, K.Tw, h);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pA[k] += h[k] - fe[k];
+      load_fe(Ix<P::NEXT_EXIT[O]>{});
+      sym6_from_inertia(I, IA);
+      if constexpr (nch == 1) {
+#pragma unroll
+        for (int k = 0; k < 21; ++k) IA[k] += C.I[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pA[k] += C.p[k];
+      } else if constexpr (nch >= 2) {
+#pragma unroll
+        for (int k = 0; k < 21; ++k) IA[k] += SH[bs].I[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pA[k] += SH[bs].p[k];
+      }
+      Hand<T> H;
+      T S[6], qd = T(0);
+      if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+        // 6-dof joint on the world: IA a_delta = S^-T tau - pA, v̇ = S^-1 a_delta (S = X(H): the body-frame twist basis seen from the root)
+        T t6[6], f6[6], ad0[6], vd[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t6[k] = ts[(voff + k) * RS];
+        xforce(K.R, K.p, t6, f6);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f6[k] -= pA[k];
+        sym6_solve(IA, f6, ad0);
+        xmotion_inv(K.R, K.p, ad0, vd);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ts[(voff + k) * RS] = vd[k]; vs[(voff + k) * RS] = ad0[k]; }  // a_delta waits in the joint's v rows
+      } else if constexpr (jt == RBD_JOINT_FIXED) {  // S = 0: the body hands its whole inertia up
+#pragma unroll
+        for (int k = 0; k < 21; ++k) H.I[k] = IA[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) H.p[k] = pA[k];
+      } else {
+        if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = T(0); S[3] = K.R[2]; S[4] = K.R[5]; S[5] = K.R[8]; }
+        else { S[0] = K.R[2]; S[1] = K.R[5]; S[2] = K.R[8]; cross3(K.p, S, S + 3); }
+        T U[6], W[6];
+        sym6_mul(IA, S, U);
+        const T Dinv = rcp_hd(dot6(S, U));
+        qd = vs[voff * RS];
+        const T u = (ts[voff * RS] - dot6(S, pA)) * Dinv;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) W[k] = U[k] * Dinv;
+        ts[voff * RS] = u;
+        xs[body * RS] = W[0];
+        vs[voff * RS] = W[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Ud[body][k] = W[2 + k];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j) H.I[SI(i, j)] = IA[SI(i, j)] - W[i] * U[j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) H.p[k] = pA[k] + U[k] * u;
+      }
+      if constexpr (lvl > 0) {
+        if constexpr (pbs >= 0) {  // the parent is a branch point: add to its slot, continue from its kinematics
+          if constexpr (cidx == 0) SH[pbs] = H;
+          else {
+#pragma unroll
+            for (int k = 0; k < 21; ++k) SH[pbs].I[k] += H.I[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) SH[pbs].p[k] += H.p[k];
+          }
+          K = SK[pbs];
+        } else {  // a chain parent: the hand-off stays in registers, the joint is un-composed
+          C = H;
+          if constexpr (jt != RBD_JOINT_FIXED) {
+            T vJ[6], cb[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
+            se3_comm(K.Tw, vJ, cb);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { K.av[k] -= cb[k]; K.Tw[k] -= vJ[k]; }
+          }
+          T Rl[9], pl[3], Rp[9], t3[3];
+          local_transform<T, O, RS>(qs, Rl, pl);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Rp[3 * i + j] = K.R[3 * i] * Rl[3 * j] + K.R[3 * i + 1] * Rl[3 * j + 1] + K.R[3 * i + 2] * Rl[3 * j + 2];  // R Rl'
+          matvec3(Rp, pl, t3);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) K.R[k] = Rp[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) K.p[k] -= t3[k];
+        }
+      }
+    }
+  });
+
+  // ---- pass 3: down again with the accelerations ----
+  T ad[6];
+  T SR[NBS][12], SA[NBS][6];  // branch points: transform, a_delta
+  sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
+    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
+    constexpr int body = P::BODY[O], nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
+    if constexpr (kind == SK_ENTER) {
+      if constexpr (lvl == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) K.p[k] = T(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ad[k] = T(0);
+      } else if constexpr (cidx > 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K.R[k] = SR[pbs][k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) K.p[k] = SR[pbs][9 + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ad[k] = SA[pbs][k];
+      }
+      if constexpr (nch > 0 || (jt != RBD_JOINT_FIXED && jt != RBD_JOINT_QUAT_FLOATING)) {  // (a leaf on a fixed joint has nothing left to do)
+        T Rl[9], pl[3], Rn[9], t3[3];
+        local_transform<T, O, RS>(qs, Rl, pl);
+        matmul3(K.R, Rl, Rn);
+        matvec3(K.R, pl, t3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) K.p[k] += t3[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
+        if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ad[k] = vs[(voff + k) * RS];  // solved for on the way up (v̇ is already in its rows)
+        } else if constexpr (jt != RBD_JOINT_FIXED) {
+          T S[6];
+          if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = T(0); S[3] = K.R[2]; S[4] = K.R[5]; S[5] = K.R[8]; }
+          else { S[0] = K.R[2]; S[1] = K.R[5]; S[2] = K.R[8]; cross3(K.p, S, S + 3); }
+          const T W[6] = {xs[body * RS], vs[voff * RS], Ud[body][0], Ud[body][1], Ud[body][2], Ud[body][3]};
+          const T vd = ts[voff * RS] - dot6(W, ad);  // v̇ = D^-1 u - (U D^-1)' a_delta,parent
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ad[k] += S[k] * vd;
+          ts[voff * RS] = vd;
+        }
+        if constexpr (nch >= 2) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) SR[bs][k] = K.R[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) SR[bs][9 + k] = K.p[k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) SA[bs][k] = ad[k];
+        }
+      }
+    }
+  });
+  wave_sync();
+  rows_out<T, NV>(rt, vdot, Lv, state0, B);
+}
+#endif  // RBD_SPEC_ABA
+
 #ifdef RBD_SPEC_CHOL
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The dense step of `dynamics_solve!` (potrf! / potrs!, src/mechanism_algorithms.jl:764, :819) specialised on the SPARSITY of the mechanism's
@@ -220,13 +567,7 @@ RBD_DEV float qsum(float x) {
   return x;
 }
 RBD_DEV int sel4(int r, int a, int b, int c, int d) { return r == 0 ? a : r == 1 ? b : r == 2 ? c : d; }
-// LDS written by some lanes of the wavefront, read by others: order the accesses for the compiler (the hardware executes a wavefront's LDS
-// instructions in order)
-RBD_DEV void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+
 
 RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const float* __restrict__ tau, const float* __restrict__ c,
                        float* __restrict__ x, Layout Lv, int* __restrict__ notpd) {

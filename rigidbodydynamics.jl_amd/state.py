@@ -244,7 +244,7 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
     """`dynamics!(result, state, torques, externalwrenches; stabilization_gains)` (src/mechanism_algorithms.jl:845-864):
     fills `result.vd` (v̇) and `result.qd` (q̇).  `torques` (B, nv) defaults to zeros; `externalwrenches` is a dense
     (B, 6*n_bodies) tensor of root-frame wrenches (torque; force) per moving body (None == NullDict).
-    algorithm="aba": fused articulated-body kernel (mapping chosen by batch size; "aba_pipe" / "aba_walk" / "aba_tracks" / "aba_lanes" / "aba_banks" / "aba_chains" force one);
+    algorithm="aba": fused articulated-body kernel (mapping chosen by batch size; "aba_compiled" / "aba_pipe" / "aba_walk" / "aba_tracks" / "aba_lanes" / "aba_banks" / "aba_chains" force one);
     "crba": the reference's own CRBA + Cholesky route, which also fills result.massmatrix and result.dynamicsbias."""
     f = state.flat
     _check_result(result, state)
@@ -252,7 +252,8 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
     state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
     state.ws.use_current_stream()
     algo = {"aba": _capi.ALGO_ABA, "crba": _capi.ALGO_CRBA_CHOLESKY, "aba_lanes": _capi.ALGO_ABA_LANES,
-            "aba_chains": _capi.ALGO_ABA_CHAINS, "aba_banks": _capi.ALGO_ABA_BANKS, "aba_tracks": _capi.ALGO_ABA_TRACKS, "aba_walk": _capi.ALGO_ABA_WALK, "aba_pipe": _capi.ALGO_ABA_PIPE}[algorithm]
+            "aba_chains": _capi.ALGO_ABA_CHAINS, "aba_banks": _capi.ALGO_ABA_BANKS, "aba_tracks": _capi.ALGO_ABA_TRACKS, "aba_walk": _capi.ALGO_ABA_WALK, "aba_pipe": _capi.ALGO_ABA_PIPE,
+            "aba_compiled": _capi.ALGO_ABA_COMPILED}[algorithm]
     opts = state._opts(algo, 0 if stabilization_gains is None else 1)
     lam = result.lambda_ if f.nc > 0 else None
     if getattr(f, "ns", 0) > 0:

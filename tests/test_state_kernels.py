@@ -194,3 +194,91 @@ def test_not_positive_definite_is_reported_by_the_compiled_cholesky(rbd, models,
     assert rbd.sync(state) == 8
     keep = [i for i in range(B) if i != 5]
     assert torch.equal(x[keep], good[keep])
+
+
+# ---- dynamics! compiled for the mechanism (aba_spec, csrc/rbd_spec.hpp) -----------------------------------------------------------------
+def backward_error(oracle, model, q, v, tau, fe, vd):
+    """‖M v̇ − (τ − c)‖ / (‖M‖‖v̇‖ + ‖τ − c‖) per state: the fp32 measure the other large-batch ABA tests use (the forward error carries cond(M))."""
+    Mr = oracle.mass_matrix(model, q, nthreads=8)
+    c = oracle.dynamics_bias(model, q, v, fe, nthreads=8)
+    Ms = sym(Mr)
+    res = np.einsum("bij,bj->bi", Ms, vd) - (tau - c)
+    return np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(vd, axis=1) + np.linalg.norm(tau - c, axis=1) + 1e-300)
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", IN_SCOPE)
+def test_compiled_aba_f32(rbd, oracle, models, name, layout):
+    """`dynamics!` through the kernel compiled for the mechanism, forced (RBD_ALGO_ABA_COMPILED): a ragged batch (three wavefronts, the last partly
+    filled), torques + a wrench on every body + q̇; then no torques and no wrenches; against the oracle (backward error, the q̇ map exactly to fp32)
+    and against the lane-per-body kernel on the same inputs."""
+    model = models[name]
+    B = 150
+    state, q, v, tau, fe = make(rbd, model, B, "f32", layout, 71)
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32, layout=layout)
+    try:
+        rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_compiled")
+    except rbd._capi.RBDError as e:
+        if e.status == 3:
+            pytest.skip("hiprtc not available")
+        raise
+    assert rbd.sync(state) == 0 and "aba_spec_f32" in rbd.last_kernel(state)
+    vd = host(result.vd, state)
+    assert np.isfinite(vd).all()
+    assert backward_error(oracle, model, q, v, tau, fe, vd).max() <= 2e-6
+    _, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    assert np.abs(host(result.qd, state) - qd_ref).max() <= 2e-6 * max(1.0, np.abs(qd_ref).max())
+    ref = rbd.DynamicsResult(model, B, dtype=torch.float32, layout=layout)
+    rbd.dynamics_(ref, state, dev(tau, state), dev(fe, state), algorithm="aba_lanes")
+    assert np.abs(vd - host(ref.vd, state)).max() <= 2e-3 * max(1.0, np.abs(vd).max())  # two fp32 evaluations of an ill-conditioned solve
+    result.vd.fill_(float("nan"))
+    rbd.dynamics_(result, state, None, None, algorithm="aba_compiled")
+    vd = host(result.vd, state)
+    assert backward_error(oracle, model, q, v, np.zeros_like(tau), None, vd).max() <= 2e-6
+
+
+def test_compiled_aba_random_trees(rbd, oracle):
+    """Random revolute / prismatic / fixed / sin-cos trees, with and without a 6-dof root: chains, bushes, branch points below branch points."""
+    from test_chain_plan import random_tree
+    rng = np.random.default_rng(23)
+    done = 0
+    for trial in range(6):
+        mech = random_tree(rbd, rng, int(rng.integers(2, 22)), bool(trial % 2), float(rng.uniform(0, 0.8)))
+        model = rbd.flatten(mech)
+        B = 70
+        state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 80 + trial)
+        result = rbd.DynamicsResult(model, B, dtype=torch.float32)
+        try:
+            rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_compiled")
+        except rbd._capi.RBDError as e:
+            if e.status == 3:
+                continue  # no hiprtc, or the tree's per-body registers did not fit
+            raise
+        vd = host(result.vd, state)
+        assert backward_error(oracle, model, q, v, tau, fe, vd).max() <= 5e-6, trial
+        _, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+        assert np.abs(host(result.qd, state) - qd_ref).max() <= 2e-6 * max(1.0, np.abs(qd_ref).max()), trial
+        done += 1
+    assert done >= 4 or done == 0
+
+
+def test_compiled_aba_is_the_default_for_large_fp32_batches(rbd, oracle, models):
+    """BASELINE configs[3]'s shard: 65 536 fp32 states go through aba_spec by default; the whole batch's backward error; a NaN state stays alone."""
+    model = models["atlas_floating"]
+    B = 65536
+    state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 31)
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32)
+    rbd.dynamics_(result, state, dev(tau, state))
+    assert rbd.sync(state) == 0
+    if "aba_spec_f32" not in rbd.last_kernel(state):
+        pytest.skip("hiprtc not available: " + rbd.last_kernel(state))
+    vd = host(result.vd, state)
+    assert backward_error(oracle, model, q, v, tau, None, vd).max() <= 2e-6
+    good = result.vd.clone()
+    state.q[77, 9] = float("nan")
+    rbd.dynamics_(result, state, dev(tau, state))
+    torch.cuda.synchronize()
+    assert not torch.isfinite(result.vd[77]).all()
+    keep = torch.ones(B, dtype=torch.bool, device="cuda")
+    keep[77] = False
+    assert torch.equal(result.vd[keep], good[keep])
