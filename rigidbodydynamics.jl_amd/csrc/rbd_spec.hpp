@@ -213,7 +213,7 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
 // (rbd_walk.hpp) keeps in LDS rows, mailboxes and switch-addressed accumulation registers is here a plain local the allocator places:
 //   * ONE kinematic state (transform to root, twist, velocity-product acceleration a_vp with the world's -g folded in) walks down the tree
 //     and back up: leaving a body towards its parent the joint is UN-COMPOSED (H_parent = H X_joint^-1, T_parent = T - S q', a_parent =
-//     a - [T, S q']) — the walk kernel's device; a body with several children (a branch point) keeps a copy that its later children start from;
+//     a - [T, S q']) — the walk kernel's device — so that no body's kinematics are kept, not even a branch point's;
 //   * bottom-up, a chain body takes the hand-off (Ia = IA - U D^-1 U', pa = pA + U D^-1 u; the bias acceleration is folded into pA = I a_vp +
 //     T x* I T - w_ext, so there is no Ia c term) straight from the registers its child left it in; a branch point sums its children's in its slot;
 //   * what a body leaves behind for the top-down pass is U D^-1 (6) and D^-1 u (1): three in LDS rows the walk has no more use for, four in
@@ -322,8 +322,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 
   Kin<T> K;               // the body the walk is at
   Hand<T> C;              // hand-off of the child just finished, on its way to a chain parent
-  Kin<T> SK[NBS];         // branch points: their kinematics ...
-  Hand<T> SH[NBS];        // ... and the sum of their children's hand-offs
+  Hand<T> SH[NBS];        // branch points: the sum of their children's hand-offs
   // per body, for the top-down pass: D^-1 u and U D^-1.  The first goes to the body's tau row (read for the last time when u is formed, written again
   // only by that pass), two of the others to its spare row and its v row (free once the joint is un-composed), four stay in registers
   T Ud[NB][4];
@@ -349,7 +348,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
         for (int k = 0; k < 3; ++k) K.p[k] = T(0);
 #pragma unroll
         for (int k = 0; k < 6; ++k) { K.Tw[k] = T(0); K.av[k] = a0[k]; }
-      }  // (otherwise K is the parent's: it was just entered, or the sibling finished before this body restored it from the parent's slot)
+      }  // (otherwise K is the parent's: it was just entered, or the sibling finished before this body un-composed its joint)
       T Rl[9], pl[3], Rn[9], pn[3], t3[3], vJ[6], cb[6];
       local_transform<T, O, RS>(qs, Rl, pl);
       matmul3(K.R, Rl, Rn);
@@ -379,7 +378,6 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
       for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) K.p[k] = pn[k];
-      if constexpr (nch >= 2) SK[bs] = K;
     } else {
       // the walk is back at this body: K is its kinematic state (un-composed from its only child, restored from its slot, or — a leaf — just entered)
       RInertia<T> I;
@@ -449,7 +447,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
         for (int k = 0; k < 6; ++k) H.p[k] = pA[k] + U[k] * u;
       }
       if constexpr (lvl > 0) {
-        if constexpr (pbs >= 0) {  // the parent is a branch point: add to its slot, continue from its kinematics
+        if constexpr (pbs >= 0) {  // the parent is a branch point: its slot sums its children's hand-offs
           if constexpr (cidx == 0) SH[pbs] = H;
           else {
 #pragma unroll
@@ -457,29 +455,29 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
             for (int k = 0; k < 6; ++k) SH[pbs].p[k] += H.p[k];
           }
-          K = SK[pbs];
-        } else {  // a chain parent: the hand-off stays in registers, the joint is un-composed
+        } else {  // a chain parent: the hand-off stays in registers
           C = H;
-          if constexpr (jt != RBD_JOINT_FIXED) {
-            T vJ[6], cb[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
-            se3_comm(K.Tw, vJ, cb);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { K.av[k] -= cb[k]; K.Tw[k] -= vJ[k]; }
-          }
-          T Rl[9], pl[3], Rp[9], t3[3];
-          local_transform<T, O, RS>(qs, Rl, pl);
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) Rp[3 * i + j] = K.R[3 * i] * Rl[3 * j] + K.R[3 * i + 1] * Rl[3 * j + 1] + K.R[3 * i + 2] * Rl[3 * j + 2];  // R Rl'
-          matvec3(Rp, pl, t3);
-#pragma unroll
-          for (int k = 0; k < 9; ++k) K.R[k] = Rp[k];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) K.p[k] -= t3[k];
         }
+        // back to the parent: the joint is un-composed (a copy of every branch point's kinematics would cost more registers than the file has)
+        if constexpr (jt != RBD_JOINT_FIXED) {
+          T vJ[6], cb[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
+          se3_comm(K.Tw, vJ, cb);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { K.av[k] -= cb[k]; K.Tw[k] -= vJ[k]; }
+        }
+        T Rl[9], pl[3], Rp[9], t3[3];
+        local_transform<T, O, RS>(qs, Rl, pl);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Rp[3 * i + j] = K.R[3 * i] * Rl[3 * j] + K.R[3 * i + 1] * Rl[3 * j + 1] + K.R[3 * i + 2] * Rl[3 * j + 2];  // R Rl'
+        matvec3(Rp, pl, t3);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K.R[k] = Rp[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) K.p[k] -= t3[k];
       }
     }
   });

@@ -11,7 +11,7 @@ def load(name): return rbd.load_flat_model(os.path.join(ROOT, "tests", "golden",
 models = {n: load(n) for n in ("atlas_floating", "atlas_fixed", "valkyrie_floating", "acrobot_urdf")}
 models["double_pendulum"] = rbd.flatten(rbd.double_pendulum())
 rng = np.random.default_rng(5)
-for name, model in models.items():
+for name, model in ([] if os.environ.get('TIMING_ONLY') else models.items()):
     B = 200
     q = rbd.rand_configuration(model, B, rng).astype(np.float32).astype(np.float64); v = rbd.rand_velocity(model, B, rng).astype(np.float32).astype(np.float64)
     tau = rng.standard_normal((B, model.nv)).astype(np.float32).astype(np.float64); fe = rng.standard_normal((B, 6 * model.n_bodies)).astype(np.float32).astype(np.float64)
@@ -37,7 +37,7 @@ for name, model in models.items():
                   "qd err", float(np.abs(host(result.qd) - qd).max()), rbd.last_kernel(state), flush=True)
 
 model = models["atlas_floating"]
-for B in (16384, 32768, 65536, 131072):
+for B in (16384, 65536):
     state = rbd.MechanismState(model, B, dtype=torch.float32); result = rbd.DynamicsResult(model, B, dtype=torch.float32)
     rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng)); rbd.set_velocity_(state, rbd.rand_velocity(model, B, rng))
     tau = torch.rand(B, model.nv, dtype=torch.float32, device="cuda")
