@@ -536,19 +536,11 @@ def main():
     if args.selftest_launch:
         return selftest_launch(args)
     env = setup(args)
+    out = run(args, env)
     headline = args.config == 2 and not args.no_other_configs and args.batch == CONFIGS[2]["batch"] and args.dtype == CONFIGS[2]["dtype"]
-    if not headline:
-        out = run(args, env)
-    else:
+    if headline:
         # The other BASELINE configs ride on the driver's line (round-2 review): each with its own ms_per_step, roofline and whole-batch parity;
         # `value` stays configs[1].  N > 1: only configs[3] (the sharded one) — with the RCCL gather outside and inside the timed region.
-        # Order: the headline's W + K steps are measured FIRST on a GPU that has been idle (`first_measurement`: the first launches run at
-        # lower clocks — a 19 us kernel x 20 steps is over before the clocks are up), then the riders, then the headline's W + K steps again:
-        # `value`, the GPU at the clocks it sustains under load.  Both are in the line.
-        import copy
-        quick = copy.copy(args)
-        quick.no_cpu_baseline = quick.no_pipelined = quick.no_extra_legs = True
-        first = run(quick, env)
         extra = {}
         todo = [("config4_shard", sub_args(args, 4))]
         if env["world"] == 1:
@@ -559,12 +551,7 @@ def main():
                 extra[name] = block(run(a, env))
             except Exception as e:  # never lose the headline to a rider
                 extra[name] = f"failed: {type(e).__name__}: {e}"
-        out = run(args, env)
         if out is not None:
-            if first is not None:
-                out["first_measurement"] = {"value": first["value"], "unit": first["unit"], "ms_per_step": first["ms_per_step"], "kernel_ms": first["roofline"]["kernel_ms"],
-                                            "note": "the same W warm-up + K timed steps as `value`, run first in this process on an idle GPU (before the other "
-                                                    "configs' blocks): the first launches run at lower clocks; `value` is measured after those blocks"}
             out.update(extra)
     if out is not None:
         print(json.dumps(out))
