@@ -101,7 +101,7 @@ def lib():
         L.rbd_simulate_contact.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.c_double, i32, ctypes.POINTER(Opts)]
         L.rbd_workspace_enable_timing.argtypes = [vp, i32]
         L.rbd_jit_precompile.argtypes = [vp, i32, ctypes.c_char_p, ctypes.c_int64]
-        L.rbd_jit_source.argtypes = [vp, i32, ctypes.c_char_p, ctypes.c_int64]
+        L.rbd_jit_source.argtypes = [vp, i32, i32, ctypes.c_char_p, ctypes.c_int64]
         L.rbd_jit_source.restype = ctypes.c_int64
         L.rbd_workspace_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         _lib = L

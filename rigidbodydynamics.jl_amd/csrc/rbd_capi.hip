@@ -116,8 +116,8 @@ struct rbd_ws {
   WalkModel pm{}; void* d_pipe_rr = nullptr; void* d_pipe_rec = nullptr; size_t pipe_lds_bytes = 0; long pipe_max_batch = 0;  // role-pipelined mapping (rbd_pipe.hpp)
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
-  bool spec_tried = false; hipModule_t spec_mod = nullptr; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr;
-  long spec_aba_min_batch = 0;
+  bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr;
+  long spec_aba_min_batch = 0, spec_rnea_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   long bank_min_batch = 0, bank_resident_states = 0;
@@ -154,9 +154,10 @@ int rbd_experimental(void) {
 #endif
 }
 // run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
-int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, char* buf, int64_t cap) {
-  if (!m || !m->state.ok || (dtype != RBD_F32 && dtype != RBD_F64)) return -1;
-  const std::string s = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype);
+int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char* buf, int64_t cap) {
+  if (!m || !m->state.ok || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family >= SPEC_FAMILIES) return -1;
+  const std::string s = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
+  if (s.empty()) return -1;
   if (buf && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)s.size()); memcpy(buf, s.data(), (size_t)n); buf[n] = 0; }
   return (int64_t)s.size();
 }
@@ -164,10 +165,17 @@ int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t c
   if (log && cap > 0) log[0] = 0;
   if (!m || (dtype != RBD_F32 && dtype != RBD_F64)) return RBD_ERR_INVALID_ARGUMENT;
   if (!m->state.ok || !jit_available()) return RBD_ERR_UNSUPPORTED;
-  std::string lg;
-  const std::vector<char> code = jit_code_object(spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype), &lg);
-  if (log && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)lg.size()); memcpy(log, lg.data(), (size_t)n); log[n] = 0; }
-  return code.empty() ? RBD_ERR_HIP : RBD_OK;
+  int st = RBD_OK;
+  std::string all;
+  for (int family = 0; family < SPEC_FAMILIES; ++family) {
+    const std::string src = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
+    if (src.empty()) continue;
+    std::string lg;
+    if (jit_code_object(src, &lg).empty()) st = RBD_ERR_HIP;
+    all += lg;
+  }
+  if (log && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)all.size()); memcpy(log, all.data(), (size_t)n); log[n] = 0; }
+  return st;
 }
 
 const char* rbd_status_string(int s) {
@@ -905,7 +913,7 @@ int rbd_workspace_destroy(rbd_ws_t* w) {
     void* mkp[] = {w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.phid[1], w->mk.phid[2], w->mk.phid[3], w->mk.vd[0], w->mk.vd[1], w->mk.vd[2], w->mk.vd[3], w->d_vdwork};
     for (void* p : mkp) if (p) (void)hipFree(p);
   }
-  if (w->spec_mod) (void)hipModuleUnload(w->spec_mod);
+  for (hipModule_t mod : w->spec_mod) if (mod) (void)hipModuleUnload(mod);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   delete w;
@@ -1080,6 +1088,8 @@ int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const vo
 static int big_scratch(rbd_ws* w, int32_t B) { return ensure(&w->d_big_scratch, &w->d_big_scratch_bytes, esize(w) * big_scratch_elems(w->big, B)); }
 
 // inverse_dynamics! / dynamics_bias! (vdot == nullptr) through the lane mapping that fits the batch: same rule as run_aba
+static void spec_load(rbd_ws* w, int family);  // the kernels compiled for the mechanism (below)
+
 static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const void* dv, const void* dvd, const void* df, void* dtau, void* dqd,
                     Layout Lq, Layout Lv, Layout Lf, void* dacc = nullptr, void* djw = nullptr) {
   const rbd_model* m = w->model;
@@ -1095,6 +1105,17 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
   const bool can_walk = m->track.ok && m->walk.ok && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch));
   if (mapping == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
+  if (!dacc && !djw && !dqd && w->dtype == RBD_F32 && (mapping == RBD_ALGO_ABA || mapping == RBD_ALGO_ABA_COMPILED)) {  // the kernel compiled for the mechanism: tau alone, large batches
+    spec_load(w, SPEC_RNEA);
+    if (w->spec_rnea && (mapping == RBD_ALGO_ABA_COMPILED || B >= w->spec_rnea_min_batch)) {
+      long Bl = B;
+      void* args[] = {&Bl, &dq, &dv, &dvd, &df, &dtau, &Lq, &Lv, &Lf};
+      HIP_TRY(hipModuleLaunchKernel(w->spec_rnea, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
+      w->last_kernel = "rnea_spec_f32 (compiled for the mechanism at run time)";
+      return RBD_OK;
+    }
+  }
+  if (mapping == RBD_ALGO_ABA_COMPILED) return RBD_ERR_UNSUPPORTED;
   if (can_walk && (mapping == RBD_ALGO_ABA_WALK || (mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->walk_min_batch))) {
     // one wavefront per track, one lane per state (rnea_walk_kernel): large batches
     const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
@@ -1114,8 +1135,6 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   return RBD_OK;
 }
 
-static void spec_load(rbd_ws* w);  // the kernels compiled for the mechanism (below)
-
 // The fused articulated-body pass through whichever lane mapping fits: `algorithm` RBD_ALGO_ABA chooses by batch size
 // (measured crossovers, profiles/r01_mapping_sweep.txt), the RBD_ALGO_ABA_* values force one.  `gravity` overrides the
 // model's (the M^-1 solve runs the pass with g = 0); `fuse` folds a Munthe-Kaas stage into the launch (lanes / banks only).
@@ -1133,7 +1152,7 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   if (algorithm == RBD_ALGO_ABA_CHAINS) return RBD_ERR_UNSUPPORTED;  // the chain mapping of round 1 lost at every batch size and was removed
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !gravity && !fuse && w->dtype == RBD_F32) {
-    spec_load(w);
+    spec_load(w, SPEC_ABA);
     if (w->spec_aba && (algorithm == RBD_ALGO_ABA_COMPILED || B >= w->spec_aba_min_batch)) {
       Timed t(w);
       long Bl = B;
@@ -1196,40 +1215,48 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
 // The run-time specialised form of the one-lane-per-state kernels (rbd_spec.hpp): compiled for this mechanism on the workspace's first use of
 // them (or loaded from the on-disk cache), nullptr when hiprtc is unavailable, RBD_JIT=0, or the compile failed — callers then keep the
 // interpreting kernels.  Its stores address M with a 32-bit lane offset: buffers of 4 GB and more stay with the interpreting kernel.
-static void spec_load(rbd_ws* w) {
-  if (w->spec_tried) return;
-  w->spec_tried = true;
+static void spec_load(rbd_ws* w, int family) {
+  if (w->spec_tried[family]) return;
+  w->spec_tried[family] = true;
   const rbd_model* m = w->model;
-  if (!m->state.ok || !jit_available()) return;
+  if (!m->state.ok || !jit_available() || !spec_has(family, w->dtype, m->nb, m->nq, m->nv)) return;
   std::string log;
-  const std::vector<char> code = jit_code_object(spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype), &log);
+  const std::vector<char> code = jit_code_object(spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype, family), &log);
   if (code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernels are used): " + log; return; }
-  if (hipModuleLoadData(&w->spec_mod, code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_mod = nullptr; return; }
-  auto get = [&](hipFunction_t* f, const char* name) { if (hipModuleGetFunction(f, w->spec_mod, name) != hipSuccess) { (void)hipGetLastError(); *f = nullptr; } };
-  get(&w->spec_crba, w->dtype == RBD_F64 ? "crba_spec_f64" : "crba_spec_f32");
-  if (w->dtype == RBD_F32 && m->nv > 0 && m->nv % 4 == 0 && m->nv <= 40) {  // (the condition under which spec_source emits them)
-    get(&w->spec_crba_perm, "crba_spec_perm_f32");
-    get(&w->spec_chol, "chol_spec_f32");
-    get(&w->spec_emit, "emit_spec_f32");
-    if (!w->spec_crba_perm || !w->spec_chol || !w->spec_emit) w->spec_crba_perm = w->spec_chol = w->spec_emit = nullptr;
-  }
-  if (w->dtype == RBD_F32) {  // dynamics!, one lane per state (absent from the program for mechanisms spec_source leaves it out for)
-    if (hipModuleGetFunction(&w->spec_aba, w->spec_mod, "aba_spec_f32") != hipSuccess) { (void)hipGetLastError(); w->spec_aba = nullptr; }
+  hipModule_t& mod = w->spec_mod[family];
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { (void)hipGetLastError(); mod = nullptr; return; }
+  auto get = [&](hipFunction_t* f, const char* name) { if (hipModuleGetFunction(f, mod, name) != hipSuccess) { (void)hipGetLastError(); *f = nullptr; } };
+  // a kernel whose registers spilled beyond a few values is slower than the kernels that interpret the mechanism: it steps aside
+  auto fits = [&](hipFunction_t* f) {
     int scratch = 0;
-    if (w->spec_aba && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_aba) != hipSuccess || scratch > 512)) {
-      (void)hipGetLastError();
-      w->spec_aba = nullptr;  // the per-body registers did not fit: the walk kernel is the better choice
+    if (*f && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, *f) != hipSuccess || scratch > 512)) { (void)hipGetLastError(); *f = nullptr; }
+  };
+  int ncu = 256;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, w->device);
+  if (family == SPEC_MASS) {
+    get(&w->spec_crba, w->dtype == RBD_F64 ? "crba_spec_f64" : "crba_spec_f32");
+    if (spec_has_chol(w->dtype, m->nv)) {
+      get(&w->spec_crba_perm, "crba_spec_perm_f32");
+      get(&w->spec_chol, "chol_spec_f32");
+      get(&w->spec_emit, "emit_spec_f32");
+      if (!w->spec_crba_perm || !w->spec_chol || !w->spec_emit) w->spec_crba_perm = w->spec_chol = w->spec_emit = nullptr;
     }
+  } else if (family == SPEC_ABA) {
+    get(&w->spec_aba, "aba_spec_f32");
+    fits(&w->spec_aba);
     // a wavefront of 64 states per SIMD: one round of them takes the same time from one wavefront to a chip-full, and beats the walk kernel's
     // rounds of half as many states from the second of those on
-    int ncu = 256;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, w->device);
     w->spec_aba_min_batch = (long)ncu * 4 * 64 / 2 + 1;
     if (const char* e = getenv("RBD_SPEC_ABA_MIN_BATCH")) w->spec_aba_min_batch = atol(e);
+  } else if (family == SPEC_RNEA) {
+    get(&w->spec_rnea, "rnea_spec_f32");
+    fits(&w->spec_rnea);
+    w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
+    if (const char* e = getenv("RBD_SPEC_RNEA_MIN_BATCH")) w->spec_rnea_min_batch = atol(e);
   }
 }
 static hipFunction_t spec_crba(rbd_ws* w, size_t buffer_bytes) {
-  spec_load(w);
+  spec_load(w, SPEC_MASS);
   return buffer_bytes < ((size_t)1 << 32) ? w->spec_crba : nullptr;
 }
 static hipError_t launch_crba_spec(rbd_ws* w, hipFunction_t f, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill) {
@@ -1272,7 +1299,7 @@ static int run_crba(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, 
     return RBD_OK;
   }
   if (B >= w->state_min_batch && layout == RBD_LAYOUT_AOS && w->dtype == RBD_F32 && Lm.sk == 1 && (Lm.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0 &&
-      esize(w) * (size_t)w->model->nv * w->model->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && (spec_load(w), w->spec_emit != nullptr)) {
+      esize(w) * (size_t)w->model->nv * w->model->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && (spec_load(w, SPEC_MASS), w->spec_emit != nullptr)) {
     // one lane per state into the staging buffer, then whole cache lines of the caller's column-per-state M (the full square: emit_spec, rbd_spec.hpp)
     int st = stage_m(w, B, true);
     if (st) return st;
@@ -1311,7 +1338,7 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
   }
   const bool state = B >= w->state_min_batch;
   if (state && layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv)) {
-    spec_load(w);
+    spec_load(w, SPEC_MASS);
     const bool mcopy_ok = !dM || (Lm.sk == 1 && (Lm.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0);
     const bool spec_route = w->spec_chol && es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && mcopy_ok && !getenv("RBD_EXP_NO_SPEC_CHOL");
     if ((st = stage_m(w, B, spec_route))) return st;

@@ -8,7 +8,11 @@
 
 namespace rbd {
 bool jit_available();  // libhiprtc found and RBD_JIT != 0
-// dtype: RBD_F32 / RBD_F64 — the kernels of one scalar type per program (the dense step's kernels only in fp32, nv a multiple of 4, nv <= 40)
-std::string spec_source(const StatePlan& P, int nb, int nq, int nv, const uint64_t* row_mask, const double* gravity, int dtype);
+// One program per (family, scalar type): SPEC_MASS = mass_matrix! (+ the dense step and the emitter of M: fp32, nv a multiple of 4, nv <= 40), SPEC_ABA = dynamics!,
+// SPEC_RNEA = inverse_dynamics! / dynamics_bias!.  Empty string: no such program for this mechanism (spec_has).
+enum { SPEC_MASS = 0, SPEC_ABA = 1, SPEC_RNEA = 2, SPEC_FAMILIES = 3 };
+bool spec_has(int family, int dtype, int nb, int nq, int nv);
+bool spec_has_chol(int dtype, int nv);
+std::string spec_source(const StatePlan& P, int nb, int nq, int nv, const uint64_t* row_mask, const double* gravity, int dtype, int family);
 std::vector<char> jit_code_object(const std::string& source, std::string* log);
 }  // namespace rbd

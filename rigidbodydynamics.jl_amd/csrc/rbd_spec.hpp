@@ -540,6 +540,165 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   wave_sync();
   rows_out<T, NV>(rt, vdot, Lv, state0, B);
 }
+
+// inverse_dynamics! / dynamics_bias! (src/mechanism_algorithms.jl:542-553, :484-498; spatial_accelerations! :387-417, newton_euler! :428-439,
+// joint_wrenches_and_torques! :442-459), one lane per state, compiled for rbd_plan's mechanism: the same walk as aba_spec with less to carry — the
+// kinematic state holds the FULL spatial acceleration (a_parent + [T_parent, S q'] + S v̇, the world's is -g), a body's net wrench
+// f = I a + T x* I T - w_ext + (its children's) goes up as six values, tau = S'f on the way; every joint is un-composed back to its parent.
+// Nothing is kept per body, so the kernel fits the register file in fp64 as well (rows of q, v, v̇ in LDS: four wavefronts per CU in fp32, two in fp64).
+// vdot == nullptr: dynamics_bias! (v̇ = 0).  tau rows: v̇ on the way in, tau on the way out.
+constexpr int RNEA_ROWS = P::NQ + 2 * P::NV;
+template <typename T>
+RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ vdot, const T* __restrict__ fext,
+                       T* __restrict__ tau, Layout Lq, Layout Lv, Layout Lf, T* lds) {
+  constexpr int NQ = P::NQ, NV = P::NV, NBS = P::NBS > 0 ? P::NBS : 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* rq = lds + (size_t)wave * RNEA_ROWS * RS;
+  T* rv = rq + NQ * RS;
+  T* rt = rv + NV * RS;
+  const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
+  if (state0 >= B) return;
+  rows_in<T, NQ>(q, Lq, state0, B, rq);
+  rows_in<T, NV>(v, Lv, state0, B, rv);
+  if (vdot) rows_in<T, NV>(vdot, Lv, state0, B, rt);
+  else {
+#pragma unroll 4
+    for (int k = 0; k < NV; ++k) rt[k * RS + lane] = T(0);
+  }
+  wave_sync();
+  const T* qs = rq + lane;
+  const T* vs = rv + lane;
+  T* ts = rt + lane;
+  const long sc = state0 + lane < B ? state0 + lane : B - 1;
+  const T* fel = fext ? fext + sc * Lf.sb : nullptr;
+  const long fsk = Lf.sk;
+  struct { T R[9], p[3], Tw[6], a[6]; } K;  // the body the walk is at: transform to root, twist, spatial acceleration
+  T C[6];                                   // net wrench of the child just finished, on its way to a chain parent
+  T SF[NBS][6];                             // branch points: the sum of their children's
+  T fe[6];
+  auto load_fe = [&](auto oc) __attribute__((always_inline)) {
+    constexpr int O = oc.value;
+    if constexpr (O >= 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fe[k] = fel ? fel[(long)(P::OPW[O][3] + k) * fsk] : T(0);
+    }
+  };
+  load_fe(Ix<P::FIRST_EXIT>{});
+  sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
+    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
+    constexpr int nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
+    // the joint's twist and acceleration in the root frame, from the body's transform (used entering the body and un-composing it)
+    auto joint_motion = [&](const T* R, const T* p, T* S, T* vJ, T* aJ) __attribute__((always_inline)) {
+      if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+        T v6[6], a6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { v6[k] = vs[(voff + k) * RS]; a6[k] = ts[(voff + k) * RS]; }
+        xmotion(R, p, v6, vJ);
+        xmotion(R, p, a6, aJ);
+      } else if constexpr (jt == RBD_JOINT_FIXED) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { vJ[k] = T(0); aJ[k] = T(0); }
+      } else {
+        if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = T(0); S[3] = R[2]; S[4] = R[5]; S[5] = R[8]; }
+        else { S[0] = R[2]; S[1] = R[5]; S[2] = R[8]; cross3(p, S, S + 3); }
+        const T qd = vs[voff * RS], vd = ts[voff * RS];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { vJ[k] = S[k] * qd; aJ[k] = S[k] * vd; }
+      }
+    };
+    if constexpr (kind == SK_ENTER) {
+      if constexpr (lvl == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) K.p[k] = T(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { K.Tw[k] = T(0); K.a[k] = T(0); }
+        K.a[3] = T(-P::GRAVITY[0]); K.a[4] = T(-P::GRAVITY[1]); K.a[5] = T(-P::GRAVITY[2]);  // mechanism_algorithms.jl:396
+      }
+      T Rl[9], pl[3], Rn[9], pn[3], t3[3], S[6], vJ[6], aJ[6], cb[6];
+      local_transform<T, O, RS>(qs, Rl, pl);
+      matmul3(K.R, Rl, Rn);
+      matvec3(K.R, pl, t3);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pn[k] = K.p[k] + t3[k];
+      joint_motion(Rn, pn, S, vJ, aJ);
+      se3_comm(K.Tw, vJ, cb);  // a_b = a_parent + [T_parent, vJ] + S v̇  (mechanism_algorithms.jl:414)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { K.a[k] += cb[k] + aJ[k]; K.Tw[k] += vJ[k]; }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) K.p[k] = pn[k];
+    } else {
+      RInertia<T> I;
+      T J6[6], mc[3];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) J6[k] = T(P::TR[O][TR_J + k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) mc[k] = T(P::TR[O][TR_MC + k]);
+      inertia_to_root(J6, mc, T(P::TR[O][TR_M]), K.R, K.p, I);
+      T f[6], h[6];
+      mul_inertia(I, K.a, f);
+      momentum_cross(I, K.Tw, h);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) f[k] += h[k] - fe[k];
+      load_fe(Ix<P::NEXT_EXIT[O]>{});
+      if constexpr (nch == 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f[k] += C[k];
+      } else if constexpr (nch >= 2) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f[k] += SF[bs][k];
+      }
+      T S[6], vJ[6], aJ[6];
+      joint_motion(K.R, K.p, S, vJ, aJ);  // (reads v̇ from the tau rows before tau overwrites it)
+      if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+        T o6[6];
+        xforce_inv(K.R, K.p, f, o6);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ts[(voff + k) * RS] = o6[k];
+      } else if constexpr (jt != RBD_JOINT_FIXED) {
+        ts[voff * RS] = dot6(S, f);
+      }
+      if constexpr (lvl > 0) {
+        if constexpr (pbs >= 0) {
+          if constexpr (cidx == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) SF[pbs][k] = f[k];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) SF[pbs][k] += f[k];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) C[k] = f[k];
+        }
+        if constexpr (jt != RBD_JOINT_FIXED) {
+          T cb[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) K.Tw[k] -= vJ[k];  // T_parent
+          se3_comm(K.Tw, vJ, cb);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) K.a[k] -= cb[k] + aJ[k];
+        }
+        T Rl[9], pl[3], Rp[9], t3[3];
+        local_transform<T, O, RS>(qs, Rl, pl);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Rp[3 * i + j] = K.R[3 * i] * Rl[3 * j] + K.R[3 * i + 1] * Rl[3 * j + 1] + K.R[3 * i + 2] * Rl[3 * j + 2];  // R Rl'
+        matvec3(Rp, pl, t3);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K.R[k] = Rp[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) K.p[k] -= t3[k];
+      }
+    }
+  });
+  wave_sync();
+  rows_out<T, NV>(rt, tau, Lv, state0, B);
+}
 #endif  // RBD_SPEC_ABA
 
 #ifdef RBD_SPEC_CHOL

@@ -299,7 +299,8 @@ def _fill_result_fields(result, state, algo, wrenches, totalwrenches_done=False)
             dynamics_bias_(result.dynamicsbias, state, wrenches)
 
 
-_MAPPING = {"auto": _capi.ALGO_ABA, "lanes": _capi.ALGO_ABA_LANES, "banks": _capi.ALGO_ABA_BANKS, "walk": _capi.ALGO_ABA_WALK, "pipe": _capi.ALGO_ABA_PIPE}
+_MAPPING = {"auto": _capi.ALGO_ABA, "lanes": _capi.ALGO_ABA_LANES, "banks": _capi.ALGO_ABA_BANKS, "walk": _capi.ALGO_ABA_WALK, "pipe": _capi.ALGO_ABA_PIPE,
+            "compiled": _capi.ALGO_ABA_COMPILED}
 
 
 def inverse_dynamics_(torquesout: torch.Tensor, state: MechanismState, vd: torch.Tensor,
@@ -561,19 +562,20 @@ def experimental():
     return bool(_capi.lib().rbd_experimental())
 
 
-def jit_source(flat, dtype=torch.float32):
+def jit_source(flat, dtype=torch.float32, family="mass_matrix"):
     """The source `rbd_jit_source` generates for a mechanism's run-time specialised kernels (csrc/rbd_jit.hip, rbd_spec.hpp); None when the
-    mechanism is outside the one-lane-per-state kernels' scope.  Host only."""
+    mechanism is outside the one-lane-per-state kernels' scope.  family: "mass_matrix" (+ Cholesky), "dynamics", "inverse_dynamics" — one program each.  Host only."""
     L = _capi.lib()
     h = ctypes.c_void_p()
     _raise(L.rbd_model_create(ctypes.cast(ctypes.byref(flat.c_struct()), ctypes.c_void_p), ctypes.byref(h)), "rbd_model_create")
     try:
         dt = _capi.F64 if dtype == torch.float64 else _capi.F32
-        n = L.rbd_jit_source(h, dt, None, 0)
+        fam = {"mass_matrix": 0, "dynamics": 1, "inverse_dynamics": 2}[family]
+        n = L.rbd_jit_source(h, dt, fam, None, 0)
         if n < 0:
             return None
         buf = ctypes.create_string_buffer(n + 1)
-        L.rbd_jit_source(h, dt, buf, n + 1)
+        L.rbd_jit_source(h, dt, fam, buf, n + 1)
         return buf.value.decode()
     finally:
         L.rbd_model_destroy(h)

@@ -126,3 +126,48 @@ def test_precompile_without_a_device(rbd, tmp_path, monkeypatch):
     assert ok and os.path.getmtime(tmp_path / files[0]) == stamp
     monkeypatch.setenv("RBD_JIT", "0")
     assert rbd.jit_precompile(model, torch.float64)[0] is None
+
+
+@pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating", "atlas_fixed"])
+def test_generated_tree_tables_of_the_walk_kernels(rbd, name):
+    """The dynamics! / inverse_dynamics! programs: children counts, sibling ranks and branch slots of every op's body against the mechanism."""
+    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", name + ".json"))
+    for fam in ("dynamics", "inverse_dynamics"):
+        src = rbd.jit_source(model, torch.float32, fam)
+        assert src is not None and "RBD_SPEC_ABA" in src
+        assert rbd.jit_source(model, torch.float64, fam) is None  # fp32 only (DESIGN §3.7)
+        opw = table(src, "OPW")
+        T = {k: table(src, k)[0] for k in ("BODY", "NCH", "BS", "PBS", "CIDX", "NEXT_EXIT")}
+        nbs = int(re.search(r"constexpr int NBS = (\d+), FIRST_EXIT = (\d+);", src).group(1))
+        first_exit = int(re.search(r"FIRST_EXIT = (\d+);", src).group(1))
+        voff_to_body = {int(v): b for b, v in enumerate(model.v_offset)}
+        nvs = [(int(model.v_offset[b + 1]) if b + 1 < model.n_bodies else model.nv) - int(model.v_offset[b]) for b in range(model.n_bodies)]
+        children = {b: [c for c in range(model.n_bodies) if model.parent[c] == b] for b in range(-1, model.n_bodies)}
+        stack, seen_rank, exits = [], {}, []
+        for o, w in enumerate(opw):
+            kind, lvl = w[0] & 0xff, (w[0] >> 8) & 0xff
+            if kind == 0:
+                assert lvl == len(stack)
+                # which body: by its v offset when it has coordinates (fixed joints: by elimination through the children counts below)
+                stack.append(o)
+                par = stack[-2] if len(stack) > 1 else None
+                if par is not None:
+                    seen_rank.setdefault(par, []).append(T["CIDX"][o])
+                    assert (T["PBS"][o] >= 0) == (T["NCH"][par] >= 2) and (T["PBS"][o] < 0 or T["PBS"][o] == T["BS"][par])
+                assert (T["BS"][o] >= 0) == (T["NCH"][o] >= 2)
+                if T["BS"][o] >= 0:
+                    assert T["BS"][o] == sum(1 for a in stack[:-1] if T["NCH"][a] >= 2) < nbs
+            else:
+                e = stack.pop()
+                exits.append(o)
+                for k in ("BODY", "NCH", "BS", "PBS", "CIDX"):
+                    assert T[k][o] == T[k][e]
+                assert sorted(seen_rank.get(e, [])) == list(range(T["NCH"][e]))
+        assert not stack and exits[0] == first_exit
+        assert sorted(T["BODY"][o] for o, w in enumerate(opw) if (w[0] & 0xff) == 0) == list(range(model.n_bodies))
+        for a, b in zip(exits, exits[1:] + [-1]):
+            assert T["NEXT_EXIT"][a] == b
+        # children counts against the mechanism, body by body (bodies with coordinates are identified by their v offset)
+        for o, w in enumerate(opw):
+            if (w[0] & 0xff) == 0 and (w[0] >> 16) != 0 and w[2] in voff_to_body and nvs[voff_to_body[w[2]]] > 0:  # 0 = RBD_JOINT_FIXED
+                assert T["NCH"][o] == len(children[voff_to_body[w[2]]])

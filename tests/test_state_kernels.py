@@ -282,3 +282,45 @@ def test_compiled_aba_is_the_default_for_large_fp32_batches(rbd, oracle, models)
     keep = torch.ones(B, dtype=torch.bool, device="cuda")
     keep[77] = False
     assert torch.equal(result.vd[keep], good[keep])
+
+
+# ---- inverse_dynamics! / dynamics_bias! compiled for the mechanism (rnea_spec) ------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", IN_SCOPE)
+def test_compiled_rnea_f32(rbd, oracle, models, name, layout):
+    """`inverse_dynamics!` (v̇ and a wrench on every body) and `dynamics_bias!` through rnea_spec, forced, on a ragged batch, against the fp64 oracle at
+    fp32 accuracy; and against the lane-per-body kernel."""
+    model = models[name]
+    B = 150
+    state, q, v, tau, fe = make(rbd, model, B, "f32", layout, 73)
+    vd = np.random.default_rng(9).standard_normal((B, model.nv)).astype(np.float32).astype(np.float64)
+    out = torch.full_like(state.v, float("nan"))
+    try:
+        rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state), mapping="compiled")
+    except rbd._capi.RBDError as e:
+        if e.status == 3:
+            pytest.skip("hiprtc not available")
+        raise
+    assert rbd.sync(state) == 0 and "rnea_spec_f32" in rbd.last_kernel(state)
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+    assert np.abs(host(out, state) - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    lanes = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(lanes, state, dev(vd, state), dev(fe, state), mapping="lanes")
+    assert np.abs(host(out, state) - host(lanes, state)).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    rbd.dynamics_bias_(out, state, mapping="compiled")
+    ref = oracle.dynamics_bias(model, q, v, None)
+    assert np.abs(host(out, state) - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_compiled_rnea_is_the_default_for_large_fp32_batches(rbd, oracle, models):
+    model = models["atlas_floating"]
+    B = 65536
+    state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 32)
+    vd = np.random.default_rng(10).standard_normal((B, model.nv)).astype(np.float32).astype(np.float64)
+    out = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state))
+    assert rbd.sync(state) == 0
+    if "rnea_spec_f32" not in rbd.last_kernel(state):
+        pytest.skip("hiprtc not available: " + rbd.last_kernel(state))
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe, nthreads=8)
+    assert np.abs(host(out, state) - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
