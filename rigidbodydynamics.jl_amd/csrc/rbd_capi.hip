@@ -116,7 +116,8 @@ struct rbd_ws {
   WalkModel pm{}; void* d_pipe_rr = nullptr; void* d_pipe_rec = nullptr; size_t pipe_lds_bytes = 0; long pipe_max_batch = 0;  // role-pipelined mapping (rbd_pipe.hpp)
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
-  bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr;
+  bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
+  bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
   long spec_aba_min_batch = 0, spec_rnea_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
@@ -143,6 +144,8 @@ struct rbd_ws {
   const char* last_kernel = "";  // dominant kernel of the last rbd_dynamics / rbd_simulate / rbd_mass_matrix_solve call
 };
 
+static std::string loop_program_source(const rbd_model* m, int dtype, std::vector<int32_t>* xi_store);  // (below)
+
 extern "C" {
 
 int rbd_version(void) { return RBD_HIP_H_VERSION; }
@@ -155,8 +158,11 @@ int rbd_experimental(void) {
 }
 // run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
 int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char* buf, int64_t cap) {
-  if (!m || !m->state.ok || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family >= SPEC_FAMILIES) return -1;
-  const std::string s = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
+  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES) return -1;
+  std::vector<int32_t> xi;
+  if (family < SPEC_FAMILIES && !m->state.ok) return -1;
+  const std::string s = family == SPEC_FAMILIES ? loop_program_source(m, dtype, &xi)  // (family 3: the program of a small loop mechanism)
+                                                : spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
   if (s.empty()) return -1;
   if (buf && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)s.size()); memcpy(buf, s.data(), (size_t)n); buf[n] = 0; }
   return (int64_t)s.size();
@@ -164,10 +170,17 @@ int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char
 int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t cap) {
   if (log && cap > 0) log[0] = 0;
   if (!m || (dtype != RBD_F32 && dtype != RBD_F64)) return RBD_ERR_INVALID_ARGUMENT;
-  if (!m->state.ok || !jit_available()) return RBD_ERR_UNSUPPORTED;
+  if ((!m->state.ok && !m->loop_fused_ok) || !jit_available()) return RBD_ERR_UNSUPPORTED;
   int st = RBD_OK;
   std::string all;
-  for (int family = 0; family < SPEC_FAMILIES; ++family) {
+  {
+    std::vector<int32_t> xi;
+    const std::string src = loop_program_source(m, dtype, &xi);
+    std::string lg;
+    if (!src.empty() && jit_code_object(src, &lg).empty()) st = RBD_ERR_HIP;
+    all += lg;
+  }
+  for (int family = 0; family < SPEC_FAMILIES && m->state.ok; ++family) {
     const std::string src = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
     if (src.empty()) continue;
     std::string lg;
@@ -914,6 +927,7 @@ int rbd_workspace_destroy(rbd_ws_t* w) {
     for (void* p : mkp) if (p) (void)hipFree(p);
   }
   for (hipModule_t mod : w->spec_mod) if (mod) (void)hipModuleUnload(mod);
+  if (w->spec_loop_mod) (void)hipModuleUnload(w->spec_loop_mod);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   delete w;
@@ -1041,6 +1055,32 @@ int ensure(void** p, size_t* have, size_t need) {
 
 }  // namespace
 
+// the loop tables of a small loop mechanism as rbd_jit.hip's generator takes them (xi as rbd_workspace_create uploads it for loop_fused_small_kernel)
+static std::string loop_program_source(const rbd_model* m, int dtype, std::vector<int32_t>* xi_store) {
+  if (!m->loop_fused_ok) return std::string();
+  xi_store->assign(3 * (size_t)m->nb, 0);
+  for (int i = 0; i < m->nb; ++i) { (*xi_store)[3 * i] = m->parent_ref[i]; (*xi_store)[3 * i + 1] = m->qoff_ref[i]; (*xi_store)[3 * i + 2] = m->slot_of[i]; }
+  LoopTables L{m->nb, m->nq, m->nv, m->nc, m->nloops, &m->loop_i, &m->loop_path, &m->jt_ref, &m->voff_ref, xi_store, &m->loop_r, &m->axis_ref, &m->axis2_ref, &m->rb, m->gravity};
+  return spec_loop_source(L, dtype);
+}
+// small loop mechanisms compiled for the mechanism (rbd_loop_small.hpp against constant tables): nullptr when unavailable
+static hipFunction_t spec_loop(rbd_ws* w) {
+  if (w->spec_loop_tried) return w->spec_loop;
+  w->spec_loop_tried = true;
+  if (!jit_available()) return nullptr;
+  std::vector<int32_t> xi;
+  const std::string src = loop_program_source(w->model, w->dtype, &xi);
+  if (src.empty()) return nullptr;
+  std::string log;
+  const std::vector<char> code = jit_code_object(src, &log);
+  if (code.empty()) { g_last_hip_error = "run-time compilation failed (the generic loop kernels are used): " + log; return nullptr; }
+  if (hipModuleLoadData(&w->spec_loop_mod, code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_loop_mod = nullptr; return nullptr; }
+  if (hipModuleGetFunction(&w->spec_loop, w->spec_loop_mod, w->dtype == RBD_F64 ? "loop_spec_f64" : "loop_spec_f32") != hipSuccess) { (void)hipGetLastError(); w->spec_loop = nullptr; }
+  int scratch = 0;
+  if (w->spec_loop && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_loop) != hipSuccess || scratch > 0)) { (void)hipGetLastError(); w->spec_loop = nullptr; }
+  return w->spec_loop;
+}
+
 namespace {
 template <typename T>
 int dynamics_loops_t(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd,
@@ -1064,6 +1104,16 @@ int dynamics_loops_t(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const 
   V.xi = (const int32_t*)w->d_fused_i; V.rb = (const T*)w->d_rb;
   Timed t(w);
   static const bool no_fused = getenv("RBD_LOOP_NO_FUSED") != nullptr;  // tests: the three-launch route on a mechanism the fused kernel would take
+  if (hipFunction_t f = (m->loop_fused_ok && !no_fused) ? spec_loop(w) : nullptr) {  // the whole evaluation as straight-line code for this mechanism
+    long Bl = B;
+    int stab = o.stabilization;
+    void* dM = w->d_M; void* dc = w->d_c; void* dK = w->d_K; void* dk = w->d_k; int* notpd = w->d_notpd;
+    Layout a_Lq = Lq, a_Lm = Lm, a_Lv = Lv, a_Lf = Lf, a_Lc = Lc, a_Lk = Lk;
+    void* args[] = {&Bl, &stab, &dq, &dv, &dtau, &df, &dM, &dc, &dvd, &dqd, &dlam, &dK, &dk, &a_Lq, &a_Lm, &a_Lv, &a_Lf, &a_Lc, &a_Lk, &notpd};
+    HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
+    w->last_kernel = "loop_spec (compiled for the mechanism at run time)";
+    return RBD_OK;
+  }
   if (m->loop_fused_ok && !no_fused &&
       launch_loop_fused<T>(V, B, o.stabilization, dq, dv, dtau, df, w->d_body, w->d_M, w->d_c, dvd, dqd, dlam, w->d_K, w->d_k, Lq, Lm, Lv, Lf, Lc, Lk, m->gravity,
                            w->d_notpd, w->stream)) {

@@ -14,5 +14,13 @@ enum { SPEC_MASS = 0, SPEC_ABA = 1, SPEC_RNEA = 2, SPEC_FAMILIES = 3 };
 bool spec_has(int family, int dtype, int nb, int nq, int nv);
 bool spec_has_chol(int dtype, int nv);
 std::string spec_source(const StatePlan& P, int nb, int nq, int nv, const uint64_t* row_mask, const double* gravity, int dtype, int family);
+// The program of ONE small loop mechanism (rbd_loop_small.hpp with the loop tables as compile-time constants): loop_spec_f32 / loop_spec_f64.
+struct LoopTables {
+  int nb, nq, nv, nc, nloops;
+  const std::vector<int32_t>*li, *path, *jt, *voff, *xi;
+  const std::vector<double>*lr, *axis, *axis2, *rb;
+  const double* gravity;
+};
+std::string spec_loop_source(const LoopTables& L, int dtype);
 std::vector<char> jit_code_object(const std::string& source, std::string* log);
 }  // namespace rbd

@@ -325,9 +325,13 @@ def four_bar_inputs(rbd, B, seed):
     return q, v, tau
 
 
+@pytest.mark.parametrize("kernels", ["compiled", "generic"])
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("stabilize", [True, False])
-def test_four_bar_dynamics_f64(rbd, oracle, models, stabilize, layout):
+def test_four_bar_dynamics_f64(rbd, oracle, models, stabilize, layout, kernels, monkeypatch):
+    """kernels: the loop branch as straight-line code compiled for the mechanism at run time (csrc/rbd_loop_small.hpp against constant tables through
+    rbd_jit.hip — the default where hiprtc is available), or the same code reading the tables from device memory (RBD_JIT=0: loop_fused_small_kernel)."""
+    monkeypatch.setenv("RBD_JIT", "1" if kernels == "compiled" else "0")
     model = models["four_bar"]
     B = 4096
     q, v, tau = four_bar_inputs(rbd, B, 31)
@@ -337,6 +341,7 @@ def test_four_bar_dynamics_f64(rbd, oracle, models, stabilize, layout):
     rbd.set_velocity_(state, v)
     rbd.dynamics_(result, state, dev(tau, state), stabilization_gains="default" if stabilize else None)
     assert rbd.sync(state) == 0
+    assert ("loop_spec" in rbd.last_kernel(state)) == (kernels == "compiled") or kernels == "compiled"  # (no hiprtc: the generic kernel serves both)
     n = 256
     ref = oracle.dynamics_loops(model, q[:n], v[:n], tau[:n], stabilize=stabilize)
     got = host(result.vd, state)
