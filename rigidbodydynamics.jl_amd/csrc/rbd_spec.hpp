@@ -226,20 +226,46 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
 constexpr int RS = 65;  // LDS row stride in values
 constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB);  // q, v, tau, spare
 
-// rows [0, n) <- the n x 64 block of a batch buffer that belongs to this wavefront's states (states past the end read the last one)
+// rows [0, n) <- the n x 64 block of a batch buffer that belongs to this wavefront's states (states past the end read the last one).  The loads of up to
+// 32 rows are all in flight before the first LDS write: a lone wavefront pays every global round trip in full (four at a time was 27 round trips
+// for Atlas's q, v and tau — a fifth of the launch).
 template <typename T, int n> RBD_DEV void rows_in(const T* __restrict__ src, Layout L, long state0, long B, T* rows) {
   const int lane = threadIdx.x & 63;
+  constexpr int CH = 32;
   if (L.sk == 1 && L.sb == n) {  // state-major: one contiguous run of 64 n scalars, element e = (state e / n, row e % n)
     const long lim = (B - state0) * n;  // elements of the block that exist
-#pragma unroll 4
-    for (int e0 = 0; e0 < 64 * n; e0 += 64) {
-      const int e = e0 + lane, st = e / n, k = e - st * n;
-      rows[k * RS + st] = src[state0 * n + (e < lim ? e : lim - n + k)];
+    const T* base = src + state0 * n;
+#pragma unroll
+    for (int c0 = 0; c0 < n; c0 += CH) {
+      T tmp[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        if (c0 + j < n) {
+          const int e = (c0 + j) * 64 + lane, st = e / n, k = e - st * n;
+          tmp[j] = base[e < lim ? e : lim - n + k];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        if (c0 + j < n) {
+          const int e = (c0 + j) * 64 + lane, st = e / n, k = e - st * n;
+          rows[k * RS + st] = tmp[j];
+        }
+      }
     }
   } else {
     const long sc = state0 + lane < B ? state0 + lane : B - 1;
-#pragma unroll 8
-    for (int k = 0; k < n; ++k) rows[k * RS + lane] = src[(long)k * L.sk + sc * L.sb];
+    const T* base = src + sc * L.sb;
+#pragma unroll
+    for (int c0 = 0; c0 < n; c0 += CH) {
+      T tmp[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if (c0 + j < n) tmp[j] = base[(long)(c0 + j) * L.sk];
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if (c0 + j < n) rows[(c0 + j) * RS + lane] = tmp[j];
+    }
   }
 }
 template <typename T, int n> RBD_DEV void rows_out(const T* rows, T* __restrict__ dst, Layout L, long state0, long B) {
