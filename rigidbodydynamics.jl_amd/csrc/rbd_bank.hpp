@@ -703,6 +703,7 @@ __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, 
   extern __shared__ double bank_lds_raw[];
   Pair2<T>* const lds = reinterpret_cast<Pair2<T>*>(bank_lds_raw);
   RneaRegs<T> r0, r1;
+  const bool out_vec = store6_vec(acc_out ? acc_out : jw_out, Lf, (int)sizeof(T)) && store6_vec(jw_out ? jw_out : acc_out, Lf, (int)sizeof(T));  // uniform
   auto fetch = [&](int k, RneaRegs<T>& c, T* qj, T* vj, T* aj) {
     load_bank_body(M, k, B, c.b);
     c.rb = reinterpret_cast<const T*>(M.rb[k]) + (c.b.sub < M.nbk[k] ? c.b.sub : 0) * RB_STRIDE;
@@ -807,10 +808,7 @@ __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, 
     load_body_wrench(c.b, fext, Lf, fe);
 #pragma unroll
     for (int k = 0; k < 6; ++k) c.w[k] = Ia[k] + x[k] - fe[k];
-    if (acc_out != nullptr && c.b.valid) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) acc_out[(long)(6 * c.b.orig + k) * Lf.sk + c.b.state * Lf.sb] = c.acc()[k];
-    }
+    if (acc_out != nullptr && c.b.valid) store6(acc_out, 6L * c.b.orig, Lf, c.b.state, c.acc(), out_vec);
   };
   auto project = [&](RneaRegs<T>& c) {  // tau = S' w
     T out[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
@@ -833,10 +831,7 @@ __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, 
       }
     }
     store_joint_v(c.b, tau, Lv, out);
-    if (jw_out != nullptr && c.b.valid) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) jw_out[(long)(6 * c.b.orig + k) * Lf.sk + c.b.state * Lf.sb] = c.w[k];
-    }
+    if (jw_out != nullptr && c.b.valid) store6(jw_out, 6L * c.b.orig, Lf, c.b.state, c.w, out_vec);
   };
 
   T qj0[7], vj0[6], aj0[6], qj1[7], vj1[6], aj1[6];

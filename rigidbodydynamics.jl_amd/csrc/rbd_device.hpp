@@ -590,6 +590,32 @@ RBD_HD void sincos_fast(f2 x, f2* s, f2* c) {
   s->x = (n0 & 2) ? -a0 : a0; s->y = (n1 & 2) ? -a1 : a1;
   c->x = ((n0 + 1) & 2) ? -b0 : b0; c->y = ((n1 + 1) & 2) ? -b1 : b1;
 }
+// Six consecutive values of a per-body output (accelerations, joint wrenches: 6 n_bodies x B buffers) of one state.  A state-major caller (sk == 1) keeps
+// them contiguous — 48 bytes in fp64, 24 in fp32, starting at a multiple of 16 / 8 bytes when the buffer and the state stride are so aligned (`vec`,
+// wave-uniform, store6_vec below): three 16- or 8-byte stores instead of six scalar ones (the per-body outputs are store-bound: DESIGN.md §8).
+RBD_HD bool store6_vec(const void* out, Layout L, int esize) {
+  return out != nullptr && L.sk == 1 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ((L.sb * esize) & 15) == 0;
+}
+RBD_DEV void store6(double* __restrict__ out, long i0, Layout L, long state, const double* x, bool vec) {
+  if (vec) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2* p = reinterpret_cast<d2*>(out + i0 + state * L.sb);
+    p[0] = d2{x[0], x[1]}; p[1] = d2{x[2], x[3]}; p[2] = d2{x[4], x[5]};
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[(i0 + k) * L.sk + state * L.sb] = x[k];
+  }
+}
+RBD_DEV void store6(float* __restrict__ out, long i0, Layout L, long state, const float* x, bool vec) {
+  if (vec) {
+    f2* p = reinterpret_cast<f2*>(out + i0 + state * L.sb);  // (i0 = 6 body: a multiple of 8 bytes)
+    p[0] = f2{x[0], x[1]}; p[1] = f2{x[2], x[3]}; p[2] = f2{x[4], x[5]};
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[(i0 + k) * L.sk + state * L.sb] = x[k];
+  }
+}
+
 // scalar type and states per lane of a kernel value type
 template <typename T> struct Lanes { using S = T; enum { N = 1 }; };
 template <> struct Lanes<f2> { using S = float; enum { N = 2 }; };

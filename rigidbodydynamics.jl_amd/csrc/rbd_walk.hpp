@@ -1196,6 +1196,7 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
       raw = walk_raw(c, s1, g);
       if (fext) wrench(walk_uniform(c.tri[s1 * M.G + g].y) & 0xffff, fn);
       if (acc_out != nullptr || jw_out != nullptr) {  // uniform
+        const bool out_vec = store6_vec(acc_out ? acc_out : jw_out, Lf, (int)sizeof(S)) && store6_vec(jw_out ? jw_out : acc_out, Lf, (int)sizeof(S));
         T ao[6], jo[6];
         walk_step_rb<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe, ao, jo);
         if (r.flags & TF_VALID) {
@@ -1203,15 +1204,14 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
           for (int j = 0; j < N; ++j) {
             const long st = state0 + 64 * j + lane;
             if (st < B) {
+              S av[6], jv[6];
 #pragma unroll
               for (int k = 0; k < 6; ++k) {
-                const long a = (long)(r.orig6 + k) * fsk + st * Lf.sb;
-                S av, jv;
-                if constexpr (N == 1) { av = ao[k]; jv = jo[k]; }
-                else { av = j == 0 ? ao[k].x : ao[k].y; jv = j == 0 ? jo[k].x : jo[k].y; }
-                if (acc_out) acc_out[a] = av;
-                if (jw_out) jw_out[a] = jv;
+                if constexpr (N == 1) { av[k] = ao[k]; jv[k] = jo[k]; }
+                else { av[k] = j == 0 ? ao[k].x : ao[k].y; jv[k] = j == 0 ? jo[k].x : jo[k].y; }
               }
+              if (acc_out) store6(acc_out, (long)r.orig6, Lf, st, av, out_vec);
+              if (jw_out) store6(jw_out, (long)r.orig6, Lf, st, jv, out_vec);
             }
           }
         }
