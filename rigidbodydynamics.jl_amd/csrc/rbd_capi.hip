@@ -1290,6 +1290,8 @@ static void spec_load(rbd_ws* w, int family) {
       get(&w->spec_chol, "chol_spec_f32");
       get(&w->spec_emit, "emit_spec_f32");
       if (!w->spec_crba_perm || !w->spec_chol || !w->spec_emit) w->spec_crba_perm = w->spec_chol = w->spec_emit = nullptr;
+    } else if (w->dtype == RBD_F64 && spec_has_chol(RBD_F32, m->nv)) {
+      get(&w->spec_emit, "emit_spec_f64");  // fp64: the emitter alone (the staging buffer in the original order; the dense kernel is rbd_kernels.hip's)
     }
   } else if (family == SPEC_ABA) {
     get(&w->spec_aba, "aba_spec_f32");
@@ -1348,17 +1350,20 @@ static int run_crba(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, 
     else HIP_TRY(launch_big_crba<float>(w->big, B, dq, dM, w->d_big_scratch, Lq, Lm, w->stream));
     return RBD_OK;
   }
-  if (B >= w->state_min_batch && layout == RBD_LAYOUT_AOS && w->dtype == RBD_F32 && Lm.sk == 1 && (Lm.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0 &&
-      esize(w) * (size_t)w->model->nv * w->model->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && (spec_load(w, SPEC_MASS), w->spec_emit != nullptr)) {
-    // one lane per state into the staging buffer, then whole cache lines of the caller's column-per-state M (the full square: emit_spec, rbd_spec.hpp)
-    int st = stage_m(w, B, true);
+  if (B >= w->state_min_batch && layout == RBD_LAYOUT_AOS && Lm.sk == 1 && ((Lm.sb * (long)esize(w)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0 &&
+      esize(w) * (size_t)w->model->nv * w->model->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) &&
+      (spec_load(w, SPEC_MASS), w->spec_emit != nullptr && (w->dtype == RBD_F32 ? w->spec_crba_perm : w->spec_crba) != nullptr)) {
+    // one lane per state into the staging buffer, then whole cache lines of the caller's column-per-state M (the full square: emit_spec, rbd_spec.hpp);
+    // fp32 stages in the factorisation's order (the emitter's gather lists follow the program's PERM), fp64 in the original one
+    const bool perm = w->dtype == RBD_F32;
+    int st = stage_m(w, B, perm);
     if (st) return st;
     const Layout Ls{16, -(long)w->model->nv * w->model->nv};
-    HIP_TRY(launch_crba_spec(w, w->spec_crba_perm, B, dq, w->d_Msoa, Lq, Ls, 0));
+    HIP_TRY(launch_crba_spec(w, perm ? w->spec_crba_perm : w->spec_crba, B, dq, w->d_Msoa, Lq, Ls, 0));
     long Bl = B;
     void* args[] = {&Bl, &w->d_Msoa, &dM, &Lm};
     HIP_TRY(hipModuleLaunchKernel(w->spec_emit, (unsigned)((B + 15) / 16), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
-    w->last_kernel = "crba_spec_perm_f32 + emit_spec_f32 (compiled for the mechanism at run time)";
+    w->last_kernel = perm ? "crba_spec_perm_f32 + emit_spec_f32 (compiled for the mechanism at run time)" : "crba_spec_f64 + emit_spec_f64 (compiled for the mechanism at run time)";
     return RBD_OK;
   }
   if (B >= w->state_min_batch && layout == RBD_LAYOUT_SOA) {  // one lane per state: its stores are coalesced when the batch is innermost

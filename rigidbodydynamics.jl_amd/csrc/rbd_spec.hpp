@@ -13,7 +13,8 @@
 // Expected before inclusion:  namespace rbd_plan { constexpr int NB, NQ, NV, NOPS, NLEVELS; constexpr int OPW[NOPS][4] (word 0, q offset,
 // v offset, 6 * reference body index); constexpr int COLS[NOPS][16]; constexpr double TR[NOPS][24]; constexpr unsigned long long
 // ROWMASK[NV]; constexpr double GRAVITY[3]; }
-// and, when the dense step is specialised too (RBD_SPEC_CHOL defined: fp32, NV a multiple of 4, NV <= 40): constexpr int NT = NV / 4, PERM[NV] (the
+// and, when NV is a multiple of 4, NV <= 40 (RBD_SPEC_EMIT; with RBD_SPEC_CHOL — fp32 — the dense step is specialised too; fp64: PERM is the identity and the
+// dense kernel of rbd_kernels.hip reads the staging buffer): constexpr int NT = NV / 4, PERM[NV] (the
 // position of a velocity coordinate in the factorisation order), INV[NV] (its inverse), constexpr unsigned char TMASK[NT][NT] (tile (I, J) of the
 // permuted lower triangle holds a non-zero), EMIT_KMAX, EMIT_K[NT], and __constant__ unsigned EMIT[NT][4 * EMIT_KMAX] (staged entry << 16 | slot in the tile).
 #pragma once
@@ -98,7 +99,7 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
   const unsigned lane_off = (unsigned)(layout_base(Lm, state) * (long)sizeof(T));
   const unsigned mskb = (unsigned)(Lm.sk * (long)sizeof(T));
   auto put = [&](int row, int col, T x) __attribute__((always_inline)) {
-#ifdef RBD_SPEC_CHOL
+#ifdef RBD_SPEC_EMIT
     if constexpr (PERMUTED) {
       const int pr = P::PERM[row], pc = P::PERM[col];
       row = pr > pc ? pr : pc;
@@ -883,22 +884,30 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
   }
 }
 
+#endif  // RBD_SPEC_CHOL
+
+#ifdef RBD_SPEC_EMIT
 // The caller's M from the staging buffer: the WHOLE nv x nv square per state, column-major, in the ORIGINAL coordinate order (the reference leaves
 // the strict upper triangle of its Symmetric(:L) undefined; here it holds the mirror image — chol_mfma_kernel's choice, kept: complete cache lines
 // written with nontemporal 16-byte stores are more than twice as fast as the lower triangle's partial lines).  16 states per wavefront; per block
 // of four columns (16 nv contiguous bytes per state) the non-zeros are gathered from the staging buffer into an LDS tile (EMIT: entry -> slot,
 // four entries x 16 states per load instruction), the zeros come from clearing the tile, and the tile leaves as whole runs.
-constexpr int EMIT_MST = 4 * P::NV + 4;  // floats per state of the LDS tile (one spare slot for the list's padding; 16-byte aligned rows)
-RBD_DEV void emit_spec(long B, long group, const float* __restrict__ Mg, float* __restrict__ Mc, Layout Lc, float* mst) {
-  constexpr int NT = P::NT, NV = P::NV, MST = EMIT_MST, CB = 4 * NV;
+template <typename T> struct EmitVec;  // a 16-byte piece
+template <> struct EmitVec<float> { typedef float type __attribute__((ext_vector_type(4))); enum { N = 4 }; };
+template <> struct EmitVec<double> { typedef double type __attribute__((ext_vector_type(2))); enum { N = 2 }; };
+template <typename T> constexpr int emit_mst() { return 4 * P::NV + EmitVec<T>::N; }  // values per state of the LDS tile (a spare piece for the list's padding)
+template <typename T>
+RBD_DEV void emit_spec(long B, long group, const T* __restrict__ Mg, T* __restrict__ Mc, Layout Lc, T* mst) {
+  using V = typename EmitVec<T>::type;
+  constexpr int NT = P::NT, NV = P::NV, MST = emit_mst<T>(), CB = 4 * NV, VN = EmitVec<T>::N, PCS = CB / VN;  // PCS: 16-byte pieces per state and block
   const int lane = threadIdx.x & 63, qd = lane >> 4, s = lane & 15;
   const long gs = group * 16 + s;
   const long gsl = gs < B ? gs : B - 1;
-  const float* src = Mg + (gsl >> 4) * (16L * NV * NV) + (gsl & 15);
-  float* mine = mst + s * MST;
+  const T* src = Mg + (gsl >> 4) * (16L * NV * NV) + (gsl & 15);
+  T* mine = mst + s * MST;
   const unsigned* tab = &P::EMIT[0][0] + qd;
   // the gathers of block Jo + 1 are in flight while block Jo goes through the tile and out
-  float v[2][P::EMIT_KMAX];
+  T v[2][P::EMIT_KMAX];
   int dst[2][P::EMIT_KMAX];
   auto gather = [&](auto Jc) __attribute__((always_inline)) {
     constexpr int Jo = Jc.value;
@@ -910,25 +919,28 @@ RBD_DEV void emit_spec(long B, long group, const float* __restrict__ Mg, float* 
     }
   };
   gather(Ix<0>{});
+  V zero;
+#pragma unroll
+  for (int k = 0; k < VN; ++k) zero[k] = T(0);
   sfor<NT>([&](auto Jc) __attribute__((always_inline)) {
     constexpr int Jo = Jc.value, K = P::EMIT_K[Jo];
     if constexpr (Jo + 1 < NT) gather(Ix<Jo + 1>{});
     wave_sync();  // the tile of the block before has been read out
-    for (int i = lane * 4; i < 16 * MST; i += 256) *reinterpret_cast<f32x4*>(mst + i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = lane * VN; i < 16 * MST; i += 64 * VN) *reinterpret_cast<V*>(mst + i) = zero;
     wave_sync();
 #pragma unroll
     for (int k = 0; k < K; ++k) mine[dst[Jo & 1][k]] = v[Jo & 1][k];
     wave_sync();
 #pragma unroll 3
-    for (int c0 = 0; c0 < 16 * NV; c0 += 64) {
-      const int ch = c0 + lane, st = ch / NV, piece = ch - st * NV;
+    for (int c0 = 0; c0 < 16 * PCS; c0 += 64) {
+      const int ch = c0 + lane, st = ch / PCS, piece = ch - st * PCS;
       const long g2 = group * 16 + st;
-      if (ch < 16 * NV && g2 < B)
-        __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(mst + st * MST + piece * 4), reinterpret_cast<f32x4*>(Mc + g2 * Lc.sb + (long)Jo * CB + piece * 4));
+      if (ch < 16 * PCS && g2 < B)
+        __builtin_nontemporal_store(*reinterpret_cast<const V*>(mst + st * MST + piece * VN), reinterpret_cast<V*>(Mc + g2 * Lc.sb + (long)Jo * CB + piece * VN));
     }
   });
 }
-#endif  // RBD_SPEC_CHOL
+#endif  // RBD_SPEC_EMIT
 
 }  // namespace spec
 }  // namespace rbd

@@ -8,7 +8,7 @@ import rbd_amd as rbd
 model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 op = os.environ.get("OP", "solve")
-tdt = torch.float32
+tdt = torch.float64 if os.environ.get("DTYPE") == "f64" else torch.float32
 rng = np.random.default_rng(2)
 state = rbd.MechanismState(model, B, dtype=tdt); result = rbd.DynamicsResult(model, B, dtype=tdt)
 rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng))
