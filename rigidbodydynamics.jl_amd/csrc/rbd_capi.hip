@@ -1201,12 +1201,14 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   if (algorithm == RBD_ALGO_ABA_TRACKS && !can_track) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_CHAINS) return RBD_ERR_UNSUPPORTED;  // the chain mapping of round 1 lost at every batch size and was removed
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
-  if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !gravity && !fuse && w->dtype == RBD_F32) {
+  if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !fuse && w->dtype == RBD_F32) {
     spec_load(w, SPEC_ABA);
     if (w->spec_aba && (algorithm == RBD_ALGO_ABA_COMPILED || B >= w->spec_aba_min_batch)) {
       Timed t(w);
       long Bl = B;
-      void* args[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf};
+      const double* gv = gravity ? gravity : m->gravity;
+      float gx = (float)gv[0], gy = (float)gv[1], gz = (float)gv[2];
+      void* args[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf, &gx, &gy, &gz};
       HIP_TRY(hipModuleLaunchKernel(w->spec_aba, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
       w->last_kernel = "aba_spec_f32 (compiled for the mechanism at run time)";
       return RBD_OK;

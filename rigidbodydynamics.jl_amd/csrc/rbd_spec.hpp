@@ -289,7 +289,7 @@ template <typename T> struct Hand { T I[21], p[6]; };
 
 template <typename T>
 RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau, const T* __restrict__ fext,
-                      T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T* lds) {
+                      T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T gx, T gy, T gz, T* lds) {
   constexpr int NQ = P::NQ, NV = P::NV, NB = P::NB, NBS = P::NBS > 0 ? P::NBS : 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* rq = lds + (size_t)wave * ABA_ROWS * RS;
@@ -299,7 +299,11 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
   if (state0 >= B) return;
   rows_in<T, NQ>(q, Lq, state0, B, rq);
-  rows_in<T, NV>(v, Lv, state0, B, rv);
+  if (v) rows_in<T, NV>(v, Lv, state0, B, rv);
+  else {  // (the M^-1 rhs pass: v = 0)
+#pragma unroll 4
+    for (int k = 0; k < NV; ++k) rv[k * RS + lane] = T(0);
+  }
   if (tau) rows_in<T, NV>(tau, Lv, state0, B, rt);
   else {
 #pragma unroll 4
@@ -345,7 +349,8 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   const long sc = state0 + lane < B ? state0 + lane : B - 1;
   const T* fel = fext ? fext + sc * Lf.sb : nullptr;
   const long fsk = Lf.sk;
-  const T a0[6] = {T(0), T(0), T(0), T(-P::GRAVITY[0]), T(-P::GRAVITY[1]), T(-P::GRAVITY[2])};  // the world's acceleration: -g (mechanism_algorithms.jl:396)
+  // the world's acceleration: -g (mechanism_algorithms.jl:396); a kernel argument, not the plan's constant: M^-1 rhs is this pass with g = 0 (rbd_mass_matrix_solve)
+  const T a0[6] = {T(0), T(0), T(0), -gx, -gy, -gz};
 
   Kin<T> K;               // the body the walk is at
   Hand<T> C;              // hand-off of the child just finished, on its way to a chain parent

@@ -324,3 +324,22 @@ def test_compiled_rnea_is_the_default_for_large_fp32_batches(rbd, oracle, models
         pytest.skip("hiprtc not available: " + rbd.last_kernel(state))
     ref = oracle.inverse_dynamics(model, q, v, vd, fe, nthreads=8)
     assert np.abs(host(out, state) - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_compiled_aba_as_the_mass_matrix_solve(rbd, oracle, models):
+    """M⁻¹ rhs by the articulated-body pass (v = 0, g = 0, τ = rhs) at a batch the compiled kernel takes: gravity is a kernel argument there, not the
+    plan's constant.  Backward error of M x = rhs against the oracle's M."""
+    model = models["atlas_floating"]
+    B = 40000
+    state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 33)
+    x = torch.zeros_like(state.v)
+    rbd.mass_matrix_solve_(x, state, dev(tau, state), algorithm="aba")
+    assert rbd.sync(state) == 0
+    if "aba_spec_f32" not in rbd.last_kernel(state):
+        pytest.skip("hiprtc not available: " + rbd.last_kernel(state))
+    idx = np.arange(0, B, 40)
+    Ms = sym(oracle.mass_matrix(model, q[idx], nthreads=8))
+    xg = x[torch.as_tensor(idx, device="cuda")].double().cpu().numpy()
+    res = np.einsum("bij,bj->bi", Ms, xg) - tau[idx]
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau[idx], axis=1))
+    assert eta.max() <= 2e-6, eta.max()
