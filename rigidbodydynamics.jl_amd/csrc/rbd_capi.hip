@@ -1155,13 +1155,13 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
   const bool can_walk = m->track.ok && m->walk.ok && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch));
   if (mapping == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
-  if (!dacc && !djw && !dqd && w->dtype == RBD_F32 && (mapping == RBD_ALGO_ABA || mapping == RBD_ALGO_ABA_COMPILED)) {  // the kernel compiled for the mechanism: tau alone, large batches
+  if (!dacc && !djw && !dqd && (mapping == RBD_ALGO_ABA || mapping == RBD_ALGO_ABA_COMPILED)) {  // the kernel compiled for the mechanism: tau alone, large batches
     spec_load(w, SPEC_RNEA);
     if (w->spec_rnea && (mapping == RBD_ALGO_ABA_COMPILED || B >= w->spec_rnea_min_batch)) {
       long Bl = B;
       void* args[] = {&Bl, &dq, &dv, &dvd, &df, &dtau, &Lq, &Lv, &Lf};
       HIP_TRY(hipModuleLaunchKernel(w->spec_rnea, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
-      w->last_kernel = "rnea_spec_f32 (compiled for the mechanism at run time)";
+      w->last_kernel = w->dtype == RBD_F64 ? "rnea_spec_f64 (compiled for the mechanism at run time)" : "rnea_spec_f32 (compiled for the mechanism at run time)";
       return RBD_OK;
     }
   }
@@ -1303,7 +1303,7 @@ static void spec_load(rbd_ws* w, int family) {
     w->spec_aba_min_batch = (long)ncu * 4 * 64 / 2 + 1;
     if (const char* e = getenv("RBD_SPEC_ABA_MIN_BATCH")) w->spec_aba_min_batch = atol(e);
   } else if (family == SPEC_RNEA) {
-    get(&w->spec_rnea, "rnea_spec_f32");
+    get(&w->spec_rnea, w->dtype == RBD_F64 ? "rnea_spec_f64" : "rnea_spec_f32");
     fits(&w->spec_rnea);
     w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
     if (const char* e = getenv("RBD_SPEC_RNEA_MIN_BATCH")) w->spec_rnea_min_batch = atol(e);

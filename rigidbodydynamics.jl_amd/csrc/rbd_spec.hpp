@@ -580,30 +580,57 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 // Nothing is kept per body, so the kernel fits the register file in fp64 as well (rows of q, v, v̇ in LDS: four wavefronts per CU in fp32, two in fp64).
 // vdot == nullptr: dynamics_bias! (v̇ = 0).  tau rows: v̇ on the way in, tau on the way out.
 constexpr int RNEA_ROWS = P::NQ + 2 * P::NV;
-template <typename T>
+constexpr int next_enter(int o) {  // the first ENTER op after op o, or -1
+  for (int k = o + 1; k < P::NOPS; ++k)
+    if ((P::OPW[k][0] & 0xff) == SK_ENTER) return k;
+  return -1;
+}
+// DIRECT (fp64): only q goes through LDS — rows of q, v and v̇ in fp64 are 57 KB per wavefront, two wavefronts per CU and two rounds at 65 536 states
+// (measured: 129 us, slower than the walk kernel).  v and v̇ of a joint are read from global memory one ENTER ahead of their use and wait on a stack
+// along the path until the joint is un-composed; tau is stored by the lane.  19 KB of LDS per wavefront: four wavefronts per CU again.
+template <typename T, bool DIRECT = false>
 RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ vdot, const T* __restrict__ fext,
                        T* __restrict__ tau, Layout Lq, Layout Lv, Layout Lf, T* lds) {
-  constexpr int NQ = P::NQ, NV = P::NV, NBS = P::NBS > 0 ? P::NBS : 1;
+  constexpr int NQ = P::NQ, NV = P::NV, NBS = P::NBS > 0 ? P::NBS : 1, ML = P::NLEVELS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  T* rq = lds + (size_t)wave * RNEA_ROWS * RS;
+  T* rq = lds + (size_t)wave * (DIRECT ? NQ : RNEA_ROWS) * RS;
   T* rv = rq + NQ * RS;
   T* rt = rv + NV * RS;
   const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
   if (state0 >= B) return;
   rows_in<T, NQ>(q, Lq, state0, B, rq);
-  rows_in<T, NV>(v, Lv, state0, B, rv);
-  if (vdot) rows_in<T, NV>(vdot, Lv, state0, B, rt);
-  else {
+  if constexpr (!DIRECT) {
+    rows_in<T, NV>(v, Lv, state0, B, rv);
+    if (vdot) rows_in<T, NV>(vdot, Lv, state0, B, rt);
+    else {
 #pragma unroll 4
-    for (int k = 0; k < NV; ++k) rt[k * RS + lane] = T(0);
+      for (int k = 0; k < NV; ++k) rt[k * RS + lane] = T(0);
+    }
   }
   wave_sync();
   const T* qs = rq + lane;
   const T* vs = rv + lane;
   T* ts = rt + lane;
-  const long sc = state0 + lane < B ? state0 + lane : B - 1;
+  const bool live = state0 + lane < B;
+  const long sc = live ? state0 + lane : B - 1;
   const T* fel = fext ? fext + sc * Lf.sb : nullptr;
   const long fsk = Lf.sk;
+  // DIRECT: this lane's columns of v, v̇, tau
+  const T* vg = v + sc * Lv.sb;
+  const T* ag = vdot ? vdot + sc * Lv.sb : nullptr;
+  T* tg = tau + sc * Lv.sb;
+  const long vsk = Lv.sk;
+  T nv6[6], na6[6];          // DIRECT: velocity / acceleration coordinates of the next body to be entered (6 only for a 6-dof root)
+  T PV[ML], PA[ML];          // DIRECT: those of the 1-dof joints on the path
+  T RV[6], RA[6];            // DIRECT: those of a 6-dof root
+  auto prefetch = [&](auto oc) __attribute__((always_inline)) {
+    constexpr int O = oc.value;
+    if constexpr (DIRECT && O >= 0) {
+      constexpr int jt = P::OPW[O][0] >> 16, voff = P::OPW[O][2], n = jt == RBD_JOINT_QUAT_FLOATING ? 6 : jt == RBD_JOINT_FIXED ? 0 : 1;
+#pragma unroll
+      for (int k = 0; k < n; ++k) { nv6[k] = vg[(long)(voff + k) * vsk]; na6[k] = ag ? ag[(long)(voff + k) * vsk] : T(0); }
+    }
+  };
   struct { T R[9], p[3], Tw[6], a[6]; } K;  // the body the walk is at: transform to root, twist, spatial acceleration
   T C[6];                                   // net wrench of the child just finished, on its way to a chain parent
   T SF[NBS][6];                             // branch points: the sum of their children's
@@ -616,6 +643,7 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
     }
   };
   load_fe(Ix<P::FIRST_EXIT>{});
+  prefetch(Ix<next_enter(-1)>{});
   sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
     constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
     constexpr int nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
@@ -624,7 +652,10 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
       if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
         T v6[6], a6[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { v6[k] = vs[(voff + k) * RS]; a6[k] = ts[(voff + k) * RS]; }
+        for (int k = 0; k < 6; ++k) {
+          if constexpr (DIRECT) { v6[k] = RV[k]; a6[k] = RA[k]; }
+          else { v6[k] = vs[(voff + k) * RS]; a6[k] = ts[(voff + k) * RS]; }
+        }
         xmotion(R, p, v6, vJ);
         xmotion(R, p, a6, aJ);
       } else if constexpr (jt == RBD_JOINT_FIXED) {
@@ -633,12 +664,23 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
       } else {
         if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = T(0); S[3] = R[2]; S[4] = R[5]; S[5] = R[8]; }
         else { S[0] = R[2]; S[1] = R[5]; S[2] = R[8]; cross3(p, S, S + 3); }
-        const T qd = vs[voff * RS], vd = ts[voff * RS];
+        T qd, vd;
+        if constexpr (DIRECT) { qd = PV[lvl]; vd = PA[lvl]; }
+        else { qd = vs[voff * RS]; vd = ts[voff * RS]; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { vJ[k] = S[k] * qd; aJ[k] = S[k] * vd; }
       }
     };
     if constexpr (kind == SK_ENTER) {
+      if constexpr (DIRECT) {  // the coordinates asked for at the ENTER before this one; then ask for the next body's
+        if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { RV[k] = nv6[k]; RA[k] = na6[k]; }
+        } else if constexpr (jt != RBD_JOINT_FIXED) {
+          PV[lvl] = nv6[0]; PA[lvl] = na6[0];
+        }
+        prefetch(Ix<next_enter(O)>{});
+      }
       if constexpr (lvl == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? T(1) : T(0);
@@ -689,9 +731,14 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
         T o6[6];
         xforce_inv(K.R, K.p, f, o6);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) ts[(voff + k) * RS] = o6[k];
+        for (int k = 0; k < 6; ++k) {
+          if constexpr (DIRECT) { if (live) tg[(long)(voff + k) * vsk] = o6[k]; }
+          else ts[(voff + k) * RS] = o6[k];
+        }
       } else if constexpr (jt != RBD_JOINT_FIXED) {
-        ts[voff * RS] = dot6(S, f);
+        const T t = dot6(S, f);
+        if constexpr (DIRECT) { if (live) tg[(long)voff * vsk] = t; }
+        else ts[voff * RS] = t;
       }
       if constexpr (lvl > 0) {
         if constexpr (pbs >= 0) {
@@ -728,8 +775,10 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
       }
     }
   });
-  wave_sync();
-  rows_out<T, NV>(rt, tau, Lv, state0, B);
+  if constexpr (!DIRECT) {
+    wave_sync();
+    rows_out<T, NV>(rt, tau, Lv, state0, B);
+  }
 }
 #endif  // RBD_SPEC_ABA
 

@@ -119,11 +119,11 @@ def test_precompile_without_a_device(rbd, tmp_path, monkeypatch):
     if ok is None:
         pytest.skip("libhiprtc not available")
     assert ok, log
-    files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
-    assert len(files) == 1 and os.path.getsize(tmp_path / files[0]) > 1000
-    stamp = os.path.getmtime(tmp_path / files[0])
+    files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".hsaco"))
+    assert len(files) == 2 and all(os.path.getsize(tmp_path / f) > 1000 for f in files)  # fp64: the mass-matrix and the inverse-dynamics programs
+    stamps = [os.path.getmtime(tmp_path / f) for f in files]
     ok, _ = rbd.jit_precompile(model, torch.float64)
-    assert ok and os.path.getmtime(tmp_path / files[0]) == stamp
+    assert ok and [os.path.getmtime(tmp_path / f) for f in files] == stamps
     monkeypatch.setenv("RBD_JIT", "0")
     assert rbd.jit_precompile(model, torch.float64)[0] is None
 
@@ -135,7 +135,7 @@ def test_generated_tree_tables_of_the_walk_kernels(rbd, name):
     for fam in ("dynamics", "inverse_dynamics"):
         src = rbd.jit_source(model, torch.float32, fam)
         assert src is not None and "RBD_SPEC_ABA" in src
-        assert rbd.jit_source(model, torch.float64, fam) is None  # fp32 only
+        assert (rbd.jit_source(model, torch.float64, fam) is None) == (fam == "dynamics")  # fp64: inverse dynamics only
         opw = table(src, "OPW")
         T = {k: table(src, k)[0] for k in ("BODY", "NCH", "BS", "PBS", "CIDX", "NEXT_EXIT")}
         nbs = int(re.search(r"constexpr int NBS = (\d+), FIRST_EXIT = (\d+);", src).group(1))

@@ -285,15 +285,19 @@ def test_compiled_aba_is_the_default_for_large_fp32_batches(rbd, oracle, models)
 
 
 # ---- inverse_dynamics! / dynamics_bias! compiled for the mechanism (rnea_spec) ------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("name", IN_SCOPE)
-def test_compiled_rnea_f32(rbd, oracle, models, name, layout):
-    """`inverse_dynamics!` (v̇ and a wrench on every body) and `dynamics_bias!` through rnea_spec, forced, on a ragged batch, against the fp64 oracle at
-    fp32 accuracy; and against the lane-per-body kernel."""
+def test_compiled_rnea(rbd, oracle, models, name, layout, dtype):
+    """`inverse_dynamics!` (v̇ and a wrench on every body) and `dynamics_bias!` through rnea_spec, forced, on a ragged batch, against the fp64 oracle
+    (fp32: q, v, v̇ staged through LDS; fp64: q alone, v and v̇ read by the lane one body ahead); and against the lane-per-body kernel."""
     model = models[name]
     B = 150
-    state, q, v, tau, fe = make(rbd, model, B, "f32", layout, 73)
-    vd = np.random.default_rng(9).standard_normal((B, model.nv)).astype(np.float32).astype(np.float64)
+    tol = 2e-5 if dtype == "f32" else 1e-10
+    state, q, v, tau, fe = make(rbd, model, B, dtype, layout, 73)
+    vd = np.random.default_rng(9).standard_normal((B, model.nv))
+    if dtype == "f32":
+        vd = vd.astype(np.float32).astype(np.float64)
     out = torch.full_like(state.v, float("nan"))
     try:
         rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state), mapping="compiled")
@@ -301,15 +305,15 @@ def test_compiled_rnea_f32(rbd, oracle, models, name, layout):
         if e.status == 3:
             pytest.skip("hiprtc not available")
         raise
-    assert rbd.sync(state) == 0 and "rnea_spec_f32" in rbd.last_kernel(state)
+    assert rbd.sync(state) == 0 and "rnea_spec_" + dtype in rbd.last_kernel(state)
     ref = oracle.inverse_dynamics(model, q, v, vd, fe)
-    assert np.abs(host(out, state) - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(host(out, state) - ref).max() <= tol * max(1.0, np.abs(ref).max())
     lanes = torch.zeros_like(state.v)
     rbd.inverse_dynamics_(lanes, state, dev(vd, state), dev(fe, state), mapping="lanes")
-    assert np.abs(host(out, state) - host(lanes, state)).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(host(out, state) - host(lanes, state)).max() <= tol * max(1.0, np.abs(ref).max())
     rbd.dynamics_bias_(out, state, mapping="compiled")
     ref = oracle.dynamics_bias(model, q, v, None)
-    assert np.abs(host(out, state) - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(host(out, state) - ref).max() <= tol * max(1.0, np.abs(ref).max())
 
 
 def test_compiled_rnea_is_the_default_for_large_fp32_batches(rbd, oracle, models):
