@@ -1281,7 +1281,8 @@ static void spec_load(rbd_ws* w, int family) {
   // a kernel whose registers spilled beyond a few values is slower than the kernels that interpret the mechanism: it steps aside
   auto fits = [&](hipFunction_t* f) {
     int scratch = 0;
-    if (*f && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, *f) != hipSuccess || scratch > 512)) { (void)hipGetLastError(); *f = nullptr; }
+    static const int max_scratch = getenv("RBD_SPEC_MAX_SCRATCH") ? atoi(getenv("RBD_SPEC_MAX_SCRATCH")) : 512;  // bytes per lane
+    if (*f && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, *f) != hipSuccess || scratch > max_scratch)) { (void)hipGetLastError(); *f = nullptr; }
   };
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, w->device);

@@ -573,6 +573,11 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   rows_out<T, NV>(rt, vdot, Lv, state0, B);
 }
 
+constexpr int next_enter(int o) {  // the first ENTER op after op o, or -1
+  for (int k = o + 1; k < P::NOPS; ++k)
+    if ((P::OPW[k][0] & 0xff) == SK_ENTER) return k;
+  return -1;
+}
 // inverse_dynamics! / dynamics_bias! (src/mechanism_algorithms.jl:542-553, :484-498; spatial_accelerations! :387-417, newton_euler! :428-439,
 // joint_wrenches_and_torques! :442-459), one lane per state, compiled for rbd_plan's mechanism: the same walk as aba_spec with less to carry — the
 // kinematic state holds the FULL spatial acceleration (a_parent + [T_parent, S q'] + S v̇, the world's is -g), a body's net wrench
@@ -580,11 +585,6 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 // Nothing is kept per body, so the kernel fits the register file in fp64 as well (rows of q, v, v̇ in LDS: four wavefronts per CU in fp32, two in fp64).
 // vdot == nullptr: dynamics_bias! (v̇ = 0).  tau rows: v̇ on the way in, tau on the way out.
 constexpr int RNEA_ROWS = P::NQ + 2 * P::NV;
-constexpr int next_enter(int o) {  // the first ENTER op after op o, or -1
-  for (int k = o + 1; k < P::NOPS; ++k)
-    if ((P::OPW[k][0] & 0xff) == SK_ENTER) return k;
-  return -1;
-}
 // DIRECT (fp64): only q goes through LDS — rows of q, v and v̇ in fp64 are 57 KB per wavefront, two wavefronts per CU and two rounds at 65 536 states
 // (measured: 129 us, slower than the walk kernel).  v and v̇ of a joint are read from global memory one ENTER ahead of their use and wait on a stack
 // along the path until the joint is un-composed; tau is stored by the lane.  19 KB of LDS per wavefront: four wavefronts per CU again.
