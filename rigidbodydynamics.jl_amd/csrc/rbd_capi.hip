@@ -1074,7 +1074,7 @@ static hipFunction_t spec_loop(rbd_ws* w) {
   std::string log;
   const std::vector<char> code = jit_code_object(src, &log);
   if (code.empty()) { g_last_hip_error = "run-time compilation failed (the generic loop kernels are used): " + log; return nullptr; }
-  if (hipModuleLoadData(&w->spec_loop_mod, code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_loop_mod = nullptr; return nullptr; }
+  if (hipModuleLoadData(&w->spec_loop_mod, code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_loop_mod = nullptr; jit_cache_discard(src); return nullptr; }
   if (hipModuleGetFunction(&w->spec_loop, w->spec_loop_mod, w->dtype == RBD_F64 ? "loop_spec_f64" : "loop_spec_f32") != hipSuccess) { (void)hipGetLastError(); w->spec_loop = nullptr; }
   int scratch = 0;
   if (w->spec_loop && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_loop) != hipSuccess || scratch > 0)) { (void)hipGetLastError(); w->spec_loop = nullptr; }
@@ -1273,10 +1273,12 @@ static void spec_load(rbd_ws* w, int family) {
   const rbd_model* m = w->model;
   if (!m->state.ok || !jit_available() || !spec_has(family, w->dtype, m->nb, m->nq, m->nv)) return;
   std::string log;
-  const std::vector<char> code = jit_code_object(spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype, family), &log);
+  const std::string src = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype, family);
+  const std::vector<char> code = jit_code_object(src, &log);
   if (code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernels are used): " + log; return; }
   hipModule_t& mod = w->spec_mod[family];
-  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { (void)hipGetLastError(); mod = nullptr; return; }
+  // (a workspace whose first call of a route falls inside a stream capture cannot load a module there and keeps the interpreting kernels: call once before capturing)
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { (void)hipGetLastError(); mod = nullptr; jit_cache_discard(src); return; }
   auto get = [&](hipFunction_t* f, const char* name) { if (hipModuleGetFunction(f, mod, name) != hipSuccess) { (void)hipGetLastError(); *f = nullptr; } };
   // a kernel whose registers spilled beyond a few values is slower than the kernels that interpret the mechanism: it steps aside
   auto fits = [&](hipFunction_t* f) {

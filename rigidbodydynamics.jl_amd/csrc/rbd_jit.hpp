@@ -23,4 +23,5 @@ struct LoopTables {
 };
 std::string spec_loop_source(const LoopTables& L, int dtype);
 std::vector<char> jit_code_object(const std::string& source, std::string* log);
+void jit_cache_discard(const std::string& source);
 }  // namespace rbd
