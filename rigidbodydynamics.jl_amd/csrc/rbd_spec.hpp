@@ -9,6 +9,9 @@
 // offsets and body constants folded in; the path of transforms / inertias / motion subspaces is a set of statically indexed arrays, i.e.
 // registers the allocator places; nothing is decoded at run time.  (The reference gets the same effect from Julia's JIT, which
 // specialises mass_matrix! on the mechanism's joint-type tuple: src/mechanism_algorithms.jl:248-272, TypeSortedCollections.)
+// In this file: crba_spec (mass_matrix!), chol_spec (the dense step over the non-zero tiles of a no-fill-in ordering) and emit_spec (M in the caller's
+// layout), aba_spec (dynamics!, fp32), rnea_spec (inverse_dynamics! / dynamics_bias!; fp64 with v, v̇ read by the lane).  One hiprtc program per kernel
+// family and scalar type (rbd_jit.hip); the interpreting kernels stay the fallback and the reference point of the parity tests.  DESIGN.md §3.7.
 //
 // Expected before inclusion:  namespace rbd_plan { constexpr int NB, NQ, NV, NOPS, NLEVELS; constexpr int OPW[NOPS][4] (word 0, q offset,
 // v offset, 6 * reference body index); constexpr int COLS[NOPS][16]; constexpr double TR[NOPS][24]; constexpr unsigned long long
