@@ -1312,9 +1312,10 @@ static void spec_load(rbd_ws* w, int family) {
     if (const char* e = getenv("RBD_SPEC_RNEA_MIN_BATCH")) w->spec_rnea_min_batch = atol(e);
   }
 }
+static bool spec_crba_fits(const rbd_ws* w) { return (size_t)w->model->nq * 256 * esize(w) <= 160u * 1024u; }  // four wavefronts' staged q in one CU's LDS
 static hipFunction_t spec_crba(rbd_ws* w, size_t buffer_bytes) {
   spec_load(w, SPEC_MASS);
-  return buffer_bytes < ((size_t)1 << 32) ? w->spec_crba : nullptr;
+  return buffer_bytes < ((size_t)1 << 32) && spec_crba_fits(w) ? w->spec_crba : nullptr;
 }
 static hipError_t launch_crba_spec(rbd_ws* w, hipFunction_t f, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill) {
   const unsigned lds = (unsigned)((size_t)w->model->nq * 256 * esize(w));  // four wavefronts' staged q
@@ -1357,7 +1358,7 @@ static int run_crba(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, 
   }
   if (B >= w->state_min_batch && layout == RBD_LAYOUT_AOS && Lm.sk == 1 && ((Lm.sb * (long)esize(w)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0 &&
       esize(w) * (size_t)w->model->nv * w->model->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) &&
-      (spec_load(w, SPEC_MASS), w->spec_emit != nullptr && (w->dtype == RBD_F32 ? w->spec_crba_perm : w->spec_crba) != nullptr)) {
+      (spec_load(w, SPEC_MASS), w->spec_emit != nullptr && spec_crba_fits(w) && (w->dtype == RBD_F32 ? w->spec_crba_perm : w->spec_crba) != nullptr)) {
     // one lane per state into the staging buffer, then whole cache lines of the caller's column-per-state M (the full square: emit_spec, rbd_spec.hpp);
     // fp32 stages in the factorisation's order (the emitter's gather lists follow the program's PERM), fp64 in the original one
     const bool perm = w->dtype == RBD_F32;
@@ -1400,7 +1401,7 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
   if (state && layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv)) {
     spec_load(w, SPEC_MASS);
     const bool mcopy_ok = !dM || (Lm.sk == 1 && (Lm.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0);
-    const bool spec_route = w->spec_chol && es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && mcopy_ok && !getenv("RBD_EXP_NO_SPEC_CHOL");
+    const bool spec_route = w->spec_chol && spec_crba_fits(w) && es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && mcopy_ok && !getenv("RBD_EXP_NO_SPEC_CHOL");
     if ((st = stage_m(w, B, spec_route))) return st;
     const Layout Ls{16, -(long)m->nv * m->nv};  // grouped by 16 states = one wavefront of the tile Cholesky (layout_base, rbd_device.hpp)
     if (spec_route) {
