@@ -261,6 +261,11 @@ int rbd_cholesky_solve(rbd_ws_t* ws, int32_t B, const void* M, const void* rhs, 
  * c: nv, K: nc×nv column-major, k: nc; layout per opts.                        */
 int rbd_dynamics_result(rbd_ws_t* ws, int32_t B, void* M, void* c, void* K, void* k,
                         const rbd_opts_t* opts);
+/* rbd_dynamics on the CRBA route leaves M and c in the workspace for rbd_dynamics_result to copy out.  A caller that wants them in its own buffers anyway
+ * (the reference's dynamics!(result, ...) fills result.massmatrix / result.dynamicsbias in place) binds those buffers first: tree mechanisms then have M and c
+ * written there directly — at 65 536 fp32 Atlas states the copy of M alone was a third of the call — and rbd_dynamics_result skips the bound fields.
+ * Device pointers in the layout of the rbd_dynamics calls that follow; NULL unbinds.  Mechanisms with loop joints keep the workspace copies. */
+int rbd_workspace_bind_result(rbd_ws_t* ws, void* M, void* c);
 
 /* ---- the caller of the hot path: batched `simulate` --------------------------------------------
  * simulate(state0, final_time; Δt) src/simulate.jl:36-55 == MuntheKaasIntegrator.step (src/ode_integrators.jl:233-299) with

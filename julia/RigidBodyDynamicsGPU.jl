@@ -302,10 +302,15 @@ function dynamics!(result::BatchedDynamicsResult{T}, state::BatchedMechanismStat
         finish(state)
         return nothing
     end
+    # the reference's route on a tree mechanism with device buffers: M and c are written into the result's own buffers (no copy out of the workspace)
+    bind = algorithm !== :aba && state.model.nc == 0 && state.memory == MEM_DEVICE
+    bind && check(ccall((:rbd_workspace_bind_result, librbd_hip[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), state.ws, result.massmatrix.ptr, result.dynamicsbias.ptr),
+        "rbd_workspace_bind_result")
     check(ccall((:rbd_dynamics, librbd_hip[]), Cint,
         (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
         state.ws, B, state.q, state.v, nullable(torques), nullable(wext), result.v̇, result.q̇, λptr, o), "rbd_dynamics")
-    if algorithm !== :aba || state.model.nc > 0
+    bind && ccall((:rbd_workspace_bind_result, librbd_hip[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), state.ws, C_NULL, C_NULL)
+    if !bind && (algorithm !== :aba || state.model.nc > 0)
         check(ccall((:rbd_dynamics_result, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
             state.ws, B, result.massmatrix, result.dynamicsbias, state.model.nc > 0 ? pointer(result.constraintjacobian) : C_NULL,
             state.model.nc > 0 ? pointer(result.constraintbias) : C_NULL, o), "rbd_dynamics_result")

@@ -118,6 +118,7 @@ struct rbd_ws {
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
+  void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
   long spec_aba_min_batch = 0, spec_rnea_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
@@ -940,6 +941,13 @@ int rbd_workspace_set_stream(rbd_ws_t* w, void* stream) {
   return RBD_OK;
 }
 
+int rbd_workspace_bind_result(rbd_ws_t* w, void* M, void* c) {
+  if (!w) return RBD_ERR_INVALID_ARGUMENT;
+  w->bound_M = M;
+  w->bound_c = c;
+  return RBD_OK;
+}
+
 int rbd_sync(rbd_ws_t* w) {
   if (!w) return RBD_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(w->device));
@@ -1441,12 +1449,15 @@ static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, con
     // the reference's own route (src/mechanism_algorithms.jl:856-862): c = dynamics_bias!, M = mass_matrix!, then
     // potrf!/potrs!.  M and c stay in the workspace (layout of this call) for rbd_dynamics_result.
     const Layout Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
-    if ((st = ensure(&w->d_M, &w->d_M_bytes, es * (size_t)m->nv * m->nv * B)) || (st = ensure(&w->d_c, &w->d_c_bytes, es * (size_t)m->nv * B)))
-      return st;
+    // M and c: the caller's own buffers when bound (rbd_workspace_bind_result: no copy afterwards), else the workspace's
+    if (!w->bound_M && (st = ensure(&w->d_M, &w->d_M_bytes, es * (size_t)m->nv * m->nv * B))) return st;
+    if (!w->bound_c && (st = ensure(&w->d_c, &w->d_c_bytes, es * (size_t)m->nv * B))) return st;
+    void* const Md = w->bound_M ? w->bound_M : w->d_M;
+    void* const cd = w->bound_c ? w->bound_c : w->d_c;
     w->result_layout = o.layout; w->result_B = B;
     Timed t(w);
-    if ((st = run_rnea(w, B, RBD_ALGO_ABA, dq, dv, nullptr, df, w->d_c, dqd, Lq, Lv, Lf))) return st;
-    if ((st = run_crba_chol(w, B, o.layout, dq, w->d_M, dtau, w->d_c, dvd, Lq, Lm, Lv))) return st;
+    if ((st = run_rnea(w, B, RBD_ALGO_ABA, dq, dv, nullptr, df, cd, dqd, Lq, Lv, Lf))) return st;
+    if ((st = run_crba_chol(w, B, o.layout, dq, Md, dtau, cd, dvd, Lq, Lm, Lv))) return st;
   } else {
     if ((st = run_aba(w, B, o.algorithm, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, nullptr, nullptr))) return st;
   }
@@ -1622,8 +1633,10 @@ int rbd_dynamics_result(rbd_ws_t* w, int32_t B, void* M, void* c, void* K, void*
   HIP_TRY(hipSetDevice(w->device));
   const size_t es = esize(w);
   const hipMemcpyKind kind = (o.memory == RBD_MEM_HOST) ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-  if (M) { if (!w->d_M) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(M, w->d_M, es * (size_t)m->nv * m->nv * B, kind, w->stream)); }
-  if (c) { if (!w->d_c) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(c, w->d_c, es * (size_t)m->nv * B, kind, w->stream)); }
+  // (a buffer bound with rbd_workspace_bind_result already holds its field: the tree-mechanism route wrote it in place)
+  const bool tree = m->nloops == 0;
+  if (M && !(tree && M == w->bound_M)) { if (!w->d_M) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(M, w->d_M, es * (size_t)m->nv * m->nv * B, kind, w->stream)); }
+  if (c && !(tree && c == w->bound_c)) { if (!w->d_c) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(c, w->d_c, es * (size_t)m->nv * B, kind, w->stream)); }
   if (K && m->nc > 0) { if (!w->d_K) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(K, w->d_K, es * (size_t)m->nc * m->nv * B, kind, w->stream)); }
   if (k && m->nc > 0) { if (!w->d_k) return RBD_ERR_INVALID_ARGUMENT; HIP_TRY(hipMemcpyAsync(k, w->d_k, es * (size_t)m->nc * B, kind, w->stream)); }
   return RBD_OK;

@@ -267,10 +267,20 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
         _raise(st, "rbd_dynamics_contact")
         _fill_result_fields(result, state, algo, result.totalwrenches, totalwrenches_done=True)
         return None
-    st = _capi.lib().rbd_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
-                                  _ptr(result.vd), _ptr(result.qd), _ptr(lam), ctypes.byref(opts))
-    _raise(st, "rbd_dynamics")
-    if algo == _capi.ALGO_CRBA_CHOLESKY or f.nc > 0:  # mechanisms with loop joints always take the reference's CRBA route
+    bind = algo == _capi.ALGO_CRBA_CHOLESKY and f.nc == 0  # (the Python mirror always hands device buffers over)
+    if bind:  # the reference's route fills result.massmatrix / dynamicsbias: written in place, no copy out of the workspace afterwards
+        _capi.lib().rbd_workspace_bind_result(state.ws.handle, _ptr(result.massmatrix), _ptr(result.dynamicsbias))
+    try:
+        st = _capi.lib().rbd_dynamics(state.ws.handle, state.batch, _ptr(state.q), _ptr(state.v), _ptr(torques), _ptr(externalwrenches),
+                                      _ptr(result.vd), _ptr(result.qd), _ptr(lam), ctypes.byref(opts))
+        _raise(st, "rbd_dynamics")
+        if bind:
+            _raise(_capi.lib().rbd_dynamics_result(state.ws.handle, state.batch, _ptr(result.massmatrix), _ptr(result.dynamicsbias), None, None, ctypes.byref(opts)),
+                   "rbd_dynamics_result")
+    finally:
+        if bind:
+            _capi.lib().rbd_workspace_bind_result(state.ws.handle, None, None)
+    if (algo == _capi.ALGO_CRBA_CHOLESKY or f.nc > 0) and not bind:  # mechanisms with loop joints always take the reference's CRBA route
         st = _capi.lib().rbd_dynamics_result(state.ws.handle, state.batch, _ptr(result.massmatrix), _ptr(result.dynamicsbias),
                                              _ptr(result.constraintjacobian if f.nc else None),
                                              _ptr(result.constraintbias if f.nc else None), ctypes.byref(opts))
