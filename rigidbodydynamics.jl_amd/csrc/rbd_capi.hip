@@ -1163,11 +1163,13 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
   const bool can_walk = m->track.ok && m->walk.ok && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch));
   if (mapping == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
-  if (!dacc && !djw && !dqd && (mapping == RBD_ALGO_ABA || mapping == RBD_ALGO_ABA_COMPILED)) {  // the kernel compiled for the mechanism: tau alone, large batches
+  // the kernel compiled for the mechanism: large batches (q̇ is not one of its outputs; with the per-body outputs it is ahead of the walk kernel in fp32 only — 119 vs 149 us at
+  // 65 536 states, fp64: 146 vs 135 — so RBD_ALGO_ABA leaves that fp64 call with the walk kernel)
+  if (!dqd && (mapping == RBD_ALGO_ABA_COMPILED || (mapping == RBD_ALGO_ABA && !((dacc || djw) && w->dtype == RBD_F64)))) {
     spec_load(w, SPEC_RNEA);
     if (w->spec_rnea && (mapping == RBD_ALGO_ABA_COMPILED || B >= w->spec_rnea_min_batch)) {
       long Bl = B;
-      void* args[] = {&Bl, &dq, &dv, &dvd, &df, &dtau, &Lq, &Lv, &Lf};
+      void* args[] = {&Bl, &dq, &dv, &dvd, &df, &dtau, &Lq, &Lv, &Lf, &dacc, &djw};
       HIP_TRY(hipModuleLaunchKernel(w->spec_rnea, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
       w->last_kernel = w->dtype == RBD_F64 ? "rnea_spec_f64 (compiled for the mechanism at run time)" : "rnea_spec_f32 (compiled for the mechanism at run time)";
       return RBD_OK;

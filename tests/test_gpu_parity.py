@@ -1172,10 +1172,11 @@ def test_per_body_outputs_of_inverse_dynamics_and_dynamics_f64(rbd, oracle, mode
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("mapping", ["lanes", "banks", "walk"])
+@pytest.mark.parametrize("mapping", ["lanes", "banks", "walk", "compiled"])
 def test_per_body_outputs_from_every_mapping(rbd, oracle, models, mapping, dtype):
     """inverse_dynamics!(τ, jointwrenches, accelerations, …) — the call the reference's own benchmark makes (perf/runbenchmarks.jl:49-57) — from the
-    one-body-per-lane, two-bodies-per-lane and walk kernels (fp32: two states per lane), ragged batches, with and without v̇ / wrenches."""
+    one-body-per-lane, two-bodies-per-lane and walk kernels (fp32: two states per lane) and from the kernel compiled for the mechanism, ragged batches,
+    with and without v̇ / wrenches."""
     model = models["atlas_floating"]
     nb = model.n_bodies
     for B, layout in ((131, "aos"), (259, "soa")):
