@@ -118,8 +118,9 @@ struct rbd_ws {
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
+  bool spec_walk_tried[2] = {false, false}; hipModule_t spec_walk_mod[2] = {nullptr, nullptr}; hipFunction_t spec_walk[2] = {nullptr, nullptr};  // [re-rooted]
   void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
-  long spec_aba_min_batch = 0, spec_rnea_min_batch = 0;
+  long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   long bank_min_batch = 0, bank_resident_states = 0;
@@ -146,6 +147,8 @@ struct rbd_ws {
 };
 
 static std::string loop_program_source(const rbd_model* m, int dtype, std::vector<int32_t>* xi_store);  // (below)
+static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted);
+static bool walk_program_rerooted(const rbd_model* m, int dtype);
 
 extern "C" {
 
@@ -159,10 +162,11 @@ int rbd_experimental(void) {
 }
 // run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
 int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char* buf, int64_t cap) {
-  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES) return -1;
+  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 1) return -1;
   std::vector<int32_t> xi;
   if (family < SPEC_FAMILIES && !m->state.ok) return -1;
-  const std::string s = family == SPEC_FAMILIES ? loop_program_source(m, dtype, &xi)  // (family 3: the program of a small loop mechanism)
+  const std::string s = family == SPEC_FAMILIES + 1 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype))  // (family 4: the one-wavefront-per-track dynamics! kernel)
+                        : family == SPEC_FAMILIES ? loop_program_source(m, dtype, &xi)  // (family 3: the program of a small loop mechanism)
                                                 : spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
   if (s.empty()) return -1;
   if (buf && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)s.size()); memcpy(buf, s.data(), (size_t)n); buf[n] = 0; }
@@ -179,6 +183,12 @@ int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t c
     const std::string src = loop_program_source(m, dtype, &xi);
     std::string lg;
     if (!src.empty() && jit_code_object(src, &lg).empty()) st = RBD_ERR_HIP;
+    all += lg;
+  }
+  {
+    const std::string src = walk_program_source(m, dtype, walk_program_rerooted(m, dtype));
+    std::string lg;
+    if (!src.empty()) (void)jit_walk_code_object(src, &lg);  // (a program whose registers do not work out is not an error: the interpreting kernel stays)
     all += lg;
   }
   for (int family = 0; family < SPEC_FAMILIES && m->state.ok; ++family) {
@@ -824,6 +834,10 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     const TrackPlan& P = m->track;
     st = upload(&w->d_walk_wk, m->walk.wk.data(), m->walk.wk.size() * sizeof(int32_t));
     if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+    // the walk kernel compiled for the mechanism (aba_walk_spec): from the batch size at which RBD_ALGO_ABA picks the walk kernel by itself on a humanoid — smaller
+    // batches that force the mapping (tests, sweeps) keep the interpreting kernel and its zero start-up cost (the compile takes about a minute per mechanism, once)
+    w->spec_walk_min_batch = 8192;
+    if (const char* e = getenv("RBD_SPEC_WALK_MIN_BATCH")) w->spec_walk_min_batch = atol(e);
     WalkModel& wm = w->wm;
     wm.ns = P.ns; wm.G = P.G; wm.nA = P.nA; wm.nB = P.nB; wm.nS = m->walk.nS; wm.nq = m->nq; wm.nv = m->nv;
     wm.ri = (const int32_t*)w->d_track_ri; wm.rr = w->d_track_rr; wm.wk = (const int32_t*)w->d_walk_wk;
@@ -929,6 +943,7 @@ int rbd_workspace_destroy(rbd_ws_t* w) {
   }
   for (hipModule_t mod : w->spec_mod) if (mod) (void)hipModuleUnload(mod);
   if (w->spec_loop_mod) (void)hipModuleUnload(w->spec_loop_mod);
+  for (int k = 0; k < 2; ++k) if (w->spec_walk_mod[k]) (void)hipModuleUnload(w->spec_walk_mod[k]);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   delete w;
@@ -1070,6 +1085,50 @@ static std::string loop_program_source(const rbd_model* m, int dtype, std::vecto
   for (int i = 0; i < m->nb; ++i) { (*xi_store)[3 * i] = m->parent_ref[i]; (*xi_store)[3 * i + 1] = m->qoff_ref[i]; (*xi_store)[3 * i + 2] = m->slot_of[i]; }
   LoopTables L{m->nb, m->nq, m->nv, m->nc, m->nloops, &m->loop_i, &m->loop_path, &m->jt_ref, &m->voff_ref, xi_store, &m->loop_r, &m->axis_ref, &m->axis2_ref, &m->rb, m->gravity};
   return spec_loop_source(L, dtype);
+}
+// the walk plan of a tree (the original one, or the one re-rooted at its centre) as rbd_jit.hip's generator takes it
+static bool walk_tables(const rbd_model* m, bool rerooted, WalkTables* W) {
+  const TrackPlan* P; const WalkPlan* K;
+  if (rerooted) { if (!m->rrs.ok || !m->rrs.track.ok || !m->rrs.walk.ok) return false; P = &m->rrs.track; K = &m->rrs.walk; }
+  else { if (!m->track.ok || !m->walk.ok) return false; P = &m->track; K = &m->walk; }
+  *W = WalkTables{};
+  W->ns = P->ns; W->G = P->G; W->nA = P->nA; W->nB = P->nB; W->nS = K->nS; W->nq = m->nq; W->nv = m->nv; W->flt = P->has_floating; W->gen = P->general; W->rr = rerooted;
+  W->ri = &P->ri; W->wk = &K->wk; W->rrc = &P->rr;
+  for (int k = 0; k < 5; ++k) { W->sfm[k] = 0; for (int s2 = 0; s2 < P->ns; ++s2) W->sfm[k] |= (uint64_t)((P->sf[s2] >> k) & 1) << s2; }
+  if (rerooted) {
+    W->nchain = (int)(m->rr.chain_i.size() / RC_I_STRIDE); W->fq = m->rr.fq; W->fv = m->rr.fv; W->chain_i = &m->rr.chain_i; W->chain_r = &m->rr.chain_r; W->fXp = m->rr.fXp;
+    if (W->nchain < 1) return false;
+  }
+  return true;
+}
+// (the plan rbd_dynamics picks for the walk kernel: the re-rooted tree when there is one and its rows fit the LDS)
+static bool walk_program_rerooted(const rbd_model* m, int dtype) {
+  WalkTables W;
+  static const bool no_rr = getenv("RBD_WALK_NO_REROOT") != nullptr;
+  return !no_rr && walk_tables(m, true, &W) && walk_lds_bytes(W.ns, W.G, W.nq, W.nv, W.nA, W.nB, W.nS, dtype == RBD_F64 ? 8 : 4, dtype == RBD_F64 ? 8 : 4) <= 160 * 1024;
+}
+static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted) {
+  WalkTables W;
+  if (!walk_tables(m, rerooted, &W)) return std::string();
+  return walk_spec_source(W, dtype);
+}
+// aba_walk_kernel compiled for the mechanism (aba_walk_spec of rbd_walk.hpp): nullptr when unavailable
+static hipFunction_t spec_walk(rbd_ws* w, bool rerooted) {
+  const int k = rerooted ? 1 : 0;
+  if (w->spec_walk_tried[k]) return w->spec_walk[k];
+  w->spec_walk_tried[k] = true;
+  if (!jit_available()) return nullptr;
+  const std::string src = walk_program_source(w->model, w->dtype, rerooted);
+  if (src.empty()) return nullptr;
+  std::string log;
+  const std::vector<char> code = jit_walk_code_object(src, &log);
+  if (code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernel is used): " + log; return nullptr; }
+  if (hipModuleLoadData(&w->spec_walk_mod[k], code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_walk_mod[k] = nullptr; jit_cache_discard(src); return nullptr; }
+  if (hipModuleGetFunction(&w->spec_walk[k], w->spec_walk_mod[k], "aba_walk_spec_f64") != hipSuccess) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
+  int scratch = 0;
+  static const int max_scratch = getenv("RBD_SPEC_MAX_SCRATCH") ? atoi(getenv("RBD_SPEC_MAX_SCRATCH")) : 512;  // bytes per lane
+  if (w->spec_walk[k] && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_walk[k]) != hipSuccess || scratch > max_scratch)) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
+  return w->spec_walk[k];
 }
 // small loop mechanisms compiled for the mechanism (rbd_loop_small.hpp against constant tables): nullptr when unavailable
 static hipFunction_t spec_loop(rbd_ws* w) {
@@ -1248,6 +1307,14 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     w->last_kernel = pair ? "aba_walk_kernel (two fp32 states per lane)" : "aba_walk_kernel";
     const TrackPlan& TP = rr ? m->rrs.track : m->track;
     const size_t lds = rr ? (pair ? w->walk_rr_lds_bytes_pair : w->walk_rr_lds_bytes) : (pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes);
+    if (hipFunction_t f = (w->dtype == RBD_F64 && B >= w->spec_walk_min_batch) ? spec_walk(w, rr) : nullptr) {  // the same kernel compiled for this mechanism
+      w->last_kernel = "aba_walk_spec (compiled for the mechanism)";
+      long Bl = B;
+      Layout lq = Lq, lv = Lv, lf = Lf;
+      double gx = wm.gravity[0], gy = wm.gravity[1], gz = wm.gravity[2];
+      void* args[] = {&Bl, (void*)&dq, (void*)&dv, (void*)&dtau, (void*)&df, (void*)&dvd, (void*)&dqd, &lq, &lv, &lf, &gx, &gy, &gz};
+      HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + 63) / 64), 1, 1, 64u * (unsigned)wm.G, 1, 1, 0, w->stream, args, nullptr));
+    } else
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, TP.has_floating, TP.general, 0, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba_walk<float>(wm, TP.has_floating, TP.general, pair, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
 #ifdef RBD_EXPERIMENTAL

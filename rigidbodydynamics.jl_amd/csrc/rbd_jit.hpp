@@ -22,6 +22,23 @@ struct LoopTables {
   const double* gravity;
 };
 std::string spec_loop_source(const LoopTables& L, int dtype);
+// The program of the one-wavefront-per-track dynamics! kernel for ONE mechanism (aba_walk_spec of rbd_walk.hpp with the plan as constants): aba_walk_spec_f64.
+// fp64 only (fp32 batches of that size run aba_spec).
+struct WalkTables {
+  int ns, G, nA, nB, nS, nq, nv, flt, gen, rr;
+  const std::vector<int32_t>*ri, *wk;
+  const std::vector<double>* rrc;  // the records' constants [ns * G][TR_STRIDE]
+  uint64_t sfm[5];
+  int nchain, fq, fv;              // rr: the chain of the re-rooted tree's floating base
+  const std::vector<int32_t>* chain_i;
+  const std::vector<double>* chain_r;
+  const double* fXp;
+};
+bool walk_spec_has(int dtype, int ns, int G, size_t lds_rows_bytes);
+size_t walk_spec_lds_bytes(const WalkTables& W, int dtype);
+std::string walk_spec_source(const WalkTables& W, int dtype);
+// compiles it twice (see aba_walk_spec): empty when the register allocator used accumulation registers of its own
+std::vector<char> jit_walk_code_object(const std::string& source, std::string* log);
 std::vector<char> jit_code_object(const std::string& source, std::string* log);
 void jit_cache_discard(const std::string& source);
 }  // namespace rbd

@@ -45,17 +45,22 @@ namespace rbd {
 // a0 upwards when it runs out of VGPRs (it parks a few loop-invariant values there in the fp64 kernels), and build.sh checks on the generated
 // assembly (scripts/check_walk_agprs.py) that what it takes stays below the WALK_MAX_STEPS steps' worth reserved here.  Host (emulation): an array.
 enum { WS_SN = 0, WS_CS = 1, WS_W = 2, WS_UD = 8, WS_N = 9 };
+// (RBD_WALK_STASH_ARRAY: the array on the device too.  Measured on the kernel compiled per mechanism, where every index is a constant: the allocator
+// spilled 529 values around the 162 long-lived ones; with the numbered registers it needs 221 VGPRs and no scratch.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RBD_WALK_STASH_ARRAY)
+#define RBD_WALK_STASH_AGPR 1
+#endif
 template <typename T> struct WalkStash {
-#if defined(__HIP_DEVICE_COMPILE__)
+#ifdef RBD_WALK_STASH_AGPR
   template <int S, int K> RBD_DEV void put(T x);
   template <int S, int K> RBD_DEV T get() const;
 #else
   T v[WALK_MAX_STEPS][WS_N];
-  template <int S, int K> void put(T x) { v[S][K] = x; }
-  template <int S, int K> T get() const { return v[S][K]; }
+  template <int S, int K> RBD_HD void put(T x) { v[S][K] = x; }
+  template <int S, int K> RBD_HD T get() const { return v[S][K]; }
 #endif
 };
-#if defined(__HIP_DEVICE_COMPILE__)
+#ifdef RBD_WALK_STASH_AGPR
 template <> template <int S, int K> RBD_DEV void WalkStash<float>::put(float x) { asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(x), "n"(255 - (S * WS_N + K))); }
 template <> template <int S, int K> RBD_DEV float WalkStash<float>::get() const {
   float x;
@@ -1076,6 +1081,160 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
     walk_stage_out<T, 10>(qdot, Lq, state0, B, M.nq, c.rows, c.rq, tid, nth);
   }
   RBD_WMARK(5);
+}
+// ---- aba_walk_kernel compiled for ONE mechanism at run time (rbd_jit.hip prints PLAN: the plan's records and constants as __device__ const
+// tables, its counts as constants).  Same step functions, same rows, same mailboxes and barriers; what changes is that every
+// (step, track) is known when the kernel is compiled: the step loops are unrolled per track, the records' flags fold the step functions down to the
+// code of that body's joint, the constants are literals and the plan takes no LDS and no staging.
+template <int I> struct WalkIx { static constexpr int value = I; };
+template <int I, int N, typename F> RBD_DEV void walk_sfor(F&& f) {
+  if constexpr (I < N) {
+    f(WalkIx<I>{});
+    walk_sfor<I + 1, N>(f);
+  }
+}
+template <typename T, typename PLAN> RBD_DEV void walk_ctx_spec(WalkCtx<T>& c, void* lds) {
+  using S = typename Lanes<T>::S;
+  c.M = PLAN::model();
+  c.tri = reinterpret_cast<const I4*>(c.M.ri);
+  c.trr = reinterpret_cast<const S*>(c.M.rr);
+  c.twk = c.M.wk;
+  c.rrv = c.M.reroot;
+  c.rows = reinterpret_cast<T*>(lds);
+  c.rq = 0; c.rv = c.M.nq; c.rt = c.rv + c.M.nv; c.rA = c.rt + c.M.nv; c.rS = c.rA + c.M.nA * WMB_A; c.rB = c.rS + c.M.nS * WMB_S;
+  c.rT = c.rB; c.sT = WMB_AT;
+}
+// (the instruction scheduler works on whole basic blocks: without a fence between the unrolled steps it pulls the next steps' LDS reads and constants
+// forward until the 512 registers of a lone wavefront are full and the allocator spills hundreds of values)
+#ifndef RBD_WALK_STEP_FENCE
+#define RBD_WALK_STEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+template <typename T, bool FLT, bool GEN, bool RR, typename PLAN, int GI>
+RBD_DEV void aba_walk_spec_track(const WalkCtx<T>& c, long B, const typename Lanes<T>::S* __restrict__ fext, bool want_qdot, Layout Lf, long state0, int lane) {
+  using S = typename Lanes<T>::S;
+  constexpr int N = Lanes<T>::N, NS = PLAN::NS;
+  WalkRegs<T> W;
+  WalkStash<T> St;
+  walk_init(W);
+  const long fsk = Lf.sk;
+  const S* fel[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const long st = state0 + 64 * j + lane;
+    fel[j] = fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr;
+  }
+  auto wrench = [&](int o6, T* f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      S x[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] = fel[j][(long)(o6 + k) * fsk];
+      if constexpr (N == 1) f[k] = x[0];
+      else { f[k].x = x[0]; f[k].y = x[1]; }
+    }
+  };
+  walk_sfor<0, NS>([&](auto si) __attribute__((always_inline)) {
+    constexpr int s = decltype(si)::value;
+    const WalkRec r = walk_rec(walk_raw(c, s, GI));
+    T rr[TR_J];
+    walk_consts<T, TR_J>(c, s, GI, rr);
+    walk_step_a<T, FLT, GEN, false, RR>(c, W, St, s, r, rr, lane, want_qdot);
+    if constexpr ((PLAN::SFM_AW >> s) & 1) __syncthreads();
+    RBD_WALK_STEP_FENCE();
+  });
+  __syncthreads();  // the B mailboxes take over the rows of the A mailboxes' twist halves
+  {
+    walk_init_b(W);
+    T fe[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fe[k] = T(0);
+    if (fext) wrench(walk_rec(walk_raw(c, NS - 1, GI)).orig6, fe);
+    walk_sfor<0, NS>([&](auto si) __attribute__((always_inline)) {
+      constexpr int s = NS - 1 - decltype(si)::value, s1 = s > 0 ? s - 1 : 0;
+      const WalkRec r = walk_rec(walk_raw(c, s, GI));
+      if constexpr (FLT && RR) {
+        if ((r.rrf & BFD_FCARRY) && (r.flags & TF_VALID)) {
+          if (r.park >= 0) walk_get_park(c, r.park, lane, W);
+          walk_fcarry_b(c, W, lane, fe);
+        }
+      }
+      T rr[TR_STRIDE], fn[6];
+      walk_consts<T, TR_STRIDE>(c, s, GI, rr);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fn[k] = T(0);
+      if (fext) wrench(walk_rec(walk_raw(c, s1, GI)).orig6, fn);  // the external wrench of the body of step s − 1 is requested while step s computes
+      walk_step_b<T, FLT, GEN, RR>(c, W, St, s, r, rr, lane, fe);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fe[k] = fn[k];
+      if constexpr ((PLAN::SFM_BW >> s) & 1) __syncthreads();
+      RBD_WALK_STEP_FENCE();
+    });
+  }
+  __syncthreads();  // pass C re-uses the B mailboxes
+  walk_init_c(W);
+  walk_sfor<0, NS>([&](auto si) __attribute__((always_inline)) {
+    constexpr int s = decltype(si)::value;
+    const WalkRec r = walk_rec(walk_raw(c, s, GI));
+    T rr[TR_J];
+    walk_consts<T, TR_J>(c, s, GI, rr);
+    walk_step_c<T, FLT, GEN, RR>(c, W, St, s, r, rr, lane, want_qdot);
+    if constexpr ((PLAN::SFM_AW >> s) & 1) __syncthreads();
+    RBD_WALK_STEP_FENCE();
+  });
+}
+template <typename T, bool FLT, bool GEN, bool RR, typename PLAN>
+RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v, const typename Lanes<T>::S* __restrict__ tau,
+                           const typename Lanes<T>::S* __restrict__ fext, typename Lanes<T>::S* __restrict__ vdot, typename Lanes<T>::S* __restrict__ qdot, Layout Lq,
+                           Layout Lv, Layout Lf, double gx, double gy, double gz, unsigned char* lds) {
+  constexpr int N = Lanes<T>::N, NQ = PLAN::NQ, NV = PLAN::NV;
+  WalkCtx<T> c;
+  walk_ctx_spec<T, PLAN>(c, lds);
+  c.a0[0] = T(0); c.a0[1] = T(0); c.a0[2] = T(0);
+  c.a0[3] = T(-gx); c.a0[4] = T(-gy); c.a0[5] = T(-gz);  // a_world = −gravity (mechanism_algorithms.jl:405)
+  const int lane = threadIdx.x & 63, tid = threadIdx.x, nth = blockDim.x;
+  const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long state0 = (long)blockIdx.x * (64 * N);
+  const bool inside = state0 + 64 * N <= B;  // wave-uniform
+  const bool fast = Lq.sk == 1 && Lv.sk == 1 && inside;
+  const bool fast_rows = Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && inside && !fast;
+  {
+    constexpr int UB = 10 * N;
+    if (fast) {
+      walk_stage_in_fast<T, UB>(q, v, tau, state0, NQ, NV, c.rows, c.rq, c.rv, c.rt, tid, nth);
+    } else if (fast_rows) {
+      walk_stage_in_rows<T, UB>(q, v, tau, B, state0, NQ, NV, c.rows, c.rq, c.rv, c.rt, tid, nth);
+    } else {
+      WalkStageIn<T, UB> in;
+      const int nmax = (NQ > NV ? NQ : NV) * 64 * N;
+      for (int e0 = 0; e0 < nmax; e0 += UB * nth) {
+        in.load(q, v, tau, Lq, Lv, state0, B, NQ, NV, e0, tid, nth);
+        in.store(c.rows, c.rq, c.rv, c.rt);
+      }
+    }
+  }
+  __syncthreads();
+#ifndef RBD_WALK_PROBE
+  // the kernel descriptor covers every accumulation register (WalkStash addresses them by number).  rbd_jit.hip compiles the program twice: first
+  // with RBD_WALK_PROBE, without this line, to read from the code object's metadata that the register allocator took NO accumulation register of
+  // its own (the check scripts/check_walk_agprs.py makes on the assembly of the kernels built ahead of time); a program that does is not used.
+  asm volatile("" ::: "a255");
+#endif
+  const bool want_qdot = qdot != nullptr;
+  walk_sfor<0, PLAN::G>([&](auto gi) __attribute__((always_inline)) {
+    constexpr int GI = decltype(gi)::value;
+    if (g == GI) aba_walk_spec_track<T, FLT, GEN, RR, PLAN, GI>(c, B, fext, want_qdot, Lf, state0, lane);
+  });
+  __syncthreads();
+  if (fast) {
+    walk_stage_out_fast<T, 10 * N>(vdot, state0, NV, c.rows, c.rt, tid, nth);
+    walk_stage_out_fast<T, 10 * N>(qdot, state0, NQ, c.rows, c.rq, tid, nth);
+  } else if (fast_rows) {
+    walk_stage_out_rows<T, 10 * N>(vdot, B, state0, NV, c.rows, c.rt, tid, nth);
+    walk_stage_out_rows<T, 10 * N>(qdot, B, state0, NQ, c.rows, c.rq, tid, nth);
+  } else {
+    walk_stage_out<T, 10>(vdot, Lv, state0, B, NV, c.rows, c.rt, tid, nth);
+    walk_stage_out<T, 10>(qdot, Lq, state0, B, NQ, c.rows, c.rq, tid, nth);
+  }
 }
 // inverse_dynamics! (vdot given) / dynamics_bias! (vdot == nullptr) through the same schedule: pass A with the full accelerations, then the
 // wrench pass (walk_step_rb).  src/mechanism_algorithms.jl:542-553, :484-498.

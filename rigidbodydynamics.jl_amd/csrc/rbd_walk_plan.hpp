@@ -7,25 +7,29 @@
 // registers still holding it.  This file numbers those parking slots and sizes the workgroup's LDS.
 // Index bookkeeping only.
 #pragma once
+#ifndef RBD_JIT_COMPILE  // (the kernel compiled per mechanism at run time includes this file for the constants below only)
 #include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <vector>
+#endif
 
 #include "rbd_device.hpp"
 
 namespace rbd {
 
+// rows of 64 states (padded to WR_STRIDE scalars): q | v | tau (v̇ written over it) | A mailboxes, transform halves | parking slots | B mailboxes
+// (pass A has the twist halves of its A mailboxes there, pass C its 6-value mailboxes); then the plan records.  Must agree with walk_ctx_lds()
+// of rbd_walk.hpp.
+enum { WR_STRIDE = 65, WMB_A = 12, WMB_AT = 12, WMB_B = 27, WMB_C = 6, WMB_S = 24, WALK_MAX_STEPS = 11 };
+
+#ifndef RBD_JIT_COMPILE
 struct WalkPlan {
   bool ok = false;
   int nS = 0;                // parking slots
   std::vector<int32_t> wk;   // [ns * G]: parking slot + 1 of the body of (step, track), 0 = none
 };
 
-// rows of 64 states (padded to WR_STRIDE scalars): q | v | tau (v̇ written over it) | A mailboxes, transform halves | parking slots | B mailboxes
-// (pass A has the twist halves of its A mailboxes there, pass C its 6-value mailboxes); then the plan records.  Must agree with walk_ctx_lds()
-// of rbd_walk.hpp.
-enum { WR_STRIDE = 65, WMB_A = 12, WMB_AT = 12, WMB_B = 27, WMB_C = 6, WMB_S = 24, WALK_MAX_STEPS = 11 };
 inline size_t walk_rows(int nq, int nv, int nA, int nB, int nS) {
   const size_t bc = std::max((size_t)nB * WMB_B, (size_t)nA * WMB_AT);
   return (size_t)nq + 2 * (size_t)nv + (size_t)nA * WMB_A + (size_t)nS * WMB_S + bc;
@@ -89,5 +93,6 @@ inline size_t pipe_lds_bytes(int ns, int nq, int nv, int nA, int nB, int nS, siz
   const size_t cells = (size_t)(nq + 2 * nv) * 17 + (3 * 12 + 2 * 10 + 2 * 34 + 2 * 2 + (size_t)ns * 6) * 64 + ((size_t)nA * (12 + 12 + 6) + (size_t)nB * 27 + (size_t)nS * 24) * 16;
   return ((nrec * TR_STRIDE * es + 15) & ~(size_t)15) + ((nrec * WREC_STRIDE * 4 + 15) & ~(size_t)15) + cells * es;
 }
+#endif  // RBD_JIT_COMPILE
 
 }  // namespace rbd

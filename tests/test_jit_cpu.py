@@ -120,7 +120,8 @@ def test_precompile_without_a_device(rbd, tmp_path, monkeypatch):
         pytest.skip("libhiprtc not available")
     assert ok, log
     files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".hsaco"))
-    assert len(files) == 2 and all(os.path.getsize(tmp_path / f) > 1000 for f in files)  # fp64: the mass-matrix and the inverse-dynamics programs
+    # fp64: the mass-matrix and the inverse-dynamics programs, and the walk kernel's (compiled twice: once to read the allocator's register use, csrc/rbd_jit.hip)
+    assert len(files) == 4 and all(os.path.getsize(tmp_path / f) > 1000 for f in files)
     stamps = [os.path.getmtime(tmp_path / f) for f in files]
     ok, _ = rbd.jit_precompile(model, torch.float64)
     assert ok and [os.path.getmtime(tmp_path / f) for f in files] == stamps
@@ -171,3 +172,41 @@ def test_generated_tree_tables_of_the_walk_kernels(rbd, name):
         for o, w in enumerate(opw):
             if (w[0] & 0xff) == 0 and (w[0] >> 16) != 0 and w[2] in voff_to_body and nvs[voff_to_body[w[2]]] > 0:  # 0 = RBD_JOINT_FIXED
                 assert T["NCH"][o] == len(children[voff_to_body[w[2]]])
+
+
+def walk_trees(rbd):
+    """The seeded random trees of tests/test_state_kernels.py::test_compiled_walk_random_trees (compiled here, on the CPU, they travel to the GPU box in the cache)."""
+    from test_chain_plan import random_tree
+    rng = np.random.default_rng(41)
+    return [rbd.flatten(random_tree(rbd, rng, n, floating, 0.4)) for n, floating in ((5, False), (7, True))]
+
+
+def test_walk_program_of_a_mechanism(rbd):
+    """The one-wavefront-per-track dynamics! kernel compiled per mechanism (aba_walk_spec, csrc/rbd_walk.hpp): fp64 only; the plan's records, constants and
+    parking words as tables of ns x G entries, the barrier masks, the re-rooted tree's chain; the rows of 64 states as static LDS."""
+    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
+    assert rbd.jit_source(model, torch.float32, "dynamics_tracks") is None
+    src = rbd.jit_source(model, torch.float64, "dynamics_tracks")
+    assert src is not None and "aba_walk_spec_f64" in src and '#include "rbd_walk.hpp"' in src
+    ns, G, nq, nv = (int(x) for x in re.search(r"NS = (\d+), G = (\d+), NQ = (\d+), NV = (\d+);", src).groups())
+    assert (nq, nv) == (model.nq, model.nv) and 1 <= G <= 4 and 1 <= ns <= 11
+    assert int(re.search(r"const int32_t RI\[(\d+)\]", src).group(1)) == 4 * ns * G
+    assert int(re.search(r"const double RR\[(\d+)\]", src).group(1)) == 24 * ns * G
+    assert int(re.search(r"const int32_t WK\[(\d+)\]", src).group(1)) == ns * G
+    assert "M.reroot.nchain" in src  # Atlas is walked from its centre (rbd_reroot.hpp)
+    lds = int(re.search(r"unsigned char lds\[(\d+)\]", src).group(1))
+    assert lds % (65 * 8) == 0 and nq + 2 * nv < lds // (65 * 8) and lds <= 160 * 1024
+    # every body of the tree sits in exactly one (step, track) record flagged valid (TF_VALID = bit 0 of the flags byte)
+    ri = [int(x) for x in re.search(r"RI\[\d+\][^=]*= \{([^}]*)\}", src).group(1).split(",")]
+    valid = sum(1 for k in range(ns * G) if (ri[4 * k + 1] >> 16) & 1)
+    assert valid == model.n_bodies
+
+
+def test_walk_programs_compile_without_a_device(rbd):
+    """... and compile for gfx950 here (into the library's cache: the GPU tests of the same trees load them)."""
+    for model in walk_trees(rbd):
+        ok, log = rbd.jit_precompile(model, torch.float64)
+        if ok is None:
+            pytest.skip("libhiprtc not available")
+        assert ok, log
+        assert rbd.jit_source(model, torch.float64, "dynamics_tracks") is not None

@@ -3,11 +3,13 @@ ones compiled for the mechanism at run time (csrc/rbd_spec.hpp through rbd_jit.h
 off).  They serve large batches (default: from half a chip-full of wavefronts up); RBD_STATE_MIN_BATCH=1 routes every batch size through them
 here, so that the same small seeded cases the lane-per-body kernels are tested on apply.
 reference: src/mechanism_algorithms.jl:248-272, :387-459, :542-553, :764, :819."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from test_gpu_parity import TD, dev, host, make
+from test_gpu_parity import NT, TD, dev, host, make
 
 pytestmark = pytest.mark.gpu
 IN_SCOPE = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf", "quickstart_pendulum"]
@@ -260,6 +262,64 @@ def test_compiled_aba_random_trees(rbd, oracle):
         assert np.abs(host(result.qd, state) - qd_ref).max() <= 2e-6 * max(1.0, np.abs(qd_ref).max()), trial
         done += 1
     assert done >= 4 or done == 0
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", ["atlas_floating", "double_pendulum", "acrobot_urdf"])
+def test_compiled_walk_f64(rbd, oracle, models, name, layout, monkeypatch):
+    """The walk kernel compiled for the mechanism (aba_walk_spec, fp64; default from 8192 states up) forced at a small ragged batch: torques + a wrench on
+    every body + q̇ at the reference's 1e-10; no torques / no wrenches; a gravity other than the mechanism's."""
+    monkeypatch.setenv("RBD_SPEC_WALK_MIN_BATCH", "1")
+    model = models[name]
+    if not rbd.jit_precompile(model, torch.float64)[0]:
+        pytest.skip("hiprtc not available")
+    B = 150
+    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 44)
+    result = rbd.DynamicsResult(model, B, layout=layout)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_walk")
+    assert rbd.sync(state) == 0
+    if os.environ.get("RBD_JIT") == "0":
+        assert "aba_walk_kernel" in rbd.last_kernel(state)
+    else:
+        assert "aba_walk_spec" in rbd.last_kernel(state)
+    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    assert np.abs(host(result.vd, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(host(result.qd, state) - qd_ref).max() <= 1e-12 * max(1.0, np.abs(qd_ref).max())
+    result.vd.fill_(float("nan"))
+    rbd.dynamics_(result, state, None, None, algorithm="aba_walk")
+    ref = oracle.dynamics(model, q, v, np.zeros_like(tau), None)
+    assert np.abs(host(result.vd, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+def test_compiled_walk_random_trees(rbd, oracle, monkeypatch):
+    """Random revolute / prismatic / fixed / sin-cos trees with and without a 6-dof root (tests/test_jit_cpu.py compiles the same ones on the CPU)."""
+    from test_jit_cpu import walk_trees
+    monkeypatch.setenv("RBD_SPEC_WALK_MIN_BATCH", "1")
+    for trial, model in enumerate(walk_trees(rbd)):
+        if not rbd.jit_precompile(model, torch.float64)[0]:
+            pytest.skip("hiprtc not available")
+        B = 70
+        state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 90 + trial)
+        result = rbd.DynamicsResult(model, B)
+        rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_walk")
+        assert "aba_walk_spec" in rbd.last_kernel(state) or os.environ.get("RBD_JIT") == "0"
+        ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+        assert np.abs(host(result.vd, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), trial
+        assert np.abs(host(result.qd, state) - qd_ref).max() <= 1e-12 * max(1.0, np.abs(qd_ref).max()), trial
+
+
+def test_compiled_walk_is_the_default_for_large_fp64_batches(rbd, oracle, models):
+    """16 384 fp64 Atlas states through RBD_ALGO_ABA: aba_walk_spec by default; the whole batch at 1e-10; and a simulate step through it."""
+    model = models["atlas_floating"]
+    B = 16384
+    state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 47)
+    result = rbd.DynamicsResult(model, B)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state))
+    assert rbd.sync(state) == 0
+    if "aba_walk_spec" not in rbd.last_kernel(state):
+        pytest.skip("hiprtc not available, or RBD_JIT=0: " + rbd.last_kernel(state))
+    ref = oracle.dynamics(model, q, v, tau, fe, nthreads=NT)
+    assert np.abs(host(result.vd, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
 
 
 def test_compiled_aba_is_the_default_for_large_fp32_batches(rbd, oracle, models):
