@@ -118,7 +118,7 @@ struct rbd_ws {
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
-  bool spec_walk_tried[2] = {false, false}; hipModule_t spec_walk_mod[2] = {nullptr, nullptr}; hipFunction_t spec_walk[2] = {nullptr, nullptr};  // [re-rooted]
+  bool spec_walk_tried[3] = {false, false, false}; hipModule_t spec_walk_mod[3] = {nullptr, nullptr, nullptr}; hipFunction_t spec_walk[3] = {nullptr, nullptr, nullptr};  // dynamics! on the original / the re-rooted tree, inverse_dynamics!
   void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
   long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
@@ -147,7 +147,7 @@ struct rbd_ws {
 };
 
 static std::string loop_program_source(const rbd_model* m, int dtype, std::vector<int32_t>* xi_store);  // (below)
-static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted);
+static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted, int kind = 0);
 static bool walk_program_rerooted(const rbd_model* m, int dtype);
 
 extern "C" {
@@ -162,10 +162,11 @@ int rbd_experimental(void) {
 }
 // run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
 int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char* buf, int64_t cap) {
-  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 1) return -1;
+  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 2) return -1;
   std::vector<int32_t> xi;
   if (family < SPEC_FAMILIES && !m->state.ok) return -1;
-  const std::string s = family == SPEC_FAMILIES + 1 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype))  // (family 4: the one-wavefront-per-track dynamics! kernel)
+  const std::string s = family == SPEC_FAMILIES + 2 ? walk_program_source(m, dtype, false, 1)  // (family 5: ... and its inverse_dynamics! kernel, on the original tree)
+                        : family == SPEC_FAMILIES + 1 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype))  // (family 4: the one-wavefront-per-track dynamics! kernel)
                         : family == SPEC_FAMILIES ? loop_program_source(m, dtype, &xi)  // (family 3: the program of a small loop mechanism)
                                                 : spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
   if (s.empty()) return -1;
@@ -189,6 +190,8 @@ int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t c
     const std::string src = walk_program_source(m, dtype, walk_program_rerooted(m, dtype));
     std::string lg;
     if (!src.empty()) (void)jit_walk_code_object(src, &lg);  // (a program whose registers do not work out is not an error: the interpreting kernel stays)
+    const std::string src2 = walk_program_source(m, dtype, false, 1);
+    if (!src2.empty()) (void)jit_walk_code_object(src2, &lg);
     all += lg;
   }
   for (int family = 0; family < SPEC_FAMILIES && m->state.ok; ++family) {
@@ -943,7 +946,7 @@ int rbd_workspace_destroy(rbd_ws_t* w) {
   }
   for (hipModule_t mod : w->spec_mod) if (mod) (void)hipModuleUnload(mod);
   if (w->spec_loop_mod) (void)hipModuleUnload(w->spec_loop_mod);
-  for (int k = 0; k < 2; ++k) if (w->spec_walk_mod[k]) (void)hipModuleUnload(w->spec_walk_mod[k]);
+  for (int k = 0; k < 3; ++k) if (w->spec_walk_mod[k]) (void)hipModuleUnload(w->spec_walk_mod[k]);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   delete w;
@@ -1107,24 +1110,24 @@ static bool walk_program_rerooted(const rbd_model* m, int dtype) {
   static const bool no_rr = getenv("RBD_WALK_NO_REROOT") != nullptr;
   return !no_rr && walk_tables(m, true, &W) && walk_lds_bytes(W.ns, W.G, W.nq, W.nv, W.nA, W.nB, W.nS, dtype == RBD_F64 ? 8 : 4, dtype == RBD_F64 ? 8 : 4) <= 160 * 1024;
 }
-static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted) {
+static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted, int kind) {
   WalkTables W;
   if (!walk_tables(m, rerooted, &W)) return std::string();
-  return walk_spec_source(W, dtype);
+  return walk_spec_source(W, dtype, kind);
 }
 // aba_walk_kernel compiled for the mechanism (aba_walk_spec of rbd_walk.hpp): nullptr when unavailable
-static hipFunction_t spec_walk(rbd_ws* w, bool rerooted) {
-  const int k = rerooted ? 1 : 0;
+static hipFunction_t spec_walk(rbd_ws* w, bool rerooted, int kind = 0) {
+  const int k = kind ? 2 : rerooted ? 1 : 0;
   if (w->spec_walk_tried[k]) return w->spec_walk[k];
   w->spec_walk_tried[k] = true;
   if (!jit_available()) return nullptr;
-  const std::string src = walk_program_source(w->model, w->dtype, rerooted);
+  const std::string src = walk_program_source(w->model, w->dtype, rerooted, kind);
   if (src.empty()) return nullptr;
   std::string log;
   const std::vector<char> code = jit_walk_code_object(src, &log);
   if (code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernel is used): " + log; return nullptr; }
   if (hipModuleLoadData(&w->spec_walk_mod[k], code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_walk_mod[k] = nullptr; jit_cache_discard(src); return nullptr; }
-  if (hipModuleGetFunction(&w->spec_walk[k], w->spec_walk_mod[k], "aba_walk_spec_f64") != hipSuccess) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
+  if (hipModuleGetFunction(&w->spec_walk[k], w->spec_walk_mod[k], kind ? "rnea_walk_spec_f64" : "aba_walk_spec_f64") != hipSuccess) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
   int scratch = 0;
   static const int max_scratch = getenv("RBD_SPEC_MAX_SCRATCH") ? atoi(getenv("RBD_SPEC_MAX_SCRATCH")) : 512;  // bytes per lane
   if (w->spec_walk[k] && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_walk[k]) != hipSuccess || scratch > max_scratch)) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
@@ -1238,6 +1241,16 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   if (can_walk && (mapping == RBD_ALGO_ABA_WALK || (mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->walk_min_batch))) {
     // one wavefront per track, one lane per state (rnea_walk_kernel): large batches
     const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
+    if (hipFunction_t f = (w->dtype == RBD_F64 && B >= w->spec_walk_min_batch) ? spec_walk(w, false, 1) : nullptr) {  // the same kernel compiled for this mechanism
+      long Bl = B;
+      Layout lq = Lq, lv = Lv, lf = Lf;
+      double gx = w->wm.gravity[0], gy = w->wm.gravity[1], gz = w->wm.gravity[2];
+      void* args[] = {&Bl, (void*)&dq, (void*)&dv, (void*)&dvd, (void*)&df, (void*)&dtau, (void*)&dqd, &lq, &lv, &lf, (void*)&dacc, (void*)&djw, &gx, &gy, &gz};
+      HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + 63) / 64), 1, 1, 64u * (unsigned)w->wm.G, 1, 1, 0, w->stream, args, nullptr));
+      w->last_kernel = "rnea_walk_spec (compiled for the mechanism)";
+      return RBD_OK;
+    }
+    w->last_kernel = pair ? "rnea_walk_kernel (two fp32 states per lane)" : "rnea_walk_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_walk<double>(w->wm, m->track.has_floating, m->track.general, 0, B, w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
     else HIP_TRY(launch_rnea_walk<float>(w->wm, m->track.has_floating, m->track.general, pair, B, pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
   } else if (!dacc && !djw && mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->state_min_batch) {  // one lane per state

@@ -36,7 +36,7 @@ struct WalkTables {
 };
 bool walk_spec_has(int dtype, int ns, int G, size_t lds_rows_bytes);
 size_t walk_spec_lds_bytes(const WalkTables& W, int dtype);
-std::string walk_spec_source(const WalkTables& W, int dtype);
+std::string walk_spec_source(const WalkTables& W, int dtype, int kind = 0);  // kind 0: dynamics! (aba_walk_spec_f64), 1: inverse_dynamics! / dynamics_bias! (rnea_walk_spec_f64)
 // compiles it twice (see aba_walk_spec): empty when the register allocator used accumulation registers of its own
 std::vector<char> jit_walk_code_object(const std::string& source, std::string* log);
 std::vector<char> jit_code_object(const std::string& source, std::string* log);

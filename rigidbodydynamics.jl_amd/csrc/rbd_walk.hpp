@@ -1236,6 +1236,139 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
     walk_stage_out<T, 10>(qdot, Lq, state0, B, NQ, c.rows, c.rq, tid, nth);
   }
 }
+// ... and rnea_walk_kernel (below) the same way: inverse_dynamics! / dynamics_bias! with the optional per-body outputs
+template <typename T, bool FLT, bool GEN, typename PLAN, int GI>
+RBD_DEV void rnea_walk_spec_track(const WalkCtx<T>& c, long B, const typename Lanes<T>::S* __restrict__ fext, bool want_qdot, Layout Lf, long state0, int lane,
+                                  bool shared_rows, typename Lanes<T>::S* __restrict__ acc_out, typename Lanes<T>::S* __restrict__ jw_out) {
+  using S = typename Lanes<T>::S;
+  constexpr int N = Lanes<T>::N, NS = PLAN::NS;
+  WalkRegs<T> W;
+  WalkStash<T> St;
+  walk_init(W);
+  const long fsk = Lf.sk;
+  const S* fel[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const long st = state0 + 64 * j + lane;
+    fel[j] = fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr;
+  }
+  auto wrench = [&](int o6, T* f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      S x[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) x[j] = fel[j][(long)(o6 + k) * fsk];
+      if constexpr (N == 1) f[k] = x[0];
+      else { f[k].x = x[0]; f[k].y = x[1]; }
+    }
+  };
+  walk_sfor<0, NS>([&](auto si) __attribute__((always_inline)) {
+    constexpr int s = decltype(si)::value;
+    const WalkRec r = walk_rec(walk_raw(c, s, GI));
+    T rr[TR_J];
+    walk_consts<T, TR_J>(c, s, GI, rr);
+    walk_step_a<T, FLT, GEN, true>(c, W, St, s, r, rr, lane, want_qdot);
+    if constexpr ((PLAN::SFM_AW >> s) & 1) __syncthreads();
+    RBD_WALK_STEP_FENCE();
+  });
+  if (shared_rows) __syncthreads();  // only then do the B mailboxes take over the rows of the A mailboxes' twist halves
+#pragma unroll
+  for (int k = 0; k < 6; ++k) W.cP[k] = T(0);
+  T fe[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) fe[k] = T(0);
+  if (fext) wrench(walk_rec(walk_raw(c, NS - 1, GI)).orig6, fe);
+  const bool outs = acc_out != nullptr || jw_out != nullptr;  // uniform
+  const bool out_vec = outs && store6_vec(acc_out ? acc_out : jw_out, Lf, (int)sizeof(S)) && store6_vec(jw_out ? jw_out : acc_out, Lf, (int)sizeof(S));
+  walk_sfor<0, NS>([&](auto si) __attribute__((always_inline)) {
+    constexpr int s = NS - 1 - decltype(si)::value, s1 = s > 0 ? s - 1 : 0;
+    const WalkRec r = walk_rec(walk_raw(c, s, GI));
+    T rr[TR_STRIDE], fn[6];
+    walk_consts<T, TR_STRIDE>(c, s, GI, rr);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fn[k] = T(0);
+    if (fext) wrench(walk_rec(walk_raw(c, s1, GI)).orig6, fn);
+    if (outs) {
+      T ao[6], jo[6];
+      walk_step_rb<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe, ao, jo);
+      if (r.flags & TF_VALID) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const long st = state0 + 64 * j + lane;
+          if (st < B) {
+            S av[6], jv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              if constexpr (N == 1) { av[k] = ao[k]; jv[k] = jo[k]; }
+              else { av[k] = j == 0 ? ao[k].x : ao[k].y; jv[k] = j == 0 ? jo[k].x : jo[k].y; }
+            }
+            if (acc_out) store6(acc_out, (long)r.orig6, Lf, st, av, out_vec);
+            if (jw_out) store6(jw_out, (long)r.orig6, Lf, st, jv, out_vec);
+          }
+        }
+      }
+    } else {
+      walk_step_rb<T, FLT, GEN>(c, W, St, s, r, rr, lane, fe);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fe[k] = fn[k];
+    if constexpr ((PLAN::SFM_BW >> s) & 1) __syncthreads();
+    RBD_WALK_STEP_FENCE();
+  });
+}
+template <typename T, bool FLT, bool GEN, typename PLAN>
+RBD_DEV void rnea_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v, const typename Lanes<T>::S* __restrict__ vdot,
+                            const typename Lanes<T>::S* __restrict__ fext, typename Lanes<T>::S* __restrict__ tau, typename Lanes<T>::S* __restrict__ qdot, Layout Lq,
+                            Layout Lv, Layout Lf, typename Lanes<T>::S* __restrict__ acc_out, typename Lanes<T>::S* __restrict__ jw_out, double gx, double gy, double gz,
+                            unsigned char* lds) {
+  constexpr int N = Lanes<T>::N, NQ = PLAN::NQ, NV = PLAN::NV;
+  WalkCtx<T> c;
+  walk_ctx_spec<T, PLAN>(c, lds);
+  c.a0[0] = T(0); c.a0[1] = T(0); c.a0[2] = T(0);
+  c.a0[3] = T(-gx); c.a0[4] = T(-gy); c.a0[5] = T(-gz);
+  const bool shared_rows = !walk_twist_rows_rnea(c);
+  const int lane = threadIdx.x & 63, tid = threadIdx.x, nth = blockDim.x;
+  const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long state0 = (long)blockIdx.x * (64 * N);
+  const bool inside = state0 + 64 * N <= B;  // wave-uniform
+  const bool fast = Lq.sk == 1 && Lv.sk == 1 && inside;
+  const bool fast_rows = Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && inside && !fast;
+  {
+    constexpr int UB = 10 * N;
+    if (fast) {
+      walk_stage_in_fast<T, UB>(q, v, vdot, state0, NQ, NV, c.rows, c.rq, c.rv, c.rt, tid, nth);
+    } else if (fast_rows) {
+      walk_stage_in_rows<T, UB>(q, v, vdot, B, state0, NQ, NV, c.rows, c.rq, c.rv, c.rt, tid, nth);
+    } else {
+      WalkStageIn<T, UB> in;
+      const int nmax = (NQ > NV ? NQ : NV) * 64 * N;
+      for (int e0 = 0; e0 < nmax; e0 += UB * nth) {
+        in.load(q, v, vdot, Lq, Lv, state0, B, NQ, NV, e0, tid, nth);
+        in.store(c.rows, c.rq, c.rv, c.rt);
+      }
+    }
+  }
+  __syncthreads();
+#ifndef RBD_WALK_PROBE
+  asm volatile("" ::: "a255");  // (see aba_walk_spec)
+#endif
+  const bool want_qdot = qdot != nullptr;
+  walk_sfor<0, PLAN::G>([&](auto gi) __attribute__((always_inline)) {
+    constexpr int GI = decltype(gi)::value;
+    if (g == GI) rnea_walk_spec_track<T, FLT, GEN, PLAN, GI>(c, B, fext, want_qdot, Lf, state0, lane, shared_rows, acc_out, jw_out);
+  });
+  __syncthreads();
+  if (fast) {
+    walk_stage_out_fast<T, 10 * N>(tau, state0, NV, c.rows, c.rt, tid, nth);
+    walk_stage_out_fast<T, 10 * N>(qdot, state0, NQ, c.rows, c.rq, tid, nth);
+  } else if (fast_rows) {
+    walk_stage_out_rows<T, 10 * N>(tau, B, state0, NV, c.rows, c.rt, tid, nth);
+    walk_stage_out_rows<T, 10 * N>(qdot, B, state0, NQ, c.rows, c.rq, tid, nth);
+  } else {
+    walk_stage_out<T, 10>(tau, Lv, state0, B, NV, c.rows, c.rt, tid, nth);
+    walk_stage_out<T, 10>(qdot, Lq, state0, B, NQ, c.rows, c.rq, tid, nth);
+  }
+}
 // inverse_dynamics! (vdot given) / dynamics_bias! (vdot == nullptr) through the same schedule: pass A with the full accelerations, then the
 // wrench pass (walk_step_rb).  src/mechanism_algorithms.jl:542-553, :484-498.
 template <typename T, bool FLT, bool GEN>

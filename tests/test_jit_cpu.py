@@ -120,8 +120,8 @@ def test_precompile_without_a_device(rbd, tmp_path, monkeypatch):
         pytest.skip("libhiprtc not available")
     assert ok, log
     files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".hsaco"))
-    # fp64: the mass-matrix and the inverse-dynamics programs, and the walk kernel's (compiled twice: once to read the allocator's register use, csrc/rbd_jit.hip)
-    assert len(files) == 4 and all(os.path.getsize(tmp_path / f) > 1000 for f in files)
+    # fp64: the mass-matrix and the inverse-dynamics programs, and the two walk kernels' (each compiled twice: once to read the allocator's register use, csrc/rbd_jit.hip)
+    assert len(files) == 6 and all(os.path.getsize(tmp_path / f) > 1000 for f in files)
     stamps = [os.path.getmtime(tmp_path / f) for f in files]
     ok, _ = rbd.jit_precompile(model, torch.float64)
     assert ok and [os.path.getmtime(tmp_path / f) for f in files] == stamps
@@ -210,3 +210,5 @@ def test_walk_programs_compile_without_a_device(rbd):
             pytest.skip("libhiprtc not available")
         assert ok, log
         assert rbd.jit_source(model, torch.float64, "dynamics_tracks") is not None
+        src = rbd.jit_source(model, torch.float64, "inverse_dynamics_tracks")
+        assert src is not None and "rnea_walk_spec_f64" in src and "M.reroot.nchain" not in src  # (inverse dynamics walks the original tree)

@@ -291,6 +291,33 @@ def test_compiled_walk_f64(rbd, oracle, models, name, layout, monkeypatch):
     assert np.abs(host(result.vd, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", ["atlas_floating", "double_pendulum", "acrobot_urdf"])
+def test_compiled_walk_inverse_dynamics_f64(rbd, oracle, models, name, layout, monkeypatch):
+    """rnea_walk_spec (the inverse-dynamics walk kernel compiled for the mechanism, fp64) forced at a small ragged batch: τ with v̇ and wrenches, the per-body
+    accelerations and joint wrenches against the oracle's, dynamics_bias!."""
+    monkeypatch.setenv("RBD_SPEC_WALK_MIN_BATCH", "1")
+    model = models[name]
+    if not rbd.jit_precompile(model, torch.float64)[0]:
+        pytest.skip("hiprtc not available")
+    B = 150
+    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 45)
+    vd = np.random.default_rng(8).standard_normal((B, model.nv))
+    out = torch.zeros_like(state.v)
+    shape = (B, 6 * model.n_bodies) if layout == "aos" else (6 * model.n_bodies, B)
+    jw = torch.full(shape, float("nan"), dtype=torch.float64, device="cuda"); acc = torch.full_like(jw, float("nan"))
+    rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state), mapping="walk", jointwrenchesout=jw, accelerations=acc)
+    assert rbd.sync(state) == 0
+    assert ("rnea_walk_spec" if os.environ.get("RBD_JIT") != "0" else "rnea_walk_kernel") in rbd.last_kernel(state)
+    ref, jw_ref, acc_ref = oracle.inverse_dynamics_bodies(model, q, v, vd, fe)
+    assert np.abs(host(out, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(host(acc, state) - acc_ref.reshape(B, -1)).max() <= 1e-10 * max(1.0, np.abs(acc_ref).max())
+    assert np.abs(host(jw, state) - jw_ref.reshape(B, -1)).max() <= 1e-10 * max(1.0, np.abs(jw_ref).max())
+    rbd.dynamics_bias_(out, state, mapping="walk")
+    ref = oracle.dynamics_bias(model, q, v, None)
+    assert np.abs(host(out, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
 def test_compiled_walk_random_trees(rbd, oracle, monkeypatch):
     """Random revolute / prismatic / fixed / sin-cos trees with and without a 6-dof root (tests/test_jit_cpu.py compiles the same ones on the CPU)."""
     from test_jit_cpu import walk_trees
