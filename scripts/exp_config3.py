@@ -13,8 +13,9 @@ rng = np.random.default_rng(2)
 state = rbd.MechanismState(model, B, dtype=tdt); result = rbd.DynamicsResult(model, B, dtype=tdt)
 rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng))
 tau = torch.rand(B, model.nv, dtype=tdt, device="cuda"); out = torch.zeros_like(tau)
-if op == "solve": f = lambda: rbd.mass_matrix_solve_(out, state, tau, result.massmatrix)
-elif op == "solve_nom": f = lambda: rbd.mass_matrix_solve_(out, state, tau, None)
+alg = os.environ.get("ALG", "cholesky")  # "aba": x from one articulated-body pass (M, when asked for, from mass_matrix!)
+if op == "solve": f = lambda: rbd.mass_matrix_solve_(out, state, tau, result.massmatrix, algorithm=alg)
+elif op == "solve_nom": f = lambda: rbd.mass_matrix_solve_(out, state, tau, None, algorithm=alg)
 else: f = lambda: rbd.mass_matrix_(result, state)
 for _ in range(5): f()
 torch.cuda.synchronize()
@@ -30,4 +31,4 @@ g.replay(); torch.cuda.synchronize()
 e0.record()
 for _ in range(5): g.replay()
 e1.record(); torch.cuda.synchronize()
-print(os.environ.get("TAG", ""), op, "B", B, "us per call", round(e0.elapsed_time(e1) * 1000 / 50, 2), rbd.last_kernel(state), flush=True)
+print(os.environ.get("TAG", ""), op, alg, "B", B, "us per call", round(e0.elapsed_time(e1) * 1000 / 50, 2), rbd.last_kernel(state), flush=True)
