@@ -118,7 +118,8 @@ struct rbd_ws {
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
-  bool spec_walk_tried[3] = {false, false, false}; hipModule_t spec_walk_mod[3] = {nullptr, nullptr, nullptr}; hipFunction_t spec_walk[3] = {nullptr, nullptr, nullptr};  // dynamics! on the original / the re-rooted tree, inverse_dynamics!
+  bool spec_walk_tried[8] = {}; hipModule_t spec_walk_mod[8] = {}; hipFunction_t spec_walk[8] = {};  // [inverse dynamics][re-rooted tree][two fp32 states per lane]
+  bool spec_walk_f32 = true;  // fp32 batches through the compiled walk kernels too (RBD_SPEC_WALK_F32=0: not)
   void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
   long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
@@ -147,8 +148,8 @@ struct rbd_ws {
 };
 
 static std::string loop_program_source(const rbd_model* m, int dtype, std::vector<int32_t>* xi_store);  // (below)
-static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted, int kind = 0);
-static bool walk_program_rerooted(const rbd_model* m, int dtype);
+static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted, int kind = 0, int pair = 0);
+static bool walk_program_rerooted(const rbd_model* m, int dtype, int pair = 0);
 
 extern "C" {
 
@@ -162,10 +163,12 @@ int rbd_experimental(void) {
 }
 // run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
 int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char* buf, int64_t cap) {
-  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 2) return -1;
+  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 4) return -1;
   std::vector<int32_t> xi;
   if (family < SPEC_FAMILIES && !m->state.ok) return -1;
-  const std::string s = family == SPEC_FAMILIES + 2 ? walk_program_source(m, dtype, false, 1)  // (family 5: ... and its inverse_dynamics! kernel, on the original tree)
+  const std::string s = family == SPEC_FAMILIES + 4 ? (dtype == RBD_F32 ? walk_program_source(m, dtype, false, 1, 1) : std::string())  // (families 6, 7: 4 and 5 with two fp32 states per lane)
+                        : family == SPEC_FAMILIES + 3 ? (dtype == RBD_F32 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype, 1), 0, 1) : std::string())
+                        : family == SPEC_FAMILIES + 2 ? walk_program_source(m, dtype, false, 1)  // (family 5: ... and its inverse_dynamics! kernel, on the original tree)
                         : family == SPEC_FAMILIES + 1 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype))  // (family 4: the one-wavefront-per-track dynamics! kernel)
                         : family == SPEC_FAMILIES ? loop_program_source(m, dtype, &xi)  // (family 3: the program of a small loop mechanism)
                                                 : spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
@@ -176,29 +179,32 @@ int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char
 int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t cap) {
   if (log && cap > 0) log[0] = 0;
   if (!m || (dtype != RBD_F32 && dtype != RBD_F64)) return RBD_ERR_INVALID_ARGUMENT;
-  if ((!m->state.ok && !m->loop_fused_ok) || !jit_available()) return RBD_ERR_UNSUPPORTED;
-  int st = RBD_OK;
-  std::string all;
+  if ((!m->state.ok && !m->loop_fused_ok && !(m->track.ok && m->walk.ok)) || !jit_available()) return RBD_ERR_UNSUPPORTED;
+  // the model's programs of this scalar type, the longest compilations first
+  struct Job { std::string src; bool walk; };
+  std::vector<Job> jobs;
+  for (int pair = 0; pair <= (dtype == RBD_F32 ? 1 : 0); ++pair) {
+    jobs.push_back({walk_program_source(m, dtype, walk_program_rerooted(m, dtype, pair), 0, pair), true});
+    jobs.push_back({walk_program_source(m, dtype, false, 1, pair), true});
+  }
+  for (int family = 0; family < SPEC_FAMILIES && m->state.ok; ++family)
+    jobs.push_back({spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family), false});
   {
     std::vector<int32_t> xi;
-    const std::string src = loop_program_source(m, dtype, &xi);
-    std::string lg;
-    if (!src.empty() && jit_code_object(src, &lg).empty()) st = RBD_ERR_HIP;
-    all += lg;
+    jobs.push_back({loop_program_source(m, dtype, &xi), false});
   }
-  {
-    const std::string src = walk_program_source(m, dtype, walk_program_rerooted(m, dtype));
+  // RBD_JIT_PRECOMPILE_PART = "k/n": only every n-th program, starting with the k-th — n processes share a model's compilations (__graft_entry__.build())
+  int part = 0, parts = 1;
+  if (const char* e = getenv("RBD_JIT_PRECOMPILE_PART")) { if (sscanf(e, "%d/%d", &part, &parts) != 2 || parts < 1 || part < 0 || part >= parts) { part = 0; parts = 1; } }
+  int st = RBD_OK, idx = 0;
+  std::string all;
+  for (const Job& j : jobs) {
+    if (j.src.empty()) continue;
+    if (idx++ % parts != part) continue;
     std::string lg;
-    if (!src.empty()) (void)jit_walk_code_object(src, &lg);  // (a program whose registers do not work out is not an error: the interpreting kernel stays)
-    const std::string src2 = walk_program_source(m, dtype, false, 1);
-    if (!src2.empty()) (void)jit_walk_code_object(src2, &lg);
-    all += lg;
-  }
-  for (int family = 0; family < SPEC_FAMILIES && m->state.ok; ++family) {
-    const std::string src = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
-    if (src.empty()) continue;
-    std::string lg;
-    if (jit_code_object(src, &lg).empty()) st = RBD_ERR_HIP;
+    // (a walk program whose registers do not work out is not an error: the interpreting kernel stays)
+    if (j.walk) (void)jit_walk_code_object(j.src, &lg);
+    else if (jit_code_object(j.src, &lg).empty()) st = RBD_ERR_HIP;
     all += lg;
   }
   if (log && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)all.size()); memcpy(log, all.data(), (size_t)n); log[n] = 0; }
@@ -841,6 +847,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     // batches that force the mapping (tests, sweeps) keep the interpreting kernel and its zero start-up cost (the compile takes about a minute per mechanism, once)
     w->spec_walk_min_batch = 8192;
     if (const char* e = getenv("RBD_SPEC_WALK_MIN_BATCH")) w->spec_walk_min_batch = atol(e);
+    if (const char* e = getenv("RBD_SPEC_WALK_F32")) w->spec_walk_f32 = atoi(e) != 0;
     WalkModel& wm = w->wm;
     wm.ns = P.ns; wm.G = P.G; wm.nA = P.nA; wm.nB = P.nB; wm.nS = m->walk.nS; wm.nq = m->nq; wm.nv = m->nv;
     wm.ri = (const int32_t*)w->d_track_ri; wm.rr = w->d_track_rr; wm.wk = (const int32_t*)w->d_walk_wk;
@@ -946,7 +953,7 @@ int rbd_workspace_destroy(rbd_ws_t* w) {
   }
   for (hipModule_t mod : w->spec_mod) if (mod) (void)hipModuleUnload(mod);
   if (w->spec_loop_mod) (void)hipModuleUnload(w->spec_loop_mod);
-  for (int k = 0; k < 3; ++k) if (w->spec_walk_mod[k]) (void)hipModuleUnload(w->spec_walk_mod[k]);
+  for (int k = 0; k < 8; ++k) if (w->spec_walk_mod[k]) (void)hipModuleUnload(w->spec_walk_mod[k]);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   delete w;
@@ -1105,29 +1112,30 @@ static bool walk_tables(const rbd_model* m, bool rerooted, WalkTables* W) {
   return true;
 }
 // (the plan rbd_dynamics picks for the walk kernel: the re-rooted tree when there is one and its rows fit the LDS)
-static bool walk_program_rerooted(const rbd_model* m, int dtype) {
+static bool walk_program_rerooted(const rbd_model* m, int dtype, int pair) {
   WalkTables W;
   static const bool no_rr = getenv("RBD_WALK_NO_REROOT") != nullptr;
-  return !no_rr && walk_tables(m, true, &W) && walk_lds_bytes(W.ns, W.G, W.nq, W.nv, W.nA, W.nB, W.nS, dtype == RBD_F64 ? 8 : 4, dtype == RBD_F64 ? 8 : 4) <= 160 * 1024;
+  return !no_rr && walk_tables(m, true, &W) && walk_lds_bytes(W.ns, W.G, W.nq, W.nv, W.nA, W.nB, W.nS, (dtype == RBD_F64 || pair) ? 8 : 4, dtype == RBD_F64 ? 8 : 4) <= 160 * 1024;
 }
-static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted, int kind) {
+static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted, int kind, int pair) {
   WalkTables W;
   if (!walk_tables(m, rerooted, &W)) return std::string();
-  return walk_spec_source(W, dtype, kind);
+  return walk_spec_source(W, dtype, kind, pair);
 }
 // aba_walk_kernel compiled for the mechanism (aba_walk_spec of rbd_walk.hpp): nullptr when unavailable
-static hipFunction_t spec_walk(rbd_ws* w, bool rerooted, int kind = 0) {
-  const int k = kind ? 2 : rerooted ? 1 : 0;
+static hipFunction_t spec_walk(rbd_ws* w, bool rerooted, int kind = 0, int pair = 0) {
+  const int k = (kind ? 4 : 0) + (rerooted ? 2 : 0) + (pair ? 1 : 0);
   if (w->spec_walk_tried[k]) return w->spec_walk[k];
   w->spec_walk_tried[k] = true;
   if (!jit_available()) return nullptr;
-  const std::string src = walk_program_source(w->model, w->dtype, rerooted, kind);
+  const std::string src = walk_program_source(w->model, w->dtype, rerooted, kind, pair);
   if (src.empty()) return nullptr;
   std::string log;
   const std::vector<char> code = jit_walk_code_object(src, &log);
   if (code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernel is used): " + log; return nullptr; }
   if (hipModuleLoadData(&w->spec_walk_mod[k], code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_walk_mod[k] = nullptr; jit_cache_discard(src); return nullptr; }
-  if (hipModuleGetFunction(&w->spec_walk[k], w->spec_walk_mod[k], kind ? "rnea_walk_spec_f64" : "aba_walk_spec_f64") != hipSuccess) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
+  const std::string fname = std::string(kind ? "rnea_walk_spec_" : "aba_walk_spec_") + walk_spec_suffix(w->dtype, pair);
+  if (hipModuleGetFunction(&w->spec_walk[k], w->spec_walk_mod[k], fname.c_str()) != hipSuccess) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
   int scratch = 0;
   static const int max_scratch = getenv("RBD_SPEC_MAX_SCRATCH") ? atoi(getenv("RBD_SPEC_MAX_SCRATCH")) : 512;  // bytes per lane
   if (w->spec_walk[k] && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_walk[k]) != hipSuccess || scratch > max_scratch)) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
@@ -1241,13 +1249,14 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   if (can_walk && (mapping == RBD_ALGO_ABA_WALK || (mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->walk_min_batch))) {
     // one wavefront per track, one lane per state (rnea_walk_kernel): large batches
     const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
-    if (hipFunction_t f = (w->dtype == RBD_F64 && B >= w->spec_walk_min_batch) ? spec_walk(w, false, 1) : nullptr) {  // the same kernel compiled for this mechanism
+    if (hipFunction_t f = ((w->dtype == RBD_F64 || w->spec_walk_f32) && B >= w->spec_walk_min_batch) ? spec_walk(w, false, 1, pair) : nullptr) {  // the same kernel compiled for this mechanism
       long Bl = B;
       Layout lq = Lq, lv = Lv, lf = Lf;
       double gx = w->wm.gravity[0], gy = w->wm.gravity[1], gz = w->wm.gravity[2];
       void* args[] = {&Bl, (void*)&dq, (void*)&dv, (void*)&dvd, (void*)&df, (void*)&dtau, (void*)&dqd, &lq, &lv, &lf, (void*)&dacc, (void*)&djw, &gx, &gy, &gz};
-      HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + 63) / 64), 1, 1, 64u * (unsigned)w->wm.G, 1, 1, 0, w->stream, args, nullptr));
-      w->last_kernel = "rnea_walk_spec (compiled for the mechanism)";
+      const long per = pair ? 128 : 64;
+      HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + per - 1) / per), 1, 1, 64u * (unsigned)w->wm.G, 1, 1, 0, w->stream, args, nullptr));
+      w->last_kernel = pair ? "rnea_walk_spec (compiled for the mechanism, two fp32 states per lane)" : "rnea_walk_spec (compiled for the mechanism)";
       return RBD_OK;
     }
     w->last_kernel = pair ? "rnea_walk_kernel (two fp32 states per lane)" : "rnea_walk_kernel";
@@ -1320,13 +1329,14 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     w->last_kernel = pair ? "aba_walk_kernel (two fp32 states per lane)" : "aba_walk_kernel";
     const TrackPlan& TP = rr ? m->rrs.track : m->track;
     const size_t lds = rr ? (pair ? w->walk_rr_lds_bytes_pair : w->walk_rr_lds_bytes) : (pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes);
-    if (hipFunction_t f = (w->dtype == RBD_F64 && B >= w->spec_walk_min_batch) ? spec_walk(w, rr) : nullptr) {  // the same kernel compiled for this mechanism
-      w->last_kernel = "aba_walk_spec (compiled for the mechanism)";
+    if (hipFunction_t f = ((w->dtype == RBD_F64 || w->spec_walk_f32) && B >= w->spec_walk_min_batch) ? spec_walk(w, rr, 0, pair) : nullptr) {  // the same kernel compiled for this mechanism
+      w->last_kernel = pair ? "aba_walk_spec (compiled for the mechanism, two fp32 states per lane)" : "aba_walk_spec (compiled for the mechanism)";
       long Bl = B;
       Layout lq = Lq, lv = Lv, lf = Lf;
       double gx = wm.gravity[0], gy = wm.gravity[1], gz = wm.gravity[2];
       void* args[] = {&Bl, (void*)&dq, (void*)&dv, (void*)&dtau, (void*)&df, (void*)&dvd, (void*)&dqd, &lq, &lv, &lf, &gx, &gy, &gz};
-      HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + 63) / 64), 1, 1, 64u * (unsigned)wm.G, 1, 1, 0, w->stream, args, nullptr));
+      const long per = pair ? 128 : 64;
+      HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + per - 1) / per), 1, 1, 64u * (unsigned)wm.G, 1, 1, 0, w->stream, args, nullptr));
     } else
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, TP.has_floating, TP.general, 0, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba_walk<float>(wm, TP.has_floating, TP.general, pair, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));

@@ -23,7 +23,7 @@ struct LoopTables {
 };
 std::string spec_loop_source(const LoopTables& L, int dtype);
 // The program of the one-wavefront-per-track dynamics! kernel for ONE mechanism (aba_walk_spec of rbd_walk.hpp with the plan as constants): aba_walk_spec_f64.
-// fp64 only (fp32 batches of that size run aba_spec).
+// fp64, fp32, and fp32 with two states per lane (pair).
 struct WalkTables {
   int ns, G, nA, nB, nS, nq, nv, flt, gen, rr;
   const std::vector<int32_t>*ri, *wk;
@@ -35,8 +35,9 @@ struct WalkTables {
   const double* fXp;
 };
 bool walk_spec_has(int dtype, int ns, int G, size_t lds_rows_bytes);
-size_t walk_spec_lds_bytes(const WalkTables& W, int dtype);
-std::string walk_spec_source(const WalkTables& W, int dtype, int kind = 0);  // kind 0: dynamics! (aba_walk_spec_f64), 1: inverse_dynamics! / dynamics_bias! (rnea_walk_spec_f64)
+size_t walk_spec_lds_bytes(const WalkTables& W, int dtype, int pair = 0);
+const char* walk_spec_suffix(int dtype, int pair);  // f64 | f32 | f32x2 (two fp32 states per lane)
+std::string walk_spec_source(const WalkTables& W, int dtype, int kind = 0, int pair = 0);  // kind 0: dynamics! (aba_walk_spec_<suffix>), 1: inverse_dynamics! / dynamics_bias! (rnea_walk_spec_<suffix>)
 // compiles it twice (see aba_walk_spec): empty when the register allocator used accumulation registers of its own
 std::vector<char> jit_walk_code_object(const std::string& source, std::string* log);
 std::vector<char> jit_code_object(const std::string& source, std::string* log);

@@ -182,10 +182,15 @@ def walk_trees(rbd):
 
 
 def test_walk_program_of_a_mechanism(rbd):
-    """The one-wavefront-per-track dynamics! kernel compiled per mechanism (aba_walk_spec, csrc/rbd_walk.hpp): fp64 only; the plan's records, constants and
+    """The one-wavefront-per-track dynamics! kernel compiled per mechanism (aba_walk_spec, csrc/rbd_walk.hpp): the plan's records, constants and
     parking words as tables of ns x G entries, the barrier masks, the re-rooted tree's chain; the rows of 64 states as static LDS."""
     model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
-    assert rbd.jit_source(model, torch.float32, "dynamics_tracks") is None
+    # fp32: one state per lane and two (packed arithmetic; the rows are 8 bytes wide like fp64's); the pair programs exist in fp32 only
+    s32, s32x2 = rbd.jit_source(model, torch.float32, "dynamics_tracks"), rbd.jit_source(model, torch.float32, "dynamics_tracks_pairs")
+    assert "aba_walk_spec_f32(" in s32 and "rbd::aba_walk_spec<float," in s32 and "aba_walk_spec_f32x2(" in s32x2 and "rbd::aba_walk_spec<rbd::f2," in s32x2
+    assert 2 * int(re.search(r"unsigned char lds\[(\d+)\]", s32).group(1)) == int(re.search(r"unsigned char lds\[(\d+)\]", s32x2).group(1))
+    assert rbd.jit_source(model, torch.float64, "dynamics_tracks_pairs") is None
+    assert "rnea_walk_spec_f32x2(" in rbd.jit_source(model, torch.float32, "inverse_dynamics_tracks_pairs")
     src = rbd.jit_source(model, torch.float64, "dynamics_tracks")
     assert src is not None and "aba_walk_spec_f64" in src and '#include "rbd_walk.hpp"' in src
     ns, G, nq, nv = (int(x) for x in re.search(r"NS = (\d+), G = (\d+), NQ = (\d+), NV = (\d+);", src).groups())

@@ -318,6 +318,39 @@ def test_compiled_walk_inverse_dynamics_f64(rbd, oracle, models, name, layout, m
     assert np.abs(host(out, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("pair", [False, True])
+@pytest.mark.parametrize("name", ["atlas_floating", "double_pendulum", "acrobot_urdf"])
+def test_compiled_walk_f32(rbd, oracle, models, name, pair, monkeypatch):
+    """The fp32 forms of the compiled walk kernels — one state per lane, and two (packed arithmetic; default from 16 385 states) — forced at a small ragged batch:
+    dynamics! by its backward error, q̇, inverse_dynamics! with the per-body outputs at fp32 accuracy."""
+    monkeypatch.setenv("RBD_SPEC_WALK_MIN_BATCH", "1")
+    monkeypatch.setenv("RBD_WALK_PAIR_MIN_BATCH", "1" if pair else "1000000000")
+    model = models[name]
+    B = 333
+    state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 46)
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_walk")
+    assert rbd.sync(state) == 0
+    kern = rbd.last_kernel(state)
+    if os.environ.get("RBD_JIT") != "0" and "aba_walk_spec" not in kern:
+        pytest.skip("hiprtc not available: " + kern)
+    assert ("two fp32 states per lane" in kern) == pair
+    vd = host(result.vd, state)
+    assert np.isfinite(vd).all() and backward_error(oracle, model, q, v, tau, fe, vd).max() <= 2e-6
+    _, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    assert np.abs(host(result.qd, state) - qd_ref).max() <= 2e-6 * max(1.0, np.abs(qd_ref).max())
+    vd_in = np.random.default_rng(9).standard_normal((B, model.nv)).astype(np.float32).astype(np.float64)
+    out = torch.zeros_like(state.v)
+    jw = torch.full((B, 6 * model.n_bodies), float("nan"), dtype=torch.float32, device="cuda"); acc = torch.full_like(jw, float("nan"))
+    rbd.inverse_dynamics_(out, state, dev(vd_in, state), dev(fe, state), mapping="walk", jointwrenchesout=jw, accelerations=acc)
+    assert "rnea_walk" in rbd.last_kernel(state) and ("two fp32 states per lane" in rbd.last_kernel(state)) == pair
+    ref, jw_ref, acc_ref = oracle.inverse_dynamics_bodies(model, q, v, vd_in, fe)
+    tol = lambda r: 2e-4 * max(1.0, np.abs(r).max())
+    assert np.abs(host(out, state) - ref).max() <= tol(ref)
+    assert np.abs(host(jw, state) - jw_ref.reshape(B, -1)).max() <= tol(jw_ref)
+    assert np.abs(host(acc, state) - acc_ref.reshape(B, -1)).max() <= tol(acc_ref)
+
+
 def test_compiled_walk_random_trees(rbd, oracle, monkeypatch):
     """Random revolute / prismatic / fixed / sin-cos trees with and without a 6-dof root (tests/test_jit_cpu.py compiles the same ones on the CPU)."""
     from test_jit_cpu import walk_trees
