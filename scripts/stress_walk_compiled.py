@@ -22,7 +22,7 @@ if pre:
     for name, model in cases:
         t = time.time()
         src = rbd.jit_source(model, torch.float64, "dynamics_tracks")
-        ok = rbd.jit_precompile(model, torch.float64)[0] if src else None
+        ok = (rbd.jit_precompile(model, torch.float64)[0], rbd.jit_precompile(model, torch.float32)[0]) if src else None
         print(name, "nv", model.nv, "program" if src else "outside the walk mapping", ok, round(time.time() - t, 1), "s", flush=True)
     sys.exit(0)
 import oracle
@@ -65,6 +65,28 @@ for trial, (name, model) in enumerate(cases):
     worst = max(worst, e)
     # same arithmetic in the same order; contraction of a * b + c may differ between the two compilations
     assert e < 1e-10 and np.abs(outs["1"][1] - qd).max() <= 1e-12 * max(1.0, np.abs(qd).max()), (name, e)
-    print(name, "nv", model.nv, "B", B, "compiled err", e, "interpreting err", e0, flush=True)
+    # fp32, one state per lane and two: against the interpreting kernel of the same form (same arithmetic up to contraction) and the fp64 oracle at fp32 accuracy
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    q32, v32, tau32, fe32 = f32(q), f32(v), f32(tau), f32(fe)
+    ref32 = oracle.dynamics(model, q32, v32, tau32, fe32)
+    e32 = {}
+    for pair in ("1000000000", "1"):
+        os.environ["RBD_WALK_PAIR_MIN_BATCH"] = pair
+        got = {}
+        for jit in ("1", "0"):
+            os.environ["RBD_JIT"] = jit
+            state = rbd.MechanismState(model, B, dtype=torch.float32); res = rbd.DynamicsResult(model, B, dtype=torch.float32)
+            rbd.set_configuration_(state, q32); rbd.set_velocity_(state, v32)
+            t32 = lambda a: torch.as_tensor(a, dtype=torch.float32, device="cuda")
+            rbd.dynamics_(res, state, t32(tau32), t32(fe32), algorithm="aba_walk")
+            assert rbd.sync(state) == 0
+            assert (("aba_walk_spec" if jit == "1" else "aba_walk_kernel") in rbd.last_kernel(state)) and (("two fp32" in rbd.last_kernel(state)) == (pair == "1")), rbd.last_kernel(state)
+            got[jit] = res.vd.double().cpu().numpy()
+        scale = max(1.0, np.abs(ref32).max())
+        e32[pair == "1"] = (np.abs(got["1"] - ref32).max() / scale, np.abs(got["0"] - ref32).max() / scale)
+        # an fp32 solve of an ill-conditioned system: the two compilations may differ by as much as either differs from the truth, not more
+        assert e32[pair == "1"][0] <= 4 * e32[pair == "1"][1] + 1e-5, (name, pair, e32)
+    os.environ.pop("RBD_WALK_PAIR_MIN_BATCH")
+    print(name, "nv", model.nv, "B", B, "compiled err %.1e interpreting err %.1e | fp32 (compiled, interpreting): one per lane %.1e %.1e two per lane %.1e %.1e" % ((e, e0) + tuple(float(x) for x in e32[False] + e32[True])), flush=True)
     done += 1
 print(done, "mechanisms ok,", skipped, "outside the mapping; worst error", worst)
