@@ -5,12 +5,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import rbd_amd as rbd
-names = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf", "quickstart_pendulum", "randmech2", "randmech3"]
-for name in names:
-    path = os.path.join(ROOT, "tests", "golden", "models", name + ".json")
-    if not os.path.exists(path):
-        continue
-    model = rbd.load_flat_model(path)
+import numpy as np
+models = {name: rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", name + ".json")) for name in ("atlas_floating", "atlas_fixed", "valkyrie_floating", "acrobot_urdf")}
+models["double_pendulum"] = rbd.flatten(rbd.double_pendulum())          # (as tests/conftest.py builds them)
+models["quickstart_pendulum"] = rbd.flatten(rbd.quickstart_double_pendulum())
+models["four_bar"] = rbd.flatten(rbd.four_bar_linkage())
+for seed in (1, 2, 3):
+    models[f"randmech{seed}"] = rbd.flatten(rbd.randmech(np.random.default_rng(seed)))
+for name, model in models.items():
     for dt in (torch.float32, torch.float64):
         t = time.time()
         ok = rbd.jit_precompile(model, dt)[0]
