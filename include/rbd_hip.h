@@ -371,7 +371,7 @@ int rbd_experimental(void);
  * (jit_cache/) or in $RBD_JIT_CACHE.  Without libhiprtc, or with RBD_JIT=0, the interpreting kernels run instead; results agree to rounding.
  * One program per family of kernels and scalar type — family 0: mass_matrix! (+ the sparse tile Cholesky and the emitter of M in fp32), 1: dynamics!
  * (fp32), 2: inverse_dynamics! / dynamics_bias! (fp32; fp64), 3: the whole loop-joint branch of dynamics! for small loop mechanisms (<= 4 bodies, nv <= 4,
- * nc <= 6: the four-bar linkage), 4 / 5: the one-wavefront-per-track kernels of dynamics! / inverse_dynamics! (from 8192 states), 6 / 7: the same with two
+ * nc <= 6: the four-bar linkage), 4 / 5: the one-wavefront-per-track kernels of dynamics! / inverse_dynamics! (batches beyond what the two-bodies-per-lane kernels hold at once), 6 / 7: the same with two
  * fp32 states per lane — each compiled when a workspace first takes that route.
  * rbd_jit_precompile compiles all of a model's programs of one scalar type (RBD_F32 / RBD_F64) into the cache ahead of time (no device needed);
  * rbd_jit_source returns the generated source of one (length without the terminator; buf may be NULL; -1: no such program for this mechanism). */

@@ -121,7 +121,7 @@ struct rbd_ws {
   bool spec_walk_tried[8] = {}; hipModule_t spec_walk_mod[8] = {}; hipFunction_t spec_walk[8] = {};  // [inverse dynamics][re-rooted tree][two fp32 states per lane]
   bool spec_walk_f32 = true;  // fp32 batches through the compiled walk kernels too (RBD_SPEC_WALK_F32=0: not)
   void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
-  long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0;
+  long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0, walk_one_round_batch = 0, rnea_walk_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   long bank_min_batch = 0, bank_resident_states = 0;
@@ -880,6 +880,14 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       int ncu = 256;
       (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
       w->walk_min_batch = (m->bank_lps > 0 && m->bank_aba_ok ? w->bank_resident_states : (long)ncu * 4 * 2 * (64 / m->lps)) + 1;
+      // Second half of round 3 (profiles/r03_mid_batches.txt, Atlas): compiled for the mechanism the walk launch takes 23 us (fp64) / 19 us (fp32) up to 16 384 states,
+      // so it is ahead of the banked kernel as soon as that one needs a second workgroup per CU (fp64 38 us, fp32 26 us from 4097 states): dynamics! switches there
+      // when the compiled kernel is available.  Inverse dynamics' banked kernel keeps two workgroups per CU in both precisions and stays ahead up to their 8192 states
+      // (fp64 17.7-19.0 vs 19.8 us, fp32 17.0-18.0 vs 17.8-18.1).
+      const bool banked = m->bank_lps > 0 && m->bank_aba_ok;
+      w->walk_one_round_batch = banked ? (long)ncu * (256 / m->bank_lps) + 1 : w->walk_min_batch;
+      w->rnea_walk_min_batch = banked ? std::max<long>(w->walk_min_batch, (long)ncu * 2 * (256 / m->bank_lps) + 1) : w->walk_min_batch;
+      if (!getenv("RBD_SPEC_WALK_MIN_BATCH")) w->spec_walk_min_batch = std::min<long>(w->spec_walk_min_batch, w->walk_one_round_batch);
     }
     if (const char* e = getenv("RBD_WALK_MIN_BATCH")) w->walk_min_batch = atol(e);
 #ifdef RBD_EXPERIMENTAL
@@ -1246,7 +1254,7 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
     }
   }
   if (mapping == RBD_ALGO_ABA_COMPILED) return RBD_ERR_UNSUPPORTED;
-  if (can_walk && (mapping == RBD_ALGO_ABA_WALK || (mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->walk_min_batch))) {
+  if (can_walk && (mapping == RBD_ALGO_ABA_WALK || (mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->rnea_walk_min_batch))) {
     // one wavefront per track, one lane per state (rnea_walk_kernel): large batches
     const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
     if (hipFunction_t f = ((w->dtype == RBD_F64 || w->spec_walk_f32) && B >= w->spec_walk_min_batch) ? spec_walk(w, false, 1, pair) : nullptr) {  // the same kernel compiled for this mechanism
@@ -1263,13 +1271,16 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_walk<double>(w->wm, m->track.has_floating, m->track.general, 0, B, w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
     else HIP_TRY(launch_rnea_walk<float>(w->wm, m->track.has_floating, m->track.general, pair, B, pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
   } else if (!dacc && !djw && mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->state_min_batch) {  // one lane per state
+    w->last_kernel = "rnea_state_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_state<double>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_rnea_state<float>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
   } else if (banks) {
     const int ncol = m->has3dof ? 3 : 1;
+    w->last_kernel = "rnea_bank_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_bank<double>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
     else HIP_TRY(launch_rnea_bank<float>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
   } else {
+    w->last_kernel = "rnea_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, dvd, df, dtau, dqd, nullptr, Lq, Lv, Lf, w->stream, dacc, djw));
     else HIP_TRY(launch_rnea<float>(w->dm, B, dq, dv, dvd, df, dtau, dqd, nullptr, Lq, Lv, Lf, w->stream, dacc, djw));
   }
@@ -1308,6 +1319,11 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   if (algorithm == RBD_ALGO_ABA_COMPILED) return RBD_ERR_UNSUPPORTED;
   int pick = algorithm;
   if (algorithm == RBD_ALGO_ABA) pick = (can_pipe && B <= w->pipe_max_batch) ? RBD_ALGO_ABA_PIPE : (can_walk && B >= w->walk_min_batch) ? RBD_ALGO_ABA_WALK : (can_track && B >= w->track_min_batch) ? RBD_ALGO_ABA_TRACKS : (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
+  if (algorithm == RBD_ALGO_ABA && pick == RBD_ALGO_ABA_BANKS && can_walk && B >= w->walk_one_round_batch && B >= w->spec_walk_min_batch && (w->dtype == RBD_F64 || w->spec_walk_f32)) {
+    // the banked kernel would need a second workgroup per CU: the walk kernel compiled for the mechanism is ahead from here (see walk_one_round_batch)
+    static const bool no_rr = getenv("RBD_WALK_NO_REROOT") != nullptr;
+    if (spec_walk(w, w->walk_rr && !no_rr && w->walk_rr_lds_bytes > 0, 0, 0)) pick = RBD_ALGO_ABA_WALK;
+  }
   Timed t(w);
   w->last_kernel = pick == RBD_ALGO_ABA_TRACKS ? "aba_track_kernel" : pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : "aba_kernel";
 #ifdef RBD_EXPERIMENTAL
