@@ -166,8 +166,9 @@ typedef struct rbd_opts {
   int32_t layout;     /* RBD_LAYOUT_*  (default SOA)                                  */
   int32_t memory;     /* RBD_MEM_*     (default DEVICE)                               */
   int32_t algorithm;  /* RBD_ALGO_*    (rbd_dynamics only)                            */
-  int32_t stabilization; /* 1 = Baumgarte stabilization with the loop joints' gains (the
-                            reference's default), 0 = `stabilization_gains=nothing`  */
+  int32_t stabilization; /* 1 = Baumgarte stabilization with the workspace's gains (the model's — the
+                            reference's default — unless rbd_workspace_set_loop_gains replaced them),
+                            0 = `stabilization_gains=nothing`                         */
 } rbd_opts_t;
 
 /* ---- model / workspace lifetime ------------------------------------------ */
@@ -204,6 +205,12 @@ int rbd_workspace_create(const rbd_model_t* model, int32_t max_batch, int32_t de
                          int32_t dtype, void* stream, rbd_ws_t** out);
 int rbd_workspace_destroy(rbd_ws_t* ws);
 int rbd_workspace_set_stream(rbd_ws_t* ws, void* stream);
+/* `stabilization_gains` as an AbstractDict{JointID, SE3PDGains} / ConstDict (src/mechanism_algorithms.jl:614-632, :848; src/simulate.jl:37): the Baumgarte
+ * gains of the calls that FOLLOW on this workspace (rbd_dynamics, rbd_simulate*, rbd_mk_stage with opts->stabilization = 1).  gains: HOST array of
+ * 4 × n_loops doubles — (angular k, angular d, linear k, linear d) for every loop joint in the order of rbd_flat_model_t.loops; NULL restores the
+ * model's (rbd_loop_joint_t.gains).  Cheap when the gains are the ones already in force (no device access), so a binding may call it before every
+ * dynamics!; otherwise it waits for the workspace's stream.  Non-finite gains: RBD_ERR_INVALID_ARGUMENT.  No-op for tree mechanisms. */
+int rbd_workspace_set_loop_gains(rbd_ws_t* ws, const double* gains);
 int rbd_sync(rbd_ws_t* ws);
 
 /* ---- the hot path ----------------------------------------------------------
@@ -360,8 +367,8 @@ int rbd_workspace_last_kernel_ms(rbd_ws_t* ws, float* ms);
 /* name of the articulated-body kernel (lane mapping) the last rbd_dynamics / rbd_simulate / rbd_mass_matrix_solve call launched */
 const char* rbd_workspace_last_kernel(const rbd_ws_t* ws);
 /* 100·round + revision of this header.  rbd_flat_model_t grew its four contact fields at 200; a caller built against an older header must
- * not call a newer library (the Python and Julia loaders compare this with the value they were written for). */
-#define RBD_HIP_H_VERSION 300
+ * not call a newer library (the Python and Julia loaders compare this with the value they were written for).  400: rbd_workspace_set_loop_gains. */
+#define RBD_HIP_H_VERSION 400
 int rbd_version(void);
 /* 1 when the library was built with RBD_EXPERIMENTAL=1 (RBD_ALGO_ABA_TRACKS / RBD_ALGO_ABA_PIPE available), else 0 */
 int rbd_experimental(void);
@@ -376,6 +383,12 @@ int rbd_experimental(void);
  * rbd_jit_precompile compiles all of a model's programs of one scalar type (RBD_F32 / RBD_F64) into the cache ahead of time (no device needed);
  * rbd_jit_source returns the generated source of one (length without the terminator; buf may be NULL; -1: no such program for this mechanism). */
 int rbd_jit_precompile(const rbd_model_t* model, int32_t dtype, char* log, int64_t log_capacity);
+/* Compilation never blocks a hot-path call (since 400): a call that would use a program that is not in the cache starts its compilation on a background thread,
+ * runs the interpreting kernel, and the first call after the compiler has finished switches over (RBD_JIT_ASYNC=0: the first call waits instead, as does a
+ * call that names the compiled kernel, RBD_ALGO_ABA_COMPILED).  rbd_jit_precompile is the blocking form (all programs of the model in parallel; the log lists
+ * the seconds each took).  rbd_jit_status is the non-blocking query for ONE program (family as above): 1 = ready, 0 = being compiled (started by this
+ * call if nobody had), -1 = no such program / no hiprtc / compilation failed. */
+int rbd_jit_status(const rbd_model_t* model, int32_t dtype, int32_t family);
 int64_t rbd_jit_source(const rbd_model_t* model, int32_t dtype, int32_t family, char* buf, int64_t capacity);
 
 #ifdef __cplusplus

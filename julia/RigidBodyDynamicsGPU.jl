@@ -20,7 +20,8 @@ module RigidBodyDynamicsGPU
 using RigidBodyDynamics
 using RigidBodyDynamics: Mechanism, MechanismState, DynamicsResult, Joint, JointType, Revolute, Prismatic, Fixed, Planar, QuaternionSpherical,
     QuaternionFloating, SinCosRevolute, RigidBody, BodyID, Wrench, tree_joints, non_tree_joints, predecessor, successor, joint_to_predecessor,
-    joint_to_successor, spatial_inertia, joint_type, num_positions, num_velocities, num_constraints, root_body, modcount, bodies
+    joint_to_successor, spatial_inertia, joint_type, num_positions, num_velocities, num_constraints, root_body, modcount, bodies, JointID
+using RigidBodyDynamics.PDControl: SE3PDGains
 using RigidBodyDynamics.Spatial: rotation, translation, angular, linear
 # the generics this file adds methods to (src/RigidBodyDynamics.jl:143-155 exports them)
 import RigidBodyDynamics: dynamics!, inverse_dynamics!, mass_matrix!, dynamics_bias!, momentum_matrix!, geometric_jacobian!, center_of_mass,
@@ -136,9 +137,10 @@ mutable struct FlatModelHandle
     nq::Int; nv::Int; nc::Int; nb::Int
     bodyindex::Dict{RigidBody, Int32}   # body -> index in the flat model (-1 = root body)
     bodyids::Dict{BodyID, Int32}
+    loopjointids::Vector{JointID}       # the non-tree joints in the order of rbd_flat_model_t.loops (= the order of rbd_workspace_set_loop_gains)
 end
 
-const HEADER_VERSION = 300    # RBD_HIP_H_VERSION of the include/rbd_hip.h these structs mirror (rbd_flat_model_t grew its contact fields at 200)
+const HEADER_VERSION = 400    # RBD_HIP_H_VERSION of the include/rbd_hip.h these structs mirror (rbd_flat_model_t grew its contact fields at 200; 400: rbd_workspace_set_loop_gains)
 
 function FlatModelHandle(mechanism::Mechanism)
     ccall((:rbd_version, librbd_hip[]), Cint, ()) == HEADER_VERSION ||
@@ -192,7 +194,7 @@ function FlatModelHandle(mechanism::Mechanism)
     end
     m = FlatModelHandle(handle[], modcount(mechanism), num_positions(mechanism), num_velocities(mechanism),
         sum(num_constraints, non_tree_joints(mechanism); init = 0), nb, Dict{RigidBody, Int32}(bodyindex),
-        Dict{BodyID, Int32}(BodyID(b) => i for (b, i) in bodyindex))
+        Dict{BodyID, Int32}(BodyID(b) => i for (b, i) in bodyindex), JointID[JointID(j) for j in non_tree_joints(mechanism)])
     finalizer(x -> ccall((:rbd_model_destroy, librbd_hip[]), Cint, (Ptr{Cvoid},), x.handle), m)
     m
 end
@@ -262,6 +264,37 @@ function BatchedDynamicsResult(mechanism::Mechanism, B::Integer; T::Type = Float
 end
 
 opts(state; algorithm = 0, stabilization = 1) = Ref(RbdOpts(LAYOUT_AOS, state.memory, algorithm, stabilization))
+
+# `stabilization_gains` (src/mechanism_algorithms.jl:614-632, :848; src/simulate.jl:37) -> the flag of rbd_opts_t + rbd_workspace_set_loop_gains:
+#   nothing                                   no Baumgarte stabilization;
+#   :default                                  the model's gains = default_constraint_stabilization_gains (100, 20, 100, 20);
+#   AbstractDict{JointID, <:SE3PDGains}       per loop joint (a ConstDict{JointID} is one — its getindex ignores the key); a missing joint throws the
+#                                             dictionary's own KeyError, as stabilization_gains[nontreejointid] (:655) does in the reference.
+# Scalar gains only: the kernels apply k and d as scalars (every use in the reference and its tests); matrix gains throw an ArgumentError
+# instead of being silently replaced.  The call is cheap when the gains are the ones already in force.
+scalargain(x::Number) = Float64(x)
+scalargain(x) = throw(ArgumentError("stabilization_gains: only scalar PD gains are supported by librbd_hip, got $(typeof(x))"))
+function stabilization(state, ::Nothing)
+    Int32(0)
+end
+function stabilization(state, gains::Symbol)
+    gains === :default || throw(ArgumentError("stabilization_gains: $gains"))
+    isempty(state.model.loopjointids) || check(ccall((:rbd_workspace_set_loop_gains, librbd_hip[]), Cint, (Ptr{Cvoid}, Ptr{Float64}), state.ws, C_NULL),
+        "rbd_workspace_set_loop_gains")
+    Int32(1)
+end
+function stabilization(state, gains::AbstractDict{JointID, <:SE3PDGains})
+    ids = state.model.loopjointids
+    isempty(ids) && return Int32(1)
+    g = Float64[]
+    for id in ids
+        gj = gains[id]
+        append!(g, (scalargain(gj.angular.k), scalargain(gj.angular.d), scalargain(gj.linear.k), scalargain(gj.linear.d)))
+    end
+    check(ccall((:rbd_workspace_set_loop_gains, librbd_hip[]), Cint, (Ptr{Cvoid}, Ptr{Float64}), state.ws, g), "rbd_workspace_set_loop_gains")
+    Int32(1)
+end
+stabilization(state, gains) = throw(ArgumentError("stabilization_gains must be nothing or an AbstractDict{JointID, <:SE3PDGains}, got $(typeof(gains))"))
 nullable(x) = pointer(x)
 nullable(::Nothing) = C_NULL
 batchsize(state) = size(state.q, 2)
@@ -290,7 +323,7 @@ function dynamics!(result::BatchedDynamicsResult{T}, state::BatchedMechanismStat
     B = batchsize(state)
     torques === nothing || size(torques) == (state.model.nv, B) || throw(DimensionMismatch("torques"))
     wext = densewrenches(state, externalwrenches)
-    o = opts(state; algorithm = algorithm === :aba ? 0 : 1, stabilization = stabilization_gains === nothing ? 0 : 1)
+    o = opts(state; algorithm = algorithm === :aba ? 0 : 1, stabilization = stabilization(state, stabilization_gains))
     λptr = state.model.nc > 0 ? pointer(result.λ) : C_NULL
     if size(state.s, 1) > 0
         # contact points: contact_dynamics! (:680-723), totalwrenches = externalwrenches + contactwrenches (:851-856), then forward dynamics.
@@ -306,10 +339,13 @@ function dynamics!(result::BatchedDynamicsResult{T}, state::BatchedMechanismStat
     bind = algorithm !== :aba && state.model.nc == 0 && state.memory == MEM_DEVICE
     bind && check(ccall((:rbd_workspace_bind_result, librbd_hip[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), state.ws, result.massmatrix.ptr, result.dynamicsbias.ptr),
         "rbd_workspace_bind_result")
-    check(ccall((:rbd_dynamics, librbd_hip[]), Cint,
-        (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
-        state.ws, B, state.q, state.v, nullable(torques), nullable(wext), result.v̇, result.q̇, λptr, o), "rbd_dynamics")
-    bind && ccall((:rbd_workspace_bind_result, librbd_hip[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), state.ws, C_NULL, C_NULL)
+    try
+        check(ccall((:rbd_dynamics, librbd_hip[]), Cint,
+            (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+            state.ws, B, state.q, state.v, nullable(torques), nullable(wext), result.v̇, result.q̇, λptr, o), "rbd_dynamics")
+    finally     # never leave the result's buffers bound to the workspace: a later call would write into them, freed or not
+        bind && ccall((:rbd_workspace_bind_result, librbd_hip[]), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), state.ws, C_NULL, C_NULL)
+    end
     if !bind && (algorithm !== :aba || state.model.nc > 0)
         check(ccall((:rbd_dynamics_result, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
             state.ws, B, result.massmatrix, result.dynamicsbias, state.model.nc > 0 ? pointer(result.constraintjacobian) : C_NULL,
@@ -377,45 +413,114 @@ function mass_matrix!(M::Buffer{T}, state::BatchedMechanismState{T}) where {T}
 end
 mass_matrix!(result::BatchedDynamicsResult, state::BatchedMechanismState) = mass_matrix!(result.massmatrix, state)
 
-"""`simulate(state0, final_time; Δt, stabilization_gains)` — src/simulate.jl:36-55 for the whole batch: Munthe-Kaas RK4 on the
-device (`rbd_simulate`), constant `torques` (the default control is `zero_torque!`); `state.q`, `state.v` are advanced in place."""
-function simulate(state::BatchedMechanismState{T}, final_time; Δt = 1e-4, torques = nothing, stabilization_gains = :default) where {T}
-    checkmodcount(state)
+# number of steps of integrate(), src/ode_integrators.jl:311-314: `while t < final_time` in the state's scalar type
+function stepcount(::Type{T}, final_time, Δt) where {T}
     nsteps, t = 0, zero(T)
-    while t < final_time            # same loop as integrate(), src/ode_integrators.jl:311-314
+    while t < final_time
         t += Δt; nsteps += 1
     end
-    if size(state.s, 1) > 0     # contact points: the additional state is integrated beside (q, v) with the same tableau
-        check(ccall((:rbd_simulate_contact, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
-            state.ws, batchsize(state), state.q, state.v, state.s, nullable(torques), C_NULL, Float64(Δt), nsteps, opts(state)), "rbd_simulate_contact")
-    else
-        check(ccall((:rbd_simulate, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
-            state.ws, batchsize(state), state.q, state.v, nullable(torques), C_NULL, Float64(Δt), nsteps,
-            opts(state; stabilization = stabilization_gains === nothing ? 0 : 1)), "rbd_simulate")
+    nsteps
+end
+hostcopy(x::Matrix) = copy(x)
+hostcopy(x::DeviceMatrix) = Array(x)
+
+"""`simulate(state0, final_time; Δt, stabilization_gains)` — src/simulate.jl:36-55 for the whole batch: Munthe-Kaas RK4 on the
+device (`rbd_simulate`), constant `torques` (the default control is `zero_torque!`), optional `externalwrenches`; `state.q`, `state.v` are advanced
+in place.  Returns `(ts, qs, vs)` like the reference; `store = true` (the reference always stores, `ExpandingStorage`) keeps a host copy of q and v
+(nq × B, nv × B) per step in `qs`, `vs` — one launch sequence per step; `store = false` (default here: B trajectories are B times the memory) runs
+all the steps without returning to the host and returns `qs = vs = nothing`."""
+function simulate(state::BatchedMechanismState{T}, final_time; Δt = 1e-4, torques = nothing, externalwrenches = nothing, stabilization_gains = :default,
+        store::Bool = false) where {T}
+    checkmodcount(state)
+    nsteps = stepcount(T, final_time, Δt)
+    B = batchsize(state)
+    wext = densewrenches(state, externalwrenches)
+    ts = range(zero(T), step = T(Δt), length = nsteps + 1)
+    qs, vs = store ? ([hostcopy(state.q)], [hostcopy(state.v)]) : (nothing, nothing)
+    for chunk in (store ? fill(1, nsteps) : (nsteps,))
+        if size(state.s, 1) > 0     # contact points: the additional state is integrated beside (q, v) with the same tableau
+            check(ccall((:rbd_simulate_contact, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
+                state.ws, B, state.q, state.v, state.s, nullable(torques), nullable(wext), Float64(Δt), chunk, opts(state)), "rbd_simulate_contact")
+        else
+            check(ccall((:rbd_simulate, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
+                state.ws, B, state.q, state.v, nullable(torques), nullable(wext), Float64(Δt), chunk,
+                opts(state; stabilization = stabilization(state, stabilization_gains))), "rbd_simulate")
+        end
+        if store
+            synchronize(state); push!(qs, hostcopy(state.q)); push!(vs, hostcopy(state.v))
+        end
     end
     finish(state)
-    range(zero(T), step = T(Δt), length = nsteps + 1)
+    ts, qs, vs
+end
+
+"""`simulate(state0, final_time, control!; Δt, stabilization_gains)` — src/simulate.jl:36-55 with ANY controller: `control!(torques, t, state)` is
+called before every Runge-Kutta stage's `dynamics!` exactly as the reference's closure does (:42-48), with `torques` the nv × B buffer of the batch
+(a `DeviceMatrix` for device-resident states: fill it with `copyto!` or a kernel of your own), `t` the stage time and `state` holding the STAGE state.
+The stage arithmetic of MuntheKaasIntegrator.step (src/ode_integrators.jl:233-299) runs on the device (`rbd_mk_stage`: stage 0 snapshots the base
+point, stages 1..3 take the previous stage's v̇, stage 4 closes the step); only the controller runs on the host.  Returns `(ts, qs, vs)` (`store`
+as above).  Controllers that can run on the device should use `TorqueTable` / `PDControl` below: no host round trip per stage."""
+function simulate(state::BatchedMechanismState{T}, final_time, control!::Function; Δt = 1e-4, externalwrenches = nothing, stabilization_gains = :default,
+        store::Bool = false) where {T}
+    checkmodcount(state)
+    size(state.s, 1) == 0 || throw(ArgumentError("control! with contact points: drive dynamics! per stage yourself"))
+    nsteps = stepcount(T, final_time, Δt)
+    B, nv, nc = batchsize(state), state.model.nv, state.model.nc
+    wext = densewrenches(state, externalwrenches)
+    o = opts(state; stabilization = stabilization(state, stabilization_gains))
+    storage = state.memory == MEM_HOST ? Val(:host) : Val(:device)
+    τ, v̇, λ = newbuffer(storage, T, nv, B), newbuffer(storage, T, nv, B), newbuffer(storage, T, max(nc, 1), B)
+    ts = range(zero(T), step = T(Δt), length = nsteps + 1)
+    qs, vs = store ? ([hostcopy(state.q)], [hostcopy(state.v)]) : (nothing, nothing)
+    stagetimes = (zero(T), T(Δt) / 2, T(Δt) / 2, T(Δt))     # runge_kutta_4's c (src/ode_integrators.jl:48-55)
+    for k in 1:nsteps
+        for stage in 0:4
+            check(ccall((:rbd_mk_stage, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Int32, Cdouble, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+                state.ws, B, stage, Float64(Δt), state.q, state.v, stage > 0 ? pointer(v̇) : Ptr{T}(C_NULL), o), "rbd_mk_stage")
+            stage == 4 && break
+            state.memory == MEM_DEVICE && synchronize(state)      # the controller may read the stage state from the host
+            control!(τ, ts[k] + stagetimes[stage + 1], state)
+            check(ccall((:rbd_dynamics, librbd_hip[]), Cint,
+                (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+                state.ws, B, state.q, state.v, τ, nullable(wext), v̇, C_NULL, nc > 0 ? pointer(λ) : Ptr{T}(C_NULL), o), "rbd_dynamics")
+        end
+        if store
+            synchronize(state); push!(qs, hostcopy(state.q)); push!(vs, hostcopy(state.v))
+        end
+    end
+    finish(state)
+    ts, qs, vs
 end
 
 """`simulate(state0, final_time, control; Δt)` with a controller that runs on the device (no host round trip per Runge-Kutta stage — the
 reference calls `control!(τ, t, state)` before every stage's `dynamics!`, src/simulate.jl:42-48):
 `TorqueTable(τ, per_stage)` — τ :: (nv·B) × entries, entry 4·step + stage (the stage times) or entry `step` (zero-order hold);
-`PDControl(kp, kd, q_des, τff)` — τ = τff − kp (q − q_des) − kd v on Revolute / Prismatic joints, on the stage state."""
+`PDControl(kp, kd, q_des, τff)` — τ = τff − kp (q − q_des) − kd v on Revolute / Prismatic joints, on the stage state (kp, kd :: nv × 1)."""
 struct TorqueTable{T}; torques::DeviceMatrix{T}; per_stage::Bool; end
 struct PDControl{T}; kp::DeviceMatrix{T}; kd::DeviceMatrix{T}; q_des::Union{Nothing, DeviceMatrix{T}}; torques::Union{Nothing, DeviceMatrix{T}}; end
-function simulate(state::BatchedMechanismState{T}, final_time, control::Union{TorqueTable{T}, PDControl{T}}; Δt = 1e-4) where {T}
+function simulate(state::BatchedMechanismState{T}, final_time, control::Union{TorqueTable{T}, PDControl{T}}; Δt = 1e-4, externalwrenches = nothing) where {T}
     checkmodcount(state)
-    nsteps, t = 0, zero(T)
-    while t < final_time
-        t += Δt; nsteps += 1
+    state.memory == MEM_DEVICE || throw(ArgumentError("device-side controllers need device-resident states (storage = :device)"))
+    nsteps = stepcount(T, final_time, Δt)
+    B, nq, nv = batchsize(state), state.model.nq, state.model.nv
+    # the kernels index the controller's buffers without bounds: check them here (the C entry point sees only pointers)
+    if control isa TorqueTable
+        need = (control.per_stage ? 4 : 1) * nsteps
+        size(control.torques, 1) == nv * B && size(control.torques, 2) >= need ||
+            throw(DimensionMismatch("TorqueTable: need a (nv·B) × n table with n ≥ $need entries, got $(size(control.torques))"))
+    else
+        prod(size(control.kp)) == nv && prod(size(control.kd)) == nv || throw(DimensionMismatch("PDControl: kp, kd must hold nv = $nv gains"))
+        control.q_des === nothing || size(control.q_des) == (nq, B) || throw(DimensionMismatch("PDControl: q_des must be nq × B"))
+        control.torques === nothing || size(control.torques) == (nv, B) || throw(DimensionMismatch("PDControl: torques must be nv × B"))
     end
+    wext = densewrenches(state, externalwrenches)
     vp(x) = x === nothing ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(x))
     ctl = control isa TorqueTable ? RbdControl(1, control.per_stage ? 1 : 0, vp(control.torques), C_NULL, C_NULL, C_NULL) :
                                     RbdControl(2, 0, vp(control.torques), vp(control.q_des), vp(control.kp), vp(control.kd))
     check(ccall((:rbd_simulate_controlled, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ref{RbdControl}, Ptr{T}, Cdouble, Int32, Ref{RbdOpts}),
-        state.ws, batchsize(state), state.q, state.v, ctl, C_NULL, Float64(Δt), nsteps, opts(state)), "rbd_simulate_controlled")
+        state.ws, B, state.q, state.v, ctl, nullable(wext), Float64(Δt), nsteps, opts(state)), "rbd_simulate_controlled")
     finish(state)
-    range(zero(T), step = T(Δt), length = nsteps + 1)
+    range(zero(T), step = T(Δt), length = nsteps + 1), nothing, nothing
 end
 
 # ---- kinematics by-products of the same forward-kinematics pass (root frame) -------------------------------------------------------

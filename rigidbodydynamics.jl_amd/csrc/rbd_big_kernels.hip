@@ -204,25 +204,28 @@ __global__ __launch_bounds__(64) void big_crba_kernel(BigModel M, long B, const 
   }
 }
 
-// dynamics_solve! without loop joints (:764, :819): L = chol(M) in place (lower triangle of the caller's / workspace's M), x = M^-1 (rhs - c)
+// dynamics_solve! without loop joints (:764, :819): L = chol(M), x = M^-1 (rhs - c).  Like the reference, which copies M into result.L before potrf!
+// (:763-764) and leaves result.massmatrix intact, the factor goes to a scratch of its own (Lg, batch-innermost: entry (row, col) of state st at
+// (col nv + row) B + st) — Mg is the caller's M_out / the bound result.massmatrix / the workspace's M and is only read.
 template <typename T>
-__global__ __launch_bounds__(64) void big_chol_solve_kernel(int nv, long B, T* __restrict__ Mg, const T* __restrict__ rhs, const T* __restrict__ c, T* __restrict__ x,
-                                                            Layout Lm, Layout Lv, int* __restrict__ notpd) {
+__global__ __launch_bounds__(64) void big_chol_solve_kernel(int nv, long B, const T* __restrict__ Mg, T* __restrict__ Lg, const T* __restrict__ rhs,
+                                                            const T* __restrict__ c, T* __restrict__ x, Layout Lm, Layout Lv, int* __restrict__ notpd) {
   const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (st >= B) return;
-  auto M = [&](int row, int col) -> T& { return Mg[((long)col * nv + row) * Lm.sk + st * Lm.sb]; };
+  auto M = [&](int row, int col) -> T { return Mg[((long)col * nv + row) * Lm.sk + st * Lm.sb]; };
+  auto L = [&](int row, int col) -> T& { return Lg[((long)col * nv + row) * B + st]; };
   bool bad = false;
   for (int j = 0; j < nv; ++j) {
     T d = M(j, j);
-    for (int k = 0; k < j; ++k) d -= M(j, k) * M(j, k);
+    for (int k = 0; k < j; ++k) d -= L(j, k) * L(j, k);
     if (!(d > T(0))) bad = true;
     d = SqrtT<T>::f(d);
-    M(j, j) = d;
+    L(j, j) = d;
     const T id = T(1) / d;
     for (int i = j + 1; i < nv; ++i) {
       T s = M(i, j);
-      for (int k = 0; k < j; ++k) s -= M(i, k) * M(j, k);
-      M(i, j) = s * id;
+      for (int k = 0; k < j; ++k) s -= L(i, k) * L(j, k);
+      L(i, j) = s * id;
     }
   }
   if (bad) atomicOr(notpd, 1);
@@ -230,13 +233,13 @@ __global__ __launch_bounds__(64) void big_chol_solve_kernel(int nv, long B, T* _
   for (int i = 0; i < nv; ++i) {
     const long a = (long)i * Lv.sk + st * Lv.sb;
     T s = (rhs ? rhs[a] : T(0)) - (c ? c[a] : T(0));
-    for (int k = 0; k < i; ++k) s -= M(i, k) * X(k);
-    X(i) = s / M(i, i);
+    for (int k = 0; k < i; ++k) s -= L(i, k) * X(k);
+    X(i) = s / L(i, i);
   }
   for (int i = nv - 1; i >= 0; --i) {
     T s = X(i);
-    for (int k = i + 1; k < nv; ++k) s -= M(k, i) * X(k);
-    X(i) = s / M(i, i);
+    for (int k = i + 1; k < nv; ++k) s -= L(k, i) * X(k);
+    X(i) = s / L(i, i);
   }
 }
 
@@ -255,15 +258,15 @@ hipError_t launch_big_crba(const BigModel& M, long B, const void* q, void* Mout,
   return hipGetLastError();
 }
 template <typename T>
-hipError_t launch_big_chol_solve(int nv, long B, void* Mg, const void* rhs, const void* c, void* x, Layout Lm, Layout Lv, int* notpd, hipStream_t s) {
-  hipLaunchKernelGGL(big_chol_solve_kernel<T>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, nv, B, (T*)Mg, (const T*)rhs, (const T*)c, (T*)x, Lm, Lv, notpd);
+hipError_t launch_big_chol_solve(int nv, long B, const void* Mg, void* Lg, const void* rhs, const void* c, void* x, Layout Lm, Layout Lv, int* notpd, hipStream_t s) {
+  hipLaunchKernelGGL(big_chol_solve_kernel<T>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, nv, B, (const T*)Mg, (T*)Lg, (const T*)rhs, (const T*)c, (T*)x, Lm, Lv, notpd);
   return hipGetLastError();
 }
 #define RBD_BIG_INST(T)                                                                                                                                     \
   template hipError_t launch_big_rnea<T>(const BigModel&, long, const void*, const void*, const void*, const void*, void*, void*, void*, void*, void*, Layout, \
                                          Layout, Layout, hipStream_t);                                                                                       \
   template hipError_t launch_big_crba<T>(const BigModel&, long, const void*, void*, void*, Layout, Layout, hipStream_t);                                    \
-  template hipError_t launch_big_chol_solve<T>(int, long, void*, const void*, const void*, void*, Layout, Layout, int*, hipStream_t);
+  template hipError_t launch_big_chol_solve<T>(int, long, const void*, void*, const void*, const void*, void*, Layout, Layout, int*, hipStream_t);
 RBD_BIG_INST(double)
 RBD_BIG_INST(float)
 

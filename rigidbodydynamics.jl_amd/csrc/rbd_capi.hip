@@ -2,6 +2,8 @@
 // workspace/stream management, argument checking, kernel dispatch.  No torch types, no CPU fallback:
 // every hot-path entry point launches HIP kernels or fails with a status code.
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -118,8 +120,10 @@ struct rbd_ws {
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
+  std::string spec_src[SPEC_FAMILIES], spec_loop_src, spec_walk_src[8];  // the programs' sources while their compilation is pending (generated once)
   bool spec_walk_tried[8] = {}; hipModule_t spec_walk_mod[8] = {}; hipFunction_t spec_walk[8] = {};  // [inverse dynamics][re-rooted tree][two fp32 states per lane]
   bool spec_walk_f32 = true;  // fp32 batches through the compiled walk kernels too (RBD_SPEC_WALK_F32=0: not)
+  std::vector<double> loop_gains; bool custom_gains = false;  // rbd_workspace_set_loop_gains: this workspace's Baumgarte gains (4 per loop joint), and whether they differ from the model's
   void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
   long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0, walk_one_round_batch = 0, rnea_walk_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
@@ -133,7 +137,7 @@ struct rbd_ws {
   void* d_M = nullptr; void* d_c = nullptr; void* d_K = nullptr; void* d_k = nullptr;
   size_t d_M_bytes = 0, d_c_bytes = 0, d_K_bytes = 0, d_k_bytes = 0;
   void* d_body = nullptr; void* d_scratch = nullptr; size_t d_body_bytes = 0, d_scratch_bytes = 0;
-  BigModel big{}; void* d_big_tbl = nullptr; void* d_big_rb = nullptr; void* d_big_scratch = nullptr; size_t d_big_scratch_bytes = 0;  // rbd_big_kernels.hip
+  BigModel big{}; void* d_big_tbl = nullptr; void* d_big_rb = nullptr; void* d_big_scratch = nullptr; size_t d_big_scratch_bytes = 0; void* d_big_L = nullptr; size_t d_big_L_bytes = 0;  // rbd_big_kernels.hip (d_big_L: the Cholesky factor, result.L)
   void* d_fused_i = nullptr;  // loop_fused_small_kernel: parent, q offset, slot by reference body index
   void* d_loop_i = nullptr; void* d_loop_r = nullptr; void* d_loop_path = nullptr; void* d_jt_ref = nullptr; void* d_voff_ref = nullptr; void* d_axis_ref = nullptr; void* d_axis2_ref = nullptr;
   MkBuffers mk{}; void* d_vdwork = nullptr; size_t mk_elems = 0;  // Munthe-Kaas integrator scratch (lazy)
@@ -162,50 +166,74 @@ int rbd_experimental(void) {
 #endif
 }
 // run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
-int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char* buf, int64_t cap) {
-  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 4) return -1;
+// the source of one program of a model (families as in include/rbd_hip.h); empty: no such program for this mechanism
+static std::string program_source(const rbd_model* m, int32_t dtype, int32_t family) {
+  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 4) return std::string();
   std::vector<int32_t> xi;
-  if (family < SPEC_FAMILIES && !m->state.ok) return -1;
-  const std::string s = family == SPEC_FAMILIES + 4 ? (dtype == RBD_F32 ? walk_program_source(m, dtype, false, 1, 1) : std::string())  // (families 6, 7: 4 and 5 with two fp32 states per lane)
-                        : family == SPEC_FAMILIES + 3 ? (dtype == RBD_F32 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype, 1), 0, 1) : std::string())
-                        : family == SPEC_FAMILIES + 2 ? walk_program_source(m, dtype, false, 1)  // (family 5: ... and its inverse_dynamics! kernel, on the original tree)
-                        : family == SPEC_FAMILIES + 1 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype))  // (family 4: the one-wavefront-per-track dynamics! kernel)
-                        : family == SPEC_FAMILIES ? loop_program_source(m, dtype, &xi)  // (family 3: the program of a small loop mechanism)
-                                                : spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
+  if (family < SPEC_FAMILIES && !m->state.ok) return std::string();
+  return family == SPEC_FAMILIES + 4 ? (dtype == RBD_F32 ? walk_program_source(m, dtype, false, 1, 1) : std::string())  // (families 6, 7: 4 and 5 with two fp32 states per lane)
+         : family == SPEC_FAMILIES + 3 ? (dtype == RBD_F32 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype, 1), 0, 1) : std::string())
+         : family == SPEC_FAMILIES + 2 ? walk_program_source(m, dtype, false, 1)  // (family 5: ... and its inverse_dynamics! kernel, on the original tree)
+         : family == SPEC_FAMILIES + 1 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype))  // (family 4: the one-wavefront-per-track dynamics! kernel)
+         : family == SPEC_FAMILIES ? loop_program_source(m, dtype, &xi)  // (family 3: the program of a small loop mechanism)
+                                   : spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
+}
+static bool family_is_walk(int family) { return family > SPEC_FAMILIES; }
+int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char* buf, int64_t cap) {
+  const std::string s = program_source(m, dtype, family);
   if (s.empty()) return -1;
   if (buf && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)s.size()); memcpy(buf, s.data(), (size_t)n); buf[n] = 0; }
   return (int64_t)s.size();
+}
+// 1: the program's code object is ready (in the cache, or compiled by this process); 0: being compiled on a background thread (started by this call if nobody
+// had); -1: no such program for this mechanism, no hiprtc, or the compilation failed.  Never waits.
+int rbd_jit_status(const rbd_model_t* m, int32_t dtype, int32_t family) {
+  const std::string src = program_source(m, dtype, family);
+  if (src.empty() || !jit_available()) return -1;
+  std::vector<char> code;
+  std::string log;
+  const int js = family_is_walk(family) ? jit_walk_code_object_get(src, false, &code, &log) : jit_code_object_get(src, false, &code, &log);
+  return js == JIT_READY ? 1 : js == JIT_PENDING ? 0 : -1;
 }
 int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t cap) {
   if (log && cap > 0) log[0] = 0;
   if (!m || (dtype != RBD_F32 && dtype != RBD_F64)) return RBD_ERR_INVALID_ARGUMENT;
   if ((!m->state.ok && !m->loop_fused_ok && !(m->track.ok && m->walk.ok)) || !jit_available()) return RBD_ERR_UNSUPPORTED;
-  // the model's programs of this scalar type, the longest compilations first
-  struct Job { std::string src; bool walk; };
+  // the model's programs of this scalar type, the longest compilations first; every one of them on its own background thread (rbd_jit.hip), then wait for all
+  struct Job { std::string src; bool walk; int family; int state; double seconds; std::string log; };
   std::vector<Job> jobs;
-  for (int pair = 0; pair <= (dtype == RBD_F32 ? 1 : 0); ++pair) {
-    jobs.push_back({walk_program_source(m, dtype, walk_program_rerooted(m, dtype, pair), 0, pair), true});
-    jobs.push_back({walk_program_source(m, dtype, false, 1, pair), true});
-  }
-  for (int family = 0; family < SPEC_FAMILIES && m->state.ok; ++family)
-    jobs.push_back({spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family), false});
-  {
-    std::vector<int32_t> xi;
-    jobs.push_back({loop_program_source(m, dtype, &xi), false});
-  }
-  // RBD_JIT_PRECOMPILE_PART = "k/n": only every n-th program, starting with the k-th — n processes share a model's compilations (__graft_entry__.build())
+  for (int family : {4, 5, 6, 7, 0, 1, 2, 3})
+    jobs.push_back({program_source(m, dtype, family), family_is_walk(family), family, JIT_PENDING, 0.0, std::string()});
+  // RBD_JIT_PRECOMPILE_PART = "k/n": only every n-th program, starting with the k-th — n processes share a model's compilations
   int part = 0, parts = 1;
   if (const char* e = getenv("RBD_JIT_PRECOMPILE_PART")) { if (sscanf(e, "%d/%d", &part, &parts) != 2 || parts < 1 || part < 0 || part >= parts) { part = 0; parts = 1; } }
-  int st = RBD_OK, idx = 0;
+  int idx = 0;
+  for (Job& j : jobs) {
+    if (j.src.empty()) { j.state = -1; continue; }
+    if (idx++ % parts != part) j.state = -1;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  int st = RBD_OK;
+  for (bool pending = true; pending;) {
+    pending = false;
+    for (Job& j : jobs) {
+      if (j.state != JIT_PENDING) continue;
+      std::vector<char> code;
+      j.state = j.walk ? jit_walk_code_object_get(j.src, false, &code, &j.log) : jit_code_object_get(j.src, false, &code, &j.log);
+      if (j.state == JIT_PENDING) pending = true;
+      else j.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (pending) usleep(20000);
+  }
   std::string all;
   for (const Job& j : jobs) {
-    if (j.src.empty()) continue;
-    if (idx++ % parts != part) continue;
-    std::string lg;
+    if (j.state < 0) continue;
+    char b[160];
     // (a walk program whose registers do not work out is not an error: the interpreting kernel stays)
-    if (j.walk) (void)jit_walk_code_object(j.src, &lg);
-    else if (jit_code_object(j.src, &lg).empty()) st = RBD_ERR_HIP;
-    all += lg;
+    snprintf(b, sizeof b, "[rbd_jit] family %d (%s): %s after %.1f s\n", j.family, dtype == RBD_F64 ? "f64" : "f32", j.state == JIT_READY ? "ready" : j.walk ? "not used" : "FAILED", j.seconds);
+    all += b;
+    all += j.log;
+    if (j.state == JIT_FAILED && !j.walk) st = RBD_ERR_HIP;
   }
   if (log && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)all.size()); memcpy(log, all.data(), (size_t)n); log[n] = 0; }
   return st;
@@ -934,6 +962,12 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
     w->state_min_batch = (long)ncu * 4 * 64 / 2;
     if (const char* e = getenv("RBD_STATE_MIN_BATCH")) w->state_min_batch = atol(e);
+    // the kernels compiled for the mechanism (spec_load): a wavefront of 64 states per SIMD — one round of them takes the same time from one wavefront to a
+    // chip-full, and beats the walk kernel's rounds of half as many states from the second of those on.  Known here, before anything is compiled, so that a
+    // small batch never starts (or waits for) a compilation it would not use
+    w->spec_aba_min_batch = w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
+    if (const char* e = getenv("RBD_SPEC_ABA_MIN_BATCH")) w->spec_aba_min_batch = atol(e);
+    if (const char* e = getenv("RBD_SPEC_RNEA_MIN_BATCH")) w->spec_rnea_min_batch = atol(e);
   } else {
     w->state_min_batch = (long)1 << 62;
   }
@@ -952,7 +986,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_big_tbl, w->d_big_rb, w->d_big_scratch, w->d_fused_i, w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_big_L, w->d_big_tbl, w->d_big_rb, w->d_big_scratch, w->d_fused_i, w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -971,6 +1005,38 @@ int rbd_workspace_destroy(rbd_ws_t* w) {
 int rbd_workspace_set_stream(rbd_ws_t* w, void* stream) {
   if (!w) return RBD_ERR_INVALID_ARGUMENT;
   w->stream = (hipStream_t)stream;
+  return RBD_OK;
+}
+
+// stabilization_gains of the calls that follow (src/mechanism_algorithms.jl:614-632, :848): the four gains of every loop joint's record in THIS workspace's copy
+// of the loop tables are rewritten (the kernels that interpret the tables read them there; the kernel compiled against constant tables is handed the
+// pointer).  A call with the gains already in force returns without touching the device, so a host mirror may call it before every dynamics!.
+int rbd_workspace_set_loop_gains(rbd_ws_t* w, const double* gains) {
+  if (!w) return RBD_ERR_INVALID_ARGUMENT;
+  const rbd_model* m = w->model;
+  if (m->nloops == 0) return RBD_OK;  // nothing to stabilize (the reference ignores the keyword for tree mechanisms)
+  std::vector<double> want(4 * (size_t)m->nloops);
+  bool custom = false;
+  for (int l = 0; l < m->nloops; ++l)
+    for (int k = 0; k < 4; ++k) {
+      const double d = m->loop_r[64 * (size_t)l + 24 + k];
+      const double g = gains ? gains[4 * l + k] : d;
+      if (!(g == g) || g - g != 0.0) return RBD_ERR_INVALID_ARGUMENT;  // NaN / Inf gains
+      want[4 * (size_t)l + k] = g;
+      custom = custom || g != d;
+    }
+  if (w->loop_gains.empty() && !custom) return RBD_OK;  // still the model's
+  if (want == w->loop_gains) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipStreamSynchronize(w->stream));  // launches in flight read the records
+  const size_t es = w->dtype == RBD_F64 ? sizeof(double) : sizeof(float);
+  for (int l = 0; l < m->nloops; ++l) {
+    double g64[4]; float g32[4];
+    for (int k = 0; k < 4; ++k) { g64[k] = want[4 * (size_t)l + k]; g32[k] = (float)g64[k]; }
+    HIP_TRY(hipMemcpy((char*)w->d_loop_r + es * (64 * (size_t)l + 24), w->dtype == RBD_F64 ? (const void*)g64 : (const void*)g32, 4 * es, hipMemcpyHostToDevice));
+  }
+  w->loop_gains = want;
+  w->custom_gains = custom;
   return RBD_OK;
 }
 
@@ -1130,40 +1196,51 @@ static std::string walk_program_source(const rbd_model* m, int dtype, bool reroo
   if (!walk_tables(m, rerooted, &W)) return std::string();
   return walk_spec_source(W, dtype, kind, pair);
 }
-// aba_walk_kernel compiled for the mechanism (aba_walk_spec of rbd_walk.hpp): nullptr when unavailable
+static bool capturing(rbd_ws* w);
+// aba_walk_kernel compiled for the mechanism (aba_walk_spec of rbd_walk.hpp): nullptr when unavailable (or while it is being compiled)
 static hipFunction_t spec_walk(rbd_ws* w, bool rerooted, int kind = 0, int pair = 0) {
   const int k = (kind ? 4 : 0) + (rerooted ? 2 : 0) + (pair ? 1 : 0);
   if (w->spec_walk_tried[k]) return w->spec_walk[k];
-  w->spec_walk_tried[k] = true;
-  if (!jit_available()) return nullptr;
-  const std::string src = walk_program_source(w->model, w->dtype, rerooted, kind, pair);
-  if (src.empty()) return nullptr;
+  if (!jit_available()) { w->spec_walk_tried[k] = true; return nullptr; }
+  if (capturing(w)) return nullptr;
+  std::string& src = w->spec_walk_src[k];
+  if (src.empty()) src = walk_program_source(w->model, w->dtype, rerooted, kind, pair);
+  if (src.empty()) { w->spec_walk_tried[k] = true; return nullptr; }
   std::string log;
-  const std::vector<char> code = jit_walk_code_object(src, &log);
-  if (code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernel is used): " + log; return nullptr; }
+  std::vector<char> code;
+  const int js = jit_walk_code_object_get(src, !jit_async(), &code, &log);
+  if (js == JIT_PENDING) return nullptr;  // being compiled on a background thread: the interpreting walk kernel meanwhile
+  w->spec_walk_tried[k] = true;
+  if (js == JIT_FAILED || code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernel is used): " + log; src.clear(); src.shrink_to_fit(); return nullptr; }
   if (hipModuleLoadData(&w->spec_walk_mod[k], code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_walk_mod[k] = nullptr; jit_cache_discard(src); return nullptr; }
   const std::string fname = std::string(kind ? "rnea_walk_spec_" : "aba_walk_spec_") + walk_spec_suffix(w->dtype, pair);
   if (hipModuleGetFunction(&w->spec_walk[k], w->spec_walk_mod[k], fname.c_str()) != hipSuccess) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
   int scratch = 0;
   static const int max_scratch = getenv("RBD_SPEC_MAX_SCRATCH") ? atoi(getenv("RBD_SPEC_MAX_SCRATCH")) : 512;  // bytes per lane
   if (w->spec_walk[k] && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_walk[k]) != hipSuccess || scratch > max_scratch)) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
+  src.clear(); src.shrink_to_fit();
   return w->spec_walk[k];
 }
 // small loop mechanisms compiled for the mechanism (rbd_loop_small.hpp against constant tables): nullptr when unavailable
 static hipFunction_t spec_loop(rbd_ws* w) {
   if (w->spec_loop_tried) return w->spec_loop;
-  w->spec_loop_tried = true;
-  if (!jit_available()) return nullptr;
+  if (!jit_available()) { w->spec_loop_tried = true; return nullptr; }
+  if (capturing(w)) return nullptr;
   std::vector<int32_t> xi;
-  const std::string src = loop_program_source(w->model, w->dtype, &xi);
-  if (src.empty()) return nullptr;
+  std::string& src = w->spec_loop_src;
+  if (src.empty()) src = loop_program_source(w->model, w->dtype, &xi);
+  if (src.empty()) { w->spec_loop_tried = true; return nullptr; }
   std::string log;
-  const std::vector<char> code = jit_code_object(src, &log);
-  if (code.empty()) { g_last_hip_error = "run-time compilation failed (the generic loop kernels are used): " + log; return nullptr; }
+  std::vector<char> code;
+  const int js = jit_code_object_get(src, !jit_async(), &code, &log);
+  if (js == JIT_PENDING) return nullptr;  // the generic loop kernels meanwhile
+  w->spec_loop_tried = true;
+  if (js == JIT_FAILED || code.empty()) { g_last_hip_error = "run-time compilation failed (the generic loop kernels are used): " + log; return nullptr; }
   if (hipModuleLoadData(&w->spec_loop_mod, code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_loop_mod = nullptr; jit_cache_discard(src); return nullptr; }
   if (hipModuleGetFunction(&w->spec_loop, w->spec_loop_mod, w->dtype == RBD_F64 ? "loop_spec_f64" : "loop_spec_f32") != hipSuccess) { (void)hipGetLastError(); w->spec_loop = nullptr; }
   int scratch = 0;
   if (w->spec_loop && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_loop) != hipSuccess || scratch > 0)) { (void)hipGetLastError(); w->spec_loop = nullptr; }
+  src.clear(); src.shrink_to_fit();
   return w->spec_loop;
 }
 
@@ -1195,7 +1272,8 @@ int dynamics_loops_t(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const 
     int stab = o.stabilization;
     void* dM = w->d_M; void* dc = w->d_c; void* dK = w->d_K; void* dk = w->d_k; int* notpd = w->d_notpd;
     Layout a_Lq = Lq, a_Lm = Lm, a_Lv = Lv, a_Lf = Lf, a_Lc = Lc, a_Lk = Lk;
-    void* args[] = {&Bl, &stab, &dq, &dv, &dtau, &df, &dM, &dc, &dvd, &dqd, &dlam, &dK, &dk, &a_Lq, &a_Lm, &a_Lv, &a_Lf, &a_Lc, &a_Lk, &notpd};
+    const T* gains = w->custom_gains ? (const T*)w->d_loop_r + 24 : nullptr;  // (nullptr: the model's gains, constants of the compiled code)
+    void* args[] = {&Bl, &stab, &dq, &dv, &dtau, &df, &dM, &dc, &dvd, &dqd, &dlam, &dK, &dk, &a_Lq, &a_Lm, &a_Lv, &a_Lf, &a_Lc, &a_Lk, &notpd, &gains};
     HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
     w->last_kernel = "loop_spec (compiled for the mechanism at run time)";
     return RBD_OK;
@@ -1224,7 +1302,7 @@ int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const vo
 static int big_scratch(rbd_ws* w, int32_t B) { return ensure(&w->d_big_scratch, &w->d_big_scratch_bytes, esize(w) * big_scratch_elems(w->big, B)); }
 
 // inverse_dynamics! / dynamics_bias! (vdot == nullptr) through the lane mapping that fits the batch: same rule as run_aba
-static void spec_load(rbd_ws* w, int family);  // the kernels compiled for the mechanism (below)
+static void spec_load(rbd_ws* w, int family, bool force = false);  // the kernels compiled for the mechanism (below)
 
 static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const void* dv, const void* dvd, const void* df, void* dtau, void* dqd,
                     Layout Lq, Layout Lv, Layout Lf, void* dacc = nullptr, void* djw = nullptr) {
@@ -1244,7 +1322,7 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   // the kernel compiled for the mechanism: large batches (q̇ is not one of its outputs; with the per-body outputs it is ahead of the walk kernel in fp32 only — 119 vs 149 us at
   // 65 536 states, fp64: 146 vs 135 — so RBD_ALGO_ABA leaves that fp64 call with the walk kernel)
   if (!dqd && (mapping == RBD_ALGO_ABA_COMPILED || (mapping == RBD_ALGO_ABA && !((dacc || djw) && w->dtype == RBD_F64)))) {
-    spec_load(w, SPEC_RNEA);
+    if (mapping == RBD_ALGO_ABA_COMPILED || B >= w->spec_rnea_min_batch) spec_load(w, SPEC_RNEA, mapping == RBD_ALGO_ABA_COMPILED);
     if (w->spec_rnea && (mapping == RBD_ALGO_ABA_COMPILED || B >= w->spec_rnea_min_batch)) {
       long Bl = B;
       void* args[] = {&Bl, &dq, &dv, &dvd, &df, &dtau, &Lq, &Lv, &Lf, &dacc, &djw};
@@ -1304,7 +1382,7 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   if (algorithm == RBD_ALGO_ABA_CHAINS) return RBD_ERR_UNSUPPORTED;  // the chain mapping of round 1 lost at every batch size and was removed
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !fuse && w->dtype == RBD_F32) {
-    spec_load(w, SPEC_ABA);
+    if (algorithm == RBD_ALGO_ABA_COMPILED || B >= w->spec_aba_min_batch) spec_load(w, SPEC_ABA, algorithm == RBD_ALGO_ABA_COMPILED);
     if (w->spec_aba && (algorithm == RBD_ALGO_ABA_COMPILED || B >= w->spec_aba_min_batch)) {
       Timed t(w);
       long Bl = B;
@@ -1383,17 +1461,28 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
 // The run-time specialised form of the one-lane-per-state kernels (rbd_spec.hpp): compiled for this mechanism on the workspace's first use of
 // them (or loaded from the on-disk cache), nullptr when hiprtc is unavailable, RBD_JIT=0, or the compile failed — callers then keep the
 // interpreting kernels.  Its stores address M with a 32-bit lane offset: buffers of 4 GB and more stay with the interpreting kernel.
-static void spec_load(rbd_ws* w, int family) {
+// `force`: the caller asked for the compiled kernel by name (RBD_ALGO_ABA_COMPILED) — wait for the compiler.  Otherwise (RBD_JIT_ASYNC != 0, the default) a
+// program that is not in the cache is compiled on a background thread (rbd_jit.hip) while the calls keep their interpreting kernels, and the module is
+// loaded by the first call that finds it ready: the first dynamics! on a new mechanism returns in milliseconds, not after a minute of hiprtc.
+static bool capturing(rbd_ws* w) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(w->stream, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return cs != hipStreamCaptureStatusNone;
+}
+static void spec_load(rbd_ws* w, int family, bool force) {
   if (w->spec_tried[family]) return;
-  w->spec_tried[family] = true;
   const rbd_model* m = w->model;
-  if (!m->state.ok || !jit_available() || !spec_has(family, w->dtype, m->nb, m->nq, m->nv)) return;
+  if (!m->state.ok || !jit_available() || !spec_has(family, w->dtype, m->nb, m->nq, m->nv)) { w->spec_tried[family] = true; return; }
+  if (capturing(w)) return;  // a module cannot be loaded inside a stream capture: the interpreting kernels serve it, the next call outside tries again
   std::string log;
-  const std::string src = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype, family);
-  const std::vector<char> code = jit_code_object(src, &log);
-  if (code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernels are used): " + log; return; }
+  std::string& src = w->spec_src[family];
+  if (src.empty()) src = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype, family);
+  std::vector<char> code;
+  const int js = jit_code_object_get(src, force || !jit_async(), &code, &log);
+  if (js == JIT_PENDING) return;
+  w->spec_tried[family] = true;
+  if (js == JIT_FAILED || code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernels are used): " + log; src.clear(); src.shrink_to_fit(); return; }
   hipModule_t& mod = w->spec_mod[family];
-  // (a workspace whose first call of a route falls inside a stream capture cannot load a module there and keeps the interpreting kernels: call once before capturing)
   if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { (void)hipGetLastError(); mod = nullptr; jit_cache_discard(src); return; }
   auto get = [&](hipFunction_t* f, const char* name) { if (hipModuleGetFunction(f, mod, name) != hipSuccess) { (void)hipGetLastError(); *f = nullptr; } };
   // a kernel whose registers spilled beyond a few values is slower than the kernels that interpret the mechanism: it steps aside
@@ -1417,15 +1506,9 @@ static void spec_load(rbd_ws* w, int family) {
   } else if (family == SPEC_ABA) {
     get(&w->spec_aba, "aba_spec_f32");
     fits(&w->spec_aba);
-    // a wavefront of 64 states per SIMD: one round of them takes the same time from one wavefront to a chip-full, and beats the walk kernel's
-    // rounds of half as many states from the second of those on
-    w->spec_aba_min_batch = (long)ncu * 4 * 64 / 2 + 1;
-    if (const char* e = getenv("RBD_SPEC_ABA_MIN_BATCH")) w->spec_aba_min_batch = atol(e);
   } else if (family == SPEC_RNEA) {
     get(&w->spec_rnea, w->dtype == RBD_F64 ? "rnea_spec_f64" : "rnea_spec_f32");
     fits(&w->spec_rnea);
-    w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
-    if (const char* e = getenv("RBD_SPEC_RNEA_MIN_BATCH")) w->spec_rnea_min_batch = atol(e);
   }
 }
 static bool spec_crba_fits(const rbd_ws* w) { return (size_t)w->model->nq * 256 * esize(w) <= 160u * 1024u; }  // four wavefronts' staged q in one CU's LDS
@@ -1507,10 +1590,11 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
   const rbd_model* m = w->model;
   const size_t es = esize(w);
   int st;
-  if (m->big) {  // any-size fallback: M in place (dM is never null here), then one thread per state factors and solves
+  if (m->big) {  // any-size fallback: M into dM (never null here), then one thread per state factors a COPY (the reference's result.L, :763-764) and solves
     if ((st = run_crba(w, B, layout, dq, dM, Lq, Lm))) return st;
-    if (w->dtype == RBD_F64) HIP_TRY(launch_big_chol_solve<double>(m->nv, B, dM, dtau, dc, dx, Lm, Lv, w->d_notpd, w->stream));
-    else HIP_TRY(launch_big_chol_solve<float>(m->nv, B, dM, dtau, dc, dx, Lm, Lv, w->d_notpd, w->stream));
+    if ((st = ensure(&w->d_big_L, &w->d_big_L_bytes, es * (size_t)m->nv * m->nv * B))) return st;
+    if (w->dtype == RBD_F64) HIP_TRY(launch_big_chol_solve<double>(m->nv, B, dM, w->d_big_L, dtau, dc, dx, Lm, Lv, w->d_notpd, w->stream));
+    else HIP_TRY(launch_big_chol_solve<float>(m->nv, B, dM, w->d_big_L, dtau, dc, dx, Lm, Lv, w->d_notpd, w->stream));
     return RBD_OK;
   }
   const bool state = B >= w->state_min_batch;

@@ -179,6 +179,9 @@ template <typename T> struct LoopView {
   // loop_fused_small_kernel only: parent, q offset and DFS slot by reference body index, and the slot-ordered body constants (RB_*)
   const int32_t* xi;   // [nb*3]
   const T* rb;
+  // per-call Baumgarte gains (rbd_workspace_set_loop_gains): record l's four gains at gains[64 l + 0..3]; nullptr: the ones in lr (the model's).
+  // Only the kernels compiled against constant tables need it — the workspace's copy of lr is patched in place for the others.
+  const T* gains = nullptr;
 };
 
 // integrator scratch of mk_stage_kernel (same layout as the caller's q / v)

@@ -38,7 +38,14 @@ bool walk_spec_has(int dtype, int ns, int G, size_t lds_rows_bytes);
 size_t walk_spec_lds_bytes(const WalkTables& W, int dtype, int pair = 0);
 const char* walk_spec_suffix(int dtype, int pair);  // f64 | f32 | f32x2 (two fp32 states per lane)
 std::string walk_spec_source(const WalkTables& W, int dtype, int kind = 0, int pair = 0);  // kind 0: dynamics! (aba_walk_spec_<suffix>), 1: inverse_dynamics! / dynamics_bias! (rnea_walk_spec_<suffix>)
-// compiles it twice (see aba_walk_spec): empty when the register allocator used accumulation registers of its own
+// Code objects.  *_get: JIT_READY with the object (cache hit, or a compilation that has finished), JIT_PENDING when `wait` is false and the compilation has been
+// started on a background thread — ask again later —, JIT_FAILED with the compiler's log.  The plain forms wait.  jit_async(): RBD_JIT_ASYNC != 0 (default).
+enum { JIT_READY = 0, JIT_PENDING = 1, JIT_FAILED = 2 };
+bool jit_async();
+int jit_code_object_get(const std::string& source, bool wait, std::vector<char>* code, std::string* log);
+// the walk kernels' object: checked for accumulation registers of the allocator's own, then its kernel descriptor made to cover all 256 (see rbd_jit.hip)
+int jit_walk_code_object_get(const std::string& source, bool wait, std::vector<char>* code, std::string* log);
+int jit_kd_cover_agprs(std::vector<char>* code);
 std::vector<char> jit_walk_code_object(const std::string& source, std::string* log);
 std::vector<char> jit_code_object(const std::string& source, std::string* log);
 void jit_cache_discard(const std::string& source);

@@ -99,8 +99,9 @@ RBD_DEV void loop_solve_small_state(const VIEW& V, long st, int stabilize, const
       xmotion_inv(FaR, Fap, jt, jl);
       const T psi[3] = {(TnR[7] - TnR[5]) / 2, (TnR[2] - TnR[6]) / 2, (TnR[3] - TnR[1]) / 2};
       matTvec3(TnR, Tnp, Rtp);
+      const T* gl = V.gains ? V.gains + 64 * l : lr + 24;  // stabilization_gains of this call, else the model's (constants in the compiled form)
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { stab[i] = -lr[24] * psi[i] - lr[25] * jl[i]; stab[3 + i] = -lr[26] * Rtp[i] - lr[27] * jl[3 + i]; }
+      for (int i = 0; i < 3; ++i) { stab[i] = -gl[0] * psi[i] - gl[1] * jl[i]; stab[3 + i] = -gl[2] * Rtp[i] - gl[3] * jl[3 + i]; }
       xmotion(FaR, Fap, stab, sw);
 #pragma unroll
       for (int j = 0; j < 6; ++j) ba[j] -= sw[j];

@@ -1213,12 +1213,9 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
     }
   }
   __syncthreads();
-#ifndef RBD_WALK_PROBE
-  // the kernel descriptor covers every accumulation register (WalkStash addresses them by number).  rbd_jit.hip compiles the program twice: first
-  // with RBD_WALK_PROBE, without this line, to read from the code object's metadata that the register allocator took NO accumulation register of
-  // its own (the check scripts/check_walk_agprs.py makes on the assembly of the kernels built ahead of time); a program that does is not used.
-  asm volatile("" ::: "a255");
-#endif
+  // WalkStash addresses accumulation registers by number, which the compiler does not see: rbd_jit.hip checks in the code object's metadata that the register
+  // allocator took NONE of its own, then rewrites the kernel descriptor to cover all 256 (jit_kd_cover_agprs) — no `a255` clobber here, the compiler must not
+  // know (with it the metadata could no longer tell the allocator's registers from the stash's; round 3 compiled every program twice for that).
   const bool want_qdot = qdot != nullptr;
   walk_sfor<0, PLAN::G>([&](auto gi) __attribute__((always_inline)) {
     constexpr int GI = decltype(gi)::value;
@@ -1349,9 +1346,7 @@ RBD_DEV void rnea_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, 
     }
   }
   __syncthreads();
-#ifndef RBD_WALK_PROBE
-  asm volatile("" ::: "a255");  // (see aba_walk_spec)
-#endif
+  // (accumulation registers: see aba_walk_spec)
   const bool want_qdot = qdot != nullptr;
   walk_sfor<0, PLAN::G>([&](auto gi) __attribute__((always_inline)) {
     constexpr int GI = decltype(gi)::value;

@@ -239,6 +239,66 @@ def _check_result(result: DynamicsResult, state: MechanismState):
         state._check(result.constraintbias, f.nc, "constraintbias")
 
 
+class PDGains:
+    """`PDGains(k, d)` — src/pdcontrol.jl:17-26."""
+
+    def __init__(self, k: float, d: float):
+        self.k, self.d = float(k), float(d)
+
+
+class SE3PDGains:
+    """`SE3PDGains(angular::PDGains, linear::PDGains)` — src/pdcontrol.jl:35-44; the value type of `stabilization_gains`
+    (src/mechanism_algorithms.jl:614-626).  Scalar gains only (the reference also admits matrix gains in a frame; `default_constraint_stabilization_gains`
+    and every use in the reference's tests are scalar)."""
+
+    def __init__(self, angular: PDGains, linear: PDGains):
+        if not isinstance(angular, PDGains) or not isinstance(linear, PDGains):
+            raise ValueError("SE3PDGains(angular::PDGains, linear::PDGains)")
+        self.angular, self.linear = angular, linear
+
+    def as_tuple(self):
+        return (self.angular.k, self.angular.d, self.linear.k, self.linear.d)
+
+
+def default_constraint_stabilization_gains():
+    """`default_constraint_stabilization_gains(T)` (src/mechanism_algorithms.jl:610-612): critical damping, T_stab = 0.1."""
+    return SE3PDGains(PDGains(100.0, 20.0), PDGains(100.0, 20.0))
+
+
+def _set_stabilization_gains(state: "MechanismState", stabilization_gains) -> int:
+    """The `stabilization_gains` keyword of `dynamics!` / `simulate` (src/mechanism_algorithms.jl:614-632, :848; src/simulate.jl:37) → the flag of
+    rbd_opts_t plus rbd_workspace_set_loop_gains.  Accepted, as in the reference: `None` (no stabilization); "default" (the model's gains — the
+    reference's default_constraint_stabilization_gains unless the flat model says otherwise); one `SE3PDGains` for every loop joint (the ConstDict
+    case); a dict from loop joint (name, or index in the model's loop-joint order) to `SE3PDGains` — every loop joint must have an entry, as
+    `stabilization_gains[nontreejointid]` (:655) would throw a KeyError otherwise.  Anything else raises ValueError (Julia: a MethodError / ArgumentError)."""
+    f = state.flat
+    if stabilization_gains is None:
+        return 0
+    n = getattr(f, "n_loops", 0)
+    if isinstance(stabilization_gains, str):
+        if stabilization_gains != "default":
+            raise ValueError(f"stabilization_gains: {stabilization_gains!r} (expected None, 'default', an SE3PDGains or a dict of them)")
+        arr = None
+    elif isinstance(stabilization_gains, SE3PDGains):
+        arr = list(stabilization_gains.as_tuple()) * n
+    elif isinstance(stabilization_gains, dict):
+        arr = []
+        for i, l in enumerate(f.loops):
+            key = l.get("name") if l.get("name") in stabilization_gains else i
+            if key not in stabilization_gains:
+                raise KeyError(f"stabilization_gains has no entry for loop joint {l.get('name', i)!r}")
+            g = stabilization_gains[key]
+            if not isinstance(g, SE3PDGains):
+                raise ValueError("stabilization_gains values must be SE3PDGains")
+            arr += list(g.as_tuple())
+    else:
+        raise ValueError(f"stabilization_gains: unsupported {type(stabilization_gains).__name__} (expected None, 'default', an SE3PDGains or a dict of them)")
+    if n:
+        buf = None if arr is None else (ctypes.c_double * len(arr))(*arr)
+        _raise(_capi.lib().rbd_workspace_set_loop_gains(state.ws.handle, buf), "rbd_workspace_set_loop_gains")
+    return 1
+
+
 def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[torch.Tensor] = None,
               externalwrenches: Optional[torch.Tensor] = None, stabilization_gains="default", algorithm: str = "aba"):
     """`dynamics!(result, state, torques, externalwrenches; stabilization_gains)` (src/mechanism_algorithms.jl:845-864):
@@ -254,7 +314,7 @@ def dynamics_(result: DynamicsResult, state: MechanismState, torques: Optional[t
     algo = {"aba": _capi.ALGO_ABA, "crba": _capi.ALGO_CRBA_CHOLESKY, "aba_lanes": _capi.ALGO_ABA_LANES,
             "aba_chains": _capi.ALGO_ABA_CHAINS, "aba_banks": _capi.ALGO_ABA_BANKS, "aba_tracks": _capi.ALGO_ABA_TRACKS, "aba_walk": _capi.ALGO_ABA_WALK, "aba_pipe": _capi.ALGO_ABA_PIPE,
             "aba_compiled": _capi.ALGO_ABA_COMPILED}[algorithm]
-    opts = state._opts(algo, 0 if stabilization_gains is None else 1)
+    opts = state._opts(algo, _set_stabilization_gains(state, stabilization_gains))
     lam = result.lambda_ if f.nc > 0 else None
     if getattr(f, "ns", 0) > 0:
         # a mechanism with contact points: contact_dynamics! first, totalwrenches = externalwrenches + contactwrenches (:849-856); state.s is
@@ -431,7 +491,7 @@ def simulate_(state: MechanismState, final_time: float, control_=None, dt: float
     state._check(torques, f.nv, "torques")
     state._check(externalwrenches, 6 * f.n_bodies, "externalwrenches")
     state.ws.use_current_stream()
-    opts = state._opts(_capi.ALGO_ABA, 0 if stabilization_gains is None else 1)
+    opts = state._opts(_capi.ALGO_ABA, _set_stabilization_gains(state, stabilization_gains))
     L = _capi.lib()
     ts, t = [0.0], 0.0
     qs, vs = ([state.q.clone()], [state.v.clone()]) if store else (None, None)
@@ -602,6 +662,18 @@ def jit_precompile(flat, dtype=torch.float32):
         log = ctypes.create_string_buffer(1 << 16)
         st = L.rbd_jit_precompile(h, _capi.F64 if dtype == torch.float64 else _capi.F32, log, len(log))
         return (None if st == 3 else st == 0), log.value.decode(errors="replace")
+    finally:
+        L.rbd_model_destroy(h)
+
+
+def jit_status(flat, dtype=torch.float32, family: int = 0) -> int:
+    """`rbd_jit_status`: 1 = the program's code object is ready, 0 = being compiled on a background thread (started by this call if nobody had),
+    -1 = no such program for this mechanism / no hiprtc / the compilation failed.  Never waits; no device needed."""
+    L = _capi.lib()
+    h = ctypes.c_void_p()
+    _raise(L.rbd_model_create(ctypes.cast(ctypes.byref(flat.c_struct()), ctypes.c_void_p), ctypes.byref(h)), "rbd_model_create")
+    try:
+        return int(L.rbd_jit_status(h, _capi.F64 if dtype == torch.float64 else _capi.F32, int(family)))
     finally:
         L.rbd_model_destroy(h)
 

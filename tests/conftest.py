@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 MODELS = os.path.join(ROOT, "tests", "golden", "models")
+# the kernels compiled per mechanism: the first call WAITS for hiprtc here, so that a test of a compiled kernel never silently runs the interpreting one
+# (the default — compile in the background, interpreting kernels meanwhile — has its own tests: test_jit_cpu.py, test_state_kernels.py)
+os.environ.setdefault("RBD_JIT_ASYNC", "0")
 
 
 def pytest_configure(config):

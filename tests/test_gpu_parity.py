@@ -912,6 +912,88 @@ def test_geometric_jacobian_f64(rbd, oracle, models, name, layout):
         rbd.geometric_jacobian_(J, state, 0, model.n_bodies)
 
 
+def _with_gains(model, gains):
+    """a copy of the flat model whose loop joints carry `gains` (one 4-tuple per loop joint) — what the oracle reads"""
+    import copy
+    m = copy.copy(model)
+    m.loops = [dict(l, gains=tuple(g)) for l, g in zip(model.loops, gains)]
+    m._c = None
+    return m
+
+
+@pytest.mark.parametrize("kernels", ["compiled", "fused", "three_launches"])
+def test_four_bar_custom_stabilization_gains(rbd, oracle, models, kernels, monkeypatch):
+    """`stabilization_gains` as a per-call argument (src/mechanism_algorithms.jl:614-632, :848): non-default Baumgarte gains — one SE3PDGains for every
+    loop joint (the ConstDict case) and a dict keyed by loop joint — through each of the three kernel forms of the small-loop branch, against the oracle
+    evaluating a model that carries those gains; then back to the defaults on the same workspace.  Anything that is not a gains object raises."""
+    monkeypatch.setenv("RBD_JIT", "1" if kernels == "compiled" else "0")
+    if kernels == "three_launches":
+        monkeypatch.setenv("RBD_LOOP_NO_FUSED", "1")
+    model = models["four_bar"]
+    B = 512
+    q, v, tau = four_bar_inputs(rbd, B, 77)
+    state = rbd.MechanismState(model, B)
+    result = rbd.DynamicsResult(model, B)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    custom = (400.0, 40.0, 250.0, 10.0)
+    g = rbd.SE3PDGains(rbd.PDGains(custom[0], custom[1]), rbd.PDGains(custom[2], custom[3]))
+    name = model.loops[0]["name"]
+    refs = {}
+    for label, arg, gains in (("default", "default", model.loops[0]["gains"]), ("const", g, custom), ("dict", {name: g}, custom), ("index", {0: g}, custom),
+                              ("default again", "default", model.loops[0]["gains"]), ("default object", rbd.default_constraint_stabilization_gains(), (100.0, 20.0, 100.0, 20.0))):
+        result.vd.fill_(float("nan"))
+        rbd.dynamics_(result, state, dev(tau, state), stabilization_gains=arg)
+        assert rbd.sync(state) == 0
+        ref = oracle.dynamics_loops(_with_gains(model, [gains]), q, v, tau, stabilize=True)
+        refs[label] = ref["vdot"]
+        assert np.abs(host(result.vd, state) - ref["vdot"]).max() <= 1e-10 * max(1.0, np.abs(ref["vdot"]).max()), label
+        assert np.abs(host(result.constraintbias, state) - ref["k"]).max() <= 1e-10 * max(1.0, np.abs(ref["k"]).max()), label
+    assert np.abs(refs["const"] - refs["default"]).max() > 1e-3  # the gains matter on these states (joint 1 is off the closure)
+    for bad in (3.0, (100.0, 20.0, 100.0, 20.0), "none", {name: (1.0, 2.0, 3.0, 4.0)}):
+        with pytest.raises(ValueError):
+            rbd.dynamics_(result, state, dev(tau, state), stabilization_gains=bad)
+    with pytest.raises(KeyError):
+        rbd.dynamics_(result, state, dev(tau, state), stabilization_gains={"no such joint": g})
+    # simulate takes the same keyword (src/simulate.jl:37): two steps with the custom gains against the oracle's integrator on a model carrying them
+    import simulate_np
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    rbd.simulate_(state, 1.5e-3, dt=1e-3, stabilization_gains=g)
+    _, q_ref, v_ref = simulate_np.simulate(_with_gains(model, [custom]), q[:4], v[:4], 1.5e-3, 1e-3, stabilize=True)
+    assert np.abs(host(state.q, state)[:4] - q_ref).max() <= 1e-10 and np.abs(host(state.v, state)[:4] - v_ref).max() <= 1e-9
+
+
+def test_maximal_coordinates_per_joint_gains(rbd, oracle):
+    """Per-joint gains on a mechanism with several loop joints (the generic loop kernels): every loop joint its own SE3PDGains, states pushed off the
+    constraint manifold so that the stabilization term is not zero."""
+    from test_oracle_loops import MC_JOINTS, maximal_state
+    rng = np.random.default_rng(54)
+    tree = rbd.rand_tree_mechanism(rng, MC_JOINTS)
+    mt, mc = rbd.flatten(tree), rbd.flatten(rbd.maximal_coordinates(tree))
+    B = 9
+    q, v = rbd.rand_configuration(mt, B, rng), rbd.rand_velocity(mt, B, rng)
+    H, T, _ = oracle.body_kinematics(mt, q, v, np.zeros((B, mt.nv)))
+    qm, vm = maximal_state(H, T)
+    qm = qm + 1e-3 * rng.standard_normal(qm.shape)   # off the manifold (the oracle and the GPU normalize nothing: same q on both sides)
+    vm = vm + 1e-3 * rng.standard_normal(vm.shape)
+    gains = [tuple(rng.uniform(10.0, 300.0, 4)) for _ in mc.loops]
+    arg = {l["name"]: rbd.SE3PDGains(rbd.PDGains(g[0], g[1]), rbd.PDGains(g[2], g[3])) for l, g in zip(mc.loops, gains)}
+    state = rbd.MechanismState(mc, B)
+    result = rbd.DynamicsResult(mc, B)
+    rbd.set_configuration_(state, qm)
+    rbd.set_velocity_(state, vm)
+    out = {}
+    for label, a, gg in (("custom", arg, gains), ("default", "default", [l["gains"] for l in mc.loops])):
+        rbd.dynamics_(result, state, stabilization_gains=a)
+        assert rbd.sync(state) == 0
+        ref = oracle.dynamics_loops(_with_gains(mc, gg), qm, vm)
+        out[label] = ref["k"]
+        assert np.abs(host(result.constraintbias, state) - ref["k"]).max() <= 1e-9 * max(1.0, np.abs(ref["k"]).max()), label
+        assert np.abs(host(result.vd, state) - ref["vdot"]).max() <= 1e-8 * max(1.0, np.abs(ref["vdot"]).max()), label
+    assert np.abs(out["custom"] - out["default"]).max() > 1e-3
+
+
 @pytest.mark.gpu
 def test_maximal_coordinates_loop_dynamics(rbd, oracle):
     """A mechanism in maximal coordinates (test/test_mechanism_modification.jl:274-318): 8 floating bodies, 8 loop joints of every
@@ -992,9 +1074,18 @@ def test_trees_of_more_than_64_bodies(rbd, oracle, dtype):
             cond = np.linalg.cond(Ms).max()
             assert rel(got, ref) <= 1e-14 * cond, (rel(got, ref), cond)
             x = torch.zeros_like(state.v)
-            rbd.mass_matrix_solve_(x, state, dev(vd, state))
+            Mo = torch.full_like(result.massmatrix, float("nan"))
+            rbd.mass_matrix_solve_(x, state, dev(vd, state), M_out=Mo)
             xr = np.linalg.solve(Ms, vd[..., None])[..., 0]
             assert rel(host(x, state), xr) <= 1e-14 * cond
+            # M_out and result.massmatrix hold M after the solve, not its Cholesky factor: the reference factors a copy (result.L, :763-764)
+            low = lambda t: np.tril(host(t, state).reshape(B, model.nv, model.nv).transpose(0, 2, 1))
+            assert rel(low(Mo), np.tril(Mref)) <= rt
+            result.massmatrix.fill_(float("nan"))
+            rbd.dynamics_(result, state, dev(vd, state), dev(fe, state), algorithm="crba")
+            assert rbd.sync(state) == 0
+            assert rel(low(result.massmatrix), np.tril(Mref)) <= rt and rel(host(result.vd, state), ref) <= 1e-14 * cond
+            assert rel(host(result.dynamicsbias, state), oracle.dynamics_bias(model, q, v, fe)) <= rt
         with pytest.raises(Exception):
             rbd.kinetic_energy(state)  # a by-product outside the four hot-path functions: RBD_ERR_UNSUPPORTED for such a model, not a wrong answer
 

@@ -120,13 +120,49 @@ def test_precompile_without_a_device(rbd, tmp_path, monkeypatch):
         pytest.skip("libhiprtc not available")
     assert ok, log
     files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".hsaco"))
-    # fp64: the mass-matrix and the inverse-dynamics programs, and the two walk kernels' (each compiled twice: once to read the allocator's register use, csrc/rbd_jit.hip)
-    assert len(files) == 6 and all(os.path.getsize(tmp_path / f) > 1000 for f in files)
+    # fp64: the mass-matrix and the inverse-dynamics programs, and the two walk kernels' (each compiled ONCE since round 4: the allocator's register use is read from
+    # the object's metadata and its kernel descriptor rewritten to cover the accumulation registers, csrc/rbd_jit.hip jit_kd_cover_agprs)
+    assert len(files) == 4 and all(os.path.getsize(tmp_path / f) > 1000 for f in files)
+    assert "ready after" in log and log.count("[rbd_jit] family") == 4  # the log lists every program with the seconds it took
     stamps = [os.path.getmtime(tmp_path / f) for f in files]
     ok, _ = rbd.jit_precompile(model, torch.float64)
     assert ok and [os.path.getmtime(tmp_path / f) for f in files] == stamps
     monkeypatch.setenv("RBD_JIT", "0")
     assert rbd.jit_precompile(model, torch.float64)[0] is None
+
+
+def test_compilation_in_the_background(rbd, tmp_path, monkeypatch):
+    """A program that is not in the cache is compiled on a background thread: rbd_jit_status — the query the hot-path calls make before they pick a kernel
+    (spec_load / spec_walk / spec_loop in csrc/rbd_capi.hip) — returns at once with 0 while hiprtc runs, and 1 once the code object is there; the object
+    is in the cache afterwards, so a second process finds it ready.  No device needed."""
+    import time
+    monkeypatch.setenv("RBD_JIT_CACHE", str(tmp_path / "cache"))  # (a missing directory is created, 0700)
+    model = rbd.flatten(rbd.builders.four_bar_linkage())
+    if rbd.jit_precompile(rbd.flatten(rbd.builders.double_pendulum()), torch.float32)[0] is None:
+        pytest.skip("libhiprtc not available")
+    LOOP = 3  # family 3: the whole loop branch of a small loop mechanism
+    assert rbd.jit_status(model, torch.float32, 0) == -1  # no one-lane-per-state programs for a mechanism with loop joints
+    t0 = time.time()
+    first = rbd.jit_status(model, torch.float64, LOOP)
+    dt_first = time.time() - t0
+    assert first == 0 and dt_first < 0.5, (first, dt_first)  # started, not waited for (the compilation takes 1.5-3 s)
+    assert rbd.jit_status(model, torch.float64, LOOP) in (0, 1)  # asking again does not start a second compilation: still one object at the end
+    deadline = time.time() + 120
+    while rbd.jit_status(model, torch.float64, LOOP) == 0:
+        assert time.time() < deadline, "background compilation never finished"
+        time.sleep(0.05)
+    assert rbd.jit_status(model, torch.float64, LOOP) == 1
+    cache = tmp_path / "cache"
+    files = [f for f in os.listdir(cache) if f.endswith(".hsaco")]
+    assert len([f for f in files if os.path.getsize(cache / f) > 1000]) >= 1 and not [f for f in os.listdir(cache) if ".tmp" in f]
+    assert (os.stat(cache).st_mode & 0o077) == 0
+    # a cache directory somebody else could write to is not used (a code object is loaded by name alone): caching is off, compilation still works
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    monkeypatch.setenv("RBD_JIT_CACHE", str(shared))
+    ok, _ = rbd.jit_precompile(rbd.flatten(rbd.builders.double_pendulum()), torch.float32)
+    assert ok and not os.listdir(shared)
 
 
 @pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating", "atlas_fixed"])
