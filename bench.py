@@ -15,6 +15,9 @@ with its loop joint, 4096 states fp64).
 N > 1: `python bench.py --gpus N` re-executes itself under torch.distributed.run (one process per GPU, RCCL); launched by the driver
 under torch.distributed.run it reads RANK / WORLD_SIZE from the environment.  The batch is sharded (weak scaling: the per-GPU batch is
 fixed), no data-path collective; `n_gpus` is the world size RCCL reports.  It refuses to run when fewer GPUs are visible than asked for.
+With N > 1 and no `--config`, the line's `value` is the SHARDED config — BASELINE configs[3], 65 536 fp32 states per GPU, the one the north star
+shards over 8 GPUs — not the 22 µs launches of configs[1]; `per_rank` lists every rank's own rate (there is no data-path collective, so a rank's rate
+IS the one-GPU rate of the same run), and the N = 1 point of the same workload is the `config4_shard` block of the one-GPU line.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM with the ALGORITHMIC bytes (sizeof(T)·(nq + 3·nv)
 per evaluation + q̇, SURVEY.md §8 d); `alu` gives the binding roof (vector ALU).  The result of the timed launches is compared with
@@ -78,7 +81,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config (2 = the headline, configs[1])")
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="BASELINE.json config (default: 2 = the headline, configs[1], on one GPU; 4 = the sharded configs[3] with --gpus N > 1)")
+    ap.add_argument("--op", default=None, choices=["dynamics", "inverse_dynamics", "mass_matrix_solve"],
+                    help="the entry point timed (default: the config's; --config 2 --op inverse_dynamics = the RNEA half of configs[1] as its own line)")
+    ap.add_argument("--no-emit-M", action="store_true", help="config 3: M_out = NULL (x only) as the timed leg")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="ONE timed leg only (no with-wrenches / graph-replay / M_out = NULL / pipelined legs): what a profiler run wants — every launch it sees is the leg")
     ap.add_argument("--batch", type=int, default=None, help="states per GPU (default: the config's)")
     ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
     ap.add_argument("--model", default=None)
@@ -86,7 +95,7 @@ def parse_args():
     ap.add_argument("--graph", action="store_true", help="capture the K steps in one hipGraph")
     ap.add_argument("--gather-every-step", action="store_true", help="RCCL all-gather of v̇ inside every timed step (config 4 reports both anyway)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--algorithm", default="aba", choices=["aba", "aba_walk", "aba_lanes", "aba_banks", "aba_tracks", "aba_pipe"],
+    ap.add_argument("--algorithm", default="aba", choices=["aba", "aba_walk", "aba_lanes", "aba_banks"],
                     help="lane mapping of the fused ABA: aba = the library's choice by batch size")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra (informational) measurement of two independent batches issued on two HIP streams")
@@ -94,12 +103,18 @@ def parse_args():
     ap.add_argument("--no-other-configs", action="store_true", help="headline only: skip the config3 / config4_shard / config5 / inverse_dynamics blocks")
     ap.add_argument("--selftest-launch", action="store_true", help="only exercise the N-rank launcher (gloo on CPU): prints the world size the ranks saw")
     args = ap.parse_args()
+    world = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
+    args.config_given = args.config is not None
+    if args.config is None:
+        args.config = 4 if world > 1 and not args.selftest_launch else 2
     cfg = CONFIGS[args.config]
     args.model = args.model or cfg["model"]
     args.batch = args.batch or cfg["batch"]
     args.dtype = args.dtype or cfg["dtype"]
-    args.op = cfg["op"]
-    args.no_extra_legs = False
+    args.op = args.op or cfg["op"]
+    if args.no_extra_legs:
+        args.no_pipelined = True
+    args.solve_only_leg = not args.no_extra_legs
     if args.steps is None:
         args.steps = 2000 if args.batch <= 8192 else 200
     if args.warmup is None:
@@ -202,7 +217,7 @@ def run(args, env):
 
     # low-overhead launch: pre-marshalled ctypes call straight into the C ABI
     L = _capi.lib()
-    algo_id = {"aba": 0, "aba_lanes": 2, "aba_banks": 4, "aba_tracks": 5, "aba_walk": 6, "aba_pipe": 7}[args.algorithm]  # tracks / pipe: RBD_EXPERIMENTAL builds only
+    algo_id = {"aba": 0, "aba_lanes": 2, "aba_banks": 4, "aba_walk": 6}[args.algorithm]
     stream = torch.cuda.current_stream(device)
     L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(stream.cuda_stream))
     vp = ctypes.c_void_p
@@ -266,6 +281,7 @@ def run(args, env):
         if dist is not None:
             dist.barrier()
         wall = time.perf_counter() - t0
+        timed.own_ms = ev0.elapsed_time(ev1)  # this rank's own K steps (device time), before the max over ranks
         if dist is not None:
             tw = torch.tensor([wall], dtype=torch.float64, device=device)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -273,8 +289,14 @@ def run(args, env):
         return wall, ev0.elapsed_time(ev1) / args.steps
 
     headline_fext = bool(args.wrenches)
-    step = make_step(headline_fext)
+    step = make_step(headline_fext, emit_M=not args.no_emit_M)
     wall, kernel_ms = timed(step, args.gather_every_step and world > 1)
+    per_rank = None
+    if dist is not None:  # every rank's own rate over the same K steps (no data-path collective: this IS the one-GPU rate of this run)
+        mine = torch.tensor([B * args.steps / (timed.own_ms * 1e-3)], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(t.item()) for t in allr]
 
     # ---- parity of the timed work against the oracle over the WHOLE batch (outside the timed region) ----
     qf, vf, tf = [a.astype(ndt).astype(np.float64) for a in (q, v, tau)]
@@ -290,7 +312,7 @@ def run(args, env):
         got_M = got_M[:n].double().cpu().numpy().reshape(n, model.nv, model.nv).transpose(0, 2, 1)
         got_x = (x_out if args.layout == "aos" else x_out.t())[:n].double().cpu().numpy()
         il = np.tril_indices(model.nv)
-        err_M = float(np.abs(got_M[:, il[0], il[1]] - Mref[:, il[0], il[1]]).max() / np.abs(Mref).max())
+        err_M = 0.0 if args.no_emit_M else float(np.abs(got_M[:, il[0], il[1]] - Mref[:, il[0], il[1]]).max() / np.abs(Mref).max())
         res = np.einsum("bij,bj->bi", Mref, got_x) - tf[:n]
         # normwise backward error of the solve (Rigal–Gaches): ||M x − r|| / (||M|| ||x|| + ||r||) with the ORACLE's M
         berr = float((np.linalg.norm(res, axis=1) / (np.linalg.norm(Mref, axis=(1, 2)) * np.linalg.norm(got_x, axis=1) + np.linalg.norm(tf[:n], axis=1))).max())
@@ -305,7 +327,7 @@ def run(args, env):
         check = {"states_compared": B}
         tol = 1e-10 if args.dtype == "f64" else 2e-4
     elif model.nc > 0:
-        n = min(B, 1024)  # the loop-joint oracle is one state per call
+        n = B  # the whole batch (the loop-joint oracle is one state per call: ~1 s for 4096 four-bar states)
         ref = oracle.dynamics_loops(model, qf[:n], vf[:n], tf[:n], ff[:n] if ff is not None else None)["vdot"]
         got = (result.vd if args.layout == "aos" else result.vd.t())[:n].double().cpu().numpy()
         err = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
@@ -354,7 +376,7 @@ def run(args, env):
                 "value": B * args.steps / w2, "unit": "evals/s", "ms_per_step": w2 / args.steps * 1e3, "kernel_ms": k2}
         except Exception as e:
             extra["with_external_wrenches"] = f"failed: {type(e).__name__}: {e}"
-    if args.op == "mass_matrix_solve" and world == 1:
+    if args.op == "mass_matrix_solve" and world == 1 and args.solve_only_leg and not args.no_emit_M:
         # the same solve for a caller that does not want M back (M_out = NULL): the whole-square store of M is most of the route's traffic
         try:
             w4, k4 = timed(make_step(False, emit_M=False), False)
@@ -396,16 +418,18 @@ def run(args, env):
     peak_tf = FP64_VECTOR_PEAK_TF if args.dtype == "f64" else FP32_VECTOR_PEAK_TF
     achieved_tf = flops * B / (kernel_ms * 1e-3) / 1e12
 
-    # HBM traffic from the PMC passes (scripts/gpu_profile.sh writes it with the hash of the kernel sources it was measured on):
-    # a figure from other sources is not passed along
+    # HBM traffic per launch from the PMC passes of scripts/gpu_measure.sh (one rocprofv3 run PER LEG since round 4: `--no-extra-legs`), recorded with the hash
+    # of the kernel sources it was measured on: a figure from other sources is flagged stale, never passed along as current
     traffic, traffic_stale = None, None
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             traffic_stale = rec.get("source_hash") != kernel_source_hash()
-            if not traffic_stale:
-                traffic = rec.get(f"{args.model}_{args.dtype}_B{B}_{args.op}")
+            key = f"{args.model}_{args.dtype}_B{B}_{args.op}" + ("_noM" if args.no_emit_M else "")
+            traffic = rec.get(key)
+            if traffic_stale and traffic is not None:
+                traffic = dict(traffic, stale=True) if isinstance(traffic, dict) else {"bytes_per_launch": traffic, "stale": True}
         except Exception:
             traffic = None
 
@@ -430,6 +454,8 @@ def run(args, env):
                                 "source": "docs/src/benchmarks.md:71-78"},
     }
     out.update(extra)
+    if per_rank is not None:
+        out["per_rank"] = {"value": per_rank, "unit": "evals/s", "note": "each rank's own K steps by HIP events; value = all ranks' states / the slowest rank's wall time"}
     if gather_ms is not None:
         out["rccl_all_gather_vdot_ms"] = gather_ms
 
@@ -512,7 +538,8 @@ def sub_args(args, config, **over):
     a.config, a.model, a.batch, a.dtype, a.op = config, cfg["model"], cfg["batch"], cfg["dtype"], cfg["op"]
     a.steps, a.warmup = (200, 20) if a.batch <= 8192 else (40, 8)
     a.no_cpu_baseline = a.no_pipelined = a.no_extra_legs = True
-    a.wrenches = a.graph = False
+    a.wrenches = a.graph = a.no_emit_M = False
+    a.solve_only_leg = True
     a.algorithm = "aba"
     for k, v in over.items():
         setattr(a, k, v)
@@ -537,15 +564,14 @@ def main():
         return selftest_launch(args)
     env = setup(args)
     out = run(args, env)
-    headline = args.config == 2 and not args.no_other_configs and args.batch == CONFIGS[2]["batch"] and args.dtype == CONFIGS[2]["dtype"]
+    headline = (args.config == 2 and not args.no_other_configs and args.batch == CONFIGS[2]["batch"] and args.dtype == CONFIGS[2]["dtype"] and args.op == "dynamics"
+                and not args.no_extra_legs and env["world"] == 1)
     if headline:
-        # The other BASELINE configs ride on the driver's line (round-2 review): each with its own ms_per_step, roofline and whole-batch parity;
-        # `value` stays configs[1].  N > 1: only configs[3] (the sharded one) — with the RCCL gather outside and inside the timed region.
+        # The other BASELINE configs ride on the driver's one-GPU line (round-2 review): each with its own ms_per_step, roofline and whole-batch parity;
+        # `value` stays configs[1].  (N > 1: the line IS configs[3], the sharded one — see the module docstring.)
         extra = {}
-        todo = [("config4_shard", sub_args(args, 4))]
-        if env["world"] == 1:
-            todo = [("inverse_dynamics", sub_args(args, 2, op="inverse_dynamics")), ("config3", sub_args(args, 3)), ("config4_shard", sub_args(args, 4)),
-                    ("config5", sub_args(args, 5))]
+        todo = [("inverse_dynamics", sub_args(args, 2, op="inverse_dynamics")), ("config3", sub_args(args, 3)), ("config4_shard", sub_args(args, 4)),
+                ("config5", sub_args(args, 5))]
         for name, a in todo:
             try:
                 extra[name] = block(run(a, env))

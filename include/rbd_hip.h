@@ -81,14 +81,14 @@ enum {
                                 size; the value stays reserved and returns RBD_ERR_UNSUPPORTED)                                     */
   RBD_ALGO_ABA_BANKS = 4,    /* lane-per-body with two bodies per lane (levels split into two banks): twice the states per
                                 wavefront; 1-dof / fixed tree joints, 6-dof joints on the world.  The bench workload (4096 Atlas states) */
-  RBD_ALGO_ABA_TRACKS = 5,   /* EXPERIMENTAL build only (csrc/build.sh RBD_EXPERIMENTAL=1; rbd_experimental() == 1): chains of the tree on a
-                                few lanes per state, per-body results in lane-private LDS rows.  RBD_ERR_UNSUPPORTED otherwise        */
+  RBD_ALGO_ABA_TRACKS = 5,   /* (round 2: chains of the tree on a few lanes per state, per-body results in lane-private LDS rows.  Removed in
+                                round 4 like RBD_ALGO_ABA_PIPE — both lost at every batch size; reserved, RBD_ERR_UNSUPPORTED)          */
   RBD_ALGO_ABA_WALK = 6,     /* the track schedule with one WAVEFRONT per track and one lane per state: a workgroup is up to four
                                 wavefronts over the same 64 states, q / v / tau staged through LDS, per-joint results in accumulation
                                 registers.  Trees of revolute / prismatic / fixed joints, 6-dof joints on the world, at most 11 steps per
                                 track; RBD_ERR_UNSUPPORTED elsewhere or when the rows of 64 states do not fit one compute unit's LDS.
                                 Large batches                                                                                       */
-  RBD_ALGO_ABA_PIPE = 7,     /* EXPERIMENTAL build only: a body-step cut into stages on the four SIMDs of a compute unit            */
+  RBD_ALGO_ABA_PIPE = 7,     /* (round 2: a body-step cut into stages on the four SIMDs of a compute unit.  Removed; reserved)     */
   RBD_ALGO_ABA_COMPILED = 8  /* one lane per state, straight-line code compiled for the mechanism at run time (rbd_jit_* below): fp32,
                                 trees the one-lane-per-state kernels take; RBD_ALGO_ABA picks it from half a chip-full of wavefronts up.
                                 RBD_ERR_UNSUPPORTED without hiprtc or outside that scope                                            */
@@ -185,7 +185,7 @@ int rbd_model_destroy(rbd_model_t* model);
  * the banked ABA (not only the banked RNEA) takes the mechanism.  RBD_ERR_UNSUPPORTED when the split would not save lanes. */
 int rbd_model_bank_plan(const rbd_model_t* model, int32_t* lanes, int32_t* first_level_of_bank1, int32_t* bodies_bank0, int32_t* bodies_bank1,
                         int32_t* aba_in_scope);
-/* ... and of the track mapping (RBD_ALGO_ABA_TRACKS): dims[6] = tracks per state, steps, A/C mailboxes, B mailboxes, has a 6-dof root,
+/* ... and of the track plan under the walk kernels (RBD_ALGO_ABA_WALK): dims[6] = tracks per state, steps, A/C mailboxes, B mailboxes, has a 6-dof root,
  * has prismatic/fixed joints; table: steps×tracks reference body indices (-1 = idle); ri / rr: the packed per-(step, track) records
  * the kernel reads (rbd_device.hpp TI_*, TR_*) — what tests/emu feeds to the CPU emulation of the kernel's step code.        */
 int rbd_model_track_plan(const rbd_model_t* model, int32_t* dims, int32_t* table, int32_t table_cap, int32_t* ri, int32_t ri_cap, double* rr, int32_t rr_cap);
@@ -370,8 +370,6 @@ const char* rbd_workspace_last_kernel(const rbd_ws_t* ws);
  * not call a newer library (the Python and Julia loaders compare this with the value they were written for).  400: rbd_workspace_set_loop_gains. */
 #define RBD_HIP_H_VERSION 400
 int rbd_version(void);
-/* 1 when the library was built with RBD_EXPERIMENTAL=1 (RBD_ALGO_ABA_TRACKS / RBD_ALGO_ABA_PIPE available), else 0 */
-int rbd_experimental(void);
 /* Run-time specialisation.  The one-lane-per-state kernels (mass_matrix! and mass_matrix! + Cholesky at large batches) exist in a second form
  * that is compiled for the mechanism at hand with hiprtc the first time a workspace needs it (the walk of the tree, joint types, offsets and
  * body constants become compile-time constants — what Julia's JIT does for the reference's `mass_matrix!`), cached on disk beside the library

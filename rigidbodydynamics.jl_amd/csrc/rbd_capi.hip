@@ -112,16 +112,16 @@ struct rbd_ws {
   // the re-rooted tree (rbd_reroot.hpp): banked records, chain table, walk plan
   void* d_rr_chain_i = nullptr; void* d_rr_chain_r = nullptr;
   WalkModel wm_rr{}; bool walk_rr = false; void* d_rrtrack_ri = nullptr; void* d_rrtrack_rr = nullptr; void* d_rrwalk_wk = nullptr; size_t walk_rr_lds_bytes = 0, walk_rr_lds_bytes_pair = 0;
-  TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr; size_t track_lds_bytes4 = 0; long track_nw4_max_batch = 0; size_t track_lds_bytes = 0; long track_min_batch = 0;
+  TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr;  // the track plan's records: what the walk kernels read
   ContactModel ctm{}; void* d_cp_body = nullptr; void* d_cp_r = nullptr; void* d_hs_r = nullptr;  // soft contact tables
   void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; size_t d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
-  WalkModel pm{}; void* d_pipe_rr = nullptr; void* d_pipe_rec = nullptr; size_t pipe_lds_bytes = 0; long pipe_max_batch = 0;  // role-pipelined mapping (rbd_pipe.hpp)
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
   std::string spec_src[SPEC_FAMILIES], spec_loop_src, spec_walk_src[8];  // the programs' sources while their compilation is pending (generated once)
   bool spec_walk_tried[8] = {}; hipModule_t spec_walk_mod[8] = {}; hipFunction_t spec_walk[8] = {};  // [inverse dynamics][re-rooted tree][two fp32 states per lane]
+  bool no_reroot = false, loop_no_fused = false; int spec_max_scratch = 512;  // RBD_TUNE: walk_no_reroot, loop_no_fused (tests: the original tree / the three-launch loop route), spec_max_scratch (spilled bytes per lane above which a compiled kernel steps aside)
   bool spec_walk_f32 = true;  // fp32 batches through the compiled walk kernels too (RBD_SPEC_WALK_F32=0: not)
   std::vector<double> loop_gains; bool custom_gains = false;  // rbd_workspace_set_loop_gains: this workspace's Baumgarte gains (4 per loop joint), and whether they differ from the model's
   void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
@@ -151,6 +151,24 @@ struct rbd_ws {
   const char* last_kernel = "";  // dominant kernel of the last rbd_dynamics / rbd_simulate / rbd_mass_matrix_solve call
 };
 
+// RBD_TUNE="key=value,key=value,...": the developer knobs of the tests and sweep scripts in ONE environment variable (batch thresholds between the lane
+// mappings, routes forced off).  Read when a model / workspace is created; `has`: the key was given.  Users need none of them.
+static long tune(const char* key, long dflt, bool* has = nullptr) {
+  if (has) *has = false;
+  const char* e = getenv("RBD_TUNE");
+  if (!e) return dflt;
+  const size_t n = strlen(key);
+  for (const char* p = e; *p;) {
+    const char* end = strchr(p, ',');
+    const size_t len = end ? (size_t)(end - p) : strlen(p);
+    if (len > n && memcmp(p, key, n) == 0 && p[n] == '=') { if (has) *has = true; return atol(p + n + 1); }
+    if (len == n && memcmp(p, key, n) == 0) { if (has) *has = true; return 1; }
+    if (!end) break;
+    p = end + 1;
+  }
+  return dflt;
+}
+
 static std::string loop_program_source(const rbd_model* m, int dtype, std::vector<int32_t>* xi_store);  // (below)
 static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted, int kind = 0, int pair = 0);
 static bool walk_program_rerooted(const rbd_model* m, int dtype, int pair = 0);
@@ -158,13 +176,6 @@ static bool walk_program_rerooted(const rbd_model* m, int dtype, int pair = 0);
 extern "C" {
 
 int rbd_version(void) { return RBD_HIP_H_VERSION; }
-int rbd_experimental(void) {
-#ifdef RBD_EXPERIMENTAL
-  return 1;
-#else
-  return 0;
-#endif
-}
 // run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
 // the source of one program of a model (families as in include/rbd_hip.h); empty: no such program for this mechanism
 static std::string program_source(const rbd_model* m, int32_t dtype, int32_t family) {
@@ -206,7 +217,7 @@ int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t c
     jobs.push_back({program_source(m, dtype, family), family_is_walk(family), family, JIT_PENDING, 0.0, std::string()});
   // RBD_JIT_PRECOMPILE_PART = "k/n": only every n-th program, starting with the k-th — n processes share a model's compilations
   int part = 0, parts = 1;
-  if (const char* e = getenv("RBD_JIT_PRECOMPILE_PART")) { if (sscanf(e, "%d/%d", &part, &parts) != 2 || parts < 1 || part < 0 || part >= parts) { part = 0; parts = 1; } }
+  if (const char* e = getenv("RBD_JIT_PRECOMPILE_PART")) { if (sscanf(e, "%d/%d", &part, &parts) != 2 || parts < 1 || part < 0 || part >= parts) { part = 0; parts = 1; } }  // (build tool only)
   int idx = 0;
   for (Job& j : jobs) {
     if (j.src.empty()) { j.state = -1; continue; }
@@ -505,7 +516,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   }
   {
     // tracks per state of the chain-scheduled ABA: enough for the chains that overlap in time, at most 4 (one wavefront per
-    // SIMD of a CU at the LDS-bound residency); RBD_CHAIN_G overrides for experiments
+    // SIMD of a CU at the LDS-bound residency); 
     int nheads = 0;
     for (int s = 0; s < nb; ++s) {
       const int ps = m->ib[(size_t)s * IB_STRIDE + IB_PARENT];
@@ -513,14 +524,13 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     }
     int G = 1;
     while (G < nheads && G < 4) G <<= 1;
-    if (const char* e = getenv("RBD_CHAIN_G")) { const int g = atoi(e); if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16) G = g; }
     if (m->nloops == 0) m->chain = build_chain_plan(nb, m->ib, G);
     if (m->nloops == 0 && G <= 4) m->track = build_track_plan(nb, m->ib, m->rb, G);
     if (m->track.ok) m->walk = build_walk_plan(m->track.ns, m->track.G, m->track.ri);
     if (m->nloops == 0 && m->nv <= 64) m->state = build_state_plan(nb, m->ib, m->rb);  // (the lane-per-state kernels keep one mask word per row)
   }
-  // ---- the same tree re-rooted at its centre, for the ABA kernels that take it (RBD_NO_REROOT=1 disables) ----
-  if (m->bank_aba_ok && !getenv("RBD_NO_REROOT")) {
+  // ---- the same tree re-rooted at its centre, for the ABA kernels that take it ----
+  if (m->bank_aba_ok) {
     m->rr = build_reroot(d);
     if (m->rr.ok) {
       const Reroot& R = m->rr;
@@ -768,13 +778,13 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     bm.simple = 1;  // every tree joint revolute, apart from 6-dof joints on the world
     for (int i = 0; i < m->nb; ++i)
       if (m->jt_ref[i] != RBD_JOINT_REVOLUTE && !(m->jt_ref[i] == RBD_JOINT_QUAT_FLOATING && m->parent_ref[i] < 0)) bm.simple = 0;
-    if (getenv("RBD_BANK_GENERIC")) bm.simple = 0;  // tests: the generic instantiation on a mechanism the SIMPLE one would take
+    if (tune("bank_generic", 0)) bm.simple = 0;  // tests: the generic instantiation on a mechanism the SIMPLE one would take
     nslots_pack_desc(bm.ns_desc, m->nslots.data(), m->nlevels);
     memcpy(bm.gravity, m->gravity, sizeof bm.gravity);
     // Two bodies per lane wherever the mechanism is in its scope: since round 3 it is ahead of one body per lane at every batch size
     // (profiles/r03_mapping_sweep.txt: 18.8 vs 21.0 us at 512 Atlas states, 19.1 vs 30.1 at 4096).  RBD_BANK_MIN_BATCH: tests.
     w->bank_min_batch = 0;
-    if (const char* e = getenv("RBD_BANK_MIN_BATCH")) w->bank_min_batch = atol(e);
+    { bool has; const long t = tune("bank_min_batch", 0, &has); if (has) w->bank_min_batch = t; }
     // ... up to the batch whose workgroups (256 lanes) are all resident at once: per compute unit as many as the LDS columns allow
     // (park + exchange pairs: 120 KB in fp64 -> one, 60 KB in fp32 -> two), at most the two the register budget allows
     {
@@ -830,29 +840,6 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     tm.ns = P.ns; tm.G = P.G; tm.nA = P.nA; tm.nB = P.nB; tm.ri = (const int32_t*)w->d_track_ri; tm.rr = w->d_track_rr;
     for (int k = 0; k < 5; ++k) { tm.sfm[k] = 0; for (int s2 = 0; s2 < P.ns; ++s2) tm.sfm[k] |= (uint64_t)((P.sf[s2] >> k) & 1) << s2; }
     memcpy(tm.gravity, m->gravity, sizeof tm.gravity);
-    const size_t spw = 64 / P.G, es = dtype == RBD_F64 ? 8 : 4;
-    const size_t nrec = (size_t)P.ns * P.G, nf = dtype == RBD_F64 ? 22 : 24;  // = track_lds_bytes<T>() of rbd_track.hpp: rows, plan records, mailboxes, flags
-    w->track_lds_bytes = (size_t)P.ns * nf * 64 * es + nrec * 16 + nrec * TR_STRIDE * es + ((size_t)P.nA * (TMB_A + TMB_C) + (size_t)P.nB * TMB_B) * spw * es +
-                         ((size_t)P.ns + 4) * sizeof(int32_t);
-    if (w->track_lds_bytes > 160 * 1024) w->track_lds_bytes = 0;  // rows of a deep tree do not fit one CU's LDS: other mappings
-#ifndef RBD_EXPERIMENTAL
-    w->track_lds_bytes = 0;  // aba_track_kernel is built only with RBD_EXPERIMENTAL=1 (build.sh): it lost to the banked / walk kernels at every size
-#else
-    if (w->track_lds_bytes > 0) {
-      const hipError_t e = dtype == RBD_F64 ? configure_track_kernel<double>(P.G, P.has_floating, P.general, w->track_lds_bytes)
-                                            : configure_track_kernel<float>(P.G, P.has_floating, P.general, w->track_lds_bytes);
-      if (e != hipSuccess) { g_last_hip_error = std::string("configure_track_kernel: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
-    }
-#endif
-    // the four-wave latency form while a workgroup (64 / G states) still has a compute unit to itself; one wave per group beyond
-    int ncu = 256;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-    w->track_nw4_max_batch = (long)ncu * (long)spw;
-    if (const char* e = getenv("RBD_TRACK_NW4_MAX_BATCH")) w->track_nw4_max_batch = atol(e);
-    // opt-in (RBD_ALGO_ABA_TRACKS, or RBD_TRACK_MIN_BATCH=<n> to let RBD_ALGO_ABA pick it from n states up): measured at parity with
-    // the banked mapping at B = 4096 and behind it at large batches, where its LDS rows cap the residency (profiles/r02_track_*.txt)
-    w->track_min_batch = (long)1 << 62;
-    if (const char* e = getenv("RBD_TRACK_MIN_BATCH")) w->track_min_batch = atol(e);
   }
   if (m->ncp > 0) {
     st = upload(&w->d_cp_body, m->cp_body.data(), m->cp_body.size() * sizeof(int32_t));
@@ -874,8 +861,8 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     // the walk kernel compiled for the mechanism (aba_walk_spec): from the batch size at which RBD_ALGO_ABA picks the walk kernel by itself on a humanoid — smaller
     // batches that force the mapping (tests, sweeps) keep the interpreting kernel and its zero start-up cost (the compile takes about a minute per mechanism, once)
     w->spec_walk_min_batch = 8192;
-    if (const char* e = getenv("RBD_SPEC_WALK_MIN_BATCH")) w->spec_walk_min_batch = atol(e);
-    if (const char* e = getenv("RBD_SPEC_WALK_F32")) w->spec_walk_f32 = atoi(e) != 0;
+    { bool has; const long t = tune("spec_walk_min_batch", 0, &has); if (has) w->spec_walk_min_batch = t; }
+    w->spec_walk_f32 = tune("spec_walk_f32", 1) != 0;
     WalkModel& wm = w->wm;
     wm.ns = P.ns; wm.G = P.G; wm.nA = P.nA; wm.nB = P.nB; wm.nS = m->walk.nS; wm.nq = m->nq; wm.nv = m->nv;
     wm.ri = (const int32_t*)w->d_track_ri; wm.rr = w->d_track_rr; wm.wk = (const int32_t*)w->d_walk_wk;
@@ -898,7 +885,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       int ncu = 256;
       (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
       w->walk_pair_min_batch = (long)ncu * 64 + 1;
-      if (const char* e = getenv("RBD_WALK_PAIR_MIN_BATCH")) w->walk_pair_min_batch = atol(e);
+      { bool has; const long t = tune("walk_pair_min_batch", 0, &has); if (has) w->walk_pair_min_batch = t; }
     }
     // RBD_ALGO_ABA picks it from this batch size up (RBD_WALK_MIN_BATCH overrides): one state past what the lane-per-body kernels run in ONE
     // round of resident wavefronts — the banked kernel's resident workgroups when the mechanism has banks, else two one-body-per-lane
@@ -915,33 +902,9 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       const bool banked = m->bank_lps > 0 && m->bank_aba_ok;
       w->walk_one_round_batch = banked ? (long)ncu * (256 / m->bank_lps) + 1 : w->walk_min_batch;
       w->rnea_walk_min_batch = banked ? std::max<long>(w->walk_min_batch, (long)ncu * 2 * (256 / m->bank_lps) + 1) : w->walk_min_batch;
-      if (!getenv("RBD_SPEC_WALK_MIN_BATCH")) w->spec_walk_min_batch = std::min<long>(w->spec_walk_min_batch, w->walk_one_round_batch);
+      if (bool has = false; (void)tune("spec_walk_min_batch", 0, &has), !has) w->spec_walk_min_batch = std::min<long>(w->spec_walk_min_batch, w->walk_one_round_batch);
     }
-    if (const char* e = getenv("RBD_WALK_MIN_BATCH")) w->walk_min_batch = atol(e);
-#ifdef RBD_EXPERIMENTAL
-    // the role-pipelined form for small batches: revolute trees (with or without a 6-dof root) on at most 4 tracks
-    if (!P.general && P.G <= 4) {
-      const std::vector<int32_t> rec = walk_unpack4(P.ns, P.G, P.ri, m->walk.wk);
-      st = upload(&w->d_pipe_rec, rec.data(), rec.size() * sizeof(int32_t));
-      if (st == RBD_OK) {
-        if (dtype == RBD_F64) { const std::vector<double> c4 = walk_consts4<double>(P.ns, P.G, P.rr); st = upload(&w->d_pipe_rr, c4.data(), c4.size() * sizeof(double)); }
-        else { const std::vector<float> c4 = walk_consts4<float>(P.ns, P.G, P.rr); st = upload(&w->d_pipe_rr, c4.data(), c4.size() * sizeof(float)); }
-      }
-      if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
-      WalkModel& pm = w->pm;
-      pm = w->wm;
-      pm.G = 4; pm.ri = nullptr; pm.rr = w->d_pipe_rr; pm.wk = (const int32_t*)w->d_pipe_rec;
-      w->pipe_lds_bytes = pipe_lds_bytes(P.ns, m->nq, m->nv, P.nA, P.nB, m->walk.nS, es);
-      if (w->pipe_lds_bytes > 160 * 1024) w->pipe_lds_bytes = 0;
-      if (w->pipe_lds_bytes > 0) {
-        const hipError_t e = dtype == RBD_F64 ? configure_pipe_kernel<double>(w->pipe_lds_bytes) : configure_pipe_kernel<float>(w->pipe_lds_bytes);
-        if (e != hipSuccess) { g_last_hip_error = std::string("configure_pipe_kernel: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
-      }
-      // RBD_ALGO_ABA picks it up to this batch size (RBD_PIPE_MAX_BATCH; 0 = never): one workgroup of 16 states per compute unit in one round
-      w->pipe_max_batch = 0;
-      if (const char* e = getenv("RBD_PIPE_MAX_BATCH")) w->pipe_max_batch = atol(e);
-    }
-#endif
+    { bool has; const long t = tune("walk_min_batch", 0, &has); if (has) w->walk_min_batch = t; }
   }
   if (m->state.ok && m->state.nlevels <= state_max_levels(dtype == RBD_F64 ? 8 : 4)) {
     const StatePlan& P = m->state;
@@ -961,13 +924,13 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
     w->state_min_batch = (long)ncu * 4 * 64 / 2;
-    if (const char* e = getenv("RBD_STATE_MIN_BATCH")) w->state_min_batch = atol(e);
+    { bool has; const long t = tune("state_min_batch", 0, &has); if (has) w->state_min_batch = t; }
     // the kernels compiled for the mechanism (spec_load): a wavefront of 64 states per SIMD — one round of them takes the same time from one wavefront to a
     // chip-full, and beats the walk kernel's rounds of half as many states from the second of those on.  Known here, before anything is compiled, so that a
     // small batch never starts (or waits for) a compilation it would not use
     w->spec_aba_min_batch = w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
-    if (const char* e = getenv("RBD_SPEC_ABA_MIN_BATCH")) w->spec_aba_min_batch = atol(e);
-    if (const char* e = getenv("RBD_SPEC_RNEA_MIN_BATCH")) w->spec_rnea_min_batch = atol(e);
+    { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = t; }
+    { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
   } else {
     w->state_min_batch = (long)1 << 62;
   }
@@ -975,10 +938,8 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     const hipError_t e = dtype == RBD_F64 ? configure_bank_kernels<double>() : configure_bank_kernels<float>();
     if (e != hipSuccess) { g_last_hip_error = std::string("configure_bank_kernels: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
   }
-  {
-    const char* e = getenv("RBD_ABA_STOP_AFTER");  // profiling aid only
-    dm.debug_stop = e ? atoi(e) : 0;
-  }
+  dm.debug_stop = 0;
+  w->no_reroot = tune("walk_no_reroot", 0) != 0; w->loop_no_fused = tune("loop_no_fused", 0) != 0; w->spec_max_scratch = (int)tune("spec_max_scratch", 512);
   *out = w;
   return RBD_OK;
 }
@@ -986,7 +947,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_big_L, w->d_big_tbl, w->d_big_rb, w->d_big_scratch, w->d_fused_i, w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_pipe_rr, w->d_pipe_rec, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_big_L, w->d_big_tbl, w->d_big_rb, w->d_big_scratch, w->d_fused_i, w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -1188,8 +1149,7 @@ static bool walk_tables(const rbd_model* m, bool rerooted, WalkTables* W) {
 // (the plan rbd_dynamics picks for the walk kernel: the re-rooted tree when there is one and its rows fit the LDS)
 static bool walk_program_rerooted(const rbd_model* m, int dtype, int pair) {
   WalkTables W;
-  static const bool no_rr = getenv("RBD_WALK_NO_REROOT") != nullptr;
-  return !no_rr && walk_tables(m, true, &W) && walk_lds_bytes(W.ns, W.G, W.nq, W.nv, W.nA, W.nB, W.nS, (dtype == RBD_F64 || pair) ? 8 : 4, dtype == RBD_F64 ? 8 : 4) <= 160 * 1024;
+  return tune("walk_no_reroot", 0) == 0 && walk_tables(m, true, &W) && walk_lds_bytes(W.ns, W.G, W.nq, W.nv, W.nA, W.nB, W.nS, (dtype == RBD_F64 || pair) ? 8 : 4, dtype == RBD_F64 ? 8 : 4) <= 160 * 1024;
 }
 static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted, int kind, int pair) {
   WalkTables W;
@@ -1216,7 +1176,7 @@ static hipFunction_t spec_walk(rbd_ws* w, bool rerooted, int kind = 0, int pair 
   const std::string fname = std::string(kind ? "rnea_walk_spec_" : "aba_walk_spec_") + walk_spec_suffix(w->dtype, pair);
   if (hipModuleGetFunction(&w->spec_walk[k], w->spec_walk_mod[k], fname.c_str()) != hipSuccess) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
   int scratch = 0;
-  static const int max_scratch = getenv("RBD_SPEC_MAX_SCRATCH") ? atoi(getenv("RBD_SPEC_MAX_SCRATCH")) : 512;  // bytes per lane
+  const int max_scratch = w->spec_max_scratch;  // bytes per lane
   if (w->spec_walk[k] && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_walk[k]) != hipSuccess || scratch > max_scratch)) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
   src.clear(); src.shrink_to_fit();
   return w->spec_walk[k];
@@ -1266,7 +1226,7 @@ int dynamics_loops_t(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const 
   V.jt = (const int32_t*)w->d_jt_ref; V.voff = (const int32_t*)w->d_voff_ref; V.axis = (const T*)w->d_axis_ref; V.axis2 = (const T*)w->d_axis2_ref;
   V.xi = (const int32_t*)w->d_fused_i; V.rb = (const T*)w->d_rb;
   Timed t(w);
-  static const bool no_fused = getenv("RBD_LOOP_NO_FUSED") != nullptr;  // tests: the three-launch route on a mechanism the fused kernel would take
+  const bool no_fused = w->loop_no_fused;  // tests: the three-launch route on a mechanism the fused kernel would take
   if (hipFunction_t f = (m->loop_fused_ok && !no_fused) ? spec_loop(w) : nullptr) {  // the whole evaluation as straight-line code for this mechanism
     long Bl = B;
     int stab = o.stabilization;
@@ -1373,13 +1333,11 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   const rbd_model* m = w->model;
   const bool can_bank = m->bank_lps > 0 && m->bank_aba_ok;
   // the track kernel addresses its batch buffers with 32-bit byte offsets
-  const bool can_track = m->track.ok && w->track_lds_bytes > 0 && !fuse && (double)B * (double)std::max(std::max(m->nq, m->nv), 6 * m->nb) * 8.0 < 4.0e9;
   const bool can_walk = m->track.ok && m->walk.ok && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch)) && !fuse;
-  const bool can_pipe = m->track.ok && m->walk.ok && w->pipe_lds_bytes > 0 && !fuse;
-  if (algorithm == RBD_ALGO_ABA_PIPE && !can_pipe) return RBD_ERR_UNSUPPORTED;
+  // (RBD_ALGO_ABA_CHAINS: removed in round 3; RBD_ALGO_ABA_TRACKS, RBD_ALGO_ABA_PIPE: the two round-2 experiments, removed in round 4 — all three lost at every
+  // batch size; the values stay reserved)
+  if (algorithm == RBD_ALGO_ABA_PIPE || algorithm == RBD_ALGO_ABA_TRACKS || algorithm == RBD_ALGO_ABA_CHAINS) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
-  if (algorithm == RBD_ALGO_ABA_TRACKS && !can_track) return RBD_ERR_UNSUPPORTED;
-  if (algorithm == RBD_ALGO_ABA_CHAINS) return RBD_ERR_UNSUPPORTED;  // the chain mapping of round 1 lost at every batch size and was removed
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !fuse && w->dtype == RBD_F32) {
     if (algorithm == RBD_ALGO_ABA_COMPILED || B >= w->spec_aba_min_batch) spec_load(w, SPEC_ABA, algorithm == RBD_ALGO_ABA_COMPILED);
@@ -1396,26 +1354,17 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   }
   if (algorithm == RBD_ALGO_ABA_COMPILED) return RBD_ERR_UNSUPPORTED;
   int pick = algorithm;
-  if (algorithm == RBD_ALGO_ABA) pick = (can_pipe && B <= w->pipe_max_batch) ? RBD_ALGO_ABA_PIPE : (can_walk && B >= w->walk_min_batch) ? RBD_ALGO_ABA_WALK : (can_track && B >= w->track_min_batch) ? RBD_ALGO_ABA_TRACKS : (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
+  if (algorithm == RBD_ALGO_ABA) pick = (can_walk && B >= w->walk_min_batch) ? RBD_ALGO_ABA_WALK : (can_bank && B >= w->bank_min_batch) ? RBD_ALGO_ABA_BANKS : RBD_ALGO_ABA_LANES;
   if (algorithm == RBD_ALGO_ABA && pick == RBD_ALGO_ABA_BANKS && can_walk && B >= w->walk_one_round_batch && B >= w->spec_walk_min_batch && (w->dtype == RBD_F64 || w->spec_walk_f32)) {
     // the banked kernel would need a second workgroup per CU: the walk kernel compiled for the mechanism is ahead from here (see walk_one_round_batch)
-    static const bool no_rr = getenv("RBD_WALK_NO_REROOT") != nullptr;
+    const bool no_rr = w->no_reroot;
     if (spec_walk(w, w->walk_rr && !no_rr && w->walk_rr_lds_bytes > 0, 0, 0)) pick = RBD_ALGO_ABA_WALK;
   }
   Timed t(w);
-  w->last_kernel = pick == RBD_ALGO_ABA_TRACKS ? "aba_track_kernel" : pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : "aba_kernel";
-#ifdef RBD_EXPERIMENTAL
-  if (pick == RBD_ALGO_ABA_PIPE) {
-    WalkModel pm = w->pm;
-    if (gravity) memcpy(pm.gravity, gravity, sizeof pm.gravity);
-    w->last_kernel = "aba_pipe_kernel";
-    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_pipe<double>(pm, B, w->pipe_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_aba_pipe<float>(pm, B, w->pipe_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-  } else
-#endif
+  w->last_kernel = pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : "aba_kernel";
   if (pick == RBD_ALGO_ABA_WALK) {
     // the tree re-rooted at its centre (rbd_reroot.hpp) when there is one: fewer steps per track, better balanced tracks (RBD_WALK_NO_REROOT=1: the original tree)
-    static const bool no_rr = getenv("RBD_WALK_NO_REROOT") != nullptr;
+    const bool no_rr = w->no_reroot;
     const int pair = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
     const bool rr = w->walk_rr && !no_rr && (pair ? w->walk_rr_lds_bytes_pair : w->walk_rr_lds_bytes) > 0;
     WalkModel wm = rr ? w->wm_rr : w->wm;
@@ -1434,16 +1383,6 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     } else
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, TP.has_floating, TP.general, 0, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba_walk<float>(wm, TP.has_floating, TP.general, pair, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-#ifdef RBD_EXPERIMENTAL
-  } else if (pick == RBD_ALGO_ABA_TRACKS) {
-    TrackModel tm = w->tm;
-    if (gravity) memcpy(tm.gravity, gravity, sizeof tm.gravity);
-    const int flt = m->track.has_floating, gen = m->track.general;
-    const int nw = B <= w->track_nw4_max_batch ? 4 : 1;
-    w->last_kernel = nw == 4 ? "aba_track_kernel (4 waves per state group)" : "aba_track_kernel";
-    if (w->dtype == RBD_F64) HIP_TRY(launch_aba_track<double>(tm, flt, gen, nw, B, w->track_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-    else HIP_TRY(launch_aba_track<float>(tm, flt, gen, nw, B, w->track_lds_bytes, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
-#endif
   } else if (pick == RBD_ALGO_ABA_BANKS) {
     BankModel bm = w->bm;
     if (gravity) memcpy(bm.gravity, gravity, sizeof bm.gravity);
@@ -1488,7 +1427,7 @@ static void spec_load(rbd_ws* w, int family, bool force) {
   // a kernel whose registers spilled beyond a few values is slower than the kernels that interpret the mechanism: it steps aside
   auto fits = [&](hipFunction_t* f) {
     int scratch = 0;
-    static const int max_scratch = getenv("RBD_SPEC_MAX_SCRATCH") ? atoi(getenv("RBD_SPEC_MAX_SCRATCH")) : 512;  // bytes per lane
+    const int max_scratch = w->spec_max_scratch;  // bytes per lane
     if (*f && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, *f) != hipSuccess || scratch > max_scratch)) { (void)hipGetLastError(); *f = nullptr; }
   };
   int ncu = 256;
@@ -1601,7 +1540,7 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
   if (state && layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv)) {
     spec_load(w, SPEC_MASS);
     const bool mcopy_ok = !dM || (Lm.sk == 1 && (Lm.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0);
-    const bool spec_route = w->spec_chol && spec_crba_fits(w) && es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && mcopy_ok && !getenv("RBD_EXP_NO_SPEC_CHOL");
+    const bool spec_route = w->spec_chol && spec_crba_fits(w) && es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && mcopy_ok;
     if ((st = stage_m(w, B, spec_route))) return st;
     const Layout Ls{16, -(long)m->nv * m->nv};  // grouped by 16 states = one wavefront of the tile Cholesky (layout_base, rbd_device.hpp)
     if (spec_route) {
@@ -1615,8 +1554,7 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
     hipFunction_t const spec = spec_crba(w, w->d_Msoa_bytes);
     if (spec) HIP_TRY(launch_crba_spec(w, spec, B, dq, w->d_Msoa, Lq, Ls, 0));
     else HIP_TRY(launch_crba_state<float>(w->sm, B, dq, w->d_Msoa, Lq, Ls, 0, w->stream));
-    static const bool exp_no_mcopy = getenv("RBD_EXP_NO_MCOPY") != nullptr, exp_no_chol = getenv("RBD_EXP_NO_CHOL") != nullptr;  // timing experiments only
-    if (!exp_no_chol) HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_Msoa, dtau, dc, dx, nullptr, Ls, Lv, w->d_notpd, w->stream, exp_no_mcopy ? nullptr : dM, Lm));
+    HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_Msoa, dtau, dc, dx, nullptr, Ls, Lv, w->d_notpd, w->stream, dM, Lm));
     w->last_kernel = spec ? "crba_spec_f32 (compiled for the mechanism at run time) + chol_mfma_kernel" : "crba_state_kernel + chol_mfma_kernel";
     return RBD_OK;
   }

@@ -64,10 +64,6 @@ template <typename T>
 hipError_t launch_momentum(const DevModel& M, long B, const void* q, const void* v, void* mom, Layout Lq, Layout Lv, Layout L12, hipStream_t s);
 }
 namespace rbd {
-template <typename T>
-hipError_t launch_aba_track(const TrackModel& M, int flt, int gen, int nw, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext,
-                            void* vdot, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
-template <typename T> hipError_t configure_track_kernel(int G, int flt, int gen, size_t lds_bytes);
 // rbd_contact_kernels.hip: soft contact
 template <typename T>
 hipError_t launch_contact(const ContactModel& M, long B, const void* body, void* s, void* sdot, const void* fext, void* contactwrenches, void* totalwrenches,
@@ -81,10 +77,6 @@ template <typename T>
 hipError_t launch_rnea_walk(const WalkModel& M, int flt, int gen, int pair, long B, size_t lds_bytes, const void* q, const void* v, const void* vdot, const void* fext,
                             void* tau, void* qdot, Layout Lq, Layout Lv, Layout Lf, hipStream_t s, void* acc_out = nullptr, void* jw_out = nullptr);
 template <typename T> hipError_t configure_walk_kernel(int flt, int gen, size_t lds_bytes, size_t lds_bytes_pair);
-template <typename T>
-hipError_t launch_aba_pipe(const WalkModel& M, long B, size_t lds_bytes, const void* q, const void* v, const void* tau, const void* fext, void* vdot, void* qdot,
-                           Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
-template <typename T> hipError_t configure_pipe_kernel(size_t lds_bytes);
 // rbd_state_kernels.hip: one lane per state
 int state_max_levels(int element_size);
 template <typename T>

@@ -1351,8 +1351,7 @@ template <typename T> struct MfmaChol {
 template <> struct MfmaChol<double> {
   static bool launch(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv, int* notpd,
                      hipStream_t s, void* Mcopy, Layout) {
-    static const bool off = getenv("RBD_NO_MFMA64") != nullptr;  // A/B against chol_reg_kernel
-    if (Mcopy || off) return false;
+    if (Mcopy) return false;
     const dim3 grid((unsigned)((B + 3) / 4));
 #define RBD_CHOL_MFMA64(NT)                                                                                                            \
     if (nv <= 4 * NT) {                                                                                                               \

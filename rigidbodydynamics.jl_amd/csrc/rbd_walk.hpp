@@ -24,10 +24,11 @@
 // wavefront between barriers (in both orders, so that a missing barrier reads a never-written mailbox and fails).
 #pragma once
 #include "rbd_device.hpp"
-#include "rbd_track.hpp"
 #include "rbd_walk_plan.hpp"
 
 namespace rbd {
+
+struct alignas(16) I4 { int32_t x, y, z, w; };  // one packed plan record (TI_*, rbd_device.hpp)
 
 // `switch (s)` with the step index as a compile-time constant SV inside every case
 #define RBD_WALK_CASE(N, ...) case N: { constexpr int SV = N; __VA_ARGS__ } break;

@@ -627,11 +627,6 @@ def gravitational_potential_energy(state: MechanismState) -> torch.Tensor:
     return e[:, 1] if state.layout == "aos" else e[1]
 
 
-def experimental():
-    """True when the library carries the two experimental lane mappings (`aba_tracks`, `aba_pipe`; csrc/build.sh RBD_EXPERIMENTAL=1)."""
-    return bool(_capi.lib().rbd_experimental())
-
-
 def jit_source(flat, dtype=torch.float32, family="mass_matrix"):
     """The source `rbd_jit_source` generates for a mechanism's run-time specialised kernels (csrc/rbd_jit.hip, rbd_spec.hpp); None when the
     mechanism is outside the one-lane-per-state kernels' scope.  family: "mass_matrix" (+ Cholesky), "dynamics", "inverse_dynamics" — one program each.  Host only."""

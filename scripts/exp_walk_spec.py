@@ -1,5 +1,5 @@
 """dynamics! through the walk kernel compiled for the mechanism (aba_walk_spec, csrc/rbd_walk.hpp; fp64): parity against the oracle, then graph-replayed µs
-per launch.  Run once as is and once with RBD_SPEC_WALK_MIN_BATCH=1000000000 (the interpreting walk kernel) to compare."""
+per launch.  Run once as is and once with RBD_TUNE=spec_walk_min_batch=1000000000 (the interpreting walk kernel) to compare."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -55,7 +55,7 @@ model = load("atlas_floating")
 B = 300
 q = rbd.rand_configuration(model, B, rng); v = rbd.rand_velocity(model, B, rng)
 vd = rng.standard_normal((B, model.nv)); fe = rng.standard_normal((B, 6 * model.n_bodies))
-os.environ["RBD_SPEC_WALK_MIN_BATCH"] = os.environ.get("RBD_SPEC_WALK_MIN_BATCH", "1")
+os.environ.setdefault("RBD_TUNE", "spec_walk_min_batch=1")
 state = rbd.MechanismState(model, B); rbd.set_configuration_(state, q); rbd.set_velocity_(state, v)
 t64 = lambda a: torch.as_tensor(a, dtype=torch.float64, device="cuda")
 out = torch.zeros(B, model.nv, dtype=torch.float64, device="cuda"); jw = torch.zeros(B, 6 * model.n_bodies, dtype=torch.float64, device="cuda"); acc = torch.zeros_like(jw)

@@ -1,6 +1,6 @@
 """Timing of the one-lane-per-state kernels against the lane-per-body ones over the batch size (Atlas floating):
 mass_matrix!, dynamics_bias!, mass_matrix! + Cholesky solve, dynamics! by the reference's route and by the fused ABA.
-usage: python scripts/state_sweep.py [f32|f64] [aos|soa]   (RBD_STATE_MIN_BATCH is set per measurement)"""
+usage: python scripts/state_sweep.py [f32|f64] [aos|soa]   (RBD_TUNE=state_min_batch=<n> is set per measurement)"""
 import json, os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -40,7 +40,7 @@ if __name__ == "__main__":
     layout = sys.argv[2] if len(sys.argv) > 2 else "aos"
     for B in (4096, 16384, 32768, 65536, 131072, 262144):
         for mode, minb in (("lane-per-body", str(1 << 40)), ("lane-per-state", "1")):
-            env = dict(os.environ, RBD_STATE_MIN_BATCH=minb)
+            env = dict(os.environ, RBD_TUNE="state_min_batch=" + minb)
             r = subprocess.run([sys.executable, __file__, "--child", dt, layout, str(B)], env=env, capture_output=True, text=True)
             line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]
             print(dt, layout, mode, line, flush=True)

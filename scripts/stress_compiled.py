@@ -4,7 +4,7 @@ sparse Cholesky and the emitter when nv is a multiple of 4) against the oracle. 
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-os.environ["RBD_STATE_MIN_BATCH"] = "1"
+os.environ["RBD_TUNE"] = "state_min_batch=1"
 import numpy as np, torch
 import rbd_amd as rbd, oracle
 from test_chain_plan import random_tree

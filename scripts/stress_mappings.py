@@ -29,7 +29,7 @@ for trial in range(N):
     rbd.set_configuration_(state, q); rbd.set_velocity_(state, v)
     ref = oracle.dynamics(model, q, v, tau, fe)
     t, f = torch.as_tensor(tau).cuda(), torch.as_tensor(fe).cuda()
-    for algo in ("aba_lanes", "aba_banks", "aba_walk") + (("aba_tracks", "aba_pipe") if rbd.experimental() else ()):
+    for algo in ("aba_lanes", "aba_banks", "aba_walk"):
         try:
             rbd.dynamics_(res, state, t, f, algorithm=algo)
         except Exception:
@@ -51,7 +51,7 @@ for trial in range(N):
         assert err < 1e-9, (trial, mp, n, B, err)
     # the walk kernels' packed fp32 form (two states per lane) on every fourth tree
     if trial % 4 == 0:
-        os.environ["RBD_WALK_PAIR_MIN_BATCH"] = "1"
+        os.environ["RBD_TUNE"] = "walk_pair_min_batch=1"
         try:
             s32 = rbd.MechanismState(model, B, dtype=torch.float32); r32 = rbd.DynamicsResult(model, B, dtype=torch.float32)
             rbd.set_configuration_(s32, q); rbd.set_velocity_(s32, v)
@@ -69,7 +69,7 @@ for trial in range(N):
         except rbd._capi.RBDError:
             skipped["walk_f32x2"] = skipped.get("walk_f32x2", 0) + 1
         finally:
-            os.environ.pop("RBD_WALK_PAIR_MIN_BATCH", None)
+            os.environ.pop("RBD_TUNE", None)
     # kinematics by-products on the same tree
     A = torch.zeros(B, 6 * model.nv, dtype=torch.float64, device="cuda")
     rbd.momentum_matrix_(A, state)

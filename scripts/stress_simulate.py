@@ -1,5 +1,5 @@
 """One-off stress: `simulate` (Munthe-Kaas RK4 on the device, fused stages) on random trees of every joint type against the numpy
-restatement of src/ode_integrators.jl:233-299, with the lane mapping forced either way (RBD_BANK_MIN_BATCH)."""
+restatement of src/ode_integrators.jl:233-299, with the lane mapping forced either way (RBD_TUNE=bank_min_batch=<n>)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,7 +17,7 @@ for trial in range(N):
     model = rbd.flatten(rbd.rand_tree_mechanism(rng, types))
     if model.nv == 0:
         continue
-    os.environ["RBD_BANK_MIN_BATCH"] = "1" if trial % 2 else "1000000"  # read when the workspace is created
+    os.environ["RBD_TUNE"] = "bank_min_batch=" + ("1" if trial % 2 else "1000000")  # read when the workspace is created
     B, dt, T = 3, 2e-3, 0.0075
     r2 = np.random.default_rng(trial)
     q, v, tau = rbd.rand_configuration(model, B, r2), rbd.rand_velocity(model, B, r2), r2.random((B, model.nv))

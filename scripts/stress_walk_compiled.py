@@ -6,7 +6,7 @@ the interpreting walk kernel bit for bit.
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-os.environ["RBD_SPEC_WALK_MIN_BATCH"] = "1"
+os.environ["RBD_TUNE"] = "spec_walk_min_batch=1"
 import numpy as np, torch
 import rbd_amd as rbd
 from test_chain_plan import random_tree
@@ -71,7 +71,7 @@ for trial, (name, model) in enumerate(cases):
     ref32 = oracle.dynamics(model, q32, v32, tau32, fe32)
     e32 = {}
     for pair in ("1000000000", "1"):
-        os.environ["RBD_WALK_PAIR_MIN_BATCH"] = pair
+        os.environ["RBD_TUNE"] = "spec_walk_min_batch=1,walk_pair_min_batch=" + pair
         got = {}
         for jit in ("1", "0"):
             os.environ["RBD_JIT"] = jit
@@ -86,7 +86,7 @@ for trial, (name, model) in enumerate(cases):
         e32[pair == "1"] = (np.abs(got["1"] - ref32).max() / scale, np.abs(got["0"] - ref32).max() / scale)
         # an fp32 solve of an ill-conditioned system: the two compilations may differ by as much as either differs from the truth, not more
         assert e32[pair == "1"][0] <= 4 * e32[pair == "1"][1] + 1e-5, (name, pair, e32)
-    os.environ.pop("RBD_WALK_PAIR_MIN_BATCH")
+    os.environ["RBD_TUNE"] = "spec_walk_min_batch=1"
     print(name, "nv", model.nv, "B", B, "compiled err %.1e interpreting err %.1e | fp32 (compiled, interpreting): one per lane %.1e %.1e two per lane %.1e %.1e" % ((e, e0) + tuple(float(x) for x in e32[False] + e32[True])), flush=True)
     done += 1
 print(done, "mechanisms ok,", skipped, "outside the mapping; worst error", worst)

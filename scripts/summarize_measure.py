@@ -1,6 +1,7 @@
-"""Condenses what scripts/gpu_measure.sh collected under gpurun_out/measure into the files that are committed under profiles/:
-r03_kernel_stats_c<C>.csv (rocprofv3 --kernel-trace --stats, our kernels), r03_pmc_c<C>.txt (PMC per launch and per wavefront) and
-r03_pmc_traffic.json (HBM bytes per step from FETCH_SIZE / WRITE_SIZE, keyed like bench.py looks it up, with the kernel-source hash)."""
+"""Condenses what scripts/gpu_measure.sh collected under gpurun_out/measure into the files that are committed under profiles/, one set PER LEG (a leg = one timed
+entry point of one BASELINE config, profiled in a run of its own): r04_kernel_stats_<leg>.csv (rocprofv3 --kernel-trace --stats, our kernels),
+r04_pmc_<leg>.txt (PMC per launch and per wavefront) and r04_pmc_traffic.json (HBM bytes per step from FETCH_SIZE / WRITE_SIZE, keyed like bench.py looks it
+up, with the kernel-source hash)."""
 import collections
 import csv
 import glob
@@ -35,9 +36,13 @@ def pmc(dirname):
     return {k: {c: (sum(v.values()) / len(v), len(v)) for c, v in d.items()} for k, d in per.items()}
 
 
+LEGS = {"c2": (2, "dynamics", ""), "c2id": (2, "inverse_dynamics", ""), "c3": (3, "mass_matrix_solve", ""), "c3noM": (3, "mass_matrix_solve", "_noM"),
+        "c4": (4, "dynamics", ""), "c5": (5, "dynamics", "")}
+
+
 def main():
-    configs = [int(c) for c in sys.argv[1:]] or [2, 3, 4, 5]
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    legs = sys.argv[1:] or list(LEGS)
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     h = bench.kernel_source_hash()
     rec = {}
     if os.path.exists(path):
@@ -50,29 +55,30 @@ def main():
                     "reads and an upper bound for the 8-byte strided ones; WRITE_SIZE is uncalibrated.  Infinity-Cache hits are counted, so with inputs "
                     "re-read every step this is fabric traffic, an upper bound of DRAM traffic.")
     rec.setdefault("detail", {})
-    for C in configs:
+    for leg in legs:
+        C, op, sfx = LEGS[leg]
         cfg = bench.CONFIGS[C]
-        key = f"{cfg['model']}_{cfg['dtype']}_B{cfg['batch']}_{cfg['op']}"
+        key = f"{cfg['model']}_{cfg['dtype']}_B{cfg['batch']}_{op}{sfx}"
         # --- kernel stats
         rows = []
-        for f in glob.glob(os.path.join(OUT, f"stats_c{C}", "**", "*kernel_stats.csv"), recursive=True):
+        for f in glob.glob(os.path.join(OUT, f"stats_{leg}", "**", "*kernel_stats.csv"), recursive=True):
             rows += list(csv.DictReader(open(f)))
-        with open(os.path.join(ROOT, "profiles", f"r03_kernel_stats_c{C}.csv"), "w") as fo:
-            fo.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {C} --no-cpu-baseline --no-pipelined --steps 60 --warmup 10 ; sources {h}\n")
+        with open(os.path.join(ROOT, "profiles", f"r04_kernel_stats_{leg}.csv"), "w") as fo:
+            fo.write(f"# leg {leg}: rocprofv3 --kernel-trace --stats -- python bench.py (scripts/gpu_measure.sh leg_args {leg}) --no-cpu-baseline --no-extra-legs --no-other-configs --steps 60 --warmup 10 ; sources {h}\n")
             fo.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
             for r in rows:
                 fo.write(",".join(['"' + short(r["Name"]) + '"'] + [r[c] for c in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")]) + "\n")
         calls = {short(r["Name"]): int(r["Calls"]) for r in rows}
         avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
         # --- PMC
-        fetch, write = pmc(os.path.join(OUT, f"pmc_fetch_c{C}")), pmc(os.path.join(OUT, f"pmc_write_c{C}"))
-        sq = pmc(os.path.join(OUT, f"pmc_sq1_c{C}"))
-        for k, d in pmc(os.path.join(OUT, f"pmc_sq2_c{C}")).items():
+        fetch, write = pmc(os.path.join(OUT, f"pmc_fetch_{leg}")), pmc(os.path.join(OUT, f"pmc_write_{leg}"))
+        sq = pmc(os.path.join(OUT, f"pmc_sq1_{leg}"))
+        for k, d in pmc(os.path.join(OUT, f"pmc_sq2_{leg}")).items():
             sq.setdefault(k, {}).update(d)
         step_kernels = [k for k, n in calls.items() if k.startswith(OURS) and n >= 60]
         total, detail = 0.0, {}
-        with open(os.path.join(ROOT, "profiles", f"r03_pmc_c{C}.txt"), "w") as fo:
-            fo.write(f"# config {C}: {key}; sources {h}; rocprofv3 --pmc (scripts/gpu_measure.sh); per launch, averaged over the launches of the run\n")
+        with open(os.path.join(ROOT, "profiles", f"r04_pmc_{leg}.txt"), "w") as fo:
+            fo.write(f"# leg {leg} (config {C}): {key}; sources {h}; rocprofv3 --pmc (scripts/gpu_measure.sh); per launch, averaged over the launches of the run\n")
             for k in sorted(set(fetch) | set(write) | set(sq)):
                 fr = fetch.get(k, {}).get("FETCH_SIZE", (0.0, 0))[0] * 1024
                 wr = write.get(k, {}).get("WRITE_SIZE", (0.0, 0))[0] * 1024
@@ -86,9 +92,11 @@ def main():
                     total += 2 * fr + wr
                     detail[k] = {"fetch_bytes_raw": fr, "fetch_bytes_x2": 2 * fr, "write_bytes": wr, "avg_ns": avg_ns.get(k),
                                  "valu_insts_per_wave": (d["SQ_INSTS_VALU"][0] / w) if w and "SQ_INSTS_VALU" in d else None}
-        rec[key] = total if detail else None
+        raw = sum(d["fetch_bytes_raw"] + d["write_bytes"] for d in detail.values())
+        sig = {k: float(r["StdDev"]) / float(r["AverageNs"]) for r in rows for k in [short(r["Name"])] if k in step_kernels and float(r["AverageNs"]) > 0}
+        rec[key] = {"bytes_per_step_fetch_x2": total, "bytes_per_step_raw": raw, "kernels": sorted(detail), "stddev_over_mean": sig} if detail else None
         rec["detail"][key] = detail
-        print(f"config {C} ({key}): step kernels {step_kernels}; traffic {total:.0f} B/step")
+        print(f"leg {leg} ({key}): step kernels {step_kernels}; traffic {total:.0f} B/step with FETCH x2, {raw:.0f} raw; sigma/mean {sig}")
     json.dump(rec, open(path, "w"), indent=1)
 
 

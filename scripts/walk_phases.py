@@ -9,7 +9,7 @@ from rigidbodydynamics_jl_amd import _capi
 model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
 for dt, tdt, B, pair in (("f64", torch.float64, 4096, False), ("f64", torch.float64, 65536, False), ("f32", torch.float32, 4096, False),
                          ("f32", torch.float32, 65536, False), ("f32", torch.float32, 65536, True)):
-    os.environ["RBD_WALK_PAIR_MIN_BATCH"] = "1" if pair else str(1 << 40)
+    os.environ["RBD_TUNE"] = "walk_pair_min_batch=" + ("1" if pair else str(1 << 40))
     rng = np.random.default_rng(1)
     state = rbd.MechanismState(model, B, dtype=tdt); result = rbd.DynamicsResult(model, B, dtype=tdt)
     rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng)); rbd.set_velocity_(state, rbd.rand_velocity(model, B, rng))

@@ -51,6 +51,14 @@ def models(rbd):
     return m
 
 
+def tune(monkeypatch, **kv):
+    """RBD_TUNE="key=value,...": the library's developer knobs (thresholds between the lane mappings, routes forced off; csrc/rbd_capi.hip tune()), read when a
+    model / workspace is created.  Several calls in one test accumulate."""
+    cur = dict(x.split("=", 1) for x in os.environ.get("RBD_TUNE", "").split(",") if "=" in x)
+    cur.update({k: str(v) for k, v in kv.items()})
+    monkeypatch.setenv("RBD_TUNE", ",".join(f"{k}={v}" for k, v in cur.items()))
+
+
 def rand_inputs(rbd, model, B, seed, fext=False):
     rng = np.random.default_rng(seed)
     q = rbd.rand_configuration(model, B, rng)

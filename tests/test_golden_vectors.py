@@ -112,7 +112,7 @@ def test_gpu_reproduces_the_independent_vectors(rbd, vmodels, name, layout):
     rbd.mass_matrix_(result, state)
     Mg = host(result.massmatrix).reshape(B, m.nv, m.nv).transpose(0, 2, 1)
     assert rel(np.tril(Mg), np.tril(g["M"])) <= tol
-    algos = ["aba", "aba_lanes", "crba"] + (["aba_walk", "aba_banks"] + (["aba_tracks"] if rbd.experimental() else []) if name not in ("randmech1", "inner_floating") else [])
+    algos = ["aba", "aba_lanes", "crba"] + (["aba_walk", "aba_banks"] if name not in ("randmech1", "inner_floating") else [])
     for a in algos:
         rbd.dynamics_(result, state, dev(g["tau_in"]), dev(g["fext"]), algorithm=a)
         assert rel(host(result.vd), g["vdot"]) <= tol, a

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rand_inputs
+from conftest import rand_inputs, tune
 
 pytestmark = pytest.mark.gpu
 
@@ -493,7 +493,7 @@ def test_simulate_device_side_controllers(rbd, oracle, models, path, monkeypatch
     ABA launches; `unfused`: the large-batch arrangement (stage kernel, element-wise PD kernel, walk kernel), forced at a small batch."""
     import simulate_np
     if path == "unfused":
-        monkeypatch.setenv("RBD_WALK_MIN_BATCH", "1")  # read when the workspace is created
+        tune(monkeypatch, walk_min_batch="1")  # read when the workspace is created
     model = models["atlas_fixed"]
     B, dt, T = 5, 2e-3, 0.0075
     nsteps = 4
@@ -736,14 +736,11 @@ def test_kinematics_byproducts_f32_and_full_size(rbd, oracle, models):
 
 # ---- chain-scheduled ABA (RBD_ALGO_ABA_CHAINS): the same dynamics! through the other lane mapping -------------------------
 CHAIN_MODELS = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf"]
-# the lane mappings of the fused ABA beside one body per lane.  aba_tracks / aba_pipe exist only in an RBD_EXPERIMENTAL=1 build (csrc/build.sh):
-# they lost to the banked / walk kernels at every batch size; the round-1 chain mapping was removed.
-MAPPINGS = ["aba_walk", "aba_banks", "aba_tracks"]
+# the lane mappings of the fused ABA beside one body per lane (the chain / track / pipe mappings of rounds 1-2 lost at every batch size and were removed:
+# DESIGN.md §8; their RBD_ALGO_* values stay reserved and return RBD_ERR_UNSUPPORTED)
+MAPPINGS = ["aba_walk", "aba_banks"]
 
 
-def need(rbd, algorithm):
-    if algorithm in ("aba_tracks", "aba_pipe") and not rbd.experimental():
-        pytest.skip(f"{algorithm}: RBD_EXPERIMENTAL build only")
 
 
 @pytest.mark.gpu
@@ -751,7 +748,6 @@ def need(rbd, algorithm):
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("name", CHAIN_MODELS)
 def test_dynamics_chains_f64(rbd, oracle, models, name, layout, algorithm):
-    need(rbd, algorithm)
     model = models[name]
     B = 67  # ragged against every states-per-wave (64, 32, 16, 4)
     state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 41)
@@ -774,7 +770,6 @@ def test_dynamics_chains_f64(rbd, oracle, models, name, layout, algorithm):
 @pytest.mark.parametrize("algorithm", MAPPINGS)
 @pytest.mark.parametrize("B", [1, 3, 4, 5, 15, 16, 17, 1000])
 def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B, algorithm):
-    need(rbd, algorithm)
     model = models["atlas_floating"]
     state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 42 + B)
     result = rbd.DynamicsResult(model, B)
@@ -795,7 +790,6 @@ def test_dynamics_chains_batch_sizes_and_f32(rbd, oracle, models, B, algorithm):
 def test_dynamics_chains_random_trees(rbd, oracle, algorithm):
     """Random revolute / prismatic / fixed / sin-cos trees (with and without a floating root), as the reference's randomized tests do."""
     from test_chain_plan import random_tree
-    need(rbd, algorithm)
     rng = np.random.default_rng(9)
     for trial in range(12):
         mech = random_tree(rbd, rng, int(rng.integers(1, 30)), bool(trial % 2), float(rng.uniform(0, 1)))
@@ -808,7 +802,7 @@ def test_dynamics_chains_random_trees(rbd, oracle, algorithm):
         except Exception:
             # banks: a tree too shallow or too small to split into two banks that save lanes; tracks: a chain so long that its
             # per-step LDS rows exceed one CU's 160 KB (RBD_ERR_UNSUPPORTED, the default then takes another mapping)
-            assert algorithm in ("aba_banks", "aba_tracks", "aba_walk")  # walk: more than 11 steps per track
+            assert algorithm in ("aba_banks", "aba_walk")  # walk: more than 11 steps per track
             continue
         ref = oracle.dynamics(model, q, v, tau, fe)
         got = host(result.vd, state)
@@ -928,7 +922,7 @@ def test_four_bar_custom_stabilization_gains(rbd, oracle, models, kernels, monke
     evaluating a model that carries those gains; then back to the defaults on the same workspace.  Anything that is not a gains object raises."""
     monkeypatch.setenv("RBD_JIT", "1" if kernels == "compiled" else "0")
     if kernels == "three_launches":
-        monkeypatch.setenv("RBD_LOOP_NO_FUSED", "1")
+        tune(monkeypatch, loop_no_fused="1")
     model = models["four_bar"]
     B = 512
     q, v, tau = four_bar_inputs(rbd, B, 77)
@@ -975,7 +969,9 @@ def test_maximal_coordinates_per_joint_gains(rbd, oracle):
     q, v = rbd.rand_configuration(mt, B, rng), rbd.rand_velocity(mt, B, rng)
     H, T, _ = oracle.body_kinematics(mt, q, v, np.zeros((B, mt.nv)))
     qm, vm = maximal_state(H, T)
-    qm = qm + 1e-3 * rng.standard_normal(qm.shape)   # off the manifold (the oracle and the GPU normalize nothing: same q on both sides)
+    qm = (qm + 1e-3 * rng.standard_normal(qm.shape)).reshape(B, -1, 7)   # off the constraint manifold, in rotation and translation ...
+    qm[:, :, :4] /= np.linalg.norm(qm[:, :, :4], axis=2, keepdims=True)       # ... with unit quaternions (non-unit ones are outside what the reference pins)
+    qm = qm.reshape(B, -1)
     vm = vm + 1e-3 * rng.standard_normal(vm.shape)
     gains = [tuple(rng.uniform(10.0, 300.0, 4)) for _ in mc.loops]
     arg = {l["name"]: rbd.SE3PDGains(rbd.PDGains(g[0], g[1]), rbd.PDGains(g[2], g[3])) for l, g in zip(mc.loops, gains)}
@@ -1150,9 +1146,9 @@ def test_momentum_and_rate_bias_f64(rbd, oracle, models, name, layout):
 @pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "valkyrie_floating"])
 def test_simulate_banked_fused_path_matches_oracle(rbd, oracle, models, name, monkeypatch):
     """`simulate` through the two-bodies-per-lane kernel with the integrator stage fused in (what large batches run): forced at a
-    small batch with RBD_BANK_MIN_BATCH so that every state can be compared with the numpy restatement of the Munthe-Kaas step."""
+    small batch with RBD_TUNE bank_min_batch so that every state can be compared with the numpy restatement of the Munthe-Kaas step."""
     import simulate_np
-    monkeypatch.setenv("RBD_BANK_MIN_BATCH", "1")  # read when the workspace is created
+    tune(monkeypatch, bank_min_batch="1")  # read when the workspace is created
     model = models[name]
     B, dt, T = 5, 1e-3, 0.0045  # 5 steps: first (stage 0 alone), middle ones (previous step closed inside stage 0), closing launch
     q, v, tau, _ = rand_inputs(rbd, model, B, 97, fext=True)
@@ -1198,7 +1194,7 @@ def test_batch_states_are_isolated_from_a_nan_state(rbd, models, name, dtype):
     B = 37
     state, q, v, tau, fe = make(rbd, model, B, dtype, "aos", 123)
     t, f = dev(tau, state), dev(fe, state)
-    algos = ["aba_lanes"] + [a for a in ("aba_banks", "aba_walk") + (("aba_tracks",) if rbd.experimental() else ()) if name != "randmech1" and (a != "aba_banks" or rbd.bank_plan(model))]
+    algos = ["aba_lanes"] + [a for a in ("aba_banks", "aba_walk") if name != "randmech1" and (a != "aba_banks" or rbd.bank_plan(model))]
 
     def run_all():
         out = {}
@@ -1333,7 +1329,7 @@ def test_c_abi_rccl_gather_single_rank(rbd, models):
 def test_dynamics_walk_two_states_per_lane_f32(rbd, oracle, models, name, layout, monkeypatch):
     """aba_walk_kernel's packed fp32 form (two states per lane, 128 per workgroup; default from 16 385 states up) forced at a small ragged batch:
     backward error of M v̇ = τ − c against the fp64 oracle's M and c, q̇, and agreement with the one-state-per-lane form."""
-    monkeypatch.setenv("RBD_WALK_PAIR_MIN_BATCH", "1")
+    tune(monkeypatch, walk_pair_min_batch="1")
     model = models[name]
     B = 300
     state, q, v, tau, fe = make(rbd, model, B, "f32", layout, 77)
@@ -1350,7 +1346,7 @@ def test_dynamics_walk_two_states_per_lane_f32(rbd, oracle, models, name, layout
     assert eta.max() <= 2e-5, eta.max()
     _, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
     assert np.abs(qd - qd_ref).max() <= 1e-5 * max(1.0, np.abs(qd_ref).max())
-    monkeypatch.setenv("RBD_WALK_PAIR_MIN_BATCH", str(1 << 40))
+    tune(monkeypatch, walk_pair_min_batch=str(1 << 40))
     state1, *_ = make(rbd, model, B, "f32", layout, 77)
     r1 = rbd.DynamicsResult(model, B, dtype=torch.float32, layout=layout)
     rbd.dynamics_(r1, state1, dev(tau, state1), dev(fe, state1), algorithm="aba_walk")
@@ -1427,52 +1423,15 @@ def test_inverse_dynamics_walk_full_size_and_pairs(rbd, oracle, models, monkeypa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", ["aos", "soa"])
-@pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum"])
-def test_dynamics_pipe_f64(rbd, oracle, models, name, layout):
-    """aba_pipe_kernel (a body-step cut into stages on the four SIMDs of a compute unit, 16 states x 4 tracks per wavefront), forced: ragged batch,
-    torques + a wrench on every body + q̇; then no torques / no wrenches; fp64 at the reference's 1e-10."""
-    need(rbd, "aba_pipe")
-    model = models[name]
-    B = 4096 + 5
-    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 93)
-    result = rbd.DynamicsResult(model, B, layout=layout)
-    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_pipe")
-    assert rbd.sync(state) == 0
-    assert rbd.last_kernel(state) == "aba_pipe_kernel"
-    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True, nthreads=NT)
-    got = host(result.vd, state)
-    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max(), np.abs(got).max())
-    assert np.abs(host(result.qd, state) - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
-    rbd.dynamics_(result, state, algorithm="aba_pipe")
-    assert rbd.sync(state) == 0
-    ref = oracle.dynamics(model, q, v, nthreads=NT)
-    got = host(result.vd, state)
-    assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max(), np.abs(got).max())
-
-
-@pytest.mark.gpu
-def test_dynamics_pipe_f32_and_scope(rbd, oracle, models):
-    """fp32: backward error of M v̇ = τ − c on every state; mechanisms outside the mapping's scope (prismatic / fixed / 3-dof joints) are refused, not mis-evaluated."""
-    need(rbd, "aba_pipe")
+def test_removed_mappings_are_refused(rbd, models):
+    """RBD_ALGO_ABA_CHAINS / _TRACKS / _PIPE (the experiments of rounds 1-2, removed): reserved values, RBD_ERR_UNSUPPORTED — never another kernel in disguise."""
     model = models["atlas_floating"]
-    B = 1000
-    state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 94)
-    result = rbd.DynamicsResult(model, B, dtype=TD["f32"])
-    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_pipe")
-    assert rbd.sync(state) == 0
-    got = host(result.vd, state)
-    M, c = oracle.mass_matrix(model, q, nthreads=NT), oracle.dynamics_bias(model, q, v, fe, nthreads=NT)
-    Ms = np.tril(M) + np.transpose(np.tril(M, -1), (0, 2, 1))
-    res = np.einsum("bij,bj->bi", Ms, got) - (tau - c)
-    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(got, axis=1) + np.linalg.norm(tau - c, axis=1))
-    assert eta.max() <= 2e-5, eta.max()
-    for other in ("acrobot_urdf", "randmech1"):
-        m2 = models[other]
-        s2, _, _, t2, _ = make(rbd, m2, 8, "f64", "aos", 95)
-        r2 = rbd.DynamicsResult(m2, 8)
-        with pytest.raises(Exception):
-            rbd.dynamics_(r2, s2, dev(t2, s2), algorithm="aba_pipe")
+    state, q, v, tau, fe = make(rbd, model, 8, "f64", "aos", 5)
+    result = rbd.DynamicsResult(model, 8)
+    for algorithm in ("aba_chains", "aba_tracks", "aba_pipe"):
+        with pytest.raises(rbd._capi.RBDError) as e:
+            rbd.dynamics_(result, state, dev(tau, state), algorithm=algorithm)
+        assert e.value.status == 3
 
 
 @pytest.mark.gpu

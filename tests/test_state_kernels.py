@@ -1,6 +1,6 @@
 """One-lane-per-state kernels against the oracle: the interpreting ones (csrc/rbd_state.hpp: crba_state_kernel, rnea_state_kernel) and the
 ones compiled for the mechanism at run time (csrc/rbd_spec.hpp through rbd_jit.hip: crba_spec, chol_spec, emit_spec; RBD_JIT=0 switches them
-off).  They serve large batches (default: from half a chip-full of wavefronts up); RBD_STATE_MIN_BATCH=1 routes every batch size through them
+off).  They serve large batches (default: from half a chip-full of wavefronts up); RBD_TUNE state_min_batch=1 routes every batch size through them
 here, so that the same small seeded cases the lane-per-body kernels are tested on apply.
 reference: src/mechanism_algorithms.jl:248-272, :387-459, :542-553, :764, :819."""
 import os
@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import tune
 from test_gpu_parity import NT, TD, dev, host, make
 
 pytestmark = pytest.mark.gpu
@@ -17,7 +18,7 @@ IN_SCOPE = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendul
 
 @pytest.fixture(params=["compiled", "interpreted"])
 def states_everywhere(monkeypatch, request):
-    monkeypatch.setenv("RBD_STATE_MIN_BATCH", "1")
+    tune(monkeypatch, state_min_batch="1")
     monkeypatch.setenv("RBD_JIT", "1" if request.param == "compiled" else "0")  # read when a workspace first needs the kernels
     return request.param
 
@@ -183,7 +184,7 @@ def test_compiled_route_is_the_default_and_matches_the_interpreting_one(rbd, ora
 def test_not_positive_definite_is_reported_by_the_compiled_cholesky(rbd, models, monkeypatch):
     """`rbd_cholesky_solve` keeps the dense kernel; the compiled one sits behind mass_matrix! — a NaN configuration must surface as status 8
     (PosDefException's batched analogue) there too, and must not disturb the other states."""
-    monkeypatch.setenv("RBD_STATE_MIN_BATCH", "1")
+    tune(monkeypatch, state_min_batch="1")
     model = models["atlas_floating"]
     B = 64
     state, q, v, tau, _ = make(rbd, model, B, "f32", "aos", 12)
@@ -269,7 +270,7 @@ def test_compiled_aba_random_trees(rbd, oracle):
 def test_compiled_walk_f64(rbd, oracle, models, name, layout, monkeypatch):
     """The walk kernel compiled for the mechanism (aba_walk_spec, fp64; default from 8192 states up) forced at a small ragged batch: torques + a wrench on
     every body + q̇ at the reference's 1e-10; no torques / no wrenches; a gravity other than the mechanism's."""
-    monkeypatch.setenv("RBD_SPEC_WALK_MIN_BATCH", "1")
+    tune(monkeypatch, spec_walk_min_batch="1")
     model = models[name]
     if not rbd.jit_precompile(model, torch.float64)[0]:
         pytest.skip("hiprtc not available")
@@ -296,7 +297,7 @@ def test_compiled_walk_f64(rbd, oracle, models, name, layout, monkeypatch):
 def test_compiled_walk_inverse_dynamics_f64(rbd, oracle, models, name, layout, monkeypatch):
     """rnea_walk_spec (the inverse-dynamics walk kernel compiled for the mechanism, fp64) forced at a small ragged batch: τ with v̇ and wrenches, the per-body
     accelerations and joint wrenches against the oracle's, dynamics_bias!."""
-    monkeypatch.setenv("RBD_SPEC_WALK_MIN_BATCH", "1")
+    tune(monkeypatch, spec_walk_min_batch="1")
     model = models[name]
     if not rbd.jit_precompile(model, torch.float64)[0]:
         pytest.skip("hiprtc not available")
@@ -323,8 +324,8 @@ def test_compiled_walk_inverse_dynamics_f64(rbd, oracle, models, name, layout, m
 def test_compiled_walk_f32(rbd, oracle, models, name, pair, monkeypatch):
     """The fp32 forms of the compiled walk kernels — one state per lane, and two (packed arithmetic; default from 16 385 states) — forced at a small ragged batch:
     dynamics! by its backward error, q̇, inverse_dynamics! with the per-body outputs at fp32 accuracy."""
-    monkeypatch.setenv("RBD_SPEC_WALK_MIN_BATCH", "1")
-    monkeypatch.setenv("RBD_WALK_PAIR_MIN_BATCH", "1" if pair else "1000000000")
+    tune(monkeypatch, spec_walk_min_batch="1")
+    tune(monkeypatch, walk_pair_min_batch="1" if pair else "1000000000")
     model = models[name]
     B = 333
     state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 46)
@@ -354,7 +355,7 @@ def test_compiled_walk_f32(rbd, oracle, models, name, pair, monkeypatch):
 def test_compiled_walk_random_trees(rbd, oracle, monkeypatch):
     """Random revolute / prismatic / fixed / sin-cos trees with and without a 6-dof root (tests/test_jit_cpu.py compiles the same ones on the CPU)."""
     from test_jit_cpu import walk_trees
-    monkeypatch.setenv("RBD_SPEC_WALK_MIN_BATCH", "1")
+    tune(monkeypatch, spec_walk_min_batch="1")
     for trial, model in enumerate(walk_trees(rbd)):
         if not rbd.jit_precompile(model, torch.float64)[0]:
             pytest.skip("hiprtc not available")
