@@ -44,6 +44,9 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 # the with-wrenches leg of a 25 us kernel).  Passive waiting; the timed headline region also runs BEFORE the first oracle call.
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 os.environ.setdefault("GOMP_SPINCOUNT", "0")
+# A benchmark must not start on the interpreting kernels while a mechanism's compiled ones are still being built in the background (the library's default for
+# a cold cache, csrc/rbd_jit.hip): wait for them.  build() compiles the bench mechanisms' ahead of time, so on the driver's box this only loads code objects.
+os.environ.setdefault("RBD_JIT_ASYNC", "0")
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X public spec (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)

@@ -1,5 +1,6 @@
 """BASELINE configs[4]: four-bar linkage (loop joint), batch 4096 fp64 — µs per dynamics! launch (RNEA + CRBA + loop solve), graph-replayed."""
 import json, os, sys
+os.environ.setdefault("RBD_JIT_ASYNC", "0")  # wait for the kernels compiled per mechanism instead of starting on the interpreting ones
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch

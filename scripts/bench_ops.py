@@ -1,6 +1,7 @@
 """Throughput of every hot-path entry point (not the headline line — bench.py is): evals/s and µs per launch, graph-replayed so
 the GPU is the bottleneck.  usage: python scripts/bench_ops.py [--batch 4096] [--dtype f64] [--model atlas_floating]"""
 import argparse, json, os, sys
+os.environ.setdefault("RBD_JIT_ASYNC", "0")  # wait for the kernels compiled per mechanism instead of starting on the interpreting ones
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch

@@ -1,6 +1,7 @@
 """Timing experiments on config 3 (mass_matrix! + tile Cholesky, fp32, 65 536 states): graph-replayed µs per call.
 OP = solve (default: mass_matrix! + Cholesky solve, M emitted) | solve_nom (M_out = None) | mm (mass_matrix! alone)."""
 import os, sys
+os.environ.setdefault("RBD_JIT_ASYNC", "0")  # wait for the kernels compiled per mechanism instead of starting on the interpreting ones
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch

@@ -1,6 +1,7 @@
 """dynamics! through the walk kernel compiled for the mechanism (aba_walk_spec, csrc/rbd_walk.hpp; fp64): parity against the oracle, then graph-replayed µs
 per launch.  Run once as is and once with RBD_TUNE=spec_walk_min_batch=1000000000 (the interpreting walk kernel) to compare."""
 import os, sys
+os.environ.setdefault("RBD_JIT_ASYNC", "0")  # wait for the kernels compiled per mechanism instead of starting on the interpreting ones
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch

@@ -1,5 +1,6 @@
 """`simulate` wall time per RK4 step; run under `rocprofv3 --kernel-trace --stats` for the per-kernel split.  usage: sim_prof.py [B] [f64|f32]"""
 import os, sys, time
+os.environ.setdefault("RBD_JIT_ASYNC", "0")  # wait for the kernels compiled per mechanism instead of starting on the interpreting ones
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
 import torch

@@ -2,6 +2,7 @@
 branch points below branch points, fixed / prismatic / sin-cos joints, with and without a 6-dof root — through aba_spec, rnea_spec, crba_spec (+ the
 sparse Cholesky and the emitter when nv is a multiple of 4) against the oracle.  Every tree costs three hiprtc compilations (seconds each)."""
 import os, sys
+os.environ.setdefault("RBD_JIT_ASYNC", "0")  # wait for the kernels compiled per mechanism instead of starting on the interpreting ones
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 os.environ["RBD_TUNE"] = "state_min_batch=1"

@@ -1,6 +1,7 @@
 """One-off stress: the loop-joint branch of dynamics! on random mechanisms in maximal coordinates (every tree joint re-expressed as a
 loop joint) against the oracle, and against the tree mechanism's body accelerations."""
 import os, sys
+os.environ.setdefault("RBD_JIT_ASYNC", "0")  # wait for the kernels compiled per mechanism instead of starting on the interpreting ones
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch

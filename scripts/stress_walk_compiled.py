@@ -4,6 +4,7 @@ the interpreting walk kernel bit for bit.
     python scripts/stress_walk_compiled.py N --precompile     (no GPU: compiles the N trees' programs into the library's cache; ~1 min per big tree)
     python scripts/stress_walk_compiled.py N                  (GPU)"""
 import os, sys
+os.environ.setdefault("RBD_JIT_ASYNC", "0")  # wait for the kernels compiled per mechanism instead of starting on the interpreting ones
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 os.environ["RBD_TUNE"] = "spec_walk_min_batch=1"

@@ -2,6 +2,7 @@
 """Launch time of `dynamics!` per lane mapping and batch size (Atlas floating): the data behind run_aba's thresholds.
 usage: python scripts/sweep_mappings.py [--batches 512,1024,...] [--dtypes f64,f32] [--algos aba_lanes,aba_banks,aba_walk,aba] [--reps 300]"""
 import argparse, os, sys
+os.environ.setdefault("RBD_JIT_ASYNC", "0")  # wait for the kernels compiled per mechanism instead of starting on the interpreting ones
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rbd_amd as rbd

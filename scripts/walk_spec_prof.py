@@ -1,6 +1,7 @@
 """Profiling driver: fp64 dynamics! / inverse_dynamics! (with the per-body outputs) at 65 536 Atlas states through the walk kernels compiled for the mechanism and
 through the interpreting ones, 40 launches each (scripts/gpu_walk_profile.sh runs it under rocprofv3)."""
 import os, sys
+os.environ.setdefault("RBD_JIT_ASYNC", "0")  # wait for the kernels compiled per mechanism instead of starting on the interpreting ones
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
