@@ -7,5 +7,5 @@ NAME=$1; shift
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -ffp-contract=fast -Wall -Wno-unused-function"
 /opt/rocm/bin/hipcc $FLAGS -c rbd_bank_kernels.hip -o librbd_hip_${NAME}_bank_kernels.o "$@"
 T=librbd_hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o librbd_hip_${NAME}.so ${T}_kernels.o librbd_hip_${NAME}_bank_kernels.o ${T}_track_kernels.o ${T}_walk_kernels.o ${T}_pipe_kernels.o ${T}_state_kernels.o ${T}_contact_kernels.o ${T}_capi.o ${T}_comm.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o librbd_hip_${NAME}.so ${T}_kernels.o librbd_hip_${NAME}_bank_kernels.o ${T}_big_kernels.o ${T}_walk_kernels.o ${T}_state_kernels.o ${T}_contact_kernels.o ${T}_capi.o ${T}_comm.o ${T}_jit.o -ldl
 echo "built librbd_hip_${NAME}.so"
