@@ -815,8 +815,14 @@ RBD_DEV float qsum(float x) {
 RBD_DEV int sel4(int r, int a, int b, int c, int d) { return r == 0 ? a : r == 1 ? b : r == 2 ? c : d; }
 
 
+// Mc (nullable) + mst (LDS, 16 * emit_mst<float>() floats): the caller's M — the WHOLE square per state in the ORIGINAL coordinate order, as emit_spec below
+// writes it — sent on its way from the tiles this wavefront has just loaded for the factorisation, before it factors them.  Round 3 ran emit_spec in front of
+// this function: a second gather of the staged triangle, whose loads sat behind the block's stores in the wavefront's one in-order memory counter (vmcnt counts
+// loads AND stores on gfx9: every block of four columns waited for the previous block's stores to be acknowledged — 9 store round trips per wavefront,
+// 72 us of the launch's 106).  Here nothing is loaded after the first store: tile -> LDS -> whole 16-byte pieces of complete runs, nine blocks back to back,
+// and the stores drain while the wavefront factors.
 RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const float* __restrict__ tau, const float* __restrict__ c,
-                       float* __restrict__ x, Layout Lv, int* __restrict__ notpd) {
+                       float* __restrict__ x, Layout Lv, int* __restrict__ notpd, float* __restrict__ Mc, Layout Lc, float* mst) {
   constexpr int NT = P::NT, NV = P::NV;
   const int lane = threadIdx.x & 63, r = lane & 3;
   const long state_raw = group * 16 + (lane >> 2);
@@ -848,6 +854,52 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
     if (c) b -= c[(long)od[I] * Lv.sk + state * Lv.sb];
     y[I] = b;
   });
+#ifdef RBD_SPEC_EMIT
+  {
+    if (Mc != nullptr) {
+      using V = f32x4;
+      constexpr int MST = 4 * NV + 4, CB = 4 * NV, PCS = CB / 4;  // values per state of the LDS tile; values / 16-byte pieces per state and block of four columns
+      float* const mine = mst + (lane >> 2) * MST;
+      const V zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      sfor<NT>([&](auto Joc) __attribute__((always_inline)) {
+        constexpr int Jo = Joc.value;
+        wave_sync();  // the tile of the block before has been read out
+        for (int i = lane * 4; i < 16 * MST; i += 256) *reinterpret_cast<V*>(mst + i) = zero;
+        wave_sync();
+        sfor<NT>([&](auto Ic) __attribute__((always_inline)) {
+          constexpr int I = Ic.value;
+          // does some row of tile row I stand for a coordinate of block Jo (its entries then also land there as the mirror image)?
+          constexpr bool rows_in = (P::INV[4 * I] >> 2) == Jo || (P::INV[4 * I + 1] >> 2) == Jo || (P::INV[4 * I + 2] >> 2) == Jo || (P::INV[4 * I + 3] >> 2) == Jo;
+          const bool mir = (od[I] >> 2) == Jo;
+          float* const mrow = mine + (od[I] & 3) * NV;  // mirror image: column od[I] of the block, row = the entry's column coordinate
+          sfor<I + 1>([&](auto Jc) __attribute__((always_inline)) {
+            constexpr int J = Jc.value;
+            if constexpr (P::TMASK[I][J] != 0) {
+              sfor<4>([&](auto ccc) __attribute__((always_inline)) {
+                constexpr int cc = ccc.value, co = P::INV[4 * J + cc];  // the entry (od[I], co) of the original matrix
+                const bool part = (I != J) || (cc <= r);                // the diagonal tile holds its lower half
+                if constexpr ((co >> 2) == Jo) {
+                  if (part) mine[(co - 4 * Jo) * NV + od[I]] = t[I][J][cc];
+                }
+                if constexpr (rows_in) {
+                  if (mir && part && !(I == J && cc == r)) mrow[co] = t[I][J][cc];
+                }
+              });
+            }
+          });
+        });
+        wave_sync();
+#pragma unroll 3
+        for (int c0 = 0; c0 < 16 * PCS; c0 += 64) {
+          const int ch = c0 + lane, st = ch / PCS, piece = ch - st * PCS;
+          const long g2 = group * 16 + st;
+          if (ch < 16 * PCS && g2 < B)
+            __builtin_nontemporal_store(*reinterpret_cast<const V*>(mst + st * MST + piece * 4), reinterpret_cast<V*>(Mc + g2 * Lc.sb + (long)Jo * CB + piece * 4));
+        }
+      });
+    }
+  }
+#endif
   bool bad = false;
   sfor<NT>([&](auto Jc) __attribute__((always_inline)) {
     constexpr int J = Jc.value;
