@@ -21,6 +21,7 @@
 #include "rbd_reroot.hpp"
 #include "rbd_state_plan.hpp"
 #include "rbd_jit.hpp"
+#include "rbd_mk_fuse.hpp"
 enum { BANK_LDS_PAIRS_HOST = 30 };  // = BANK_LDS_PAIRS of rbd_bank.hpp (16 parked + 14 exchange pairs per lane; checked in rbd_bank_kernels.hip)
 
 using namespace rbd;
@@ -73,6 +74,7 @@ struct rbd_model {
   int32_t row_words = 1;
   std::vector<rbd_loop_joint_t> loops;
   std::vector<int32_t> loop_i, loop_path, jt_ref, voff_ref, parent_ref, qoff_ref;  // loop tables (reference body indices)
+  std::vector<int32_t> mk1, mkf;  // the joints as the integrator stage folded into the compiled dynamics! kernels sees them (rbd_mk_fuse.hpp)
   bool loop_fused_ok = false;
   bool big = false;  // more than 64 bodies: only the any-size kernels of rbd_big_kernels.hip apply (reference-order tables below)
   std::vector<int32_t> big_tbl;
@@ -432,6 +434,11 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   m->parent_ref.assign(d->parent, d->parent + nb);
   m->voff_ref.assign(d->v_offset, d->v_offset + nb);
   m->qoff_ref.assign(d->q_offset, d->q_offset + nb);
+  for (int i = 0; i < nb; ++i) {
+    const int jt = d->joint_type[i];
+    if (jt == RBD_JOINT_QUAT_FLOATING) { m->mkf.push_back(d->q_offset[i]); m->mkf.push_back(d->v_offset[i]); }
+    else if (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_PRISMATIC || jt == RBD_JOINT_SINCOS_REVOLUTE) { m->mk1.push_back(d->q_offset[i]); m->mk1.push_back(d->v_offset[i]); m->mk1.push_back(jt); }
+  }
   m->loop_fused_ok = d->n_loops > 0 && nb <= 4 && m->nv <= 4;
   for (int i = 0; i < nb && m->loop_fused_ok; ++i) {
     const int t = d->joint_type[i];
@@ -1139,6 +1146,7 @@ static bool walk_tables(const rbd_model* m, bool rerooted, WalkTables* W) {
   *W = WalkTables{};
   W->ns = P->ns; W->G = P->G; W->nA = P->nA; W->nB = P->nB; W->nS = K->nS; W->nq = m->nq; W->nv = m->nv; W->flt = P->has_floating; W->gen = P->general; W->rr = rerooted;
   W->ri = &P->ri; W->wk = &K->wk; W->rrc = &P->rr;
+  W->mk1 = &m->mk1; W->mkf = &m->mkf;
   for (int k = 0; k < 5; ++k) { W->sfm[k] = 0; for (int s2 = 0; s2 < P->ns; ++s2) W->sfm[k] |= (uint64_t)((P->sf[s2] >> k) & 1) << s2; }
   if (rerooted) {
     W->nchain = (int)(m->rr.chain_i.size() / RC_I_STRIDE); W->fq = m->rr.fq; W->fv = m->rr.fv; W->chain_i = &m->rr.chain_i; W->chain_r = &m->rr.chain_r; W->fXp = m->rr.fXp;
@@ -1328,8 +1336,11 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
 // The fused articulated-body pass through whichever lane mapping fits: `algorithm` RBD_ALGO_ABA chooses by batch size
 // (measured crossovers, profiles/r01_mapping_sweep.txt), the RBD_ALGO_ABA_* values force one.  `gravity` overrides the
 // model's (the M^-1 solve runs the pass with g = 0); `fuse` folds a Munthe-Kaas stage into the launch (lanes / banks only).
+static const MkStage kNoStage{-1, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+// `mk` (simulate_core): the launch is a stage of a Munthe-Kaas step folded into a kernel compiled for the mechanism (rbd_mk_fuse.hpp) — only those kernels take it:
+// RBD_ERR_UNSUPPORTED when the batch would go to another kernel (the caller then keeps the stage in its own launches)
 static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd,
-                   Layout Lq, Layout Lv, Layout Lf, const double* gravity, const MkFuse* fuse) {
+                   Layout Lq, Layout Lv, Layout Lf, const double* gravity, const MkFuse* fuse, const MkStage* mk = nullptr) {
   const rbd_model* m = w->model;
   const bool can_bank = m->bank_lps > 0 && m->bank_aba_ok;
   // the track kernel addresses its batch buffers with 32-bit byte offsets
@@ -1346,7 +1357,8 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
       long Bl = B;
       const double* gv = gravity ? gravity : m->gravity;
       float gx = (float)gv[0], gy = (float)gv[1], gz = (float)gv[2];
-      void* args[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf, &gx, &gy, &gz};
+      MkStage F = mk ? *mk : kNoStage;
+      void* args[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf, &gx, &gy, &gz, &F};
       HIP_TRY(hipModuleLaunchKernel(w->spec_aba, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
       w->last_kernel = "aba_spec_f32 (compiled for the mechanism at run time)";
       return RBD_OK;
@@ -1360,6 +1372,7 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     const bool no_rr = w->no_reroot;
     if (spec_walk(w, w->walk_rr && !no_rr && w->walk_rr_lds_bytes > 0, 0, 0)) pick = RBD_ALGO_ABA_WALK;
   }
+  if (mk && pick != RBD_ALGO_ABA_WALK) return RBD_ERR_UNSUPPORTED;
   Timed t(w);
   w->last_kernel = pick == RBD_ALGO_ABA_BANKS ? "aba_bank_kernel" : "aba_kernel";
   if (pick == RBD_ALGO_ABA_WALK) {
@@ -1377,10 +1390,12 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
       long Bl = B;
       Layout lq = Lq, lv = Lv, lf = Lf;
       double gx = wm.gravity[0], gy = wm.gravity[1], gz = wm.gravity[2];
-      void* args[] = {&Bl, (void*)&dq, (void*)&dv, (void*)&dtau, (void*)&df, (void*)&dvd, (void*)&dqd, &lq, &lv, &lf, &gx, &gy, &gz};
+      MkStage F = mk ? *mk : kNoStage;
+      void* args[] = {&Bl, (void*)&dq, (void*)&dv, (void*)&dtau, (void*)&df, (void*)&dvd, (void*)&dqd, &lq, &lv, &lf, &gx, &gy, &gz, &F};
       const long per = pair ? 128 : 64;
       HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + per - 1) / per), 1, 1, 64u * (unsigned)wm.G, 1, 1, 0, w->stream, args, nullptr));
-    } else
+    } else if (mk) return RBD_ERR_UNSUPPORTED;
+    else
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, TP.has_floating, TP.general, 0, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_aba_walk<float>(wm, TP.has_floating, TP.general, pair, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
   } else if (pick == RBD_ALGO_ABA_BANKS) {
@@ -1843,8 +1858,29 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   // large batches: the walk kernel (one wavefront per track, §3.4 of DESIGN.md) with the stage bookkeeping in its own launches beats the
   // lane-per-body kernels with the stage fused in (fp64 Atlas, 65 536 states: 4 x 147 us + 5 stage launches vs 4 x 290 us)
   const bool walk_sim = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && m->track.ok && m->walk.ok && w->walk_lds_bytes > 0 && B >= w->walk_min_batch;
-  const bool fused = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && !walk_sim;
   const Layout Lf = layout_of(o.layout, 6L * m->nb, B);
+  // ... and when the batch goes to a kernel COMPILED for the mechanism (aba_walk_spec, aba_spec_f32), the stage is folded into that launch (rbd_mk_fuse.hpp):
+  // four launches per step and nothing else.  The first launch decides: a kernel that takes the stage runs it, any other returns RBD_ERR_UNSUPPORTED untouched.
+  bool spec_sim = false;
+  for (int step = 0; walk_sim && step < nsteps; ++step) {
+    for (int stage = 0; stage < 4; ++stage) {
+      const MkStage F{stage, pd ? 1 : 0, dt, w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.vd[0], dq, dv, ctl.kp, ctl.kd, ctl.q_des};
+      st = run_aba(w, B, RBD_ALGO_ABA, dq, dv, tau_at(step, stage), df, nullptr, nullptr, Lq, Lv, Lf, nullptr, nullptr, &F);
+      if (st == RBD_ERR_UNSUPPORTED && step == 0 && stage == 0) break;
+      if (st) return st;
+      spec_sim = true;
+    }
+    if (!spec_sim) break;
+  }
+  if (spec_sim) {
+    w->last_kernel = w->dtype == RBD_F32 && B >= w->spec_aba_min_batch && w->spec_aba ? "aba_spec_f32 with the Munthe-Kaas stage folded in (compiled for the mechanism at run time)"
+                                                                                   : "aba_walk_spec with the Munthe-Kaas stage folded in (compiled for the mechanism)";
+    if (o.memory == RBD_MEM_HOST) {
+      if ((st = stage_out_copy(w, q, dq, es * m->nq * B)) || (st = stage_out_copy(w, v, dv, es * m->nv * B))) return st;
+    }
+    return RBD_OK;
+  }
+  const bool fused = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && !walk_sim;
   for (int step = 0; fused && step < nsteps; ++step) {
     // tree mechanism, articulated-body route: each of the four stages is ONE launch (stage bookkeeping — and the PD law, on the stage state —
     // fused into the ABA kernel; the closing stage of a step rides in the first launch of the next one; only the last step closes on its own)

@@ -33,6 +33,7 @@ struct WalkTables {
   const std::vector<int32_t>* chain_i;
   const std::vector<double>* chain_r;
   const double* fXp;
+  const std::vector<int32_t>*mk1, *mkf;  // the joints as rbd_mk_fuse.hpp sees them: (q offset, v offset, type) of the 1-dof ones, (q offset, v offset) of the 6-dof ones
 };
 bool walk_spec_has(int dtype, int ns, int G, size_t lds_rows_bytes);
 size_t walk_spec_lds_bytes(const WalkTables& W, int dtype, int pair = 0);

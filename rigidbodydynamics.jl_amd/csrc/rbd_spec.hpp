@@ -22,6 +22,9 @@
 // permuted lower triangle holds a non-zero), EMIT_KMAX, EMIT_K[NT], and __constant__ unsigned EMIT[NT][4 * EMIT_KMAX] (staged entry << 16 | slot in the tile).
 #pragma once
 #include "rbd_device.hpp"
+#ifdef RBD_SPEC_ABA
+#include "rbd_mk_fuse.hpp"
+#endif
 
 namespace rbd {
 namespace spec {
@@ -292,7 +295,7 @@ template <typename T> struct Hand { T I[21], p[6]; };
 
 template <typename T>
 RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau, const T* __restrict__ fext,
-                      T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T gx, T gy, T gz, T* lds) {
+                      T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T gx, T gy, T gz, T* lds, const MkStage& F) {
   constexpr int NQ = P::NQ, NV = P::NV, NB = P::NB, NBS = P::NBS > 0 ? P::NBS : 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* rq = lds + (size_t)wave * ABA_ROWS * RS;
@@ -313,6 +316,13 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
     for (int k = 0; k < NV; ++k) rt[k * RS + lane] = T(0);
   }
   wave_sync();
+  // `simulate`: this launch is stage F.stage of a Munthe-Kaas RK4 step (rbd_mk_fuse.hpp): the next stage's q from the staged rows before the passes, its v
+  // from the v̇ rows behind them — the wavefront's own 64 states, no launch of its own
+  auto cell = [&](int row, int st) __attribute__((always_inline)) { return rq + row * RS + st; };
+  if (F.stage >= 0) {  // uniform
+    mk_prologue<T, P::MK_N1, P::MK_NF>(F, cell, P::MK1, P::MKF, 0, NQ, NQ + NV, state0, B, 64, Lq, Lv, lane, 64);
+    wave_sync();  // (the PD law wrote into the τ rows)
+  }
   const T* qs = rq + lane;
   T* vs = rv + lane;
   T* ts = rt + lane;
@@ -573,7 +583,8 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
     }
   });
   wave_sync();
-  rows_out<T, NV>(rt, vdot, Lv, state0, B);
+  if (F.stage >= 0) mk_epilogue<T, NV>(F, cell, NQ + NV, state0, B, 64, Lv, lane, 64);
+  if (vdot) rows_out<T, NV>(rt, vdot, Lv, state0, B);
 }
 
 constexpr int next_enter(int o) {  // the first ENTER op after op o, or -1

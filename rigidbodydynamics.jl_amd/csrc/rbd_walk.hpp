@@ -25,6 +25,7 @@
 #pragma once
 #include "rbd_device.hpp"
 #include "rbd_walk_plan.hpp"
+#include "rbd_mk_fuse.hpp"
 
 namespace rbd {
 
@@ -1186,8 +1187,10 @@ RBD_DEV void aba_walk_spec_track(const WalkCtx<T>& c, long B, const typename Lan
 template <typename T, bool FLT, bool GEN, bool RR, typename PLAN>
 RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v, const typename Lanes<T>::S* __restrict__ tau,
                            const typename Lanes<T>::S* __restrict__ fext, typename Lanes<T>::S* __restrict__ vdot, typename Lanes<T>::S* __restrict__ qdot, Layout Lq,
-                           Layout Lv, Layout Lf, double gx, double gy, double gz, unsigned char* lds) {
+                           Layout Lv, Layout Lf, double gx, double gy, double gz, unsigned char* lds, const MkStage& F = MkStage{-1, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
+                           const int32_t* mk1 = nullptr, const int32_t* mkf = nullptr) {
   constexpr int N = Lanes<T>::N, NQ = PLAN::NQ, NV = PLAN::NV;
+  using S = typename Lanes<T>::S;
   WalkCtx<T> c;
   walk_ctx_spec<T, PLAN>(c, lds);
   c.a0[0] = T(0); c.a0[1] = T(0); c.a0[2] = T(0);
@@ -1214,6 +1217,12 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
     }
   }
   __syncthreads();
+  // `simulate`: this launch is stage F.stage of a Munthe-Kaas RK4 step (rbd_mk_fuse.hpp) — the next stage's q from the staged rows before the passes ...
+  auto cell = [&](int row, int st) __attribute__((always_inline)) { return reinterpret_cast<S*>(c.rows + (long)row * WR_STRIDE + (st & 63)) + (st >> 6); };
+  if (F.stage >= 0) {  // uniform
+    mk_prologue<S, PLAN::MK_N1, PLAN::MK_NF>(F, cell, mk1, mkf, c.rq, c.rv, c.rt, state0, B, 64 * N, Lq, Lv, tid, nth);
+    __syncthreads();  // (the PD law wrote into the τ rows)
+  }
   // WalkStash addresses accumulation registers by number, which the compiler does not see: rbd_jit.hip checks in the code object's metadata that the register
   // allocator took NONE of its own, then rewrites the kernel descriptor to cover all 256 (jit_kd_cover_agprs) — no `a255` clobber here, the compiler must not
   // know (with it the metadata could no longer tell the allocator's registers from the stash's; round 3 compiled every program twice for that).
@@ -1223,6 +1232,7 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
     if (g == GI) aba_walk_spec_track<T, FLT, GEN, RR, PLAN, GI>(c, B, fext, want_qdot, Lf, state0, lane);
   });
   __syncthreads();
+  if (F.stage >= 0) mk_epilogue<S, NV>(F, cell, c.rt, state0, B, 64 * N, Lv, tid, nth);  // ... and its v from the v̇ rows behind them
   if (fast) {
     walk_stage_out_fast<T, 10 * N>(vdot, state0, NV, c.rows, c.rt, tid, nth);
     walk_stage_out_fast<T, 10 * N>(qdot, state0, NQ, c.rows, c.rq, tid, nth);

@@ -528,6 +528,68 @@ def test_simulate_device_side_controllers(rbd, oracle, models, path, monkeypatch
     assert ("walk" in k) == (path == "unfused"), k
 
 
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("kernel", ["walk_spec_f64", "walk_spec_f32", "walk_spec_f32x2", "aba_spec_f32"])
+def test_simulate_stage_folded_into_the_compiled_kernels(rbd, oracle, models, kernel, layout, monkeypatch):
+    """Large batches: the Munthe-Kaas stage of `simulate` (src/ode_integrators.jl:233-299) inside the dynamics! kernels compiled for the mechanism
+    (csrc/rbd_mk_fuse.hpp: four launches per step, no stage kernels) — forced at a small ragged batch so that states can be compared with the numpy
+    restatement of the integrator: Atlas with its floating base (the SE(3) log / exp path), constant torques, the torque table at the stage times, the PD law
+    on the stage state; fp64 at 1e-10, fp32 against the fp64 oracle."""
+    import simulate_np
+    dtype = "f64" if kernel.endswith("f64") else "f32"
+    knobs = dict(walk_min_batch=1, spec_walk_min_batch=1, walk_pair_min_batch=1 if kernel == "walk_spec_f32x2" else 1 << 40,
+                 spec_aba_min_batch=1 if kernel == "aba_spec_f32" else 1 << 40)
+    tune(monkeypatch, **knobs)
+    model = models["atlas_floating"]
+    B, dt, nsteps = 70, 1e-3, 3
+    T = (nsteps - 0.5) * dt
+    state, q, v, tau, _ = make(rbd, model, B, dtype, layout, 91, fext=False)
+    sel = np.r_[0:3, B - 2:B]  # (the oracle integrates one state at a time)
+    tq, tv = (1e-10, 1e-9) if dtype == "f64" else (2e-5, 2e-3)
+
+    def check(ref, what):
+        assert "Munthe-Kaas stage folded in" in rbd.last_kernel(state) and ("aba_spec_f32" in rbd.last_kernel(state)) == (kernel == "aba_spec_f32"), rbd.last_kernel(state)
+        qg, vg = host(state.q, state)[sel], host(state.v, state)[sel]
+        assert np.isfinite(host(state.q, state)).all() and np.isfinite(host(state.v, state)).all(), what
+        assert np.abs(canon_q(model, qg) - canon_q(model, ref[1])).max() <= tq * max(1.0, np.abs(ref[1]).max()), what
+        assert np.abs(vg - ref[2]).max() <= tv * max(1.0, np.abs(ref[2]).max()), what
+
+    def reset():
+        rbd.set_configuration_(state, q); rbd.set_velocity_(state, v)
+
+    try:
+        rbd.simulate_(state, T, dt=dt, torques=dev(tau, state))
+    except rbd._capi.RBDError as e:
+        if e.status == 3:
+            pytest.skip("hiprtc not available")
+        raise
+    if "folded in" not in rbd.last_kernel(state):
+        pytest.skip("no compiled kernel for this route on this box: " + rbd.last_kernel(state))
+    check(simulate_np.simulate(model, q[sel], v[sel], T, dt, tau[sel]), "constant torques")
+    # the torque table sampled at the four stage times
+    rng = np.random.default_rng(92)
+    A, om, ph = rng.random((B, model.nv)), 40 * rng.random((B, model.nv)), rng.random((B, model.nv))
+    stage_t = np.array([k * dt + c * dt for k in range(nsteps) for c in (0.0, 0.5, 0.5, 1.0)])
+    table = np.stack([A * np.sin(om * t + ph) for t in stage_t]).astype(ND[dtype])  # (4 nsteps, B, nv)
+    tab_dev = torch.as_tensor(table if layout == "aos" else np.ascontiguousarray(table.transpose(0, 2, 1))).cuda()
+    reset()
+    rbd.simulate_(state, T, control_=rbd.TorqueTable(tab_dev, per_stage=True), dt=dt)
+    tau_of = lambda b, t: (A[sel][b] * np.sin(om[sel][b] * t + ph[sel][b])).astype(ND[dtype]).astype(np.float64)
+    check(simulate_np.simulate(model, q[sel], v[sel], T, dt, control=lambda b, t, qq, vv: tau_of(b, t)), "torque table")
+    # the PD law on the stage state, with a feed-forward term (revolute joints; the floating base takes the feed-forward term alone)
+    kp, kd = (2 * rng.random(model.nv)).astype(ND[dtype]).astype(np.float64), (0.02 * rng.random(model.nv)).astype(ND[dtype]).astype(np.float64)
+    qdes = (0.3 * rng.standard_normal((B, model.nq))).astype(ND[dtype]).astype(np.float64)
+    tff = rng.random((B, model.nv)).astype(ND[dtype]).astype(np.float64)
+    reset()
+    rbd.simulate_(state, T, control_=rbd.PDControl(torch.as_tensor(kp), torch.as_tensor(kd), dev(qdes, state), dev(tff, state)), dt=dt)
+    one = np.array([0.0 if t == 3 else 1.0 for t in model.joint_type for _ in range({0: 0, 3: 6}.get(int(t), 1))])  # 1-dof coordinates (v indexing)
+    qidx = np.array([int(model.q_offset[b]) for b in range(model.n_bodies) for _ in range({0: 0, 3: 6}.get(int(model.joint_type[b]), 1))])  # q coordinate of a 1-dof v coordinate
+
+    def pd(b, t, qq, vv):
+        return tff[sel][b] - one * (kp * (qq[qidx] - qdes[sel][b][qidx]) + kd * vv)
+    check(simulate_np.simulate(model, q[sel], v[sel], T, dt, control=pd), "PD law")
+
+
 def test_simulate_four_bar_loops(rbd, oracle, models):
     """The loop-joint branch inside the integrator: closure is kept (no stabilization) like test/test_simulate.jl:203-213, here
     for 0.1 s on the GPU, against the oracle's integration of the same states."""
