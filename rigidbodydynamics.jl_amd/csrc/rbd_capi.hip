@@ -1862,7 +1862,8 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   // ... and when the batch goes to a kernel COMPILED for the mechanism (aba_walk_spec, aba_spec_f32), the stage is folded into that launch (rbd_mk_fuse.hpp):
   // four launches per step and nothing else.  The first launch decides: a kernel that takes the stage runs it, any other returns RBD_ERR_UNSUPPORTED untouched.
   bool spec_sim = false;
-  for (int step = 0; walk_sim && step < nsteps; ++step) {
+  const bool try_spec_sim = walk_sim && tune("sim_fuse", 1) != 0;  // (RBD_TUNE sim_fuse=0: the stage in its own launches, for A/B measurements)
+  for (int step = 0; try_spec_sim && step < nsteps; ++step) {
     for (int stage = 0; stage < 4; ++stage) {
       const MkStage F{stage, pd ? 1 : 0, dt, w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.vd[0], dq, dv, ctl.kp, ctl.kd, ctl.q_des};
       st = run_aba(w, B, RBD_ALGO_ABA, dq, dv, tau_at(step, stage), df, nullptr, nullptr, Lq, Lv, Lf, nullptr, nullptr, &F);

@@ -304,6 +304,8 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   T* rx = rt + NV * RS;  // max(NQ, NB) rows: q̇ on its way out first, then one value per body for the top-down pass
   const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
   if (state0 >= B) return;
+  MkPre<T, (P::MK_N1 > 0 ? P::MK_N1 : 1)> mkp;  // `simulate`: the stage's loads of the base point and the running sums go out ahead of the staging (rbd_mk_fuse.hpp)
+  if (F.stage >= 0) mk_pre_load<T, P::MK_N1, P::MK_NF, (P::MK_N1 > 0 ? P::MK_N1 : 1)>(F, mkp, P::MK1, P::MKF, state0, B, 64, Lq, Lv, lane, 64);
   rows_in<T, NQ>(q, Lq, state0, B, rq);
   if (v) rows_in<T, NV>(v, Lv, state0, B, rv);
   else {  // (the M^-1 rhs pass: v = 0)
@@ -320,7 +322,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   // from the v̇ rows behind them — the wavefront's own 64 states, no launch of its own
   auto cell = [&](int row, int st) __attribute__((always_inline)) { return rq + row * RS + st; };
   if (F.stage >= 0) {  // uniform
-    mk_prologue<T, P::MK_N1, P::MK_NF>(F, cell, P::MK1, P::MKF, 0, NQ, NQ + NV, state0, B, 64, Lq, Lv, lane, 64);
+    mk_prologue<T, P::MK_N1, P::MK_NF, (P::MK_N1 > 0 ? P::MK_N1 : 1)>(F, mkp, cell, P::MK1, P::MKF, 0, NQ, NQ + NV, state0, B, 64, Lq, Lv, lane, 64);
     wave_sync();  // (the PD law wrote into the τ rows)
   }
   const T* qs = rq + lane;
@@ -583,7 +585,11 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
     }
   });
   wave_sync();
-  if (F.stage >= 0) mk_epilogue<T, NV>(F, cell, NQ + NV, state0, B, 64, Lv, lane, 64);
+  if (F.stage >= 0) {
+    MkPost<T, NV> mkq;
+    mk_post_load<T, NV, NV>(F, mkq, state0, B, 64, Lv, lane, 64);
+    mk_epilogue<T, NV, NV>(F, mkq, cell, NQ + NV, state0, B, 64, Lv, lane, 64);
+  }
   if (vdot) rows_out<T, NV>(rt, vdot, Lv, state0, B);
 }
 

@@ -1201,6 +1201,8 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
   const bool inside = state0 + 64 * N <= B;  // wave-uniform
   const bool fast = Lq.sk == 1 && Lv.sk == 1 && inside;
   const bool fast_rows = Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && inside && !fast;
+  // `simulate`: this launch is stage F.stage of a Munthe-Kaas RK4 step (rbd_mk_fuse.hpp).  Its loads of the base point and the running sums go out ahead of the staging
+  constexpr int MKU = (PLAN::MK_N1 * N + PLAN::G - 1) / PLAN::G > 0 ? (PLAN::MK_N1 * N + PLAN::G - 1) / PLAN::G : 1, MKE = (NV * N + PLAN::G - 1) / PLAN::G;
   {
     constexpr int UB = 10 * N;
     if (fast) {
@@ -1216,12 +1218,14 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
       }
     }
   }
+  MkPre<S, MKU> mkp;  // (its loads of the base point and the running sums go out together, ahead of the barrier that ends the staging)
+  if (F.stage >= 0) mk_pre_load<S, PLAN::MK_N1, PLAN::MK_NF, MKU>(F, mkp, mk1, mkf, state0, B, 64 * N, Lq, Lv, tid, nth);
   __syncthreads();
-  // `simulate`: this launch is stage F.stage of a Munthe-Kaas RK4 step (rbd_mk_fuse.hpp) — the next stage's q from the staged rows before the passes ...
+  // ... the next stage's q from the staged rows before the passes ...
   auto cell = [&](int row, int st) __attribute__((always_inline)) { return reinterpret_cast<S*>(c.rows + (long)row * WR_STRIDE + (st & 63)) + (st >> 6); };
   if (F.stage >= 0) {  // uniform
-    mk_prologue<S, PLAN::MK_N1, PLAN::MK_NF>(F, cell, mk1, mkf, c.rq, c.rv, c.rt, state0, B, 64 * N, Lq, Lv, tid, nth);
-    __syncthreads();  // (the PD law wrote into the τ rows)
+    mk_prologue<S, PLAN::MK_N1, PLAN::MK_NF, MKU>(F, mkp, cell, mk1, mkf, c.rq, c.rv, c.rt, state0, B, 64 * N, Lq, Lv, tid, nth);
+    if (F.pd) __syncthreads();  // (the PD law wrote into the τ rows)
   }
   // WalkStash addresses accumulation registers by number, which the compiler does not see: rbd_jit.hip checks in the code object's metadata that the register
   // allocator took NONE of its own, then rewrites the kernel descriptor to cover all 256 (jit_kd_cover_agprs) — no `a255` clobber here, the compiler must not
@@ -1231,8 +1235,10 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
     constexpr int GI = decltype(gi)::value;
     if (g == GI) aba_walk_spec_track<T, FLT, GEN, RR, PLAN, GI>(c, B, fext, want_qdot, Lf, state0, lane);
   });
+  MkPost<S, MKE> mkq;
+  if (F.stage >= 0) mk_post_load<S, NV, MKE>(F, mkq, state0, B, 64 * N, Lv, tid, nth);  // (requested while the other tracks finish)
   __syncthreads();
-  if (F.stage >= 0) mk_epilogue<S, NV>(F, cell, c.rt, state0, B, 64 * N, Lv, tid, nth);  // ... and its v from the v̇ rows behind them
+  if (F.stage >= 0) mk_epilogue<S, NV, MKE>(F, mkq, cell, c.rt, state0, B, 64 * N, Lv, tid, nth);  // ... and its v from the v̇ rows behind them
   if (fast) {
     walk_stage_out_fast<T, 10 * N>(vdot, state0, NV, c.rows, c.rt, tid, nth);
     walk_stage_out_fast<T, 10 * N>(qdot, state0, NQ, c.rows, c.rq, tid, nth);
