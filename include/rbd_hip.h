@@ -377,7 +377,8 @@ int rbd_version(void);
  * One program per family of kernels and scalar type — family 0: mass_matrix! (+ the sparse tile Cholesky and the emitter of M in fp32), 1: dynamics!
  * (fp32), 2: inverse_dynamics! / dynamics_bias! (fp32; fp64), 3: the whole loop-joint branch of dynamics! for small loop mechanisms (<= 4 bodies, nv <= 4,
  * nc <= 6: the four-bar linkage), 4 / 5: the one-wavefront-per-track kernels of dynamics! / inverse_dynamics! (batches beyond what the two-bodies-per-lane kernels hold at once), 6 / 7: the same with two
- * fp32 states per lane — each compiled when a workspace first takes that route.
+ * fp32 states per lane, 8: the two-bodies-per-lane kernels themselves (small batches — the bench workload — with the loops over the tree's levels unrolled against the
+ * mechanism's level structure) — each compiled when a workspace first takes that route.
  * rbd_jit_precompile compiles all of a model's programs of one scalar type (RBD_F32 / RBD_F64) into the cache ahead of time (no device needed);
  * rbd_jit_source returns the generated source of one (length without the terminator; buf may be NULL; -1: no such program for this mechanism). */
 int rbd_jit_precompile(const rbd_model_t* model, int32_t dtype, char* log, int64_t log_capacity);

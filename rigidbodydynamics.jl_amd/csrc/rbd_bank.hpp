@@ -35,6 +35,28 @@
 #define RBD_BANK_HANDOFF_LDS 0  // 1: every bottom-up hand-off through the exchange columns
 #endif
 
+// Experiment (scripts/build_bank_variant.sh fixed -DRBD_BANK_FIXED_NL=11 -DRBD_BANK_FIXED_L0=5 "-DRBD_BANK_FIXED_NS=0,3,1,1,3,1,1,1,1,1,1"): the level structure of ONE
+// mechanism as compile-time constants and the level loops unrolled — what a per-mechanism compilation of this kernel (as rbd_jit.hip does for the large-batch
+// kernels) would know: which levels hop by DPP and which through the exchange columns, how many later children a gather visits.  Measured in round 4: see DESIGN.md §3.5.
+#ifdef RBD_BANK_FIXED_NL
+#define RBD_BANK_UNROLL _Pragma("unroll")
+namespace rbd { constexpr int kBankNs[] = {RBD_BANK_FIXED_NS}; }
+#define RBD_BK_NL RBD_BANK_FIXED_NL
+#define RBD_BK_L0 RBD_BANK_FIXED_L0
+#define RBD_BK_NS(l) kBankNs[l]
+#ifdef RBD_BANK_FIXED_PERM
+#define RBD_BK_PERM(l) (((RBD_BANK_FIXED_PERM) >> (l)) & 1ull)
+#else
+#define RBD_BK_PERM(l) (kBankNs[l] > 1)
+#endif
+#else
+#define RBD_BANK_UNROLL _Pragma("unroll 1")
+#define RBD_BK_NL M.nlevels
+#define RBD_BK_L0 M.L0
+#define RBD_BK_NS(l) ns_next(nss, M.ns_desc)
+#define RBD_BK_PERM(l) ((M.perm_down >> (l)) & 1)
+#endif
+
 namespace rbd {
 
 template <typename T> struct alignas(2 * sizeof(T)) Pair2 { T a, b; };
@@ -160,9 +182,9 @@ RBD_DEV void bank_fk_commit(bool mine, BankRegs<T>& c, const T* k18 /* the paren
 }
 // level l inside a bank.  On most levels every body is the first child of its parent = the previous lane: (R, p, Tw) arrive by DPP.  On the
 // levels where some body is a later child (perm_down) the parents leave theirs in their exchange column and every child reads its parent's.
-template <typename T, bool SIMPLE> RBD_DEV void bank_fk_step(const BankModel& M, int l, BankRegs<T>& c, Pair2<T>* lds, const T* XR, const T* Xp, const T* tl) {
+template <typename T, bool SIMPLE> RBD_DEV void bank_fk_step(const BankModel& M, int l, bool perm, BankRegs<T>& c, Pair2<T>* lds, const T* XR, const T* Xp, const T* tl) {
   T k18[18];
-  if (RBD_BANK_FK_LDS || ((M.perm_down >> l) & 1)) {  // uniform
+  if (RBD_BANK_FK_LDS || perm) {  // uniform
     if (c.b.level == l - 1 && c.b.nchild >= 1) {
       RBD_KEEP_BRANCH();
       lds_put<T, 18>(lds + threadIdx.x, PK_XCH, c.K);
@@ -278,9 +300,9 @@ template <typename T> RBD_DEV void bank_joint_accel(bool mine, BankRegs<T>& r, c
   r.vd[0] = mine ? x : r.vd[0];
 }
 // top-down acceleration step at level l inside a bank (same hop rules as bank_fk_step)
-template <typename T> RBD_DEV void bank_accel_step(const BankModel& M, int l, BankRegs<T>& c, Pair2<T>* lds) {
+template <typename T> RBD_DEV void bank_accel_step(const BankModel& M, int l, bool perm, BankRegs<T>& c, Pair2<T>* lds) {
   T ap[6];
-  if (RBD_BANK_FK_LDS || ((M.perm_down >> l) & 1)) {  // uniform
+  if (RBD_BANK_FK_LDS || perm) {  // uniform
     if (c.b.level == l - 1 && c.b.nchild >= 1) {
       RBD_KEEP_BRANCH();
       lds_put<T, 6>(lds + threadIdx.x, PK_XCH, c.acc);
@@ -307,12 +329,12 @@ template <typename T> struct InPtr<T, true> { typedef const T* __restrict__ type
 
 // FUSED: the launch is also a stage of a Munthe-Kaas RK4 step (`simulate`): q / v alias F.q_state / F.v_state, so no __restrict__ on them.
 // SIMPLE: every tree joint is revolute, apart from 6-dof joints on the world (BankModel::simple, set by the host).
+// (aba_bank_body: the kernel's code; aba_bank_kernel below wraps it for the build-time instantiations, rbd_jit.hip's program wraps it per mechanism with
+// RBD_BANK_FIXED_* defined — the level loops unrolled against the mechanism's own level structure: 19.5 -> 16.7 us at 4096 fp64 Atlas states)
 template <typename T, bool FUSED, bool SIMPLE>
-__global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel M, long B, typename InPtr<T, !FUSED>::type q, typename InPtr<T, !FUSED>::type v,
-                                                         const T* __restrict__ tau, const T* __restrict__ fext, T* __restrict__ vdot,
-                                                         T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, MkFuse F) {
-  extern __shared__ double bank_lds_raw[];
-  Pair2<T>* const lds = reinterpret_cast<Pair2<T>*>(bank_lds_raw);
+RBD_DEV void aba_bank_body(const BankModel& M, long B, typename InPtr<T, !FUSED>::type q, typename InPtr<T, !FUSED>::type v, const T* __restrict__ tau,
+                           const T* __restrict__ fext, T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, const MkFuse& F,
+                           Pair2<T>* const lds) {
   Pair2<T>* const col = lds + threadIdx.x;
   RBD_MARK(0);
   BankRegs<T> r0, r1;
@@ -483,8 +505,8 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
     T XR[9], Xp[3], tl[6], ta[4];
     setup(r0, qj0, vj0, XR, Xp, tl, ta);
     RBD_MARK(1);
-#pragma unroll 1
-    for (int l = 1; l < M.L0; ++l) bank_fk_step<T, SIMPLE>(M, l, r0, lds, XR, Xp, SIMPLE ? ta : tl);
+RBD_BANK_UNROLL
+    for (int l = 1; l < RBD_BK_L0; ++l) bank_fk_step<T, SIMPLE>(M, l, RBD_BK_PERM(l), r0, lds, XR, Xp, SIMPLE ? ta : tl);
   }
   {
     T XR[9], Xp[3], tl[6], ta[4];
@@ -494,9 +516,9 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
     // bank 0 rests until bank 1 has been swept bottom-up; its parked (R, p, Tw) are what bank 1's first level reads
     lds_put<T, (SIMPLE ? 20 : 24)>(col, PK_KIN, r0.K);
     wave_lds_sync();
-    bank_fk_cross<T, SIMPLE>(M.L0, r1, lds, XR, Xp, SIMPLE ? ta : tl);
-#pragma unroll 1
-    for (int l = M.L0 + 1; l < M.nlevels; ++l) bank_fk_step<T, SIMPLE>(M, l, r1, lds, XR, Xp, SIMPLE ? ta : tl);
+    bank_fk_cross<T, SIMPLE>(RBD_BK_L0, r1, lds, XR, Xp, SIMPLE ? ta : tl);
+RBD_BANK_UNROLL
+    for (int l = RBD_BK_L0 + 1; l < RBD_BK_NL; ++l) bank_fk_step<T, SIMPLE>(M, l, RBD_BK_PERM(l), r1, lds, XR, Xp, SIMPLE ? ta : tl);
   }
   RBD_MARK(4);
   terms(r1, false);
@@ -504,12 +526,13 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
 
   // ---- bottom-up: articulated-body inertias and bias forces ----
   NsStream nss = ns_begin(M.ns_desc);
-#pragma unroll 1
-  for (int l = M.nlevels - 1; l > M.L0; --l) {
+  (void)nss;
+RBD_BANK_UNROLL
+  for (int l = RBD_BK_NL - 1; l > RBD_BK_L0; --l) {
     bank_finish_joint<T, SIMPLE>(l, r1);
-    bank_handoff<T, RBD_BANK_HANDOFF_LDS>(l, ns_next(nss, M.ns_desc), r1, r1, lds);
+    bank_handoff<T, RBD_BANK_HANDOFF_LDS>(l, RBD_BK_NS(l), r1, r1, lds);
   }
-  bank_finish_joint<T, SIMPLE>(M.L0, r1);
+  bank_finish_joint<T, SIMPLE>(RBD_BK_L0, r1);
   RBD_MARK(6);
   // across the banks: the children's hand-off lands in bank 0's (still empty) accumulators; bank 1 then keeps only what the
   // top-down sweep needs, parked while bank 0 is swept; only then does bank 0 wake up and add its own inertia and bias force
@@ -517,7 +540,7 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
   for (int i = 0; i < 21; ++i) r0.IA[i] = T(0);
 #pragma unroll
   for (int i = 0; i < 6; ++i) r0.pA[i] = T(0);
-  bank_handoff<T, 1>(M.L0, ns_next(nss, M.ns_desc), r1, r0, lds);
+  bank_handoff<T, 1>(RBD_BK_L0, RBD_BK_NS(RBD_BK_L0), r1, r0, lds);
   {
     lds_get<T, (SIMPLE ? 20 : 24)>(col, PK_KIN, r0.K);
     // (bank 0's Tw, vJ pairs are free again: bank 1's set takes them; R, p stay for the 6-dof joints)
@@ -531,10 +554,10 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
   RBD_MARK(7);
   terms(r0, true);
   RBD_MARK(8);
-#pragma unroll 1
-  for (int l = M.L0 - 1; l >= 1; --l) {
+RBD_BANK_UNROLL
+  for (int l = RBD_BK_L0 - 1; l >= 1; --l) {
     bank_finish_joint<T, SIMPLE>(l, r0);
-    bank_handoff<T, RBD_BANK_HANDOFF_LDS>(l, ns_next(nss, M.ns_desc), r0, r0, lds);
+    bank_handoff<T, RBD_BANK_HANDOFF_LDS>(l, RBD_BK_NS(l), r0, r0, lds);
   }
   bank_finish_joint<T, SIMPLE>(0, r0);
   RBD_MARK(9);
@@ -563,8 +586,8 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
     massign<T, 6>(fl0, c.vd, fv);
     bank_joint_accel(c.b.level == 0 && !fl0, c, a0);
   }
-#pragma unroll 1
-  for (int l = 1; l < M.L0; ++l) bank_accel_step<T>(M, l, r0, lds);
+RBD_BANK_UNROLL
+  for (int l = 1; l < RBD_BK_L0; ++l) bank_accel_step<T>(M, l, RBD_BK_PERM(l), r0, lds);
   RBD_MARK(10);
   if (vdot) store_joint_v(r0.b, vdot, Lv, r0.vd);
   if (FUSED) store_joint_v(r0.b, (T*)F.W.vd[F.stage], Lv, r0.vd);
@@ -588,14 +611,23 @@ __global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel
     T ap[6];
     lds_get<T, 6>(lds + r1.pcol, PK_XCH, ap);
     wave_lds_sync();
-    bank_joint_accel(r1.b.level == M.L0, r1, ap);
+    bank_joint_accel(r1.b.level == RBD_BK_L0, r1, ap);
   }
-#pragma unroll 1
-  for (int l = M.L0 + 1; l < M.nlevels; ++l) bank_accel_step<T>(M, l, r1, lds);
+RBD_BANK_UNROLL
+  for (int l = RBD_BK_L0 + 1; l < RBD_BK_NL; ++l) bank_accel_step<T>(M, l, RBD_BK_PERM(l), r1, lds);
   RBD_MARK(11);
   if (vdot) store_joint_v(r1.b, vdot, Lv, r1.vd);
   if (FUSED) store_joint_v(r1.b, (T*)F.W.vd[F.stage], Lv, r1.vd);
 }
+#ifndef RBD_BANK_FIXED_NL
+template <typename T, bool FUSED, bool SIMPLE>
+__global__ __launch_bounds__(256, RBD_BANK_WAVES) void aba_bank_kernel(BankModel M, long B, typename InPtr<T, !FUSED>::type q, typename InPtr<T, !FUSED>::type v,
+                                                         const T* __restrict__ tau, const T* __restrict__ fext, T* __restrict__ vdot,
+                                                         T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, MkFuse F) {
+  extern __shared__ double bank_lds_raw[];
+  aba_bank_body<T, FUSED, SIMPLE>(M, B, q, v, tau, fext, vdot, qdot, Lq, Lv, Lf, F, reinterpret_cast<Pair2<T>*>(bank_lds_raw));
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Banked RNEA: inverse_dynamics! (vdot != nullptr) and dynamics_bias! (vdot == nullptr), src/mechanism_algorithms.jl:542-553,
@@ -648,9 +680,9 @@ RBD_DEV void rnea_fk_commit(bool mine, RneaRegs<T>& c, const T* k24, const T* XR
   massign<T, 24>(mine, c.K, n);
 }
 template <typename T, bool SIMPLE>
-RBD_DEV void rnea_fk_step(const BankModel& M, int l, RneaRegs<T>& c, Pair2<T>* lds, const T* XR, const T* Xp, const T* tl, const T* al) {
+RBD_DEV void rnea_fk_step(const BankModel& M, int l, bool perm, RneaRegs<T>& c, Pair2<T>* lds, const T* XR, const T* Xp, const T* tl, const T* al) {
   T k24[24];
-  if ((M.perm_down >> l) & 1) {  // uniform
+  if (perm) {  // uniform
     if (c.b.level == l - 1 && c.b.nchild >= 1) {
       RBD_KEEP_BRANCH();
       lds_put<T, 24>(lds + threadIdx.x, 0, c.K);
@@ -696,12 +728,9 @@ template <typename T, bool CROSS> RBD_DEV void rnea_gather(int l, int ns, const 
 // acc_out / jw_out (nullable): spatial accelerations of the bodies (spatial_accelerations! :387-417, the gravitational acceleration of
 // the root included, as result.accelerations holds them) and joint wrenches (:442-459), 6 x n_bodies x B in reference body order, root frame
 template <typename T, bool SIMPLE>
-__global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, int ncol, const T* __restrict__ q, const T* __restrict__ v,
-                                                          const T* __restrict__ vdot, const T* __restrict__ fext, T* __restrict__ tau,
-                                                          T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T* __restrict__ acc_out,
-                                                          T* __restrict__ jw_out) {
-  extern __shared__ double bank_lds_raw[];
-  Pair2<T>* const lds = reinterpret_cast<Pair2<T>*>(bank_lds_raw);
+RBD_DEV void rnea_bank_body(const BankModel& M, long B, int ncol, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ vdot,
+                            const T* __restrict__ fext, T* __restrict__ tau, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T* __restrict__ acc_out,
+                            T* __restrict__ jw_out, Pair2<T>* const lds) {
   RneaRegs<T> r0, r1;
   const bool out_vec = store6_vec(acc_out ? acc_out : jw_out, Lf, (int)sizeof(T)) && store6_vec(jw_out ? jw_out : acc_out, Lf, (int)sizeof(T));  // uniform
   auto fetch = [&](int k, RneaRegs<T>& c, T* qj, T* vj, T* aj) {
@@ -840,8 +869,8 @@ __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, 
   {
     T XR[9], Xp[3], tl[6], al[6], ta[5];
     setup(r0, qj0, vj0, aj0, XR, Xp, tl, al, ta);
-#pragma unroll 1
-    for (int l = 1; l < M.L0; ++l) rnea_fk_step<T, SIMPLE>(M, l, r0, lds, XR, Xp, SIMPLE ? ta : tl, al);
+RBD_BANK_UNROLL
+    for (int l = 1; l < RBD_BK_L0; ++l) rnea_fk_step<T, SIMPLE>(M, l, RBD_BK_PERM(l), r0, lds, XR, Xp, SIMPLE ? ta : tl, al);
   }
   {
     T XR[9], Xp[3], tl[6], al[6], ta[5];
@@ -852,21 +881,32 @@ __global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, 
       wave_lds_sync();
       lds_get<T, 24>(lds + r1.pcol, 0, k24);
       wave_lds_sync();
-      rnea_fk_commit<T, SIMPLE>(r1.b.level == M.L0, r1, k24, XR, Xp, SIMPLE ? ta : tl, al);
+      rnea_fk_commit<T, SIMPLE>(r1.b.level == RBD_BK_L0, r1, k24, XR, Xp, SIMPLE ? ta : tl, al);
     }
-#pragma unroll 1
-    for (int l = M.L0 + 1; l < M.nlevels; ++l) rnea_fk_step<T, SIMPLE>(M, l, r1, lds, XR, Xp, SIMPLE ? ta : tl, al);
+RBD_BANK_UNROLL
+    for (int l = RBD_BK_L0 + 1; l < RBD_BK_NL; ++l) rnea_fk_step<T, SIMPLE>(M, l, RBD_BK_PERM(l), r1, lds, XR, Xp, SIMPLE ? ta : tl, al);
   }
   newton_euler(r1);
   newton_euler(r0);
   NsStream nss = ns_begin(M.ns_desc);
-#pragma unroll 1
-  for (int l = M.nlevels - 1; l > M.L0; --l) rnea_gather<T, false>(l, ns_next(nss, M.ns_desc), r1, r1);
-  rnea_gather<T, true>(M.L0, ns_next(nss, M.ns_desc), r1, r0);
-#pragma unroll 1
-  for (int l = M.L0 - 1; l >= 1; --l) rnea_gather<T, false>(l, ns_next(nss, M.ns_desc), r0, r0);
+  (void)nss;
+RBD_BANK_UNROLL
+  for (int l = RBD_BK_NL - 1; l > RBD_BK_L0; --l) rnea_gather<T, false>(l, RBD_BK_NS(l), r1, r1);
+  rnea_gather<T, true>(RBD_BK_L0, RBD_BK_NS(RBD_BK_L0), r1, r0);
+RBD_BANK_UNROLL
+  for (int l = RBD_BK_L0 - 1; l >= 1; --l) rnea_gather<T, false>(l, RBD_BK_NS(l), r0, r0);
   project(r0);
   project(r1);
 }
+#ifndef RBD_BANK_FIXED_NL
+template <typename T, bool SIMPLE>
+__global__ __launch_bounds__(256, 2) void rnea_bank_kernel(BankModel M, long B, int ncol, const T* __restrict__ q, const T* __restrict__ v,
+                                                          const T* __restrict__ vdot, const T* __restrict__ fext, T* __restrict__ tau,
+                                                          T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T* __restrict__ acc_out,
+                                                          T* __restrict__ jw_out) {
+  extern __shared__ double bank_lds_raw[];
+  rnea_bank_body<T, SIMPLE>(M, B, ncol, q, v, vdot, fext, tau, qdot, Lq, Lv, Lf, acc_out, jw_out, reinterpret_cast<Pair2<T>*>(bank_lds_raw));
+}
+#endif
 
 }  // namespace rbd

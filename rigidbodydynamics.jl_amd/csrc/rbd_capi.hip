@@ -121,6 +121,7 @@ struct rbd_ws {
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
+  bool spec_bank_tried = false; hipModule_t spec_bank_mod = nullptr; hipFunction_t spec_bank_aba = nullptr, spec_bank_fused = nullptr, spec_bank_rnea = nullptr; std::string spec_bank_src;  // the banked kernels compiled for the mechanism
   std::string spec_src[SPEC_FAMILIES], spec_loop_src, spec_walk_src[8];  // the programs' sources while their compilation is pending (generated once)
   bool spec_walk_tried[8] = {}; hipModule_t spec_walk_mod[8] = {}; hipFunction_t spec_walk[8] = {};  // [inverse dynamics][re-rooted tree][two fp32 states per lane]
   bool no_reroot = false, loop_no_fused = false; int spec_max_scratch = 512;  // RBD_TUNE: walk_no_reroot, loop_no_fused (tests: the original tree / the three-launch loop route), spec_max_scratch (spilled bytes per lane above which a compiled kernel steps aside)
@@ -172,6 +173,8 @@ static long tune(const char* key, long dflt, bool* has = nullptr) {
 }
 
 static std::string loop_program_source(const rbd_model* m, int dtype, std::vector<int32_t>* xi_store);  // (below)
+static int bank_simple(const rbd_model* m);
+static std::string bank_program_source(const rbd_model* m, int dtype, int simple);
 static std::string walk_program_source(const rbd_model* m, int dtype, bool rerooted, int kind = 0, int pair = 0);
 static bool walk_program_rerooted(const rbd_model* m, int dtype, int pair = 0);
 
@@ -181,9 +184,10 @@ int rbd_version(void) { return RBD_HIP_H_VERSION; }
 // run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
 // the source of one program of a model (families as in include/rbd_hip.h); empty: no such program for this mechanism
 static std::string program_source(const rbd_model* m, int32_t dtype, int32_t family) {
-  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 4) return std::string();
+  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 5) return std::string();
   std::vector<int32_t> xi;
   if (family < SPEC_FAMILIES && !m->state.ok) return std::string();
+  if (family == SPEC_FAMILIES + 5) return bank_program_source(m, dtype, bank_simple(m));  // (family 8: the two-bodies-per-lane kernels)
   return family == SPEC_FAMILIES + 4 ? (dtype == RBD_F32 ? walk_program_source(m, dtype, false, 1, 1) : std::string())  // (families 6, 7: 4 and 5 with two fp32 states per lane)
          : family == SPEC_FAMILIES + 3 ? (dtype == RBD_F32 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype, 1), 0, 1) : std::string())
          : family == SPEC_FAMILIES + 2 ? walk_program_source(m, dtype, false, 1)  // (family 5: ... and its inverse_dynamics! kernel, on the original tree)
@@ -191,7 +195,7 @@ static std::string program_source(const rbd_model* m, int32_t dtype, int32_t fam
          : family == SPEC_FAMILIES ? loop_program_source(m, dtype, &xi)  // (family 3: the program of a small loop mechanism)
                                    : spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
 }
-static bool family_is_walk(int family) { return family > SPEC_FAMILIES; }
+static bool family_is_walk(int family) { return family > SPEC_FAMILIES && family <= SPEC_FAMILIES + 4; }
 int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char* buf, int64_t cap) {
   const std::string s = program_source(m, dtype, family);
   if (s.empty()) return -1;
@@ -211,11 +215,11 @@ int rbd_jit_status(const rbd_model_t* m, int32_t dtype, int32_t family) {
 int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t cap) {
   if (log && cap > 0) log[0] = 0;
   if (!m || (dtype != RBD_F32 && dtype != RBD_F64)) return RBD_ERR_INVALID_ARGUMENT;
-  if ((!m->state.ok && !m->loop_fused_ok && !(m->track.ok && m->walk.ok)) || !jit_available()) return RBD_ERR_UNSUPPORTED;
+  if ((!m->state.ok && !m->loop_fused_ok && !(m->track.ok && m->walk.ok) && m->bank_lps <= 0) || !jit_available()) return RBD_ERR_UNSUPPORTED;
   // the model's programs of this scalar type, the longest compilations first; every one of them on its own background thread (rbd_jit.hip), then wait for all
   struct Job { std::string src; bool walk; int family; int state; double seconds; std::string log; };
   std::vector<Job> jobs;
-  for (int family : {4, 5, 6, 7, 0, 1, 2, 3})
+  for (int family : {4, 5, 6, 7, 8, 0, 1, 2, 3})
     jobs.push_back({program_source(m, dtype, family), family_is_walk(family), family, JIT_PENDING, 0.0, std::string()});
   // RBD_JIT_PRECOMPILE_PART = "k/n": only every n-th program, starting with the k-th — n processes share a model's compilations
   int part = 0, parts = 1;
@@ -782,9 +786,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     }
     if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
     bm.lps = m->bank_lps; bm.nlevels = m->nlevels; bm.L0 = m->bank_L0; bm.perm_down = m->bank_perm_down;
-    bm.simple = 1;  // every tree joint revolute, apart from 6-dof joints on the world
-    for (int i = 0; i < m->nb; ++i)
-      if (m->jt_ref[i] != RBD_JOINT_REVOLUTE && !(m->jt_ref[i] == RBD_JOINT_QUAT_FLOATING && m->parent_ref[i] < 0)) bm.simple = 0;
+    bm.simple = bank_simple(m);  // every tree joint revolute, apart from 6-dof joints on the world
     if (tune("bank_generic", 0)) bm.simple = 0;  // tests: the generic instantiation on a mechanism the SIMPLE one would take
     nslots_pack_desc(bm.ns_desc, m->nslots.data(), m->nlevels);
     memcpy(bm.gravity, m->gravity, sizeof bm.gravity);
@@ -963,6 +965,7 @@ int rbd_workspace_destroy(rbd_ws_t* w) {
   }
   for (hipModule_t mod : w->spec_mod) if (mod) (void)hipModuleUnload(mod);
   if (w->spec_loop_mod) (void)hipModuleUnload(w->spec_loop_mod);
+  if (w->spec_bank_mod) (void)hipModuleUnload(w->spec_bank_mod);
   for (int k = 0; k < 8; ++k) if (w->spec_walk_mod[k]) (void)hipModuleUnload(w->spec_walk_mod[k]);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
@@ -1130,6 +1133,17 @@ int ensure(void** p, size_t* have, size_t need) {
 
 }  // namespace
 
+// the two-bodies-per-lane kernels: every tree joint revolute, apart from 6-dof joints on the world -> their SIMPLE instantiation
+static int bank_simple(const rbd_model* m) {
+  for (int i = 0; i < m->nb; ++i)
+    if (m->jt_ref[i] != RBD_JOINT_REVOLUTE && !(m->jt_ref[i] == RBD_JOINT_QUAT_FLOATING && m->parent_ref[i] < 0)) return 0;
+  return 1;
+}
+// ... and their program for this mechanism (rbd_jit.hip spec_bank_source): empty when the banked mapping does not apply
+static std::string bank_program_source(const rbd_model* m, int dtype, int simple) {
+  if (m->bank_lps <= 0) return std::string();
+  return spec_bank_source(m->nlevels, m->bank_L0, m->nslots.data(), (unsigned long long)m->bank_perm_down, simple, dtype);
+}
 // the loop tables of a small loop mechanism as rbd_jit.hip's generator takes them (xi as rbd_workspace_create uploads it for loop_fused_small_kernel)
 static std::string loop_program_source(const rbd_model* m, int dtype, std::vector<int32_t>* xi_store) {
   if (!m->loop_fused_ok) return std::string();
@@ -1210,6 +1224,34 @@ static hipFunction_t spec_loop(rbd_ws* w) {
   if (w->spec_loop && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, w->spec_loop) != hipSuccess || scratch > 0)) { (void)hipGetLastError(); w->spec_loop = nullptr; }
   src.clear(); src.shrink_to_fit();
   return w->spec_loop;
+}
+
+// the two-bodies-per-lane kernels compiled for the mechanism (rbd_bank.hpp with the level structure as constants); false while unavailable
+static bool spec_bank(rbd_ws* w) {
+  if (w->spec_bank_tried) return w->spec_bank_aba != nullptr;
+  if (!jit_available() || w->model->bank_lps <= 0) { w->spec_bank_tried = true; return false; }
+  if (capturing(w)) return false;
+  std::string& src = w->spec_bank_src;
+  if (src.empty()) src = bank_program_source(w->model, w->dtype, w->bm.simple);
+  if (src.empty()) { w->spec_bank_tried = true; return false; }
+  std::string log;
+  std::vector<char> code;
+  const int js = jit_code_object_get(src, !jit_async(), &code, &log);
+  if (js == JIT_PENDING) return false;  // the kernels built with the library meanwhile
+  w->spec_bank_tried = true;
+  if (js == JIT_FAILED || code.empty()) { g_last_hip_error = "run-time compilation failed (the banked kernels built with the library are used): " + log; return false; }
+  if (hipModuleLoadData(&w->spec_bank_mod, code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_bank_mod = nullptr; jit_cache_discard(src); return false; }
+  const char* sfx = w->dtype == RBD_F64 ? "f64" : "f32";
+  auto get = [&](hipFunction_t* f, const std::string& name) {
+    int scratch = 0;
+    if (hipModuleGetFunction(f, w->spec_bank_mod, name.c_str()) != hipSuccess) { (void)hipGetLastError(); *f = nullptr; }
+    else if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, *f) != hipSuccess || scratch > w->spec_max_scratch) { (void)hipGetLastError(); *f = nullptr; }
+  };
+  get(&w->spec_bank_aba, std::string("aba_bank_spec_") + sfx);
+  get(&w->spec_bank_fused, std::string("aba_bank_fused_spec_") + sfx);
+  get(&w->spec_bank_rnea, std::string("rnea_bank_spec_") + sfx);
+  src.clear(); src.shrink_to_fit();
+  return w->spec_bank_aba != nullptr;
 }
 
 namespace {
@@ -1323,6 +1365,15 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   } else if (banks) {
     const int ncol = m->has3dof ? 3 : 1;
     w->last_kernel = "rnea_bank_kernel";
+    if (spec_bank(w) && w->spec_bank_rnea) {  // the same kernel compiled against this mechanism's level structure (rbd_jit.hip spec_bank_source)
+      BankModel bm = w->bm;
+      long Bl = B;
+      int nc = ncol;
+      const long spw = 64 / bm.lps, waves = (B + spw - 1) / spw;
+      void* args[] = {&bm, &Bl, &nc, (void*)&dq, (void*)&dv, (void*)&dvd, (void*)&df, (void*)&dtau, (void*)&dqd, &Lq, &Lv, &Lf, (void*)&dacc, (void*)&djw};
+      HIP_TRY(hipModuleLaunchKernel(w->spec_bank_rnea, (unsigned)((waves + 3) / 4), 1, 1, 256, 1, 1, 0, w->stream, args, nullptr));
+      w->last_kernel = "rnea_bank_kernel (compiled for the mechanism at run time)";
+    } else
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_bank<double>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
     else HIP_TRY(launch_rnea_bank<float>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
   } else {
@@ -1401,6 +1452,17 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   } else if (pick == RBD_ALGO_ABA_BANKS) {
     BankModel bm = w->bm;
     if (gravity) memcpy(bm.gravity, gravity, sizeof bm.gravity);
+    hipFunction_t f = spec_bank(w) ? (fuse ? w->spec_bank_fused : w->spec_bank_aba) : nullptr;
+    if (f) {  // the same kernel compiled against this mechanism's level structure: the level loops unrolled (rbd_jit.hip spec_bank_source)
+      MkFuse F{};
+      F.stage = -1;
+      if (fuse) F = *fuse;
+      long Bl = B;
+      const long spw = 64 / bm.lps, waves = (B + spw - 1) / spw;
+      void* args[] = {&bm, &Bl, (void*)&dq, (void*)&dv, (void*)&dtau, (void*)&df, (void*)&dvd, (void*)&dqd, &Lq, &Lv, &Lf, &F};
+      HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((waves + 3) / 4), 1, 1, 256, 1, 1, 0, w->stream, args, nullptr));
+      w->last_kernel = "aba_bank_kernel (compiled for the mechanism at run time)";
+    } else
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_bank<double>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
     else HIP_TRY(launch_aba_bank<float>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
   } else {

@@ -22,6 +22,9 @@ struct LoopTables {
   const double* gravity;
 };
 std::string spec_loop_source(const LoopTables& L, int dtype);
+// The program of the two-bodies-per-lane kernels (rbd_bank.hpp) for ONE mechanism: aba_bank_spec_<sfx>, aba_bank_fused_spec_<sfx>, rnea_bank_spec_<sfx> — the level loops
+// unrolled against the mechanism's level structure (levels, first level of bank 1, later-children counts and hop kind per level).
+std::string spec_bank_source(int nlevels, int L0, const int32_t* nslots, unsigned long long perm_down, int simple, int dtype);
 // The program of the one-wavefront-per-track dynamics! kernel for ONE mechanism (aba_walk_spec of rbd_walk.hpp with the plan as constants): aba_walk_spec_f64.
 // fp64, fp32, and fp32 with two states per lane (pair).
 struct WalkTables {

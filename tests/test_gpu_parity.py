@@ -805,11 +805,17 @@ MAPPINGS = ["aba_walk", "aba_banks"]
 
 
 
+# the banked and walk kernels exist twice: built with the library (they interpret the level structure / the plan; RBD_JIT=0 here) and compiled for the mechanism at run time
+JIT = ["compiled", "built"]
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("jit", JIT)
 @pytest.mark.parametrize("algorithm", MAPPINGS)
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("name", CHAIN_MODELS)
-def test_dynamics_chains_f64(rbd, oracle, models, name, layout, algorithm):
+def test_dynamics_chains_f64(rbd, oracle, models, name, layout, algorithm, jit, monkeypatch):
+    monkeypatch.setenv("RBD_JIT", "1" if jit == "compiled" else "0")
     model = models[name]
     B = 67  # ragged against every states-per-wave (64, 32, 16, 4)
     state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 41)
@@ -904,9 +910,11 @@ def test_dynamics_chains_scope_and_auto_selection(rbd, oracle, models):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("jit", JIT)
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("name", MODELS)
-def test_inverse_dynamics_and_bias_banked_f64(rbd, oracle, models, name, layout):
+def test_inverse_dynamics_and_bias_banked_f64(rbd, oracle, models, name, layout, jit, monkeypatch):
+    monkeypatch.setenv("RBD_JIT", "1" if jit == "compiled" else "0")
     """The two-bodies-per-lane RNEA (every tree joint type) against the oracle and against the one-body-per-lane kernel."""
     model = models[name]
     B = 45
@@ -1205,8 +1213,10 @@ def test_momentum_and_rate_bias_f64(rbd, oracle, models, name, layout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("jit", JIT)
 @pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "valkyrie_floating"])
-def test_simulate_banked_fused_path_matches_oracle(rbd, oracle, models, name, monkeypatch):
+def test_simulate_banked_fused_path_matches_oracle(rbd, oracle, models, name, jit, monkeypatch):
+    monkeypatch.setenv("RBD_JIT", "1" if jit == "compiled" else "0")
     """`simulate` through the two-bodies-per-lane kernel with the integrator stage fused in (what large batches run): forced at a
     small batch with RBD_TUNE bank_min_batch so that every state can be compared with the numpy restatement of the Munthe-Kaas step."""
     import simulate_np
@@ -1219,7 +1229,8 @@ def test_simulate_banked_fused_path_matches_oracle(rbd, oracle, models, name, mo
     rbd.set_velocity_(state, v)
     rbd.simulate_(state, T, dt=dt, torques=dev(tau, state))
     from rigidbodydynamics_jl_amd import _capi
-    assert _capi.lib().rbd_workspace_last_kernel(state.ws.handle) == b"aba_bank_kernel"
+    k = _capi.lib().rbd_workspace_last_kernel(state.ws.handle)
+    assert k.startswith(b"aba_bank_kernel") and (b"compiled" not in k or jit == "compiled"), k
     _, q_ref, v_ref = simulate_np.simulate(model, q, v, T, dt, tau)
     qg, vg = host(state.q, state), host(state.v, state)
     assert np.abs(canon_q(model, qg) - canon_q(model, q_ref)).max() <= 1e-11 * max(1.0, np.abs(q_ref).max())
