@@ -1013,6 +1013,13 @@ int rbd_workspace_set_loop_gains(rbd_ws_t* w, const double* gains) {
 
 int rbd_workspace_bind_result(rbd_ws_t* w, void* M, void* c) {
   if (!w) return RBD_ERR_INVALID_ARGUMENT;
+  // the kernels write through these pointers: they must be device memory (a host pointer here used to reach the kernels unchecked)
+  for (void* p : {M, c}) {
+    if (!p) continue;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return RBD_ERR_INVALID_ARGUMENT; }
+    if (a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeManaged && a.type != hipMemoryTypeUnified) return RBD_ERR_INVALID_ARGUMENT;
+  }
   w->bound_M = M;
   w->bound_c = c;
   return RBD_OK;
@@ -1657,10 +1664,13 @@ static int run_dynamics(rbd_ws* w, int32_t B, const Opts& o, const void* dq, con
     // potrf!/potrs!.  M and c stay in the workspace (layout of this call) for rbd_dynamics_result.
     const Layout Lm = layout_of(o.layout, (long)m->nv * m->nv, B);
     // M and c: the caller's own buffers when bound (rbd_workspace_bind_result: no copy afterwards), else the workspace's
-    if (!w->bound_M && (st = ensure(&w->d_M, &w->d_M_bytes, es * (size_t)m->nv * m->nv * B))) return st;
-    if (!w->bound_c && (st = ensure(&w->d_c, &w->d_c_bytes, es * (size_t)m->nv * B))) return st;
-    void* const Md = w->bound_M ? w->bound_M : w->d_M;
-    void* const cd = w->bound_c ? w->bound_c : w->d_c;
+    // (bound buffers are laid out like the DEVICE buffers of the call: a host-memory call — its q, v are staged copies — keeps the workspace's)
+    void* const bM = o.memory == RBD_MEM_HOST ? nullptr : w->bound_M;
+    void* const bc = o.memory == RBD_MEM_HOST ? nullptr : w->bound_c;
+    if (!bM && (st = ensure(&w->d_M, &w->d_M_bytes, es * (size_t)m->nv * m->nv * B))) return st;
+    if (!bc && (st = ensure(&w->d_c, &w->d_c_bytes, es * (size_t)m->nv * B))) return st;
+    void* const Md = bM ? bM : w->d_M;
+    void* const cd = bc ? bc : w->d_c;
     w->result_layout = o.layout; w->result_B = B;
     Timed t(w);
     if ((st = run_rnea(w, B, RBD_ALGO_ABA, dq, dv, nullptr, df, cd, dqd, Lq, Lv, Lf))) return st;

@@ -122,8 +122,10 @@ def test_precompile_without_a_device(rbd, tmp_path, monkeypatch):
     files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".hsaco"))
     # fp64: the mass-matrix and the inverse-dynamics programs, and the two walk kernels' (each compiled ONCE since round 4: the allocator's register use is read from
     # the object's metadata and its kernel descriptor rewritten to cover the accumulation registers, csrc/rbd_jit.hip jit_kd_cover_agprs)
-    assert len(files) == 4 and all(os.path.getsize(tmp_path / f) > 1000 for f in files)
-    assert "ready after" in log and log.count("[rbd_jit] family") == 4  # the log lists every program with the seconds it took
+    # ... and, where the mechanism has a two-bodies-per-lane split, the banked kernels' (round 4: their level loops unrolled against the mechanism's level structure)
+    n = 4 + (rbd.jit_source(model, torch.float64, "banked") is not None)
+    assert len(files) == n and all(os.path.getsize(tmp_path / f) > 1000 for f in files)
+    assert "ready after" in log and log.count("[rbd_jit] family") == n  # the log lists every program with the seconds it took
     stamps = [os.path.getmtime(tmp_path / f) for f in files]
     ok, _ = rbd.jit_precompile(model, torch.float64)
     assert ok and [os.path.getmtime(tmp_path / f) for f in files] == stamps
@@ -229,7 +231,9 @@ def test_walk_program_of_a_mechanism(rbd):
     assert "rnea_walk_spec_f32x2(" in rbd.jit_source(model, torch.float32, "inverse_dynamics_tracks_pairs")
     src = rbd.jit_source(model, torch.float64, "dynamics_tracks")
     assert src is not None and "aba_walk_spec_f64" in src and '#include "rbd_walk.hpp"' in src
-    ns, G, nq, nv = (int(x) for x in re.search(r"NS = (\d+), G = (\d+), NQ = (\d+), NV = (\d+);", src).groups())
+    ns, G, nq, nv, n1, nf = (int(x) for x in re.search(r"NS = (\d+), G = (\d+), NQ = (\d+), NV = (\d+), MK_N1 = (\d+), MK_NF = (\d+);", src).groups())
+    # (MK_N1 / MK_NF, MK1 / MKF: the joints as the integrator stage folded into the launch sees them, csrc/rbd_mk_fuse.hpp: Atlas has 30 revolute joints and the floating base)
+    assert (n1, nf) == (30, 1) and int(re.search(r"const int32_t MK1\[(\d+)\]", src).group(1)) == 90 and "rbd::MkStage F" in src
     assert (nq, nv) == (model.nq, model.nv) and 1 <= G <= 4 and 1 <= ns <= 11
     assert int(re.search(r"const int32_t RI\[(\d+)\]", src).group(1)) == 4 * ns * G
     assert int(re.search(r"const double RR\[(\d+)\]", src).group(1)) == 24 * ns * G
@@ -241,6 +245,31 @@ def test_walk_program_of_a_mechanism(rbd):
     ri = [int(x) for x in re.search(r"RI\[\d+\][^=]*= \{([^}]*)\}", src).group(1).split(",")]
     valid = sum(1 for k in range(ns * G) if (ri[4 * k + 1] >> 16) & 1)
     assert valid == model.n_bodies
+
+
+def test_banked_program_of_a_mechanism(rbd):
+    """The two-bodies-per-lane kernels compiled per mechanism (family 8): the level structure as compile-time constants — Atlas: 11 levels, bank 1 from level 5,
+    three children to gather below the pelvis and below the upper torso and one everywhere else — and the three entry points."""
+    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
+    src = rbd.jit_source(model, torch.float64, "banked")
+    assert src is not None and '#include "rbd_bank.hpp"' in src
+    plan = rbd.bank_plan(model)
+    assert int(re.search(r"#define RBD_BANK_FIXED_NL (\d+)", src).group(1)) == int(model.levels().max()) + 1 == 11
+    assert int(re.search(r"#define RBD_BANK_FIXED_L0 (\d+)", src).group(1)) == plan["L0"] == 5
+    ns = [int(x) for x in re.search(r"#define RBD_BANK_FIXED_NS ([\d,]+)", src).group(1).split(",")]
+    lev = model.levels()
+    nch = np.zeros(model.n_bodies, int)
+    for b in range(model.n_bodies):
+        if model.parent[b] >= 0:
+            nch[model.parent[b]] += 1
+    assert ns == [0] + [int(nch[lev == l - 1].max()) for l in range(1, 11)] == [0, 3, 1, 1, 3, 1, 1, 1, 1, 1, 1]
+    perm = int(re.search(r"#define RBD_BANK_FIXED_PERM (0x[0-9a-f]+)ull", src).group(1), 16)
+    assert all(((perm >> l) & 1) == (ns[l] > 1) for l in range(1, 11) if l != plan["L0"])  # a hop needs the exchange column where some body has later children
+    for k in ("aba_bank_spec_f64", "aba_bank_fused_spec_f64", "rnea_bank_spec_f64"):
+        assert k + "(" in src
+    assert "aba_bank_body<double, false, true>" in src  # Atlas: every tree joint revolute below the floating base -> the SIMPLE instantiation
+    # a mechanism outside the banked scope has no such program
+    assert rbd.jit_source(rbd.flatten(rbd.builders.four_bar_linkage()), torch.float64, "banked") is None or rbd.bank_plan(rbd.flatten(rbd.builders.four_bar_linkage())) is not None
 
 
 def test_walk_programs_compile_without_a_device(rbd):
