@@ -243,6 +243,24 @@ __global__ __launch_bounds__(64) void big_chol_solve_kernel(int nv, long B, cons
   }
 }
 
+// the per-body kinematics the loop branch reads (24 per body and state: R, p, twist, bias acceleration with the world's -g, as rnea_kernel exports them) out of
+// the scratch big_rnea_kernel (vdot == nullptr) has just filled: body[st * 24 nb + 24 i + k]
+template <typename T>
+__global__ __launch_bounds__(256) void big_export_body_kernel(BigModel M, long B, const T* __restrict__ scratch, T* __restrict__ body) {
+  const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (st >= B) return;
+  for (int i = 0; i < M.nb; ++i)
+#pragma unroll 8
+    for (int k = 0; k < 24; ++k) body[(st * M.nb + i) * 24 + k] = scratch[((long)(BIG_K + k) * M.nb + i) * B + st];
+}
+template <typename T>
+hipError_t launch_big_export_body(const BigModel& M, long B, const void* scratch, void* body, hipStream_t s) {
+  hipLaunchKernelGGL(big_export_body_kernel<T>, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, M, B, (const T*)scratch, (T*)body);
+  return hipGetLastError();
+}
+template hipError_t launch_big_export_body<double>(const BigModel&, long, const void*, void*, hipStream_t);
+template hipError_t launch_big_export_body<float>(const BigModel&, long, const void*, void*, hipStream_t);
+
 size_t big_scratch_elems(const BigModel& M, long B) { return (size_t)BIG_FIELDS * (size_t)M.nb * (size_t)B; }
 
 template <typename T>

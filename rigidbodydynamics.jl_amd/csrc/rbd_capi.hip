@@ -272,6 +272,53 @@ const char* rbd_status_string(int s) {
 }
 const char* rbd_last_hip_error(void) { return g_last_hip_error.c_str(); }
 
+// the loop (non-tree) joints' tables, in reference body indices: records, local constraint wrench bases, tree paths (constraint_jacobian_structure,
+// src/mechanism_state.jl:51, :99-100).  Independent of the lane mappings: also what trees of more than 64 bodies use.
+static int build_loop_tables(rbd_model* m, const rbd_flat_model_t* d) {
+  const int nb = m->nb;
+  for (int l = 0; l < d->n_loops; ++l) {
+    const rbd_loop_joint_t& lj = d->loops[l];
+    const int nvl = joint_nv_host(lj.joint_type);
+    if (nvl < 0) return RBD_ERR_INVALID_ARGUMENT;
+    if (lj.predecessor >= nb || lj.successor >= nb || lj.predecessor < -1 || lj.successor < -1) return RBD_ERR_INVALID_ARGUMENT;
+    const int ncl = 6 - nvl;  // num_constraints: src/joint.jl:12
+    // local constraint wrench basis in frame_after(joint): revolute.jl:91-98, prismatic.jl:101-108, fixed.jl
+    double Tl[36] = {0};
+    const double* R = lj.rotation_from_z_aligned;
+    if (lj.joint_type == RBD_JOINT_REVOLUTE || lj.joint_type == RBD_JOINT_SINCOS_REVOLUTE) {
+      for (int r = 0; r < 3; ++r) { Tl[0 + r] = R[3 * r]; Tl[6 + r] = R[3 * r + 1]; Tl[12 + 3 + r] = R[3 * r]; Tl[18 + 3 + r] = R[3 * r + 1]; Tl[24 + 3 + r] = R[3 * r + 2]; }
+    } else if (lj.joint_type == RBD_JOINT_PRISMATIC) {
+      for (int r = 0; r < 3; ++r) { Tl[0 + r] = R[3 * r]; Tl[6 + r] = R[3 * r + 1]; Tl[12 + r] = R[3 * r + 2]; Tl[18 + 3 + r] = R[3 * r]; Tl[24 + 3 + r] = R[3 * r + 1]; }
+    } else if (lj.joint_type == RBD_JOINT_FIXED) {
+      for (int c = 0; c < 6; ++c) Tl[6 * c + c] = 1;
+    } else if (lj.joint_type == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl:50-55: angular 0, linear identity
+      for (int c = 0; c < 3; ++c) Tl[6 * c + 3 + c] = 1;
+    } else if (lj.joint_type == RBD_JOINT_PLANAR) {  // planar.jl:96-101: (0; rot_axis), (x_axis; 0), (y_axis; 0); R columns = (x, y, x × y)
+      for (int r = 0; r < 3; ++r) { Tl[0 + 3 + r] = R[3 * r + 2]; Tl[6 + r] = R[3 * r]; Tl[12 + r] = R[3 * r + 1]; }
+    } else if (lj.joint_type != RBD_JOINT_QUAT_FLOATING) {
+      return RBD_ERR_UNSUPPORTED;
+    }
+    const int path_begin = (int)m->loop_path.size() / 2;
+    int a = lj.predecessor, b = lj.successor;  // TreePath(pred, succ): src/graphs/tree_path.jl:41-63
+    while (a != b) {
+      if (a > b) { m->loop_path.push_back(a); m->loop_path.push_back(-1); a = d->parent[a]; }
+      else { m->loop_path.push_back(b); m->loop_path.push_back(1); b = d->parent[b]; }
+    }
+    const int path_end = (int)m->loop_path.size() / 2;
+    const int32_t rec[8] = {lj.predecessor, lj.successor, lj.joint_type, m->nc, ncl, path_begin, path_end, 0};
+    m->loop_i.insert(m->loop_i.end(), rec, rec + 8);
+    double r64[64] = {0};
+    for (int k = 0; k < 9; ++k) { r64[k] = lj.pred_rot[k]; r64[12 + k] = lj.succ_rot[k]; }
+    for (int k = 0; k < 3; ++k) { r64[9 + k] = lj.pred_trans[k]; r64[21 + k] = lj.succ_trans[k]; }
+    for (int k = 0; k < 4; ++k) r64[24 + k] = lj.gains[k];
+    for (int k = 0; k < 36; ++k) r64[28 + k] = Tl[k];
+    m->loop_r.insert(m->loop_r.end(), r64, r64 + 64);
+    m->nc += ncl;
+    m->loops.push_back(lj);
+  }
+  return RBD_OK;
+}
+
 int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   if (!d || !out) return RBD_ERR_INVALID_ARGUMENT;
   *out = nullptr;
@@ -306,7 +353,8 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   if (nb > 64) {
     // More bodies than a wavefront has lanes: the any-size fallback (rbd_big_kernels.hip) — tree mechanisms without contact points; dynamics!,
     // inverse_dynamics!, dynamics_bias!, mass_matrix!, mass_matrix_solve.  Everything else returns RBD_ERR_UNSUPPORTED for such a model.
-    if (d->n_loops > 0 || m->ncp > 0) { delete m; return RBD_ERR_UNSUPPORTED; }
+    // (round 4: loop joints too — their tables are in reference body indices, and the loop branch's kernels read per-body kinematics, M and c from memory)
+    if (m->ncp > 0) { delete m; return RBD_ERR_UNSUPPORTED; }
     int qs = 0, vs = 0;
     m->big_tbl.resize(4 * (size_t)nb);
     m->big_rb.assign((size_t)nb * RB_STRIDE, 0.0);
@@ -331,6 +379,13 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     if (qs != d->nq || vs != d->nv) { delete m; return RBD_ERR_DIMENSION_MISMATCH; }
     m->big = true;
     m->nc = 0;
+    m->jt_ref.assign(d->joint_type, d->joint_type + nb);
+    m->parent_ref.assign(d->parent, d->parent + nb);
+    m->voff_ref.assign(d->v_offset, d->v_offset + nb);
+    m->qoff_ref.assign(d->q_offset, d->q_offset + nb);
+    m->axis_ref.assign(d->joint_axis, d->joint_axis + 3 * nb);
+    if (d->joint_axis2) m->axis2_ref.assign(d->joint_axis2, d->joint_axis2 + 3 * nb); else m->axis2_ref.assign(3 * nb, 0.0);
+    if (int lst = build_loop_tables(m, d)) { delete m; return lst; }
     *out = m;
     return RBD_OK;
   }
@@ -450,46 +505,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   }
   m->axis_ref.assign(d->joint_axis, d->joint_axis + 3 * nb);
   if (d->joint_axis2) m->axis2_ref.assign(d->joint_axis2, d->joint_axis2 + 3 * nb); else m->axis2_ref.assign(3 * nb, 0.0);
-  for (int l = 0; l < d->n_loops; ++l) {
-    const rbd_loop_joint_t& lj = d->loops[l];
-    const int nvl = joint_nv_host(lj.joint_type);
-    if (nvl < 0) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
-    if (lj.predecessor >= nb || lj.successor >= nb || lj.predecessor < -1 || lj.successor < -1) { delete m; return RBD_ERR_INVALID_ARGUMENT; }
-    const int ncl = 6 - nvl;  // num_constraints: src/joint.jl:12
-    // local constraint wrench basis in frame_after(joint): revolute.jl:91-98, prismatic.jl:101-108, fixed.jl
-    double Tl[36] = {0};
-    const double* R = lj.rotation_from_z_aligned;
-    if (lj.joint_type == RBD_JOINT_REVOLUTE || lj.joint_type == RBD_JOINT_SINCOS_REVOLUTE) {
-      for (int r = 0; r < 3; ++r) { Tl[0 + r] = R[3 * r]; Tl[6 + r] = R[3 * r + 1]; Tl[12 + 3 + r] = R[3 * r]; Tl[18 + 3 + r] = R[3 * r + 1]; Tl[24 + 3 + r] = R[3 * r + 2]; }
-    } else if (lj.joint_type == RBD_JOINT_PRISMATIC) {
-      for (int r = 0; r < 3; ++r) { Tl[0 + r] = R[3 * r]; Tl[6 + r] = R[3 * r + 1]; Tl[12 + r] = R[3 * r + 2]; Tl[18 + 3 + r] = R[3 * r]; Tl[24 + 3 + r] = R[3 * r + 1]; }
-    } else if (lj.joint_type == RBD_JOINT_FIXED) {
-      for (int c = 0; c < 6; ++c) Tl[6 * c + c] = 1;
-    } else if (lj.joint_type == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl:50-55: angular 0, linear identity
-      for (int c = 0; c < 3; ++c) Tl[6 * c + 3 + c] = 1;
-    } else if (lj.joint_type == RBD_JOINT_PLANAR) {  // planar.jl:96-101: (0; rot_axis), (x_axis; 0), (y_axis; 0); R columns = (x, y, x × y)
-      for (int r = 0; r < 3; ++r) { Tl[0 + 3 + r] = R[3 * r + 2]; Tl[6 + r] = R[3 * r]; Tl[12 + r] = R[3 * r + 1]; }
-    } else if (lj.joint_type != RBD_JOINT_QUAT_FLOATING) {
-      delete m; return RBD_ERR_UNSUPPORTED;
-    }
-    const int path_begin = (int)m->loop_path.size() / 2;
-    int a = lj.predecessor, b = lj.successor;  // TreePath(pred, succ): src/graphs/tree_path.jl:41-63
-    while (a != b) {
-      if (a > b) { m->loop_path.push_back(a); m->loop_path.push_back(-1); a = d->parent[a]; }
-      else { m->loop_path.push_back(b); m->loop_path.push_back(1); b = d->parent[b]; }
-    }
-    const int path_end = (int)m->loop_path.size() / 2;
-    const int32_t rec[8] = {lj.predecessor, lj.successor, lj.joint_type, m->nc, ncl, path_begin, path_end, 0};
-    m->loop_i.insert(m->loop_i.end(), rec, rec + 8);
-    double r64[64] = {0};
-    for (int k = 0; k < 9; ++k) { r64[k] = lj.pred_rot[k]; r64[12 + k] = lj.succ_rot[k]; }
-    for (int k = 0; k < 3; ++k) { r64[9 + k] = lj.pred_trans[k]; r64[21 + k] = lj.succ_trans[k]; }
-    for (int k = 0; k < 4; ++k) r64[24 + k] = lj.gains[k];
-    for (int k = 0; k < 36; ++k) r64[28 + k] = Tl[k];
-    m->loop_r.insert(m->loop_r.end(), r64, r64 + 64);
-    m->nc += ncl;
-    m->loops.push_back(lj);
-  }
+  if (int lst = build_loop_tables(m, d)) { delete m; return lst; }
   m->bank_aba_ok = (m->nloops == 0 && !m->has3dof && !m->inner_floating);  // the banked ABA handles 1-dof / fixed joints and 6-dof joints on the world
   if (m->nlevels >= 2) {
     // banked mapping (the RNEA variant takes every joint type): split the levels so that both banks fit the fewest lanes
@@ -695,46 +711,9 @@ static int upload(void** dst, const void* src, size_t bytes) {
   return RBD_OK;
 }
 
-int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device, int32_t dtype, void* stream, rbd_ws_t** out) {
-  if (!m || !out || max_batch < 1 || (dtype != RBD_F64 && dtype != RBD_F32)) return RBD_ERR_INVALID_ARGUMENT;
-  *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
-    g_last_hip_error = "hipGetDeviceCount: no device";
-    return RBD_ERR_NO_DEVICE;
-  }
-  if (device < 0 || device >= ndev) return RBD_ERR_INVALID_ARGUMENT;
-  HIP_TRY(hipSetDevice(device));
-  rbd_ws* w = new (std::nothrow) rbd_ws();
-  if (!w) return RBD_ERR_OUT_OF_MEMORY;
-  w->model = m; w->device = device; w->dtype = dtype; w->max_batch = max_batch; w->stream = (hipStream_t)stream;
-  if (m->big) {  // the any-size fallback needs its two tables only
-    int st = upload(&w->d_big_tbl, m->big_tbl.data(), m->big_tbl.size() * sizeof(int32_t));
-    if (st == RBD_OK) {
-      if (dtype == RBD_F64) st = upload(&w->d_big_rb, m->big_rb.data(), m->big_rb.size() * sizeof(double));
-      else { std::vector<float> f(m->big_rb.begin(), m->big_rb.end()); st = upload(&w->d_big_rb, f.data(), f.size() * sizeof(float)); }
-    }
-    if (st == RBD_OK) { int zero = 0; st = upload((void**)&w->d_notpd, &zero, sizeof(int)); }
-    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
-    w->big.nb = m->nb; w->big.nq = m->nq; w->big.nv = m->nv; w->big.tbl = (const int32_t*)w->d_big_tbl; w->big.rb = w->d_big_rb;
-    memcpy(w->big.gravity, m->gravity, sizeof w->big.gravity);
-    w->last_kernel = "big_* kernels (one thread per state, HBM scratch)";
-    *out = w;
-    return RBD_OK;
-  }
-  int st = upload(&w->d_ib, m->ib.data(), m->ib.size() * sizeof(int32_t));
-  if (st == RBD_OK) {
-    if (dtype == RBD_F64) {
-      st = upload(&w->d_rb, m->rb.data(), m->rb.size() * sizeof(double));
-    } else {
-      std::vector<float> rbf(m->rb.begin(), m->rb.end());
-      st = upload(&w->d_rb, rbf.data(), rbf.size() * sizeof(float));
-    }
-  }
-  if (st == RBD_OK) st = upload(&w->d_dof_body, m->dof_body.data(), m->dof_body.size() * sizeof(int32_t));
-  if (st == RBD_OK) st = upload(&w->d_anc, m->anc.data(), m->anc.size() * sizeof(int32_t));
-  if (st == RBD_OK) st = upload(&w->d_row_mask, m->row_mask.data(), m->row_mask.size() * sizeof(uint64_t));
-  if (st == RBD_OK) { int zero = 0; st = upload((void**)&w->d_notpd, &zero, sizeof(int)); }
+// the loop joints' tables on the device (workspace copies: rbd_workspace_set_loop_gains rewrites the gains in place)
+static int upload_loop_tables(rbd_ws* w, const rbd_model* m, int dtype) {
+  int st = RBD_OK;
   if (st == RBD_OK && m->nloops > 0) {
     st = upload(&w->d_loop_i, m->loop_i.data(), m->loop_i.size() * sizeof(int32_t));
     if (st == RBD_OK) st = upload(&w->d_loop_path, m->loop_path.data(), m->loop_path.size() * sizeof(int32_t));
@@ -758,6 +737,51 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
       }
     }
   }
+  return st;
+}
+
+int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device, int32_t dtype, void* stream, rbd_ws_t** out) {
+  if (!m || !out || max_batch < 1 || (dtype != RBD_F64 && dtype != RBD_F32)) return RBD_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    g_last_hip_error = "hipGetDeviceCount: no device";
+    return RBD_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) return RBD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(device));
+  rbd_ws* w = new (std::nothrow) rbd_ws();
+  if (!w) return RBD_ERR_OUT_OF_MEMORY;
+  w->model = m; w->device = device; w->dtype = dtype; w->max_batch = max_batch; w->stream = (hipStream_t)stream;
+  if (m->big) {  // the any-size fallback needs its two tables only
+    int st = upload(&w->d_big_tbl, m->big_tbl.data(), m->big_tbl.size() * sizeof(int32_t));
+    if (st == RBD_OK) {
+      if (dtype == RBD_F64) st = upload(&w->d_big_rb, m->big_rb.data(), m->big_rb.size() * sizeof(double));
+      else { std::vector<float> f(m->big_rb.begin(), m->big_rb.end()); st = upload(&w->d_big_rb, f.data(), f.size() * sizeof(float)); }
+    }
+    if (st == RBD_OK) { int zero = 0; st = upload((void**)&w->d_notpd, &zero, sizeof(int)); }
+    if (st == RBD_OK) st = upload_loop_tables(w, m, dtype);
+    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
+    w->big.nb = m->nb; w->big.nq = m->nq; w->big.nv = m->nv; w->big.tbl = (const int32_t*)w->d_big_tbl; w->big.rb = w->d_big_rb;
+    memcpy(w->big.gravity, m->gravity, sizeof w->big.gravity);
+    w->last_kernel = "big_* kernels (one thread per state, HBM scratch)";
+    *out = w;
+    return RBD_OK;
+  }
+  int st = upload(&w->d_ib, m->ib.data(), m->ib.size() * sizeof(int32_t));
+  if (st == RBD_OK) {
+    if (dtype == RBD_F64) {
+      st = upload(&w->d_rb, m->rb.data(), m->rb.size() * sizeof(double));
+    } else {
+      std::vector<float> rbf(m->rb.begin(), m->rb.end());
+      st = upload(&w->d_rb, rbf.data(), rbf.size() * sizeof(float));
+    }
+  }
+  if (st == RBD_OK) st = upload(&w->d_dof_body, m->dof_body.data(), m->dof_body.size() * sizeof(int32_t));
+  if (st == RBD_OK) st = upload(&w->d_anc, m->anc.data(), m->anc.size() * sizeof(int32_t));
+  if (st == RBD_OK) st = upload(&w->d_row_mask, m->row_mask.data(), m->row_mask.size() * sizeof(uint64_t));
+  if (st == RBD_OK) { int zero = 0; st = upload((void**)&w->d_notpd, &zero, sizeof(int)); }
+  if (st == RBD_OK) st = upload_loop_tables(w, m, dtype);
   if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
   DevModel& dm = w->dm;
   dm.nb = m->nb; dm.nq = m->nq; dm.nv = m->nv; dm.lps = m->lps; dm.nlevels = m->nlevels; dm.maxchild = m->maxchild; dm.maxnvj = m->maxnvj;
@@ -1210,6 +1234,8 @@ static hipFunction_t spec_walk(rbd_ws* w, bool rerooted, int kind = 0, int pair 
   src.clear(); src.shrink_to_fit();
   return w->spec_walk[k];
 }
+// scratch of the any-size kernels (rbd_big_kernels.hip)
+static int big_scratch(rbd_ws* w, int32_t B) { return ensure(&w->d_big_scratch, &w->d_big_scratch_bytes, esize(w) * big_scratch_elems(w->big, B)); }
 // small loop mechanisms compiled for the mechanism (rbd_loop_small.hpp against constant tables): nullptr when unavailable
 static hipFunction_t spec_loop(rbd_ws* w) {
   if (w->spec_loop_tried) return w->spec_loop;
@@ -1302,6 +1328,16 @@ int dynamics_loops_t(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const 
     w->last_kernel = "loop_fused_small_kernel";
     return RBD_OK;
   }
+  if (m->big) {  // more than 64 bodies: bias forces + per-body kinematics and the mass matrix from the any-size kernels, then the same constrained solve
+    if ((st = big_scratch(w, B))) return st;
+    HIP_TRY(launch_big_rnea<T>(w->big, B, dq, dv, nullptr, df, w->d_c, dqd, w->d_big_scratch, nullptr, nullptr, Lq, Lv, Lf, w->stream));
+    HIP_TRY(launch_big_export_body<T>(w->big, B, w->d_big_scratch, w->d_body, w->stream));
+    HIP_TRY(launch_big_crba<T>(w->big, B, dq, w->d_M, w->d_big_scratch, Lq, Lm, w->stream));
+    HIP_TRY(launch_loop_solve<T>(V, B, o.stabilization, w->d_body, w->d_M, w->d_c, dtau, dvd, dlam, w->d_K, w->d_k, w->d_scratch, stride, Lm, Lv, Lc, Lk,
+                                 m->gravity, w->d_notpd, w->stream));
+    w->last_kernel = "big_rnea + big_crba + loop_solve kernel";
+    return RBD_OK;
+  }
   HIP_TRY(launch_rnea<T>(w->dm, B, dq, dv, nullptr, df, w->d_c, dqd, w->d_body, Lq, Lv, Lf, w->stream));
   HIP_TRY(launch_crba<T>(w->dm, B, dq, w->d_M, Lq, Lm, 1, w->stream));
   HIP_TRY(launch_loop_solve<T>(V, B, o.stabilization, w->d_body, w->d_M, w->d_c, dtau, dvd, dlam, w->d_K, w->d_k, w->d_scratch, stride, Lm, Lv, Lc, Lk,
@@ -1315,8 +1351,6 @@ int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const vo
 }
 }  // namespace
 
-// scratch of the any-size kernels (rbd_big_kernels.hip)
-static int big_scratch(rbd_ws* w, int32_t B) { return ensure(&w->d_big_scratch, &w->d_big_scratch_bytes, esize(w) * big_scratch_elems(w->big, B)); }
 
 // inverse_dynamics! / dynamics_bias! (vdot == nullptr) through the lane mapping that fits the batch: same rule as run_aba
 static void spec_load(rbd_ws* w, int family, bool force = false);  // the kernels compiled for the mechanism (below)

@@ -93,6 +93,7 @@ hipError_t launch_big_rnea(const BigModel& M, long B, const void* q, const void*
                            void* acc_out, void* jw_out, Layout Lq, Layout Lv, Layout Lf, hipStream_t s);
 template <typename T>
 hipError_t launch_big_crba(const BigModel& M, long B, const void* q, void* Mout, void* scratch, Layout Lq, Layout Lm, hipStream_t s);
+template <typename T> hipError_t launch_big_export_body(const BigModel& M, long B, const void* scratch, void* body, hipStream_t s);
 template <typename T>
 hipError_t launch_big_chol_solve(int nv, long B, const void* Mg, void* Lg, const void* rhs, const void* c, void* x, Layout Lm, Layout Lv, int* notpd, hipStream_t s);
 }

@@ -1157,6 +1157,56 @@ def test_trees_of_more_than_64_bodies(rbd, oracle, dtype):
 
 
 @pytest.mark.gpu
+def test_loop_joints_on_a_tree_of_more_than_64_bodies(rbd, oracle):
+    """Round 4: the reference has no size limit for mechanisms with loop joints either (`constraint_jacobian!`, `constraint_bias!`, the loop branch of
+    `dynamics_solve!`: src/mechanism_algorithms.jl:574-673, :768-816).  A 72-body random tree (floating base, revolute / prismatic / fixed joints) closed by three
+    loop joints — Revolute, Fixed, QuaternionSpherical: nc = 14 — through the any-size kernels (bias forces, per-body kinematics, mass matrix) and the same
+    constrained solve: v̇, K, k, M, c against the oracle, the KKT residuals, and per-call stabilization gains."""
+    from rigidbodydynamics_jl_amd.builders import rand_joint_type, _rand_rotation
+    from rigidbodydynamics_jl_amd.mechanism import Joint, Transform3D, attach_
+    rng = np.random.default_rng(5)
+    tree = rbd.rand_tree_mechanism(rng, ["QuaternionFloating"] + ["Revolute"] * 60 + ["Prismatic"] * 8 + ["Fixed"] * 3)
+    bodies = tree.bodies[1:]
+    for k, name in enumerate(["Revolute", "Fixed", "QuaternionSpherical"]):
+        a, b = rng.choice(len(bodies), 2, replace=False)
+        j = Joint(f"loop{k}", rand_joint_type(rng, name))
+        attach_(tree, bodies[a], bodies[b], j, joint_pose=Transform3D(j.frame_before, bodies[a].default_frame, _rand_rotation(rng), rng.uniform(-0.5, 0.5, 3)),
+                successor_pose=Transform3D(bodies[b].default_frame, j.frame_after, _rand_rotation(rng), rng.uniform(-0.5, 0.5, 3)))
+    model = rbd.flatten(tree)
+    assert model.n_bodies == 72 and model.n_loops == 3 and model.nc == 14
+    B = 37
+    q, v, tau = rbd.rand_configuration(model, B, rng), rbd.rand_velocity(model, B, rng), rng.random((B, model.nv))
+    state = rbd.MechanismState(model, B)
+    result = rbd.DynamicsResult(model, B)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    custom = rbd.SE3PDGains(rbd.PDGains(30.0, 7.0), rbd.PDGains(55.0, 9.0))
+    for gains_arg, gains in (("default", [l["gains"] for l in model.loops]), (custom, [custom.as_tuple()] * 3), (None, None)):
+        rbd.dynamics_(result, state, dev(tau, state), stabilization_gains=gains_arg)
+        assert rbd.sync(state) == 0 and "big_" in rbd.last_kernel(state)
+        ref = oracle.dynamics_loops(_with_gains(model, gains) if gains else model, q, v, tau, stabilize=gains is not None)
+        got = host(result.vd, state)
+        assert np.abs(got - ref["vdot"]).max() <= 1e-8 * max(1.0, np.abs(ref["vdot"]).max()), gains_arg
+        K = host(result.constraintjacobian, state).reshape(B, model.nv, model.nc).transpose(0, 2, 1)
+        assert np.abs(K - ref["K"]).max() <= 1e-11 * max(1.0, np.abs(ref["K"]).max())
+        assert np.abs(host(result.constraintbias, state) - ref["k"]).max() <= 1e-9 * max(1.0, np.abs(ref["k"]).max())
+    Mg = host(result.massmatrix, state).reshape(B, model.nv, model.nv).transpose(0, 2, 1)
+    Mref = oracle.mass_matrix(model, q)
+    assert np.abs(np.tril(Mg) - np.tril(Mref)).max() <= 1e-10 * max(1.0, np.abs(Mref).max())
+    assert np.abs(host(result.dynamicsbias, state) - oracle.dynamics_bias(model, q, v, None)).max() <= 1e-9 * max(1.0, np.abs(host(result.dynamicsbias, state)).max())
+    Ms = np.tril(Mg) + np.transpose(np.tril(Mg, -1), (0, 2, 1))
+    lam = host(result.lambda_, state)
+    r1 = np.einsum("bij,bj->bi", Ms, got) + host(result.dynamicsbias, state) + np.einsum("bcv,bc->bv", K, lam) - tau
+    assert np.abs(r1).max() <= 1e-8 * max(1.0, np.abs(host(result.dynamicsbias, state)).max())
+    # entry points outside dynamics! still refuse such a model (simulate would need the integrator's lane kernels)
+    with pytest.raises(Exception):
+        rbd.simulate_(state, 1e-3, dt=1e-3)
+    tv = torch.zeros_like(state.v)
+    with pytest.raises(Exception):  # inverse_dynamics! on a mechanism with loop joints: "can currently only handle tree Mechanisms" (:549)
+        rbd.inverse_dynamics_(tv, state, dev(tau, state))
+
+
+@pytest.mark.gpu
 def test_maximal_coordinates_at_the_reference_size(rbd, oracle):
     """The reference's own pin of constraint_jacobian! / constraint_bias! / the loop branch of dynamics_solve! at ITS size
     (test/test_mechanism_modification.jl:274-318): QuaternionFloating + 10 Revolute + QuaternionSpherical + Planar + 10 Fixed + 5 SinCosRevolute
