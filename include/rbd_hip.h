@@ -173,9 +173,9 @@ typedef struct rbd_opts {
 
 /* ---- model / workspace lifetime ------------------------------------------ */
 /* Sizes: mechanisms of up to 64 moving bodies run on the wavefront-shaped kernels (any nv; at most 8 children per body).  Mechanisms of MORE than 64
- * bodies (no contact points; loop joints since header 400) are accepted too and run on one-thread-per-state kernels with an HBM scratch — rbd_dynamics
- * (with its loop branch), rbd_inverse_dynamics[_bodies], rbd_dynamics_bias[_bodies], rbd_mass_matrix, rbd_mass_matrix_solve, rbd_dynamics_result; every other
- * entry point returns RBD_ERR_UNSUPPORTED for such a model. */
+ * bodies (with loop joints or contact points since header 400) are accepted too and run on one-thread-per-state kernels with an HBM scratch — rbd_dynamics
+ * (with its loop branch), rbd_inverse_dynamics[_bodies], rbd_dynamics_bias[_bodies], rbd_mass_matrix, rbd_mass_matrix_solve, rbd_dynamics_result,
+ * rbd_contact_dynamics, rbd_dynamics_contact; every other entry point (simulate, kinematics by-products) returns RBD_ERR_UNSUPPORTED for such a model. */
 int rbd_model_create(const rbd_flat_model_t* desc, rbd_model_t** out); /* deep-copies desc */
 int rbd_model_destroy(rbd_model_t* model);
 /* Introspection of the chain schedule under the track / walk plans: tracks per state, steps per pass, (lds_fields: 0, kept for ABI

@@ -353,8 +353,8 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
   if (nb > 64) {
     // More bodies than a wavefront has lanes: the any-size fallback (rbd_big_kernels.hip) — tree mechanisms without contact points; dynamics!,
     // inverse_dynamics!, dynamics_bias!, mass_matrix!, mass_matrix_solve.  Everything else returns RBD_ERR_UNSUPPORTED for such a model.
-    // (round 4: loop joints too — their tables are in reference body indices, and the loop branch's kernels read per-body kinematics, M and c from memory)
-    if (m->ncp > 0) { delete m; return RBD_ERR_UNSUPPORTED; }
+    // (round 4: loop joints and contact points too — their tables are in reference body indices, and the loop branch's and the contact kernels read the
+    // per-body kinematics from memory)
     int qs = 0, vs = 0;
     m->big_tbl.resize(4 * (size_t)nb);
     m->big_rb.assign((size_t)nb * RB_STRIDE, 0.0);
@@ -740,6 +740,23 @@ static int upload_loop_tables(rbd_ws* w, const rbd_model* m, int dtype) {
   return st;
 }
 
+// soft contact: the points' and half-spaces' tables on the device (contact_kernel)
+static int upload_contact_tables(rbd_ws* w, const rbd_model* m, int dtype) {
+  if (m->ncp <= 0) return RBD_OK;
+  int st = upload(&w->d_cp_body, m->cp_body.data(), m->cp_body.size() * sizeof(int32_t));
+  auto up = [&](void** dst, const std::vector<double>& src) {
+    if (dtype == RBD_F64) return upload(dst, src.data(), src.size() * sizeof(double));
+    std::vector<float> f(src.begin(), src.end());
+    return upload(dst, f.data(), f.size() * sizeof(float));
+  };
+  if (st == RBD_OK) st = up(&w->d_cp_r, m->cp_r);
+  if (st == RBD_OK) st = up(&w->d_hs_r, m->hs_r);
+  if (st != RBD_OK) return st;
+  w->ctm.nb = m->nb; w->ctm.np = m->ncp; w->ctm.nh = m->nhs;
+  w->ctm.cbody = (const int32_t*)w->d_cp_body; w->ctm.cp = w->d_cp_r; w->ctm.hs = w->d_hs_r;
+  return RBD_OK;
+}
+
 int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device, int32_t dtype, void* stream, rbd_ws_t** out) {
   if (!m || !out || max_batch < 1 || (dtype != RBD_F64 && dtype != RBD_F32)) return RBD_ERR_INVALID_ARGUMENT;
   *out = nullptr;
@@ -761,6 +778,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     }
     if (st == RBD_OK) { int zero = 0; st = upload((void**)&w->d_notpd, &zero, sizeof(int)); }
     if (st == RBD_OK) st = upload_loop_tables(w, m, dtype);
+    if (st == RBD_OK) st = upload_contact_tables(w, m, dtype);
     if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
     w->big.nb = m->nb; w->big.nq = m->nq; w->big.nv = m->nv; w->big.tbl = (const int32_t*)w->d_big_tbl; w->big.rb = w->d_big_rb;
     memcpy(w->big.gravity, m->gravity, sizeof w->big.gravity);
@@ -874,19 +892,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     for (int k = 0; k < 5; ++k) { tm.sfm[k] = 0; for (int s2 = 0; s2 < P.ns; ++s2) tm.sfm[k] |= (uint64_t)((P.sf[s2] >> k) & 1) << s2; }
     memcpy(tm.gravity, m->gravity, sizeof tm.gravity);
   }
-  if (m->ncp > 0) {
-    st = upload(&w->d_cp_body, m->cp_body.data(), m->cp_body.size() * sizeof(int32_t));
-    auto up = [&](void** dst, const std::vector<double>& src) {
-      if (dtype == RBD_F64) return upload(dst, src.data(), src.size() * sizeof(double));
-      std::vector<float> f(src.begin(), src.end());
-      return upload(dst, f.data(), f.size() * sizeof(float));
-    };
-    if (st == RBD_OK) st = up(&w->d_cp_r, m->cp_r);
-    if (st == RBD_OK) st = up(&w->d_hs_r, m->hs_r);
-    if (st != RBD_OK) { rbd_workspace_destroy(w); return st; }
-    w->ctm.nb = m->nb; w->ctm.np = m->ncp; w->ctm.nh = m->nhs;
-    w->ctm.cbody = (const int32_t*)w->d_cp_body; w->ctm.cp = w->d_cp_r; w->ctm.hs = w->d_hs_r;
-  }
+  if ((st = upload_contact_tables(w, m, dtype)) != RBD_OK) { rbd_workspace_destroy(w); return st; }
   if (m->track.ok && m->walk.ok) {
     const TrackPlan& P = m->track;
     st = upload(&w->d_walk_wk, m->walk.wk.data(), m->walk.wk.size() * sizeof(int32_t));
@@ -2058,6 +2064,19 @@ static int run_contact(rbd_ws* w, int32_t B, const Opts& o, const void* dq, cons
   if ((st = ensure(&w->d_body, &w->d_body_bytes, es * (size_t)m->nb * 24 * B)) || (st = ensure(&w->d_c, &w->d_c_bytes, es * (size_t)m->nv * B))) return st;
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lf = layout_of(o.layout, 6L * m->nb, B);
   const Layout Ls = layout_of(o.layout, 3L * m->ncp * m->nhs, B);
+  if (m->big) {  // more than 64 bodies: the per-body kinematics from the any-size kernels
+    if ((st = big_scratch(w, B))) return st;
+    if (w->dtype == RBD_F64) {
+      HIP_TRY(launch_big_rnea<double>(w->big, B, dq, dv, nullptr, nullptr, w->d_c, nullptr, w->d_big_scratch, nullptr, nullptr, Lq, Lv, Lf, w->stream));
+      HIP_TRY(launch_big_export_body<double>(w->big, B, w->d_big_scratch, w->d_body, w->stream));
+      HIP_TRY(launch_contact<double>(w->ctm, B, w->d_body, ds, dsd, df, dcw, dtw, Ls, Lf, w->stream));
+    } else {
+      HIP_TRY(launch_big_rnea<float>(w->big, B, dq, dv, nullptr, nullptr, w->d_c, nullptr, w->d_big_scratch, nullptr, nullptr, Lq, Lv, Lf, w->stream));
+      HIP_TRY(launch_big_export_body<float>(w->big, B, w->d_big_scratch, w->d_body, w->stream));
+      HIP_TRY(launch_contact<float>(w->ctm, B, w->d_body, ds, dsd, df, dcw, dtw, Ls, Lf, w->stream));
+    }
+    return RBD_OK;
+  }
   if (w->dtype == RBD_F64) {
     HIP_TRY(launch_rnea<double>(w->dm, B, dq, dv, nullptr, nullptr, w->d_c, nullptr, w->d_body, Lq, Lv, Lf, w->stream));
     HIP_TRY(launch_contact<double>(w->ctm, B, w->d_body, ds, dsd, df, dcw, dtw, Ls, Lf, w->stream));
@@ -2076,6 +2095,7 @@ static int contact_scope(const rbd_ws* w, const Opts& o) {
 }
 
 int rbd_contact_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* s, void* contactwrenches, void* sdot, const rbd_opts_t* opts) {
+  BigOk big_ok;
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
@@ -2088,6 +2108,7 @@ int rbd_contact_dynamics(rbd_ws_t* w, int32_t B, const void* q, const void* v, v
 
 int rbd_dynamics_contact(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* s, const void* tau, const void* fext, void* vdot, void* qdot,
                          void* sdot, void* contactwrenches, void* totalwrenches, const rbd_opts_t* opts) {
+  BigOk big_ok;
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;

@@ -139,6 +139,44 @@ def test_contact_dynamics_matches_oracle(rbd, oracle, layout):
 
 
 @pytest.mark.gpu
+def test_contact_dynamics_on_a_tree_of_more_than_64_bodies(rbd, oracle):
+    """Round 4: contact points on a tree the wavefront-shaped kernels do not take (70 bodies): contact_dynamics! and dynamics! through the any-size kernels
+    (per-body kinematics from big_rnea_kernel's scratch, then the same contact kernel, then the reference's CRBA + Cholesky route) against the oracle."""
+    import torch
+    rng = np.random.default_rng(15)
+    mech = rbd.rand_tree_mechanism(rng, ["QuaternionFloating"] + ["Revolute"] * 69)
+    for b in mech.bodies[1:]:
+        if rng.random() < 0.15:
+            model = rbd.SoftContactModel(rbd.hunt_crossley_hertz(k=2e3 * (1 + rng.random()), alpha=0.3 * rng.random()),
+                                         rbd.ViscoelasticCoulombModel(0.3 + rng.random(), 1e3 * (1 + rng.random()), 1e2 * (1 + rng.random())))
+            rbd.add_contact_point_(b, rbd.ContactPoint(0.3 * rng.standard_normal(3), model))
+    rbd.add_environment_primitive_(mech, rbd.HalfSpace3D([0, 0, 0.2], [0.1, -0.2, 1.0]))
+    flat = rbd.flatten(mech)
+    assert flat.n_bodies == 70 and flat.ns > 0
+    B = 21
+    q, v = rbd.rand_configuration(flat, B, rng), rbd.rand_velocity(flat, B, rng)
+    s = 1e-3 * rng.standard_normal((B, flat.ns))
+    tau, fe = rng.random((B, flat.nv)), rng.random((B, 6 * flat.n_bodies))
+    vd_ref, s_ref, sd_ref, cw_ref, tw_ref = oracle.dynamics_contact(flat, q, v, s, tau, fe)
+    inside = (sd_ref.reshape(B, -1, 3) != 0).any(axis=2)
+    assert inside.any() and not inside.all()
+    state = rbd.MechanismState(flat, B)
+    rbd.set_configuration_(state, q); rbd.set_velocity_(state, v)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    state.s.copy_(dev(s))
+    result = rbd.DynamicsResult(flat, B)
+    rbd.dynamics_(result, state, dev(tau), dev(fe))
+    assert rbd.sync(state) == 0
+    rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    assert rel(result.contactwrenches.cpu().numpy(), cw_ref) <= 1e-10
+    assert rel(result.totalwrenches.cpu().numpy(), tw_ref) <= 1e-10
+    assert rel(result.sd.cpu().numpy(), sd_ref) <= 1e-10
+    assert rel(state.s.cpu().numpy(), s_ref) <= 1e-14
+    cond = np.linalg.cond(np.tril(oracle.mass_matrix(flat, q)) + np.transpose(np.tril(oracle.mass_matrix(flat, q), -1), (0, 2, 1))).max()
+    assert rel(result.vd.cpu().numpy(), vd_ref) <= 1e-14 * cond
+
+
+@pytest.mark.gpu
 def test_simulate_contact_ball_drop_batch(rbd, oracle):
     """`simulate` with contact on the GPU: a batch of balls dropped from different heights.  Against the numpy restatement after 120 steps
     (through first impact for the lowest drops) at 1e-9, and the energy balance of the reference's test along the whole 0.5 s."""
