@@ -239,7 +239,9 @@ int rbd_dynamics_bias(rbd_ws_t* ws, int32_t B, const void* q, const void* v, con
  *                                    / result.accelerations of dynamics_bias! (bias_accelerations!, :377-385);
  * both in the ROOT frame, (angular; linear) / (torque; force), bodies in the flat model's order, layout as fext.  With them
  * DynamicsResult's accelerations / jointwrenches / totalwrenches (src/dynamics_result.jl:26-29) are complete: totalwrenches of a
- * mechanism without contact points is the caller's own fext (mechanism_algorithms.jl:851-855).                                  */
+ * mechanism without contact points is the caller's own fext (mechanism_algorithms.jl:851-855).
+ * Large batches: the batch-innermost layout (RBD_LAYOUT_SOA) is the cheap one for these outputs — Atlas, 65 536 states, both outputs: fp32 51 us
+ * (state-major 100 us: the kernel stores batch-innermost scratch and a second kernel moves it), fp64 78 us (state-major 118 us).      */
 int rbd_inverse_dynamics_bodies(rbd_ws_t* ws, int32_t B, const void* q, const void* v, const void* vdot, const void* fext, void* tau_out,
                                 void* jointwrenches_out, void* accelerations_out, const rbd_opts_t* opts);
 int rbd_dynamics_bias_bodies(rbd_ws_t* ws, int32_t B, const void* q, const void* v, const void* fext, void* c_out, void* jointwrenches_out,

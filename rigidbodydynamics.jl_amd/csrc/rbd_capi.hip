@@ -116,7 +116,7 @@ struct rbd_ws {
   WalkModel wm_rr{}; bool walk_rr = false; void* d_rrtrack_ri = nullptr; void* d_rrtrack_rr = nullptr; void* d_rrwalk_wk = nullptr; size_t walk_rr_lds_bytes = 0, walk_rr_lds_bytes_pair = 0;
   TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr;  // the track plan's records: what the walk kernels read
   ContactModel ctm{}; void* d_cp_body = nullptr; void* d_cp_r = nullptr; void* d_hs_r = nullptr;  // soft contact tables
-  void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; size_t d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
+  void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; void* d_rows = nullptr; size_t d_rows_bytes = 0, d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
@@ -986,7 +986,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
 int rbd_workspace_destroy(rbd_ws_t* w) {
   if (!w) return RBD_OK;
   (void)hipSetDevice(w->device);
-  void* ptrs[] = {w->d_big_L, w->d_big_tbl, w->d_big_rb, w->d_big_scratch, w->d_fused_i, w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_walk_wk, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
+  void* ptrs[] = {w->d_big_L, w->d_big_tbl, w->d_big_rb, w->d_big_scratch, w->d_fused_i, w->d_tauwork, w->d_rr_chain_i, w->d_rr_chain_r, w->d_rrtrack_ri, w->d_rrtrack_rr, w->d_rrwalk_wk, w->d_cp_body, w->d_cp_r, w->d_hs_r, w->d_tw, w->d_cw, w->d_s0, w->d_sacc, w->d_sdot, w->d_rows, w->d_walk_wk, w->d_state_ops, w->d_state_cols, w->d_state_sr, w->d_Msoa, w->d_track_ri, w->d_track_rr, w->d_bank_ib[0], w->d_bank_ib[1], w->d_bank_rb[0], w->d_bank_rb[1], w->d_ib, w->d_rb, w->d_nslots, w->d_dof_body, w->d_anc, w->d_row_mask, w->d_M, w->d_c, w->d_K, w->d_k, (void*)w->d_notpd, w->d_body, w->d_scratch, w->d_loop_i, w->d_loop_r, w->d_loop_path, w->d_jt_ref, w->d_voff_ref, w->d_axis_ref, w->d_axis2_ref};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : w->stage) if (p) (void)hipFree(p);
   {
@@ -1376,15 +1376,35 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
   const bool can_walk = m->track.ok && m->walk.ok && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch));
   if (mapping == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
-  // the kernel compiled for the mechanism: large batches (q̇ is not one of its outputs; with the per-body outputs it is ahead of the walk kernel in fp32 only — 119 vs 149 us at
-  // 65 536 states, fp64: 146 vs 135 — so RBD_ALGO_ABA leaves that fp64 call with the walk kernel)
-  if (!dqd && (mapping == RBD_ALGO_ABA_COMPILED || (mapping == RBD_ALGO_ABA && !((dacc || djw) && w->dtype == RBD_F64)))) {
+  // the kernel compiled for the mechanism: large batches (q̇ is not one of its outputs).  Per-body outputs: a lane storing its own state-major row writes
+  // 24-byte pieces (65 536 fp32 states: 120 us against 42 without them, 51 into batch-innermost buffers), so for a state-major caller the fp32 kernel
+  // stores into batch-innermost scratch and rows_to_state_major_kernel moves it; fp64 state-major stays with the walk kernel under RBD_ALGO_ABA
+  // (118 us against 146), fp64 batch-innermost comes here.
+  const bool bodies = dacc || djw, rows_out = Lf.sb == 1;
+  if (!dqd && (mapping == RBD_ALGO_ABA_COMPILED || (mapping == RBD_ALGO_ABA && !(bodies && w->dtype == RBD_F64 && !rows_out)))) {
     if (mapping == RBD_ALGO_ABA_COMPILED || B >= w->spec_rnea_min_batch) spec_load(w, SPEC_RNEA, mapping == RBD_ALGO_ABA_COMPILED);
     if (w->spec_rnea && (mapping == RBD_ALGO_ABA_COMPILED || B >= w->spec_rnea_min_batch)) {
       long Bl = B;
-      void* args[] = {&Bl, &dq, &dv, &dvd, &df, &dtau, &Lq, &Lv, &Lf, &dacc, &djw};
+      const long ld = (long)B + 64;  // scratch rows 256 bytes past a power of two apart
+      const size_t es = w->dtype == RBD_F64 ? 8 : 4, each = es * 6 * (size_t)m->nb * (size_t)ld;
+      const bool staged = bodies && !rows_out && w->dtype == RBD_F32;
+      Layout Lo = Lf;
+      void *oacc = dacc, *ojw = djw;
+      if (staged) {
+        if (int st = ensure(&w->d_rows, &w->d_rows_bytes, 2 * each)) return st;
+        Lo = Layout{ld, 1};
+        if (dacc) oacc = w->d_rows;
+        if (djw) ojw = (char*)w->d_rows + each;
+      }
+      void* args[] = {&Bl, &dq, &dv, &dvd, &df, &dtau, &Lq, &Lv, &Lf, &oacc, &ojw, &Lo};
       HIP_TRY(hipModuleLaunchKernel(w->spec_rnea, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
-      w->last_kernel = w->dtype == RBD_F64 ? "rnea_spec_f64 (compiled for the mechanism at run time)" : "rnea_spec_f32 (compiled for the mechanism at run time)";
+      if (staged) {
+        if (dacc && djw) HIP_TRY(launch_rows_to_state_major<float>(6 * m->nb, B, ld, oacc, dacc, ojw, djw, w->stream));
+        else HIP_TRY(launch_rows_to_state_major<float>(6 * m->nb, B, ld, dacc ? oacc : ojw, dacc ? dacc : djw, nullptr, nullptr, w->stream));
+      }
+      w->last_kernel = w->dtype == RBD_F64 ? "rnea_spec_f64 (compiled for the mechanism at run time)"
+                       : staged            ? "rnea_spec_f32 (compiled for the mechanism at run time) + rows_to_state_major_kernel"
+                                           : "rnea_spec_f32 (compiled for the mechanism at run time)";
       return RBD_OK;
     }
   }

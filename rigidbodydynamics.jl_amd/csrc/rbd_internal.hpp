@@ -94,6 +94,9 @@ hipError_t launch_big_rnea(const BigModel& M, long B, const void* q, const void*
 template <typename T>
 hipError_t launch_big_crba(const BigModel& M, long B, const void* q, void* Mout, void* scratch, Layout Lq, Layout Lm, hipStream_t s);
 template <typename T> hipError_t launch_big_export_body(const BigModel& M, long B, const void* scratch, void* body, hipStream_t s);
+// dst[b * n + k] = src[k * ld + b] for one or two (src1 != nullptr) buffer pairs (n <= 384: per-body outputs of a one-lane-per-state kernel, stored
+// batch-innermost, for a state-major caller)
+template <typename T> hipError_t launch_rows_to_state_major(int n, long B, long ld, const void* src0, void* dst0, const void* src1, void* dst1, hipStream_t s);
 template <typename T>
 hipError_t launch_big_chol_solve(int nv, long B, const void* Mg, void* Lg, const void* rhs, const void* c, void* x, Layout Lm, Layout Lv, int* notpd, hipStream_t s);
 }

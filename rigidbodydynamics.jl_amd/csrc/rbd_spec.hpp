@@ -610,10 +610,12 @@ constexpr int RNEA_ROWS = P::NQ + 2 * P::NV;
 // along the path until the joint is un-composed; tau is stored by the lane.  19 KB of LDS per wavefront: four wavefronts per CU again.
 template <typename T, bool DIRECT = false>
 RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ vdot, const T* __restrict__ fext,
-                       T* __restrict__ tau, Layout Lq, Layout Lv, Layout Lf, T* __restrict__ acc_out, T* __restrict__ jw_out, T* lds) {
-  // acc_out / jw_out (nullable; 6 n_bodies x B, the layout of fext): accelerations[body] and jointwrenches[body] of the reference's inverse_dynamics!
+                       T* __restrict__ tau, Layout Lq, Layout Lv, Layout Lf, T* __restrict__ acc_out, T* __restrict__ jw_out, Layout Lo, T* lds) {
+  // acc_out / jw_out (nullable; 6 n_bodies x B in layout Lo — the caller's, or batch-innermost scratch the host transposes afterwards: a lane
+  // that stores its own state-major row writes 24-byte pieces 6 n_bodies elements apart, 77 us for the two outputs at 65 536 fp32 states
+  // against 12 us batch-innermost): accelerations[body] and jointwrenches[body] of the reference's inverse_dynamics!
   // signature (spatial_accelerations! :387-417 — the world's -g included, as the other kernels export it; joint_wrenches_and_torques! :442-459), stored by the lane
-  const bool out_vec = store6_vec(acc_out ? acc_out : jw_out, Lf, (int)sizeof(T)) && store6_vec(jw_out ? jw_out : acc_out, Lf, (int)sizeof(T));  // uniform
+  const bool out_vec = store6_vec(acc_out ? acc_out : jw_out, Lo, (int)sizeof(T)) && store6_vec(jw_out ? jw_out : acc_out, Lo, (int)sizeof(T));  // uniform
   constexpr int NQ = P::NQ, NV = P::NV, NBS = P::NBS > 0 ? P::NBS : 1, ML = P::NLEVELS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* rq = lds + (size_t)wave * (DIRECT ? NQ : RNEA_ROWS) * RS;
@@ -727,7 +729,7 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
       for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) K.p[k] = pn[k];
-      if (acc_out && live) store6(acc_out, (long)P::OPW[O][3], Lf, sc, K.a, out_vec);
+      if (acc_out && live) store6(acc_out, (long)P::OPW[O][3], Lo, sc, K.a, out_vec);
     } else {
       RInertia<T> I;
       T J6[6], mc[3];
@@ -749,7 +751,7 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
 #pragma unroll
         for (int k = 0; k < 6; ++k) f[k] += SF[bs][k];
       }
-      if (jw_out && live) store6(jw_out, (long)P::OPW[O][3], Lf, sc, f, out_vec);
+      if (jw_out && live) store6(jw_out, (long)P::OPW[O][3], Lo, sc, f, out_vec);
       T S[6], vJ[6], aJ[6];
       joint_motion(K.R, K.p, S, vJ, aJ);  // (reads v̇ from the tau rows before tau overwrites it)
       if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {

@@ -1401,6 +1401,8 @@ def test_per_body_outputs_from_every_mapping(rbd, oracle, models, mapping, dtype
         assert np.abs(host(tau, state) - t_ref).max() <= tol(t_ref)
         assert np.abs(host(jw, state).reshape(B, nb, 6) - jw_ref).max() <= tol(jw_ref)
         assert np.abs(host(acc, state).reshape(B, nb, 6) - acc_ref).max() <= tol(acc_ref)
+        if mapping == "compiled":  # fp32, state-major buffers: the lanes store batch-innermost scratch, a second kernel moves it
+            assert ("rows_to_state_major" in rbd.last_kernel(state)) == (dtype == "f32" and layout == "aos")
         # only one of the two, no v̇ (dynamics_bias!), no wrenches
         acc2 = torch.full_like(jw, float("nan"))
         rbd.inverse_dynamics_(tau, state, torch.zeros_like(state.v), None, mapping=mapping, accelerations=acc2)
