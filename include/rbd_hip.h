@@ -90,7 +90,8 @@ enum {
                                 Large batches                                                                                       */
   RBD_ALGO_ABA_PIPE = 7,     /* (round 2: a body-step cut into stages on the four SIMDs of a compute unit.  Removed; reserved)     */
   RBD_ALGO_ABA_COMPILED = 8  /* one lane per state, straight-line code compiled for the mechanism at run time (rbd_jit_* below): fp32,
-                                trees the one-lane-per-state kernels take; RBD_ALGO_ABA picks it from half a chip-full of wavefronts up.
+                                trees of every joint type above (since 400: Planar, QuaternionSpherical, QuaternionFloating below the world
+                                too), no loop joints, nv <= 64; RBD_ALGO_ABA picks it from half a chip-full of wavefronts up.
                                 RBD_ERR_UNSUPPORTED without hiprtc or outside that scope                                            */
 };
 
@@ -380,7 +381,8 @@ int rbd_version(void);
  * (fp32), 2: inverse_dynamics! / dynamics_bias! (fp32; fp64), 3: the whole loop-joint branch of dynamics! for small loop mechanisms (<= 4 bodies, nv <= 4,
  * nc <= 6: the four-bar linkage), 4 / 5: the one-wavefront-per-track kernels of dynamics! / inverse_dynamics! (batches beyond what the two-bodies-per-lane kernels hold at once), 6 / 7: the same with two
  * fp32 states per lane, 8: the two-bodies-per-lane kernels themselves (small batches — the bench workload — with the loops over the tree's levels unrolled against the
- * mechanism's level structure) — each compiled when a workspace first takes that route.
+ * mechanism's level structure) — each compiled when a workspace first takes that route.  Families 0-2 take every tree joint type; 4-7 and the fast form of 8 trees of 1-dof / fixed
+ * joints with 6-dof joints on the world.
  * rbd_jit_precompile compiles all of a model's programs of one scalar type (RBD_F32 / RBD_F64) into the cache ahead of time (no device needed);
  * rbd_jit_source returns the generated source of one (length without the terminator; buf may be NULL; -1: no such program for this mechanism). */
 int rbd_jit_precompile(const rbd_model_t* model, int32_t dtype, char* log, int64_t log_capacity);

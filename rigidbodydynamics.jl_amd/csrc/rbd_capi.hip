@@ -103,6 +103,8 @@ struct rbd_model {
   std::vector<double> cp_r, hs_r;  // ncp * CP_STRIDE, nhs * 6
   WalkPlan walk;    // parking slots of aba_walk_kernel on top of the track plan (walk.ok == false: track plan missing or too many steps)
   StatePlan state;  // plan of the one-lane-per-state kernels (state.ok == false: mechanism outside their scope)
+  StatePlan state_wide;  // ... of the ones compiled for the mechanism when it has 3-dof joints / 6-dof joints below the world (state.ok == false, state_wide.ok)
+  const StatePlan& spec_plan() const { return state.ok ? state : state_wide; }
 };
 
 struct rbd_ws {
@@ -129,7 +131,7 @@ struct rbd_ws {
   std::vector<double> loop_gains; bool custom_gains = false;  // rbd_workspace_set_loop_gains: this workspace's Baumgarte gains (4 per loop joint), and whether they differ from the model's
   void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
   long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0, walk_one_round_batch = 0, rnea_walk_min_batch = 0;
-  StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0;
+  StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0; bool state_aot = false;  // state_aot: the interpreting one-lane-per-state kernels take the mechanism
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   long bank_min_batch = 0, bank_resident_states = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
@@ -186,14 +188,14 @@ int rbd_version(void) { return RBD_HIP_H_VERSION; }
 static std::string program_source(const rbd_model* m, int32_t dtype, int32_t family) {
   if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 5) return std::string();
   std::vector<int32_t> xi;
-  if (family < SPEC_FAMILIES && !m->state.ok) return std::string();
+  if (family < SPEC_FAMILIES && !m->spec_plan().ok) return std::string();
   if (family == SPEC_FAMILIES + 5) return bank_program_source(m, dtype, bank_simple(m));  // (family 8: the two-bodies-per-lane kernels)
   return family == SPEC_FAMILIES + 4 ? (dtype == RBD_F32 ? walk_program_source(m, dtype, false, 1, 1) : std::string())  // (families 6, 7: 4 and 5 with two fp32 states per lane)
          : family == SPEC_FAMILIES + 3 ? (dtype == RBD_F32 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype, 1), 0, 1) : std::string())
          : family == SPEC_FAMILIES + 2 ? walk_program_source(m, dtype, false, 1)  // (family 5: ... and its inverse_dynamics! kernel, on the original tree)
          : family == SPEC_FAMILIES + 1 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype))  // (family 4: the one-wavefront-per-track dynamics! kernel)
          : family == SPEC_FAMILIES ? loop_program_source(m, dtype, &xi)  // (family 3: the program of a small loop mechanism)
-                                   : spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
+                                   : spec_source(m->spec_plan(), m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
 }
 static bool family_is_walk(int family) { return family > SPEC_FAMILIES && family <= SPEC_FAMILIES + 4; }
 int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char* buf, int64_t cap) {
@@ -215,7 +217,7 @@ int rbd_jit_status(const rbd_model_t* m, int32_t dtype, int32_t family) {
 int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t cap) {
   if (log && cap > 0) log[0] = 0;
   if (!m || (dtype != RBD_F32 && dtype != RBD_F64)) return RBD_ERR_INVALID_ARGUMENT;
-  if ((!m->state.ok && !m->loop_fused_ok && !(m->track.ok && m->walk.ok) && m->bank_lps <= 0) || !jit_available()) return RBD_ERR_UNSUPPORTED;
+  if ((!m->spec_plan().ok && !m->loop_fused_ok && !(m->track.ok && m->walk.ok) && m->bank_lps <= 0) || !jit_available()) return RBD_ERR_UNSUPPORTED;
   // the model's programs of this scalar type, the longest compilations first; every one of them on its own background thread (rbd_jit.hip), then wait for all
   struct Job { std::string src; bool walk; int family; int state; double seconds; std::string log; };
   std::vector<Job> jobs;
@@ -555,6 +557,7 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     if (m->nloops == 0 && G <= 4) m->track = build_track_plan(nb, m->ib, m->rb, G);
     if (m->track.ok) m->walk = build_walk_plan(m->track.ns, m->track.G, m->track.ri);
     if (m->nloops == 0 && m->nv <= 64) m->state = build_state_plan(nb, m->ib, m->rb);  // (the lane-per-state kernels keep one mask word per row)
+    if (m->nloops == 0 && m->nv <= 64 && !m->state.ok) m->state_wide = build_state_plan(nb, m->ib, m->rb, true);
   }
   // ---- the same tree re-rooted at its centre, for the ABA kernels that take it ----
   if (m->bank_aba_ok) {
@@ -967,6 +970,15 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     // the kernels compiled for the mechanism (spec_load): a wavefront of 64 states per SIMD — one round of them takes the same time from one wavefront to a
     // chip-full, and beats the walk kernel's rounds of half as many states from the second of those on.  Known here, before anything is compiled, so that a
     // small batch never starts (or waits for) a compilation it would not use
+    w->spec_aba_min_batch = w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
+    { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = t; }
+    { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
+    w->state_aot = true;
+  } else if (m->state_wide.ok) {  // the compiled kernels alone (no interpreting form of them for these joint types): the same thresholds, the lane-per-body kernels behind them
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+    w->state_min_batch = (long)ncu * 4 * 64 / 2;
+    { bool has; const long t = tune("state_min_batch", 0, &has); if (has) w->state_min_batch = t; }
     w->spec_aba_min_batch = w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
     { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = t; }
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
@@ -1425,7 +1437,7 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
     w->last_kernel = pair ? "rnea_walk_kernel (two fp32 states per lane)" : "rnea_walk_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_walk<double>(w->wm, m->track.has_floating, m->track.general, 0, B, w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
     else HIP_TRY(launch_rnea_walk<float>(w->wm, m->track.has_floating, m->track.general, pair, B, pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
-  } else if (!dacc && !djw && mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->state_min_batch) {  // one lane per state
+  } else if (w->state_aot && !dacc && !djw && mapping != RBD_ALGO_ABA_BANKS && mapping != RBD_ALGO_ABA_LANES && B >= w->state_min_batch) {  // one lane per state
     w->last_kernel = "rnea_state_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_state<double>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
     else HIP_TRY(launch_rnea_state<float>(w->sm, B, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream));
@@ -1555,11 +1567,11 @@ static bool capturing(rbd_ws* w) {
 static void spec_load(rbd_ws* w, int family, bool force) {
   if (w->spec_tried[family]) return;
   const rbd_model* m = w->model;
-  if (!m->state.ok || !jit_available() || !spec_has(family, w->dtype, m->nb, m->nq, m->nv)) { w->spec_tried[family] = true; return; }
+  if (!m->spec_plan().ok || !jit_available() || !spec_has(family, w->dtype, m->nb, m->nq, m->nv, m->spec_plan().n3)) { w->spec_tried[family] = true; return; }
   if (capturing(w)) return;  // a module cannot be loaded inside a stream capture: the interpreting kernels serve it, the next call outside tries again
   std::string log;
   std::string& src = w->spec_src[family];
-  if (src.empty()) src = spec_source(m->state, m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype, family);
+  if (src.empty()) src = spec_source(m->spec_plan(), m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype, family);
   std::vector<char> code;
   const int js = jit_code_object_get(src, force || !jit_async(), &code, &log);
   if (js == JIT_PENDING) return;
@@ -1654,11 +1666,14 @@ static int run_crba(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, 
     w->last_kernel = perm ? "crba_spec_perm_f32 + emit_spec_f32 (compiled for the mechanism at run time)" : "crba_spec_f64 + emit_spec_f64 (compiled for the mechanism at run time)";
     return RBD_OK;
   }
-  if (B >= w->state_min_batch && layout == RBD_LAYOUT_SOA) {  // one lane per state: its stores are coalesced when the batch is innermost
-    if (hipFunction_t f = spec_crba(w, esize(w) * (size_t)w->model->nv * w->model->nv * B)) HIP_TRY(launch_crba_spec(w, f, B, dq, dM, Lq, Lm, 1));
+  hipFunction_t const fsoa = B >= w->state_min_batch && layout == RBD_LAYOUT_SOA ? spec_crba(w, esize(w) * (size_t)w->model->nv * w->model->nv * B) : nullptr;
+  if (B >= w->state_min_batch && layout == RBD_LAYOUT_SOA && (fsoa || w->state_aot)) {  // one lane per state: its stores are coalesced when the batch is innermost
+    w->last_kernel = fsoa ? (w->dtype == RBD_F64 ? "crba_spec_f64 (compiled for the mechanism at run time)" : "crba_spec_f32 (compiled for the mechanism at run time)") : "crba_state_kernel";
+    if (hipFunction_t f = fsoa) HIP_TRY(launch_crba_spec(w, f, B, dq, dM, Lq, Lm, 1));
     else if (w->dtype == RBD_F64) HIP_TRY(launch_crba_state<double>(w->sm, B, dq, dM, Lq, Lm, 1, w->stream));
     else HIP_TRY(launch_crba_state<float>(w->sm, B, dq, dM, Lq, Lm, 1, w->stream));
   } else {
+    w->last_kernel = "crba_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_crba<double>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
     else HIP_TRY(launch_crba<float>(w->dm, B, dq, dM, Lq, Lm, 1, w->stream));
   }
@@ -1685,6 +1700,7 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
     spec_load(w, SPEC_MASS);
     const bool mcopy_ok = !dM || (Lm.sk == 1 && (Lm.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0);
     const bool spec_route = w->spec_chol && spec_crba_fits(w) && es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && mcopy_ok;
+    if (!spec_route && !w->state_aot && !spec_crba(w, es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15))) goto lanes;  // (a mechanism only the compiled kernels take, and they are not there)
     if ((st = stage_m(w, B, spec_route))) return st;
     const Layout Ls{16, -(long)m->nv * m->nv};  // grouped by 16 states = one wavefront of the tile Cholesky (layout_base, rbd_device.hpp)
     if (spec_route) {
@@ -1701,6 +1717,11 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
     HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_Msoa, dtau, dc, dx, nullptr, Ls, Lv, w->d_notpd, w->stream, dM, Lm));
     w->last_kernel = spec ? "crba_spec_f32 (compiled for the mechanism at run time) + chol_mfma_kernel" : "crba_state_kernel + chol_mfma_kernel";
     return RBD_OK;
+  }
+lanes:
+  if (!dM) {  // (the caller left M out counting on the staged route)
+    if ((st = ensure(&w->d_M, &w->d_M_bytes, es * (size_t)m->nv * m->nv * B))) return st;
+    dM = w->d_M;
   }
   if ((st = run_crba(w, B, layout, dq, dM, Lq, Lm))) return st;
   if (w->dtype == RBD_F64) HIP_TRY(launch_chol_solve<double>(m->nv, B, dM, dtau, dc, dx, nullptr, Lm, Lv, w->d_notpd, w->stream));

@@ -123,11 +123,11 @@ struct WalkModel {
 // ---- one lane per state (crba_state_kernel / rnea_state_kernel, rbd_state.hpp; plan: rbd_state_plan.hpp) ------------------------
 // The depth-first walk of the tree as a flat op list: ENTER(body) on the way down, EXIT(body) when its subtree is done.
 //   op words: w0 = kind | level << 8 | joint type << 16, slot, q offset, v offset, 6 * reference body index
-//   cols[op * SC_STRIDE + k]: velocity column of the op's body's ancestor at level k (-1: fixed joint; | SC_FLOATING: 6-dof joint on the world)
+//   cols[op * SC_STRIDE + k]: velocity column of the op's body's ancestor at level k (-1: fixed joint; | SC_FLOATING / SC_SPHERICAL / SC_PLANAR: the first column of a 6- / 3-dof joint)
 //   sr: the canonical-frame body constants of the track mapping (TR_* below), by op
 enum { SO_W0 = 0, SO_SLOT, SO_QOFF, SO_VOFF, SO_ORIG6, SO_STRIDE = 8 };
 enum { SK_ENTER = 0, SK_EXIT = 1 };
-enum { SC_STRIDE = 16, SC_FLOATING = 0x10000 };
+enum { SC_STRIDE = 16, SC_FLOATING = 0x10000, SC_SPHERICAL = 0x20000, SC_PLANAR = 0x40000, SC_MULTI = 0x70000 };  // (the last two: the plans of the compiled kernels only)
 struct StateModel {
   int32_t nb, nq, nv, nops, nlevels;
   const int32_t* ops;

@@ -11,7 +11,7 @@ bool jit_available();  // libhiprtc found and RBD_JIT != 0
 // One program per (family, scalar type): SPEC_MASS = mass_matrix! (+ the dense step and the emitter of M: fp32, nv a multiple of 4, nv <= 40), SPEC_ABA = dynamics!,
 // SPEC_RNEA = inverse_dynamics! / dynamics_bias!.  Empty string: no such program for this mechanism (spec_has).
 enum { SPEC_MASS = 0, SPEC_ABA = 1, SPEC_RNEA = 2, SPEC_FAMILIES = 3 };
-bool spec_has(int family, int dtype, int nb, int nq, int nv);
+bool spec_has(int family, int dtype, int nb, int nq, int nv, int n3 = 0);  // n3: 3-dof joints (10 more LDS rows each in dynamics!)
 bool spec_has_chol(int dtype, int nv);
 std::string spec_source(const StatePlan& P, int nb, int nq, int nv, const uint64_t* row_mask, const double* gravity, int dtype, int family);
 // The program of ONE small loop mechanism (rbd_loop_small.hpp with the loop tables as compile-time constants): loop_spec_f32 / loop_spec_f64.

@@ -46,7 +46,28 @@ RBD_DEV void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// (Rl, pl) = joint_to_predecessor * joint_transform(q) of op O in canonical frames (joint axis +z); qs: this lane's column of the staged q
+// joints with more than one velocity coordinate (quaternion_floating.jl, quaternion_spherical.jl, planar.jl): their motion subspace is constant in the body's
+// (canonical) frame and made of unit twists — coordinate k drives component comp_of(jt, k) of the body-frame twist (angular 0..2, linear 3..5; the planar
+// joint: linear x, linear y, angular z).  Seen from the root, column k is X(R, p) e_comp; S' f picks the same components of X^-T f.
+constexpr int nvj_of(int jt) { return jt == RBD_JOINT_QUAT_FLOATING ? 6 : (jt == RBD_JOINT_QUAT_SPHERICAL || jt == RBD_JOINT_PLANAR) ? 3 : jt == RBD_JOINT_FIXED ? 0 : 1; }
+constexpr int comp_of(int jt, int k) { return jt == RBD_JOINT_PLANAR ? (k == 0 ? 3 : k == 1 ? 4 : 2) : k; }
+constexpr int jt_of_col(int col) { return (col & SC_FLOATING) ? RBD_JOINT_QUAT_FLOATING : (col & SC_SPHERICAL) ? RBD_JOINT_QUAT_SPHERICAL : RBD_JOINT_PLANAR; }
+// body-frame twist of the joint's n coordinates at c[0], c[stride], ...
+template <typename T, int jt> RBD_DEV void body_twist(const T* c, int stride, T* v6) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v6[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < nvj_of(jt); ++k) v6[comp_of(jt, k)] = c[k * stride];
+}
+// inverse of a symmetric 3 x 3 matrix {a00, a01, a02, a11, a12, a22} (same packing out)
+template <typename T> RBD_DEV void sym3_inv(const T* a, T* o) {
+  const T c00 = a[3] * a[5] - a[4] * a[4], c01 = a[2] * a[4] - a[1] * a[5], c02 = a[1] * a[4] - a[2] * a[3];
+  const T id = rcp_hd(a[0] * c00 + a[1] * c01 + a[2] * c02);
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+  o[3] = (a[0] * a[5] - a[2] * a[2]) * id; o[4] = (a[1] * a[2] - a[0] * a[4]) * id; o[5] = (a[0] * a[3] - a[1] * a[1]) * id;
+}
+
+// (Rl, pl) = joint_to_predecessor * joint_transform(q) of op O in canonical frames (joint axis +z; planar: x, y, x × y = +x, +y, +z); qs: this lane's column of the staged q
 template <typename T, int O, int QS = 64> RBD_DEV void local_transform(const T* qs, T* Rl, T* pl) {
   constexpr int jt = P::OPW[O][0] >> 16, qoff = P::OPW[O][1];
   T C[9];
@@ -72,6 +93,21 @@ template <typename T, int O, int QS = 64> RBD_DEV void local_transform(const T* 
     matvec3(C, pq, t);
 #pragma unroll
     for (int k = 0; k < 3; ++k) pl[k] += t[k];
+  } else if constexpr (jt == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl:39-42
+    T Rq[9];
+    rot_quat(qs[qoff * QS], qs[(qoff + 1) * QS], qs[(qoff + 2) * QS], qs[(qoff + 3) * QS], Rq);
+    matmul3(C, Rq, Rl);
+  } else if constexpr (jt == RBD_JOINT_PLANAR) {  // planar.jl:65-70: translate in the x-y plane, turn about z
+    T s, c;
+    sincos_fast(qs[(qoff + 2) * QS], &s, &c);
+    const T x = qs[qoff * QS], y = qs[(qoff + 1) * QS];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Rl[3 * i] = c * C[3 * i] + s * C[3 * i + 1];
+      Rl[3 * i + 1] = c * C[3 * i + 1] - s * C[3 * i];
+      Rl[3 * i + 2] = C[3 * i + 2];
+      pl[i] += C[3 * i] * x + C[3 * i + 1] * y;
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rl[k] = C[k];
@@ -177,35 +213,42 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
 #pragma unroll
         for (int k = 0; k < 10; ++k) IC[lvl - 1][k] += IC[lvl][k];
       }
-      if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {  // level 0: the 6 x 6 block S' Ic S with S = Ad(H)
-        sfor<6>([&](auto cic) __attribute__((always_inline)) {
+      // this body's columns against an ancestor's: one entry for a 1-dof joint, the joint's components of X_anc^-T F for one with several
+      auto ancestors = [&](auto rowc, const T* F) __attribute__((always_inline)) {
+        constexpr int row = rowc.value;
+        sfor<lvl>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = kc.value, col = P::COLS[O][k];
+          if constexpr (col >= 0) {
+            if constexpr ((col & SC_MULTI) != 0) {
+              constexpr int ajt = jt_of_col(col);
+              T o6[6];
+              xforce_inv(X[k], X[k] + 9, F, o6);
+#pragma unroll
+              for (int cj = 0; cj < nvj_of(ajt); ++cj) put(row, (col & ~SC_MULTI) + cj, o6[comp_of(ajt, cj)]);
+            } else {
+              put(row, col, dot6(F, S[k]));
+            }
+          }
+        });
+      };
+      if constexpr (nvj_of(jt) > 1) {  // the n x n block S' Ic S with S = X(H) E, then the ancestors, column by column
+        sfor<nvj_of(jt)>([&](auto cic) __attribute__((always_inline)) {
           constexpr int ci = cic.value;
           T e[6], Si[6], Fc[6], o6[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) e[k] = (k == ci) ? T(1) : T(0);
-          xmotion(X[0], X[0] + 9, e, Si);
+          for (int k = 0; k < 6; ++k) e[k] = (k == comp_of(jt, ci)) ? T(1) : T(0);
+          xmotion(X[lvl], X[lvl] + 9, e, Si);
           mul_inertia(Ic, Si, Fc);
-          xforce_inv(X[0], X[0] + 9, Fc, o6);
+          xforce_inv(X[lvl], X[lvl] + 9, Fc, o6);
 #pragma unroll
-          for (int cj = 0; cj <= ci; ++cj) put(voff + ci, voff + cj, o6[cj]);
+          for (int cj = 0; cj <= ci; ++cj) put(voff + ci, voff + cj, o6[comp_of(jt, cj)]);
+          ancestors(Ix<voff + ci>{}, Fc);
         });
       } else if constexpr (jt != RBD_JOINT_FIXED) {
         T F[6];
         mul_inertia(Ic, S[lvl], F);
         put(voff, voff, dot6(F, S[lvl]));
-        sfor<lvl>([&](auto kc) __attribute__((always_inline)) {
-          constexpr int k = kc.value, col = P::COLS[O][k];
-          if constexpr (col >= 0) {
-            if constexpr ((col & SC_FLOATING) != 0) {
-              T o6[6];
-              xforce_inv(X[0], X[0] + 9, F, o6);
-#pragma unroll
-              for (int cj = 0; cj < 6; ++cj) put(voff, (col & ~SC_FLOATING) + cj, o6[cj]);
-            } else {
-              put(voff, col, dot6(F, S[k]));
-            }
-          }
-        });
+        ancestors(Ix<voff>{}, F);
       }
     }
   });
@@ -231,7 +274,7 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
 // q, v, tau of the wavefront's 64 states are staged through LDS rows (stride 65: conflict-free both ways); v̇ and q̇ leave the same way, q̇ first.
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int RS = 65;  // LDS row stride in values
-constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB);  // q, v, tau, spare
+constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB) + 10 * P::N3;  // q, v, tau, spare, ten of the 18 values of U D^-1 of every 3-dof joint
 
 // rows [0, n) <- the n x 64 block of a batch buffer that belongs to this wavefront's states (states past the end read the last one).  The loads of up to
 // 32 rows are all in flight before the first LDS write: a lone wavefront pays every global round trip in full (four at a time was 27 round trips
@@ -302,6 +345,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   T* rv = rq + NQ * RS;
   T* rt = rv + NV * RS;
   T* rx = rt + NV * RS;  // max(NQ, NB) rows: q̇ on its way out first, then one value per body for the top-down pass
+  T* r3 = rx + (NQ > NB ? NQ : NB) * RS;  // 10 rows per 3-dof joint: the part of its U D^-1 (18 values) that its v rows (3), its spare row and its four registers do not take
   const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
   if (state0 >= B) return;
   MkPre<T, (P::MK_N1 > 0 ? P::MK_N1 : 1)> mkp;  // `simulate`: the stage's loads of the base point and the running sums go out ahead of the staging (rbd_mk_fuse.hpp)
@@ -329,6 +373,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   T* vs = rv + lane;
   T* ts = rt + lane;
   T* xs = rx + lane;
+  T* x3 = r3 + lane;
   // q̇ (configuration_derivative!, src/mechanism_state.jl:905-910) depends on q and v alone: assembled in the spare rows and sent off before the
   // passes start (its stores drain while they run; the rows are free again long before pass 2 writes them)
   if (qdot) {
@@ -352,6 +397,20 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
           const T qd = vs[voff * RS];
           xs[qoff * RS] = qs[(qoff + 1) * RS] * qd;
           xs[(qoff + 1) * RS] = -qs[qoff * RS] * qd;
+        } else if constexpr (jt == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl velocity_to_configuration_derivative!
+          const T w0 = vs[voff * RS], w1 = vs[(voff + 1) * RS], w2 = vs[(voff + 2) * RS];
+          const T qw = qs[qoff * RS], qx = qs[(qoff + 1) * RS], qy = qs[(qoff + 2) * RS], qz = qs[(qoff + 3) * RS];
+          xs[qoff * RS] = (-qx * w0 - qy * w1 - qz * w2) / 2;
+          xs[(qoff + 1) * RS] = (qw * w0 - qz * w1 + qy * w2) / 2;
+          xs[(qoff + 2) * RS] = (qz * w0 + qw * w1 - qx * w2) / 2;
+          xs[(qoff + 3) * RS] = (-qy * w0 + qx * w1 + qw * w2) / 2;
+        } else if constexpr (jt == RBD_JOINT_PLANAR) {  // planar.jl velocity_to_configuration_derivative!: q̇_lin = Rot2(θ) v_lin
+          T sn, cs;
+          sincos_fast(qs[(qoff + 2) * RS], &sn, &cs);
+          const T vx = vs[voff * RS], vy = vs[(voff + 1) * RS];
+          xs[qoff * RS] = cs * vx - sn * vy;
+          xs[(qoff + 1) * RS] = sn * vx + cs * vy;
+          xs[(qoff + 2) * RS] = vs[(voff + 2) * RS];
         } else if constexpr (jt != RBD_JOINT_FIXED) {
           xs[qoff * RS] = vs[voff * RS];
         }
@@ -402,10 +461,9 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
       matvec3(K.R, pl, t3);
 #pragma unroll
       for (int k = 0; k < 3; ++k) pn[k] = K.p[k] + t3[k];
-      if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+      if constexpr (nvj_of(jt) > 1) {
         T v6[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v6[k] = vs[(voff + k) * RS];
+        body_twist<T, jt>(vs + voff * RS, RS, v6);
         xmotion(Rn, pn, v6, vJ);  // twist of the joint: X(H) v, v the body-frame twist
       } else if constexpr (jt == RBD_JOINT_FIXED) {
 #pragma unroll
@@ -454,18 +512,73 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
       }
       Hand<T> H;
       T S[6], qd = T(0);
+      T vJm[6];  // joints with several coordinates: their twist, kept for the un-composition (their v rows are given another use first)
       if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
-        // 6-dof joint on the world: IA a_delta = S^-T tau - pA, v̇ = S^-1 a_delta (S = X(H): the body-frame twist basis seen from the root)
-        T t6[6], f6[6], ad0[6], vd[6];
+        // 6-dof joint: IA a = S^-T tau - pA for the body's own a_delta whatever its parent's is, v̇ = S^-1 (a - a_parent) (S = X(H): the body-frame twist basis
+        // seen from the root).  On the world a_parent = 0 and v̇ is final here; below it the top-down pass finishes it.  The parent sees no inertia
+        // (IA - U D^-1 U' = 0) and the wrench S^-T tau
+        T t6[6], f6[6], ad0[6], vd[6], v6[6];
+        body_twist<T, jt>(vs + voff * RS, RS, v6);
+        xmotion(K.R, K.p, v6, vJm);
 #pragma unroll
         for (int k = 0; k < 6; ++k) t6[k] = ts[(voff + k) * RS];
         xforce(K.R, K.p, t6, f6);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) f6[k] -= pA[k];
-        sym6_solve(IA, f6, ad0);
-        xmotion_inv(K.R, K.p, ad0, vd);
+        for (int k = 0; k < 21; ++k) H.I[k] = T(0);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { ts[(voff + k) * RS] = vd[k]; vs[(voff + k) * RS] = ad0[k]; }  // a_delta waits in the joint's v rows
+        for (int k = 0; k < 6; ++k) { H.p[k] = f6[k]; f6[k] -= pA[k]; }
+        sym6_solve(IA, f6, ad0);
+        if constexpr (lvl == 0) {
+          xmotion_inv(K.R, K.p, ad0, vd);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ts[(voff + k) * RS] = vd[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vs[(voff + k) * RS] = ad0[k];  // a_delta waits in the joint's v rows
+      } else if constexpr (nvj_of(jt) == 3) {
+        // 3-dof joint: U = IA S (6 x 3), D = S'U, u = tau - S'pA; the top-down pass needs D^-1 u (tau rows) and W = U D^-1 (18 rows of the joint's own)
+        T v6[6], U[3][6], D[6], Di[6], u[3], du[3], W[3][6];
+        body_twist<T, jt>(vs + voff * RS, RS, v6);
+        xmotion(K.R, K.p, v6, vJm);
+        T Sm[3][6];
+        sfor<3>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = kc.value;
+          T e[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) e[i] = (i == comp_of(jt, k)) ? T(1) : T(0);
+          xmotion(K.R, K.p, e, Sm[k]);
+          sym6_mul(IA, Sm[k], U[k]);
+          u[k] = ts[(voff + k) * RS] - dot6(Sm[k], pA);
+        });
+        D[0] = dot6(Sm[0], U[0]); D[1] = dot6(Sm[0], U[1]); D[2] = dot6(Sm[0], U[2]);
+        D[3] = dot6(Sm[1], U[1]); D[4] = dot6(Sm[1], U[2]); D[5] = dot6(Sm[2], U[2]);
+        sym3_inv(D, Di);
+        du[0] = Di[0] * u[0] + Di[1] * u[1] + Di[2] * u[2];
+        du[1] = Di[1] * u[0] + Di[3] * u[1] + Di[4] * u[2];
+        du[2] = Di[2] * u[0] + Di[4] * u[1] + Di[5] * u[2];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          W[0][i] = U[0][i] * Di[0] + U[1][i] * Di[1] + U[2][i] * Di[2];
+          W[1][i] = U[0][i] * Di[1] + U[1][i] * Di[3] + U[2][i] * Di[4];
+          W[2][i] = U[0][i] * Di[2] + U[1][i] * Di[4] + U[2][i] * Di[5];
+        }
+        constexpr int xr = 10 * P::X3[O];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ts[(voff + k) * RS] = du[k];
+        sfor<18>([&](auto jc) __attribute__((always_inline)) {  // W[j / 6][j % 6]: v rows, spare row, registers, the joint's own rows
+          constexpr int j = jc.value;
+          const T x = W[j / 6][j % 6];
+          if constexpr (j < 3) vs[(voff + j) * RS] = x;
+          else if constexpr (j == 3) xs[body * RS] = x;
+          else if constexpr (j < 8) Ud[body][j - 4] = x;
+          else x3[(xr + j - 8) * RS] = x;
+        });
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j) H.I[SI(i, j)] = IA[SI(i, j)] - (W[0][i] * U[0][j] + W[1][i] * U[1][j] + W[2][i] * U[2][j]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) H.p[i] = pA[i] + U[0][i] * du[0] + U[1][i] * du[1] + U[2][i] * du[2];
       } else if constexpr (jt == RBD_JOINT_FIXED) {  // S = 0: the body hands its whole inertia up
 #pragma unroll
         for (int k = 0; k < 21; ++k) H.I[k] = IA[k];
@@ -509,7 +622,10 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
         if constexpr (jt != RBD_JOINT_FIXED) {
           T vJ[6], cb[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
+          for (int k = 0; k < 6; ++k) {
+            if constexpr (nvj_of(jt) > 1) vJ[k] = vJm[k];
+            else vJ[k] = S[k] * qd;
+          }
           se3_comm(K.Tw, vJ, cb);
 #pragma unroll
           for (int k = 0; k < 6; ++k) { K.av[k] -= cb[k]; K.Tw[k] -= vJ[k]; }
@@ -551,7 +667,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
         for (int k = 0; k < 6; ++k) ad[k] = SA[pbs][k];
       }
-      if constexpr (nch > 0 || (jt != RBD_JOINT_FIXED && jt != RBD_JOINT_QUAT_FLOATING)) {  // (a leaf on a fixed joint has nothing left to do)
+      if constexpr (nch > 0 || (jt != RBD_JOINT_FIXED && !(jt == RBD_JOINT_QUAT_FLOATING && lvl == 0))) {  // (a leaf on a fixed joint, or on a 6-dof joint on the world, has nothing left to do)
         T Rl[9], pl[3], Rn[9], t3[3];
         local_transform<T, O, RS>(qs, Rl, pl);
         matmul3(K.R, Rl, Rn);
@@ -561,8 +677,38 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
         for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
         if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+          T a0b[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) ad[k] = vs[(voff + k) * RS];  // solved for on the way up (v̇ is already in its rows)
+          for (int k = 0; k < 6; ++k) a0b[k] = vs[(voff + k) * RS];  // solved for on the way up
+          if constexpr (lvl > 0) {  // v̇ = S^-1 (a - a_parent); on the world it is already in its rows
+            T d6[6], vd6[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d6[k] = a0b[k] - ad[k];
+            xmotion_inv(K.R, K.p, d6, vd6);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ts[(voff + k) * RS] = vd6[k];
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ad[k] = a0b[k];
+        } else if constexpr (nvj_of(jt) == 3) {
+          constexpr int xr = 10 * P::X3[O];
+          T Wf[18], vd3[3];
+          sfor<18>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = jc.value;
+            if constexpr (j < 3) Wf[j] = vs[(voff + j) * RS];
+            else if constexpr (j == 3) Wf[j] = xs[body * RS];
+            else if constexpr (j < 8) Wf[j] = Ud[body][j - 4];
+            else Wf[j] = x3[(xr + j - 8) * RS];
+          });
+#pragma unroll
+          for (int k = 0; k < 3; ++k) vd3[k] = ts[(voff + k) * RS] - dot6(Wf + 6 * k, ad);  // v̇ = D^-1 u - (U D^-1)' a_delta,parent
+          T v6[6], aj[6];
+          body_twist<T, jt>(vd3, 1, v6);
+          xmotion(K.R, K.p, v6, aj);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ad[k] += aj[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) ts[(voff + k) * RS] = vd3[k];
         } else if constexpr (jt != RBD_JOINT_FIXED) {
           T S[6];
           if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = T(0); S[3] = K.R[2]; S[4] = K.R[5]; S[5] = K.R[8]; }
@@ -645,13 +791,13 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
   const T* ag = vdot ? vdot + sc * Lv.sb : nullptr;
   T* tg = tau + sc * Lv.sb;
   const long vsk = Lv.sk;
-  T nv6[6], na6[6];          // DIRECT: velocity / acceleration coordinates of the next body to be entered (6 only for a 6-dof root)
+  T nv6[6], na6[6];          // DIRECT: velocity / acceleration coordinates of the next body to be entered (more than one: 3- / 6-dof joints)
   T PV[ML], PA[ML];          // DIRECT: those of the 1-dof joints on the path
-  T RV[6], RA[6];            // DIRECT: those of a 6-dof root
+  T MV[ML][6], MA[ML][6];    // DIRECT: those of the 3- / 6-dof joints on the path (only the levels that have one exist)
   auto prefetch = [&](auto oc) __attribute__((always_inline)) {
     constexpr int O = oc.value;
     if constexpr (DIRECT && O >= 0) {
-      constexpr int jt = P::OPW[O][0] >> 16, voff = P::OPW[O][2], n = jt == RBD_JOINT_QUAT_FLOATING ? 6 : jt == RBD_JOINT_FIXED ? 0 : 1;
+      constexpr int jt = P::OPW[O][0] >> 16, voff = P::OPW[O][2], n = nvj_of(jt);
 #pragma unroll
       for (int k = 0; k < n; ++k) { nv6[k] = vg[(long)(voff + k) * vsk]; na6[k] = ag ? ag[(long)(voff + k) * vsk] : T(0); }
     }
@@ -674,13 +820,10 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
     constexpr int nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
     // the joint's twist and acceleration in the root frame, from the body's transform (used entering the body and un-composing it)
     auto joint_motion = [&](const T* R, const T* p, T* S, T* vJ, T* aJ) __attribute__((always_inline)) {
-      if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+      if constexpr (nvj_of(jt) > 1) {
         T v6[6], a6[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          if constexpr (DIRECT) { v6[k] = RV[k]; a6[k] = RA[k]; }
-          else { v6[k] = vs[(voff + k) * RS]; a6[k] = ts[(voff + k) * RS]; }
-        }
+        if constexpr (DIRECT) { body_twist<T, jt>(MV[lvl], 1, v6); body_twist<T, jt>(MA[lvl], 1, a6); }
+        else { body_twist<T, jt>(vs + voff * RS, RS, v6); body_twist<T, jt>(ts + voff * RS, RS, a6); }
         xmotion(R, p, v6, vJ);
         xmotion(R, p, a6, aJ);
       } else if constexpr (jt == RBD_JOINT_FIXED) {
@@ -698,9 +841,9 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
     };
     if constexpr (kind == SK_ENTER) {
       if constexpr (DIRECT) {  // the coordinates asked for at the ENTER before this one; then ask for the next body's
-        if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+        if constexpr (nvj_of(jt) > 1) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) { RV[k] = nv6[k]; RA[k] = na6[k]; }
+          for (int k = 0; k < nvj_of(jt); ++k) { MV[lvl][k] = nv6[k]; MA[lvl][k] = na6[k]; }
         } else if constexpr (jt != RBD_JOINT_FIXED) {
           PV[lvl] = nv6[0]; PA[lvl] = na6[0];
         }
@@ -754,13 +897,13 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
       if (jw_out && live) store6(jw_out, (long)P::OPW[O][3], Lo, sc, f, out_vec);
       T S[6], vJ[6], aJ[6];
       joint_motion(K.R, K.p, S, vJ, aJ);  // (reads v̇ from the tau rows before tau overwrites it)
-      if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
+      if constexpr (nvj_of(jt) > 1) {
         T o6[6];
         xforce_inv(K.R, K.p, f, o6);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          if constexpr (DIRECT) { if (live) tg[(long)(voff + k) * vsk] = o6[k]; }
-          else ts[(voff + k) * RS] = o6[k];
+        for (int k = 0; k < nvj_of(jt); ++k) {
+          if constexpr (DIRECT) { if (live) tg[(long)(voff + k) * vsk] = o6[comp_of(jt, k)]; }
+          else ts[(voff + k) * RS] = o6[comp_of(jt, k)];
         }
       } else if constexpr (jt != RBD_JOINT_FIXED) {
         const T t = dot6(S, f);

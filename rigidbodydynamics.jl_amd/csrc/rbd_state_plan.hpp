@@ -16,13 +16,15 @@ namespace rbd {
 
 struct StatePlan {
   bool ok = false;
+  bool wide = false;  // 3-dof joints or 6-dof joints below the world on the walk: the kernels compiled for the mechanism take them (rbd_spec.hpp), the interpreting ones do not
+  int n3 = 0;         // 3-dof joints
   int nops = 0, nlevels = 0;
   std::vector<int32_t> ops;   // [nops * SO_STRIDE]
   std::vector<int32_t> cols;  // [nops * SC_STRIDE] (by op): velocity column of the ancestor at level k (k < level), -1 for a fixed joint, | SC_FLOATING for a 6-dof root
   std::vector<double> sr;     // [nops * TR_STRIDE] (by op)
 };
 
-inline StatePlan build_state_plan(int nb, const std::vector<int32_t>& ib, const std::vector<double>& rb) {
+inline StatePlan build_state_plan(int nb, const std::vector<int32_t>& ib, const std::vector<double>& rb, bool wide = false) {
   using namespace trackplan;
   StatePlan P;
   auto I = [&](int s, int f) { return ib[(size_t)s * IB_STRIDE + f]; };
@@ -30,8 +32,11 @@ inline StatePlan build_state_plan(int nb, const std::vector<int32_t>& ib, const 
     const int t = I(s, IB_JTYPE);
     if (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC || t == RBD_JOINT_FIXED || t == RBD_JOINT_SINCOS_REVOLUTE) continue;
     if (t == RBD_JOINT_QUAT_FLOATING && I(s, IB_PARENT) < 0) continue;
-    return P;  // 3-dof joints, inner 6-dof joints: the lane-per-body kernels
-    }
+    if (!wide) return P;  // 3-dof joints, inner 6-dof joints: the lane-per-body kernels, or the kernels compiled for the mechanism (wide plan)
+    if (t != RBD_JOINT_QUAT_FLOATING && t != RBD_JOINT_QUAT_SPHERICAL && t != RBD_JOINT_PLANAR) return P;
+    P.wide = true;
+    if (t != RBD_JOINT_QUAT_FLOATING) ++P.n3;
+  }
   for (int s = 0; s < nb; ++s) {
     if (I(s, IB_LEVEL) + 1 > P.nlevels) P.nlevels = I(s, IB_LEVEL) + 1;
     if (s > 0 && I(s, IB_PARENT) >= s) return P;  // not pre-order (never happens for rbd_model slots)
@@ -61,6 +66,8 @@ inline StatePlan build_state_plan(int nb, const std::vector<int32_t>& ib, const 
       const int t = I(a, IB_JTYPE);
       int32_t c = -1;
       if (t == RBD_JOINT_QUAT_FLOATING) c = I(a, IB_VOFF) | SC_FLOATING;
+      else if (t == RBD_JOINT_QUAT_SPHERICAL) c = I(a, IB_VOFF) | SC_SPHERICAL;
+      else if (t == RBD_JOINT_PLANAR) c = I(a, IB_VOFF) | SC_PLANAR;
       else if (t != RBD_JOINT_FIXED) c = I(a, IB_VOFF);
       P.cols[(size_t)s * SC_STRIDE + I(a, IB_LEVEL)] = c;
       a = I(a, IB_PARENT);
@@ -72,7 +79,12 @@ inline StatePlan build_state_plan(int nb, const std::vector<int32_t>& ib, const 
     double* Ps = &Pb[(size_t)s * 9];
     const int t = I(s, IB_JTYPE);
     if (t == RBD_JOINT_REVOLUTE || t == RBD_JOINT_PRISMATIC || t == RBD_JOINT_SINCOS_REVOLUTE) frame_with_z(&rb[(size_t)s * RB_STRIDE + RB_AXIS], Ps);
-    else { Ps[0] = Ps[4] = Ps[8] = 1.0; }
+    else if (t == RBD_JOINT_PLANAR) {  // columns x, y, x × y (planar.jl:65-86): the joint translates along +x, +y and turns about +z
+      const double* ax = &rb[(size_t)s * RB_STRIDE + RB_AXIS];
+      const double* ay = &rb[(size_t)s * RB_STRIDE + RB_AXIS2];
+      const double az[3] = {ax[1] * ay[2] - ax[2] * ay[1], ax[2] * ay[0] - ax[0] * ay[2], ax[0] * ay[1] - ax[1] * ay[0]};
+      for (int i = 0; i < 3; ++i) { Ps[3 * i] = ax[i]; Ps[3 * i + 1] = ay[i]; Ps[3 * i + 2] = az[i]; }
+    } else { Ps[0] = Ps[4] = Ps[8] = 1.0; }
   }
   const double Id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   P.sr.assign((size_t)nb * TR_STRIDE, 0.0);

@@ -12,6 +12,9 @@ models["quickstart_pendulum"] = rbd.flatten(rbd.quickstart_double_pendulum())
 models["four_bar"] = rbd.flatten(rbd.four_bar_linkage())
 for seed in (1, 2, 3):
     models[f"randmech{seed}"] = rbd.flatten(rbd.randmech(np.random.default_rng(seed)))
+models["inner_floating"] = rbd.flatten(rbd.rand_tree_mechanism(np.random.default_rng(7), ["Revolute", "Prismatic", "QuaternionFloating", "Revolute", "QuaternionSpherical", "Planar", "QuaternionFloating", "Revolute"]))
+models["mixed20"] = rbd.flatten(rbd.rand_tree_mechanism(np.random.default_rng(11), ["QuaternionFloating", "QuaternionSpherical", "Planar", "Revolute", "Revolute", "Prismatic",
+                                                                                   "QuaternionSpherical", "Revolute", "SinCosRevolute"]))
 for name, model in models.items():
     for dt in (torch.float32, torch.float64):
         t = time.time()

@@ -48,6 +48,9 @@ def models(rbd):
         m[f"randmech{seed}"] = rbd.flatten(rbd.randmech(np.random.default_rng(seed)))
     # a 6-dof joint in the middle of a chain (maximal-coordinates style) and a spherical/planar mix below it
     m["inner_floating"] = rbd.flatten(rbd.rand_tree_mechanism(np.random.default_rng(7), ["Revolute", "Prismatic", "QuaternionFloating", "Revolute", "QuaternionSpherical", "Planar", "QuaternionFloating", "Revolute"]))
+    # ... and one whose nv is a multiple of 4 (the Cholesky compiled for the mechanism's sparsity then applies): 6 + 3 + 3 + 1 + 1 + 1 + 3 + 1 + 1 = 20
+    m["mixed20"] = rbd.flatten(rbd.rand_tree_mechanism(np.random.default_rng(11), ["QuaternionFloating", "QuaternionSpherical", "Planar", "Revolute", "Revolute", "Prismatic",
+                                                                                     "QuaternionSpherical", "Revolute", "SinCosRevolute"]))
     return m
 
 

@@ -14,6 +14,9 @@ from test_gpu_parity import NT, TD, dev, host, make
 
 pytestmark = pytest.mark.gpu
 IN_SCOPE = ["atlas_floating", "atlas_fixed", "valkyrie_floating", "double_pendulum", "acrobot_urdf", "quickstart_pendulum"]
+# Planar / QuaternionSpherical joints, QuaternionFloating joints below the world (the reference's randmech, test/test_mechanism_algorithms.jl:1-11): the
+# kernels compiled for the mechanism take them, the interpreting one-lane-per-state kernels do not (the lane-per-body kernels stand behind)
+EVERY_JOINT_TYPE = ["randmech1", "randmech2", "randmech3", "inner_floating", "mixed20"]
 
 
 @pytest.fixture(params=["compiled", "interpreted"])
@@ -28,7 +31,7 @@ def sym(M):
 
 
 @pytest.mark.parametrize("layout", ["aos", "soa"])
-@pytest.mark.parametrize("name", IN_SCOPE)
+@pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE)
 def test_state_kernels_f64(rbd, oracle, models, name, layout, states_everywhere):
     model = models[name]
     B, nv = 70, model.nv  # two wavefronts, the second partly filled
@@ -61,7 +64,7 @@ def test_state_kernels_f64(rbd, oracle, models, name, layout, states_everywhere)
 
 
 @pytest.mark.parametrize("layout", ["aos", "soa"])
-@pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating", "double_pendulum"])
+@pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating", "double_pendulum", "mixed20", "randmech1"])
 def test_state_kernels_f32_solve(rbd, oracle, models, name, layout, states_everywhere):
     """fp32: mass_matrix! + Cholesky solve (BASELINE configs[2] shape).  AOS callers get M re-emitted by the tile Cholesky from the staging copy."""
     model = models[name]
@@ -210,7 +213,7 @@ def backward_error(oracle, model, q, v, tau, fe, vd):
 
 
 @pytest.mark.parametrize("layout", ["aos", "soa"])
-@pytest.mark.parametrize("name", IN_SCOPE)
+@pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE)
 def test_compiled_aba_f32(rbd, oracle, models, name, layout):
     """`dynamics!` through the kernel compiled for the mechanism, forced (RBD_ALGO_ABA_COMPILED): a ragged batch (three wavefronts, the last partly
     filled), torques + a wrench on every body + q̇; then no torques and no wrenches; against the oracle (backward error, the q̇ map exactly to fp32)
@@ -429,7 +432,7 @@ def test_compiled_aba_is_the_default_for_large_fp32_batches(rbd, oracle, models)
 # ---- inverse_dynamics! / dynamics_bias! compiled for the mechanism (rnea_spec) ------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 @pytest.mark.parametrize("layout", ["aos", "soa"])
-@pytest.mark.parametrize("name", IN_SCOPE)
+@pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE)
 def test_compiled_rnea(rbd, oracle, models, name, layout, dtype):
     """`inverse_dynamics!` (v̇ and a wrench on every body) and `dynamics_bias!` through rnea_spec, forced, on a ragged batch, against the fp64 oracle
     (fp32: q, v, v̇ staged through LDS; fp64: q alone, v and v̇ read by the lane one body ahead); and against the lane-per-body kernel."""
@@ -489,3 +492,32 @@ def test_compiled_aba_as_the_mass_matrix_solve(rbd, oracle, models):
     res = np.einsum("bij,bj->bi", Ms, xg) - tau[idx]
     eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau[idx], axis=1))
     assert eta.max() <= 2e-6, eta.max()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("name", EVERY_JOINT_TYPE)
+def test_compiled_mass_matrix_every_joint_type(rbd, oracle, models, name, dtype, monkeypatch):
+    """`mass_matrix!` of mechanisms with 3-dof joints and 6-dof joints below the world through crba_spec (batch-innermost M: the kernel's own stores), a ragged
+    batch, structural zeros included; and the same M through the Cholesky solve."""
+    tune(monkeypatch, state_min_batch="1")
+    model = models[name]
+    B, nv = 70, model.nv
+    state, q, v, tau, _ = make(rbd, model, B, dtype, "soa", 43)
+    result = rbd.DynamicsResult(model, B, dtype=TD[dtype], layout="soa")
+    result.massmatrix.fill_(float("nan"))
+    rbd.mass_matrix_(result, state)
+    if "crba_spec" not in rbd.last_kernel(state):
+        pytest.skip("hiprtc not available: " + rbd.last_kernel(state))
+    got = host(result.massmatrix, state).reshape(B, nv, nv).transpose(0, 2, 1)
+    Mr = oracle.mass_matrix(model, q)
+    il = np.tril_indices(nv)
+    assert np.isfinite(got[:, il[0], il[1]]).all()
+    assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= (1e-10 if dtype == "f64" else 2e-6) * max(1.0, np.abs(Mr).max())
+    x = torch.zeros_like(state.v)
+    rbd.mass_matrix_solve_(x, state, dev(tau, state), result.massmatrix)
+    assert rbd.sync(state) == 0
+    Ms = sym(Mr)
+    xg = host(x, state)
+    res = np.einsum("bij,bj->bi", Ms, xg) - tau
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau, axis=1))
+    assert eta.max() <= (1e-12 if dtype == "f64" else 1e-5), eta.max()
