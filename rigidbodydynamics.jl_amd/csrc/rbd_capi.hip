@@ -1726,7 +1726,8 @@ lanes:
   if ((st = run_crba(w, B, layout, dq, dM, Lq, Lm))) return st;
   if (w->dtype == RBD_F64) HIP_TRY(launch_chol_solve<double>(m->nv, B, dM, dtau, dc, dx, nullptr, Lm, Lv, w->d_notpd, w->stream));
   else HIP_TRY(launch_chol_solve<float>(m->nv, B, dM, dtau, dc, dx, nullptr, Lm, Lv, w->d_notpd, w->stream));
-  w->last_kernel = (state && layout == RBD_LAYOUT_SOA) ? "crba_state_kernel + chol kernel" : "crba_kernel + chol kernel";
+  w->last_kernel = strstr(w->last_kernel, "crba_spec") ? "crba_spec (compiled for the mechanism at run time) + chol kernel"
+                   : strstr(w->last_kernel, "crba_state") ? "crba_state_kernel + chol kernel" : "crba_kernel + chol kernel";
   return RBD_OK;
 }
 
