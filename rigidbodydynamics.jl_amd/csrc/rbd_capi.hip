@@ -86,7 +86,7 @@ struct rbd_model {
   std::vector<double> bank_rb[2];
   uint64_t bank_perm_down = 0;
   ChainPlan chain;  // the chains of the tree packed on G tracks by list scheduling: what the track / walk plans are built on (rbd_model_chain_plan exposes it)
-  TrackPlan track;  // plan of aba_track_kernel (track.ok == false: mechanism outside its scope)
+  TrackPlan track;  // the track schedule of the walk kernels (track.ok == false: mechanism outside their scope)
   // the tree re-rooted at its centre (rbd_reroot.hpp): its own slots, banks and track / walk plans; used by the ABA kernels that support it
   Reroot rr;
   struct RrSlots {

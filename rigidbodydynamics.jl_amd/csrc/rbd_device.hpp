@@ -92,7 +92,7 @@ struct BankModel {
   double gravity[3];
 };
 
-// ---- track-scheduled ABA with canonical body frames (aba_track_kernel, rbd_track.hpp; plan: rbd_track_plan.hpp) ----------
+// ---- the track schedule with canonical body frames (the walk kernels, rbd_walk.hpp; plan: rbd_track_plan.hpp) ----------
 // One packed int4 and one 24-scalar record per (step, track):
 //   w0 = qoff | voff << 16;  w1 = 6*orig | flags << 16 | n_cross_children << 24;
 //   w2 = (A/C mailbox to write + 1) | (A/C mailbox to read + 1) << 16;  w3 = (B mailbox to write + 1) | (first B mailbox to read + 1) << 16
@@ -105,7 +105,7 @@ struct TrackModel {
   int32_t ns, G, nA, nB;
   const int32_t* ri;  // [ns * G * TI_STRIDE]
   const void* rr;     // [ns * G * TR_STRIDE] of the kernel's scalar type
-  uint64_t sfm[5];    // wave-uniform flags of the steps (SF_* bit k of step s = bit s of sfm[k], rbd_track.hpp): which rare blocks any lane needs
+  uint64_t sfm[5];    // wave-uniform flags of the steps (SF_* bit k of step s = bit s of sfm[k], rbd_walk.hpp): which rare blocks any lane needs
   double gravity[3];
 };
 
@@ -116,7 +116,7 @@ struct WalkModel {
   const int32_t* ri;  // [ns * G * TI_STRIDE]  track-plan records
   const void* rr;     // [ns * G * TR_STRIDE]  ... constants, kernel scalar type
   const int32_t* wk;  // [ns * G]              parking slots (rbd_walk_plan.hpp)
-  uint64_t sfm[5];    // wave-uniform step flags (SF_* of rbd_track.hpp)
+  uint64_t sfm[5];    // wave-uniform step flags (SF_* of rbd_walk.hpp)
   double gravity[3];
 };
 

@@ -1,4 +1,4 @@
-// rbd_track_plan.hpp — host-side plan for aba_track_kernel (rbd_track.hpp).
+// rbd_track_plan.hpp — host-side plan of the track schedule the walk kernels run (rbd_walk.hpp; rbd_walk_plan.hpp adds their parking slots).
 //
 // The track mapping gives a state G lanes ("tracks").  The tree is cut into chains along its longest paths and the chains are
 // packed on the tracks by list scheduling (same scheduler as rbd_chain_plan.hpp); at step s track g works on one body.
@@ -32,7 +32,7 @@ struct TrackPlan {
   std::vector<double> rr;   // [ns * G * TR_STRIDE]
   std::vector<int32_t> tab; // [ns * G] body slot or -1 (introspection / tests)
   std::vector<int32_t> sf;  // [ns] wave-uniform step flags: 1 some body not chained to the previous step of its track, 2 some A/C mailbox
-                            // written, 4 some B mailbox read, 8 some hand-off leaves its track, 16 a 6-dof root (SF_* in rbd_track.hpp)
+                            // written, 4 some B mailbox read, 8 some hand-off leaves its track, 16 a 6-dof root (SF_* in rbd_walk.hpp)
 };
 
 namespace trackplan {

@@ -61,38 +61,6 @@ inline WalkPlan build_walk_plan(int ns, int G, const std::vector<int32_t>& ri) {
   return P;
 }
 
-// ---- the role-pipelined mapping (rbd_pipe.hpp): the same plan on exactly 4 tracks (idle records for the missing ones), one record of
-// WREC_STRIDE ints per (step, track) with every field in a word of its own (each lane reads its own track's record from LDS)
-enum { WREC_FLAGS = 0, WREC_QOFF, WREC_VOFF, WREC_ORIG6, WREC_NBR, WREC_AW, WREC_AR, WREC_BW, WREC_BR0, WREC_PARK, WREC_RRF, WREC_STRIDE = 12 };
-inline std::vector<int32_t> walk_unpack4(int ns, int G, const std::vector<int32_t>& ri, const std::vector<int32_t>& wk) {
-  std::vector<int32_t> out((size_t)ns * 4 * WREC_STRIDE, 0);
-  for (int s = 0; s < ns; ++s)
-    for (int g = 0; g < G && g < 4; ++g) {
-      const size_t i = (size_t)s * G + g;
-      const int32_t* w = &ri[i * TI_STRIDE];
-      int32_t* o = &out[((size_t)s * 4 + g) * WREC_STRIDE];
-      const int x = w[0], y = w[1], z = w[2], ww = w[3], kk = wk[i];
-      o[WREC_FLAGS] = (y >> 16) & 0xff; o[WREC_QOFF] = x & 0xffff; o[WREC_VOFF] = (x >> 16) & 0xffff; o[WREC_ORIG6] = y & 0xffff; o[WREC_NBR] = (y >> 24) & 0x7f;
-      o[WREC_AW] = (z & 0xffff) - 1; o[WREC_AR] = ((z >> 16) & 0xffff) - 1; o[WREC_BW] = (ww & 0xffff) - 1; o[WREC_BR0] = ((ww >> 16) & 0xffff) - 1;
-      o[WREC_PARK] = (kk & 0xff) - 1; o[WREC_RRF] = (kk >> 8) & 3;
-    }
-  return out;
-}
-// the constants [ns * G][TR_STRIDE] spread to 4 tracks
-template <typename S> inline std::vector<S> walk_consts4(int ns, int G, const std::vector<double>& rr) {
-  std::vector<S> out((size_t)ns * 4 * TR_STRIDE, S(0));
-  for (int s = 0; s < ns; ++s)
-    for (int g = 0; g < G && g < 4; ++g)
-      for (int k = 0; k < TR_STRIDE; ++k) out[((size_t)s * 4 + g) * TR_STRIDE + k] = (S)rr[((size_t)s * G + g) * TR_STRIDE + k];
-  return out;
-}
-// LDS of a workgroup of 16 states: constants | records | q, v, τ rows | rings (K 3 x 12, I 2 x 10, T 2 x 34, sin/cos 2 x 2 values x 64 lanes) | the motion subspaces of the steps (6 x 64 each) | mailboxes.
-// Must agree with pipe_ctx_lds() of rbd_pipe.hpp.
-inline size_t pipe_lds_bytes(int ns, int nq, int nv, int nA, int nB, int nS, size_t es) {
-  const size_t nrec = (size_t)ns * 4;
-  const size_t cells = (size_t)(nq + 2 * nv) * 17 + (3 * 12 + 2 * 10 + 2 * 34 + 2 * 2 + (size_t)ns * 6) * 64 + ((size_t)nA * (12 + 12 + 6) + (size_t)nB * 27 + (size_t)nS * 24) * 16;
-  return ((nrec * TR_STRIDE * es + 15) & ~(size_t)15) + ((nrec * WREC_STRIDE * 4 + 15) & ~(size_t)15) + cells * es;
-}
 #endif  // RBD_JIT_COMPILE
 
 }  // namespace rbd

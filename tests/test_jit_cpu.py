@@ -177,8 +177,8 @@ def test_generated_tree_tables_of_the_walk_kernels(rbd, name):
         assert (rbd.jit_source(model, torch.float64, fam) is None) == (fam == "dynamics")  # fp64: inverse dynamics only
         opw = table(src, "OPW")
         T = {k: table(src, k)[0] for k in ("BODY", "NCH", "BS", "PBS", "CIDX", "NEXT_EXIT")}
-        nbs = int(re.search(r"constexpr int NBS = (\d+), FIRST_EXIT = (\d+);", src).group(1))
-        first_exit = int(re.search(r"FIRST_EXIT = (\d+);", src).group(1))
+        nbs = int(re.search(r"constexpr int NBS = (\d+), FIRST_EXIT = (\d+), N3 = \d+;", src).group(1))
+        first_exit = int(re.search(r"FIRST_EXIT = (\d+),", src).group(1))
         voff_to_body = {int(v): b for b, v in enumerate(model.v_offset)}
         nvs = [(int(model.v_offset[b + 1]) if b + 1 < model.n_bodies else model.nv) - int(model.v_offset[b]) for b in range(model.n_bodies)]
         children = {b: [c for c in range(model.n_bodies) if model.parent[c] == b] for b in range(-1, model.n_bodies)}

@@ -20,7 +20,7 @@ CSRC = os.path.join(ROOT, "rigidbodydynamics.jl_amd", "csrc")
 @pytest.fixture(scope="session")
 def emu():
     so, src = os.path.join(EMU_DIR, "libwalk_emu.so"), os.path.join(EMU_DIR, "walk_emu.hip")
-    deps = [src] + [os.path.join(CSRC, f) for f in ("rbd_walk.hpp", "rbd_walk_plan.hpp", "rbd_track.hpp", "rbd_device.hpp")]
+    deps = [src] + [os.path.join(CSRC, f) for f in ("rbd_walk.hpp", "rbd_walk_plan.hpp", "rbd_track_plan.hpp", "rbd_mk_fuse.hpp", "rbd_device.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC,
                                "-I" + os.path.join(ROOT, "include"), src, "-o", so])
