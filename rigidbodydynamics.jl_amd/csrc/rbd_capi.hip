@@ -977,9 +977,13 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   } else if (m->state_wide.ok) {  // the compiled kernels alone (no interpreting form of them for these joint types): the same thresholds, the lane-per-body kernels behind them
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-    w->state_min_batch = (long)ncu * 4 * 64 / 2;
+    // behind them here: one body per lane (no walk kernel), whose time grows with the batch while a lane per state takes one round up to a chip-full — randmech
+    // (25 bodies, nv 39), fp32, 16 384 states: dynamics! 90 us against aba_spec's 43, mass_matrix! + Cholesky 173 against 137 for TWICE the batch; inverse
+    // dynamics 33 (two bodies per lane) against 31.5, fp64 44 against 32
+    w->state_min_batch = (long)ncu * 32;
     { bool has; const long t = tune("state_min_batch", 0, &has); if (has) w->state_min_batch = t; }
-    w->spec_aba_min_batch = w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
+    w->spec_aba_min_batch = (long)ncu * 32 + 1;
+    w->spec_rnea_min_batch = (long)ncu * 64;
     { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = t; }
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
   } else {

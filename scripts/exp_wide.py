@@ -31,7 +31,10 @@ for dname, tdt in (("f32", torch.float32), ("f64", torch.float64)):
     rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng)); rbd.set_velocity_(state, rbd.rand_velocity(model, B, rng))
     tau = torch.rand(B, model.nv, dtype=tdt, device="cuda"); out = torch.zeros_like(tau)
     for name, f in (("dynamics! auto", lambda: rbd.dynamics_(result, state, tau)), ("dynamics! lanes", lambda: rbd.dynamics_(result, state, tau, algorithm="aba_lanes")),
+                    ("dynamics! compiled", (lambda: rbd.dynamics_(result, state, tau, algorithm="aba_compiled")) if dname == "f32" else None),
+                    ("inverse_dynamics! compiled", lambda: rbd.inverse_dynamics_(out, state, tau, mapping="compiled")),
                     ("inverse_dynamics! auto", lambda: rbd.inverse_dynamics_(out, state, tau)), ("inverse_dynamics! lanes", lambda: rbd.inverse_dynamics_(out, state, tau, mapping="lanes")),
                     ("mass_matrix! + Cholesky", lambda: rbd.mass_matrix_solve_(out, state, tau, result.massmatrix))):
-        res[f"{name} {dname}"] = [timed(f), rbd.last_kernel(state).split(" (")[0]]
+        if f is not None:
+            res[f"{name} {dname}"] = [timed(f), rbd.last_kernel(state).split(" (")[0]]
 print(json.dumps({"model": "randmech(seed 1)", "nb": model.n_bodies, "nv": model.nv, "batch": B, "us": res}))

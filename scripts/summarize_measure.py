@@ -28,7 +28,10 @@ def short(name):
 def pmc(dirname):
     """kernel -> counter -> mean per dispatch (rows of one dispatch summed first)"""
     per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
-    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)
+    if len(files) > 1:  # gpurun MERGES into gpurun_out/: an earlier measurement left in place would be summed with this one
+        sys.exit(f"{dirname}: {len(files)} counter files — remove gpurun_out/measure before running scripts/gpu_measure.sh again")
+    for f in files:
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if k.startswith(OURS):
