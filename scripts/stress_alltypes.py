@@ -1,11 +1,16 @@
 """One-off stress: random trees with EVERY tree joint type (incl. Planar, QuaternionSpherical, 6-dof joints below other bodies),
-both layouts, fp64 — dynamics!, inverse_dynamics! (lanes / banks), mass_matrix!, kinematics by-products against the oracle."""
+both layouts, fp64 — dynamics!, inverse_dynamics! (lanes / banks), mass_matrix!, kinematics by-products against the oracle.
+--compiled: inverse_dynamics! through the kernel compiled for the mechanism as well (RBD_ALGO_ABA_COMPILED; one hiprtc compilation per tree — the fp32 / dynamics! /
+mass-matrix side of the compiled kernels on such trees is scripts/stress_compiled_alltypes.py)."""
 import os, sys
+os.environ.setdefault("RBD_JIT_ASYNC", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
 import rbd_amd as rbd, oracle
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+COMPILED = "--compiled" in sys.argv
+_a = [a for a in sys.argv[1:] if not a.startswith("--")]
+N = int(_a[0]) if _a else 200
 rng = np.random.default_rng(777)
 TYPES = ["Revolute", "Prismatic", "Fixed", "SinCosRevolute", "Planar", "QuaternionSpherical", "QuaternionFloating"]
 worst, skipped = {}, 0
@@ -39,7 +44,7 @@ for trial in range(N):
     chk("dynamics", Hh(res.vd), oracle.dynamics(model, q, v, tau, fe), 1e-8)
     out = torch.zeros_like(D(tau))
     ref = oracle.inverse_dynamics(model, q, v, vd, fe)
-    for mp in ("lanes", "banks"):
+    for mp in ("lanes", "banks") + (("compiled",) if COMPILED else ()):
         try:
             rbd.inverse_dynamics_(out, state, D(vd), D(fe), mapping=mp)
         except Exception:
