@@ -42,9 +42,21 @@ def ancestors(model):
     return anc
 
 
-@pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating", "atlas_fixed"])
+def mechanism(rbd, name):
+    """the URDF fixtures, and the in-code mechanisms with 3-dof joints / 6-dof joints below the world as tests/conftest.py builds them"""
+    if name == "mixed20":  # nv = 20: the Cholesky compiled for the sparsity applies
+        return rbd.flatten(rbd.rand_tree_mechanism(np.random.default_rng(11), ["QuaternionFloating", "QuaternionSpherical", "Planar", "Revolute", "Revolute", "Prismatic",
+                                                                                "QuaternionSpherical", "Revolute", "SinCosRevolute"]))
+    if name == "inner_floating":
+        return rbd.flatten(rbd.rand_tree_mechanism(np.random.default_rng(7), ["Revolute", "Prismatic", "QuaternionFloating", "Revolute", "QuaternionSpherical", "Planar", "QuaternionFloating", "Revolute"]))
+    if name.startswith("randmech"):
+        return rbd.flatten(rbd.randmech(np.random.default_rng(int(name[8:]))))
+    return rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", name + ".json"))
+
+
+@pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating", "atlas_fixed", "mixed20", "inner_floating", "randmech1"])
 def test_generated_plan_matches_the_mechanism(rbd, name):
-    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", name + ".json"))
+    model = mechanism(rbd, name)
     src = rbd.jit_source(model, torch.float32)
     assert src is not None
     dims = re.search(r"constexpr int NB = (\d+), NQ = (\d+), NV = (\d+), NOPS = (\d+), NLEVELS = (\d+);", src)
@@ -104,6 +116,42 @@ def test_generated_plan_matches_the_mechanism(rbd, name):
             seen.add((row, col))
         assert all((e & 0xffff) == 4 * nv for e in emit[jo][4 * ks[jo]:])
     assert len(seen) == int(nz.sum())
+
+
+def test_programs_of_mechanisms_with_every_joint_type(rbd, tmp_path, monkeypatch):
+    """Planar / QuaternionSpherical joints and QuaternionFloating joints below the world (the reference's randmech, test/test_mechanism_algorithms.jl:1-11): all three
+    one-lane-per-state programs exist, the ancestor columns carry the joint's kind, the 3-dof joints are ranked (dynamics! keeps part of U D^-1 in rows of their
+    own), and the programs compile without a device."""
+    model = mechanism(rbd, "inner_floating")
+    jt = [int(t) for t in model.joint_type]
+    n3 = sum(1 for t in jt if t in (4, 5))
+    assert n3 == 2 and jt.count(3) == 2
+    for fam in ("mass_matrix", "dynamics", "inverse_dynamics"):
+        for dt in (torch.float32, torch.float64):
+            src = rbd.jit_source(model, dt, fam)
+            assert (src is None) == (fam == "dynamics" and dt == torch.float64), (fam, dt)
+    src = rbd.jit_source(model, torch.float32, "dynamics")
+    assert int(re.search(r"N3 = (\d+);", src).group(1)) == n3
+    opw, x3, cols = table(src, "OPW"), table(src, "X3")[0], table(src, "COLS")
+    for o, w in enumerate(opw):
+        t = w[0] >> 16
+        assert (x3[o] >= 0) == (t in (4, 5))
+    assert sorted({x for x in x3 if x >= 0}) == list(range(n3))
+    flag = {3: 0x10000, 5: 0x20000, 4: 0x40000}
+    body_of_voff = {int(model.v_offset[b]): b for b in range(model.n_bodies)}
+    seen = set()
+    for row in cols:
+        for c in row:
+            if c >= 0:
+                b = body_of_voff[c & 0xffff]
+                assert (c & 0x70000) == flag.get(jt[b], 0), (c, jt[b])
+                seen.add(jt[b])
+    assert {3, 4, 5} & seen  # a joint with several coordinates is somebody's ancestor in this mechanism
+    monkeypatch.setenv("RBD_JIT_CACHE", str(tmp_path / "cache"))
+    ok, log = rbd.jit_precompile(model, torch.float32)
+    if ok is None:
+        pytest.skip("hiprtc not available")
+    assert ok, log
 
 
 def test_out_of_scope_mechanisms_have_no_specialised_kernels(rbd):
