@@ -162,16 +162,22 @@ def setup(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: reporting the world size actually running", file=sys.stderr)
+    # developer switch (scripts/gpu_check.sh): every rank on cuda:0 with gloo for the collectives, so that a 1-GPU box runs the N > 1 code path of this file
+    # (sharding, max over ranks, per-rank rates); nothing it prints is a measurement
+    one_device = os.environ.get("RBD_BENCH_ONE_DEVICE") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(0 if one_device else local_rank)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()  # what RCCL sees
     else:
         dist = None
         torch.cuda.set_device(0)
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", local_rank if world > 1 and not one_device else 0)
     import rbd_amd as rbd
     from rigidbodydynamics_jl_amd import _capi
     import oracle

@@ -6,6 +6,8 @@ R=$GRAFT_REPO_ROOT
 echo "== pytest gpu"; timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 | tee gpurun_out/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 echo "== bench"; timeout 600 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.json
+echo "== bench, the N > 1 code path on this one GPU (two ranks on cuda:0, gloo for the collectives: sharding / max over ranks / per-rank rates run; the numbers mean nothing)"
+RBD_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 10 --warmup 3 2>/dev/null | tail -1 | cut -c1-400 | tee gpurun_out/bench_two_ranks.json
 echo "== bench variants"; rm -f gpurun_out/bench_variants.jsonl
 for extra in "--graph" "--dtype f32" "--dtype f32 --batch 65536 --steps 200" "--batch 65536 --steps 200" "--layout soa" "--wrenches" "--model atlas_fixed" "--batch 524288 --steps 30 --dtype f32"; do
   timeout 600 python bench.py --no-cpu-baseline $extra 2>&1 | tail -1 >> gpurun_out/bench_variants.jsonl
