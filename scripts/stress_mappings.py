@@ -8,7 +8,7 @@ from test_chain_plan import random_tree
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(2024)
 worst = {}
-skipped = {"aba_banks": 0, "aba_tracks": 0, "aba_walk": 0, "aba_pipe": 0}
+skipped = {"aba_banks": 0, "aba_walk": 0}
 for trial in range(N):
     n = int(rng.integers(1, 45))
     mech = random_tree(rbd, rng, n, bool(rng.integers(2)), float(rng.uniform(0, 1)))
