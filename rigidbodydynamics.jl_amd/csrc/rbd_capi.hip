@@ -1610,13 +1610,13 @@ static void spec_load(rbd_ws* w, int family, bool force) {
     fits(&w->spec_rnea);
   }
 }
-static bool spec_crba_fits(const rbd_ws* w) { return (size_t)w->model->nq * 256 * esize(w) <= 160u * 1024u; }  // four wavefronts' staged q in one CU's LDS
+static bool spec_crba_fits(const rbd_ws* w) { return (size_t)w->model->nq * 4 * 65 * esize(w) <= 160u * 1024u; }  // four wavefronts' staged q (rows of 65) in one CU's LDS
 static hipFunction_t spec_crba(rbd_ws* w, size_t buffer_bytes) {
   spec_load(w, SPEC_MASS);
   return buffer_bytes < ((size_t)1 << 32) && spec_crba_fits(w) ? w->spec_crba : nullptr;
 }
 static hipError_t launch_crba_spec(rbd_ws* w, hipFunction_t f, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill) {
-  const unsigned lds = (unsigned)((size_t)w->model->nq * 256 * esize(w));  // four wavefronts' staged q
+  const unsigned lds = (unsigned)((size_t)w->model->nq * 4 * 65 * esize(w));  // four wavefronts' staged q, rows of 65 (rbd_spec.hpp RS)
   void* args[] = {&B, &q, &Mout, &Lq, &Lm, &zero_fill};
   return hipModuleLaunchKernel(f, (unsigned)((B + 255) / 256), 1, 1, 256, 1, 1, lds, w->stream, args, nullptr);
 }

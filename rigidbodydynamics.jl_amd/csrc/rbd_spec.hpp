@@ -119,6 +119,108 @@ template <typename T, int O, int QS = 64> RBD_DEV void local_transform(const T* 
   }
 }
 
+constexpr int RS = 65;  // LDS row stride in values
+
+// rows [0, n) <- the n x 64 block of a batch buffer that belongs to this wavefront's states (states past the end read the last one).  The loads of up to
+// 32 rows are all in flight before the first LDS write: a lone wavefront pays every global round trip in full (four at a time was 27 round trips
+// for Atlas's q, v and tau — a fifth of the launch).
+// State-major buffers: the block is one contiguous run of 64 n scalars, element e = 64 c + lane = (state e / n, row e % n).  With lane = n st0 + k0 and c a
+// constant of the unrolled loop that is ONE wrap test per element (place), and a block that exists entirely needs no clamping: 15 -> 6 vector instructions per
+// element (PMC, Atlas fp32: 19 913 VALU per wavefront state-major against 17 692 batch-innermost, 145 elements in and out).
+template <int n> RBD_DEV void place(int c, int st0, int k0, int& st, int& k) {
+  const int A = (64 * c) / n, R = (64 * c) % n;
+  const int t = k0 + R;  // < 2 n
+  const bool w = t >= n;
+  k = w ? t - n : t;
+  st = st0 + A + (w ? 1 : 0);
+}
+template <typename T, int n> RBD_DEV void rows_in(const T* __restrict__ src, Layout L, long state0, long B, T* rows) {
+  const int lane = threadIdx.x & 63;
+  constexpr int CH = 32;
+  if (L.sk == 1 && L.sb == n) {
+    const T* base = src + state0 * n;
+    const int st0 = lane / n, k0 = lane - st0 * n;
+    if (B - state0 >= 64) {  // (uniform) every state of the block exists
+#pragma unroll
+      for (int c0 = 0; c0 < n; c0 += CH) {
+        T tmp[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+          if (c0 + j < n) tmp[j] = base[(c0 + j) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          if (c0 + j < n) {
+            int st, k;
+            place<n>(c0 + j, st0, k0, st, k);
+            rows[k * RS + st] = tmp[j];
+          }
+        }
+      }
+    } else {
+      const int lim = (int)(B - state0) * n;  // elements of the block that exist
+#pragma unroll
+      for (int c0 = 0; c0 < n; c0 += CH) {
+        T tmp[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          if (c0 + j < n) {
+            int st, k;
+            place<n>(c0 + j, st0, k0, st, k);
+            const int e = (c0 + j) * 64 + lane;
+            tmp[j] = base[e < lim ? e : lim - n + k];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          if (c0 + j < n) {
+            int st, k;
+            place<n>(c0 + j, st0, k0, st, k);
+            rows[k * RS + st] = tmp[j];
+          }
+        }
+      }
+    }
+  } else {
+    const long sc = state0 + lane < B ? state0 + lane : B - 1;
+    const T* base = src + sc * L.sb;
+#pragma unroll
+    for (int c0 = 0; c0 < n; c0 += CH) {
+      T tmp[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if (c0 + j < n) tmp[j] = base[(long)(c0 + j) * L.sk];
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if (c0 + j < n) rows[(c0 + j) * RS + lane] = tmp[j];
+    }
+  }
+}
+template <typename T, int n> RBD_DEV void rows_out(const T* rows, T* __restrict__ dst, Layout L, long state0, long B) {
+  const int lane = threadIdx.x & 63;
+  if (L.sk == 1 && L.sb == n) {
+    T* base = dst + state0 * n;
+    const int st0 = lane / n, k0 = lane - st0 * n;
+    const int lim = B - state0 >= 64 ? 64 * n : (int)(B - state0) * n;
+    if (lim == 64 * n) {
+#pragma unroll
+      for (int c = 0; c < n; ++c) {
+        int st, k;
+        place<n>(c, st0, k0, st, k);
+        base[c * 64 + lane] = rows[k * RS + st];
+      }
+    } else {
+#pragma unroll 4
+      for (int c = 0; c < n; ++c) {
+        const int e = c * 64 + lane, st = e / n, k = e - st * n;
+        if (e < lim) base[e] = rows[k * RS + st];
+      }
+    }
+  } else if (state0 + lane < B) {
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) dst[(long)k * L.sk + (state0 + lane) * L.sb] = rows[k * RS + lane];
+  }
+}
+
 // mass_matrix! (src/mechanism_algorithms.jl:248-272) of rbd_plan's mechanism, one lane per state.  Mout: any Layout (the caller's SOA
 // buffer, or the staging buffer grouped by 16 states the tile Cholesky reads); zero_fill: also write the structural zeros of the lower triangle.
 // PERMUTED (the staging buffer of chol_spec below): entry (row, col) goes to (max, min) of (PERM[row], PERM[col]).
@@ -126,16 +228,14 @@ template <typename T, bool PERMUTED = false>
 RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, Layout Lq, Layout Lm, int zero_fill, T* lds) {
   constexpr int ML = P::NLEVELS, NQ = P::NQ, NV = P::NV;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  T* qs = lds + (size_t)wave * NQ * 64;
-  const long state_raw = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64 + lane;
+  const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
+  if (state0 >= B) return;  // (no workgroup barrier below: the wavefronts of a block share nothing but the launch)
+  const long state_raw = state0 + lane;
   const bool live = state_raw < B;
   const long state = live ? state_raw : B - 1;
-  {
-    const T* base = q + state * Lq.sb;
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) qs[k * 64 + lane] = base[(long)k * Lq.sk];
-  }
-  qs += lane;
+  T* qrows = lds + (size_t)wave * NQ * RS;
+  rows_in<T, NQ>(q, Lq, state0, B, qrows);  // (a state-major q arrives in whole runs, not in 64 pieces of one value per load)
+  const T* qs = qrows + lane;
   // byte offset of this lane's column; an entry adds a wave-uniform (row, col) term.  32-bit offsets (the host keeps buffers of 4 GB and more
   // away from this kernel): one scalar multiply and one vector add per store, scalar base address
   const unsigned lane_off = (unsigned)(layout_base(Lm, state) * (long)sizeof(T));
@@ -159,8 +259,7 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
       });
     });
   }
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the staged q column is this wave's own
-  __builtin_amdgcn_wave_barrier();
+  wave_sync();  // the staged rows are this wavefront's own
   T X[ML][12];   // path: transforms to root (R row-major, p)
   T IC[ML][10];  // path: inertias being accumulated (J 6, c 3, m)
   T S[ML][6];    // path: motion subspace columns (1-dof joints)
@@ -168,7 +267,7 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
     constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
     if constexpr (kind == SK_ENTER) {
       T Rl[9], pl[3];
-      local_transform<T, O>(qs, Rl, pl);
+      local_transform<T, O, RS>(qs, Rl, pl);
       T* R = X[lvl];
       T* p = X[lvl] + 9;
       if constexpr (lvl == 0) {
@@ -273,65 +372,7 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
 // (its parent's branch slot, or -1), CIDX[NOPS] (its rank among its siblings), NBS (slots), NEXT_EXIT[NOPS] (the next EXIT op after this one, or -1).
 // q, v, tau of the wavefront's 64 states are staged through LDS rows (stride 65: conflict-free both ways); v̇ and q̇ leave the same way, q̇ first.
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int RS = 65;  // LDS row stride in values
 constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB) + 10 * P::N3;  // q, v, tau, spare, ten of the 18 values of U D^-1 of every 3-dof joint
-
-// rows [0, n) <- the n x 64 block of a batch buffer that belongs to this wavefront's states (states past the end read the last one).  The loads of up to
-// 32 rows are all in flight before the first LDS write: a lone wavefront pays every global round trip in full (four at a time was 27 round trips
-// for Atlas's q, v and tau — a fifth of the launch).
-template <typename T, int n> RBD_DEV void rows_in(const T* __restrict__ src, Layout L, long state0, long B, T* rows) {
-  const int lane = threadIdx.x & 63;
-  constexpr int CH = 32;
-  if (L.sk == 1 && L.sb == n) {  // state-major: one contiguous run of 64 n scalars, element e = (state e / n, row e % n)
-    const long lim = (B - state0) * n;  // elements of the block that exist
-    const T* base = src + state0 * n;
-#pragma unroll
-    for (int c0 = 0; c0 < n; c0 += CH) {
-      T tmp[CH];
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        if (c0 + j < n) {
-          const int e = (c0 + j) * 64 + lane, st = e / n, k = e - st * n;
-          tmp[j] = base[e < lim ? e : lim - n + k];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        if (c0 + j < n) {
-          const int e = (c0 + j) * 64 + lane, st = e / n, k = e - st * n;
-          rows[k * RS + st] = tmp[j];
-        }
-      }
-    }
-  } else {
-    const long sc = state0 + lane < B ? state0 + lane : B - 1;
-    const T* base = src + sc * L.sb;
-#pragma unroll
-    for (int c0 = 0; c0 < n; c0 += CH) {
-      T tmp[CH];
-#pragma unroll
-      for (int j = 0; j < CH; ++j)
-        if (c0 + j < n) tmp[j] = base[(long)(c0 + j) * L.sk];
-#pragma unroll
-      for (int j = 0; j < CH; ++j)
-        if (c0 + j < n) rows[(c0 + j) * RS + lane] = tmp[j];
-    }
-  }
-}
-template <typename T, int n> RBD_DEV void rows_out(const T* rows, T* __restrict__ dst, Layout L, long state0, long B) {
-  const int lane = threadIdx.x & 63;
-  if (L.sk == 1 && L.sb == n) {
-    const long lim = (B - state0) * n;
-#pragma unroll 4
-    for (int e0 = 0; e0 < 64 * n; e0 += 64) {
-      const int e = e0 + lane, st = e / n, k = e - st * n;
-      if (e < lim) dst[state0 * n + e] = rows[k * RS + st];
-    }
-  } else if (state0 + lane < B) {
-#pragma unroll 8
-    for (int k = 0; k < n; ++k) dst[(long)k * L.sk + (state0 + lane) * L.sb] = rows[k * RS + lane];
-  }
-}
 
 template <typename T> struct Kin { T R[9], p[3], Tw[6], av[6]; };
 template <typename T> struct Hand { T I[21], p[6]; };
