@@ -131,7 +131,7 @@ struct rbd_ws {
   std::vector<double> loop_gains; bool custom_gains = false;  // rbd_workspace_set_loop_gains: this workspace's Baumgarte gains (4 per loop joint), and whether they differ from the model's
   void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
   long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0, walk_one_round_batch = 0, rnea_walk_min_batch = 0;
-  StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0; bool state_aot = false;  // state_aot: the interpreting one-lane-per-state kernels take the mechanism
+  StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0; long spec_aba_fused_min_batch = (long)1 << 62; bool state_aot = false;  // state_aot: the interpreting one-lane-per-state kernels take the mechanism
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   long bank_min_batch = 0, bank_resident_states = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
@@ -971,7 +971,8 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     // chip-full, and beats the walk kernel's rounds of half as many states from the second of those on.  Known here, before anything is compiled, so that a
     // small batch never starts (or waits for) a compilation it would not use
     w->spec_aba_min_batch = w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
-    { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = t; }
+    w->spec_aba_fused_min_batch = (long)ncu * 80;  // (`simulate`: run_aba)
+    { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = w->spec_aba_fused_min_batch = t; }
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
     w->state_aot = true;
   } else if (m->state_wide.ok) {  // the compiled kernels alone (no interpreting form of them for these joint types): the same thresholds, the lane-per-body kernels behind them
@@ -1485,8 +1486,11 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   if (algorithm == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !fuse && w->dtype == RBD_F32) {
-    if (algorithm == RBD_ALGO_ABA_COMPILED || B >= w->spec_aba_min_batch) spec_load(w, SPEC_ABA, algorithm == RBD_ALGO_ABA_COMPILED);
-    if (w->spec_aba && (algorithm == RBD_ALGO_ABA_COMPILED || B >= w->spec_aba_min_batch)) {
+    // with the integrator stage folded in, the lane-per-state kernel is ahead of the walk kernel earlier than without it (Atlas fp32, RK4 step: 24 576 states
+    // 209 against 226 us, 32 768: 220 against 240; 16 384: 201 against 143) — the stage costs this kernel 10 us per launch, the walk kernel 28
+    const long spec_from = mk ? std::min<long>(w->spec_aba_min_batch, w->spec_aba_fused_min_batch) : w->spec_aba_min_batch;
+    if (algorithm == RBD_ALGO_ABA_COMPILED || B >= spec_from) spec_load(w, SPEC_ABA, algorithm == RBD_ALGO_ABA_COMPILED);
+    if (w->spec_aba && (algorithm == RBD_ALGO_ABA_COMPILED || B >= spec_from)) {
       Timed t(w);
       long Bl = B;
       const double* gv = gravity ? gravity : m->gravity;
@@ -2021,19 +2025,27 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   // four launches per step and nothing else.  The first launch decides: a kernel that takes the stage runs it, any other returns RBD_ERR_UNSUPPORTED untouched.
   bool spec_sim = false;
   const bool try_spec_sim = walk_sim && tune("sim_fuse", 1) != 0;  // (RBD_TUNE sim_fuse=0: the stage in its own launches, for A/B measurements)
+  // The kernel of the FIRST launch serves the whole call: aba_spec keeps the stage buffers in a layout of its own (rbd_spec.hpp), and a compilation that finishes
+  // in the background must not move a step from one kernel to the other between two of its stages.
+  int sim_algo = RBD_ALGO_ABA;
+  bool sim_lane_per_state = false;
   for (int step = 0; try_spec_sim && step < nsteps; ++step) {
     for (int stage = 0; stage < 4; ++stage) {
       const MkStage F{stage, pd ? 1 : 0, dt, w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.vd[0], dq, dv, ctl.kp, ctl.kd, ctl.q_des};
-      st = run_aba(w, B, RBD_ALGO_ABA, dq, dv, tau_at(step, stage), df, nullptr, nullptr, Lq, Lv, Lf, nullptr, nullptr, &F);
+      st = run_aba(w, B, sim_algo, dq, dv, tau_at(step, stage), df, nullptr, nullptr, Lq, Lv, Lf, nullptr, nullptr, &F);
       if (st == RBD_ERR_UNSUPPORTED && step == 0 && stage == 0) break;
       if (st) return st;
+      if (!spec_sim) {
+        sim_lane_per_state = strstr(w->last_kernel, "aba_spec_f32") != nullptr;
+        sim_algo = sim_lane_per_state ? RBD_ALGO_ABA_COMPILED : RBD_ALGO_ABA_WALK;
+      }
       spec_sim = true;
     }
     if (!spec_sim) break;
   }
   if (spec_sim) {
-    w->last_kernel = w->dtype == RBD_F32 && B >= w->spec_aba_min_batch && w->spec_aba ? "aba_spec_f32 with the Munthe-Kaas stage folded in (compiled for the mechanism at run time)"
-                                                                                   : "aba_walk_spec with the Munthe-Kaas stage folded in (compiled for the mechanism)";
+    w->last_kernel = sim_lane_per_state ? "aba_spec_f32 with the Munthe-Kaas stage folded in (compiled for the mechanism at run time)"
+                                        : "aba_walk_spec with the Munthe-Kaas stage folded in (compiled for the mechanism)";
     if (o.memory == RBD_MEM_HOST) {
       if ((st = stage_out_copy(w, q, dq, es * m->nq * B)) || (st = stage_out_copy(w, v, dv, es * m->nv * B))) return st;
     }

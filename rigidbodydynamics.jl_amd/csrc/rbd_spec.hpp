@@ -389,8 +389,6 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   T* r3 = rx + (NQ > NB ? NQ : NB) * RS;  // 10 rows per 3-dof joint: the part of its U D^-1 (18 values) that its v rows (3), its spare row and its four registers do not take
   const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
   if (state0 >= B) return;
-  MkPre<T, (P::MK_N1 > 0 ? P::MK_N1 : 1)> mkp;  // `simulate`: the stage's loads of the base point and the running sums go out ahead of the staging (rbd_mk_fuse.hpp)
-  if (F.stage >= 0) mk_pre_load<T, P::MK_N1, P::MK_NF, (P::MK_N1 > 0 ? P::MK_N1 : 1)>(F, mkp, P::MK1, P::MKF, state0, B, 64, Lq, Lv, lane, 64);
   rows_in<T, NQ>(q, Lq, state0, B, rq);
   if (v) rows_in<T, NV>(v, Lv, state0, B, rv);
   else {  // (the M^-1 rhs pass: v = 0)
@@ -405,16 +403,76 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   wave_sync();
   // `simulate`: this launch is stage F.stage of a Munthe-Kaas RK4 step (rbd_mk_fuse.hpp): the next stage's q from the staged rows before the passes, its v
   // from the v̇ rows behind them — the wavefront's own 64 states, no launch of its own
-  auto cell = [&](int row, int st) __attribute__((always_inline)) { return rq + row * RS + st; };
-  if (F.stage >= 0) {  // uniform
-    mk_prologue<T, P::MK_N1, P::MK_NF, (P::MK_N1 > 0 ? P::MK_N1 : 1)>(F, mkp, cell, P::MK1, P::MKF, 0, NQ, NQ + NV, state0, B, 64, Lq, Lv, lane, 64);
-    wave_sync();  // (the PD law wrote into the τ rows)
-  }
   const T* qs = rq + lane;
   T* vs = rv + lane;
   T* ts = rt + lane;
   T* xs = rx + lane;
   T* x3 = r3 + lane;
+  // Here the lane IS the state and the joints are compile-time constants, so the stage is straight-line code like the passes: the base point and the running
+  // sums live in the workspace's stage buffers in a layout of this kernel's own — batch-innermost, element (k, state) at k B + state, whatever the caller's
+  // layout (stage 0 writes them, stages 1-3 of the same step read them: nobody else sees them) — one coalesced access per lane and value; the next q is formed in
+  // the spare rows and leaves through rows_out.  ALL loads first, then the arithmetic and the stores: vmcnt counts loads and stores in order, a load issued
+  // behind a store waits for that store's acknowledgement (the element-parallel form of rbd_mk_fuse.hpp, a table lookup in front of every element's loads,
+  // cost the launch 32 of its 88 us at 65 536 states: 19 us waiting, 3 200 extra vector instructions per wavefront).
+  const long mk_gi = state0 + lane;
+  const bool mk_live = mk_gi < B;
+  const long mk_si = mk_live ? mk_gi : B - 1;
+  const int mk_s = F.stage;
+  const T mk_h = (T)F.dt, mk_bs = (mk_s == 0 || mk_s == 3) ? T(1) / T(6) : T(1) / T(3), mk_an = mk_s < 2 ? T(0.5) : T(1);
+  if (mk_s >= 0) {  // uniform
+    T* __restrict__ q0b = (T*)F.q0; T* __restrict__ v0b = (T*)F.v0; T* __restrict__ apb = (T*)F.accp;
+    const T* kp = (const T*)F.kp; const T* kd = (const T*)F.kd; const T* qdes = (const T*)F.qdes;
+    T Q0[NQ > 0 ? NQ : 1], AC[NV > 0 ? NV : 1], QD[NQ > 0 ? NQ : 1];
+    if (mk_s > 0) {
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) Q0[k] = q0b[(long)k * B + mk_si];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) AC[k] = apb[(long)k * B + mk_si];
+    }
+    if (F.pd) {
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) QD[k] = qdes ? qdes[(long)k * Lq.sk + mk_si * Lq.sb] : T(0);
+    }
+    sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
+      constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, jt = w0 >> 16, qoff = P::OPW[O][1], voff = P::OPW[O][2];
+      constexpr int nqj = jt == RBD_JOINT_QUAT_FLOATING ? 7 : jt == RBD_JOINT_QUAT_SPHERICAL ? 4 : jt == RBD_JOINT_PLANAR ? 3 : jt == RBD_JOINT_SINCOS_REVOLUTE ? 2 : jt == RBD_JOINT_FIXED ? 0 : 1;
+      constexpr int nvj = nvj_of(jt);
+      if constexpr (kind == SK_ENTER && nvj > 0) {
+        T qj[7], vj[6], q0j[7], rate[6], phi[6], qn[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { qj[k] = k < nqj ? qs[(qoff + (k < nqj ? k : 0)) * RS] : T(0); q0j[k] = qj[k]; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vj[k] = k < nvj ? vs[(voff + (k < nvj ? k : 0)) * RS] : T(0);
+        if (mk_s > 0) {
+#pragma unroll
+          for (int k = 0; k < nqj; ++k) q0j[k] = Q0[qoff + k];
+        } else if (mk_live) {
+#pragma unroll
+          for (int k = 0; k < nqj; ++k) q0b[(long)(qoff + k) * B + mk_gi] = qj[k];
+#pragma unroll
+          for (int k = 0; k < nvj; ++k) v0b[(long)(voff + k) * B + mk_gi] = vj[k];
+        }
+        joint_local_rate<T, 0>(jt, q0j, qj, vj, rate);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) phi[k] = T(0);
+#pragma unroll
+        for (int k = 0; k < nvj; ++k) {
+          const T sum = (mk_s > 0 ? AC[voff + k] : T(0)) + mk_bs * rate[k];
+          if (mk_s < 3 && mk_live) apb[(long)(voff + k) * B + mk_gi] = sum;
+          phi[k] = mk_s < 3 ? mk_h * mk_an * rate[k] : mk_h * sum;
+        }
+        joint_global<T, 0>(jt, q0j, phi, qn);
+#pragma unroll
+        for (int k = 0; k < nqj; ++k) xs[(qoff + k) * RS] = qn[k];
+        if constexpr (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_PRISMATIC) {
+          if (F.pd) ts[voff * RS] -= kp[voff] * (qj[0] - QD[qoff]) + kd[voff] * vj[0];
+        }
+      }
+    });
+    wave_sync();
+    rows_out<T, NQ>(rx, (T*)F.q_state, Lq, state0, B);  // the kernel's own q input: this wavefront has read its block, nobody else touches it
+    wave_sync();  // (the spare rows are used again below; the PD law wrote into the τ rows)
+  }
   // q̇ (configuration_derivative!, src/mechanism_state.jl:905-910) depends on q and v alone: assembled in the spare rows and sent off before the
   // passes start (its stores drain while they run; the rows are free again long before pass 2 writes them)
   if (qdot) {
@@ -772,10 +830,30 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
     }
   });
   wave_sync();
-  if (F.stage >= 0) {
-    MkPost<T, NV> mkq;
-    mk_post_load<T, NV, NV>(F, mkq, state0, B, 64, Lv, lane, 64);
-    mk_epilogue<T, NV, NV>(F, mkq, cell, NQ + NV, state0, B, 64, Lv, lane, 64);
+  if (mk_s >= 0) {  // the next v from the v̇ rows, through the v rows (free by now)
+    const T* __restrict__ v0b = (const T*)F.v0; T* __restrict__ avb = (T*)F.accv;
+    T V0[NV > 0 ? NV : 1], AV[NV > 0 ? NV : 1];
+    wave_sync();  // (every lane is done with the v rows of the top-down pass)
+    if (mk_s > 0) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) V0[k] = v0b[(long)k * B + mk_si];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) AV[k] = avb[(long)k * B + mk_si];
+    } else {  // stage 0: the base point is still in the kernel's own v input (the passes have used its rows for other things)
+      rows_in<T, NV>((const T*)F.v_state, Lv, state0, B, rv);
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < NV; ++k) V0[k] = vs[k * RS];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const T vd = ts[k * RS];
+      const T sum = (mk_s > 0 ? AV[k] : T(0)) + mk_bs * vd;
+      if (mk_s < 3 && mk_live) avb[(long)k * B + mk_gi] = sum;
+      vs[k * RS] = V0[k] + mk_h * (mk_s < 3 ? mk_an * vd : sum);
+    }
+    wave_sync();
+    rows_out<T, NV>(rv, (T*)F.v_state, Lv, state0, B);
   }
   if (vdot) rows_out<T, NV>(rt, vdot, Lv, state0, B);
 }
