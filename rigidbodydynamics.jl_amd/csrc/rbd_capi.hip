@@ -2024,7 +2024,9 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   // ... and when the batch goes to a kernel COMPILED for the mechanism (aba_walk_spec, aba_spec_f32), the stage is folded into that launch (rbd_mk_fuse.hpp):
   // four launches per step and nothing else.  The first launch decides: a kernel that takes the stage runs it, any other returns RBD_ERR_UNSUPPORTED untouched.
   bool spec_sim = false;
-  const bool try_spec_sim = walk_sim && tune("sim_fuse", 1) != 0;  // (RBD_TUNE sim_fuse=0: the stage in its own launches, for A/B measurements)
+  // (mechanisms the walk kernels do not take — 3-dof joints, 6-dof joints below the world: aba_spec_f32 takes them, stage included, from its own batch threshold on)
+  const bool lane_per_state_sim = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && w->dtype == RBD_F32 && m->spec_plan().ok && B >= std::min<long>(w->spec_aba_min_batch, w->spec_aba_fused_min_batch);
+  const bool try_spec_sim = (walk_sim || lane_per_state_sim) && tune("sim_fuse", 1) != 0;  // (RBD_TUNE sim_fuse=0: the stage in its own launches, for A/B measurements)
   // The kernel of the FIRST launch serves the whole call: aba_spec keeps the stage buffers in a layout of its own (rbd_spec.hpp), and a compilation that finishes
   // in the background must not move a step from one kernel to the other between two of its stages.
   int sim_algo = RBD_ALGO_ABA;

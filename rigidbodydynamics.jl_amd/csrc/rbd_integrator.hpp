@@ -64,10 +64,18 @@ template <typename T, int MODE = 0> RBD_DEV void joint_local_rate(int t, const T
 #pragma unroll
     for (int k = 0; k < 3; ++k) o[k] = v[k] + c1[k] / 2;
     const T th = norm3(phi);
-    if (th > eps_t<T>()) {  // Bortz equation, spatial/util.jl:88-102
-      T s, c;
-      sincos_t(th, &s, &c);
-      const T f = (1 - (th * s) / (2 * (1 - c))) / (th * th);
+    {  // Bortz equation, spatial/util.jl:88-102: f = (1 - θ sin θ / (2 (1 - cos θ))) / θ².  Evaluated as written it divides by 1 - cos θ, which is exactly zero in
+       // fp32 for θ < 3e-4 (and θ is rounding noise, not zero, whenever q = q0: the first stage of every step) — inf · 0 further down; and it loses every digit to
+       // cancellation long before.  (θ/2) cot(θ/2) = 1 - θ²/12 - θ⁴/720 - ..., so f = 1/12 + θ²/720 + θ⁴/30240 + θ⁶/1209600 + θ⁸/47900160 for small θ.
+      const T t2 = th * th;
+      T f;
+      if (th < (sizeof(T) == 4 ? T(0.5) : T(1e-2))) {
+        f = T(1) / T(12) + t2 * (T(1) / T(720) + t2 * (T(1) / T(30240) + t2 * (T(1) / T(1209600) + t2 * (T(1) / T(47900160)))));
+      } else {
+        T s, c;
+        sincos_t(th, &s, &c);
+        f = (1 - (th * s) / (2 * (1 - c))) / t2;
+      }
       cross3(phi, c1, c2);
 #pragma unroll
       for (int k = 0; k < 3; ++k) o[k] += f * c2[k];

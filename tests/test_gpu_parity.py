@@ -461,6 +461,28 @@ def test_simulate_matches_oracle_f64(rbd, oracle, models, name):
     assert np.abs(vg - v_ref).max() <= 1e-9 * max(1.0, np.abs(v_ref).max())
 
 
+@pytest.mark.parametrize("batch", [6, 300])
+@pytest.mark.parametrize("name", ["inner_floating", "mixed20", "randmech1"])
+def test_simulate_fp32_with_spherical_joints(rbd, oracle, models, name, batch):
+    """fp32 and QuaternionSpherical joints: the Bortz factor of the local-coordinate rates (spatial/util.jl:88-102) divides by 1 - cos θ, which is exactly zero in
+    fp32 for θ < 3e-4 — and θ is rounding noise whenever q = q0, i.e. at the first stage of EVERY step (NaN for one state in ten before the small-angle series,
+    rbd_integrator.hpp).  The lane-per-body kernels with the stage folded in (6 states) and the stage kernels (300), fp32 against the fp64 oracle."""
+    import simulate_np
+    model = models[name]
+    B, dt, T = batch, 1e-3, 0.0045
+    q, v, tau, _ = rand_inputs(rbd, model, B, 53, fext=True)
+    state = rbd.MechanismState(model, B, dtype=torch.float32)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    rbd.simulate_(state, T, dt=dt, torques=dev(tau, state))
+    qg, vg = host(state.q, state), host(state.v, state)
+    assert np.isfinite(qg).all() and np.isfinite(vg).all()
+    sel = np.r_[0:3, B - 3:B]
+    _, q_ref, v_ref = simulate_np.simulate(model, q[sel].astype(np.float32).astype(np.float64), v[sel].astype(np.float32).astype(np.float64), T, dt, tau[sel].astype(np.float32).astype(np.float64))
+    assert np.abs(canon_q(model, qg[sel]) - canon_q(model, q_ref)).max() <= 2e-5 * max(1.0, np.abs(q_ref).max())
+    assert np.abs(vg[sel] - v_ref).max() <= 2e-3 * max(1.0, np.abs(v_ref).max())
+
+
 def test_simulate_with_controller_and_store(rbd, oracle, models):
     """control!(torques, t, state) is evaluated before every stage's dynamics! (src/simulate.jl:42-48)."""
     import simulate_np
@@ -526,6 +548,35 @@ def test_simulate_device_side_controllers(rbd, oracle, models, path, monkeypatch
     assert np.abs(host(state.q, state) - q_ref).max() <= 1e-10 and np.abs(host(state.v, state) - v_ref).max() <= 1e-9
     k = rbd.last_kernel(state)
     assert ("walk" in k) == (path == "unfused"), k
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", ["mixed20", "inner_floating", "randmech1"])
+def test_simulate_stage_folded_in_on_every_joint_type(rbd, oracle, models, name, layout, monkeypatch):
+    """The same for mechanisms with Planar / QuaternionSpherical joints and QuaternionFloating joints below the world: only the lane-per-state kernel compiled for the
+    mechanism takes them (its stage is generic over the joint types: the Bortz equation for the spherical joints, the SE(3) log / exp for every 6-dof joint)."""
+    import simulate_np
+    tune(monkeypatch, spec_aba_min_batch=1)
+    model = models[name]
+    B, dt, nsteps = 70, 1e-3, 3
+    T = (nsteps - 0.5) * dt
+    state, q, v, tau, _ = make(rbd, model, B, "f32", layout, 93, fext=False)
+    sel = np.r_[0:3, B - 2:B]
+    try:
+        rbd.simulate_(state, T, dt=dt, torques=dev(tau, state))
+    except rbd._capi.RBDError as e:
+        if e.status == 3:
+            pytest.skip("hiprtc not available")
+        raise
+    k = rbd.last_kernel(state)
+    if "folded in" not in k:
+        pytest.skip("no compiled kernel for this route on this box: " + k)
+    assert "aba_spec_f32" in k, k
+    ref = simulate_np.simulate(model, q[sel], v[sel], T, dt, tau[sel])
+    qg, vg = host(state.q, state)[sel], host(state.v, state)[sel]
+    assert np.isfinite(host(state.q, state)).all() and np.isfinite(host(state.v, state)).all()
+    assert np.abs(canon_q(model, qg) - canon_q(model, ref[1])).max() <= 2e-5 * max(1.0, np.abs(ref[1]).max())
+    assert np.abs(vg - ref[2]).max() <= 2e-3 * max(1.0, np.abs(ref[2]).max())
 
 
 @pytest.mark.parametrize("layout", ["aos", "soa"])
