@@ -1,7 +1,8 @@
 // rbd_mk_fuse.hpp — one stage of `simulate`'s Munthe-Kaas RK4 step (src/ode_integrators.jl:233-299 with the runge_kutta_4 tableau :48-55;
-// src/simulate.jl:42-48) folded into the LARGE-BATCH dynamics! kernels that are compiled for the mechanism (aba_walk_spec of rbd_walk.hpp, aba_spec of
-// rbd_spec.hpp): those kernels stage q, v and τ of their states through LDS rows anyway, so the integrator's arithmetic runs on the rows — no launch of
-// its own, no second trip of q and v through HBM.  Round 3 left the stage bookkeeping of large batches in its own launches (≈ 5 per step, each streaming
+// src/simulate.jl:42-48) folded into the LARGE-BATCH dynamics! kernels that are compiled for the mechanism: those kernels stage q, v and τ of their states
+// through LDS rows anyway, so the integrator's arithmetic runs on the rows — no launch of its own, no second trip of q and v through HBM.  This file: the
+// stage struct both kernels take, and the ELEMENT-PARALLEL form of the arithmetic that aba_walk_spec (rbd_walk.hpp) uses — a workgroup's threads share the
+// (joint, state) cells.  aba_spec (rbd_spec.hpp), where a lane is a state, has the same arithmetic as straight-line per-lane code of its own.  Round 3 left the stage bookkeeping of large batches in its own launches (≈ 5 per step, each streaming
 // the eight stage buffers: a third of the 605 µs step at 65 536 fp64 states).
 //
 // The classical tableau has ONE non-zero per row (a21 = a32 = ½, a43 = 1), so the state of stage s + 1 needs only the base point of the step and the
