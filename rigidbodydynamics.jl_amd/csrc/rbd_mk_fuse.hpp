@@ -49,27 +49,15 @@ RBD_DEV void mk_pre_load(const MkStage& F, MkPre<S, UB>& P, const int32_t* mk1, 
   const S* __restrict__ q0 = (const S*)F.q0; const S* __restrict__ accp = (const S*)F.accp;
   const bool aos = Lq.sk == 1;  // consecutive threads on consecutive coordinates of a state, or on consecutive states of a coordinate: coalesced either way
   const int tot = N1 * nstates;
-  // the table entries of ALL this thread's elements first, then their loads: a lookup in front of every element's loads made every element a round trip of
-  // its own (the address waits for the table value, and vmcnt is in order: so does everything issued before it)
-  int qo[UB], vo[UB];
-#pragma unroll
-  for (int u = 0; u < UB; ++u) {
-    const int e = tid + u * nth;
-    int i, st;
-    mk_elem<N1>(aos, e, nstates, i, st);
-    const bool on = N1 > 0 && s > 0 && e < tot && state0 + st < B;
-    qo[u] = on ? mk1[3 * i] : -1;
-    vo[u] = on ? mk1[3 * i + 1] : 0;
-  }
 #pragma unroll
   for (int u = 0; u < UB; ++u) {
     const int e = tid + u * nth;
     int i, st;
     mk_elem<N1>(aos, e, nstates, i, st);
     P.q0a[u] = S(0); P.acc[u] = S(0);
-    if (qo[u] >= 0) {
-      P.q0a[u] = q0[(long)qo[u] * Lq.sk + (state0 + st) * Lq.sb];
-      P.acc[u] = accp[(long)vo[u] * Lv.sk + (state0 + st) * Lv.sb];
+    if (N1 > 0 && s > 0 && e < tot && state0 + st < B) {
+      P.q0a[u] = q0[(long)mk1[3 * i] * Lq.sk + (state0 + st) * Lq.sb];
+      P.acc[u] = accp[(long)mk1[3 * i + 1] * Lv.sk + (state0 + st) * Lv.sb];
     }
   }
   if constexpr (NF > 0) {
@@ -100,31 +88,16 @@ RBD_DEV void mk_prologue(const MkStage& F, const MkPre<S, UB>& P, CELL cell, con
   const S an = s < 2 ? S(0.5) : S(1);
   S* __restrict__ q0 = (S*)F.q0; S* __restrict__ v0 = (S*)F.v0; S* __restrict__ accp = (S*)F.accp; S* qs = (S*)F.q_state;
   const S* kp = (const S*)F.kp; const S* kd = (const S*)F.kd;
-  int fqo0 = 0, fvo0 = 0;  // the 6-dof joint of this thread's first round below: looked up ahead of the stores of the 1-dof joints
-  if constexpr (NF > 0) {
-    if (tid < NF * nstates) { const int f = tid / nstates; fqo0 = mkf[2 * f]; fvo0 = mkf[2 * f + 1]; }
-  }
   if constexpr (N1 > 0) {
     const bool aos = Lq.sk == 1;
     const S* qdes = (const S*)F.qdes;
-    int tq[UB], tv[UB], tt[UB];  // (all lookups ahead of the first store: a load behind a store waits for the store's acknowledgement)
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int e = tid + u * nth;
       int i, st;
       mk_elem<N1>(aos, e, nstates, i, st);
-      const bool on = e < N1 * nstates && state0 + st < B;
-      tq[u] = on ? mk1[3 * i] : -1;
-      tv[u] = on ? mk1[3 * i + 1] : 0;
-      tt[u] = on ? mk1[3 * i + 2] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int e = tid + u * nth;
-      int i, st;
-      mk_elem<N1>(aos, e, nstates, i, st);
-      if (tq[u] < 0) continue;
-      const int qo = tq[u], vo = tv[u], ty = tt[u];
+      if (!(e < N1 * nstates && state0 + st < B)) continue;
+      const int qo = mk1[3 * i], vo = mk1[3 * i + 1], ty = mk1[3 * i + 2];
       const long aq = (long)qo * Lq.sk + (state0 + st) * Lq.sb, av = (long)vo * Lv.sk + (state0 + st) * Lv.sb;
       const bool sc = ty == RBD_JOINT_SINCOS_REVOLUTE;
       const S rate = *cell(rv + vo, st);  // a 1-dof joint's local-coordinate rate is its velocity (joint_types.jl:9-18, sin_cos_revolute.jl:173-196)
@@ -151,7 +124,7 @@ RBD_DEV void mk_prologue(const MkStage& F, const MkPre<S, UB>& P, CELL cell, con
     for (int e = tid; e < NF * nstates; e += nth) {
       const int f = e / nstates, st = e - f * nstates;
       if (state0 + st >= B) continue;
-      const int qo = e == tid ? fqo0 : mkf[2 * f], vo = e == tid ? fvo0 : mkf[2 * f + 1];
+      const int qo = mkf[2 * f], vo = mkf[2 * f + 1];
       const long aq = (long)qo * Lq.sk + (state0 + st) * Lq.sb, av = (long)vo * Lv.sk + (state0 + st) * Lv.sb;
       S qj[7], vj[6], q0j[7], rate[6], phi[6], qn[7], acc[6];
 #pragma unroll
