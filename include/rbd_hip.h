@@ -392,6 +392,10 @@ int rbd_jit_precompile(const rbd_model_t* model, int32_t dtype, char* log, int64
  * the seconds each took).  rbd_jit_status is the non-blocking query for ONE program (family as above): 1 = ready, 0 = being compiled (started by this
  * call if nobody had), -1 = no such program / no hiprtc / compilation failed. */
 int rbd_jit_status(const rbd_model_t* model, int32_t dtype, int32_t family);
+/* Waits for every compilation this process has started in the background (no-op when there is none).  A host process calls it before it exits — the
+ * Python mirror and the Julia shim register it with their `atexit`: the compiler's own teardown at process exit does not wait for a thread that is still
+ * inside it (a process that exited seconds after its first large-batch call on a new mechanism ended in a segmentation fault). */
+void rbd_jit_wait_idle(void);
 int64_t rbd_jit_source(const rbd_model_t* model, int32_t dtype, int32_t family, char* buf, int64_t capacity);
 
 #ifdef __cplusplus

@@ -140,11 +140,16 @@ mutable struct FlatModelHandle
     loopjointids::Vector{JointID}       # the non-tree joints in the order of rbd_flat_model_t.loops (= the order of rbd_workspace_set_loop_gains)
 end
 
+const WAIT_HOOK = Ref(false)
 const HEADER_VERSION = 400    # RBD_HIP_H_VERSION of the include/rbd_hip.h these structs mirror (rbd_flat_model_t grew its contact fields at 200; 400: rbd_workspace_set_loop_gains)
 
 function FlatModelHandle(mechanism::Mechanism)
     ccall((:rbd_version, librbd_hip[]), Cint, ()) == HEADER_VERSION ||
         error("librbd_hip.so reports another header version than this shim was written for ($HEADER_VERSION): struct layouts may differ")
+    if !WAIT_HOOK[]  # once: a kernel compilation still running in the background is waited for before the process tears the compiler down
+        atexit(() -> ccall((:rbd_jit_wait_idle, librbd_hip[]), Cvoid, ()))
+        WAIT_HOOK[] = true
+    end
     tj = collect(tree_joints(mechanism))
     nb = length(tj)
     bodyindex = Dict(successor(j, mechanism) => Int32(i - 1) for (i, j) in enumerate(tj))

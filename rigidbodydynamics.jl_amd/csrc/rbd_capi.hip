@@ -206,6 +206,7 @@ int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char
 }
 // 1: the program's code object is ready (in the cache, or compiled by this process); 0: being compiled on a background thread (started by this call if nobody
 // had); -1: no such program for this mechanism, no hiprtc, or the compilation failed.  Never waits.
+void rbd_jit_wait_idle(void) { jit_wait_idle(); }
 int rbd_jit_status(const rbd_model_t* m, int32_t dtype, int32_t family) {
   const std::string src = program_source(m, dtype, family);
   if (src.empty() || !jit_available()) return -1;

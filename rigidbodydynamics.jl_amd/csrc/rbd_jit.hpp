@@ -46,6 +46,7 @@ std::string walk_spec_source(const WalkTables& W, int dtype, int kind = 0, int p
 // started on a background thread — ask again later —, JIT_FAILED with the compiler's log.  The plain forms wait.  jit_async(): RBD_JIT_ASYNC != 0 (default).
 enum { JIT_READY = 0, JIT_PENDING = 1, JIT_FAILED = 2 };
 bool jit_async();
+void jit_wait_idle();  // joins every background compilation of this process
 int jit_code_object_get(const std::string& source, bool wait, std::vector<char>* code, std::string* log);
 // the walk kernels' object: checked for accumulation registers of the allocator's own, then its kernel descriptor made to cover all 256 (see rbd_jit.hip)
 int jit_walk_code_object_get(const std::string& source, bool wait, std::vector<char>* code, std::string* log);

@@ -61,7 +61,7 @@ def header_prototypes():
     h = open(os.path.join(ROOT, "include", "rbd_hip.h")).read()
     h = re.sub(r"/\*.*?\*/", " ", h, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(rbd_\w+)\s*\(([^;{]*?)\)\s*;", h, flags=re.S):
+    for m in re.finditer(r"\b(?:int|void|const char\*)\s+(rbd_\w+)\s*\(([^;{]*?)\)\s*;", h, flags=re.S):
         params = [c_kind(p) for p in split_top(" ".join(m.group(2).split()))]
         protos[m.group(1)] = [k for k in params if k is not None]
     return protos

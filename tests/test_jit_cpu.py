@@ -154,6 +154,28 @@ def test_programs_of_mechanisms_with_every_joint_type(rbd, tmp_path, monkeypatch
     assert ok, log
 
 
+def test_a_process_that_exits_waits_for_its_background_compilations(tmp_path):
+    """A process that ends while kernels are still being compiled for it: the `atexit` hook of the Python mirror (rbd_jit_wait_idle, include/rbd_hip.h) waits for the
+    compiler — without it the compiler's own teardown pulled the ground from under its thread (segmentation fault at exit) — and the cache has the programs."""
+    import subprocess, sys
+    cache = tmp_path / "cache"
+    code = (
+        "import os, sys\n"
+        "os.environ['RBD_JIT_CACHE'] = %r\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'oracle'))\n"
+        "import torch, rbd_amd as rbd\n"
+        "m = rbd.flatten(rbd.builders.double_pendulum())\n"
+        "st = [rbd.jit_status(m, torch.float32, f) for f in (0, 1, 2)]\n"
+        "print('status', st)\n" % (str(cache), ROOT, ROOT))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280)
+    if "status [-1, -1, -1]" in r.stdout:
+        pytest.skip("hiprtc not available")
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert "status [0, 0, 0]" in r.stdout, r.stdout  # all three were started in the background, none waited for
+    files = [f for f in os.listdir(cache) if f.endswith(".hsaco")]
+    assert len(files) == 3 and not [f for f in os.listdir(cache) if ".tmp" in f]
+
+
 def test_out_of_scope_mechanisms_have_no_specialised_kernels(rbd):
     mech = rbd.builders.four_bar_linkage()  # loop joints: the state plan does not apply
     assert rbd.jit_source(rbd.flatten(mech), torch.float32) is None
