@@ -4,7 +4,7 @@ dynamics! (fp32, RBD_ALGO_ABA_COMPILED, q̇ included), mass_matrix! (crba_spec) 
 usage: python scripts/stress_compiled_alltypes.py [N=40] [--precompile]   (--precompile: no GPU — compile the N mechanisms' programs into the cache and exit)"""
 import os, sys
 os.environ.setdefault("RBD_JIT_ASYNC", "0")
-os.environ["RBD_TUNE"] = "state_min_batch=1"  # every batch size through the one-lane-per-state routes
+os.environ["RBD_TUNE"] = "state_min_batch=1,spec_aba_min_batch=1"  # every batch size through the one-lane-per-state routes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
@@ -13,7 +13,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 N = int(args[0]) if args else 40
 PRE = "--precompile" in sys.argv
 if not PRE:
-    import oracle
+    import oracle, simulate_np
 rng = np.random.default_rng(4242)
 TYPES = ["Revolute", "Prismatic", "Fixed", "SinCosRevolute", "Planar", "QuaternionSpherical", "QuaternionFloating"]
 worst, used = {}, {}
@@ -109,4 +109,15 @@ for trial in range(10 * N):
             assert np.isfinite(vg).all() and eta < 2e-5, (trial, types, B, layout, eta)
             _, qd_ref = oracle.dynamics(model, qd_, v_, tau_, fe_, want_qdot=True)
             chk("q̇ f32", Hh(res.qd), qd_ref, 3e-6)
+            # simulate: two RK4 steps with the Munthe-Kaas stage inside aba_spec_f32 (generic over the joint types), two states against the numpy integrator
+            st2 = rbd.MechanismState(model, B, dtype=tdt, layout=layout)
+            rbd.set_configuration_(st2, qd_); rbd.set_velocity_(st2, v_)
+            rbd.simulate_(st2, 1.5e-3, dt=1e-3, torques=D(tau_))
+            kernel(st2, "aba_spec_f32 with the Munthe-Kaas stage folded in")
+            qs_, vs_ = Hh(st2.q), Hh(st2.v)
+            assert np.isfinite(qs_).all() and np.isfinite(vs_).all(), (trial, types)
+            sel = [0, B - 1] if B > 1 else [0]
+            _, q_ref, v_ref = simulate_np.simulate(model, qd_[sel], v_[sel], 1.5e-3, 1e-3, tau_[sel])
+            chk("simulate q f32 (|.|: quaternion sign)", np.abs(qs_[sel]), np.abs(q_ref), 2e-5)
+            chk("simulate v f32", vs_[sel], v_ref, 2e-3)
 print(f"{done} random trees of all joint types through the compiled kernels ok; worst {worst}; kernels {used}")
