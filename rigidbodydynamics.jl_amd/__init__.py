@@ -12,7 +12,7 @@ from .mechanism import (DEFAULT_GRAVITATIONAL_ACCELERATION, CartesianFrame3D, Fi
                         ViscoelasticCoulombModel, add_contact_point_, add_environment_primitive_, hunt_crossley_hertz)
 from .urdf import default_urdf_joint_types, parse_pose, parse_urdf, write_urdf
 from .builders import (maximal_coordinates, FOUR_BAR_INITIAL_Q, FOUR_BAR_INITIAL_V, double_pendulum, four_bar_linkage, quickstart_double_pendulum,
-                       rand_tree_mechanism, randmech)
+                       rand_tree_mechanism, randmech, tree_mechanism)
 from .flatio import load_flat_model, save_flat_model
 from . import _capi
 from .state import (PDGains, SE3PDGains, default_constraint_stabilization_gains, TorqueTable, PDControl, jit_source, jit_precompile, jit_status, bank_plan, track_plan, reroot_plan, momentum, momentum_rate_bias, geometric_jacobian_, chain_plan, center_of_mass, gravitational_potential_energy, kinetic_energy, momentum_matrix_, DimensionMismatch, DynamicsResult, MechanismState, dynamics_, dynamics_bias_, dynamics_ode_, inverse_dynamics_, mass_matrix_,

@@ -142,3 +142,41 @@ def maximal_coordinates(mechanism: Mechanism):
         attach_(ret, dp, ds, nj, joint_pose=Transform3D(nj.frame_before, dp.default_frame, j2p.R, j2p.p),
                 successor_pose=Transform3D(ds.default_frame, nj.frame_after, s2j.R, s2j.p))
     return ret
+
+
+def tree_mechanism(rng, spec, axis_aligned=False) -> Mechanism:
+    """A tree of a GIVEN shape with random bodies: `spec` is a list of (joint type name, [children specs]) hanging off the world.  Limbs of the same shape
+    (the same nested spec twice under one parent) get their own random poses and inertias — what the kernels that walk such limbs in lockstep must cope with.
+    axis_aligned: joint axes and poses drawn from the coordinate axes / quarter turns, the way URDF robots are built (many structural zeros in the constants)."""
+    from .mechanism import Fixed, Planar, Prismatic, QuaternionFloating, QuaternionSpherical, Revolute, SinCosRevolute
+    world = RigidBody("world")
+    mech = Mechanism(world)
+    count = [0]
+
+    def pose_rotation():
+        if not axis_aligned:
+            return _rand_rotation(rng)
+        P = np.eye(3)[rng.permutation(3)] * rng.choice([-1.0, 1.0], 3)[:, None]
+        return P if np.linalg.det(P) > 0 else -P
+
+    def joint_type(name):
+        if not axis_aligned or name in ("Fixed", "QuaternionFloating", "QuaternionSpherical", "Planar"):
+            return rand_joint_type(rng, name)
+        ax = np.eye(3)[rng.integers(3)] * rng.choice([-1.0, 1.0])
+        return {"Revolute": Revolute, "Prismatic": Prismatic, "SinCosRevolute": SinCosRevolute}[name](ax)
+
+    def grow(parent, node):
+        name, children = node
+        count[0] += 1
+        i = count[0]
+        joint = Joint(f"joint{i}", joint_type(name))
+        p = rng.random(3) * (rng.random(3) < 0.5 if axis_aligned else 1.0)
+        pose = Transform3D(joint.frame_before, parent.default_frame, pose_rotation(), p)
+        body = RigidBody(rand_spatial_inertia(rng, CartesianFrame3D(f"body{i}")))
+        attach_(mech, parent, body, joint, joint_pose=pose, successor_pose=Transform3D(body.default_frame, joint.frame_after))
+        for c in children:
+            grow(body, c)
+
+    for node in spec:
+        grow(world, node)
+    return mech

@@ -570,6 +570,7 @@ RBD_HD void sincos_fast(float x, float* sp, float* cp) {
 RBD_HD f2 rcp_hd(f2 x) { f2 r; r.x = rcp_hd(x.x); r.y = rcp_hd(x.y); return r; }
 // two states per lane: the polynomial part as packed arithmetic (v_pk_fma_f32), the quadrant logic per component
 RBD_HD void sincos_fast(f2 x, f2* s, f2* c) {
+#ifndef RBD_JIT_COMPILE  // (as in the one-state form above: the kernels compiled at run time carry no copy of the library path)
   if (!(__builtin_fabsf(x.x) <= 8192.0f && __builtin_fabsf(x.y) <= 8192.0f)) {
     float s0, c0, s1, c1;
     sincos_hd(x.x, &s0, &c0);
@@ -577,6 +578,7 @@ RBD_HD void sincos_fast(f2 x, f2* s, f2* c) {
     s->x = s0; s->y = s1; c->x = c0; c->y = c1;
     return;
   }
+#endif
   f2 k;
   k.x = __builtin_rintf(x.x * 6.36619772e-01f); k.y = __builtin_rintf(x.y * 6.36619772e-01f);
   f2 r = k * f2(-1.57079637e+00f) + x;

@@ -377,10 +377,196 @@ constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB) + 1
 template <typename T> struct Kin { T R[9], p[3], Tw[6], av[6]; };
 template <typename T> struct Hand { T I[21], p[6]; };
 
+// ---- limbs in lockstep -----------------------------------------------------------------------------------------------------------
+// An op of the walk may stand for TWO bodies (rbd_plan::PAIR, rbd_jit.hip: merge_limbs): the same place in two sibling subtrees of the same shape, e.g. the left
+// and the right knee.  Such an op computes in V = f2 — the first body in the low halves, its partner in the high halves of register pairs — and every arithmetic
+// instruction of it is a packed one (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32: the issue slot of the scalar form, two bodies' worth of work; operands broadcast
+// from either half for free; scripts/ubench/pk_ubench.hip).  A lone wavefront per SIMD is bound by the instructions it issues, so a humanoid's 26 limb bodies cost
+// 13.  The code of an op is written once, generic in V; what differs is how a value is fetched (two LDS rows / two registers for a pair) and its constants.
+template <typename V> struct NLanes { enum { N = 1 }; };
+template <> struct NLanes<f2> { enum { N = 2 }; };
+template <typename T, bool PR> struct PairOf { using type = T; };
+template <> struct PairOf<float, true> { using type = f2; };
+template <typename V, typename T> RBD_DEV V widen(T x) {  // both limbs start from their common parent's value
+  if constexpr (NLanes<V>::N == 2) return V{x, x}; else return x;
+}
+RBD_DEV float hsum(f2 x) { return x.x + x.y; }  // what the two limbs hand their common parent
+RBD_DEV float hsum(float x) { return x; }
+RBD_DEV double hsum(double x) { return x; }
+// LDS rows / registers of the op's body (and of its partner's)
+template <typename V, typename S> RBD_DEV V rd2(const S* col, int ra, int rb) {
+  if constexpr (NLanes<V>::N == 2) return V{col[ra * RS], col[rb * RS]}; else return col[ra * RS];
+}
+template <typename V, typename S> RBD_DEV void wr2(S* col, int ra, int rb, V x) {
+  if constexpr (NLanes<V>::N == 2) { col[ra * RS] = x.x; col[rb * RS] = x.y; } else col[ra * RS] = x;
+}
+// constant K of op O's body record (canonical frames: TR_*), and what kind of number it is: 0, 1, -1 or any other (2).  A pair's constant is the pair of the
+// two bodies' constants.
+#ifdef RBD_SPEC_TRP
+// the table's address as ONE opaque scalar pair: every read is then an s_load with an immediate offset (left to itself the compiler forms the pc-relative
+// address afresh — three scalar instructions — at every use)
+typedef const float __attribute__((address_space(4)))* TrpPtr;
+RBD_DEV TrpPtr trp_base() {
+  TrpPtr p = (TrpPtr)(&P::TRP[0][0]);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+s"(p));
+#endif
+  return p;
+}
+#endif
+template <typename V, int O, int K> RBD_DEV V cst() {
+  if constexpr (NLanes<V>::N == 2) {
+    constexpr float a = (float)P::TR[O][K], b = (float)P::TR2[O][K];
+#ifdef RBD_SPEC_TRP
+    // from the plan's table of pairs through the scalar unit (what folds — 0, 1, -1 — never gets here: cterm)
+    return V{trp_base()[O * 48 + 2 * K], trp_base()[O * 48 + 2 * K + 1]};
+#else
+    return V{a, b};
+#endif
+  } else return V(P::TR[O][K]);
+}
+template <typename V, int O, int K> constexpr int ccls() {
+  constexpr double a = P::TR[O][K], b = NLanes<V>::N == 2 ? P::TR2[O][K] : P::TR[O][K];
+  return (a == 0 && b == 0) ? 0 : (a == 1 && b == 1) ? 1 : (a == -1 && b == -1) ? -1 : 2;
+}
+// acc + (constant K) x with the arithmetic the constant needs: none for 0, an addition for +-1 (the frames of a mechanism built from axis-aligned joints are
+// signed permutations: x * 0 and x * 1 are not the compiler's to drop under IEEE rules, they are dropped here).  Sums start from -0.0: -0.0 + x IS x.
+template <typename V, int O, int K> RBD_DEV void cterm(V& acc, V x) {
+  constexpr int c = ccls<V, O, K>();
+  if constexpr (c == 1) acc += x;
+  else if constexpr (c == -1) acc -= x;
+  else if constexpr (c == 2) acc += cst<V, O, K>() * x;
+}
+template <typename V, int O, int K0, int K1, int K2> RBD_DEV V lin3(V x0, V x1, V x2) {  // (constant K0) x0 + (constant K1) x1 + (constant K2) x2
+  V acc = V(-0.0f);
+  cterm<V, O, K0>(acc, x0);
+  cterm<V, O, K1>(acc, x1);
+  cterm<V, O, K2>(acc, x2);
+  return acc;
+}
+template <typename V, int O, int K0, int K1, int K2> constexpr bool lin3_zero() { return ccls<V, O, K0>() == 0 && ccls<V, O, K1>() == 0 && ccls<V, O, K2>() == 0; }
+
+// sin, cos of op O's joint angle(s) — a revolute joint's coordinate, or the two coordinates of a sin-cos joint
+template <typename V, int O, typename S> RBD_DEV void joint_sincos(const S* qs, V& s, V& c) {
+  constexpr int jt = P::OPW[O][0] >> 16, qa = P::OPW[O][1], qb = P::OPW2[O][1];
+  if constexpr (jt == RBD_JOINT_REVOLUTE) sincos_fast(rd2<V>(qs, qa, qb), &s, &c);
+  else { s = rd2<V>(qs, qa, qb); c = rd2<V>(qs, qa + 1, qb + 1); }
+}
+// (Rn, pn) = (R, p) o joint_to_predecessor o joint_transform(q) for a 1-dof or fixed joint in canonical frames (joint axis +z), in the order that lets the
+// constants fold: A = R C, then A Rz(q) (twelve multiplications) — C q-independent, in most mechanisms a signed permutation
+template <typename V, int O, typename S> RBD_DEV void compose_1dof(const S* qs, const V* R, const V* p, V* Rn, V* pn) {
+  constexpr int jt = P::OPW[O][0] >> 16, qa = P::OPW[O][1], qb = P::OPW2[O][1];
+  V A[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    A[3 * i] = lin3<V, O, TR_C + 0, TR_C + 3, TR_C + 6>(R[3 * i], R[3 * i + 1], R[3 * i + 2]);
+    A[3 * i + 1] = lin3<V, O, TR_C + 1, TR_C + 4, TR_C + 7>(R[3 * i], R[3 * i + 1], R[3 * i + 2]);
+    A[3 * i + 2] = lin3<V, O, TR_C + 2, TR_C + 5, TR_C + 8>(R[3 * i], R[3 * i + 1], R[3 * i + 2]);
+    pn[i] = p[i] + lin3<V, O, TR_PP, TR_PP + 1, TR_PP + 2>(R[3 * i], R[3 * i + 1], R[3 * i + 2]);
+  }
+  if constexpr (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_SINCOS_REVOLUTE) {
+    V s, c;
+    joint_sincos<V, O>(qs, s, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Rn[3 * i] = c * A[3 * i] + s * A[3 * i + 1];
+      Rn[3 * i + 1] = c * A[3 * i + 1] - s * A[3 * i];
+      Rn[3 * i + 2] = A[3 * i + 2];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rn[k] = A[k];
+    if constexpr (jt == RBD_JOINT_PRISMATIC) {
+      const V d = rd2<V>(qs, qa, qb);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pn[i] += d * A[3 * i + 2];
+    }
+  }
+}
+// the inverse: from the body's (R, p) back to its parent's.  Rp = R Rl' = (R Rz') C', pp = p - Rp pl
+template <typename V, int O, typename S> RBD_DEV void uncompose_1dof(const S* qs, V* R, V* p) {
+  constexpr int jt = P::OPW[O][0] >> 16, qa = P::OPW[O][1], qb = P::OPW2[O][1];
+  V Bm[9], Rp[9];
+  if constexpr (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_SINCOS_REVOLUTE) {
+    V s, c;
+    joint_sincos<V, O>(qs, s, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Bm[3 * i] = c * R[3 * i] - s * R[3 * i + 1];
+      Bm[3 * i + 1] = s * R[3 * i] + c * R[3 * i + 1];
+      Bm[3 * i + 2] = R[3 * i + 2];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Bm[k] = R[k];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Rp[3 * i] = lin3<V, O, TR_C + 0, TR_C + 1, TR_C + 2>(Bm[3 * i], Bm[3 * i + 1], Bm[3 * i + 2]);
+    Rp[3 * i + 1] = lin3<V, O, TR_C + 3, TR_C + 4, TR_C + 5>(Bm[3 * i], Bm[3 * i + 1], Bm[3 * i + 2]);
+    Rp[3 * i + 2] = lin3<V, O, TR_C + 6, TR_C + 7, TR_C + 8>(Bm[3 * i], Bm[3 * i + 1], Bm[3 * i + 2]);
+  }
+  if constexpr (jt == RBD_JOINT_PRISMATIC) {  // pl = pp + d C[:, 2]:  Rp pl = Rp pp + d Bm[:, 2]  (Rp C[:, 2] = Bm C' C e_z = Bm[:, 2])
+    const V d = rd2<V>(qs, qa, qb);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p[i] -= d * Bm[3 * i + 2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    p[i] -= lin3<V, O, TR_PP, TR_PP + 1, TR_PP + 2>(Rp[3 * i], Rp[3 * i + 1], Rp[3 * i + 2]);
+    R[3 * i] = Rp[3 * i]; R[3 * i + 1] = Rp[3 * i + 1]; R[3 * i + 2] = Rp[3 * i + 2];
+  }
+}
+// transform(inertia, H) (src/spatial/motion_force_interaction.jl:160-176) with op O's body constants folded (inertia_to_root of rbd_device.hpp, same formulas)
+template <typename V, int O> RBD_DEV void inertia_to_root_c(const V* R, const V* p, RInertia<V>& Out) {
+  const V m = cst<V, O, TR_M>();
+  V Rmc[3], mp[3], Y[6];
+  constexpr bool mcz = lin3_zero<V, O, TR_MC, TR_MC + 1, TR_MC + 2>();  // centre of mass at the frame's origin
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { Rmc[k] = lin3<V, O, TR_MC, TR_MC + 1, TR_MC + 2>(R[3 * k], R[3 * k + 1], R[3 * k + 2]); mp[k] = m * p[k]; }
+  if constexpr (mcz) {
+    Y[0] = mp[0] * p[0]; Y[1] = mp[0] * p[1]; Y[2] = mp[0] * p[2]; Y[3] = mp[1] * p[1]; Y[4] = mp[1] * p[2]; Y[5] = mp[2] * p[2];
+  } else {
+    Y[0] = 2 * Rmc[0] * p[0] + mp[0] * p[0];
+    Y[1] = Rmc[0] * p[1] + Rmc[1] * p[0] + mp[0] * p[1];
+    Y[2] = Rmc[0] * p[2] + Rmc[2] * p[0] + mp[0] * p[2];
+    Y[3] = 2 * Rmc[1] * p[1] + mp[1] * p[1];
+    Y[4] = Rmc[1] * p[2] + Rmc[2] * p[1] + mp[1] * p[2];
+    Y[5] = 2 * Rmc[2] * p[2] + mp[2] * p[2];
+  }
+  const V trY = Y[0] + Y[3] + Y[5];
+  V RJ[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    RJ[3 * i] = lin3<V, O, TR_J + 0, TR_J + 1, TR_J + 2>(R[3 * i], R[3 * i + 1], R[3 * i + 2]);
+    RJ[3 * i + 1] = lin3<V, O, TR_J + 1, TR_J + 3, TR_J + 4>(R[3 * i], R[3 * i + 1], R[3 * i + 2]);
+    RJ[3 * i + 2] = lin3<V, O, TR_J + 2, TR_J + 4, TR_J + 5>(R[3 * i], R[3 * i + 1], R[3 * i + 2]);
+  }
+  V A[6];
+  A[0] = RJ[0] * R[0] + RJ[1] * R[1] + RJ[2] * R[2];
+  A[1] = RJ[0] * R[3] + RJ[1] * R[4] + RJ[2] * R[5];
+  A[2] = RJ[0] * R[6] + RJ[1] * R[7] + RJ[2] * R[8];
+  A[3] = RJ[3] * R[3] + RJ[4] * R[4] + RJ[5] * R[5];
+  A[4] = RJ[3] * R[6] + RJ[4] * R[7] + RJ[5] * R[8];
+  A[5] = RJ[6] * R[6] + RJ[7] * R[7] + RJ[8] * R[8];
+  Out.J[0] = A[0] - Y[0] + trY; Out.J[1] = A[1] - Y[1]; Out.J[2] = A[2] - Y[2];
+  Out.J[3] = A[3] - Y[3] + trY; Out.J[4] = A[4] - Y[4]; Out.J[5] = A[5] - Y[5] + trY;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) Out.c[k] = mcz ? mp[k] : Rmc[k] + mp[k];
+  Out.m = m;
+}
+// motion subspace column of a revolute / prismatic joint from the body's transform (axis +z of the canonical frame)
+template <typename V, int jt> RBD_DEV void subspace_1dof(const V* R, const V* p, V* S) {
+  if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = V(0.0f); S[3] = R[2]; S[4] = R[5]; S[5] = R[8]; }
+  else { S[0] = R[2]; S[1] = R[5]; S[2] = R[8]; cross3(p, S, S + 3); }
+}
+constexpr bool jt_1dof(int jt) { return jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_PRISMATIC || jt == RBD_JOINT_SINCOS_REVOLUTE; }
+
 template <typename T>
 RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau, const T* __restrict__ fext,
                       T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T gx, T gy, T gz, T* lds, const MkStage& F) {
-  constexpr int NQ = P::NQ, NV = P::NV, NB = P::NB, NBS = P::NBS > 0 ? P::NBS : 1;
+  constexpr int NQ = P::NQ, NV = P::NV, NB = P::NB, NBS = P::NBS > 0 ? P::NBS : 1, NPR = P::NPAIR > 0 ? P::NPAIR : 1;
+  using T2 = typename PairOf<T, true>::type;  // the value type of an op that stands for two bodies
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* rq = lds + (size_t)wave * ABA_ROWS * RS;
   T* rv = rq + NQ * RS;
@@ -433,11 +619,11 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
       for (int k = 0; k < NQ; ++k) QD[k] = qdes ? qdes[(long)k * Lq.sk + mk_si * Lq.sb] : T(0);
     }
-    sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
-      constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, jt = w0 >> 16, qoff = P::OPW[O][1], voff = P::OPW[O][2];
+    sfor<NB>([&](auto jc) __attribute__((always_inline)) {  // joint by joint (the limbs one after the other: element-wise work, nothing to pair up)
+      constexpr int J = jc.value, jt = P::JOINTS[J][0], qoff = P::JOINTS[J][1], voff = P::JOINTS[J][2];
       constexpr int nqj = jt == RBD_JOINT_QUAT_FLOATING ? 7 : jt == RBD_JOINT_QUAT_SPHERICAL ? 4 : jt == RBD_JOINT_PLANAR ? 3 : jt == RBD_JOINT_SINCOS_REVOLUTE ? 2 : jt == RBD_JOINT_FIXED ? 0 : 1;
       constexpr int nvj = nvj_of(jt);
-      if constexpr (kind == SK_ENTER && nvj > 0) {
+      if constexpr (nvj > 0) {
         T qj[7], vj[6], q0j[7], rate[6], phi[6], qn[7];
 #pragma unroll
         for (int k = 0; k < 7; ++k) { qj[k] = k < nqj ? qs[(qoff + (k < nqj ? k : 0)) * RS] : T(0); q0j[k] = qj[k]; }
@@ -476,43 +662,41 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   // q̇ (configuration_derivative!, src/mechanism_state.jl:905-910) depends on q and v alone: assembled in the spare rows and sent off before the
   // passes start (its stores drain while they run; the rows are free again long before pass 2 writes them)
   if (qdot) {
-    sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
-      constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, jt = w0 >> 16, qoff = P::OPW[O][1], voff = P::OPW[O][2];
-      if constexpr (kind == SK_ENTER) {
-        if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {  // velocity_to_configuration_derivative! (quaternion_floating.jl:126-136)
-          T v6[6], Rq[9], lin[3];
+    sfor<NB>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int J = jc.value, jt = P::JOINTS[J][0], qoff = P::JOINTS[J][1], voff = P::JOINTS[J][2];
+      if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {  // velocity_to_configuration_derivative! (quaternion_floating.jl:126-136)
+        T v6[6], Rq[9], lin[3];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) v6[k] = vs[(voff + k) * RS];
-          const T qw = qs[qoff * RS], qx = qs[(qoff + 1) * RS], qy = qs[(qoff + 2) * RS], qz = qs[(qoff + 3) * RS];
-          xs[qoff * RS] = (-qx * v6[0] - qy * v6[1] - qz * v6[2]) / 2;
-          xs[(qoff + 1) * RS] = (qw * v6[0] - qz * v6[1] + qy * v6[2]) / 2;
-          xs[(qoff + 2) * RS] = (qz * v6[0] + qw * v6[1] - qx * v6[2]) / 2;
-          xs[(qoff + 3) * RS] = (-qy * v6[0] + qx * v6[1] + qw * v6[2]) / 2;
-          rot_quat(qw, qx, qy, qz, Rq);
-          matvec3(Rq, v6 + 3, lin);
+        for (int k = 0; k < 6; ++k) v6[k] = vs[(voff + k) * RS];
+        const T qw = qs[qoff * RS], qx = qs[(qoff + 1) * RS], qy = qs[(qoff + 2) * RS], qz = qs[(qoff + 3) * RS];
+        xs[qoff * RS] = (-qx * v6[0] - qy * v6[1] - qz * v6[2]) / 2;
+        xs[(qoff + 1) * RS] = (qw * v6[0] - qz * v6[1] + qy * v6[2]) / 2;
+        xs[(qoff + 2) * RS] = (qz * v6[0] + qw * v6[1] - qx * v6[2]) / 2;
+        xs[(qoff + 3) * RS] = (-qy * v6[0] + qx * v6[1] + qw * v6[2]) / 2;
+        rot_quat(qw, qx, qy, qz, Rq);
+        matvec3(Rq, v6 + 3, lin);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) xs[(qoff + 4 + k) * RS] = lin[k];
-        } else if constexpr (jt == RBD_JOINT_SINCOS_REVOLUTE) {  // d/dt (sin, cos) = (cos, -sin) q'
-          const T qd = vs[voff * RS];
-          xs[qoff * RS] = qs[(qoff + 1) * RS] * qd;
-          xs[(qoff + 1) * RS] = -qs[qoff * RS] * qd;
-        } else if constexpr (jt == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl velocity_to_configuration_derivative!
-          const T w0 = vs[voff * RS], w1 = vs[(voff + 1) * RS], w2 = vs[(voff + 2) * RS];
-          const T qw = qs[qoff * RS], qx = qs[(qoff + 1) * RS], qy = qs[(qoff + 2) * RS], qz = qs[(qoff + 3) * RS];
-          xs[qoff * RS] = (-qx * w0 - qy * w1 - qz * w2) / 2;
-          xs[(qoff + 1) * RS] = (qw * w0 - qz * w1 + qy * w2) / 2;
-          xs[(qoff + 2) * RS] = (qz * w0 + qw * w1 - qx * w2) / 2;
-          xs[(qoff + 3) * RS] = (-qy * w0 + qx * w1 + qw * w2) / 2;
-        } else if constexpr (jt == RBD_JOINT_PLANAR) {  // planar.jl velocity_to_configuration_derivative!: q̇_lin = Rot2(θ) v_lin
-          T sn, cs;
-          sincos_fast(qs[(qoff + 2) * RS], &sn, &cs);
-          const T vx = vs[voff * RS], vy = vs[(voff + 1) * RS];
-          xs[qoff * RS] = cs * vx - sn * vy;
-          xs[(qoff + 1) * RS] = sn * vx + cs * vy;
-          xs[(qoff + 2) * RS] = vs[(voff + 2) * RS];
-        } else if constexpr (jt != RBD_JOINT_FIXED) {
-          xs[qoff * RS] = vs[voff * RS];
-        }
+        for (int k = 0; k < 3; ++k) xs[(qoff + 4 + k) * RS] = lin[k];
+      } else if constexpr (jt == RBD_JOINT_SINCOS_REVOLUTE) {  // d/dt (sin, cos) = (cos, -sin) q'
+        const T qd = vs[voff * RS];
+        xs[qoff * RS] = qs[(qoff + 1) * RS] * qd;
+        xs[(qoff + 1) * RS] = -qs[qoff * RS] * qd;
+      } else if constexpr (jt == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl velocity_to_configuration_derivative!
+        const T w0 = vs[voff * RS], w1 = vs[(voff + 1) * RS], w2 = vs[(voff + 2) * RS];
+        const T qw = qs[qoff * RS], qx = qs[(qoff + 1) * RS], qy = qs[(qoff + 2) * RS], qz = qs[(qoff + 3) * RS];
+        xs[qoff * RS] = (-qx * w0 - qy * w1 - qz * w2) / 2;
+        xs[(qoff + 1) * RS] = (qw * w0 - qz * w1 + qy * w2) / 2;
+        xs[(qoff + 2) * RS] = (qz * w0 + qw * w1 - qx * w2) / 2;
+        xs[(qoff + 3) * RS] = (-qy * w0 + qx * w1 + qw * w2) / 2;
+      } else if constexpr (jt == RBD_JOINT_PLANAR) {  // planar.jl velocity_to_configuration_derivative!: q̇_lin = Rot2(θ) v_lin
+        T sn, cs;
+        sincos_fast(qs[(qoff + 2) * RS], &sn, &cs);
+        const T vx = vs[voff * RS], vy = vs[(voff + 1) * RS];
+        xs[qoff * RS] = cs * vx - sn * vy;
+        xs[(qoff + 1) * RS] = sn * vx + cs * vy;
+        xs[(qoff + 2) * RS] = vs[(voff + 2) * RS];
+      } else if constexpr (jt != RBD_JOINT_FIXED) {
+        xs[qoff * RS] = vs[voff * RS];
       }
     });
     wave_sync();
@@ -525,73 +709,92 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   // the world's acceleration: -g (mechanism_algorithms.jl:396); a kernel argument, not the plan's constant: M^-1 rhs is this pass with g = 0 (rbd_mass_matrix_solve)
   const T a0[6] = {T(0), T(0), T(0), -gx, -gy, -gz};
 
-  Kin<T> K;               // the body the walk is at
-  Hand<T> C;              // hand-off of the child just finished, on its way to a chain parent
-  Hand<T> SH[NBS];        // branch points: the sum of their children's hand-offs
+  // the walk's state, once for the ops that stand for one body and once for those that stand for two (the allocator keeps what is live)
+  Kin<T> K1;  Kin<T2> K2;       // the body the walk is at
+  Hand<T> C1; Hand<T2> C2;      // hand-off of the child just finished, on its way to a chain parent
+  Hand<T> SH1[NBS]; Hand<T2> SH2[NBS];  // branch points: the sum of their children's hand-offs
   // per body, for the top-down pass: D^-1 u and U D^-1.  The first goes to the body's tau row (read for the last time when u is formed, written again
   // only by that pass), two of the others to its spare row and its v row (free once the joint is un-composed), four stay in registers
-  T Ud[NB][4];
-  T fe[6];                // external wrench of the body the next EXIT finishes (asked for one EXIT ahead)
+  T Ud1[NB][4]; T2 Ud2[NPR][4];
+  T fe1[6]; T2 fe2[6];          // external wrench of the body the next EXIT finishes (asked for one EXIT ahead)
   auto load_fe = [&](auto oc) __attribute__((always_inline)) {
     constexpr int O = oc.value;
     if constexpr (O >= 0) {
+      if constexpr (P::PAIR[O] != 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) fe[k] = fel ? fel[(long)(P::OPW[O][3] + k) * fsk] : T(0);
+        for (int k = 0; k < 6; ++k) fe2[k] = fel ? T2{fel[(long)(P::OPW[O][3] + k) * fsk], fel[(long)(P::OPW2[O][3] + k) * fsk]} : T2(0.0f);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) fe1[k] = fel ? fel[(long)(P::OPW[O][3] + k) * fsk] : T(0);
+      }
     }
   };
   load_fe(Ix<P::FIRST_EXIT>{});
 
   // ---- passes 1 + 2: down with the kinematics, up with the articulated inertias ----
   sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
-    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
-    constexpr int body = P::BODY[O], nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
+    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2], voff2 = P::OPW2[O][2];
+    constexpr int body = P::BODY[O], body2 = P::BODY2[O], nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
+    constexpr bool PR = P::PAIR[O] != 0, ROOT = P::PROOT[O] != 0;
+    using V = typename PairOf<T, PR>::type;
+    auto& K = [&]() -> auto& { if constexpr (PR) return K2; else return K1; }();
+    auto& C = [&]() -> auto& { if constexpr (PR) return C2; else return C1; }();
+    auto& SH = [&]() -> auto& { if constexpr (PR) return SH2; else return SH1; }();
+    auto& fe = [&]() -> auto& { if constexpr (PR) return fe2; else return fe1; }();
+    auto ud_set = [&](int k, V x) __attribute__((always_inline)) { if constexpr (PR) Ud2[P::PIDX[O]][k] = x; else Ud1[body][k] = x; };
     if constexpr (kind == SK_ENTER) {
       if constexpr (lvl == 0) {  // the parent is the world
 #pragma unroll
-        for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? T(1) : T(0);
+        for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? V(1) : V(0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) K.p[k] = T(0);
+        for (int k = 0; k < 3; ++k) K.p[k] = V(0);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { K.Tw[k] = T(0); K.av[k] = a0[k]; }
+        for (int k = 0; k < 6; ++k) { K.Tw[k] = V(0); K.av[k] = widen<V>(a0[k]); }
+      } else if constexpr (ROOT) {  // two limbs leave their common parent: its kinematic state in both halves (K1 itself stays the parent's until the limbs are done)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K2.R[k] = widen<T2>(K1.R[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) K2.p[k] = widen<T2>(K1.p[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { K2.Tw[k] = widen<T2>(K1.Tw[k]); K2.av[k] = widen<T2>(K1.av[k]); }
       }  // (otherwise K is the parent's: it was just entered, or the sibling finished before this body un-composed its joint)
-      T Rl[9], pl[3], Rn[9], pn[3], t3[3], vJ[6], cb[6];
-      local_transform<T, O, RS>(qs, Rl, pl);
-      matmul3(K.R, Rl, Rn);
-      matvec3(K.R, pl, t3);
+      V Rn[9], pn[3], vJ[6], cb[6];
+      if constexpr (jt_1dof(jt) || jt == RBD_JOINT_FIXED) {
+        compose_1dof<V, O>(qs, K.R, K.p, Rn, pn);
+        if constexpr (jt == RBD_JOINT_FIXED) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) pn[k] = K.p[k] + t3[k];
-      if constexpr (nvj_of(jt) > 1) {
-        T v6[6];
+          for (int k = 0; k < 6; ++k) vJ[k] = V(0);
+        } else {
+          const V qd = rd2<V>(vs, voff, voff2);
+          V S[6];
+          subspace_1dof<V, jt>(Rn, pn, S);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
+        }
+      } else {  // joints with several coordinates: one body per op
+        T Rl[9], pl[3], t3[3], v6[6];
+        local_transform<T, O, RS>(qs, Rl, pl);
+        matmul3(K.R, Rl, Rn);
+        matvec3(K.R, pl, t3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pn[k] = K.p[k] + t3[k];
         body_twist<T, jt>(vs + voff * RS, RS, v6);
         xmotion(Rn, pn, v6, vJ);  // twist of the joint: X(H) v, v the body-frame twist
-      } else if constexpr (jt == RBD_JOINT_FIXED) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) vJ[k] = T(0);
-      } else {
-        const T qd = vs[voff * RS];
-        T S[6];
-        if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = T(0); S[3] = Rn[2]; S[4] = Rn[5]; S[5] = Rn[8]; }
-        else { S[0] = Rn[2]; S[1] = Rn[5]; S[2] = Rn[8]; cross3(pn, S, S + 3); }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) vJ[k] = S[k] * qd;
       }
-      se3_comm(K.Tw, vJ, cb);  // [T_parent, vJ]: the bias acceleration increment (mechanism_state.jl:814-830)
+      if constexpr (jt != RBD_JOINT_FIXED) {
+        se3_comm(K.Tw, vJ, cb);  // [T_parent, vJ]: the bias acceleration increment (mechanism_state.jl:814-830)
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { K.av[k] += cb[k]; K.Tw[k] += vJ[k]; }
+        for (int k = 0; k < 6; ++k) { K.av[k] += cb[k]; K.Tw[k] += vJ[k]; }
+      }
 #pragma unroll
       for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) K.p[k] = pn[k];
     } else {
       // the walk is back at this body: K is its kinematic state (un-composed from its only child, restored from its slot, or — a leaf — just entered)
-      RInertia<T> I;
-      T J6[6], mc[3];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) J6[k] = T(P::TR[O][TR_J + k]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) mc[k] = T(P::TR[O][TR_MC + k]);
-      inertia_to_root(J6, mc, T(P::TR[O][TR_M]), K.R, K.p, I);
-      T IA[21], pA[6], h[6];
+      RInertia<V> I;
+      inertia_to_root_c<V, O>(K.R, K.p, I);
+      V IA[21], pA[6], h[6];
       mul_inertia(I, K.av, pA);
       momentum_cross(I, K.Tw, h);
 #pragma unroll
@@ -609,9 +812,9 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
         for (int k = 0; k < 6; ++k) pA[k] += SH[bs].p[k];
       }
-      Hand<T> H;
-      T S[6], qd = T(0);
-      T vJm[6];  // joints with several coordinates: their twist, kept for the un-composition (their v rows are given another use first)
+      Hand<V> H;
+      V S[6], qd = V(0);
+      V vJm[6];  // joints with several coordinates: their twist, kept for the un-composition (their v rows are given another use first)
       if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
         // 6-dof joint: IA a = S^-T tau - pA for the body's own a_delta whatever its parent's is, v̇ = S^-1 (a - a_parent) (S = X(H): the body-frame twist basis
         // seen from the root).  On the world a_parent = 0 and v̇ is final here; below it the top-down pass finishes it.  The parent sees no inertia
@@ -669,7 +872,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
           const T x = W[j / 6][j % 6];
           if constexpr (j < 3) vs[(voff + j) * RS] = x;
           else if constexpr (j == 3) xs[body * RS] = x;
-          else if constexpr (j < 8) Ud[body][j - 4] = x;
+          else if constexpr (j < 8) Ud1[body][j - 4] = x;
           else x3[(xr + j - 8) * RS] = x;
         });
 #pragma unroll
@@ -684,20 +887,19 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
         for (int k = 0; k < 6; ++k) H.p[k] = pA[k];
       } else {
-        if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = T(0); S[3] = K.R[2]; S[4] = K.R[5]; S[5] = K.R[8]; }
-        else { S[0] = K.R[2]; S[1] = K.R[5]; S[2] = K.R[8]; cross3(K.p, S, S + 3); }
-        T U[6], W[6];
+        subspace_1dof<V, jt>(K.R, K.p, S);
+        V U[6], W[6];
         sym6_mul(IA, S, U);
-        const T Dinv = rcp_hd(dot6(S, U));
-        qd = vs[voff * RS];
-        const T u = (ts[voff * RS] - dot6(S, pA)) * Dinv;
+        const V Dinv = rcp_hd(dot6(S, U));
+        qd = rd2<V>(vs, voff, voff2);
+        const V u = (rd2<V>(ts, voff, voff2) - dot6(S, pA)) * Dinv;
 #pragma unroll
         for (int k = 0; k < 6; ++k) W[k] = U[k] * Dinv;
-        ts[voff * RS] = u;
-        xs[body * RS] = W[0];
-        vs[voff * RS] = W[1];
+        wr2<V>(ts, voff, voff2, u);
+        wr2<V>(xs, body, body2, W[0]);
+        wr2<V>(vs, voff, voff2, W[1]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Ud[body][k] = W[2 + k];
+        for (int k = 0; k < 4; ++k) ud_set(k, W[2 + k]);
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -706,58 +908,99 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
         for (int k = 0; k < 6; ++k) H.p[k] = pA[k] + U[k] * u;
       }
       if constexpr (lvl > 0) {
-        if constexpr (pbs >= 0) {  // the parent is a branch point: its slot sums its children's hand-offs
-          if constexpr (cidx == 0) SH[pbs] = H;
-          else {
+        if constexpr (ROOT) {
+          // the two limbs' hand-offs go to their common parent as their sum; K1 is still that parent's kinematic state: nothing to un-compose
+          if constexpr (pbs >= 0) {
+            if constexpr (cidx == 0) {
 #pragma unroll
-            for (int k = 0; k < 21; ++k) SH[pbs].I[k] += H.I[k];
+              for (int k = 0; k < 21; ++k) SH1[pbs].I[k] = hsum(H.I[k]);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) SH[pbs].p[k] += H.p[k];
+              for (int k = 0; k < 6; ++k) SH1[pbs].p[k] = hsum(H.p[k]);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 21; ++k) SH1[pbs].I[k] += hsum(H.I[k]);
+#pragma unroll
+              for (int k = 0; k < 6; ++k) SH1[pbs].p[k] += hsum(H.p[k]);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 21; ++k) C1.I[k] = hsum(H.I[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) C1.p[k] = hsum(H.p[k]);
           }
-        } else {  // a chain parent: the hand-off stays in registers
-          C = H;
-        }
-        // back to the parent: the joint is un-composed (a copy of every branch point's kinematics would cost more registers than the file has)
-        if constexpr (jt != RBD_JOINT_FIXED) {
-          T vJ[6], cb[6];
+        } else {
+          if constexpr (pbs >= 0) {  // the parent is a branch point: its slot sums its children's hand-offs
+            if constexpr (cidx == 0) SH[pbs] = H;
+            else {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            if constexpr (nvj_of(jt) > 1) vJ[k] = vJm[k];
-            else vJ[k] = S[k] * qd;
+              for (int k = 0; k < 21; ++k) SH[pbs].I[k] += H.I[k];
+#pragma unroll
+              for (int k = 0; k < 6; ++k) SH[pbs].p[k] += H.p[k];
+            }
+          } else {  // a chain parent: the hand-off stays in registers
+            C = H;
           }
-          se3_comm(K.Tw, vJ, cb);
+          // back to the parent: the joint is un-composed (a copy of every branch point's kinematics would cost more registers than the file has)
+          if constexpr (jt != RBD_JOINT_FIXED) {
+            V vJ[6], cb[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) { K.av[k] -= cb[k]; K.Tw[k] -= vJ[k]; }
+            for (int k = 0; k < 6; ++k) {
+              if constexpr (nvj_of(jt) > 1) vJ[k] = vJm[k];
+              else vJ[k] = S[k] * qd;
+            }
+            se3_comm(K.Tw, vJ, cb);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { K.av[k] -= cb[k]; K.Tw[k] -= vJ[k]; }
+          }
+          if constexpr (jt_1dof(jt) || jt == RBD_JOINT_FIXED) {
+            uncompose_1dof<V, O>(qs, K.R, K.p);
+          } else {
+            T Rl[9], pl[3], Rp[9], t3[3];
+            local_transform<T, O, RS>(qs, Rl, pl);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int j = 0; j < 3; ++j) Rp[3 * i + j] = K.R[3 * i] * Rl[3 * j] + K.R[3 * i + 1] * Rl[3 * j + 1] + K.R[3 * i + 2] * Rl[3 * j + 2];  // R Rl'
+            matvec3(Rp, pl, t3);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) K.R[k] = Rp[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) K.p[k] -= t3[k];
+          }
         }
-        T Rl[9], pl[3], Rp[9], t3[3];
-        local_transform<T, O, RS>(qs, Rl, pl);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) Rp[3 * i + j] = K.R[3 * i] * Rl[3 * j] + K.R[3 * i + 1] * Rl[3 * j + 1] + K.R[3 * i + 2] * Rl[3 * j + 2];  // R Rl'
-        matvec3(Rp, pl, t3);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) K.R[k] = Rp[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) K.p[k] -= t3[k];
       }
     }
   });
 
   // ---- pass 3: down again with the accelerations ----
-  T ad[6];
-  T SR[NBS][12], SA[NBS][6];  // branch points: transform, a_delta
+  T ad1[6]; T2 ad2[6];
+  T SR1[NBS][12], SA1[NBS][6];  // branch points: transform, a_delta
+  T2 SR2[NBS][12], SA2[NBS][6];
   sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
-    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
-    constexpr int body = P::BODY[O], nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
+    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2], voff2 = P::OPW2[O][2];
+    constexpr int body = P::BODY[O], body2 = P::BODY2[O], nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
+    constexpr bool PR = P::PAIR[O] != 0, ROOT = P::PROOT[O] != 0;
+    using V = typename PairOf<T, PR>::type;
+    auto& K = [&]() -> auto& { if constexpr (PR) return K2; else return K1; }();
+    auto& ad = [&]() -> auto& { if constexpr (PR) return ad2; else return ad1; }();
+    auto& SR = [&]() -> auto& { if constexpr (PR) return SR2; else return SR1; }();
+    auto& SA = [&]() -> auto& { if constexpr (PR) return SA2; else return SA1; }();
+    auto ud_get = [&](int k) __attribute__((always_inline)) -> V { if constexpr (PR) return Ud2[P::PIDX[O]][k]; else return Ud1[body][k]; };
     if constexpr (kind == SK_ENTER) {
       if constexpr (lvl == 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? T(1) : T(0);
+        for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? V(1) : V(0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) K.p[k] = T(0);
+        for (int k = 0; k < 3; ++k) K.p[k] = V(0);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) ad[k] = T(0);
+        for (int k = 0; k < 6; ++k) ad[k] = V(0);
+      } else if constexpr (ROOT) {  // both limbs from their common parent's transform and a_delta (its slot's, or the live ones when the limbs are its first children)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K2.R[k] = widen<T2>(cidx > 0 ? SR1[pbs >= 0 ? pbs : 0][k] : K1.R[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) K2.p[k] = widen<T2>(cidx > 0 ? SR1[pbs >= 0 ? pbs : 0][9 + k] : K1.p[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ad2[k] = widen<T2>(cidx > 0 ? SA1[pbs >= 0 ? pbs : 0][k] : ad1[k]);
       } else if constexpr (cidx > 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) K.R[k] = SR[pbs][k];
@@ -767,14 +1010,23 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
         for (int k = 0; k < 6; ++k) ad[k] = SA[pbs][k];
       }
       if constexpr (nch > 0 || (jt != RBD_JOINT_FIXED && !(jt == RBD_JOINT_QUAT_FLOATING && lvl == 0))) {  // (a leaf on a fixed joint, or on a 6-dof joint on the world, has nothing left to do)
-        T Rl[9], pl[3], Rn[9], t3[3];
-        local_transform<T, O, RS>(qs, Rl, pl);
-        matmul3(K.R, Rl, Rn);
-        matvec3(K.R, pl, t3);
+        if constexpr (jt_1dof(jt) || jt == RBD_JOINT_FIXED) {
+          V Rn[9], pn[3];
+          compose_1dof<V, O>(qs, K.R, K.p, Rn, pn);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) K.p[k] += t3[k];
+          for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
+          for (int k = 0; k < 3; ++k) K.p[k] = pn[k];
+        } else {
+          T Rl[9], pl[3], Rn[9], t3[3];
+          local_transform<T, O, RS>(qs, Rl, pl);
+          matmul3(K.R, Rl, Rn);
+          matvec3(K.R, pl, t3);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) K.p[k] += t3[k];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
+        }
         if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {
           T a0b[6];
 #pragma unroll
@@ -796,7 +1048,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
             constexpr int j = jc.value;
             if constexpr (j < 3) Wf[j] = vs[(voff + j) * RS];
             else if constexpr (j == 3) Wf[j] = xs[body * RS];
-            else if constexpr (j < 8) Wf[j] = Ud[body][j - 4];
+            else if constexpr (j < 8) Wf[j] = Ud1[body][j - 4];
             else Wf[j] = x3[(xr + j - 8) * RS];
           });
 #pragma unroll
@@ -809,14 +1061,13 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
           for (int k = 0; k < 3; ++k) ts[(voff + k) * RS] = vd3[k];
         } else if constexpr (jt != RBD_JOINT_FIXED) {
-          T S[6];
-          if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = T(0); S[3] = K.R[2]; S[4] = K.R[5]; S[5] = K.R[8]; }
-          else { S[0] = K.R[2]; S[1] = K.R[5]; S[2] = K.R[8]; cross3(K.p, S, S + 3); }
-          const T W[6] = {xs[body * RS], vs[voff * RS], Ud[body][0], Ud[body][1], Ud[body][2], Ud[body][3]};
-          const T vd = ts[voff * RS] - dot6(W, ad);  // v̇ = D^-1 u - (U D^-1)' a_delta,parent
+          V S[6];
+          subspace_1dof<V, jt>(K.R, K.p, S);
+          const V W[6] = {rd2<V>(xs, body, body2), rd2<V>(vs, voff, voff2), ud_get(0), ud_get(1), ud_get(2), ud_get(3)};
+          const V vd = rd2<V>(ts, voff, voff2) - dot6(W, ad);  // v̇ = D^-1 u - (U D^-1)' a_delta,parent
 #pragma unroll
           for (int k = 0; k < 6; ++k) ad[k] += S[k] * vd;
-          ts[voff * RS] = vd;
+          wr2<V>(ts, voff, voff2, vd);
         }
         if constexpr (nch >= 2) {
 #pragma unroll

@@ -51,7 +51,26 @@ def models(rbd):
     # ... and one whose nv is a multiple of 4 (the Cholesky compiled for the mechanism's sparsity then applies): 6 + 3 + 3 + 1 + 1 + 1 + 3 + 1 + 1 = 20
     m["mixed20"] = rbd.flatten(rbd.rand_tree_mechanism(np.random.default_rng(11), ["QuaternionFloating", "QuaternionSpherical", "Planar", "Revolute", "Revolute", "Prismatic",
                                                                                      "QuaternionSpherical", "Revolute", "SinCosRevolute"]))
+    # mechanisms with LIMBS: sibling subtrees of the same shape, which the fp32 kernels compiled per mechanism walk in lockstep (rbd_spec.hpp, rbd_jit.hip:
+    # merge_limbs) — every way a limb can hang in a tree
+    R, P, F, S = "Revolute", "Prismatic", "Fixed", "SinCosRevolute"
+    chain = lambda *names: (lambda f: f(f, list(names)))(lambda f, ns: (ns[0], [f(f, ns[1:])] if len(ns) > 1 else []))
+    hand = (R, [(R, [(R, [])]), (P, []), (R, [(R, [])])])  # a branch point inside a limb (two fingers of the same shape around a thumb: pairs are not nested)
+    arm = (R, [(R, [(F, [(R, [hand])])])])
+    leg = chain(R, R, P, R, S, R)
+    # a humanoid: floating pelvis; torso chain first, the legs behind it (restored from the pelvis's slot); arms around a neck
+    m["limbs_humanoid"] = rbd.flatten(rbd.tree_mechanism(np.random.default_rng(21), [("QuaternionFloating", [(R, [(R, [arm, chain(R, R), arm])]), leg, leg])]))
+    # two limbs as the ONLY children of a chain body on a fixed base (their sum is the hand-off of a chain parent); axis-aligned constants
+    m["limbs_only_children"] = rbd.flatten(rbd.tree_mechanism(np.random.default_rng(22), [(R, [(P, [chain(R, S, R), chain(R, S, R)])])], axis_aligned=True))
+    # a quadruped (two pairs under one body, the first pair the first children) with a spherical tail and a planar attachment that stay single
+    m["limbs_quadruped"] = rbd.flatten(rbd.tree_mechanism(np.random.default_rng(23), [("QuaternionFloating", [chain(R, R, R), chain(R, R, R), chain(R, R, R), chain(R, R, R),
+                                                                                                                  ("QuaternionSpherical", [(R, [])]), ("Planar", [])])], axis_aligned=True))
+    # three limbs of one shape (a pair and a single), single-body limbs, limbs ending in fixed joints
+    m["limbs_three"] = rbd.flatten(rbd.tree_mechanism(np.random.default_rng(24), [(R, [chain(R, P, F), chain(R, P, F), chain(R, P, F), (R, []), (R, []), (P, [])])]))
     return m
+
+
+LIMBS = ["limbs_humanoid", "limbs_only_children", "limbs_quadruped", "limbs_three"]
 
 
 def tune(monkeypatch, **kv):

@@ -1,0 +1,67 @@
+"""TEST INFRASTRUCTURE ONLY — host emulation of the kernels compiled per mechanism (csrc/rbd_spec.hpp through rbd_jit_source): the generated program is compiled
+as plain C++ against tests/emu/spec_shim/hip/hip_runtime.h and run one lane at a time (tests/emu/spec_emu_main.inc).  What it checks is the ARITHMETIC of the
+straight-line code hiprtc will compile — the plan tables, the limbs walked in lockstep, the folded constants — against the oracle, on the CPU."""
+import ctypes
+import hashlib
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def available():
+    return os.path.exists(CLANG)
+
+
+def build(source: str, which: str) -> ctypes.CDLL:
+    """which: ABA | RNEA_F32 | RNEA_F64 — the entry point to keep (the program holds one kernel family)."""
+    main = open(os.path.join(ROOT, "tests", "emu", "spec_emu_main.inc")).read()
+    # __shared__ arrays inside extern "C" kernels become function statics; the kernels' own `extern __shared__` (mass matrix) is not emulated
+    text = "#define RBD_EMU_%s 1\n#include <hip/hip_runtime.h>\n" % which + source + "\n" + main
+    key = hashlib.sha256((text + open(os.path.join(ROOT, "rigidbodydynamics.jl_amd", "csrc", "rbd_spec.hpp")).read()
+                          + open(os.path.join(ROOT, "rigidbodydynamics.jl_amd", "csrc", "rbd_device.hpp")).read()).encode()).hexdigest()[:16]
+    d = os.path.join(tempfile.gettempdir(), "rbd_spec_emu")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, "emu_%s.so" % key)
+    if not os.path.exists(so):
+        src = os.path.join(d, "emu_%s.cpp" % key)
+        open(src, "w").write(text)
+        cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=fast", "-march=native", "-DRBD_JIT_COMPILE", "-Wno-everything",
+               "-I", os.path.join(ROOT, "tests", "emu", "spec_shim"), "-I", os.path.join(ROOT, "rigidbodydynamics.jl_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+               src, "-o", so + ".tmp"]
+        subprocess.check_call(cmd)
+        os.replace(so + ".tmp", so)
+    return ctypes.CDLL(so)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def aba_f32(lib, model, q, v, tau, fext=None, want_qdot=False):
+    """q (B, nq), v (B, nv), tau (B, nv) -> v̇ (B, nv) [, q̇ (B, nq)] through aba_spec_f32 on the host."""
+    B = q.shape[0]
+    qs = np.ascontiguousarray(q.T, dtype=np.float32); vs = np.ascontiguousarray(v.T, dtype=np.float32); ts = np.ascontiguousarray(tau.T, dtype=np.float32)
+    fs = np.ascontiguousarray(fext.T, dtype=np.float32) if fext is not None else None
+    vd = np.full((model.nv, B), np.nan, dtype=np.float32)
+    qd = np.full((model.nq, B), np.nan, dtype=np.float32) if want_qdot else None
+    g = np.asarray(model.gravity, dtype=np.float64)
+    lib.emu_aba_f32(ctypes.c_long(B), _p(qs), _p(vs), _p(ts), _p(fs), _p(vd), _p(qd), _p(g))
+    return (vd.T.copy(), qd.T.copy()) if want_qdot else vd.T.copy()
+
+
+def rnea(lib, model, q, v, vdot, fext=None, dtype=np.float32, want_bodies=False):
+    B = q.shape[0]
+    qs = np.ascontiguousarray(q.T, dtype=dtype); vs = np.ascontiguousarray(v.T, dtype=dtype)
+    ws = np.ascontiguousarray(vdot.T, dtype=dtype) if vdot is not None else None
+    fs = np.ascontiguousarray(fext.T, dtype=dtype) if fext is not None else None
+    tau = np.full((model.nv, B), np.nan, dtype=dtype)
+    acc = np.full((6 * model.n_bodies, B), np.nan, dtype=dtype) if want_bodies else None
+    jw = np.full((6 * model.n_bodies, B), np.nan, dtype=dtype) if want_bodies else None
+    f = lib.emu_rnea_f32 if dtype == np.float32 else lib.emu_rnea_f64
+    f(ctypes.c_long(B), _p(qs), _p(vs), _p(ws), _p(fs), _p(tau), _p(acc), _p(jw))
+    return (tau.T.copy(), acc.T.copy(), jw.T.copy()) if want_bodies else tau.T.copy()

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import tune
+from conftest import LIMBS, tune
 from test_gpu_parity import NT, TD, dev, host, make
 
 pytestmark = pytest.mark.gpu
@@ -213,7 +213,7 @@ def backward_error(oracle, model, q, v, tau, fe, vd):
 
 
 @pytest.mark.parametrize("layout", ["aos", "soa"])
-@pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE)
+@pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE + LIMBS)
 def test_compiled_aba_f32(rbd, oracle, models, name, layout):
     """`dynamics!` through the kernel compiled for the mechanism, forced (RBD_ALGO_ABA_COMPILED): a ragged batch (three wavefronts, the last partly
     filled), torques + a wrench on every body + q̇; then no torques and no wrenches; against the oracle (backward error, the q̇ map exactly to fp32)
