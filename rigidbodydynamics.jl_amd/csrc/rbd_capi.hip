@@ -121,7 +121,8 @@ struct rbd_ws {
   void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; void* d_rows = nullptr; size_t d_rows_bytes = 0, d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
-  bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
+  bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_aba_nofext = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
+  int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
   bool spec_bank_tried = false; hipModule_t spec_bank_mod = nullptr; hipFunction_t spec_bank_aba = nullptr, spec_bank_fused = nullptr, spec_bank_rnea = nullptr; std::string spec_bank_src;  // the banked kernels compiled for the mechanism
   std::string spec_src[SPEC_FAMILIES], spec_loop_src, spec_walk_src[8];  // the programs' sources while their compilation is pending (generated once)
@@ -1401,7 +1402,7 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   const bool bodies = dacc || djw, rows_out = Lf.sb == 1;
   if (!dqd && (mapping == RBD_ALGO_ABA_COMPILED || (mapping == RBD_ALGO_ABA && !(bodies && w->dtype == RBD_F64 && !rows_out)))) {
     if (mapping == RBD_ALGO_ABA_COMPILED || B >= w->spec_rnea_min_batch) spec_load(w, SPEC_RNEA, mapping == RBD_ALGO_ABA_COMPILED);
-    if (w->spec_rnea && (mapping == RBD_ALGO_ABA_COMPILED || B >= w->spec_rnea_min_batch)) {
+    if (w->spec_rnea && (mapping == RBD_ALGO_ABA_COMPILED || (B >= w->spec_rnea_min_batch && w->spec_rnea_scratch == 0))) {
       long Bl = B;
       const long ld = (long)B + 64;  // scratch rows 256 bytes past a power of two apart
       const size_t es = w->dtype == RBD_F64 ? 8 : 4, each = es * 6 * (size_t)m->nb * (size_t)ld;
@@ -1491,14 +1492,19 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     // 209 against 226 us, 32 768: 220 against 240; 16 384: 201 against 143) — the stage costs this kernel 10 us per launch, the walk kernel 28
     const long spec_from = mk ? std::min<long>(w->spec_aba_min_batch, w->spec_aba_fused_min_batch) : w->spec_aba_min_batch;
     if (algorithm == RBD_ALGO_ABA_COMPILED || B >= spec_from) spec_load(w, SPEC_ABA, algorithm == RBD_ALGO_ABA_COMPILED);
-    if (w->spec_aba && (algorithm == RBD_ALGO_ABA_COMPILED || B >= spec_from)) {
+    // without external wrenches: the instantiation that holds no registers for them.  Left to itself (RBD_ALGO_ABA) the library takes a compiled kernel only
+    // when it spilled nothing
+    const bool nofext = df == nullptr && w->spec_aba_nofext != nullptr;
+    hipFunction_t const faba = nofext ? w->spec_aba_nofext : w->spec_aba;
+    const int faba_scratch = nofext ? w->spec_aba_nofext_scratch : w->spec_aba_scratch;
+    if (faba && (algorithm == RBD_ALGO_ABA_COMPILED || (B >= spec_from && faba_scratch == 0))) {
       Timed t(w);
       long Bl = B;
       const double* gv = gravity ? gravity : m->gravity;
       float gx = (float)gv[0], gy = (float)gv[1], gz = (float)gv[2];
       MkStage F = mk ? *mk : kNoStage;
       void* args[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf, &gx, &gy, &gz, &F};
-      HIP_TRY(hipModuleLaunchKernel(w->spec_aba, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
+      HIP_TRY(hipModuleLaunchKernel(faba, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
       w->last_kernel = "aba_spec_f32 (compiled for the mechanism at run time)";
       return RBD_OK;
     }
@@ -1590,10 +1596,11 @@ static void spec_load(rbd_ws* w, int family, bool force) {
   if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { (void)hipGetLastError(); mod = nullptr; jit_cache_discard(src); return; }
   auto get = [&](hipFunction_t* f, const char* name) { if (hipModuleGetFunction(f, mod, name) != hipSuccess) { (void)hipGetLastError(); *f = nullptr; } };
   // a kernel whose registers spilled beyond a few values is slower than the kernels that interpret the mechanism: it steps aside
-  auto fits = [&](hipFunction_t* f) {
+  auto fits = [&](hipFunction_t* f, int* bytes = nullptr) {
     int scratch = 0;
     const int max_scratch = w->spec_max_scratch;  // bytes per lane
     if (*f && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, *f) != hipSuccess || scratch > max_scratch)) { (void)hipGetLastError(); *f = nullptr; }
+    if (bytes) *bytes = scratch;
   };
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, w->device);
@@ -1609,10 +1616,12 @@ static void spec_load(rbd_ws* w, int family, bool force) {
     }
   } else if (family == SPEC_ABA) {
     get(&w->spec_aba, "aba_spec_f32");
-    fits(&w->spec_aba);
+    fits(&w->spec_aba, &w->spec_aba_scratch);
+    get(&w->spec_aba_nofext, "aba_spec_nofext_f32");  // the instantiation for calls without external wrenches (rbd_spec.hpp: FEXT)
+    fits(&w->spec_aba_nofext, &w->spec_aba_nofext_scratch);
   } else if (family == SPEC_RNEA) {
     get(&w->spec_rnea, w->dtype == RBD_F64 ? "rnea_spec_f64" : "rnea_spec_f32");
-    fits(&w->spec_rnea);
+    fits(&w->spec_rnea, &w->spec_rnea_scratch);
   }
 }
 static bool spec_crba_fits(const rbd_ws* w) { return (size_t)w->model->nq * 4 * 65 * esize(w) <= 160u * 1024u; }  // four wavefronts' staged q (rows of 65) in one CU's LDS

@@ -221,158 +221,6 @@ template <typename T, int n> RBD_DEV void rows_out(const T* rows, T* __restrict_
   }
 }
 
-// mass_matrix! (src/mechanism_algorithms.jl:248-272) of rbd_plan's mechanism, one lane per state.  Mout: any Layout (the caller's SOA
-// buffer, or the staging buffer grouped by 16 states the tile Cholesky reads); zero_fill: also write the structural zeros of the lower triangle.
-// PERMUTED (the staging buffer of chol_spec below): entry (row, col) goes to (max, min) of (PERM[row], PERM[col]).
-template <typename T, bool PERMUTED = false>
-RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, Layout Lq, Layout Lm, int zero_fill, T* lds) {
-  constexpr int ML = P::NLEVELS, NQ = P::NQ, NV = P::NV;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
-  if (state0 >= B) return;  // (no workgroup barrier below: the wavefronts of a block share nothing but the launch)
-  const long state_raw = state0 + lane;
-  const bool live = state_raw < B;
-  const long state = live ? state_raw : B - 1;
-  T* qrows = lds + (size_t)wave * NQ * RS;
-  rows_in<T, NQ>(q, Lq, state0, B, qrows);  // (a state-major q arrives in whole runs, not in 64 pieces of one value per load)
-  const T* qs = qrows + lane;
-  // byte offset of this lane's column; an entry adds a wave-uniform (row, col) term.  32-bit offsets (the host keeps buffers of 4 GB and more
-  // away from this kernel): one scalar multiply and one vector add per store, scalar base address
-  const unsigned lane_off = (unsigned)(layout_base(Lm, state) * (long)sizeof(T));
-  const unsigned mskb = (unsigned)(Lm.sk * (long)sizeof(T));
-  auto put = [&](int row, int col, T x) __attribute__((always_inline)) {
-#ifdef RBD_SPEC_EMIT
-    if constexpr (PERMUTED) {
-      const int pr = P::PERM[row], pc = P::PERM[col];
-      row = pr > pc ? pr : pc;
-      col = pr > pc ? pc : pr;
-    }
-#endif
-    if (live) *reinterpret_cast<T*>(reinterpret_cast<char*>(Mout) + (unsigned long)(lane_off + (unsigned)(col * NV + row) * mskb)) = x;
-  };
-  if (zero_fill) {
-    sfor<NV>([&](auto rc) __attribute__((always_inline)) {
-      constexpr int row = rc.value;
-      sfor<row + 1>([&](auto cc) __attribute__((always_inline)) {
-        constexpr int col = cc.value;
-        if constexpr (!((P::ROWMASK[row] >> col) & 1ull)) put(row, col, T(0));
-      });
-    });
-  }
-  wave_sync();  // the staged rows are this wavefront's own
-  T X[ML][12];   // path: transforms to root (R row-major, p)
-  T IC[ML][10];  // path: inertias being accumulated (J 6, c 3, m)
-  T S[ML][6];    // path: motion subspace columns (1-dof joints)
-  sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
-    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
-    if constexpr (kind == SK_ENTER) {
-      T Rl[9], pl[3];
-      local_transform<T, O, RS>(qs, Rl, pl);
-      T* R = X[lvl];
-      T* p = X[lvl] + 9;
-      if constexpr (lvl == 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = Rl[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = pl[k];
-      } else {
-        T t[3];
-        matmul3(X[lvl - 1], Rl, R);
-        matvec3(X[lvl - 1], pl, t);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = X[lvl - 1][9 + k] + t[k];
-      }
-      if constexpr (jt == RBD_JOINT_PRISMATIC) {
-        S[lvl][0] = S[lvl][1] = S[lvl][2] = T(0); S[lvl][3] = R[2]; S[lvl][4] = R[5]; S[lvl][5] = R[8];
-      } else if constexpr (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_SINCOS_REVOLUTE) {
-        const T z[3] = {R[2], R[5], R[8]};
-        S[lvl][0] = z[0]; S[lvl][1] = z[1]; S[lvl][2] = z[2];
-        cross3(p, z, S[lvl] + 3);
-      }
-      T Jb[6], mc[3];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) Jb[k] = T(P::TR[O][TR_J + k]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) mc[k] = T(P::TR[O][TR_MC + k]);
-      RInertia<T> Ib;
-      inertia_to_root(Jb, mc, T(P::TR[O][TR_M]), R, p, Ib);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) IC[lvl][k] = Ib.J[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) IC[lvl][6 + k] = Ib.c[k];
-      IC[lvl][9] = Ib.m;
-    } else {
-      RInertia<T> Ic;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) Ic.J[k] = IC[lvl][k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) Ic.c[k] = IC[lvl][6 + k];
-      Ic.m = IC[lvl][9];
-      if constexpr (lvl > 0) {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) IC[lvl - 1][k] += IC[lvl][k];
-      }
-      // this body's columns against an ancestor's: one entry for a 1-dof joint, the joint's components of X_anc^-T F for one with several
-      auto ancestors = [&](auto rowc, const T* F) __attribute__((always_inline)) {
-        constexpr int row = rowc.value;
-        sfor<lvl>([&](auto kc) __attribute__((always_inline)) {
-          constexpr int k = kc.value, col = P::COLS[O][k];
-          if constexpr (col >= 0) {
-            if constexpr ((col & SC_MULTI) != 0) {
-              constexpr int ajt = jt_of_col(col);
-              T o6[6];
-              xforce_inv(X[k], X[k] + 9, F, o6);
-#pragma unroll
-              for (int cj = 0; cj < nvj_of(ajt); ++cj) put(row, (col & ~SC_MULTI) + cj, o6[comp_of(ajt, cj)]);
-            } else {
-              put(row, col, dot6(F, S[k]));
-            }
-          }
-        });
-      };
-      if constexpr (nvj_of(jt) > 1) {  // the n x n block S' Ic S with S = X(H) E, then the ancestors, column by column
-        sfor<nvj_of(jt)>([&](auto cic) __attribute__((always_inline)) {
-          constexpr int ci = cic.value;
-          T e[6], Si[6], Fc[6], o6[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) e[k] = (k == comp_of(jt, ci)) ? T(1) : T(0);
-          xmotion(X[lvl], X[lvl] + 9, e, Si);
-          mul_inertia(Ic, Si, Fc);
-          xforce_inv(X[lvl], X[lvl] + 9, Fc, o6);
-#pragma unroll
-          for (int cj = 0; cj <= ci; ++cj) put(voff + ci, voff + cj, o6[comp_of(jt, cj)]);
-          ancestors(Ix<voff + ci>{}, Fc);
-        });
-      } else if constexpr (jt != RBD_JOINT_FIXED) {
-        T F[6];
-        mul_inertia(Ic, S[lvl], F);
-        put(voff, voff, dot6(F, S[lvl]));
-        ancestors(Ix<voff>{}, F);
-      }
-    }
-  });
-}
-
-
-
-#ifdef RBD_SPEC_ABA
-// ---------------------------------------------------------------------------------------------------------------------------------
-// dynamics! (the articulated-body algorithm, src/mechanism_algorithms.jl:845-864 through the world-frame recursion of the other ABA kernels),
-// one lane per state, compiled for rbd_plan's mechanism.  The depth-first walk is straight-line code, so everything the walk kernel
-// (rbd_walk.hpp) keeps in LDS rows, mailboxes and switch-addressed accumulation registers is here a plain local the allocator places:
-//   * ONE kinematic state (transform to root, twist, velocity-product acceleration a_vp with the world's -g folded in) walks down the tree
-//     and back up: leaving a body towards its parent the joint is UN-COMPOSED (H_parent = H X_joint^-1, T_parent = T - S q', a_parent =
-//     a - [T, S q']) — the walk kernel's device — so that no body's kinematics are kept, not even a branch point's;
-//   * bottom-up, a chain body takes the hand-off (Ia = IA - U D^-1 U', pa = pA + U D^-1 u; the bias acceleration is folded into pA = I a_vp +
-//     T x* I T - w_ext, so there is no Ia c term) straight from the registers its child left it in; a branch point sums its children's in its slot;
-//   * what a body leaves behind for the top-down pass is U D^-1 (6) and D^-1 u (1): three in LDS rows the walk has no more use for, four in
-//     registers named by the body; that pass composes the
-//     transforms again (S is read off the body's transform), starting later children of a branch point from its saved (transform, a_delta).
-// Extra plan tables: BODY[NOPS] (depth-first ordinal of the op's body), NCH[NOPS] (its children), BS[NOPS] (its branch slot, or -1), PBS[NOPS]
-// (its parent's branch slot, or -1), CIDX[NOPS] (its rank among its siblings), NBS (slots), NEXT_EXIT[NOPS] (the next EXIT op after this one, or -1).
-// q, v, tau of the wavefront's 64 states are staged through LDS rows (stride 65: conflict-free both ways); v̇ and q̇ leave the same way, q̇ first.
-// ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB) + 10 * P::N3;  // q, v, tau, spare, ten of the 18 values of U D^-1 of every 3-dof joint
 
 template <typename T> struct Kin { T R[9], p[3], Tw[6], av[6]; };
 template <typename T> struct Hand { T I[21], p[6]; };
@@ -390,6 +238,15 @@ template <> struct PairOf<float, true> { using type = f2; };
 template <typename V, typename T> RBD_DEV V widen(T x) {  // both limbs start from their common parent's value
   if constexpr (NLanes<V>::N == 2) return V{x, x}; else return x;
 }
+template <typename V, typename T> RBD_DEV V mk2(T a, T b) {  // (first body, partner)
+  if constexpr (NLanes<V>::N == 2) return V{a, b}; else return a;
+}
+// a value of either kind as V (a pair seen as one body: its first — only where a branch that is never taken must still compile)
+template <typename V, typename U> RBD_DEV V conv(U x) {
+  if constexpr (NLanes<V>::N == NLanes<U>::N) return x;
+  else if constexpr (NLanes<V>::N == 2) return V{x, x};
+  else return x.x;
+}
 RBD_DEV float hsum(f2 x) { return x.x + x.y; }  // what the two limbs hand their common parent
 RBD_DEV float hsum(float x) { return x; }
 RBD_DEV double hsum(double x) { return x; }
@@ -402,28 +259,10 @@ template <typename V, typename S> RBD_DEV void wr2(S* col, int ra, int rb, V x) 
 }
 // constant K of op O's body record (canonical frames: TR_*), and what kind of number it is: 0, 1, -1 or any other (2).  A pair's constant is the pair of the
 // two bodies' constants.
-#ifdef RBD_SPEC_TRP
-// the table's address as ONE opaque scalar pair: every read is then an s_load with an immediate offset (left to itself the compiler forms the pc-relative
-// address afresh — three scalar instructions — at every use)
-typedef const float __attribute__((address_space(4)))* TrpPtr;
-RBD_DEV TrpPtr trp_base() {
-  TrpPtr p = (TrpPtr)(&P::TRP[0][0]);
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm("" : "+s"(p));
-#endif
-  return p;
-}
-#endif
 template <typename V, int O, int K> RBD_DEV V cst() {
-  if constexpr (NLanes<V>::N == 2) {
-    constexpr float a = (float)P::TR[O][K], b = (float)P::TR2[O][K];
-#ifdef RBD_SPEC_TRP
-    // from the plan's table of pairs through the scalar unit (what folds — 0, 1, -1 — never gets here: cterm)
-    return V{trp_base()[O * 48 + 2 * K], trp_base()[O * 48 + 2 * K + 1]};
-#else
-    return V{a, b};
-#endif
-  } else return V(P::TR[O][K]);
+  // (a pair of literals reaches a packed instruction through a scalar register pair: two s_mov.  The plan's constants as a table in the constant address space,
+  // read with s_load several pairs at a time, measured 1 us SLOWER on Atlas: the loads' latency is exposed to a lone wavefront.)
+  if constexpr (NLanes<V>::N == 2) return V{(float)P::TR[O][K], (float)P::TR2[O][K]}; else return V(P::TR[O][K]);
 }
 template <typename V, int O, int K> constexpr int ccls() {
   constexpr double a = P::TR[O][K], b = NLanes<V>::N == 2 ? P::TR2[O][K] : P::TR[O][K];
@@ -446,16 +285,24 @@ template <typename V, int O, int K0, int K1, int K2> RBD_DEV V lin3(V x0, V x1, 
 }
 template <typename V, int O, int K0, int K1, int K2> constexpr bool lin3_zero() { return ccls<V, O, K0>() == 0 && ccls<V, O, K1>() == 0 && ccls<V, O, K2>() == 0; }
 
-// sin, cos of op O's joint angle(s) — a revolute joint's coordinate, or the two coordinates of a sin-cos joint
-template <typename V, int O, typename S> RBD_DEV void joint_sincos(const S* qs, V& s, V& c) {
+// the coordinates of op O's 1-dof joint as values: c0 = the angle / the displacement / the sine of a sin-cos joint, c1 = its cosine
+template <typename V> struct JointQ { V c0, c1; };
+template <typename V, int O, typename S> RBD_DEV JointQ<V> joint_q(const S* qs) {
   constexpr int jt = P::OPW[O][0] >> 16, qa = P::OPW[O][1], qb = P::OPW2[O][1];
-  if constexpr (jt == RBD_JOINT_REVOLUTE) sincos_fast(rd2<V>(qs, qa, qb), &s, &c);
-  else { s = rd2<V>(qs, qa, qb); c = rd2<V>(qs, qa + 1, qb + 1); }
+  JointQ<V> J;
+  J.c0 = J.c1 = V(0.0f);
+  if constexpr (jt != RBD_JOINT_FIXED) J.c0 = rd2<V>(qs, qa, qb);
+  if constexpr (jt == RBD_JOINT_SINCOS_REVOLUTE) J.c1 = rd2<V>(qs, qa + 1, qb + 1);
+  return J;
+}
+template <typename V, int jt> RBD_DEV void joint_sincos(const JointQ<V>& J, V& s, V& c) {
+  if constexpr (jt == RBD_JOINT_REVOLUTE) sincos_fast(J.c0, &s, &c);
+  else { s = J.c0; c = J.c1; }
 }
 // (Rn, pn) = (R, p) o joint_to_predecessor o joint_transform(q) for a 1-dof or fixed joint in canonical frames (joint axis +z), in the order that lets the
 // constants fold: A = R C, then A Rz(q) (twelve multiplications) — C q-independent, in most mechanisms a signed permutation
-template <typename V, int O, typename S> RBD_DEV void compose_1dof(const S* qs, const V* R, const V* p, V* Rn, V* pn) {
-  constexpr int jt = P::OPW[O][0] >> 16, qa = P::OPW[O][1], qb = P::OPW2[O][1];
+template <typename V, int O> RBD_DEV void compose_1dof(const JointQ<V>& J, const V* R, const V* p, V* Rn, V* pn) {
+  constexpr int jt = P::OPW[O][0] >> 16;
   V A[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -466,7 +313,7 @@ template <typename V, int O, typename S> RBD_DEV void compose_1dof(const S* qs, 
   }
   if constexpr (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_SINCOS_REVOLUTE) {
     V s, c;
-    joint_sincos<V, O>(qs, s, c);
+    joint_sincos<V, jt>(J, s, c);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       Rn[3 * i] = c * A[3 * i] + s * A[3 * i + 1];
@@ -477,19 +324,18 @@ template <typename V, int O, typename S> RBD_DEV void compose_1dof(const S* qs, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rn[k] = A[k];
     if constexpr (jt == RBD_JOINT_PRISMATIC) {
-      const V d = rd2<V>(qs, qa, qb);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) pn[i] += d * A[3 * i + 2];
+      for (int i = 0; i < 3; ++i) pn[i] += J.c0 * A[3 * i + 2];
     }
   }
 }
 // the inverse: from the body's (R, p) back to its parent's.  Rp = R Rl' = (R Rz') C', pp = p - Rp pl
-template <typename V, int O, typename S> RBD_DEV void uncompose_1dof(const S* qs, V* R, V* p) {
-  constexpr int jt = P::OPW[O][0] >> 16, qa = P::OPW[O][1], qb = P::OPW2[O][1];
+template <typename V, int O> RBD_DEV void uncompose_1dof(const JointQ<V>& J, V* R, V* p) {
+  constexpr int jt = P::OPW[O][0] >> 16;
   V Bm[9], Rp[9];
   if constexpr (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_SINCOS_REVOLUTE) {
     V s, c;
-    joint_sincos<V, O>(qs, s, c);
+    joint_sincos<V, jt>(J, s, c);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       Bm[3 * i] = c * R[3 * i] - s * R[3 * i + 1];
@@ -507,9 +353,8 @@ template <typename V, int O, typename S> RBD_DEV void uncompose_1dof(const S* qs
     Rp[3 * i + 2] = lin3<V, O, TR_C + 6, TR_C + 7, TR_C + 8>(Bm[3 * i], Bm[3 * i + 1], Bm[3 * i + 2]);
   }
   if constexpr (jt == RBD_JOINT_PRISMATIC) {  // pl = pp + d C[:, 2]:  Rp pl = Rp pp + d Bm[:, 2]  (Rp C[:, 2] = Bm C' C e_z = Bm[:, 2])
-    const V d = rd2<V>(qs, qa, qb);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) p[i] -= d * Bm[3 * i + 2];
+    for (int i = 0; i < 3; ++i) p[i] -= J.c0 * Bm[3 * i + 2];
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -560,9 +405,202 @@ template <typename V, int jt> RBD_DEV void subspace_1dof(const V* R, const V* p,
   if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = V(0.0f); S[3] = R[2]; S[4] = R[5]; S[5] = R[8]; }
   else { S[0] = R[2]; S[1] = R[5]; S[2] = R[8]; cross3(p, S, S + 3); }
 }
+constexpr int next_enter(int o) {  // the first ENTER op after op o, or -1
+  for (int k = o + 1; k < P::NOPS; ++k)
+    if ((P::OPW[k][0] & 0xff) == SK_ENTER) return k;
+  return -1;
+}
 constexpr bool jt_1dof(int jt) { return jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_PRISMATIC || jt == RBD_JOINT_SINCOS_REVOLUTE; }
 
-template <typename T>
+
+// mass_matrix! (src/mechanism_algorithms.jl:248-272) of rbd_plan's mechanism, one lane per state.  Mout: any Layout (the caller's SOA
+// buffer, or the staging buffer grouped by 16 states the tile Cholesky reads); zero_fill: also write the structural zeros of the lower triangle.
+// PERMUTED (the staging buffer of chol_spec below): entry (row, col) goes to (max, min) of (PERM[row], PERM[col]).
+template <typename T, bool PERMUTED = false>
+RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, Layout Lq, Layout Lm, int zero_fill, T* lds) {
+  constexpr int ML = P::NLEVELS, NQ = P::NQ, NV = P::NV;
+  using T2 = typename PairOf<T, true>::type;  // limbs in lockstep (fp32): the value type of an op that stands for two bodies
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
+  if (state0 >= B) return;  // (no workgroup barrier below: the wavefronts of a block share nothing but the launch)
+  const long state_raw = state0 + lane;
+  const bool live = state_raw < B;
+  const long state = live ? state_raw : B - 1;
+  T* qrows = lds + (size_t)wave * NQ * RS;
+  rows_in<T, NQ>(q, Lq, state0, B, qrows);  // (a state-major q arrives in whole runs, not in 64 pieces of one value per load)
+  const T* qs = qrows + lane;
+  // byte offset of this lane's column; an entry adds a wave-uniform (row, col) term.  32-bit offsets (the host keeps buffers of 4 GB and more
+  // away from this kernel): one scalar multiply and one vector add per store, scalar base address
+  const unsigned lane_off = (unsigned)(layout_base(Lm, state) * (long)sizeof(T));
+  const unsigned mskb = (unsigned)(Lm.sk * (long)sizeof(T));
+  auto put = [&](int row, int col, T x) __attribute__((always_inline)) {
+#ifdef RBD_SPEC_EMIT
+    if constexpr (PERMUTED) {
+      const int pr = P::PERM[row], pc = P::PERM[col];
+      row = pr > pc ? pr : pc;
+      col = pr > pc ? pc : pr;
+    }
+#endif
+    if (live) *reinterpret_cast<T*>(reinterpret_cast<char*>(Mout) + (unsigned long)(lane_off + (unsigned)(col * NV + row) * mskb)) = x;
+  };
+  if (zero_fill) {
+    sfor<NV>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int row = rc.value;
+      sfor<row + 1>([&](auto cc) __attribute__((always_inline)) {
+        constexpr int col = cc.value;
+        if constexpr (!((P::ROWMASK[row] >> col) & 1ull)) put(row, col, T(0));
+      });
+    });
+  }
+  wave_sync();  // the staged rows are this wavefront's own
+  // the path from the root to the body the walk is at, level by level: transforms to root (R row-major, p), inertias being accumulated (J 6, c 3, m), motion
+  // subspace columns (1-dof joints) — once for the levels whose op stands for one body, once (f2: packed arithmetic, aba_spec above) for those inside a pair of limbs
+  T X1[ML][12], IC1[ML][10], S1[ML][6];
+  T2 X2[ML][12], IC2[ML][10], S2[ML][6];
+  sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
+    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2], voff2 = P::OPW2[O][2];
+    constexpr bool PR = P::PAIR[O] != 0, ROOT = P::PROOT[O] != 0;
+    using V = typename PairOf<T, PR>::type;
+    auto& X = [&]() -> auto& { if constexpr (PR) return X2; else return X1; }();
+    auto& IC = [&]() -> auto& { if constexpr (PR) return IC2; else return IC1; }();
+    auto& S = [&]() -> auto& { if constexpr (PR) return S2; else return S1; }();
+    // entry (this op's coordinate, column col) — for a pair the partner's entry (its coordinate, its column col2) rides in the high half
+    auto put2 = [&](int row, int row2, int col, int col2, V x) __attribute__((always_inline)) {
+      if constexpr (PR) { put(row, col, x.x); put(row2, col2, x.y); } else put(row, col, x);
+    };
+    if constexpr (kind == SK_ENTER) {
+      V* R = X[lvl];
+      V* p = X[lvl] + 9;
+      if constexpr (jt_1dof(jt) || jt == RBD_JOINT_FIXED) {
+        V Rp[9], pp[3];  // the parent's transform: the level above (in both halves when the limbs start here), or the world's
+        if constexpr (lvl == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rp[k] = (k % 4 == 0) ? V(1) : V(0);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pp[k] = V(0);
+        } else if constexpr (ROOT) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rp[k] = widen<V>(X1[lvl - 1][k]);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pp[k] = widen<V>(X1[lvl - 1][9 + k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rp[k] = X[lvl - 1][k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pp[k] = X[lvl - 1][9 + k];
+        }
+        compose_1dof<V, O>(joint_q<V, O>(qs), Rp, pp, R, p);
+      } else {
+        T Rl[9], pl[3];
+        local_transform<T, O, RS>(qs, Rl, pl);
+        if constexpr (lvl == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) R[k] = Rl[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) p[k] = pl[k];
+        } else {
+          T t[3];
+          matmul3(X[lvl - 1], Rl, R);
+          matvec3(X[lvl - 1], pl, t);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) p[k] = X[lvl - 1][9 + k] + t[k];
+        }
+      }
+      if constexpr (jt_1dof(jt)) subspace_1dof<V, jt>(R, p, S[lvl]);
+      RInertia<V> Ib;
+      inertia_to_root_c<V, O>(R, p, Ib);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) IC[lvl][k] = Ib.J[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) IC[lvl][6 + k] = Ib.c[k];
+      IC[lvl][9] = Ib.m;
+    } else {
+      RInertia<V> Ic;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Ic.J[k] = IC[lvl][k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ic.c[k] = IC[lvl][6 + k];
+      Ic.m = IC[lvl][9];
+      if constexpr (lvl > 0) {
+        if constexpr (ROOT) {  // the two limbs' composite inertias reach their common parent as their sum
+#pragma unroll
+          for (int k = 0; k < 10; ++k) IC1[lvl - 1][k] += hsum(IC[lvl][k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 10; ++k) IC[lvl - 1][k] += IC[lvl][k];
+        }
+      }
+      // this body's columns against an ancestor's: one entry for a 1-dof joint, the joint's components of X_anc^-T F for one with several.  For a pair: the
+      // ancestors inside the limbs are pairs themselves (their own columns each), those above the limbs are common to both
+      auto ancestors = [&](auto rowc, auto row2c, const V* F) __attribute__((always_inline)) {
+        constexpr int row = rowc.value, row2 = row2c.value;
+        sfor<lvl>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = kc.value, col = P::COLS[O][k], col2 = PR ? P::COLS2[O][k] : col;
+          constexpr bool inside = PR && col2 != col;  // (an ancestor of both limbs has ONE column)
+          if constexpr (col >= 0) {
+            if constexpr ((col & SC_MULTI) != 0) {  // (never inside a limb: limbs hold 1-dof and fixed joints only)
+              constexpr int ajt = jt_of_col(col);
+              V Xa[12], o6[6];
+#pragma unroll
+              for (int i = 0; i < 12; ++i) Xa[i] = widen<V>(X1[k][i]);
+              xforce_inv(Xa, Xa + 9, F, o6);
+#pragma unroll
+              for (int cj = 0; cj < nvj_of(ajt); ++cj) put2(row, row2, (col & ~SC_MULTI) + cj, (col & ~SC_MULTI) + cj, o6[comp_of(ajt, cj)]);
+            } else {
+              V Sa[6];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) {
+                if constexpr (inside) Sa[i] = conv<V>(S2[k][i]); else Sa[i] = conv<V>(S1[k][i]);
+              }
+              put2(row, row2, col, inside ? col2 : col, dot6(F, Sa));
+            }
+          }
+        });
+      };
+      if constexpr (nvj_of(jt) > 1) {  // the n x n block S' Ic S with S = X(H) E, then the ancestors, column by column
+        sfor<nvj_of(jt)>([&](auto cic) __attribute__((always_inline)) {
+          constexpr int ci = cic.value;
+          T e[6], Si[6], Fc[6], o6[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) e[k] = (k == comp_of(jt, ci)) ? T(1) : T(0);
+          xmotion(X[lvl], X[lvl] + 9, e, Si);
+          mul_inertia(Ic, Si, Fc);
+          xforce_inv(X[lvl], X[lvl] + 9, Fc, o6);
+#pragma unroll
+          for (int cj = 0; cj <= ci; ++cj) put(voff + ci, voff + cj, o6[comp_of(jt, cj)]);
+          ancestors(Ix<voff + ci>{}, Ix<voff + ci>{}, Fc);
+        });
+      } else if constexpr (jt != RBD_JOINT_FIXED) {
+        V F[6];
+        mul_inertia(Ic, S[lvl], F);
+        put2(voff, voff2, voff, voff2, dot6(F, S[lvl]));
+        ancestors(Ix<voff>{}, Ix<voff2>{}, F);
+      }
+    }
+  });
+}
+
+
+#ifdef RBD_SPEC_ABA
+// ---------------------------------------------------------------------------------------------------------------------------------
+// dynamics! (the articulated-body algorithm, src/mechanism_algorithms.jl:845-864 through the world-frame recursion of the other ABA kernels),
+// one lane per state, compiled for rbd_plan's mechanism.  The depth-first walk is straight-line code, so everything the walk kernel
+// (rbd_walk.hpp) keeps in LDS rows, mailboxes and switch-addressed accumulation registers is here a plain local the allocator places:
+//   * ONE kinematic state (transform to root, twist, velocity-product acceleration a_vp with the world's -g folded in) walks down the tree
+//     and back up: leaving a body towards its parent the joint is UN-COMPOSED (H_parent = H X_joint^-1, T_parent = T - S q', a_parent =
+//     a - [T, S q']) — the walk kernel's device — so that no body's kinematics are kept, not even a branch point's;
+//   * bottom-up, a chain body takes the hand-off (Ia = IA - U D^-1 U', pa = pA + U D^-1 u; the bias acceleration is folded into pA = I a_vp +
+//     T x* I T - w_ext, so there is no Ia c term) straight from the registers its child left it in; a branch point sums its children's in its slot;
+//   * what a body leaves behind for the top-down pass is U D^-1 (6) and D^-1 u (1): three in LDS rows the walk has no more use for, four in
+//     registers named by the body; that pass composes the
+//     transforms again (S is read off the body's transform), starting later children of a branch point from its saved (transform, a_delta).
+// Extra plan tables: BODY[NOPS] (depth-first ordinal of the op's body), NCH[NOPS] (its children), BS[NOPS] (its branch slot, or -1), PBS[NOPS]
+// (its parent's branch slot, or -1), CIDX[NOPS] (its rank among its siblings), NBS (slots), NEXT_EXIT[NOPS] (the next EXIT op after this one, or -1).
+// q, v, tau of the wavefront's 64 states are staged through LDS rows (stride 65: conflict-free both ways); v̇ and q̇ leave the same way, q̇ first.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB) + 10 * P::N3;  // q, v, tau, spare, ten of the 18 values of U D^-1 of every 3-dof joint
+
+template <typename T, bool FEXT = true>
 RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau, const T* __restrict__ fext,
                       T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T gx, T gy, T gz, T* lds, const MkStage& F) {
   constexpr int NQ = P::NQ, NV = P::NV, NB = P::NB, NBS = P::NBS > 0 ? P::NBS : 1, NPR = P::NPAIR > 0 ? P::NPAIR : 1;
@@ -575,6 +613,11 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   T* r3 = rx + (NQ > NB ? NQ : NB) * RS;  // 10 rows per 3-dof joint: the part of its U D^-1 (18 values) that its v rows (3), its spare row and its four registers do not take
   const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
   if (state0 >= B) return;
+#ifdef RBD_SPEC_ABLATE_NO_LOADS  // (timing experiments, RBD_TUNE spec_variant: the passes on made-up rows, nothing read)
+  for (int k = 0; k < NQ; ++k) rq[k * RS + lane] = T(0.01f) * T(k + 1) + T(0.001f) * T(lane);
+  for (int k = 0; k < NV; ++k) { rv[k * RS + lane] = T(0.02f) * T(k + 1); rt[k * RS + lane] = T(0.5f); }
+  rq[0 * RS + lane] = T(1); rq[1 * RS + lane] = rq[2 * RS + lane] = rq[3 * RS + lane] = T(0);
+#else
   rows_in<T, NQ>(q, Lq, state0, B, rq);
   if (v) rows_in<T, NV>(v, Lv, state0, B, rv);
   else {  // (the M^-1 rhs pass: v = 0)
@@ -586,7 +629,13 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll 4
     for (int k = 0; k < NV; ++k) rt[k * RS + lane] = T(0);
   }
+#endif
   wave_sync();
+#ifdef RBD_SPEC_ABLATE_STAGING_ONLY  // (timing experiments: the staging of the rows and the way out, no passes)
+  if (vdot) rows_out<T, NV>(rt, vdot, Lv, state0, B);
+  if (qdot) rows_out<T, NQ>(rq, qdot, Lq, state0, B);
+  return;
+#endif
   // `simulate`: this launch is stage F.stage of a Munthe-Kaas RK4 step (rbd_mk_fuse.hpp): the next stage's q from the staged rows before the passes, its v
   // from the v̇ rows behind them — the wavefront's own 64 states, no launch of its own
   const T* qs = rq + lane;
@@ -716,13 +765,16 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   // per body, for the top-down pass: D^-1 u and U D^-1.  The first goes to the body's tau row (read for the last time when u is formed, written again
   // only by that pass), two of the others to its spare row and its v row (free once the joint is un-composed), four stay in registers
   T Ud1[NB][4]; T2 Ud2[NPR][4];
-  T fe1[6]; T2 fe2[6];          // external wrench of the body the next EXIT finishes (asked for one EXIT ahead)
+  // external wrench of the body the next EXIT finishes (asked for one EXIT ahead).  FEXT = false: the instantiation for callers without external wrenches —
+  // no registers held for them, no branch per body (the twelve registers decide whether Atlas's limbs fit the file without scratch; a kernel with ANY scratch
+  // runs 3.4 times slower here: 144 us against 42, the dispatcher admits fewer wavefronts at a time)
+  T fe1[6]; T2 fe2[6];
   auto load_fe = [&](auto oc) __attribute__((always_inline)) {
     constexpr int O = oc.value;
-    if constexpr (O >= 0) {
+    if constexpr (FEXT && O >= 0) {
       if constexpr (P::PAIR[O] != 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) fe2[k] = fel ? T2{fel[(long)(P::OPW[O][3] + k) * fsk], fel[(long)(P::OPW2[O][3] + k) * fsk]} : T2(0.0f);
+        for (int k = 0; k < 6; ++k) fe2[k] = fel ? mk2<T2>(fel[(long)(P::OPW[O][3] + k) * fsk], fel[(long)(P::OPW2[O][3] + k) * fsk]) : T2(0.0f);
       } else {
 #pragma unroll
         for (int k = 0; k < 6; ++k) fe1[k] = fel ? fel[(long)(P::OPW[O][3] + k) * fsk] : T(0);
@@ -737,6 +789,9 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
     constexpr int body = P::BODY[O], body2 = P::BODY2[O], nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
     constexpr bool PR = P::PAIR[O] != 0, ROOT = P::PROOT[O] != 0;
     using V = typename PairOf<T, PR>::type;
+    // (asking for the NEXT op's row values while this op computes — with a scheduling barrier to keep the request in place — was built and measured: no gain,
+    //  42 us either way; a lone wavefront's time goes to issue slots, 4 cycles per VALU instruction and 5 per packed one, not to the ~380 LDS round trips)
+    const JointQ<V> JQ = joint_q<V, O>(qs);
     auto& K = [&]() -> auto& { if constexpr (PR) return K2; else return K1; }();
     auto& C = [&]() -> auto& { if constexpr (PR) return C2; else return C1; }();
     auto& SH = [&]() -> auto& { if constexpr (PR) return SH2; else return SH1; }();
@@ -760,7 +815,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
       }  // (otherwise K is the parent's: it was just entered, or the sibling finished before this body un-composed its joint)
       V Rn[9], pn[3], vJ[6], cb[6];
       if constexpr (jt_1dof(jt) || jt == RBD_JOINT_FIXED) {
-        compose_1dof<V, O>(qs, K.R, K.p, Rn, pn);
+        compose_1dof<V, O>(JQ, K.R, K.p, Rn, pn);
         if constexpr (jt == RBD_JOINT_FIXED) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) vJ[k] = V(0);
@@ -798,7 +853,9 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
       mul_inertia(I, K.av, pA);
       momentum_cross(I, K.Tw, h);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) pA[k] += h[k] - fe[k];
+      for (int k = 0; k < 6; ++k) {
+        if constexpr (FEXT) pA[k] += h[k] - fe[k]; else pA[k] += h[k];
+      }
       load_fe(Ix<P::NEXT_EXIT[O]>{});
       sym6_from_inertia(I, IA);
       if constexpr (nch == 1) {
@@ -928,7 +985,8 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
             for (int k = 0; k < 6; ++k) C1.p[k] = hsum(H.p[k]);
           }
-        } else {
+        }
+        if constexpr (!ROOT) {
           if constexpr (pbs >= 0) {  // the parent is a branch point: its slot sums its children's hand-offs
             if constexpr (cidx == 0) SH[pbs] = H;
             else {
@@ -940,6 +998,11 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
           } else {  // a chain parent: the hand-off stays in registers
             C = H;
           }
+        }
+        // (where two limbs started, K1 is still their common parent's state and nothing needs un-composing — unless the registers are needed: with external
+        //  wrenches in flight K1 is given up while the limbs are walked and comes back from the first halves of K2)
+        constexpr bool UNC = !ROOT || FEXT;
+        if constexpr (UNC) {
           // back to the parent: the joint is un-composed (a copy of every branch point's kinematics would cost more registers than the file has)
           if constexpr (jt != RBD_JOINT_FIXED) {
             V vJ[6], cb[6];
@@ -953,7 +1016,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
             for (int k = 0; k < 6; ++k) { K.av[k] -= cb[k]; K.Tw[k] -= vJ[k]; }
           }
           if constexpr (jt_1dof(jt) || jt == RBD_JOINT_FIXED) {
-            uncompose_1dof<V, O>(qs, K.R, K.p);
+            uncompose_1dof<V, O>(JQ, K.R, K.p);
           } else {
             T Rl[9], pl[3], Rp[9], t3[3];
             local_transform<T, O, RS>(qs, Rl, pl);
@@ -966,6 +1029,14 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
             for (int k = 0; k < 9; ++k) K.R[k] = Rp[k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) K.p[k] -= t3[k];
+          }
+          if constexpr (ROOT) {  // both halves are the common parent's state again
+#pragma unroll
+            for (int k = 0; k < 9; ++k) K1.R[k] = conv<T>(K.R[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) K1.p[k] = conv<T>(K.p[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { K1.Tw[k] = conv<T>(K.Tw[k]); K1.av[k] = conv<T>(K.av[k]); }
           }
         }
       }
@@ -987,6 +1058,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
     auto& SA = [&]() -> auto& { if constexpr (PR) return SA2; else return SA1; }();
     auto ud_get = [&](int k) __attribute__((always_inline)) -> V { if constexpr (PR) return Ud2[P::PIDX[O]][k]; else return Ud1[body][k]; };
     if constexpr (kind == SK_ENTER) {
+      const JointQ<V> JQ = joint_q<V, O>(qs);
       if constexpr (lvl == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? V(1) : V(0);
@@ -1012,7 +1084,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
       if constexpr (nch > 0 || (jt != RBD_JOINT_FIXED && !(jt == RBD_JOINT_QUAT_FLOATING && lvl == 0))) {  // (a leaf on a fixed joint, or on a 6-dof joint on the world, has nothing left to do)
         if constexpr (jt_1dof(jt) || jt == RBD_JOINT_FIXED) {
           V Rn[9], pn[3];
-          compose_1dof<V, O>(qs, K.R, K.p, Rn, pn);
+          compose_1dof<V, O>(JQ, K.R, K.p, Rn, pn);
 #pragma unroll
           for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
 #pragma unroll
@@ -1109,11 +1181,6 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   if (vdot) rows_out<T, NV>(rt, vdot, Lv, state0, B);
 }
 
-constexpr int next_enter(int o) {  // the first ENTER op after op o, or -1
-  for (int k = o + 1; k < P::NOPS; ++k)
-    if ((P::OPW[k][0] & 0xff) == SK_ENTER) return k;
-  return -1;
-}
 // inverse_dynamics! / dynamics_bias! (src/mechanism_algorithms.jl:542-553, :484-498; spatial_accelerations! :387-417, newton_euler! :428-439,
 // joint_wrenches_and_torques! :442-459), one lane per state, compiled for rbd_plan's mechanism: the same walk as aba_spec with less to carry — the
 // kinematic state holds the FULL spatial acceleration (a_parent + [T_parent, S q'] + S v̇, the world's is -g), a body's net wrench
@@ -1133,6 +1200,7 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
   // signature (spatial_accelerations! :387-417 — the world's -g included, as the other kernels export it; joint_wrenches_and_torques! :442-459), stored by the lane
   const bool out_vec = store6_vec(acc_out ? acc_out : jw_out, Lo, (int)sizeof(T)) && store6_vec(jw_out ? jw_out : acc_out, Lo, (int)sizeof(T));  // uniform
   constexpr int NQ = P::NQ, NV = P::NV, NBS = P::NBS > 0 ? P::NBS : 1, ML = P::NLEVELS;
+  using T2 = typename PairOf<T, true>::type;  // limbs in lockstep (aba_spec above): the value type of an op that stands for two bodies (fp32, rows in LDS)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* rq = lds + (size_t)wave * (DIRECT ? NQ : RNEA_ROWS) * RS;
   T* rv = rq + NQ * RS;
@@ -1172,24 +1240,47 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
       for (int k = 0; k < n; ++k) { nv6[k] = vg[(long)(voff + k) * vsk]; na6[k] = ag ? ag[(long)(voff + k) * vsk] : T(0); }
     }
   };
-  struct { T R[9], p[3], Tw[6], a[6]; } K;  // the body the walk is at: transform to root, twist, spatial acceleration
-  T C[6];                                   // net wrench of the child just finished, on its way to a chain parent
-  T SF[NBS][6];                             // branch points: the sum of their children's
-  T fe[6];
+  struct KinA { T R[9], p[3], Tw[6], a[6]; };    // the body the walk is at: transform to root, twist, spatial acceleration
+  struct KinB { T2 R[9], p[3], Tw[6], a[6]; };
+  KinA K1; KinB K2;
+  T C1[6]; T2 C2[6];                           // net wrench of the child just finished, on its way to a chain parent
+  T SF1[NBS][6]; T2 SF2[NBS][6];               // branch points: the sum of their children's
+  T fe1[6]; T2 fe2[6];
   auto load_fe = [&](auto oc) __attribute__((always_inline)) {
     constexpr int O = oc.value;
     if constexpr (O >= 0) {
+      if constexpr (P::PAIR[O] != 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) fe[k] = fel ? fel[(long)(P::OPW[O][3] + k) * fsk] : T(0);
+        for (int k = 0; k < 6; ++k) fe2[k] = fel ? mk2<T2>(fel[(long)(P::OPW[O][3] + k) * fsk], fel[(long)(P::OPW2[O][3] + k) * fsk]) : T2(0.0f);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) fe1[k] = fel ? fel[(long)(P::OPW[O][3] + k) * fsk] : T(0);
+      }
     }
   };
   load_fe(Ix<P::FIRST_EXIT>{});
   prefetch(Ix<next_enter(-1)>{});
   sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
-    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
+    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2], voff2 = P::OPW2[O][2];
     constexpr int nch = P::NCH[O], bs = P::BS[O], pbs = P::PBS[O], cidx = P::CIDX[O];
+    constexpr bool PR = P::PAIR[O] != 0, ROOT = P::PROOT[O] != 0;
+    using V = typename PairOf<T, PR>::type;
+    auto& K = [&]() -> auto& { if constexpr (PR) return K2; else return K1; }();
+    auto& C = [&]() -> auto& { if constexpr (PR) return C2; else return C1; }();
+    auto& SF = [&]() -> auto& { if constexpr (PR) return SF2; else return SF1; }();
+    auto& fe = [&]() -> auto& { if constexpr (PR) return fe2; else return fe1; }();
+    // a per-body output of this op's body (and of its partner's)
+    auto store_body = [&](T* out, const V* x) __attribute__((always_inline)) {
+      if constexpr (PR) {
+        T xa[6], xb[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { xa[k] = x[k].x; xb[k] = x[k].y; }
+        store6(out, (long)P::OPW[O][3], Lo, sc, xa, out_vec);
+        store6(out, (long)P::OPW2[O][3], Lo, sc, xb, out_vec);
+      } else store6(out, (long)P::OPW[O][3], Lo, sc, x, out_vec);
+    };
     // the joint's twist and acceleration in the root frame, from the body's transform (used entering the body and un-composing it)
-    auto joint_motion = [&](const T* R, const T* p, T* S, T* vJ, T* aJ) __attribute__((always_inline)) {
+    auto joint_motion = [&](const V* R, const V* p, V* S, V* vJ, V* aJ) __attribute__((always_inline)) {
       if constexpr (nvj_of(jt) > 1) {
         T v6[6], a6[6];
         if constexpr (DIRECT) { body_twist<T, jt>(MV[lvl], 1, v6); body_twist<T, jt>(MA[lvl], 1, a6); }
@@ -1198,13 +1289,12 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
         xmotion(R, p, a6, aJ);
       } else if constexpr (jt == RBD_JOINT_FIXED) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { vJ[k] = T(0); aJ[k] = T(0); }
+        for (int k = 0; k < 6; ++k) { vJ[k] = V(0); aJ[k] = V(0); }
       } else {
-        if constexpr (jt == RBD_JOINT_PRISMATIC) { S[0] = S[1] = S[2] = T(0); S[3] = R[2]; S[4] = R[5]; S[5] = R[8]; }
-        else { S[0] = R[2]; S[1] = R[5]; S[2] = R[8]; cross3(p, S, S + 3); }
-        T qd, vd;
+        subspace_1dof<V, jt>(R, p, S);
+        V qd, vd;
         if constexpr (DIRECT) { qd = PV[lvl]; vd = PA[lvl]; }
-        else { qd = vs[voff * RS]; vd = ts[voff * RS]; }
+        else { qd = rd2<V>(vs, voff, voff2); vd = rd2<V>(ts, voff, voff2); }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { vJ[k] = S[k] * qd; aJ[k] = S[k] * vd; }
       }
@@ -1221,37 +1311,46 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
       }
       if constexpr (lvl == 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? T(1) : T(0);
+        for (int k = 0; k < 9; ++k) K.R[k] = (k % 4 == 0) ? V(1) : V(0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) K.p[k] = T(0);
+        for (int k = 0; k < 3; ++k) K.p[k] = V(0);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { K.Tw[k] = T(0); K.a[k] = T(0); }
-        K.a[3] = T(-P::GRAVITY[0]); K.a[4] = T(-P::GRAVITY[1]); K.a[5] = T(-P::GRAVITY[2]);  // mechanism_algorithms.jl:396
+        for (int k = 0; k < 6; ++k) { K.Tw[k] = V(0); K.a[k] = V(0); }
+        K.a[3] = V(-P::GRAVITY[0]); K.a[4] = V(-P::GRAVITY[1]); K.a[5] = V(-P::GRAVITY[2]);  // mechanism_algorithms.jl:396
+      } else if constexpr (ROOT) {  // two limbs leave their common parent (K1 itself stays the parent's until they are done)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) K2.R[k] = widen<T2>(K1.R[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) K2.p[k] = widen<T2>(K1.p[k]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { K2.Tw[k] = widen<T2>(K1.Tw[k]); K2.a[k] = widen<T2>(K1.a[k]); }
       }
-      T Rl[9], pl[3], Rn[9], pn[3], t3[3], S[6], vJ[6], aJ[6], cb[6];
-      local_transform<T, O, RS>(qs, Rl, pl);
-      matmul3(K.R, Rl, Rn);
-      matvec3(K.R, pl, t3);
+      V Rn[9], pn[3], S[6], vJ[6], aJ[6], cb[6];
+      if constexpr (jt_1dof(jt) || jt == RBD_JOINT_FIXED) {
+        compose_1dof<V, O>(joint_q<V, O>(qs), K.R, K.p, Rn, pn);
+      } else {
+        T Rl[9], pl[3], t3[3];
+        local_transform<T, O, RS>(qs, Rl, pl);
+        matmul3(K.R, Rl, Rn);
+        matvec3(K.R, pl, t3);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) pn[k] = K.p[k] + t3[k];
+        for (int k = 0; k < 3; ++k) pn[k] = K.p[k] + t3[k];
+      }
       joint_motion(Rn, pn, S, vJ, aJ);
-      se3_comm(K.Tw, vJ, cb);  // a_b = a_parent + [T_parent, vJ] + S v̇  (mechanism_algorithms.jl:414)
+      if constexpr (jt != RBD_JOINT_FIXED) {
+        se3_comm(K.Tw, vJ, cb);  // a_b = a_parent + [T_parent, vJ] + S v̇  (mechanism_algorithms.jl:414)
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { K.a[k] += cb[k] + aJ[k]; K.Tw[k] += vJ[k]; }
+        for (int k = 0; k < 6; ++k) { K.a[k] += cb[k] + aJ[k]; K.Tw[k] += vJ[k]; }
+      }
 #pragma unroll
       for (int k = 0; k < 9; ++k) K.R[k] = Rn[k];
 #pragma unroll
       for (int k = 0; k < 3; ++k) K.p[k] = pn[k];
-      if (acc_out && live) store6(acc_out, (long)P::OPW[O][3], Lo, sc, K.a, out_vec);
+      if (acc_out && live) store_body(acc_out, K.a);
     } else {
-      RInertia<T> I;
-      T J6[6], mc[3];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) J6[k] = T(P::TR[O][TR_J + k]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) mc[k] = T(P::TR[O][TR_MC + k]);
-      inertia_to_root(J6, mc, T(P::TR[O][TR_M]), K.R, K.p, I);
-      T f[6], h[6];
+      RInertia<V> I;
+      inertia_to_root_c<V, O>(K.R, K.p, I);
+      V f[6], h[6];
       mul_inertia(I, K.a, f);
       momentum_cross(I, K.Tw, h);
 #pragma unroll
@@ -1264,8 +1363,8 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
 #pragma unroll
         for (int k = 0; k < 6; ++k) f[k] += SF[bs][k];
       }
-      if (jw_out && live) store6(jw_out, (long)P::OPW[O][3], Lo, sc, f, out_vec);
-      T S[6], vJ[6], aJ[6];
+      if (jw_out && live) store_body(jw_out, f);
+      V S[6], vJ[6], aJ[6];
       joint_motion(K.R, K.p, S, vJ, aJ);  // (reads v̇ from the tau rows before tau overwrites it)
       if constexpr (nvj_of(jt) > 1) {
         T o6[6];
@@ -1276,42 +1375,51 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
           else ts[(voff + k) * RS] = o6[comp_of(jt, k)];
         }
       } else if constexpr (jt != RBD_JOINT_FIXED) {
-        const T t = dot6(S, f);
+        const V t = dot6(S, f);
         if constexpr (DIRECT) { if (live) tg[(long)voff * vsk] = t; }
-        else ts[voff * RS] = t;
+        else wr2<V>(ts, voff, voff2, t);
       }
       if constexpr (lvl > 0) {
-        if constexpr (pbs >= 0) {
-          if constexpr (cidx == 0) {
+        if constexpr (ROOT) {  // the two limbs' wrenches reach their common parent as their sum; K1 is still that parent's state
+          if constexpr (pbs >= 0) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) SF[pbs][k] = f[k];
+            for (int k = 0; k < 6; ++k) { if constexpr (cidx == 0) SF1[pbs][k] = hsum(f[k]); else SF1[pbs][k] += hsum(f[k]); }
           } else {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) SF[pbs][k] += f[k];
+            for (int k = 0; k < 6; ++k) C1[k] = hsum(f[k]);
           }
         } else {
+          if constexpr (pbs >= 0) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) C[k] = f[k];
+            for (int k = 0; k < 6; ++k) { if constexpr (cidx == 0) SF[pbs][k] = f[k]; else SF[pbs][k] += f[k]; }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) C[k] = f[k];
+          }
+          if constexpr (jt != RBD_JOINT_FIXED) {
+            V cb[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) K.Tw[k] -= vJ[k];  // T_parent
+            se3_comm(K.Tw, vJ, cb);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) K.a[k] -= cb[k] + aJ[k];
+          }
+          if constexpr (jt_1dof(jt) || jt == RBD_JOINT_FIXED) {
+            uncompose_1dof<V, O>(joint_q<V, O>(qs), K.R, K.p);
+          } else {
+            T Rl[9], pl[3], Rp[9], t3[3];
+            local_transform<T, O, RS>(qs, Rl, pl);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int j = 0; j < 3; ++j) Rp[3 * i + j] = K.R[3 * i] * Rl[3 * j] + K.R[3 * i + 1] * Rl[3 * j + 1] + K.R[3 * i + 2] * Rl[3 * j + 2];  // R Rl'
+            matvec3(Rp, pl, t3);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) K.R[k] = Rp[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) K.p[k] -= t3[k];
+          }
         }
-        if constexpr (jt != RBD_JOINT_FIXED) {
-          T cb[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) K.Tw[k] -= vJ[k];  // T_parent
-          se3_comm(K.Tw, vJ, cb);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) K.a[k] -= cb[k] + aJ[k];
-        }
-        T Rl[9], pl[3], Rp[9], t3[3];
-        local_transform<T, O, RS>(qs, Rl, pl);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) Rp[3 * i + j] = K.R[3 * i] * Rl[3 * j] + K.R[3 * i + 1] * Rl[3 * j + 1] + K.R[3 * i + 2] * Rl[3 * j + 2];  // R Rl'
-        matvec3(Rp, pl, t3);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) K.R[k] = Rp[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) K.p[k] -= t3[k];
       }
     }
   });
@@ -1322,7 +1430,7 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
 }
 #endif  // RBD_SPEC_ABA
 
-#ifdef RBD_SPEC_CHOL
+#if defined(RBD_SPEC_CHOL) && !defined(RBD_SPEC_EMU)  // (the host emulation of tests/emu has no matrix cores)
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The dense step of `dynamics_solve!` (potrf! / potrs!, src/mechanism_algorithms.jl:764, :819) specialised on the SPARSITY of the mechanism's
 // mass matrix.  M[i][j] is non-zero only when one of the two coordinates is an ancestor of the other (mass_matrix!'s support sets,
@@ -1532,7 +1640,7 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
 
 #endif  // RBD_SPEC_CHOL
 
-#ifdef RBD_SPEC_EMIT
+#if defined(RBD_SPEC_EMIT) && !defined(RBD_SPEC_EMU)
 // The caller's M from the staging buffer: the WHOLE nv x nv square per state, column-major, in the ORIGINAL coordinate order (the reference leaves
 // the strict upper triangle of its Symmetric(:L) undefined; here it holds the mirror image — chol_mfma_kernel's choice, kept: complete cache lines
 // written with nontemporal 16-byte stores are more than twice as fast as the lower triangle's partial lines).  16 states per wavefront; per block

@@ -37,6 +37,10 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def models(rbd):
+    return build_models(rbd)
+
+
+def build_models(rbd):
     """name -> FlatModel: URDF mechanisms from the committed flat-model fixtures, the rest built in code."""
     m = {name: rbd.load_flat_model(os.path.join(MODELS, name + ".json"))
          for name in ("atlas_floating", "atlas_fixed", "acrobot_urdf", "valkyrie_floating")}

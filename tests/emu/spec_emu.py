@@ -21,7 +21,9 @@ def build(source: str, which: str) -> ctypes.CDLL:
     """which: ABA | RNEA_F32 | RNEA_F64 — the entry point to keep (the program holds one kernel family)."""
     main = open(os.path.join(ROOT, "tests", "emu", "spec_emu_main.inc")).read()
     # __shared__ arrays inside extern "C" kernels become function statics; the kernels' own `extern __shared__` (mass matrix) is not emulated
-    text = "#define RBD_EMU_%s 1\n#include <hip/hip_runtime.h>\n" % which + source + "\n" + main
+    if which.startswith("MASS"):  # the program's own kernels use dynamic LDS, matrix cores and DPP: the harness calls crba_spec itself
+        source = source[:source.index('extern "C" __global__')]
+    text = "#define RBD_EMU_%s 1\n#define RBD_SPEC_EMU 1\n#include <hip/hip_runtime.h>\n" % which + source + "\n" + main
     key = hashlib.sha256((text + open(os.path.join(ROOT, "rigidbodydynamics.jl_amd", "csrc", "rbd_spec.hpp")).read()
                           + open(os.path.join(ROOT, "rigidbodydynamics.jl_amd", "csrc", "rbd_device.hpp")).read()).encode()).hexdigest()[:16]
     d = os.path.join(tempfile.gettempdir(), "rbd_spec_emu")
@@ -65,3 +67,13 @@ def rnea(lib, model, q, v, vdot, fext=None, dtype=np.float32, want_bodies=False)
     f = lib.emu_rnea_f32 if dtype == np.float32 else lib.emu_rnea_f64
     f(ctypes.c_long(B), _p(qs), _p(vs), _p(ws), _p(fs), _p(tau), _p(acc), _p(jw))
     return (tau.T.copy(), acc.T.copy(), jw.T.copy()) if want_bodies else tau.T.copy()
+
+
+def crba(lib, model, q, dtype=np.float32, permuted=False):
+    """q (B, nq) -> M (B, nv, nv) as crba_spec leaves it (lower triangle; permuted: position (max, min) of (PERM[row], PERM[col])), NaN where nothing was written."""
+    B, nv = q.shape[0], model.nv
+    qs = np.ascontiguousarray(q.T, dtype=dtype)
+    M = np.full((nv * nv, B), np.nan, dtype=dtype)
+    f = lib.emu_crba_f32 if dtype == np.float32 else lib.emu_crba_f64
+    f(ctypes.c_long(B), _p(qs), _p(M), ctypes.c_int(1 if permuted else 0))
+    return M.T.reshape(B, nv, nv).transpose(0, 2, 1).copy()  # [b, row, col]

@@ -52,3 +52,57 @@ def test_emulated_aba_f32(rbd, oracle, models, name):
     assert np.abs(qd - qd_ref).max() <= 2e-6 * max(1.0, np.abs(qd_ref).max())
     vd = spec_emu.aba_f32(lib, model, q, v, tau, None)
     assert backward_error(oracle, model, q, v, tau, None, vd).max() <= 2e-6
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE + LIMBS)
+def test_emulated_rnea(rbd, oracle, models, name, dtype):
+    """inverse_dynamics! with v̇, wrenches on every body and the per-body outputs; dynamics_bias! (v̇ = 0, no wrenches).  fp32: the limbs in lockstep."""
+    model = models[name]
+    src = rbd.jit_source(model, torch.float32 if dtype == "f32" else torch.float64, "inverse_dynamics")
+    if src is None:
+        pytest.skip("outside the compiled kernels' scope")
+    npair = int(re.search(r"NPAIR = (\d+)", src).group(1))
+    assert npair == (EXPECTED_PAIRS.get(name, npair) if dtype == "f32" else 0)  # fp64 has no packed arithmetic: every body on its own
+    lib = spec_emu.build(src, "RNEA_F32" if dtype == "f32" else "RNEA_F64")
+    np_t, tol = (np.float32, 3e-5) if dtype == "f32" else (np.float64, 1e-10)
+    B = 70
+    rng = np.random.default_rng(9)
+    q = rbd.rand_configuration(model, B, rng)
+    v = rbd.rand_velocity(model, B, rng)
+    vd = rng.standard_normal((B, model.nv))
+    fe = rng.random((B, 6 * model.n_bodies))
+    tau, acc, jw = spec_emu.rnea(lib, model, q, v, vd, fe, dtype=np_t, want_bodies=True)
+    ref, jw_ref, acc_ref = oracle.inverse_dynamics_bodies(model, q, v, vd, fe)
+    for got, want in ((tau, ref), (acc, acc_ref.reshape(B, -1)), (jw, jw_ref.reshape(B, -1))):
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max())
+    tau = spec_emu.rnea(lib, model, q, v, None, None, dtype=np_t)
+    ref = oracle.dynamics_bias(model, q, v, None)
+    assert np.abs(tau - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE + LIMBS)
+def test_emulated_mass_matrix(rbd, oracle, models, name, dtype):
+    """mass_matrix!: the lower triangle with its structural zeros; fp32 with nv a multiple of 4: also the permuted staging triangle the tile Cholesky reads."""
+    model = models[name]
+    src = rbd.jit_source(model, torch.float32 if dtype == "f32" else torch.float64, "mass_matrix")
+    if src is None:
+        pytest.skip("outside the compiled kernels' scope")
+    lib = spec_emu.build(src, "MASS_F32" if dtype == "f32" else "MASS_F64")
+    np_t, tol = (np.float32, 2e-6) if dtype == "f32" else (np.float64, 1e-10)
+    B, nv = 70, model.nv
+    q = rbd.rand_configuration(model, B, np.random.default_rng(13))
+    Mr = oracle.mass_matrix(model, q)  # [b][row][col]: lower triangle valid
+    il = np.tril_indices(nv)
+    got = spec_emu.crba(lib, model, q, np_t)
+    assert np.isfinite(got[:, il[0], il[1]]).all()
+    assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= tol * max(1.0, np.abs(Mr).max())
+    if dtype == "f32" and "RBD_SPEC_CHOL" in src:
+        perm = np.array([int(x) for x in re.search(r"constexpr int PERM\[NV\] = \{([^}]*)\}", src).group(1).split(",")])
+        got = spec_emu.crba(lib, model, q, np_t, permuted=True)
+        pr, pc = perm[il[0]], perm[il[1]]
+        vals = got[:, np.maximum(pr, pc), np.minimum(pr, pc)]
+        assert np.isfinite(vals).all()
+        assert np.abs(vals - Mr[:, il[0], il[1]]).max() <= tol * max(1.0, np.abs(Mr).max())

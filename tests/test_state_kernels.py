@@ -64,7 +64,7 @@ def test_state_kernels_f64(rbd, oracle, models, name, layout, states_everywhere)
 
 
 @pytest.mark.parametrize("layout", ["aos", "soa"])
-@pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating", "double_pendulum", "mixed20", "randmech1"])
+@pytest.mark.parametrize("name", ["atlas_floating", "valkyrie_floating", "double_pendulum", "mixed20", "randmech1"] + LIMBS)
 def test_state_kernels_f32_solve(rbd, oracle, models, name, layout, states_everywhere):
     """fp32: mass_matrix! + Cholesky solve (BASELINE configs[2] shape).  AOS callers get M re-emitted by the tile Cholesky from the staging copy."""
     model = models[name]
@@ -432,7 +432,7 @@ def test_compiled_aba_is_the_default_for_large_fp32_batches(rbd, oracle, models)
 # ---- inverse_dynamics! / dynamics_bias! compiled for the mechanism (rnea_spec) ------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 @pytest.mark.parametrize("layout", ["aos", "soa"])
-@pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE)
+@pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE + LIMBS)
 def test_compiled_rnea(rbd, oracle, models, name, layout, dtype):
     """`inverse_dynamics!` (v̇ and a wrench on every body) and `dynamics_bias!` through rnea_spec, forced, on a ragged batch, against the fp64 oracle
     (fp32: q, v, v̇ staged through LDS; fp64: q alone, v and v̇ read by the lane one body ahead); and against the lane-per-body kernel."""
@@ -495,7 +495,7 @@ def test_compiled_aba_as_the_mass_matrix_solve(rbd, oracle, models):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
-@pytest.mark.parametrize("name", EVERY_JOINT_TYPE)
+@pytest.mark.parametrize("name", EVERY_JOINT_TYPE + LIMBS)
 def test_compiled_mass_matrix_every_joint_type(rbd, oracle, models, name, dtype, monkeypatch):
     """`mass_matrix!` of mechanisms with 3-dof joints and 6-dof joints below the world through crba_spec (batch-innermost M: the kernel's own stores), a ragged
     batch, structural zeros included; and the same M through the Cholesky solve."""
