@@ -89,6 +89,7 @@ def parse_args():
     ap.add_argument("--op", default=None, choices=["dynamics", "inverse_dynamics", "mass_matrix_solve"],
                     help="the entry point timed (default: the config's; --config 2 --op inverse_dynamics = the RNEA half of configs[1] as its own line)")
     ap.add_argument("--no-emit-M", action="store_true", help="config 3: M_out = NULL (x only) as the timed leg")
+    ap.add_argument("--bodies", action="store_true", help="--op inverse_dynamics: with jointwrenches and accelerations out (the call shape of perf/runbenchmarks.jl:49-57)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="ONE timed leg only (no with-wrenches / graph-replay / M_out = NULL / pipelined legs): what a profiler run wants — every launch it sees is the leg")
     ap.add_argument("--batch", type=int, default=None, help="states per GPU (default: the config's)")
@@ -222,6 +223,9 @@ def run(args, env):
 
     d_tau, d_fext = to_dev(tau), to_dev(fext_all)
     x_out = torch.zeros_like(d_tau)
+    bodies = args.op == "inverse_dynamics" and getattr(args, "bodies", False)
+    d_jw = torch.zeros_like(d_fext) if bodies else None
+    d_acc = torch.zeros_like(d_fext) if bodies else None
     gathered = torch.empty((world * B, model.nv) if args.layout == "aos" else (world, model.nv, B), dtype=tdt, device=device) if world > 1 else None
 
     # low-overhead launch: pre-marshalled ctypes call straight into the C ABI
@@ -236,6 +240,11 @@ def run(args, env):
             opts = st._opts(_capi.ALGO_CRBA_CHOLESKY)
             c_args = (st.ws.handle, B, vp(st.q.data_ptr()), vp(d_tau.data_ptr()), vp(out.data_ptr()), vp(res.massmatrix.data_ptr() if emit_M else 0), ctypes.byref(opts))
             fn, name = L.rbd_mass_matrix_solve, "rbd_mass_matrix_solve"
+        elif args.op == "inverse_dynamics" and getattr(args, "bodies", False):  # ... with the per-body outputs of the reference's signature (:542-553)
+            opts = st._opts(0)
+            c_args = (st.ws.handle, B, vp(st.q.data_ptr()), vp(st.v.data_ptr()), vp(d_tau.data_ptr()), vp(d_fext.data_ptr() if with_fext else 0),
+                      vp(out.data_ptr()), vp(d_jw.data_ptr()), vp(d_acc.data_ptr()), ctypes.byref(opts))
+            fn, name = L.rbd_inverse_dynamics_bodies, "rbd_inverse_dynamics_bodies"
         elif args.op == "inverse_dynamics":  # the RNEA half of BASELINE configs[1]: v̇ ~ U[0,1) (the `tau` draw) in, τ out
             opts = st._opts(0)
             c_args = (st.ws.handle, B, vp(st.q.data_ptr()), vp(st.v.data_ptr()), vp(d_tau.data_ptr()), vp(d_fext.data_ptr() if with_fext else 0),
@@ -321,19 +330,28 @@ def run(args, env):
         got_M = got_M[:n].double().cpu().numpy().reshape(n, model.nv, model.nv).transpose(0, 2, 1)
         got_x = (x_out if args.layout == "aos" else x_out.t())[:n].double().cpu().numpy()
         il = np.tril_indices(model.nv)
-        err_M = 0.0 if args.no_emit_M else float(np.abs(got_M[:, il[0], il[1]] - Mref[:, il[0], il[1]]).max() / np.abs(Mref).max())
+        err_M = None if args.no_emit_M else float(np.abs(got_M[:, il[0], il[1]] - Mref[:, il[0], il[1]]).max() / np.abs(Mref).max())  # (None: M was not produced)
         res = np.einsum("bij,bj->bi", Mref, got_x) - tf[:n]
         # normwise backward error of the solve (Rigal–Gaches): ||M x − r|| / (||M|| ||x|| + ||r||) with the ORACLE's M
         berr = float((np.linalg.norm(res, axis=1) / (np.linalg.norm(Mref, axis=(1, 2)) * np.linalg.norm(got_x, axis=1) + np.linalg.norm(tf[:n], axis=1))).max())
         check = {"states_compared": n, "mass_matrix_rel_err": err_M, "solve_backward_err": berr,
                  "forward_err_rel_max": float(np.abs(got_x - xref).max() / np.abs(xref).max())}
-        err = max(err_M, berr)
+        err = berr if err_M is None else max(err_M, berr)
         tol = 1e-10 if args.dtype == "f64" else 2e-5
     elif args.op == "inverse_dynamics":
         ref = oracle.inverse_dynamics(model, qf, vf, tf, ff, nthreads=ncores)
         got = (x_out if args.layout == "aos" else x_out.t()).double().cpu().numpy()
         err = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
         check = {"states_compared": B}
+        if bodies:  # the per-body outputs on a sample (the oracle's per-body entry point is one state per call)
+            n = min(B, 4096)
+            _, jw_ref, acc_ref = oracle.inverse_dynamics_bodies(model, qf[:n], vf[:n], tf[:n], ff[:n] if ff is not None else None)
+            for name_, dev_, ref_ in (("jointwrenches", d_jw, jw_ref), ("accelerations", d_acc, acc_ref)):
+                g = (dev_ if args.layout == "aos" else dev_.t())[:n].double().cpu().numpy()
+                e = float(np.abs(g - ref_.reshape(n, -1)).max() / max(1.0, np.abs(ref_).max()))
+                check[name_ + "_rel_err"] = e
+                err = max(err, e)
+            check["per_body_states_compared"] = n
         tol = 1e-10 if args.dtype == "f64" else 2e-4
     elif model.nc > 0:
         n = B  # the whole batch (the loop-joint oracle is one state per call: ~1 s for 4096 four-bar states)
@@ -412,7 +430,7 @@ def run(args, env):
         metric = "mass_matrix! + Cholesky solves/sec (Atlas 30-DoF, batch)"
         opname = f"{args.dtype} mass_matrix! + Cholesky solve"
     elif args.op == "inverse_dynamics":
-        alg_bytes = es * (model.nq + 3 * model.nv)  # q, v, v̇ in; τ out
+        alg_bytes = es * (model.nq + 3 * model.nv + (12 * model.n_bodies if bodies else 0))  # q, v, v̇ in; τ out (+ a wrench and an acceleration per body)
         flops = 18.6e3
         metric = "inverse_dynamics! evals/sec (Atlas 30-DoF, batch)"
         opname = f"{args.dtype} inverse_dynamics! (RNEA)"
@@ -430,12 +448,12 @@ def run(args, env):
     # HBM traffic per launch from the PMC passes of scripts/gpu_measure.sh (one rocprofv3 run PER LEG since round 4: `--no-extra-legs`), recorded with the hash
     # of the kernel sources it was measured on: a figure from other sources is flagged stale, never passed along as current
     traffic, traffic_stale = None, None
-    pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             traffic_stale = rec.get("source_hash") != kernel_source_hash()
-            key = f"{args.model}_{args.dtype}_B{B}_{args.op}" + ("_noM" if args.no_emit_M else "")
+            key = f"{args.model}_{args.dtype}_B{B}_{args.op}" + ("_noM" if args.no_emit_M else "") + ("_bodies" if bodies else "")
             traffic = rec.get(key)
             if traffic_stale and traffic is not None:
                 traffic = dict(traffic, stale=True) if isinstance(traffic, dict) else {"bytes_per_launch": traffic, "stale": True}
@@ -453,6 +471,9 @@ def run(args, env):
                    "gather_every_step": bool(args.gather_every_step and world > 1), "inputs": "resident in HBM, re-evaluated every step (L2 / Infinity-Cache hits)"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
+                     # the inputs of a batch this small never leave the caches between steps: the "HBM" axis is then fabric traffic (the counters' raw FETCH_SIZE
+                     # is below the input bytes; profiles/r05_pmc_traffic.json)
+                     "resident": "L2/MALL" if alg_bytes * B < 64e6 and isinstance(traffic, dict) and traffic.get("fetch_raw_bytes", 1e30) < es * (model.nq + 2 * model.nv) * B else None,
                      "kernel": KERNELS.get(args.op) or (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode(),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": alg_bytes},
         "alu": {"bound": "fp64 vector ALU" if args.dtype == "f64" else "fp32 vector ALU", "achieved": achieved_tf, "peak": peak_tf,
@@ -539,6 +560,69 @@ def run(args, env):
     return out
 
 
+def sim_leg(env, B, dtype, steps=12, warm=2, nsample=8, dt=1e-3):
+    """One RK4 step of the batched `simulate` (src/simulate.jl:36-55, MuntheKaasIntegrator.step src/ode_integrators.jl:233-299; rbd_simulate: four launches per
+    step, the stage folded into the dynamics kernel): K steps between HIP events on Atlas at B states, then — from the same initial state — two steps compared with
+    the numpy restatement of the integrator (oracle/simulate_np.py) on a sample of the batch."""
+    np, torch, device = env["np"], env["torch"], env["device"]
+    rbd, _capi = env["rbd"], env["_capi"]
+    import simulate_np
+    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    rng = np.random.default_rng(7)
+    q0 = rbd.rand_configuration(model, B, rng)
+    v0 = 0.3 * rbd.rand_velocity(model, B, rng)
+    tau = rng.random((B, model.nv))
+    state = rbd.MechanismState(model, B, dtype=tdt, device=device)
+    d_tau = torch.as_tensor(tau, dtype=tdt).to(device)
+    L = _capi.lib()
+    stream = torch.cuda.current_stream(device)
+    L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(stream.cuda_stream))
+    opts = state._opts(_capi.ALGO_ABA)
+    vp = ctypes.c_void_p
+
+    def advance(n):
+        st = L.rbd_simulate(state.ws.handle, B, vp(state.q.data_ptr()), vp(state.v.data_ptr()), vp(d_tau.data_ptr()), vp(0), ctypes.c_double(dt), n, ctypes.byref(opts))
+        if st != 0:
+            raise RuntimeError(f"rbd_simulate status {st}: {L.rbd_status_string(st)} {L.rbd_last_hip_error()}")
+
+    def reset():
+        rbd.set_configuration_(state, q0)
+        rbd.set_velocity_(state, v0)
+
+    reset()
+    advance(warm)
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    advance(steps)
+    ev1.record(stream)
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    kernel = (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode()
+    # parity: two steps from the initial state, a sample of the batch against the integrator's numpy restatement (fp64)
+    reset()
+    advance(2)
+    torch.cuda.synchronize(device)
+    n = min(nsample, B)
+    ndt = np.float64 if dtype == "f64" else np.float32
+    qs, vs, ts_ = [a[:n].astype(ndt).astype(np.float64) for a in (q0, v0, tau)]
+    _, q_ref, v_ref = simulate_np.simulate(model, qs, vs, 2 * dt - 1e-12, dt, tau=ts_)
+    qg, vg = state.q[:n].double().cpu().numpy(), state.v[:n].double().cpu().numpy()
+    for o in range(0, 1):  # Atlas: one quaternion, at q[0:4] — compared up to sign
+        sg = np.sign(qg[:, o:o + 1] * q_ref[:, o:o + 1]); sg[sg == 0] = 1
+        qg[:, o:o + 4] *= sg
+    eq = float(np.abs(qg - q_ref).max() / max(1.0, np.abs(q_ref).max()))
+    ev = float(np.abs(vg - v_ref).max() / max(1.0, np.abs(v_ref).max()))
+    tq, tv = (1e-10, 1e-9) if dtype == "f64" else (2e-5, 2e-3)
+    assert eq < tq and ev < tv, f"simulate parity lost in bench: q {eq} v {ev}"
+    us = ev0.elapsed_time(ev1) / steps * 1e3
+    return {"metric": "RK4 simulate steps/sec x states (Atlas 30-DoF, batch)", "value": B * steps / wall, "unit": "state-steps/s", "steps": steps, "warmup": warm,
+            "us_per_step": wall / steps * 1e6, "kernel_us_per_step": us, "launches_per_step": 4, "dtype": dtype, "batch": B, "dt": dt, "kernel": kernel,
+            "parity_check": {"states_compared": n, "steps": 2, "q_rel_err": eq, "v_rel_err": ev, "against": "oracle/simulate_np.py (Munthe-Kaas RK4 restated in numpy, fp64)"}}
+
+
 def sub_args(args, config, **over):
     """The arguments of another BASELINE config run inside this process (short: it rides on the headline's line)."""
     import copy
@@ -547,7 +631,7 @@ def sub_args(args, config, **over):
     a.config, a.model, a.batch, a.dtype, a.op = config, cfg["model"], cfg["batch"], cfg["dtype"], cfg["op"]
     a.steps, a.warmup = (200, 20) if a.batch <= 8192 else (40, 8)
     a.no_cpu_baseline = a.no_pipelined = a.no_extra_legs = True
-    a.wrenches = a.graph = a.no_emit_M = False
+    a.wrenches = a.graph = a.no_emit_M = a.bodies = False
     a.solve_only_leg = True
     a.algorithm = "aba"
     for k, v in over.items():
@@ -580,11 +664,20 @@ def main():
         # `value` stays configs[1].  (N > 1: the line IS configs[3], the sharded one — see the module docstring.)
         extra = {}
         todo = [("inverse_dynamics", sub_args(args, 2, op="inverse_dynamics")), ("config3", sub_args(args, 3)), ("config4_shard", sub_args(args, 4)),
-                ("config5", sub_args(args, 5))]
+                ("config5", sub_args(args, 5)),
+                # the reference's own arithmetic at the large batch (round-4 review: the figures existed in the builder's tables only): dynamics!, and
+                # inverse_dynamics! with its per-body outputs — the call shape of perf/runbenchmarks.jl:49-57 — at 65 536 fp64 states
+                ("dynamics_f64_B65536", sub_args(args, 2, batch=65536)),
+                ("inverse_dynamics_bodies_f64_B65536", sub_args(args, 2, batch=65536, op="inverse_dynamics", bodies=True))]
         for name, a in todo:
             try:
                 extra[name] = block(run(a, env))
             except Exception as e:  # never lose the headline to a rider
+                extra[name] = f"failed: {type(e).__name__}: {e}"
+        for name, (B_, dt_) in (("simulate_step_f64_B4096", (4096, "f64")), ("simulate_step_f32_B65536", (65536, "f32")), ("simulate_step_f64_B65536", (65536, "f64"))):
+            try:
+                extra[name] = sim_leg(env, B_, dt_)
+            except Exception as e:
                 extra[name] = f"failed: {type(e).__name__}: {e}"
         if out is not None:
             out.update(extra)

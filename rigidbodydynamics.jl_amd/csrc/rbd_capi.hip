@@ -1725,6 +1725,8 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
       // both kernels compiled for the mechanism: M in the factorisation's own order (children before parents: no fill-in), only the tiles
       // that hold non-zeros are factored; the same launch writes the caller's M
       HIP_TRY(launch_crba_spec(w, w->spec_crba_perm, B, dq, w->d_Msoa, Lq, Ls, 0));
+      // (the emission of M as a launch of its own on a second stream beside the factorisation — emit_spec beside chol_spec without M — was measured: 145 us
+      //  against 120 for the pair in one launch; what pays is the staggered order inside chol_spec, rbd_spec.hpp)
       HIP_TRY(launch_chol_spec(w, B, w->d_Msoa, dtau, dc, dx, Lv, dM, Lm));
       w->last_kernel = "crba_spec_perm_f32 + chol_spec_f32 (compiled for the mechanism at run time)";
       return RBD_OK;

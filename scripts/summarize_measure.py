@@ -1,6 +1,6 @@
 """Condenses what scripts/gpu_measure.sh collected under gpurun_out/measure into the files that are committed under profiles/, one set PER LEG (a leg = one timed
-entry point of one BASELINE config, profiled in a run of its own): r04_kernel_stats_<leg>.csv (rocprofv3 --kernel-trace --stats, our kernels),
-r04_pmc_<leg>.txt (PMC per launch and per wavefront) and r04_pmc_traffic.json (HBM bytes per step from FETCH_SIZE / WRITE_SIZE, keyed like bench.py looks it
+entry point of one BASELINE config, profiled in a run of its own): r05_kernel_stats_<leg>.csv (rocprofv3 --kernel-trace --stats, our kernels),
+r05_pmc_<leg>.txt (PMC per launch and per wavefront) and r05_pmc_traffic.json (HBM bytes per step from FETCH_SIZE / WRITE_SIZE, keyed like bench.py looks it
 up, with the kernel-source hash)."""
 import collections
 import csv
@@ -40,12 +40,12 @@ def pmc(dirname):
 
 
 LEGS = {"c2": (2, "dynamics", ""), "c2id": (2, "inverse_dynamics", ""), "c3": (3, "mass_matrix_solve", ""), "c3noM": (3, "mass_matrix_solve", "_noM"),
-        "c4": (4, "dynamics", ""), "c5": (5, "dynamics", "")}
+        "c4": (4, "dynamics", ""), "c5": (5, "dynamics", ""), "c2big": (2, "dynamics", "", 65536), "c2idb": (2, "inverse_dynamics", "_bodies", 65536)}
 
 
 def main():
     legs = sys.argv[1:] or list(LEGS)
-    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
     h = bench.kernel_source_hash()
     rec = {}
     if os.path.exists(path):
@@ -59,14 +59,14 @@ def main():
                     "re-read every step this is fabric traffic, an upper bound of DRAM traffic.")
     rec.setdefault("detail", {})
     for leg in legs:
-        C, op, sfx = LEGS[leg]
+        C, op, sfx = LEGS[leg][:3]
         cfg = bench.CONFIGS[C]
-        key = f"{cfg['model']}_{cfg['dtype']}_B{cfg['batch']}_{op}{sfx}"
+        key = f"{cfg['model']}_{cfg['dtype']}_B{LEGS[leg][3] if len(LEGS[leg]) > 3 else cfg['batch']}_{op}{sfx}"
         # --- kernel stats
         rows = []
         for f in glob.glob(os.path.join(OUT, f"stats_{leg}", "**", "*kernel_stats.csv"), recursive=True):
             rows += list(csv.DictReader(open(f)))
-        with open(os.path.join(ROOT, "profiles", f"r04_kernel_stats_{leg}.csv"), "w") as fo:
+        with open(os.path.join(ROOT, "profiles", f"r05_kernel_stats_{leg}.csv"), "w") as fo:
             fo.write(f"# leg {leg}: rocprofv3 --kernel-trace --stats -- python bench.py (scripts/gpu_measure.sh leg_args {leg}) --no-cpu-baseline --no-extra-legs --no-other-configs --steps 60 --warmup 10 ; sources {h}\n")
             fo.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
             for r in rows:
@@ -80,7 +80,7 @@ def main():
             sq.setdefault(k, {}).update(d)
         step_kernels = [k for k, n in calls.items() if k.startswith(OURS) and n >= 60]
         total, detail = 0.0, {}
-        with open(os.path.join(ROOT, "profiles", f"r04_pmc_{leg}.txt"), "w") as fo:
+        with open(os.path.join(ROOT, "profiles", f"r05_pmc_{leg}.txt"), "w") as fo:
             fo.write(f"# leg {leg} (config {C}): {key}; sources {h}; rocprofv3 --pmc (scripts/gpu_measure.sh); per launch, averaged over the launches of the run\n")
             for k in sorted(set(fetch) | set(write) | set(sq)):
                 fr = fetch.get(k, {}).get("FETCH_SIZE", (0.0, 0))[0] * 1024
@@ -97,7 +97,8 @@ def main():
                                  "valu_insts_per_wave": (d["SQ_INSTS_VALU"][0] / w) if w and "SQ_INSTS_VALU" in d else None}
         raw = sum(d["fetch_bytes_raw"] + d["write_bytes"] for d in detail.values())
         sig = {k: float(r["StdDev"]) / float(r["AverageNs"]) for r in rows for k in [short(r["Name"])] if k in step_kernels and float(r["AverageNs"]) > 0}
-        rec[key] = {"bytes_per_step_fetch_x2": total, "bytes_per_step_raw": raw, "kernels": sorted(detail), "stddev_over_mean": sig} if detail else None
+        rec[key] = {"bytes_per_step_fetch_x2": total, "bytes_per_step_raw": raw, "fetch_raw_bytes": sum(d["fetch_bytes_raw"] for d in detail.values()),
+                    "kernels": sorted(detail), "stddev_over_mean": sig} if detail else None
         rec["detail"][key] = detail
         print(f"leg {leg} ({key}): step kernels {step_kernels}; traffic {total:.0f} B/step with FETCH x2, {raw:.0f} raw; sigma/mean {sig}")
     json.dump(rec, open(path, "w"), indent=1)
