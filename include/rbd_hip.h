@@ -357,6 +357,9 @@ int rbd_comm_create(const void* id128, int32_t world, int32_t rank, int32_t devi
 int rbd_comm_destroy(rbd_comm_t* comm);
 int rbd_comm_info(const rbd_comm_t* comm, int32_t* world, int32_t* rank);
 int rbd_gather(rbd_comm_t* comm, int32_t dtype, const void* shard, void* gathered, int64_t count, int32_t root /* < 0: every rank */, void* stream);
+/* ... with shards of different sizes (a batch that does not divide by the number of ranks): counts[world] scalars per rank, the shards back to back in rank
+ * order in `gathered`; an empty shard is legal.  Every rank passes the same counts. */
+int rbd_gatherv(rbd_comm_t* comm, int32_t dtype, const void* shard, void* gathered, const int64_t* counts, int32_t root /* < 0: every rank */, void* stream);
 const char* rbd_comm_last_error(void);
 
 /* ---- diagnostics ------------------------------------------------------------ */

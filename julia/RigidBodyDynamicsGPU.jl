@@ -461,7 +461,7 @@ end
 
 """`simulate(state0, final_time, control!; Δt, stabilization_gains)` — src/simulate.jl:36-55 with ANY controller: `control!(torques, t, state)` is
 called before every Runge-Kutta stage's `dynamics!` exactly as the reference's closure does (:42-48), with `torques` the nv × B buffer of the batch
-(a `DeviceMatrix` for device-resident states: fill it with `copyto!` or a kernel of your own), `t` the stage time and `state` holding the STAGE state.
+(a `DeviceMatrix`: fill it with `copyto!` or a kernel of your own; the state must be device-resident — `ArgumentError` otherwise), `t` the stage time and `state` holding the STAGE state.
 The stage arithmetic of MuntheKaasIntegrator.step (src/ode_integrators.jl:233-299) runs on the device (`rbd_mk_stage`: stage 0 snapshots the base
 point, stages 1..3 take the previous stage's v̇, stage 4 closes the step); only the controller runs on the host.  Returns `(ts, qs, vs)` (`store`
 as above).  Controllers that can run on the device should use `TorqueTable` / `PDControl` below: no host round trip per stage."""
@@ -469,11 +469,14 @@ function simulate(state::BatchedMechanismState{T}, final_time, control!::Functio
         store::Bool = false) where {T}
     checkmodcount(state)
     size(state.s, 1) == 0 || throw(ArgumentError("control! with contact points: drive dynamics! per stage yourself"))
+    # rbd_mk_stage advances q, v in place on the device (it answers RBD_ERR_INVALID_ARGUMENT to host memory): say so here, by name
+    state.memory == MEM_DEVICE || throw(ArgumentError("simulate with a control! callback needs a device-resident state (storage = :device); " *
+                                                      "a host-resident one can be stepped with dynamics!(ẋ, result, state, x) and an integrator of your own"))
     nsteps = stepcount(T, final_time, Δt)
     B, nv, nc = batchsize(state), state.model.nv, state.model.nc
     wext = densewrenches(state, externalwrenches)
     o = opts(state; stabilization = stabilization(state, stabilization_gains))
-    storage = state.memory == MEM_HOST ? Val(:host) : Val(:device)
+    storage = Val(:device)
     τ, v̇, λ = newbuffer(storage, T, nv, B), newbuffer(storage, T, nv, B), newbuffer(storage, T, max(nc, 1), B)
     ts = range(zero(T), step = T(Δt), length = nsteps + 1)
     qs, vs = store ? ([hostcopy(state.q)], [hostcopy(state.v)]) : (nothing, nothing)
@@ -483,7 +486,7 @@ function simulate(state::BatchedMechanismState{T}, final_time, control!::Functio
             check(ccall((:rbd_mk_stage, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Int32, Cdouble, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
                 state.ws, B, stage, Float64(Δt), state.q, state.v, stage > 0 ? pointer(v̇) : Ptr{T}(C_NULL), o), "rbd_mk_stage")
             stage == 4 && break
-            state.memory == MEM_DEVICE && synchronize(state)      # the controller may read the stage state from the host
+            synchronize(state)      # the controller may read the stage state from the host
             control!(τ, ts[k] + stagetimes[stage + 1], state)
             check(ccall((:rbd_dynamics, librbd_hip[]), Cint,
                 (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
@@ -599,6 +602,14 @@ end
 function gather!(gathered::Union{DeviceMatrix{T}, Nothing}, comm::RbdComm, shard::DeviceMatrix{T}; root = nothing) where {T}
     check(ccall((:rbd_gather, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}),
         comm.handle, T === Float64 ? 0 : 1, shard.ptr, gathered === nothing ? C_NULL : gathered.ptr, prod(size(shard)), root === nothing ? -1 : root, C_NULL), "rbd_gather")
+    gathered
+end
+"... of shards with different numbers of states: `cols[r + 1]` states on rank r (a batch that does not divide by the number of ranks), gathered n × sum(cols)"
+function gatherv!(gathered::Union{DeviceMatrix{T}, Nothing}, comm::RbdComm, shard::DeviceMatrix{T}, cols::AbstractVector{<:Integer}; root = nothing) where {T}
+    length(cols) == comm.world && cols[comm.rank + 1] == size(shard, 2) || throw(DimensionMismatch("cols must list every rank's states; cols[rank + 1] must be this shard's"))
+    counts = Int64[size(shard, 1) * c for c in cols]
+    check(ccall((:rbd_gatherv, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Int32, Ptr{Cvoid}),
+        comm.handle, T === Float64 ? 0 : 1, shard.ptr, gathered === nothing ? C_NULL : gathered.ptr, counts, root === nothing ? -1 : root, C_NULL), "rbd_gatherv")
     gathered
 end
 

@@ -1718,7 +1718,10 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
     spec_load(w, SPEC_MASS);
     const bool mcopy_ok = !dM || (Lm.sk == 1 && (Lm.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0);
     const bool spec_route = w->spec_chol && spec_crba_fits(w) && es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) && mcopy_ok;
-    if (!spec_route && !w->state_aot && !spec_crba(w, es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15))) goto lanes;  // (a mechanism only the compiled kernels take, and they are not there)
+    // the compiled mass-matrix kernel for THIS call's staging size, asked for once (the buffer itself keeps the high-water mark of earlier, larger batches: asking
+    // again with its size could answer differently — 4 GB and more — and leave a mechanism the interpreting kernel does not take without any kernel)
+    hipFunction_t const spec = spec_route ? nullptr : spec_crba(w, es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15));
+    if (!spec_route && !w->state_aot && !spec) goto lanes;  // (a mechanism only the compiled kernels take, and they are not there)
     if ((st = stage_m(w, B, spec_route))) return st;
     const Layout Ls{16, -(long)m->nv * m->nv};  // grouped by 16 states = one wavefront of the tile Cholesky (layout_base, rbd_device.hpp)
     if (spec_route) {
@@ -1731,7 +1734,6 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
       w->last_kernel = "crba_spec_perm_f32 + chol_spec_f32 (compiled for the mechanism at run time)";
       return RBD_OK;
     }
-    hipFunction_t const spec = spec_crba(w, w->d_Msoa_bytes);
     if (spec) HIP_TRY(launch_crba_spec(w, spec, B, dq, w->d_Msoa, Lq, Ls, 0));
     else HIP_TRY(launch_crba_state<float>(w->sm, B, dq, w->d_Msoa, Lq, Ls, 0, w->stream));
     HIP_TRY(launch_chol_solve<float>(m->nv, B, w->d_Msoa, dtau, dc, dx, nullptr, Ls, Lv, w->d_notpd, w->stream, dM, Lm));

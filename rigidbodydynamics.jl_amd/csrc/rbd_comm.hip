@@ -134,4 +134,36 @@ int rbd_gather(rbd_comm_t* c, int32_t dtype, const void* shard, void* gathered, 
   return RBD_OK;
 }
 
+// ... with shards of DIFFERENT sizes (a batch that does not divide by the number of ranks: shard_range gives the first B % world ranks one state more):
+// counts[r] = rank r's scalars, gathered = the shards back to back in rank order.  Grouped ncclSend / ncclRecv (there is no ragged all-gather in RCCL): to the
+// root only, or — root < 0 — from every rank to every rank.
+int rbd_gatherv(rbd_comm_t* c, int32_t dtype, const void* shard, void* gathered, const int64_t* counts, int32_t root, void* stream) {
+  if (!c || !counts || (dtype != RBD_F64 && dtype != RBD_F32) || root >= c->world) return RBD_ERR_INVALID_ARGUMENT;
+  for (int p = 0; p < c->world; ++p)
+    if (counts[p] < 0) return RBD_ERR_INVALID_ARGUMENT;
+  if (counts[c->rank] > 0 && !shard) return RBD_ERR_INVALID_ARGUMENT;
+  if ((root < 0 || root == c->rank) && !gathered) return RBD_ERR_INVALID_ARGUMENT;
+  Rccl& R = rccl();
+  if (!R.ok) { g_comm_error = "librccl.so could not be opened"; return RBD_ERR_UNSUPPORTED; }
+  const ncclDataType_t t = dtype == RBD_F64 ? ncclDouble : ncclFloat;
+  const size_t es = dtype == RBD_F64 ? 8 : 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipSetDevice(c->device) != hipSuccess) return RBD_ERR_NO_DEVICE;
+  ncclResult_t r = R.GroupStart();
+  const int64_t mine = counts[c->rank];
+  for (int dst = 0; dst < c->world && r == ncclSuccess; ++dst)  // (an empty shard is neither sent nor waited for: both sides read the same counts)
+    if (mine > 0 && (root < 0 || dst == root)) r = R.Send(shard, (size_t)mine, t, dst, c->comm, s);
+  if (root < 0 || root == c->rank) {
+    size_t off = 0;
+    for (int p = 0; p < c->world && r == ncclSuccess; ++p) {
+      if (counts[p] > 0) r = R.Recv((char*)gathered + off * es, (size_t)counts[p], t, p, c->comm, s);
+      off += (size_t)counts[p];
+    }
+  }
+  const ncclResult_t e = R.GroupEnd();
+  if (r == ncclSuccess) r = e;
+  if (r != ncclSuccess) { g_comm_error = R.GetErrorString ? R.GetErrorString(r) : "rccl call failed"; return RBD_ERR_HIP; }
+  return RBD_OK;
+}
+
 }  // extern "C"

@@ -5,7 +5,7 @@ constants are replicated (a few KB); there is NO collective in the data path.  T
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -95,6 +95,29 @@ class Comm:
                                 ctypes.c_int64(shard.numel()), -1 if root is None else int(root), ctypes.c_void_p(torch.cuda.current_stream(shard.device).cuda_stream))
         if st != 0:
             raise _capi.RBDError(st, "rbd_gather", (self._L.rbd_comm_last_error() or b"").decode())
+        return out
+
+    def gatherv(self, shard: torch.Tensor, rows: List[int], root: Optional[int] = None) -> Optional[torch.Tensor]:
+        """... of shards with DIFFERENT numbers of states (`rows[r]` states on rank r — `shard_sizes(B, world)` for a batch that does not divide): the shards back
+        to back in rank order, (sum(rows), n).  `rbd_gatherv`."""
+        import ctypes
+        from . import _capi
+        if shard.dtype not in (torch.float64, torch.float32):
+            raise TypeError(f"Comm.gatherv moves float64 / float32 results, not {shard.dtype}")
+        if len(rows) != self.world or shard.shape[0] != rows[self.rank]:
+            raise ValueError(f"rows must list every rank's states ({self.world} entries) and rows[{self.rank}] must be this shard's {shard.shape[0]}")
+        if not shard.is_cuda or shard.device.index != self.device:
+            raise ValueError(f"the shard lives on {shard.device}, the communicator on cuda:{self.device}")
+        shard = shard.contiguous()
+        per = int(shard.numel() // max(1, shard.shape[0])) if shard.shape[0] else int(torch.Size(shard.shape[1:]).numel())
+        want = root is None or root == self.rank
+        out = torch.empty((sum(rows),) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device) if want else None
+        counts = (ctypes.c_int64 * self.world)(*[int(r) * per for r in rows])
+        dt = _capi.F64 if shard.dtype == torch.float64 else _capi.F32
+        st = self._L.rbd_gatherv(self.handle, dt, ctypes.c_void_p(shard.data_ptr() if shard.numel() else 0), ctypes.c_void_p(out.data_ptr() if out is not None else 0),
+                                 counts, -1 if root is None else int(root), ctypes.c_void_p(torch.cuda.current_stream(shard.device).cuda_stream))
+        if st != 0:
+            raise _capi.RBDError(st, "rbd_gatherv", (self._L.rbd_comm_last_error() or b"").decode())
         return out
 
     def close(self):

@@ -1495,6 +1495,13 @@ def test_c_abi_rccl_gather_single_rank(rbd, models):
         out32 = comm.gather(result.vd.float())
         torch.cuda.synchronize()
         assert torch.equal(out32, result.vd.float())
+        # ... and the ragged form (rbd_gatherv: a count per rank — here one rank; more ranks need more GPUs than the test box has)
+        for root in (None, 0):
+            out = comm.gatherv(result.vd, [B], root)
+            torch.cuda.synchronize()
+            assert torch.equal(out, result.vd)
+        with pytest.raises(ValueError):
+            comm.gatherv(result.vd, [B - 1])
     finally:
         comm.close()
 

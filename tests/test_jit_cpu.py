@@ -61,10 +61,13 @@ def test_generated_plan_matches_the_mechanism(rbd, name):
     assert src is not None
     dims = re.search(r"constexpr int NB = (\d+), NQ = (\d+), NV = (\d+), NOPS = (\d+), NLEVELS = (\d+);", src)
     nb, nq, nv, nops, nlev = map(int, dims.groups())
-    assert (nb, nq, nv, nops) == (model.n_bodies, model.nq, model.nv, 2 * model.n_bodies)
-    opw = table(src, "OPW")
-    assert len(opw) == nops
-    enter = [w for w in opw if (w[0] & 0xff) == 0]
+    # fp32 programs walk sibling limbs of the same shape in lockstep (rbd_jit.hip: merge_limbs): an op of a limb stands for two bodies, the partner's words in OPW2
+    npair = int(re.search(r"constexpr int NPAIR = (\d+);", src).group(1))
+    assert (nb, nq, nv, nops) == (model.n_bodies, model.nq, model.nv, 2 * (model.n_bodies - npair))
+    opw, opw2, pair = table(src, "OPW"), table(src, "OPW2"), table(src, "PAIR")[0]
+    assert len(opw) == len(opw2) == len(pair) == nops and sum(pair) == 2 * npair
+    enter = [w for w in opw if (w[0] & 0xff) == 0] + [w2 for w, w2, p_ in zip(opw, opw2, pair) if p_ and (w[0] & 0xff) == 0]
+    assert all(w2[0] == w[0] for w, w2, p_ in zip(opw, opw2, pair) if p_)  # partners: same kind, level and joint type
     assert sorted(w[2] for w in enter) == sorted(int(v) for v in model.v_offset)  # every body entered once
     anc = ancestors(model)
     nz = anc | anc.T  # support of the mass matrix (src/mechanism_state.jl:95-98)
@@ -273,13 +276,27 @@ def test_generated_tree_tables_of_the_walk_kernels(rbd, name):
                     assert T[k][o] == T[k][e]
                 assert sorted(seen_rank.get(e, [])) == list(range(T["NCH"][e]))
         assert not stack and exits[0] == first_exit
-        assert sorted(T["BODY"][o] for o, w in enumerate(opw) if (w[0] & 0xff) == 0) == list(range(model.n_bodies))
+        # limbs in lockstep: an op of a limb stands for two bodies (PAIR), the partner's ordinal in BODY2; a limb's first op (PROOT) hangs off a body walked alone
+        P2 = {k: table(src, k)[0] for k in ("PAIR", "PROOT", "BODY2")}
+        ent = [o for o, w in enumerate(opw) if (w[0] & 0xff) == 0]
+        assert sorted([T["BODY"][o] for o in ent] + [P2["BODY2"][o] for o in ent if P2["PAIR"][o]]) == list(range(model.n_bodies))
+        assert name != "atlas_floating" or sum(P2["PAIR"][o] for o in ent) == 13  # Atlas: two arms of seven bodies, two legs of six
         for a, b in zip(exits, exits[1:] + [-1]):
             assert T["NEXT_EXIT"][a] == b
         # children counts against the mechanism, body by body (bodies with coordinates are identified by their v offset)
+        # (a pair of limbs counts as ONE child of the body they hang off)
+        limbs_below = {o: 0 for o in ent}
+        stack = []
+        for o, w in enumerate(opw):
+            if (w[0] & 0xff) == 0:
+                if stack and P2["PROOT"][o]:
+                    limbs_below[stack[-1]] += 1
+                stack.append(o)
+            else:
+                stack.pop()
         for o, w in enumerate(opw):
             if (w[0] & 0xff) == 0 and (w[0] >> 16) != 0 and w[2] in voff_to_body and nvs[voff_to_body[w[2]]] > 0:  # 0 = RBD_JOINT_FIXED
-                assert T["NCH"][o] == len(children[voff_to_body[w[2]]])
+                assert T["NCH"][o] + limbs_below[o] == len(children[voff_to_body[w[2]]])
 
 
 def walk_trees(rbd):
@@ -352,3 +369,44 @@ def test_walk_programs_compile_without_a_device(rbd):
         assert rbd.jit_source(model, torch.float64, "dynamics_tracks") is not None
         src = rbd.jit_source(model, torch.float64, "inverse_dynamics_tracks")
         assert src is not None and "rnea_walk_spec_f64" in src and "M.reroot.nchain" not in src  # (inverse dynamics walks the original tree)
+
+
+def test_code_objects_are_the_kind_the_descriptor_rewrite_knows(rbd, tmp_path, monkeypatch):
+    """The walk programs address accumulation registers by number; the library gives the wavefront all 256 of them by rewriting GRANULATED_WORKITEM_VGPR_COUNT in
+    the kernel descriptor (csrc/rbd_jit.hip: jit_kd_cover_agprs), which ties it to the descriptor layout of AMDGPU HSA code objects v5 / v6.  What this build of
+    hiprtc produces is checked here, field by field, the way the library checks it before it touches an object: ELF64 little-endian, OS ABI 64 (AMDGPU HSA), ABI
+    version 3 or 4, machine 224, gfx950; one 64-byte `<kernel>.kd` symbol per kernel whose rsrc3 ACCUM_OFFSET is the next multiple of 4 above the kernel's VGPRs
+    and whose rsrc1 granule covers them.  An object of another kind makes the library step aside to the interpreting kernel, never run with a wrong descriptor."""
+    import struct
+    monkeypatch.setenv("RBD_JIT_CACHE", str(tmp_path))
+    model = rbd.flatten(rbd.builders.double_pendulum())
+    ok, log = rbd.jit_precompile(model, torch.float64)
+    if ok is None:
+        pytest.skip("libhiprtc not available")
+    assert ok and "not used" not in log, log  # every walk program passed the library's own check and rewrite
+    seen = 0
+    for f in sorted(os.listdir(tmp_path)):
+        c = open(tmp_path / f, "rb").read()
+        assert c[:4] == b"\x7fELF" and c[4] == 2 and c[5] == 1 and c[7] == 64 and c[8] in (3, 4)
+        assert struct.unpack_from("<H", c, 0x12)[0] == 224 and struct.unpack_from("<I", c, 0x30)[0] & 0xff == 0x4f
+        shoff, = struct.unpack_from("<Q", c, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", c, 0x3a)
+        sh = lambda i: struct.unpack_from("<IIQQQQIIQQ", c, shoff + i * shentsize)  # name type flags addr offset size link info align entsize
+        for i in range(shnum):
+            _, typ, _, _, off, size, link, _, _, entsize = sh(i)
+            if typ != 2:
+                continue
+            stroff = sh(link)[4]
+            for e in range(off, off + size, entsize):
+                name, info, other, shndx, value, symsize = struct.unpack_from("<IBBHQQ", c, e)
+                nm = c[stroff + name:c.index(b"\0", stroff + name)].decode()
+                if not nm.endswith(".kd"):
+                    continue
+                assert symsize == 64
+                _, _, _, saddr, soff, _, _, _, _, _ = sh(shndx)
+                kd = soff + value - saddr
+                rsrc3, rsrc1 = struct.unpack_from("<II", c, kd + 44)
+                accum_offset, granule = ((rsrc3 & 0x3f) + 1) * 4, ((rsrc1 & 0x3f) + 1) * 8
+                assert 4 <= accum_offset <= 256 and granule >= accum_offset  # (before the rewrite: the VGPRs alone, or VGPRs + the allocator's own AGPRs)
+                seen += 1
+    assert seen >= 4
