@@ -260,6 +260,11 @@ int rbd_mass_matrix(rbd_ws_t* ws, int32_t B, const void* q, void* M_out, const r
  * tau = rhs), which never forms M.  M_out nullable (same layout as rbd_mass_matrix); tree mechanisms.              */
 int rbd_mass_matrix_solve(rbd_ws_t* ws, int32_t B, const void* q, const void* rhs, void* x,
                           void* M_out, const rbd_opts_t* opts);
+/* ... (CRBA + Cholesky) with M as LAPACK's PACKED lower triangle: element (i, j), i >= j, of state b at index i + j (2 nv − j − 1) / 2 of its
+ * np = nv (nv + 1) / 2 values — M_packed_out: np × B in opts->layout (AOS: the np values of a state contiguous).  This is the part of M the reference defines
+ * (`Symmetric(…, :L)`: src/dynamics_result.jl:42, mass_matrix! :248-272) and half the bytes of the square, which is what the emission of M costs at large
+ * batches (Atlas, 65 536 fp32 states: 175 MB instead of 357 MB).  SURVEY.md §8(b) "lower triangle valid; or packed".                                    */
+int rbd_mass_matrix_solve_packed(rbd_ws_t* ws, int32_t B, const void* q, const void* rhs, void* x, void* M_packed_out, const rbd_opts_t* opts);
 
 /* The dense step of dynamics_solve! on its own: L = potrf!('L', M) and x = potrs!(L, rhs) for B caller-provided nv×nv SPD
  * matrices (lower triangles read; device pointers).  L_out (nullable) receives the factor — DynamicsResult.L

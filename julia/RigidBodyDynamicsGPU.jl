@@ -28,7 +28,7 @@ import RigidBodyDynamics: dynamics!, inverse_dynamics!, mass_matrix!, dynamics_b
     kinetic_energy, gravitational_potential_energy, momentum, momentum_rate_bias, simulate
 using LinearAlgebra
 
-export BatchedMechanismState, BatchedDynamicsResult, DeviceMatrix, RbdComm, gather!, synchronize, librbd_hip, TorqueTable, PDControl
+export BatchedMechanismState, BatchedDynamicsResult, DeviceMatrix, RbdComm, gather!, gatherv!, mass_matrix_solve_packed!, synchronize, librbd_hip, TorqueTable, PDControl
 
 const librbd_hip = Ref("librbd_hip.so")   # set to <repo>/rigidbodydynamics.jl_amd/csrc/librbd_hip.so
 const libhip = Ref("libamdhip64.so")
@@ -417,6 +417,19 @@ function mass_matrix!(M::Buffer{T}, state::BatchedMechanismState{T}) where {T}
     M
 end
 mass_matrix!(result::BatchedDynamicsResult, state::BatchedMechanismState) = mass_matrix!(result.massmatrix, state)
+
+"""`mass_matrix_solve_packed!(x, Mpacked, state, rhs)` — `mass_matrix!` + the potrf!/potrs! of `dynamics_solve!` (:764, :819) with M as LAPACK's packed lower
+triangle: `Mpacked` is nv(nv+1)/2 × B, element (i, j), i ≥ j (0-based), of a state at i + j(2nv − j − 1)/2 — what `Symmetric(M, :L)` defines, half the bytes of
+the square (`rbd_mass_matrix_solve_packed`)."""
+function mass_matrix_solve_packed!(x::Buffer{T}, Mpacked::Buffer{T}, state::BatchedMechanismState{T}, rhs::Buffer{T}) where {T}
+    checkmodcount(state)
+    nv, B = state.model.nv, batchsize(state)
+    size(Mpacked) == (nv * (nv + 1) ÷ 2, B) && size(x) == (nv, B) && size(rhs) == (nv, B) || throw(DimensionMismatch("packed mass matrix / x / rhs have wrong sizes"))
+    check(ccall((:rbd_mass_matrix_solve_packed, librbd_hip[]), Cint, (Ptr{Cvoid}, Int32, Ptr{T}, Ptr{T}, Ptr{T}, Ptr{T}, Ref{RbdOpts}),
+        state.ws, B, state.q, rhs, x, Mpacked, opts(state; algorithm = 1)), "rbd_mass_matrix_solve_packed")   # 1 = RBD_ALGO_CRBA_CHOLESKY
+    finish(state)
+    x
+end
 
 # number of steps of integrate(), src/ode_integrators.jl:311-314: `while t < final_time` in the state's scalar type
 function stepcount(::Type{T}, final_time, Δt) where {T}

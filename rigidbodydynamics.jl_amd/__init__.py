@@ -15,6 +15,6 @@ from .builders import (maximal_coordinates, FOUR_BAR_INITIAL_Q, FOUR_BAR_INITIAL
                        rand_tree_mechanism, randmech, tree_mechanism)
 from .flatio import load_flat_model, save_flat_model
 from . import _capi
-from .state import (PDGains, SE3PDGains, default_constraint_stabilization_gains, TorqueTable, PDControl, jit_source, jit_precompile, jit_status, bank_plan, track_plan, reroot_plan, momentum, momentum_rate_bias, geometric_jacobian_, chain_plan, center_of_mass, gravitational_potential_energy, kinetic_energy, momentum_matrix_, DimensionMismatch, DynamicsResult, MechanismState, dynamics_, dynamics_bias_, dynamics_ode_, inverse_dynamics_, mass_matrix_,
+from .state import (PDGains, SE3PDGains, default_constraint_stabilization_gains, TorqueTable, PDControl, jit_source, jit_precompile, jit_status, bank_plan, track_plan, reroot_plan, momentum, momentum_rate_bias, geometric_jacobian_, chain_plan, center_of_mass, gravitational_potential_energy, kinetic_energy, momentum_matrix_, DimensionMismatch, DynamicsResult, MechanismState, dynamics_, dynamics_bias_, dynamics_ode_, inverse_dynamics_, mass_matrix_, unpack_lower,
                     mass_matrix_solve_, rand_, set_configuration_, set_velocity_, simulate_, sync, last_kernel, zero_configuration_)
 from .distributed import Comm, gather_results, shard_range, shard_sizes

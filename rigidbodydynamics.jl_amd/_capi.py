@@ -23,7 +23,7 @@ SYMBOLS = (
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
     "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan", "rbd_model_track_plan", "rbd_inverse_dynamics_bodies", "rbd_dynamics_bias_bodies",
     "rbd_model_reroot_plan", "rbd_model_contact_dims", "rbd_contact_dynamics", "rbd_dynamics_contact", "rbd_simulate_contact",
-    "rbd_workspace_bind_result", "rbd_workspace_set_loop_gains", "rbd_jit_precompile", "rbd_jit_source", "rbd_jit_status", "rbd_jit_wait_idle", "rbd_simulate_controlled", "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_gatherv", "rbd_comm_last_error",
+    "rbd_workspace_bind_result", "rbd_workspace_set_loop_gains", "rbd_jit_precompile", "rbd_jit_source", "rbd_jit_status", "rbd_jit_wait_idle", "rbd_simulate_controlled", "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_gatherv", "rbd_mass_matrix_solve_packed", "rbd_comm_last_error",
 )
 
 
@@ -77,6 +77,7 @@ def lib():
         L.rbd_dynamics_bias_bodies.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_mass_matrix.argtypes = [vp, i32, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_mass_matrix_solve.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
+        L.rbd_mass_matrix_solve_packed.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_dynamics_result.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_cholesky_solve.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.POINTER(Opts)]
         L.rbd_model_chain_plan.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32), i32]

@@ -337,3 +337,31 @@ RBD_BIG_INST(double)
 RBD_BIG_INST(float)
 
 }  // namespace rbd
+
+// ---- M as LAPACK's packed lower triangle (rbd_mass_matrix_solve_packed, the routes that form the square): element (i, j), i >= j, of state b from the square at
+// (j nv + i) to the triangle at i + j (2 nv - j - 1) / 2.  One thread per packed value, consecutive threads along the caller's contiguous direction.
+namespace rbd {
+template <typename T>
+__global__ __launch_bounds__(256) void pack_lower_kernel(int nv, long B, const T* __restrict__ M, T* __restrict__ P, Layout Lm, Layout Lp) {
+  const long np = (long)nv * (nv + 1) / 2;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= np * B) return;
+  long b, k;
+  if (Lp.sk == 1) { b = e / np; k = e - b * np; } else { k = e / B; b = e - k * B; }
+  // column of packed index k: the largest j with j (2 nv - j + 1) / 2 <= k
+  int j = (int)(((2.0f * nv + 1.0f) - sqrtf((2.0f * nv + 1.0f) * (2.0f * nv + 1.0f) - 8.0f * (float)k)) * 0.5f);
+  j = j < 0 ? 0 : (j > nv - 1 ? nv - 1 : j);
+  while (j > 0 && (long)j * (2 * nv - j + 1) / 2 > k) --j;
+  while (j + 1 < nv && (long)(j + 1) * (2 * nv - j) / 2 <= k) ++j;
+  const int i = j + (int)(k - (long)j * (2 * nv - j + 1) / 2);
+  P[k * Lp.sk + layout_base(Lp, b)] = M[((long)j * nv + i) * Lm.sk + layout_base(Lm, b)];
+}
+template <typename T> hipError_t launch_pack_lower(int nv, long B, const void* M, void* P, Layout Lm, Layout Lp, hipStream_t s) {
+  const long total = (long)nv * (nv + 1) / 2 * B;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_lower_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, nv, B, (const T*)M, (T*)P, Lm, Lp);
+  return hipGetLastError();
+}
+template hipError_t launch_pack_lower<float>(int, long, const void*, void*, Layout, Layout, hipStream_t);
+template hipError_t launch_pack_lower<double>(int, long, const void*, void*, Layout, Layout, hipStream_t);
+}  // namespace rbd

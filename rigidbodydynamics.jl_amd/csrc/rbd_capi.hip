@@ -121,7 +121,7 @@ struct rbd_ws {
   void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; void* d_rows = nullptr; size_t d_rows_bytes = 0, d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
-  bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_aba_nofext = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
+  bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_chol_nom = nullptr, spec_chol_packed = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_aba_nofext = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
   bool spec_bank_tried = false; hipModule_t spec_bank_mod = nullptr; hipFunction_t spec_bank_aba = nullptr, spec_bank_fused = nullptr, spec_bank_rnea = nullptr; std::string spec_bank_src;  // the banked kernels compiled for the mechanism
@@ -1609,6 +1609,9 @@ static void spec_load(rbd_ws* w, int family, bool force) {
     if (spec_has_chol(w->dtype, m->nv)) {
       get(&w->spec_crba_perm, "crba_spec_perm_f32");
       get(&w->spec_chol, "chol_spec_f32");
+      get(&w->spec_chol_packed, "chol_spec_packed_f32");  // M as the packed lower triangle (rbd_mass_matrix_solve_packed); optional
+      get(&w->spec_chol_nom, "chol_spec_nom_f32");        // no M wanted: a kernel of its own (rbd_spec.hpp: EMIT)
+      if (!w->spec_chol_nom) w->spec_chol = nullptr;
       get(&w->spec_emit, "emit_spec_f32");
       if (!w->spec_crba_perm || !w->spec_chol || !w->spec_emit) w->spec_crba_perm = w->spec_chol = w->spec_emit = nullptr;
     } else if (w->dtype == RBD_F64 && spec_has_chol(RBD_F32, m->nv)) {
@@ -1636,10 +1639,10 @@ static hipError_t launch_crba_spec(rbd_ws* w, hipFunction_t f, long B, const voi
 }
 
 // the sparsity-specialised tile Cholesky on the permuted staging buffer (and, before it, the caller's M from the same buffer)
-static hipError_t launch_chol_spec(rbd_ws* w, long B, const void* Mg, const void* tau, const void* c, void* x, Layout Lv, void* Mcopy, Layout Lc) {
+static hipError_t launch_chol_spec(rbd_ws* w, long B, const void* Mg, const void* tau, const void* c, void* x, Layout Lv, void* Mcopy, Layout Lc, bool packed = false) {
   int* notpd = w->d_notpd;
   void* args[] = {&B, &Mg, &tau, &c, &x, &Lv, &notpd, &Mcopy, &Lc};
-  return hipModuleLaunchKernel(w->spec_chol, (unsigned)((B + 15) / 16), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr);
+  return hipModuleLaunchKernel(!Mcopy ? w->spec_chol_nom : packed ? w->spec_chol_packed : w->spec_chol, (unsigned)((B + 15) / 16), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr);
 }
 
 // The staging buffer of M for the one-lane-per-state CRBA when the caller's layout is AOS: grouped by 16 states (Layout{16, -nv nv}).  Its
@@ -1940,6 +1943,54 @@ int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs
   }
   if (o.memory == RBD_MEM_HOST) {
     if ((st = stage_out_copy(w, x, dx, es * m->nv * B)) || (st = stage_out_copy(w, M_out, dM, mbytes))) return st;
+  }
+  return RBD_OK;
+}
+
+// x = M(q)^-1 rhs with M as LAPACK's packed lower triangle — the part of M the reference defines (Symmetric, uplo 'L': src/dynamics_result.jl:42), half the bytes
+// of the square, and bytes are what the emission of M costs.  Large fp32 batches of a mechanism with compiled kernels: the tile Cholesky sends the triangle
+// on its way from its own tiles (chol_spec<PACKED>, rbd_spec.hpp); everything else forms the square in the workspace and packs it.
+int rbd_mass_matrix_solve_packed(rbd_ws_t* w, int32_t B, const void* q, const void* rhs, void* x, void* M_packed_out, const rbd_opts_t* opts) {
+  BigOk big_ok;
+  const Opts o = read_opts(opts);
+  int st = check_common(w, B, o);
+  if (st != RBD_OK) return st;
+  const rbd_model* m = w->model;
+  if (missing(q, m->nq) || missing(rhs, m->nv) || missing(x, m->nv) || !M_packed_out) return RBD_ERR_INVALID_ARGUMENT;
+  if (B == 0) return RBD_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t es = esize(w);
+  const long np = (long)m->nv * (m->nv + 1) / 2;
+  const size_t pbytes = es * (size_t)np * B;
+  const void *dq = q, *dr = rhs;
+  void *dx = x, *dP = M_packed_out;
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_in(w, 2, rhs, es * m->nv * B, &dr)) ||
+        (st = stage_out_alloc(w, 4, x, es * m->nv * B, &dx)) || (st = stage_out_alloc(w, 6, M_packed_out, pbytes, &dP)))
+      return st;
+  }
+  const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lm = layout_of(o.layout, (long)m->nv * m->nv, B), Lp = layout_of(o.layout, np, B);
+  const bool fast = !m->big && m->nv > 0 && B >= w->state_min_batch && o.layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv) &&
+                    (spec_load(w, SPEC_MASS), w->spec_chol_packed != nullptr && w->spec_crba_perm != nullptr) && spec_crba_fits(w) &&
+                    es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) &&
+                    (reinterpret_cast<uintptr_t>(dP) & 15) == 0;  // (the triangle leaves in 16-byte pieces)
+  {
+    Timed t(w);
+    if (fast) {
+      if ((st = stage_m(w, B, true))) return st;
+      const Layout Ls{16, -(long)m->nv * m->nv};
+      HIP_TRY(launch_crba_spec(w, w->spec_crba_perm, B, dq, w->d_Msoa, Lq, Ls, 0));
+      HIP_TRY(launch_chol_spec(w, B, w->d_Msoa, dr, nullptr, dx, Lv, dP, Lp, true));
+      w->last_kernel = "crba_spec_perm_f32 + chol_spec_packed_f32 (compiled for the mechanism at run time)";
+    } else {
+      if ((st = ensure(&w->d_M, &w->d_M_bytes, es * (size_t)m->nv * m->nv * B))) return st;
+      if ((st = run_crba_chol(w, B, o.layout, dq, w->d_M, dr, nullptr, dx, Lq, Lm, Lv))) return st;
+      if (w->dtype == RBD_F64) HIP_TRY(launch_pack_lower<double>(m->nv, B, w->d_M, dP, Lm, Lp, w->stream));
+      else HIP_TRY(launch_pack_lower<float>(m->nv, B, w->d_M, dP, Lm, Lp, w->stream));
+    }
+  }
+  if (o.memory == RBD_MEM_HOST) {
+    if ((st = stage_out_copy(w, x, dx, es * m->nv * B)) || (st = stage_out_copy(w, M_packed_out, dP, pbytes))) return st;
   }
   return RBD_OK;
 }

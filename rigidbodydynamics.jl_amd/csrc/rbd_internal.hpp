@@ -18,6 +18,8 @@ template <typename T>
 hipError_t launch_chol_solve(int nv, long B, const void* M, const void* tau, const void* c, void* x, void* Lout, Layout Lm, Layout Lv,
                              int* notpd, hipStream_t s, void* Mcopy = nullptr, Layout Lc = Layout{0, 0});
 bool chol_copies_m(int element_size, int nv);  // the kernel launch_chol_solve picks can also write M in a second layout (Mcopy)
+// the lower triangle of B nv x nv matrices (column-major per state, layout Lm) as LAPACK's packed 'L' storage (layout Lp over nv (nv + 1) / 2 values per state)
+template <typename T> hipError_t launch_pack_lower(int nv, long B, const void* M, void* P, Layout Lm, Layout Lp, hipStream_t s);
 }
 namespace rbd {
 template <typename T>

@@ -1455,7 +1455,11 @@ RBD_DEV float qsum(float x) {
 RBD_DEV int sel4(int r, int a, int b, int c, int d) { return r == 0 ? a : r == 1 ? b : r == 2 ? c : d; }
 
 
-// Mc (nullable) + mst (LDS, 16 * emit_mst<float>() floats): the caller's M — the WHOLE square per state in the ORIGINAL coordinate order, as emit_spec below
+// EMIT is a template parameter, not a test of Mc: with both paths in one kernel they meet again in front of the factorisation, where the compiler must then
+// wait for the tile loads of the path WITHOUT emission — s_waitcnt vmcnt(0), which on the path with emission also waits for every store just issued (vmcnt
+// counts loads and stores alike): the wavefront sat out the drain of its 83 KB before it factored, 93 us for the launch.  As two kernels the factorisation
+// runs while the stores drain.
+// Mc + mst (LDS, 16 * emit_mst<float>() floats): the caller's M — the WHOLE square per state in the ORIGINAL coordinate order, as emit_spec below
 // writes it — sent on its way from the tiles this wavefront has just loaded for the factorisation, before it factors them.  Round 3 ran emit_spec in front of
 // this function: a second gather of the staged triangle, whose loads sat behind the block's stores in the wavefront's one in-order memory counter (vmcnt counts
 // loads AND stores on gfx9: every block of four columns waited for the previous block's stores to be acknowledged — 9 store round trips per wavefront,
@@ -1463,6 +1467,7 @@ RBD_DEV int sel4(int r, int a, int b, int c, int d) { return r == 0 ? a : r == 1
 // and the stores drain while the wavefront factors.
 // (Every other workgroup taking the two steps in the opposite order — factor first, the tiles read a second time, then out — so that half the chip emits while
 //  half factors was built and measured: 95 us against 93.  The launch is not waiting on wavefronts that march in step.)
+template <bool PACKED, bool EMIT>
 RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const float* __restrict__ tau, const float* __restrict__ c,
                        float* __restrict__ x, Layout Lv, int* __restrict__ notpd, float* __restrict__ Mc, Layout Lc, float* mst) {
   constexpr int NT = P::NT, NV = P::NV;
@@ -1497,8 +1502,93 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
     y[I] = b;
   });
 #ifdef RBD_SPEC_EMIT
-  {
-    if (Mc != nullptr) {
+  if constexpr (EMIT) {
+    // every load of this wavefront — tiles, right-hand side — has arrived before its first store is issued: vmcnt counts loads and stores in order, so a value
+    // first used behind a store would be waited for together with that store's acknowledgement (the compiler waits for each tile where it is first used: the
+    // scatter of block 1 waited for the stores of block 0, and so on down the nine blocks)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  }
+  if constexpr (PACKED) {
+    // The caller's M as LAPACK's packed lower triangle (element (i, j), i >= j, at i + j (2 nv - j - 1) / 2: nv (nv + 1) / 2 values per state, columns back to
+    // back) — the part of M the reference defines (Symmetric, uplo 'L': src/dynamics_result.jl:42) and half the bytes of the square.  Same scheme as the square
+    // below: per block of four columns the tile goes through LDS — an entry (a, b) of the original matrix belongs to column min(a, b) — and leaves in 16-byte
+    // pieces.  The pieces matter: the memory takes this kernel's stores at a rate per REQUEST (4-byte pieces: 115 us for the launch, 8-byte: 99, the square in
+    // 16-byte pieces: 93), and a block's run starts wherever the columns before it end.  So a state's triangle is treated as one stream: a block's values are
+    // laid behind the 0..3 values the block before could not complete a piece with (c), whole pieces leave, the rest is carried; a state whose run starts in the
+    // middle of a piece (nv (nv + 1) / 2 = 2 mod 4: every other state) sends its first two values, the one before it its last two, as 8-byte pieces.
+    if constexpr (EMIT) {
+      constexpr int MST = 4 * NV + 4, NP = NV * (NV + 1) / 2, A1 = NP % 4;  // A1: where an odd state's run starts within a 16-byte piece (0 or 2)
+      static_assert(A1 == 0 || A1 == 2, "nv a multiple of 4");
+      float* const mine = mst + (lane >> 2) * MST;
+      const int odd = (lane >> 2) & 1;
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      sfor<NT>([&](auto Joc) __attribute__((always_inline)) {
+        constexpr int Jo = Joc.value, j0 = 4 * Jo;
+        constexpr int LB = 4 * NV - 16 * Jo - 6;              // values of the block per state: columns j0 .. j0 + 3 from their diagonals down
+        constexpr int P0 = j0 * NV - j0 * (j0 - 1) / 2;        // where column j0 starts in the packed triangle
+        constexpr int C0 = P0 % 4, C1 = (A1 + P0) % 4;         // values carried in from the block before (even / odd state)
+        constexpr int N0 = (C0 + LB) / 4, N1 = (C1 + LB) / 4;  // whole pieces now
+        constexpr int NMAX = N0 > N1 ? N0 : N1;
+        constexpr int LBP = 4 * NV - 16 * (Jo - 1) - 6, P0P = P0 - LBP;                       // the block before
+        constexpr int NP0 = Jo > 0 ? ((P0P % 4) + LBP) / 4 : 0, NP1 = Jo > 0 ? (((A1 + P0P) % 4) + LBP) / 4 : 0;
+        const int cm = odd ? C1 : C0;
+        wave_sync();  // the tile of the block before has been read out
+        float carry = 0.0f;
+        if (Jo > 0 && r < cm) carry = mine[4 * (odd ? NP1 : NP0) + r];
+        wave_sync();
+        for (int i = lane * 4; i < 16 * MST; i += 256) *reinterpret_cast<f32x4*>(mst + i) = zero;
+        wave_sync();
+        if (Jo > 0 && r < cm) mine[r] = carry;
+        sfor<NT>([&](auto Ic) __attribute__((always_inline)) {
+          constexpr int I = Ic.value;
+          constexpr bool rows_in = (P::INV[4 * I] >> 2) == Jo || (P::INV[4 * I + 1] >> 2) == Jo || (P::INV[4 * I + 2] >> 2) == Jo || (P::INV[4 * I + 3] >> 2) == Jo;
+          const int a = od[I];                      // this lane's row coordinate in tile row I
+          const int ca = a - j0;                    // ... as a column of this block (when 0 <= ca < 4)
+          const bool mir = (a >> 2) == Jo;
+          const int offa = cm + ca * (NV - j0) - (ca * (ca - 1)) / 2 - a;  // start of column a in the block, minus a: + row = position
+          sfor<I + 1>([&](auto Jc) __attribute__((always_inline)) {
+            constexpr int J = Jc.value;
+            if constexpr (P::TMASK[I][J] != 0) {
+              sfor<4>([&](auto ccc) __attribute__((always_inline)) {
+                constexpr int cc = ccc.value, co = P::INV[4 * J + cc];  // the entry (a, co) of the original matrix
+                const bool part = (I != J) || (cc <= r);                // the diagonal tile holds its lower half
+                if constexpr ((co >> 2) == Jo) {  // column co of this block takes it when it lies on or below the diagonal
+                  constexpr int cb = co - j0, offb = cb * (NV - j0) - (cb * (cb - 1)) / 2 - co;
+                  if (part && a >= co) mine[cm + offb + a] = t[I][J][cc];
+                }
+                if constexpr (rows_in) {           // ... and column a takes it when it lies above
+                  if (mir && part && a < co) mine[offa + co] = t[I][J][cc];
+                }
+              });
+            }
+          });
+        });
+        wave_sync();
+#pragma unroll 3
+        for (int c0 = 0; c0 < 16 * NMAX; c0 += 64) {
+          const int ch = c0 + lane, st = ch / NMAX, pc = ch - st * NMAX, so = st & 1;
+          const long g2 = group * 16 + st;
+          const int first = (Jo == 0 && so && A1 != 0) ? 1 : 0;  // (an odd state's first piece starts with the state before's last two values)
+          if (ch < 16 * NMAX && pc >= first && pc < (so ? N1 : N0) && g2 < B)
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(mst + st * MST + 4 * pc),
+                                        reinterpret_cast<f32x4*>(Mc + g2 * (long)NP + (P0 - (so ? C1 : C0)) + 4 * pc));
+        }
+        const long gm = group * 16 + (lane >> 2);
+        if constexpr (Jo == 0 && A1 != 0) {  // the first two values of an odd state
+          if (odd && r == 0 && gm < B) __builtin_nontemporal_store(*reinterpret_cast<const f2*>(mine + 2), reinterpret_cast<f2*>(Mc + gm * (long)NP));
+        }
+        if constexpr (Jo == NT - 1) {        // what is left behind the last whole piece: two values, or none
+          constexpr int R0 = (C0 + LB) % 4, R1 = (C1 + LB) % 4;
+          static_assert((R0 == 0 || R0 == 2) && (R1 == 0 || R1 == 2), "a state's run ends on an 8-byte boundary");
+          const int rm = odd ? R1 : R0, nm = odd ? N1 : N0;
+          if (rm == 2 && r == 0 && gm < B)
+            __builtin_nontemporal_store(*reinterpret_cast<const f2*>(mine + 4 * nm), reinterpret_cast<f2*>(Mc + gm * (long)NP + (P0 - cm) + 4 * nm));
+        }
+      });
+      static_assert(NP == 4 * NV * NT - 16 * (NT * (NT - 1) / 2) - 6 * NT, "blocks cover the triangle");
+    }
+  } else {
+    if constexpr (EMIT) {
       using V = f32x4;
       constexpr int MST = 4 * NV + 4, CB = 4 * NV, PCS = CB / 4;  // values per state of the LDS tile; values / 16-byte pieces per state and block of four columns
       float* const mine = mst + (lane >> 2) * MST;

@@ -431,18 +431,41 @@ def mass_matrix_(M_or_result, state: MechanismState):
 
 
 def mass_matrix_solve_(x: torch.Tensor, state: MechanismState, rhs: torch.Tensor, M_out: Optional[torch.Tensor] = None,
-                       algorithm: str = "cholesky"):
+                       algorithm: str = "cholesky", packed: bool = False):
     """x = M(q)⁻¹ rhs.  algorithm="cholesky": CRBA + batched lower Cholesky — `dynamics_solve!`'s potrf!/potrs! branch (:764, :819);
-    algorithm="aba": the O(n) articulated-body solve (same x, M never formed unless `M_out` is given)."""
+    algorithm="aba": the O(n) articulated-body solve (same x, M never formed unless `M_out` is given).
+    packed=True (cholesky): `M_out` is (B, nv (nv + 1) / 2) — LAPACK's packed lower triangle, element (i, j), i ≥ j, at i + j (2 nv − j − 1) / 2: the part of M
+    the reference defines, half the bytes (`rbd_mass_matrix_solve_packed`; `unpack_lower` turns it into (B, nv, nv))."""
     f = state.flat
     state._check(x, f.nv, "x")
     state._check(rhs, f.nv, "rhs")
+    if packed:
+        if M_out is None or algorithm != "cholesky":
+            raise ValueError("packed=True needs M_out and algorithm='cholesky'")
+        state._check(M_out, f.nv * (f.nv + 1) // 2, "M_out (packed)")
+        state.ws.use_current_stream()
+        opts = state._opts(_capi.ALGO_CRBA_CHOLESKY)
+        st = _capi.lib().rbd_mass_matrix_solve_packed(state.ws.handle, state.batch, _ptr(state.q), _ptr(rhs), _ptr(x), _ptr(M_out), ctypes.byref(opts))
+        _raise(st, "rbd_mass_matrix_solve_packed")
+        return x
     state._check(M_out, f.nv * f.nv, "M_out")
     state.ws.use_current_stream()
     opts = state._opts(_capi.ALGO_CRBA_CHOLESKY if algorithm == "cholesky" else _capi.ALGO_ABA)
     st = _capi.lib().rbd_mass_matrix_solve(state.ws.handle, state.batch, _ptr(state.q), _ptr(rhs), _ptr(x), _ptr(M_out), ctypes.byref(opts))
     _raise(st, "rbd_mass_matrix_solve")
     return x
+
+
+def unpack_lower(packed, nv: int):
+    """(B, nv (nv + 1) / 2) packed lower triangles (LAPACK 'L': columns back to back from their diagonals down) -> (B, nv, nv) with the strict upper part zero."""
+    import numpy as np
+    P = packed.detach().cpu().numpy() if hasattr(packed, "detach") else np.asarray(packed)
+    out = np.zeros((P.shape[0], nv, nv), dtype=P.dtype)
+    k = 0
+    for j in range(nv):
+        out[:, j:, j] = P[:, k:k + nv - j]
+        k += nv - j
+    return out
 
 
 def sync(state: MechanismState) -> int:

@@ -13,13 +13,13 @@
 # driver's --steps 20 --warmup 5 -> profiles/r05_bench_driver_steps.json.
 # profiles/r05_pmc_traffic.json records bench.kernel_source_hash(); bench.py marks the figures stale when the sources have changed since.
 # Everything is also copied to gpurun_out/profiles/ so that it comes back from the box; copy it from there into profiles/ and commit.
-LEGS=${*:-c2 c2id c3 c3noM c4 c5 c2big c2idb}
+LEGS=${*:-c2 c2id c3 c3noM c3pk c4 c5 c2big c2idb}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 OUT=$R/gpurun_out/measure; rm -rf $OUT; mkdir -p $OUT $R/gpurun_out/profiles
 leg_args() {
   case $1 in
-    c2) echo "--config 2";; c2id) echo "--config 2 --op inverse_dynamics";; c3) echo "--config 3";; c3noM) echo "--config 3 --no-emit-M";;
+    c2) echo "--config 2";; c2id) echo "--config 2 --op inverse_dynamics";; c3) echo "--config 3";; c3noM) echo "--config 3 --no-emit-M";; c3pk) echo "--config 3 --packed-M";;
     c4) echo "--config 4";; c5) echo "--config 5";;
     c2big) echo "--config 2 --batch 65536";; c2idb) echo "--config 2 --batch 65536 --op inverse_dynamics --bodies";; *) echo "unknown leg $1" >&2; exit 1;;
   esac

@@ -39,7 +39,7 @@ def pmc(dirname):
     return {k: {c: (sum(v.values()) / len(v), len(v)) for c, v in d.items()} for k, d in per.items()}
 
 
-LEGS = {"c2": (2, "dynamics", ""), "c2id": (2, "inverse_dynamics", ""), "c3": (3, "mass_matrix_solve", ""), "c3noM": (3, "mass_matrix_solve", "_noM"),
+LEGS = {"c2": (2, "dynamics", ""), "c2id": (2, "inverse_dynamics", ""), "c3": (3, "mass_matrix_solve", ""), "c3noM": (3, "mass_matrix_solve", "_noM"), "c3pk": (3, "mass_matrix_solve", "_packed"),
         "c4": (4, "dynamics", ""), "c5": (5, "dynamics", ""), "c2big": (2, "dynamics", "", 65536), "c2idb": (2, "inverse_dynamics", "_bodies", 65536)}
 
 

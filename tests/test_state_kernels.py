@@ -521,3 +521,33 @@ def test_compiled_mass_matrix_every_joint_type(rbd, oracle, models, name, dtype,
     res = np.einsum("bij,bj->bi", Ms, xg) - tau
     eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau, axis=1))
     assert eta.max() <= (1e-12 if dtype == "f64" else 1e-5), eta.max()
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("dtype,name", [("f32", "atlas_floating"), ("f32", "limbs_humanoid"), ("f32", "mixed20"), ("f32", "double_pendulum"), ("f64", "atlas_floating"),
+                                        ("f64", "randmech1")])
+def test_mass_matrix_solve_packed(rbd, oracle, models, name, dtype, layout, states_everywhere):
+    """`rbd_mass_matrix_solve_packed`: M as LAPACK's packed lower triangle (what the reference's Symmetric(:L) defines) — from the tile Cholesky's own tiles
+    (fp32 with compiled kernels, state-major) or packed from the square (every other route); a ragged batch; x as in the square form."""
+    model = models[name]
+    B, nv = 150, model.nv
+    state, q, v, tau, _ = make(rbd, model, B, dtype, layout, 91)
+    np_ = nv * (nv + 1) // 2
+    x = torch.zeros_like(state.v)
+    # (a guard behind the buffer: the kernel writes a state's run in 16-byte pieces that straddle states — none may land past the last state)
+    whole = torch.full((B * np_ + 64,), float("nan"), dtype=TD[dtype], device="cuda")
+    P = whole[:B * np_].view((B, np_) if layout == "aos" else (np_, B))
+    rbd.mass_matrix_solve_(x, state, dev(tau, state), P, packed=True)
+    assert rbd.sync(state) == 0
+    assert bool(torch.isnan(whole[B * np_:]).all())
+    if dtype == "f32" and layout == "aos" and states_everywhere == "compiled" and nv % 4 == 0 and nv <= 40:
+        assert "chol_spec_packed_f32" in rbd.last_kernel(state), rbd.last_kernel(state)
+    got = rbd.unpack_lower(host(P, state), nv)
+    Mr = oracle.mass_matrix(model, q)
+    il = np.tril_indices(nv)
+    assert np.isfinite(got[:, il[0], il[1]]).all()
+    assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= (1e-10 if dtype == "f64" else 2e-6) * max(1.0, np.abs(Mr).max())
+    Ms, xg = sym(Mr), host(x, state)
+    res = np.einsum("bij,bj->bi", Ms, xg) - tau
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau, axis=1))
+    assert eta.max() <= (1e-12 if dtype == "f64" else 1e-5), eta.max()
