@@ -378,8 +378,9 @@ int rbd_workspace_last_kernel_ms(rbd_ws_t* ws, float* ms);
 /* name of the articulated-body kernel (lane mapping) the last rbd_dynamics / rbd_simulate / rbd_mass_matrix_solve call launched */
 const char* rbd_workspace_last_kernel(const rbd_ws_t* ws);
 /* 100·round + revision of this header.  rbd_flat_model_t grew its four contact fields at 200; a caller built against an older header must
- * not call a newer library (the Python and Julia loaders compare this with the value they were written for).  400: rbd_workspace_set_loop_gains. */
-#define RBD_HIP_H_VERSION 400
+ * not call a newer library (the Python and Julia loaders compare this with the value they were written for).  400: rbd_workspace_set_loop_gains.
+ * 500: rbd_mass_matrix_solve_packed, rbd_gatherv. */
+#define RBD_HIP_H_VERSION 500
 int rbd_version(void);
 /* Run-time specialisation.  The one-lane-per-state kernels (mass_matrix! and mass_matrix! + Cholesky at large batches) exist in a second form
  * that is compiled for the mechanism at hand with hiprtc the first time a workspace needs it (the walk of the tree, joint types, offsets and

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RBD_LIB") or os.path.join(_HERE, "csrc", "librbd_hip.so")  # RBD_LIB: A/B kernel variants (experiments only)
 
 RBD_OK = 0
-HEADER_VERSION = 400  # RBD_HIP_H_VERSION of the include/rbd_hip.h this binding was written against
+HEADER_VERSION = 500  # RBD_HIP_H_VERSION of the include/rbd_hip.h this binding was written against
 F64, F32 = 0, 1
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 MEM_DEVICE, MEM_HOST = 0, 1
