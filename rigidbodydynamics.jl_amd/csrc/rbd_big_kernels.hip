@@ -365,3 +365,34 @@ template <typename T> hipError_t launch_pack_lower(int nv, long B, const void* M
 template hipError_t launch_pack_lower<float>(int, long, const void*, void*, Layout, Layout, hipStream_t);
 template hipError_t launch_pack_lower<double>(int, long, const void*, void*, Layout, Layout, hipStream_t);
 }  // namespace rbd
+
+// ---- `simulate` on trees of more than 64 bodies: one stage of the Munthe-Kaas RK4 step (mk_stage_kernel of rbd_kernels.hip: same per-joint arithmetic,
+// rbd_integrator.hpp) with one thread per (state, body) over the any-size tables.  Correctness, no speed claim — like every kernel of this file.
+namespace rbd {
+template <typename T>
+__global__ __launch_bounds__(256) void big_mk_stage_kernel(BigModel M, long B, int stage, T dt, T* __restrict__ q, T* __restrict__ v, const T* __restrict__ vdot_prev,
+                                                           MkBuffers W, Layout Lq, Layout Lv, int close_prev) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)M.nb * B) return;
+  const long state = e / M.nb;
+  const int i = (int)(e - state * M.nb);
+  Body<T> b{};
+  b.jtype = M.tbl[4 * i + 1]; b.qoff = M.tbl[4 * i + 2]; b.voff = M.tbl[4 * i + 3]; b.state = state; b.valid = true;
+  if (b.jtype == RBD_JOINT_FIXED) return;
+  T qj[7], vj[6];
+  load_joint_q(b, q, Lq, qj);
+  load_joint_v(b, v, Lv, vj);
+  if (close_prev) mk_stage_lane<T, 0>(b, 4, dt, qj, vj, vdot_prev, W, q, v, Lq, Lv);  // the step before closes in this launch
+  mk_stage_lane<T, 0>(b, stage, dt, qj, vj, vdot_prev, W, q, v, Lq, Lv);
+}
+template <typename T>
+hipError_t launch_big_mk_stage(const BigModel& M, long B, int stage, double dt, void* q, void* v, const void* vdot_prev, const MkBuffers& W, Layout Lq, Layout Lv,
+                               hipStream_t s, int close_prev) {
+  const long total = (long)M.nb * B;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(big_mk_stage_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, M, B, stage, (T)dt, (T*)q, (T*)v, (const T*)vdot_prev, W, Lq, Lv, close_prev);
+  return hipGetLastError();
+}
+template hipError_t launch_big_mk_stage<float>(const BigModel&, long, int, double, void*, void*, const void*, const MkBuffers&, Layout, Layout, hipStream_t, int);
+template hipError_t launch_big_mk_stage<double>(const BigModel&, long, int, double, void*, void*, const void*, const MkBuffers&, Layout, Layout, hipStream_t, int);
+}  // namespace rbd

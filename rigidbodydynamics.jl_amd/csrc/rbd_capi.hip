@@ -2032,7 +2032,17 @@ static int mk_ensure(rbd_ws* w, int32_t B) {
   return RBD_OK;
 }
 
+// one stage of the integrator in a launch of its own: lane-per-body tables, or the any-size ones (more than 64 bodies)
+static hipError_t stage_launch(rbd_ws* w, long B, int stage, double dt, void* q, void* v, const void* vdot_prev, Layout Lq, Layout Lv, int close_prev = 0) {
+  if (w->model->big)
+    return w->dtype == RBD_F64 ? launch_big_mk_stage<double>(w->big, B, stage, dt, q, v, vdot_prev, w->mk, Lq, Lv, w->stream, close_prev)
+                               : launch_big_mk_stage<float>(w->big, B, stage, dt, q, v, vdot_prev, w->mk, Lq, Lv, w->stream, close_prev);
+  return w->dtype == RBD_F64 ? launch_mk_stage<double>(w->dm, B, stage, dt, q, v, vdot_prev, w->mk, Lq, Lv, w->stream, close_prev)
+                             : launch_mk_stage<float>(w->dm, B, stage, dt, q, v, vdot_prev, w->mk, Lq, Lv, w->stream, close_prev);
+}
+
 int rbd_mk_stage(rbd_ws_t* w, int32_t B, int32_t stage, double dt, void* q, void* v, const void* vdot_prev, const rbd_opts_t* opts) {
+  BigOk big_ok;
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
@@ -2043,8 +2053,7 @@ int rbd_mk_stage(rbd_ws_t* w, int32_t B, int32_t stage, double dt, void* q, void
   if ((st = mk_ensure(w, B))) return st;
   const rbd_model* m = w->model;
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B);
-  if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, stage, dt, q, v, vdot_prev, w->mk, Lq, Lv, w->stream));
-  else HIP_TRY(launch_mk_stage<float>(w->dm, B, stage, dt, q, v, vdot_prev, w->mk, Lq, Lv, w->stream));
+  HIP_TRY(stage_launch(w, B, stage, dt, q, v, vdot_prev, Lq, Lv));
   return RBD_OK;
 }
 
@@ -2056,6 +2065,7 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   if (!q || !v || nsteps < 0 || !(dt > 0)) return RBD_ERR_INVALID_ARGUMENT;
   if (w->model->ncp > 0 && w->model->nhs > 0) return RBD_ERR_UNSUPPORTED;  // contact points: rbd_simulate_contact (carries the additional state)
   if (ctl.kind != RBD_CONTROL_CONSTANT && (o.memory != RBD_MEM_DEVICE || w->model->nloops > 0)) return RBD_ERR_UNSUPPORTED;
+  if (ctl.kind == RBD_CONTROL_PD && w->model->big) return RBD_ERR_UNSUPPORTED;  // (the PD law's kernel reads the lane-per-body tables)
   if (ctl.kind == RBD_CONTROL_TABLE && !ctl.tau) return RBD_ERR_INVALID_ARGUMENT;
   if (ctl.kind == RBD_CONTROL_PD && (!ctl.kp || !ctl.kd)) return RBD_ERR_INVALID_ARGUMENT;
   if (ctl.kind < RBD_CONTROL_CONSTANT || ctl.kind > RBD_CONTROL_PD) return RBD_ERR_INVALID_ARGUMENT;
@@ -2118,7 +2128,7 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
     }
     return RBD_OK;
   }
-  const bool fused = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && !walk_sim;
+  const bool fused = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && !walk_sim && !m->big;  // (more than 64 bodies: the stage in launches of its own around rbd_dynamics' any-size route)
   for (int step = 0; fused && step < nsteps; ++step) {
     // tree mechanism, articulated-body route: each of the four stages is ONE launch (stage bookkeeping — and the PD law, on the stage state —
     // fused into the ABA kernel; the closing stage of a step rides in the first launch of the next one; only the last step closes on its own)
@@ -2138,8 +2148,7 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
     // the closing stage of a step rides in the stage-0 launch of the next one (as in the fused kernels); only the last step closes on its own
     for (int stage = 0; stage < 4; ++stage) {
       const int close_prev = (stage == 0 && step > 0) ? 1 : 0;
-      if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream, close_prev));
-      else HIP_TRY(launch_mk_stage<float>(w->dm, B, stage, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream, close_prev));
+      HIP_TRY(stage_launch(w, B, stage, dt, dq, dv, w->d_vdwork, Lq, Lv, close_prev));
       const void* ts = tau_at(step, stage);
       if (pd) {  // the PD law on the stage state the launch above left in (q, v): one element-wise launch, no host round trip
         if (w->dtype == RBD_F64) HIP_TRY(launch_pd_control<double>(w->dm, B, dq, dv, ts, ctl.q_des, ctl.kp, ctl.kd, w->d_tauwork, Lq, Lv, w->stream));
@@ -2148,10 +2157,7 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
       }
       if ((st = run_dynamics(w, B, od, dq, dv, ts, df, w->d_vdwork, nullptr, nullptr))) return st;
     }
-    if (step == nsteps - 1) {
-      if (w->dtype == RBD_F64) HIP_TRY(launch_mk_stage<double>(w->dm, B, 4, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));
-      else HIP_TRY(launch_mk_stage<float>(w->dm, B, 4, dt, dq, dv, w->d_vdwork, w->mk, Lq, Lv, w->stream));
-    }
+    if (step == nsteps - 1) HIP_TRY(stage_launch(w, B, 4, dt, dq, dv, w->d_vdwork, Lq, Lv));
   }
   if (o.memory == RBD_MEM_HOST) {
     if ((st = stage_out_copy(w, q, dq, es * m->nq * B)) || (st = stage_out_copy(w, v, dv, es * m->nv * B))) return st;
@@ -2159,6 +2165,7 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   return RBD_OK;
 }
 int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, const void* fext, double dt, int32_t nsteps, const rbd_opts_t* opts) {
+  BigOk big_ok;
   rbd_control_t ctl{};
   ctl.kind = RBD_CONTROL_CONSTANT;
   ctl.tau = tau;
@@ -2166,6 +2173,7 @@ int rbd_simulate(rbd_ws_t* w, int32_t B, void* q, void* v, const void* tau, cons
 }
 int rbd_simulate_controlled(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_control_t* control, const void* fext, double dt, int32_t nsteps,
                             const rbd_opts_t* opts) {
+  BigOk big_ok;
   if (!control) return RBD_ERR_INVALID_ARGUMENT;
   return simulate_core(w, B, q, v, *control, fext, dt, nsteps, opts);
 }

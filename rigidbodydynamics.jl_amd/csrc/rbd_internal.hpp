@@ -96,6 +96,9 @@ hipError_t launch_big_rnea(const BigModel& M, long B, const void* q, const void*
 template <typename T>
 hipError_t launch_big_crba(const BigModel& M, long B, const void* q, void* Mout, void* scratch, Layout Lq, Layout Lm, hipStream_t s);
 template <typename T> hipError_t launch_big_export_body(const BigModel& M, long B, const void* scratch, void* body, hipStream_t s);
+template <typename T>
+hipError_t launch_big_mk_stage(const BigModel& M, long B, int stage, double dt, void* q, void* v, const void* vdot_prev, const MkBuffers& W, Layout Lq, Layout Lv,
+                               hipStream_t s, int close_prev = 0);
 // dst[b * n + k] = src[k * ld + b] for one or two (src1 != nullptr) buffer pairs (n <= 384: per-body outputs of a one-lane-per-state kernel, stored
 // batch-innermost, for a state-major caller)
 template <typename T> hipError_t launch_rows_to_state_major(int n, long B, long ld, const void* src0, void* dst0, const void* src1, void* dst1, hipStream_t s);

@@ -1208,6 +1208,42 @@ def test_trees_of_more_than_64_bodies(rbd, oracle, dtype):
 
 
 @pytest.mark.gpu
+def test_simulate_on_a_tree_of_more_than_64_bodies(rbd, oracle):
+    """Round 5: `simulate` has no size limit in the reference (src/simulate.jl:36-55).  A 70-body random tree of every joint type: three RK4 steps — the stage in
+    launches of its own over the any-size tables (big_mk_stage_kernel) around rbd_dynamics' any-size route — against the numpy restatement of the integrator;
+    and the stage-by-stage form a host-side controller uses (rbd_mk_stage)."""
+    import simulate_np
+    rng = np.random.default_rng(64)
+    joints = ["QuaternionFloating"] + ["Revolute"] * 50 + ["Prismatic"] * 8 + ["SinCosRevolute"] * 4 + ["Fixed"] * 3 + ["Planar"] * 2 + ["QuaternionSpherical"] * 2
+    order = rng.permutation(len(joints) - 1)
+    model = rbd.flatten(rbd.rand_tree_mechanism(rng, [joints[0]] + [joints[1 + k] for k in order]))
+    assert model.n_bodies == 70
+    B, dt = 5, 2e-3
+    q0, v0 = rbd.rand_configuration(model, B, rng), 0.2 * rbd.rand_velocity(model, B, rng)
+    tau = 0.1 * rng.standard_normal((B, model.nv))
+    state = rbd.MechanismState(model, B)
+    rbd.set_configuration_(state, q0)
+    rbd.set_velocity_(state, v0)
+    ts = rbd.simulate_(state, 3 * dt - 1e-12, dt=dt, torques=dev(tau, state))
+    assert len(ts) == 4
+    _, q_ref, v_ref = simulate_np.simulate(model, q0, v0, 3 * dt - 1e-12, dt, tau=tau)
+    qg, vg = host(state.q, state), host(state.v, state)
+    assert np.abs(canon_q(model, qg) - canon_q(model, q_ref)).max() <= 1e-10 * max(1.0, np.abs(q_ref).max())
+    assert np.abs(vg - v_ref).max() <= 1e-8 * max(1.0, np.abs(v_ref).max())
+    # the same three steps with a controller on the host: control_(torques, t, state) before every stage
+    rbd.set_configuration_(state, q0)
+    rbd.set_velocity_(state, v0)
+    calls = []
+    def control_(torques, t, st):
+        calls.append(t)
+        torques.copy_(dev(tau, st))
+    rbd.simulate_(state, 3 * dt - 1e-12, control_, dt=dt)
+    assert len(calls) == 12
+    assert np.abs(canon_q(model, host(state.q, state)) - canon_q(model, q_ref)).max() <= 1e-10 * max(1.0, np.abs(q_ref).max())
+    assert np.abs(host(state.v, state) - v_ref).max() <= 1e-8 * max(1.0, np.abs(v_ref).max())
+
+
+@pytest.mark.gpu
 def test_loop_joints_on_a_tree_of_more_than_64_bodies(rbd, oracle):
     """Round 4: the reference has no size limit for mechanisms with loop joints either (`constraint_jacobian!`, `constraint_bias!`, the loop branch of
     `dynamics_solve!`: src/mechanism_algorithms.jl:574-673, :768-816).  A 72-body random tree (floating base, revolute / prismatic / fixed joints) closed by three
@@ -1249,9 +1285,15 @@ def test_loop_joints_on_a_tree_of_more_than_64_bodies(rbd, oracle):
     lam = host(result.lambda_, state)
     r1 = np.einsum("bij,bj->bi", Ms, got) + host(result.dynamicsbias, state) + np.einsum("bcv,bc->bv", K, lam) - tau
     assert np.abs(r1).max() <= 1e-8 * max(1.0, np.abs(host(result.dynamicsbias, state)).max())
-    # entry points outside dynamics! still refuse such a model (simulate would need the integrator's lane kernels)
-    with pytest.raises(Exception):
-        rbd.simulate_(state, 1e-3, dt=1e-3)
+    # ... and `simulate` (round 5: the integrator's stage over the any-size tables): one RK4 step, loop joints and their stabilization included
+    import simulate_np
+    rbd.simulate_(state, 1e-3 - 1e-12, dt=1e-3, torques=dev(tau, state))
+    n = 3
+    _, q_ref, v_ref = simulate_np.simulate(model, q[:n], v[:n], 1e-3 - 1e-12, 1e-3, tau=tau[:n])
+    assert np.abs(canon_q(model, host(state.q, state)[:n]) - canon_q(model, q_ref)).max() <= 1e-9 * max(1.0, np.abs(q_ref).max())
+    assert np.abs(host(state.v, state)[:n] - v_ref).max() <= 1e-7 * max(1.0, np.abs(v_ref).max())
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
     tv = torch.zeros_like(state.v)
     with pytest.raises(Exception):  # inverse_dynamics! on a mechanism with loop joints: "can currently only handle tree Mechanisms" (:549)
         rbd.inverse_dynamics_(tv, state, dev(tau, state))
