@@ -1496,11 +1496,18 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
   sfor<NT>([&](auto Ic) __attribute__((always_inline)) {
     constexpr int I = Ic.value;
     od[I] = sel4(r, P::INV[4 * I], P::INV[4 * I + 1], P::INV[4 * I + 2], P::INV[4 * I + 3]);
-    float b = 0.0f;
-    if (tau) b = tau[(long)od[I] * Lv.sk + state * Lv.sb];
-    if (c) b -= c[(long)od[I] * Lv.sk + state * Lv.sb];
-    y[I] = b;
+    y[I] = 0.0f;
   });
+  // the right-hand side: ALL of a wavefront's loads of tau behind one (uniform) test, then all of c's — with the two tests inside the loop over the blocks
+  // every block's pair of loads sat in a branch of its own with a wait behind it: nine dependent round trips in front of the factorisation
+  if (tau) {
+    sfor<NT>([&](auto Ic) __attribute__((always_inline)) { y[Ic.value] = tau[(long)od[Ic.value] * Lv.sk + state * Lv.sb]; });
+  }
+  if (c) {
+    float yc[NT];
+    sfor<NT>([&](auto Ic) __attribute__((always_inline)) { yc[Ic.value] = c[(long)od[Ic.value] * Lv.sk + state * Lv.sb]; });
+    sfor<NT>([&](auto Ic) __attribute__((always_inline)) { y[Ic.value] -= yc[Ic.value]; });
+  }
 #ifdef RBD_SPEC_EMIT
   if constexpr (EMIT) {
     // every load of this wavefront — tiles, right-hand side — has arrived before its first store is issued: vmcnt counts loads and stores in order, so a value
@@ -1552,12 +1559,15 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
               sfor<4>([&](auto ccc) __attribute__((always_inline)) {
                 constexpr int cc = ccc.value, co = P::INV[4 * J + cc];  // the entry (a, co) of the original matrix
                 const bool part = (I != J) || (cc <= r);                // the diagonal tile holds its lower half
+                // (a value that does not belong to this block goes to the tile's spare slot: a select and an unconditional write — as `if (p) mine[..] = x` every
+                //  entry was a branch of its own, s_and_saveexec + s_cbranch_execz + s_or: 340 scalar instructions per block, at ~7 cycles each for a wavefront
+                //  that has the SIMD almost to itself more than the vector and LDS work of the block together)
                 if constexpr ((co >> 2) == Jo) {  // column co of this block takes it when it lies on or below the diagonal
                   constexpr int cb = co - j0, offb = cb * (NV - j0) - (cb * (cb - 1)) / 2 - co;
-                  if (part && a >= co) mine[cm + offb + a] = t[I][J][cc];
+                  mine[(part && a >= co) ? cm + offb + a : 4 * NV] = t[I][J][cc];
                 }
                 if constexpr (rows_in) {           // ... and column a takes it when it lies above
-                  if (mir && part && a < co) mine[offa + co] = t[I][J][cc];
+                  mine[(mir && part && a < co) ? offa + co : 4 * NV] = t[I][J][cc];
                 }
               });
             }
@@ -1610,11 +1620,13 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
               sfor<4>([&](auto ccc) __attribute__((always_inline)) {
                 constexpr int cc = ccc.value, co = P::INV[4 * J + cc];  // the entry (od[I], co) of the original matrix
                 const bool part = (I != J) || (cc <= r);                // the diagonal tile holds its lower half
+                // (what does not belong here goes to the tile's spare slot — a select and an unconditional write, not a branch per entry: see the packed form above)
                 if constexpr ((co >> 2) == Jo) {
-                  if (part) mine[(co - 4 * Jo) * NV + od[I]] = t[I][J][cc];
+                  if constexpr (I != J) mine[(co - 4 * Jo) * NV + od[I]] = t[I][J][cc];
+                  else mine[part ? (co - 4 * Jo) * NV + od[I] : 4 * NV] = t[I][J][cc];
                 }
                 if constexpr (rows_in) {
-                  if (mir && part && !(I == J && cc == r)) mrow[co] = t[I][J][cc];
+                  mine[(mir && part && !(I == J && cc == r)) ? (od[I] & 3) * NV + co : 4 * NV] = t[I][J][cc];
                 }
               });
             }
