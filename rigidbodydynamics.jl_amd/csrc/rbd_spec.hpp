@@ -1455,18 +1455,38 @@ RBD_DEV float qsum(float x) {
 RBD_DEV int sel4(int r, int a, int b, int c, int d) { return r == 0 ? a : r == 1 ? b : r == 2 ? c : d; }
 
 
+// entry (r, CC) of a symmetric 4 x 4 tile whose quad of lanes holds the lower half (lane r: row r, the columns above the diagonal zero): the lane's own
+// value on and below the diagonal, lane CC's column r above it
+template <int CC> RBD_DEV float diag_entry(const f32x4& tt, int r) {
+  if constexpr (CC == 0) return tt[0];
+  else {
+    // (every DPP read on its own line, outside the selects: inside a conditional expression it would run under the condition's exec mask and read a
+    //  lane that is switched off — zero)
+    const float b0 = qbcast<CC>(tt[0]);
+    const float b1 = CC >= 2 ? qbcast<CC>(tt[1]) : 0.0f;
+    const float b2 = CC >= 3 ? qbcast<CC>(tt[2]) : 0.0f;
+    const float m = r == 0 ? b0 : r == 1 ? b1 : b2;
+    return r >= CC ? tt[CC] : m;
+  }
+}
+// LDS floats of chol_spec's emission: the tiles of 16 states and, behind them, a row per state for the writes that do not belong to the block in hand
+constexpr int chol_emit_lds() { return 16 * (4 * P::NV + 4) + 16 * P::NV; }
+
 // EMIT is a template parameter, not a test of Mc: with both paths in one kernel they meet again in front of the factorisation, where the compiler must then
 // wait for the tile loads of the path WITHOUT emission — s_waitcnt vmcnt(0), which on the path with emission also waits for every store just issued (vmcnt
 // counts loads and stores alike): the wavefront sat out the drain of its 83 KB before it factored, 93 us for the launch.  As two kernels the factorisation
 // runs while the stores drain.
-// Mc + mst (LDS, 16 * emit_mst<float>() floats): the caller's M — the WHOLE square per state in the ORIGINAL coordinate order, as emit_spec below
+// Mc + mst (LDS, chol_emit_lds() floats): the caller's M — the WHOLE square per state in the ORIGINAL coordinate order, as emit_spec below
 // writes it — sent on its way from the tiles this wavefront has just loaded for the factorisation, before it factors them.  Round 3 ran emit_spec in front of
 // this function: a second gather of the staged triangle, whose loads sat behind the block's stores in the wavefront's one in-order memory counter (vmcnt counts
 // loads AND stores on gfx9: every block of four columns waited for the previous block's stores to be acknowledged — 9 store round trips per wavefront,
 // 72 us of the launch's 106).  Here nothing is loaded after the first store: tile -> LDS -> whole 16-byte pieces of complete runs, nine blocks back to back,
 // and the stores drain while the wavefront factors.
 // (Every other workgroup taking the two steps in the opposite order — factor first, the tiles read a second time, then out — so that half the chip emits while
-//  half factors was built and measured: 95 us against 93.  The launch is not waiting on wavefronts that march in step.)
+//  half factors was built and measured: 95 us against 93; every other wavefront of the first round starting 7 / 14 / 20 us late: +2.5 / +8 / +13 us.  The launch
+//  is not waiting on wavefronts that march in step: a wavefront's own chain — load, through LDS and out, factor, solve: 31 us of which it issues for 7 — is the
+//  time, two rounds of them with two per SIMD; the square with its stores sent to one place instead of 357 MB takes 62 us against 86, the packed triangle with
+//  half the bytes 84.)
 template <bool PACKED, bool EMIT>
 RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const float* __restrict__ tau, const float* __restrict__ c,
                        float* __restrict__ x, Layout Lv, int* __restrict__ notpd, float* __restrict__ Mc, Layout Lc, float* mst) {
@@ -1519,8 +1539,8 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
     // The caller's M as LAPACK's packed lower triangle (element (i, j), i >= j, at i + j (2 nv - j - 1) / 2: nv (nv + 1) / 2 values per state, columns back to
     // back) — the part of M the reference defines (Symmetric, uplo 'L': src/dynamics_result.jl:42) and half the bytes of the square.  Same scheme as the square
     // below: per block of four columns the tile goes through LDS — an entry (a, b) of the original matrix belongs to column min(a, b) — and leaves in 16-byte
-    // pieces.  The pieces matter: the memory takes this kernel's stores at a rate per REQUEST (4-byte pieces: 115 us for the launch, 8-byte: 99, the square in
-    // 16-byte pieces: 93), and a block's run starts wherever the columns before it end.  So a state's triangle is treated as one stream: a block's values are
+    // pieces.  The pieces matter (4-byte pieces: 115 us for the launch, 8-byte: 99, 16-byte: 94 — with the round-4 address arithmetic; 84 now), and a block's
+    // run starts wherever the columns before it end.  So a state's triangle is treated as one stream: a block's values are
     // laid behind the 0..3 values the block before could not complete a piece with (c), whole pieces leave, the rest is carried; a state whose run starts in the
     // middle of a piece (nv (nv + 1) / 2 = 2 mod 4: every other state) sends its first two values, the one before it its last two, as 8-byte pieces.
     if constexpr (EMIT) {
@@ -1529,6 +1549,9 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
       float* const mine = mst + (lane >> 2) * MST;
       const int odd = (lane >> 2) & 1;
       const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      const long left = B - group * 16;
+      const unsigned nlive = left < 16 ? (unsigned)left : 16u;  // states of this group inside the batch
+      float* const Mw = Mc + group * 16 * (long)NP;
       sfor<NT>([&](auto Joc) __attribute__((always_inline)) {
         constexpr int Jo = Joc.value, j0 = 4 * Jo;
         constexpr int LB = 4 * NV - 16 * Jo - 6;              // values of the block per state: columns j0 .. j0 + 3 from their diagonals down
@@ -1546,42 +1569,51 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
         for (int i = lane * 4; i < 16 * MST; i += 256) *reinterpret_cast<f32x4*>(mst + i) = zero;
         wave_sync();
         if (Jo > 0 && r < cm) mine[r] = carry;
+        // an entry (a, co) of the original matrix goes to column co when it lies on or below the diagonal (a >= co), to column a when above — and only when
+        // that column is one of this block's four.  Which of the two is a test per lane (a = od[I] is the lane's row): the address is a select between the
+        // lane's base and the state's dump word, the rest of it a constant in the instruction's offset field (the dump's base is taken back by that constant).
+        // A diagonal tile is made symmetric within its quad first (diag_entry): column images only.
+        float* const cbase = mine + cm;
+        float* const dump0 = mst + 16 * MST + (lane >> 2);
         sfor<NT>([&](auto Ic) __attribute__((always_inline)) {
           constexpr int I = Ic.value;
           constexpr bool rows_in = (P::INV[4 * I] >> 2) == Jo || (P::INV[4 * I + 1] >> 2) == Jo || (P::INV[4 * I + 2] >> 2) == Jo || (P::INV[4 * I + 3] >> 2) == Jo;
           const int a = od[I];                      // this lane's row coordinate in tile row I
           const int ca = a - j0;                    // ... as a column of this block (when 0 <= ca < 4)
-          const bool mir = (a >> 2) == Jo;
-          const int offa = cm + ca * (NV - j0) - (ca * (ca - 1)) / 2 - a;  // start of column a in the block, minus a: + row = position
+          const bool mir = (unsigned)ca < 4u;
+          float* const colp = cbase + ca;           // column co, row a: + (start of column co in the block) - (co - j0)
+          float* const mirp = cbase + (ca * (NV - j0) - (ca * (ca - 1)) / 2 - ca);  // column a, row co: + (co - j0)
           sfor<I + 1>([&](auto Jc) __attribute__((always_inline)) {
             constexpr int J = Jc.value;
             if constexpr (P::TMASK[I][J] != 0) {
               sfor<4>([&](auto ccc) __attribute__((always_inline)) {
                 constexpr int cc = ccc.value, co = P::INV[4 * J + cc];  // the entry (a, co) of the original matrix
-                const bool part = (I != J) || (cc <= r);                // the diagonal tile holds its lower half
-                // (a value that does not belong to this block goes to the tile's spare slot: a select and an unconditional write — as `if (p) mine[..] = x` every
-                //  entry was a branch of its own, s_and_saveexec + s_cbranch_execz + s_or: 340 scalar instructions per block, at ~7 cycles each for a wavefront
-                //  that has the SIMD almost to itself more than the vector and LDS work of the block together)
-                if constexpr ((co >> 2) == Jo) {  // column co of this block takes it when it lies on or below the diagonal
-                  constexpr int cb = co - j0, offb = cb * (NV - j0) - (cb * (cb - 1)) / 2 - co;
-                  mine[(part && a >= co) ? cm + offb + a : 4 * NV] = t[I][J][cc];
-                }
-                if constexpr (rows_in) {           // ... and column a takes it when it lies above
-                  mine[(mir && part && a < co) ? offa + co : 4 * NV] = t[I][J][cc];
+                constexpr bool col_here = (co >> 2) == Jo, mir_here = I != J && rows_in && co > j0;
+                if constexpr (col_here || mir_here) {
+                  float val;
+                  if constexpr (I == J) val = diag_entry<cc>(t[I][I], r); else val = t[I][J][cc];
+                  const bool ge = a >= co;
+                  if constexpr (col_here) {
+                    constexpr int cb = co - j0, imm = cb * (NV - j0) - (cb * (cb - 1)) / 2 - cb;
+                    (ge ? colp : dump0 - imm)[imm] = val;
+                  }
+                  if constexpr (mir_here) {
+                    constexpr int imm2 = co - j0;
+                    ((mir && !ge) ? mirp : dump0 - imm2)[imm2] = val;
+                  }
                 }
               });
             }
           });
         });
         wave_sync();
-#pragma unroll 3
-        for (int c0 = 0; c0 < 16 * NMAX; c0 += 64) {
-          const int ch = c0 + lane, st = ch / NMAX, pc = ch - st * NMAX, so = st & 1;
-          const long g2 = group * 16 + st;
-          const int first = (Jo == 0 && so && A1 != 0) ? 1 : 0;  // (an odd state's first piece starts with the state before's last two values)
-          if (ch < 16 * NMAX && pc >= first && pc < (so ? N1 : N0) && g2 < B)
-            __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(mst + st * MST + 4 * pc),
-                                        reinterpret_cast<f32x4*>(Mc + g2 * (long)NP + (P0 - (so ? C1 : C0)) + 4 * pc));
+#pragma unroll
+        for (int c0 = 0; c0 < 16 * NMAX; c0 += 64) {  // (32-bit offsets from the wavefront's own base: the address arithmetic is most of what a store costs here)
+          const unsigned ch = (unsigned)(c0 + lane), st = ch / (unsigned)NMAX, pc = ch - st * (unsigned)NMAX, so = st & 1u;
+          const unsigned first = (Jo == 0 && so && A1 != 0) ? 1u : 0u;  // (an odd state's first piece starts with the state before's last two values)
+          if (pc >= first && pc < (so ? (unsigned)N1 : (unsigned)N0) && st < nlive)
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(mst + st * (unsigned)MST + 4u * pc),
+                                        reinterpret_cast<f32x4*>(Mw + (st * (unsigned)NP + (unsigned)P0 - (so ? (unsigned)C1 : (unsigned)C0) + 4u * pc)));
         }
         const long gm = group * 16 + (lane >> 2);
         if constexpr (Jo == 0 && A1 != 0) {  // the first two values of an odd state
@@ -1599,10 +1631,39 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
     }
   } else {
     if constexpr (EMIT) {
+      // Per block of four columns (16 nv contiguous bytes per state): the tile of the 16 states is cleared in LDS (the structural zeros), the entries of the
+      // block are written into it — an entry (a, b) below the diagonal lands in column b, and as its mirror image in column a — and the tile leaves as whole
+      // 16-byte pieces of complete runs.  What this costs is instructions, not bytes (RBD_TUNE spec_variant=1024, every wavefront's M onto the same 64 states:
+      // 81 us against 97 — the memory behind the stores is worth 15 us of the 62 the emission took), so every address is a per-lane base plus a constant:
+      //  * the column image of row a = od[I]: base mine + a, the column and the block in the instruction's offset field — no arithmetic per entry;
+      //  * the mirror image: base = the lane's column of this block, or a dump row behind the tiles when its row belongs to another block — one select per
+      //    (tile row, block), not one per entry;
+      //  * a diagonal tile is made symmetric within its quad of lanes first (its upper half comes from the lanes below by DPP): column images only;
+      //  * the way out: which piece of which state a lane sends in each of its stores is the same for every block — worked out once (a division by nv), the
+      //    block is a constant added to the wavefront's base; states past the end of the batch send their last live neighbour's pieces again (no branch).
       using V = f32x4;
-      constexpr int MST = 4 * NV + 4, CB = 4 * NV, PCS = CB / 4;  // values per state of the LDS tile; values / 16-byte pieces per state and block of four columns
+      constexpr int MST = 4 * NV + 4, CB = 4 * NV, PCS = CB / 4, NK = (16 * PCS + 63) / 64;  // values per state of the LDS tile; values / 16-byte pieces per state and block
       float* const mine = mst + (lane >> 2) * MST;
+      float* const dump = mst + 16 * MST + (lane >> 2) * NV;
       const V zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      const long left = B - group * 16;
+      const int nlive = left < 16 ? (int)left : 16;
+      unsigned lo[NK], go[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        int ch = 64 * k + lane;
+        ch = ch < 16 * PCS ? ch : 16 * PCS - 1;
+        int st = ch / PCS;
+        const int piece = ch - st * PCS;
+        st = st < nlive ? st : nlive - 1;
+        lo[k] = (unsigned)(st * MST + piece * 4);
+        go[k] = (unsigned)st * (unsigned)Lc.sb + (unsigned)(piece * 4);
+      }
+#ifdef RBD_SPEC_ABLATE_EMIT_LOCAL  // (timing experiments, spec_variant 1024: every wavefront's M lands on the same 64 states — the stores without the memory behind them)
+      float* const Mw = Mc + ((group * 16) & 63) * Lc.sb;
+#else
+      float* const Mw = Mc + group * 16 * Lc.sb;
+#endif
       sfor<NT>([&](auto Joc) __attribute__((always_inline)) {
         constexpr int Jo = Joc.value;
         wave_sync();  // the tile of the block before has been read out
@@ -1612,34 +1673,27 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
           constexpr int I = Ic.value;
           // does some row of tile row I stand for a coordinate of block Jo (its entries then also land there as the mirror image)?
           constexpr bool rows_in = (P::INV[4 * I] >> 2) == Jo || (P::INV[4 * I + 1] >> 2) == Jo || (P::INV[4 * I + 2] >> 2) == Jo || (P::INV[4 * I + 3] >> 2) == Jo;
-          const bool mir = (od[I] >> 2) == Jo;
-          float* const mrow = mine + (od[I] & 3) * NV;  // mirror image: column od[I] of the block, row = the entry's column coordinate
+          float* const colp = mine + od[I];
+          float* mp = dump;
+          if constexpr (rows_in) mp = ((od[I] >> 2) == Jo) ? mine + (od[I] & 3) * NV : dump;
           sfor<I + 1>([&](auto Jc) __attribute__((always_inline)) {
             constexpr int J = Jc.value;
             if constexpr (P::TMASK[I][J] != 0) {
               sfor<4>([&](auto ccc) __attribute__((always_inline)) {
                 constexpr int cc = ccc.value, co = P::INV[4 * J + cc];  // the entry (od[I], co) of the original matrix
-                const bool part = (I != J) || (cc <= r);                // the diagonal tile holds its lower half
-                // (what does not belong here goes to the tile's spare slot — a select and an unconditional write, not a branch per entry: see the packed form above)
                 if constexpr ((co >> 2) == Jo) {
-                  if constexpr (I != J) mine[(co - 4 * Jo) * NV + od[I]] = t[I][J][cc];
-                  else mine[part ? (co - 4 * Jo) * NV + od[I] : 4 * NV] = t[I][J][cc];
+                  if constexpr (I == J) colp[(co - 4 * Jo) * NV] = diag_entry<cc>(t[I][I], r);
+                  else colp[(co - 4 * Jo) * NV] = t[I][J][cc];
                 }
-                if constexpr (rows_in) {
-                  mine[(mir && part && !(I == J && cc == r)) ? (od[I] & 3) * NV + co : 4 * NV] = t[I][J][cc];
-                }
+                if constexpr (I != J && rows_in) mp[co] = t[I][J][cc];
               });
             }
           });
         });
         wave_sync();
-#pragma unroll 3
-        for (int c0 = 0; c0 < 16 * PCS; c0 += 64) {
-          const int ch = c0 + lane, st = ch / PCS, piece = ch - st * PCS;
-          const long g2 = group * 16 + st;
-          if (ch < 16 * PCS && g2 < B)
-            __builtin_nontemporal_store(*reinterpret_cast<const V*>(mst + st * MST + piece * 4), reinterpret_cast<V*>(Mc + g2 * Lc.sb + (long)Jo * CB + piece * 4));
-        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+          __builtin_nontemporal_store(*reinterpret_cast<const V*>(mst + lo[k]), reinterpret_cast<V*>(Mw + Jo * CB + go[k]));
       });
     }
   }

@@ -379,7 +379,8 @@ def test_code_objects_are_the_kind_the_descriptor_rewrite_knows(rbd, tmp_path, m
     and whose rsrc1 granule covers them.  An object of another kind makes the library step aside to the interpreting kernel, never run with a wrong descriptor."""
     import struct
     monkeypatch.setenv("RBD_JIT_CACHE", str(tmp_path))
-    model = rbd.flatten(rbd.builders.double_pendulum())
+    # (a mechanism nobody else compiles: programs this process has compiled before are remembered in memory and would not be written to the new directory)
+    model = rbd.flatten(rbd.builders.tree_mechanism(np.random.default_rng(987654), [("Revolute", [("Revolute", [("Prismatic", [])])])]))
     ok, log = rbd.jit_precompile(model, torch.float64)
     if ok is None:
         pytest.skip("libhiprtc not available")
