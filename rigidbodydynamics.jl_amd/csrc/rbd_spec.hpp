@@ -1469,6 +1469,8 @@ template <int CC> RBD_DEV float diag_entry(const f32x4& tt, int r) {
     return r >= CC ? tt[CC] : m;
   }
 }
+constexpr int cmin4(int a, int b, int c, int d) { return (a < b ? a : b) < (c < d ? c : d) ? (a < b ? a : b) : (c < d ? c : d); }
+constexpr int cmax4(int a, int b, int c, int d) { return (a > b ? a : b) > (c > d ? c : d) ? (a > b ? a : b) : (c > d ? c : d); }
 // LDS floats of chol_spec's emission: the tiles of 16 states and, behind them, a row per state for the writes that do not belong to the block in hand
 constexpr int chol_emit_lds() { return 16 * (4 * P::NV + 4) + 16 * P::NV; }
 
@@ -1564,17 +1566,17 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
         const int cm = odd ? C1 : C0;
         wave_sync();  // the tile of the block before has been read out
         float carry = 0.0f;
-        if (Jo > 0 && r < cm) carry = mine[4 * (odd ? NP1 : NP0) + r];
+        if constexpr (Jo > 0) carry = mine[4 * (odd ? NP1 : NP0) + r];  // (every lane reads; what it keeps is decided where it is written)
         wave_sync();
         for (int i = lane * 4; i < 16 * MST; i += 256) *reinterpret_cast<f32x4*>(mst + i) = zero;
         wave_sync();
-        if (Jo > 0 && r < cm) mine[r] = carry;
+        if constexpr (Jo > 0) (r < cm ? mine : mst + 16 * MST + (lane >> 2) * NV)[r] = carry;
         // an entry (a, co) of the original matrix goes to column co when it lies on or below the diagonal (a >= co), to column a when above — and only when
         // that column is one of this block's four.  Which of the two is a test per lane (a = od[I] is the lane's row): the address is a select between the
         // lane's base and the state's dump word, the rest of it a constant in the instruction's offset field (the dump's base is taken back by that constant).
         // A diagonal tile is made symmetric within its quad first (diag_entry): column images only.
         float* const cbase = mine + cm;
-        float* const dump0 = mst + 16 * MST + (lane >> 2);
+        float* const dump0 = mst + 16 * MST + (lane >> 2) * NV;  // a row of nv words per state behind the tiles for what does not belong to the block
         sfor<NT>([&](auto Ic) __attribute__((always_inline)) {
           constexpr int I = Ic.value;
           constexpr bool rows_in = (P::INV[4 * I] >> 2) == Jo || (P::INV[4 * I + 1] >> 2) == Jo || (P::INV[4 * I + 2] >> 2) == Jo || (P::INV[4 * I + 3] >> 2) == Jo;
@@ -1583,23 +1585,31 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
           const bool mir = (unsigned)ca < 4u;
           float* const colp = cbase + ca;           // column co, row a: + (start of column co in the block) - (co - j0)
           float* const mirp = cbase + (ca * (NV - j0) - (ca * (ca - 1)) / 2 - ca);  // column a, row co: + (co - j0)
+          float* const mirq = mir ? mirp : dump0;  // (offsets below nv: inside the dump row)
+          constexpr int AMIN = cmin4(P::INV[4 * I], P::INV[4 * I + 1], P::INV[4 * I + 2], P::INV[4 * I + 3]);
+          constexpr int AMAX = cmax4(P::INV[4 * I], P::INV[4 * I + 1], P::INV[4 * I + 2], P::INV[4 * I + 3]);
           sfor<I + 1>([&](auto Jc) __attribute__((always_inline)) {
             constexpr int J = Jc.value;
             if constexpr (P::TMASK[I][J] != 0) {
               sfor<4>([&](auto ccc) __attribute__((always_inline)) {
                 constexpr int cc = ccc.value, co = P::INV[4 * J + cc];  // the entry (a, co) of the original matrix
-                constexpr bool col_here = (co >> 2) == Jo, mir_here = I != J && rows_in && co > j0;
+                // where the four rows of the tile row all lie on one side of co the test is settled here, not per lane (the elimination order keeps most of
+                // the coordinates' order: most tiles)
+                constexpr bool all_ge = AMIN >= co, all_lt = AMAX < co;
+                constexpr bool col_here = (co >> 2) == Jo && !all_lt, mir_here = I != J && rows_in && co > j0 && !all_ge;
                 if constexpr (col_here || mir_here) {
                   float val;
                   if constexpr (I == J) val = diag_entry<cc>(t[I][I], r); else val = t[I][J][cc];
                   const bool ge = a >= co;
                   if constexpr (col_here) {
                     constexpr int cb = co - j0, imm = cb * (NV - j0) - (cb * (cb - 1)) / 2 - cb;
-                    (ge ? colp : dump0 - imm)[imm] = val;
+                    if constexpr (all_ge) colp[imm] = val;
+                    else (ge ? colp : dump0 - imm)[imm] = val;
                   }
                   if constexpr (mir_here) {
                     constexpr int imm2 = co - j0;
-                    ((mir && !ge) ? mirp : dump0 - imm2)[imm2] = val;
+                    if constexpr (all_lt) mirq[imm2] = val;
+                    else ((mir && !ge) ? mirp : dump0 - imm2)[imm2] = val;
                   }
                 }
               });
@@ -1608,12 +1618,19 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
         });
         wave_sync();
 #pragma unroll
-        for (int c0 = 0; c0 < 16 * NMAX; c0 += 64) {  // (32-bit offsets from the wavefront's own base: the address arithmetic is most of what a store costs here)
-          const unsigned ch = (unsigned)(c0 + lane), st = ch / (unsigned)NMAX, pc = ch - st * (unsigned)NMAX, so = st & 1u;
-          const unsigned first = (Jo == 0 && so && A1 != 0) ? 1u : 0u;  // (an odd state's first piece starts with the state before's last two values)
-          if (pc >= first && pc < (so ? (unsigned)N1 : (unsigned)N0) && st < nlive)
-            __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(mst + st * (unsigned)MST + 4u * pc),
-                                        reinterpret_cast<f32x4*>(Mw + (st * (unsigned)NP + (unsigned)P0 - (so ? (unsigned)C1 : (unsigned)C0) + 4u * pc)));
+        for (int c0 = 0; c0 < 16 * NMAX; c0 += 64) {
+          // The way out: the block's pieces dealt out along the lanes, 64 consecutive ones per store — whole runs of a state, 1 KB per instruction.  What the
+          // memory is given per request decides here, not what the wavefront issues: a quad of lanes per state (each store 16 separate 64-byte segments that
+          // start anywhere in their cache lines) needs a fifth of the address arithmetic and took the launch from 84 to 133 us; the lanes without a piece
+          // sending their neighbour's again instead of being switched off: 89.  So: the LDS read for every lane, the store under its predicate; byte offsets in
+          // 32 bits from the wavefront's own base.
+          const unsigned ch0 = (unsigned)(c0 + lane), ch = ch0 < 16u * NMAX ? ch0 : 16u * NMAX - 1u;
+          const unsigned st = ch / (unsigned)NMAX, pc = ch - st * (unsigned)NMAX, so = st & 1u;
+          const unsigned first = (Jo == 0 && so && A1 != 0) ? 1u : 0u;  // (an odd state's first piece starts with the state before's last two values: sent below)
+          const f32x4 piece = *reinterpret_cast<const f32x4*>(mst + st * (unsigned)MST + 4u * pc);
+          const unsigned gb = 4u * (st * (unsigned)NP + (unsigned)P0 - (so ? (unsigned)C1 : (unsigned)C0) + 4u * pc);
+          if (ch0 < 16u * NMAX && pc >= first && pc < (so ? (unsigned)N1 : (unsigned)N0) && st < nlive)
+            __builtin_nontemporal_store(piece, reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Mw) + gb));
         }
         const long gm = group * 16 + (lane >> 2);
         if constexpr (Jo == 0 && A1 != 0) {  // the first two values of an odd state
@@ -1657,7 +1674,7 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
         const int piece = ch - st * PCS;
         st = st < nlive ? st : nlive - 1;
         lo[k] = (unsigned)(st * MST + piece * 4);
-        go[k] = (unsigned)st * (unsigned)Lc.sb + (unsigned)(piece * 4);
+        go[k] = 4u * ((unsigned)st * (unsigned)Lc.sb + (unsigned)(piece * 4));  // in bytes: the store then takes it as its 32-bit offset beside a scalar base
       }
 #ifdef RBD_SPEC_ABLATE_EMIT_LOCAL  // (timing experiments, spec_variant 1024: every wavefront's M lands on the same 64 states — the stores without the memory behind them)
       float* const Mw = Mc + ((group * 16) & 63) * Lc.sb;
@@ -1693,7 +1710,7 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
         wave_sync();
 #pragma unroll
         for (int k = 0; k < NK; ++k)
-          __builtin_nontemporal_store(*reinterpret_cast<const V*>(mst + lo[k]), reinterpret_cast<V*>(Mw + Jo * CB + go[k]));
+          __builtin_nontemporal_store(*reinterpret_cast<const V*>(mst + lo[k]), reinterpret_cast<V*>(reinterpret_cast<char*>(Mw + Jo * CB) + go[k]));
       });
     }
   }
