@@ -1201,8 +1201,6 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
   const bool inside = state0 + 64 * N <= B;  // wave-uniform
   const bool fast = Lq.sk == 1 && Lv.sk == 1 && inside;
   const bool fast_rows = Lq.sb == 1 && Lv.sb == 1 && Lq.sk == B && Lv.sk == B && inside && !fast;
-  // `simulate`: this launch is stage F.stage of a Munthe-Kaas RK4 step (rbd_mk_fuse.hpp).  Its loads of the base point and the running sums go out ahead of the staging
-  constexpr int MKU = (PLAN::MK_N1 * N + PLAN::G - 1) / PLAN::G > 0 ? (PLAN::MK_N1 * N + PLAN::G - 1) / PLAN::G : 1, MKE = (NV * N + PLAN::G - 1) / PLAN::G;
   {
     constexpr int UB = 10 * N;
     if (fast) {
@@ -1218,14 +1216,15 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
       }
     }
   }
-  MkPre<S, MKU> mkp;  // (its loads of the base point and the running sums go out together, ahead of the barrier that ends the staging)
-  if (F.stage >= 0) mk_pre_load<S, PLAN::MK_N1, PLAN::MK_NF, MKU>(F, mkp, mk1, mkf, state0, B, 64 * N, Lq, Lv, tid, nth);
   __syncthreads();
-  // ... the next stage's q from the staged rows before the passes ...
-  auto cell = [&](int row, int st) __attribute__((always_inline)) { return reinterpret_cast<S*>(c.rows + (long)row * WR_STRIDE + (st & 63)) + (st >> 6); };
-  if (F.stage >= 0) {  // uniform
-    mk_prologue<S, PLAN::MK_N1, PLAN::MK_NF, MKU>(F, mkp, cell, mk1, mkf, c.rq, c.rv, c.rt, state0, B, 64 * N, Lq, Lv, tid, nth);
-    if (F.pd) __syncthreads();  // (the PD law wrote into the τ rows)
+  // `simulate`: this launch is stage F.stage of a Munthe-Kaas RK4 step — the lane-is-state form of rbd_mk_fuse.hpp, the whole stage behind the passes (they read
+  // the q and v rows and leave them alone when no q̇ is asked for); only the PD law needs the stage state in front of them
+  // (the rows are LDS: said in the pointer's type, or the stage's stores — behind selects and uniform branches — come out as FLAT instructions)
+  typedef __attribute__((address_space(3))) S* LdsS;
+  auto cell = [&](int row, int st) __attribute__((always_inline)) { return (LdsS)(reinterpret_cast<S*>(c.rows + (long)row * WR_STRIDE + (st & 63)) + (st >> 6)); };
+  if (F.stage >= 0 && F.pd) {  // uniform
+    mk_lane_pd<S, PLAN::MK_N1, PLAN::G, N>(F, cell, mk1, c.rq, c.rv, c.rt, state0, B, Lq, g, lane);
+    __syncthreads();
   }
   // WalkStash addresses accumulation registers by number, which the compiler does not see: rbd_jit.hip checks in the code object's metadata that the register
   // allocator took NONE of its own, then rewrites the kernel descriptor to cover all 256 (jit_kd_cover_agprs) — no `a255` clobber here, the compiler must not
@@ -1235,19 +1234,35 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
     constexpr int GI = decltype(gi)::value;
     if (g == GI) aba_walk_spec_track<T, FLT, GEN, RR, PLAN, GI>(c, B, fext, want_qdot, Lf, state0, lane);
   });
-  MkPost<S, MKE> mkq;
-  if (F.stage >= 0) mk_post_load<S, NV, MKE>(F, mkq, state0, B, 64 * N, Lv, tid, nth);  // (requested while the other tracks finish)
+#ifndef RBD_WALK_NO_STAGE
+  MkLane<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N> mkl;
+  if (F.stage >= 0) mk_lane_load<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N>(F, mkl, mk1, mkf, state0, B, g, lane);  // (requested while the other tracks finish)
   __syncthreads();
-  if (F.stage >= 0) mk_epilogue<S, NV, MKE>(F, mkq, cell, c.rt, state0, B, 64 * N, Lv, tid, nth);  // ... and its v from the v̇ rows behind them
+  S* q_next = nullptr; S* v_next = nullptr;
+  if (F.stage >= 0) {  // uniform
+    mk_lane_stage<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N>(F, mkl, cell, mk1, mkf, c.rq, c.rv, c.rt, state0, B, g, lane);
+    __syncthreads();
+    q_next = (S*)F.q_state; v_next = (S*)F.v_state;  // the kernel's own q / v inputs: this workgroup has read its states' rows, nobody else touches them
+  }
+#else
+  __syncthreads();
+  S* q_next = nullptr; S* v_next = nullptr;
+#endif
   if (fast) {
     walk_stage_out_fast<T, 10 * N>(vdot, state0, NV, c.rows, c.rt, tid, nth);
     walk_stage_out_fast<T, 10 * N>(qdot, state0, NQ, c.rows, c.rq, tid, nth);
+    walk_stage_out_fast<T, 10 * N>(q_next, state0, NQ, c.rows, c.rq, tid, nth);
+    walk_stage_out_fast<T, 10 * N>(v_next, state0, NV, c.rows, c.rv, tid, nth);
   } else if (fast_rows) {
     walk_stage_out_rows<T, 10 * N>(vdot, B, state0, NV, c.rows, c.rt, tid, nth);
     walk_stage_out_rows<T, 10 * N>(qdot, B, state0, NQ, c.rows, c.rq, tid, nth);
+    walk_stage_out_rows<T, 10 * N>(q_next, B, state0, NQ, c.rows, c.rq, tid, nth);
+    walk_stage_out_rows<T, 10 * N>(v_next, B, state0, NV, c.rows, c.rv, tid, nth);
   } else {
     walk_stage_out<T, 10>(vdot, Lv, state0, B, NV, c.rows, c.rt, tid, nth);
     walk_stage_out<T, 10>(qdot, Lq, state0, B, NQ, c.rows, c.rq, tid, nth);
+    walk_stage_out<T, 10>(q_next, Lq, state0, B, NQ, c.rows, c.rq, tid, nth);
+    walk_stage_out<T, 10>(v_next, Lv, state0, B, NV, c.rows, c.rv, tid, nth);
   }
 }
 // ... and rnea_walk_kernel (below) the same way: inverse_dynamics! / dynamics_bias! with the optional per-body outputs
@@ -1316,8 +1331,13 @@ RBD_DEV void rnea_walk_spec_track(const WalkCtx<T>& c, long B, const typename La
               if constexpr (N == 1) { av[k] = ao[k]; jv[k] = jo[k]; }
               else { av[k] = j == 0 ? ao[k].x : ao[k].y; jv[k] = j == 0 ? jo[k].x : jo[k].y; }
             }
-            if (acc_out) store6(acc_out, (long)r.orig6, Lf, st, av, out_vec);
-            if (jw_out) store6(jw_out, (long)r.orig6, Lf, st, jv, out_vec);
+#ifdef RBD_WALK_ABLATE_OUT_LOCAL
+            const long so = st & 63;
+#else
+            const long so = st;
+#endif
+            if (acc_out) store6(acc_out, (long)r.orig6, Lf, so, av, out_vec);
+            if (jw_out) store6(jw_out, (long)r.orig6, Lf, so, jv, out_vec);
           }
         }
       }
