@@ -21,6 +21,16 @@
 
 namespace rbd {
 
+// A pointer that comes out of a struct (or out of a conditional) has lost its address space: the compiler then emits FLAT loads and stores, which count on
+// the LDS counter too — every wait for an LDS read behind them waits for the memory round trip.  Say it in the type.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RBD_GLOBAL_PTR(T) __attribute__((address_space(1))) T*
+#else
+#define RBD_GLOBAL_PTR(T) T*
+#endif
+template <typename T> RBD_DEV RBD_GLOBAL_PTR(T) as_global(T* p) { return (RBD_GLOBAL_PTR(T))p; }
+template <typename T> RBD_DEV RBD_GLOBAL_PTR(const T) as_global(const T* p) { return (RBD_GLOBAL_PTR(const T))p; }
+
 struct MkStage {
   int32_t stage;  // 0..3, or -1: plain dynamics!
   int32_t pd;     // 1: τ −= kp (q − q_des) + kd v on the revolute / prismatic joints, on the stage state
@@ -51,8 +61,7 @@ template <typename S, int N1, int NF, int G, int N> struct MkLane {
 template <typename S, int N1, int NF, int G, int N>
 RBD_DEV void mk_lane_load(const MkStage& F, MkLane<S, N1, NF, G, N>& P, const int32_t* mk1, const int32_t* mkf, long state0, long B, int g, int lane) {
   if (F.stage <= 0) return;
-  const S* __restrict__ q0 = (const S*)F.q0; const S* __restrict__ v0 = (const S*)F.v0;
-  const S* __restrict__ ap = (const S*)F.accp; const S* __restrict__ av = (const S*)F.accv;
+  const auto q0 = as_global((const S*)F.q0), v0 = as_global((const S*)F.v0), ap = as_global((const S*)F.accp), av = as_global((const S*)F.accv);
 #pragma unroll
   for (int u = 0; u < MkLane<S, N1, NF, G, N>::U1; ++u) {
     const int i = g + u * G;  // wave-uniform
@@ -100,7 +109,7 @@ RBD_DEV void mk_lane_stage(const MkStage& F, const MkLane<S, N1, NF, G, N>& P, C
   const S h = (S)F.dt;
   const S bs = (s == 0 || s == 3) ? S(1) / S(6) : S(1) / S(3);
   const S an = s < 2 ? S(0.5) : S(1);
-  S* __restrict__ q0 = (S*)F.q0; S* __restrict__ v0 = (S*)F.v0; S* __restrict__ ap = (S*)F.accp; S* __restrict__ av = (S*)F.accv;
+  const auto q0 = as_global((S*)F.q0), v0 = as_global((S*)F.v0), ap = as_global((S*)F.accp), av = as_global((S*)F.accv);
 #pragma unroll
   for (int u = 0; u < MkLane<S, N1, NF, G, N>::U1; ++u) {
     const int i = g + u * G;
@@ -177,7 +186,7 @@ RBD_DEV void mk_lane_stage(const MkStage& F, const MkLane<S, N1, NF, G, N>& P, C
 // the PD law of rbd_simulate_controlled on the stage state, into the tau rows (in front of the passes; the caller puts a barrier behind it)
 template <typename S, int N1, int G, int N, typename CELL>
 RBD_DEV void mk_lane_pd(const MkStage& F, CELL cell, const int32_t* mk1, int rq, int rv, int rt, long state0, long B, Layout Lq, int g, int lane) {
-  const S* kp = (const S*)F.kp; const S* kd = (const S*)F.kd; const S* qdes = (const S*)F.qdes;
+  const auto kp = as_global((const S*)F.kp), kd = as_global((const S*)F.kd), qdes = as_global((const S*)F.qdes);
   for (int i = g; i < N1; i += G) {
     const int qo = mk1[3 * i], vo = mk1[3 * i + 1], ty = mk1[3 * i + 2];
     if (ty != RBD_JOINT_REVOLUTE && ty != RBD_JOINT_PRISMATIC) continue;

@@ -655,8 +655,8 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   const int mk_s = F.stage;
   const T mk_h = (T)F.dt, mk_bs = (mk_s == 0 || mk_s == 3) ? T(1) / T(6) : T(1) / T(3), mk_an = mk_s < 2 ? T(0.5) : T(1);
   if (mk_s >= 0) {  // uniform
-    T* __restrict__ q0b = (T*)F.q0; T* __restrict__ v0b = (T*)F.v0; T* __restrict__ apb = (T*)F.accp;
-    const T* kp = (const T*)F.kp; const T* kd = (const T*)F.kd; const T* qdes = (const T*)F.qdes;
+    const auto q0b = as_global((T*)F.q0), v0b = as_global((T*)F.v0), apb = as_global((T*)F.accp);  // (global, said in the type: pointers out of a struct come out as FLAT accesses otherwise)
+    const auto kp = as_global((const T*)F.kp), kd = as_global((const T*)F.kd), qdes = as_global((const T*)F.qdes);
     T Q0[NQ > 0 ? NQ : 1], AC[NV > 0 ? NV : 1], QD[NQ > 0 ? NQ : 1];
     if (mk_s > 0) {
 #pragma unroll
@@ -705,7 +705,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
       }
     });
     wave_sync();
-    rows_out<T, NQ>(rx, (T*)F.q_state, Lq, state0, B);  // the kernel's own q input: this wavefront has read its block, nobody else touches it
+    rows_out<T, NQ>(rx, const_cast<T*>(q), Lq, state0, B);  // F.q_state IS the kernel's own q input (its address space is known): this wavefront has read its block, nobody else touches it
     wave_sync();  // (the spare rows are used again below; the PD law wrote into the τ rows)
   }
   // q̇ (configuration_derivative!, src/mechanism_state.jl:905-910) depends on q and v alone: assembled in the spare rows and sent off before the
@@ -753,7 +753,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
     wave_sync();
   }
   const long sc = state0 + lane < B ? state0 + lane : B - 1;
-  const T* fel = fext ? fext + sc * Lf.sb : nullptr;
+  const auto fel = as_global(fext ? fext + sc * Lf.sb : nullptr);  // (behind the conditional the pointer has lost its address space: FLAT loads, counted on the LDS counter too)
   const long fsk = Lf.sk;
   // the world's acceleration: -g (mechanism_algorithms.jl:396); a kernel argument, not the plan's constant: M^-1 rhs is this pass with g = 0 (rbd_mass_matrix_solve)
   const T a0[6] = {T(0), T(0), T(0), -gx, -gy, -gz};
@@ -1154,7 +1154,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   });
   wave_sync();
   if (mk_s >= 0) {  // the next v from the v̇ rows, through the v rows (free by now)
-    const T* __restrict__ v0b = (const T*)F.v0; T* __restrict__ avb = (T*)F.accv;
+    const auto v0b = as_global((const T*)F.v0); const auto avb = as_global((T*)F.accv);
     T V0[NV > 0 ? NV : 1], AV[NV > 0 ? NV : 1];
     wave_sync();  // (every lane is done with the v rows of the top-down pass)
     if (mk_s > 0) {
@@ -1163,7 +1163,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
       for (int k = 0; k < NV; ++k) AV[k] = avb[(long)k * B + mk_si];
     } else {  // stage 0: the base point is still in the kernel's own v input (the passes have used its rows for other things)
-      rows_in<T, NV>((const T*)F.v_state, Lv, state0, B, rv);
+      rows_in<T, NV>(v, Lv, state0, B, rv);  // (F.v_state is v)
       wave_sync();
 #pragma unroll
       for (int k = 0; k < NV; ++k) V0[k] = vs[k * RS];
@@ -1176,7 +1176,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
       vs[k * RS] = V0[k] + mk_h * (mk_s < 3 ? mk_an * vd : sum);
     }
     wave_sync();
-    rows_out<T, NV>(rv, (T*)F.v_state, Lv, state0, B);
+    rows_out<T, NV>(rv, const_cast<T*>(v), Lv, state0, B);
   }
   if (vdot) rows_out<T, NV>(rt, vdot, Lv, state0, B);
 }
@@ -1222,11 +1222,11 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
   T* ts = rt + lane;
   const bool live = state0 + lane < B;
   const long sc = live ? state0 + lane : B - 1;
-  const T* fel = fext ? fext + sc * Lf.sb : nullptr;
+  const auto fel = as_global(fext ? fext + sc * Lf.sb : nullptr);  // (behind the conditional the pointer has lost its address space: FLAT loads, counted on the LDS counter too)
   const long fsk = Lf.sk;
   // DIRECT: this lane's columns of v, v̇, tau
   const T* vg = v + sc * Lv.sb;
-  const T* ag = vdot ? vdot + sc * Lv.sb : nullptr;
+  const auto ag = as_global(vdot ? vdot + sc * Lv.sb : nullptr);
   T* tg = tau + sc * Lv.sb;
   const long vsk = Lv.sk;
   T nv6[6], na6[6];          // DIRECT: velocity / acceleration coordinates of the next body to be entered (more than one: 3- / 6-dof joints)

@@ -825,8 +825,8 @@ __device__ __forceinline__ void walk_stage_in_fast(const typename Lanes<T>::S* _
   using S = typename Lanes<T>::S;
   constexpr int N = Lanes<T>::N;
   const S* bq = q + state0 * nq;
-  const S* bv = v ? v + state0 * nv : nullptr;
-  const S* bt = tau ? tau + state0 * nv : nullptr;
+  const auto bv = as_global(v ? v + state0 * nv : nullptr);    // (behind the conditional the pointer has lost its address space: the rows' loads would be
+  const auto bt = as_global(tau ? tau + state0 * nv : nullptr);  //  FLAT instructions)
   S* cells = reinterpret_cast<S*>(rows);
   const int totq = nq * 64 * N, totv = nv * 64 * N, tot = totq > totv ? totq : totv;
   WalkCursor<N> cq, cv;
@@ -986,11 +986,11 @@ __global__ __launch_bounds__(256) void aba_walk_kernel(WalkModel M, long B, cons
   const bool want_qdot = qdot != nullptr;
   // external wrenches: requested from global memory a step ahead (one load per state of the lane)
   const long fsk = Lf.sk;
-  const S* fel[N];
+  RBD_GLOBAL_PTR(const S) fel[N];  // (global, said in the type: behind the conditional below the compiler would emit FLAT loads)
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     const long st = state0 + 64 * j + lane;
-    fel[j] = fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr;
+    fel[j] = as_global(fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr);
   }
   auto wrench = [&](int o6, T* f) {
 #pragma unroll
@@ -1119,11 +1119,11 @@ RBD_DEV void aba_walk_spec_track(const WalkCtx<T>& c, long B, const typename Lan
   WalkStash<T> St;
   walk_init(W);
   const long fsk = Lf.sk;
-  const S* fel[N];
+  RBD_GLOBAL_PTR(const S) fel[N];  // (global, said in the type: behind the conditional below the compiler would emit FLAT loads)
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     const long st = state0 + 64 * j + lane;
-    fel[j] = fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr;
+    fel[j] = as_global(fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr);
   }
   auto wrench = [&](int o6, T* f) __attribute__((always_inline)) {
 #pragma unroll
@@ -1238,32 +1238,31 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
   MkLane<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N> mkl;
   if (F.stage >= 0) mk_lane_load<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N>(F, mkl, mk1, mkf, state0, B, g, lane);  // (requested while the other tracks finish)
   __syncthreads();
-  S* q_next = nullptr; S* v_next = nullptr;
+  // rows [row0, row0 + n) out to dst in the caller's layout (dst nullable)
+  auto send = [&](S* dst, Layout L, int n, int row0) __attribute__((always_inline)) {
+    if (fast) walk_stage_out_fast<T, 10 * N>(dst, state0, n, c.rows, row0, tid, nth);
+    else if (fast_rows) walk_stage_out_rows<T, 10 * N>(dst, B, state0, n, c.rows, row0, tid, nth);
+    else walk_stage_out<T, 10>(dst, L, state0, B, n, c.rows, row0, tid, nth);
+  };
   if (F.stage >= 0) {  // uniform
     mk_lane_stage<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N>(F, mkl, cell, mk1, mkf, c.rq, c.rv, c.rt, state0, B, g, lane);
     __syncthreads();
-    q_next = (S*)F.q_state; v_next = (S*)F.v_state;  // the kernel's own q / v inputs: this workgroup has read its states' rows, nobody else touches them
+    // F.q_state / F.v_state ARE the kernel's own q / v inputs (the arguments' address space is known to the compiler, that of the struct's pointers is not —
+    // and neither is that of a pointer that was null on another path: the stores would come out as FLAT instructions): this workgroup has read its states'
+    // rows, nobody else touches them
+    send(const_cast<S*>(q), Lq, NQ, c.rq);
+    send(const_cast<S*>(v), Lv, NV, c.rv);
   }
 #else
   __syncthreads();
-  S* q_next = nullptr; S* v_next = nullptr;
+  auto send = [&](S* dst, Layout L, int n, int row0) __attribute__((always_inline)) {
+    if (fast) walk_stage_out_fast<T, 10 * N>(dst, state0, n, c.rows, row0, tid, nth);
+    else if (fast_rows) walk_stage_out_rows<T, 10 * N>(dst, B, state0, n, c.rows, row0, tid, nth);
+    else walk_stage_out<T, 10>(dst, L, state0, B, n, c.rows, row0, tid, nth);
+  };
 #endif
-  if (fast) {
-    walk_stage_out_fast<T, 10 * N>(vdot, state0, NV, c.rows, c.rt, tid, nth);
-    walk_stage_out_fast<T, 10 * N>(qdot, state0, NQ, c.rows, c.rq, tid, nth);
-    walk_stage_out_fast<T, 10 * N>(q_next, state0, NQ, c.rows, c.rq, tid, nth);
-    walk_stage_out_fast<T, 10 * N>(v_next, state0, NV, c.rows, c.rv, tid, nth);
-  } else if (fast_rows) {
-    walk_stage_out_rows<T, 10 * N>(vdot, B, state0, NV, c.rows, c.rt, tid, nth);
-    walk_stage_out_rows<T, 10 * N>(qdot, B, state0, NQ, c.rows, c.rq, tid, nth);
-    walk_stage_out_rows<T, 10 * N>(q_next, B, state0, NQ, c.rows, c.rq, tid, nth);
-    walk_stage_out_rows<T, 10 * N>(v_next, B, state0, NV, c.rows, c.rv, tid, nth);
-  } else {
-    walk_stage_out<T, 10>(vdot, Lv, state0, B, NV, c.rows, c.rt, tid, nth);
-    walk_stage_out<T, 10>(qdot, Lq, state0, B, NQ, c.rows, c.rq, tid, nth);
-    walk_stage_out<T, 10>(q_next, Lq, state0, B, NQ, c.rows, c.rq, tid, nth);
-    walk_stage_out<T, 10>(v_next, Lv, state0, B, NV, c.rows, c.rv, tid, nth);
-  }
+  send(vdot, Lv, NV, c.rt);
+  send(qdot, Lq, NQ, c.rq);
 }
 // ... and rnea_walk_kernel (below) the same way: inverse_dynamics! / dynamics_bias! with the optional per-body outputs
 template <typename T, bool FLT, bool GEN, typename PLAN, int GI>
@@ -1275,11 +1274,11 @@ RBD_DEV void rnea_walk_spec_track(const WalkCtx<T>& c, long B, const typename La
   WalkStash<T> St;
   walk_init(W);
   const long fsk = Lf.sk;
-  const S* fel[N];
+  RBD_GLOBAL_PTR(const S) fel[N];  // (global, said in the type: behind the conditional below the compiler would emit FLAT loads)
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     const long st = state0 + 64 * j + lane;
-    fel[j] = fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr;
+    fel[j] = as_global(fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr);
   }
   auto wrench = [&](int o6, T* f) __attribute__((always_inline)) {
 #pragma unroll
@@ -1466,11 +1465,11 @@ __global__ __launch_bounds__(256) void rnea_walk_kernel(WalkModel M, long B, con
   const bool want_qdot = qdot != nullptr;
   // external wrenches: requested from global memory a step ahead (one load per state of the lane)
   const long fsk = Lf.sk;
-  const S* fel[N];
+  RBD_GLOBAL_PTR(const S) fel[N];  // (global, said in the type: behind the conditional below the compiler would emit FLAT loads)
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     const long st = state0 + 64 * j + lane;
-    fel[j] = fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr;
+    fel[j] = as_global(fext ? fext + (st < B ? st : B - 1) * Lf.sb : nullptr);
   }
   auto wrench = [&](int o6, T* f) {
 #pragma unroll
