@@ -580,18 +580,20 @@ def test_simulate_stage_folded_in_on_every_joint_type(rbd, oracle, models, name,
 
 
 @pytest.mark.parametrize("layout", ["aos", "soa"])
-@pytest.mark.parametrize("kernel", ["walk_spec_f64", "walk_spec_f32", "walk_spec_f32x2", "aba_spec_f32"])
-def test_simulate_stage_folded_into_the_compiled_kernels(rbd, oracle, models, kernel, layout, monkeypatch):
+@pytest.mark.parametrize("kernel,name", [("walk_spec_f64", "atlas_floating"), ("walk_spec_f32", "atlas_floating"), ("walk_spec_f32x2", "atlas_floating"), ("aba_spec_f32", "atlas_floating"),
+                                         ("walk_spec_f32", "limbs_humanoid"), ("walk_spec_f32x2", "limbs_humanoid"), ("walk_spec_f64", "limbs_only_children")])
+def test_simulate_stage_folded_into_the_compiled_kernels(rbd, oracle, models, kernel, name, layout, monkeypatch):
     """Large batches: the Munthe-Kaas stage of `simulate` (src/ode_integrators.jl:233-299) inside the dynamics! kernels compiled for the mechanism
     (csrc/rbd_mk_fuse.hpp: four launches per step, no stage kernels) — forced at a small ragged batch so that states can be compared with the numpy
     restatement of the integrator: Atlas with its floating base (the SE(3) log / exp path), constant torques, the torque table at the stage times, the PD law
-    on the stage state; fp64 at 1e-10, fp32 against the fp64 oracle."""
+    on the stage state; fp64 at 1e-10, fp32 against the fp64 oracle.  limbs_humanoid / limbs_only_children: the same through prismatic, sin-cos and fixed joints
+    (the sin-cos joint's two coordinates per velocity in the stage's arithmetic; the PD law leaves sin-cos joints alone)."""
     import simulate_np
     dtype = "f64" if kernel.endswith("f64") else "f32"
     knobs = dict(walk_min_batch=1, spec_walk_min_batch=1, walk_pair_min_batch=1 if kernel == "walk_spec_f32x2" else 1 << 40,
                  spec_aba_min_batch=1 if kernel == "aba_spec_f32" else 1 << 40)
     tune(monkeypatch, **knobs)
-    model = models["atlas_floating"]
+    model = models[name]
     B, dt, nsteps = 70, 1e-3, 3
     T = (nsteps - 0.5) * dt
     state, q, v, tau, _ = make(rbd, model, B, dtype, layout, 91, fext=False)
@@ -633,7 +635,7 @@ def test_simulate_stage_folded_into_the_compiled_kernels(rbd, oracle, models, ke
     tff = rng.random((B, model.nv)).astype(ND[dtype]).astype(np.float64)
     reset()
     rbd.simulate_(state, T, control_=rbd.PDControl(torch.as_tensor(kp), torch.as_tensor(kd), dev(qdes, state), dev(tff, state)), dt=dt)
-    one = np.array([0.0 if t == 3 else 1.0 for t in model.joint_type for _ in range({0: 0, 3: 6}.get(int(t), 1))])  # 1-dof coordinates (v indexing)
+    one = np.array([1.0 if t in (1, 2) else 0.0 for t in model.joint_type for _ in range({0: 0, 3: 6}.get(int(t), 1))])  # revolute / prismatic coordinates (v indexing)
     qidx = np.array([int(model.q_offset[b]) for b in range(model.n_bodies) for _ in range({0: 0, 3: 6}.get(int(model.joint_type[b]), 1))])  # q coordinate of a 1-dof v coordinate
 
     def pd(b, t, qq, vv):
