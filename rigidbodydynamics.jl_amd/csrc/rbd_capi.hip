@@ -3,6 +3,7 @@
 // every hot-path entry point launches HIP kernels or fails with a status code.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <cmath>
 #include <unistd.h>
 
 #include <algorithm>
@@ -125,8 +126,9 @@ struct rbd_ws {
   int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
   bool spec_bank_tried = false; hipModule_t spec_bank_mod = nullptr; hipFunction_t spec_bank_aba = nullptr, spec_bank_fused = nullptr, spec_bank_rnea = nullptr; std::string spec_bank_src;  // the banked kernels compiled for the mechanism
-  std::string spec_src[SPEC_FAMILIES], spec_loop_src, spec_walk_src[8];  // the programs' sources while their compilation is pending (generated once)
-  bool spec_walk_tried[8] = {}; hipModule_t spec_walk_mod[8] = {}; hipFunction_t spec_walk[8] = {};  // [inverse dynamics][re-rooted tree][two fp32 states per lane]
+  std::string spec_src[SPEC_FAMILIES], spec_loop_src, spec_walk_src[12];  // the programs' sources while their compilation is pending (generated once)
+  bool spec_walk_tried[12] = {}; hipModule_t spec_walk_mod[12] = {}; hipFunction_t spec_walk[12] = {};  // [dynamics! | inverse dynamics | dynamics!, four `simulate` stages per launch][re-rooted tree][two fp32 states per lane]
+  int sim_loop_checked[4] = {};  // [two fp32 states per lane][external wrenches]: 0 not yet, 1 the four-stages-per-launch kernel agrees with the single-stage one, -1 it does not (never used then)
   bool no_reroot = false, loop_no_fused = false; int spec_max_scratch = 512;  // RBD_TUNE: walk_no_reroot, loop_no_fused (tests: the original tree / the three-launch loop route), spec_max_scratch (spilled bytes per lane above which a compiled kernel steps aside)
   bool spec_walk_f32 = true;  // fp32 batches through the compiled walk kernels too (RBD_SPEC_WALK_F32=0: not)
   std::vector<double> loop_gains; bool custom_gains = false;  // rbd_workspace_set_loop_gains: this workspace's Baumgarte gains (4 per loop joint), and whether they differ from the model's
@@ -187,7 +189,9 @@ int rbd_version(void) { return RBD_HIP_H_VERSION; }
 // run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
 // the source of one program of a model (families as in include/rbd_hip.h); empty: no such program for this mechanism
 static std::string program_source(const rbd_model* m, int32_t dtype, int32_t family) {
-  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 5) return std::string();
+  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 7) return std::string();
+  if (family == SPEC_FAMILIES + 6) return walk_program_source(m, dtype, walk_program_rerooted(m, dtype), 2);  // (family 9: family 4 with the four stages of a `simulate` step in one launch)
+  if (family == SPEC_FAMILIES + 7) return dtype == RBD_F32 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype, 1), 2, 1) : std::string();  // (family 10: family 6 likewise)
   std::vector<int32_t> xi;
   if (family < SPEC_FAMILIES && !m->spec_plan().ok) return std::string();
   if (family == SPEC_FAMILIES + 5) return bank_program_source(m, dtype, bank_simple(m));  // (family 8: the two-bodies-per-lane kernels)
@@ -198,7 +202,7 @@ static std::string program_source(const rbd_model* m, int32_t dtype, int32_t fam
          : family == SPEC_FAMILIES ? loop_program_source(m, dtype, &xi)  // (family 3: the program of a small loop mechanism)
                                    : spec_source(m->spec_plan(), m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, family);
 }
-static bool family_is_walk(int family) { return family > SPEC_FAMILIES && family <= SPEC_FAMILIES + 4; }
+static bool family_is_walk(int family) { return (family > SPEC_FAMILIES && family <= SPEC_FAMILIES + 4) || family == SPEC_FAMILIES + 6 || family == SPEC_FAMILIES + 7; }
 int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char* buf, int64_t cap) {
   const std::string s = program_source(m, dtype, family);
   if (s.empty()) return -1;
@@ -223,7 +227,7 @@ int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t c
   // the model's programs of this scalar type, the longest compilations first; every one of them on its own background thread (rbd_jit.hip), then wait for all
   struct Job { std::string src; bool walk; int family; int state; double seconds; std::string log; };
   std::vector<Job> jobs;
-  for (int family : {4, 5, 6, 7, 8, 0, 1, 2, 3})
+  for (int family : {4, 9, 5, 6, 10, 7, 8, 0, 1, 2, 3})
     jobs.push_back({program_source(m, dtype, family), family_is_walk(family), family, JIT_PENDING, 0.0, std::string()});
   // RBD_JIT_PRECOMPILE_PART = "k/n": only every n-th program, starting with the k-th — n processes share a model's compilations
   int part = 0, parts = 1;
@@ -1015,7 +1019,7 @@ int rbd_workspace_destroy(rbd_ws_t* w) {
   for (hipModule_t mod : w->spec_mod) if (mod) (void)hipModuleUnload(mod);
   if (w->spec_loop_mod) (void)hipModuleUnload(w->spec_loop_mod);
   if (w->spec_bank_mod) (void)hipModuleUnload(w->spec_bank_mod);
-  for (int k = 0; k < 8; ++k) if (w->spec_walk_mod[k]) (void)hipModuleUnload(w->spec_walk_mod[k]);
+  for (int k = 0; k < 12; ++k) if (w->spec_walk_mod[k]) (void)hipModuleUnload(w->spec_walk_mod[k]);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   delete w;
@@ -1237,7 +1241,7 @@ static std::string walk_program_source(const rbd_model* m, int dtype, bool reroo
 static bool capturing(rbd_ws* w);
 // aba_walk_kernel compiled for the mechanism (aba_walk_spec of rbd_walk.hpp): nullptr when unavailable (or while it is being compiled)
 static hipFunction_t spec_walk(rbd_ws* w, bool rerooted, int kind = 0, int pair = 0) {
-  const int k = (kind ? 4 : 0) + (rerooted ? 2 : 0) + (pair ? 1 : 0);
+  const int k = 4 * kind + (rerooted ? 2 : 0) + (pair ? 1 : 0);  // kind 0: dynamics!, 1: inverse dynamics, 2: dynamics! with the four stages of a `simulate` step in one launch
   if (w->spec_walk_tried[k]) return w->spec_walk[k];
   if (!jit_available()) { w->spec_walk_tried[k] = true; return nullptr; }
   if (capturing(w)) return nullptr;
@@ -1251,7 +1255,7 @@ static hipFunction_t spec_walk(rbd_ws* w, bool rerooted, int kind = 0, int pair 
   w->spec_walk_tried[k] = true;
   if (js == JIT_FAILED || code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernel is used): " + log; src.clear(); src.shrink_to_fit(); return nullptr; }
   if (hipModuleLoadData(&w->spec_walk_mod[k], code.data()) != hipSuccess) { (void)hipGetLastError(); w->spec_walk_mod[k] = nullptr; jit_cache_discard(src); return nullptr; }
-  const std::string fname = std::string(kind ? "rnea_walk_spec_" : "aba_walk_spec_") + walk_spec_suffix(w->dtype, pair);
+  const std::string fname = std::string(kind == 1 ? "rnea_walk_spec_" : kind == 2 ? "aba_walk_sim_spec_" : "aba_walk_spec_") + walk_spec_suffix(w->dtype, pair);
   if (hipModuleGetFunction(&w->spec_walk[k], w->spec_walk_mod[k], fname.c_str()) != hipSuccess) { (void)hipGetLastError(); w->spec_walk[k] = nullptr; }
   int scratch = 0;
   const int max_scratch = w->spec_max_scratch;  // bytes per lane
@@ -1473,7 +1477,7 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
 // The fused articulated-body pass through whichever lane mapping fits: `algorithm` RBD_ALGO_ABA chooses by batch size
 // (measured crossovers, profiles/r01_mapping_sweep.txt), the RBD_ALGO_ABA_* values force one.  `gravity` overrides the
 // model's (the M^-1 solve runs the pass with g = 0); `fuse` folds a Munthe-Kaas stage into the launch (lanes / banks only).
-static const MkStage kNoStage{-1, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+static const MkStage kNoStage{-1, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
 // `mk` (simulate_core): the launch is a stage of a Munthe-Kaas step folded into a kernel compiled for the mechanism (rbd_mk_fuse.hpp) — only those kernels take it:
 // RBD_ERR_UNSUPPORTED when the batch would go to another kernel (the caller then keeps the stage in its own launches)
 static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd,
@@ -1487,7 +1491,7 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   if (algorithm == RBD_ALGO_ABA_PIPE || algorithm == RBD_ALGO_ABA_TRACKS || algorithm == RBD_ALGO_ABA_CHAINS) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
-  if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !fuse && w->dtype == RBD_F32) {
+  if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !fuse && w->dtype == RBD_F32 && !(mk && mk->stage == 4)) {  // (all four stages in one launch: the walk kernels only)
     // with the integrator stage folded in, the lane-per-state kernel is ahead of the walk kernel earlier than without it (Atlas fp32, RK4 step: 24 576 states
     // 209 against 226 us, 32 768: 220 against 240; 16 384: 201 against 143) — the stage costs this kernel 10 us per launch, the walk kernel 28
     const long spec_from = mk ? std::min<long>(w->spec_aba_min_batch, w->spec_aba_fused_min_batch) : w->spec_aba_min_batch;
@@ -1530,7 +1534,8 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     w->last_kernel = pair ? "aba_walk_kernel (two fp32 states per lane)" : "aba_walk_kernel";
     const TrackPlan& TP = rr ? m->rrs.track : m->track;
     const size_t lds = rr ? (pair ? w->walk_rr_lds_bytes_pair : w->walk_rr_lds_bytes) : (pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes);
-    if (hipFunction_t f = ((w->dtype == RBD_F64 || w->spec_walk_f32) && B >= w->spec_walk_min_batch) ? spec_walk(w, rr, 0, pair) : nullptr) {  // the same kernel compiled for this mechanism
+    const int wkind = (mk && mk->stage == 4) ? 2 : 0;  // (all four stages of a `simulate` step in one launch: the instantiation with the passes inside a loop)
+    if (hipFunction_t f = ((w->dtype == RBD_F64 || w->spec_walk_f32) && B >= w->spec_walk_min_batch) ? spec_walk(w, rr, wkind, pair) : nullptr) {  // the same kernel compiled for this mechanism
       w->last_kernel = pair ? "aba_walk_spec (compiled for the mechanism, two fp32 states per lane)" : "aba_walk_spec (compiled for the mechanism)";
       long Bl = B;
       Layout lq = Lq, lv = Lv, lf = Lf;
@@ -2058,6 +2063,69 @@ int rbd_mk_stage(rbd_ws_t* w, int32_t B, int32_t stage, double dt, void* q, void
 }
 
 // simulate with a controller descriptor (rbd_simulate: constant τ)
+// The walk kernel that takes the four stages of a `simulate` step in one launch has its passes inside a loop, and the register allocator of THAT program takes
+// accumulation registers of its own (rbd_jit.hip accepts it, by its marker).  The passes' stash addresses accumulation registers by number behind the
+// compiler's back: fine as long as the allocator's live only between the passes (where the stash is dead) — as they do in every program looked at, but nothing
+// in a code object's metadata says so.  So the kernel is RUN before it is used: one step of the first states of the caller's own batch (a ragged two
+// workgroups' worth, same layout, with or without external wrenches as the call has them: the passes have no other branches) through the single-stage kernel,
+// four launches, and through this one, one launch; they must agree.  1: they do; -1: they do not (the kernel is never used by this workspace); 0: could not
+// be checked now (a kernel still being compiled, a stream being captured).
+static int sim_loop_check(rbd_ws* w, int32_t B, const void* dq, const void* dv, const void* dtau, const void* df, double dt, const Opts& o, int pair) {
+  const rbd_model* m = w->model;
+  const size_t es = esize(w);
+  if (capturing(w)) return 0;
+  // (the check's small batch must go to the very kernels the call's batch goes to: the batch thresholds stand aside while it runs)
+  struct Thresholds {
+    rbd_ws* w; long a, b;
+    Thresholds(rbd_ws* w_, int pair_) : w(w_), a(w_->spec_walk_min_batch), b(w_->walk_pair_min_batch) { w->spec_walk_min_batch = 1; w->walk_pair_min_batch = pair_ ? 1 : ((long)1 << 40); }
+    ~Thresholds() { w->spec_walk_min_batch = a; w->walk_pair_min_batch = b; }
+  } thresholds(w, pair);
+  const int32_t Bt = std::min<int32_t>(B, 200);
+  const Layout Lq = layout_of(o.layout, m->nq, Bt), Lv = layout_of(o.layout, m->nv, Bt), Lf = layout_of(o.layout, 6L * m->nb, Bt);
+  const size_t nq = es * (size_t)m->nq * Bt, nv = es * (size_t)m->nv * Bt, nf = es * 6 * (size_t)m->nb * Bt;
+  char* buf = nullptr;
+  if (hipMalloc((void**)&buf, 2 * nq + 3 * nv + nf + 64) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  char *q0 = buf, *q1 = q0 + nq, *v0 = q1 + nq, *v1 = v0 + nv, *tt = v1 + nv, *ff = tt + nv;
+  // the first Bt states of the caller's buffers: contiguous when a state's coordinates are (RBD_LAYOUT_AOS), one run per coordinate otherwise
+  auto take = [&](char* dst, const void* src, long n) -> hipError_t {
+    if (o.layout == RBD_LAYOUT_AOS) return hipMemcpyAsync(dst, src, es * (size_t)n * Bt, hipMemcpyDeviceToDevice, w->stream);
+    return hipMemcpy2DAsync(dst, es * (size_t)Bt, src, es * (size_t)B, es * (size_t)Bt, (size_t)n, hipMemcpyDeviceToDevice, w->stream);
+  };
+  int verdict = 0;
+  std::vector<char> h0(nq + nv), h1(nq + nv);
+  do {
+    if (take(q0, dq, m->nq) != hipSuccess || take(q1, dq, m->nq) != hipSuccess || take(v0, dv, m->nv) != hipSuccess || take(v1, dv, m->nv) != hipSuccess) break;
+    if (dtau) { if (take(tt, dtau, m->nv) != hipSuccess) break; }
+    if (df) { if (take(ff, df, 6L * m->nb) != hipSuccess) break; }
+    const void* tp = dtau ? tt : nullptr; const void* fp = df ? ff : nullptr;
+    int st = RBD_OK;
+    for (int stage = 0; stage < 4 && st == RBD_OK; ++stage) {
+      const MkStage F{stage, 0, dt, w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.vd[0], q0, v0, nullptr, nullptr, nullptr, 0};
+      st = run_aba(w, Bt, RBD_ALGO_ABA_WALK, q0, v0, tp, fp, nullptr, nullptr, Lq, Lv, Lf, nullptr, nullptr, &F);
+    }
+    if (st != RBD_OK) break;  // (RBD_ERR_UNSUPPORTED: the single-stage kernel is not there yet)
+    const MkStage F4{4, 0, dt, w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.vd[0], q1, v1, nullptr, nullptr, nullptr, 0};
+    if (run_aba(w, Bt, RBD_ALGO_ABA_WALK, q1, v1, tp, fp, nullptr, nullptr, Lq, Lv, Lf, nullptr, nullptr, &F4) != RBD_OK) break;
+    if (hipMemcpyAsync(h0.data(), q0, nq, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipMemcpyAsync(h0.data() + nq, v0, nv, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+        hipMemcpyAsync(h1.data(), q1, nq, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipMemcpyAsync(h1.data() + nq, v1, nv, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+        hipStreamSynchronize(w->stream) != hipSuccess) break;
+    // the two programs are compiled apart (their multiply-adds need not be fused alike): agreement to rounding, not bit for bit
+    double worst = 0.0;
+    const size_t n = (nq + nv) / es;
+    for (size_t i = 0; i < n; ++i) {
+      const double a = w->dtype == RBD_F64 ? ((const double*)h0.data())[i] : (double)((const float*)h0.data())[i];
+      const double b = w->dtype == RBD_F64 ? ((const double*)h1.data())[i] : (double)((const float*)h1.data())[i];
+      const double d = std::fabs(a - b) / std::max(1.0, std::fabs(a));
+      worst = (d == d) ? std::max(worst, d) : 1e300;  // (a NaN on either side)
+    }
+    verdict = worst <= (w->dtype == RBD_F64 ? 1e-9 : 2e-4) ? 1 : -1;
+    if (verdict < 0) g_last_hip_error = "simulate: the kernel that takes four stages per launch disagrees with the single-stage kernel on the batch's first states (not used)";
+  } while (false);
+  (void)hipGetLastError();
+  (void)hipStreamSynchronize(w->stream);
+  (void)hipFree(buf);
+  return verdict;
+}
 static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_control_t& ctl, const void* fext, double dt, int32_t nsteps, const rbd_opts_t* opts) {
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
@@ -2106,6 +2174,34 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   // in the background must not move a step from one kernel to the other between two of its stages.
   int sim_algo = RBD_ALGO_ABA;
   bool sim_lane_per_state = false;
+  // the walk kernel compiled for the mechanism takes ALL FOUR stages of a step in one launch (rbd_walk.hpp aba_walk_spec, MkStage::stage = 4): the stage states
+  // never leave its LDS rows.  Tried first where the lane-per-state kernel is not in line for the batch; RBD_ERR_UNSUPPORTED (the program is not compiled yet,
+  // or the batch goes elsewhere) leaves everything untouched for the routes below.
+  bool one_launch = try_spec_sim && walk_sim && !lane_per_state_sim && tune("sim_one_launch", 1) != 0;
+  if (one_launch) {  // checked against the single-stage kernel before its first use (sim_loop_check)
+    const int pairv = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
+    int& chk = w->sim_loop_checked[2 * pairv + (df ? 1 : 0)];
+    if (chk == 0) chk = sim_loop_check(w, B, dq, dv, tau_at(0, 0), df, dt, o, pairv);
+    one_launch = chk == 1;
+  }
+  if (one_launch) {
+    const bool per_stage = ctl.kind == RBD_CONTROL_TABLE && ctl.per_stage;
+    bool ok = true;
+    for (int step = 0; step < nsteps; ++step) {
+      MkStage F{4, pd ? 1 : 0, dt, w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.vd[0], dq, dv, ctl.kp, ctl.kd, ctl.q_des, 0};
+      F.tau_stride = per_stage ? (int64_t)m->nv * B : 0;
+      st = run_aba(w, B, RBD_ALGO_ABA_WALK, dq, dv, tau_at(step, 0), df, nullptr, nullptr, Lq, Lv, Lf, nullptr, nullptr, &F);
+      if (st == RBD_ERR_UNSUPPORTED && step == 0) { ok = false; break; }
+      if (st) return st;
+    }
+    if (ok) {
+      w->last_kernel = "aba_walk_spec with the Munthe-Kaas stage folded in (compiled for the mechanism; four stages per launch)";
+      if (o.memory == RBD_MEM_HOST) {
+        if ((st = stage_out_copy(w, q, dq, es * m->nq * B)) || (st = stage_out_copy(w, v, dv, es * m->nv * B))) return st;
+      }
+      return RBD_OK;
+    }
+  }
   for (int step = 0; try_spec_sim && step < nsteps; ++step) {
     for (int stage = 0; stage < 4; ++stage) {
       const MkStage F{stage, pd ? 1 : 0, dt, w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.vd[0], dq, dv, ctl.kp, ctl.kd, ctl.q_des};

@@ -1184,7 +1184,11 @@ RBD_DEV void aba_walk_spec_track(const WalkCtx<T>& c, long B, const typename Lan
     RBD_WALK_STEP_FENCE();
   });
 }
-template <typename T, bool FLT, bool GEN, bool RR, typename PLAN>
+// LOOP: the instantiation that takes all four stages of a `simulate` step in one launch (MkStage::stage = 4) — its passes stand inside a loop, which changes
+// what the register allocator does with the whole kernel (it takes accumulation registers of its own: rbd_jit.hip accepts that for this instantiation only,
+// and the library checks it against the single-stage instantiation on the first states of the first batch before it is used: rbd_capi.hip).  The other
+// instantiation is straight-line code as before and serves everything else.
+template <typename T, bool FLT, bool GEN, bool RR, typename PLAN, bool LOOP = false>
 RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, const typename Lanes<T>::S* __restrict__ v, const typename Lanes<T>::S* __restrict__ tau,
                            const typename Lanes<T>::S* __restrict__ fext, typename Lanes<T>::S* __restrict__ vdot, typename Lanes<T>::S* __restrict__ qdot, Layout Lq,
                            Layout Lv, Layout Lf, double gx, double gy, double gz, unsigned char* lds, const MkStage& F = MkStage{-1, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr},
@@ -1217,50 +1221,87 @@ RBD_DEV void aba_walk_spec(long B, const typename Lanes<T>::S* __restrict__ q, c
     }
   }
   __syncthreads();
-  // `simulate`: this launch is stage F.stage of a Munthe-Kaas RK4 step — the lane-is-state form of rbd_mk_fuse.hpp, the whole stage behind the passes (they read
-  // the q and v rows and leave them alone when no q̇ is asked for); only the PD law needs the stage state in front of them
+  // `simulate`: this launch is stage F.stage of a Munthe-Kaas RK4 step — or, F.stage = 4, ALL FOUR of them — in the lane-is-state form of rbd_mk_fuse.hpp: the
+  // whole stage stands behind the passes (they read the q and v rows and leave them alone when no q̇ is asked for); only the PD law needs the stage state in
+  // front of them.  With the four stages in one launch the stage states never leave the rows: per step one trip of q, v in and out, four of τ in, and the
+  // stage buffers (base point, two slopes) — a third of the bytes of four launches, and one launch's tail instead of four.
   // (the rows are LDS: said in the pointer's type, or the stage's stores — behind selects and uniform branches — come out as FLAT instructions)
   typedef __attribute__((address_space(3))) S* LdsS;
   auto cell = [&](int row, int st) __attribute__((always_inline)) { return (LdsS)(reinterpret_cast<S*>(c.rows + (long)row * WR_STRIDE + (st & 63)) + (st >> 6)); };
-  if (F.stage >= 0 && F.pd) {  // uniform
-    mk_lane_pd<S, PLAN::MK_N1, PLAN::G, N>(F, cell, mk1, c.rq, c.rv, c.rt, state0, B, Lq, g, lane);
-    __syncthreads();
-  }
-  // WalkStash addresses accumulation registers by number, which the compiler does not see: rbd_jit.hip checks in the code object's metadata that the register
-  // allocator took NONE of its own, then rewrites the kernel descriptor to cover all 256 (jit_kd_cover_agprs) — no `a255` clobber here, the compiler must not
-  // know (with it the metadata could no longer tell the allocator's registers from the stash's; round 3 compiled every program twice for that).
-  const bool want_qdot = qdot != nullptr;
-  walk_sfor<0, PLAN::G>([&](auto gi) __attribute__((always_inline)) {
-    constexpr int GI = decltype(gi)::value;
-    if (g == GI) aba_walk_spec_track<T, FLT, GEN, RR, PLAN, GI>(c, B, fext, want_qdot, Lf, state0, lane);
-  });
-#ifndef RBD_WALK_NO_STAGE
-  MkLane<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N> mkl;
-  if (F.stage >= 0) mk_lane_load<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N>(F, mkl, mk1, mkf, state0, B, g, lane);  // (requested while the other tracks finish)
-  __syncthreads();
   // rows [row0, row0 + n) out to dst in the caller's layout (dst nullable)
   auto send = [&](S* dst, Layout L, int n, int row0) __attribute__((always_inline)) {
     if (fast) walk_stage_out_fast<T, 10 * N>(dst, state0, n, c.rows, row0, tid, nth);
     else if (fast_rows) walk_stage_out_rows<T, 10 * N>(dst, B, state0, n, c.rows, row0, tid, nth);
     else walk_stage_out<T, 10>(dst, L, state0, B, n, c.rows, row0, tid, nth);
   };
-  if (F.stage >= 0) {  // uniform
-    mk_lane_stage<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N>(F, mkl, cell, mk1, mkf, c.rq, c.rv, c.rt, state0, B, g, lane);
+  // WalkStash addresses accumulation registers by number, which the compiler does not see: rbd_jit.hip checks in the code object's metadata that the register
+  // allocator took NONE of its own, then rewrites the kernel descriptor to cover all 256 (jit_kd_cover_agprs) — no `a255` clobber here, the compiler must not
+  // know (with it the metadata could no longer tell the allocator's registers from the stash's; round 3 compiled every program twice for that).
+  const bool want_qdot = qdot != nullptr;
+  const int s_first = (LOOP && F.stage == 4) ? 0 : F.stage, s_last = (LOOP && F.stage == 4) ? 3 : F.stage;  // uniform (-1: plain dynamics!)
+  // one stage: the PD law, the passes, the stage behind them.  st0 / Bo / Lfo / lane_o: state0, B, Lf, lane — as they are, or made opaque per turn of the loop
+  auto one_stage = [&](int sg, long st0, long Bo, Layout Lfo, int lane_o) __attribute__((always_inline)) {
+    MkStage Fs = F;
+    Fs.stage = sg;
+    const int32_t* const mk1o = mk1; const int32_t* const mkfo = mkf;
+    if (sg >= 0 && F.pd) {  // uniform
+      mk_lane_pd<S, PLAN::MK_N1, PLAN::G, N>(Fs, cell, mk1o, c.rq, c.rv, c.rt, st0, Bo, Lq, g, lane_o);
+      __syncthreads();
+    }
+    walk_sfor<0, PLAN::G>([&](auto gi) __attribute__((always_inline)) {
+      constexpr int GI = decltype(gi)::value;
+      if (g == GI) aba_walk_spec_track<T, FLT, GEN, RR, PLAN, GI>(c, Bo, fext, want_qdot, Lfo, st0, lane_o);
+    });
+#ifndef RBD_WALK_NO_STAGE
+    MkLane<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N> mkl;
+    if (sg >= 0) {  // (asked for — and the 6-dof joints' SE(3) arithmetic done — while the other tracks finish)
+      mk_lane_load_float<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N>(Fs, mkl, mkfo, st0, Bo, g, lane_o, PLAN::MK_FW);
+      mk_lane_float_q<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N>(Fs, mkl, cell, mkfo, c.rq, c.rv, st0, Bo, g, lane_o, PLAN::MK_FW);
+      mk_lane_load<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N>(Fs, mkl, mk1o, mkfo, st0, Bo, g, lane_o, PLAN::MK_FW);
+    }
     __syncthreads();
+    if (sg >= 0) {  // uniform
+      mk_lane_stage<S, PLAN::MK_N1, PLAN::MK_NF, PLAN::G, N>(Fs, mkl, cell, mk1o, mkfo, c.rq, c.rv, c.rt, st0, Bo, g, lane_o, PLAN::MK_FW);
+      if (sg < s_last) {  // the next stage's torques into the τ rows (they held v̇): the table's next entry (F.tau_stride elements on), or the same ones again
+        __syncthreads();  // (every wavefront has read its joints' v̇)
+        const auto tn = as_global(tau ? tau + (long)(sg + 1) * F.tau_stride : nullptr);
+        for (int e = tid; e < NV * 64 * N; e += nth) {
+          int k, st;
+          if (Lv.sk == 1) { st = e / NV; k = e - st * NV; } else { k = e / (64 * N); st = e - k * (64 * N); }  // consecutive threads on consecutive addresses either way
+          const long gi = st0 + st;
+          *cell(c.rt + k, st) = (tn && gi < Bo) ? tn[(long)k * Lv.sk + gi * Lv.sb] : S(0);
+        }
+      }
+      __syncthreads();
+    }
+#else
+    __syncthreads();
+#endif
+  };
+  if constexpr (LOOP) {
+#pragma unroll 1
+    for (int sg = s_first; sg <= s_last; ++sg) {
+      // every address of the loop body hangs on the workgroup's first state, the batch size, the wrenches' strides, the lane: made opaque here, or the compiler
+      // lifts ~140 64-bit address computations (the external wrenches', the stage buffers'), their scalar offset products and every LDS row address out of the
+      // loop and keeps them across the passes — 1.7 KB of scratch per lane, 512 registers.  (The materialisation of the passes' constants is lifted the same
+      // way by the machine-level loop-invariant code motion: switched off for this program, rbd_jit.hip.)
+      long st0 = state0, Bo = B;
+      Layout Lfo = Lf;
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      asm volatile("" : "+s"(st0), "+s"(Bo), "+s"(Lfo.sk), "+s"(Lfo.sb));
+      one_stage(sg, st0, Bo, Lfo, lane_o);
+    }
+  } else {
+    one_stage(F.stage, state0, B, Lf, lane);
+  }
+  if (F.stage >= 0) {
     // F.q_state / F.v_state ARE the kernel's own q / v inputs (the arguments' address space is known to the compiler, that of the struct's pointers is not —
     // and neither is that of a pointer that was null on another path: the stores would come out as FLAT instructions): this workgroup has read its states'
     // rows, nobody else touches them
     send(const_cast<S*>(q), Lq, NQ, c.rq);
     send(const_cast<S*>(v), Lv, NV, c.rv);
   }
-#else
-  __syncthreads();
-  auto send = [&](S* dst, Layout L, int n, int row0) __attribute__((always_inline)) {
-    if (fast) walk_stage_out_fast<T, 10 * N>(dst, state0, n, c.rows, row0, tid, nth);
-    else if (fast_rows) walk_stage_out_rows<T, 10 * N>(dst, B, state0, n, c.rows, row0, tid, nth);
-    else walk_stage_out<T, 10>(dst, L, state0, B, n, c.rows, row0, tid, nth);
-  };
-#endif
   send(vdot, Lv, NV, c.rt);
   send(qdot, Lq, NQ, c.rq);
 }

@@ -196,7 +196,8 @@ def test_precompile_without_a_device(rbd, tmp_path, monkeypatch):
     # fp64: the mass-matrix and the inverse-dynamics programs, and the two walk kernels' (each compiled ONCE since round 4: the allocator's register use is read from
     # the object's metadata and its kernel descriptor rewritten to cover the accumulation registers, csrc/rbd_jit.hip jit_kd_cover_agprs)
     # ... and, where the mechanism has a two-bodies-per-lane split, the banked kernels' (round 4: their level loops unrolled against the mechanism's level structure)
-    n = 4 + (rbd.jit_source(model, torch.float64, "banked") is not None)
+    # ... and (round 5) the walk kernel that takes the four stages of a `simulate` step in one launch, a program of its own
+    n = 5 + (rbd.jit_source(model, torch.float64, "banked") is not None)
     assert len(files) == n and all(os.path.getsize(tmp_path / f) > 1000 for f in files)
     assert "ready after" in log and log.count("[rbd_jit] family") == n  # the log lists every program with the seconds it took
     stamps = [os.path.getmtime(tmp_path / f) for f in files]
@@ -318,7 +319,14 @@ def test_walk_program_of_a_mechanism(rbd):
     assert "rnea_walk_spec_f32x2(" in rbd.jit_source(model, torch.float32, "inverse_dynamics_tracks_pairs")
     src = rbd.jit_source(model, torch.float64, "dynamics_tracks")
     assert src is not None and "aba_walk_spec_f64" in src and '#include "rbd_walk.hpp"' in src
-    ns, G, nq, nv, n1, nf = (int(x) for x in re.search(r"NS = (\d+), G = (\d+), NQ = (\d+), NV = (\d+), MK_N1 = (\d+), MK_NF = (\d+);", src).groups())
+    ns, G, nq, nv, n1, nf, fw = (int(x) for x in re.search(r"NS = (\d+), G = (\d+), NQ = (\d+), NV = (\d+), MK_N1 = (\d+), MK_NF = (\d+), MK_FW = (\d+);", src).groups())
+    assert 0 <= fw < G  # (the wavefront with the shortest track: it takes the 6-dof joints' stage arithmetic)
+    # the `simulate` program: the same plan, the instantiation with the passes inside a loop over the four stages, machine-level LICM off, and the marker that lets
+    # its register allocator take accumulation registers of its own (the library checks the kernel against the single-stage one before it uses it)
+    sim = rbd.jit_source(model, torch.float64, "dynamics_tracks_sim")
+    assert "aba_walk_sim_spec_f64(" in sim and "rbd_walk_tables::Plan, true>" in sim and "// rbd-walk-sim-loop\n" in sim and "-disable-machine-licm" in sim
+    assert "rbd_walk_tables::Plan, false>" in src and "rbd-walk-sim-loop" not in src and "disable-machine-licm" not in src
+    assert "aba_walk_sim_spec_f32x2(" in rbd.jit_source(model, torch.float32, "dynamics_tracks_pairs_sim") and rbd.jit_source(model, torch.float64, "dynamics_tracks_pairs_sim") is None
     # (MK_N1 / MK_NF, MK1 / MKF: the joints as the integrator stage folded into the launch sees them, csrc/rbd_mk_fuse.hpp: Atlas has 30 revolute joints and the floating base)
     assert (n1, nf) == (30, 1) and int(re.search(r"const int32_t MK1\[(\d+)\]", src).group(1)) == 90 and "rbd::MkStage F" in src
     assert (nq, nv) == (model.nq, model.nv) and 1 <= G <= 4 and 1 <= ns <= 11
