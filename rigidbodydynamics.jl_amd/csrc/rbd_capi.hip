@@ -2074,6 +2074,14 @@ static int sim_loop_check(rbd_ws* w, int32_t B, const void* dq, const void* dv, 
   const rbd_model* m = w->model;
   const size_t es = esize(w);
   if (capturing(w)) return 0;
+  if (w->dtype != RBD_F64 && !w->spec_walk_f32) return -1;  // (RBD_TUNE spec_walk_f32=0: fp32 batches stay off the compiled walk kernels)
+  {  // both programs there?  (still being compiled: ask again at the next call, nothing spent; refused or failed: never)
+    const bool rr = w->walk_rr && !w->no_reroot && (pair ? w->walk_rr_lds_bytes_pair : w->walk_rr_lds_bytes) > 0;
+    for (int kind : {0, 2}) {
+      if (spec_walk(w, rr, kind, pair)) continue;
+      return w->spec_walk_tried[4 * kind + (rr ? 2 : 0) + (pair ? 1 : 0)] ? -1 : 0;
+    }
+  }
   // (the check's small batch must go to the very kernels the call's batch goes to: the batch thresholds stand aside while it runs)
   struct Thresholds {
     rbd_ws* w; long a, b;
