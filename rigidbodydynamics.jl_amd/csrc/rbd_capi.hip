@@ -134,7 +134,7 @@ struct rbd_ws {
   std::vector<double> loop_gains; bool custom_gains = false;  // rbd_workspace_set_loop_gains: this workspace's Baumgarte gains (4 per loop joint), and whether they differ from the model's
   void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
   long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0, walk_one_round_batch = 0, rnea_walk_min_batch = 0;
-  StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0; long spec_aba_fused_min_batch = (long)1 << 62; bool state_aot = false;  // state_aot: the interpreting one-lane-per-state kernels take the mechanism
+  StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0; long spec_aba_fused_min_batch = (long)1 << 62; long sim_walk_max_batch = 0; bool state_aot = false;  // state_aot: the interpreting one-lane-per-state kernels take the mechanism
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   long bank_min_batch = 0, bank_resident_states = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
@@ -978,6 +978,10 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     // small batch never starts (or waits for) a compilation it would not use
     w->spec_aba_min_batch = w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
     w->spec_aba_fused_min_batch = (long)ncu * 80;  // (`simulate`: run_aba)
+    // `simulate` in fp32: as long as the batch is ONE round of the walk kernel with two states per lane (128 states per workgroup, one workgroup per CU), the four
+    // stages of a step in one launch of it beat four launches of the lane-per-state kernel (Atlas, 32 768 states: 128 against 150 us per step; 40 960 — a second
+    // round — 237 against 161)
+    w->sim_walk_max_batch = tune("sim_walk_max_batch", (long)ncu * 128);
     { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = w->spec_aba_fused_min_batch = t; }
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
     w->state_aot = true;
@@ -2185,7 +2189,8 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   // the walk kernel compiled for the mechanism takes ALL FOUR stages of a step in one launch (rbd_walk.hpp aba_walk_spec, MkStage::stage = 4): the stage states
   // never leave its LDS rows.  Tried first where the lane-per-state kernel is not in line for the batch; RBD_ERR_UNSUPPORTED (the program is not compiled yet,
   // or the batch goes elsewhere) leaves everything untouched for the routes below.
-  bool one_launch = try_spec_sim && walk_sim && !lane_per_state_sim && tune("sim_one_launch", 1) != 0;
+  const bool walk_round = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch && B <= w->sim_walk_max_batch;  // (see sim_walk_max_batch)
+  bool one_launch = try_spec_sim && walk_sim && (!lane_per_state_sim || walk_round) && tune("sim_one_launch", 1) != 0;
   if (one_launch) {  // checked against the single-stage kernel before its first use (sim_loop_check)
     const int pairv = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
     int& chk = w->sim_loop_checked[2 * pairv + (df ? 1 : 0)];
