@@ -52,6 +52,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X public spec (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 FP32_VECTOR_PEAK_TF = 157.3
 ABA_FLOPS_PER_EVAL = 27.0e3  # fused world-frame ABA, Atlas floating
+PMC_FILE = "r06_pmc_traffic.json"  # written by scripts/gpu_measure.sh
 KERNELS = {"inverse_dynamics": "rnea_bank_kernel (<= one resident round of workgroups) / rnea_walk_kernel"}
 CONFIGS = {
     2: dict(model="atlas_floating", batch=4096, dtype="f64", op="dynamics", label="BASELINE configs[1]"),
@@ -106,6 +107,9 @@ def parse_args():
                     help="skip the extra (informational) measurement of two independent batches issued on two HIP streams")
     ap.add_argument("--wrenches", action="store_true", help="headline WITH a random external wrench on every body (reported next to it otherwise)")
     ap.add_argument("--no-other-configs", action="store_true", help="headline only: skip the config3 / config4_shard / config5 / inverse_dynamics blocks")
+    ap.add_argument("--full-out", default=None, help="also write the line with every rider's full block (roofline, alu, parity_check, traffic) to this file")
+    ap.add_argument("--op-sim", action="store_true", help="ONE leg: K RK4 steps of rbd_simulate at --batch / --dtype (what scripts/gpu_measure.sh profiles as sim64 / sim32)")
+    ap.add_argument("--op-kin", action="store_true", help="ONE leg: the kinematics by-products at --batch / --dtype (gpu_measure.sh: kin)")
     ap.add_argument("--selftest-launch", action="store_true", help="only exercise the N-rank launcher (gloo on CPU): prints the world size the ranks saw")
     args = ap.parse_args()
     world = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
@@ -458,18 +462,8 @@ def run(args, env):
 
     # HBM traffic per launch from the PMC passes of scripts/gpu_measure.sh (one rocprofv3 run PER LEG since round 4: `--no-extra-legs`), recorded with the hash
     # of the kernel sources it was measured on: a figure from other sources is flagged stale, never passed along as current
-    traffic, traffic_stale = None, None
-    pmc = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            rec = json.load(open(pmc))
-            traffic_stale = rec.get("source_hash") != kernel_source_hash()
-            key = f"{args.model}_{args.dtype}_B{B}_{args.op}" + ("_noM" if args.no_emit_M else "") + ("_bodies" if bodies else "") + ("_packed" if packed_M else "")
-            traffic = rec.get(key)
-            if traffic_stale and traffic is not None:
-                traffic = dict(traffic, stale=True) if isinstance(traffic, dict) else {"bytes_per_launch": traffic, "stale": True}
-        except Exception:
-            traffic = None
+    key = f"{args.model}_{args.dtype}_B{B}_{args.op}" + ("_noM" if args.no_emit_M else "") + ("_bodies" if bodies else "") + ("_packed" if packed_M else "")
+    traffic, traffic_stale = pmc_traffic(key)
 
     out = {
         "metric": metric, "value": value, "unit": "evals/s",
@@ -483,7 +477,7 @@ def run(args, env):
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale,
                      # the inputs of a batch this small never leave the caches between steps: the "HBM" axis is then fabric traffic (the counters' raw FETCH_SIZE
-                     # is below the input bytes; profiles/r05_pmc_traffic.json)
+                     # is below the input bytes; profiles/r06_pmc_traffic.json)
                      "resident": "L2/MALL" if alg_bytes * B < 64e6 and isinstance(traffic, dict) and traffic.get("fetch_raw_bytes", 1e30) < es * (model.nq + 2 * model.nv) * B else None,
                      "kernel": KERNELS.get(args.op) or (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode(),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": alg_bytes},
@@ -571,15 +565,17 @@ def run(args, env):
     return out
 
 
-def sim_leg(env, B, dtype, steps=12, warm=2, nsample=8, dt=1e-3):
-    """One RK4 step of the batched `simulate` (src/simulate.jl:36-55, MuntheKaasIntegrator.step src/ode_integrators.jl:233-299; rbd_simulate: four launches per
-    step, the stage folded into the dynamics kernel): K steps between HIP events on Atlas at B states, then — from the same initial state — two steps compared with
-    the numpy restatement of the integrator (oracle/simulate_np.py) on a sample of the batch."""
+def sim_leg(env, B, dtype, steps=12, warm=2, dt=1e-3):
+    """One RK4 step of the batched `simulate` (src/simulate.jl:36-55, MuntheKaasIntegrator.step src/ode_integrators.jl:233-299; rbd_simulate, the stage folded
+    into the dynamics kernel): K steps between HIP events on Atlas at B states, then — from the same initial state — two steps of EVERY state compared with the
+    numpy restatement of the integrator (oracle/simulate_np.py, its batch-vectorised form).  One step = four dynamics! evaluations: `alu` prices 4 x 27 kflop,
+    `roofline` the step's compulsory bytes (q, v in and out, tau in)."""
     np, torch, device = env["np"], env["torch"], env["device"]
     rbd, _capi = env["rbd"], env["_capi"]
     import simulate_np
     model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
     tdt = torch.float64 if dtype == "f64" else torch.float32
+    es = 8 if dtype == "f64" else 4
     rng = np.random.default_rng(7)
     q0 = rbd.rand_configuration(model, B, rng)
     v0 = 0.3 * rbd.rand_velocity(model, B, rng)
@@ -612,15 +608,15 @@ def sim_leg(env, B, dtype, steps=12, warm=2, nsample=8, dt=1e-3):
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
     kernel = (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode()
-    # parity: two steps from the initial state, a sample of the batch against the integrator's numpy restatement (fp64)
+    # parity: two steps from the initial state, EVERY state against the integrator's numpy restatement (fp64)
     reset()
     advance(2)
     torch.cuda.synchronize(device)
-    n = min(nsample, B)
     ndt = np.float64 if dtype == "f64" else np.float32
-    qs, vs, ts_ = [a[:n].astype(ndt).astype(np.float64) for a in (q0, v0, tau)]
-    _, q_ref, v_ref = simulate_np.simulate(model, qs, vs, 2 * dt - 1e-12, dt, tau=ts_)
-    qg, vg = state.q[:n].double().cpu().numpy(), state.v[:n].double().cpu().numpy()
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    qs, vs, ts_ = [a.astype(ndt).astype(np.float64) for a in (q0, v0, tau)]
+    q_ref, v_ref = simulate_np.simulate_batch(model, qs, vs, 2, dt, ts_, nthreads=ncores)
+    qg, vg = state.q.double().cpu().numpy(), state.v.double().cpu().numpy()
     for o in range(0, 1):  # Atlas: one quaternion, at q[0:4] — compared up to sign
         sg = np.sign(qg[:, o:o + 1] * q_ref[:, o:o + 1]); sg[sg == 0] = 1
         qg[:, o:o + 4] *= sg
@@ -629,9 +625,129 @@ def sim_leg(env, B, dtype, steps=12, warm=2, nsample=8, dt=1e-3):
     tq, tv = (1e-10, 1e-9) if dtype == "f64" else (2e-5, 2e-3)
     assert eq < tq and ev < tv, f"simulate parity lost in bench: q {eq} v {ev}"
     us = ev0.elapsed_time(ev1) / steps * 1e3
+    alg_bytes = es * (2 * model.nq + 3 * model.nv)
+    gbs = alg_bytes * B / (us * 1e-6) / 1e9
+    tf = 4 * ABA_FLOPS_PER_EVAL * B / (us * 1e-6) / 1e12
+    peak_tf = FP64_VECTOR_PEAK_TF if dtype == "f64" else FP32_VECTOR_PEAK_TF
+    launches = 1 if "four stages per launch" in kernel else 4  # (what the workspace says it ran: rbd_workspace_last_kernel)
     return {"metric": "RK4 simulate steps/sec x states (Atlas 30-DoF, batch)", "value": B * steps / wall, "unit": "state-steps/s", "steps": steps, "warmup": warm,
-            "us_per_step": wall / steps * 1e6, "kernel_us_per_step": us, "launches_per_step": 4, "dtype": dtype, "batch": B, "dt": dt, "kernel": kernel,
-            "parity_check": {"states_compared": n, "steps": 2, "q_rel_err": eq, "v_rel_err": ev, "against": "oracle/simulate_np.py (Munthe-Kaas RK4 restated in numpy, fp64)"}}
+            "ms_per_step": wall / steps * 1e3, "dtype": dtype, "launches_per_step": launches, "dt": dt,
+            "config": {"workload": f"atlas_floating, batch={B}, {dtype} RK4 simulate step (4 dynamics! evaluations)", "batch_per_gpu": B},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": sim_traffic(dtype, B),
+                         "kernel": kernel, "kernel_ms": us * 1e-3, "algorithmic_bytes_per_eval": alg_bytes},
+            "alu": {"bound": "fp64 vector ALU" if dtype == "f64" else "fp32 vector ALU", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf,
+                    "flops_per_eval": 4 * ABA_FLOPS_PER_EVAL},
+            "parity_rel_err_vs_oracle": max(eq, ev),
+            "parity_check": {"states_compared": B, "steps": 2, "q_rel_err": eq, "v_rel_err": ev, "against": "oracle/simulate_np.py (Munthe-Kaas RK4 restated in numpy, fp64)"}}
+
+
+def pmc_traffic(key):
+    """HBM bytes per step from the PMC passes of scripts/gpu_measure.sh (profiles/r06_pmc_traffic.json), flagged stale when the kernel sources have changed since."""
+    pmc = os.path.join(ROOT, "profiles", PMC_FILE)
+    if not os.path.exists(pmc):
+        return None, None
+    try:
+        rec = json.load(open(pmc))
+        stale = rec.get("source_hash") != kernel_source_hash()
+        traffic = rec.get(key)
+        if stale and traffic is not None:
+            traffic = dict(traffic, stale=True) if isinstance(traffic, dict) else {"bytes_per_launch": traffic, "stale": True}
+        return traffic, stale
+    except Exception:
+        return None, None
+
+
+def sim_traffic(dtype, B):
+    return pmc_traffic(f"atlas_floating_{dtype}_B{B}_simulate")[0]
+
+
+def kin_leg(env, B, dtype, steps=40, warm=8, model_name="atlas_floating"):
+    """The kinematics by-products the reference benchmarks beside the dynamics (perf/runbenchmarks.jl:69-110: momentum_matrix!, geometric_jacobian!, momentum,
+    kinetic_energy, center_of_mass — SURVEY.md §8 f3): one step = rbd_kinematics (momentum matrix + centre of mass + both energies) + rbd_geometric_jacobian (world ->
+    the last body: a hand) + rbd_momentum (momentum, momentum_rate_bias) over the batch, each also timed on its own by HIP events; parity of every output against
+    the oracle.  Algorithmic bytes: the inputs each call reads plus the outputs it writes."""
+    np, torch, device = env["np"], env["torch"], env["device"]
+    rbd, _capi, oracle = env["rbd"], env["_capi"], env["oracle"]
+    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", model_name + ".json"))
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    es = 8 if dtype == "f64" else 4
+    rng = np.random.default_rng(11)
+    q = rbd.rand_configuration(model, B, rng)
+    v = rbd.rand_velocity(model, B, rng)
+    state = rbd.MechanismState(model, B, dtype=tdt, device=device)
+    rbd.set_configuration_(state, q)
+    rbd.set_velocity_(state, v)
+    nv, nq = model.nv, model.nq
+    A = torch.zeros((B, 6 * nv), dtype=tdt, device=device)
+    J = torch.zeros((B, 6 * nv), dtype=tdt, device=device)
+    com = torch.zeros((B, 3), dtype=tdt, device=device)
+    en = torch.zeros((B, 2), dtype=tdt, device=device)
+    mom = torch.zeros((B, 12), dtype=tdt, device=device)
+    L = _capi.lib()
+    stream = torch.cuda.current_stream(device)
+    L.rbd_workspace_set_stream(state.ws.handle, ctypes.c_void_p(stream.cuda_stream))
+    opts = state._opts()
+    vp = ctypes.c_void_p
+    target = model.n_bodies - 1
+    h = state.ws.handle
+    calls = {
+        "kinematics": (lambda: L.rbd_kinematics(h, B, vp(state.q.data_ptr()), vp(state.v.data_ptr()), vp(A.data_ptr()), vp(com.data_ptr()), vp(en.data_ptr()), ctypes.byref(opts)),
+                       es * (nq + nv + 6 * nv + 3 + 2)),
+        "geometric_jacobian": (lambda: L.rbd_geometric_jacobian(h, B, vp(state.q.data_ptr()), -1, target, vp(J.data_ptr()), ctypes.byref(opts)), es * (nq + 6 * nv)),
+        "momentum": (lambda: L.rbd_momentum(h, B, vp(state.q.data_ptr()), vp(state.v.data_ptr()), vp(mom.data_ptr()), ctypes.byref(opts)), es * (nq + nv + 12)),
+    }
+
+    def run_all(names):
+        for n_ in names:
+            st = calls[n_][0]()
+            if st != 0:
+                raise RuntimeError(f"rbd_{n_} status {st}: {L.rbd_status_string(st)} {L.rbd_last_hip_error()}")
+
+    def time_of(names):
+        for _ in range(warm):
+            run_all(names)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(steps):
+            run_all(names)
+        e1.record(stream)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0, e0.elapsed_time(e1) / steps * 1e3
+
+    wall, us = time_of(list(calls))
+    each = {n_: time_of([n_])[1] for n_ in calls}
+    # parity (the per-state oracle entry points are one ctypes call per state: a sample of 4096 states)
+    n = min(B, 4096)
+    ndt = np.float64 if dtype == "f64" else np.float32
+    qf, vf = q[:n].astype(ndt).astype(np.float64), v[:n].astype(ndt).astype(np.float64)
+    A_ref, _, com_ref = oracle.momentum_matrix(model, qf, vf)
+    ke_ref, pe_ref = oracle.energy(model, qf, vf)
+    J_ref, _ = oracle.geometric_jacobian(model, qf, -1, target)
+    h_ref, hb_ref = oracle.momentum(model, qf, vf)
+
+    def rel(got, ref):
+        return float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+    errs = {"momentum_matrix": rel(A[:n].double().cpu().numpy().reshape(n, nv, 6).transpose(0, 2, 1), A_ref),
+            "center_of_mass": rel(com[:n].double().cpu().numpy(), com_ref),
+            "energies": rel(en[:n].double().cpu().numpy(), np.stack([ke_ref, pe_ref], axis=1)),
+            "geometric_jacobian": rel(J[:n].double().cpu().numpy().reshape(n, nv, 6).transpose(0, 2, 1), J_ref),
+            "momentum": rel(mom[:n].double().cpu().numpy(), np.concatenate([h_ref, hb_ref], axis=1))}
+    err = max(errs.values())
+    tol = 1e-10 if dtype == "f64" else 2e-4
+    assert err < tol, f"kinematics parity lost in bench: {errs}"
+    alg_bytes = sum(c[1] for c in calls.values())
+    gbs = alg_bytes * B / (us * 1e-6) / 1e9
+    return {"metric": "kinematics by-products sets/sec (momentum_matrix! + center_of_mass + energies, geometric_jacobian!, momentum + momentum_rate_bias)",
+            "value": B * steps / wall, "unit": "sets/s", "steps": steps, "warmup": warm, "ms_per_step": wall / steps * 1e3, "dtype": dtype,
+            "config": {"workload": f"{model_name}, batch={B}, {dtype} rbd_kinematics + rbd_geometric_jacobian + rbd_momentum", "batch_per_gpu": B},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(f"{model_name}_{dtype}_B{B}_kinematics")[0], "kernel": "kin_kernel x2 + momentum_kernel", "kernel_ms": us * 1e-3,
+                         "algorithmic_bytes_per_eval": alg_bytes,
+                         "each": {n_: {"us": round(each[n_], 2), "bytes_per_state": calls[n_][1], "hbm_frac": round(calls[n_][1] * B / (each[n_] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                                  for n_ in calls}},
+            "parity_rel_err_vs_oracle": err, "parity_check": dict(errs, states_compared=n)}
 
 
 def sub_args(args, config, **over):
@@ -650,15 +766,65 @@ def sub_args(args, config, **over):
     return a
 
 
-def block(d):
-    """What of a config's line rides along under the headline: rate, times, roofline, parity."""
-    if d is None:
-        return None
-    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "alu", "parity_rel_err_vs_oracle", "parity_check",
-            "rccl_all_gather_vdot_ms", "with_gather_every_step", "solve_only_M_not_emitted")
-    o = {k: d[k] for k in keep if k in d}
-    o["workload"] = d["config"]["workload"]
-    return o
+def sig(x, n=4):
+    """A float at n significant digits (the driver keeps an 8 KB tail of stdout: the line must fit it — round-5 review)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{n}g}")
+
+
+def shrink(o, n=4):
+    if isinstance(o, dict):
+        return {k: shrink(v, n) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [shrink(v, n) for v in o]
+    return sig(o, n)
+
+
+def short_kernel(k):
+    return k.split(" (")[0][:48] if isinstance(k, str) else k
+
+
+def rider(d):
+    """A config's own line cut down to what the driver's record must carry: rate, step and kernel time, kernel, both roofline fractions, the counters' HBM bytes
+    per step against the algorithmic bytes, parity and how many states were compared.  The full blocks go to stderr and to --full-out."""
+    if not isinstance(d, dict):
+        return d
+    r, al, pc = d.get("roofline", {}), d.get("alu", {}), d.get("parity_check", {})
+    B = d.get("config", {}).get("batch_per_gpu")
+    o = {"value": d["value"], "unit": d["unit"], "us": d["ms_per_step"] * 1e3, "k_us": r.get("kernel_ms", 0.0) * 1e3, "kernel": short_kernel(r.get("kernel")),
+         "dtype": d.get("dtype"), "B": B, "hbm": r.get("frac"), "alu": al.get("frac"), "err": d.get("parity_rel_err_vs_oracle"),
+         "cmp": pc.get("states_compared")}
+    t = r.get("traffic")
+    if isinstance(t, dict) and B and t.get("bytes_per_step_fetch_x2") and r.get("algorithmic_bytes_per_eval"):
+        o["pmc_x"] = t["bytes_per_step_fetch_x2"] / (r["algorithmic_bytes_per_eval"] * B)  # counters' HBM bytes per step / algorithmic bytes
+        if t.get("stale"):
+            o["pmc_stale"] = True
+    if "launches_per_step" in d:
+        o["launches"] = d["launches_per_step"]
+    if isinstance(r.get("each"), dict):
+        o["each_us"] = {k: v["us"] for k, v in r["each"].items()}
+    so = d.get("solve_only_M_not_emitted")
+    if isinstance(so, dict):
+        o["noM_us"] = so["ms_per_step"] * 1e3
+    for k in ("with_external_wrenches", "hip_graph_replay", "pipelined_independent_batches"):
+        if isinstance(d.get(k), dict):
+            o[k.split("_")[0] + "_us"] = d[k]["ms_per_step"] * 1e3
+    return shrink(o)
+
+
+def compact_headline(out):
+    """The headline keeps the contract's keys in full; its informational legs become one number each."""
+    o = dict(out)
+    for k in ("with_external_wrenches", "without_external_wrenches", "hip_graph_replay", "pipelined_independent_batches", "with_gather_every_step"):
+        if isinstance(o.get(k), dict):
+            o[k] = shrink({"value": o[k]["value"], "us": o[k]["ms_per_step"] * 1e3})
+    o.pop("published_reference", None)
+    o["alu"] = {k: v for k, v in o["alu"].items() if k != "note"}
+    t = o["roofline"].get("traffic")
+    if isinstance(t, dict):
+        o["roofline"] = dict(o["roofline"], traffic={k: v for k, v in t.items() if k in ("bytes_per_step_fetch_x2", "bytes_per_step_raw", "fetch_raw_bytes", "stale")})
+    return {k: (shrink(v, 5) if k not in ("value", "ms_per_step") else v) for k, v in o.items()}
 
 
 def main():
@@ -667,34 +833,55 @@ def main():
     if args.selftest_launch:
         return selftest_launch(args)
     env = setup(args)
+    if args.op_sim or args.op_kin:  # one leg of its own for a profiler run
+        d = sim_leg(env, args.batch, args.dtype, steps=min(args.steps, 60), warm=min(args.warmup, 10)) if args.op_sim else \
+            kin_leg(env, args.batch, args.dtype, steps=min(args.steps, 60), warm=min(args.warmup, 10), model_name=args.model)
+        print(json.dumps(d))
+        return
     out = run(args, env)
     headline = (args.config == 2 and not args.no_other_configs and args.batch == CONFIGS[2]["batch"] and args.dtype == CONFIGS[2]["dtype"] and args.op == "dynamics"
                 and not args.no_extra_legs and env["world"] == 1)
+    full = {}
     if headline:
-        # The other BASELINE configs ride on the driver's one-GPU line (round-2 review): each with its own ms_per_step, roofline and whole-batch parity;
-        # `value` stays configs[1].  (N > 1: the line IS configs[3], the sharded one — see the module docstring.)
-        extra = {}
+        # The other BASELINE configs ride on the driver's one-GPU line (round-2 review): each with its own step time, roofline fractions and whole-batch parity;
+        # `value` stays configs[1].  (N > 1: the line IS configs[3], the sharded one — see the module docstring.)  Every rider is cut to a dozen numbers (`rider`):
+        # the round-5 line was 14 KB and the driver keeps 8.
         todo = [("inverse_dynamics", sub_args(args, 2, op="inverse_dynamics")), ("config3", sub_args(args, 3)), ("config4_shard", sub_args(args, 4)),
                 ("config5", sub_args(args, 5)),
-                # the reference's own arithmetic at the large batch (round-4 review: the figures existed in the builder's tables only): dynamics!, and
-                # inverse_dynamics! with its per-body outputs — the call shape of perf/runbenchmarks.jl:49-57 — at 65 536 fp64 states
                 ("config3_packed_M", sub_args(args, 3, packed_M=True, solve_only_leg=False)),
+                # "AF and AX ... benchmark both" — the fixed-base Atlas at the headline's batch and dtype
+                ("atlas_fixed_f64_B4096", sub_args(args, 2, model="atlas_fixed")),
+                # the reference's own arithmetic at the large batch: dynamics!, and inverse_dynamics! with its per-body outputs — the call shape of
+                # perf/runbenchmarks.jl:49-57 — at 65 536 fp64 states
                 ("dynamics_f64_B65536", sub_args(args, 2, batch=65536)),
                 ("inverse_dynamics_bodies_f64_B65536", sub_args(args, 2, batch=65536, op="inverse_dynamics", bodies=True))]
         for name, a in todo:
             try:
-                extra[name] = block(run(a, env))
+                full[name] = run(a, env)
             except Exception as e:  # never lose the headline to a rider
-                extra[name] = f"failed: {type(e).__name__}: {e}"
+                full[name] = f"failed: {type(e).__name__}: {e}"
         for name, (B_, dt_) in (("simulate_step_f64_B4096", (4096, "f64")), ("simulate_step_f32_B65536", (65536, "f32")), ("simulate_step_f64_B65536", (65536, "f64"))):
             try:
-                extra[name] = sim_leg(env, B_, dt_)
+                full[name] = sim_leg(env, B_, dt_)
             except Exception as e:
-                extra[name] = f"failed: {type(e).__name__}: {e}"
-        if out is not None:
-            out.update(extra)
+                full[name] = f"failed: {type(e).__name__}: {e}"
+        # the by-products the reference benchmarks (perf/runbenchmarks.jl:69-110), never timed before round 6
+        for name, (B_, dt_) in (("kinematics_f64_B4096", (4096, "f64")), ("kinematics_f64_B65536", (65536, "f64"))):
+            try:
+                full[name] = kin_leg(env, B_, dt_)
+            except Exception as e:
+                full[name] = f"failed: {type(e).__name__}: {e}"
     if out is not None:
-        print(json.dumps(out))
+        line = compact_headline(out) if headline else out
+        for name, d in full.items():
+            line[name] = rider(d)
+        if headline or args.full_out:
+            fo = dict(out, **full)
+            print("bench.py full record: " + json.dumps(fo), file=sys.stderr)
+            if args.full_out:
+                with open(args.full_out, "w") as f:
+                    json.dump(fo, f)
+        print(json.dumps(line))
     if env["dist"] is not None:
         env["dist"].destroy_process_group()
 

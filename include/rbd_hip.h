@@ -379,8 +379,8 @@ int rbd_workspace_last_kernel_ms(rbd_ws_t* ws, float* ms);
 const char* rbd_workspace_last_kernel(const rbd_ws_t* ws);
 /* 100·round + revision of this header.  rbd_flat_model_t grew its four contact fields at 200; a caller built against an older header must
  * not call a newer library (the Python and Julia loaders compare this with the value they were written for).  400: rbd_workspace_set_loop_gains.
- * 500: rbd_mass_matrix_solve_packed, rbd_gatherv. */
-#define RBD_HIP_H_VERSION 500
+ * 500: rbd_mass_matrix_solve_packed, rbd_gatherv.  600: rbd_jit_check_walk_object. */
+#define RBD_HIP_H_VERSION 600
 int rbd_version(void);
 /* Run-time specialisation.  The one-lane-per-state kernels (mass_matrix! and mass_matrix! + Cholesky at large batches) exist in a second form
  * that is compiled for the mechanism at hand with hiprtc the first time a workspace needs it (the walk of the tree, joint types, offsets and
@@ -406,6 +406,14 @@ int rbd_jit_status(const rbd_model_t* model, int32_t dtype, int32_t family);
  * inside it (a process that exited seconds after its first large-batch call on a new mechanism ended in a segmentation fault). */
 void rbd_jit_wait_idle(void);
 int64_t rbd_jit_source(const rbd_model_t* model, int32_t dtype, int32_t family, char* buf, int64_t capacity);
+/* The admission test the library applies to the code object of a one-wavefront-per-track ("walk") program before it loads it, on an object the caller hands in
+ * (diagnostics and tests; host only, nothing is loaded).  Those kernels keep per-joint results in accumulation registers addressed BY NUMBER, counted down from a255
+ * (csrc/rbd_walk.hpp WalkStash), behind the compiler's back.  Admitted: no scratch; the metadata's .agpr_count == 0 and <= 248 VGPRs — or, for the `simulate` program
+ * whose source carries the marker "// rbd-walk-sim-loop stash-from=a<N>" (its register allocator may take accumulation registers of its own: a0 upwards), .agpr_count
+ * <= N, so that the allocator's registers and the stash cannot alias whatever is live when; and a kernel descriptor of the known kind (AMDGPU HSA code object v5 / v6,
+ * gfx950) that could be rewritten to cover all 256 accumulation registers.  RBD_OK: would be loaded; RBD_ERR_UNSUPPORTED: refused (log says why) — the kernels that
+ * interpret the mechanism, or the four-launch form of `simulate`, serve then. */
+int rbd_jit_check_walk_object(const char* source, const void* code, int64_t size, char* log, int64_t log_capacity);
 
 #ifdef __cplusplus
 }

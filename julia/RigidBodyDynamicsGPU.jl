@@ -141,7 +141,7 @@ mutable struct FlatModelHandle
 end
 
 const WAIT_HOOK = Ref(false)
-const HEADER_VERSION = 500    # RBD_HIP_H_VERSION of the include/rbd_hip.h these structs mirror (rbd_flat_model_t grew its contact fields at 200; 400: rbd_workspace_set_loop_gains; 500: rbd_mass_matrix_solve_packed, rbd_gatherv)
+const HEADER_VERSION = 600    # RBD_HIP_H_VERSION of the include/rbd_hip.h these structs mirror (rbd_flat_model_t grew its contact fields at 200; 400: rbd_workspace_set_loop_gains; 500: rbd_mass_matrix_solve_packed, rbd_gatherv; 600: rbd_jit_check_walk_object)
 
 function FlatModelHandle(mechanism::Mechanism)
     ccall((:rbd_version, librbd_hip[]), Cint, ()) == HEADER_VERSION ||

@@ -220,3 +220,110 @@ def simulate_contact(model, q, v, s, final_time, dt, tau=None, record=False):
         if record:
             traj.append((q.copy(), v.copy(), s.copy()))
     return (np.array(ts), q, v, s, traj) if record else (np.array(ts), q, v, s)
+
+
+# ---- the same step, vectorised over the batch (whole-batch parity of `simulate` at 4096 … 65 536 states: bench.py, GPU tests) ---------------------------
+# Same formulas as above, arrays shaped (B, …); mechanisms of Fixed / Revolute / Prismatic / QuaternionFloating tree joints without loop joints (Atlas,
+# Valkyrie); anything else takes the one-state-at-a-time functions.  tests/test_oracle_simulate.py checks it against `step` state by state.
+def _bq_mul(a, b):
+    w1, x1, y1, z1 = a.T
+    w2, x2, y2, z2 = b.T
+    return np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], axis=1)
+
+
+def _bq_conj(a):
+    return a * np.array([1.0, -1.0, -1.0, -1.0])
+
+
+def _bq_rot(q):
+    w, x, y, z = q.T
+    return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], axis=1),
+                     np.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], axis=1),
+                     np.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], axis=1)], axis=1)
+
+
+def _b_log_with_rate(dq, dp, w, v):
+    s = np.linalg.norm(dq[:, 1:], axis=1)
+    th = 2 * np.arctan2(s, dq[:, 0])
+    small = th < EPS
+    sc = np.where(s < EPS, 2.0, th / np.where(s < EPS, 1.0, s))
+    psi = sc[:, None] * dq[:, 1:]
+    ths = np.where(small, 1.0, th)  # (small angles: the branch that returns the inputs, below)
+    th2 = ths / 2
+    alpha = th2 * np.cos(th2) / np.sin(th2)
+    qv = dp - np.cross(psi, dp) / 2 + ((1 - alpha) / ths ** 2)[:, None] * np.cross(psi, np.cross(psi, dp))
+    beta = th2 ** 2 / np.sin(th2) ** 2
+    A = (2 * (1 - alpha) + (alpha - beta) / 2) / ths ** 2
+    Bc = ((1 - alpha) + (alpha - beta) / 2) / ths ** 4
+    a1 = se3_comm(psi, qv, w, v)
+    a2 = se3_comm(psi, qv, *a1)
+    a3 = se3_comm(psi, qv, *a2)
+    a4 = se3_comm(psi, qv, *a3)
+    wd = w + a1[0] / 2 + A[:, None] * a2[0] + Bc[:, None] * a4[0]
+    vd = v + a1[1] / 2 + A[:, None] * a2[1] + Bc[:, None] * a4[1]
+    return np.where(small[:, None], w, wd), np.where(small[:, None], v, vd)
+
+
+def _b_exp(prot, ptrans):
+    th = np.linalg.norm(prot, axis=1)
+    small = th < EPS
+    ths = np.where(small, 1.0, th)
+    om = prot / ths[:, None]
+    dq = np.concatenate([np.cos(ths / 2)[:, None], (np.sin(ths / 2) / ths)[:, None] * prot], axis=1)
+    vv = ptrans / ths[:, None]
+    t = np.cross(om, vv)
+    t = t - np.einsum("bij,bj->bi", _bq_rot(dq), t) + om * (np.einsum("bi,bi->b", om, vv) * ths)[:, None]
+    dq = np.where(small[:, None], np.array([1.0, 0, 0, 0]), dq)
+    return dq, np.where(small[:, None], ptrans, t)
+
+
+def batchable(model):
+    return model.n_loops == 0 and all(int(t) in (FIXED, REVOLUTE, PRISMATIC, FLOATING) for t in model.joint_type)
+
+
+def local_rate_batch(model, q0, q, v):
+    out = np.array(v, float)  # 1-dof joints: ϕ̇ = v
+    for i in range(model.n_bodies):
+        if int(model.joint_type[i]) == FLOATING:
+            qo, vo = int(model.q_offset[i]), int(model.v_offset[i])
+            dq = _bq_mul(_bq_conj(q0[:, qo:qo + 4]), q[:, qo:qo + 4])
+            dp = np.einsum("bji,bj->bi", _bq_rot(q0[:, qo:qo + 4]), q[:, qo + 4:qo + 7] - q0[:, qo + 4:qo + 7])
+            wd, vd = _b_log_with_rate(dq, dp, v[:, vo:vo + 3], v[:, vo + 3:vo + 6])
+            out[:, vo:vo + 3], out[:, vo + 3:vo + 6] = wd, vd
+    return out
+
+
+def global_coordinates_batch(model, q0, phi):
+    q = np.zeros_like(q0)
+    for i in range(model.n_bodies):
+        t, qo, vo = int(model.joint_type[i]), int(model.q_offset[i]), int(model.v_offset[i])
+        if t in (REVOLUTE, PRISMATIC):
+            q[:, qo] = q0[:, qo] + phi[:, vo]
+        elif t == FLOATING:
+            dq, dt = _b_exp(phi[:, vo:vo + 3], phi[:, vo + 3:vo + 6])
+            q[:, qo:qo + 4] = _bq_mul(q0[:, qo:qo + 4], dq)
+            q[:, qo + 4:qo + 7] = q0[:, qo + 4:qo + 7] + np.einsum("bij,bj->bi", _bq_rot(q0[:, qo:qo + 4]), dt)
+    return q
+
+
+def step_batch(model, q0, v0, dt, tau=None, nthreads=1):
+    """`step` for every state of a batch at once (constant τ): the four dynamics evaluations are one batched oracle call each."""
+    assert batchable(model)
+    phids, vds = [], []
+    for i in range(4):
+        phi = sum((dt * RK4_A[i, j] * phids[j] for j in range(i) if RK4_A[i, j] != 0), np.zeros_like(v0))
+        v = v0 + sum((dt * RK4_A[i, j] * vds[j] for j in range(i) if RK4_A[i, j] != 0), np.zeros_like(v0))
+        q = global_coordinates_batch(model, q0, phi)
+        vds.append(oracle.dynamics(model, q, v, tau, nthreads=nthreads))
+        phids.append(local_rate_batch(model, q0, q, v))
+    phi = sum(dt * RK4_B[i] * phids[i] for i in range(4))
+    v = v0 + sum(dt * RK4_B[i] * vds[i] for i in range(4))
+    return global_coordinates_batch(model, q0, phi), v
+
+
+def simulate_batch(model, q, v, nsteps, dt, tau=None, nthreads=1):
+    q, v = np.array(q, float), np.array(v, float)
+    for _ in range(nsteps):
+        q, v = step_batch(model, q, v, dt, tau, nthreads)
+    return q, v

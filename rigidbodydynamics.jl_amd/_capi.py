@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RBD_LIB") or os.path.join(_HERE, "csrc", "librbd_hip.so")  # RBD_LIB: A/B kernel variants (experiments only)
 
 RBD_OK = 0
-HEADER_VERSION = 500  # RBD_HIP_H_VERSION of the include/rbd_hip.h this binding was written against
+HEADER_VERSION = 600  # RBD_HIP_H_VERSION of the include/rbd_hip.h this binding was written against
 F64, F32 = 0, 1
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 MEM_DEVICE, MEM_HOST = 0, 1
@@ -23,7 +23,7 @@ SYMBOLS = (
     "rbd_mass_matrix_solve", "rbd_dynamics_result", "rbd_status_string", "rbd_last_hip_error",
     "rbd_workspace_enable_timing", "rbd_workspace_last_kernel_ms", "rbd_version", "rbd_simulate", "rbd_mk_stage", "rbd_cholesky_solve", "rbd_kinematics", "rbd_model_chain_plan", "rbd_workspace_last_kernel", "rbd_geometric_jacobian", "rbd_momentum", "rbd_model_bank_plan", "rbd_model_track_plan", "rbd_inverse_dynamics_bodies", "rbd_dynamics_bias_bodies",
     "rbd_model_reroot_plan", "rbd_model_contact_dims", "rbd_contact_dynamics", "rbd_dynamics_contact", "rbd_simulate_contact",
-    "rbd_workspace_bind_result", "rbd_workspace_set_loop_gains", "rbd_jit_precompile", "rbd_jit_source", "rbd_jit_status", "rbd_jit_wait_idle", "rbd_simulate_controlled", "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_gatherv", "rbd_mass_matrix_solve_packed", "rbd_comm_last_error",
+    "rbd_workspace_bind_result", "rbd_workspace_set_loop_gains", "rbd_jit_precompile", "rbd_jit_source", "rbd_jit_status", "rbd_jit_wait_idle", "rbd_simulate_controlled", "rbd_comm_unique_id", "rbd_comm_create", "rbd_comm_destroy", "rbd_comm_info", "rbd_gather", "rbd_gatherv", "rbd_mass_matrix_solve_packed", "rbd_comm_last_error", "rbd_jit_check_walk_object",
 )
 
 
@@ -109,6 +109,7 @@ def lib():
         L.rbd_jit_source.argtypes = [vp, i32, i32, ctypes.c_char_p, ctypes.c_int64]
         L.rbd_jit_source.restype = ctypes.c_int64
         L.rbd_jit_status.argtypes = [vp, i32, i32]
+        L.rbd_jit_check_walk_object.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64]
         L.rbd_jit_wait_idle.argtypes = []
         L.rbd_jit_wait_idle.restype = None
         atexit.register(L.rbd_jit_wait_idle)  # a compilation still running in the background: wait for it before the compiler's own teardown

@@ -128,7 +128,6 @@ struct rbd_ws {
   bool spec_bank_tried = false; hipModule_t spec_bank_mod = nullptr; hipFunction_t spec_bank_aba = nullptr, spec_bank_fused = nullptr, spec_bank_rnea = nullptr; std::string spec_bank_src;  // the banked kernels compiled for the mechanism
   std::string spec_src[SPEC_FAMILIES], spec_loop_src, spec_walk_src[12];  // the programs' sources while their compilation is pending (generated once)
   bool spec_walk_tried[12] = {}; hipModule_t spec_walk_mod[12] = {}; hipFunction_t spec_walk[12] = {};  // [dynamics! | inverse dynamics | dynamics!, four `simulate` stages per launch][re-rooted tree][two fp32 states per lane]
-  int sim_loop_checked[4] = {};  // [two fp32 states per lane][external wrenches]: 0 not yet, 1 the four-stages-per-launch kernel agrees with the single-stage one, -1 it does not (never used then)
   bool no_reroot = false, loop_no_fused = false; int spec_max_scratch = 512;  // RBD_TUNE: walk_no_reroot, loop_no_fused (tests: the original tree / the three-launch loop route), spec_max_scratch (spilled bytes per lane above which a compiled kernel steps aside)
   bool spec_walk_f32 = true;  // fp32 batches through the compiled walk kernels too (RBD_SPEC_WALK_F32=0: not)
   std::vector<double> loop_gains; bool custom_gains = false;  // rbd_workspace_set_loop_gains: this workspace's Baumgarte gains (4 per loop joint), and whether they differ from the model's
@@ -212,6 +211,15 @@ int64_t rbd_jit_source(const rbd_model_t* m, int32_t dtype, int32_t family, char
 // 1: the program's code object is ready (in the cache, or compiled by this process); 0: being compiled on a background thread (started by this call if nobody
 // had); -1: no such program for this mechanism, no hiprtc, or the compilation failed.  Never waits.
 void rbd_jit_wait_idle(void) { jit_wait_idle(); }
+int rbd_jit_check_walk_object(const char* source, const void* code, int64_t size, char* log, int64_t cap) {
+  if (log && cap > 0) log[0] = 0;
+  if (!source || !code || size <= 0) return RBD_ERR_INVALID_ARGUMENT;
+  std::vector<char> c((const char*)code, (const char*)code + size);
+  std::string l;
+  const bool ok = jit_walk_admit(source, &c, &l);
+  if (log && cap > 0) { const int64_t n = std::min<int64_t>(cap - 1, (int64_t)l.size()); memcpy(log, l.data(), (size_t)n); log[n] = 0; }
+  return ok ? RBD_OK : RBD_ERR_UNSUPPORTED;
+}
 int rbd_jit_status(const rbd_model_t* m, int32_t dtype, int32_t family) {
   const std::string src = program_source(m, dtype, family);
   if (src.empty() || !jit_available()) return -1;
@@ -2067,77 +2075,6 @@ int rbd_mk_stage(rbd_ws_t* w, int32_t B, int32_t stage, double dt, void* q, void
 }
 
 // simulate with a controller descriptor (rbd_simulate: constant τ)
-// The walk kernel that takes the four stages of a `simulate` step in one launch has its passes inside a loop, and the register allocator of THAT program takes
-// accumulation registers of its own (rbd_jit.hip accepts it, by its marker).  The passes' stash addresses accumulation registers by number behind the
-// compiler's back: fine as long as the allocator's live only between the passes (where the stash is dead) — as they do in every program looked at, but nothing
-// in a code object's metadata says so.  So the kernel is RUN before it is used: one step of the first states of the caller's own batch (a ragged two
-// workgroups' worth, same layout, with or without external wrenches as the call has them: the passes have no other branches) through the single-stage kernel,
-// four launches, and through this one, one launch; they must agree.  1: they do; -1: they do not (the kernel is never used by this workspace); 0: could not
-// be checked now (a kernel still being compiled, a stream being captured).
-static int sim_loop_check(rbd_ws* w, int32_t B, const void* dq, const void* dv, const void* dtau, const void* df, double dt, const Opts& o, int pair) {
-  const rbd_model* m = w->model;
-  const size_t es = esize(w);
-  if (capturing(w)) return 0;
-  if (w->dtype != RBD_F64 && !w->spec_walk_f32) return -1;  // (RBD_TUNE spec_walk_f32=0: fp32 batches stay off the compiled walk kernels)
-  {  // both programs there?  (still being compiled: ask again at the next call, nothing spent; refused or failed: never)
-    const bool rr = w->walk_rr && !w->no_reroot && (pair ? w->walk_rr_lds_bytes_pair : w->walk_rr_lds_bytes) > 0;
-    for (int kind : {0, 2}) {
-      if (spec_walk(w, rr, kind, pair)) continue;
-      return w->spec_walk_tried[4 * kind + (rr ? 2 : 0) + (pair ? 1 : 0)] ? -1 : 0;
-    }
-  }
-  // (the check's small batch must go to the very kernels the call's batch goes to: the batch thresholds stand aside while it runs)
-  struct Thresholds {
-    rbd_ws* w; long a, b;
-    Thresholds(rbd_ws* w_, int pair_) : w(w_), a(w_->spec_walk_min_batch), b(w_->walk_pair_min_batch) { w->spec_walk_min_batch = 1; w->walk_pair_min_batch = pair_ ? 1 : ((long)1 << 40); }
-    ~Thresholds() { w->spec_walk_min_batch = a; w->walk_pair_min_batch = b; }
-  } thresholds(w, pair);
-  const int32_t Bt = std::min<int32_t>(B, 200);
-  const Layout Lq = layout_of(o.layout, m->nq, Bt), Lv = layout_of(o.layout, m->nv, Bt), Lf = layout_of(o.layout, 6L * m->nb, Bt);
-  const size_t nq = es * (size_t)m->nq * Bt, nv = es * (size_t)m->nv * Bt, nf = es * 6 * (size_t)m->nb * Bt;
-  char* buf = nullptr;
-  if (hipMalloc((void**)&buf, 2 * nq + 3 * nv + nf + 64) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  char *q0 = buf, *q1 = q0 + nq, *v0 = q1 + nq, *v1 = v0 + nv, *tt = v1 + nv, *ff = tt + nv;
-  // the first Bt states of the caller's buffers: contiguous when a state's coordinates are (RBD_LAYOUT_AOS), one run per coordinate otherwise
-  auto take = [&](char* dst, const void* src, long n) -> hipError_t {
-    if (o.layout == RBD_LAYOUT_AOS) return hipMemcpyAsync(dst, src, es * (size_t)n * Bt, hipMemcpyDeviceToDevice, w->stream);
-    return hipMemcpy2DAsync(dst, es * (size_t)Bt, src, es * (size_t)B, es * (size_t)Bt, (size_t)n, hipMemcpyDeviceToDevice, w->stream);
-  };
-  int verdict = 0;
-  std::vector<char> h0(nq + nv), h1(nq + nv);
-  do {
-    if (take(q0, dq, m->nq) != hipSuccess || take(q1, dq, m->nq) != hipSuccess || take(v0, dv, m->nv) != hipSuccess || take(v1, dv, m->nv) != hipSuccess) break;
-    if (dtau) { if (take(tt, dtau, m->nv) != hipSuccess) break; }
-    if (df) { if (take(ff, df, 6L * m->nb) != hipSuccess) break; }
-    const void* tp = dtau ? tt : nullptr; const void* fp = df ? ff : nullptr;
-    int st = RBD_OK;
-    for (int stage = 0; stage < 4 && st == RBD_OK; ++stage) {
-      const MkStage F{stage, 0, dt, w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.vd[0], q0, v0, nullptr, nullptr, nullptr, 0};
-      st = run_aba(w, Bt, RBD_ALGO_ABA_WALK, q0, v0, tp, fp, nullptr, nullptr, Lq, Lv, Lf, nullptr, nullptr, &F);
-    }
-    if (st != RBD_OK) break;  // (RBD_ERR_UNSUPPORTED: the single-stage kernel is not there yet)
-    const MkStage F4{4, 0, dt, w->mk.q0, w->mk.v0, w->mk.phid[0], w->mk.vd[0], q1, v1, nullptr, nullptr, nullptr, 0};
-    if (run_aba(w, Bt, RBD_ALGO_ABA_WALK, q1, v1, tp, fp, nullptr, nullptr, Lq, Lv, Lf, nullptr, nullptr, &F4) != RBD_OK) break;
-    if (hipMemcpyAsync(h0.data(), q0, nq, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipMemcpyAsync(h0.data() + nq, v0, nv, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
-        hipMemcpyAsync(h1.data(), q1, nq, hipMemcpyDeviceToHost, w->stream) != hipSuccess || hipMemcpyAsync(h1.data() + nq, v1, nv, hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
-        hipStreamSynchronize(w->stream) != hipSuccess) break;
-    // the two programs are compiled apart (their multiply-adds need not be fused alike): agreement to rounding, not bit for bit
-    double worst = 0.0;
-    const size_t n = (nq + nv) / es;
-    for (size_t i = 0; i < n; ++i) {
-      const double a = w->dtype == RBD_F64 ? ((const double*)h0.data())[i] : (double)((const float*)h0.data())[i];
-      const double b = w->dtype == RBD_F64 ? ((const double*)h1.data())[i] : (double)((const float*)h1.data())[i];
-      const double d = std::fabs(a - b) / std::max(1.0, std::fabs(a));
-      worst = (d == d) ? std::max(worst, d) : 1e300;  // (a NaN on either side)
-    }
-    verdict = worst <= (w->dtype == RBD_F64 ? 1e-9 : 2e-4) ? 1 : -1;
-    if (verdict < 0) g_last_hip_error = "simulate: the kernel that takes four stages per launch disagrees with the single-stage kernel on the batch's first states (not used)";
-  } while (false);
-  (void)hipGetLastError();
-  (void)hipStreamSynchronize(w->stream);
-  (void)hipFree(buf);
-  return verdict;
-}
 static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_control_t& ctl, const void* fext, double dt, int32_t nsteps, const rbd_opts_t* opts) {
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
@@ -2191,12 +2128,11 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   // or the batch goes elsewhere) leaves everything untouched for the routes below.
   const bool walk_round = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch && B <= w->sim_walk_max_batch;  // (see sim_walk_max_batch)
   bool one_launch = try_spec_sim && walk_sim && (!lane_per_state_sim || walk_round) && tune("sim_one_launch", 1) != 0;
-  if (one_launch) {  // checked against the single-stage kernel before its first use (sim_loop_check)
-    const int pairv = w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch;
-    int& chk = w->sim_loop_checked[2 * pairv + (df ? 1 : 0)];
-    if (chk == 0) chk = sim_loop_check(w, B, dq, dv, tau_at(0, 0), df, dt, o, pairv);
-    one_launch = chk == 1;
-  }
+  // (Round 5 ran this kernel against the single-stage one inside the first call before using it — a hipMalloc and two synchronisations in a hot-path call — because
+  //  the looped program's register allocator may take accumulation registers of its own beside the stash the passes address by number.  Since round 6 the
+  //  admission is static: rbd_jit.hip loads the program only when the allocator's registers a0 .. a[.agpr_count − 1] end below the stash's lowest register, so
+  //  they cannot alias whatever the live ranges are; a program that does not qualify is not loaded and the four-launch form below serves.  The comparison of the
+  //  two forms lives in the tests: tests/test_gpu_parity.py test_simulate_stage_folded_into_the_compiled_kernels[one_launch], scripts/stress_simulate_walk.py.)
   if (one_launch) {
     const bool per_stage = ctl.kind == RBD_CONTROL_TABLE && ctl.per_stage;
     bool ok = true;

@@ -51,6 +51,8 @@ int jit_code_object_get(const std::string& source, bool wait, std::vector<char>*
 // the walk kernels' object: checked for accumulation registers of the allocator's own, then its kernel descriptor made to cover all 256 (see rbd_jit.hip)
 int jit_walk_code_object_get(const std::string& source, bool wait, std::vector<char>* code, std::string* log);
 int jit_kd_cover_agprs(std::vector<char>* code);
+// the admission of a walk program's code object (registers against the numbered stash, no scratch, the descriptor rewritten): what jit_walk_code_object_get applies
+bool jit_walk_admit(const std::string& source, std::vector<char>* code, std::string* log);
 std::vector<char> jit_walk_code_object(const std::string& source, std::string* log);
 std::vector<char> jit_code_object(const std::string& source, std::string* log);
 void jit_cache_discard(const std::string& source);

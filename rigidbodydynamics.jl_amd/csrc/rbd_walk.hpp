@@ -47,6 +47,7 @@ struct alignas(16) I4 { int32_t x, y, z, w; };  // one packed plan record (TI_*,
 // a0 upwards when it runs out of VGPRs (it parks a few loop-invariant values there in the fp64 kernels), and build.sh checks on the generated
 // assembly (scripts/check_walk_agprs.py) that what it takes stays below the WALK_MAX_STEPS steps' worth reserved here.  Host (emulation): an array.
 enum { WS_SN = 0, WS_CS = 1, WS_W = 2, WS_UD = 8, WS_N = 9 };
+static_assert(WS_N == WALK_STASH_N, "rbd_walk_plan.hpp: WALK_STASH_N");
 // (RBD_WALK_STASH_ARRAY: the array on the device too.  Measured on the kernel compiled per mechanism, where every index is a constant: the allocator
 // spilled 529 values around the 162 long-lived ones; with the numbered registers it needs 221 VGPRs and no scratch.)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RBD_WALK_STASH_ARRAY)

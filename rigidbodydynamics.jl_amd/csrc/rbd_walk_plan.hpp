@@ -22,6 +22,8 @@ namespace rbd {
 // (pass A has the twist halves of its A mailboxes there, pass C its 6-value mailboxes); then the plan records.  Must agree with walk_ctx_lds()
 // of rbd_walk.hpp.
 enum { WR_STRIDE = 65, WMB_A = 12, WMB_AT = 12, WMB_B = 27, WMB_C = 6, WMB_S = 24, WALK_MAX_STEPS = 11 };
+// values a step of a track leaves in the numbered accumulation registers between the passes (WalkStash, rbd_walk.hpp: WS_N); rbd_jit.hip sizes the stash with it
+enum { WALK_STASH_N = 9 };
 
 #ifndef RBD_JIT_COMPILE
 struct WalkPlan {

@@ -322,9 +322,9 @@ def test_walk_program_of_a_mechanism(rbd):
     ns, G, nq, nv, n1, nf, fw = (int(x) for x in re.search(r"NS = (\d+), G = (\d+), NQ = (\d+), NV = (\d+), MK_N1 = (\d+), MK_NF = (\d+), MK_FW = (\d+);", src).groups())
     assert 0 <= fw < G  # (the wavefront with the shortest track: it takes the 6-dof joints' stage arithmetic)
     # the `simulate` program: the same plan, the instantiation with the passes inside a loop over the four stages, machine-level LICM off, and the marker that lets
-    # its register allocator take accumulation registers of its own (the library checks the kernel against the single-stage one before it uses it)
+    # its register allocator take accumulation registers of its own — below the stash's lowest register, which the marker names (jit_walk_admit)
     sim = rbd.jit_source(model, torch.float64, "dynamics_tracks_sim")
-    assert "aba_walk_sim_spec_f64(" in sim and "rbd_walk_tables::Plan, true>" in sim and "// rbd-walk-sim-loop\n" in sim and "-disable-machine-licm" in sim
+    assert "aba_walk_sim_spec_f64(" in sim and "rbd_walk_tables::Plan, true>" in sim and "// rbd-walk-sim-loop stash-from=a%d\n" % (256 - 18 * ns) in sim and "-disable-machine-licm" in sim
     assert "rbd_walk_tables::Plan, false>" in src and "rbd-walk-sim-loop" not in src and "disable-machine-licm" not in src
     assert "aba_walk_sim_spec_f32x2(" in rbd.jit_source(model, torch.float32, "dynamics_tracks_pairs_sim") and rbd.jit_source(model, torch.float64, "dynamics_tracks_pairs_sim") is None
     # (MK_N1 / MK_NF, MK1 / MKF: the joints as the integrator stage folded into the launch sees them, csrc/rbd_mk_fuse.hpp: Atlas has 30 revolute joints and the floating base)
@@ -419,3 +419,49 @@ def test_code_objects_are_the_kind_the_descriptor_rewrite_knows(rbd, tmp_path, m
                 assert 4 <= accum_offset <= 256 and granule >= accum_offset  # (before the rewrite: the VGPRs alone, or VGPRs + the allocator's own AGPRs)
                 seen += 1
     assert seen >= 4
+
+
+def test_a_looped_walk_program_whose_allocator_reaches_the_stash_is_refused(rbd, tmp_path):
+    """The `simulate` program with four stages per launch (csrc/rbd_walk.hpp, LOOP = true) is the one walk program whose register allocator may take accumulation
+    registers of its own, beside the stash the passes address by number from a255 down.  Admission is static (csrc/rbd_jit.hip jit_walk_admit, round 6; round 5 ran
+    the kernel against the single-stage one inside the first rbd_simulate call): loaded only if .agpr_count <= the stash's lowest register, which the program's marker
+    names.  Fed here: a kernel that deliberately takes a100 (.agpr_count = 101) — refused against a stash that reaches down to a58 (Atlas fp64: 11 steps x 9 values x 2),
+    admitted against one that ends at a120, refused as an ordinary walk program (those must take none), and refused when the marker is missing the register."""
+    import ctypes
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = tmp_path / "k.hip"
+    src.write_text('#include <hip/hip_runtime.h>\nextern "C" __global__ __launch_bounds__(64) void clobber(float* x) {\n  float v = x[threadIdx.x];\n'
+                   '  asm volatile("v_accvgpr_write_b32 a[100], %0" ::"v"(v) : "a100");\n  asm volatile("v_accvgpr_read_b32 %0, a[100]" : "=v"(v));\n  x[threadIdx.x] = v;\n}\n')
+    obj = tmp_path / "k.hsaco"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "--offload-device-only", "--no-gpu-bundle-output", "-O3", "-c", str(src), "-o", str(obj)],
+                          stderr=subprocess.DEVNULL)
+    code = obj.read_bytes()
+    L = rbd._capi.lib()
+
+    def admitted(marker):
+        log = ctypes.create_string_buffer(512)
+        st = L.rbd_jit_check_walk_object(marker.encode(), code, len(code), log, len(log))
+        assert st in (0, 3), st
+        return st == 0, log.value.decode()
+    ok, log = admitted("// rbd-walk-sim-loop stash-from=a58\n")
+    assert not ok and "101 accumulation registers" in log, log
+    ok, log = admitted("// rbd-walk-sim-loop stash-from=a120\n")
+    assert ok, log
+    ok, log = admitted("// rbd-walk-sim-loop stash-from=a100\n")  # a0 .. a100 against a stash from a100: one register shared
+    assert not ok
+    ok, log = admitted("// rbd-walk-sim-loop stash-from=a101\n")
+    assert ok, log
+    assert not admitted("// a walk program of the straight-line kind\n")[0]
+    assert not admitted("// rbd-walk-sim-loop\n")[0]
+    # every looped program of the mechanisms in the cache names its stash: Atlas fp64 re-rooted = 256 - 2 * 9 * steps
+    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", "atlas_floating.json"))
+    for dt, fam, regs in ((torch.float64, "dynamics_tracks_sim", 2), (torch.float32, "dynamics_tracks_sim", 1), (torch.float32, "dynamics_tracks_pairs_sim", 2)):
+        s = rbd.jit_source(model, dt, fam)
+        assert s is not None
+        m = re.search(r"// rbd-walk-sim-loop stash-from=a(\d+)\n", s)
+        ns = int(re.search(r"static constexpr int NS = (\d+)", s).group(1))
+        assert m and int(m.group(1)) == 256 - regs * 9 * ns

@@ -148,3 +148,17 @@ def test_local_and_global_coordinates_are_consistent(rbd, oracle, models, sim, n
         qd_fd = (sim.global_coordinates(m, q0, phi + h * phid) - sim.global_coordinates(m, q0, phi - h * phid)) / (2 * h)
         _, qd = oracle.dynamics(m, q[None], v[None], want_qdot=True)
         assert np.allclose(qd_fd, qd[0], atol=2e-8), np.abs(qd_fd - qd[0]).max()
+
+
+@pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "valkyrie_floating"])
+def test_batched_step_equals_the_one_state_step(rbd, oracle, models, sim, name):
+    """simulate_np.step_batch (what bench.py and the GPU tests compare whole batches with) restates `step` with arrays over the batch: same numbers, including
+    a state that starts at rest (zero rotation in the SE(3) log / exp: the small-angle branches)."""
+    m = models[name]
+    q, v, tau = rand_inputs(rbd, m, 6, 61)
+    v *= 0.3
+    v[0] = 0.0
+    assert sim.batchable(m)
+    q1, v1 = sim.simulate_batch(m, q, v, 2, 1e-3, tau)
+    _, q2, v2 = sim.simulate(m, q, v, 2e-3 - 1e-12, 1e-3, tau=tau)
+    assert np.abs(q1 - q2).max() < 1e-13 and np.abs(v1 - v2).max() < 1e-9 * max(1.0, np.abs(v2).max())
