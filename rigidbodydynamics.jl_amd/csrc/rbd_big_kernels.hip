@@ -243,6 +243,166 @@ __global__ __launch_bounds__(64) void big_chol_solve_kernel(int nv, long B, cons
   }
 }
 
+// The kinematics by-products on trees of any size (round 6; rbd_kinematics / rbd_geometric_jacobian / rbd_momentum of trees the lane-per-body kin_kernel does
+// not take): momentum_matrix! (src/mechanism_algorithms.jl:313-327), center_of_mass (:28-50), kinetic_energy / gravitational_potential_energy
+// (src/mechanism_state.jl:886-903), geometric_jacobian! of path(base -> target) (:80-99), momentum / momentum_rate_bias (src/mechanism_state.jl:975-987).
+// One thread per state like everything in this file; every output nullable; base / target: reference body indices, -1 = the root body.
+template <typename T>
+__global__ __launch_bounds__(64) void big_kin_kernel(BigModel M, long B, const T* __restrict__ q, const T* __restrict__ v, T* __restrict__ A_out, T* __restrict__ com_out,
+                                                     T* __restrict__ energy_out, T* __restrict__ J_out, int base, int target, T* __restrict__ mom_out,
+                                                     T* __restrict__ scratch, Layout Lq, Layout Lv, Layout La, Layout L3, Layout L2, Layout L12) {
+  const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (st >= B) return;
+  const BigCtx<T> C{M, B, st, scratch};
+  const T* rbase = reinterpret_cast<const T*>(M.rb);
+  const T z6[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  T ke = T(0), pe = T(0), ms = T(0), cs[3] = {T(0), T(0), T(0)}, hs[6], ws[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) hs[k] = ws[k] = T(0);
+  for (int i = 0; i < M.nb; ++i) {  // parents first: transforms, twists, bias accelerations (the world's -g inside), inertias in the root frame
+    const Body<T> b = big_body<T>(M, i, st);
+    const T* rb = rbase + (long)i * RB_STRIDE;
+    T qj[7], vj[6], K[24];
+    load_joint_q(b, q, Lq, qj);
+    load_joint_v(b, v, Lv, vj);
+    big_fk(C, b, rb, qj, vj, z6, K);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) C.at(BIG_K + k, i) = K[k];
+    RInertia<T> I;
+    T Jb[6], mc[3], h[6], acc[6], Ia[6], x[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jb[k] = rb[RB_J + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mc[k] = rb[RB_MC + k];
+    inertia_to_root(Jb, mc, rb[RB_M], K, K + 9, I);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) C.at(BIG_IC + k, i) = I.J[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) C.at(BIG_IC + 6 + k, i) = I.c[k];
+    C.at(BIG_IC + 9, i) = I.m;
+    mul_inertia(I, K + 12, h);
+    ke += dot6(h, K + 12) / 2;
+    if (I.m > T(0)) {  // (bodies without mass have no centre of mass: center_of_mass / gravitational_potential_energy skip them, mechanism_algorithms.jl:36)
+      pe -= T(M.gravity[0]) * I.c[0] + T(M.gravity[1]) * I.c[1] + T(M.gravity[2]) * I.c[2];
+      ms += I.m;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cs[k] += I.c[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = K[18 + k];
+    acc[3] += T(M.gravity[0]); acc[4] += T(M.gravity[1]); acc[5] += T(M.gravity[2]);  // bias accelerations proper: without the root's -g
+    mul_inertia(I, acc, Ia);
+    momentum_cross(I, K + 12, x);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { hs[k] += h[k]; ws[k] += Ia[k] + x[k]; }
+  }
+  if (energy_out) { energy_out[0 * L2.sk + st * L2.sb] = ke; energy_out[1 * L2.sk + st * L2.sb] = pe; }
+  if (com_out) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) com_out[(long)k * L3.sk + st * L3.sb] = cs[k] / ms;
+  }
+  if (mom_out) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { mom_out[(long)k * L12.sk + st * L12.sb] = hs[k]; mom_out[(long)(6 + k) * L12.sk + st * L12.sb] = ws[k]; }
+  }
+  auto subspace = [&](int a, int col, T* S) {  // column `col` of the motion subspace of body a's joint, root frame
+    const T* rb = rbase + (long)a * RB_STRIDE;
+    const T ax[3] = {rb[RB_AXIS], rb[RB_AXIS + 1], rb[RB_AXIS + 2]}, ay[3] = {rb[RB_AXIS2], rb[RB_AXIS2 + 1], rb[RB_AXIS2 + 2]};
+    T sl[6], K[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) K[k] = C.at(BIG_K + k, a);
+    subspace_col(M.tbl[4 * a + 1], ax, ay, col, sl);
+    xmotion(K, K + 9, sl, S);
+  };
+  if (J_out) {
+    // fill!(jac, 0), then the joints of path(base, target) (src/graphs/tree_path.jl:41-63: both ends walked up to their lowest common ancestor; a body's
+    // parent has the smaller index): -S for those walked upwards from the base, +S downwards to the target
+    for (long e = 0; e < 6L * M.nv; ++e) J_out[e * La.sk + st * La.sb] = T(0);
+    int a = base, bb = target;
+    while (a != bb) {
+      const int i = a > bb ? a : bb;
+      const T sg = a > bb ? T(-1) : T(1);
+      const int nvi = joint_nv(M.tbl[4 * i + 1]), vi = M.tbl[4 * i + 3];
+      for (int ci = 0; ci < nvi; ++ci) {
+        T Si[6];
+        subspace(i, ci, Si);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J_out[((long)(vi + ci) * 6 + k) * La.sk + st * La.sb] = sg * Si[k];
+      }
+      if (a > bb) a = M.tbl[4 * a]; else bb = M.tbl[4 * bb];
+    }
+  }
+  if (A_out) {
+    for (int i = M.nb - 1; i >= 0; --i) {  // composite inertias bottom-up (update_crb_inertias!), column i = crb_inertia(body i) S_i
+      RInertia<T> Ic;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Ic.J[k] = C.at(BIG_IC + k, i);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ic.c[k] = C.at(BIG_IC + 6 + k, i);
+      Ic.m = C.at(BIG_IC + 9, i);
+      const int p = M.tbl[4 * i];
+      if (p >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) C.at(BIG_IC + k, p) += Ic.J[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) C.at(BIG_IC + 6 + k, p) += Ic.c[k];
+        C.at(BIG_IC + 9, p) += Ic.m;
+      }
+      const int nvi = joint_nv(M.tbl[4 * i + 1]), vi = M.tbl[4 * i + 3];
+      for (int ci = 0; ci < nvi; ++ci) {
+        T Si[6], F[6];
+        subspace(i, ci, Si);
+        mul_inertia(Ic, Si, F);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) A_out[((long)(vi + ci) * 6 + k) * La.sk + st * La.sb] = F[k];
+      }
+    }
+  }
+}
+template <typename T>
+hipError_t launch_big_kin(const BigModel& M, long B, const void* q, const void* v, void* A, void* com, void* energy, void* J, int base, int target, void* mom,
+                          void* scratch, Layout Lq, Layout Lv, Layout La, Layout L3, Layout L2, Layout L12, hipStream_t s) {
+  hipLaunchKernelGGL(big_kin_kernel<T>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, M, B, (const T*)q, (const T*)v, (T*)A, (T*)com, (T*)energy, (T*)J, base, target,
+                     (T*)mom, (T*)scratch, Lq, Lv, La, L3, L2, L12);
+  return hipGetLastError();
+}
+template hipError_t launch_big_kin<double>(const BigModel&, long, const void*, const void*, void*, void*, void*, void*, int, int, void*, void*, Layout, Layout, Layout, Layout, Layout, Layout, hipStream_t);
+template hipError_t launch_big_kin<float>(const BigModel&, long, const void*, const void*, void*, void*, void*, void*, int, int, void*, void*, Layout, Layout, Layout, Layout, Layout, Layout, hipStream_t);
+
+// The PD law of rbd_simulate_controlled (RBD_CONTROL_PD) over the any-size tables: one thread per (state, body); tau_out = tau_ff − kp (q − q_des) − kd v on
+// Revolute / Prismatic joints, tau_ff on every other joint's coordinates (pd_control_kernel of rbd_kernels.hip reads the lane-per-body tables)
+template <typename T>
+__global__ __launch_bounds__(256) void big_pd_control_kernel(BigModel M, long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau_ff,
+                                                             const T* __restrict__ qdes, const T* __restrict__ kp, const T* __restrict__ kd, T* __restrict__ tau_out,
+                                                             Layout Lq, Layout Lv) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)M.nb * B) return;
+  // consecutive threads walk the fastest-varying index of the layout
+  const long st = Lv.sk == 1 ? e / M.nb : e % B;
+  const int i = (int)(Lv.sk == 1 ? e % M.nb : e / B);
+  const int jt = M.tbl[4 * i + 1], qo = M.tbl[4 * i + 2], vo = M.tbl[4 * i + 3], nvi = joint_nv(jt);
+  for (int k = 0; k < nvi; ++k) {
+    const long a = (long)(vo + k) * Lv.sk + st * Lv.sb;
+    T t = tau_ff ? tau_ff[a] : T(0);
+    if (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_PRISMATIC) {
+      const long qa = (long)qo * Lq.sk + st * Lq.sb;
+      t -= kp[vo] * (q[qa] - (qdes ? qdes[qa] : T(0))) + kd[vo] * v[a];
+    }
+    tau_out[a] = t;
+  }
+}
+template <typename T>
+hipError_t launch_big_pd_control(const BigModel& M, long B, const void* q, const void* v, const void* tau_ff, const void* qdes, const void* kp, const void* kd,
+                                 void* tau_out, Layout Lq, Layout Lv, hipStream_t s) {
+  const long n = (long)M.nb * B;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(big_pd_control_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, B, (const T*)q, (const T*)v, (const T*)tau_ff, (const T*)qdes,
+                     (const T*)kp, (const T*)kd, (T*)tau_out, Lq, Lv);
+  return hipGetLastError();
+}
+template hipError_t launch_big_pd_control<double>(const BigModel&, long, const void*, const void*, const void*, const void*, const void*, const void*, void*, Layout, Layout, hipStream_t);
+template hipError_t launch_big_pd_control<float>(const BigModel&, long, const void*, const void*, const void*, const void*, const void*, const void*, void*, Layout, Layout, hipStream_t);
+
 // the per-body kinematics the loop branch reads (24 per body and state: R, p, twist, bias acceleration with the world's -g, as rnea_kernel exports them) out of
 // the scratch big_rnea_kernel (vdot == nullptr) has just filled: body[st * 24 nb + 24 i + k]
 template <typename T>

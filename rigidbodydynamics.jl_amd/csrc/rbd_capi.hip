@@ -366,7 +366,17 @@ int rbd_model_create(const rbd_flat_model_t* d, rbd_model_t** out) {
     const double r[6] = {h.point[0], h.point[1], h.point[2], h.outward_normal[0] / nn, h.outward_normal[1] / nn, h.outward_normal[2] / nn};
     m->hs_r.insert(m->hs_r.end(), r, r + 6);
   }
-  if (nb > 64) {
+  // ... or a body with more children than a lane-per-body record lists (IB_MAXCHILD = 8; round 6: such a tree takes the any-size route instead of being refused —
+  // the reference has no limit: rand_tree_mechanism attaches any number of joints to one body)
+  bool many_children = false;
+  {
+    std::vector<int> nkids(nb, 0);
+    for (int i = 0; i < nb; ++i) {
+      const int p = d->parent[i];
+      if (p >= 0 && p < i && ++nkids[p] > IB_MAXCHILD) many_children = true;
+    }
+  }
+  if (nb > 64 || many_children) {
     // More bodies than a wavefront has lanes: the any-size fallback (rbd_big_kernels.hip) — tree mechanisms without contact points; dynamics!,
     // inverse_dynamics!, dynamics_bias!, mass_matrix!, mass_matrix_solve.  Everything else returns RBD_ERR_UNSUPPORTED for such a model.
     // (round 4: loop joints and contact points too — their tables are in reference body indices, and the loop branch's and the contact kernels read the
@@ -2082,7 +2092,6 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   if (!q || !v || nsteps < 0 || !(dt > 0)) return RBD_ERR_INVALID_ARGUMENT;
   if (w->model->ncp > 0 && w->model->nhs > 0) return RBD_ERR_UNSUPPORTED;  // contact points: rbd_simulate_contact (carries the additional state)
   if (ctl.kind != RBD_CONTROL_CONSTANT && (o.memory != RBD_MEM_DEVICE || w->model->nloops > 0)) return RBD_ERR_UNSUPPORTED;
-  if (ctl.kind == RBD_CONTROL_PD && w->model->big) return RBD_ERR_UNSUPPORTED;  // (the PD law's kernel reads the lane-per-body tables)
   if (ctl.kind == RBD_CONTROL_TABLE && !ctl.tau) return RBD_ERR_INVALID_ARGUMENT;
   if (ctl.kind == RBD_CONTROL_PD && (!ctl.kp || !ctl.kd)) return RBD_ERR_INVALID_ARGUMENT;
   if (ctl.kind < RBD_CONTROL_CONSTANT || ctl.kind > RBD_CONTROL_PD) return RBD_ERR_INVALID_ARGUMENT;
@@ -2196,6 +2205,10 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
       HIP_TRY(stage_launch(w, B, stage, dt, dq, dv, w->d_vdwork, Lq, Lv, close_prev));
       const void* ts = tau_at(step, stage);
       if (pd) {  // the PD law on the stage state the launch above left in (q, v): one element-wise launch, no host round trip
+        if (m->big) {  // (trees of more than 64 bodies: the same law over the any-size tables, round 6)
+          if (w->dtype == RBD_F64) HIP_TRY(launch_big_pd_control<double>(w->big, B, dq, dv, ts, ctl.q_des, ctl.kp, ctl.kd, w->d_tauwork, Lq, Lv, w->stream));
+          else HIP_TRY(launch_big_pd_control<float>(w->big, B, dq, dv, ts, ctl.q_des, ctl.kp, ctl.kd, w->d_tauwork, Lq, Lv, w->stream));
+        } else
         if (w->dtype == RBD_F64) HIP_TRY(launch_pd_control<double>(w->dm, B, dq, dv, ts, ctl.q_des, ctl.kp, ctl.kd, w->d_tauwork, Lq, Lv, w->stream));
         else HIP_TRY(launch_pd_control<float>(w->dm, B, dq, dv, ts, ctl.q_des, ctl.kp, ctl.kd, w->d_tauwork, Lq, Lv, w->stream));
         ts = w->d_tauwork;
@@ -2356,6 +2369,7 @@ int rbd_cholesky_solve(rbd_ws_t* w, int32_t B, const void* M, const void* rhs, v
 
 
 int rbd_kinematics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* momentum_matrix, void* com, void* energy, const rbd_opts_t* opts) {
+  BigOk big_ok;  // (round 6: trees of more than 64 bodies through big_kin_kernel)
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
@@ -2374,7 +2388,12 @@ int rbd_kinematics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* m
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), La = layout_of(o.layout, 6L * m->nv, B);
   const Layout L3 = layout_of(o.layout, 3, B), L2 = layout_of(o.layout, 2, B);
-  {
+  if (m->big) {
+    if ((st = big_scratch(w, B))) return st;
+    Timed t(w);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_big_kin<double>(w->big, B, dq, dv, dA, dcom, den, nullptr, -1, -1, nullptr, w->d_big_scratch, Lq, Lv, La, L3, L2, L2, w->stream));
+    else HIP_TRY(launch_big_kin<float>(w->big, B, dq, dv, dA, dcom, den, nullptr, -1, -1, nullptr, w->d_big_scratch, Lq, Lv, La, L3, L2, L2, w->stream));
+  } else {
     Timed t(w);
     if (w->dtype == RBD_F64) HIP_TRY(launch_kin<double>(w->dm, B, dq, dv, dA, dcom, den, nullptr, 0, 0, Lq, Lv, La, L3, L2, w->stream));
     else HIP_TRY(launch_kin<float>(w->dm, B, dq, dv, dA, dcom, den, nullptr, 0, 0, Lq, Lv, La, L3, L2, w->stream));
@@ -2389,6 +2408,7 @@ int rbd_kinematics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* m
 
 
 int rbd_geometric_jacobian(rbd_ws_t* w, int32_t B, const void* q, int32_t base_body, int32_t target_body, void* jac, const rbd_opts_t* opts) {
+  BigOk big_ok;
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
@@ -2401,7 +2421,7 @@ int rbd_geometric_jacobian(rbd_ws_t* w, int32_t B, const void* q, int32_t base_b
   // base side are traversed upwards (-S), those on the target side downwards (+S)
   uint64_t plus = 0, minus = 0;
   int a = base_body, b = target_body;
-  while (a != b) {
+  while (!m->big && a != b) {  // (the any-size kernel walks the path itself)
     if (a > b) { minus |= (uint64_t)1 << m->slot_of[a]; a = m->parent_ref[a]; }
     else { plus |= (uint64_t)1 << m->slot_of[b]; b = m->parent_ref[b]; }
   }
@@ -2413,7 +2433,12 @@ int rbd_geometric_jacobian(rbd_ws_t* w, int32_t B, const void* q, int32_t base_b
   if (o.memory == RBD_MEM_HOST) {
     if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_out_alloc(w, 4, jac, es * 6 * m->nv * B, &dJ))) return st;
   }
-  {
+  if (m->big) {
+    if ((st = big_scratch(w, B))) return st;
+    Timed t(w);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_big_kin<double>(w->big, B, dq, nullptr, nullptr, nullptr, nullptr, dJ, base_body, target_body, nullptr, w->d_big_scratch, Lq, Lv, La, L3, L2, L2, w->stream));
+    else HIP_TRY(launch_big_kin<float>(w->big, B, dq, nullptr, nullptr, nullptr, nullptr, dJ, base_body, target_body, nullptr, w->d_big_scratch, Lq, Lv, La, L3, L2, L2, w->stream));
+  } else {
     Timed t(w);
     if (w->dtype == RBD_F64) HIP_TRY(launch_kin<double>(w->dm, B, dq, nullptr, nullptr, nullptr, nullptr, dJ, plus, minus, Lq, Lv, La, L3, L2, w->stream));
     else HIP_TRY(launch_kin<float>(w->dm, B, dq, nullptr, nullptr, nullptr, nullptr, dJ, plus, minus, Lq, Lv, La, L3, L2, w->stream));
@@ -2424,6 +2449,7 @@ int rbd_geometric_jacobian(rbd_ws_t* w, int32_t B, const void* q, int32_t base_b
 
 
 int rbd_momentum(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* out12, const rbd_opts_t* opts) {
+  BigOk big_ok;
   const Opts o = read_opts(opts);
   int st = check_common(w, B, o);
   if (st != RBD_OK) return st;
@@ -2440,7 +2466,12 @@ int rbd_momentum(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* out
       return st;
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), L12 = layout_of(o.layout, 12, B);
-  {
+  if (m->big) {
+    if ((st = big_scratch(w, B))) return st;
+    Timed t(w);
+    if (w->dtype == RBD_F64) HIP_TRY(launch_big_kin<double>(w->big, B, dq, dv, nullptr, nullptr, nullptr, nullptr, -1, -1, dout, w->d_big_scratch, Lq, Lv, Lq, Lq, Lq, L12, w->stream));
+    else HIP_TRY(launch_big_kin<float>(w->big, B, dq, dv, nullptr, nullptr, nullptr, nullptr, -1, -1, dout, w->d_big_scratch, Lq, Lv, Lq, Lq, Lq, L12, w->stream));
+  } else {
     Timed t(w);
     if (w->dtype == RBD_F64) HIP_TRY(launch_momentum<double>(w->dm, B, dq, dv, dout, Lq, Lv, L12, w->stream));
     else HIP_TRY(launch_momentum<float>(w->dm, B, dq, dv, dout, Lq, Lv, L12, w->stream));

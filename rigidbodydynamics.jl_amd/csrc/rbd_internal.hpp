@@ -102,6 +102,13 @@ hipError_t launch_big_mk_stage(const BigModel& M, long B, int stage, double dt, 
 // dst[b * n + k] = src[k * ld + b] for one or two (src1 != nullptr) buffer pairs (n <= 384: per-body outputs of a one-lane-per-state kernel, stored
 // batch-innermost, for a state-major caller)
 template <typename T> hipError_t launch_rows_to_state_major(int n, long B, long ld, const void* src0, void* dst0, const void* src1, void* dst1, hipStream_t s);
+// the kinematics by-products and the PD law of rbd_simulate_controlled on trees of any size (round 6)
+template <typename T>
+hipError_t launch_big_kin(const BigModel& M, long B, const void* q, const void* v, void* A, void* com, void* energy, void* J, int base, int target, void* mom,
+                          void* scratch, Layout Lq, Layout Lv, Layout La, Layout L3, Layout L2, Layout L12, hipStream_t s);
+template <typename T>
+hipError_t launch_big_pd_control(const BigModel& M, long B, const void* q, const void* v, const void* tau_ff, const void* qdes, const void* kp, const void* kd,
+                                 void* tau_out, Layout Lq, Layout Lv, hipStream_t s);
 template <typename T>
 hipError_t launch_big_chol_solve(int nv, long B, const void* Mg, void* Lg, const void* rhs, const void* c, void* x, Layout Lm, Layout Lv, int* notpd, hipStream_t s);
 }

@@ -1216,8 +1216,6 @@ def test_trees_of_more_than_64_bodies(rbd, oracle, dtype):
             assert rbd.sync(state) == 0
             assert rel(low(result.massmatrix), np.tril(Mref)) <= rt and rel(host(result.vd, state), ref) <= 1e-14 * cond
             assert rel(host(result.dynamicsbias, state), oracle.dynamics_bias(model, q, v, fe)) <= rt
-        with pytest.raises(Exception):
-            rbd.kinetic_energy(state)  # a by-product outside the four hot-path functions: RBD_ERR_UNSUPPORTED for such a model, not a wrong answer
 
 
 @pytest.mark.gpu
@@ -1252,6 +1250,90 @@ def test_simulate_on_a_tree_of_more_than_64_bodies(rbd, oracle):
         torques.copy_(dev(tau, st))
     rbd.simulate_(state, 3 * dt - 1e-12, control_, dt=dt)
     assert len(calls) == 12
+    assert np.abs(canon_q(model, host(state.q, state)) - canon_q(model, q_ref)).max() <= 1e-10 * max(1.0, np.abs(q_ref).max())
+    assert np.abs(host(state.v, state) - v_ref).max() <= 1e-8 * max(1.0, np.abs(v_ref).max())
+
+
+def _big_tree(rbd, seed=64):
+    rng = np.random.default_rng(seed)
+    joints = ["QuaternionFloating"] + ["Revolute"] * 50 + ["Prismatic"] * 8 + ["SinCosRevolute"] * 4 + ["Fixed"] * 3 + ["Planar"] * 2 + ["QuaternionSpherical"] * 2
+    order = rng.permutation(len(joints) - 1)
+    model = rbd.flatten(rbd.rand_tree_mechanism(rng, [joints[0]] + [joints[1 + k] for k in order]))
+    assert model.n_bodies == 70
+    return model, rng
+
+
+def _star(rbd, seed=65, spokes=11):
+    """a hub with more children than a lane-per-body record lists (IB_MAXCHILD = 8): eleven 1-dof / 3-dof spokes on a floating hub, two of them two bodies long"""
+    rng = np.random.default_rng(seed)
+    kinds = ["Revolute", "Prismatic", "Planar", "QuaternionSpherical", "SinCosRevolute", "Revolute", "Revolute", "Prismatic", "Revolute", "Fixed", "Revolute"][:spokes]
+    spec = [("QuaternionFloating", [(k, [("Revolute", [])] if i < 2 else []) for i, k in enumerate(kinds)])]
+    return rbd.flatten(rbd.builders.tree_mechanism(rng, spec)), rng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("tree", ["70_bodies", "11_children"])
+def test_kinematics_byproducts_without_a_size_limit(rbd, oracle, tree, layout):
+    """Round 6: momentum_matrix!, center_of_mass, the energies, geometric_jacobian!, momentum and momentum_rate_bias have no size limit in the reference
+    (src/mechanism_algorithms.jl:28-50, :80-99, :313-327; src/mechanism_state.jl:886-903, :975-987).  A 70-body random tree of every joint type, and a hub with
+    eleven children (both outside the lane-per-body tables: one thread per state over the any-size tables, big_kin_kernel) against the oracle, fp64 at 1e-11 and
+    fp32."""
+    model, rng = _big_tree(rbd) if tree == "70_bodies" else _star(rbd)
+    assert tree == "70_bodies" or max(np.bincount(np.asarray(model.parent)[np.asarray(model.parent) >= 0])) > 8
+    B = 37
+    for dtype, tol in (("f64", 1e-11), ("f32", 3e-4)):
+        state, q, v, _, _ = make(rbd, model, B, dtype, layout, 131)
+        A = torch.zeros_like(state.v).new_zeros((B, 6 * model.nv) if layout == "aos" else (6 * model.nv, B))
+        rbd.momentum_matrix_(A, state)
+        com = rbd.center_of_mass(state)
+        ke, pe = rbd.kinetic_energy(state), rbd.gravitational_potential_energy(state)
+        h, hb = rbd.momentum(state), rbd.momentum_rate_bias(state)
+        assert rbd.sync(state) == 0
+        rel = lambda got, ref: np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+        A_ref, _, com_ref = oracle.momentum_matrix(model, q, v)
+        ke_ref, pe_ref = oracle.energy(model, q, v)
+        h_ref, hb_ref = oracle.momentum(model, q, v)
+        assert rel(host(A, state).reshape(B, model.nv, 6).transpose(0, 2, 1), A_ref) <= tol
+        assert rel(host(com, state), com_ref) <= tol
+        assert rel(ke.double().cpu().numpy(), ke_ref) <= tol and rel(pe.double().cpu().numpy(), pe_ref) <= tol
+        assert rel(h.double().cpu().numpy(), h_ref) <= tol and rel(hb.double().cpu().numpy(), hb_ref) <= 10 * tol
+        J = torch.full_like(A, 7.0)  # off-path columns must be zeroed
+        for _ in range(5):
+            base, body = rng.choice(np.arange(-1, model.n_bodies), 2, replace=False)
+            rbd.geometric_jacobian_(J, state, int(base), int(body))
+            ref, trel = oracle.geometric_jacobian(model, q, base, body, v)
+            got = host(J, state).reshape(B, model.nv, 6).transpose(0, 2, 1)
+            assert rel(got, ref) <= tol and rel(np.einsum("bkn,bn->bk", got, v), trel) <= 10 * tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tree", ["70_bodies", "11_children"])
+def test_dynamics_and_pd_controller_without_a_size_limit(rbd, oracle, tree):
+    """... and the hot path itself on the hub with eleven children (refused until round 6), plus the device-side PD law of `simulate(state, T, control!)` on both
+    trees (RBD_CONTROL_PD: refused for trees of more than 64 bodies until round 6): two RK4 steps against the numpy integrator with the same law as control!."""
+    import simulate_np
+    model, rng = _big_tree(rbd, 66) if tree == "70_bodies" else _star(rbd, 67)
+    B, dt = 4, 1e-3
+    state, q, v, tau, fe = make(rbd, model, B, "f64", "aos", 132, fext=True)
+    result = rbd.DynamicsResult(model, B)
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state))
+    assert rbd.sync(state) == 0
+    ref = oracle.dynamics(model, q, v, tau, fe)
+    assert np.abs(host(result.vd, state) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    out = torch.zeros_like(state.v)
+    rbd.inverse_dynamics_(out, state, dev(ref, state), dev(fe, state))
+    assert np.abs(host(out, state) - tau).max() <= 1e-9 * max(1.0, np.abs(tau).max())
+    kp, kd = 2 * rng.random(model.nv), 0.02 * rng.random(model.nv)
+    qdes, tff = 0.3 * rng.standard_normal((B, model.nq)), 0.1 * rng.random((B, model.nv))
+    v0 = 0.2 * v
+    rbd.set_velocity_(state, v0)
+    rbd.simulate_(state, 1.5 * dt, control_=rbd.PDControl(torch.as_tensor(kp), torch.as_tensor(kd), dev(qdes, state), dev(tff, state)), dt=dt)
+    nvj = {0: 0, 3: 6, 4: 3, 5: 3}
+    one = np.array([1.0 if int(t) in (1, 2) else 0.0 for t in model.joint_type for _ in range(nvj.get(int(t), 1))])
+    qidx = np.array([int(model.q_offset[b]) for b in range(model.n_bodies) for _ in range(nvj.get(int(model.joint_type[b]), 1))])
+    pd = lambda b, t, qq, vv: tff[b] - one * (kp * (qq[qidx] - qdes[b][qidx]) + kd * vv)
+    _, q_ref, v_ref = simulate_np.simulate(model, q, v0, 1.5 * dt, dt, control=pd)
     assert np.abs(canon_q(model, host(state.q, state)) - canon_q(model, q_ref)).max() <= 1e-10 * max(1.0, np.abs(q_ref).max())
     assert np.abs(host(state.v, state) - v_ref).max() <= 1e-8 * max(1.0, np.abs(v_ref).max())
 
