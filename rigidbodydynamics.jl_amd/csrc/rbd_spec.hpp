@@ -1430,6 +1430,9 @@ RBD_DEV void rnea_spec(long B, const T* __restrict__ q, const T* __restrict__ v,
 }
 #endif  // RBD_SPEC_ABA
 
+#ifndef RBD_SPEC_CHOL_WAVES
+#define RBD_SPEC_CHOL_WAVES 2  // wavefronts per SIMD the chol_spec kernels are compiled for (their tiles: 230 registers)
+#endif
 #if defined(RBD_SPEC_CHOL) && !defined(RBD_SPEC_EMU)  // (the host emulation of tests/emu has no matrix cores)
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The dense step of `dynamics_solve!` (potrf! / potrs!, src/mechanism_algorithms.jl:764, :819) specialised on the SPARSITY of the mechanism's
@@ -1666,6 +1669,28 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
       const long left = B - group * 16;
       const int nlive = left < 16 ? (int)left : 16;
       unsigned lo[NK], go[NK];
+#ifdef RBD_SPEC_EMIT_SKIP_UPPER
+      // The reference defines the LOWER triangle of M (Symmetric, uplo 'L'); the mirror image above it is written only because whole cache lines leave faster.
+      // A 64-byte segment of a state's square that lies strictly above the diagonal altogether (Atlas: 15 of a state's 81) need not leave at all: the pieces of
+      // such segments are switched off, every segment that does leave is still complete.  keep[k]: bit Jo = the piece this lane sends in store k of block Jo
+      // belongs to a segment with an entry on or below the diagonal.
+      struct KeepTab { unsigned m[PCS]; };
+      static constexpr KeepTab KT = [] {
+        KeepTab t{};
+        for (int p = 0; p < PCS; ++p) {
+          unsigned m = 0;
+          for (int Jo = 0; Jo < NT; ++Jo) {
+            const int g0 = (Jo * CB + 4 * p) & ~15;
+            bool any = false;
+            for (int e = g0; e < g0 + 16 && e < NV * NV; ++e) any = any || (e % NV >= e / NV);
+            if (any) m |= 1u << Jo;
+          }
+          t.m[p] = m;
+        }
+        return t;
+      }();
+      unsigned keep[NK];
+#endif
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         int ch = 64 * k + lane;
@@ -1675,6 +1700,9 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
         st = st < nlive ? st : nlive - 1;
         lo[k] = (unsigned)(st * MST + piece * 4);
         go[k] = 4u * ((unsigned)st * (unsigned)Lc.sb + (unsigned)(piece * 4));  // in bytes: the store then takes it as its 32-bit offset beside a scalar base
+#ifdef RBD_SPEC_EMIT_SKIP_UPPER
+        keep[k] = KT.m[piece];
+#endif
       }
 #ifdef RBD_SPEC_ABLATE_EMIT_LOCAL  // (timing experiments, spec_variant 1024: every wavefront's M lands on the same 64 states — the stores without the memory behind them)
       float* const Mw = Mc + ((group * 16) & 63) * Lc.sb;
@@ -1709,8 +1737,14 @@ RBD_DEV void chol_spec(long B, long group, const float* __restrict__ Mg, const f
         });
         wave_sync();
 #pragma unroll
-        for (int k = 0; k < NK; ++k)
+        for (int k = 0; k < NK; ++k) {
+#ifdef RBD_SPEC_EMIT_SKIP_UPPER
+          const V piece = *reinterpret_cast<const V*>(mst + lo[k]);  // (the LDS read for every lane, the store under its predicate)
+          if (keep[k] & (1u << Jo)) __builtin_nontemporal_store(piece, reinterpret_cast<V*>(reinterpret_cast<char*>(Mw + Jo * CB) + go[k]));
+#else
           __builtin_nontemporal_store(*reinterpret_cast<const V*>(mst + lo[k]), reinterpret_cast<V*>(reinterpret_cast<char*>(Mw + Jo * CB) + go[k]));
+#endif
+        }
       });
     }
   }

@@ -599,10 +599,10 @@ def test_simulate_stage_folded_into_the_compiled_kernels(rbd, oracle, models, ke
     # round 6: the walk kernels' four-stages-per-launch program (LOOP = true) is admitted statically (csrc/rbd_jit.hip jit_walk_admit) and no longer compared with
     # the single-stage kernel inside rbd_simulate; both forms are held against the oracle here — constant torques, the torque table (the per-stage reload between
     # the passes) and the PD law (evaluated between the passes), which the round-5 run-time check never exercised
-    one = launches == "one_launch_per_step"
-    if one and kernel == "aba_spec_f32" and not ONE_LAUNCH_LANE_PER_STATE:
+    one_launch = launches == "one_launch_per_step"
+    if one_launch and kernel == "aba_spec_f32" and not ONE_LAUNCH_LANE_PER_STATE:
         pytest.skip("the lane-per-state kernel takes four launches per step")
-    tune(monkeypatch, sim_one_launch=1 if one else 0, **knobs)
+    tune(monkeypatch, sim_one_launch=1 if one_launch else 0, **knobs)
     model = models[name]
     B, dt, nsteps = 70, 1e-3, 3
     T = (nsteps - 0.5) * dt
@@ -612,7 +612,7 @@ def test_simulate_stage_folded_into_the_compiled_kernels(rbd, oracle, models, ke
 
     def check(ref, what):
         assert "Munthe-Kaas stage folded in" in rbd.last_kernel(state) and ("aba_spec_f32" in rbd.last_kernel(state)) == (kernel == "aba_spec_f32"), rbd.last_kernel(state)
-        assert ("four stages per launch" in rbd.last_kernel(state)) == one, rbd.last_kernel(state)
+        assert ("four stages per launch" in rbd.last_kernel(state)) == one_launch, rbd.last_kernel(state)
         qg, vg = host(state.q, state)[sel], host(state.v, state)[sel]
         assert np.isfinite(host(state.q, state)).all() and np.isfinite(host(state.v, state)).all(), what
         assert np.abs(canon_q(model, qg) - canon_q(model, ref[1])).max() <= tq * max(1.0, np.abs(ref[1]).max()), what
