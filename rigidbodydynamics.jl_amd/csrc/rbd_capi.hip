@@ -122,11 +122,13 @@ struct rbd_ws {
   void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; void* d_rows = nullptr; size_t d_rows_bytes = 0, d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
-  bool spec_tried[SPEC_FAMILIES] = {false, false, false}; hipModule_t spec_mod[SPEC_FAMILIES] = {nullptr, nullptr, nullptr}; hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_chol_nom = nullptr, spec_chol_packed = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_aba_nofext = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
+  bool spec_tried[SPEC_SLOTS] = {false, false, false, false}; hipModule_t spec_mod[SPEC_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // (by spec_slot(family))
+  hipFunction_t spec_kin = nullptr, spec_jac = nullptr, spec_mom = nullptr, spec_energy = nullptr; long spec_kin_min_batch = (long)1 << 62;  // the kinematics by-products compiled for the mechanism (SPEC_KIN, round 6)
+  hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_chol_nom = nullptr, spec_chol_packed = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_aba_nofext = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
   bool spec_bank_tried = false; hipModule_t spec_bank_mod = nullptr; hipFunction_t spec_bank_aba = nullptr, spec_bank_fused = nullptr, spec_bank_rnea = nullptr; std::string spec_bank_src;  // the banked kernels compiled for the mechanism
-  std::string spec_src[SPEC_FAMILIES], spec_loop_src, spec_walk_src[12];  // the programs' sources while their compilation is pending (generated once)
+  std::string spec_src[SPEC_SLOTS], spec_loop_src, spec_walk_src[12];  // the programs' sources while their compilation is pending (generated once)
   bool spec_walk_tried[12] = {}; hipModule_t spec_walk_mod[12] = {}; hipFunction_t spec_walk[12] = {};  // [dynamics! | inverse dynamics | dynamics!, four `simulate` stages per launch][re-rooted tree][two fp32 states per lane]
   bool no_reroot = false, loop_no_fused = false; int spec_max_scratch = 512;  // RBD_TUNE: walk_no_reroot, loop_no_fused (tests: the original tree / the three-launch loop route), spec_max_scratch (spilled bytes per lane above which a compiled kernel steps aside)
   bool spec_walk_f32 = true;  // fp32 batches through the compiled walk kernels too (RBD_SPEC_WALK_F32=0: not)
@@ -188,7 +190,8 @@ int rbd_version(void) { return RBD_HIP_H_VERSION; }
 // run-time specialisation (rbd_jit.hip): the generated source of a model's kernels, and its compilation into the on-disk cache.  Neither needs a device.
 // the source of one program of a model (families as in include/rbd_hip.h); empty: no such program for this mechanism
 static std::string program_source(const rbd_model* m, int32_t dtype, int32_t family) {
-  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_FAMILIES + 7) return std::string();
+  if (!m || (dtype != RBD_F32 && dtype != RBD_F64) || family < 0 || family > SPEC_KIN) return std::string();
+  if (family == SPEC_KIN) return m->spec_plan().ok ? spec_source(m->spec_plan(), m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, dtype, SPEC_KIN) : std::string();  // (family 11: the kinematics by-products)
   if (family == SPEC_FAMILIES + 6) return walk_program_source(m, dtype, walk_program_rerooted(m, dtype), 2);  // (family 9: family 4 with the four stages of a `simulate` step in one launch)
   if (family == SPEC_FAMILIES + 7) return dtype == RBD_F32 ? walk_program_source(m, dtype, walk_program_rerooted(m, dtype, 1), 2, 1) : std::string();  // (family 10: family 6 likewise)
   std::vector<int32_t> xi;
@@ -235,7 +238,7 @@ int rbd_jit_precompile(const rbd_model_t* m, int32_t dtype, char* log, int64_t c
   // the model's programs of this scalar type, the longest compilations first; every one of them on its own background thread (rbd_jit.hip), then wait for all
   struct Job { std::string src; bool walk; int family; int state; double seconds; std::string log; };
   std::vector<Job> jobs;
-  for (int family : {4, 9, 5, 6, 10, 7, 8, 0, 1, 2, 3})
+  for (int family : {4, 9, 5, 6, 10, 7, 8, 0, 1, 2, 11, 3})
     jobs.push_back({program_source(m, dtype, family), family_is_walk(family), family, JIT_PENDING, 0.0, std::string()});
   // RBD_JIT_PRECOMPILE_PART = "k/n": only every n-th program, starting with the k-th — n processes share a model's compilations
   int part = 0, parts = 1;
@@ -1002,6 +1005,8 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->sim_walk_max_batch = tune("sim_walk_max_batch", (long)ncu * 128);
     { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = w->spec_aba_fused_min_batch = t; }
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
+    // the kinematics by-products one lane per state (kin_spec / jac_spec / mom_spec): from half a chip-full of wavefronts on, like the other compiled kernels
+    w->spec_kin_min_batch = tune("spec_kin_min_batch", (long)ncu * 4 * 64 / 2 + 1);
     w->state_aot = true;
   } else if (m->state_wide.ok) {  // the compiled kernels alone (no interpreting form of them for these joint types): the same thresholds, the lane-per-body kernels behind them
     int ncu = 256;
@@ -1015,6 +1020,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->spec_rnea_min_batch = (long)ncu * 64;
     { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = t; }
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
+    w->spec_kin_min_batch = tune("spec_kin_min_batch", (long)ncu * 64);
   } else {
     w->state_min_batch = (long)1 << 62;
   }
@@ -1607,19 +1613,20 @@ static bool capturing(rbd_ws* w) {
   return cs != hipStreamCaptureStatusNone;
 }
 static void spec_load(rbd_ws* w, int family, bool force) {
-  if (w->spec_tried[family]) return;
+  const int slot = spec_slot(family);
+  if (w->spec_tried[slot]) return;
   const rbd_model* m = w->model;
-  if (!m->spec_plan().ok || !jit_available() || !spec_has(family, w->dtype, m->nb, m->nq, m->nv, m->spec_plan().n3)) { w->spec_tried[family] = true; return; }
+  if (!m->spec_plan().ok || !jit_available() || !spec_has(family, w->dtype, m->nb, m->nq, m->nv, m->spec_plan().n3)) { w->spec_tried[slot] = true; return; }
   if (capturing(w)) return;  // a module cannot be loaded inside a stream capture: the interpreting kernels serve it, the next call outside tries again
   std::string log;
-  std::string& src = w->spec_src[family];
+  std::string& src = w->spec_src[slot];
   if (src.empty()) src = spec_source(m->spec_plan(), m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype, family);
   std::vector<char> code;
   const int js = jit_code_object_get(src, force || !jit_async(), &code, &log);
   if (js == JIT_PENDING) return;
-  w->spec_tried[family] = true;
+  w->spec_tried[slot] = true;
   if (js == JIT_FAILED || code.empty()) { g_last_hip_error = "run-time compilation failed (the interpreting kernels are used): " + log; src.clear(); src.shrink_to_fit(); return; }
-  hipModule_t& mod = w->spec_mod[family];
+  hipModule_t& mod = w->spec_mod[slot];
   if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { (void)hipGetLastError(); mod = nullptr; jit_cache_discard(src); return; }
   auto get = [&](hipFunction_t* f, const char* name) { if (hipModuleGetFunction(f, mod, name) != hipSuccess) { (void)hipGetLastError(); *f = nullptr; } };
   // a kernel whose registers spilled beyond a few values is slower than the kernels that interpret the mechanism: it steps aside
@@ -1652,7 +1659,19 @@ static void spec_load(rbd_ws* w, int family, bool force) {
   } else if (family == SPEC_RNEA) {
     get(&w->spec_rnea, w->dtype == RBD_F64 ? "rnea_spec_f64" : "rnea_spec_f32");
     fits(&w->spec_rnea, &w->spec_rnea_scratch);
+  } else if (family == SPEC_KIN) {  // (a kernel that spilled steps aside: the lane-per-body kin_kernel serves)
+    int sc = 0;
+    get(&w->spec_kin, w->dtype == RBD_F64 ? "kin_spec_f64" : "kin_spec_f32"); fits(&w->spec_kin, &sc); if (sc) w->spec_kin = nullptr;
+    get(&w->spec_jac, w->dtype == RBD_F64 ? "jac_spec_f64" : "jac_spec_f32"); fits(&w->spec_jac, &sc); if (sc) w->spec_jac = nullptr;
+    get(&w->spec_mom, w->dtype == RBD_F64 ? "mom_spec_f64" : "mom_spec_f32"); fits(&w->spec_mom, &sc); if (sc) w->spec_mom = nullptr;
+    get(&w->spec_energy, w->dtype == RBD_F64 ? "energy_spec_f64" : "energy_spec_f32"); fits(&w->spec_energy, &sc); if (sc) w->spec_energy = nullptr;
   }
+}
+// one launch of a by-product kernel compiled for the mechanism (rbd_spec.hpp kin_spec<T, WHAT>): a wavefront of 64 states per workgroup
+static hipError_t launch_kin_spec(rbd_ws* w, hipFunction_t f, long B, const void* q, const void* v, void* A, void* com, void* energy, void* J, unsigned long long jplus,
+                                  unsigned long long jminus, void* mom, Layout Lq, Layout Lv, Layout La, Layout L3, Layout L2, Layout L12) {
+  void* args[] = {&B, &q, &v, &A, &com, &energy, &J, &jplus, &jminus, &mom, &Lq, &Lv, &La, &L3, &L2, &L12};
+  return hipModuleLaunchKernel(f, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr);
 }
 static bool spec_crba_fits(const rbd_ws* w) { return (size_t)w->model->nq * 4 * 65 * esize(w) <= 160u * 1024u; }  // four wavefronts' staged q (rows of 65) in one CU's LDS
 static hipFunction_t spec_crba(rbd_ws* w, size_t buffer_bytes) {
@@ -2388,9 +2407,24 @@ int rbd_kinematics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* m
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), La = layout_of(o.layout, 6L * m->nv, B);
   const Layout L3 = layout_of(o.layout, 3, B), L2 = layout_of(o.layout, 2, B);
+  w->last_kernel = "kin_kernel";
+  if (!m->big && B >= w->spec_kin_min_batch) spec_load(w, SPEC_KIN, false);
+  if (!m->big && B >= w->spec_kin_min_batch && w->spec_kin && w->spec_energy) {
+    // large batches: one lane per state, compiled for the mechanism — the momentum matrix (with the centre of mass) and the energies (with the centre of mass
+    // when the matrix is not asked for) are a walk each: what a walk carries is decided at compile time (rbd_spec.hpp kin_spec)
+    Timed t(w);
+    if (dA) HIP_TRY(launch_kin_spec(w, w->spec_kin, B, dq, nullptr, dA, dcom, nullptr, nullptr, 0, 0, nullptr, Lq, Lv, La, L3, L2, L2));
+    if (den) HIP_TRY(launch_kin_spec(w, w->spec_energy, B, dq, dv, nullptr, dA ? nullptr : dcom, den, nullptr, 0, 0, nullptr, Lq, Lv, La, L3, L2, L2));
+    else if (!dA && dcom) {  // the centre of mass alone: the energies' walk without its twists would do; it runs with v = q's rows read as velocities... no: its own instantiation is not worth a kernel — use the matrix walk's inertias
+      if ((st = ensure(&w->d_rows, &w->d_rows_bytes, es * 6 * (size_t)m->nv * (size_t)B))) return st;
+      HIP_TRY(launch_kin_spec(w, w->spec_kin, B, dq, nullptr, w->d_rows, dcom, nullptr, nullptr, 0, 0, nullptr, Lq, Lv, La, L3, L2, L2));
+    }
+    w->last_kernel = "kin_spec (compiled for the mechanism at run time)";
+  } else
   if (m->big) {
     if ((st = big_scratch(w, B))) return st;
     Timed t(w);
+    w->last_kernel = "big_kin_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_big_kin<double>(w->big, B, dq, dv, dA, dcom, den, nullptr, -1, -1, nullptr, w->d_big_scratch, Lq, Lv, La, L3, L2, L2, w->stream));
     else HIP_TRY(launch_big_kin<float>(w->big, B, dq, dv, dA, dcom, den, nullptr, -1, -1, nullptr, w->d_big_scratch, Lq, Lv, La, L3, L2, L2, w->stream));
   } else {
@@ -2433,9 +2467,17 @@ int rbd_geometric_jacobian(rbd_ws_t* w, int32_t B, const void* q, int32_t base_b
   if (o.memory == RBD_MEM_HOST) {
     if ((st = stage_in(w, 0, q, es * m->nq * B, &dq)) || (st = stage_out_alloc(w, 4, jac, es * 6 * m->nv * B, &dJ))) return st;
   }
+  w->last_kernel = "kin_kernel";
+  if (!m->big && B >= w->spec_kin_min_batch) spec_load(w, SPEC_KIN, false);
+  if (!m->big && B >= w->spec_kin_min_batch && w->spec_jac) {
+    Timed t(w);
+    HIP_TRY(launch_kin_spec(w, w->spec_jac, B, dq, nullptr, nullptr, nullptr, nullptr, dJ, plus, minus, nullptr, Lq, Lv, La, L3, L2, L2));
+    w->last_kernel = "jac_spec (compiled for the mechanism at run time)";
+  } else
   if (m->big) {
     if ((st = big_scratch(w, B))) return st;
     Timed t(w);
+    w->last_kernel = "big_kin_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_big_kin<double>(w->big, B, dq, nullptr, nullptr, nullptr, nullptr, dJ, base_body, target_body, nullptr, w->d_big_scratch, Lq, Lv, La, L3, L2, L2, w->stream));
     else HIP_TRY(launch_big_kin<float>(w->big, B, dq, nullptr, nullptr, nullptr, nullptr, dJ, base_body, target_body, nullptr, w->d_big_scratch, Lq, Lv, La, L3, L2, L2, w->stream));
   } else {
@@ -2466,9 +2508,17 @@ int rbd_momentum(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* out
       return st;
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), L12 = layout_of(o.layout, 12, B);
+  w->last_kernel = "momentum_kernel";
+  if (!m->big && B >= w->spec_kin_min_batch) spec_load(w, SPEC_KIN, false);
+  if (!m->big && B >= w->spec_kin_min_batch && w->spec_mom) {
+    Timed t(w);
+    HIP_TRY(launch_kin_spec(w, w->spec_mom, B, dq, dv, nullptr, nullptr, nullptr, nullptr, 0, 0, dout, Lq, Lv, Lq, Lq, Lq, L12));
+    w->last_kernel = "mom_spec (compiled for the mechanism at run time)";
+  } else
   if (m->big) {
     if ((st = big_scratch(w, B))) return st;
     Timed t(w);
+    w->last_kernel = "big_kin_kernel";
     if (w->dtype == RBD_F64) HIP_TRY(launch_big_kin<double>(w->big, B, dq, dv, nullptr, nullptr, nullptr, nullptr, -1, -1, dout, w->d_big_scratch, Lq, Lv, Lq, Lq, Lq, L12, w->stream));
     else HIP_TRY(launch_big_kin<float>(w->big, B, dq, dv, nullptr, nullptr, nullptr, nullptr, -1, -1, dout, w->d_big_scratch, Lq, Lv, Lq, Lq, Lq, L12, w->stream));
   } else {

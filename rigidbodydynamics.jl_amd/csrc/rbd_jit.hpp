@@ -11,6 +11,11 @@ bool jit_available();  // libhiprtc found and RBD_JIT != 0
 // One program per (family, scalar type): SPEC_MASS = mass_matrix! (+ the dense step and the emitter of M: fp32, nv a multiple of 4, nv <= 40), SPEC_ABA = dynamics!,
 // SPEC_RNEA = inverse_dynamics! / dynamics_bias!.  Empty string: no such program for this mechanism (spec_has).
 enum { SPEC_MASS = 0, SPEC_ABA = 1, SPEC_RNEA = 2, SPEC_FAMILIES = 3 };
+// ... and (round 6) SPEC_KIN = the kinematics by-products (kin_spec / jac_spec / mom_spec of rbd_spec.hpp: momentum_matrix!, center_of_mass, energies, geometric_jacobian!,
+// momentum, momentum_rate_bias).  Its public family number is 11 (3..10 were taken by the loop, walk, banked and `simulate` programs when it was added); a workspace
+// keeps its module in slot spec_slot(SPEC_KIN) = 3 of the per-family arrays.
+enum { SPEC_KIN = 11, SPEC_SLOTS = 4 };
+inline int spec_slot(int family) { return family == SPEC_KIN ? 3 : family; }
 bool spec_has(int family, int dtype, int nb, int nq, int nv, int n3 = 0);  // n3: 3-dof joints (10 more LDS rows each in dynamics!)
 bool spec_has_chol(int dtype, int nv);
 std::string spec_source(const StatePlan& P, int nb, int nq, int nv, const uint64_t* row_mask, const double* gravity, int dtype, int family);

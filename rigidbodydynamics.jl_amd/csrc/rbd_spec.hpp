@@ -581,6 +581,241 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
 }
 
 
+#ifdef RBD_SPEC_KIN
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The kinematics by-products of the forward-kinematics pass (round 6; SURVEY.md §8 f3 — what the reference benchmarks beside the dynamics,
+// perf/runbenchmarks.jl:69-110), one lane per state, compiled for rbd_plan's mechanism — the same depth-first walk as crba_spec above, every tree joint type:
+//   WHAT = 0  momentum_matrix!(A, state) (src/mechanism_algorithms.jl:313-327: column i = crb_inertia(body(i)) S_i) and, from the same inertias,
+//             center_of_mass (:28-50)                                                                                 -> A_out, com_out (nullable)
+//   WHAT = 3  kinetic_energy / gravitational_potential_energy (src/mechanism_state.jl:886-903) and center_of_mass     -> energy_out, com_out (nullable)
+//   WHAT = 1  geometric_jacobian!(J, state, path) (:80-99): +S on the joints walked down to the target, -S on those walked up from the base (jplus / jminus: one
+//             bit per body in depth-first order — the order of the ENTER ops), zero elsewhere                          -> J_out
+//   WHAT = 2  momentum(state), momentum_rate_bias(state) (src/mechanism_state.jl:975-987): Σ I_b T_b and Σ I_b A_b + T_b x* I_b T_b with the bias accelerations
+//             of update_bias_accelerations_wrt_world! (:814-830, no gravity term)                                       -> mom_out (12 per state)
+// Why a kernel of its own: the lane-per-body kin_kernel (rbd_kernels.hip) keeps a state on 32 lanes of which a level sweep uses a handful — at 65 536 fp64 Atlas
+// states rbd_kinematics took 207 us, rbd_geometric_jacobian 149, rbd_momentum 164 for 154 + 120 + 44 MB of compulsory traffic (profiles/r06_kernel_stats_kin.csv, first
+// measurement of this row).  Here every vector instruction works on 64 states, q and v arrive through LDS rows in whole runs, and a column of A / J leaves as the
+// lane's own 48 contiguous bytes (three 16-byte stores in fp64).  What is wanted is a TEMPLATE parameter, never a test of a pointer inside the walk: with run-time
+// flags there (`v ? row : 0`, `if (A_out)`) the compiler turned every LDS read of the v rows into a speculated load at the top of the kernel and spilled what it
+// had read — 564 spilled registers for Atlas in fp64 (2.2 KB of scratch per lane); as four instantiations the same walks take 130 - 400 registers and none.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int kin_slot_of(int O) {  // depth-first ordinal of op O's body = the number of ENTER ops before it
+  int n = 0;
+  for (int o = 0; o < O; ++o) n += ((P::OPW[o][0] & 0xff) == SK_ENTER) ? 1 : 0;
+  return n;
+}
+template <typename T, int WHAT>
+RBD_DEV void kin_spec(long B, const T* __restrict__ q, const T* __restrict__ v, T* __restrict__ A_out, T* __restrict__ com_out, T* __restrict__ energy_out,
+                      T* __restrict__ J_out, unsigned long long jplus, unsigned long long jminus, T* __restrict__ mom_out, Layout Lq, Layout Lv, Layout La, Layout L3,
+                      Layout L2, Layout L12, T gx, T gy, T gz, T* lds) {
+  constexpr int ML = P::NLEVELS, NQ = P::NQ, NV = P::NV;
+  constexpr bool TWISTS = WHAT >= 2, INERTIAS = WHAT != 1, CRB = WHAT == 0;  // what the walk carries: twists (v needed), bodies' inertias, their composites
+  const int lane = threadIdx.x & 63;
+  const long state0 = (long)blockIdx.x * 64;
+  if (state0 >= B) return;
+  const long state_raw = state0 + lane;
+  const bool live = state_raw < B;
+  const long state = live ? state_raw : B - 1;
+  T* qrows = lds;
+  T* vrows = lds + (size_t)NQ * RS;
+  rows_in<T, NQ>(q, Lq, state0, B, qrows);
+  if constexpr (TWISTS) rows_in<T, NV>(v, Lv, state0, B, vrows);
+  wave_sync();
+  const T* qs = qrows + lane;
+  // a velocity is read where the walk uses it: the rows are written once, so nothing but this `volatile` keeps the compiler from reading all of them at the top
+  // of the kernel and carrying — or spilling — them from there (seen: 765 spilled registers in the fp32 momentum walk, none in the fp64 one, and the other way
+  // round with a run-time test in front of the read)
+  const T* vs = vrows + lane;
+  auto vrow = [&](int k) __attribute__((always_inline)) { return *reinterpret_cast<const volatile T*>(vs + k * RS); };
+  // a column (6 values) of A or J of this lane's state: 48 contiguous bytes when a state's values are (the caller's n x B column-major matrix), else a strided run
+  auto put_col = [&](T* out, int col, const T* x) __attribute__((always_inline)) {
+    if (!live) return;
+    T* dst = out + (long)(6 * col) * La.sk + state * La.sb;
+    if (La.sk == 1) {
+      if constexpr (sizeof(T) == 8) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { d2 w = {(double)x[2 * k], (double)x[2 * k + 1]}; *reinterpret_cast<d2*>(dst + 2 * k) = w; }  // (A / J of a state start on 16 bytes: 6 nv values of 8)
+      } else {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { f2v w = {(float)x[2 * k], (float)x[2 * k + 1]}; *reinterpret_cast<f2v*>(dst + 2 * k) = w; }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dst[(long)k * La.sk] = x[k];
+    }
+  };
+  // the path from the root to the body the walk is at: transforms to root, twists, bias accelerations, inertias being accumulated, motion subspace columns
+  T X[ML][12], TW[ML][6], AB[ML][6], IC[ML][10], S[ML][6];
+  T ke = T(0), pe = T(0), ms = T(0), cs[3] = {T(0), T(0), T(0)}, hs[6], ws[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) hs[k] = ws[k] = T(0);
+  sfor<P::NOPS>([&](auto oc) __attribute__((always_inline)) {
+    constexpr int O = oc.value, w0 = P::OPW[O][0], kind = w0 & 0xff, lvl = (w0 >> 8) & 0xff, jt = w0 >> 16, voff = P::OPW[O][2];
+    if constexpr (kind == SK_ENTER) {
+      T* R = X[lvl];
+      T* p = X[lvl] + 9;
+      if constexpr (jt_1dof(jt) || jt == RBD_JOINT_FIXED) {
+        T Rp[9], pp[3];
+        if constexpr (lvl == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rp[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pp[k] = T(0);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rp[k] = X[lvl - 1][k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pp[k] = X[lvl - 1][9 + k];
+        }
+        compose_1dof<T, O>(joint_q<T, O>(qs), Rp, pp, R, p);
+      } else {
+        T Rl[9], pl[3];
+        local_transform<T, O, RS>(qs, Rl, pl);
+        if constexpr (lvl == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) R[k] = Rl[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) p[k] = pl[k];
+        } else {
+          T t[3];
+          matmul3(X[lvl - 1], Rl, R);
+          matvec3(X[lvl - 1], pl, t);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) p[k] = X[lvl - 1][9 + k] + t[k];
+        }
+      }
+      if constexpr (jt_1dof(jt)) subspace_1dof<T, jt>(R, p, S[lvl]);
+      if constexpr (WHAT == 1) {
+        // every column is written (fill!(jac, 0) first in the reference): ±S on the path, zeros off it
+        constexpr int slot = kin_slot_of(O);
+        const T sg = ((jplus >> slot) & 1ull) ? T(1) : ((jminus >> slot) & 1ull) ? T(-1) : T(0);  // (uniform)
+        if constexpr (jt_1dof(jt)) {
+          T c[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) c[k] = sg * S[lvl][k];
+          put_col(J_out, voff, c);
+        } else if constexpr (nvj_of(jt) > 1) {
+          sfor<nvj_of(jt)>([&](auto cic) __attribute__((always_inline)) {
+            constexpr int ci = cic.value;
+            T e[6], Si[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) e[k] = (k == comp_of(jt, ci)) ? sg : T(0);
+            xmotion(R, p, e, Si);
+            put_col(J_out, voff + ci, Si);
+          });
+        }
+      }
+      if constexpr (TWISTS) {
+        // twist_wrt_world (update_twists_wrt_world!, mechanism_state.jl:769-780) and, for the momentum rate, the bias acceleration A_b = A_p + [T_b, T_b - T_p]
+        T vJ[6];
+        if constexpr (jt_1dof(jt)) {
+          const T qd = vrow(voff);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) vJ[k] = S[lvl][k] * qd;
+        } else if constexpr (nvj_of(jt) > 1) {
+          T v6[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v6[k] = T(0);
+#pragma unroll
+          for (int k = 0; k < nvj_of(jt); ++k) v6[comp_of(jt, k)] = vrow(voff + k);  // (body_twist)
+          xmotion(R, p, v6, vJ);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) vJ[k] = T(0);
+        }
+        if constexpr (lvl == 0) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { TW[0][k] = vJ[k]; AB[0][k] = T(0); }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) TW[lvl][k] = TW[lvl - 1][k] + vJ[k];
+          if constexpr (WHAT == 2) {
+            T cr[6];
+            se3_comm(TW[lvl], vJ, cr);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) AB[lvl][k] = AB[lvl - 1][k] + cr[k];
+          }
+        }
+      }
+      if constexpr (INERTIAS) {
+        RInertia<T> Ib;
+        inertia_to_root_c<T, O>(R, p, Ib);
+        if constexpr (CRB) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) IC[lvl][k] = Ib.J[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) IC[lvl][6 + k] = Ib.c[k];
+          IC[lvl][9] = Ib.m;
+        }
+        if constexpr (WHAT == 3) {
+          T h[6];
+          mul_inertia(Ib, TW[lvl], h);
+          ke += dot6(h, TW[lvl]) / 2;
+        }
+        if constexpr (WHAT != 2) {
+          if constexpr (P::TR[O][TR_M] > 0.0) {  // (a body without mass has no centre of mass: center_of_mass skips it, mechanism_algorithms.jl:36)
+            pe -= gx * Ib.c[0] + gy * Ib.c[1] + gz * Ib.c[2];
+            ms += Ib.m;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cs[k] += Ib.c[k];
+          }
+        } else {
+          T h[6], Ia[6], x[6];
+          mul_inertia(Ib, TW[lvl], h);
+          mul_inertia(Ib, AB[lvl], Ia);
+          momentum_cross(Ib, TW[lvl], x);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { hs[k] += h[k]; ws[k] += Ia[k] + x[k]; }
+        }
+      }
+    } else if constexpr (WHAT == 0) {
+      // EXIT: the subtree below is finished — IC[lvl] is the composite inertia (update_crb_inertias!, mechanism_state.jl:852-868); column(s) = Ic S
+      RInertia<T> Ic;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Ic.J[k] = IC[lvl][k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ic.c[k] = IC[lvl][6 + k];
+      Ic.m = IC[lvl][9];
+      if constexpr (lvl > 0) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) IC[lvl - 1][k] += IC[lvl][k];
+      }
+      {
+        if constexpr (nvj_of(jt) > 1) {
+          sfor<nvj_of(jt)>([&](auto cic) __attribute__((always_inline)) {
+            constexpr int ci = cic.value;
+            T e[6], Si[6], F[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) e[k] = (k == comp_of(jt, ci)) ? T(1) : T(0);
+            xmotion(X[lvl], X[lvl] + 9, e, Si);
+            mul_inertia(Ic, Si, F);
+            put_col(A_out, voff + ci, F);
+          });
+        } else if constexpr (jt != RBD_JOINT_FIXED) {
+          T F[6];
+          mul_inertia(Ic, S[lvl], F);
+          put_col(A_out, voff, F);
+        }
+      }
+    }
+  });
+  if (!live) return;
+  if constexpr (WHAT == 3) { energy_out[0 * L2.sk + state * L2.sb] = ke; energy_out[1 * L2.sk + state * L2.sb] = pe; }
+  if constexpr (WHAT == 0 || WHAT == 3) {
+    if (com_out) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) com_out[(long)k * L3.sk + state * L3.sb] = cs[k] / ms;
+    }
+  }
+  if constexpr (WHAT == 2) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { mom_out[(long)k * L12.sk + state * L12.sb] = hs[k]; mom_out[(long)(6 + k) * L12.sk + state * L12.sb] = ws[k]; }
+  }
+}
+#endif  // RBD_SPEC_KIN
+
 #ifdef RBD_SPEC_ABA
 // ---------------------------------------------------------------------------------------------------------------------------------
 // dynamics! (the articulated-body algorithm, src/mechanism_algorithms.jl:845-864 through the world-frame recursion of the other ABA kernels),

@@ -659,7 +659,7 @@ def jit_source(flat, dtype=torch.float32, family="mass_matrix"):
     try:
         dt = _capi.F64 if dtype == torch.float64 else _capi.F32
         fam = {"mass_matrix": 0, "dynamics": 1, "inverse_dynamics": 2, "loops": 3, "dynamics_tracks": 4, "inverse_dynamics_tracks": 5, "dynamics_tracks_pairs": 6,
-               "inverse_dynamics_tracks_pairs": 7, "banked": 8, "dynamics_tracks_sim": 9, "dynamics_tracks_pairs_sim": 10}[family]
+               "inverse_dynamics_tracks_pairs": 7, "banked": 8, "dynamics_tracks_sim": 9, "dynamics_tracks_pairs_sim": 10, "kinematics": 11}[family]
         n = L.rbd_jit_source(h, dt, fam, None, 0)
         if n < 0:
             return None

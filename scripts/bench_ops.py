@@ -9,12 +9,16 @@ import rbd_amd as rbd
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--dtype", default="f64"); ap.add_argument("--model", default="atlas_floating")
-ap.add_argument("--reps", type=int, default=200); ap.add_argument("--only", default="", help="substring filter on the op names")
+ap.add_argument("--no-sim", action="store_true"); ap.add_argument("--reps", type=int, default=200); ap.add_argument("--only", default="", help="substring filter on the op names")
 args = ap.parse_args()
 tdt = torch.float64 if args.dtype == "f64" else torch.float32
-model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
+if args.model.startswith("randmech"):  # the reference's own test mechanism (test/test_mechanism_algorithms.jl:1-11; SPQuatFloating -> QuaternionSpherical), seed = the suffix
+    model = rbd.flatten(rbd.randmech(np.random.default_rng(int(args.model[8:] or 1))))
+else:
+    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
 B = args.batch
 rng = np.random.default_rng(1)
+if args.no_sim: pass
 state = rbd.MechanismState(model, B, dtype=tdt); result = rbd.DynamicsResult(model, B, dtype=tdt)
 rbd.set_configuration_(state, rbd.rand_configuration(model, B, rng)); rbd.set_velocity_(state, rbd.rand_velocity(model, B, rng))
 tau = torch.rand(B, model.nv, dtype=tdt, device="cuda"); out = torch.zeros_like(tau)
@@ -35,6 +39,7 @@ ops = {
     "geometric_jacobian! (root -> last body)": lambda: rbd.geometric_jacobian_(Abuf, state, -1, model.n_bodies - 1),
     "center_of_mass": lambda: rbd.center_of_mass(state),
     "kinetic_energy": lambda: rbd.kinetic_energy(state),
+    "momentum + momentum_rate_bias": lambda: rbd.momentum(state),
 }
 res = {}
 for name, f in ops.items():
@@ -52,7 +57,9 @@ for name, f in ops.items():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / args.reps * 1e3
-    res[name] = {"us_per_launch": round(us, 2), "Mevals_per_s": round(B / us, 1)}
+    res[name] = {"us_per_launch": round(us, 2), "Mevals_per_s": round(B / us, 1), "kernel": rbd.last_kernel(state)[:60]}
+if args.no_sim:
+    print(json.dumps({"model": args.model, "batch": B, "dtype": args.dtype, "ops": res})); sys.exit(0)
 # simulate: steps/s (each step = 4 dynamics! + 5 stage kernels)
 q0, v0 = state.q.clone(), state.v.clone()
 rbd.simulate_(state, 0.0095, dt=1e-3); torch.cuda.synchronize()

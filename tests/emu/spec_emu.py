@@ -77,3 +77,17 @@ def crba(lib, model, q, dtype=np.float32, permuted=False):
     f = lib.emu_crba_f32 if dtype == np.float32 else lib.emu_crba_f64
     f(ctypes.c_long(B), _p(qs), _p(M), ctypes.c_int(1 if permuted else 0))
     return M.T.reshape(B, nv, nv).transpose(0, 2, 1).copy()  # [b, row, col]
+
+
+def kin(lib, model, q, v, dtype=np.float64, path=None):
+    """The by-product kernels (kin_spec / jac_spec / mom_spec) on the host: A (B, 6, nv), com (B, 3), energies (B, 2), J (B, 6, nv) of path = (jplus, jminus) bit
+    masks over the bodies in depth-first order, momentum + momentum_rate_bias (B, 12)."""
+    B, nv = q.shape[0], model.nv
+    qs = np.ascontiguousarray(q.T, dtype=dtype); vs = np.ascontiguousarray(v.T, dtype=dtype)
+    A = np.full((6 * nv, B), np.nan, dtype=dtype); com = np.full((3, B), np.nan, dtype=dtype); en = np.full((2, B), np.nan, dtype=dtype)
+    J = np.full((6 * nv, B), np.nan, dtype=dtype) if path is not None else None
+    mom = np.full((12, B), np.nan, dtype=dtype)
+    jp, jm = path if path is not None else (0, 0)
+    lib.emu_kin(ctypes.c_long(B), _p(qs), _p(vs), _p(A), _p(com), _p(en), _p(J), ctypes.c_ulonglong(jp), ctypes.c_ulonglong(jm), _p(mom))
+    unp = lambda X: X.T.reshape(B, nv, 6).transpose(0, 2, 1).copy()
+    return unp(A), com.T.copy(), en.T.copy(), (unp(J) if J is not None else None), mom.T.copy()

@@ -1040,6 +1040,48 @@ def test_geometric_jacobian_f64(rbd, oracle, models, name, layout):
         rbd.geometric_jacobian_(J, state, 0, model.n_bodies)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", ["atlas_floating", "atlas_fixed", "valkyrie_floating", "randmech1", "inner_floating", "mixed20", "limbs_humanoid"])
+def test_kinematics_byproducts_compiled_for_the_mechanism(rbd, oracle, models, name, dtype, layout, monkeypatch):
+    """Round 6: momentum_matrix! / center_of_mass / energies, geometric_jacobian!, momentum / momentum_rate_bias one lane per state, compiled for the mechanism
+    (csrc/rbd_spec.hpp kin_spec<T, WHAT>: what large batches take — forced at a small ragged one here) against the oracle, on every tree joint type, both layouts;
+    fp64 at the reference's 1e-12 (test/test_mechanism_algorithms.jl:527-545), fp32 against the fp64 oracle."""
+    tune(monkeypatch, spec_kin_min_batch=1)
+    model = models[name]
+    B = 70
+    tol = 1e-12 if dtype == "f64" else 3e-4
+    state, q, v, _, _ = make(rbd, model, B, dtype, layout, 141)
+    shape = (B, 6 * model.nv) if layout == "aos" else (6 * model.nv, B)
+    A = torch.zeros(shape, dtype=TD[dtype], device="cuda")
+    rbd.momentum_matrix_(A, state)
+    if "kin_spec" not in rbd.last_kernel(state):
+        pytest.skip("no compiled kernel on this box: " + rbd.last_kernel(state))
+    com = rbd.center_of_mass(state)
+    ke, pe = rbd.kinetic_energy(state), rbd.gravitational_potential_energy(state)
+    h, hb = rbd.momentum(state), rbd.momentum_rate_bias(state)
+    assert "mom_spec" in rbd.last_kernel(state) or dtype == "f32"  # (a program whose registers spilled steps aside: the fp32 momentum walk of the larger trees)
+    assert rbd.sync(state) == 0
+    rel = lambda got, ref: np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+    A_ref, _, com_ref = oracle.momentum_matrix(model, q, v)
+    ke_ref, pe_ref = oracle.energy(model, q, v)
+    h_ref, hb_ref = oracle.momentum(model, q, v)
+    assert rel(host(A, state).reshape(B, model.nv, 6).transpose(0, 2, 1), A_ref) <= tol
+    assert rel(host(com, state), com_ref) <= tol
+    assert rel(ke.double().cpu().numpy(), ke_ref) <= tol and rel(pe.double().cpu().numpy(), pe_ref) <= tol
+    assert rel(h.double().cpu().numpy(), h_ref) <= 10 * tol and rel(hb.double().cpu().numpy(), hb_ref) <= 100 * tol
+    rng = np.random.default_rng(142)
+    J = torch.full(shape, 7.0, dtype=TD[dtype], device="cuda")  # off-path columns must be zeroed
+    for _ in range(5):
+        base, body = rng.choice(np.arange(-1, model.n_bodies), 2, replace=False)
+        rbd.geometric_jacobian_(J, state, int(base), int(body))
+        assert "jac_spec" in rbd.last_kernel(state)
+        ref, trel = oracle.geometric_jacobian(model, q, base, body, v)
+        got = host(J, state).reshape(B, model.nv, 6).transpose(0, 2, 1)
+        assert rel(got, ref) <= tol and rel(np.einsum("bkn,bn->bk", got, v), trel) <= 10 * tol
+
+
 def _with_gains(model, gains):
     """a copy of the flat model whose loop joints carry `gains` (one 4-tuple per loop joint) — what the oracle reads"""
     import copy

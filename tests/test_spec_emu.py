@@ -106,3 +106,51 @@ def test_emulated_mass_matrix(rbd, oracle, models, name, dtype):
         vals = got[:, np.maximum(pr, pc), np.minimum(pr, pc)]
         assert np.isfinite(vals).all()
         assert np.abs(vals - Mr[:, il[0], il[1]]).max() <= tol * max(1.0, np.abs(Mr).max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE + ["limbs_humanoid"])
+def test_emulated_kinematics_byproducts(rbd, oracle, models, name, dtype):
+    """Round 6: momentum_matrix! / center_of_mass / energies, geometric_jacobian! of random paths, momentum / momentum_rate_bias — the three kernels of the
+    `kinematics` program (csrc/rbd_spec.hpp kin_spec<T, WHAT>) on the host against the oracle; fp64 at the reference's 1e-12
+    (test/test_mechanism_algorithms.jl:527-545)."""
+    model = models[name]
+    src = rbd.jit_source(model, torch.float32 if dtype == "f32" else torch.float64, "kinematics")
+    if src is None:
+        pytest.skip("outside the compiled kernels' scope")
+    assert all(k + "_spec_" + dtype in src for k in ("kin", "jac", "mom", "energy")) and "NPAIR = 0" in src  # (every body walked on its own)
+    lib = spec_emu.build(src, "KIN_F32" if dtype == "f32" else "KIN_F64")
+    np_t, tol = (np.float32, 3e-5) if dtype == "f32" else (np.float64, 1e-12)
+    B = 70
+    rng = np.random.default_rng(23)
+    q, v = rbd.rand_configuration(model, B, rng), rbd.rand_velocity(model, B, rng)
+    q, v = q.astype(np_t).astype(np.float64), v.astype(np_t).astype(np.float64)
+    # bodies in depth-first order (the order of the ENTER ops = the slots of csrc/rbd_capi.hip): children in the reference's order, first child first
+    kids = {i: [] for i in range(-1, model.n_bodies)}
+    for i, p_ in enumerate(model.parent):
+        kids[int(p_)].append(i)
+    order, stack = [], list(reversed(kids[-1]))
+    while stack:
+        i = stack.pop()
+        order.append(i)
+        stack.extend(reversed(kids[i]))
+    slot = {b: s for s, b in enumerate(order)}
+    rel = lambda got, ref: np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+    A_ref, _, com_ref = oracle.momentum_matrix(model, q, v)
+    ke_ref, pe_ref = oracle.energy(model, q, v)
+    h_ref, hb_ref = oracle.momentum(model, q, v)
+    for trial in range(3):
+        base, body = (int(x) for x in rng.choice(np.arange(-1, model.n_bodies), 2, replace=False))
+        jp = jm = 0
+        a, b = base, body
+        while a != b:  # TreePath(base, body): src/graphs/tree_path.jl:41-63
+            if a > b:
+                jm |= 1 << slot[a]; a = int(model.parent[a])
+            else:
+                jp |= 1 << slot[b]; b = int(model.parent[b])
+        A, com, en, J, mom = spec_emu.kin(lib, model, q, v, np_t, path=(jp, jm))
+        J_ref, _ = oracle.geometric_jacobian(model, q, base, body)
+        assert np.isfinite(J).all() and rel(J, J_ref) <= tol
+    assert np.isfinite(A).all() and rel(A, A_ref) <= tol
+    assert rel(com, com_ref) <= tol and rel(en, np.stack([ke_ref, pe_ref], axis=1)) <= 10 * tol
+    assert rel(mom, np.concatenate([h_ref, hb_ref], axis=1)) <= 100 * tol
