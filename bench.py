@@ -717,7 +717,10 @@ def kin_leg(env, B, dtype, steps=40, warm=8, model_name="atlas_floating"):
         return time.perf_counter() - t0, e0.elapsed_time(e1) / steps * 1e3
 
     wall, us = time_of(list(calls))
-    each = {n_: time_of([n_])[1] for n_ in calls}
+    each, kernels = {}, []
+    for n_ in calls:
+        each[n_] = time_of([n_])[1]
+        kernels.append((L.rbd_workspace_last_kernel(h) or b"").decode().split(" (")[0])
     # parity (the per-state oracle entry points are one ctypes call per state: a sample of 4096 states)
     n = min(B, 4096)
     ndt = np.float64 if dtype == "f64" else np.float32
@@ -743,7 +746,7 @@ def kin_leg(env, B, dtype, steps=40, warm=8, model_name="atlas_floating"):
             "value": B * steps / wall, "unit": "sets/s", "steps": steps, "warmup": warm, "ms_per_step": wall / steps * 1e3, "dtype": dtype,
             "config": {"workload": f"{model_name}, batch={B}, {dtype} rbd_kinematics + rbd_geometric_jacobian + rbd_momentum", "batch_per_gpu": B},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(f"{model_name}_{dtype}_B{B}_kinematics")[0], "kernel": "kin_kernel x2 + momentum_kernel", "kernel_ms": us * 1e-3,
+                         "traffic": pmc_traffic(f"{model_name}_{dtype}_B{B}_kinematics")[0], "kernel": " + ".join(kernels), "kernel_ms": us * 1e-3,
                          "algorithmic_bytes_per_eval": alg_bytes,
                          "each": {n_: {"us": round(each[n_], 2), "bytes_per_state": calls[n_][1], "hbm_frac": round(calls[n_][1] * B / (each[n_] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
                                   for n_ in calls}},

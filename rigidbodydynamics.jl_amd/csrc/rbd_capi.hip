@@ -123,7 +123,7 @@ struct rbd_ws {
   WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_SLOTS] = {false, false, false, false}; hipModule_t spec_mod[SPEC_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // (by spec_slot(family))
-  hipFunction_t spec_kin = nullptr, spec_jac = nullptr, spec_mom = nullptr, spec_energy = nullptr; long spec_kin_min_batch = (long)1 << 62;  // the kinematics by-products compiled for the mechanism (SPEC_KIN, round 6)
+  hipFunction_t spec_kin = nullptr, spec_jac = nullptr, spec_mom = nullptr, spec_energy = nullptr, spec_com = nullptr; long spec_kin_min_batch = (long)1 << 62;  // the kinematics by-products compiled for the mechanism (SPEC_KIN, round 6)
   hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_chol_nom = nullptr, spec_chol_packed = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_aba_nofext = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
@@ -1517,6 +1517,9 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   // (RBD_ALGO_ABA_CHAINS: removed in round 3; RBD_ALGO_ABA_TRACKS, RBD_ALGO_ABA_PIPE: the two round-2 experiments, removed in round 4 — all three lost at every
   // batch size; the values stay reserved)
   if (algorithm == RBD_ALGO_ABA_PIPE || algorithm == RBD_ALGO_ABA_TRACKS || algorithm == RBD_ALGO_ABA_CHAINS) return RBD_ERR_UNSUPPORTED;
+  // the kernels that take the integrator's stage write the next stage state over their own q / v inputs (rbd_walk.hpp, rbd_spec.hpp: the stage state is the launch's
+  // own block of rows) and do not look at MkStage::q_state / v_state: a caller with stage buffers of its own would have its inputs overwritten (round-5 advice)
+  if (mk && mk->stage >= 0 && (mk->q_state != dq || mk->v_state != dv)) return RBD_ERR_INVALID_ARGUMENT;
   if (algorithm == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !fuse && w->dtype == RBD_F32 && !(mk && mk->stage == 4)) {  // (all four stages in one launch: the walk kernels only)
@@ -1665,6 +1668,7 @@ static void spec_load(rbd_ws* w, int family, bool force) {
     get(&w->spec_jac, w->dtype == RBD_F64 ? "jac_spec_f64" : "jac_spec_f32"); fits(&w->spec_jac, &sc); if (sc) w->spec_jac = nullptr;
     get(&w->spec_mom, w->dtype == RBD_F64 ? "mom_spec_f64" : "mom_spec_f32"); fits(&w->spec_mom, &sc); if (sc) w->spec_mom = nullptr;
     get(&w->spec_energy, w->dtype == RBD_F64 ? "energy_spec_f64" : "energy_spec_f32"); fits(&w->spec_energy, &sc); if (sc) w->spec_energy = nullptr;
+    get(&w->spec_com, w->dtype == RBD_F64 ? "com_spec_f64" : "com_spec_f32"); fits(&w->spec_com, &sc); if (sc) w->spec_com = nullptr;
   }
 }
 // one launch of a by-product kernel compiled for the mechanism (rbd_spec.hpp kin_spec<T, WHAT>): a wavefront of 64 states per workgroup
@@ -2409,16 +2413,14 @@ int rbd_kinematics(rbd_ws_t* w, int32_t B, const void* q, const void* v, void* m
   const Layout L3 = layout_of(o.layout, 3, B), L2 = layout_of(o.layout, 2, B);
   w->last_kernel = "kin_kernel";
   if (!m->big && B >= w->spec_kin_min_batch) spec_load(w, SPEC_KIN, false);
-  if (!m->big && B >= w->spec_kin_min_batch && w->spec_kin && w->spec_energy) {
+  if (!m->big && B >= w->spec_kin_min_batch && w->spec_kin && w->spec_energy && w->spec_com) {
     // large batches: one lane per state, compiled for the mechanism — the momentum matrix (with the centre of mass) and the energies (with the centre of mass
-    // when the matrix is not asked for) are a walk each: what a walk carries is decided at compile time (rbd_spec.hpp kin_spec)
+    // when the matrix is not asked for) are a walk each, the centre of mass alone the lightest one: what a walk carries is decided at compile time (rbd_spec.hpp
+    // kin_spec)
     Timed t(w);
     if (dA) HIP_TRY(launch_kin_spec(w, w->spec_kin, B, dq, nullptr, dA, dcom, nullptr, nullptr, 0, 0, nullptr, Lq, Lv, La, L3, L2, L2));
     if (den) HIP_TRY(launch_kin_spec(w, w->spec_energy, B, dq, dv, nullptr, dA ? nullptr : dcom, den, nullptr, 0, 0, nullptr, Lq, Lv, La, L3, L2, L2));
-    else if (!dA && dcom) {  // the centre of mass alone: the energies' walk without its twists would do; it runs with v = q's rows read as velocities... no: its own instantiation is not worth a kernel — use the matrix walk's inertias
-      if ((st = ensure(&w->d_rows, &w->d_rows_bytes, es * 6 * (size_t)m->nv * (size_t)B))) return st;
-      HIP_TRY(launch_kin_spec(w, w->spec_kin, B, dq, nullptr, w->d_rows, dcom, nullptr, nullptr, 0, 0, nullptr, Lq, Lv, La, L3, L2, L2));
-    }
+    if (!dA && !den && dcom) HIP_TRY(launch_kin_spec(w, w->spec_com, B, dq, nullptr, nullptr, dcom, nullptr, nullptr, 0, 0, nullptr, Lq, Lv, La, L3, L2, L2));
     w->last_kernel = "kin_spec (compiled for the mechanism at run time)";
   } else
   if (m->big) {

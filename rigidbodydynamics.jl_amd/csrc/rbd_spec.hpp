@@ -588,6 +588,7 @@ RBD_DEV void crba_spec(long B, const T* __restrict__ q, T* __restrict__ Mout, La
 //   WHAT = 0  momentum_matrix!(A, state) (src/mechanism_algorithms.jl:313-327: column i = crb_inertia(body(i)) S_i) and, from the same inertias,
 //             center_of_mass (:28-50)                                                                                 -> A_out, com_out (nullable)
 //   WHAT = 3  kinetic_energy / gravitational_potential_energy (src/mechanism_state.jl:886-903) and center_of_mass     -> energy_out, com_out (nullable)
+//   WHAT = 4  center_of_mass alone (transforms and the bodies' first mass moments: the lightest walk)                    -> com_out
 //   WHAT = 1  geometric_jacobian!(J, state, path) (:80-99): +S on the joints walked down to the target, -S on those walked up from the base (jplus / jminus: one
 //             bit per body in depth-first order — the order of the ENTER ops), zero elsewhere                          -> J_out
 //   WHAT = 2  momentum(state), momentum_rate_bias(state) (src/mechanism_state.jl:975-987): Σ I_b T_b and Σ I_b A_b + T_b x* I_b T_b with the bias accelerations
@@ -609,7 +610,7 @@ RBD_DEV void kin_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
                       T* __restrict__ J_out, unsigned long long jplus, unsigned long long jminus, T* __restrict__ mom_out, Layout Lq, Layout Lv, Layout La, Layout L3,
                       Layout L2, Layout L12, T gx, T gy, T gz, T* lds) {
   constexpr int ML = P::NLEVELS, NQ = P::NQ, NV = P::NV;
-  constexpr bool TWISTS = WHAT >= 2, INERTIAS = WHAT != 1, CRB = WHAT == 0;  // what the walk carries: twists (v needed), bodies' inertias, their composites
+  constexpr bool TWISTS = WHAT == 2 || WHAT == 3, INERTIAS = WHAT != 1, CRB = WHAT == 0;  // what the walk carries: twists (v needed), bodies' inertias, their composites
   const int lane = threadIdx.x & 63;
   const long state0 = (long)blockIdx.x * 64;
   if (state0 >= B) return;
@@ -803,7 +804,7 @@ RBD_DEV void kin_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   });
   if (!live) return;
   if constexpr (WHAT == 3) { energy_out[0 * L2.sk + state * L2.sb] = ke; energy_out[1 * L2.sk + state * L2.sb] = pe; }
-  if constexpr (WHAT == 0 || WHAT == 3) {
+  if constexpr (WHAT == 0 || WHAT == 3 || WHAT == 4) {
     if (com_out) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) com_out[(long)k * L3.sk + state * L3.sb] = cs[k] / ms;

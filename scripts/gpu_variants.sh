@@ -5,7 +5,7 @@ LEG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 OUT=$R/gpurun_out/variants; rm -rf $OUT; mkdir -p $OUT
-case $LEG in c2) A="--config 2";; c2id) A="--config 2 --op inverse_dynamics";; c3) A="--config 3";; c3noM) A="--config 3 --no-emit-M";; c3pk) A="--config 3 --packed-M";; c4) A="--config 4";; c2big) A="--config 2 --batch 65536";; c2idb) A="--config 2 --batch 65536 --op inverse_dynamics --bodies";; c5) A="--config 5";; esac
+case $LEG in c2) A="--config 2";; c2id) A="--config 2 --op inverse_dynamics";; c3) A="--config 3";; c3noM) A="--config 3 --no-emit-M";; c3pk) A="--config 3 --packed-M";; c4) A="--config 4";; c2big) A="--config 2 --batch 65536";; c2idb) A="--config 2 --batch 65536 --op inverse_dynamics --bodies";; c5) A="--config 5";; sim64) A="--config 2 --op-sim";; sim64b) A="--config 2 --batch 65536 --op-sim";; sim32) A="--config 4 --op-sim";; kin) A="--config 2 --batch 65536 --op-kin";; esac
 SHORT="$A --no-cpu-baseline --no-extra-legs --no-other-configs --steps 60 --warmup 10"
 cd /tmp
 for V in "$@"; do

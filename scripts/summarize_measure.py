@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (CONFIGS, kernel_source_hash)
 
 OUT = os.path.join(ROOT, "gpurun_out", "measure")
-OURS = ("aba_", "rnea_", "crba_", "chol_", "loop_", "mk_", "kin_", "momentum_", "emit_", "pack_", "big_")
+OURS = ("aba_", "rnea_", "crba_", "chol_", "loop_", "mk_", "kin_", "momentum_", "emit_", "pack_", "big_", "jac_", "mom_", "energy_", "com_")
 
 
 def short(name):

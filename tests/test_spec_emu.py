@@ -1,6 +1,7 @@
 """The kernels compiled per mechanism (csrc/rbd_spec.hpp), run on the HOST one lane at a time (tests/emu/spec_emu.py) against the oracle: the arithmetic of the
 generated straight-line code — plan tables, limbs walked in lockstep, folded constants — checked without a GPU.  The GPU tests (test_state_kernels.py) run the
 same programs through hiprtc."""
+import ctypes
 import os
 import re
 import sys
@@ -118,7 +119,7 @@ def test_emulated_kinematics_byproducts(rbd, oracle, models, name, dtype):
     src = rbd.jit_source(model, torch.float32 if dtype == "f32" else torch.float64, "kinematics")
     if src is None:
         pytest.skip("outside the compiled kernels' scope")
-    assert all(k + "_spec_" + dtype in src for k in ("kin", "jac", "mom", "energy")) and "NPAIR = 0" in src  # (every body walked on its own)
+    assert all(k + "_spec_" + dtype in src for k in ("kin", "jac", "mom", "energy", "com")) and "NPAIR = 0" in src  # (every body walked on its own)
     lib = spec_emu.build(src, "KIN_F32" if dtype == "f32" else "KIN_F64")
     np_t, tol = (np.float32, 3e-5) if dtype == "f32" else (np.float64, 1e-12)
     B = 70
@@ -153,4 +154,8 @@ def test_emulated_kinematics_byproducts(rbd, oracle, models, name, dtype):
         assert np.isfinite(J).all() and rel(J, J_ref) <= tol
     assert np.isfinite(A).all() and rel(A, A_ref) <= tol
     assert rel(com, com_ref) <= tol and rel(en, np.stack([ke_ref, pe_ref], axis=1)) <= 10 * tol
+    # ... and the centre of mass from the walk of its own (what center_of_mass(state) alone launches)
+    lib.emu_kin(ctypes.c_long(B), spec_emu._p(np.ascontiguousarray(q.T, dtype=np_t)), None, None, spec_emu._p(com2 := np.full((3, B), np.nan, dtype=np_t)), None, None,
+                ctypes.c_ulonglong(0), ctypes.c_ulonglong(0), None)
+    assert rel(com2.T, com_ref) <= tol
     assert rel(mom, np.concatenate([h_ref, hb_ref], axis=1)) <= 100 * tol
