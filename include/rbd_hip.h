@@ -87,7 +87,8 @@ enum {
                                 wavefronts over the same 64 states, q / v / tau staged through LDS, per-joint results in accumulation
                                 registers.  Trees of revolute / prismatic / fixed joints, 6-dof joints on the world, at most 11 steps per
                                 track; RBD_ERR_UNSUPPORTED elsewhere or when the rows of 64 states do not fit one compute unit's LDS.
-                                Large batches                                                                                       */
+                                Large batches.  `simulate` on this mapping takes the four stages of a step in ONE launch (a looped instantiation of its own:
+                                admitted statically — rbd_jit_check_walk_object — since 600)                                        */
   RBD_ALGO_ABA_PIPE = 7,     /* (round 2: a body-step cut into stages on the four SIMDs of a compute unit.  Removed; reserved)     */
   RBD_ALGO_ABA_COMPILED = 8  /* one lane per state, straight-line code compiled for the mechanism at run time (rbd_jit_* below): fp32,
                                 trees of every joint type above (since 400: Planar, QuaternionSpherical, QuaternionFloating below the world
@@ -173,10 +174,11 @@ typedef struct rbd_opts {
 } rbd_opts_t;
 
 /* ---- model / workspace lifetime ------------------------------------------ */
-/* Sizes: mechanisms of up to 64 moving bodies run on the wavefront-shaped kernels (any nv; at most 8 children per body).  Mechanisms of MORE than 64
- * bodies (with loop joints or contact points since header 400) are accepted too and run on one-thread-per-state kernels with an HBM scratch — rbd_dynamics
- * (with its loop branch), rbd_inverse_dynamics[_bodies], rbd_dynamics_bias[_bodies], rbd_mass_matrix, rbd_mass_matrix_solve, rbd_dynamics_result,
- * rbd_contact_dynamics, rbd_dynamics_contact; every other entry point (simulate, kinematics by-products) returns RBD_ERR_UNSUPPORTED for such a model. */
+/* Sizes: mechanisms of up to 64 moving bodies with at most 8 children per body run on the wavefront-shaped kernels (any nv).  Mechanisms of MORE than 64 bodies, or
+ * with a body of more than 8 children (since header 600; refused before), are accepted too and run on one-thread-per-state kernels with an HBM scratch (no speed
+ * claim) — every entry point: rbd_dynamics with its loop branch, rbd_inverse_dynamics[_bodies], rbd_dynamics_bias[_bodies], rbd_mass_matrix[_solve], rbd_dynamics_result,
+ * the contact entry points, rbd_simulate / rbd_simulate_controlled (the PD law included) / rbd_mk_stage (since 500), and since 600 the kinematics by-products
+ * rbd_kinematics, rbd_geometric_jacobian, rbd_momentum.  The reference has no size limit (src/mechanism_algorithms.jl:28-50, :80-99, :313-327). */
 int rbd_model_create(const rbd_flat_model_t* desc, rbd_model_t** out); /* deep-copies desc */
 int rbd_model_destroy(rbd_model_t* model);
 /* Introspection of the chain schedule under the track / walk plans: tracks per state, steps per pass, (lds_fields: 0, kept for ABI
@@ -336,7 +338,10 @@ int rbd_simulate_contact(rbd_ws_t* ws, int32_t B, void* q, void* v, void* s, con
 /* ---- kinematics by-products of the same forward-kinematics pass (every output nullable; opts->memory as for rbd_dynamics) ---------------
  * momentum_matrix: 6×nv column-major per state, root frame, (angular; linear) — momentum_matrix!(out, state)
  *   src/mechanism_algorithms.jl:313-327;  com: 3×B — center_of_mass(state) :28-50;  energy: 2×B = (kinetic_energy,
- *   gravitational_potential_energy) src/mechanism_state.jl:886-903 (needs v).                                          */
+ *   gravitational_potential_energy) src/mechanism_state.jl:886-903 (needs v).
+ * Large batches (from half a chip-full of wavefronts: 32 769 states on an MI355X) take kernels compiled for the mechanism with one lane per state (family 11; Atlas,
+ * 65 536 fp64 states: momentum matrix 56 us, energies 34, Jacobian 46, momentum 41 against 207 / 149 / 164 on the lane-per-body kernels).  A column of the momentum
+ * matrix / Jacobian leaves as the lane's own 48 bytes: callers that can take the batch-innermost layout (RBD_LAYOUT_SOA) get whole 512-byte runs instead. */
 int rbd_kinematics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* momentum_matrix, void* com, void* energy,
                    const rbd_opts_t* opts);
 
@@ -363,7 +368,8 @@ int rbd_comm_destroy(rbd_comm_t* comm);
 int rbd_comm_info(const rbd_comm_t* comm, int32_t* world, int32_t* rank);
 int rbd_gather(rbd_comm_t* comm, int32_t dtype, const void* shard, void* gathered, int64_t count, int32_t root /* < 0: every rank */, void* stream);
 /* ... with shards of different sizes (a batch that does not divide by the number of ranks): counts[world] scalars per rank, the shards back to back in rank
- * order in `gathered`; an empty shard is legal.  Every rank passes the same counts. */
+ * order in `gathered`; an empty shard is legal.  Every rank passes the same counts (not checked across ranks: ranks that disagree wait for each other forever,
+ * like mismatched ncclSend / ncclRecv sizes). */
 int rbd_gatherv(rbd_comm_t* comm, int32_t dtype, const void* shard, void* gathered, const int64_t* counts, int32_t root /* < 0: every rank */, void* stream);
 const char* rbd_comm_last_error(void);
 
@@ -379,7 +385,7 @@ int rbd_workspace_last_kernel_ms(rbd_ws_t* ws, float* ms);
 const char* rbd_workspace_last_kernel(const rbd_ws_t* ws);
 /* 100·round + revision of this header.  rbd_flat_model_t grew its four contact fields at 200; a caller built against an older header must
  * not call a newer library (the Python and Julia loaders compare this with the value they were written for).  400: rbd_workspace_set_loop_gains.
- * 500: rbd_mass_matrix_solve_packed, rbd_gatherv.  600: rbd_jit_check_walk_object. */
+ * 500: rbd_mass_matrix_solve_packed, rbd_gatherv.  600: rbd_jit_check_walk_object; no size limit left on any entry point; program family 11. */
 #define RBD_HIP_H_VERSION 600
 int rbd_version(void);
 /* Run-time specialisation.  The one-lane-per-state kernels (mass_matrix! and mass_matrix! + Cholesky at large batches) exist in a second form
@@ -390,8 +396,9 @@ int rbd_version(void);
  * (fp32), 2: inverse_dynamics! / dynamics_bias! (fp32; fp64), 3: the whole loop-joint branch of dynamics! for small loop mechanisms (<= 4 bodies, nv <= 4,
  * nc <= 6: the four-bar linkage), 4 / 5: the one-wavefront-per-track kernels of dynamics! / inverse_dynamics! (batches beyond what the two-bodies-per-lane kernels hold at once), 6 / 7: the same with two
  * fp32 states per lane, 8: the two-bodies-per-lane kernels themselves (small batches — the bench workload — with the loops over the tree's levels unrolled against the
- * mechanism's level structure) — each compiled when a workspace first takes that route.  Families 0-2 take every tree joint type; 4-7 and the fast form of 8 trees of 1-dof / fixed
- * joints with 6-dof joints on the world.
+ * mechanism's level structure), 9 / 10: 4 / 6 with the four stages of a `simulate` step in one launch, 11 (since 600): the kinematics by-products one lane per state
+ * (rbd_kinematics / rbd_geometric_jacobian / rbd_momentum at large batches: kin_spec, energy_spec, com_spec, jac_spec, mom_spec) — each compiled when a workspace first takes
+ * that route.  Families 0-2 and 11 take every tree joint type; 4-7, 9, 10 and the fast form of 8 trees of 1-dof / fixed joints with 6-dof joints on the world.
  * rbd_jit_precompile compiles all of a model's programs of one scalar type (RBD_F32 / RBD_F64) into the cache ahead of time (no device needed);
  * rbd_jit_source returns the generated source of one (length without the terminator; buf may be NULL; -1: no such program for this mechanism). */
 int rbd_jit_precompile(const rbd_model_t* model, int32_t dtype, char* log, int64_t log_capacity);

@@ -492,18 +492,12 @@ RBD_DEV void aba_bank_body(const BankModel& M, long B, typename InPtr<T, !FUSED>
     // `simulate` fusion: this launch is stage F.stage of a Munthe-Kaas RK4 step (see aba_kernel).  Both banks' stage bookkeeping
     // runs here, back to back, so that their loads of the integrator buffers share one round trip and bank 1's hide behind the
     // SE(3) log/exp of bank 0's floating joint.
-    // (round 6: every load of BOTH banks' stage before the first store of either — rbd_integrator.hpp mk_stage_loads)
-    MkStageLoads<T> S0, S1;
     if (F.close_prev) {
-      mk_stage_loads(r0.b, 4, (const T*)nullptr, F.W, Lq, Lv, S0);
-      mk_stage_loads(r1.b, 4, (const T*)nullptr, F.W, Lq, Lv, S1);
-      mk_stage_finish(r0.b, 4, (T)F.dt, qj0, vj0, false, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv, S0);
-      mk_stage_finish(r1.b, 4, (T)F.dt, qj1, vj1, false, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv, S1);
+      mk_stage_lane(r0.b, 4, (T)F.dt, qj0, vj0, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
+      mk_stage_lane(r1.b, 4, (T)F.dt, qj1, vj1, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
     }
-    mk_stage_loads(r0.b, F.stage, (const T*)nullptr, F.W, Lq, Lv, S0);
-    mk_stage_loads(r1.b, F.stage, (const T*)nullptr, F.W, Lq, Lv, S1);
-    mk_stage_finish(r0.b, F.stage, (T)F.dt, qj0, vj0, false, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv, S0);
-    mk_stage_finish(r1.b, F.stage, (T)F.dt, qj1, vj1, false, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv, S1);
+    mk_stage_lane(r0.b, F.stage, (T)F.dt, qj0, vj0, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
+    mk_stage_lane(r1.b, F.stage, (T)F.dt, qj1, vj1, (const T*)nullptr, F.W, (T*)F.q_state, (T*)F.v_state, Lq, Lv);
     pd_control_lane(r0.b, F, Lq, qj0, vj0, r0.tj);
     pd_control_lane(r1.b, F, Lq, qj1, vj1, r1.tj);
   }

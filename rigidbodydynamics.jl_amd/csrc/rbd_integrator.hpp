@@ -177,92 +177,67 @@ template <typename T, int MODE = 0> RBD_DEV void joint_global(int t, const T* q0
 // One lane's share of stage `stage` (0..4) of a step: see mk_stage_kernel.  qj / vj: the lane's joint state as loaded from the
 // state buffers (previous stage state) in, the new stage state out; the new state is also written to q_state / v_state.
 // vdot_prev == nullptr means W.vd[stage-1] already holds the previous stage's v̇ (fused launches).
-// In two halves (round 6): mk_stage_loads issues EVERY load of the stage, mk_stage_finish computes and stores.  The stage's buffers are different allocations
-// but nothing tells the compiler so: a load that stands behind a store in the source stays behind it, and vmcnt counts loads and stores in order — waiting for
-// that load's data also waits for the store's acknowledgement.  The rates' store (phid[stage - 1]) used to stand between the base point's loads and the tableau's,
-// and bank 1's loads behind bank 0's stores: dependent round trips through memory in front of the passes of every fused `simulate` launch (Atlas, 4096 fp64
-// states: 27 us per launch against 18 plain).  A caller with two bodies per lane loads for both, then finishes both.
-template <typename T> struct MkStageLoads { T q0j[7], v0j[6], vdp[6], pdv[4][6], vsv[4][6]; };
-template <typename T> RBD_DEV void mk_tableau(int stage, T* w) {  // Butcher tableau of runge_kutta_4 (ode_integrators.jl:48-55)
-  w[0] = w[1] = w[2] = w[3] = T(0);
-  if (stage == 1) w[0] = T(0.5);
-  else if (stage == 2) w[1] = T(0.5);
-  else if (stage == 3) w[2] = T(1);
-  else if (stage == 4) { w[0] = T(1) / 6; w[1] = T(1) / 3; w[2] = T(1) / 3; w[3] = T(1) / 6; }
-}
-template <typename T>
-RBD_DEV void mk_stage_loads(const Body<T>& b, int stage, const T* __restrict__ vdot_prev, const MkBuffers& W, Layout Lq, Layout Lv, MkStageLoads<T>& L) {
-  const int nv = joint_nv(b.jtype);
-  T w[4];
-  mk_tableau(stage, w);
-#pragma unroll
-  for (int k = 0; k < 6; ++k) L.vdp[k] = T(0);
-  if (stage > 0) {
-    load_joint_q(b, (const T*)W.q0, Lq, L.q0j);
-    load_joint_v(b, (const T*)W.v0, Lv, L.v0j);
-    if (vdot_prev != nullptr) load_joint_v(b, vdot_prev, Lv, L.vdp);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (w[j] != T(0)) {  // uniform
-      const T* pd = (const T*)W.phid[j]; const T* vs = (const T*)W.vd[j];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const bool on = b.valid && k < nv;
-        const long a = on ? (long)(b.voff + k) * Lv.sk + b.state * Lv.sb : 0;
-        L.pdv[j][k] = (on && j != stage - 1) ? pd[a] : T(0);
-        L.vsv[j][k] = (on && !(j == stage - 1 && vdot_prev != nullptr)) ? vs[a] : T(0);
-      }
-    }
-  }
-}
+// (Round 6, measured and taken back: the stage split into a half that issues EVERY load — both banks' in the two-bodies-per-lane kernel — and a half that computes
+//  and stores, so that no load waits behind a store in the wavefront's one in-order memory counter.  aba_bank_fused_spec_f64 at 4096 Atlas states: 27.98 us against
+//  27.13 — the general form's zeroed arrays and selects cost 440 vector instructions per wavefront and the waits did not move: profiles/r06_experiments.txt.)
 template <typename T, int MODE = 0>
-RBD_DEV void mk_stage_finish(const Body<T>& b, int stage, T dt, T* qj, T* vj, bool have_vdp, const MkBuffers& W, T* __restrict__ q_state, T* __restrict__ v_state,
-                             Layout Lq, Layout Lv, MkStageLoads<T>& L) {
+RBD_DEV void mk_stage_lane(const Body<T>& b, int stage, T dt, T* qj, T* vj, const T* __restrict__ vdot_prev, const MkBuffers& W,
+                           T* __restrict__ q_state, T* __restrict__ v_state, Layout Lq, Layout Lv) {
   const int t = b.jtype;
   const int nq = joint_nq<T>(t), nv = joint_nv(t);
+  T q0j[7], v0j[6];
   T rate[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};  // local-coordinate rates of the stage just evaluated (kept in registers: the
                                                      // tableau below needs them again, and reading them back from phid[stage-1]
                                                      // would be a store -> load round trip through L2 on the critical path)
+  T vdp[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // v̇ of the stage just evaluated, when the caller hands it over (un-fused launches)
   T* q0 = (T*)W.q0; T* v0 = (T*)W.v0;
-  T w[4];
-  mk_tableau(stage, w);
   if (stage == 0) {
 #pragma unroll
-    for (int k = 0; k < 7; ++k) { L.q0j[k] = qj[k]; if (b.valid && k < nq) q0[(long)(b.qoff + k) * Lq.sk + b.state * Lq.sb] = qj[k]; }
+    for (int k = 0; k < 7; ++k) { q0j[k] = qj[k]; if (b.valid && k < nq) q0[(long)(b.qoff + k) * Lq.sk + b.state * Lq.sb] = qj[k]; }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { L.v0j[k] = vj[k]; if (b.valid && k < nv) v0[(long)(b.voff + k) * Lv.sk + b.state * Lv.sb] = vj[k]; }
+    for (int k = 0; k < 6; ++k) { v0j[k] = vj[k]; if (b.valid && k < nv) v0[(long)(b.voff + k) * Lv.sk + b.state * Lv.sb] = vj[k]; }
   } else {
+    load_joint_q(b, q0, Lq, q0j);
+    load_joint_v(b, v0, Lv, v0j);
     // rates of the stage that has just been evaluated
-    joint_local_rate<T, MODE>(t, L.q0j, qj, vj, rate);
+    joint_local_rate<T, MODE>(t, q0j, qj, vj, rate);
     T* pd = (T*)W.phid[stage - 1];
 #pragma unroll
     for (int k = 0; k < 6; ++k)
       if (b.valid && k < nv) pd[(long)(b.voff + k) * Lv.sk + b.state * Lv.sb] = rate[k];
-    if (have_vdp) {  // v̇ of the stage just evaluated, handed over by the caller (un-fused launches): kept for the closing combination
+    if (vdot_prev != nullptr) {
+      load_joint_v(b, vdot_prev, Lv, vdp);
       T* vs = (T*)W.vd[stage - 1];
 #pragma unroll
       for (int k = 0; k < 6; ++k)
-        if (b.valid && k < nv) vs[(long)(b.voff + k) * Lv.sk + b.state * Lv.sb] = L.vdp[k];
+        if (b.valid && k < nv) vs[(long)(b.voff + k) * Lv.sk + b.state * Lv.sb] = vdp[k];
     }
   }
+  // Butcher tableau of runge_kutta_4 (ode_integrators.jl:48-55)
+  T w[4] = {T(0), T(0), T(0), T(0)};
+  if (stage == 1) w[0] = T(0.5);
+  else if (stage == 2) w[1] = T(0.5);
+  else if (stage == 3) w[2] = T(1);
+  else if (stage == 4) { w[0] = T(1) / 6; w[1] = T(1) / 3; w[2] = T(1) / 3; w[3] = T(1) / 6; }
   T phi[6], vn[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { phi[k] = T(0); vn[k] = L.v0j[k]; }
+  for (int k = 0; k < 6; ++k) { phi[k] = T(0); vn[k] = v0j[k]; }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (w[j] != T(0)) {  // uniform
       const T wj = dt * w[j];
+      const T* pd = (const T*)W.phid[j]; const T* vs = (const T*)W.vd[j];
 #pragma unroll
       for (int k = 0; k < 6; ++k)
         if (b.valid && k < nv) {
-          phi[k] += wj * ((j == stage - 1) ? rate[k] : L.pdv[j][k]);
-          vn[k] += wj * ((j == stage - 1 && have_vdp) ? L.vdp[k] : L.vsv[j][k]);
+          const long a = (long)(b.voff + k) * Lv.sk + b.state * Lv.sb;
+          phi[k] += wj * ((j == stage - 1) ? rate[k] : pd[a]);
+          vn[k] += wj * ((j == stage - 1 && vdot_prev != nullptr) ? vdp[k] : vs[a]);
         }
     }
   }
   T qn[7];
-  joint_global<T, MODE>(t, L.q0j, phi, qn);
+  joint_global<T, MODE>(t, q0j, phi, qn);
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
     qj[k] = qn[k];
@@ -273,13 +248,6 @@ RBD_DEV void mk_stage_finish(const Body<T>& b, int stage, T dt, T* qj, T* vj, bo
     vj[k] = vn[k];
     if (b.valid && k < nv) v_state[(long)(b.voff + k) * Lv.sk + b.state * Lv.sb] = vn[k];
   }
-}
-template <typename T, int MODE = 0>
-RBD_DEV void mk_stage_lane(const Body<T>& b, int stage, T dt, T* qj, T* vj, const T* __restrict__ vdot_prev, const MkBuffers& W,
-                           T* __restrict__ q_state, T* __restrict__ v_state, Layout Lq, Layout Lv) {
-  MkStageLoads<T> L;
-  mk_stage_loads(b, stage, vdot_prev, W, Lq, Lv, L);
-  mk_stage_finish<T, MODE>(b, stage, dt, qj, vj, vdot_prev != nullptr, W, q_state, v_state, Lq, Lv, L);
 }
 
 }  // namespace rbd

@@ -197,7 +197,8 @@ def test_precompile_without_a_device(rbd, tmp_path, monkeypatch):
     # the object's metadata and its kernel descriptor rewritten to cover the accumulation registers, csrc/rbd_jit.hip jit_kd_cover_agprs)
     # ... and, where the mechanism has a two-bodies-per-lane split, the banked kernels' (round 4: their level loops unrolled against the mechanism's level structure)
     # ... and (round 5) the walk kernel that takes the four stages of a `simulate` step in one launch, a program of its own
-    n = 5 + (rbd.jit_source(model, torch.float64, "banked") is not None)
+    # ... and (round 6) the kinematics by-products' five kernels, one program (family 11)
+    n = 6 + (rbd.jit_source(model, torch.float64, "banked") is not None)
     assert len(files) == n and all(os.path.getsize(tmp_path / f) > 1000 for f in files)
     assert "ready after" in log and log.count("[rbd_jit] family") == n  # the log lists every program with the seconds it took
     stamps = [os.path.getmtime(tmp_path / f) for f in files]
