@@ -197,6 +197,8 @@ def run(args, env):
 
     if args.model == "four_bar":
         model = rbd.flatten(rbd.four_bar_linkage())
+    elif args.model.startswith("randmech"):  # the reference's own test mechanism (test/test_mechanism_algorithms.jl:1-11; SPQuatFloating -> QuaternionSpherical), seed = the suffix
+        model = rbd.flatten(rbd.randmech(np.random.default_rng(int(args.model[8:] or 1))))
     else:
         model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
     B = args.batch
@@ -453,7 +455,7 @@ def run(args, env):
         alg_bytes = es * (model.nq + 3 * model.nv + model.nq + (model.nc if model.nc else 0))  # q, v, τ in; v̇ and q̇ out (+ λ)
         if headline_fext:
             alg_bytes += es * 6 * model.n_bodies
-        flops = ABA_FLOPS_PER_EVAL if model.nc == 0 else 43.0e3 * model.nv / 36.0
+        flops = ABA_FLOPS_PER_EVAL * model.nv / 36.0 if model.nc == 0 else 43.0e3 * model.nv / 36.0  # (27 kflop is Atlas's count, nv 36: scaled by nv for other trees)
         metric = "ABA dynamics! evals/sec (Atlas 30-DoF, batch)" if args.model.startswith("atlas") else f"dynamics! evals/sec ({args.model}, batch)"
         opname = f"{args.dtype} " + ("fused ABA dynamics!" if model.nc == 0 else "dynamics! with loop joints (RNEA + CRBA + constrained solve)")
     achieved_gbs = alg_bytes * B / (kernel_ms * 1e-3) / 1e9
@@ -857,6 +859,8 @@ def main():
                 # the reference's own arithmetic at the large batch: dynamics!, and inverse_dynamics! with its per-body outputs — the call shape of
                 # perf/runbenchmarks.jl:49-57 — at 65 536 fp64 states
                 ("dynamics_f64_B65536", sub_args(args, 2, batch=65536)),
+                # the reference's own test mechanism (Planar / spherical joints below a floating base: what no walk kernel takes) in its own arithmetic at the large batch
+                ("randmech_dynamics_f64_B65536", sub_args(args, 2, model="randmech1", batch=65536)),
                 ("inverse_dynamics_bodies_f64_B65536", sub_args(args, 2, batch=65536, op="inverse_dynamics", bodies=True))]
         for name, a in todo:
             try:

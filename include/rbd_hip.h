@@ -92,7 +92,9 @@ enum {
   RBD_ALGO_ABA_PIPE = 7,     /* (round 2: a body-step cut into stages on the four SIMDs of a compute unit.  Removed; reserved)     */
   RBD_ALGO_ABA_COMPILED = 8  /* one lane per state, straight-line code compiled for the mechanism at run time (rbd_jit_* below): fp32,
                                 trees of every joint type above (since 400: Planar, QuaternionSpherical, QuaternionFloating below the world
-                                too), no loop joints, nv <= 64; RBD_ALGO_ABA picks it from half a chip-full of wavefronts up.
+                                too), no loop joints, nv <= 64; RBD_ALGO_ABA picks it from half a chip-full of wavefronts up.  Since 600 also
+                                fp64 for the mechanisms no walk kernel takes (3-dof joints, 6-dof joints below the world — the reference's
+                                randmech(): 65 536 states 200 us against 684 one body per lane); RBD_ALGO_ABA picks it from 8193 states.
                                 RBD_ERR_UNSUPPORTED without hiprtc or outside that scope                                            */
 };
 
@@ -385,7 +387,7 @@ int rbd_workspace_last_kernel_ms(rbd_ws_t* ws, float* ms);
 const char* rbd_workspace_last_kernel(const rbd_ws_t* ws);
 /* 100·round + revision of this header.  rbd_flat_model_t grew its four contact fields at 200; a caller built against an older header must
  * not call a newer library (the Python and Julia loaders compare this with the value they were written for).  400: rbd_workspace_set_loop_gains.
- * 500: rbd_mass_matrix_solve_packed, rbd_gatherv.  600: rbd_jit_check_walk_object; no size limit left on any entry point; program family 11. */
+ * 500: rbd_mass_matrix_solve_packed, rbd_gatherv.  600: rbd_jit_check_walk_object; no size limit left on any entry point; program family 11; family 1 in fp64. */
 #define RBD_HIP_H_VERSION 600
 int rbd_version(void);
 /* Run-time specialisation.  The one-lane-per-state kernels (mass_matrix! and mass_matrix! + Cholesky at large batches) exist in a second form
@@ -393,7 +395,7 @@ int rbd_version(void);
  * body constants become compile-time constants — what Julia's JIT does for the reference's `mass_matrix!`), cached on disk beside the library
  * (jit_cache/) or in $RBD_JIT_CACHE.  Without libhiprtc, or with RBD_JIT=0, the interpreting kernels run instead; results agree to rounding.
  * One program per family of kernels and scalar type — family 0: mass_matrix! (+ the sparse tile Cholesky and the emitter of M in fp32), 1: dynamics!
- * (fp32), 2: inverse_dynamics! / dynamics_bias! (fp32; fp64), 3: the whole loop-joint branch of dynamics! for small loop mechanisms (<= 4 bodies, nv <= 4,
+ * (fp32; since 600 fp64 for mechanisms with 3-dof joints / 6-dof joints below the world), 2: inverse_dynamics! / dynamics_bias! (fp32; fp64), 3: the whole loop-joint branch of dynamics! for small loop mechanisms (<= 4 bodies, nv <= 4,
  * nc <= 6: the four-bar linkage), 4 / 5: the one-wavefront-per-track kernels of dynamics! / inverse_dynamics! (batches beyond what the two-bodies-per-lane kernels hold at once), 6 / 7: the same with two
  * fp32 states per lane, 8: the two-bodies-per-lane kernels themselves (small batches — the bench workload — with the loops over the tree's levels unrolled against the
  * mechanism's level structure), 9 / 10: 4 / 6 with the four stages of a `simulate` step in one launch, 11 (since 600): the kinematics by-products one lane per state

@@ -125,6 +125,7 @@ struct rbd_ws {
   bool spec_tried[SPEC_SLOTS] = {false, false, false, false}; hipModule_t spec_mod[SPEC_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // (by spec_slot(family))
   hipFunction_t spec_kin = nullptr, spec_jac = nullptr, spec_mom = nullptr, spec_energy = nullptr, spec_com = nullptr; long spec_kin_min_batch = (long)1 << 62;  // the kinematics by-products compiled for the mechanism (SPEC_KIN, round 6)
   hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_chol_nom = nullptr, spec_chol_packed = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_aba_nofext = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
+  int spec_f64_max_scratch = 0;  // (RBD_TUNE spec_f64_max_scratch; set from the measurement in workspace_create)
   int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
   bool spec_bank_tried = false; hipModule_t spec_bank_mod = nullptr; hipFunction_t spec_bank_aba = nullptr, spec_bank_fused = nullptr, spec_bank_rnea = nullptr; std::string spec_bank_src;  // the banked kernels compiled for the mechanism
@@ -1021,6 +1022,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = t; }
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
     w->spec_kin_min_batch = tune("spec_kin_min_batch", (long)ncu * 64);
+    w->spec_f64_max_scratch = (int)tune("spec_f64_max_scratch", 2048);
   } else {
     w->state_min_batch = (long)1 << 62;
   }
@@ -1522,7 +1524,10 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   if (mk && mk->stage >= 0 && (mk->q_state != dq || mk->v_state != dv)) return RBD_ERR_INVALID_ARGUMENT;
   if (algorithm == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
-  if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !fuse && w->dtype == RBD_F32 && !(mk && mk->stage == 4)) {  // (all four stages in one launch: the walk kernels only)
+  // fp64 (round 6): mechanisms with 3-dof joints / 6-dof joints below the world — what no walk or banked kernel takes — have the lane-per-state program in doubles
+  // too (rbd_jit.hip spec_has); plain dynamics! only (the integrator's stage stays with the fp32 program)
+  const bool spec_f64 = w->dtype == RBD_F64 && m->state_wide.ok && !m->state.ok && !mk;
+  if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !fuse && (w->dtype == RBD_F32 || spec_f64) && !(mk && mk->stage == 4)) {  // (all four stages in one launch: the walk kernels only)
     // with the integrator stage folded in, the lane-per-state kernel is ahead of the walk kernel earlier than without it (Atlas fp32, RK4 step: 24 576 states
     // 209 against 226 us, 32 768: 220 against 240; 16 384: 201 against 143) — the stage costs this kernel 10 us per launch, the walk kernel 28
     const long spec_from = mk ? std::min<long>(w->spec_aba_min_batch, w->spec_aba_fused_min_batch) : w->spec_aba_min_batch;
@@ -1532,15 +1537,19 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     const bool nofext = df == nullptr && w->spec_aba_nofext != nullptr;
     hipFunction_t const faba = nofext ? w->spec_aba_nofext : w->spec_aba;
     const int faba_scratch = nofext ? w->spec_aba_nofext_scratch : w->spec_aba_scratch;
-    if (faba && (algorithm == RBD_ALGO_ABA_COMPILED || (B >= spec_from && faba_scratch == 0))) {
+    // (fp64: the program spills by construction — its per-body leave-behind does not fit 512 registers in doubles; it is taken up to spec_f64_max_scratch bytes
+    //  per lane because what it replaces is the one-body-per-lane kernel, not a walk kernel)
+    if (faba && (algorithm == RBD_ALGO_ABA_COMPILED || (B >= spec_from && (faba_scratch == 0 || (spec_f64 && faba_scratch <= w->spec_f64_max_scratch))))) {
       Timed t(w);
       long Bl = B;
       const double* gv = gravity ? gravity : m->gravity;
       float gx = (float)gv[0], gy = (float)gv[1], gz = (float)gv[2];
+      double gxd = gv[0], gyd = gv[1], gzd = gv[2];
       MkStage F = mk ? *mk : kNoStage;
       void* args[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf, &gx, &gy, &gz, &F};
-      HIP_TRY(hipModuleLaunchKernel(faba, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, args, nullptr));
-      w->last_kernel = "aba_spec_f32 (compiled for the mechanism at run time)";
+      void* args64[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf, &gxd, &gyd, &gzd, &F};
+      HIP_TRY(hipModuleLaunchKernel(faba, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, w->dtype == RBD_F64 ? args64 : args, nullptr));
+      w->last_kernel = w->dtype == RBD_F64 ? "aba_spec_f64 (compiled for the mechanism at run time)" : "aba_spec_f32 (compiled for the mechanism at run time)";
       return RBD_OK;
     }
   }
@@ -1624,6 +1633,7 @@ static void spec_load(rbd_ws* w, int family, bool force) {
   std::string log;
   std::string& src = w->spec_src[slot];
   if (src.empty()) src = spec_source(m->spec_plan(), m->nb, m->nq, m->nv, m->row_mask.data(), m->gravity, w->dtype, family);
+  if (src.empty()) { w->spec_tried[slot] = true; return; }  // (no such program for this mechanism: fp64 dynamics! of a tree the walk kernels take)
   std::vector<char> code;
   const int js = jit_code_object_get(src, force || !jit_async(), &code, &log);
   if (js == JIT_PENDING) return;
@@ -1635,7 +1645,8 @@ static void spec_load(rbd_ws* w, int family, bool force) {
   // a kernel whose registers spilled beyond a few values is slower than the kernels that interpret the mechanism: it steps aside
   auto fits = [&](hipFunction_t* f, int* bytes = nullptr) {
     int scratch = 0;
-    const int max_scratch = w->spec_max_scratch;  // bytes per lane
+    // bytes per lane (the fp64 dynamics! program of round 6 spills by construction and is taken with it: what it replaces is the one-body-per-lane kernel)
+    const int max_scratch = (family == SPEC_ABA && w->dtype == RBD_F64) ? std::max(w->spec_max_scratch, w->spec_f64_max_scratch) : w->spec_max_scratch;
     if (*f && (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, *f) != hipSuccess || scratch > max_scratch)) { (void)hipGetLastError(); *f = nullptr; }
     if (bytes) *bytes = scratch;
   };
@@ -1655,9 +1666,9 @@ static void spec_load(rbd_ws* w, int family, bool force) {
       get(&w->spec_emit, "emit_spec_f64");  // fp64: the emitter alone (the staging buffer in the original order; the dense kernel is rbd_kernels.hip's)
     }
   } else if (family == SPEC_ABA) {
-    get(&w->spec_aba, "aba_spec_f32");
+    get(&w->spec_aba, w->dtype == RBD_F64 ? "aba_spec_f64" : "aba_spec_f32");
     fits(&w->spec_aba, &w->spec_aba_scratch);
-    get(&w->spec_aba_nofext, "aba_spec_nofext_f32");  // the instantiation for calls without external wrenches (rbd_spec.hpp: FEXT)
+    get(&w->spec_aba_nofext, w->dtype == RBD_F64 ? "aba_spec_nofext_f64" : "aba_spec_nofext_f32");  // the instantiation for calls without external wrenches (rbd_spec.hpp: FEXT)
     fits(&w->spec_aba_nofext, &w->spec_aba_nofext_scratch);
   } else if (family == SPEC_RNEA) {
     get(&w->spec_rnea, w->dtype == RBD_F64 ? "rnea_spec_f64" : "rnea_spec_f32");

@@ -837,7 +837,14 @@ RBD_DEV void kin_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 // (its parent's branch slot, or -1), CIDX[NOPS] (its rank among its siblings), NBS (slots), NEXT_EXIT[NOPS] (the next EXIT op after this one, or -1).
 // q, v, tau of the wavefront's 64 states are staged through LDS rows (stride 65: conflict-free both ways); v̇ and q̇ leave the same way, q̇ first.
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB) + 10 * P::N3;  // q, v, tau, spare, ten of the 18 values of U D^-1 of every 3-dof joint
+// RBD_SPEC_ABA_UDL (0..4; rbd_jit.hip: 0 for fp32): how many of a body's four "register" values of U D^-1 live in LDS rows of their own instead.  The fp64 program
+// (round 6: the mechanisms no walk kernel takes) has a CU's LDS to itself — one wavefront per CU by its q, v, tau rows alone — and 512 registers that 4 NB doubles
+// overflow: 147 spilled registers for the reference's randmech() with all four in registers, none with three of them in rows.
+#ifndef RBD_SPEC_ABA_UDL
+#define RBD_SPEC_ABA_UDL 0
+#endif
+constexpr int ABA_UDL = RBD_SPEC_ABA_UDL;
+constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB) + 10 * P::N3 + ABA_UDL * P::NB;  // q, v, tau, spare, ten of the 18 values of U D^-1 of every 3-dof joint, ABA_UDL per body
 
 template <typename T, bool FEXT = true>
 RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau, const T* __restrict__ fext,
@@ -850,6 +857,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   T* rt = rv + NV * RS;
   T* rx = rt + NV * RS;  // max(NQ, NB) rows: q̇ on its way out first, then one value per body for the top-down pass
   T* r3 = rx + (NQ > NB ? NQ : NB) * RS;  // 10 rows per 3-dof joint: the part of its U D^-1 (18 values) that its v rows (3), its spare row and its four registers do not take
+  T* ru = r3 + 10 * P::N3 * RS;           // ABA_UDL rows per body (fp64: see RBD_SPEC_ABA_UDL)
   const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
   if (state0 >= B) return;
 #ifdef RBD_SPEC_ABLATE_NO_LOADS  // (timing experiments, RBD_TUNE spec_variant: the passes on made-up rows, nothing read)
@@ -882,6 +890,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   T* ts = rt + lane;
   T* xs = rx + lane;
   T* x3 = r3 + lane;
+  T* us = ru + lane;
   // Here the lane IS the state and the joints are compile-time constants, so the stage is straight-line code like the passes: the base point and the running
   // sums live in the workspace's stage buffers in a layout of this kernel's own — batch-innermost, element (k, state) at k B + state, whatever the caller's
   // layout (stage 0 writes them, stages 1-3 of the same step read them: nobody else sees them) — one coalesced access per lane and value; the next q is formed in
@@ -1003,7 +1012,9 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   Hand<T> SH1[NBS]; Hand<T2> SH2[NBS];  // branch points: the sum of their children's hand-offs
   // per body, for the top-down pass: D^-1 u and U D^-1.  The first goes to the body's tau row (read for the last time when u is formed, written again
   // only by that pass), two of the others to its spare row and its v row (free once the joint is un-composed), four stay in registers
-  T Ud1[NB][4]; T2 Ud2[NPR][4];
+  T Ud1[NB][4 - ABA_UDL > 0 ? 4 - ABA_UDL : 1]; T2 Ud2[NPR][4];  // (the first ABA_UDL of a body's four in LDS rows: ud1_put / ud1_get)
+  auto ud1_put = [&](int body_, int k, T x) __attribute__((always_inline)) { if (k < ABA_UDL) us[(body_ * ABA_UDL + k) * RS] = x; else Ud1[body_][k - ABA_UDL > 0 ? k - ABA_UDL : 0] = x; };
+  auto ud1_get = [&](int body_, int k) __attribute__((always_inline)) -> T { return k < ABA_UDL ? us[(body_ * ABA_UDL + k) * RS] : Ud1[body_][k - ABA_UDL > 0 ? k - ABA_UDL : 0]; };
   // external wrench of the body the next EXIT finishes (asked for one EXIT ahead).  FEXT = false: the instantiation for callers without external wrenches —
   // no registers held for them, no branch per body (the twelve registers decide whether Atlas's limbs fit the file without scratch; a kernel with ANY scratch
   // runs 3.4 times slower here: 144 us against 42, the dispatcher admits fewer wavefronts at a time)
@@ -1035,7 +1046,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
     auto& C = [&]() -> auto& { if constexpr (PR) return C2; else return C1; }();
     auto& SH = [&]() -> auto& { if constexpr (PR) return SH2; else return SH1; }();
     auto& fe = [&]() -> auto& { if constexpr (PR) return fe2; else return fe1; }();
-    auto ud_set = [&](int k, V x) __attribute__((always_inline)) { if constexpr (PR) Ud2[P::PIDX[O]][k] = x; else Ud1[body][k] = x; };
+    auto ud_set = [&](int k, V x) __attribute__((always_inline)) { if constexpr (PR) Ud2[P::PIDX[O]][k] = x; else ud1_put(body, k, x); };
     if constexpr (kind == SK_ENTER) {
       if constexpr (lvl == 0) {  // the parent is the world
 #pragma unroll
@@ -1168,7 +1179,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
           const T x = W[j / 6][j % 6];
           if constexpr (j < 3) vs[(voff + j) * RS] = x;
           else if constexpr (j == 3) xs[body * RS] = x;
-          else if constexpr (j < 8) Ud1[body][j - 4] = x;
+          else if constexpr (j < 8) ud1_put(body, j - 4, x);
           else x3[(xr + j - 8) * RS] = x;
         });
 #pragma unroll
@@ -1295,7 +1306,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
     auto& ad = [&]() -> auto& { if constexpr (PR) return ad2; else return ad1; }();
     auto& SR = [&]() -> auto& { if constexpr (PR) return SR2; else return SR1; }();
     auto& SA = [&]() -> auto& { if constexpr (PR) return SA2; else return SA1; }();
-    auto ud_get = [&](int k) __attribute__((always_inline)) -> V { if constexpr (PR) return Ud2[P::PIDX[O]][k]; else return Ud1[body][k]; };
+    auto ud_get = [&](int k) __attribute__((always_inline)) -> V { if constexpr (PR) return Ud2[P::PIDX[O]][k]; else return ud1_get(body, k); };
     if constexpr (kind == SK_ENTER) {
       const JointQ<V> JQ = joint_q<V, O>(qs);
       if constexpr (lvl == 0) {
@@ -1359,7 +1370,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
             constexpr int j = jc.value;
             if constexpr (j < 3) Wf[j] = vs[(voff + j) * RS];
             else if constexpr (j == 3) Wf[j] = xs[body * RS];
-            else if constexpr (j < 8) Wf[j] = Ud1[body][j - 4];
+            else if constexpr (j < 8) Wf[j] = ud1_get(body, j - 4);
             else Wf[j] = x3[(xr + j - 8) * RS];
           });
 #pragma unroll

@@ -10,7 +10,7 @@ leg_args() {
   case $1 in
     c2) echo "--config 2";; c2id) echo "--config 2 --op inverse_dynamics";; c3) echo "--config 3";; c3noM) echo "--config 3 --no-emit-M";; c3pk) echo "--config 3 --packed-M";;
     c4) echo "--config 4";; c5) echo "--config 5";; c2big) echo "--config 2 --batch 65536";; c2idb) echo "--config 2 --batch 65536 --op inverse_dynamics --bodies";;
-    axf) echo "--config 2 --model atlas_fixed";; sim64) echo "--config 2 --op-sim";; sim64b) echo "--config 2 --batch 65536 --op-sim";; sim32) echo "--config 4 --op-sim";;
+    axf) echo "--config 2 --model atlas_fixed";; rmech) echo "--config 2 --model randmech1 --batch 65536";; sim64) echo "--config 2 --op-sim";; sim64b) echo "--config 2 --batch 65536 --op-sim";; sim32) echo "--config 4 --op-sim";;
     kin) echo "--config 2 --batch 65536 --op-kin";; kin4k) echo "--config 2 --op-kin";;
     *) echo "unknown leg $1" >&2; exit 1;;
   esac

@@ -5,6 +5,7 @@
 #   c2 = configs[1] dynamics!          c2id = configs[1] inverse_dynamics!      c3 = configs[2] mass_matrix! + Cholesky, M emitted
 #   c3noM = configs[2], M_out = NULL   c4 = configs[3], one GPU's shard         c5 = configs[4] four-bar
 #   c2big = configs[1]'s dynamics! at 65 536 fp64 states      c2idb = inverse_dynamics! with per-body outputs at 65 536 fp64 states
+#   rmech = dynamics! of randmech() at 65 536 fp64 states (aba_spec_f64)
 #   axf = configs[1] on the fixed-base Atlas       sim64 / sim64b / sim32 = the RK4 `simulate` step at 4096 fp64 / 65 536 fp64 / 65 536 fp32 states
 #   kin / kin4k = the kinematics by-products (rbd_kinematics + rbd_geometric_jacobian + rbd_momentum) at 65 536 / 4096 fp64 states
 # For every leg (default: all six)
@@ -15,7 +16,7 @@
 # driver's --steps 20 --warmup 5 -> profiles/r06_bench_driver_steps.json.
 # profiles/r06_pmc_traffic.json records bench.kernel_source_hash(); bench.py marks the figures stale when the sources have changed since.
 # Everything is also copied to gpurun_out/profiles/ so that it comes back from the box; copy it from there into profiles/ and commit.
-LEGS=${*:-c2 c2id c3 c3noM c3pk c4 c5 c2big c2idb axf sim64 sim64b sim32 kin kin4k}
+LEGS=${*:-c2 c2id c3 c3noM c3pk c4 c5 c2big c2idb axf rmech sim64 sim64b sim32 kin kin4k}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 OUT=$R/gpurun_out/measure; rm -rf $OUT; mkdir -p $OUT $R/gpurun_out/profiles
@@ -24,7 +25,7 @@ leg_args() {
     c2) echo "--config 2";; c2id) echo "--config 2 --op inverse_dynamics";; c3) echo "--config 3";; c3noM) echo "--config 3 --no-emit-M";; c3pk) echo "--config 3 --packed-M";;
     c4) echo "--config 4";; c5) echo "--config 5";;
     c2big) echo "--config 2 --batch 65536";; c2idb) echo "--config 2 --batch 65536 --op inverse_dynamics --bodies";;
-    axf) echo "--config 2 --model atlas_fixed";;
+    axf) echo "--config 2 --model atlas_fixed";; rmech) echo "--config 2 --model randmech1 --batch 65536";;
     sim64) echo "--config 2 --op-sim";; sim64b) echo "--config 2 --batch 65536 --op-sim";; sim32) echo "--config 4 --op-sim";;
     kin) echo "--config 2 --batch 65536 --op-kin";; kin4k) echo "--config 2 --op-kin";;
     *) echo "unknown leg $1" >&2; exit 1;;

@@ -1,5 +1,5 @@
 """One-off stress of `simulate` through the walk kernels compiled per mechanism — the kernel that takes the four stages of a step in one launch
-(aba_walk_sim_spec, csrc/rbd_walk.hpp; admitted per workspace by running it against the single-stage kernel, rbd_capi.hip sim_loop_check) and the four-launch
+(aba_walk_sim_spec, csrc/rbd_walk.hpp; admitted statically since round 6: csrc/rbd_jit.hip jit_walk_admit) and the four-launch
 route beside it: random trees of 1-dof joints (revolute, prismatic, sin-cos, fixed; chains and bushes) with and without a 6-dof root, fp64 and fp32, both
 layouts, constant torques with and without external wrenches, against the numpy restatement of the integrator (oracle/simulate_np.py).
     python scripts/stress_simulate_walk.py N --precompile     (no GPU: the N trees' programs into the library's cache)
@@ -50,7 +50,7 @@ for trial, (name, model) in enumerate(cases):
             if "four stages per launch" in k: one += 1
             elif "folded in" in k: four += 1
             else: other += 1
-            assert one_launch == 0 or "four stages per launch" in k or "folded in" not in k, (name, k)  # (a looped kernel the check turned down shows here)
+            assert one_launch == 0 or "four stages per launch" in k or "folded in" not in k, (name, k)  # (a looped program the static admission turned down shows here)
             got[one_launch] = (host(state.q, state).astype(np.float64), host(state.v, state).astype(np.float64), k)
             assert np.isfinite(got[one_launch][0]).all() and np.isfinite(got[one_launch][1]).all(), (name, dtype, layout, k)
         # the two routes against each other (the same arithmetic from two compilations) ...

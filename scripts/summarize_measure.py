@@ -43,7 +43,7 @@ LEGS = {"c2": (2, "dynamics", ""), "c2id": (2, "inverse_dynamics", ""), "c3": (3
         "c4": (4, "dynamics", ""), "c5": (5, "dynamics", ""), "c2big": (2, "dynamics", "", 65536), "c2idb": (2, "inverse_dynamics", "_bodies", 65536),
         # round 6: the fixed-base Atlas, the RK4 `simulate` step (a leg runs 10 + 60 + 2 steps: warm-up, timed, parity) and the kinematics by-products (a leg
         # runs the set of three calls 2 x 70 times: together, then each on its own) — (config, op, suffix, batch, model, dtype, steps the leg runs)
-        "axf": (2, "dynamics", "", 4096, "atlas_fixed"),
+        "axf": (2, "dynamics", "", 4096, "atlas_fixed"), "rmech": (2, "dynamics", "", 65536, "randmech1"),
         "sim64": (2, "simulate", "", 4096, "atlas_floating", "f64", 72), "sim64b": (2, "simulate", "", 65536, "atlas_floating", "f64", 72),
         "sim32": (2, "simulate", "", 65536, "atlas_floating", "f32", 72),
         "kin": (2, "kinematics", "", 65536, "atlas_floating", "f64", 140), "kin4k": (2, "kinematics", "", 4096, "atlas_floating", "f64", 140)}

@@ -55,6 +55,30 @@ def test_emulated_aba_f32(rbd, oracle, models, name):
     assert backward_error(oracle, model, q, v, tau, None, vd).max() <= 2e-6
 
 
+@pytest.mark.parametrize("name", IN_SCOPE[:2] + EVERY_JOINT_TYPE)
+def test_emulated_aba_f64(rbd, oracle, models, name):
+    """Round 6: dynamics! in doubles on the lane-per-state program — generated only for the mechanisms no walk kernel takes (3-dof joints, 6-dof joints below the
+    world: the reference's own randmech()); the same template as aba_spec_f32, held to the reference's 1e-10 against the oracle, with and without external wrenches."""
+    model = models[name]
+    src = rbd.jit_source(model, torch.float64, "dynamics")
+    if name in IN_SCOPE:
+        assert src is None  # (trees of 1-dof joints below a floating base: the walk kernels are ahead in fp64)
+        return
+    assert src is not None and "aba_spec_f64" in src and "aba_spec_nofext_f64" in src and "NPAIR = 0" in src
+    lib = spec_emu.build(src, "ABA_F64")
+    B = 70
+    rng = np.random.default_rng(6)
+    q, v, tau = rbd.rand_configuration(model, B, rng), rbd.rand_velocity(model, B, rng), rng.random((B, model.nv))
+    fe = rng.random((B, 6 * model.n_bodies))
+    vd, qd = spec_emu.aba_f64(lib, model, q, v, tau, fe, want_qdot=True)
+    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    assert np.isfinite(vd).all() and np.abs(vd - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(qd - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
+    vd = spec_emu.aba_f64(lib, model, q, v, tau, None)
+    ref = oracle.dynamics(model, q, v, tau)
+    assert np.abs(vd - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 @pytest.mark.parametrize("name", IN_SCOPE + EVERY_JOINT_TYPE + LIMBS)
 def test_emulated_rnea(rbd, oracle, models, name, dtype):

@@ -243,6 +243,46 @@ def test_compiled_aba_f32(rbd, oracle, models, name, layout):
     assert backward_error(oracle, model, q, v, np.zeros_like(tau), None, vd).max() <= 2e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("name", ["randmech1", "randmech2", "randmech3", "inner_floating", "mixed20"])
+def test_compiled_aba_f64_of_mechanisms_no_walk_kernel_takes(rbd, oracle, models, name, layout, monkeypatch):
+    """Round 6: `dynamics!` in fp64 for mechanisms with 3-dof joints / 6-dof joints below the world (the reference's own randmech(),
+    test/test_mechanism_algorithms.jl:1-11) through the lane-per-state program in doubles (aba_spec_f64): forced (RBD_ALGO_ABA_COMPILED) at a ragged batch and picked
+    by the library from its batch threshold on; with a wrench on every body and q̇, without torques and wrenches, and as the M^-1 rhs solve — the reference's 1e-10
+    against the oracle.  Atlas-like trees have no such program (the walk kernels are ahead in fp64)."""
+    model = models[name]
+    B = 150
+    state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 73)
+    result = rbd.DynamicsResult(model, B, layout=layout)
+    try:
+        rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm="aba_compiled")
+    except rbd._capi.RBDError as e:
+        if e.status == 3:
+            pytest.skip("hiprtc not available")
+        raise
+    assert rbd.sync(state) == 0 and "aba_spec_f64" in rbd.last_kernel(state)
+    ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
+    rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    assert rel(host(result.vd, state), ref) <= 1e-10 and rel(host(result.qd, state), qd_ref) <= 1e-13
+    result.vd.fill_(float("nan"))
+    rbd.dynamics_(result, state, None, None, algorithm="aba_compiled")
+    assert rel(host(result.vd, state), oracle.dynamics(model, q, v, None, None)) <= 1e-10
+    # the library's own choice from its threshold on (forced down to this batch), and the articulated-body solve M^-1 rhs on the same kernel
+    tune(monkeypatch, spec_aba_min_batch=1)
+    state2, q2, v2, tau2, _ = make(rbd, model, B, "f64", layout, 74)
+    result2 = rbd.DynamicsResult(model, B, layout=layout)
+    rbd.dynamics_(result2, state2, dev(tau2, state2))
+    assert "aba_spec_f64" in rbd.last_kernel(state2), rbd.last_kernel(state2)
+    assert rel(host(result2.vd, state2), oracle.dynamics(model, q2, v2, tau2)) <= 1e-10
+    x = torch.zeros_like(state2.v)
+    rbd.mass_matrix_solve_(x, state2, dev(tau2, state2), algorithm="aba")
+    M = oracle.mass_matrix(model, q2)
+    xr = np.linalg.solve(sym(M), tau2[..., None])[..., 0]
+    assert rel(host(x, state2), xr) <= 1e-9
+    assert rbd.jit_source(models["atlas_floating"], torch.float64, "dynamics") is None
+
+
 def test_first_call_does_not_wait_for_the_compiler(rbd, models, tmp_path):
     """The library's default (RBD_JIT_ASYNC unset; the test suite otherwise runs with 0): with an EMPTY cache the first `dynamics!` on Atlas at 65 536 fp32
     states returns at once on a kernel that interprets the mechanism while hiprtc compiles `aba_spec_f32` on a background thread (csrc/rbd_jit.hip), a later
