@@ -1525,8 +1525,8 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
   if (algorithm == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   if (algorithm == RBD_ALGO_ABA_BANKS && !can_bank) return RBD_ERR_UNSUPPORTED;
   // fp64 (round 6): mechanisms with 3-dof joints / 6-dof joints below the world — what no walk or banked kernel takes — have the lane-per-state program in doubles
-  // too (rbd_jit.hip spec_has); plain dynamics! only (the integrator's stage stays with the fp32 program)
-  const bool spec_f64 = w->dtype == RBD_F64 && m->state_wide.ok && !m->state.ok && !mk;
+  // too (rbd_jit.hip spec_has), the integrator's stage of `simulate` included (the same template: rbd_spec.hpp aba_spec)
+  const bool spec_f64 = w->dtype == RBD_F64 && m->state_wide.ok && !m->state.ok;
   if ((algorithm == RBD_ALGO_ABA || algorithm == RBD_ALGO_ABA_COMPILED) && !fuse && (w->dtype == RBD_F32 || spec_f64) && !(mk && mk->stage == 4)) {  // (all four stages in one launch: the walk kernels only)
     // with the integrator stage folded in, the lane-per-state kernel is ahead of the walk kernel earlier than without it (Atlas fp32, RK4 step: 24 576 states
     // 209 against 226 us, 32 768: 220 against 240; 16 384: 201 against 143) — the stage costs this kernel 10 us per launch, the walk kernel 28
@@ -2160,7 +2160,7 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   // four launches per step and nothing else.  The first launch decides: a kernel that takes the stage runs it, any other returns RBD_ERR_UNSUPPORTED untouched.
   bool spec_sim = false;
   // (mechanisms the walk kernels do not take — 3-dof joints, 6-dof joints below the world: aba_spec_f32 takes them, stage included, from its own batch threshold on)
-  const bool lane_per_state_sim = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && w->dtype == RBD_F32 && m->spec_plan().ok && B >= std::min<long>(w->spec_aba_min_batch, w->spec_aba_fused_min_batch);
+  const bool lane_per_state_sim = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && (w->dtype == RBD_F32 || (m->state_wide.ok && !m->state.ok)) && m->spec_plan().ok && B >= std::min<long>(w->spec_aba_min_batch, w->spec_aba_fused_min_batch);  // (fp64, round 6: the mechanisms whose dynamics! runs on aba_spec_f64)
   const bool try_spec_sim = (walk_sim || lane_per_state_sim) && tune("sim_fuse", 1) != 0;  // (RBD_TUNE sim_fuse=0: the stage in its own launches, for A/B measurements)
   // The kernel of the FIRST launch serves the whole call: aba_spec keeps the stage buffers in a layout of its own (rbd_spec.hpp), and a compilation that finishes
   // in the background must not move a step from one kernel to the other between two of its stages.
@@ -2201,7 +2201,7 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
       if (st == RBD_ERR_UNSUPPORTED && step == 0 && stage == 0) break;
       if (st) return st;
       if (!spec_sim) {
-        sim_lane_per_state = strstr(w->last_kernel, "aba_spec_f32") != nullptr;
+        sim_lane_per_state = strstr(w->last_kernel, "aba_spec_f") != nullptr;
         sim_algo = sim_lane_per_state ? RBD_ALGO_ABA_COMPILED : RBD_ALGO_ABA_WALK;
       }
       spec_sim = true;
@@ -2209,7 +2209,8 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
     if (!spec_sim) break;
   }
   if (spec_sim) {
-    w->last_kernel = sim_lane_per_state ? "aba_spec_f32 with the Munthe-Kaas stage folded in (compiled for the mechanism at run time)"
+    w->last_kernel = sim_lane_per_state ? (w->dtype == RBD_F64 ? "aba_spec_f64 with the Munthe-Kaas stage folded in (compiled for the mechanism at run time)"
+                                                               : "aba_spec_f32 with the Munthe-Kaas stage folded in (compiled for the mechanism at run time)")
                                         : "aba_walk_spec with the Munthe-Kaas stage folded in (compiled for the mechanism)";
     if (o.memory == RBD_MEM_HOST) {
       if ((st = stage_out_copy(w, q, dq, es * m->nq * B)) || (st = stage_out_copy(w, v, dv, es * m->nv * B))) return st;

@@ -552,15 +552,17 @@ def test_simulate_device_side_controllers(rbd, oracle, models, path, monkeypatch
 
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("name", ["mixed20", "inner_floating", "randmech1"])
-def test_simulate_stage_folded_in_on_every_joint_type(rbd, oracle, models, name, layout, monkeypatch):
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_simulate_stage_folded_in_on_every_joint_type(rbd, oracle, models, name, layout, dtype, monkeypatch):
     """The same for mechanisms with Planar / QuaternionSpherical joints and QuaternionFloating joints below the world: only the lane-per-state kernel compiled for the
-    mechanism takes them (its stage is generic over the joint types: the Bortz equation for the spherical joints, the SE(3) log / exp for every 6-dof joint)."""
+    mechanism takes them (its stage is generic over the joint types: the Bortz equation for the spherical joints, the SE(3) log / exp for every 6-dof joint) — in fp32
+    and, since round 6, in fp64 (aba_spec_f64: the program in doubles of exactly these mechanisms)."""
     import simulate_np
     tune(monkeypatch, spec_aba_min_batch=1)
     model = models[name]
     B, dt, nsteps = 70, 1e-3, 3
     T = (nsteps - 0.5) * dt
-    state, q, v, tau, _ = make(rbd, model, B, "f32", layout, 93, fext=False)
+    state, q, v, tau, _ = make(rbd, model, B, dtype, layout, 93, fext=False)
     sel = np.r_[0:3, B - 2:B]
     try:
         rbd.simulate_(state, T, dt=dt, torques=dev(tau, state))
@@ -571,12 +573,13 @@ def test_simulate_stage_folded_in_on_every_joint_type(rbd, oracle, models, name,
     k = rbd.last_kernel(state)
     if "folded in" not in k:
         pytest.skip("no compiled kernel for this route on this box: " + k)
-    assert "aba_spec_f32" in k, k
+    assert "aba_spec_" + dtype in k, k
     ref = simulate_np.simulate(model, q[sel], v[sel], T, dt, tau[sel])
     qg, vg = host(state.q, state)[sel], host(state.v, state)[sel]
     assert np.isfinite(host(state.q, state)).all() and np.isfinite(host(state.v, state)).all()
-    assert np.abs(canon_q(model, qg) - canon_q(model, ref[1])).max() <= 2e-5 * max(1.0, np.abs(ref[1]).max())
-    assert np.abs(vg - ref[2]).max() <= 2e-3 * max(1.0, np.abs(ref[2]).max())
+    tq, tv = (2e-5, 2e-3) if dtype == "f32" else (1e-10, 1e-9)
+    assert np.abs(canon_q(model, qg) - canon_q(model, ref[1])).max() <= tq * max(1.0, np.abs(ref[1]).max())
+    assert np.abs(vg - ref[2]).max() <= tv * max(1.0, np.abs(ref[2]).max())
 
 
 ONE_LAUNCH_LANE_PER_STATE = False  # (aba_spec_f32: four launches per step)

@@ -132,8 +132,16 @@ def test_programs_of_mechanisms_with_every_joint_type(rbd, tmp_path, monkeypatch
     for fam in ("mass_matrix", "dynamics", "inverse_dynamics"):
         for dt in (torch.float32, torch.float64):
             src = rbd.jit_source(model, dt, fam)
-            assert (src is None) == (fam == "dynamics" and dt == torch.float64), (fam, dt)
+            assert src is not None, (fam, dt)  # (round 6: dynamics! in fp64 too — for exactly these mechanisms; an Atlas-like tree has none)
+    atlas = mechanism(rbd, "atlas_floating")
+    assert rbd.jit_source(atlas, torch.float64, "dynamics") is None and rbd.jit_source(atlas, torch.float32, "dynamics") is not None
+    # fp64: as many of a body's four register values of U D^-1 in LDS rows as one CU's LDS has room for (csrc/rbd_spec.hpp RBD_SPEC_ABA_UDL), at most three
+    s64 = rbd.jit_source(model, torch.float64, "dynamics")
+    udl = int(re.search(r"#define RBD_SPEC_ABA_UDL (\d+)", s64).group(1))
+    rows = model.nq + 2 * model.nv + max(model.nq, model.n_bodies) + 10 * n3
+    assert udl == max(0, min(3, (160 * 1024 // (65 * 8) - rows) // model.n_bodies)) and "aba_lds[%d]" % ((rows + udl * model.n_bodies) * 65) in s64 and "NPAIR = 0" in s64
     src = rbd.jit_source(model, torch.float32, "dynamics")
+    assert "RBD_SPEC_ABA_UDL" not in src
     assert int(re.search(r"N3 = (\d+);", src).group(1)) == n3
     opw, x3, cols = table(src, "OPW"), table(src, "X3")[0], table(src, "COLS")
     for o, w in enumerate(opw):
