@@ -31,6 +31,9 @@ for trial in range(10 * N):
         continue
     done += 1
     if PRE:
+        part = os.environ.get("STRESS_PART")  # "k/n": this process compiles every n-th mechanism (hiprtc compiles one program at a time per process)
+        if part and (done - 1) % int(part.split("/")[1]) != int(part.split("/")[0]):
+            continue
         for dt in (torch.float32, torch.float64):
             ok, log = rbd.jit_precompile(model, dt)
             assert ok, (types, log[-2000:])
@@ -92,6 +95,46 @@ for trial in range(10 * N):
         assert eta < (1e-12 if dname == "f64" else 2e-5), (trial, types, eta, rbd.last_kernel(state))
         k = rbd.last_kernel(state).split(" (")[0]
         used[k] = used.get(k, 0) + 1
+        # round 6: the kinematics by-products one lane per state (family 11), both scalar types
+        os.environ["RBD_TUNE"] = "state_min_batch=1,spec_aba_min_batch=1,spec_kin_min_batch=1"
+        stk = rbd.MechanismState(model, B, dtype=tdt, layout=layout)
+        rbd.set_configuration_(stk, qd_); rbd.set_velocity_(stk, v_)
+        A = torch.zeros((B, 6 * nv) if layout == "aos" else (6 * nv, B), dtype=tdt, device="cuda")
+        rbd.momentum_matrix_(A, stk)
+        if "kin_spec" in rbd.last_kernel(stk):
+            used["kin_spec_" + dname] = used.get("kin_spec_" + dname, 0) + 1
+            tk = 1e-11 if dname == "f64" else 3e-4
+            A_ref, _, com_ref = oracle.momentum_matrix(model, qd_, v_)
+            chk("momentum matrix " + dname, Hh(A).reshape(B, nv, 6).transpose(0, 2, 1), A_ref, tk)
+            ke_ref, pe_ref = oracle.energy(model, qd_, v_)
+            chk("kinetic energy " + dname, rbd.kinetic_energy(stk).double().cpu().numpy(), ke_ref, tk)
+            chk("potential energy " + dname, rbd.gravitational_potential_energy(stk).double().cpu().numpy(), pe_ref, tk)
+            chk("centre of mass " + dname, Hh(rbd.center_of_mass(stk)), com_ref, tk)
+            h_ref, hb_ref = oracle.momentum(model, qd_, v_)
+            chk("momentum " + dname, rbd.momentum(stk).double().cpu().numpy(), h_ref, 10 * tk)
+            chk("momentum rate bias " + dname, rbd.momentum_rate_bias(stk).double().cpu().numpy(), hb_ref, 100 * tk)
+            base, body = (int(x) for x in r2.choice(np.arange(-1, nb), 2, replace=False)) if nb > 1 else (-1, 0)
+            J = torch.full_like(A, 7.0)
+            rbd.geometric_jacobian_(J, stk, base, body)
+            J_ref, _ = oracle.geometric_jacobian(model, qd_, base, body)
+            chk("geometric jacobian " + dname, Hh(J).reshape(B, nv, 6).transpose(0, 2, 1), J_ref, tk)
+        if dname == "f64" and rbd.jit_source(model, torch.float64, "dynamics") is not None:  # round 6: dynamics! in doubles for what no walk kernel takes
+            res = rbd.DynamicsResult(model, B, dtype=tdt, layout=layout)
+            rbd.dynamics_(res, state, D(tau_), D(fe_), algorithm="aba_compiled")
+            kernel(state, "aba_spec_f64")
+            ref64, qd_ref = oracle.dynamics(model, qd_, v_, tau_, fe_, want_qdot=True)
+            chk("dynamics! f64", Hh(res.vd), ref64, 1e-10)
+            chk("q̇ f64", Hh(res.qd), qd_ref, 1e-13)
+            rbd.dynamics_(res, state, D(tau_), None, algorithm="aba_compiled")
+            chk("dynamics! f64 without wrenches", Hh(res.vd), oracle.dynamics(model, qd_, v_, tau_), 1e-10)
+            st2 = rbd.MechanismState(model, B, dtype=tdt, layout=layout)
+            rbd.set_configuration_(st2, qd_); rbd.set_velocity_(st2, v_)
+            rbd.simulate_(st2, 1.5e-3, dt=1e-3, torques=D(tau_))
+            kernel(st2, "aba_spec_f64 with the Munthe-Kaas stage folded in")
+            sel = [0, B - 1] if B > 1 else [0]
+            _, q_ref, v_ref = simulate_np.simulate(model, qd_[sel], v_[sel], 1.5e-3, 1e-3, tau_[sel])
+            chk("simulate q f64 (|.|: quaternion sign)", np.abs(Hh(st2.q)[sel]), np.abs(q_ref), 1e-10)
+            chk("simulate v f64", Hh(st2.v)[sel], v_ref, 1e-8)
         if dname == "f32":
             res = rbd.DynamicsResult(model, B, dtype=tdt, layout=layout)
             try:
