@@ -370,8 +370,9 @@ int rbd_comm_destroy(rbd_comm_t* comm);
 int rbd_comm_info(const rbd_comm_t* comm, int32_t* world, int32_t* rank);
 int rbd_gather(rbd_comm_t* comm, int32_t dtype, const void* shard, void* gathered, int64_t count, int32_t root /* < 0: every rank */, void* stream);
 /* ... with shards of different sizes (a batch that does not divide by the number of ranks): counts[world] scalars per rank, the shards back to back in rank
- * order in `gathered`; an empty shard is legal.  Every rank passes the same counts (not checked across ranks: ranks that disagree wait for each other forever,
- * like mismatched ncclSend / ncclRecv sizes). */
+ * order in `gathered`; an empty shard is legal.  Every rank passes the same counts: ranks that disagree wait for each other forever, like mismatched ncclSend /
+ * ncclRecv sizes — unless RBD_COMM_CHECK=1 is set (on every rank), in which case the ranks compare their counts first (one small all-gather and a wait for the
+ * stream) and a rank that finds a disagreement returns RBD_ERR_DIMENSION_MISMATCH. */
 int rbd_gatherv(rbd_comm_t* comm, int32_t dtype, const void* shard, void* gathered, const int64_t* counts, int32_t root /* < 0: every rank */, void* stream);
 const char* rbd_comm_last_error(void);
 

@@ -7,9 +7,11 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include <mutex>
 #include "rbd_hip.h"
@@ -59,6 +61,7 @@ thread_local std::string g_comm_error;
 struct rbd_comm {
   ncclComm_t comm = nullptr;
   int32_t world = 0, rank = 0, device = 0;
+  int64_t* d_counts = nullptr;  // RBD_COMM_CHECK=1: world + world * world counts (this rank's, then everybody's), allocated with the communicator
 };
 
 extern "C" {
@@ -90,6 +93,7 @@ int rbd_comm_create(const void* id128, int32_t world, int32_t rank, int32_t devi
   const ncclResult_t r = R.CommInitRank(&c->comm, world, id, rank);
   if (r != ncclSuccess) { g_comm_error = R.GetErrorString ? R.GetErrorString(r) : "ncclCommInitRank failed"; delete c; return RBD_ERR_HIP; }
   c->world = world; c->rank = rank; c->device = device;
+  if (hipMalloc((void**)&c->d_counts, sizeof(int64_t) * ((size_t)world + (size_t)world * world)) != hipSuccess) { (void)hipGetLastError(); c->d_counts = nullptr; }
   *out = c;
   return RBD_OK;
 }
@@ -97,6 +101,7 @@ int rbd_comm_create(const void* id128, int32_t world, int32_t rank, int32_t devi
 int rbd_comm_destroy(rbd_comm_t* c) {
   if (!c) return RBD_OK;
   if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+  if (c->d_counts) (void)hipFree(c->d_counts);
   delete c;
   return RBD_OK;
 }
@@ -149,6 +154,24 @@ int rbd_gatherv(rbd_comm_t* c, int32_t dtype, const void* shard, void* gathered,
   const size_t es = dtype == RBD_F64 ? 8 : 4;
   hipStream_t s = (hipStream_t)stream;
   if (hipSetDevice(c->device) != hipSuccess) return RBD_ERR_NO_DEVICE;
+  // RBD_COMM_CHECK=1 (set on EVERY rank or on none): the ranks compare their counts first — one all-gather of world values each, a wait for the stream — and a rank
+  // whose neighbours disagree with it returns RBD_ERR_DIMENSION_MISMATCH instead of waiting for a send that never comes (round-5 advice: disagreeing counts hang
+  // the group like mismatched ncclSend / ncclRecv sizes).  Off by default: the gather of v̇ is asynchronous on the caller's stream.
+  if (const char* e = getenv("RBD_COMM_CHECK")) {
+    if (e[0] == '1' && c->d_counts) {
+      const size_t w = (size_t)c->world;
+      std::vector<int64_t> all(w * w);
+      if (hipMemcpyAsync(c->d_counts, counts, sizeof(int64_t) * w, hipMemcpyHostToDevice, s) != hipSuccess) return RBD_ERR_HIP;
+      const ncclResult_t rc = R.AllGather(c->d_counts, c->d_counts + w, w, ncclInt64, c->comm, s);
+      if (rc != ncclSuccess) { g_comm_error = R.GetErrorString ? R.GetErrorString(rc) : "rccl call failed"; return RBD_ERR_HIP; }
+      if (hipMemcpyAsync(all.data(), c->d_counts + w, sizeof(int64_t) * w * w, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return RBD_ERR_HIP;
+      for (size_t p = 0; p < w; ++p)
+        if (memcmp(&all[p * w], counts, sizeof(int64_t) * w) != 0) {
+          g_comm_error = "rbd_gatherv: rank " + std::to_string(p) + " passed other counts than rank " + std::to_string(c->rank);
+          return RBD_ERR_DIMENSION_MISMATCH;
+        }
+    }
+  }
   ncclResult_t r = R.GroupStart();
   const int64_t mine = counts[c->rank];
   for (int dst = 0; dst < c->world && r == ncclSuccess; ++dst)  // (an empty shard is neither sent nor waited for: both sides read the same counts)

@@ -1684,6 +1684,14 @@ def test_c_abi_rccl_gather_single_rank(rbd, models):
             assert torch.equal(out, result.vd)
         with pytest.raises(ValueError):
             comm.gatherv(result.vd, [B - 1])
+        # RBD_COMM_CHECK=1 (round 6): the ranks compare their counts before the grouped sends — with one rank the comparison is with itself, the path runs
+        os.environ["RBD_COMM_CHECK"] = "1"
+        try:
+            out = comm.gatherv(result.vd, [B])
+            torch.cuda.synchronize()
+            assert torch.equal(out, result.vd)
+        finally:
+            del os.environ["RBD_COMM_CHECK"]
     finally:
         comm.close()
 
