@@ -124,8 +124,11 @@ struct rbd_ws {
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_SLOTS] = {false, false, false, false}; hipModule_t spec_mod[SPEC_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // (by spec_slot(family))
   hipFunction_t spec_kin = nullptr, spec_jac = nullptr, spec_mom = nullptr, spec_energy = nullptr, spec_com = nullptr; long spec_kin_min_batch = (long)1 << 62;  // the kinematics by-products compiled for the mechanism (SPEC_KIN, round 6)
-  hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_chol_nom = nullptr, spec_chol_packed = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_aba_nofext = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
+  hipFunction_t spec_crba = nullptr, spec_crba_perm = nullptr, spec_chol = nullptr, spec_chol_nom = nullptr, spec_chol_packed = nullptr, spec_emit = nullptr, spec_aba = nullptr, spec_aba_nofext = nullptr, spec_aba_gst = nullptr, spec_aba_gst_nofext = nullptr, spec_rnea = nullptr, spec_loop = nullptr;
   int spec_f64_max_scratch = 0;  // (RBD_TUNE spec_f64_max_scratch; set from the measurement in workspace_create)
+  // fp64 dynamics! of those mechanisms: the program with its spare rows in the HBM stash (two wavefronts per CU, a longer chain) against the one with every row in
+  // LDS (one per CU): RBD_TUNE spec_f64_stash = 1 always / 0 never / -1 whichever needs fewer chain-times for the batch; the chains' ratio in percent
+  int spec_f64_stash = -1, spec_f64_stash_ratio = 170, spec_f64_stash_ratio_fext = 120, spec_ncu = 256;
   int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
   bool spec_bank_tried = false; hipModule_t spec_bank_mod = nullptr; hipFunction_t spec_bank_aba = nullptr, spec_bank_fused = nullptr, spec_bank_rnea = nullptr; std::string spec_bank_src;  // the banked kernels compiled for the mechanism
@@ -1023,6 +1026,11 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
     w->spec_kin_min_batch = tune("spec_kin_min_batch", (long)ncu * 64);
     w->spec_f64_max_scratch = (int)tune("spec_f64_max_scratch", 2048);
+    // randmech() (25 bodies, nv 39), one round: 50 us with every row in LDS, 85 us with the stash (with a wrench on every body: 98 and 112) — see run_aba
+    w->spec_f64_stash = (int)tune("spec_f64_stash", -1);
+    w->spec_f64_stash_ratio = (int)tune("spec_f64_stash_ratio", 170);
+    w->spec_f64_stash_ratio_fext = (int)tune("spec_f64_stash_ratio_fext", 120);
+    w->spec_ncu = ncu;
   } else {
     w->state_min_batch = (long)1 << 62;
   }
@@ -1535,8 +1543,18 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     // without external wrenches: the instantiation that holds no registers for them.  Left to itself (RBD_ALGO_ABA) the library takes a compiled kernel only
     // when it spilled nothing
     const bool nofext = df == nullptr && w->spec_aba_nofext != nullptr;
-    hipFunction_t const faba = nofext ? w->spec_aba_nofext : w->spec_aba;
+    hipFunction_t faba = nofext ? w->spec_aba_nofext : w->spec_aba;
     const int faba_scratch = nofext ? w->spec_aba_nofext_scratch : w->spec_aba_scratch;
+    // fp64: the program with the spare rows in the HBM stash runs two wavefronts per CU where the one with every row in LDS runs one, on a chain 1.7 times as
+    // long (1.2 with wrenches: randmech(), 16 384 states 84 against 50 us, 65 536 states 176 against 200; with wrenches 218 against 393) — the one that needs
+    // less time for this batch's rounds
+    bool stash_program = false;
+    if (spec_f64 && faba) {
+      hipFunction_t const fg = nofext ? w->spec_aba_gst_nofext : w->spec_aba_gst;
+      const long waves = (B + 63) / 64, r_lds = (waves + w->spec_ncu - 1) / w->spec_ncu, r_gst = (waves + 2 * w->spec_ncu - 1) / (2 * w->spec_ncu);
+      const long ratio = nofext ? w->spec_f64_stash_ratio : w->spec_f64_stash_ratio_fext;
+      if (fg && (w->spec_f64_stash > 0 || (w->spec_f64_stash < 0 && r_lds * 100 > r_gst * ratio))) { faba = fg; stash_program = true; }
+    }
     // (fp64: the program spills by construction — its per-body leave-behind does not fit 512 registers in doubles; it is taken up to spec_f64_max_scratch bytes
     //  per lane because what it replaces is the one-body-per-lane kernel, not a walk kernel)
     if (faba && (algorithm == RBD_ALGO_ABA_COMPILED || (B >= spec_from && (faba_scratch == 0 || (spec_f64 && faba_scratch <= w->spec_f64_max_scratch))))) {
@@ -1547,9 +1565,17 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
       double gxd = gv[0], gyd = gv[1], gzd = gv[2];
       MkStage F = mk ? *mk : kNoStage;
       void* args[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf, &gx, &gy, &gz, &F};
-      void* args64[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf, &gxd, &gyd, &gzd, &F};
+      void* stash = nullptr;
+      if (w->dtype == RBD_F64) {  // the HBM stash of aba_spec_gst_f64 (rbd_spec.hpp aba_spec GST): (nb + 10 n3) values per state, batch-innermost; grown on demand like every workspace buffer
+        if (stash_program) {
+          if (int st = ensure(&w->d_rows, &w->d_rows_bytes, sizeof(double) * (size_t)(m->nb + 10 * m->spec_plan().n3) * (size_t)B)) return st;
+          stash = w->d_rows;
+        }
+      }
+      void* args64[] = {&Bl, &dq, &dv, &dtau, &df, &dvd, &dqd, &Lq, &Lv, &Lf, &gxd, &gyd, &gzd, &F, &stash};
       HIP_TRY(hipModuleLaunchKernel(faba, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, w->dtype == RBD_F64 ? args64 : args, nullptr));
-      w->last_kernel = w->dtype == RBD_F64 ? "aba_spec_f64 (compiled for the mechanism at run time)" : "aba_spec_f32 (compiled for the mechanism at run time)";
+      w->last_kernel = stash_program ? "aba_spec_gst_f64 (compiled for the mechanism at run time; spare rows in the HBM stash)"
+                       : w->dtype == RBD_F64 ? "aba_spec_f64 (compiled for the mechanism at run time)" : "aba_spec_f32 (compiled for the mechanism at run time)";
       return RBD_OK;
     }
   }
@@ -1670,6 +1696,10 @@ static void spec_load(rbd_ws* w, int family, bool force) {
     fits(&w->spec_aba, &w->spec_aba_scratch);
     get(&w->spec_aba_nofext, w->dtype == RBD_F64 ? "aba_spec_nofext_f64" : "aba_spec_nofext_f32");  // the instantiation for calls without external wrenches (rbd_spec.hpp: FEXT)
     fits(&w->spec_aba_nofext, &w->spec_aba_nofext_scratch);
+    if (w->dtype == RBD_F64) {  // (the stash programs step in only where the LDS ones are taken: no threshold of their own)
+      get(&w->spec_aba_gst, "aba_spec_gst_f64"); fits(&w->spec_aba_gst);
+      get(&w->spec_aba_gst_nofext, "aba_spec_gst_nofext_f64"); fits(&w->spec_aba_gst_nofext);
+    }
   } else if (family == SPEC_RNEA) {
     get(&w->spec_rnea, w->dtype == RBD_F64 ? "rnea_spec_f64" : "rnea_spec_f32");
     fits(&w->spec_rnea, &w->spec_rnea_scratch);
@@ -2201,7 +2231,7 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
       if (st == RBD_ERR_UNSUPPORTED && step == 0 && stage == 0) break;
       if (st) return st;
       if (!spec_sim) {
-        sim_lane_per_state = strstr(w->last_kernel, "aba_spec_f") != nullptr;
+        sim_lane_per_state = strstr(w->last_kernel, "aba_spec_") != nullptr;  // (aba_spec_f32 / aba_spec_f64 / aba_spec_gst_f64)
         sim_algo = sim_lane_per_state ? RBD_ALGO_ABA_COMPILED : RBD_ALGO_ABA_WALK;
       }
       spec_sim = true;
@@ -2209,7 +2239,9 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
     if (!spec_sim) break;
   }
   if (spec_sim) {
-    w->last_kernel = sim_lane_per_state ? (w->dtype == RBD_F64 ? "aba_spec_f64 with the Munthe-Kaas stage folded in (compiled for the mechanism at run time)"
+    const bool sim_stash = strstr(w->last_kernel, "aba_spec_gst_") != nullptr;
+    w->last_kernel = sim_lane_per_state ? (sim_stash ? "aba_spec_gst_f64 with the Munthe-Kaas stage folded in (compiled for the mechanism at run time; spare rows in the HBM stash)"
+                                           : w->dtype == RBD_F64 ? "aba_spec_f64 with the Munthe-Kaas stage folded in (compiled for the mechanism at run time)"
                                                                : "aba_spec_f32 with the Munthe-Kaas stage folded in (compiled for the mechanism at run time)")
                                         : "aba_walk_spec with the Munthe-Kaas stage folded in (compiled for the mechanism)";
     if (o.memory == RBD_MEM_HOST) {

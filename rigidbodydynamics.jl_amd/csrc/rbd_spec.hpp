@@ -837,27 +837,30 @@ RBD_DEV void kin_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 // (its parent's branch slot, or -1), CIDX[NOPS] (its rank among its siblings), NBS (slots), NEXT_EXIT[NOPS] (the next EXIT op after this one, or -1).
 // q, v, tau of the wavefront's 64 states are staged through LDS rows (stride 65: conflict-free both ways); v̇ and q̇ leave the same way, q̇ first.
 // ---------------------------------------------------------------------------------------------------------------------------------
-// RBD_SPEC_ABA_UDL (0..4; rbd_jit.hip: 0 for fp32): how many of a body's four "register" values of U D^-1 live in LDS rows of their own instead.  The fp64 program
-// (round 6: the mechanisms no walk kernel takes) has a CU's LDS to itself — one wavefront per CU by its q, v, tau rows alone — and 512 registers that 4 NB doubles
-// overflow: 147 spilled registers for the reference's randmech() with all four in registers, none with three of them in rows.
-#ifndef RBD_SPEC_ABA_UDL
-#define RBD_SPEC_ABA_UDL 0
-#endif
-constexpr int ABA_UDL = RBD_SPEC_ABA_UDL;
-constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (P::NQ > P::NB ? P::NQ : P::NB) + 10 * P::N3 + ABA_UDL * P::NB;  // q, v, tau, spare, ten of the 18 values of U D^-1 of every 3-dof joint, ABA_UDL per body
-
-template <typename T, bool FEXT = true>
+// Template parameters beside the scalar type (both 0 for fp32):
+// UDL (0..4): how many of a body's four "register" values of U D^-1 live in LDS rows of their own instead.
+// GST: the spare row per body and the ten rows per 3-dof joint — what the bottom-up pass leaves for the top-down pass beside the joint's own v / tau rows — live in
+// a batch-innermost HBM stash (value s of state b at stash[s B + b]: one 512-byte run per wavefront and value, NB + 10 N3 values per state) instead of LDS, and
+// q̇ / the integrator's next q leave from the lanes themselves instead of through spare rows.
+// The fp64 program (round 6: the mechanisms no walk kernel takes) is bound by LDS: with every row in LDS the reference's randmech() needs 236 - 311 rows of 520
+// bytes — ONE wavefront per CU, a 50 us chain per round of 16 384 states.  With q, v, tau alone in LDS (122 rows, 63 KB) two wavefronts share a CU, but the chain
+// is 85 us (the stash stores and the scratch reloads share one in-order counter).  rbd_jit.hip generates both (aba_spec_f64, aba_spec_gst_f64); rbd_capi.hip
+// launches whichever needs less time for the batch (run_aba).
+template <typename T, bool FEXT = true, int UDL = 0, int GST = 0>
 RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, const T* __restrict__ tau, const T* __restrict__ fext,
-                      T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T gx, T gy, T gz, T* lds, const MkStage& F) {
+                      T* __restrict__ vdot, T* __restrict__ qdot, Layout Lq, Layout Lv, Layout Lf, T gx, T gy, T gz, T* lds, const MkStage& F, T* __restrict__ stash = nullptr) {
+  constexpr int ABA_UDL = UDL;
+  constexpr bool ABA_GST = GST != 0;
+  constexpr int ABA_ROWS = P::NQ + 2 * P::NV + (ABA_GST ? 0 : (P::NQ > P::NB ? P::NQ : P::NB) + 10 * P::N3) + ABA_UDL * P::NB;  // q, v, tau, [spare, ten of the 18 values of U D^-1 of every 3-dof joint,] ABA_UDL per body
   constexpr int NQ = P::NQ, NV = P::NV, NB = P::NB, NBS = P::NBS > 0 ? P::NBS : 1, NPR = P::NPAIR > 0 ? P::NPAIR : 1;
   using T2 = typename PairOf<T, true>::type;  // the value type of an op that stands for two bodies
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* rq = lds + (size_t)wave * ABA_ROWS * RS;
   T* rv = rq + NQ * RS;
   T* rt = rv + NV * RS;
-  T* rx = rt + NV * RS;  // max(NQ, NB) rows: q̇ on its way out first, then one value per body for the top-down pass
-  T* r3 = rx + (NQ > NB ? NQ : NB) * RS;  // 10 rows per 3-dof joint: the part of its U D^-1 (18 values) that its v rows (3), its spare row and its four registers do not take
-  T* ru = r3 + 10 * P::N3 * RS;           // ABA_UDL rows per body (fp64: see RBD_SPEC_ABA_UDL)
+  T* rx = rt + NV * RS;  // max(NQ, NB) rows: q̇ on its way out first, then one value per body for the top-down pass (ABA_GST: none — the HBM stash)
+  T* r3 = rx + (ABA_GST ? 0 : (NQ > NB ? NQ : NB)) * RS;  // 10 rows per 3-dof joint: the part of its U D^-1 (18 values) that its v rows (3), its spare row and its four registers do not take (ABA_GST: none)
+  T* ru = r3 + (ABA_GST ? 0 : 10 * P::N3) * RS;           // ABA_UDL rows per body (fp64: see RBD_SPEC_ABA_UDL)
   const long state0 = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * 64;
   if (state0 >= B) return;
 #ifdef RBD_SPEC_ABLATE_NO_LOADS  // (timing experiments, RBD_TUNE spec_variant: the passes on made-up rows, nothing read)
@@ -901,6 +904,12 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
   const bool mk_live = mk_gi < B;
   const long mk_si = mk_live ? mk_gi : B - 1;
   const int mk_s = F.stage;
+  // what the bottom-up pass leaves per body / per 3-dof joint for the top-down pass: an LDS row of the lane's column, or (ABA_GST) the HBM stash
+  const auto gst = as_global(stash);
+  auto sx_put = [&](int slot, T x) __attribute__((always_inline)) { if constexpr (ABA_GST) { if (mk_live) gst[(long)slot * B + mk_gi] = x; } else xs[slot * RS] = x; };
+  auto sx_get = [&](int slot) __attribute__((always_inline)) -> T { if constexpr (ABA_GST) return gst[(long)slot * B + mk_si]; else return xs[slot * RS]; };
+  auto s3_put = [&](int slot, T x) __attribute__((always_inline)) { if constexpr (ABA_GST) { if (mk_live) gst[(long)(NB + slot) * B + mk_gi] = x; } else x3[slot * RS] = x; };
+  auto s3_get = [&](int slot) __attribute__((always_inline)) -> T { if constexpr (ABA_GST) return gst[(long)(NB + slot) * B + mk_si]; else return x3[slot * RS]; };
   const T mk_h = (T)F.dt, mk_bs = (mk_s == 0 || mk_s == 3) ? T(1) / T(6) : T(1) / T(3), mk_an = mk_s < 2 ? T(0.5) : T(1);
   if (mk_s >= 0) {  // uniform
     const auto q0b = as_global((T*)F.q0), v0b = as_global((T*)F.v0), apb = as_global((T*)F.accp);  // (global, said in the type: pointers out of a struct come out as FLAT accesses otherwise)
@@ -916,6 +925,8 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
       for (int k = 0; k < NQ; ++k) QD[k] = qdes ? qdes[(long)k * Lq.sk + mk_si * Lq.sb] : T(0);
     }
+    // the next q: through the spare rows and out in whole runs — or (ABA_GST: no spare rows) from the lane itself, over its own state's q
+    auto qput = [&](int k, T x) __attribute__((always_inline)) { if constexpr (ABA_GST) { if (mk_live) const_cast<T*>(q)[(long)k * Lq.sk + mk_gi * Lq.sb] = x; } else xs[k * RS] = x; };
     sfor<NB>([&](auto jc) __attribute__((always_inline)) {  // joint by joint (the limbs one after the other: element-wise work, nothing to pair up)
       constexpr int J = jc.value, jt = P::JOINTS[J][0], qoff = P::JOINTS[J][1], voff = P::JOINTS[J][2];
       constexpr int nqj = jt == RBD_JOINT_QUAT_FLOATING ? 7 : jt == RBD_JOINT_QUAT_SPHERICAL ? 4 : jt == RBD_JOINT_PLANAR ? 3 : jt == RBD_JOINT_SINCOS_REVOLUTE ? 2 : jt == RBD_JOINT_FIXED ? 0 : 1;
@@ -946,19 +957,20 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
         }
         joint_global<T, 0>(jt, q0j, phi, qn);
 #pragma unroll
-        for (int k = 0; k < nqj; ++k) xs[(qoff + k) * RS] = qn[k];
+        for (int k = 0; k < nqj; ++k) qput((qoff + k), qn[k]);
         if constexpr (jt == RBD_JOINT_REVOLUTE || jt == RBD_JOINT_PRISMATIC) {
           if (F.pd) ts[voff * RS] -= kp[voff] * (qj[0] - QD[qoff]) + kd[voff] * vj[0];
         }
       }
     });
     wave_sync();
-    rows_out<T, NQ>(rx, const_cast<T*>(q), Lq, state0, B);  // F.q_state IS the kernel's own q input (its address space is known): this wavefront has read its block, nobody else touches it
+    if constexpr (!ABA_GST) rows_out<T, NQ>(rx, const_cast<T*>(q), Lq, state0, B);  // F.q_state IS the kernel's own q input (its address space is known): this wavefront has read its block, nobody else touches it
     wave_sync();  // (the spare rows are used again below; the PD law wrote into the τ rows)
   }
   // q̇ (configuration_derivative!, src/mechanism_state.jl:905-910) depends on q and v alone: assembled in the spare rows and sent off before the
   // passes start (its stores drain while they run; the rows are free again long before pass 2 writes them)
   if (qdot) {
+    auto qdput = [&](int k, T x) __attribute__((always_inline)) { if constexpr (ABA_GST) { if (mk_live) qdot[(long)k * Lq.sk + mk_gi * Lq.sb] = x; } else xs[k * RS] = x; };
     sfor<NB>([&](auto jc) __attribute__((always_inline)) {
       constexpr int J = jc.value, jt = P::JOINTS[J][0], qoff = P::JOINTS[J][1], voff = P::JOINTS[J][2];
       if constexpr (jt == RBD_JOINT_QUAT_FLOATING) {  // velocity_to_configuration_derivative! (quaternion_floating.jl:126-136)
@@ -966,38 +978,38 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
         for (int k = 0; k < 6; ++k) v6[k] = vs[(voff + k) * RS];
         const T qw = qs[qoff * RS], qx = qs[(qoff + 1) * RS], qy = qs[(qoff + 2) * RS], qz = qs[(qoff + 3) * RS];
-        xs[qoff * RS] = (-qx * v6[0] - qy * v6[1] - qz * v6[2]) / 2;
-        xs[(qoff + 1) * RS] = (qw * v6[0] - qz * v6[1] + qy * v6[2]) / 2;
-        xs[(qoff + 2) * RS] = (qz * v6[0] + qw * v6[1] - qx * v6[2]) / 2;
-        xs[(qoff + 3) * RS] = (-qy * v6[0] + qx * v6[1] + qw * v6[2]) / 2;
+        qdput(qoff, (-qx * v6[0] - qy * v6[1] - qz * v6[2]) / 2);
+        qdput((qoff + 1), (qw * v6[0] - qz * v6[1] + qy * v6[2]) / 2);
+        qdput((qoff + 2), (qz * v6[0] + qw * v6[1] - qx * v6[2]) / 2);
+        qdput((qoff + 3), (-qy * v6[0] + qx * v6[1] + qw * v6[2]) / 2);
         rot_quat(qw, qx, qy, qz, Rq);
         matvec3(Rq, v6 + 3, lin);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xs[(qoff + 4 + k) * RS] = lin[k];
+        for (int k = 0; k < 3; ++k) qdput((qoff + 4 + k), lin[k]);
       } else if constexpr (jt == RBD_JOINT_SINCOS_REVOLUTE) {  // d/dt (sin, cos) = (cos, -sin) q'
         const T qd = vs[voff * RS];
-        xs[qoff * RS] = qs[(qoff + 1) * RS] * qd;
-        xs[(qoff + 1) * RS] = -qs[qoff * RS] * qd;
+        qdput(qoff, qs[(qoff + 1) * RS] * qd);
+        qdput((qoff + 1), -qs[qoff * RS] * qd);
       } else if constexpr (jt == RBD_JOINT_QUAT_SPHERICAL) {  // quaternion_spherical.jl velocity_to_configuration_derivative!
         const T w0 = vs[voff * RS], w1 = vs[(voff + 1) * RS], w2 = vs[(voff + 2) * RS];
         const T qw = qs[qoff * RS], qx = qs[(qoff + 1) * RS], qy = qs[(qoff + 2) * RS], qz = qs[(qoff + 3) * RS];
-        xs[qoff * RS] = (-qx * w0 - qy * w1 - qz * w2) / 2;
-        xs[(qoff + 1) * RS] = (qw * w0 - qz * w1 + qy * w2) / 2;
-        xs[(qoff + 2) * RS] = (qz * w0 + qw * w1 - qx * w2) / 2;
-        xs[(qoff + 3) * RS] = (-qy * w0 + qx * w1 + qw * w2) / 2;
+        qdput(qoff, (-qx * w0 - qy * w1 - qz * w2) / 2);
+        qdput((qoff + 1), (qw * w0 - qz * w1 + qy * w2) / 2);
+        qdput((qoff + 2), (qz * w0 + qw * w1 - qx * w2) / 2);
+        qdput((qoff + 3), (-qy * w0 + qx * w1 + qw * w2) / 2);
       } else if constexpr (jt == RBD_JOINT_PLANAR) {  // planar.jl velocity_to_configuration_derivative!: q̇_lin = Rot2(θ) v_lin
         T sn, cs;
         sincos_fast(qs[(qoff + 2) * RS], &sn, &cs);
         const T vx = vs[voff * RS], vy = vs[(voff + 1) * RS];
-        xs[qoff * RS] = cs * vx - sn * vy;
-        xs[(qoff + 1) * RS] = sn * vx + cs * vy;
-        xs[(qoff + 2) * RS] = vs[(voff + 2) * RS];
+        qdput(qoff, cs * vx - sn * vy);
+        qdput((qoff + 1), sn * vx + cs * vy);
+        qdput((qoff + 2), vs[(voff + 2) * RS]);
       } else if constexpr (jt != RBD_JOINT_FIXED) {
-        xs[qoff * RS] = vs[voff * RS];
+        qdput(qoff, vs[voff * RS]);
       }
     });
     wave_sync();
-    rows_out<T, NQ>(rx, qdot, Lq, state0, B);
+    if constexpr (!ABA_GST) rows_out<T, NQ>(rx, qdot, Lq, state0, B);
     wave_sync();
   }
   const long sc = state0 + lane < B ? state0 + lane : B - 1;
@@ -1178,9 +1190,9 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
           constexpr int j = jc.value;
           const T x = W[j / 6][j % 6];
           if constexpr (j < 3) vs[(voff + j) * RS] = x;
-          else if constexpr (j == 3) xs[body * RS] = x;
+          else if constexpr (j == 3) sx_put(body, x);
           else if constexpr (j < 8) ud1_put(body, j - 4, x);
-          else x3[(xr + j - 8) * RS] = x;
+          else s3_put(xr + j - 8, x);
         });
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -1203,7 +1215,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
 #pragma unroll
         for (int k = 0; k < 6; ++k) W[k] = U[k] * Dinv;
         wr2<V>(ts, voff, voff2, u);
-        wr2<V>(xs, body, body2, W[0]);
+        if constexpr (ABA_GST) sx_put(body, hsum(W[0])); else wr2<V>(xs, body, body2, W[0]);  // (ABA_GST: no pairs — hsum of a scalar is itself)
         wr2<V>(vs, voff, voff2, W[1]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) ud_set(k, W[2 + k]);
@@ -1369,9 +1381,9 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
           sfor<18>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = jc.value;
             if constexpr (j < 3) Wf[j] = vs[(voff + j) * RS];
-            else if constexpr (j == 3) Wf[j] = xs[body * RS];
+            else if constexpr (j == 3) Wf[j] = sx_get(body);
             else if constexpr (j < 8) Wf[j] = ud1_get(body, j - 4);
-            else Wf[j] = x3[(xr + j - 8) * RS];
+            else Wf[j] = s3_get(xr + j - 8);
           });
 #pragma unroll
           for (int k = 0; k < 3; ++k) vd3[k] = ts[(voff + k) * RS] - dot6(Wf + 6 * k, ad);  // v̇ = D^-1 u - (U D^-1)' a_delta,parent
@@ -1385,7 +1397,7 @@ RBD_DEV void aba_spec(long B, const T* __restrict__ q, const T* __restrict__ v, 
         } else if constexpr (jt != RBD_JOINT_FIXED) {
           V S[6];
           subspace_1dof<V, jt>(K.R, K.p, S);
-          const V W[6] = {rd2<V>(xs, body, body2), rd2<V>(vs, voff, voff2), ud_get(0), ud_get(1), ud_get(2), ud_get(3)};
+          const V W[6] = {[&]() -> V { if constexpr (ABA_GST) return conv<V>(sx_get(body)); else return rd2<V>(xs, body, body2); }(), rd2<V>(vs, voff, voff2), ud_get(0), ud_get(1), ud_get(2), ud_get(3)};
           const V vd = rd2<V>(ts, voff, voff2) - dot6(W, ad);  // v̇ = D^-1 u - (U D^-1)' a_delta,parent
 #pragma unroll
           for (int k = 0; k < 6; ++k) ad[k] += S[k] * vd;

@@ -33,5 +33,5 @@ for algo in ("aba", "aba_compiled"):
         e0.record()
         for _ in range(20): f()
         e1.record(); torch.cuda.synchronize()
-        out[f"{algo}{'+fext' if wr else ''}"] = {"us": round(e0.elapsed_time(e1) / 20 * 1e3, 1), "err": err, "kernel": rbd.last_kernel(state)[:40]}
+        out[f"{algo}{'+fext' if wr else ''}"] = {"us": round(e0.elapsed_time(e1) / 20 * 1e3, 1), "err": err, "kernel": rbd.last_kernel(state)[:24]}
 print(json.dumps({"model": name, "B": B, "nv": model.nv, "results": out}))

@@ -56,14 +56,14 @@ def aba_f32(lib, model, q, v, tau, fext=None, want_qdot=False):
     return (vd.T.copy(), qd.T.copy()) if want_qdot else vd.T.copy()
 
 
-def aba_f64(lib, model, q, v, tau, fext=None, want_qdot=False):
-    """... through aba_spec_f64 (round 6: the program in doubles of the mechanisms no walk kernel takes)."""
+def aba_f64(lib, model, q, v, tau, fext=None, want_qdot=False, stash=False):
+    """... through aba_spec_f64 (round 6: the program in doubles of the mechanisms no walk kernel takes), or (stash) aba_spec_gst_f64."""
     B = q.shape[0]
     qs = np.ascontiguousarray(q.T, dtype=np.float64); vs = np.ascontiguousarray(v.T, dtype=np.float64); ts = np.ascontiguousarray(tau.T, dtype=np.float64)
     fs = np.ascontiguousarray(fext.T, dtype=np.float64) if fext is not None else None
     vd = np.full((model.nv, B), np.nan); qd = np.full((model.nq, B), np.nan) if want_qdot else None
     g = np.asarray(model.gravity, dtype=np.float64)
-    lib.emu_aba_f64(ctypes.c_long(B), _p(qs), _p(vs), _p(ts), _p(fs), _p(vd), _p(qd), _p(g))
+    lib.emu_aba_f64(ctypes.c_long(B), _p(qs), _p(vs), _p(ts), _p(fs), _p(vd), _p(qd), _p(g), ctypes.c_int(1 if stash else 0))
     return (vd.T.copy(), qd.T.copy()) if want_qdot else vd.T.copy()
 
 

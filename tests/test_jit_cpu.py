@@ -135,13 +135,19 @@ def test_programs_of_mechanisms_with_every_joint_type(rbd, tmp_path, monkeypatch
             assert src is not None, (fam, dt)  # (round 6: dynamics! in fp64 too — for exactly these mechanisms; an Atlas-like tree has none)
     atlas = mechanism(rbd, "atlas_floating")
     assert rbd.jit_source(atlas, torch.float64, "dynamics") is None and rbd.jit_source(atlas, torch.float32, "dynamics") is not None
-    # fp64: as many of a body's four register values of U D^-1 in LDS rows as one CU's LDS has room for (csrc/rbd_spec.hpp RBD_SPEC_ABA_UDL), at most three
+    # fp64: two programs (csrc/rbd_spec.hpp aba_spec UDL, GST) — every row in LDS (one CU's 160 KB: one wavefront per CU), or the spare and 3-dof rows in an HBM
+    # stash (half of it: two) — each with as many of a body's four register values of U D^-1 in LDS rows as its budget has room for, at most three
     s64 = rbd.jit_source(model, torch.float64, "dynamics")
-    udl = int(re.search(r"#define RBD_SPEC_ABA_UDL (\d+)", s64).group(1))
-    rows = model.nq + 2 * model.nv + max(model.nq, model.n_bodies) + 10 * n3
-    assert udl == max(0, min(3, (160 * 1024 // (65 * 8) - rows) // model.n_bodies)) and "aba_lds[%d]" % ((rows + udl * model.n_bodies) * 65) in s64 and "NPAIR = 0" in s64
+    for gst, kb in ((0, 160), (1, 80)):
+        rows = model.nq + 2 * model.nv + (0 if gst else max(model.nq, model.n_bodies) + 10 * n3)
+        udl = max(0, min(3, (kb * 1024 // (65 * 8) - rows) // model.n_bodies))
+        for fx in ("", "nofext_"):
+            body = s64[s64.index("void aba_spec_%s%sf64(" % ("gst_" if gst else "", fx)):]
+            body = body[:body.index("}\n") + 1]
+            assert "aba_lds[%d]" % ((rows + udl * model.n_bodies) * 65) in body and "aba_spec<double, %s, %d, %d>" % ("false" if fx else "true", udl, gst) in body, body
+    assert "NPAIR = 0" in s64
     src = rbd.jit_source(model, torch.float32, "dynamics")
-    assert "RBD_SPEC_ABA_UDL" not in src
+    assert "aba_spec_gst" not in src and "aba_spec<float, true, 0, 0>" in src
     assert int(re.search(r"N3 = (\d+);", src).group(1)) == n3
     opw, x3, cols = table(src, "OPW"), table(src, "X3")[0], table(src, "COLS")
     for o, w in enumerate(opw):

@@ -65,18 +65,20 @@ def test_emulated_aba_f64(rbd, oracle, models, name):
         assert src is None  # (trees of 1-dof joints below a floating base: the walk kernels are ahead in fp64)
         return
     assert src is not None and "aba_spec_f64" in src and "aba_spec_nofext_f64" in src and "NPAIR = 0" in src
+    assert "aba_spec_gst_f64" in src and "aba_spec_gst_nofext_f64" in src  # ... and the one with its spare rows in the HBM stash (two wavefronts per CU)
     lib = spec_emu.build(src, "ABA_F64")
     B = 70
     rng = np.random.default_rng(6)
     q, v, tau = rbd.rand_configuration(model, B, rng), rbd.rand_velocity(model, B, rng), rng.random((B, model.nv))
     fe = rng.random((B, 6 * model.n_bodies))
-    vd, qd = spec_emu.aba_f64(lib, model, q, v, tau, fe, want_qdot=True)
     ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
-    assert np.isfinite(vd).all() and np.abs(vd - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
-    assert np.abs(qd - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
-    vd = spec_emu.aba_f64(lib, model, q, v, tau, None)
-    ref = oracle.dynamics(model, q, v, tau)
-    assert np.abs(vd - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    ref0 = oracle.dynamics(model, q, v, tau)
+    for stash in (False, True):
+        vd, qd = spec_emu.aba_f64(lib, model, q, v, tau, fe, want_qdot=True, stash=stash)
+        assert np.isfinite(vd).all() and np.abs(vd - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+        assert np.abs(qd - qd_ref).max() <= 1e-13 * max(1.0, np.abs(qd_ref).max())
+        vd = spec_emu.aba_f64(lib, model, q, v, tau, None, stash=stash)
+        assert np.abs(vd - ref0).max() <= 1e-10 * max(1.0, np.abs(ref0).max())
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f64"])

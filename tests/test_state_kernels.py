@@ -245,14 +245,19 @@ def test_compiled_aba_f32(rbd, oracle, models, name, layout):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("stash", [0, 1])
 @pytest.mark.parametrize("name", ["randmech1", "randmech2", "randmech3", "inner_floating", "mixed20"])
-def test_compiled_aba_f64_of_mechanisms_no_walk_kernel_takes(rbd, oracle, models, name, layout, monkeypatch):
+def test_compiled_aba_f64_of_mechanisms_no_walk_kernel_takes(rbd, oracle, models, name, layout, stash, monkeypatch):
     """Round 6: `dynamics!` in fp64 for mechanisms with 3-dof joints / 6-dof joints below the world (the reference's own randmech(),
     test/test_mechanism_algorithms.jl:1-11) through the lane-per-state program in doubles (aba_spec_f64): forced (RBD_ALGO_ABA_COMPILED) at a ragged batch and picked
     by the library from its batch threshold on; with a wrench on every body and q̇, without torques and wrenches, and as the M^-1 rhs solve — the reference's 1e-10
-    against the oracle.  Atlas-like trees have no such program (the walk kernels are ahead in fp64)."""
+    against the oracle.  Atlas-like trees have no such program (the walk kernels are ahead in fp64).  Both programs (csrc/rbd_spec.hpp aba_spec GST): every row in
+    LDS (aba_spec_f64), and the spare rows in the workspace's HBM stash (aba_spec_gst_f64: two wavefronts per CU — what the library takes by itself when the
+    batch needs fewer of its longer rounds)."""
     model = models[name]
     B = 150
+    kernel = "aba_spec_gst_f64" if stash else "aba_spec_f64"
+    tune(monkeypatch, spec_f64_stash=stash)
     state, q, v, tau, fe = make(rbd, model, B, "f64", layout, 73)
     result = rbd.DynamicsResult(model, B, layout=layout)
     try:
@@ -261,7 +266,7 @@ def test_compiled_aba_f64_of_mechanisms_no_walk_kernel_takes(rbd, oracle, models
         if e.status == 3:
             pytest.skip("hiprtc not available")
         raise
-    assert rbd.sync(state) == 0 and "aba_spec_f64" in rbd.last_kernel(state)
+    assert rbd.sync(state) == 0 and kernel in rbd.last_kernel(state)
     ref, qd_ref = oracle.dynamics(model, q, v, tau, fe, want_qdot=True)
     rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
     assert rel(host(result.vd, state), ref) <= 1e-10 and rel(host(result.qd, state), qd_ref) <= 1e-13
@@ -269,11 +274,11 @@ def test_compiled_aba_f64_of_mechanisms_no_walk_kernel_takes(rbd, oracle, models
     rbd.dynamics_(result, state, None, None, algorithm="aba_compiled")
     assert rel(host(result.vd, state), oracle.dynamics(model, q, v, None, None)) <= 1e-10
     # the library's own choice from its threshold on (forced down to this batch), and the articulated-body solve M^-1 rhs on the same kernel
-    tune(monkeypatch, spec_aba_min_batch=1)
+    tune(monkeypatch, spec_aba_min_batch=1, spec_f64_stash=stash)
     state2, q2, v2, tau2, _ = make(rbd, model, B, "f64", layout, 74)
     result2 = rbd.DynamicsResult(model, B, layout=layout)
     rbd.dynamics_(result2, state2, dev(tau2, state2))
-    assert "aba_spec_f64" in rbd.last_kernel(state2), rbd.last_kernel(state2)
+    assert kernel in rbd.last_kernel(state2), rbd.last_kernel(state2)
     assert rel(host(result2.vd, state2), oracle.dynamics(model, q2, v2, tau2)) <= 1e-10
     x = torch.zeros_like(state2.v)
     rbd.mass_matrix_solve_(x, state2, dev(tau2, state2), algorithm="aba")
@@ -281,6 +286,30 @@ def test_compiled_aba_f64_of_mechanisms_no_walk_kernel_takes(rbd, oracle, models
     xr = np.linalg.solve(sym(M), tau2[..., None])[..., 0]
     assert rel(host(x, state2), xr) <= 1e-9
     assert rbd.jit_source(models["atlas_floating"], torch.float64, "dynamics") is None
+
+
+@pytest.mark.gpu
+def test_compiled_aba_f64_program_by_batch(rbd, oracle, models):
+    """Left to itself (no RBD_TUNE) the library takes, of the two fp64 programs, the one whose rounds need less time: one wavefront per CU with every row in LDS,
+    two with the stash on a chain 1.7 times as long (1.2 with wrenches) — csrc/rbd_capi.hip run_aba.  Ragged batches of one, two and three chip-fulls of
+    wavefronts; parity on the first 1024 states and the ragged tail."""
+    model = models["randmech1"]
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    for chips, wrenches, want in ((1, False, "aba_spec_f64"), (2, False, "aba_spec_gst_f64"), (3, False, "aba_spec_f64"), (2, True, "aba_spec_gst_f64"), (3, True, "aba_spec_gst_f64")):
+        B = chips * ncu * 64 - 30
+        state, q, v, tau, fe = make(rbd, model, B, "f64", "soa", 75 + chips)
+        result = rbd.DynamicsResult(model, B, layout="soa")
+        try:
+            rbd.dynamics_(result, state, dev(tau, state), dev(fe, state) if wrenches else None)
+        except rbd._capi.RBDError as e:
+            if e.status == 3:
+                pytest.skip("hiprtc not available")
+            raise
+        assert rbd.sync(state) == 0 and want in rbd.last_kernel(state), (chips, wrenches, rbd.last_kernel(state))
+        got = host(result.vd, state)
+        for sl in (slice(0, 1024), slice(B - 100, B)):
+            assert rel(got[sl], oracle.dynamics(model, q[sl], v[sl], tau[sl], fe[sl] if wrenches else None)) <= 1e-10
 
 
 def test_first_call_does_not_wait_for_the_compiler(rbd, models, tmp_path):
