@@ -94,7 +94,9 @@ enum {
                                 trees of every joint type above (since 400: Planar, QuaternionSpherical, QuaternionFloating below the world
                                 too), no loop joints, nv <= 64; RBD_ALGO_ABA picks it from half a chip-full of wavefronts up.  Since 600 also
                                 fp64 for the mechanisms no walk kernel takes (3-dof joints, 6-dof joints below the world — the reference's
-                                randmech(): 65 536 states 200 us against 684 one body per lane); RBD_ALGO_ABA picks it from 8193 states.
+                                randmech(): 65 536 states 177 us against 684 one body per lane; two programs — every row in LDS, or the spare
+                                rows in an HBM stash of the workspace and two wavefronts per CU — picked by batch); RBD_ALGO_ABA picks it from
+                                8193 states.
                                 RBD_ERR_UNSUPPORTED without hiprtc or outside that scope                                            */
 };
 
@@ -341,7 +343,7 @@ int rbd_simulate_contact(rbd_ws_t* ws, int32_t B, void* q, void* v, void* s, con
  * momentum_matrix: 6×nv column-major per state, root frame, (angular; linear) — momentum_matrix!(out, state)
  *   src/mechanism_algorithms.jl:313-327;  com: 3×B — center_of_mass(state) :28-50;  energy: 2×B = (kinetic_energy,
  *   gravitational_potential_energy) src/mechanism_state.jl:886-903 (needs v).
- * Large batches (from half a chip-full of wavefronts: 32 769 states on an MI355X) take kernels compiled for the mechanism with one lane per state (family 11; Atlas,
+ * Larger batches (from 8193 states on an MI355X: a wavefront of 64 states for every other CU) take kernels compiled for the mechanism with one lane per state (family 11; Atlas,
  * 65 536 fp64 states: momentum matrix 56 us, energies 34, Jacobian 46, momentum 41 against 207 / 149 / 164 on the lane-per-body kernels).  A column of the momentum
  * matrix / Jacobian leaves as the lane's own 48 bytes: callers that can take the batch-innermost layout (RBD_LAYOUT_SOA) get whole 512-byte runs instead. */
 int rbd_kinematics(rbd_ws_t* ws, int32_t B, const void* q, const void* v, void* momentum_matrix, void* com, void* energy,

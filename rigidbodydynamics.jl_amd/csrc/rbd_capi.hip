@@ -1009,8 +1009,10 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->sim_walk_max_batch = tune("sim_walk_max_batch", (long)ncu * 128);
     { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = w->spec_aba_fused_min_batch = t; }
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
-    // the kinematics by-products one lane per state (kin_spec / jac_spec / mom_spec): from half a chip-full of wavefronts on, like the other compiled kernels
-    w->spec_kin_min_batch = tune("spec_kin_min_batch", (long)ncu * 4 * 64 / 2 + 1);
+    // the kinematics by-products one lane per state (kin_spec / jac_spec / mom_spec): from an eighth of a chip-full of wavefronts on — a round of them takes the
+    // same 30 us per kernel from one wavefront to a chip-full, the one-body-per-lane kernels' time grows with the batch (Atlas fp64, the set of three calls:
+    // 4096 states 57.5 against 89.3 us compiled, 8192: 96.6 against 91.8, 16 384: 160 against 117, 32 768: 284 against 133; scripts/exp_kin_small.sh)
+    w->spec_kin_min_batch = tune("spec_kin_min_batch", (long)ncu * 32 + 1);
     w->state_aot = true;
   } else if (m->state_wide.ok) {  // the compiled kernels alone (no interpreting form of them for these joint types): the same thresholds, the lane-per-body kernels behind them
     int ncu = 256;

@@ -119,22 +119,30 @@ for trial in range(10 * N):
             J_ref, _ = oracle.geometric_jacobian(model, qd_, base, body)
             chk("geometric jacobian " + dname, Hh(J).reshape(B, nv, 6).transpose(0, 2, 1), J_ref, tk)
         if dname == "f64" and rbd.jit_source(model, torch.float64, "dynamics") is not None:  # round 6: dynamics! in doubles for what no walk kernel takes
-            res = rbd.DynamicsResult(model, B, dtype=tdt, layout=layout)
-            rbd.dynamics_(res, state, D(tau_), D(fe_), algorithm="aba_compiled")
-            kernel(state, "aba_spec_f64")
             ref64, qd_ref = oracle.dynamics(model, qd_, v_, tau_, fe_, want_qdot=True)
-            chk("dynamics! f64", Hh(res.vd), ref64, 1e-10)
-            chk("q̇ f64", Hh(res.qd), qd_ref, 1e-13)
-            rbd.dynamics_(res, state, D(tau_), None, algorithm="aba_compiled")
-            chk("dynamics! f64 without wrenches", Hh(res.vd), oracle.dynamics(model, qd_, v_, tau_), 1e-10)
-            st2 = rbd.MechanismState(model, B, dtype=tdt, layout=layout)
-            rbd.set_configuration_(st2, qd_); rbd.set_velocity_(st2, v_)
-            rbd.simulate_(st2, 1.5e-3, dt=1e-3, torques=D(tau_))
-            kernel(st2, "aba_spec_f64 with the Munthe-Kaas stage folded in")
-            sel = [0, B - 1] if B > 1 else [0]
-            _, q_ref, v_ref = simulate_np.simulate(model, qd_[sel], v_[sel], 1.5e-3, 1e-3, tau_[sel])
-            chk("simulate q f64 (|.|: quaternion sign)", np.abs(Hh(st2.q)[sel]), np.abs(q_ref), 1e-10)
-            chk("simulate v f64", Hh(st2.v)[sel], v_ref, 1e-8)
+            tune0 = os.environ.get("RBD_TUNE")
+            for stash in (0, 1):  # both programs: every row in LDS, and the spare rows in the workspace's HBM stash (csrc/rbd_spec.hpp aba_spec GST)
+                os.environ["RBD_TUNE"] = (tune0 + "," if tune0 else "") + "spec_f64_stash=%d" % stash
+                name = "aba_spec_gst_f64" if stash else "aba_spec_f64"
+                st1 = rbd.MechanismState(model, B, dtype=tdt, layout=layout)
+                rbd.set_configuration_(st1, qd_); rbd.set_velocity_(st1, v_)
+                res = rbd.DynamicsResult(model, B, dtype=tdt, layout=layout)
+                rbd.dynamics_(res, st1, D(tau_), D(fe_), algorithm="aba_compiled")
+                kernel(st1, name)
+                chk("dynamics! f64 " + name, Hh(res.vd), ref64, 1e-10)
+                chk("q̇ f64 " + name, Hh(res.qd), qd_ref, 1e-13)
+                rbd.dynamics_(res, st1, D(tau_), None, algorithm="aba_compiled")
+                chk("dynamics! f64 without wrenches " + name, Hh(res.vd), oracle.dynamics(model, qd_, v_, tau_), 1e-10)
+                st2 = rbd.MechanismState(model, B, dtype=tdt, layout=layout)
+                rbd.set_configuration_(st2, qd_); rbd.set_velocity_(st2, v_)
+                rbd.simulate_(st2, 1.5e-3, dt=1e-3, torques=D(tau_))
+                kernel(st2, name + " with the Munthe-Kaas stage folded in")
+                sel = [0, B - 1] if B > 1 else [0]
+                _, q_ref, v_ref = simulate_np.simulate(model, qd_[sel], v_[sel], 1.5e-3, 1e-3, tau_[sel])
+                chk("simulate q f64 (|.|: quaternion sign) " + name, np.abs(Hh(st2.q)[sel]), np.abs(q_ref), 1e-10)
+                chk("simulate v f64 " + name, Hh(st2.v)[sel], v_ref, 1e-8)
+            if tune0 is None: os.environ.pop("RBD_TUNE")
+            else: os.environ["RBD_TUNE"] = tune0
         if dname == "f32":
             res = rbd.DynamicsResult(model, B, dtype=tdt, layout=layout)
             try:

@@ -552,13 +552,16 @@ def test_simulate_device_side_controllers(rbd, oracle, models, path, monkeypatch
 
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 @pytest.mark.parametrize("name", ["mixed20", "inner_floating", "randmech1"])
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("dtype", ["f32", "f64", "f64_stash"])
 def test_simulate_stage_folded_in_on_every_joint_type(rbd, oracle, models, name, layout, dtype, monkeypatch):
     """The same for mechanisms with Planar / QuaternionSpherical joints and QuaternionFloating joints below the world: only the lane-per-state kernel compiled for the
     mechanism takes them (its stage is generic over the joint types: the Bortz equation for the spherical joints, the SE(3) log / exp for every 6-dof joint) — in fp32
-    and, since round 6, in fp64 (aba_spec_f64: the program in doubles of exactly these mechanisms)."""
+    and, since round 6, in fp64 (aba_spec_f64: the program in doubles of exactly these mechanisms; f64_stash: its sibling with the spare rows in the workspace's HBM
+    stash, where the next q leaves from the lanes instead of through spare rows)."""
     import simulate_np
-    tune(monkeypatch, spec_aba_min_batch=1)
+    stash = dtype == "f64_stash"
+    dtype = dtype[:3]
+    tune(monkeypatch, spec_aba_min_batch=1, spec_f64_stash=1 if stash else 0)
     model = models[name]
     B, dt, nsteps = 70, 1e-3, 3
     T = (nsteps - 0.5) * dt
@@ -573,7 +576,7 @@ def test_simulate_stage_folded_in_on_every_joint_type(rbd, oracle, models, name,
     k = rbd.last_kernel(state)
     if "folded in" not in k:
         pytest.skip("no compiled kernel for this route on this box: " + k)
-    assert "aba_spec_" + dtype in k, k
+    assert ("aba_spec_gst_f64" if stash else "aba_spec_" + dtype) in k, k
     ref = simulate_np.simulate(model, q[sel], v[sel], T, dt, tau[sel])
     qg, vg = host(state.q, state)[sel], host(state.v, state)[sel]
     assert np.isfinite(host(state.q, state)).all() and np.isfinite(host(state.v, state)).all()
