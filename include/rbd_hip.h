@@ -97,7 +97,9 @@ enum {
                                 randmech(): 65 536 states 177 us against 684 one body per lane; two programs — every row in LDS, or the spare
                                 rows in an HBM stash of the workspace and two wavefronts per CU — picked by batch); RBD_ALGO_ABA picks it from
                                 8193 states.
-                                RBD_ERR_UNSUPPORTED without hiprtc or outside that scope                                            */
+                                RBD_ERR_UNSUPPORTED without hiprtc, outside that scope, or when the program's first result in this workspace
+                                differs from the interpreting kernel's on the same states (first-use check, since 600: the program is
+                                dropped, rbd_last_hip_error says so; RBD_ALGO_ABA recomputes the call on the interpreting kernels)    */
 };
 
 /* ---- loop (non-tree) joint: src/mechanism_modification.jl:38-43,

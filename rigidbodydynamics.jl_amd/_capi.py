@@ -123,6 +123,6 @@ def check(status: int, where: str):
         L = lib()
         detail = L.rbd_status_string(status).decode()
         hip = L.rbd_last_hip_error().decode()
-        if status in (4, 5, 6) and hip:
+        if hip and (status in (4, 5, 6) or (status == 3 and "differs from the interpreting kernel" in hip)):  # (3: a compiled program the first-use check dropped)
             detail += "; " + hip
         raise RBDError(status, where, detail)

@@ -129,6 +129,10 @@ struct rbd_ws {
   // fp64 dynamics! of those mechanisms: the program with its spare rows in the HBM stash (two wavefronts per CU, a longer chain) against the one with every row in
   // LDS (one per CU): RBD_TUNE spec_f64_stash = 1 always / 0 never / -1 whichever needs fewer chain-times for the batch; the chains' ratio in percent
   int spec_f64_stash = -1, spec_f64_stash_ratio = 170, spec_f64_stash_ratio_fext = 120, spec_ncu = 256;
+  // first use of a run-time compiled dynamics! program by this workspace: its result on the first states of the call against the interpreting kernel's
+  // (first_use_check; RBD_TUNE first_use_check=0 for timing experiments with programs that are wrong by construction).  [stash program][no wrenches]
+  bool spec_first_use_check = true, spec_aba_checked[4] = {false, false, false, false};
+  double spec_check_err = 0;  // (what the last check measured: max |difference| / max(1, max |reference|))
   int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
   bool spec_bank_tried = false; hipModule_t spec_bank_mod = nullptr; hipFunction_t spec_bank_aba = nullptr, spec_bank_fused = nullptr, spec_bank_rnea = nullptr; std::string spec_bank_src;  // the banked kernels compiled for the mechanism
@@ -1036,6 +1040,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
   } else {
     w->state_min_batch = (long)1 << 62;
   }
+  w->spec_first_use_check = tune("first_use_check", 1) != 0;
   {
     const hipError_t e = dtype == RBD_F64 ? configure_bank_kernels<double>() : configure_bank_kernels<float>();
     if (e != hipSuccess) { g_last_hip_error = std::string("configure_bank_kernels: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
@@ -1520,6 +1525,36 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
 static const MkStage kNoStage{-1, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
 // `mk` (simulate_core): the launch is a stage of a Munthe-Kaas step folded into a kernel compiled for the mechanism (rbd_mk_fuse.hpp) — only those kernels take it:
 // RBD_ERR_UNSUPPORTED when the batch would go to another kernel (the caller then keeps the stage in its own launches)
+// The first result of a run-time compiled dynamics! program against the interpreting one-body-per-lane kernel (aba_kernel) on the first states of the same call
+// (up to 256): max |difference| <= tol max(1, max |reference|), tol 1e-7 in fp64, 5e-3 in fp32 (two fp32 evaluations in different operation orders).  One
+// allocation, two small launches and a synchronisation — once per program and workspace, on a call that has just waited for the module to load.
+static bool capturing(rbd_ws* w);
+static int first_use_check(rbd_ws* w, long B, const void* dq, const void* dv, const void* dtau, const void* df, const void* dvd, Layout Lq, Layout Lv, Layout Lf,
+                           const double* gravity, bool* same) {
+  const rbd_model* m = w->model;
+  const long n = std::min<long>(B, 256);
+  const size_t es = w->dtype == RBD_F64 ? 8 : 4;
+  const size_t elems = (size_t)(layout_base(Lv, n - 1) + (long)(m->nv - 1) * Lv.sk + 1);  // v̇'s layout, its first n states
+  void* ref = nullptr;
+  double* out = nullptr;
+  HIP_TRY(hipMalloc(&ref, elems * es));
+  if (hipMalloc((void**)&out, 2 * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ref); return RBD_ERR_OUT_OF_MEMORY; }
+  DevModel dm = w->dm;
+  if (gravity) memcpy(dm.gravity, gravity, sizeof dm.gravity);
+  double h[2] = {0, 0};
+  hipError_t e = w->dtype == RBD_F64 ? launch_aba<double>(dm, n, dq, dv, dtau, df, ref, nullptr, Lq, Lv, Lf, w->stream)
+                                     : launch_aba<float>(dm, n, dq, dv, dtau, df, ref, nullptr, Lq, Lv, Lf, w->stream);
+  if (e == hipSuccess) e = w->dtype == RBD_F64 ? launch_max_diff<double>(n, m->nv, dvd, ref, Lv, out, w->stream) : launch_max_diff<float>(n, m->nv, dvd, ref, Lv, out, w->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h, out, sizeof h, hipMemcpyDeviceToHost, w->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+  (void)hipFree(ref);
+  (void)hipFree(out);
+  if (e != hipSuccess) { g_last_hip_error = std::string("first_use_check: ") + hipGetErrorString(e); (void)hipGetLastError(); return RBD_ERR_HIP; }
+  w->spec_check_err = h[0] / std::max(1.0, h[1]);
+  *same = w->spec_check_err <= (w->dtype == RBD_F64 ? 1e-7 : 5e-3);
+  return RBD_OK;
+}
+
 static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd,
                    Layout Lq, Layout Lv, Layout Lf, const double* gravity, const MkFuse* fuse, const MkStage* mk = nullptr) {
   const rbd_model* m = w->model;
@@ -1578,7 +1613,22 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
       HIP_TRY(hipModuleLaunchKernel(faba, (unsigned)((B + 63) / 64), 1, 1, 64, 1, 1, 0, w->stream, w->dtype == RBD_F64 ? args64 : args, nullptr));
       w->last_kernel = stash_program ? "aba_spec_gst_f64 (compiled for the mechanism at run time; spare rows in the HBM stash)"
                        : w->dtype == RBD_F64 ? "aba_spec_f64 (compiled for the mechanism at run time)" : "aba_spec_f32 (compiled for the mechanism at run time)";
-      return RBD_OK;
+      // The first result a workspace gets from one of these programs is held against the interpreting one-body-per-lane kernel on the call's first states: a
+      // program that hiprtc miscompiled (round 6 met one in an experiment: profiles/r06_experiments.txt §8) is dropped, loudly, and the call recomputed
+      bool& checked = w->spec_aba_checked[(stash_program ? 2 : 0) + (nofext ? 1 : 0)];
+      if (mk || !dv || !dvd || !w->spec_first_use_check || checked || capturing(w)) return RBD_OK;
+      checked = true;
+      bool same = true;
+      if (int st = first_use_check(w, B, dq, dv, dtau, df, dvd, Lq, Lv, Lf, gravity, &same)) return st;
+      if (same) return RBD_OK;
+      (stash_program ? (nofext ? w->spec_aba_gst_nofext : w->spec_aba_gst) : (nofext ? w->spec_aba_nofext : w->spec_aba)) = nullptr;
+      char msg[256];
+      snprintf(msg, sizeof msg, "%s differs from the interpreting kernel on this call's first states by %.3g of the largest acceleration: the program is dropped, the interpreting kernels serve",
+               w->last_kernel, w->spec_check_err);
+      g_last_hip_error = msg;
+      fprintf(stderr, "[rbd] %s\n", msg);
+      if (algorithm == RBD_ALGO_ABA_COMPILED) return RBD_ERR_UNSUPPORTED;
+      // (falls through: the call is recomputed below)
     }
   }
   if (algorithm == RBD_ALGO_ABA_COMPILED) return RBD_ERR_UNSUPPORTED;

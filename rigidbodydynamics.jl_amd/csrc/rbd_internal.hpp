@@ -10,6 +10,7 @@ hipError_t launch_aba(const DevModel& M, long B, const void* q, const void* v, c
 template <typename T>
 hipError_t launch_rnea(const DevModel& M, long B, const void* q, const void* v, const void* vdot, const void* fext, void* tau,
                        void* qdot, void* body_out, Layout Lq, Layout Lv, Layout Lf, hipStream_t s, void* acc_out = nullptr, void* jw_out = nullptr);
+template <typename T> hipError_t launch_max_diff(long n, int nk, const void* a, const void* b, Layout L, double* out, hipStream_t s);  // out[0] = max |a - b|, out[1] = max |b| over the first n states
 template <typename T>
 hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Layout Lq, Layout Lm, int zero_fill, hipStream_t s);
 }  // namespace rbd

@@ -844,6 +844,34 @@ hipError_t launch_crba(const DevModel& M, long B, const void* q, void* Mout, Lay
   return hipGetLastError();
 }
 
+// max |a - b| and max |b| over the first n states of two n x nk arrays of one layout (a value that is not finite counts as infinitely far): the comparison of
+// a run-time compiled program's first result with the interpreting kernel's (rbd_capi.hip: first_use_check).  One workgroup; out[0] = max |a - b|, out[1] = max |b|.
+template <typename T>
+__global__ __launch_bounds__(256) void max_diff_kernel(long n, int nk, const T* __restrict__ a, const T* __restrict__ b, Layout L, double* __restrict__ out) {
+  __shared__ double sd[256], sr[256];
+  double d = 0, r = 0;
+  for (long i = threadIdx.x; i < n * nk; i += 256) {
+    const long s = i / nk, k = i % nk, o = layout_base(L, s) + k * L.sk;
+    const double x = (double)a[o], y = (double)b[o], e = fabs(x - y);
+    d = fmax(d, (e == e && e <= 1.7e308) ? e : 1.7e308);
+    r = fmax(r, fabs(y) <= 1.7e308 ? fabs(y) : 0.0);
+  }
+  sd[threadIdx.x] = d; sr[threadIdx.x] = r;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { sd[threadIdx.x] = fmax(sd[threadIdx.x], sd[threadIdx.x + w]); sr[threadIdx.x] = fmax(sr[threadIdx.x], sr[threadIdx.x + w]); }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = sd[0]; out[1] = sr[0]; }
+}
+template <typename T>
+hipError_t launch_max_diff(long n, int nk, const void* a, const void* b, Layout L, double* out, hipStream_t s) {
+  hipLaunchKernelGGL((max_diff_kernel<T>), dim3(1), dim3(256), 0, s, n, nk, (const T*)a, (const T*)b, L, out);
+  return hipGetLastError();
+}
+template hipError_t launch_max_diff<double>(long, int, const void*, const void*, Layout, double*, hipStream_t);
+template hipError_t launch_max_diff<float>(long, int, const void*, const void*, Layout, double*, hipStream_t);
+
 template hipError_t launch_aba<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t, const MkFuse*);
 template hipError_t launch_aba<float>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, Layout, Layout, Layout, hipStream_t, const MkFuse*);
 template hipError_t launch_rnea<double>(const DevModel&, long, const void*, const void*, const void*, const void*, void*, void*, void*, Layout, Layout, Layout, hipStream_t, void*, void*);

@@ -312,6 +312,40 @@ def test_compiled_aba_f64_program_by_batch(rbd, oracle, models):
             assert rel(got[sl], oracle.dynamics(model, q[sl], v[sl], tau[sl], fe[sl] if wrenches else None)) <= 1e-10
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,name", [("f32", "double_pendulum"), ("f64", "inner_floating")])
+def test_first_use_check_drops_a_wrong_program(rbd, oracle, models, dtype, name, monkeypatch, capfd):
+    """The first result a workspace gets from a run-time compiled dynamics! program is compared with the interpreting one-body-per-lane kernel on the call's first
+    states (csrc/rbd_capi.hip first_use_check): a program that computes something else — here one that is wrong by construction, RBD_TUNE spec_variant=16: the
+    passes on made-up rows instead of q, v, tau — is dropped with a message; asked for by name the call fails, left to the library it is recomputed on the
+    interpreting kernels and the caller gets the right v̇.  (Round 6 met a miscompiled variant of the fp64 program in an experiment: profiles/r06_experiments.txt §8.)"""
+    model = models[name]
+    tune(monkeypatch, spec_variant=16, spec_aba_min_batch=1, state_min_batch=1)
+    B = 300
+    state, q, v, tau, fe = make(rbd, model, B, dtype, "soa", 77)
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32 if dtype == "f32" else torch.float64, layout="soa")
+    try:
+        rbd.dynamics_(result, state, dev(tau, state), None, algorithm="aba_compiled")
+        raise AssertionError("the wrong program was not caught: " + rbd.last_kernel(state))
+    except rbd._capi.RBDError as e:
+        if e.status == 3 and "differs from the interpreting kernel" not in str(e):
+            pytest.skip("hiprtc not available")
+        assert e.status == 3 and "differs from the interpreting kernel" in str(e), str(e)
+    # the library's own choice: a fresh workspace meets the same wrong program, drops it and recomputes the call
+    state2, q2, v2, tau2, _ = make(rbd, model, B, dtype, "soa", 78)
+    result2 = rbd.DynamicsResult(model, B, dtype=result.vd.dtype, layout="soa")
+    rbd.dynamics_(result2, state2, dev(tau2, state2))
+    assert rbd.sync(state2) == 0 and "aba_spec" not in rbd.last_kernel(state2), rbd.last_kernel(state2)
+    ref = oracle.dynamics(model, q2, v2, tau2)
+    assert np.abs(host(result2.vd, state2) - ref).max() <= (1e-10 if dtype == "f64" else 2e-3) * max(1.0, np.abs(ref).max())
+    assert "differs from the interpreting kernel" in capfd.readouterr().err
+    # ... and with wrenches, a program of its own (checked on its own first use)
+    rbd.dynamics_(result2, state2, dev(tau2, state2), dev(fe, state2))
+    assert "aba_spec" not in rbd.last_kernel(state2)
+    ref = oracle.dynamics(model, q2, v2, tau2, fe)
+    assert np.abs(host(result2.vd, state2) - ref).max() <= (1e-10 if dtype == "f64" else 2e-3) * max(1.0, np.abs(ref).max())
+
+
 def test_first_call_does_not_wait_for_the_compiler(rbd, models, tmp_path):
     """The library's default (RBD_JIT_ASYNC unset; the test suite otherwise runs with 0): with an EMPTY cache the first `dynamics!` on Atlas at 65 536 fp32
     states returns at once on a kernel that interprets the mechanism while hiprtc compiles `aba_spec_f32` on a background thread (csrc/rbd_jit.hip), a later
