@@ -131,7 +131,7 @@ struct rbd_ws {
   int spec_f64_stash = -1, spec_f64_stash_ratio = 170, spec_f64_stash_ratio_fext = 120, spec_ncu = 256;
   // first use of a run-time compiled dynamics! program by this workspace: its result on the first states of the call against the interpreting kernel's
   // (first_use_check; RBD_TUNE first_use_check=0 for timing experiments with programs that are wrong by construction).  [stash program][no wrenches]
-  bool spec_first_use_check = true, spec_aba_checked[4] = {false, false, false, false};
+  bool spec_first_use_check = true, spec_first_use_inject = false, spec_aba_checked[4] = {false, false, false, false}, spec_walk_checked[12] = {}, spec_bank_checked = false;
   double spec_check_err = 0;  // (what the last check measured: max |difference| / max(1, max |reference|))
   int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
@@ -1041,6 +1041,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->state_min_batch = (long)1 << 62;
   }
   w->spec_first_use_check = tune("first_use_check", 1) != 0;
+  w->spec_first_use_inject = tune("first_use_inject", 0) != 0;  // (tests: every check finds a difference — the drop-and-recompute path of each route without a wrong program)
   {
     const hipError_t e = dtype == RBD_F64 ? configure_bank_kernels<double>() : configure_bank_kernels<float>();
     if (e != hipSuccess) { g_last_hip_error = std::string("configure_bank_kernels: ") + hipGetErrorString(e); rbd_workspace_destroy(w); return RBD_ERR_HIP; }
@@ -1551,7 +1552,14 @@ static int first_use_check(rbd_ws* w, long B, const void* dq, const void* dv, co
   (void)hipFree(out);
   if (e != hipSuccess) { g_last_hip_error = std::string("first_use_check: ") + hipGetErrorString(e); (void)hipGetLastError(); return RBD_ERR_HIP; }
   w->spec_check_err = h[0] / std::max(1.0, h[1]);
-  *same = w->spec_check_err <= (w->dtype == RBD_F64 ? 1e-7 : 5e-3);
+  *same = w->spec_check_err <= (w->dtype == RBD_F64 ? 1e-7 : 5e-3) && !w->spec_first_use_inject;
+  if (!*same) {
+    char msg[320];
+    snprintf(msg, sizeof msg, "%s differs from the interpreting kernel on this call's first states by %.3g of the largest acceleration%s: the program is dropped, the kernels built with the library serve",
+             w->last_kernel, w->spec_check_err, w->spec_first_use_inject ? " (RBD_TUNE first_use_inject)" : "");
+    g_last_hip_error = msg;
+    fprintf(stderr, "[rbd] %s\n", msg);
+  }
   return RBD_OK;
 }
 
@@ -1622,11 +1630,6 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
       if (int st = first_use_check(w, B, dq, dv, dtau, df, dvd, Lq, Lv, Lf, gravity, &same)) return st;
       if (same) return RBD_OK;
       (stash_program ? (nofext ? w->spec_aba_gst_nofext : w->spec_aba_gst) : (nofext ? w->spec_aba_nofext : w->spec_aba)) = nullptr;
-      char msg[256];
-      snprintf(msg, sizeof msg, "%s differs from the interpreting kernel on this call's first states by %.3g of the largest acceleration: the program is dropped, the interpreting kernels serve",
-               w->last_kernel, w->spec_check_err);
-      g_last_hip_error = msg;
-      fprintf(stderr, "[rbd] %s\n", msg);
       if (algorithm == RBD_ALGO_ABA_COMPILED) return RBD_ERR_UNSUPPORTED;
       // (falls through: the call is recomputed below)
     }
@@ -1662,6 +1665,14 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
       void* args[] = {&Bl, (void*)&dq, (void*)&dv, (void*)&dtau, (void*)&df, (void*)&dvd, (void*)&dqd, &lq, &lv, &lf, &gx, &gy, &gz, &F};
       const long per = pair ? 128 : 64;
       HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + per - 1) / per), 1, 1, 64u * (unsigned)wm.G, 1, 1, 0, w->stream, args, nullptr));
+      // (first use of this program by this workspace: see first_use_check; a program that differs is dropped and the call recomputed on the kernel built with the library)
+      const int k = 4 * wkind + (rr ? 2 : 0) + (pair ? 1 : 0);
+      if (!mk && dv && dvd && w->spec_first_use_check && !w->spec_walk_checked[k] && !capturing(w)) {
+        w->spec_walk_checked[k] = true;
+        bool same = true;
+        if (int st = first_use_check(w, B, dq, dv, dtau, df, dvd, Lq, Lv, Lf, gravity, &same)) return st;
+        if (!same) { w->spec_walk[k] = nullptr; return run_aba(w, B, algorithm, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, gravity, fuse, mk); }
+      }
     } else if (mk) return RBD_ERR_UNSUPPORTED;
     else
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_walk<double>(wm, TP.has_floating, TP.general, 0, B, lds, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream));
@@ -1679,6 +1690,12 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
       void* args[] = {&bm, &Bl, (void*)&dq, (void*)&dv, (void*)&dtau, (void*)&df, (void*)&dvd, (void*)&dqd, &Lq, &Lv, &Lf, &F};
       HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((waves + 3) / 4), 1, 1, 256, 1, 1, 0, w->stream, args, nullptr));
       w->last_kernel = "aba_bank_kernel (compiled for the mechanism at run time)";
+      if (!fuse && dv && dvd && w->spec_first_use_check && !w->spec_bank_checked && !capturing(w)) {  // (first use: see first_use_check)
+        w->spec_bank_checked = true;
+        bool same = true;
+        if (int st = first_use_check(w, B, dq, dv, dtau, df, dvd, Lq, Lv, Lf, gravity, &same)) return st;
+        if (!same) { w->spec_bank_aba = w->spec_bank_fused = nullptr; return run_aba(w, B, algorithm, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, gravity, fuse, mk); }
+      }
     } else
     if (w->dtype == RBD_F64) HIP_TRY(launch_aba_bank<double>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));
     else HIP_TRY(launch_aba_bank<float>(bm, B, dq, dv, dtau, df, dvd, dqd, Lq, Lv, Lf, w->stream, fuse));

@@ -346,6 +346,33 @@ def test_first_use_check_drops_a_wrong_program(rbd, oracle, models, dtype, name,
     assert np.abs(host(result2.vd, state2) - ref).max() <= (1e-10 if dtype == "f64" else 2e-3) * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("route,dtype", [("aba_walk", "f64"), ("aba_walk", "f32"), ("aba_banks", "f64"), ("aba_compiled", "f32")])
+def test_first_use_check_recomputes_on_the_kernels_built_with_the_library(rbd, oracle, models, route, dtype, monkeypatch, capfd):
+    """The same check on the other run-time compiled dynamics! programs — the walk kernel and the two-bodies-per-lane kernel compiled for the mechanism — with
+    every check made to find a difference (RBD_TUNE first_use_inject=1): the program is dropped, the call recomputed on the kernel of the same lane mapping that
+    was built with the library, the caller sees the right v̇ and a message."""
+    model = models["atlas_floating"]
+    tune(monkeypatch, first_use_inject=1, walk_min_batch=1, spec_walk_min_batch=1, walk_pair_min_batch=1 << 40, bank_min_batch=1, spec_aba_min_batch=1)
+    B = 300
+    state, q, v, tau, fe = make(rbd, model, B, dtype, "aos", 79)
+    result = rbd.DynamicsResult(model, B, dtype=torch.float32 if dtype == "f32" else torch.float64, layout="aos")
+    try:
+        rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm=route)
+    except rbd._capi.RBDError as e:
+        assert route == "aba_compiled" and e.status == 3 and "first_use_inject" in str(e), str(e)  # (asked for by name: no other kernel may answer)
+        return
+    assert route != "aba_compiled"
+    k = rbd.last_kernel(state)
+    assert rbd.sync(state) == 0 and "compiled" not in k and ("walk" in k) == (route == "aba_walk"), k
+    assert "first_use_inject" in capfd.readouterr().err
+    ref = oracle.dynamics(model, q, v, tau, fe)
+    assert np.abs(host(result.vd, state) - ref).max() <= (1e-9 if dtype == "f64" else 5e-3) * max(1.0, np.abs(ref).max())
+    # the second call: no check, the kernel built with the library
+    rbd.dynamics_(result, state, dev(tau, state), dev(fe, state), algorithm=route)
+    assert "compiled" not in rbd.last_kernel(state) and capfd.readouterr().err == ""
+
+
 def test_first_call_does_not_wait_for_the_compiler(rbd, models, tmp_path):
     """The library's default (RBD_JIT_ASYNC unset; the test suite otherwise runs with 0): with an EMPTY cache the first `dynamics!` on Atlas at 65 536 fp32
     states returns at once on a kernel that interprets the mechanism while hiprtc compiles `aba_spec_f32` on a background thread (csrc/rbd_jit.hip), a later
