@@ -131,7 +131,7 @@ struct rbd_ws {
   int spec_f64_stash = -1, spec_f64_stash_ratio = 170, spec_f64_stash_ratio_fext = 120, spec_ncu = 256;
   // first use of a run-time compiled dynamics! program by this workspace: its result on the first states of the call against the interpreting kernel's
   // (first_use_check; RBD_TUNE first_use_check=0 for timing experiments with programs that are wrong by construction).  [stash program][no wrenches]
-  bool spec_first_use_check = true, spec_first_use_inject = false, spec_aba_checked[4] = {false, false, false, false}, spec_walk_checked[12] = {}, spec_bank_checked = false;
+  bool spec_first_use_check = true, spec_first_use_inject = false, spec_aba_checked[4] = {false, false, false, false}, spec_walk_checked[12] = {}, spec_bank_checked = false, spec_rnea_checked = false, spec_bank_rnea_checked = false;
   double spec_check_err = 0;  // (what the last check measured: max |difference| / max(1, max |reference|))
   int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
@@ -1430,6 +1430,45 @@ int dynamics_loops(rbd_ws* w, int32_t B, const Opts& o, const void* dq, const vo
 // inverse_dynamics! / dynamics_bias! (vdot == nullptr) through the lane mapping that fits the batch: same rule as run_aba
 static void spec_load(rbd_ws* w, int family, bool force = false);  // the kernels compiled for the mechanism (below)
 
+// The first result of a run-time compiled dynamics! program against the interpreting one-body-per-lane kernel (aba_kernel) on the first states of the same call
+// (up to 256): max |difference| <= tol max(1, max |reference|), tol 1e-7 in fp64, 5e-3 in fp32 (two fp32 evaluations in different operation orders).  One
+// allocation, two small launches and a synchronisation — once per program and workspace, on a call that has just waited for the module to load.
+static bool capturing(rbd_ws* w);
+static int first_use_check(rbd_ws* w, long B, const void* dq, const void* dv, const void* dtau, const void* df, const void* dvd, Layout Lq, Layout Lv, Layout Lf,
+                           const double* gravity, bool* same, bool inverse = false) {  // inverse: inverse_dynamics! — `dtau` is v̇ (input), `dvd` the torques (output), against rnea_kernel
+  const rbd_model* m = w->model;
+  const long n = std::min<long>(B, 256);
+  const size_t es = w->dtype == RBD_F64 ? 8 : 4;
+  const size_t elems = (size_t)(layout_base(Lv, n - 1) + (long)(m->nv - 1) * Lv.sk + 1);  // v̇'s layout, its first n states
+  void* ref = nullptr;
+  double* out = nullptr;
+  HIP_TRY(hipMalloc(&ref, elems * es));
+  if (hipMalloc((void**)&out, 2 * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ref); return RBD_ERR_OUT_OF_MEMORY; }
+  DevModel dm = w->dm;
+  if (gravity) memcpy(dm.gravity, gravity, sizeof dm.gravity);
+  double h[2] = {0, 0};
+  hipError_t e = inverse ? (w->dtype == RBD_F64 ? launch_rnea<double>(dm, n, dq, dv, dtau, df, ref, nullptr, nullptr, Lq, Lv, Lf, w->stream)
+                                                : launch_rnea<float>(dm, n, dq, dv, dtau, df, ref, nullptr, nullptr, Lq, Lv, Lf, w->stream))
+                 : w->dtype == RBD_F64 ? launch_aba<double>(dm, n, dq, dv, dtau, df, ref, nullptr, Lq, Lv, Lf, w->stream)
+                                       : launch_aba<float>(dm, n, dq, dv, dtau, df, ref, nullptr, Lq, Lv, Lf, w->stream);
+  if (e == hipSuccess) e = w->dtype == RBD_F64 ? launch_max_diff<double>(n, m->nv, dvd, ref, Lv, out, w->stream) : launch_max_diff<float>(n, m->nv, dvd, ref, Lv, out, w->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h, out, sizeof h, hipMemcpyDeviceToHost, w->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+  (void)hipFree(ref);
+  (void)hipFree(out);
+  if (e != hipSuccess) { g_last_hip_error = std::string("first_use_check: ") + hipGetErrorString(e); (void)hipGetLastError(); return RBD_ERR_HIP; }
+  w->spec_check_err = h[0] / std::max(1.0, h[1]);
+  *same = w->spec_check_err <= (w->dtype == RBD_F64 ? 1e-7 : 5e-3) && !w->spec_first_use_inject;
+  if (!*same) {
+    char msg[320];
+    snprintf(msg, sizeof msg, "%s differs from the interpreting kernel on this call's first states by %.3g of the largest %s%s: the program is dropped, the kernels built with the library serve",
+             w->last_kernel, w->spec_check_err, inverse ? "torque" : "acceleration", w->spec_first_use_inject ? " (RBD_TUNE first_use_inject)" : "");
+    g_last_hip_error = msg;
+    fprintf(stderr, "[rbd] %s\n", msg);
+  }
+  return RBD_OK;
+}
+
 static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const void* dv, const void* dvd, const void* df, void* dtau, void* dqd,
                     Layout Lq, Layout Lv, Layout Lf, void* dacc = nullptr, void* djw = nullptr) {
   const rbd_model* m = w->model;
@@ -1474,6 +1513,15 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
       w->last_kernel = w->dtype == RBD_F64 ? "rnea_spec_f64 (compiled for the mechanism at run time)"
                        : staged            ? "rnea_spec_f32 (compiled for the mechanism at run time) + rows_to_state_major_kernel"
                                            : "rnea_spec_f32 (compiled for the mechanism at run time)";
+      if (dvd && dtau && w->spec_first_use_check && !w->spec_rnea_checked && !capturing(w)) {  // (first use of this program by this workspace: first_use_check)
+        w->spec_rnea_checked = true;
+        bool same = true;
+        if (int st = first_use_check(w, B, dq, dv, dvd, df, dtau, Lq, Lv, Lf, nullptr, &same, true)) return st;
+        if (!same) {
+          w->spec_rnea = nullptr;
+          return mapping == RBD_ALGO_ABA_COMPILED ? RBD_ERR_UNSUPPORTED : run_rnea(w, B, mapping, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, dacc, djw);
+        }
+      }
       return RBD_OK;
     }
   }
@@ -1489,6 +1537,13 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
       const long per = pair ? 128 : 64;
       HIP_TRY(hipModuleLaunchKernel(f, (unsigned)((B + per - 1) / per), 1, 1, 64u * (unsigned)w->wm.G, 1, 1, 0, w->stream, args, nullptr));
       w->last_kernel = pair ? "rnea_walk_spec (compiled for the mechanism, two fp32 states per lane)" : "rnea_walk_spec (compiled for the mechanism)";
+      const int k = 4 + (pair ? 1 : 0);
+      if (dvd && dtau && w->spec_first_use_check && !w->spec_walk_checked[k] && !capturing(w)) {
+        w->spec_walk_checked[k] = true;
+        bool same = true;
+        if (int st = first_use_check(w, B, dq, dv, dvd, df, dtau, Lq, Lv, Lf, nullptr, &same, true)) return st;
+        if (!same) { w->spec_walk[k] = nullptr; return run_rnea(w, B, mapping, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, dacc, djw); }
+      }
       return RBD_OK;
     }
     w->last_kernel = pair ? "rnea_walk_kernel (two fp32 states per lane)" : "rnea_walk_kernel";
@@ -1509,6 +1564,12 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
       void* args[] = {&bm, &Bl, &nc, (void*)&dq, (void*)&dv, (void*)&dvd, (void*)&df, (void*)&dtau, (void*)&dqd, &Lq, &Lv, &Lf, (void*)&dacc, (void*)&djw};
       HIP_TRY(hipModuleLaunchKernel(w->spec_bank_rnea, (unsigned)((waves + 3) / 4), 1, 1, 256, 1, 1, 0, w->stream, args, nullptr));
       w->last_kernel = "rnea_bank_kernel (compiled for the mechanism at run time)";
+      if (dvd && dtau && w->spec_first_use_check && !w->spec_bank_rnea_checked && !capturing(w)) {
+        w->spec_bank_rnea_checked = true;
+        bool same = true;
+        if (int st = first_use_check(w, B, dq, dv, dvd, df, dtau, Lq, Lv, Lf, nullptr, &same, true)) return st;
+        if (!same) { w->spec_bank_rnea = nullptr; return run_rnea(w, B, mapping, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, dacc, djw); }
+      }
     } else
     if (w->dtype == RBD_F64) HIP_TRY(launch_rnea_bank<double>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
     else HIP_TRY(launch_rnea_bank<float>(w->bm, B, ncol, dq, dv, dvd, df, dtau, dqd, Lq, Lv, Lf, w->stream, dacc, djw));
@@ -1526,43 +1587,6 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
 static const MkStage kNoStage{-1, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
 // `mk` (simulate_core): the launch is a stage of a Munthe-Kaas step folded into a kernel compiled for the mechanism (rbd_mk_fuse.hpp) — only those kernels take it:
 // RBD_ERR_UNSUPPORTED when the batch would go to another kernel (the caller then keeps the stage in its own launches)
-// The first result of a run-time compiled dynamics! program against the interpreting one-body-per-lane kernel (aba_kernel) on the first states of the same call
-// (up to 256): max |difference| <= tol max(1, max |reference|), tol 1e-7 in fp64, 5e-3 in fp32 (two fp32 evaluations in different operation orders).  One
-// allocation, two small launches and a synchronisation — once per program and workspace, on a call that has just waited for the module to load.
-static bool capturing(rbd_ws* w);
-static int first_use_check(rbd_ws* w, long B, const void* dq, const void* dv, const void* dtau, const void* df, const void* dvd, Layout Lq, Layout Lv, Layout Lf,
-                           const double* gravity, bool* same) {
-  const rbd_model* m = w->model;
-  const long n = std::min<long>(B, 256);
-  const size_t es = w->dtype == RBD_F64 ? 8 : 4;
-  const size_t elems = (size_t)(layout_base(Lv, n - 1) + (long)(m->nv - 1) * Lv.sk + 1);  // v̇'s layout, its first n states
-  void* ref = nullptr;
-  double* out = nullptr;
-  HIP_TRY(hipMalloc(&ref, elems * es));
-  if (hipMalloc((void**)&out, 2 * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ref); return RBD_ERR_OUT_OF_MEMORY; }
-  DevModel dm = w->dm;
-  if (gravity) memcpy(dm.gravity, gravity, sizeof dm.gravity);
-  double h[2] = {0, 0};
-  hipError_t e = w->dtype == RBD_F64 ? launch_aba<double>(dm, n, dq, dv, dtau, df, ref, nullptr, Lq, Lv, Lf, w->stream)
-                                     : launch_aba<float>(dm, n, dq, dv, dtau, df, ref, nullptr, Lq, Lv, Lf, w->stream);
-  if (e == hipSuccess) e = w->dtype == RBD_F64 ? launch_max_diff<double>(n, m->nv, dvd, ref, Lv, out, w->stream) : launch_max_diff<float>(n, m->nv, dvd, ref, Lv, out, w->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(h, out, sizeof h, hipMemcpyDeviceToHost, w->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
-  (void)hipFree(ref);
-  (void)hipFree(out);
-  if (e != hipSuccess) { g_last_hip_error = std::string("first_use_check: ") + hipGetErrorString(e); (void)hipGetLastError(); return RBD_ERR_HIP; }
-  w->spec_check_err = h[0] / std::max(1.0, h[1]);
-  *same = w->spec_check_err <= (w->dtype == RBD_F64 ? 1e-7 : 5e-3) && !w->spec_first_use_inject;
-  if (!*same) {
-    char msg[320];
-    snprintf(msg, sizeof msg, "%s differs from the interpreting kernel on this call's first states by %.3g of the largest acceleration%s: the program is dropped, the kernels built with the library serve",
-             w->last_kernel, w->spec_check_err, w->spec_first_use_inject ? " (RBD_TUNE first_use_inject)" : "");
-    g_last_hip_error = msg;
-    fprintf(stderr, "[rbd] %s\n", msg);
-  }
-  return RBD_OK;
-}
-
 static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const void* dv, const void* dtau, const void* df, void* dvd, void* dqd,
                    Layout Lq, Layout Lv, Layout Lf, const double* gravity, const MkFuse* fuse, const MkStage* mk = nullptr) {
   const rbd_model* m = w->model;

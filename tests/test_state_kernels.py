@@ -373,6 +373,33 @@ def test_first_use_check_recomputes_on_the_kernels_built_with_the_library(rbd, o
     assert "compiled" not in rbd.last_kernel(state) and capfd.readouterr().err == ""
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mapping,dtype", [("walk", "f64"), ("banks", "f64"), ("auto", "f32"), ("compiled", "f32")])
+def test_first_use_check_of_the_inverse_dynamics_programs(rbd, oracle, models, mapping, dtype, monkeypatch, capfd):
+    """... and on the run-time compiled inverse_dynamics! programs (rnea_spec_*, rnea_walk_spec_*, rnea_bank_spec_*) against rnea_kernel: every check made to
+    find a difference (RBD_TUNE first_use_inject=1) — dropped, recomputed on the kernel built with the library, right torques, a message."""
+    model = models["atlas_floating"]
+    tune(monkeypatch, first_use_inject=1, walk_min_batch=1, spec_walk_min_batch=1, rnea_walk_min_batch=1, walk_pair_min_batch=1 << 40, bank_min_batch=1,
+         spec_rnea_min_batch=1, state_min_batch=1)
+    B = 300
+    state, q, v, tau, fe = make(rbd, model, B, dtype, "soa", 80)
+    vd = np.random.default_rng(81).standard_normal((B, model.nv))
+    out = torch.zeros_like(state.v)
+    try:
+        rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state), mapping=mapping)
+    except rbd._capi.RBDError as e:
+        assert mapping == "compiled" and e.status == 3 and "first_use_inject" in str(e), str(e)
+        return
+    assert mapping != "compiled"
+    k = rbd.last_kernel(state)
+    assert rbd.sync(state) == 0 and "compiled" not in k, k
+    assert "first_use_inject" in capfd.readouterr().err
+    ref = oracle.inverse_dynamics(model, q, v, vd, fe)
+    assert np.abs(host(out, state) - ref).max() <= (1e-10 if dtype == "f64" else 2e-4) * max(1.0, np.abs(ref).max())
+    rbd.inverse_dynamics_(out, state, dev(vd, state), dev(fe, state), mapping=mapping)
+    assert "compiled" not in rbd.last_kernel(state) and capfd.readouterr().err == ""
+
+
 def test_first_call_does_not_wait_for_the_compiler(rbd, models, tmp_path):
     """The library's default (RBD_JIT_ASYNC unset; the test suite otherwise runs with 0): with an EMPTY cache the first `dynamics!` on Atlas at 65 536 fp32
     states returns at once on a kernel that interprets the mechanism while hiprtc compiles `aba_spec_f32` on a background thread (csrc/rbd_jit.hip), a later
