@@ -259,8 +259,9 @@ int rbd_dynamics_bias_bodies(rbd_ws_t* ws, int32_t B, const void* q, const void*
 /* M_out: nv×nv column-major per state (element (i,j) of state b at
  * M[(j*nv+i)*B + b] for SOA, M[b*nv*nv + j*nv + i] for AOS). Like the
  * reference (Symmetric, uplo 'L') the LOWER triangle i>=j is the result; the strict upper triangle is not to
- * be read (the reference leaves it undefined; most paths do not touch it, the large-batch fp32 path of
- * rbd_mass_matrix_solve writes the mirror image there because whole cache lines leave the chip faster). */
+ * be read (the reference leaves it undefined; most paths do not touch it, the fp32 path of
+ * rbd_mass_matrix_solve on the kernels compiled for the mechanism — column-per-state callers, from 256 states since 600 (32 768 before: it is ahead at
+ * every batch) — writes the mirror image there because whole cache lines leave the chip faster). */
 int rbd_mass_matrix(rbd_ws_t* ws, int32_t B, const void* q, void* M_out, const rbd_opts_t* opts);
 
 /* x = M(q)^-1 rhs; rhs, x: nv×B.  opts->algorithm == RBD_ALGO_CRBA_CHOLESKY: CRBA + batched lower Cholesky, the potrf/potrs

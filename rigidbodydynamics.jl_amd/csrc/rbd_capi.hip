@@ -143,7 +143,7 @@ struct rbd_ws {
   std::vector<double> loop_gains; bool custom_gains = false;  // rbd_workspace_set_loop_gains: this workspace's Baumgarte gains (4 per loop joint), and whether they differ from the model's
   void* bound_M = nullptr; void* bound_c = nullptr;  // rbd_workspace_bind_result: the caller's own M / c buffers for the CRBA route of rbd_dynamics
   long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0, walk_one_round_batch = 0, rnea_walk_min_batch = 0;
-  StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0; long spec_aba_fused_min_batch = (long)1 << 62; long sim_walk_max_batch = 0; bool state_aot = false;  // state_aot: the interpreting one-lane-per-state kernels take the mechanism
+  StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0; long mass_min_batch = (long)1 << 62, mass_solve_min_batch = (long)1 << 62; long spec_aba_fused_min_batch = (long)1 << 62; long sim_walk_max_batch = 0; bool state_aot = false;  // state_aot: the interpreting one-lane-per-state kernels take the mechanism
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
   long bank_min_batch = 0, bank_resident_states = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
@@ -1002,6 +1002,14 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
     w->state_min_batch = (long)ncu * 4 * 64 / 2;
     { bool has; const long t = tune("state_min_batch", 0, &has); if (has) w->state_min_batch = t; }
+    // fp32 mass_matrix! + Cholesky solve on the two kernels compiled for the mechanism (crba_spec_perm + chol_spec): ahead of the one-body-per-lane kernels at
+    // EVERY batch measured — Atlas: 256 states 28.1 against 40.4 us, 4096: 31.1 against 44.8, 16 384: 46.1 against 117, 24 576: 58.2 against 161; without M
+    // 22 - 33 us, the packed triangle 31 - 51 against 44 - 171 (round 6, scripts/exp_mass_small.sh; until then they waited for state_min_batch = 32 768).
+    // mass_matrix! alone (crba_spec_perm + emit_spec): 1024 states 31.2 against 19.0 us, 4096: 33.7 against 21.5, 16 384: 42.4 against 53.1 — from 10 241.
+    // fp64 (crba_spec + emit_spec + the dense Cholesky kernel): 4096 states 94 against 54 us, 16 384: 179 against 183 — stays at state_min_batch.
+    w->mass_min_batch = w->mass_solve_min_batch = w->state_min_batch;
+    if (dtype == RBD_F32) { w->mass_min_batch = std::min<long>(w->state_min_batch, (long)ncu * 40 + 1); w->mass_solve_min_batch = std::min<long>(w->state_min_batch, 256); }
+    { bool has; const long t = tune("mass_min_batch", 0, &has); if (has) w->mass_min_batch = w->mass_solve_min_batch = t; }
     // the kernels compiled for the mechanism (spec_load): a wavefront of 64 states per SIMD — one round of them takes the same time from one wavefront to a
     // chip-full, and beats the walk kernel's rounds of half as many states from the second of those on.  Known here, before anything is compiled, so that a
     // small batch never starts (or waits for) a compilation it would not use
@@ -1026,6 +1034,7 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     // dynamics 33 (two bodies per lane) against 31.5, fp64 44 against 32
     w->state_min_batch = (long)ncu * 32;
     { bool has; const long t = tune("state_min_batch", 0, &has); if (has) w->state_min_batch = t; }
+    w->mass_min_batch = w->mass_solve_min_batch = tune("mass_min_batch", w->state_min_batch);
     w->spec_aba_min_batch = (long)ncu * 32 + 1;
     w->spec_rnea_min_batch = (long)ncu * 64;
     { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = t; }
@@ -1855,7 +1864,7 @@ static int run_crba(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, 
     else HIP_TRY(launch_big_crba<float>(w->big, B, dq, dM, w->d_big_scratch, Lq, Lm, w->stream));
     return RBD_OK;
   }
-  if (B >= w->state_min_batch && layout == RBD_LAYOUT_AOS && Lm.sk == 1 && ((Lm.sb * (long)esize(w)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0 &&
+  if (B >= w->mass_min_batch && layout == RBD_LAYOUT_AOS && Lm.sk == 1 && ((Lm.sb * (long)esize(w)) & 15) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0 &&
       esize(w) * (size_t)w->model->nv * w->model->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) &&
       (spec_load(w, SPEC_MASS), w->spec_emit != nullptr && spec_crba_fits(w) && (w->dtype == RBD_F32 ? w->spec_crba_perm : w->spec_crba) != nullptr)) {
     // one lane per state into the staging buffer, then whole cache lines of the caller's column-per-state M (the full square: emit_spec, rbd_spec.hpp);
@@ -1900,7 +1909,7 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
     else HIP_TRY(launch_big_chol_solve<float>(m->nv, B, dM, w->d_big_L, dtau, dc, dx, Lm, Lv, w->d_notpd, w->stream));
     return RBD_OK;
   }
-  const bool state = B >= w->state_min_batch;
+  const bool state = B >= w->mass_solve_min_batch;  // (below state_min_batch: only with both kernels compiled for the mechanism — spec_route)
   if (state && layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv)) {
     spec_load(w, SPEC_MASS);
     const bool mcopy_ok = !dM || (Lm.sk == 1 && (Lm.sb & 3) == 0 && (reinterpret_cast<uintptr_t>(dM) & 15) == 0);
@@ -1909,6 +1918,7 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
     // again with its size could answer differently — 4 GB and more — and leave a mechanism the interpreting kernel does not take without any kernel)
     hipFunction_t const spec = spec_route ? nullptr : spec_crba(w, es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15));
     if (!spec_route && !w->state_aot && !spec) goto lanes;  // (a mechanism only the compiled kernels take, and they are not there)
+    if (!spec_route && B < w->state_min_batch) goto lanes;
     if ((st = stage_m(w, B, spec_route))) return st;
     const Layout Ls{16, -(long)m->nv * m->nv};  // grouped by 16 states = one wavefront of the tile Cholesky (layout_base, rbd_device.hpp)
     if (spec_route) {
@@ -2108,7 +2118,7 @@ int rbd_mass_matrix_solve(rbd_ws_t* w, int32_t B, const void* q, const void* rhs
   // reads the staged triangle, and the whole-square store is 340 MB of the route's ~560 MB at 65 536 Atlas states; the other routes factor M in
   // place and need a buffer of their own
   const bool crba_route = o.algorithm == RBD_ALGO_CRBA_CHOLESKY || m->big;
-  const bool state_route = !m->big && B >= w->state_min_batch && o.layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv);
+  const bool state_route = !m->big && B >= w->mass_solve_min_batch && o.layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv);
   if (!dM && crba_route && !state_route) {
     if ((st = ensure(&w->d_M, &w->d_M_bytes, mbytes))) return st;
     dM = w->d_M;
@@ -2154,7 +2164,7 @@ int rbd_mass_matrix_solve_packed(rbd_ws_t* w, int32_t B, const void* q, const vo
       return st;
   }
   const Layout Lq = layout_of(o.layout, m->nq, B), Lv = layout_of(o.layout, m->nv, B), Lm = layout_of(o.layout, (long)m->nv * m->nv, B), Lp = layout_of(o.layout, np, B);
-  const bool fast = !m->big && m->nv > 0 && B >= w->state_min_batch && o.layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv) &&
+  const bool fast = !m->big && m->nv > 0 && B >= w->mass_solve_min_batch && o.layout == RBD_LAYOUT_AOS && chol_copies_m((int)es, m->nv) &&
                     (spec_load(w, SPEC_MASS), w->spec_chol_packed != nullptr && w->spec_crba_perm != nullptr) && spec_crba_fits(w) &&
                     es * (size_t)m->nv * m->nv * (((size_t)B + 15) & ~(size_t)15) < ((size_t)1 << 32) &&
                     (reinterpret_cast<uintptr_t>(dP) & 15) == 0;  // (the triangle leaves in 16-byte pieces)

@@ -93,6 +93,37 @@ def test_state_kernels_f32_solve(rbd, oracle, models, name, layout, states_every
     assert eta.max() <= 2e-5, eta.max()
 
 
+@pytest.mark.gpu
+def test_mass_matrix_solve_f32_takes_the_compiled_kernels_from_small_batches(rbd, oracle, models):
+    """Round 6: fp32 `mass_matrix!` + Cholesky solve (BASELINE configs[2]'s call) runs on the two kernels compiled for the mechanism from 256 states on — measured
+    ahead of the one-body-per-lane kernels at every batch (scripts/exp_mass_small.sh: 256 states 28 against 40 us, 16 384: 46 against 117) — instead of from
+    32 768; `mass_matrix!` alone from 10 241.  No RBD_TUNE here: the library's own thresholds."""
+    model = models["atlas_floating"]
+    nv = model.nv
+    for B, compiled in ((200, False), (300, True)):
+        state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 47)
+        x = torch.zeros_like(state.v)
+        Mout = torch.full((B, nv * nv), float("nan"), dtype=torch.float32, device="cuda")
+        try:
+            rbd.mass_matrix_solve_(x, state, dev(tau, state), Mout)
+        except rbd._capi.RBDError as e:
+            if e.status == 3:
+                pytest.skip("hiprtc not available")
+            raise
+        k = rbd.last_kernel(state)
+        if compiled and "chol_spec" not in k and not rbd.jit_precompile(models["double_pendulum"], torch.float32)[0]:
+            pytest.skip("hiprtc not available")
+        assert rbd.sync(state) == 0 and ("chol_spec_f32" in k) == compiled, (B, k)
+        Mr = oracle.mass_matrix(model, q)
+        got = host(Mout, state).reshape(B, nv, nv).transpose(0, 2, 1)
+        il = np.tril_indices(nv)
+        assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= 2e-6 * np.abs(Mr).max()
+        Ms, xg = sym(Mr), host(x, state)
+        res = np.einsum("bij,bj->bi", Ms, xg) - tau
+        eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau, axis=1))
+        assert eta.max() <= 1e-5, eta.max()
+
+
 def test_state_kernels_random_trees(rbd, oracle, states_everywhere):
     """Random revolute / prismatic / fixed / sin-cos trees, with and without a 6-dof root, up to the 12 tree levels the kernels keep in registers."""
     from test_chain_plan import random_tree
