@@ -120,7 +120,7 @@ struct rbd_ws {
   TrackModel tm{}; void* d_track_ri = nullptr; void* d_track_rr = nullptr;  // the track plan's records: what the walk kernels read
   ContactModel ctm{}; void* d_cp_body = nullptr; void* d_cp_r = nullptr; void* d_hs_r = nullptr;  // soft contact tables
   void* d_tw = nullptr; void* d_cw = nullptr; void* d_s0 = nullptr; void* d_sacc = nullptr; void* d_sdot = nullptr; void* d_rows = nullptr; size_t d_rows_bytes = 0, d_tw_bytes = 0, d_cw_bytes = 0, d_s0_bytes = 0, d_sacc_bytes = 0, d_sdot_bytes = 0;
-  WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0;
+  WalkModel wm{}; void* d_walk_wk = nullptr; size_t walk_lds_bytes = 0, walk_lds_bytes_pair = 0; long walk_min_batch = 0, walk_pair_min_batch = 0, sim_walk_min_batch = 1;
   // run-time specialised kernels (rbd_jit.hip), built on the first use of a route that has them; null: not available
   bool spec_tried[SPEC_SLOTS] = {false, false, false, false}; hipModule_t spec_mod[SPEC_SLOTS] = {nullptr, nullptr, nullptr, nullptr};  // (by spec_slot(family))
   hipFunction_t spec_kin = nullptr, spec_jac = nullptr, spec_mom = nullptr, spec_energy = nullptr, spec_com = nullptr; long spec_kin_min_batch = (long)1 << 62;  // the kinematics by-products compiled for the mechanism (SPEC_KIN, round 6)
@@ -1014,11 +1014,15 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     // chip-full, and beats the walk kernel's rounds of half as many states from the second of those on.  Known here, before anything is compiled, so that a
     // small batch never starts (or waits for) a compilation it would not use
     w->spec_aba_min_batch = w->spec_rnea_min_batch = (long)ncu * 4 * 64 / 2 + 1;
+    // (fp64 inverse_dynamics!: the walk kernel's rounds of 16 384 states stay ahead of rnea_spec_f64 until the fourth — Atlas, 49 152 states 58.5 against 66.1 us,
+    //  65 536: 77.1 against 75.7; scripts/sweep_routes.py)
+    if (dtype == RBD_F64 && m->track.ok && m->walk.ok && w->walk_lds_bytes > 0) w->spec_rnea_min_batch = (long)ncu * 240 + 1;
     w->spec_aba_fused_min_batch = (long)ncu * 80;  // (`simulate`: run_aba)
     // `simulate` in fp32: as long as the batch is ONE round of the walk kernel with two states per lane (128 states per workgroup, one workgroup per CU), the four
     // stages of a step in one launch of it beat four launches of the lane-per-state kernel (Atlas, 32 768 states: 128 against 150 us per step; 40 960 — a second
     // round — 237 against 161)
     w->sim_walk_max_batch = tune("sim_walk_max_batch", (long)ncu * 128);
+    w->sim_walk_min_batch = tune("sim_walk_min_batch", 1);  // (`simulate` on the looped walk program from this batch on when it is compiled: simulate_core)
     { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = w->spec_aba_fused_min_batch = t; }
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
     // the kinematics by-products one lane per state (kin_spec / jac_spec / mom_spec): from an eighth of a chip-full of wavefronts on — a round of them takes the
@@ -1689,7 +1693,7 @@ static int run_aba(rbd_ws* w, int32_t B, int algorithm, const void* dq, const vo
     const TrackPlan& TP = rr ? m->rrs.track : m->track;
     const size_t lds = rr ? (pair ? w->walk_rr_lds_bytes_pair : w->walk_rr_lds_bytes) : (pair ? w->walk_lds_bytes_pair : w->walk_lds_bytes);
     const int wkind = (mk && mk->stage == 4) ? 2 : 0;  // (all four stages of a `simulate` step in one launch: the instantiation with the passes inside a loop)
-    if (hipFunction_t f = ((w->dtype == RBD_F64 || w->spec_walk_f32) && B >= w->spec_walk_min_batch) ? spec_walk(w, rr, wkind, pair) : nullptr) {  // the same kernel compiled for this mechanism
+    if (hipFunction_t f = ((w->dtype == RBD_F64 || w->spec_walk_f32) && (B >= w->spec_walk_min_batch || wkind == 2)) ? spec_walk(w, rr, wkind, pair) : nullptr) {  // the same kernel compiled for this mechanism
       w->last_kernel = pair ? "aba_walk_spec (compiled for the mechanism, two fp32 states per lane)" : "aba_walk_spec (compiled for the mechanism)";
       long Bl = B;
       Layout lq = Lq, lv = Lv, lf = Lf;
@@ -2287,7 +2291,14 @@ static int simulate_core(rbd_ws_t* w, int32_t B, void* q, void* v, const rbd_con
   const bool pd = ctl.kind == RBD_CONTROL_PD;
   // large batches: the walk kernel (one wavefront per track, §3.4 of DESIGN.md) with the stage bookkeeping in its own launches beats the
   // lane-per-body kernels with the stage fused in (fp64 Atlas, 65 536 states: 4 x 147 us + 5 stage launches vs 4 x 290 us)
-  const bool walk_sim = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && m->track.ok && m->walk.ok && w->walk_lds_bytes > 0 && B >= w->walk_min_batch;
+  const bool can_walk_sim = (m->nloops == 0) && (o.algorithm == RBD_ALGO_ABA) && m->track.ok && m->walk.ok && w->walk_lds_bytes > 0;
+  bool walk_sim = can_walk_sim && B >= w->walk_min_batch;
+  // ... and at EVERY smaller batch when the walk program compiled for the mechanism with the four stages in a loop is there: one launch per step whose time does
+  // not depend on the batch up to 16 384 states — Atlas, us per step against the banked kernel with the stage fused in (four launches): fp64 256 states 102.8 / 115.3,
+  // 2048: 103.6 / 107.8, 4096: 104.6 / 109.9; fp32 256: 81.1 / 99.9, 4096: 82.3 / 93.8, 8192: 84.6 / 120.7 (round 6; until then from walk_min_batch = 4097 / 8193)
+  if (!walk_sim && can_walk_sim && B >= w->sim_walk_min_batch && (w->dtype == RBD_F64 || w->spec_walk_f32) &&
+      tune("sim_fuse", 1) != 0 && tune("sim_one_launch", 1) != 0 && !(w->dtype == RBD_F32 && w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch))
+    walk_sim = spec_walk(w, w->walk_rr && !w->no_reroot && w->walk_rr_lds_bytes > 0, 2, 0) != nullptr;
   const Layout Lf = layout_of(o.layout, 6L * m->nb, B);
   // ... and when the batch goes to a kernel COMPILED for the mechanism (aba_walk_spec, aba_spec_f32), the stage is folded into that launch (rbd_mk_fuse.hpp):
   // four launches per step and nothing else.  The first launch decides: a kernel that takes the stage runs it, any other returns RBD_ERR_UNSUPPORTED untouched.
