@@ -670,7 +670,10 @@ def kin_leg(env, B, dtype, steps=40, warm=8, model_name="atlas_floating"):
     the oracle.  Algorithmic bytes: the inputs each call reads plus the outputs it writes."""
     np, torch, device = env["np"], env["torch"], env["device"]
     rbd, _capi, oracle = env["rbd"], env["_capi"], env["oracle"]
-    model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", model_name + ".json"))
+    if model_name.startswith("randmech"):  # the reference's own test mechanism, seed = the suffix (as in run())
+        model = rbd.flatten(rbd.randmech(np.random.default_rng(int(model_name[8:] or 1))))
+    else:
+        model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", model_name + ".json"))
     tdt = torch.float64 if dtype == "f64" else torch.float32
     es = 8 if dtype == "f64" else 4
     rng = np.random.default_rng(11)

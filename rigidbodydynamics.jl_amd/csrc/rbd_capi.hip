@@ -145,7 +145,7 @@ struct rbd_ws {
   long spec_aba_min_batch = 0, spec_rnea_min_batch = 0, spec_walk_min_batch = 0, walk_one_round_batch = 0, rnea_walk_min_batch = 0;
   StateModel sm{}; void* d_state_ops = nullptr; void* d_state_cols = nullptr; void* d_state_sr = nullptr; long state_min_batch = 0; long mass_min_batch = (long)1 << 62, mass_solve_min_batch = (long)1 << 62; long spec_aba_fused_min_batch = (long)1 << 62; long sim_walk_max_batch = 0; bool state_aot = false;  // state_aot: the interpreting one-lane-per-state kernels take the mechanism
   void* d_Msoa = nullptr; size_t d_Msoa_bytes = 0; long Msoa_B = -1; int Msoa_perm = -1;  // batch-innermost staging of M for the one-lane-per-state CRBA when the caller's layout is AOS
-  long bank_min_batch = 0, bank_resident_states = 0;
+  long bank_min_batch = 0, rnea_bank_min_batch = 0, bank_resident_states = 0;
   void* d_ib = nullptr; void* d_rb = nullptr; void* d_nslots = nullptr; void* d_dof_body = nullptr; void* d_anc = nullptr; void* d_row_mask = nullptr;
   // staging for RBD_MEM_HOST (lazy)
   void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -873,7 +873,16 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     // Two bodies per lane wherever the mechanism is in its scope: since round 3 it is ahead of one body per lane at every batch size
     // (profiles/r03_mapping_sweep.txt: 18.8 vs 21.0 us at 512 Atlas states, 19.1 vs 30.1 at 4096).  RBD_BANK_MIN_BATCH: tests.
     w->bank_min_batch = 0;
-    { bool has; const long t = tune("bank_min_batch", 0, &has); if (has) w->bank_min_batch = t; }
+    // ... except inverse dynamics of mechanisms with 3-dof joints (three columns per body in the banked kernel): one body per lane is ahead up to ≈ 7000 states —
+    // fp64, 1024 / 4096 states: randmech() seeds 1-3 12.3-12.6 / 15.6-16.3 us against 16.8-18.8 / 17.6-19.8, mixed20 11.3 / 11.2 against 14.8 / 13.7; at 8192 the
+    // banked kernel leads again (22.7-26.1 against 26.5-27.2) (round 6, scripts/sweep_routes.py)
+    w->rnea_bank_min_batch = 0;
+    {
+      int ncu = 256;
+      (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+      if (m->has3dof) w->rnea_bank_min_batch = (long)ncu * 28 + 1;  // (6000 states: 19.9 / 12.3 against 23.7 / 13.9)
+    }
+    { bool has; const long t = tune("bank_min_batch", 0, &has); if (has) w->bank_min_batch = w->rnea_bank_min_batch = t; }
     // ... up to the batch whose workgroups (256 lanes) are all resident at once: per compute unit as many as the LDS columns allow
     // (park + exchange pairs: 120 KB in fp64 -> one, 60 KB in fp32 -> two), at most the two the register budget allows
     {
@@ -1039,11 +1048,13 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     w->state_min_batch = (long)ncu * 32;
     { bool has; const long t = tune("state_min_batch", 0, &has); if (has) w->state_min_batch = t; }
     w->mass_min_batch = w->mass_solve_min_batch = tune("mass_min_batch", w->state_min_batch);
-    w->spec_aba_min_batch = (long)ncu * 32 + 1;
-    w->spec_rnea_min_batch = (long)ncu * 64;
+    // (round 6, scripts/sweep_routes.py, randmech(): fp64 4096 states 47.6 one body per lane against 47.8 compiled, 8192: 91.7 against 48.0 — from 4097; fp32 4096:
+    //  26.8 against 34.1, 8192: 50.1 against 34.3 — from 5377.  Until then both waited for 8193)
+    w->spec_aba_min_batch = (long)ncu * (dtype == RBD_F64 ? 16 : 21) + 1;
+    w->spec_rnea_min_batch = (long)ncu * (dtype == RBD_F64 ? 40 : 52);  // (randmech(), fp64: 8192 states 26.6 lane-per-body against 31.2 compiled, 16 384: 45.6 against 32.1; fp32 18.5 / 26.8 and 32.7 / 27.5)
     { bool has; const long t = tune("spec_aba_min_batch", 0, &has); if (has) w->spec_aba_min_batch = t; }
     { bool has; const long t = tune("spec_rnea_min_batch", 0, &has); if (has) w->spec_rnea_min_batch = t; }
-    w->spec_kin_min_batch = tune("spec_kin_min_batch", (long)ncu * 64);
+    w->spec_kin_min_batch = tune("spec_kin_min_batch", (long)ncu * 32 + 1);  // (randmech(), the set of three calls: fp64 8192 states 79.6 compiled against 86.6, 12 288: 88.7 against 110; fp32 63.3 / 67.2 and 72.1 / 91.6)
     w->spec_f64_max_scratch = (int)tune("spec_f64_max_scratch", 2048);
     // randmech() (25 bodies, nv 39), one round: 50 us with every row in LDS, 85 us with the stash (with a wrench on every body: 98 and 112) — see run_aba
     w->spec_f64_stash = (int)tune("spec_f64_stash", -1);
@@ -1494,7 +1505,7 @@ static int run_rnea(rbd_ws* w, int32_t B, int mapping, const void* dq, const voi
   }
   if (mapping == RBD_ALGO_ABA_BANKS && m->bank_lps == 0) return RBD_ERR_UNSUPPORTED;
   // the per-body outputs (accelerations, joint wrenches) are written by the lane-per-body kernels (one or two bodies per lane)
-  const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->bank_min_batch));
+  const bool banks = m->bank_lps > 0 && (mapping == RBD_ALGO_ABA_BANKS || (mapping != RBD_ALGO_ABA_LANES && B >= w->rnea_bank_min_batch));
   const bool can_walk = m->track.ok && m->walk.ok && (w->walk_lds_bytes > 0 || (w->walk_lds_bytes_pair > 0 && B >= w->walk_pair_min_batch));
   if (mapping == RBD_ALGO_ABA_WALK && !can_walk) return RBD_ERR_UNSUPPORTED;
   // the kernel compiled for the mechanism: large batches (q̇ is not one of its outputs).  Per-body outputs: a lane storing its own state-major row writes

@@ -11,13 +11,17 @@ import rbd_amd as rbd
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="atlas_floating"); ap.add_argument("--dtype", default="f64")
 ap.add_argument("--batches", default="256,512,1024,2048,4096,8192,12288,16384,24576,32768,49152,65536")
-ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--reps", type=int, default=30); ap.add_argument("--op", default="both", help="dynamics | inverse | both")
 args = ap.parse_args()
 tdt = torch.float64 if args.dtype == "f64" else torch.float32
 if args.model.startswith("randmech"):
     model = rbd.flatten(rbd.randmech(np.random.default_rng(int(args.model[8:] or 1))))
-else:
+elif os.path.exists(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json")):
     model = rbd.load_flat_model(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
+else:  # one of the test suite's mechanisms (tests/conftest.py build_models)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import build_models
+    model = build_models(rbd)[args.model]
 
 
 def timed(f, reps):
@@ -34,6 +38,8 @@ def timed(f, reps):
 
 
 for op, routes in (("dynamics!", ["aba", "aba_lanes", "aba_banks", "aba_walk", "aba_compiled"]), ("inverse_dynamics!", ["auto", "lanes", "banks", "walk", "compiled"])):
+    if args.op != "both" and not op.startswith(args.op):
+        continue
     print(f"== {op} {args.model} {args.dtype}: us per call by route (first column: the library's choice)")
     print("       B  " + "  ".join(f"{r:>13s}" for r in routes) + "   chosen kernel")
     for B in [int(b) for b in args.batches.split(",")]:
