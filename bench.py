@@ -481,7 +481,7 @@ def run(args, env):
                      # the inputs of a batch this small never leave the caches between steps: the "HBM" axis is then fabric traffic (the counters' raw FETCH_SIZE
                      # is below the input bytes; profiles/r06_pmc_traffic.json)
                      "resident": "L2/MALL" if alg_bytes * B < 64e6 and isinstance(traffic, dict) and traffic.get("fetch_raw_bytes", 1e30) < es * (model.nq + 2 * model.nv) * B else None,
-                     "kernel": KERNELS.get(args.op) or (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode(),
+                     "kernel": (L.rbd_workspace_last_kernel(state.ws.handle) or b"").decode() or KERNELS.get(args.op),  # (what the workspace launched last; the table only if it cannot say)
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_eval": alg_bytes},
         "alu": {"bound": "fp64 vector ALU" if args.dtype == "f64" else "fp32 vector ALU", "achieved": achieved_tf, "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": achieved_tf / peak_tf, "flops_per_eval": flops,
