@@ -131,7 +131,7 @@ struct rbd_ws {
   int spec_f64_stash = -1, spec_f64_stash_ratio = 170, spec_f64_stash_ratio_fext = 120, spec_ncu = 256;
   // first use of a run-time compiled dynamics! program by this workspace: its result on the first states of the call against the interpreting kernel's
   // (first_use_check; RBD_TUNE first_use_check=0 for timing experiments with programs that are wrong by construction).  [stash program][no wrenches]
-  bool spec_first_use_check = true, spec_first_use_inject = false, spec_aba_checked[4] = {false, false, false, false}, spec_walk_checked[12] = {}, spec_bank_checked = false, spec_rnea_checked = false, spec_bank_rnea_checked = false;
+  bool spec_first_use_check = true, spec_first_use_inject = false, spec_aba_checked[4] = {false, false, false, false}, spec_walk_checked[12] = {}, spec_bank_checked = false, spec_rnea_checked = false, spec_bank_rnea_checked = false, spec_mass_checked[3] = {false, false, false};  // (mass: [M emitted | M_out = NULL | packed triangle])
   double spec_check_err = 0;  // (what the last check measured: max |difference| / max(1, max |reference|))
   int spec_aba_scratch = 0, spec_aba_nofext_scratch = 0, spec_rnea_scratch = 0;  // bytes per lane spilled by those kernels: only a kernel without any is picked on its own (it runs 3.4 times slower with: the dispatcher admits fewer wavefronts)
   bool spec_loop_tried = false; hipModule_t spec_loop_mod = nullptr;
@@ -1912,6 +1912,40 @@ static int run_crba(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, 
 // mass_matrix! into dM (caller's layout) followed by the Cholesky solve of M x = tau - c (either may be null).  Large batches
 // build M with one lane per state; for an AOS caller that kernel writes a batch-innermost staging copy which the tile Cholesky
 // reads (coalesced) and re-emits as the caller's M.
+// ... and of the fp32 mass_matrix! + Cholesky solve on the two kernels compiled for the mechanism (crba_spec_perm + chol_spec[_nom | _packed]) — taken from 256 states
+// since round 6 —: x on the first states of the call against crba_kernel + the dense Cholesky kernel, 2e-2 of the largest |x| (two fp32 factorisations in different
+// elimination orders of a matrix of condition 1e4).  Column-per-state callers only (the compiled pair's scope).
+static int first_use_check_solve(rbd_ws* w, long B, const void* dq, const void* dtau, const void* dc, const void* dx, Layout Lq, Layout Lm, Layout Lv, bool* same) {
+  const rbd_model* m = w->model;
+  const long n = std::min<long>(B, 256);
+  const size_t es = esize(w);
+  void *Mt = nullptr, *xt = nullptr;
+  double* out = nullptr;
+  HIP_TRY(hipMalloc(&Mt, es * (size_t)m->nv * m->nv * n));
+  if (hipMalloc(&xt, es * (size_t)m->nv * n) != hipSuccess || hipMalloc((void**)&out, 2 * sizeof(double)) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipFree(Mt); (void)hipFree(xt); return RBD_ERR_OUT_OF_MEMORY;
+  }
+  double h[2] = {0, 0};
+  hipError_t e = launch_crba<float>(w->dm, n, dq, Mt, Lq, Lm, 1, w->stream);
+  if (e == hipSuccess) e = launch_chol_solve<float>(m->nv, n, Mt, dtau, dc, xt, nullptr, Lm, Lv, w->d_notpd, w->stream);
+  if (e == hipSuccess) e = launch_max_diff<float>(n, m->nv, dx, xt, Lv, out, w->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h, out, sizeof h, hipMemcpyDeviceToHost, w->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+  (void)hipFree(Mt); (void)hipFree(xt); (void)hipFree(out);
+  if (e != hipSuccess) { g_last_hip_error = std::string("first_use_check_solve: ") + hipGetErrorString(e); (void)hipGetLastError(); return RBD_ERR_HIP; }
+  w->spec_check_err = h[0] / std::max(1e-30, h[1]);
+  *same = w->spec_check_err <= 2e-2 && !w->spec_first_use_inject;
+  if (!*same) {
+    char msg[320];
+    snprintf(msg, sizeof msg, "%s differs from crba_kernel + the dense Cholesky kernel on this call's first states by %.3g of the largest solution component%s: the programs are dropped, the kernels built with the library serve",
+             w->last_kernel, w->spec_check_err, w->spec_first_use_inject ? " (RBD_TUNE first_use_inject)" : "");
+    g_last_hip_error = msg;
+    fprintf(stderr, "[rbd] %s\n", msg);
+    w->spec_chol = w->spec_chol_nom = w->spec_chol_packed = nullptr;  // (the pair's second kernel in its three forms: every route that needs one falls back)
+  }
+  return RBD_OK;
+}
+
 static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void* dM, const void* dtau, const void* dc, void* dx, Layout Lq,
                          Layout Lm, Layout Lv) {
   const rbd_model* m = w->model;
@@ -1944,6 +1978,13 @@ static int run_crba_chol(rbd_ws* w, int32_t B, int layout, const void* dq, void*
       //  against 120 for the pair in one launch; what pays is the staggered order inside chol_spec, rbd_spec.hpp)
       HIP_TRY(launch_chol_spec(w, B, w->d_Msoa, dtau, dc, dx, Lv, dM, Lm));
       w->last_kernel = "crba_spec_perm_f32 + chol_spec_f32 (compiled for the mechanism at run time)";
+      bool& checked = w->spec_mass_checked[dM ? 0 : 1];
+      if (w->spec_first_use_check && !checked && dx && !capturing(w)) {  // (first use of the pair by this workspace: first_use_check_solve)
+        checked = true;
+        bool same = true;
+        if ((st = first_use_check_solve(w, B, dq, dtau, dc, dx, Lq, Lm, Lv, &same))) return st;
+        if (!same) goto lanes;
+      }
       return RBD_OK;
     }
     if (spec) HIP_TRY(launch_crba_spec(w, spec, B, dq, w->d_Msoa, Lq, Ls, 0));
@@ -2185,13 +2226,21 @@ int rbd_mass_matrix_solve_packed(rbd_ws_t* w, int32_t B, const void* q, const vo
                     (reinterpret_cast<uintptr_t>(dP) & 15) == 0;  // (the triangle leaves in 16-byte pieces)
   {
     Timed t(w);
+    bool fast_failed = false;
     if (fast) {
       if ((st = stage_m(w, B, true))) return st;
       const Layout Ls{16, -(long)m->nv * m->nv};
       HIP_TRY(launch_crba_spec(w, w->spec_crba_perm, B, dq, w->d_Msoa, Lq, Ls, 0));
       HIP_TRY(launch_chol_spec(w, B, w->d_Msoa, dr, nullptr, dx, Lv, dP, Lp, true));
       w->last_kernel = "crba_spec_perm_f32 + chol_spec_packed_f32 (compiled for the mechanism at run time)";
-    } else {
+      if (w->spec_first_use_check && !w->spec_mass_checked[2] && dx && !capturing(w)) {
+        w->spec_mass_checked[2] = true;
+        bool same = true;
+        if ((st = first_use_check_solve(w, B, dq, dr, nullptr, dx, Lq, Lm, Lv, &same))) return st;
+        if (!same) fast_failed = true;
+      }
+    }
+    if (!fast || fast_failed) {
       if ((st = ensure(&w->d_M, &w->d_M_bytes, es * (size_t)m->nv * m->nv * B))) return st;
       if ((st = run_crba_chol(w, B, o.layout, dq, w->d_M, dr, nullptr, dx, Lq, Lm, Lv))) return st;
       if (w->dtype == RBD_F64) HIP_TRY(launch_pack_lower<double>(m->nv, B, w->d_M, dP, Lm, Lp, w->stream));

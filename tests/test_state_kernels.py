@@ -124,6 +124,46 @@ def test_mass_matrix_solve_f32_takes_the_compiled_kernels_from_small_batches(rbd
         assert eta.max() <= 1e-5, eta.max()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["dense", "no_M", "packed"])
+def test_first_use_check_of_the_compiled_mass_matrix_solve(rbd, oracle, models, form, monkeypatch, capfd):
+    """The first x a workspace gets from the fp32 pair compiled for the mechanism (crba_spec_perm + chol_spec, its M_out = NULL and packed-triangle forms) is
+    compared with crba_kernel + the dense Cholesky kernel on the call's first states (csrc/rbd_capi.hip first_use_check_solve); here every check is made to find
+    a difference (RBD_TUNE first_use_inject=1): the pair is dropped, the call recomputed, x and M are right, a message says so."""
+    model = models["atlas_floating"]
+    nv = model.nv
+    tune(monkeypatch, first_use_inject=1)
+    B = 300
+    state, q, v, tau, fe = make(rbd, model, B, "f32", "aos", 48)
+    x = torch.zeros_like(state.v)
+    Mr = oracle.mass_matrix(model, q)
+    il = np.tril_indices(nv)
+    if form == "packed":
+        P = torch.full((B, nv * (nv + 1) // 2), float("nan"), dtype=torch.float32, device="cuda")
+        rbd.mass_matrix_solve_(x, state, dev(tau, state), P, packed=True)
+    else:
+        Mout = torch.full((B, nv * nv), float("nan"), dtype=torch.float32, device="cuda") if form == "dense" else None
+        rbd.mass_matrix_solve_(x, state, dev(tau, state), Mout)
+    k = rbd.last_kernel(state)
+    err = capfd.readouterr().err
+    if "first_use_inject" not in err and not rbd.jit_precompile(models["double_pendulum"], torch.float32)[0]:
+        pytest.skip("hiprtc not available")
+    assert rbd.sync(state) == 0 and "chol_spec" not in k and "first_use_inject" in err, (k, err)
+    Ms, xg = sym(Mr), host(x, state)
+    res = np.einsum("bij,bj->bi", Ms, xg) - tau
+    eta = np.linalg.norm(res, axis=1) / (np.linalg.norm(Ms, axis=(1, 2)) * np.linalg.norm(xg, axis=1) + np.linalg.norm(tau, axis=1))
+    assert eta.max() <= 1e-5, eta.max()
+    if form == "dense":
+        got = host(Mout, state).reshape(B, nv, nv).transpose(0, 2, 1)
+        assert np.abs(got[:, il[0], il[1]] - Mr[:, il[0], il[1]]).max() <= 2e-6 * np.abs(Mr).max()
+    # the second call: the kernels built with the library, no check
+    if form == "packed":
+        rbd.mass_matrix_solve_(x, state, dev(tau, state), P, packed=True)
+    else:
+        rbd.mass_matrix_solve_(x, state, dev(tau, state), Mout)
+    assert "chol_spec" not in rbd.last_kernel(state) and capfd.readouterr().err == ""
+
+
 def test_state_kernels_random_trees(rbd, oracle, states_everywhere):
     """Random revolute / prismatic / fixed / sin-cos trees, with and without a 6-dof root, up to the 12 tree levels the kernels keep in registers."""
     from test_chain_plan import random_tree
