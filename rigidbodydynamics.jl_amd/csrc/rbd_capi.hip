@@ -1026,6 +1026,9 @@ int rbd_workspace_create(const rbd_model_t* m, int32_t max_batch, int32_t device
     // (fp64 inverse_dynamics!: the walk kernel's rounds of 16 384 states stay ahead of rnea_spec_f64 until the fourth — Atlas, 49 152 states 58.5 against 66.1 us,
     //  65 536: 77.1 against 75.7; scripts/sweep_routes.py)
     if (dtype == RBD_F64 && m->track.ok && m->walk.ok && w->walk_lds_bytes > 0) w->spec_rnea_min_batch = (long)ncu * 240 + 1;
+    // (no walk kernel for the mechanism — its rows do not fit a CU's LDS —: behind rnea_spec is the banked kernel, whose time grows with the batch; limbs_humanoid
+    //  fp64, 16 384 states: 85.3 us against 54.1 compiled -> the thresholds of the mechanisms outside the walk kernels' scope)
+    else if (!(m->track.ok && m->walk.ok && w->walk_lds_bytes > 0)) w->spec_rnea_min_batch = (long)ncu * (dtype == RBD_F64 ? 40 : 52) + 1;
     w->spec_aba_fused_min_batch = (long)ncu * 80;  // (`simulate`: run_aba)
     // `simulate` in fp32: as long as the batch is ONE round of the walk kernel with two states per lane (128 states per workgroup, one workgroup per CU), the four
     // stages of a step in one launch of it beat four launches of the lane-per-state kernel (Atlas, 32 768 states: 128 against 150 us per step; 40 960 — a second
