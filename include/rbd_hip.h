@@ -28,6 +28,12 @@
  *  - motion vectors are (angular; linear), force vectors (torque; force), as in
  *    src/spatial/spatialmotion.jl:122-153 and src/spatial/spatialforce.jl:73-111;
  *  - calls are asynchronous on the workspace's HIP stream; rbd_sync() waits.
+ *    (Since 600 one exception per program and workspace: the FIRST result of a
+ *    kernel compiled for the mechanism at run time — dynamics!, inverse_dynamics!,
+ *    fp32 mass_matrix! + solve — is compared with the interpreting kernel on the
+ *    call's first states: a small allocation and one synchronisation in that call,
+ *    never inside a stream capture; a program that differs is dropped, the call
+ *    recomputed, rbd_last_hip_error says so.)
  *    A model handle is immutable and shareable; a workspace must not be used
  *    from two host threads at once (same rule as MechanismState/DynamicsResult,
  *    which are mutable caches: src/mechanism_state.jl:35-78).
